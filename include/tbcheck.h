@@ -1,0 +1,290 @@
+/*
+ * tbcheck.h -- C-ABI of libtbcheck.so, the MI355X-native linearizability checker.
+ *
+ * This is the drop-in boundary for the hot path named by BASELINE.json's
+ * north_star: the Wing-Gong/Lowe search behind
+ *
+ *     (knossos.wgl/analysis model history)
+ *     (knossos.linear/analysis model history)
+ *     (knossos.competition/analysis model history)
+ *     (jepsen.checker/linearizable {:model m :algorithm a})
+ *
+ * None of those live in /root/reference: the reference reaches Knossos only
+ * transitively through `jepsen "0.2.8-SNAPSHOT"` (project.clj:8) and never
+ * calls the search.  There is therefore no existing
+ * FFI to replace; every entry point below is a new design, and each one cites
+ * the Clojure function (recalled from the public jepsen-io/knossos and
+ * jepsen-io/jepsen libraries) or the reference call site whose work it takes
+ * over.  The binding a maintainer would add (JNA) is in INTEGRATION.md.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no C++/torch types.
+ *   - every function returns a tbc_status (0 = OK); no exception or abort ever
+ *     crosses the boundary.
+ *   - all entry points are re-entrant: jepsen.checker/compose and
+ *     jepsen.independent/checker evaluate sub-checkers from several JVM threads
+ *     (reference call sites: set_full.clj:155-158, tests/ledger.clj:363-367,
+ *     core.clj:139-146), so a call owns its own HIP stream and arena.
+ *   - there is NO CPU fallback in this library: without a usable gfx950 device
+ *     every compute entry point returns TBC_ERR_NO_DEVICE.
+ */
+#ifndef TBCHECK_H
+#define TBCHECK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TBC_ABI_VERSION 1u
+
+/* ------------------------------------------------------------------ status */
+typedef enum tbc_status {
+  TBC_OK = 0,
+  TBC_ERR_INVALID_ARG = 1,   /* null pointer, bad enum, inconsistent sizes      */
+  TBC_ERR_BAD_HISTORY = 2,   /* unsorted invocations, return before invoke, ... */
+  TBC_ERR_NO_DEVICE = 3,     /* no gfx950 device / HIP runtime failure          */
+  TBC_ERR_OOM = 4,           /* host or device allocation failed                */
+  TBC_ERR_WINDOW_TOO_WIDE = 5, /* more open processes than the kernels support  */
+  TBC_ERR_MODEL = 6,         /* op not understood by the model / bad table      */
+  TBC_ERR_HIP = 7,           /* a HIP call failed; see tbc_last_error()         */
+  TBC_ERR_UNSUPPORTED = 8
+} tbc_status;
+
+/* ----------------------------------------------------------------- history
+ *
+ * Event level: one row per Jepsen history op map, exactly the columns the
+ * reference's own checkers read -- :type :f :value :process (:index is the row
+ * number).  Shapes: set_full.clj:29-31,42-45,113-116,128-134;
+ * tests/ledger.clj:89-114; README.md:41-50,67-74.  Rows whose :process is not
+ * an integer (:nemesis ...) must be dropped by the caller, as the reference
+ * itself does with (int? process) at tests/ledger.clj:94,204,228.
+ */
+enum { TBC_INVOKE = 0, TBC_OK_ = 1, TBC_FAIL = 2, TBC_INFO = 3 };
+
+/* op function codes (the :f of an op), shared by every model */
+enum {
+  TBC_F_READ = 0,     /* register family: a = value read or TBC_NIL             */
+  TBC_F_WRITE = 1,    /* register family: a = value written                     */
+  TBC_F_CAS = 2,      /* cas-register: a = expected, b = new                    */
+  TBC_F_ACQUIRE = 3,  /* mutex                                                  */
+  TBC_F_RELEASE = 4,  /* mutex                                                  */
+  TBC_F_ADD = 5,      /* set: a = element                                       */
+  TBC_F_TXN = 6,      /* multi-register: a = pool offset, b = #micro-ops        */
+  TBC_F_TRANSFER = 7, /* bank: a = pool offset of {debit, credit, amount}       */
+  TBC_F_CLASS = 8     /* table model: a = op class id (column of the table)     */
+  /* TBC_F_READ on set/bank: a = pool offset, b = #values (or TBC_NIL in a)     */
+};
+
+#define TBC_NIL INT32_MIN             /* Clojure nil in a value column           */
+#define TBC_POS_CRASHED 0xFFFFFFFFu   /* ret_pos of an op that never completed   */
+
+typedef struct tbc_events {
+  uint32_t n;               /* number of rows                                   */
+  const uint8_t* type;      /* TBC_INVOKE / TBC_OK_ / TBC_FAIL / TBC_INFO       */
+  const int32_t* process;   /* integer :process                                 */
+  const uint8_t* f;         /* TBC_F_*                                          */
+  const int32_t* a;         /* first value column                               */
+  const int32_t* b;         /* second value column                              */
+} tbc_events;
+
+/*
+ * Op level: the history after knossos.history/complete, /without-failures and
+ * pairing (recalled: knossos.history complete, without-failures, pair-index;
+ * reference uses of the same helpers: tests/ledger.clj:206,239,
+ * checker/perf.clj:617,623).  One row per invocation that may have taken
+ * effect, sorted by invocation position.  SoA, caller-owned, read-only.
+ */
+typedef struct tbc_ops {
+  uint32_t n;               /* number of ops                                    */
+  uint32_t n_events;        /* every position below is < n_events               */
+  const uint8_t* f;         /* TBC_F_*                                          */
+  const int32_t* a;         /* value column 0 (completed value for reads)       */
+  const int32_t* b;         /* value column 1                                   */
+  const int32_t* process;   /* dense process id, 0 <= process < n_process       */
+  const uint32_t* inv_pos;  /* history position of the invocation, ascending    */
+  const uint32_t* ret_pos;  /* position of the :ok completion, TBC_POS_CRASHED  */
+  const int32_t* pool;      /* value pool for wide ops (may be NULL)            */
+  uint32_t pool_len;
+  uint32_t n_process;       /* number of distinct processes (= window slots)    */
+} tbc_ops;
+
+/*
+ * tbc_pair_events: knossos.history/complete + without-failures + pairing.
+ *   - an :ok completion's value columns replace its invocation's (a read learns
+ *     what it read), a :fail completion deletes the pair, an :info completion
+ *     or a missing one leaves the invocation open for ever (TBC_POS_CRASHED);
+ *   - process ids are re-numbered densely in order of first appearance.
+ * Output arrays are caller-allocated with capacity ev->n; *n_ops, *n_process
+ * receive the counts.  ev_index[i] = row of op i's invocation (its :index).
+ * Pure host code, no device needed.
+ */
+tbc_status tbc_pair_events(const tbc_events* ev,
+                           uint8_t* f, int32_t* a, int32_t* b, int32_t* process,
+                           uint32_t* inv_pos, uint32_t* ret_pos,
+                           uint32_t* n_ops, uint32_t* n_process);
+
+/* ------------------------------------------------------------------ models
+ *
+ * knossos.model constructors (recalled): register,
+ * cas-register, mutex, multi-register, set.  Knossos ships no bank model; the
+ * one here follows the reference's own ledger->bank mapping
+ * (tests/ledger.clj:89-114; balance = credits - debits, :102-103).
+ * TBC_MODEL_TABLE is knossos.model.memo/memo: a dense transition table
+ * next = table[state * n_classes + class], 0xFFFF = inconsistent.
+ */
+enum {
+  TBC_MODEL_REGISTER = 0,
+  TBC_MODEL_CAS_REGISTER = 1,
+  TBC_MODEL_MUTEX = 2,
+  TBC_MODEL_TABLE = 3,
+  TBC_MODEL_MULTI_REGISTER = 4,
+  TBC_MODEL_SET = 5,
+  TBC_MODEL_BANK = 6
+};
+
+#define TBC_TABLE_INCONSISTENT 0xFFFFu
+
+typedef struct tbc_model {
+  uint32_t kind;            /* TBC_MODEL_*                                      */
+  int32_t init;             /* initial value (TBC_NIL for (cas-register))       */
+  const uint16_t* table;    /* TBC_MODEL_TABLE only                             */
+  uint32_t n_states;        /* TBC_MODEL_TABLE only                             */
+  uint32_t n_classes;       /* TBC_MODEL_TABLE only                             */
+  uint32_t n_keys;          /* multi-register keys / bank accounts              */
+  uint32_t flags;           /* TBC_MODEL_F_*                                    */
+} tbc_model;
+
+enum { TBC_MODEL_F_NO_NEGATIVE = 1u }; /* bank: balances may not go negative    */
+
+/* ----------------------------------------------------------------- options */
+enum { TBC_ALG_COMPETITION = 0, TBC_ALG_WGL = 1, TBC_ALG_LINEAR = 2 };
+
+typedef struct tbc_opts {
+  uint32_t algorithm;        /* TBC_ALG_*; jepsen.checker/linearizable :algorithm */
+  uint32_t device;           /* HIP device ordinal                               */
+  uint64_t time_limit_ms;    /* 0 = none; exceeded => :valid? :unknown           */
+  uint64_t max_steps;        /* 0 = none; search-step budget (deterministic)     */
+  uint64_t max_visited_bytes;/* 0 = library default; visited-set cap per history */
+  uint32_t want_witness;     /* copy the linearization order back                */
+  uint32_t reserved;
+} tbc_opts;
+
+/* ------------------------------------------------------------------ result */
+enum { TBC_VALID = 1, TBC_INVALID = 0, TBC_UNKNOWN = -1 };
+enum {
+  TBC_CAUSE_NONE = 0,
+  TBC_CAUSE_TIME_LIMIT = 1,
+  TBC_CAUSE_STEP_LIMIT = 2,
+  TBC_CAUSE_VISITED_FULL = 3   /* visited set hit max_visited_bytes              */
+};
+
+#define TBC_MAX_FINAL_CONFIGS 10   /* jepsen.checker/linearizable truncates to 10 */
+#define TBC_NO_OP 0xFFFFFFFFu
+
+typedef struct tbc_config {      /* one knossos config: {:model :pending :last-op} */
+  int32_t state;                 /* model state (value / table state id)          */
+  uint32_t last_op;              /* op index linearized last, or TBC_NO_OP        */
+  uint32_t n_pending;            /* open ops at the front ...                     */
+  uint32_t n_linearized;         /* ... of which this many are already linearized */
+  uint32_t pending[16];          /* first 16 open op indices                      */
+  uint32_t linearized_mask;      /* bit i: pending[i] is linearized               */
+} tbc_config;
+
+typedef struct tbc_counters {
+  uint64_t steps;        /* candidate linearizations attempted (model step ok)   */
+  uint64_t visited;      /* configs inserted into the visited set                */
+  uint64_t probes;       /* visited-set lookups                                  */
+  uint64_t backtracks;   /* frames popped                                        */
+  uint64_t max_depth;    /* deepest DFS stack                                    */
+  uint64_t table_slots;  /* final visited-set capacity (entries)                 */
+  uint64_t ns_pack;      /* device time: history pack kernel                     */
+  uint64_t ns_search;    /* device time: search kernel(s)                        */
+  uint64_t ns_total;     /* wall time inside the call                            */
+} tbc_counters;
+
+typedef struct tbc_result {
+  int32_t valid;             /* TBC_VALID / TBC_INVALID / TBC_UNKNOWN            */
+  int32_t cause;             /* TBC_CAUSE_* when unknown                         */
+  uint32_t analyzer;         /* TBC_ALG_WGL or TBC_ALG_LINEAR: who answered      */
+  uint32_t fail_op;          /* invalid: op whose completion cannot be passed    */
+  uint32_t prev_ok_op;       /* invalid: op completing just before it (:previous-ok) */
+  int32_t final_state;       /* valid: model state after the witness             */
+  uint32_t n_witness;        /* valid: ops linearized                            */
+  uint32_t* witness;         /* valid && want_witness: op indices, library-owned */
+  uint32_t n_configs;        /* final configs (<= TBC_MAX_FINAL_CONFIGS)         */
+  tbc_config configs[TBC_MAX_FINAL_CONFIGS];
+  tbc_counters counters;
+} tbc_result;
+
+/* --------------------------------------------------------- single history
+ *
+ * tbc_check == (knossos.wgl/analysis model history) et al.: host SoA in,
+ * verdict out (H2D + pack kernel + search kernel + D2H).  `out` is caller
+ * allocated; out->witness is library-allocated and released by
+ * tbc_result_free.
+ */
+tbc_status tbc_check(const tbc_ops* ops, const tbc_model* model,
+                     const tbc_opts* opts, tbc_result* out);
+void tbc_result_free(tbc_result* r);
+
+/* ------------------------------------------------------------- batch mode
+ *
+ * Many independent histories per launch -- what jepsen.independent/checker
+ * does per key (set_full.clj:155) and BASELINE.json's batch configs ask for.
+ * A batch owns device memory for its inputs, packed layout, stacks and
+ * visited sets; inputs stay resident in HBM across tbc_batch_run calls.
+ * Histories are concatenated: history h owns ops [op_off[h], op_off[h+1]).
+ */
+typedef struct tbc_batch tbc_batch;
+
+typedef struct tbc_batch_desc {
+  uint32_t n_hist;
+  const uint64_t* op_off;     /* n_hist+1 offsets into the op columns            */
+  const uint32_t* n_events;   /* per history                                     */
+  const uint32_t* n_process;  /* per history                                     */
+  tbc_ops cols;               /* concatenated columns; cols.n = total ops        */
+} tbc_batch_desc;
+
+tbc_status tbc_batch_create(const tbc_batch_desc* desc, const tbc_model* model,
+                            const tbc_opts* opts, tbc_batch** out);
+/* one pass of the hot path over the resident batch: pack + search (+ retries
+ * of histories whose visited set overflowed).  results: n_hist entries,
+ * caller-allocated (witness pointers are library-owned, valid until the next
+ * run or tbc_batch_destroy). */
+tbc_status tbc_batch_run(tbc_batch* b, tbc_result* results);
+/* device-time breakdown of the last run, ns, measured with HIP events on the
+ * batch's own stream: [0] memset/init, [1] pack, [2] search, [3] retries */
+tbc_status tbc_batch_last_timing(const tbc_batch* b, uint64_t ns[4]);
+/* sum of tbc_counters over the last run (probes, visited ...) */
+tbc_status tbc_batch_last_counters(const tbc_batch* b, tbc_counters* out);
+uint64_t tbc_batch_device_bytes(const tbc_batch* b);
+void tbc_batch_destroy(tbc_batch* b);
+
+/* ----------------------------------------------------------------- memo
+ *
+ * knossos.model.memo/memo for a caller-defined model: given the closure
+ * step(state, class) over n_classes op classes, enumerate reachable states
+ * breadth-first from state 0 and fill a dense table.  `step` returns the next
+ * state id handle or -1 for inconsistent; ids are opaque int64 handles chosen
+ * by the caller (for example a packed value).  Host only.
+ */
+typedef int64_t (*tbc_step_fn)(int64_t state, uint32_t op_class, void* user);
+tbc_status tbc_memo_build(int64_t init_state, uint32_t n_classes,
+                          tbc_step_fn step, void* user, uint32_t max_states,
+                          uint16_t* table /* max_states*n_classes */,
+                          int64_t* state_handles /* max_states */,
+                          uint32_t* n_states);
+
+/* ------------------------------------------------------------------- misc */
+uint32_t tbc_version(void);             /* TBC_ABI_VERSION                       */
+const char* tbc_strerror(int status);
+const char* tbc_last_error(void);       /* thread-local detail of the last error */
+int32_t tbc_device_count(void);         /* gfx950 devices visible; 0 if none     */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TBCHECK_H */

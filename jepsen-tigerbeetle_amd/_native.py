@@ -1,0 +1,169 @@
+"""ctypes binding of libtbcheck.so (include/tbcheck.h, include/tbsynth.h).
+
+This is the Python stand-in for the JNA binding a Clojure caller would use
+(INTEGRATION.md): same entry points, same structs.  The library is built
+in-tree by `build()` (hipcc, gfx950) and there is NO fallback: if the shared
+object is missing or a GPU entry point reports TBC_ERR_NO_DEVICE the caller
+gets an exception, never a CPU answer.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libtbcheck.so")
+
+NIL = -(2 ** 31)
+POS_CRASHED = 0xFFFFFFFF
+NO_OP = 0xFFFFFFFF
+MAX_FINAL_CONFIGS = 10
+
+# :type
+INVOKE, OK, FAIL, INFO = 0, 1, 2, 3
+# :f
+F_READ, F_WRITE, F_CAS, F_ACQUIRE, F_RELEASE, F_ADD, F_TXN, F_TRANSFER, F_CLASS = range(9)
+# models
+MODEL_REGISTER, MODEL_CAS_REGISTER, MODEL_MUTEX, MODEL_TABLE, MODEL_MULTI_REGISTER, MODEL_SET, MODEL_BANK = range(7)
+# algorithms
+ALG_COMPETITION, ALG_WGL, ALG_LINEAR = 0, 1, 2
+# verdicts / causes
+VALID, INVALID, UNKNOWN = 1, 0, -1
+CAUSE_NONE, CAUSE_TIME_LIMIT, CAUSE_STEP_LIMIT, CAUSE_VISITED_FULL = 0, 1, 2, 3
+# status
+(OK_STATUS, ERR_INVALID_ARG, ERR_BAD_HISTORY, ERR_NO_DEVICE, ERR_OOM, ERR_WINDOW_TOO_WIDE,
+ ERR_MODEL, ERR_HIP, ERR_UNSUPPORTED) = range(9)
+
+
+class TbcError(RuntimeError):
+    def __init__(self, status, detail):
+        super().__init__(f"libtbcheck status {status}: {detail}")
+        self.status = status
+        self.detail = detail
+
+
+class NoDeviceError(TbcError):
+    pass
+
+
+class Events(C.Structure):
+    _fields_ = [("n", C.c_uint32), ("type", C.POINTER(C.c_uint8)), ("process", C.POINTER(C.c_int32)),
+                ("f", C.POINTER(C.c_uint8)), ("a", C.POINTER(C.c_int32)), ("b", C.POINTER(C.c_int32))]
+
+
+class Ops(C.Structure):
+    _fields_ = [("n", C.c_uint32), ("n_events", C.c_uint32), ("f", C.POINTER(C.c_uint8)),
+                ("a", C.POINTER(C.c_int32)), ("b", C.POINTER(C.c_int32)), ("process", C.POINTER(C.c_int32)),
+                ("inv_pos", C.POINTER(C.c_uint32)), ("ret_pos", C.POINTER(C.c_uint32)),
+                ("pool", C.POINTER(C.c_int32)), ("pool_len", C.c_uint32), ("n_process", C.c_uint32)]
+
+
+class Model(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("init", C.c_int32), ("table", C.POINTER(C.c_uint16)),
+                ("n_states", C.c_uint32), ("n_classes", C.c_uint32), ("n_keys", C.c_uint32),
+                ("flags", C.c_uint32)]
+
+
+class Opts(C.Structure):
+    _fields_ = [("algorithm", C.c_uint32), ("device", C.c_uint32), ("time_limit_ms", C.c_uint64),
+                ("max_steps", C.c_uint64), ("max_visited_bytes", C.c_uint64),
+                ("want_witness", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class Config(C.Structure):
+    _fields_ = [("state", C.c_int32), ("last_op", C.c_uint32), ("n_pending", C.c_uint32),
+                ("n_linearized", C.c_uint32), ("pending", C.c_uint32 * 16), ("linearized_mask", C.c_uint32)]
+
+
+class Counters(C.Structure):
+    _fields_ = [("steps", C.c_uint64), ("visited", C.c_uint64), ("probes", C.c_uint64),
+                ("backtracks", C.c_uint64), ("max_depth", C.c_uint64), ("table_slots", C.c_uint64),
+                ("ns_pack", C.c_uint64), ("ns_search", C.c_uint64), ("ns_total", C.c_uint64)]
+
+
+class Result(C.Structure):
+    _fields_ = [("valid", C.c_int32), ("cause", C.c_int32), ("analyzer", C.c_uint32),
+                ("fail_op", C.c_uint32), ("prev_ok_op", C.c_uint32), ("final_state", C.c_int32),
+                ("n_witness", C.c_uint32), ("witness", C.POINTER(C.c_uint32)), ("n_configs", C.c_uint32),
+                ("configs", Config * MAX_FINAL_CONFIGS), ("counters", Counters)]
+
+
+class BatchDesc(C.Structure):
+    _fields_ = [("n_hist", C.c_uint32), ("op_off", C.POINTER(C.c_uint64)), ("n_events", C.POINTER(C.c_uint32)),
+                ("n_process", C.POINTER(C.c_uint32)), ("cols", Ops)]
+
+
+class SynthParams(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("n_ops", C.c_uint32), ("n_procs", C.c_uint32), ("n_values", C.c_uint32),
+                ("busy_permille", C.c_uint32), ("info_permille", C.c_uint32), ("read_permille", C.c_uint32),
+                ("write_permille", C.c_uint32), ("corrupt_permille", C.c_uint32)]
+
+
+STEP_FN = C.CFUNCTYPE(C.c_int64, C.c_int64, C.c_uint32, C.c_void_p)
+
+# every symbol the headers declare: (name, restype, argtypes)
+SYMBOLS = {
+    "tbc_pair_events": (C.c_int, [C.POINTER(Events), C.POINTER(C.c_uint8), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                  C.POINTER(C.c_int32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+                                  C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "tbc_check": (C.c_int, [C.POINTER(Ops), C.POINTER(Model), C.POINTER(Opts), C.POINTER(Result)]),
+    "tbc_result_free": (None, [C.POINTER(Result)]),
+    "tbc_batch_create": (C.c_int, [C.POINTER(BatchDesc), C.POINTER(Model), C.POINTER(Opts), C.POINTER(C.c_void_p)]),
+    "tbc_batch_run": (C.c_int, [C.c_void_p, C.POINTER(Result)]),
+    "tbc_batch_last_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "tbc_batch_last_counters": (C.c_int, [C.c_void_p, C.POINTER(Counters)]),
+    "tbc_batch_device_bytes": (C.c_uint64, [C.c_void_p]),
+    "tbc_batch_destroy": (None, [C.c_void_p]),
+    "tbc_memo_build": (C.c_int, [C.c_int64, C.c_uint32, STEP_FN, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint16),
+                                 C.POINTER(C.c_int64), C.POINTER(C.c_uint32)]),
+    "tbc_version": (C.c_uint32, []),
+    "tbc_strerror": (C.c_char_p, [C.c_int]),
+    "tbc_last_error": (C.c_char_p, []),
+    "tbc_device_count": (C.c_int32, []),
+    "tbs_gen_register": (C.c_int, [C.POINTER(SynthParams), C.POINTER(C.c_uint8), C.POINTER(C.c_int32),
+                                   C.POINTER(C.c_uint8), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                   C.POINTER(C.c_uint32)]),
+}
+
+_LIB = None
+
+
+def build(force: bool = False) -> str:
+    """Compile libtbcheck.so for gfx950 with hipcc (in-tree, so it travels to the GPU box)."""
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp", ".h"))]
+    srcs += [os.path.join(_HERE, "..", "include", f) for f in ("tbcheck.h", "tbsynth.h")]
+    stale = force or not os.path.exists(LIB_PATH) or any(
+        os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    if stale:
+        subprocess.check_call(["make", "-C", CSRC, "-s", "-j8", "libtbcheck.so"])
+    return LIB_PATH
+
+
+def lib():
+    """The loaded library; raises if it has not been built (no fallback)."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise FileNotFoundError(
+                f"{LIB_PATH} is missing: run __graft_entry__.build() (hipcc). There is no CPU fallback.")
+        try:  # share torch's HIP runtime (same SONAME) when torch is in the process
+            import torch  # noqa: F401
+        except Exception:  # pragma: no cover
+            pass
+        _LIB = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(_LIB, name)
+            fn.restype = res
+            fn.argtypes = args
+    return _LIB
+
+
+def check_status(status: int):
+    if status == OK_STATUS:
+        return
+    detail = lib().tbc_last_error().decode() or lib().tbc_strerror(status).decode()
+    if status == ERR_NO_DEVICE:
+        raise NoDeviceError(status, detail)
+    raise TbcError(status, detail)

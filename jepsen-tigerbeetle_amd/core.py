@@ -1,0 +1,150 @@
+"""Thin Python over the C-ABI compute entry points: `check_ops` (tbc_check) and
+`Batch` (tbc_batch_*).  Nothing here computes a verdict: it marshals columns to
+the library and verdict structs back.  No GPU => NoDeviceError."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Sequence
+
+import numpy as np
+
+from . import _native as N
+from .columns import OpColumns, _p
+
+
+def make_model(kind, init=N.NIL, table=None):
+    """-> (N.Model, keepalive).  `table`: (n_states, n_classes) uint16 for MODEL_TABLE."""
+    m = N.Model()
+    m.kind = kind
+    m.init = init
+    keep = None
+    if table is not None:
+        t = np.ascontiguousarray(table, np.uint16)
+        m.table = _p(t, C.c_uint16)
+        m.n_states, m.n_classes = t.shape
+        keep = t
+    return m, keep
+
+
+def make_opts(algorithm=N.ALG_WGL, device=0, time_limit_ms=0, max_steps=0, max_visited_bytes=0,
+              want_witness=True):
+    o = N.Opts()
+    o.algorithm = algorithm
+    o.device = device
+    o.time_limit_ms = int(time_limit_ms)
+    o.max_steps = int(max_steps)
+    o.max_visited_bytes = int(max_visited_bytes)
+    o.want_witness = 1 if want_witness else 0
+    return o
+
+
+def _result_dict(r: N.Result, copy_witness=True):
+    d = {
+        "valid": r.valid, "cause": r.cause, "analyzer": r.analyzer,
+        "fail_op": None if r.fail_op == N.NO_OP else r.fail_op,
+        "prev_ok_op": None if r.prev_ok_op == N.NO_OP else r.prev_ok_op,
+        "final_state": r.final_state, "n_witness": r.n_witness, "witness": None,
+        "configs": [],
+    }
+    if r.valid == N.VALID and bool(r.witness) and copy_witness:
+        d["witness"] = np.ctypeslib.as_array(r.witness, shape=(max(r.n_witness, 1),))[:r.n_witness].copy()
+    for i in range(r.n_configs):
+        c = r.configs[i]
+        d["configs"].append({"state": c.state, "last_op": None if c.last_op == N.NO_OP else c.last_op,
+                             "pending": list(c.pending[:min(c.n_pending, 16)]),
+                             "n_pending": c.n_pending, "linearized_mask": c.linearized_mask})
+    for k, _ in N.Counters._fields_:
+        d[k] = getattr(r.counters, k)
+    return d
+
+
+def check_ops(ops: OpColumns, model, opts=None):
+    """tbc_check: one history, host columns in, verdict dict out."""
+    m, keep = model if isinstance(model, tuple) else (model, None)
+    o = opts or make_opts()
+    s = ops.struct()
+    r = N.Result()
+    st = N.lib().tbc_check(C.byref(s), C.byref(m), C.byref(o), C.byref(r))
+    N.check_status(st)
+    try:
+        return _result_dict(r)
+    finally:
+        N.lib().tbc_result_free(C.byref(r))
+        del keep
+
+
+class Batch:
+    """tbc_batch_*: many independent histories resident in HBM, one launch per run."""
+
+    def __init__(self, histories: Sequence[OpColumns], model, opts=None):
+        self._m, self._keep = model if isinstance(model, tuple) else (model, None)
+        self._o = opts or make_opts()
+        nh = len(histories)
+        self.n_hist = nh
+        self.op_off = np.zeros(nh + 1, np.uint64)
+        for i, h in enumerate(histories):
+            self.op_off[i + 1] = self.op_off[i] + len(h)
+        self.n_events = np.array([h.n_events for h in histories], np.uint32)
+        self.n_process = np.array([h.n_process for h in histories], np.uint32)
+        cat = lambda name, dt: (np.concatenate([getattr(h, name) for h in histories]).astype(dt, copy=False)
+                                if nh else np.zeros(0, dt))
+        self._cols = OpColumns(cat("f", np.uint8), cat("a", np.int32), cat("b", np.int32),
+                               cat("process", np.int32), cat("inv_pos", np.uint32), cat("ret_pos", np.uint32),
+                               n_events=0, n_process=0)
+        for name in ("f", "a", "b", "process", "inv_pos", "ret_pos"):
+            setattr(self._cols, name, np.ascontiguousarray(getattr(self._cols, name)))
+        d = N.BatchDesc()
+        d.n_hist = nh
+        d.op_off = _p(self.op_off, C.c_uint64)
+        d.n_events = _p(self.n_events, C.c_uint32)
+        d.n_process = _p(self.n_process, C.c_uint32)
+        d.cols = self._cols.struct()
+        self._h = C.c_void_p()
+        st = N.lib().tbc_batch_create(C.byref(d), C.byref(self._m), C.byref(self._o), C.byref(self._h))
+        N.check_status(st)
+        self._res = (N.Result * nh)()
+
+    @property
+    def total_ops(self):
+        return int(self.op_off[-1])
+
+    def run(self, want_results=True):
+        st = N.lib().tbc_batch_run(self._h, self._res if want_results else None)
+        N.check_status(st)
+        return self
+
+    def results(self, copy_witness=True):
+        return [_result_dict(self._res[i], copy_witness) for i in range(self.n_hist)]
+
+    def verdicts(self):
+        return np.array([self._res[i].valid for i in range(self.n_hist)], np.int32)
+
+    def timing_ns(self):
+        t = (C.c_uint64 * 4)()
+        N.check_status(N.lib().tbc_batch_last_timing(self._h, t))
+        return {"init": t[0], "pack": t[1], "search": t[2], "retries": t[3]}
+
+    def counters(self):
+        c = N.Counters()
+        N.check_status(N.lib().tbc_batch_last_counters(self._h, C.byref(c)))
+        return {k: getattr(c, k) for k, _ in N.Counters._fields_}
+
+    def device_bytes(self):
+        return int(N.lib().tbc_batch_device_bytes(self._h))
+
+    def close(self):
+        if self._h:
+            N.lib().tbc_batch_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

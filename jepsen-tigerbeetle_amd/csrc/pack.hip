@@ -1,0 +1,214 @@
+// pack.hip -- K1: history pack kernel (gfx950).
+//
+// Takes the op-level history as it crosses the C-ABI (SoA columns, invocation
+// order; include/tbcheck.h `tbc_ops`) and builds, entirely on the device, the
+// layout the search kernel walks:
+//
+//   * completion ranks: ret_rank(op) = number of completions positioned before
+//     its own, inv_rank(op) = number of completions positioned before its
+//     invocation.  An op is open at front F iff inv_rank <= F <= ret_rank, so
+//     the search never needs history positions again.  Ranks come from a
+//     position bitmap (one bit per history row) + a popcount prefix per word.
+//   * ret_slot[r] / ret_op[r]: process slot and op index of the completion of
+//     rank r (the knossos.wgl return entries, in order).
+//   * slot-major records: a stable counting sort of the ops by process -- the
+//     per-process op lists knossos.linear.config keeps its pending calls in
+//      -- each list bracketed by a head and a tail sentinel so
+//     the per-lane cursors of the search kernel need no bounds checks.
+//
+// One 256-thread workgroup per history, grid-strided over the batch.  The
+// column reads are coalesced (lane i reads row base+i of each column); the
+// record scatter is 32 B per op.  Algorithmic HBM bytes per op: 21 B of
+// columns read + 32 B record + 8 B ret_slot/ret_op written (+ 12 B scratch
+// written and re-read), about 85 B/op -- the kernel is a small fraction of a
+// check.
+//
+// Also validates what the search relies on: invocations strictly ascending,
+// completion after invocation, positions in range and unique, process ids in
+// range, one open op per process at a time, ops understood by the model.
+#include <hip/hip_runtime.h>
+#include "tbc_internal.h"
+
+namespace tbc {
+
+namespace {
+
+__device__ __forceinline__ uint32_t ld_agent(const uint32_t* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ bool op_ok_for_model(uint32_t kind, uint32_t f, int32_t a, uint32_t n_classes) {
+  switch (kind) {
+    case TBC_MODEL_REGISTER: return f == TBC_F_READ || f == TBC_F_WRITE;
+    case TBC_MODEL_CAS_REGISTER: return f == TBC_F_READ || f == TBC_F_WRITE || f == TBC_F_CAS;
+    case TBC_MODEL_MUTEX: return f == TBC_F_ACQUIRE || f == TBC_F_RELEASE;
+    case TBC_MODEL_TABLE: return f == TBC_F_CLASS && (uint32_t)a < n_classes;
+    default: return false;
+  }
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(256) void pack_kernel(PackArgs A) {
+  __shared__ uint32_t s_cnt[kMaxSlots];
+  __shared__ uint32_t s_seg[kMaxSlots + 1];
+  __shared__ uint32_t s_mark[kMaxSlots];
+  __shared__ uint32_t s_part[256];
+  __shared__ uint32_t s_err, s_total, s_done;
+  const uint32_t tid = threadIdx.x;
+
+  for (uint32_t h = blockIdx.x; h < A.n_hist; h += gridDim.x) {
+    Hist* H = &A.hist[h];
+    const uint32_t n = H->n_ops, W = H->n_slots, E = H->n_events;
+    const uint8_t* f = A.f + H->op_off;
+    const int32_t* a = A.a + H->op_off;
+    const int32_t* b = A.b + H->op_off;
+    const int32_t* proc = A.process + H->op_off;
+    const uint32_t* inv = A.inv_pos + H->op_off;
+    const uint32_t* ret = A.ret_pos + H->op_off;
+    uint32_t* bm = A.bitmap + H->bm_off;
+    uint32_t* wpre = A.wpre + H->bm_off;
+    const uint32_t nw = E / 32 + 1;
+    uint32_t* sc_inv = A.scratch + H->frame_off;
+    uint32_t* sc_ret = sc_inv + n;
+    uint32_t* sc_dst = sc_ret + n;
+    Rec* rec = A.rec + H->rec_off;
+
+    if (tid == 0) { s_err = 0; s_done = 0; }
+    for (uint32_t p = tid; p < W; p += 256) { s_cnt[p] = 0; s_mark[p] = kInf; }
+    __syncthreads();
+
+    // phase 1: validate rows, set completion bits, count ops per process
+    for (uint32_t i = tid; i < n; i += 256) {
+      const uint32_t iv = inv[i], rt = ret[i];
+      const int32_t p = proc[i];
+      bool bad = iv >= E || p < 0 || (uint32_t)p >= W || (i > 0 && inv[i - 1] >= iv);
+      if (rt != TBC_POS_CRASHED) bad = bad || rt <= iv || rt >= E;
+      if (bad) { atomicOr(&s_err, (uint32_t)TBC_ERR_BAD_HISTORY); continue; }
+      if (!op_ok_for_model(A.model_kind, f[i], a[i], A.n_classes)) { atomicOr(&s_err, 0x100u | (uint32_t)TBC_ERR_MODEL); continue; }
+      if (rt != TBC_POS_CRASHED) { atomicOr(&bm[rt >> 5], 1u << (rt & 31)); atomicAdd(&s_done, 1u); }
+      atomicAdd(&s_cnt[p], 1u);
+    }
+    __syncthreads();
+    if (s_err) {
+      if (tid == 0) { H->n_ret = 0; H->status = (s_err & 0x100u) ? (uint32_t)TBC_ERR_MODEL : (uint32_t)TBC_ERR_BAD_HISTORY; }
+      __syncthreads();
+      continue;
+    }
+
+    // phase 2: exclusive popcount prefix per bitmap word
+    const uint32_t chunk = (nw + 255) / 256;
+    const uint32_t lo = min(tid * chunk, nw), hi = min(lo + chunk, nw);
+    uint32_t sum = 0;
+    for (uint32_t w = lo; w < hi; w++) sum += __popc(ld_agent(&bm[w]));
+    s_part[tid] = sum;
+    __syncthreads();
+    if (tid == 0) {
+      uint32_t run = 0;
+      for (uint32_t t = 0; t < 256; t++) { uint32_t x = s_part[t]; s_part[t] = run; run += x; }
+      s_total = run;
+    }
+    __syncthreads();
+    {
+      uint32_t run = s_part[tid];
+      for (uint32_t w = lo; w < hi; w++) { wpre[w] = run; run += __popc(ld_agent(&bm[w])); }
+    }
+    __syncthreads();
+    const uint32_t R = s_total;
+    if (R != s_done) {   // two completions on one history row
+      if (tid == 0) { H->n_ret = 0; H->status = (uint32_t)TBC_ERR_BAD_HISTORY; }
+      __syncthreads();
+      continue;
+    }
+
+    // phase 3: ranks; completion order tables
+    for (uint32_t i = tid; i < n; i += 256) {
+      const uint32_t iv = inv[i], rt = ret[i];
+      const uint32_t ir = ld_agent(&wpre[iv >> 5]) + __popc(ld_agent(&bm[iv >> 5]) & ((1u << (iv & 31)) - 1u));
+      uint32_t rr = kInf;
+      if (rt != TBC_POS_CRASHED) {
+        rr = ld_agent(&wpre[rt >> 5]) + __popc(ld_agent(&bm[rt >> 5]) & ((1u << (rt & 31)) - 1u));
+        A.ret_slot[H->ret_off + rr] = (uint32_t)proc[i];
+        A.ret_op[H->ret_off + rr] = i;
+      }
+      sc_inv[i] = ir;
+      sc_ret[i] = rr;
+    }
+
+    // phase 4: segment starts (each list gets a head and a tail sentinel)
+    if (tid == 0) {
+      uint32_t run = 0;
+      for (uint32_t p = 0; p < W; p++) { s_seg[p] = run; run += s_cnt[p] + 2; }
+      s_seg[W] = run;
+    }
+    __syncthreads();
+    for (uint32_t p = tid; p <= W; p += 256) A.seg[H->seg_off + p] = s_seg[p];
+    for (uint32_t p = tid; p < W; p += 256) s_cnt[p] = 0;   // now: ops placed so far
+    __syncthreads();
+
+    // phase 5: stable position of every op inside its process list.  One wave
+    // walks the ops in invocation order, 64 at a time; lanes of one process
+    // inside a chunk are ranked by repeated LDS min (round r elects the r-th
+    // lowest lane), which a single wave executes in program order.
+    if (tid < 64) {
+      const uint32_t lane = tid;
+      for (uint32_t base = 0; base < n; base += 64) {
+        const uint32_t i = base + lane;
+        const bool valid = i < n;
+        const uint32_t p = valid ? (uint32_t)proc[i] : 0u;
+        bool unresolved = valid;
+        uint32_t r = 0, my = 0;
+        while (__ballot(unresolved)) {
+          if (unresolved) atomicMin(&s_mark[p], lane);
+          __builtin_amdgcn_wave_barrier();
+          if (unresolved && __hip_atomic_load(&s_mark[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == lane) {
+            my = __hip_atomic_load(&s_cnt[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + r;
+            unresolved = false;
+            __hip_atomic_store(&s_mark[p], kInf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+          __builtin_amdgcn_wave_barrier();
+          r++;
+        }
+        if (valid) sc_dst[i] = s_seg[p] + 1 + my;
+        __builtin_amdgcn_wave_barrier();
+        if (valid) atomicAdd(&s_cnt[p], 1u);
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    __syncthreads();
+
+    // phase 6: scatter the records, write the sentinels
+    for (uint32_t i = tid; i < n; i += 256) {
+      Rec r;
+      r.inv_rank = sc_inv[i]; r.ret_rank = sc_ret[i]; r.opidx = i; r.f = f[i];
+      r.a = a[i]; r.b = b[i]; r.pad0 = 0; r.pad1 = 0;
+      rec[ld_agent(&sc_dst[i])] = r;
+    }
+    for (uint32_t p = tid; p < W; p += 256) {
+      Rec hd; hd.inv_rank = 0; hd.ret_rank = 0; hd.opidx = kInf; hd.f = kFNone; hd.a = 0; hd.b = 0; hd.pad0 = 0; hd.pad1 = 0;
+      Rec tl = hd; tl.inv_rank = kInf; tl.ret_rank = kInf;
+      rec[s_seg[p]] = hd;
+      rec[s_seg[p + 1] - 1] = tl;
+    }
+    __syncthreads();
+
+    // phase 7: one open op per process: the previous op of the same process
+    // must have completed before this one was invoked
+    for (uint32_t i = tid; i < n; i += 256) {
+      const uint32_t d = ld_agent(&sc_dst[i]);
+      const uint32_t* prev = reinterpret_cast<const uint32_t*>(&rec[d - 1]);
+      const uint32_t prev_ret = ld_agent(prev + 1), prev_f = ld_agent(prev + 3);
+      if (prev_f != kFNone && !(prev_ret < sc_inv[i])) atomicOr(&s_err, (uint32_t)TBC_ERR_BAD_HISTORY);
+    }
+    __syncthreads();
+    if (tid == 0) { H->n_ret = R; H->status = s_err ? (uint32_t)TBC_ERR_BAD_HISTORY : 0u; }
+    __syncthreads();
+  }
+}
+
+void launch_pack(const PackArgs& a, void* stream) {
+  uint32_t grid = a.n_hist < 4096 ? a.n_hist : 4096;
+  hipLaunchKernelGGL(pack_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+}
+
+}  // namespace tbc

@@ -1,0 +1,474 @@
+// tbc_api.hip -- host orchestration behind the C-ABI (include/tbcheck.h):
+// device arenas, H2D of the op columns, pack + search launches on the batch's
+// own HIP stream, visited-set overflow retries, verdict marshalling.
+//
+// There is no CPU path in here by design: every compute entry point needs a
+// gfx950 device and says TBC_ERR_NO_DEVICE otherwise.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+#include "tbc_internal.h"
+
+using namespace tbc;
+
+namespace {
+
+#define HIP_TRY(expr)                                                             \
+  do {                                                                            \
+    hipError_t e_ = (expr);                                                       \
+    if (e_ != hipSuccess) {                                                       \
+      set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return e_ == hipErrorOutOfMemory ? TBC_ERR_OOM : TBC_ERR_HIP;               \
+    }                                                                             \
+  } while (0)
+
+inline uint32_t ceil_log2(uint64_t x) {
+  uint32_t l = 0;
+  while ((1ull << l) < x) l++;
+  return l;
+}
+
+bool device_is_gfx950(int dev) {
+  hipDeviceProp_t p;
+  if (hipGetDeviceProperties(&p, dev) != hipSuccess) return false;
+  return std::strncmp(p.gcnArchName, "gfx950", 6) == 0;
+}
+
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  tbc_status alloc(size_t count) {
+    n = count;
+    if (count == 0) count = 1;
+    HIP_TRY(hipMalloc((void**)&p, count * sizeof(T)));
+    return TBC_OK;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+  size_t bytes() const { return (n ? n : 1) * sizeof(T); }
+};
+
+uint64_t now_ns() {
+  return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(
+             std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+}  // namespace
+
+struct tbc_batch {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[6] = {};
+  uint32_t n_hist = 0;
+  uint64_t total_ops = 0;
+  uint32_t mask_words = 1;
+  uint32_t frame_words = 6;
+  tbc_model model{};
+  tbc_opts opts{};
+  std::vector<Hist> hist;          // host mirror
+  std::vector<uint16_t> table_host;
+  // device arenas
+  DevBuf<uint8_t> d_f;
+  DevBuf<int32_t> d_a, d_b, d_proc;
+  DevBuf<uint32_t> d_inv, d_ret;
+  DevBuf<Hist> d_hist;
+  DevBuf<Rec> d_rec;
+  DevBuf<uint32_t> d_seg, d_ret_slot, d_ret_op, d_bitmap, d_wpre, d_frames, d_witness, d_work, d_queue;
+  DevBuf<uint64_t> d_tab;
+  DevBuf<DevResult> d_results;
+  DevBuf<uint16_t> d_table;
+  // last run
+  std::vector<DevResult> res_host;
+  std::vector<uint32_t> fail_host;   // 2 per history: fail_op, prev_ok_op
+  std::vector<uint32_t> witness_host;
+  uint64_t timing_ns[4] = {0, 0, 0, 0};
+  tbc_counters sum{};
+  uint64_t device_bytes = 0;
+
+  ~tbc_batch() {
+    d_f.release(); d_a.release(); d_b.release(); d_proc.release(); d_inv.release(); d_ret.release();
+    d_hist.release(); d_rec.release(); d_seg.release(); d_ret_slot.release(); d_ret_op.release();
+    d_bitmap.release(); d_wpre.release(); d_frames.release(); d_witness.release(); d_work.release();
+    d_queue.release(); d_tab.release(); d_results.release(); d_table.release();
+    for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+};
+
+extern "C" {
+
+int32_t tbc_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  int k = 0;
+  for (int d = 0; d < n; d++) if (device_is_gfx950(d)) k++;
+  return k;
+}
+
+static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model* model,
+                                    const tbc_opts* opts, tbc_batch* B) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    set_error("no HIP device visible; libtbcheck has no CPU fallback");
+    return TBC_ERR_NO_DEVICE;
+  }
+  B->opts = *opts;
+  B->model = *model;
+  B->device = (int)opts->device;
+  if (B->device >= ndev || !device_is_gfx950(B->device)) {
+    set_error("device %d is not a gfx950 (MI355X) device", B->device);
+    return TBC_ERR_NO_DEVICE;
+  }
+  HIP_TRY(hipSetDevice(B->device));
+  switch (model->kind) {
+    case TBC_MODEL_REGISTER: case TBC_MODEL_CAS_REGISTER: case TBC_MODEL_MUTEX: break;
+    case TBC_MODEL_TABLE:
+      if (!model->table || model->n_states == 0 || model->n_classes == 0 || model->n_states > 0xFFFEu) {
+        set_error("table model needs table, n_states, n_classes");
+        return TBC_ERR_MODEL;
+      }
+      if (model->init < 0 || (uint32_t)model->init >= model->n_states) { set_error("table model: bad init state"); return TBC_ERR_MODEL; }
+      break;
+    default:
+      set_error("model kind %u is not implemented by this build", model->kind);
+      return TBC_ERR_UNSUPPORTED;
+  }
+  if (opts->algorithm > TBC_ALG_LINEAR) { set_error("unknown algorithm %u", opts->algorithm); return TBC_ERR_INVALID_ARG; }
+
+  const uint32_t nh = desc->n_hist;
+  B->n_hist = nh;
+  B->total_ops = desc->op_off[nh];
+  if (B->total_ops != desc->cols.n) { set_error("op_off[n_hist] (%llu) != cols.n (%u)", (unsigned long long)B->total_ops, desc->cols.n); return TBC_ERR_INVALID_ARG; }
+  uint32_t maxW = 1;
+  for (uint32_t h = 0; h < nh; h++) maxW = std::max(maxW, desc->n_process[h]);
+  if (maxW > kMaxSlots) { set_error("%u open processes > %u supported", maxW, kMaxSlots); return TBC_ERR_WINDOW_TOO_WIDE; }
+  uint32_t mw = (maxW + 63) / 64;
+  B->mask_words = mw <= 1 ? 1 : mw <= 2 ? 2 : mw <= 4 ? 4 : mw <= 8 ? 8 : 16;
+  B->frame_words = search_frame_words(B->mask_words);
+  const uint32_t KW = 1 + B->mask_words;
+
+  const uint64_t default_cap_bytes = 1ull << 30;
+  const uint64_t max_bytes = opts->max_visited_bytes ? opts->max_visited_bytes : default_cap_bytes;
+  B->hist.resize(nh);
+  uint64_t rec_n = 0, seg_n = 0, bm_n = 0, frame_n = 0, tab_n = 0;
+  for (uint32_t h = 0; h < nh; h++) {
+    Hist& H = B->hist[h];
+    std::memset(&H, 0, sizeof H);
+    const uint64_t n = desc->op_off[h + 1] - desc->op_off[h];
+    if (desc->op_off[h + 1] < desc->op_off[h] || n > 0x7FFFFFFFull) { set_error("history %u: bad op_off", h); return TBC_ERR_INVALID_ARG; }
+    H.op_off = desc->op_off[h];
+    H.n_ops = (uint32_t)n;
+    H.n_events = desc->n_events[h];
+    H.n_slots = std::max(1u, desc->n_process[h]);
+    H.rec_off = rec_n; rec_n += n + 2ull * H.n_slots;
+    H.seg_off = seg_n; seg_n += H.n_slots + 1;
+    H.ret_off = H.op_off;
+    H.bm_off = bm_n; bm_n += H.n_events / 32 + 1;
+    H.frame_off = frame_n; frame_n += std::max<uint64_t>(n, 1) * B->frame_words;
+    uint32_t lg = std::max(10u, ceil_log2(4 * std::max<uint64_t>(n, 1)));
+    while (lg > 10 && (1ull << lg) * KW * 8 > max_bytes) lg--;
+    H.tab_log2 = lg;
+    H.tab_off = tab_n; tab_n += (1ull << lg) * KW;
+    tab_n = (tab_n + 1) & ~1ull;   // keep 16 B alignment
+  }
+
+  tbc_status s;
+  const uint64_t T = B->total_ops;
+  if ((s = B->d_f.alloc(T)) || (s = B->d_a.alloc(T)) || (s = B->d_b.alloc(T)) || (s = B->d_proc.alloc(T)) ||
+      (s = B->d_inv.alloc(T)) || (s = B->d_ret.alloc(T)) || (s = B->d_hist.alloc(nh)) || (s = B->d_rec.alloc(rec_n)) ||
+      (s = B->d_seg.alloc(seg_n)) || (s = B->d_ret_slot.alloc(T)) || (s = B->d_ret_op.alloc(T)) ||
+      (s = B->d_bitmap.alloc(bm_n)) || (s = B->d_wpre.alloc(bm_n)) || (s = B->d_frames.alloc(frame_n)) ||
+      (s = B->d_tab.alloc(tab_n)) || (s = B->d_results.alloc(nh)) || (s = B->d_work.alloc(nh)) ||
+      (s = B->d_queue.alloc(4)) || (s = B->d_witness.alloc(opts->want_witness ? T : 0)))
+    return s;
+  if (model->kind == TBC_MODEL_TABLE) {
+    const size_t tn = (size_t)model->n_states * model->n_classes;
+    B->table_host.assign(model->table, model->table + tn);
+    if ((s = B->d_table.alloc(tn))) return s;
+    HIP_TRY(hipMemcpy(B->d_table.p, B->table_host.data(), tn * 2, hipMemcpyHostToDevice));
+    B->model.table = nullptr;
+  }
+  B->device_bytes = B->d_f.bytes() + B->d_a.bytes() + B->d_b.bytes() + B->d_proc.bytes() + B->d_inv.bytes() +
+                    B->d_ret.bytes() + B->d_hist.bytes() + B->d_rec.bytes() + B->d_seg.bytes() + B->d_ret_slot.bytes() +
+                    B->d_ret_op.bytes() + B->d_bitmap.bytes() + B->d_wpre.bytes() + B->d_frames.bytes() +
+                    B->d_tab.bytes() + B->d_results.bytes() + B->d_work.bytes() + B->d_witness.bytes();
+
+  HIP_TRY(hipStreamCreateWithFlags(&B->stream, hipStreamNonBlocking));
+  for (auto& e : B->ev) HIP_TRY(hipEventCreate(&e));
+
+  // inputs become resident
+  if (T) {
+    HIP_TRY(hipMemcpyAsync(B->d_f.p, desc->cols.f, T, hipMemcpyHostToDevice, B->stream));
+    HIP_TRY(hipMemcpyAsync(B->d_a.p, desc->cols.a, T * 4, hipMemcpyHostToDevice, B->stream));
+    HIP_TRY(hipMemcpyAsync(B->d_b.p, desc->cols.b, T * 4, hipMemcpyHostToDevice, B->stream));
+    HIP_TRY(hipMemcpyAsync(B->d_proc.p, desc->cols.process, T * 4, hipMemcpyHostToDevice, B->stream));
+    HIP_TRY(hipMemcpyAsync(B->d_inv.p, desc->cols.inv_pos, T * 4, hipMemcpyHostToDevice, B->stream));
+    HIP_TRY(hipMemcpyAsync(B->d_ret.p, desc->cols.ret_pos, T * 4, hipMemcpyHostToDevice, B->stream));
+  }
+  HIP_TRY(hipMemcpyAsync(B->d_hist.p, B->hist.data(), nh * sizeof(Hist), hipMemcpyHostToDevice, B->stream));
+  std::vector<uint32_t> work(nh);
+  for (uint32_t h = 0; h < nh; h++) work[h] = h;
+  HIP_TRY(hipMemcpyAsync(B->d_work.p, work.data(), nh * 4, hipMemcpyHostToDevice, B->stream));
+  HIP_TRY(hipStreamSynchronize(B->stream));
+  B->res_host.resize(nh);
+  return TBC_OK;
+}
+
+tbc_status tbc_batch_create(const tbc_batch_desc* desc, const tbc_model* model,
+                            const tbc_opts* opts, tbc_batch** out) {
+  if (!desc || !model || !opts || !out || !desc->op_off || !desc->n_events || !desc->n_process ||
+      desc->n_hist == 0) {
+    set_error("tbc_batch_create: null or empty argument");
+    return TBC_ERR_INVALID_ARG;
+  }
+  const tbc_ops& c = desc->cols;
+  if (c.n && (!c.f || !c.a || !c.b || !c.process || !c.inv_pos || !c.ret_pos)) {
+    set_error("tbc_batch_create: null op column");
+    return TBC_ERR_INVALID_ARG;
+  }
+  tbc_batch* B = new (std::nothrow) tbc_batch();
+  if (!B) return TBC_ERR_OOM;
+  tbc_status s;
+  try {
+    s = batch_create_impl(desc, model, opts, B);
+  } catch (const std::bad_alloc&) {
+    set_error("host allocation failed");
+    s = TBC_ERR_OOM;
+  } catch (...) {
+    set_error("unexpected exception");
+    s = TBC_ERR_HIP;
+  }
+  if (s != TBC_OK) { delete B; return s; }
+  *out = B;
+  return TBC_OK;
+}
+
+static SearchArgs make_search_args(tbc_batch* B, uint64_t* tab, uint32_t n_work) {
+  SearchArgs a{};
+  a.hist = B->d_hist.p; a.rec = B->d_rec.p; a.seg = B->d_seg.p; a.ret_slot = B->d_ret_slot.p;
+  a.ret_op = B->d_ret_op.p;
+  a.frames = B->d_frames.p; a.tab = tab; a.results = B->d_results.p;
+  a.witness = B->opts.want_witness ? B->d_witness.p : nullptr;
+  a.work = B->d_work.p; a.queue = B->d_queue.p;
+  a.table = B->d_table.p; a.n_work = n_work; a.model_kind = B->model.kind;
+  a.init_state = B->model.kind == TBC_MODEL_MUTEX ? 0 : B->model.init;
+  a.n_classes = B->model.n_classes; a.n_states = B->model.n_states;
+  a.max_steps = B->opts.max_steps;
+  a.time_limit_ticks = B->opts.time_limit_ms * 100000ull;   // wall_clock64 runs at 100 MHz
+  return a;
+}
+
+static uint32_t search_blocks(uint32_t n_work) {
+  const uint32_t need = (n_work + kWavesPerBlock - 1) / kWavesPerBlock;
+  return std::max(1u, std::min(need, 256u * 8u));
+}
+
+static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results) {
+  HIP_TRY(hipSetDevice(B->device));
+  const uint64_t t_start = now_ns();
+  const uint32_t nh = B->n_hist;
+  hipStream_t s = B->stream;
+
+  HIP_TRY(hipEventRecord(B->ev[0], s));
+  HIP_TRY(hipMemsetAsync(B->d_bitmap.p, 0, B->d_bitmap.bytes(), s));
+  HIP_TRY(hipMemsetAsync(B->d_tab.p, 0, B->d_tab.bytes(), s));
+  HIP_TRY(hipMemsetAsync(B->d_queue.p, 0, B->d_queue.bytes(), s));
+  HIP_TRY(hipMemcpyAsync(B->d_hist.p, B->hist.data(), nh * sizeof(Hist), hipMemcpyHostToDevice, s));
+  HIP_TRY(hipEventRecord(B->ev[1], s));
+
+  PackArgs pa{};
+  pa.hist = B->d_hist.p; pa.f = B->d_f.p; pa.a = B->d_a.p; pa.b = B->d_b.p; pa.process = B->d_proc.p;
+  pa.inv_pos = B->d_inv.p; pa.ret_pos = B->d_ret.p; pa.rec = B->d_rec.p; pa.seg = B->d_seg.p;
+  pa.ret_slot = B->d_ret_slot.p; pa.ret_op = B->d_ret_op.p; pa.bitmap = B->d_bitmap.p; pa.wpre = B->d_wpre.p;
+  pa.scratch = B->d_frames.p; pa.frame_words = B->frame_words; pa.n_hist = nh;
+  pa.model_kind = B->model.kind; pa.n_classes = B->model.n_classes;
+  launch_pack(pa, s);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(B->ev[2], s));
+
+  SearchArgs sa = make_search_args(B, B->d_tab.p, nh);
+  if (!launch_search(sa, B->mask_words, search_blocks(nh), s)) { set_error("unsupported mask width"); return TBC_ERR_UNSUPPORTED; }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(B->ev[3], s));
+  HIP_TRY(hipMemcpyAsync(B->res_host.data(), B->d_results.p, nh * sizeof(DevResult), hipMemcpyDeviceToHost, s));
+  std::vector<Hist> hist_back(nh);
+  HIP_TRY(hipMemcpyAsync(hist_back.data(), B->d_hist.p, nh * sizeof(Hist), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+
+  // ---- retries: histories whose visited set filled up get a 16x larger one
+  const uint32_t KW = 1 + B->mask_words;
+  const uint64_t max_bytes = B->opts.max_visited_bytes ? B->opts.max_visited_bytes : (1ull << 30);
+  std::vector<uint32_t> final_log2(nh);
+  for (uint32_t h = 0; h < nh; h++) final_log2[h] = B->hist[h].tab_log2;
+  HIP_TRY(hipEventRecord(B->ev[4], s));
+  for (;;) {
+    std::vector<uint32_t> pending;
+    for (uint32_t h = 0; h < nh; h++)
+      if (B->res_host[h].valid == TBC_UNKNOWN && B->res_host[h].cause == TBC_CAUSE_VISITED_FULL) {
+        uint32_t lg = final_log2[h] + 4;
+        while (lg > final_log2[h] && (1ull << lg) * KW * 8 > max_bytes) lg--;
+        if (lg > final_log2[h]) pending.push_back(h);
+      }
+    if (pending.empty()) break;
+    // process in groups whose tables fit a 32 GiB scratch arena
+    const uint64_t arena_budget = 32ull << 30;
+    size_t pos = 0;
+    while (pos < pending.size()) {
+      std::vector<uint32_t> grp;
+      std::vector<Hist> patched;
+      uint64_t words = 0;
+      while (pos < pending.size()) {
+        const uint32_t h = pending[pos];
+        uint32_t lg = final_log2[h] + 4;
+        while ((1ull << lg) * KW * 8 > max_bytes) lg--;
+        const uint64_t need = (1ull << lg) * KW;
+        if (!grp.empty() && (words + need) * 8 > arena_budget) break;
+        Hist P = hist_back[h];
+        P.tab_off = words; P.tab_log2 = lg;
+        words += need; words = (words + 1) & ~1ull;
+        grp.push_back(h); patched.push_back(P);
+        final_log2[h] = lg;
+        pos++;
+      }
+      DevBuf<uint64_t> big;
+      tbc_status st = big.alloc(words);
+      if (st != TBC_OK) return st;
+      hipError_t e = hipMemsetAsync(big.p, 0, words * 8, s);
+      for (size_t i = 0; i < grp.size() && e == hipSuccess; i++)
+        e = hipMemcpyAsync(B->d_hist.p + grp[i], &patched[i], sizeof(Hist), hipMemcpyHostToDevice, s);
+      if (e == hipSuccess) e = hipMemcpyAsync(B->d_work.p, grp.data(), grp.size() * 4, hipMemcpyHostToDevice, s);
+      if (e == hipSuccess) e = hipMemsetAsync(B->d_queue.p, 0, B->d_queue.bytes(), s);
+      if (e == hipSuccess) {
+        SearchArgs ra = make_search_args(B, big.p, (uint32_t)grp.size());
+        launch_search(ra, B->mask_words, search_blocks((uint32_t)grp.size()), s);
+        e = hipGetLastError();
+      }
+      for (size_t i = 0; i < grp.size() && e == hipSuccess; i++)
+        e = hipMemcpyAsync(&B->res_host[grp[i]], B->d_results.p + grp[i], sizeof(DevResult), hipMemcpyDeviceToHost, s);
+      if (e == hipSuccess) e = hipStreamSynchronize(s);
+      big.release();
+      if (e != hipSuccess) { set_error("retry pass failed: %s", hipGetErrorString(e)); return TBC_ERR_HIP; }
+    }
+    // restore the identity work list for the next run
+    std::vector<uint32_t> work(nh);
+    for (uint32_t h = 0; h < nh; h++) work[h] = h;
+    HIP_TRY(hipMemcpyAsync(B->d_work.p, work.data(), nh * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));
+  }
+  HIP_TRY(hipEventRecord(B->ev[5], s));
+  HIP_TRY(hipStreamSynchronize(s));
+
+  if (B->opts.want_witness) {
+    B->witness_host.resize(B->total_ops ? B->total_ops : 1);
+    HIP_TRY(hipMemcpy(B->witness_host.data(), B->d_witness.p, B->total_ops * 4, hipMemcpyDeviceToHost));
+  }
+
+  float ms;
+  for (int i = 0; i < 3; i++) {
+    HIP_TRY(hipEventElapsedTime(&ms, B->ev[i], B->ev[i + 1]));
+    B->timing_ns[i] = (uint64_t)(ms * 1e6);
+  }
+  HIP_TRY(hipEventElapsedTime(&ms, B->ev[4], B->ev[5]));
+  B->timing_ns[3] = (uint64_t)(ms * 1e6);
+
+  std::memset(&B->sum, 0, sizeof B->sum);
+  const uint64_t t_end = now_ns();
+  tbc_status worst = TBC_OK;
+  for (uint32_t h = 0; h < nh; h++) {
+    const DevResult& d = B->res_host[h];
+    B->sum.steps += d.steps; B->sum.visited += d.visited; B->sum.probes += d.probes;
+    B->sum.backtracks += d.backtracks; B->sum.max_depth = std::max(B->sum.max_depth, d.max_depth);
+    B->sum.table_slots += 1ull << final_log2[h];
+    if (hist_back[h].status != 0 && worst == TBC_OK) {
+      worst = (tbc_status)hist_back[h].status;
+      set_error("history %u rejected by the pack kernel: %s", h, tbc_strerror((int)hist_back[h].status));
+    }
+    if (!results) continue;
+    tbc_result& r = results[h];
+    std::memset(&r, 0, sizeof r);
+    r.valid = d.valid; r.cause = d.cause;
+    r.analyzer = TBC_ALG_WGL;
+    r.fail_op = TBC_NO_OP; r.prev_ok_op = TBC_NO_OP;
+    if (d.valid == TBC_INVALID) { r.fail_op = d.fail_op; r.prev_ok_op = d.prev_ok_op; }
+    if (d.valid == TBC_VALID) {
+      r.final_state = d.final_state; r.n_witness = d.depth;
+      if (B->opts.want_witness) r.witness = B->witness_host.data() + B->hist[h].op_off;
+    }
+    r.counters.steps = d.steps; r.counters.visited = d.visited; r.counters.probes = d.probes;
+    r.counters.backtracks = d.backtracks; r.counters.max_depth = d.max_depth;
+    r.counters.table_slots = 1ull << final_log2[h];
+    r.counters.ns_pack = B->timing_ns[1]; r.counters.ns_search = B->timing_ns[2] + B->timing_ns[3];
+    r.counters.ns_total = t_end - t_start;
+  }
+  B->sum.ns_pack = B->timing_ns[1]; B->sum.ns_search = B->timing_ns[2] + B->timing_ns[3];
+  B->sum.ns_total = t_end - t_start;
+  return worst;
+}
+
+tbc_status tbc_batch_run(tbc_batch* b, tbc_result* results) {
+  if (!b) { set_error("tbc_batch_run: null batch"); return TBC_ERR_INVALID_ARG; }
+  try {
+    return batch_run_impl(b, results);
+  } catch (const std::bad_alloc&) {
+    set_error("host allocation failed");
+    return TBC_ERR_OOM;
+  } catch (...) {
+    set_error("unexpected exception");
+    return TBC_ERR_HIP;
+  }
+}
+
+tbc_status tbc_batch_last_timing(const tbc_batch* b, uint64_t ns[4]) {
+  if (!b || !ns) return TBC_ERR_INVALID_ARG;
+  for (int i = 0; i < 4; i++) ns[i] = b->timing_ns[i];
+  return TBC_OK;
+}
+
+tbc_status tbc_batch_last_counters(const tbc_batch* b, tbc_counters* out) {
+  if (!b || !out) return TBC_ERR_INVALID_ARG;
+  *out = b->sum;
+  return TBC_OK;
+}
+
+uint64_t tbc_batch_device_bytes(const tbc_batch* b) { return b ? b->device_bytes : 0; }
+
+void tbc_batch_destroy(tbc_batch* b) {
+  if (!b) return;
+  (void)hipSetDevice(b->device);
+  delete b;
+}
+
+tbc_status tbc_check(const tbc_ops* ops, const tbc_model* model, const tbc_opts* opts, tbc_result* out) {
+  if (!ops || !model || !opts || !out) { set_error("tbc_check: null argument"); return TBC_ERR_INVALID_ARG; }
+  const uint64_t t0 = now_ns();
+  uint64_t op_off[2] = {0, ops->n};
+  tbc_batch_desc d{};
+  d.n_hist = 1; d.op_off = op_off; d.n_events = &ops->n_events; d.n_process = &ops->n_process; d.cols = *ops;
+  tbc_batch* B = nullptr;
+  tbc_status s = tbc_batch_create(&d, model, opts, &B);
+  if (s != TBC_OK) return s;
+  s = tbc_batch_run(B, out);
+  if (s == TBC_OK && out->witness) {   // hand the witness over: the batch dies here
+    uint32_t* w = (uint32_t*)std::malloc((size_t)std::max(1u, out->n_witness) * 4);
+    if (!w) { tbc_batch_destroy(B); return TBC_ERR_OOM; }
+    std::memcpy(w, out->witness, (size_t)out->n_witness * 4);
+    out->witness = w;
+  } else {
+    out->witness = nullptr;
+  }
+  tbc_batch_destroy(B);
+  out->counters.ns_total = now_ns() - t0;
+  return s;
+}
+
+void tbc_result_free(tbc_result* r) {
+  if (!r) return;
+  std::free(r->witness);
+  r->witness = nullptr;
+}
+
+}  // extern "C"

@@ -1,0 +1,111 @@
+// tbc_internal.h -- shared between the host orchestration and the HIP kernels.
+#pragma once
+#include <cstdarg>
+#include <cstdint>
+#include "../../include/tbcheck.h"
+
+namespace tbc {
+
+void set_error(const char* fmt, ...);
+
+constexpr uint32_t kInf = 0xFFFFFFFFu;
+constexpr uint32_t kMaxSlots = 1024;       // 16 mask words x 64 lanes
+constexpr uint32_t kWavesPerBlock = 4;
+constexpr uint32_t kBlock = 64 * kWavesPerBlock;
+constexpr uint8_t kFNone = 0xFF;           // sentinel record: never a candidate
+
+// One op in the slot-major ("per process, in time order") layout the search
+// kernel walks.  32 bytes = two dwordx4 loads per cursor move.
+struct __attribute__((aligned(16))) Rec {
+  uint32_t inv_rank;   // #completions positioned before this invocation
+  uint32_t ret_rank;   // rank of its own completion, kInf if crashed
+  uint32_t opidx;      // index in the caller's op columns (= invocation order)
+  uint32_t f;          // TBC_F_* or kFNone
+  int32_t a, b;
+  uint32_t pad0, pad1;
+};
+static_assert(sizeof(Rec) == 32, "Rec must be 32 bytes");
+
+// Per-history descriptor (device resident; written once by the host, n_ret and
+// status filled by the pack kernel).
+struct __attribute__((aligned(16))) Hist {
+  uint64_t op_off;     // first op in the concatenated columns
+  uint64_t rec_off;    // Rec units
+  uint64_t seg_off;    // u32 units (n_slots + 1 entries)
+  uint64_t ret_off;    // u32 units (ret_slot / ret_op, n_ops entries each)
+  uint64_t bm_off;     // u32 units (bitmap + word-prefix arenas)
+  uint64_t frame_off;  // u32 units (n_ops * frame words)
+  uint64_t tab_off;    // u64 units
+  uint32_t n_ops;
+  uint32_t n_events;
+  uint32_t n_slots;
+  uint32_t tab_log2;   // visited-set capacity = 1 << tab_log2 entries
+  uint32_t n_ret;      // pack: number of completions
+  uint32_t status;     // pack: 0 ok, else tbc_status
+  uint32_t pad0, pad1;
+};
+
+struct __attribute__((aligned(8))) DevResult {
+  int32_t valid;
+  int32_t cause;
+  uint32_t max_front;   // greatest front reached (invalid: the completion nobody passes)
+  uint32_t depth;       // valid: witness length
+  int32_t final_state;
+  uint32_t n_configs;
+  uint32_t fail_op;     // invalid: op whose completion has rank max_front
+  uint32_t prev_ok_op;  // invalid: op completing just before it, or TBC_NO_OP
+  uint64_t steps, visited, probes, backtracks, max_depth, bucket_reads;
+};
+
+struct PackArgs {
+  Hist* hist;
+  const uint8_t* f;
+  const int32_t* a;
+  const int32_t* b;
+  const int32_t* process;
+  const uint32_t* inv_pos;
+  const uint32_t* ret_pos;
+  Rec* rec;
+  uint32_t* seg;
+  uint32_t* ret_slot;
+  uint32_t* ret_op;
+  uint32_t* bitmap;     // zeroed before launch
+  uint32_t* wpre;
+  uint32_t* scratch;    // the frames arena doubles as pack scratch
+  uint32_t frame_words; // words per op available in scratch (>= 3)
+  uint32_t n_hist;
+  uint32_t model_kind;
+  uint32_t n_classes;
+  uint32_t pad;
+};
+
+struct SearchArgs {
+  const Hist* hist;
+  const Rec* rec;
+  const uint32_t* seg;
+  const uint32_t* ret_slot;
+  const uint32_t* ret_op;
+  uint32_t* frames;
+  uint64_t* tab;
+  DevResult* results;
+  uint32_t* witness;        // n_ops entries per history at op_off, may be null
+  const uint32_t* work;     // history indices to process
+  uint32_t* queue;          // work-queue head, zeroed before launch
+  const uint16_t* table;    // TBC_MODEL_TABLE
+  uint32_t n_work;
+  uint32_t model_kind;
+  int32_t init_state;
+  uint32_t n_classes;
+  uint32_t n_states;
+  uint32_t pad;
+  uint64_t max_steps;
+  uint64_t time_limit_ticks;  // wall_clock64 ticks (100 MHz), 0 = none
+};
+
+// kernel launchers (defined in the .hip files)
+void launch_pack(const PackArgs& a, void* stream);
+// returns false if mw is unsupported
+bool launch_search(const SearchArgs& a, uint32_t mask_words, uint32_t n_blocks, void* stream);
+uint32_t search_frame_words(uint32_t mask_words);
+
+}  // namespace tbc

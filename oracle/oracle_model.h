@@ -1,0 +1,75 @@
+/*
+ * TEST INFRASTRUCTURE -- NOT PRODUCT CODE.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * build, link, load or call anything under oracle/.
+ *
+ * PARITY UNPINNED: the algorithm restated here lives in the third-party
+ * library `knossos` (Clojars; reached transitively through
+ * `jepsen "0.2.8-SNAPSHOT"`, /root/reference/project.clj:8; its version is not
+ * pinned anywhere in the reference).  That library is not on
+ * this machine, the reference holds no golden vectors for it
+ * (/root/reference/test/tigerbeetle/core_test.clj:1-6 asserts `true`), and no
+ * JVM exists here to run it.  What follows restates the PUBLISHED algorithms
+ * (Wing & Gong 1993; Lowe, "Testing for linearizability", 2017) with the
+ * Knossos semantics recalled in SURVEY.md section 8a, and is cross-checked against
+ * an independent brute-force definition of linearizability (oracle/brute.py).
+ *
+ * oracle_model.h -- knossos.model/step for the models on the hot path.
+ * Recalled semantics:
+ *   register      :write v -> v ; :read v ok iff v nil or v = value
+ *   cas-register  + :cas [cur new] -> new iff cur = value, else inconsistent
+ *   mutex         :acquire inconsistent if held ; :release inconsistent if free
+ *   table         next = table[state*n_classes + class] (knossos.model.memo)
+ */
+#ifndef ORACLE_MODEL_H
+#define ORACLE_MODEL_H
+#include <stdint.h>
+
+#define O_NIL INT32_MIN
+#define O_CRASHED 0xFFFFFFFFu
+enum { O_READ = 0, O_WRITE = 1, O_CAS = 2, O_ACQUIRE = 3, O_RELEASE = 4, O_CLASS = 8 };
+enum { O_REGISTER = 0, O_CAS_REGISTER = 1, O_MUTEX = 2, O_TABLE = 3 };
+
+typedef struct oracle_model {
+  uint32_t kind;
+  int32_t init;
+  const uint16_t* table;
+  uint32_t n_states, n_classes;
+} oracle_model;
+
+/* returns 1 and sets *next if op (f,a,b) may be applied in `state`, else 0 */
+static inline int oracle_step(const oracle_model* m, int32_t state, uint8_t f,
+                              int32_t a, int32_t b, int32_t* next) {
+  switch (m->kind) {
+    case O_REGISTER:
+    case O_CAS_REGISTER:
+      if (f == O_WRITE) { *next = a; return 1; }
+      if (f == O_READ) { *next = state; return a == O_NIL || a == state; }
+      if (f == O_CAS && m->kind == O_CAS_REGISTER) { *next = b; return a == state; }
+      return 0;
+    case O_MUTEX:
+      if (f == O_ACQUIRE) { *next = 1; return state == 0; }
+      if (f == O_RELEASE) { *next = 0; return state == 1; }
+      return 0;
+    case O_TABLE: {
+      if (f != O_CLASS || (uint32_t)a >= m->n_classes || (uint32_t)state >= m->n_states) return 0;
+      uint16_t t = m->table[(uint32_t)state * m->n_classes + (uint32_t)a];
+      if (t == 0xFFFFu) return 0;
+      *next = (int32_t)t;
+      return 1;
+    }
+  }
+  return 0;
+}
+
+/* result block shared by every oracle entry point */
+typedef struct oracle_result {
+  int32_t valid;          /* 1 / 0 / -1 (step limit) */
+  uint32_t fail_op;       /* invalid: op whose completion no config passes */
+  uint32_t prev_ok_op;    /* invalid: op completing just before it, or 0xFFFFFFFF */
+  int32_t final_state;    /* valid */
+  uint32_t n_witness;     /* valid: ops in linearization order */
+  uint64_t steps, visited, probes, backtracks, max_depth;
+} oracle_result;
+
+#endif

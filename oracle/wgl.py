@@ -1,0 +1,94 @@
+"""TEST INFRASTRUCTURE -- NOT PRODUCT CODE (see oracle_model.h).
+
+ctypes front-end of liboracle.so (wgl_ref.c = published DLL/bitset form,
+wgl_window.c = windowed-key form).  `build()` compiles it with gcc.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+NIL = -(2 ** 31)
+CRASHED = 0xFFFFFFFF
+
+
+class OracleModel(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("init", C.c_int32),
+                ("table", C.POINTER(C.c_uint16)),
+                ("n_states", C.c_uint32), ("n_classes", C.c_uint32)]
+
+
+class OracleResult(C.Structure):
+    _fields_ = [("valid", C.c_int32), ("fail_op", C.c_uint32), ("prev_ok_op", C.c_uint32),
+                ("final_state", C.c_int32), ("n_witness", C.c_uint32),
+                ("steps", C.c_uint64), ("visited", C.c_uint64), ("probes", C.c_uint64),
+                ("backtracks", C.c_uint64), ("max_depth", C.c_uint64)]
+
+
+def build(force: bool = False) -> str:
+    so = os.path.join(_HERE, "liboracle.so")
+    srcs = [os.path.join(_HERE, f) for f in ("wgl_ref.c", "wgl_window.c", "oracle_model.h")]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "liboracle.so"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        for fn in (_LIB.wgl_ref_check, _LIB.wgl_window_check):
+            fn.restype = C.c_int
+    return _LIB
+
+
+def _model(model):
+    m = OracleModel()
+    m.kind = model["kind"]
+    m.init = model.get("init", 0)
+    keep = None
+    if model.get("table") is not None:
+        t = np.ascontiguousarray(model["table"], dtype=np.uint16)
+        m.n_states, m.n_classes = t.shape
+        m.table = t.ctypes.data_as(C.POINTER(C.c_uint16))
+        keep = t
+    return m, keep
+
+
+def _p(arr, ct):
+    return arr.ctypes.data_as(C.POINTER(ct))
+
+
+def check(ops, model, algorithm="window", max_steps=0, want_witness=True):
+    """ops: dict of numpy columns f,a,b,process,inv_pos,ret_pos (+ n_process).
+    Returns dict(valid, fail_op, prev_ok_op, final_state, witness, counters...)."""
+    n = len(ops["f"])
+    f = np.ascontiguousarray(ops["f"], np.uint8)
+    a = np.ascontiguousarray(ops["a"], np.int32)
+    b = np.ascontiguousarray(ops["b"], np.int32)
+    inv = np.ascontiguousarray(ops["inv_pos"], np.uint32)
+    ret = np.ascontiguousarray(ops["ret_pos"], np.uint32)
+    m, keep = _model(model)
+    res = OracleResult()
+    wit = np.zeros(max(n, 1), np.uint32)
+    if algorithm == "ref":
+        rc = lib().wgl_ref_check(C.c_uint32(n), _p(f, C.c_uint8), _p(a, C.c_int32), _p(b, C.c_int32),
+                                 _p(inv, C.c_uint32), _p(ret, C.c_uint32), C.byref(m),
+                                 C.c_uint64(max_steps), _p(wit, C.c_uint32), C.byref(res))
+    else:
+        proc = np.ascontiguousarray(ops["process"], np.int32)
+        rc = lib().wgl_window_check(C.c_uint32(n), _p(f, C.c_uint8), _p(a, C.c_int32), _p(b, C.c_int32),
+                                    _p(proc, C.c_int32), C.c_uint32(int(ops["n_process"])),
+                                    _p(inv, C.c_uint32), _p(ret, C.c_uint32), C.byref(m),
+                                    C.c_uint64(max_steps), _p(wit, C.c_uint32), C.byref(res))
+    if rc != 0:
+        raise ValueError(f"oracle rejected history (rc={rc})")
+    out = {k: getattr(res, k) for k, _ in OracleResult._fields_}
+    out["witness"] = wit[:res.n_witness].copy() if (res.valid == 1 and want_witness) else None
+    return out
