@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void pack_kernel(PackArgs A) {
     uint32_t* sc_dst = sc_ret + n;
     Rec* rec = A.rec + H->rec_off;
 
-    if (tid == 0) { s_err = 0; s_done = 0; }
+    if (tid == 0) { s_err = 0; s_done = 0; if (A.dbg) { A.dbg[0] = 0x10u; A.dbg[1] = h; } }
     for (uint32_t p = tid; p < W; p += 256) { s_cnt[p] = 0; s_mark[p] = kInf; }
     __syncthreads();
 
@@ -96,6 +96,7 @@ __global__ __launch_bounds__(256) void pack_kernel(PackArgs A) {
       continue;
     }
 
+    if (tid == 0 && A.dbg) A.dbg[0] = 0x20u;
     // phase 2: exclusive popcount prefix per bitmap word
     const uint32_t chunk = (nw + 255) / 256;
     const uint32_t lo = min(tid * chunk, nw), hi = min(lo + chunk, nw);
@@ -121,6 +122,7 @@ __global__ __launch_bounds__(256) void pack_kernel(PackArgs A) {
       continue;
     }
 
+    if (tid == 0 && A.dbg) A.dbg[0] = 0x30u;
     // phase 3: ranks; completion order tables
     for (uint32_t i = tid; i < n; i += 256) {
       const uint32_t iv = inv[i], rt = ret[i];
@@ -146,6 +148,7 @@ __global__ __launch_bounds__(256) void pack_kernel(PackArgs A) {
     for (uint32_t p = tid; p < W; p += 256) s_cnt[p] = 0;   // now: ops placed so far
     __syncthreads();
 
+    if (tid == 0 && A.dbg) A.dbg[0] = 0x40u;
     // phase 5: stable position of every op inside its process list.  One wave
     // walks the ops in invocation order, 64 at a time; lanes of one process
     // inside a chunk are ranked by repeated LDS min (round r elects the r-th
@@ -177,6 +180,7 @@ __global__ __launch_bounds__(256) void pack_kernel(PackArgs A) {
     }
     __syncthreads();
 
+    if (tid == 0 && A.dbg) A.dbg[0] = 0x50u;
     // phase 6: scatter the records, write the sentinels
     for (uint32_t i = tid; i < n; i += 256) {
       Rec r;
@@ -192,6 +196,7 @@ __global__ __launch_bounds__(256) void pack_kernel(PackArgs A) {
     }
     __syncthreads();
 
+    if (tid == 0 && A.dbg) A.dbg[0] = 0x60u;
     // phase 7: one open op per process: the previous op of the same process
     // must have completed before this one was invoked
     for (uint32_t i = tid; i < n; i += 256) {
@@ -201,7 +206,7 @@ __global__ __launch_bounds__(256) void pack_kernel(PackArgs A) {
       if (prev_f != kFNone && !(prev_ret < sc_inv[i])) atomicOr(&s_err, (uint32_t)TBC_ERR_BAD_HISTORY);
     }
     __syncthreads();
-    if (tid == 0) { H->n_ret = R; H->status = s_err ? (uint32_t)TBC_ERR_BAD_HISTORY : 0u; }
+    if (tid == 0) { H->n_ret = R; H->status = s_err ? (uint32_t)TBC_ERR_BAD_HISTORY : 0u; if (A.dbg) A.dbg[0] = 0x90u; }
     __syncthreads();
   }
 }

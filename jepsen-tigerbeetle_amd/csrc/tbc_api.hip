@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -52,12 +53,43 @@ struct DevBuf {
   size_t bytes() const { return (n ? n : 1) * sizeof(T); }
 };
 
+uint64_t now_ns();
+#define SYNC_TRACE(msg) do { if (std::getenv("TBC_SYNC_EACH")) { hipError_t e__ = hipStreamSynchronize(s); std::fprintf(stderr, "[tbc sync] %s -> %s\n", msg, hipGetErrorString(e__)); std::fflush(stderr); } } while (0)
+#define TRACE(msg) do { if (std::getenv("TBC_DEBUG")) { std::fprintf(stderr, "[tbc %9.3f ms] %s\n", (double)(now_ns() % 100000000000ull) / 1e6, msg); std::fflush(stderr); } } while (0)
+
 uint64_t now_ns() {
   return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(
              std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
 }  // namespace
+
+namespace {
+// TBC_DEBUG=1: kernels mirror their progress into host-mapped words so a hang can be diagnosed
+// from another thread (tbc_debug_peek) while the call is still blocked.
+uint32_t* g_dbg = nullptr;
+uint32_t* debug_words() {
+  static bool tried = false;
+  if (!tried) {
+    tried = true;
+    const char* e = std::getenv("TBC_DEBUG");
+    if (e && e[0] == '1') {
+      void* p = nullptr;
+      if (hipHostMalloc(&p, 64 * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
+        std::memset(p, 0, 64 * sizeof(uint32_t));
+        g_dbg = (uint32_t*)p;
+      }
+    }
+  }
+  return g_dbg;
+}
+}  // namespace
+
+extern "C" int tbc_debug_peek(uint32_t* out, uint32_t n) {
+  if (!g_dbg || !out) return 0;
+  for (uint32_t i = 0; i < n && i < 64; i++) out[i] = ((volatile uint32_t*)g_dbg)[i];
+  return 1;
+}
 
 struct tbc_batch {
   int device = 0;
@@ -259,12 +291,12 @@ static SearchArgs make_search_args(tbc_batch* B, uint64_t* tab, uint32_t n_work)
   a.n_classes = B->model.n_classes; a.n_states = B->model.n_states;
   a.max_steps = B->opts.max_steps;
   a.time_limit_ticks = B->opts.time_limit_ms * 100000ull;   // wall_clock64 runs at 100 MHz
+  a.dbg = debug_words();
   return a;
 }
 
 static uint32_t search_blocks(uint32_t n_work) {
-  const uint32_t need = (n_work + kWavesPerBlock - 1) / kWavesPerBlock;
-  return std::max(1u, std::min(need, 256u * 8u));
+  return std::max(1u, (n_work + kWavesPerBlock - 1) / kWavesPerBlock);
 }
 
 static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results) {
@@ -273,6 +305,7 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results) {
   const uint32_t nh = B->n_hist;
   hipStream_t s = B->stream;
 
+  TRACE("run: begin");
   HIP_TRY(hipEventRecord(B->ev[0], s));
   HIP_TRY(hipMemsetAsync(B->d_bitmap.p, 0, B->d_bitmap.bytes(), s));
   HIP_TRY(hipMemsetAsync(B->d_tab.p, 0, B->d_tab.bytes(), s));
@@ -285,20 +318,27 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results) {
   pa.inv_pos = B->d_inv.p; pa.ret_pos = B->d_ret.p; pa.rec = B->d_rec.p; pa.seg = B->d_seg.p;
   pa.ret_slot = B->d_ret_slot.p; pa.ret_op = B->d_ret_op.p; pa.bitmap = B->d_bitmap.p; pa.wpre = B->d_wpre.p;
   pa.scratch = B->d_frames.p; pa.frame_words = B->frame_words; pa.n_hist = nh;
-  pa.model_kind = B->model.kind; pa.n_classes = B->model.n_classes;
+  pa.model_kind = B->model.kind; pa.n_classes = B->model.n_classes; pa.dbg = debug_words();
+  TRACE("run: memsets queued");
+  SYNC_TRACE("memsets");
   launch_pack(pa, s);
+  TRACE("run: pack launched");
+  SYNC_TRACE("pack");
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(B->ev[2], s));
 
   SearchArgs sa = make_search_args(B, B->d_tab.p, nh);
   if (!launch_search(sa, B->mask_words, search_blocks(nh), s)) { set_error("unsupported mask width"); return TBC_ERR_UNSUPPORTED; }
   HIP_TRY(hipGetLastError());
+  TRACE("run: search launched");
+  SYNC_TRACE("search");
   HIP_TRY(hipEventRecord(B->ev[3], s));
   HIP_TRY(hipMemcpyAsync(B->res_host.data(), B->d_results.p, nh * sizeof(DevResult), hipMemcpyDeviceToHost, s));
   std::vector<Hist> hist_back(nh);
   HIP_TRY(hipMemcpyAsync(hist_back.data(), B->d_hist.p, nh * sizeof(Hist), hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
 
+  TRACE("run: first pass synced");
   // ---- retries: histories whose visited set filled up get a 16x larger one
   const uint32_t KW = 1 + B->mask_words;
   const uint64_t max_bytes = B->opts.max_visited_bytes ? B->opts.max_visited_bytes : (1ull << 30);
@@ -362,11 +402,13 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results) {
   HIP_TRY(hipEventRecord(B->ev[5], s));
   HIP_TRY(hipStreamSynchronize(s));
 
+  TRACE("run: retries done");
   if (B->opts.want_witness) {
     B->witness_host.resize(B->total_ops ? B->total_ops : 1);
     HIP_TRY(hipMemcpy(B->witness_host.data(), B->d_witness.p, B->total_ops * 4, hipMemcpyDeviceToHost));
   }
 
+  TRACE("run: witness copied");
   float ms;
   for (int i = 0; i < 3; i++) {
     HIP_TRY(hipEventElapsedTime(&ms, B->ev[i], B->ev[i + 1]));
@@ -375,6 +417,7 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results) {
   HIP_TRY(hipEventElapsedTime(&ms, B->ev[4], B->ev[5]));
   B->timing_ns[3] = (uint64_t)(ms * 1e6);
 
+  TRACE("run: timings read");
   std::memset(&B->sum, 0, sizeof B->sum);
   const uint64_t t_end = now_ns();
   tbc_status worst = TBC_OK;
@@ -451,7 +494,9 @@ tbc_status tbc_check(const tbc_ops* ops, const tbc_model* model, const tbc_opts*
   tbc_batch* B = nullptr;
   tbc_status s = tbc_batch_create(&d, model, opts, &B);
   if (s != TBC_OK) return s;
+  TRACE("check: batch created");
   s = tbc_batch_run(B, out);
+  TRACE("check: run returned");
   if (s == TBC_OK && out->witness) {   // hand the witness over: the batch dies here
     uint32_t* w = (uint32_t*)std::malloc((size_t)std::max(1u, out->n_witness) * 4);
     if (!w) { tbc_batch_destroy(B); return TBC_ERR_OOM; }
@@ -461,6 +506,7 @@ tbc_status tbc_check(const tbc_ops* ops, const tbc_model* model, const tbc_opts*
     out->witness = nullptr;
   }
   tbc_batch_destroy(B);
+  TRACE("check: destroyed");
   out->counters.ns_total = now_ns() - t0;
   return s;
 }

@@ -77,6 +77,7 @@ struct PackArgs {
   uint32_t model_kind;
   uint32_t n_classes;
   uint32_t pad;
+  uint32_t* dbg;
 };
 
 struct SearchArgs {
@@ -100,6 +101,7 @@ struct SearchArgs {
   uint32_t pad;
   uint64_t max_steps;
   uint64_t time_limit_ticks;  // wall_clock64 ticks (100 MHz), 0 = none
+  uint32_t* dbg;              // optional host-mapped progress words (TBC_DEBUG=1), else null
 };
 
 // kernel launchers (defined in the .hip files)

@@ -40,13 +40,14 @@ namespace tbc {
 
 namespace {
 
-constexpr int kRing = 128;   // frames kept in LDS per wave (MW <= 2)
-
 __host__ __device__ constexpr uint32_t frame_words(uint32_t mw) { return 4 + 2 * mw; }
 __host__ __device__ constexpr uint32_t ring_frames(uint32_t mw) { return mw <= 2 ? 128 : (mw <= 4 ? 64 : 32); }
 
 __device__ __forceinline__ uint32_t rfl(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ uint32_t rl(uint32_t v, uint32_t lane) { return __builtin_amdgcn_readlane(v, lane); }
+__device__ __forceinline__ uint64_t ru64(uint64_t v) {
+  return (uint64_t)rfl((uint32_t)v) | ((uint64_t)rfl((uint32_t)(v >> 32)) << 32);
+}
 
 // min over the 64 lanes of a fully active wave; result is wave-uniform
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
@@ -99,14 +100,18 @@ __device__ void search_one(const SearchArgs& A, const uint32_t hidx, uint32_t* r
   constexpr uint32_t KW = 1 + MW;           // u64 words per visited-set entry
   constexpr uint32_t RING = ring_frames(MW);
 
+  // Every per-history quantity is wave-uniform; pin it in SGPRs explicitly (a value
+  // loaded through the vector path is otherwise treated as divergent by the compiler).
   const Hist* H = A.hist + hidx;
-  const Rec* rec = A.rec + H->rec_off;
-  const uint32_t* seg = A.seg + H->seg_off;
-  const uint32_t* ret_slot = A.ret_slot + H->ret_off;
-  uint32_t* frames = A.frames + H->frame_off;
-  uint64_t* tab = A.tab + H->tab_off;
-  const uint32_t W = H->n_slots, R = H->n_ret, n_ops = H->n_ops;
-  const uint64_t cap = 1ull << H->tab_log2;
+  const Rec* rec = A.rec + ru64(H->rec_off);
+  const uint32_t* seg = A.seg + ru64(H->seg_off);
+  const uint64_t ret_off = ru64(H->ret_off);
+  const uint32_t* ret_slot = A.ret_slot + ret_off;
+  uint32_t* frames = A.frames + ru64(H->frame_off);
+  uint64_t* tab = A.tab + ru64(H->tab_off);
+  const uint64_t op_off = ru64(H->op_off);
+  const uint32_t W = rfl(H->n_slots), R = rfl(H->n_ret), status = rfl(H->status);
+  const uint64_t cap = 1ull << rfl(H->tab_log2);
   const uint64_t cap_mask = cap - 1;
   const uint64_t full_at = cap - (cap >> 2);       // 75 % load => give up (host retries bigger)
   DevResult* out = A.results + hidx;
@@ -115,11 +120,9 @@ __device__ void search_one(const SearchArgs& A, const uint32_t hidx, uint32_t* r
   uint64_t steps = 0, visited = 0, probes = 0, backtracks = 0, max_depth = 0, bucket_reads = 0;
   int32_t verdict = -2, cause = TBC_CAUSE_NONE;
 
-  if (H->status != 0) {   // pack rejected it; host reports the status
-    if (lane == 0) { out->valid = TBC_UNKNOWN; out->cause = TBC_CAUSE_NONE; out->max_front = 0; out->depth = 0;
-      out->steps = out->visited = out->probes = out->backtracks = out->max_depth = out->bucket_reads = 0; }
-    return;
-  }
+  if (A.dbg && lane == 0) { A.dbg[4] = 0x100u + hidx; A.dbg[5] = R; A.dbg[6] = status; A.dbg[7] = W; }
+  if (status != 0) verdict = TBC_UNKNOWN;   // pack rejected it; the host reports the status
+  else if (R == 0) verdict = TBC_VALID;
 
   // ---- per-lane cursors (lane + 64*j = process slot)
   Rec cur[MW], nxt[MW];
@@ -127,7 +130,7 @@ __device__ void search_one(const SearchArgs& A, const uint32_t hidx, uint32_t* r
 #pragma unroll
   for (int j = 0; j < MW; j++) {
     const uint32_t slot = lane + 64u * j;
-    if (slot < W) {
+    if (slot < W && verdict == -2) {
       kpos[j] = seg[slot];
       cur[j] = load_rec(rec + kpos[j]);        // head sentinel
       nxt[j] = load_rec(rec + kpos[j] + 1);
@@ -145,11 +148,9 @@ __device__ void search_one(const SearchArgs& A, const uint32_t hidx, uint32_t* r
   for (int j = 0; j < MW; j++) M[j] = 0;
   // chunk of ret_slot held one entry per lane
   uint32_t rs_base = 0;
-  uint32_t rs_val = (lane < R) ? ret_slot[lane] : 0u;
+  uint32_t rs_val = (lane < R && verdict == -2) ? ret_slot[lane] : 0u;
 
   const uint64_t t0 = A.time_limit_ticks ? wall_clock64() : 0;
-
-  if (R == 0) verdict = TBC_VALID;
 
   while (verdict == -2) {
     // ---- A: bring every cursor to the front (forward after a push, backward after a pop)
@@ -193,6 +194,10 @@ __device__ void search_one(const SearchArgs& A, const uint32_t hidx, uint32_t* r
         }
       }
       steps++;
+      if (A.dbg && (steps & 63u) == 1u && lane == 0) {
+        A.dbg[8] = hidx; A.dbg[9] = fi; A.dbg[10] = depth; A.dbg[11] = (uint32_t)steps;
+        A.dbg[12] = (uint32_t)visited; A.dbg[13] = best; A.dbg[14] = (uint32_t)any; A.dbg[15] = (uint32_t)(any >> 32);
+      }
       if (A.max_steps && steps > A.max_steps) { verdict = TBC_UNKNOWN; cause = TBC_CAUSE_STEP_LIMIT; break; }
       if (A.time_limit_ticks && (steps & 255u) == 0 && (uint64_t)wall_clock64() - t0 > A.time_limit_ticks) {
         verdict = TBC_UNKNOWN; cause = TBC_CAUSE_TIME_LIMIT; break;
@@ -332,8 +337,9 @@ __device__ void search_one(const SearchArgs& A, const uint32_t hidx, uint32_t* r
   }
 
   // ---- results
+  if (A.dbg && lane == 0) { A.dbg[4] = 0x200u + hidx; A.dbg[16] = (uint32_t)verdict; A.dbg[17] = (uint32_t)steps; }
   if (verdict == TBC_VALID && A.witness) {
-    uint32_t* wit = A.witness + H->op_off;
+    uint32_t* wit = A.witness + op_off;
     for (uint32_t d = lane; d < depth; d += 64) wit[d] = frames[(uint64_t)d * FW + 2];
   }
   if (lane == 0) {
@@ -341,28 +347,23 @@ __device__ void search_one(const SearchArgs& A, const uint32_t hidx, uint32_t* r
     out->final_state = st; out->n_configs = 0;
     out->fail_op = TBC_NO_OP; out->prev_ok_op = TBC_NO_OP;
     if (verdict == TBC_INVALID) {
-      const uint32_t* ret_op = A.ret_op + H->ret_off;
+      const uint32_t* ret_op = A.ret_op + ret_off;
       out->fail_op = ret_op[maxf];
       if (maxf) out->prev_ok_op = ret_op[maxf - 1];
     }
     out->steps = steps; out->visited = visited; out->probes = probes; out->backtracks = backtracks;
     out->max_depth = max_depth; out->bucket_reads = bucket_reads;
   }
-  (void)n_ops;
 }
 
 template <int MW>
 __global__ __launch_bounds__(kBlock) void wgl_search_kernel(SearchArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-  const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+  const uint32_t lane = threadIdx.x & 63u, wv = rfl(threadIdx.x >> 6);
   uint32_t* ring = lds + wv * (ring_frames(MW) * frame_words(MW));
-  for (;;) {
-    uint32_t h = 0;
-    if (lane == 0) h = atomicAdd(A.queue, 1u);
-    h = rfl(h);
-    if (h >= A.n_work) break;
-    search_one<MW>(A, A.work[h], ring, lane);
-  }
+  // one wavefront per history; the hardware workgroup dispatcher is the work queue
+  const uint32_t w = blockIdx.x * kWavesPerBlock + wv;
+  if (w < A.n_work) search_one<MW>(A, rfl(A.work[w]), ring, lane);
 }
 
 template <int MW>

@@ -48,17 +48,17 @@ def main():
     cases = []
     for n_ops, procs in ((8, 3), (40, 4), (200, 8), (1000, 16), (3000, 64)):
         for seed in range(6 if args.quick else 12):
-            for info in (0.0, 0.02):
-                for corrupt in (0.0, 0.6):
-                    cases.append((n_ops, procs, seed, info, corrupt))
+            cases.append((n_ops, procs, seed, 0.0, 0.0, 0.5))            # valid, no crashes
+            cases.append((n_ops, procs, seed, 0.02, 0.0, 0.5))           # valid, 2 % crashed ops
+            cases.append((n_ops, procs, seed, 0.0, 0.6, min(0.5, 3.0 / procs)))   # violation late
+            cases.append((n_ops, procs, seed, 0.02, 0.1, min(0.5, 3.0 / procs)))  # violation early, crashes
     hists, tags = [], []
-    for (n_ops, procs, seed, info, corrupt) in cases:
-        busy = 0.15 if (corrupt and procs >= 16) else 0.5
+    for (n_ops, procs, seed, info, corrupt, busy) in cases:
         ev = synth.register_events(n_ops=n_ops, n_procs=procs, seed=seed, busy=busy, info=info, corrupt=corrupt)
         hists.append(columns.pair_events(ev))
         tags.append(f"n{n_ops}p{procs}s{seed}i{info}c{corrupt}")
     t = time.time()
-    oras = [wgl.check(h.as_dict(), model, "window", max_steps=20_000_000) for h in hists]
+    oras = [wgl.check(h.as_dict(), model, "window", max_steps=3_000_000) for h in hists]
     print(f"oracle: {len(hists)} histories in {time.time() - t:.2f}s; "
           f"valid={sum(o['valid'] == 1 for o in oras)} invalid={sum(o['valid'] == 0 for o in oras)} "
           f"unknown={sum(o['valid'] == -1 for o in oras)}", flush=True)

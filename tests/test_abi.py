@@ -1,0 +1,77 @@
+"""The C-ABI library loads and exports every symbol include/*.h declares;
+struct layouts seen from ctypes match the header (sizes computed by gcc);
+and there is no CPU fallback behind the compute entry points."""
+import ctypes as C
+import os
+import re
+import subprocess
+import tempfile
+
+import pytest
+
+from conftest import ROOT, has_gpu
+
+
+def declared_functions():
+    names = set()
+    for h in ("tbcheck.h", "tbsynth.h"):
+        src = open(os.path.join(ROOT, "include", h)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        for m in re.finditer(r"\b(tb[cs]_[a-z0-9_]+)\s*\(", src):
+            names.add(m.group(1))
+    names.discard("tbc_step_fn")
+    return sorted(names)
+
+
+def test_every_declared_symbol_is_exported_and_bound(native):
+    lib = native.lib()
+    decl = declared_functions()
+    assert len(decl) >= 15
+    for name in decl:
+        assert hasattr(lib, name), f"{name} declared in include/ but not exported"
+        assert name in native.SYMBOLS, f"{name} has no ctypes binding"
+    assert lib.tbc_version() == 1
+    assert lib.tbc_strerror(3).decode().startswith("no usable gfx950")
+
+
+def test_struct_layouts_match_header(native):
+    prog = r'''
+#include <stdio.h>
+#include "tbcheck.h"
+#include "tbsynth.h"
+int main(void){ printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(tbc_events), sizeof(tbc_ops),
+  sizeof(tbc_model), sizeof(tbc_opts), sizeof(tbc_config), sizeof(tbc_counters), sizeof(tbc_result),
+  sizeof(tbc_batch_desc), sizeof(tbs_params), offsetof(tbc_result, counters)); return 0; }
+'''
+    with tempfile.TemporaryDirectory() as d:
+        src = os.path.join(d, "s.c")
+        open(src, "w").write(prog)
+        exe = os.path.join(d, "s")
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), src, "-o", exe])
+        sizes = [int(x) for x in subprocess.check_output([exe]).split()]
+    N = native
+    mine = [C.sizeof(N.Events), C.sizeof(N.Ops), C.sizeof(N.Model), C.sizeof(N.Opts), C.sizeof(N.Config),
+            C.sizeof(N.Counters), C.sizeof(N.Result), C.sizeof(N.BatchDesc), C.sizeof(N.SynthParams),
+            N.Result.counters.offset]
+    assert mine == sizes
+
+
+@pytest.mark.skipif(has_gpu(), reason="only meaningful on a box without a GPU")
+def test_no_cpu_fallback(native):
+    from jepsen_tigerbeetle_amd import columns, core, synth
+    assert native.lib().tbc_device_count() == 0
+    ops = columns.pair_events(synth.register_events(n_ops=20, n_procs=3, seed=1))
+    with pytest.raises(native.NoDeviceError):
+        core.check_ops(ops, core.make_model(native.MODEL_CAS_REGISTER, native.NIL))
+    with pytest.raises(native.NoDeviceError):
+        core.Batch([ops], core.make_model(native.MODEL_CAS_REGISTER, native.NIL))
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "jepsen-tigerbeetle_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, re.M), f
+                assert "liboracle" not in txt and "oracle/" not in txt.replace("oracle/wgl_window.c", "").replace("oracle/wgl_ref.c", ""), f

@@ -1,0 +1,184 @@
+"""Parity proper: the HIP search, called through the C-ABI, against the CPU
+oracle on the same seeded inputs -- bit-exact verdict, failing op, witness,
+final state and traversal counters -- plus the hand-derived known-answer
+histories and, at BASELINE.json's full size, size-independent properties
+(the witness is a legal real-time-respecting run; batch == single; re-runs are
+idempotent)."""
+import numpy as np
+import pytest
+
+from helpers import MODELS, load_kats, op_tuples, oracle_model
+from jepsen_tigerbeetle_amd import _native as N, columns, core, synth
+from jepsen_tigerbeetle_amd.jepsen import checker as jc, independent
+from jepsen_tigerbeetle_amd.knossos import _analysis, competition, linear, model as M, op as kop, wgl
+from oracle import brute
+
+pytestmark = pytest.mark.gpu
+
+CAS = {"kind": 1, "init": N.NIL}
+
+
+def gm():
+    return core.make_model(N.MODEL_CAS_REGISTER, N.NIL)
+
+
+def assert_same(got, exp, tag=""):
+    assert got["valid"] == exp["valid"], (tag, got["valid"], exp["valid"])
+    if exp["valid"] == 0:
+        assert got["fail_op"] == exp["fail_op"], tag
+        assert got["prev_ok_op"] == (None if exp["prev_ok_op"] == N.NO_OP else exp["prev_ok_op"]), tag
+    if exp["valid"] == 1:
+        assert got["final_state"] == exp["final_state"], tag
+        assert np.array_equal(got["witness"], exp["witness"]), tag
+    for k in ("steps", "visited", "probes", "backtracks", "max_depth"):
+        assert got[k] == exp[k], (tag, k, got[k], exp[k])
+
+
+KATS = load_kats()
+
+
+@pytest.mark.parametrize("name,model,hist,valid,fail_index", KATS, ids=[k[0] for k in KATS])
+def test_kat_through_knossos_surface(native, name, model, hist, valid, fail_index):
+    for analysis in (wgl.analysis, linear.analysis, competition.analysis):
+        a = analysis(MODELS[model](), hist)
+        assert a["valid?"] is valid
+        if not valid:
+            assert a["op"]["index"] == fail_index and a["op"]["type"] == "ok"
+
+
+@pytest.mark.parametrize("n_ops,procs,info,corrupt,busy", [
+    (8, 3, 0.1, 0.0, 0.8), (8, 3, 0.1, 0.5, 0.8), (40, 4, 0.0, 0.0, 0.5), (40, 4, 0.05, 0.5, 0.5),
+    (200, 8, 0.02, 0.0, 0.5), (200, 8, 0.0, 0.6, 0.3), (1000, 16, 0.0, 0.0, 0.5), (1000, 16, 0.01, 0.0, 0.5),
+    (1000, 16, 0.0, 0.6, 0.2), (1000, 16, 0.02, 0.1, 0.2), (3000, 64, 0.0, 0.0, 0.5), (3000, 64, 0.0, 0.6, 0.05),
+])
+def test_single_history_matches_oracle(native, oracle, n_ops, procs, info, corrupt, busy):
+    for seed in range(4):
+        ops = columns.pair_events(synth.register_events(n_ops=n_ops, n_procs=procs, seed=seed, busy=busy,
+                                                        info=info, corrupt=corrupt))
+        exp = oracle.check(ops.as_dict(), CAS, "window", max_steps=3_000_000)
+        if exp["valid"] == -1:
+            continue
+        got = core.check_ops(ops, gm(), core.make_opts(time_limit_ms=30000))
+        assert_same(got, exp, f"seed{seed}")
+
+
+def test_batch_matches_oracle_and_single(native, oracle):
+    hists = []
+    for seed in range(48):
+        n_ops, procs = [(30, 3), (300, 8), (1500, 32)][seed % 3]
+        hists.append(columns.pair_events(synth.register_events(
+            n_ops=n_ops, n_procs=procs, seed=seed, busy=0.3, info=0.02 * (seed % 2), corrupt=0.5 * (seed % 4 == 3))))
+    exps = [oracle.check(h.as_dict(), CAS, "window", max_steps=3_000_000) for h in hists]
+    keep = [i for i, e in enumerate(exps) if e["valid"] != -1]
+    with core.Batch([hists[i] for i in keep], gm(), core.make_opts(time_limit_ms=60000)) as b:
+        first = b.run().results()
+        second = b.run().results()          # inputs stay resident; a re-run is idempotent
+    for j, i in enumerate(keep):
+        assert_same(first[j], exps[i], f"hist{i}")
+        assert_same(second[j], exps[i], f"hist{i} rerun")
+    assert any(e["valid"] == 0 for e in exps) and any(e["valid"] == 1 for e in exps)
+
+
+def test_wide_window_many_crashed_processes(native, oracle):
+    """> 64 processes (crashed ops retire their process id): 2- and 4-word masks."""
+    for n_ops, info in ((1500, 0.05), (3000, 0.05)):
+        ops = columns.pair_events(synth.register_events(n_ops=n_ops, n_procs=48, seed=3, busy=0.4, info=info))
+        assert ops.n_process > 64
+        exp = oracle.check(ops.as_dict(), CAS, "window", max_steps=5_000_000)
+        got = core.check_ops(ops, gm(), core.make_opts(time_limit_ms=60000))
+        assert_same(got, exp)
+
+
+def test_visited_set_overflow_is_retried(native, oracle):
+    """An invalid history whose search outgrows the first (4 x n_ops) table."""
+    ops = columns.pair_events(synth.register_events(n_ops=1000, n_procs=16, seed=1, busy=0.5, info=0.01, corrupt=0.5))
+    exp = oracle.check(ops.as_dict(), CAS, "window")
+    assert exp["valid"] == 0 and exp["visited"] > 4 * len(ops)
+    got = core.check_ops(ops, gm(), core.make_opts(time_limit_ms=60000))
+    assert_same(got, exp)
+    assert got["table_slots"] > 4 * len(ops)
+    # and with the cap too small to ever fit: :unknown, cause memory -- never a wrong verdict
+    small = core.check_ops(ops, gm(), core.make_opts(max_visited_bytes=64 * 1024))
+    assert small["valid"] == N.UNKNOWN and small["cause"] == N.CAUSE_VISITED_FULL
+
+
+def test_step_limit_gives_unknown(native):
+    ops = columns.pair_events(synth.register_events(n_ops=1000, n_procs=16, seed=1, busy=0.5, info=0.01, corrupt=0.5))
+    r = core.check_ops(ops, gm(), core.make_opts(max_steps=1000))
+    assert r["valid"] == N.UNKNOWN and r["cause"] == N.CAUSE_STEP_LIMIT
+
+
+def test_full_size_properties_10k_ops_64_procs(native, oracle):
+    """BASELINE.json config 2 shape.  Size-independent properties + the oracle."""
+    for seed, info in ((0, 0.0), (1, 0.01)):
+        ops = columns.pair_events(synth.register_events(n_ops=10000, n_procs=64, seed=seed, busy=0.5, info=info))
+        got = core.check_ops(ops, gm(), core.make_opts(time_limit_ms=60000))
+        assert got["valid"] == N.VALID       # linearizable by construction
+        tup = op_tuples(ops)
+        assert brute.check_witness(CAS, tup, [int(x) for x in got["witness"]]) == got["final_state"]
+        assert_same(got, oracle.check(ops.as_dict(), CAS, "window"))
+    # one corrupted read => not linearizable, and the op reported is that read
+    ev = synth.register_events(n_ops=10000, n_procs=64, seed=5, busy=0.04, info=0.0, corrupt=0.7)
+    ops = columns.pair_events(ev)
+    got = core.check_ops(ops, gm(), core.make_opts(time_limit_ms=60000))
+    assert got["valid"] == N.INVALID
+    assert ops.a[got["fail_op"]] == 5 + 7    # the impossible value the generator planted
+
+
+def test_rejects_malformed_ops(native):
+    ops = columns.pair_events(synth.register_events(n_ops=50, n_procs=4, seed=2))
+    bad = columns.OpColumns(ops.f.copy(), ops.a.copy(), ops.b.copy(), ops.process.copy(), ops.inv_pos.copy(),
+                            ops.ret_pos.copy(), ops.n_events, ops.n_process)
+    bad.inv_pos[3], bad.inv_pos[4] = bad.inv_pos[4], bad.inv_pos[3]          # not ascending
+    with pytest.raises(N.TbcError) as e:
+        core.check_ops(bad, gm())
+    assert e.value.status == N.ERR_BAD_HISTORY
+    reg = core.make_model(N.MODEL_REGISTER, N.NIL)                           # :cas on a plain register
+    if (ops.f == N.F_CAS).any():
+        with pytest.raises(N.TbcError) as e:
+            core.check_ops(ops, reg)
+        assert e.value.status == N.ERR_MODEL
+
+
+def test_mutex_and_table_models(native, oracle):
+    h = []
+    for i in range(40):   # two processes handing a lock back and forth, one bad double-acquire at the end
+        p = i % 2
+        h += [kop.invoke(p, "acquire", None), kop.ok(p, "acquire", None), kop.invoke(p, "release", None), kop.ok(p, "release", None)]
+    assert wgl.analysis(M.mutex(), h)["valid?"] is True
+    h += [kop.invoke(0, "acquire", None), kop.ok(0, "acquire", None), kop.invoke(1, "acquire", None), kop.ok(1, "acquire", None)]
+    a = wgl.analysis(M.mutex(), h)
+    assert a["valid?"] is False and a["op"]["index"] == len(h) - 1
+    # memo-table path: the set model and multi-register through knossos.model.memo
+    s = [kop.invoke(0, "add", 1), kop.invoke(1, "add", 2), kop.ok(1, "add", 2), kop.invoke(2, "read", None),
+         kop.ok(2, "read", [2]), kop.ok(0, "add", 1), kop.invoke(2, "read", None), kop.ok(2, "read", [1, 2])]
+    assert wgl.analysis(M.set(), s)["valid?"] is True
+    s[-1] = kop.ok(2, "read", [2])      # add 1 completed before this read was invoked
+    a = wgl.analysis(M.set(), s)
+    assert a["valid?"] is False and a["op"]["index"] == 7
+    t = [kop.invoke(0, "txn", [["w", "x", 1], ["w", "y", 1]]), kop.ok(0, "txn", [["w", "x", 1], ["w", "y", 1]]),
+         kop.invoke(1, "txn", [["r", "x", None], ["r", "y", None]]), kop.ok(1, "txn", [["r", "x", 1], ["r", "y", 1]])]
+    assert wgl.analysis(M.multi_register({}), t)["valid?"] is True
+    t[-1] = kop.ok(1, "txn", [["r", "x", 1], ["r", "y", None]])
+    assert wgl.analysis(M.multi_register({}), t)["valid?"] is True      # nil read matches anything
+    t[-1] = kop.ok(1, "txn", [["r", "x", 1], ["r", "y", 2]])
+    assert wgl.analysis(M.multi_register({}), t)["valid?"] is False
+
+
+def test_jepsen_checker_surface(native):
+    """checker/linearizable inside checker/compose inside independent/checker -- the
+    composition the reference uses at set_full.clj:155-158 -- batched on the device."""
+    t = independent.tuple_
+    h = []
+    for k in (1, 2, 3):
+        h += [kop.invoke(k, "write", t(k, k)), kop.ok(k, "write", t(k, k)),
+              kop.invoke(k, "read", t(k, None)), kop.ok(k, "read", t(k, k if k != 2 else 99))]
+    h.insert(3, {"type": "info", "f": "start-partition", "process": "nemesis", "value": None})
+    c = independent.checker(jc.linearizable({"model": M.cas_register(), "algorithm": "wgl"}))
+    r = c.check({}, h, {})
+    assert r["valid?"] is False and r["failures"] == [2]
+    assert r["results"][1]["valid?"] is True and r["results"][2]["op"]["value"] == 99
+    comp = jc.compose({"linear": jc.linearizable({"model": M.cas_register(), "algorithm": "linear"}),
+                       "wgl": jc.linearizable({"model": M.cas_register()})})
+    r2 = comp.check({}, independent.subhistory(1, h), {})
+    assert r2["valid?"] is True and r2["linear"]["analyzer"] == "linear"

@@ -1,0 +1,77 @@
+"""The oracle pinned as far as it can be: the reference holds no golden vectors
+(PARITY UNPINNED, oracle/oracle_model.h), so the CPU restatements are checked
+against (1) hand-derived known-answer histories, (2) an independent brute-force
+definition of linearizability on small random histories, (3) each other (the
+published DLL/bit-set form vs the windowed-key form the HIP kernel uses)."""
+import numpy as np
+import pytest
+
+from helpers import load_kats, op_tuples, oracle_model
+from jepsen_tigerbeetle_amd import _native as N, columns, synth
+from jepsen_tigerbeetle_amd.knossos import _analysis
+from helpers import MODELS
+from oracle import brute
+
+KATS = load_kats()
+
+
+@pytest.mark.parametrize("name,model,hist,valid,fail_index", KATS, ids=[k[0] for k in KATS])
+def test_kat_oracles(native, oracle, name, model, hist, valid, fail_index):
+    enc = _analysis.Encoded(MODELS[model](), hist)
+    om = oracle_model(model)
+    for alg in ("ref", "window"):
+        r = oracle.check(enc.ops.as_dict(), om, alg)
+        assert r["valid"] == (1 if valid else 0), (alg, r)
+        if not valid:
+            assert enc.op_completion(r["fail_op"])["index"] == fail_index
+    # brute force agrees with the hand derivation too
+    tup = op_tuples(enc.ops)
+    bad = brute.first_bad_completion(om, tup)
+    assert (bad is None) == valid
+    if not valid:
+        assert enc.op_completion(bad)["index"] == fail_index
+
+
+@pytest.mark.parametrize("block", range(4))
+def test_oracles_match_brute_force_on_small_histories(native, oracle, block):
+    m = {"kind": 1, "init": N.NIL}
+    n_invalid = 0
+    for seed in range(block * 150, block * 150 + 150):
+        ev = synth.register_events(n_ops=7, n_procs=3, seed=seed, busy=0.8, info=0.15, n_values=3,
+                                   corrupt=(0.5 if seed % 2 else 0.0))
+        ops = columns.pair_events(ev)
+        if seed % 3 == 0:   # a second kind of corruption: a stale-but-plausible value
+            rd = [i for i in range(len(ops)) if ops.f[i] == N.F_READ and ops.ret_pos[i] != N.POS_CRASHED]
+            if rd:
+                ops.a[rd[len(rd) // 2]] = (seed // 3) % 3
+        tup = op_tuples(ops)
+        bad = brute.first_bad_completion(m, tup)
+        n_invalid += bad is not None
+        for alg in ("ref", "window"):
+            r = oracle.check(ops.as_dict(), m, alg)
+            assert r["valid"] == (1 if bad is None else 0), (seed, alg)
+            if bad is not None:
+                assert r["fail_op"] == bad, (seed, alg)
+            else:
+                assert brute.check_witness(m, tup, list(r["witness"])) == r["final_state"]
+    assert n_invalid > 20
+
+
+@pytest.mark.parametrize("n_ops,procs,info,corrupt,busy", [
+    (300, 8, 0.0, 0.0, 0.5), (300, 8, 0.03, 0.0, 0.5), (300, 8, 0.0, 0.7, 0.3), (300, 8, 0.03, 0.2, 0.3),
+    (2000, 64, 0.0, 0.0, 0.5), (2000, 64, 0.01, 0.0, 0.5), (1000, 16, 0.0, 0.5, 0.2),
+])
+def test_windowed_form_equals_published_form(native, oracle, n_ops, procs, info, corrupt, busy):
+    """Same traversal: verdict, failing op, witness and every counter."""
+    m = {"kind": 1, "init": N.NIL}
+    for seed in range(5):
+        ops = columns.pair_events(synth.register_events(n_ops=n_ops, n_procs=procs, seed=seed, busy=busy,
+                                                        info=info, corrupt=corrupt))
+        a = oracle.check(ops.as_dict(), m, "ref", max_steps=2_000_000)
+        b = oracle.check(ops.as_dict(), m, "window", max_steps=2_000_000)
+        for k in ("valid", "fail_op", "prev_ok_op", "final_state", "n_witness", "steps", "visited", "backtracks", "max_depth"):
+            assert a[k] == b[k], (seed, k)
+        if a["valid"] == 1:
+            assert np.array_equal(a["witness"], b["witness"])
+            # a witness is a legal run that respects real-time order
+            brute.check_witness(m, op_tuples(ops), list(a["witness"]))
