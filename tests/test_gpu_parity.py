@@ -90,13 +90,13 @@ def test_wide_window_many_crashed_processes(native, oracle):
 
 
 def test_visited_set_overflow_is_retried(native, oracle):
-    """An invalid history whose search outgrows the first (4 x n_ops) table."""
+    """An invalid history whose search outgrows the first (16 x n_ops) table."""
     ops = columns.pair_events(synth.register_events(n_ops=1000, n_procs=16, seed=1, busy=0.5, info=0.01, corrupt=0.5))
     exp = oracle.check(ops.as_dict(), CAS, "window")
-    assert exp["valid"] == 0 and exp["visited"] > 4 * len(ops)
+    assert exp["valid"] == 0 and exp["visited"] > 16 * len(ops)
     got = core.check_ops(ops, gm(), core.make_opts(time_limit_ms=60000))
     assert_same(got, exp)
-    assert got["table_slots"] > 4 * len(ops)
+    assert got["table_slots"] > 32 * len(ops)
     # and with the cap too small to ever fit: :unknown, cause memory -- never a wrong verdict
     small = core.check_ops(ops, gm(), core.make_opts(max_visited_bytes=64 * 1024))
     assert small["valid"] == N.UNKNOWN and small["cause"] == N.CAUSE_VISITED_FULL
