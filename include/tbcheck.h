@@ -169,7 +169,7 @@ typedef struct tbc_opts {
   uint64_t max_steps;        /* 0 = none; search-step budget (deterministic)     */
   uint64_t max_visited_bytes;/* 0 = library default; visited-set cap per history */
   uint32_t want_witness;     /* copy the linearization order back                */
-  uint32_t visited_per_op;   /* 0 = default (16): first visited-set capacity is   */
+  uint32_t visited_per_op;   /* 0 = default (64): first visited-set capacity is   */
                              /* this many entries per op, x16 on each overflow    */
 } tbc_opts;
 

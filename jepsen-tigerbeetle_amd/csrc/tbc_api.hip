@@ -201,7 +201,7 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
     H.ret_off = H.op_off;
     H.bm_off = bm_n; bm_n += H.n_events / 32 + 1;
     H.frame_off = frame_n; frame_n += std::max<uint64_t>(n, 1) * B->frame_words;
-    const uint64_t per_op = opts->visited_per_op ? opts->visited_per_op : 16;
+    const uint64_t per_op = opts->visited_per_op ? opts->visited_per_op : 64;
     uint32_t lg = std::max(10u, ceil_log2(per_op * std::max<uint64_t>(n, 1)));
     while (lg > 10 && (1ull << lg) * KW * 8 > max_bytes) lg--;
     H.tab_log2 = lg;

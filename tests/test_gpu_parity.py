@@ -82,21 +82,22 @@ def test_batch_matches_oracle_and_single(native, oracle):
 def test_wide_window_many_crashed_processes(native, oracle):
     """> 64 processes (crashed ops retire their process id): 2- and 4-word masks."""
     for n_ops, info in ((1500, 0.05), (3000, 0.05)):
-        ops = columns.pair_events(synth.register_events(n_ops=n_ops, n_procs=48, seed=3, busy=0.4, info=info))
+        ops = columns.pair_events(synth.register_events(n_ops=n_ops, n_procs=48, seed=3, busy=0.12, info=info))
         assert ops.n_process > 64
-        exp = oracle.check(ops.as_dict(), CAS, "window", max_steps=5_000_000)
-        got = core.check_ops(ops, gm(), core.make_opts(time_limit_ms=60000))
+        exp = oracle.check(ops.as_dict(), CAS, "window", max_steps=20_000_000)
+        assert exp["valid"] != -1
+        got = core.check_ops(ops, gm(), core.make_opts(time_limit_ms=120000))
         assert_same(got, exp)
 
 
 def test_visited_set_overflow_is_retried(native, oracle):
-    """An invalid history whose search outgrows the first (16 x n_ops) table."""
+    """An invalid history whose search outgrows its first table (forced small: 4 entries per op)."""
     ops = columns.pair_events(synth.register_events(n_ops=1000, n_procs=16, seed=1, busy=0.5, info=0.01, corrupt=0.5))
     exp = oracle.check(ops.as_dict(), CAS, "window")
     assert exp["valid"] == 0 and exp["visited"] > 16 * len(ops)
-    got = core.check_ops(ops, gm(), core.make_opts(time_limit_ms=60000))
+    got = core.check_ops(ops, gm(), core.make_opts(time_limit_ms=60000, visited_per_op=4))
     assert_same(got, exp)
-    assert got["table_slots"] > 32 * len(ops)
+    assert got["table_slots"] > 16 * len(ops)
     # and with the cap too small to ever fit: :unknown, cause memory -- never a wrong verdict
     small = core.check_ops(ops, gm(), core.make_opts(max_visited_bytes=64 * 1024))
     assert small["valid"] == N.UNKNOWN and small["cause"] == N.CAUSE_VISITED_FULL
