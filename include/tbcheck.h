@@ -171,6 +171,13 @@ typedef struct tbc_opts {
   uint32_t want_witness;     /* copy the linearization order back                */
   uint32_t visited_per_op;   /* 0 = default (64): first visited-set capacity is   */
                              /* this many entries per op, x16 on each overflow    */
+  uint32_t search_width;     /* configs expanded per iteration.  1 = the sequential*/
+                             /* knossos.wgl order (witness and counters equal the */
+                             /* published algorithm's); 2..16 = the wide schedule */
+                             /* (same verdict / failing op, one (config, call)    */
+                             /* pair per lane).  0 = default: 1 for TBC_ALG_WGL,  */
+                             /* 16 for TBC_ALG_LINEAR / TBC_ALG_COMPETITION       */
+  uint32_t reserved;
 } tbc_opts;
 
 /* ------------------------------------------------------------------ result */

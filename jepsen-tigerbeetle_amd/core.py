@@ -27,7 +27,7 @@ def make_model(kind, init=N.NIL, table=None):
 
 
 def make_opts(algorithm=N.ALG_WGL, device=0, time_limit_ms=0, max_steps=0, max_visited_bytes=0,
-              want_witness=True, visited_per_op=0):
+              want_witness=True, visited_per_op=0, search_width=0):
     o = N.Opts()
     o.algorithm = algorithm
     o.device = device
@@ -36,6 +36,7 @@ def make_opts(algorithm=N.ALG_WGL, device=0, time_limit_ms=0, max_steps=0, max_v
     o.max_visited_bytes = int(max_visited_bytes)
     o.want_witness = 1 if want_witness else 0
     o.visited_per_op = int(visited_per_op)
+    o.search_width = int(search_width)
     return o
 
 

@@ -1,0 +1,170 @@
+// pack_open.hip -- K1b: open-call lists for the wide search kernel (gfx950).
+//
+// Runs after pack_kernel (which left every op's inv_rank / ret_rank in the
+// scratch arena).  For every front F (= rank of a completion) the wide search
+// needs the calls that are open at F.  This kernel builds, per history:
+//
+//   occ[F]   bit p set  <=>  process p has a LIVE (eventually completed) call open at F
+//   off[F]   CSR offsets, off[F+1]-off[F] = popcount(occ[F])
+//   lst[]    the live open calls of front F in process-slot order
+//            (position of p's call = popcount(occ[F] below p): no sorting needed)
+//   crashed[] the :info calls in invocation order, ncr[F] = how many of them were
+//            invoked before completion F (they stay open for ever, so they are
+//            kept out of the per-front lists)
+//   opinfo[] 16 B per op {ret_rank, f | slot<<8, a, b}: one load per candidate
+//
+// This is knossos.linear.config's "pending calls by process" materialised for
+// every point of the history.  One 256-thread workgroup per
+// history.  off/ncr/occ arenas are zeroed by the host before the launch.
+#include <hip/hip_runtime.h>
+#include "tbc_internal.h"
+
+namespace tbc {
+
+namespace {
+
+__device__ __forceinline__ uint32_t ld_agent(const uint32_t* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint64_t ld_agent64(const uint64_t* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// in-place exclusive scan of v[0..m) by a 256-thread block; returns the total.
+// `part` is 256 words of LDS.  Every element is read and written by one thread only.
+__device__ uint32_t block_exclusive_scan(uint32_t* v, uint32_t m, uint32_t* part, uint32_t* total_slot) {
+  const uint32_t tid = threadIdx.x;
+  const uint32_t chunk = (m + 255) / 256;
+  const uint32_t lo = min(tid * chunk, m), hi = min(lo + chunk, m);
+  uint32_t sum = 0;
+  for (uint32_t i = lo; i < hi; i++) sum += ld_agent(&v[i]);
+  part[tid] = sum;
+  __syncthreads();
+  if (tid == 0) {
+    uint32_t run = 0;
+    for (uint32_t t = 0; t < 256; t++) { uint32_t x = part[t]; part[t] = run; run += x; }
+    *total_slot = run;
+  }
+  __syncthreads();
+  uint32_t run = part[tid];
+  for (uint32_t i = lo; i < hi; i++) { uint32_t x = ld_agent(&v[i]); v[i] = run; run += x; }
+  __syncthreads();
+  return *total_slot;
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(256) void pack_open_kernel(PackOpenArgs A) {
+  __shared__ uint32_t s_part[256];
+  __shared__ uint32_t s_total;
+  const uint32_t tid = threadIdx.x;
+  const uint32_t MW = A.mask_words;
+
+  for (uint32_t h = blockIdx.x; h < A.n_hist; h += gridDim.x) {
+    const Hist* H = &A.hist[h];
+    BeamHist* B = &A.bh[h];
+    const uint32_t n = H->n_ops, R = H->n_ret;
+    if (H->status != 0 || R == 0) {
+      if (tid == 0) { B->status = 0; B->n_crashed = 0; }
+      continue;
+    }
+    const uint8_t* f = A.f + H->op_off;
+    const int32_t* a = A.a + H->op_off;
+    const int32_t* b = A.b + H->op_off;
+    const int32_t* proc = A.process + H->op_off;
+    const uint32_t* sc_inv = A.scratch + H->frame_off;
+    const uint32_t* sc_ret = sc_inv + n;
+    uint32_t* off = A.off + B->off_off;      // R + 1 entries used
+    uint32_t* ncr = A.ncr + B->off_off;      // R entries used
+    uint64_t* occ = A.occ + B->occ_off;      // R * MW words used
+    uint32_t* lst = A.lst + B->lst_off;
+    uint32_t* crashed = A.crashed + H->op_off;
+    OpInfo* info = A.opinfo + H->op_off;
+
+    // A: occupancy bits of live calls; crashed-call counts by front; op records
+    for (uint32_t i = tid; i < n; i += 256) {
+      const uint32_t ir = sc_inv[i], rr = sc_ret[i];
+      const uint32_t p = (uint32_t)proc[i];
+      OpInfo o; o.ret_rank = rr; o.f_slot = (uint32_t)f[i] | (p << 8); o.a = a[i]; o.b = b[i];
+      info[i] = o;
+      if (rr == kInf) {
+        if (ir < R) atomicAdd(&ncr[ir], 1u);
+      } else {
+        const unsigned long long bit = 1ull << (p & 63u);
+        for (uint32_t fr = ir; fr <= rr; fr++)
+          atomicOr((unsigned long long*)&occ[(uint64_t)fr * MW + (p >> 6)], bit);
+      }
+    }
+    __syncthreads();
+    // B: live count per front -> off[F+1]; then exclusive scan -> CSR offsets
+    for (uint32_t fr = tid; fr < R; fr += 256) {
+      uint32_t c = 0;
+      for (uint32_t w = 0; w < MW; w++) c += __popcll(ld_agent64(&occ[(uint64_t)fr * MW + w]));
+      off[fr] = c;
+    }
+    if (tid == 0) off[R] = 0;
+    __syncthreads();
+    const uint32_t total = block_exclusive_scan(off, R + 1, s_part, &s_total);
+    // ncr[F] = crashed calls invoked before completion F (inclusive prefix)
+    {
+      // exclusive scan then add own count: do it as exclusive scan of a shifted view
+      // (ncr[F] currently = #crashed with inv_rank == F)
+      const uint32_t chunk = (R + 255) / 256;
+      const uint32_t lo = min(tid * chunk, R), hi = min(lo + chunk, R);
+      uint32_t sum = 0;
+      for (uint32_t i = lo; i < hi; i++) sum += ld_agent(&ncr[i]);
+      s_part[tid] = sum;
+      __syncthreads();
+      if (tid == 0) {
+        uint32_t run = 0;
+        for (uint32_t t = 0; t < 256; t++) { uint32_t x = s_part[t]; s_part[t] = run; run += x; }
+      }
+      __syncthreads();
+      uint32_t run = s_part[tid];
+      for (uint32_t i = lo; i < hi; i++) { run += ld_agent(&ncr[i]); ncr[i] = run; }
+      __syncthreads();
+    }
+    if (total > B->lst_cap) {
+      if (tid == 0) { B->status = 1; B->n_crashed = 0; }
+      __syncthreads();
+      continue;
+    }
+    // C: fill the per-front lists in process-slot order
+    for (uint32_t i = tid; i < n; i += 256) {
+      const uint32_t ir = sc_inv[i], rr = sc_ret[i];
+      if (rr == kInf) continue;
+      const uint32_t p = (uint32_t)proc[i];
+      for (uint32_t fr = ir; fr <= rr; fr++) {
+        uint32_t pos = ld_agent(&off[fr]);
+        for (uint32_t w = 0; w < (p >> 6); w++) pos += __popcll(ld_agent64(&occ[(uint64_t)fr * MW + w]));
+        pos += __popcll(ld_agent64(&occ[(uint64_t)fr * MW + (p >> 6)]) & ((1ull << (p & 63u)) - 1ull));
+        lst[pos] = i;
+      }
+    }
+    // D: crashed calls in invocation order (stable compaction)
+    {
+      const uint32_t chunk = (n + 255) / 256;
+      const uint32_t lo = min(tid * chunk, n), hi = min(lo + chunk, n);
+      uint32_t cnt = 0;
+      for (uint32_t i = lo; i < hi; i++) cnt += sc_ret[i] == kInf;
+      s_part[tid] = cnt;
+      __syncthreads();
+      if (tid == 0) {
+        uint32_t run = 0;
+        for (uint32_t t = 0; t < 256; t++) { uint32_t x = s_part[t]; s_part[t] = run; run += x; }
+        B->n_crashed = run; B->status = 0;
+      }
+      __syncthreads();
+      uint32_t run = s_part[tid];
+      for (uint32_t i = lo; i < hi; i++) if (sc_ret[i] == kInf) crashed[run++] = i;
+      __syncthreads();
+    }
+  }
+}
+
+void launch_pack_open(const PackOpenArgs& a, void* stream) {
+  uint32_t grid = a.n_hist < 4096 ? a.n_hist : 4096;
+  hipLaunchKernelGGL(pack_open_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+}
+
+}  // namespace tbc

@@ -113,6 +113,13 @@ struct tbc_batch {
   DevBuf<uint64_t> d_tab;
   DevBuf<DevResult> d_results;
   DevBuf<uint16_t> d_table;
+  // wide schedule (search_width > 1)
+  uint32_t width = 1;
+  std::vector<BeamHist> bh;
+  DevBuf<BeamHist> d_bh;
+  DevBuf<uint32_t> d_off, d_ncr, d_lst, d_crashed, d_stack;
+  DevBuf<uint64_t> d_occ, d_btab;
+  DevBuf<OpInfo> d_opinfo;
   // last run
   std::vector<DevResult> res_host;
   std::vector<uint32_t> fail_host;   // 2 per history: fail_op, prev_ok_op
@@ -126,6 +133,8 @@ struct tbc_batch {
     d_hist.release(); d_rec.release(); d_seg.release(); d_ret_slot.release(); d_ret_op.release();
     d_bitmap.release(); d_wpre.release(); d_frames.release(); d_witness.release(); d_work.release();
     d_queue.release(); d_tab.release(); d_results.release(); d_table.release();
+    d_bh.release(); d_off.release(); d_ncr.release(); d_lst.release(); d_crashed.release(); d_stack.release();
+    d_occ.release(); d_btab.release(); d_opinfo.release();
     for (auto& e : ev) if (e) (void)hipEventDestroy(e);
     if (stream) (void)hipStreamDestroy(stream);
   }
@@ -182,10 +191,18 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
   B->mask_words = mw <= 1 ? 1 : mw <= 2 ? 2 : mw <= 4 ? 4 : mw <= 8 ? 8 : 16;
   B->frame_words = search_frame_words(B->mask_words);
   const uint32_t KW = 1 + B->mask_words;
+  uint32_t width = opts->search_width ? opts->search_width : (opts->algorithm == TBC_ALG_WGL ? 1u : 16u);
+  if (width > 16) width = 16;
+  if (B->mask_words > 4) width = 1;          // very wide windows: sequential kernel only
+  B->width = width;
+  const bool beam = width > 1;
+  const uint32_t EW = B->mask_words + 3;     // u64 words per wide-schedule entry
 
   const uint64_t default_cap_bytes = 1ull << 30;
   const uint64_t max_bytes = opts->max_visited_bytes ? opts->max_visited_bytes : default_cap_bytes;
   B->hist.resize(nh);
+  if (beam) B->bh.resize(nh);
+  uint64_t boff_n = 0, bocc_n = 0, blst_n = 0, bstack_n = 0, btab_n = 0;
   uint64_t rec_n = 0, seg_n = 0, bm_n = 0, frame_n = 0, tab_n = 0;
   for (uint32_t h = 0; h < nh; h++) {
     Hist& H = B->hist[h];
@@ -205,8 +222,21 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
     uint32_t lg = std::max(10u, ceil_log2(per_op * std::max<uint64_t>(n, 1)));
     while (lg > 10 && (1ull << lg) * KW * 8 > max_bytes) lg--;
     H.tab_log2 = lg;
-    H.tab_off = tab_n; tab_n += (1ull << lg) * KW;
-    tab_n = (tab_n + 1) & ~1ull;   // keep 16 B alignment
+    H.tab_off = tab_n;
+    if (!beam) { tab_n += (1ull << lg) * KW; tab_n = (tab_n + 1) & ~1ull; }   // keep 16 B alignment
+    if (beam) {
+      BeamHist& Q = B->bh[h];
+      std::memset(&Q, 0, sizeof Q);
+      uint32_t blg = lg;
+      while (blg > 10 && (1ull << blg) * EW * 8 > max_bytes) blg--;
+      Q.tab_log2 = blg;
+      Q.off_off = boff_n; boff_n += n + 2;
+      Q.occ_off = bocc_n; bocc_n += (n + 1) * B->mask_words;
+      Q.lst_cap = (uint32_t)std::min<uint64_t>(0xFFFFFFF0ull, std::max<uint64_t>(n, 1) * std::min(H.n_slots, 32u));
+      Q.lst_off = blst_n; blst_n += Q.lst_cap;
+      Q.stack_off = bstack_n; bstack_n += (1ull << blg);
+      Q.tab_off = btab_n; btab_n += (1ull << blg);
+    }
   }
 
   tbc_status s;
@@ -218,6 +248,12 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
       (s = B->d_tab.alloc(tab_n)) || (s = B->d_results.alloc(nh)) || (s = B->d_work.alloc(nh)) ||
       (s = B->d_queue.alloc(4)) || (s = B->d_witness.alloc(opts->want_witness ? T : 0)))
     return s;
+  if (beam) {
+    if ((s = B->d_bh.alloc(nh)) || (s = B->d_off.alloc(boff_n)) || (s = B->d_ncr.alloc(boff_n)) ||
+        (s = B->d_occ.alloc(bocc_n)) || (s = B->d_lst.alloc(blst_n)) || (s = B->d_crashed.alloc(T)) ||
+        (s = B->d_opinfo.alloc(T)) || (s = B->d_stack.alloc(bstack_n)) || (s = B->d_btab.alloc(btab_n * EW)))
+      return s;
+  }
   if (model->kind == TBC_MODEL_TABLE) {
     const size_t tn = (size_t)model->n_states * model->n_classes;
     B->table_host.assign(model->table, model->table + tn);
@@ -229,6 +265,8 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
                     B->d_ret.bytes() + B->d_hist.bytes() + B->d_rec.bytes() + B->d_seg.bytes() + B->d_ret_slot.bytes() +
                     B->d_ret_op.bytes() + B->d_bitmap.bytes() + B->d_wpre.bytes() + B->d_frames.bytes() +
                     B->d_tab.bytes() + B->d_results.bytes() + B->d_work.bytes() + B->d_witness.bytes();
+  if (beam) B->device_bytes += B->d_bh.bytes() + B->d_off.bytes() + B->d_ncr.bytes() + B->d_occ.bytes() + B->d_lst.bytes() +
+                               B->d_crashed.bytes() + B->d_opinfo.bytes() + B->d_stack.bytes() + B->d_btab.bytes();
 
   HIP_TRY(hipStreamCreateWithFlags(&B->stream, hipStreamNonBlocking));
   for (auto& e : B->ev) HIP_TRY(hipEventCreate(&e));
@@ -300,19 +338,96 @@ static uint32_t search_blocks(uint32_t n_work) {
   return std::max(1u, (n_work + kWavesPerBlock - 1) / kWavesPerBlock);
 }
 
+static BeamArgs make_beam_args(tbc_batch* B, uint64_t* tab, uint32_t* stack, uint32_t n_work) {
+  BeamArgs a{};
+  a.hist = B->d_hist.p; a.bh = B->d_bh.p; a.off = B->d_off.p; a.ncr = B->d_ncr.p; a.lst = B->d_lst.p;
+  a.crashed = B->d_crashed.p; a.opinfo = B->d_opinfo.p; a.ret_slot = B->d_ret_slot.p; a.ret_op = B->d_ret_op.p;
+  a.stack = stack; a.tab = tab; a.results = B->d_results.p;
+  a.witness = B->opts.want_witness ? B->d_witness.p : nullptr;
+  a.work = B->d_work.p; a.table = B->d_table.p; a.n_work = n_work; a.model_kind = B->model.kind;
+  a.init_state = B->model.kind == TBC_MODEL_MUTEX ? 0 : B->model.init;
+  a.n_classes = B->model.n_classes; a.width = B->width;
+  a.max_steps = B->opts.max_steps;
+  a.time_limit_ticks = B->opts.time_limit_ms * 100000ull;
+  a.dbg = debug_words();
+  return a;
+}
+
+// One extra pass over the histories in `grp` with per-history visited sets of 2^lg[i] entries in a
+// scratch arena (overflow retries, and wide-schedule histories that fall back to the sequential kernel).
+static tbc_status scratch_pass(tbc_batch* B, const std::vector<uint32_t>& grp, const std::vector<uint32_t>& lg,
+                               bool beam, const std::vector<Hist>& hist_back, const std::vector<BeamHist>& bh_back) {
+  hipStream_t s = B->stream;
+  const uint32_t KW = 1 + B->mask_words, EW = B->mask_words + 3;
+  const uint64_t words_per_entry = beam ? EW : KW;
+  uint64_t entries = 0;
+  std::vector<Hist> ph(grp.size());
+  std::vector<BeamHist> pb(beam ? grp.size() : 0);
+  for (size_t i = 0; i < grp.size(); i++) {
+    ph[i] = hist_back[grp[i]];
+    if (beam) {
+      pb[i] = bh_back[grp[i]];
+      pb[i].tab_off = entries; pb[i].stack_off = entries; pb[i].tab_log2 = lg[i];
+    } else {
+      ph[i].tab_off = entries * KW; ph[i].tab_log2 = lg[i];
+    }
+    entries += 1ull << lg[i];
+  }
+  DevBuf<uint64_t> big;
+  DevBuf<uint32_t> bstack;
+  tbc_status st = big.alloc(entries * words_per_entry);
+  if (st != TBC_OK) return st;
+  if (beam && (st = bstack.alloc(entries)) != TBC_OK) { big.release(); return st; }
+  hipError_t e = hipMemsetAsync(big.p, 0, entries * words_per_entry * 8, s);
+  for (size_t i = 0; i < grp.size() && e == hipSuccess; i++) {
+    e = hipMemcpyAsync(B->d_hist.p + grp[i], &ph[i], sizeof(Hist), hipMemcpyHostToDevice, s);
+    if (beam && e == hipSuccess) e = hipMemcpyAsync(B->d_bh.p + grp[i], &pb[i], sizeof(BeamHist), hipMemcpyHostToDevice, s);
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(B->d_work.p, grp.data(), grp.size() * 4, hipMemcpyHostToDevice, s);
+  if (e == hipSuccess) {
+    const uint32_t nw = (uint32_t)grp.size();
+    if (beam) { BeamArgs ba = make_beam_args(B, big.p, bstack.p, nw); launch_beam(ba, B->mask_words, search_blocks(nw), s); }
+    else { SearchArgs ra = make_search_args(B, big.p, nw); launch_search(ra, B->mask_words, search_blocks(nw), s); }
+    e = hipGetLastError();
+  }
+  for (size_t i = 0; i < grp.size() && e == hipSuccess; i++)
+    e = hipMemcpyAsync(&B->res_host[grp[i]], B->d_results.p + grp[i], sizeof(DevResult), hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  // put the descriptors back so the next run starts from the resident layout
+  for (size_t i = 0; i < grp.size() && e == hipSuccess; i++) {
+    e = hipMemcpyAsync(B->d_hist.p + grp[i], &hist_back[grp[i]], sizeof(Hist), hipMemcpyHostToDevice, s);
+    if (beam && e == hipSuccess) e = hipMemcpyAsync(B->d_bh.p + grp[i], &bh_back[grp[i]], sizeof(BeamHist), hipMemcpyHostToDevice, s);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  big.release(); bstack.release();
+  if (e != hipSuccess) { set_error("scratch pass failed: %s", hipGetErrorString(e)); return TBC_ERR_HIP; }
+  return TBC_OK;
+}
+
 static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results) {
   HIP_TRY(hipSetDevice(B->device));
   const uint64_t t_start = now_ns();
   const uint32_t nh = B->n_hist;
   hipStream_t s = B->stream;
+  const bool beam = B->width > 1;
+  const uint32_t KW = 1 + B->mask_words, EW = B->mask_words + 3;
 
   TRACE("run: begin");
   HIP_TRY(hipEventRecord(B->ev[0], s));
   HIP_TRY(hipMemsetAsync(B->d_bitmap.p, 0, B->d_bitmap.bytes(), s));
-  HIP_TRY(hipMemsetAsync(B->d_tab.p, 0, B->d_tab.bytes(), s));
-  HIP_TRY(hipMemsetAsync(B->d_queue.p, 0, B->d_queue.bytes(), s));
+  if (beam) {
+    HIP_TRY(hipMemsetAsync(B->d_btab.p, 0, B->d_btab.bytes(), s));
+    HIP_TRY(hipMemsetAsync(B->d_off.p, 0, B->d_off.bytes(), s));
+    HIP_TRY(hipMemsetAsync(B->d_ncr.p, 0, B->d_ncr.bytes(), s));
+    HIP_TRY(hipMemsetAsync(B->d_occ.p, 0, B->d_occ.bytes(), s));
+    HIP_TRY(hipMemcpyAsync(B->d_bh.p, B->bh.data(), nh * sizeof(BeamHist), hipMemcpyHostToDevice, s));
+  } else {
+    HIP_TRY(hipMemsetAsync(B->d_tab.p, 0, B->d_tab.bytes(), s));
+  }
   HIP_TRY(hipMemcpyAsync(B->d_hist.p, B->hist.data(), nh * sizeof(Hist), hipMemcpyHostToDevice, s));
   HIP_TRY(hipEventRecord(B->ev[1], s));
+  TRACE("run: memsets queued");
+  SYNC_TRACE("memsets");
 
   PackArgs pa{};
   pa.hist = B->d_hist.p; pa.f = B->d_f.p; pa.a = B->d_a.p; pa.b = B->d_b.p; pa.process = B->d_proc.p;
@@ -320,96 +435,110 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results) {
   pa.ret_slot = B->d_ret_slot.p; pa.ret_op = B->d_ret_op.p; pa.bitmap = B->d_bitmap.p; pa.wpre = B->d_wpre.p;
   pa.scratch = B->d_frames.p; pa.frame_words = B->frame_words; pa.n_hist = nh;
   pa.model_kind = B->model.kind; pa.n_classes = B->model.n_classes; pa.dbg = debug_words();
-  TRACE("run: memsets queued");
-  SYNC_TRACE("memsets");
   launch_pack(pa, s);
+  HIP_TRY(hipGetLastError());
+  if (beam) {
+    PackOpenArgs po{};
+    po.hist = B->d_hist.p; po.bh = B->d_bh.p; po.f = B->d_f.p; po.a = B->d_a.p; po.b = B->d_b.p; po.process = B->d_proc.p;
+    po.scratch = B->d_frames.p; po.off = B->d_off.p; po.ncr = B->d_ncr.p; po.occ = B->d_occ.p; po.lst = B->d_lst.p;
+    po.crashed = B->d_crashed.p; po.opinfo = B->d_opinfo.p; po.n_hist = nh; po.mask_words = B->mask_words;
+    launch_pack_open(po, s);
+    HIP_TRY(hipGetLastError());
+  }
   TRACE("run: pack launched");
   SYNC_TRACE("pack");
-  HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(B->ev[2], s));
 
-  SearchArgs sa = make_search_args(B, B->d_tab.p, nh);
-  if (!launch_search(sa, B->mask_words, search_blocks(nh), s)) { set_error("unsupported mask width"); return TBC_ERR_UNSUPPORTED; }
+  if (beam) {
+    BeamArgs ba = make_beam_args(B, B->d_btab.p, B->d_stack.p, nh);
+    if (!launch_beam(ba, B->mask_words, search_blocks(nh), s)) { set_error("unsupported mask width"); return TBC_ERR_UNSUPPORTED; }
+  } else {
+    SearchArgs sa = make_search_args(B, B->d_tab.p, nh);
+    if (!launch_search(sa, B->mask_words, search_blocks(nh), s)) { set_error("unsupported mask width"); return TBC_ERR_UNSUPPORTED; }
+  }
   HIP_TRY(hipGetLastError());
   TRACE("run: search launched");
   SYNC_TRACE("search");
   HIP_TRY(hipEventRecord(B->ev[3], s));
   HIP_TRY(hipMemcpyAsync(B->res_host.data(), B->d_results.p, nh * sizeof(DevResult), hipMemcpyDeviceToHost, s));
   std::vector<Hist> hist_back(nh);
+  std::vector<BeamHist> bh_back(beam ? nh : 0);
   HIP_TRY(hipMemcpyAsync(hist_back.data(), B->d_hist.p, nh * sizeof(Hist), hipMemcpyDeviceToHost, s));
+  if (beam) HIP_TRY(hipMemcpyAsync(bh_back.data(), B->d_bh.p, nh * sizeof(BeamHist), hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
-
   TRACE("run: first pass synced");
-  // ---- retries: histories whose visited set filled up get a 16x larger one
-  const uint32_t KW = 1 + B->mask_words;
+
   const uint64_t max_bytes = B->opts.max_visited_bytes ? B->opts.max_visited_bytes : (1ull << 30);
   std::vector<uint32_t> final_log2(nh);
-  for (uint32_t h = 0; h < nh; h++) final_log2[h] = B->hist[h].tab_log2;
+  std::vector<uint8_t> is_seq(nh, beam ? 0 : 1);       // which kernel owns the history's result
+  for (uint32_t h = 0; h < nh; h++) final_log2[h] = beam ? B->bh[h].tab_log2 : B->hist[h].tab_log2;
   HIP_TRY(hipEventRecord(B->ev[4], s));
+  bool touched_work = false;
+  // wide-schedule histories whose open-call lists did not fit: sequential kernel
+  if (beam) {
+    std::vector<uint32_t> fb, lg;
+    for (uint32_t h = 0; h < nh; h++)
+      if (hist_back[h].status == 0 && bh_back[h].status != 0) {
+        uint32_t l = B->hist[h].tab_log2;
+        fb.push_back(h); lg.push_back(l); final_log2[h] = l; is_seq[h] = 1;
+      }
+    if (!fb.empty()) {
+      // the sequential kernel reads Hist.status only; clear the wide-schedule flag for it
+      tbc_status st = scratch_pass(B, fb, lg, false, hist_back, bh_back);
+      if (st != TBC_OK) return st;
+      touched_work = true;
+    }
+  }
+  // overflow retries: 16x larger visited set each time, up to max_visited_bytes
+  const uint64_t arena_budget = 32ull << 30;
   for (;;) {
-    std::vector<uint32_t> pending;
+    std::vector<uint32_t> pend_seq, lg_seq, pend_beam, lg_beam;
     for (uint32_t h = 0; h < nh; h++)
       if (B->res_host[h].valid == TBC_UNKNOWN && B->res_host[h].cause == TBC_CAUSE_VISITED_FULL) {
+        const uint64_t wpe = is_seq[h] ? KW : EW;
         uint32_t lg = final_log2[h] + 4;
-        while (lg > final_log2[h] && (1ull << lg) * KW * 8 > max_bytes) lg--;
-        if (lg > final_log2[h]) pending.push_back(h);
+        while (lg > final_log2[h] && (1ull << lg) * wpe * 8 > max_bytes) lg--;
+        if (lg > final_log2[h]) {
+          if (is_seq[h]) { pend_seq.push_back(h); lg_seq.push_back(lg); }
+          else { pend_beam.push_back(h); lg_beam.push_back(lg); }
+        }
       }
-    if (pending.empty()) break;
-    // process in groups whose tables fit a 32 GiB scratch arena
-    const uint64_t arena_budget = 32ull << 30;
-    size_t pos = 0;
-    while (pos < pending.size()) {
-      std::vector<uint32_t> grp;
-      std::vector<Hist> patched;
-      uint64_t words = 0;
-      while (pos < pending.size()) {
-        const uint32_t h = pending[pos];
-        uint32_t lg = final_log2[h] + 4;
-        while ((1ull << lg) * KW * 8 > max_bytes) lg--;
-        const uint64_t need = (1ull << lg) * KW;
-        if (!grp.empty() && (words + need) * 8 > arena_budget) break;
-        Hist P = hist_back[h];
-        P.tab_off = words; P.tab_log2 = lg;
-        words += need; words = (words + 1) & ~1ull;
-        grp.push_back(h); patched.push_back(P);
-        final_log2[h] = lg;
-        pos++;
+    if (pend_seq.empty() && pend_beam.empty()) break;
+    for (int pass = 0; pass < 2; pass++) {
+      const std::vector<uint32_t>& pend = pass ? pend_beam : pend_seq;
+      const std::vector<uint32_t>& lgs = pass ? lg_beam : lg_seq;
+      const uint64_t wpe = pass ? (uint64_t)EW + 1 : KW;     // + the stack word
+      size_t pos = 0;
+      while (pos < pend.size()) {
+        std::vector<uint32_t> grp, glg;
+        uint64_t bytes = 0;
+        while (pos < pend.size()) {
+          const uint64_t need = (1ull << lgs[pos]) * wpe * 8;
+          if (!grp.empty() && bytes + need > arena_budget) break;
+          grp.push_back(pend[pos]); glg.push_back(lgs[pos]); final_log2[pend[pos]] = lgs[pos];
+          bytes += need; pos++;
+        }
+        tbc_status st = scratch_pass(B, grp, glg, pass == 1, hist_back, bh_back);
+        if (st != TBC_OK) return st;
+        touched_work = true;
       }
-      DevBuf<uint64_t> big;
-      tbc_status st = big.alloc(words);
-      if (st != TBC_OK) return st;
-      hipError_t e = hipMemsetAsync(big.p, 0, words * 8, s);
-      for (size_t i = 0; i < grp.size() && e == hipSuccess; i++)
-        e = hipMemcpyAsync(B->d_hist.p + grp[i], &patched[i], sizeof(Hist), hipMemcpyHostToDevice, s);
-      if (e == hipSuccess) e = hipMemcpyAsync(B->d_work.p, grp.data(), grp.size() * 4, hipMemcpyHostToDevice, s);
-      if (e == hipSuccess) e = hipMemsetAsync(B->d_queue.p, 0, B->d_queue.bytes(), s);
-      if (e == hipSuccess) {
-        SearchArgs ra = make_search_args(B, big.p, (uint32_t)grp.size());
-        launch_search(ra, B->mask_words, search_blocks((uint32_t)grp.size()), s);
-        e = hipGetLastError();
-      }
-      for (size_t i = 0; i < grp.size() && e == hipSuccess; i++)
-        e = hipMemcpyAsync(&B->res_host[grp[i]], B->d_results.p + grp[i], sizeof(DevResult), hipMemcpyDeviceToHost, s);
-      if (e == hipSuccess) e = hipStreamSynchronize(s);
-      big.release();
-      if (e != hipSuccess) { set_error("retry pass failed: %s", hipGetErrorString(e)); return TBC_ERR_HIP; }
     }
-    // restore the identity work list for the next run
+  }
+  if (touched_work) {   // restore the identity work list for the next run
     std::vector<uint32_t> work(nh);
     for (uint32_t h = 0; h < nh; h++) work[h] = h;
     HIP_TRY(hipMemcpyAsync(B->d_work.p, work.data(), nh * 4, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipStreamSynchronize(s));
   }
   HIP_TRY(hipEventRecord(B->ev[5], s));
   HIP_TRY(hipStreamSynchronize(s));
-
   TRACE("run: retries done");
+
   if (B->opts.want_witness) {
     B->witness_host.resize(B->total_ops ? B->total_ops : 1);
     HIP_TRY(hipMemcpy(B->witness_host.data(), B->d_witness.p, B->total_ops * 4, hipMemcpyDeviceToHost));
   }
-
   TRACE("run: witness copied");
+
   float ms;
   for (int i = 0; i < 3; i++) {
     HIP_TRY(hipEventElapsedTime(&ms, B->ev[i], B->ev[i + 1]));
@@ -417,8 +546,8 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results) {
   }
   HIP_TRY(hipEventElapsedTime(&ms, B->ev[4], B->ev[5]));
   B->timing_ns[3] = (uint64_t)(ms * 1e6);
-
   TRACE("run: timings read");
+
   std::memset(&B->sum, 0, sizeof B->sum);
   const uint64_t t_end = now_ns();
   tbc_status worst = TBC_OK;
@@ -435,7 +564,7 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results) {
     tbc_result& r = results[h];
     std::memset(&r, 0, sizeof r);
     r.valid = d.valid; r.cause = d.cause;
-    r.analyzer = TBC_ALG_WGL;
+    r.analyzer = B->opts.algorithm == TBC_ALG_LINEAR ? TBC_ALG_LINEAR : TBC_ALG_WGL;
     r.fail_op = TBC_NO_OP; r.prev_ok_op = TBC_NO_OP;
     if (d.valid == TBC_INVALID) { r.fail_op = d.fail_op; r.prev_ok_op = d.prev_ok_op; }
     if (d.valid == TBC_VALID) {

@@ -104,6 +104,75 @@ struct SearchArgs {
   uint32_t* dbg;              // optional host-mapped progress words (TBC_DEBUG=1), else null
 };
 
+// ---- wide ("beam") schedule of the search: extra per-history layout built by pack_open_kernel
+struct __attribute__((aligned(16))) OpInfo {   // indexed by op (invocation order)
+  uint32_t ret_rank;    // kInf if crashed
+  uint32_t f_slot;      // f | slot << 8
+  int32_t a, b;
+};
+static_assert(sizeof(OpInfo) == 16, "OpInfo must be 16 bytes");
+
+struct __attribute__((aligned(16))) BeamHist {
+  uint64_t off_off;     // u32 units: off[] (n_ops + 2), ncr[] at the same offset in its own arena
+  uint64_t occ_off;     // u64 units: occ[] ((n_ops + 1) * mask_words)
+  uint64_t lst_off;     // u32 units
+  uint64_t stack_off;   // u32 units (capacity = table capacity)
+  uint64_t tab_off;     // entry units
+  uint32_t lst_cap;     // entries available in lst
+  uint32_t tab_log2;
+  uint32_t n_crashed;   // pack_open: number of crashed ops
+  uint32_t status;      // pack_open: 0 ok, 1 = open lists do not fit lst_cap (use the sequential kernel)
+  uint32_t pad0, pad1;
+};
+
+struct PackOpenArgs {
+  const Hist* hist;
+  BeamHist* bh;
+  const uint8_t* f;
+  const int32_t* a;
+  const int32_t* b;
+  const int32_t* process;
+  const uint32_t* scratch;   // pack_kernel's per-op inv_rank / ret_rank (frames arena)
+  uint32_t* off;
+  uint32_t* ncr;
+  uint64_t* occ;
+  uint32_t* lst;
+  uint32_t* crashed;         // n_ops entries per history at op_off
+  OpInfo* opinfo;            // n_ops entries per history at op_off
+  uint32_t n_hist;
+  uint32_t mask_words;
+};
+
+struct BeamArgs {
+  const Hist* hist;
+  const BeamHist* bh;
+  const uint32_t* off;
+  const uint32_t* ncr;
+  const uint32_t* lst;
+  const uint32_t* crashed;
+  const OpInfo* opinfo;
+  const uint32_t* ret_slot;
+  const uint32_t* ret_op;
+  uint32_t* stack;
+  uint64_t* tab;             // entries of (4 + mask_words) u64 words: k0, M[], {owner, parent}, {op, pad}
+  DevResult* results;
+  uint32_t* witness;         // n_ops per history at op_off, may be null
+  const uint32_t* work;
+  const uint16_t* table;
+  uint32_t n_work;
+  uint32_t model_kind;
+  int32_t init_state;
+  uint32_t n_classes;
+  uint32_t width;            // K: configs taken off the stack per iteration (1..16)
+  uint32_t pad;
+  uint64_t max_steps;
+  uint64_t time_limit_ticks;
+  uint32_t* dbg;
+};
+
+void launch_pack_open(const PackOpenArgs& a, void* stream);
+bool launch_beam(const BeamArgs& a, uint32_t mask_words, uint32_t n_blocks, void* stream);
+
 // kernel launchers (defined in the .hip files)
 void launch_pack(const PackArgs& a, void* stream);
 // returns false if mw is unsupported

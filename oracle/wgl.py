@@ -33,7 +33,7 @@ class OracleResult(C.Structure):
 
 def build(force: bool = False) -> str:
     so = os.path.join(_HERE, "liboracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("wgl_ref.c", "wgl_window.c", "linear_ref.c", "oracle_model.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("wgl_ref.c", "wgl_window.c", "linear_ref.c", "wgl_beam.c", "oracle_model.h")]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s", "liboracle.so"])
     return so
@@ -43,7 +43,7 @@ def lib():
     global _LIB
     if _LIB is None:
         _LIB = C.CDLL(build())
-        for fn in (_LIB.wgl_ref_check, _LIB.wgl_window_check, _LIB.linear_ref_check):
+        for fn in (_LIB.wgl_ref_check, _LIB.wgl_window_check, _LIB.linear_ref_check, _LIB.wgl_beam_check):
             fn.restype = C.c_int
     return _LIB
 
@@ -128,5 +128,35 @@ def check_linear(ops, model, max_configs=0, max_final=4096):
     cfg[:, 0] -= 1          # state word is stored +1
     out["configs"] = cfg
     for name, _ in LinearStats._fields_:
+        out[name] = getattr(st, name)
+    return out
+
+
+class BeamStats(C.Structure):
+    _fields_ = [("iterations", C.c_uint64), ("probes", C.c_uint64), ("visited", C.c_uint64),
+                ("expanded", C.c_uint64), ("max_stack", C.c_uint64), ("rounds", C.c_uint64)]
+
+
+def check_beam(ops, model, width=16, max_probes=0, want_witness=True):
+    """The wide (K configs per iteration) schedule of the same search: wgl_beam.c."""
+    n = len(ops["f"])
+    f = np.ascontiguousarray(ops["f"], np.uint8)
+    a = np.ascontiguousarray(ops["a"], np.int32)
+    b = np.ascontiguousarray(ops["b"], np.int32)
+    inv = np.ascontiguousarray(ops["inv_pos"], np.uint32)
+    ret = np.ascontiguousarray(ops["ret_pos"], np.uint32)
+    proc = np.ascontiguousarray(ops["process"], np.int32)
+    m, keep = _model(model)
+    res, st = OracleResult(), BeamStats()
+    wit = np.zeros(max(n, 1), np.uint32)
+    rc = lib().wgl_beam_check(C.c_uint32(n), _p(f, C.c_uint8), _p(a, C.c_int32), _p(b, C.c_int32),
+                              _p(proc, C.c_int32), C.c_uint32(int(ops["n_process"])), _p(inv, C.c_uint32),
+                              _p(ret, C.c_uint32), C.byref(m), C.c_uint32(width), C.c_uint64(max_probes),
+                              _p(wit, C.c_uint32), C.byref(res), C.byref(st))
+    if rc != 0:
+        raise ValueError(f"oracle rejected history (rc={rc})")
+    out = {k: getattr(res, k) for k, _ in OracleResult._fields_}
+    out["witness"] = wit[:res.n_witness].copy() if (res.valid == 1 and want_witness) else None
+    for name, _ in BeamStats._fields_:
         out[name] = getattr(st, name)
     return out

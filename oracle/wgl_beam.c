@@ -1,0 +1,258 @@
+/*
+ * TEST INFRASTRUCTURE -- NOT PRODUCT CODE (see oracle_model.h for the rules
+ * and the PARITY UNPINNED statement).
+ *
+ * wgl_beam.c -- scalar CPU restatement of the WIDE schedule of the Wing-Gong/
+ * Lowe search that jepsen-tigerbeetle_amd/csrc/wgl_beam.hip runs: the same
+ * search space and the same memoisation as wgl_ref.c / wgl_window.c
+ * (configs = (front, mask, state), exact visited set), but instead of one
+ * config per step it takes the K most recent configs off an explicit stack,
+ * expands ALL their successors at once and pushes the new ones (so the most
+ * recent config's first successor is on top: depth-first in spirit, K wide).
+ * The verdict and the failing op are properties of (model, history) and are
+ * the same as the sequential search's; the witness and the counters are those
+ * of THIS schedule, which is fully deterministic and specified here:
+ *
+ *   open(F)  = live ops with inv_rank <= F <= ret_rank in order of process slot,
+ *              then crashed ops with inv_rank <= F in invocation order.
+ *   iteration: pop np = min(K, |stack|) configs P_0 (top) .. P_{np-1};
+ *     pairs are enumerated parent-bottom-first (P_{np-1} .. P_0), and within a
+ *     parent from its LAST open op to its first; pair number r = 0, 1, ...;
+ *     pairs are processed in rounds of 64 consecutive r:
+ *       - a pair is viable if its op is not yet linearized in the parent and
+ *         the model accepts it; its child config is computed as in WGL
+ *         (linearize; if it was the front's own op the front moves past every
+ *         completion already linearized);
+ *       - if any child of the round has passed every completion the search
+ *         ends VALID with the lowest such r (nothing of that round is
+ *         inserted);
+ *       - otherwise, in ascending r, each viable pair probes the visited set;
+ *         a child that is new is inserted (remembering parent and op) and
+ *         pushed.
+ *   empty stack  =>  INVALID; the failing op is the completion of the greatest
+ *   front ever inserted (the first completion whose prefix cannot be
+ *   linearized), as in wgl_ref.c.
+ *
+ * Counters: probes = viable pairs of completed rounds, visited = configs
+ * inserted (root included), expanded = configs popped, iterations,
+ * max_stack.
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include "oracle_model.h"
+
+typedef struct { uint32_t pos, op; } posop;
+static int cmp_posop(const void* x, const void* y) {
+  uint32_t a = ((const posop*)x)->pos, b = ((const posop*)y)->pos;
+  return a < b ? -1 : a > b;
+}
+static uint64_t mix64(uint64_t x) {
+  x ^= x >> 33; x *= 0xFF51AFD7ED558CCDull;
+  x ^= x >> 33; x *= 0xC4CEB9FE1A85EC53ull;
+  x ^= x >> 33; return x;
+}
+
+typedef struct beam_stats {
+  uint64_t iterations, probes, visited, expanded, max_stack, rounds;
+} beam_stats;
+
+/* arena of configs: kw words key + parent + op; index 0 unused */
+typedef struct {
+  uint64_t* keys; uint32_t* parent; uint32_t* op; size_t n, cap, kw;
+  uint32_t* slots; size_t nslots;
+} arena;
+
+static uint64_t key_hash(const uint64_t* k, size_t kw) {
+  uint64_t h = mix64(k[0]);
+  for (size_t i = 1; i < kw; i++) h = mix64(h ^ k[i]) + 0x9E3779B97F4A7C15ull;
+  return h;
+}
+static void arena_rehash(arena* a) {
+  size_t ns = a->nslots * 2;
+  uint32_t* s = (uint32_t*)calloc(ns, 4);
+  for (size_t i = 1; i < a->n; i++) {
+    size_t j = key_hash(a->keys + i * a->kw, a->kw) & (ns - 1);
+    while (s[j]) j = (j + 1) & (ns - 1);
+    s[j] = (uint32_t)i;
+  }
+  free(a->slots); a->slots = s; a->nslots = ns;
+}
+/* returns new index if inserted, 0 if present */
+static uint32_t arena_add(arena* a, const uint64_t* k, uint32_t parent, uint32_t op) {
+  size_t j = key_hash(k, a->kw) & (a->nslots - 1);
+  while (a->slots[j]) {
+    if (memcmp(a->keys + (size_t)a->slots[j] * a->kw, k, a->kw * 8) == 0) return 0;
+    j = (j + 1) & (a->nslots - 1);
+  }
+  if (a->n == a->cap) {
+    a->cap *= 2;
+    a->keys = (uint64_t*)realloc(a->keys, a->cap * a->kw * 8);
+    a->parent = (uint32_t*)realloc(a->parent, a->cap * 4);
+    a->op = (uint32_t*)realloc(a->op, a->cap * 4);
+  }
+  uint32_t id = (uint32_t)a->n++;
+  memcpy(a->keys + (size_t)id * a->kw, k, a->kw * 8);
+  a->parent[id] = parent; a->op[id] = op;
+  a->slots[j] = id;
+  if (a->n * 2 > a->nslots) arena_rehash(a);
+  return id;
+}
+
+int wgl_beam_check(uint32_t n, const uint8_t* f, const int32_t* a, const int32_t* b,
+                   const int32_t* process, uint32_t n_process,
+                   const uint32_t* inv_pos, const uint32_t* ret_pos,
+                   const oracle_model* model, uint32_t K, uint64_t max_probes,
+                   uint32_t* witness, oracle_result* out, beam_stats* st) {
+  memset(out, 0, sizeof *out); memset(st, 0, sizeof *st);
+  out->fail_op = out->prev_ok_op = 0xFFFFFFFFu;
+  if (K == 0 || K > 64) return 1;
+  uint32_t R = 0;
+  for (uint32_t i = 0; i < n; i++) {
+    if (i && inv_pos[i] <= inv_pos[i - 1]) return 2;
+    if (process[i] < 0 || (uint32_t)process[i] >= n_process) return 2;
+    if (ret_pos[i] != O_CRASHED) { if (ret_pos[i] <= inv_pos[i]) return 2; R++; }
+  }
+  if (R == 0) { out->valid = 1; out->final_state = model->init; return 0; }
+  const uint32_t W = n_process, MW = (W + 63) / 64, KW = 1 + MW;
+
+  posop* rets = (posop*)malloc(sizeof(posop) * R);
+  uint32_t* ret_rank = (uint32_t*)malloc(4 * n);
+  uint32_t* inv_rank = (uint32_t*)malloc(4 * n);
+  uint32_t* ret_op = (uint32_t*)malloc(4 * R);
+  uint32_t k = 0;
+  for (uint32_t i = 0; i < n; i++) if (ret_pos[i] != O_CRASHED) { rets[k].pos = ret_pos[i]; rets[k].op = i; k++; }
+  qsort(rets, R, sizeof(posop), cmp_posop);
+  for (uint32_t r = 0; r < R; r++) { ret_rank[rets[r].op] = r; ret_op[r] = rets[r].op; }
+  { uint32_t r = 0;
+    for (uint32_t i = 0; i < n; i++) { while (r < R && rets[r].pos < inv_pos[i]) r++; inv_rank[i] = r; } }
+  for (uint32_t i = 0; i < n; i++) if (ret_pos[i] == O_CRASHED) ret_rank[i] = 0xFFFFFFFFu;
+
+  /* open lists: CSR of live ops per front; crashed ops as one list + count per front */
+  uint32_t* off = (uint32_t*)calloc((size_t)R + 1, 4);
+  uint32_t* ncr = (uint32_t*)calloc((size_t)R + 1, 4);   /* crashed ops with inv_rank <= F */
+  uint32_t n_crashed = 0;
+  for (uint32_t i = 0; i < n; i++) {
+    if (ret_rank[i] == 0xFFFFFFFFu) { n_crashed++; if (inv_rank[i] < R) ncr[inv_rank[i]]++; continue; }
+    for (uint32_t fr = inv_rank[i]; fr <= ret_rank[i]; fr++) off[fr + 1]++;
+  }
+  for (uint32_t r = 0; r < R; r++) off[r + 1] += off[r];
+  for (uint32_t r = 1; r < R; r++) ncr[r] += ncr[r - 1];
+  uint32_t* lst = (uint32_t*)malloc(4 * ((size_t)off[R] + 1));
+  uint32_t* fill = (uint32_t*)malloc(4 * ((size_t)R + 1));
+  memcpy(fill, off, 4 * ((size_t)R + 1));
+  uint32_t* crashed = (uint32_t*)malloc(4 * ((size_t)n_crashed + 1));
+  { uint32_t c = 0;
+    for (uint32_t i = 0; i < n; i++) {
+      if (ret_rank[i] == 0xFFFFFFFFu) { crashed[c++] = i; continue; }
+      for (uint32_t fr = inv_rank[i]; fr <= ret_rank[i]; fr++) lst[fill[fr]++] = i;
+    }
+    for (uint32_t fr = 0; fr < R; fr++)          /* each front's live list in process-slot order */
+      for (uint32_t x = off[fr] + 1; x < off[fr + 1]; x++) {
+        uint32_t v = lst[x], y = x;
+        while (y > off[fr] && process[lst[y - 1]] > process[v]) { lst[y] = lst[y - 1]; y--; }
+        lst[y] = v;
+      } }
+
+  arena ar; ar.kw = KW; ar.cap = 4096; ar.n = 1; ar.nslots = 8192;
+  ar.keys = (uint64_t*)calloc(ar.cap * KW, 8); ar.parent = (uint32_t*)calloc(ar.cap, 4); ar.op = (uint32_t*)calloc(ar.cap, 4);
+  ar.slots = (uint32_t*)calloc(ar.nslots, 4);
+  size_t scap = 1 << 16, sp = 0;
+  uint32_t* stack = (uint32_t*)malloc(scap * 4);
+  uint64_t* key = (uint64_t*)calloc(KW, 8);
+  key[0] = 1ull | ((uint64_t)(uint32_t)model->init << 32);
+  stack[sp++] = arena_add(&ar, key, 0, 0xFFFFFFFFu);
+  st->visited = 1; st->max_stack = 1;
+  uint32_t maxf = 0;
+  int verdict = -2;
+  uint32_t win_parent = 0, win_op = 0; int32_t win_state = 0;
+
+  uint32_t par[64], pcnt[64], pstart[65];
+  /* per-round scratch */
+  uint64_t* ck = (uint64_t*)malloc(64 * KW * 8);
+  uint32_t cop[64], cpar[64]; int cviable[64]; uint32_t cfront[64]; int32_t cstate[64];
+
+  while (verdict == -2) {
+    if (sp == 0) { verdict = 0; break; }
+    uint32_t np = sp < K ? (uint32_t)sp : K;
+    for (uint32_t q = 0; q < np; q++) par[q] = stack[sp - np + q];      /* q = 0 is the bottom-most popped */
+    sp -= np;
+    st->iterations++; st->expanded += np;
+    uint32_t T = 0;
+    for (uint32_t q = 0; q < np; q++) {
+      uint32_t fi = (uint32_t)ar.keys[(size_t)par[q] * KW] - 1;
+      pcnt[q] = (off[fi + 1] - off[fi]) + ncr[fi];
+      pstart[q] = T; T += pcnt[q];
+    }
+    pstart[np] = T;
+    for (uint32_t base = 0; base < T && verdict == -2; base += 64) {
+      uint32_t m = T - base < 64 ? T - base : 64;
+      int success = -1;
+      for (uint32_t l = 0; l < m; l++) {
+        uint32_t r = base + l, q = 0;
+        while (pstart[q + 1] <= r) q++;
+        const uint64_t* pk = ar.keys + (size_t)par[q] * KW;
+        uint32_t fi = (uint32_t)pk[0] - 1; int32_t s = (int32_t)(pk[0] >> 32);
+        uint32_t nlive = off[fi + 1] - off[fi];
+        uint32_t c = pcnt[q] - 1 - (r - pstart[q]);
+        uint32_t op = c < nlive ? lst[off[fi] + c] : crashed[c - nlive];
+        uint32_t p = (uint32_t)process[op];
+        cviable[l] = 0; cop[l] = op; cpar[l] = par[q];
+        if (pk[1 + (p >> 6)] >> (p & 63) & 1) continue;
+        int32_t s2;
+        if (!oracle_step(model, s, f[op], a[op], b[op], &s2)) continue;
+        uint64_t* c2 = ck + (size_t)l * KW;
+        memcpy(c2, pk, KW * 8);
+        c2[1 + (p >> 6)] |= 1ull << (p & 63);
+        uint32_t fi2 = fi;
+        if (ret_rank[op] == fi) {
+          uint32_t pp = p;
+          for (;;) {
+            c2[1 + (pp >> 6)] &= ~(1ull << (pp & 63));
+            fi2++;
+            if (fi2 == R) break;
+            pp = (uint32_t)process[ret_op[fi2]];
+            if (!(c2[1 + (pp >> 6)] >> (pp & 63) & 1)) break;
+          }
+        }
+        c2[0] = (uint64_t)(fi2 + 1) | ((uint64_t)(uint32_t)s2 << 32);
+        cviable[l] = 1; cfront[l] = fi2; cstate[l] = s2;
+        if (fi2 == R && success < 0) success = (int)l;
+      }
+      st->rounds++;
+      if (success >= 0) { verdict = 1; win_parent = cpar[success]; win_op = cop[success]; win_state = cstate[success]; break; }
+      for (uint32_t l = 0; l < m; l++) {
+        if (!cviable[l]) continue;
+        st->probes++;
+        uint32_t id = arena_add(&ar, ck + (size_t)l * KW, cpar[l], cop[l]);
+        if (!id) continue;
+        st->visited++;
+        if (cfront[l] > maxf) maxf = cfront[l];
+        if (sp == scap) { scap *= 2; stack = (uint32_t*)realloc(stack, scap * 4); }
+        stack[sp++] = id;
+      }
+      if (max_probes && st->probes > max_probes) { verdict = -1; break; }
+    }
+    if (sp > st->max_stack) st->max_stack = sp;
+  }
+
+  out->valid = verdict;
+  out->steps = st->probes; out->probes = st->probes; out->visited = st->visited;
+  out->backtracks = st->expanded; out->max_depth = st->max_stack;
+  if (verdict == 1) {
+    /* witness: path root -> win_parent, then win_op */
+    uint32_t len = 1, id = win_parent;
+    while (ar.parent[id]) { len++; id = ar.parent[id]; }
+    out->n_witness = len; out->final_state = win_state;
+    if (witness) {
+      uint32_t w = len - 1; witness[w] = win_op; id = win_parent;
+      while (ar.parent[id]) { witness[--w] = ar.op[id]; id = ar.parent[id]; }
+    }
+  } else if (verdict == 0) {
+    out->fail_op = ret_op[maxf];
+    out->prev_ok_op = maxf ? ret_op[maxf - 1] : 0xFFFFFFFFu;
+  }
+  free(rets); free(ret_rank); free(inv_rank); free(ret_op); free(off); free(ncr); free(lst); free(fill); free(crashed);
+  free(ar.keys); free(ar.parent); free(ar.op); free(ar.slots); free(stack); free(key); free(ck);
+  return 0;
+}
