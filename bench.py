@@ -10,7 +10,7 @@
              max-over-ranks clock only); histories are independent units, so they
              are sharded across ranks with NO data-path collective -- weak scaling
              (B per GPU fixed)
-  roofline : wgl_search_kernel, HBM bound.  achieved = algorithmic bytes per launch
+  roofline : the search kernel (wgl_beam_kernel, or wgl_search_kernel at --width 1), HBM bound.  achieved = algorithmic bytes per launch
              (16 B per visited-set probe that finds a duplicate,
              32 B per probe that inserts a new config) / the kernel's average
              duration, measured with HIP events on the library's own stream
@@ -45,6 +45,8 @@ def main():
     ap.add_argument("--busy", type=float, default=0.1,
                     help="fraction of time a process has an op open (64 x 0.1 = 6.4 ops in flight on average)")
     ap.add_argument("--info", type=float, default=0.0, help="crashed-op (:info) rate")
+    ap.add_argument("--width", type=int, default=int(os.environ.get("TBC_BENCH_WIDTH", "8")),
+                    help="configs expanded per iteration: 1 = sequential knossos.wgl order, 2..16 = wide schedule")
     ap.add_argument("--cpu-sample", type=int, default=256, help="histories timed on the CPU oracle (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
@@ -82,7 +84,8 @@ def main():
         for i in range(B)]
     t_gen = time.time() - t_gen
     model = core.make_model(N.MODEL_CAS_REGISTER, N.NIL)
-    opts = core.make_opts(device=local_rank, time_limit_ms=600000, want_witness=False)
+    opts = core.make_opts(device=local_rank, time_limit_ms=600000, want_witness=False,
+                          algorithm=N.ALG_COMPETITION, search_width=args.width)
     batch = core.Batch(hists, model, opts)        # H2D happens here: inputs resident before timing
 
     for _ in range(args.warmup):
@@ -127,10 +130,11 @@ def main():
             "dtype": "u64", "data": "synthetic",
             "config": {"workload": WORKLOAD, "histories_per_gpu": B, "ops_after_pairing": int(batch.total_ops // B),
                        "processes": args.procs, "busy": args.busy, "info_rate": args.info,
+                       "search_width": args.width,
                        "parallelism": f"independent histories sharded over {world} GPU(s), no collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
-                         "kernel": "wgl_search_kernel", "kernel_ms": round(k_ms, 3),
+                         "kernel": "wgl_search_kernel" if args.width == 1 else "wgl_beam_kernel", "kernel_ms": round(k_ms, 3),
                          "probes_per_launch": counters["probes"], "new_configs_per_launch": counters["visited"],
                          "algorithmic_bytes_per_launch": alg_bytes},
             "extra": {"valid": n_valid, "unknown": n_unknown,
@@ -143,11 +147,13 @@ def main():
         # time-to-verdict for ONE history through tbc_check (H2D + kernels + D2H), rank 0
         ttv = []
         for i in range(min(5, B)):
-            r = core.check_ops(hists[i], model, core.make_opts(device=local_rank, want_witness=True))
+            r = core.check_ops(hists[i], model, core.make_opts(device=local_rank, want_witness=True,
+                                                               algorithm=N.ALG_COMPETITION, search_width=args.width))
             ttv.append(r["ns_total"] / 1e6)
         bad = columns.pair_events(synth.register_events(n_ops=args.ops, n_procs=args.procs, seed=12345, busy=args.busy / 2,
                                                         info=args.info, corrupt=0.7))
-        rb = core.check_ops(bad, model, core.make_opts(device=local_rank, time_limit_ms=120000))
+        rb = core.check_ops(bad, model, core.make_opts(device=local_rank, time_limit_ms=120000,
+                                                       algorithm=N.ALG_COMPETITION, search_width=args.width))
         line["extra"]["time_to_verdict_ms"] = {"valid_median": round(statistics.median(ttv), 3),
                                                "invalid_example": round(rb["ns_total"] / 1e6, 3),
                                                "invalid_example_verdict": rb["valid"], "invalid_example_steps": rb["steps"]}

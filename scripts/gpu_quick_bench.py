@@ -7,13 +7,15 @@ from jepsen_tigerbeetle_amd import _native as N, columns, core, synth
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 n_ops = int(sys.argv[2]) if len(sys.argv) > 2 else 10000
-uniq = 32
+uniq = 64
+W = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+VPO = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 t = time.time()
 base = [columns.pair_events(synth.register_events(n_ops=n_ops, n_procs=64, seed=s, busy=0.1, info=0.0)) for s in range(uniq)]
 hists = [base[i % uniq] for i in range(B)]
 print(f"gen {time.time()-t:.2f}s ops/hist={len(base[0])}", flush=True)
 gm = core.make_model(N.MODEL_CAS_REGISTER, N.NIL)
-with core.Batch(hists, gm, core.make_opts(time_limit_ms=120000, want_witness=False)) as b:
+with core.Batch(hists, gm, core.make_opts(time_limit_ms=120000, want_witness=False, search_width=W, algorithm=N.ALG_COMPETITION, visited_per_op=VPO)) as b:
     print("device MB", b.device_bytes() / 1e6, flush=True)
     for it in range(3):
         t = time.time(); b.run(); dt = time.time() - t

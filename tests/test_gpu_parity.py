@@ -22,6 +22,9 @@ def gm():
     return core.make_model(N.MODEL_CAS_REGISTER, N.NIL)
 
 
+SEQ = dict(algorithm=N.ALG_WGL)   # the sequential knossos.wgl order (search_width 1)
+
+
 def assert_same(got, exp, tag=""):
     assert got["valid"] == exp["valid"], (tag, got["valid"], exp["valid"])
     if exp["valid"] == 0:
@@ -60,6 +63,47 @@ def test_single_history_matches_oracle(native, oracle, n_ops, procs, info, corru
             continue
         got = core.check_ops(ops, gm(), core.make_opts(time_limit_ms=30000))
         assert_same(got, exp, f"seed{seed}")
+
+
+@pytest.mark.parametrize("width", [2, 8, 16])
+def test_wide_schedule_matches_its_oracle(native, oracle, width):
+    """search_width > 1: the (config, open call)-pair-per-lane kernel against oracle/wgl_beam.c --
+    verdict, failing op, witness, final state and counters, bit for bit; and the verdict /
+    failing op also against the sequential oracle (they are properties of the history)."""
+    cases = [(8, 3, 0.1, 0.5, 0.8), (40, 4, 0.05, 0.0, 0.5), (200, 8, 0.02, 0.0, 0.5), (200, 8, 0.0, 0.6, 0.3),
+             (1000, 16, 0.02, 0.0, 0.5), (1000, 16, 0.0, 0.6, 0.2), (3000, 64, 0.02, 0.0, 0.1), (3000, 64, 0.0, 0.6, 0.05)]
+    hists = [columns.pair_events(synth.register_events(n_ops=n, n_procs=p, seed=s, busy=busy, info=info, corrupt=corrupt))
+             for (n, p, info, corrupt, busy) in cases for s in range(3)]
+    opts = core.make_opts(time_limit_ms=60000, search_width=width, algorithm=N.ALG_COMPETITION)
+    with core.Batch(hists, gm(), opts) as b:
+        res = b.run().results()
+    single = core.check_ops(hists[5], gm(), opts)
+    for i, (h, got) in enumerate(zip(hists, res)):
+        exp = oracle.check_beam(h.as_dict(), CAS, width)
+        seq = oracle.check(h.as_dict(), CAS, "window", max_steps=5_000_000, want_witness=False)
+        assert got["valid"] == exp["valid"], i
+        if seq["valid"] != -1:
+            assert got["valid"] == seq["valid"], i
+        if exp["valid"] == 0:
+            assert got["fail_op"] == exp["fail_op"] == seq["fail_op"], i
+            assert got["prev_ok_op"] == (None if exp["prev_ok_op"] == N.NO_OP else exp["prev_ok_op"]), i
+        if exp["valid"] == 1:
+            assert got["final_state"] == exp["final_state"], i
+            assert np.array_equal(got["witness"], exp["witness"]), i
+            assert brute.check_witness(CAS, op_tuples(h), [int(x) for x in got["witness"]]) == got["final_state"]
+        assert (got["probes"], got["visited"], got["backtracks"], got["max_depth"]) == \
+               (exp["probes"], exp["visited"], exp["expanded"], exp["max_stack"]), i
+    assert single["valid"] == res[5]["valid"] and single["probes"] == res[5]["probes"]
+
+
+def test_wide_schedule_overflow_retry_and_default_algorithm(native, oracle):
+    ops = columns.pair_events(synth.register_events(n_ops=1000, n_procs=16, seed=1, busy=0.5, info=0.01, corrupt=0.5))
+    exp = oracle.check_beam(ops.as_dict(), CAS, 16)
+    got = core.check_ops(ops, gm(), core.make_opts(time_limit_ms=60000, algorithm=N.ALG_COMPETITION, visited_per_op=4))
+    assert got["valid"] == exp["valid"] == 0 and got["fail_op"] == exp["fail_op"]
+    assert got["visited"] == exp["visited"] and got["table_slots"] > 16 * len(ops)
+    small = core.check_ops(ops, gm(), core.make_opts(algorithm=N.ALG_LINEAR, max_visited_bytes=64 * 1024))
+    assert small["valid"] == N.UNKNOWN and small["cause"] == N.CAUSE_VISITED_FULL
 
 
 def test_batch_matches_oracle_and_single(native, oracle):
@@ -112,18 +156,22 @@ def test_step_limit_gives_unknown(native):
 def test_full_size_properties_10k_ops_64_procs(native, oracle):
     """BASELINE.json config 2 shape.  Size-independent properties + the oracle."""
     for seed, info in ((0, 0.0), (1, 0.01)):
-        ops = columns.pair_events(synth.register_events(n_ops=10000, n_procs=64, seed=seed, busy=0.5, info=info))
+        ops = columns.pair_events(synth.register_events(n_ops=10000, n_procs=64, seed=seed, busy=0.1, info=info))
         got = core.check_ops(ops, gm(), core.make_opts(time_limit_ms=60000))
         assert got["valid"] == N.VALID       # linearizable by construction
+        wide = core.check_ops(ops, gm(), core.make_opts(time_limit_ms=60000, algorithm=N.ALG_COMPETITION))
+        assert wide["valid"] == N.VALID
+        assert brute.check_witness(CAS, op_tuples(ops), [int(x) for x in wide["witness"]]) == wide["final_state"]
         tup = op_tuples(ops)
         assert brute.check_witness(CAS, tup, [int(x) for x in got["witness"]]) == got["final_state"]
         assert_same(got, oracle.check(ops.as_dict(), CAS, "window"))
     # one corrupted read => not linearizable, and the op reported is that read
     ev = synth.register_events(n_ops=10000, n_procs=64, seed=5, busy=0.04, info=0.0, corrupt=0.7)
     ops = columns.pair_events(ev)
-    got = core.check_ops(ops, gm(), core.make_opts(time_limit_ms=60000))
-    assert got["valid"] == N.INVALID
-    assert ops.a[got["fail_op"]] == 5 + 7    # the impossible value the generator planted
+    for alg in (N.ALG_WGL, N.ALG_COMPETITION):
+        got = core.check_ops(ops, gm(), core.make_opts(time_limit_ms=60000, algorithm=alg))
+        assert got["valid"] == N.INVALID
+        assert ops.a[got["fail_op"]] == 5 + 7    # the impossible value the generator planted
 
 
 def test_rejects_malformed_ops(native):
