@@ -196,7 +196,7 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
   if (B->mask_words > 4) width = 1;          // very wide windows: sequential kernel only
   B->width = width;
   const bool beam = width > 1;
-  const uint32_t EW = B->mask_words + 3;     // u64 words per wide-schedule entry
+  const uint32_t EW = B->mask_words + 2;     // u64 words per wide-schedule entry
 
   const uint64_t default_cap_bytes = 1ull << 30;
   const uint64_t max_bytes = opts->max_visited_bytes ? opts->max_visited_bytes : default_cap_bytes;
@@ -358,7 +358,7 @@ static BeamArgs make_beam_args(tbc_batch* B, uint64_t* tab, uint32_t* stack, uin
 static tbc_status scratch_pass(tbc_batch* B, const std::vector<uint32_t>& grp, const std::vector<uint32_t>& lg,
                                bool beam, const std::vector<Hist>& hist_back, const std::vector<BeamHist>& bh_back) {
   hipStream_t s = B->stream;
-  const uint32_t KW = 1 + B->mask_words, EW = B->mask_words + 3;
+  const uint32_t KW = 1 + B->mask_words, EW = B->mask_words + 2;
   const uint64_t words_per_entry = beam ? EW : KW;
   uint64_t entries = 0;
   std::vector<Hist> ph(grp.size());
@@ -410,7 +410,7 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results) {
   const uint32_t nh = B->n_hist;
   hipStream_t s = B->stream;
   const bool beam = B->width > 1;
-  const uint32_t KW = 1 + B->mask_words, EW = B->mask_words + 3;
+  const uint32_t KW = 1 + B->mask_words, EW = B->mask_words + 2;
 
   TRACE("run: begin");
   HIP_TRY(hipEventRecord(B->ev[0], s));

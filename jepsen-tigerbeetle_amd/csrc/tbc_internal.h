@@ -154,7 +154,7 @@ struct BeamArgs {
   const uint32_t* ret_slot;
   const uint32_t* ret_op;
   uint32_t* stack;
-  uint64_t* tab;             // entries of (4 + mask_words) u64 words: k0, M[], {owner, parent}, {op, pad}
+  uint64_t* tab;             // entries of (2 + mask_words) u64 words: k0, M[], {parent | op << 32}
   DevResult* results;
   uint32_t* witness;         // n_ops per history at op_off, may be null
   const uint32_t* work;

@@ -23,12 +23,14 @@
 //
 // The schedule is deterministic and specified in oracle/wgl_beam.c, which
 // tests/ compare bit-for-bit (verdict, failing op, witness, counters):
-// duplicates inside a round are resolved in favour of the lowest lane through
-// an epoch-tagged owner word (atomicMax), everything else follows program
-// order of one wavefront.
+// lanes that produce one and the same new config in a round are found by their
+// common table slot (equal keys probe in lockstep, so exactly one of them wins
+// the CAS and the others lose it on that very slot) and the lowest lane keeps
+// the config; everything else follows program order of one wavefront.
 //
 // Visited-set entry (MW = mask words): k0 = front+1 | state<<32, M[MW],
-// {owner tag, parent entry}, {op, 0}: 32 B at MW = 1.  A history is owned by
+// {parent entry | op<<32}: 24 B at MW = 1.  The 16 most recent pushes are
+// mirrored in an LDS ring so the next iteration's parents come from LDS.  A history is owned by
 // one wavefront; entries are read/written with agent-scope (sc1) accesses so
 // a lane never sees a stale L1 line of an entry another lane just claimed.
 #include <hip/hip_runtime.h>
@@ -53,11 +55,12 @@ __device__ __forceinline__ uint32_t ld32(const uint32_t* p) {
 }
 
 // LDS words per wave: p_k0[16] u64, p_M[16*MW] u64, then 5 x 16 u32 + start[17]
-__host__ __device__ constexpr uint32_t beam_lds_words(uint32_t mw) { return 2 * 16 + 2 * 16 * mw + 16 * 5 + 20; }
+// + ring of the 16 most recent pushes: pos[16], idx[16], k0[16] u64, M[16*MW] u64
+__host__ __device__ constexpr uint32_t beam_lds_words(uint32_t mw) { return 2 * 16 + 2 * 16 * mw + 16 * 5 + 20 + 32 + 2 * 16 + 2 * 16 * mw; }
 
 template <int MW>
 __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, const uint32_t lane) {
-  constexpr uint32_t EW = MW + 3;   // u64 words per entry
+  constexpr uint32_t EW = MW + 2;   // u64 words per entry
 
   const Hist* H = A.hist + hidx;
   const BeamHist* B = A.bh + hidx;
@@ -87,10 +90,15 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
   uint32_t* p_off = p_cnt + 16;
   uint32_t* p_nlive = p_off + 16;
   uint32_t* p_fi = p_nlive + 16;
-  uint32_t* p_start = p_fi + 16;     // 17 entries
+  uint32_t* p_start = p_fi + 16;     // 17 entries (20 reserved)
+  uint32_t* r_pos = p_start + 20;    // ring: stack position mirrored in this slot (kNone = empty)
+  uint32_t* r_idx = r_pos + 16;
+  uint64_t* r_k0 = reinterpret_cast<uint64_t*>(r_idx + 16);
+  uint64_t* r_M = r_k0 + 16;
+  if (lane < 16) r_pos[lane] = kNone;
 
   uint64_t probes = 0, visited = 0, expanded = 0, iterations = 0, rounds = 0, max_stack = 0;
-  uint32_t sp = 0, lane_maxf = 0, epoch = 0;
+  uint32_t sp = 0, lane_maxf = 0;
   int32_t verdict = -2, cause = TBC_CAUSE_NONE;
   uint32_t win_parent = kNone, win_op = kNone;
   int32_t win_state = A.init_state;
@@ -110,8 +118,7 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
       st64(e + 0, k0);
 #pragma unroll
       for (int j = 0; j < MW; j++) st64(e + 1 + j, 0ull);
-      st64(e + 1 + MW, (uint64_t)0u | ((uint64_t)kNone << 32));
-      st64(e + 2 + MW, (uint64_t)kNone);
+      st64(e + 1 + MW, (uint64_t)kNone | ((uint64_t)kNone << 32));
       stack[0] = (uint32_t)idx;
     }
     sp = 1; visited = 1; max_stack = 1;
@@ -120,15 +127,25 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
   while (verdict == -2) {
     if (sp == 0) { verdict = TBC_INVALID; break; }
     const uint32_t np = min(K, sp);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     // ---- pop the np most recent configs (lane q = q-th from the bottom of the popped run)
     uint32_t my_cnt = 0;
     if (lane < np) {
-      const uint32_t idx = ld32(stack + (sp - np + lane));
-      const uint64_t* e = tab + (uint64_t)idx * EW;
-      const uint64_t k0 = ld64(e);
-      p_k0[lane] = k0;
+      const uint32_t spos = sp - np + lane;
+      uint32_t idx; uint64_t k0;
+      if (r_pos[spos & 15u] == spos) {          // pushed recently: config still in the LDS ring
+        idx = r_idx[spos & 15u]; k0 = r_k0[spos & 15u];
 #pragma unroll
-      for (int j = 0; j < MW; j++) p_M[lane * MW + j] = ld64(e + 1 + j);
+        for (int j = 0; j < MW; j++) p_M[lane * MW + j] = r_M[(spos & 15u) * MW + j];
+      } else {
+        idx = ld32(stack + spos);
+        const uint64_t* e = tab + (uint64_t)idx * EW;
+        k0 = ld64(e);
+#pragma unroll
+        for (int j = 0; j < MW; j++) p_M[lane * MW + j] = ld64(e + 1 + j);
+      }
+      p_k0[lane] = k0;
       const uint32_t fi = (uint32_t)k0 - 1u;
       const uint32_t o0 = off[fi], o1 = off[fi + 1], nc = ncr[fi];
       p_slot[lane] = idx; p_fi[lane] = fi; p_off[lane] = o0; p_nlive[lane] = o1 - o0;
@@ -168,6 +185,7 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
       if (act) op = c < nlive ? lst[p_off[q] + c] : crashed[c - nlive];
       OpInfo oi; oi.ret_rank = 0; oi.f_slot = kFNone; oi.a = 0; oi.b = 0;
       if (act) oi = opinfo[op];
+      const uint32_t next_slot = (act && fi + 1u < R) ? ret_slot[fi + 1u] : 0u;   // speculative: first step of a front advance
       const uint32_t f = oi.f_slot & 0xFFu, p = oi.f_slot >> 8;
       bool lin = false;
 #pragma unroll
@@ -186,7 +204,7 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
             for (int j = 0; j < MW; j++) if ((pp >> 6) == (uint32_t)j) M2[j] &= ~(1ull << (pp & 63u));
             fi2++;
             if (fi2 == R) break;
-            pp = ret_slot[fi2];
+            pp = (fi2 == fi + 1u) ? next_slot : ret_slot[fi2];
             bool bit = false;
 #pragma unroll
             for (int j = 0; j < MW; j++) if ((pp >> 6) == (uint32_t)j) bit = (M2[j] >> (pp & 63u)) & 1ull;
@@ -205,16 +223,13 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
       const uint64_t vb = __ballot(viable);
       probes += (uint64_t)__popcll(vb);
       if (visited + 64 > full_at) { verdict = TBC_UNKNOWN; cause = TBC_CAUSE_VISITED_FULL; break; }
-      epoch++;
-
       // ---- visited set: lookup / claim.  All lanes stay in the loop until every lane is done.
       const uint64_t k0 = (uint64_t)(fi2 + 1u) | ((uint64_t)(uint32_t)st2 << 32);
       uint64_t hsh = mix64(k0);
 #pragma unroll
       for (int j = 0; j < MW; j++) hsh = mix64(hsh ^ M2[j]) + 0x9E3779B97F4A7C15ull;
       uint64_t idx = hsh & cap_mask;
-      const uint32_t mytag = (epoch << 6) | (63u - lane);
-      bool pending = viable, fresh = false;
+      bool pending = viable, fresh = false, lost = false;
       while (__ballot(pending)) {
         if (pending) {
           uint64_t* e = tab + idx * EW;
@@ -224,53 +239,60 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
             if (old == 0ull) {
 #pragma unroll
               for (int j = 0; j < MW; j++) st64(e + 1 + j, M2[j]);
-              st64(e + 1 + MW, (uint64_t)mytag | ((uint64_t)kNone << 32));
               fresh = true; pending = false;
+            } else {
+              lost = true;     // claimed by another lane in this very step: look at the same entry again
             }
-            // else: claimed by another lane in this very step: look at the same entry again
           } else {
             bool same = k0e == k0;
 #pragma unroll
             for (int j = 0; j < MW; j++) same = same && ld64(e + 1 + j) == M2[j];
             if (same) {
-              uint32_t* ow = reinterpret_cast<uint32_t*>(e + 1 + MW);
-              if ((ld32(ow) >> 6) == epoch) { atomicMax(ow, mytag); fresh = true; }
-              pending = false;
+              fresh = lost;    // equal keys probe in lockstep: a lost CAS followed by a match on that slot
+              pending = false; //   means the config was inserted in THIS round by a sibling lane
             } else {
+              lost = false;
               idx = (idx + 1) & cap_mask;
             }
           }
         }
       }
       // the lowest lane among the lanes that produced one and the same new config keeps it
-      bool is_new = false;
-      if (fresh) {
-        uint64_t* e = tab + idx * EW;
-        is_new = ld32(reinterpret_cast<uint32_t*>(e + 1 + MW)) == mytag;
-        if (is_new) {
-          st64(e + 1 + MW, (uint64_t)mytag | ((uint64_t)p_slot[q] << 32));
-          st64(e + 2 + MW, (uint64_t)op);
-        }
+      bool is_new = fresh;
+      uint64_t dupl = __ballot(fresh && lost);
+      while (dupl) {
+        const uint32_t l0 = (uint32_t)__builtin_ctzll(dupl);
+        const uint32_t ilo = rl((uint32_t)idx, l0), ihi = rl((uint32_t)(idx >> 32), l0);
+        const uint64_t grp = __ballot(fresh && (uint32_t)idx == ilo && (uint32_t)(idx >> 32) == ihi);
+        const uint32_t winner = (uint32_t)__builtin_ctzll(grp);
+        if ((grp >> lane) & 1ull) is_new = lane == winner;
+        dupl &= ~grp;
       }
+      if (is_new) st64(tab + idx * EW + 1 + MW, (uint64_t)p_slot[q] | ((uint64_t)op << 32));
       const uint64_t nb = __ballot(is_new);
+      const uint32_t nn = (uint32_t)__popcll(nb);
       if (is_new) {
         const uint32_t pos = sp + (uint32_t)__popcll(nb & ((1ull << lane) - 1ull));
         __hip_atomic_store(stack + pos, (uint32_t)idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (pos + 16u >= sp + nn) {               // one of the 16 topmost: mirror it in the LDS ring
+          r_pos[pos & 15u] = pos; r_idx[pos & 15u] = (uint32_t)idx; r_k0[pos & 15u] = k0;
+#pragma unroll
+          for (int j = 0; j < MW; j++) r_M[(pos & 15u) * MW + j] = M2[j];
+        }
         lane_maxf = max(lane_maxf, fi2);
       }
-      const uint32_t nn = (uint32_t)__popcll(nb);
       sp += nn; visited += nn;
     }
     max_stack = max(max_stack, (uint64_t)sp);
     if (A.dbg && lane == 0 && (iterations & 255u) == 1u) {
       A.dbg[8] = hidx; A.dbg[9] = (uint32_t)iterations; A.dbg[10] = sp; A.dbg[11] = (uint32_t)probes;
-      A.dbg[12] = (uint32_t)visited; A.dbg[13] = T; A.dbg[14] = np; A.dbg[15] = epoch;
+      A.dbg[12] = (uint32_t)visited; A.dbg[13] = T; A.dbg[14] = np; A.dbg[15] = (uint32_t)rounds;
     }
     if (verdict == -2) {
       if (A.max_steps && probes > A.max_steps) { verdict = TBC_UNKNOWN; cause = TBC_CAUSE_STEP_LIMIT; }
       else if (A.time_limit_ticks && (iterations & 63u) == 0 && (uint64_t)wall_clock64() - t0 > A.time_limit_ticks) {
         verdict = TBC_UNKNOWN; cause = TBC_CAUSE_TIME_LIMIT;
-      } else if (epoch >= (1u << 26) - 2u) { verdict = TBC_UNKNOWN; cause = TBC_CAUSE_STEP_LIMIT; }
+      }
     }
   }
 
@@ -285,7 +307,7 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
     wlen = 1;
     uint32_t id = win_parent;
     for (;;) {
-      const uint32_t par = (uint32_t)(ld64(tab + (uint64_t)id * EW + 1 + MW) >> 32);
+      const uint32_t par = (uint32_t)ld64(tab + (uint64_t)id * EW + 1 + MW);
       if (par == kNone) break;
       wlen++; id = par;
     }
@@ -295,9 +317,10 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
       if (lane == 0) wit[w] = win_op;
       id = win_parent;
       for (;;) {
-        const uint32_t par = (uint32_t)(ld64(tab + (uint64_t)id * EW + 1 + MW) >> 32);
+        const uint64_t po = ld64(tab + (uint64_t)id * EW + 1 + MW);
+        const uint32_t par = (uint32_t)po;
         if (par == kNone) break;
-        const uint32_t opx = (uint32_t)ld64(tab + (uint64_t)id * EW + 2 + MW);
+        const uint32_t opx = (uint32_t)(po >> 32);
         w--;
         if (lane == 0) wit[w] = opx;
         id = par;
