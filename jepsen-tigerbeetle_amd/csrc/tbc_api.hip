@@ -193,6 +193,7 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
   const uint32_t KW = 1 + B->mask_words;
   uint32_t width = opts->search_width ? opts->search_width : (opts->algorithm == TBC_ALG_WGL ? 1u : 16u);
   if (width > 16) width = 16;
+  while (width & (width - 1)) width &= width - 1;   // the wide kernel takes a power of two (lanes per parent = 64 / width)
   if (B->mask_words > 4) width = 1;          // very wide windows: sequential kernel only
   B->width = width;
   const bool beam = width > 1;

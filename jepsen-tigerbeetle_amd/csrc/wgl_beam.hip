@@ -54,9 +54,19 @@ __device__ __forceinline__ uint32_t ld32(const uint32_t* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// LDS words per wave: p_k0[16] u64, p_M[16*MW] u64, then 5 x 16 u32 + start[17]
-// + ring of the 16 most recent pushes: pos[16], idx[16], k0[16] u64, M[16*MW] u64
-__host__ __device__ constexpr uint32_t beam_lds_words(uint32_t mw) { return 2 * 16 + 2 * 16 * mw + 16 * 5 + 20 + 32 + 2 * 16 + 2 * 16 * mw; }
+// LDS words per wave: parents p_k0[16] p_M[16*MW] (u64) p_slot p_off p_nlive p_cnt (u32 x16),
+// ring of the 16 most recent pushes r_k0[16] r_M[16*MW] (u64) r_pos r_idx r_off r_nlive r_cnt (u32 x16)
+__host__ __device__ constexpr uint32_t beam_lds_words(uint32_t mw) { return 2 * (32 + 32 * mw) + 16 * 9 + 20; }
+
+__device__ __forceinline__ uint32_t key_hash32(uint64_t k0, const uint64_t* M, int mw) {
+  uint32_t h = (uint32_t)k0 * 0x9E3779B1u ^ (uint32_t)(k0 >> 32) * 0x85EBCA77u;
+  for (int j = 0; j < mw; j++) {
+    h = (h << 13) | (h >> 19);
+    h ^= (uint32_t)M[j] * 0xC2B2AE3Du ^ (uint32_t)(M[j] >> 32) * 0x27D4EB2Fu;
+  }
+  h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15;
+  return h;
+}
 
 template <int MW>
 __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, const uint32_t lane) {
@@ -76,29 +86,32 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
   uint32_t* stack = A.stack + ru64(B->stack_off);
   uint64_t* tab = A.tab + ru64(B->tab_off) * EW;
   const uint32_t R = rfl(H->n_ret), status = rfl(H->status) | rfl(B->status);
-  const uint64_t cap = 1ull << rfl(B->tab_log2);
-  const uint64_t cap_mask = cap - 1;
-  const uint64_t full_at = cap - (cap >> 2);
-  const uint32_t K = min(max(A.width, 1u), kMaxWidth);
+  const uint32_t cap_log2 = rfl(B->tab_log2);
+  const uint32_t cap_mask = (uint32_t)((1ull << cap_log2) - 1ull);
+  const uint32_t full_at = (uint32_t)((1ull << cap_log2) - (1ull << (cap_log2 - 2)));
+  // K parents per iteration, G = 64 / K lanes (candidate slots) per parent per round
+  const uint32_t K = A.width, gshift = 6u - (31u - (uint32_t)__builtin_clz(K)), G = 1u << gshift;
   DevResult* out = A.results + hidx;
   Model model{A.model_kind, A.table, A.n_classes};
 
   uint64_t* p_k0 = reinterpret_cast<uint64_t*>(lds);
   uint64_t* p_M = p_k0 + 16;
-  uint32_t* p_slot = reinterpret_cast<uint32_t*>(p_M + 16 * MW);
-  uint32_t* p_cnt = p_slot + 16;
-  uint32_t* p_off = p_cnt + 16;
-  uint32_t* p_nlive = p_off + 16;
-  uint32_t* p_fi = p_nlive + 16;
-  uint32_t* p_start = p_fi + 16;     // 17 entries (20 reserved)
-  uint32_t* r_pos = p_start + 20;    // ring: stack position mirrored in this slot (kNone = empty)
-  uint32_t* r_idx = r_pos + 16;
-  uint64_t* r_k0 = reinterpret_cast<uint64_t*>(r_idx + 16);
+  uint64_t* r_k0 = p_M + 16 * MW;
   uint64_t* r_M = r_k0 + 16;
+  uint32_t* p_slot = reinterpret_cast<uint32_t*>(r_M + 16 * MW);
+  uint32_t* p_off = p_slot + 16;
+  uint32_t* p_nlive = p_off + 16;
+  uint32_t* p_cnt = p_nlive + 16;
+  uint32_t* r_pos = p_cnt + 16;      // stack position mirrored in this ring slot (kNone = empty)
+  uint32_t* r_idx = r_pos + 16;
+  uint32_t* r_off = r_idx + 16;
+  uint32_t* r_nlive = r_off + 16;
+  uint32_t* r_cnt = r_nlive + 16;
+  uint32_t* p_start = r_cnt + 16;    // 17 entries: pair-number prefix, general mapping only
   if (lane < 16) r_pos[lane] = kNone;
 
-  uint64_t probes = 0, visited = 0, expanded = 0, iterations = 0, rounds = 0, max_stack = 0;
-  uint32_t sp = 0, lane_maxf = 0;
+  uint64_t probes = 0, visited = 0, expanded = 0, iterations = 0, rounds = 0;
+  uint32_t sp = 0, max_sp = 0, lane_maxf = 0;
   int32_t verdict = -2, cause = TBC_CAUSE_NONE;
   uint32_t win_parent = kNone, win_op = kNone;
   int32_t win_state = A.init_state;
@@ -109,19 +122,19 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
   else {
     // root config
     const uint64_t k0 = 1ull | ((uint64_t)(uint32_t)A.init_state << 32);
-    uint64_t h = mix64(k0);
+    uint64_t zero[MW];
 #pragma unroll
-    for (int j = 0; j < MW; j++) h = mix64(h ^ 0ull) + 0x9E3779B97F4A7C15ull;
-    const uint64_t idx = h & cap_mask;
+    for (int j = 0; j < MW; j++) zero[j] = 0;
+    const uint32_t idx = key_hash32(k0, zero, MW) & cap_mask;
     if (lane == 0) {
-      uint64_t* e = tab + idx * EW;
+      uint64_t* e = tab + (uint64_t)idx * EW;
       st64(e + 0, k0);
 #pragma unroll
       for (int j = 0; j < MW; j++) st64(e + 1 + j, 0ull);
       st64(e + 1 + MW, (uint64_t)kNone | ((uint64_t)kNone << 32));
-      stack[0] = (uint32_t)idx;
+      __hip_atomic_store(stack, idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    sp = 1; visited = 1; max_stack = 1;
+    sp = 1; visited = 1; max_sp = 1;
   }
 
   while (verdict == -2) {
@@ -129,70 +142,94 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
     const uint32_t np = min(K, sp);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    // ---- pop the np most recent configs (lane q = q-th from the bottom of the popped run)
+    // ---- pop the np most recent configs: lane l < np loads the l-th from the bottom of the popped run
     uint32_t my_cnt = 0;
     if (lane < np) {
-      const uint32_t spos = sp - np + lane;
-      uint32_t idx; uint64_t k0;
-      if (r_pos[spos & 15u] == spos) {          // pushed recently: config still in the LDS ring
-        idx = r_idx[spos & 15u]; k0 = r_k0[spos & 15u];
+      const uint32_t spos = sp - np + lane, rs = spos & 15u;
+      if (r_pos[rs] == spos) {                  // pushed recently: config (and its front's list) still in the ring
+        p_k0[lane] = r_k0[rs];
 #pragma unroll
-        for (int j = 0; j < MW; j++) p_M[lane * MW + j] = r_M[(spos & 15u) * MW + j];
+        for (int j = 0; j < MW; j++) p_M[lane * MW + j] = r_M[rs * MW + j];
+        p_slot[lane] = r_idx[rs]; p_off[lane] = r_off[rs]; p_nlive[lane] = r_nlive[rs];
+        my_cnt = r_cnt[rs];
       } else {
-        idx = ld32(stack + spos);
+        const uint32_t idx = ld32(stack + spos);
         const uint64_t* e = tab + (uint64_t)idx * EW;
-        k0 = ld64(e);
+        const uint64_t k0 = ld64(e);
+        p_k0[lane] = k0;
 #pragma unroll
         for (int j = 0; j < MW; j++) p_M[lane * MW + j] = ld64(e + 1 + j);
+        const uint32_t fi = (uint32_t)k0 - 1u;
+        const uint32_t o0 = off[fi], o1 = off[fi + 1], nc = ncr[fi];
+        p_slot[lane] = idx; p_off[lane] = o0; p_nlive[lane] = o1 - o0;
+        my_cnt = (o1 - o0) + nc;
       }
-      p_k0[lane] = k0;
-      const uint32_t fi = (uint32_t)k0 - 1u;
-      const uint32_t o0 = off[fi], o1 = off[fi + 1], nc = ncr[fi];
-      p_slot[lane] = idx; p_fi[lane] = fi; p_off[lane] = o0; p_nlive[lane] = o1 - o0;
-      my_cnt = (o1 - o0) + nc;
       p_cnt[lane] = my_cnt;
     }
     sp -= np;
-    // inclusive scan of the pair counts over lanes 0..15
-    uint32_t x = my_cnt;
+    uint32_t maxcnt = my_cnt;                   // lanes >= np hold 0
 #pragma unroll
-    for (int d = 1; d < 16; d <<= 1) {
-      const uint32_t y = __shfl_up(x, d);
-      if (lane >= (uint32_t)d) x += y;
+    for (int d = 8; d >= 1; d >>= 1) maxcnt = max(maxcnt, (uint32_t)__shfl_xor(maxcnt, d));
+    maxcnt = rl(maxcnt, 0);
+    // Pair order (oracle/wgl_beam.c): parents bottom-first, each parent's open calls last-to-first,
+    // 64 consecutive pairs per round.  When every parent has at most G = 64/K open calls all pairs
+    // fit one round and lane = parent*G + i realises that order directly; otherwise pairs are
+    // numbered through a prefix sum over the parents (crash-heavy histories).
+    const bool grouped = maxcnt <= G;
+    uint32_t T = maxcnt ? 64u : 0u;
+    if (!grouped) {
+      uint32_t x = my_cnt;
+#pragma unroll
+      for (int d = 1; d < 16; d <<= 1) {
+        const uint32_t y = __shfl_up(x, d);
+        if (lane >= (uint32_t)d) x += y;
+      }
+      if (lane < np) p_start[lane] = x - my_cnt;
+      T = rl(x, np - 1);
+      if (lane == 0) p_start[np] = T;
     }
-    if (lane < np) p_start[lane] = x - my_cnt;
-    const uint32_t T = rl(x, np - 1);
-    if (lane == 0) p_start[np] = T;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     iterations++; expanded += np;
 
     for (uint32_t base = 0; base < T && verdict == -2; base += 64) {
-      const uint32_t r = base + lane;
-      const bool act = r < T;
-      uint32_t q = 0;
+      // ---- which (parent, open call) pair this lane handles
+      uint32_t q, cd;
+      bool has_parent;
+      if (grouped) {
+        q = lane >> gshift; cd = lane & (G - 1u); has_parent = q < np;
+      } else {
+        const uint32_t r = base + lane;
+        q = 0;
 #pragma unroll
-      for (uint32_t t = 1; t < kMaxWidth; t++) q += (t < np && p_start[t] <= r) ? 1u : 0u;
-      const uint32_t fi = p_fi[q];
-      const uint64_t k0p = p_k0[q];
+        for (uint32_t t = 1; t < 16; t++) q += (t < np && p_start[t] <= r) ? 1u : 0u;
+        has_parent = r < T;
+        cd = has_parent ? r - p_start[q] : 0u;
+      }
+      const uint64_t k0p = has_parent ? p_k0[q] : 1ull;
+      const uint32_t fi = (uint32_t)k0p - 1u;
       const int32_t st = (int32_t)(uint32_t)(k0p >> 32);
-      uint64_t M2[MW];
+      uint64_t Mp[MW];
 #pragma unroll
-      for (int j = 0; j < MW; j++) M2[j] = p_M[q * MW + j];
-      const uint32_t nlive = p_nlive[q];
-      const uint32_t c = act ? (p_cnt[q] - 1u - (r - p_start[q])) : 0u;
+      for (int j = 0; j < MW; j++) Mp[j] = has_parent ? p_M[q * MW + j] : 0ull;
+      const uint32_t pslot = has_parent ? p_slot[q] : 0u, poff = has_parent ? p_off[q] : 0u;
+      const uint32_t nlive = has_parent ? p_nlive[q] : 0u, cnt = has_parent ? p_cnt[q] : 0u;
+      const bool act = has_parent && cd < cnt;
+      const uint32_t next_slot = (act && fi + 1u < R) ? ret_slot[fi + 1u] : 0u;   // first step of a front advance
+      const uint32_t c = cnt - 1u - cd;
       uint32_t op = 0;
-      if (act) op = c < nlive ? lst[p_off[q] + c] : crashed[c - nlive];
       OpInfo oi; oi.ret_rank = 0; oi.f_slot = kFNone; oi.a = 0; oi.b = 0;
-      if (act) oi = opinfo[op];
-      const uint32_t next_slot = (act && fi + 1u < R) ? ret_slot[fi + 1u] : 0u;   // speculative: first step of a front advance
+      if (act) { op = c < nlive ? lst[poff + c] : crashed[c - nlive]; oi = opinfo[op]; }
       const uint32_t f = oi.f_slot & 0xFFu, p = oi.f_slot >> 8;
       bool lin = false;
 #pragma unroll
-      for (int j = 0; j < MW; j++) if ((p >> 6) == (uint32_t)j) lin = (M2[j] >> (p & 63u)) & 1ull;
+      for (int j = 0; j < MW; j++) if ((p >> 6) == (uint32_t)j) lin = (Mp[j] >> (p & 63u)) & 1ull;
       const bool viable = act && !lin && model.ok(st, f, oi.a);
       int32_t st2 = st;
       uint32_t fi2 = fi;
+      uint64_t M2[MW];
+#pragma unroll
+      for (int j = 0; j < MW; j++) M2[j] = Mp[j];
       if (viable) {
         st2 = model.apply(st, f, oi.a, oi.b);
 #pragma unroll
@@ -216,30 +253,32 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
       const uint64_t succ = __ballot(viable && fi2 == R);
       if (succ) {   // linearizable: lowest pair wins, nothing of this round is inserted
         const uint32_t wl = (uint32_t)__builtin_ctzll(succ);
-        win_parent = rl(p_slot[q], wl); win_op = rl(op, wl); win_state = (int32_t)rl((uint32_t)st2, wl);
+        win_parent = rl(pslot, wl); win_op = rl(op, wl); win_state = (int32_t)rl((uint32_t)st2, wl);
         verdict = TBC_VALID;
         break;
       }
       const uint64_t vb = __ballot(viable);
       probes += (uint64_t)__popcll(vb);
-      if (visited + 64 > full_at) { verdict = TBC_UNKNOWN; cause = TBC_CAUSE_VISITED_FULL; break; }
-      // ---- visited set: lookup / claim.  All lanes stay in the loop until every lane is done.
+      if ((uint32_t)visited + 64u > full_at) { verdict = TBC_UNKNOWN; cause = TBC_CAUSE_VISITED_FULL; break; }
+
+      // the child's front: its open-call list (issued now, consumed at push; hidden under the probe)
+      uint32_t co0 = 0, co1 = 0, cnc = 0;
+      if (viable) { co0 = off[fi2]; co1 = off[fi2 + 1u]; cnc = ncr[fi2]; }
+
+      // ---- visited set: claim-or-find with one CAS per probe step.  Equal keys probe in lockstep.
       const uint64_t k0 = (uint64_t)(fi2 + 1u) | ((uint64_t)(uint32_t)st2 << 32);
-      uint64_t hsh = mix64(k0);
-#pragma unroll
-      for (int j = 0; j < MW; j++) hsh = mix64(hsh ^ M2[j]) + 0x9E3779B97F4A7C15ull;
-      uint64_t idx = hsh & cap_mask;
-      bool pending = viable, fresh = false, lost = false;
+      uint32_t idx = key_hash32(k0, M2, MW) & cap_mask;
+      bool pending = viable, fresh = false, won = false, lost = false;
       while (__ballot(pending)) {
         if (pending) {
-          uint64_t* e = tab + idx * EW;
+          uint64_t* e = tab + (uint64_t)idx * EW;
           const uint64_t k0e = ld64(e);
           if ((uint32_t)k0e == 0u) {
             const uint64_t old = atomicCAS((unsigned long long*)e, 0ull, (unsigned long long)k0);
-            if (old == 0ull) {
+            if (old == 0ull) {                       // claimed an empty entry
 #pragma unroll
               for (int j = 0; j < MW; j++) st64(e + 1 + j, M2[j]);
-              fresh = true; pending = false;
+              won = true; fresh = true; pending = false;
             } else {
               lost = true;     // claimed by another lane in this very step: look at the same entry again
             }
@@ -252,41 +291,43 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
               pending = false; //   means the config was inserted in THIS round by a sibling lane
             } else {
               lost = false;
-              idx = (idx + 1) & cap_mask;
+              idx = (idx + 1u) & cap_mask;
             }
           }
         }
       }
       // the lowest lane among the lanes that produced one and the same new config keeps it
       bool is_new = fresh;
-      uint64_t dupl = __ballot(fresh && lost);
+      uint64_t dupl = __ballot(fresh && !won);
       while (dupl) {
         const uint32_t l0 = (uint32_t)__builtin_ctzll(dupl);
-        const uint32_t ilo = rl((uint32_t)idx, l0), ihi = rl((uint32_t)(idx >> 32), l0);
-        const uint64_t grp = __ballot(fresh && (uint32_t)idx == ilo && (uint32_t)(idx >> 32) == ihi);
+        const uint32_t i0 = rl(idx, l0);
+        const uint64_t grp = __ballot(fresh && idx == i0);
         const uint32_t winner = (uint32_t)__builtin_ctzll(grp);
         if ((grp >> lane) & 1ull) is_new = lane == winner;
         dupl &= ~grp;
       }
-      if (is_new) st64(tab + idx * EW + 1 + MW, (uint64_t)p_slot[q] | ((uint64_t)op << 32));
+      if (is_new) st64(tab + (uint64_t)idx * EW + 1 + MW, (uint64_t)pslot | ((uint64_t)(op + 1u) << 32));
       const uint64_t nb = __ballot(is_new);
       const uint32_t nn = (uint32_t)__popcll(nb);
       if (is_new) {
         const uint32_t pos = sp + (uint32_t)__popcll(nb & ((1ull << lane) - 1ull));
-        __hip_atomic_store(stack + pos, (uint32_t)idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(stack + pos, idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (pos + 16u >= sp + nn) {               // one of the 16 topmost: mirror it in the LDS ring
-          r_pos[pos & 15u] = pos; r_idx[pos & 15u] = (uint32_t)idx; r_k0[pos & 15u] = k0;
+          const uint32_t rs = pos & 15u;
+          r_pos[rs] = pos; r_idx[rs] = idx; r_k0[rs] = k0;
 #pragma unroll
-          for (int j = 0; j < MW; j++) r_M[(pos & 15u) * MW + j] = M2[j];
+          for (int j = 0; j < MW; j++) r_M[rs * MW + j] = M2[j];
+          r_off[rs] = co0; r_nlive[rs] = co1 - co0; r_cnt[rs] = (co1 - co0) + cnc;
         }
         lane_maxf = max(lane_maxf, fi2);
       }
       sp += nn; visited += nn;
     }
-    max_stack = max(max_stack, (uint64_t)sp);
+    max_sp = max(max_sp, sp);
     if (A.dbg && lane == 0 && (iterations & 255u) == 1u) {
       A.dbg[8] = hidx; A.dbg[9] = (uint32_t)iterations; A.dbg[10] = sp; A.dbg[11] = (uint32_t)probes;
-      A.dbg[12] = (uint32_t)visited; A.dbg[13] = T; A.dbg[14] = np; A.dbg[15] = (uint32_t)rounds;
+      A.dbg[12] = (uint32_t)visited; A.dbg[13] = maxcnt; A.dbg[14] = np; A.dbg[15] = (uint32_t)rounds;
     }
     if (verdict == -2) {
       if (A.max_steps && probes > A.max_steps) { verdict = TBC_UNKNOWN; cause = TBC_CAUSE_STEP_LIMIT; }
@@ -320,9 +361,8 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
         const uint64_t po = ld64(tab + (uint64_t)id * EW + 1 + MW);
         const uint32_t par = (uint32_t)po;
         if (par == kNone) break;
-        const uint32_t opx = (uint32_t)(po >> 32);
         w--;
-        if (lane == 0) wit[w] = opx;
+        if (lane == 0) wit[w] = (uint32_t)(po >> 32) - 1u;
         id = par;
       }
     }
@@ -337,7 +377,7 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
       if (maxf) out->prev_ok_op = ret_op[maxf - 1];
     }
     out->steps = probes; out->visited = visited; out->probes = probes; out->backtracks = expanded;
-    out->max_depth = max_stack; out->bucket_reads = rounds;
+    out->max_depth = max_sp; out->bucket_reads = rounds;
   }
   if (A.dbg && lane == 0) { A.dbg[4] = 0x300u + hidx; A.dbg[16] = (uint32_t)verdict; A.dbg[17] = (uint32_t)iterations; }
 }
