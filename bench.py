@@ -45,7 +45,7 @@ def main():
     ap.add_argument("--busy", type=float, default=0.1,
                     help="fraction of time a process has an op open (64 x 0.1 = 6.4 ops in flight on average)")
     ap.add_argument("--info", type=float, default=0.0, help="crashed-op (:info) rate")
-    ap.add_argument("--width", type=int, default=int(os.environ.get("TBC_BENCH_WIDTH", "8")),
+    ap.add_argument("--width", type=int, default=int(os.environ.get("TBC_BENCH_WIDTH", "4")),
                     help="configs expanded per iteration: 1 = sequential knossos.wgl order, 2..16 = wide schedule")
     ap.add_argument("--cpu-sample", type=int, default=256, help="histories timed on the CPU oracle (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
@@ -69,7 +69,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import jepsen_tigerbeetle_amd  # noqa: F401
-    from jepsen_tigerbeetle_amd import _native as N, columns, core, synth
+    from jepsen_tigerbeetle_amd import _native as N, columns, core, shard, synth
 
     def barrier():
         if world > 1:
@@ -79,9 +79,10 @@ def main():
     # ---- synthetic input: B distinct seeded histories per rank
     B = args.batch
     t_gen = time.time()
+    seeds = shard.shard_indices(B * world, rank, world)      # history i of the job lives on rank i % world
     hists = [columns.pair_events(synth.register_events(
-        n_ops=args.ops, n_procs=args.procs, seed=rank * B + i, busy=args.busy, info=args.info))
-        for i in range(B)]
+        n_ops=args.ops, n_procs=args.procs, seed=int(i), busy=args.busy, info=args.info))
+        for i in seeds]
     t_gen = time.time() - t_gen
     model = core.make_model(N.MODEL_CAS_REGISTER, N.NIL)
     opts = core.make_opts(device=local_rank, time_limit_ms=600000, want_witness=False,
@@ -99,10 +100,7 @@ def main():
         search_ns.append(tm["search"]); pack_ns.append(tm["pack"]); init_ns.append(tm["init"]); retry_ns.append(tm["retries"])
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = shard.max_over_ranks(elapsed, world, dist)
 
     verdicts = batch.verdicts()
     counters = batch.counters()

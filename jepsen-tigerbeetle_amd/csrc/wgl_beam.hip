@@ -116,6 +116,9 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
   uint32_t win_parent = kNone, win_op = kNone;
   int32_t win_state = A.init_state;
   const uint64_t t0 = A.time_limit_ticks ? wall_clock64() : 0;
+  const bool prof = A.dbg != nullptr;
+  uint64_t seg[6] = {0, 0, 0, 0, 0, 0}, tlast = prof ? __builtin_readcyclecounter() : 0;
+#define SEG(i) do { if (prof) { const uint64_t tn_ = __builtin_readcyclecounter(); seg[i] += tn_ - tlast; tlast = tn_; } } while (0)
 
   if (status != 0) verdict = TBC_UNKNOWN;
   else if (R == 0) verdict = TBC_VALID;
@@ -191,6 +194,7 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     iterations++; expanded += np;
+    SEG(0);
 
     for (uint32_t base = 0; base < T && verdict == -2; base += 64) {
       // ---- which (parent, open call) pair this lane handles
@@ -221,6 +225,7 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
       OpInfo oi; oi.ret_rank = 0; oi.f_slot = kFNone; oi.a = 0; oi.b = 0;
       if (act) { op = c < nlive ? lst[poff + c] : crashed[c - nlive]; oi = opinfo[op]; }
       const uint32_t f = oi.f_slot & 0xFFu, p = oi.f_slot >> 8;
+      if (prof) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); SEG(1); }
       bool lin = false;
 #pragma unroll
       for (int j = 0; j < MW; j++) if ((p >> 6) == (uint32_t)j) lin = (Mp[j] >> (p & 63u)) & 1ull;
@@ -249,6 +254,7 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
           }
         }
       }
+      SEG(2);
       rounds++;
       const uint64_t succ = __ballot(viable && fi2 == R);
       if (succ) {   // linearizable: lowest pair wins, nothing of this round is inserted
@@ -296,6 +302,7 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
           }
         }
       }
+      SEG(3);
       // the lowest lane among the lanes that produced one and the same new config keeps it
       bool is_new = fresh;
       uint64_t dupl = __ballot(fresh && !won);
@@ -323,6 +330,7 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
         lane_maxf = max(lane_maxf, fi2);
       }
       sp += nn; visited += nn;
+      SEG(4);
     }
     max_sp = max(max_sp, sp);
     if (A.dbg && lane == 0 && (iterations & 255u) == 1u) {
@@ -379,7 +387,12 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
     out->steps = probes; out->visited = visited; out->probes = probes; out->backtracks = expanded;
     out->max_depth = max_sp; out->bucket_reads = rounds;
   }
-  if (A.dbg && lane == 0) { A.dbg[4] = 0x300u + hidx; A.dbg[16] = (uint32_t)verdict; A.dbg[17] = (uint32_t)iterations; }
+  if (A.dbg && lane == 0) {
+    A.dbg[4] = 0x300u + hidx; A.dbg[16] = (uint32_t)verdict; A.dbg[17] = (uint32_t)iterations;
+    for (int i = 0; i < 5; i++) { A.dbg[20 + 2 * i] = (uint32_t)seg[i]; A.dbg[21 + 2 * i] = (uint32_t)(seg[i] >> 32); }
+    A.dbg[30] = (uint32_t)rounds;
+  }
+#undef SEG
 }
 
 template <int MW>
