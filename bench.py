@@ -47,6 +47,7 @@ def main():
     ap.add_argument("--info", type=float, default=0.0, help="crashed-op (:info) rate")
     ap.add_argument("--width", type=int, default=int(os.environ.get("TBC_BENCH_WIDTH", "4")),
                     help="configs expanded per iteration: 1 = sequential knossos.wgl order, 2..16 = wide schedule")
+    ap.add_argument("--visited-per-op", type=int, default=0, help="first visited-set capacity per op (0 = library default 64)")
     ap.add_argument("--cpu-sample", type=int, default=256, help="histories timed on the CPU oracle (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
@@ -80,13 +81,11 @@ def main():
     B = args.batch
     t_gen = time.time()
     seeds = shard.shard_indices(B * world, rank, world)      # history i of the job lives on rank i % world
-    hists = [columns.pair_events(synth.register_events(
-        n_ops=args.ops, n_procs=args.procs, seed=int(i), busy=args.busy, info=args.info))
-        for i in seeds]
+    hists = synth.register_ops_many(seeds, n_ops=args.ops, n_procs=args.procs, busy=args.busy, info=args.info)
     t_gen = time.time() - t_gen
     model = core.make_model(N.MODEL_CAS_REGISTER, N.NIL)
     opts = core.make_opts(device=local_rank, time_limit_ms=600000, want_witness=False,
-                          algorithm=N.ALG_COMPETITION, search_width=args.width)
+                          algorithm=N.ALG_COMPETITION, search_width=args.width, visited_per_op=args.visited_per_op)
     batch = core.Batch(hists, model, opts)        # H2D happens here: inputs resident before timing
 
     for _ in range(args.warmup):

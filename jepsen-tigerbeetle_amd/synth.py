@@ -36,3 +36,21 @@ def register_events(n_ops=1000, n_procs=16, seed=0, n_values=5, busy=0.5, info=0
         raise ValueError(f"tbs_gen_register rc={rc}")
     k = rows.value
     return EventColumns(typ[:k].copy(), proc[:k].copy(), f[:k].copy(), a[:k].copy(), b[:k].copy())
+
+
+def register_ops_many(seeds, workers=None, **kw):
+    """pair_events(register_events(seed=s, **kw)) for every seed.  The generator and the pairing
+    step are C code called through ctypes (the GIL is released), so a thread pool scales."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    from .columns import pair_events
+    seeds = [int(s) for s in seeds]
+    workers = workers or min(32, os.cpu_count() or 1)
+
+    def one(seed):
+        return pair_events(register_events(seed=seed, **kw))
+
+    if workers <= 1 or len(seeds) < 64:
+        return [one(s) for s in seeds]
+    with ThreadPoolExecutor(workers) as ex:
+        return list(ex.map(one, seeds))
