@@ -118,7 +118,8 @@ struct tbc_batch {
   std::vector<BeamHist> bh;
   DevBuf<BeamHist> d_bh;
   DevBuf<uint32_t> d_off, d_ncr, d_lst, d_crashed, d_stack;
-  DevBuf<uint64_t> d_occ, d_btab;
+  DevBuf<uint64_t> d_occ, d_btab, d_pool;
+  DevBuf<unsigned long long> d_pool_cursor;
   DevBuf<OpInfo> d_opinfo;
   // last run
   std::vector<DevResult> res_host;
@@ -134,7 +135,7 @@ struct tbc_batch {
     d_bitmap.release(); d_wpre.release(); d_frames.release(); d_witness.release(); d_work.release();
     d_queue.release(); d_tab.release(); d_results.release(); d_table.release();
     d_bh.release(); d_off.release(); d_ncr.release(); d_lst.release(); d_crashed.release(); d_stack.release();
-    d_occ.release(); d_btab.release(); d_opinfo.release();
+    d_occ.release(); d_btab.release(); d_opinfo.release(); d_pool.release(); d_pool_cursor.release();
     for (auto& e : ev) if (e) (void)hipEventDestroy(e);
     if (stream) (void)hipStreamDestroy(stream);
   }
@@ -252,8 +253,17 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
   if (beam) {
     if ((s = B->d_bh.alloc(nh)) || (s = B->d_off.alloc(boff_n)) || (s = B->d_ncr.alloc(boff_n)) ||
         (s = B->d_occ.alloc(bocc_n)) || (s = B->d_lst.alloc(blst_n)) || (s = B->d_crashed.alloc(T)) ||
-        (s = B->d_opinfo.alloc(T)) || (s = B->d_stack.alloc(bstack_n)) || (s = B->d_btab.alloc(btab_n * EW)))
+        (s = B->d_opinfo.alloc(T)) || (s = B->d_stack.alloc(bstack_n)) || (s = B->d_btab.alloc(btab_n * EW)) ||
+        (s = B->d_pool_cursor.alloc(1)))
       return s;
+    // growth pool: a quarter of the visited-set arena, at least room for one history to grow twice, at most 32 GiB
+    {
+      uint64_t biggest = 0;
+      for (uint32_t h = 0; h < nh; h++) biggest = std::max<uint64_t>(biggest, 1ull << B->bh[h].tab_log2);
+      uint64_t words = std::max<uint64_t>(btab_n * EW / 4, biggest * (4 + 16) * (EW + 1));
+      words = std::min<uint64_t>(words, (32ull << 30) / 8);
+      if ((s = B->d_pool.alloc(words))) return s;
+    }
   }
   if (model->kind == TBC_MODEL_TABLE) {
     const size_t tn = (size_t)model->n_states * model->n_classes;
@@ -267,7 +277,7 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
                     B->d_ret_op.bytes() + B->d_bitmap.bytes() + B->d_wpre.bytes() + B->d_frames.bytes() +
                     B->d_tab.bytes() + B->d_results.bytes() + B->d_work.bytes() + B->d_witness.bytes();
   if (beam) B->device_bytes += B->d_bh.bytes() + B->d_off.bytes() + B->d_ncr.bytes() + B->d_occ.bytes() + B->d_lst.bytes() +
-                               B->d_crashed.bytes() + B->d_opinfo.bytes() + B->d_stack.bytes() + B->d_btab.bytes();
+                               B->d_crashed.bytes() + B->d_opinfo.bytes() + B->d_stack.bytes() + B->d_btab.bytes() + B->d_pool.bytes();
 
   HIP_TRY(hipStreamCreateWithFlags(&B->stream, hipStreamNonBlocking));
   for (auto& e : B->ev) HIP_TRY(hipEventCreate(&e));
@@ -351,6 +361,13 @@ static BeamArgs make_beam_args(tbc_batch* B, uint64_t* tab, uint32_t* stack, uin
   a.max_steps = B->opts.max_steps;
   a.time_limit_ticks = B->opts.time_limit_ms * 100000ull;
   a.dbg = debug_words();
+  a.pool = B->d_pool.p; a.pool_cursor = B->d_pool_cursor.p; a.pool_words = B->d_pool.n;
+  {
+    const uint64_t max_bytes = B->opts.max_visited_bytes ? B->opts.max_visited_bytes : (1ull << 30);
+    uint32_t lg = 10;
+    while (lg < 31 && (1ull << (lg + 1)) * (B->mask_words + 2) * 8 <= max_bytes) lg++;
+    a.max_tab_log2 = lg;
+  }
   return a;
 }
 
@@ -387,7 +404,7 @@ static tbc_status scratch_pass(tbc_batch* B, const std::vector<uint32_t>& grp, c
   if (e == hipSuccess) e = hipMemcpyAsync(B->d_work.p, grp.data(), grp.size() * 4, hipMemcpyHostToDevice, s);
   if (e == hipSuccess) {
     const uint32_t nw = (uint32_t)grp.size();
-    if (beam) { BeamArgs ba = make_beam_args(B, big.p, bstack.p, nw); launch_beam(ba, B->mask_words, search_blocks(nw), s); }
+    if (beam) { BeamArgs ba = make_beam_args(B, big.p, bstack.p, nw); ba.pool = nullptr; ba.pool_words = 0; launch_beam(ba, B->mask_words, search_blocks(nw), s); }
     else { SearchArgs ra = make_search_args(B, big.p, nw); launch_search(ra, B->mask_words, search_blocks(nw), s); }
     e = hipGetLastError();
   }
@@ -418,6 +435,8 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results) {
   HIP_TRY(hipMemsetAsync(B->d_bitmap.p, 0, B->d_bitmap.bytes(), s));
   if (beam) {
     HIP_TRY(hipMemsetAsync(B->d_btab.p, 0, B->d_btab.bytes(), s));
+    HIP_TRY(hipMemsetAsync(B->d_pool.p, 0, B->d_pool.bytes(), s));
+    HIP_TRY(hipMemsetAsync(B->d_pool_cursor.p, 0, sizeof(unsigned long long), s));
     HIP_TRY(hipMemsetAsync(B->d_off.p, 0, B->d_off.bytes(), s));
     HIP_TRY(hipMemsetAsync(B->d_ncr.p, 0, B->d_ncr.bytes(), s));
     HIP_TRY(hipMemsetAsync(B->d_occ.p, 0, B->d_occ.bytes(), s));
@@ -556,6 +575,7 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results) {
     const DevResult& d = B->res_host[h];
     B->sum.steps += d.steps; B->sum.visited += d.visited; B->sum.probes += d.probes;
     B->sum.backtracks += d.backtracks; B->sum.max_depth = std::max(B->sum.max_depth, d.max_depth);
+    if (!is_seq[h] && d.tab_log2 > final_log2[h]) final_log2[h] = d.tab_log2;
     B->sum.table_slots += 1ull << final_log2[h];
     if (hist_back[h].status != 0 && worst == TBC_OK) {
       worst = (tbc_status)hist_back[h].status;

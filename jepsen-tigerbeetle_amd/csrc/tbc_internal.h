@@ -54,6 +54,8 @@ struct __attribute__((aligned(8))) DevResult {
   uint32_t n_configs;
   uint32_t fail_op;     // invalid: op whose completion has rank max_front
   uint32_t prev_ok_op;  // invalid: op completing just before it, or TBC_NO_OP
+  uint32_t tab_log2;    // wide schedule: final visited-set capacity (it can grow inside the kernel)
+  uint32_t pad;
   uint64_t steps, visited, probes, backtracks, max_depth, bucket_reads;
 };
 
@@ -168,6 +170,12 @@ struct BeamArgs {
   uint64_t max_steps;
   uint64_t time_limit_ticks;
   uint32_t* dbg;
+  // growth pool: zeroed scratch a wavefront takes a 4x larger visited set + stack from when its own fills up
+  uint64_t* pool;
+  unsigned long long* pool_cursor;   // words handed out so far (zeroed before the launch)
+  uint64_t pool_words;
+  uint32_t max_tab_log2;             // growth stops here (tbc_opts.max_visited_bytes)
+  uint32_t pad2;
 };
 
 void launch_pack_open(const PackOpenArgs& a, void* stream);

@@ -84,11 +84,11 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
   const OpInfo* opinfo = A.opinfo + op_off;
   const uint32_t* ret_slot = A.ret_slot + ret_off;
   uint32_t* stack = A.stack + ru64(B->stack_off);
-  uint64_t* tab = A.tab + ru64(B->tab_off) * EW;
+  uint64_t* tab = A.tab + ru64(B->tab_off) * EW;   // both move when the visited set grows
   const uint32_t R = rfl(H->n_ret), status = rfl(H->status) | rfl(B->status);
-  const uint32_t cap_log2 = rfl(B->tab_log2);
-  const uint32_t cap_mask = (uint32_t)((1ull << cap_log2) - 1ull);
-  const uint32_t full_at = (uint32_t)((1ull << cap_log2) - (1ull << (cap_log2 - 2)));
+  uint32_t cap_log2 = rfl(B->tab_log2);
+  uint32_t cap_mask = (uint32_t)((1ull << cap_log2) - 1ull);
+  uint32_t full_at = (uint32_t)((1ull << cap_log2) - (1ull << (cap_log2 - 2)));
   // K parents per iteration, G = 64 / K lanes (candidate slots) per parent per round
   const uint32_t K = A.width, gshift = 6u - (31u - (uint32_t)__builtin_clz(K)), G = 1u << gshift;
   DevResult* out = A.results + hidx;
@@ -193,6 +193,63 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    // ---- room for every pair of this iteration?  If not, move to a 4x larger visited set (and stack)
+    // taken from the batch's growth pool: re-insert every entry, then translate the slot numbers held
+    // by parent links, the stack and this iteration's parents.  Results do not depend on the layout.
+    {
+      const uint32_t worst = grouped ? np * G : T;
+      bool failed = false;
+      while (!failed && (uint64_t)visited + worst > full_at) {
+        const uint64_t old_cap = 1ull << cap_log2, new_cap = old_cap << 2;
+        const uint64_t need = new_cap * EW + new_cap / 2 + old_cap / 2;      // table, stack, slot translation
+        unsigned long long base = 0;
+        if (lane == 0) base = (A.pool && cap_log2 + 2 <= A.max_tab_log2) ? atomicAdd(A.pool_cursor, (unsigned long long)need) : ~0ull;
+        base = ru64(base);
+        if (!A.pool || cap_log2 + 2 > 31 || cap_log2 + 2 > A.max_tab_log2 || base + need > A.pool_words) { failed = true; break; }
+        uint64_t* ntab = A.pool + base;
+        uint32_t* nstack = reinterpret_cast<uint32_t*>(ntab + new_cap * EW);
+        uint32_t* remap = nstack + new_cap;
+        const uint32_t nmask = (uint32_t)(new_cap - 1);
+        for (uint64_t s = lane; s < old_cap; s += 64) {
+          const uint64_t* e = tab + s * EW;
+          const uint64_t k0 = ld64(e);
+          if ((uint32_t)k0 == 0u) continue;
+          uint64_t Mx[MW];
+#pragma unroll
+          for (int j = 0; j < MW; j++) Mx[j] = ld64(e + 1 + j);
+          const uint64_t pw = ld64(e + 1 + MW);
+          uint32_t idx = key_hash32(k0, Mx, MW) & nmask;
+          for (;;) {
+            uint64_t* ne = ntab + (uint64_t)idx * EW;
+            if (atomicCAS((unsigned long long*)ne, 0ull, (unsigned long long)k0) == 0ull) {
+#pragma unroll
+              for (int j = 0; j < MW; j++) st64(ne + 1 + j, Mx[j]);
+              st64(ne + 1 + MW, pw);
+              break;
+            }
+            idx = (idx + 1u) & nmask;
+          }
+          __hip_atomic_store(remap + s, idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __threadfence();
+        for (uint64_t s = lane; s < old_cap; s += 64) {       // parent links -> new slot numbers
+          if ((uint32_t)ld64(tab + s * EW) == 0u) continue;
+          uint64_t* ne = ntab + (uint64_t)ld32(remap + s) * EW + 1 + MW;
+          const uint64_t pw = ld64(ne);
+          if ((uint32_t)pw != kNone) st64(ne, (uint64_t)ld32(remap + (uint32_t)pw) | (pw & 0xFFFFFFFF00000000ull));
+        }
+        for (uint32_t i = lane; i < sp; i += 64)                // sp was already lowered by np: the popped run ...
+          __hip_atomic_store(nstack + i, ld32(remap + ld32(stack + i)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane < np) p_slot[lane] = ld32(remap + p_slot[lane]);   // ... lives in p_slot
+        if (lane < 16) r_pos[lane] = kNone;                      // the ring held old slot numbers
+        __threadfence();
+        tab = ntab; stack = nstack; cap_log2 += 2; cap_mask = nmask;
+        full_at = (uint32_t)(new_cap - (new_cap >> 2));
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+      if (failed) { sp += np; verdict = TBC_UNKNOWN; cause = TBC_CAUSE_VISITED_FULL; break; }
+    }
     iterations++; expanded += np;
     SEG(0);
 
@@ -265,7 +322,6 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
       }
       const uint64_t vb = __ballot(viable);
       probes += (uint64_t)__popcll(vb);
-      if ((uint32_t)visited + 64u > full_at) { verdict = TBC_UNKNOWN; cause = TBC_CAUSE_VISITED_FULL; break; }
 
       // the child's front: its open-call list (issued now, consumed at push; hidden under the probe)
       uint32_t co0 = 0, co1 = 0, cnc = 0;
@@ -385,7 +441,7 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
       if (maxf) out->prev_ok_op = ret_op[maxf - 1];
     }
     out->steps = probes; out->visited = visited; out->probes = probes; out->backtracks = expanded;
-    out->max_depth = max_sp; out->bucket_reads = rounds;
+    out->max_depth = max_sp; out->bucket_reads = rounds; out->tab_log2 = cap_log2;
   }
   if (A.dbg && lane == 0) {
     A.dbg[4] = 0x300u + hidx; A.dbg[16] = (uint32_t)verdict; A.dbg[17] = (uint32_t)iterations;
