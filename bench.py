@@ -38,7 +38,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("TBC_BENCH_BATCH", "4096")),
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("TBC_BENCH_BATCH", "16384")),
                     help="histories per GPU per step")
     ap.add_argument("--ops", type=int, default=10000)
     ap.add_argument("--procs", type=int, default=64)
@@ -47,7 +47,7 @@ def main():
     ap.add_argument("--info", type=float, default=0.0, help="crashed-op (:info) rate")
     ap.add_argument("--width", type=int, default=int(os.environ.get("TBC_BENCH_WIDTH", "4")),
                     help="configs expanded per iteration: 1 = sequential knossos.wgl order, 2..16 = wide schedule")
-    ap.add_argument("--visited-per-op", type=int, default=0, help="first visited-set capacity per op (0 = library default 64)")
+    ap.add_argument("--visited-per-op", type=int, default=32, help="first visited-set capacity per op (0 = library default 64)")
     ap.add_argument("--cpu-sample", type=int, default=256, help="histories timed on the CPU oracle (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
@@ -118,6 +118,15 @@ def main():
         alg_bytes = 16 * dup + 32 * counters["visited"]
         k_ms = statistics.mean(search_ns) / 1e6
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        traffic = None
+        try:   # HBM bytes per launch from the committed rocprofv3 PMC passes, when they cover this very config
+            with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as fh:
+                for e in json.load(fh)["entries"]:
+                    if (e["histories_per_gpu"], e["search_width"], e["visited_per_op"], e["ops"], e["procs"], e["busy"], e["info"]) == \
+                       (B, args.width, args.visited_per_op, args.ops, args.procs, args.busy, args.info):
+                        traffic = e["traffic_bytes"]
+        except (OSError, KeyError, ValueError):
+            pass
         line = {
             "metric": "histories/sec, 10k-op/64-proc cas-register histories (time-to-verdict ms in extra)",
             "value": round(value, 2), "unit": "histories/s",
@@ -130,7 +139,7 @@ def main():
                        "search_width": args.width,
                        "parallelism": f"independent histories sharded over {world} GPU(s), no collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                          "kernel": "wgl_search_kernel" if args.width == 1 else "wgl_beam_kernel", "kernel_ms": round(k_ms, 3),
                          "probes_per_launch": counters["probes"], "new_configs_per_launch": counters["visited"],
                          "algorithmic_bytes_per_launch": alg_bytes},
