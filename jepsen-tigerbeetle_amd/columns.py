@@ -50,6 +50,7 @@ class OpColumns:
     ret_pos: np.ndarray   # uint32, POS_CRASHED for :info
     n_events: int
     n_process: int
+    pool: np.ndarray = None   # int32 values of wide ops (multi-register micro-ops), or None
 
     def __len__(self):
         return len(self.f)
@@ -64,14 +65,18 @@ class OpColumns:
         o.process = _p(self.process, C.c_int32)
         o.inv_pos = _p(self.inv_pos, C.c_uint32)
         o.ret_pos = _p(self.ret_pos, C.c_uint32)
-        o.pool = None
-        o.pool_len = 0
+        if self.pool is not None and len(self.pool):
+            o.pool = _p(self.pool, C.c_int32)
+            o.pool_len = len(self.pool)
+        else:
+            o.pool = None
+            o.pool_len = 0
         o.n_process = self.n_process
         return o
 
     def as_dict(self):
         return {"f": self.f, "a": self.a, "b": self.b, "process": self.process,
-                "inv_pos": self.inv_pos, "ret_pos": self.ret_pos, "n_process": self.n_process}
+                "inv_pos": self.inv_pos, "ret_pos": self.ret_pos, "n_process": self.n_process, "pool": self.pool}
 
 
 def pair_events(ev: EventColumns) -> OpColumns:

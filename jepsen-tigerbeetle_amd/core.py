@@ -12,11 +12,12 @@ from . import _native as N
 from .columns import OpColumns, _p
 
 
-def make_model(kind, init=N.NIL, table=None):
+def make_model(kind, init=N.NIL, table=None, n_keys=0):
     """-> (N.Model, keepalive).  `table`: (n_states, n_classes) uint16 for MODEL_TABLE."""
     m = N.Model()
     m.kind = kind
     m.init = init
+    m.n_keys = n_keys
     keep = None
     if table is not None:
         t = np.ascontiguousarray(table, np.uint16)
@@ -93,6 +94,16 @@ class Batch:
         self._cols = OpColumns(cat("f", np.uint8), cat("a", np.int32), cat("b", np.int32),
                                cat("process", np.int32), cat("inv_pos", np.uint32), cat("ret_pos", np.uint32),
                                n_events=0, n_process=0)
+        if any(h.pool is not None and len(h.pool) for h in histories):
+            # one pool for the batch: shift each history's offsets (wide ops keep their pool offset in `a`)
+            pools, shift, a_cols = [], 0, []
+            for h in histories:
+                p = h.pool if h.pool is not None else np.zeros(0, np.int32)
+                a_cols.append(np.where(h.f == N.F_TXN, h.a + shift, h.a).astype(np.int32))
+                pools.append(np.asarray(p, np.int32))
+                shift += len(p)
+            self._cols.a = np.concatenate(a_cols)
+            self._cols.pool = np.ascontiguousarray(np.concatenate(pools))
         for name in ("f", "a", "b", "process", "inv_pos", "ret_pos"):
             setattr(self._cols, name, np.ascontiguousarray(getattr(self._cols, name)))
         d = N.BatchDesc()

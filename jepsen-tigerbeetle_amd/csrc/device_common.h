@@ -33,16 +33,33 @@ struct Model {
   uint32_t kind;
   const uint16_t* table;
   uint32_t n_classes;
+  const int32_t* pool;     // wide op values (multi-register micro-ops: {f, key, value} triples)
+
+  // multi-register: :f :txn, value = [[f k v] ...], atomic.  State = 4 bits per key (0 = nil, v+1).
+  __device__ __forceinline__ bool txn(int32_t st, int32_t a, int32_t b, int32_t* out) const {
+    uint32_t s = (uint32_t)st;
+    bool ok = true;
+    for (int32_t i = 0; i < b; i++) {
+      const int32_t mf = pool[a + 3 * i], k = pool[a + 3 * i + 1], v = pool[a + 3 * i + 2];
+      const uint32_t cur = (s >> (4 * k)) & 15u;
+      if (mf == 0) ok = ok && (v == TBC_NIL || cur == (uint32_t)(v + 1));
+      else s = (s & ~(15u << (4 * k))) | ((uint32_t)(v + 1) << (4 * k));
+    }
+    *out = (int32_t)s;
+    return ok;
+  }
   // knossos.model/step: may op (f,a,b) be applied in state st?
-  __device__ __forceinline__ bool ok(int32_t st, uint32_t f, int32_t a) const {
+  __device__ __forceinline__ bool ok(int32_t st, uint32_t f, int32_t a, int32_t b) const {
     if (kind == TBC_MODEL_MUTEX) return (f == TBC_F_ACQUIRE && st == 0) || (f == TBC_F_RELEASE && st == 1);
     if (kind == TBC_MODEL_TABLE) return f == TBC_F_CLASS && table[(uint32_t)st * n_classes + (uint32_t)a] != TBC_TABLE_INCONSISTENT;
+    if (kind == TBC_MODEL_MULTI_REGISTER) { int32_t s2; return f == TBC_F_TXN && txn(st, a, b, &s2); }
     // register / cas-register (pack rejected :cas for plain registers)
     return f == TBC_F_WRITE || (f == TBC_F_READ && (a == TBC_NIL || a == st)) || (f == TBC_F_CAS && a == st);
   }
   __device__ __forceinline__ int32_t apply(int32_t st, uint32_t f, int32_t a, int32_t b) const {
     if (kind == TBC_MODEL_MUTEX) return f == TBC_F_ACQUIRE ? 1 : 0;
     if (kind == TBC_MODEL_TABLE) return (int32_t)table[(uint32_t)st * n_classes + (uint32_t)a];
+    if (kind == TBC_MODEL_MULTI_REGISTER) { int32_t s2 = st; (void)txn(st, a, b, &s2); return s2; }
     return f == TBC_F_WRITE ? a : (f == TBC_F_CAS ? b : st);
   }
 };

@@ -37,6 +37,16 @@ __device__ __forceinline__ uint32_t ld_agent(const uint32_t* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+__device__ __forceinline__ bool txn_ok(const PackArgs& A, int32_t a, int32_t b) {
+  if (a < 0 || b < 0 || (uint64_t)a + 3ull * (uint64_t)b > A.pool_len) return false;
+  for (int32_t i = 0; i < b; i++) {
+    const int32_t mf = A.pool_vals[a + 3 * i], k = A.pool_vals[a + 3 * i + 1], v = A.pool_vals[a + 3 * i + 2];
+    if ((mf != 0 && mf != 1) || k < 0 || (uint32_t)k >= A.n_keys || k >= 8) return false;
+    if (!(v == TBC_NIL && mf == 0) && (v < 0 || v > 13)) return false;
+  }
+  return true;
+}
+
 __device__ __forceinline__ bool op_ok_for_model(uint32_t kind, uint32_t f, int32_t a, uint32_t n_classes) {
   switch (kind) {
     case TBC_MODEL_REGISTER: return f == TBC_F_READ || f == TBC_F_WRITE;
@@ -85,7 +95,8 @@ __global__ __launch_bounds__(256) void pack_kernel(PackArgs A) {
       bool bad = iv >= E || p < 0 || (uint32_t)p >= W || (i > 0 && inv[i - 1] >= iv);
       if (rt != TBC_POS_CRASHED) bad = bad || rt <= iv || rt >= E;
       if (bad) { atomicOr(&s_err, (uint32_t)TBC_ERR_BAD_HISTORY); continue; }
-      if (!op_ok_for_model(A.model_kind, f[i], a[i], A.n_classes)) { atomicOr(&s_err, 0x100u | (uint32_t)TBC_ERR_MODEL); continue; }
+      if (!(A.model_kind == TBC_MODEL_MULTI_REGISTER ? (f[i] == TBC_F_TXN && txn_ok(A, a[i], b[i]))
+                                                    : op_ok_for_model(A.model_kind, f[i], a[i], A.n_classes))) { atomicOr(&s_err, 0x100u | (uint32_t)TBC_ERR_MODEL); continue; }
       if (rt != TBC_POS_CRASHED) { atomicOr(&bm[rt >> 5], 1u << (rt & 31)); atomicAdd(&s_done, 1u); }
       atomicAdd(&s_cnt[p], 1u);
     }

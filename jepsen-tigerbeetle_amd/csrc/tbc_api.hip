@@ -113,6 +113,8 @@ struct tbc_batch {
   DevBuf<uint64_t> d_tab;
   DevBuf<DevResult> d_results;
   DevBuf<uint16_t> d_table;
+  DevBuf<int32_t> d_pool_vals;
+  uint32_t pool_len = 0;
   // wide schedule (search_width > 1)
   uint32_t width = 1;
   std::vector<BeamHist> bh;
@@ -133,7 +135,7 @@ struct tbc_batch {
     d_f.release(); d_a.release(); d_b.release(); d_proc.release(); d_inv.release(); d_ret.release();
     d_hist.release(); d_rec.release(); d_seg.release(); d_ret_slot.release(); d_ret_op.release();
     d_bitmap.release(); d_wpre.release(); d_frames.release(); d_witness.release(); d_work.release();
-    d_queue.release(); d_tab.release(); d_results.release(); d_table.release();
+    d_queue.release(); d_tab.release(); d_results.release(); d_table.release(); d_pool_vals.release();
     d_bh.release(); d_off.release(); d_ncr.release(); d_lst.release(); d_crashed.release(); d_stack.release();
     d_occ.release(); d_btab.release(); d_opinfo.release(); d_pool.release(); d_pool_cursor.release();
     for (auto& e : ev) if (e) (void)hipEventDestroy(e);
@@ -168,6 +170,10 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
   HIP_TRY(hipSetDevice(B->device));
   switch (model->kind) {
     case TBC_MODEL_REGISTER: case TBC_MODEL_CAS_REGISTER: case TBC_MODEL_MUTEX: break;
+    case TBC_MODEL_MULTI_REGISTER:
+      if (model->n_keys == 0 || model->n_keys > 8) { set_error("multi-register: 1..8 keys on the device (more: use the memo table)"); return TBC_ERR_MODEL; }
+      if (desc->cols.pool_len && !desc->cols.pool) { set_error("multi-register needs the value pool"); return TBC_ERR_INVALID_ARG; }
+      break;
     case TBC_MODEL_TABLE:
       if (!model->table || model->n_states == 0 || model->n_classes == 0 || model->n_states > 0xFFFEu) {
         set_error("table model needs table, n_states, n_classes");
@@ -265,6 +271,9 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
       if ((s = B->d_pool.alloc(words))) return s;
     }
   }
+  B->pool_len = desc->cols.pool ? desc->cols.pool_len : 0;
+  if ((s = B->d_pool_vals.alloc(B->pool_len))) return s;
+  if (B->pool_len) HIP_TRY(hipMemcpy(B->d_pool_vals.p, desc->cols.pool, (size_t)B->pool_len * 4, hipMemcpyHostToDevice));
   if (model->kind == TBC_MODEL_TABLE) {
     const size_t tn = (size_t)model->n_states * model->n_classes;
     B->table_host.assign(model->table, model->table + tn);
@@ -342,6 +351,7 @@ static SearchArgs make_search_args(tbc_batch* B, uint64_t* tab, uint32_t n_work)
   a.max_steps = B->opts.max_steps;
   a.time_limit_ticks = B->opts.time_limit_ms * 100000ull;   // wall_clock64 runs at 100 MHz
   a.dbg = debug_words();
+  a.pool_vals = B->d_pool_vals.p;
   return a;
 }
 
@@ -361,6 +371,7 @@ static BeamArgs make_beam_args(tbc_batch* B, uint64_t* tab, uint32_t* stack, uin
   a.max_steps = B->opts.max_steps;
   a.time_limit_ticks = B->opts.time_limit_ms * 100000ull;
   a.dbg = debug_words();
+  a.pool_vals = B->d_pool_vals.p;
   a.pool = B->d_pool.p; a.pool_cursor = B->d_pool_cursor.p; a.pool_words = B->d_pool.n;
   {
     const uint64_t max_bytes = B->opts.max_visited_bytes ? B->opts.max_visited_bytes : (1ull << 30);
@@ -455,6 +466,7 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results) {
   pa.ret_slot = B->d_ret_slot.p; pa.ret_op = B->d_ret_op.p; pa.bitmap = B->d_bitmap.p; pa.wpre = B->d_wpre.p;
   pa.scratch = B->d_frames.p; pa.frame_words = B->frame_words; pa.n_hist = nh;
   pa.model_kind = B->model.kind; pa.n_classes = B->model.n_classes; pa.dbg = debug_words();
+  pa.pool_vals = B->d_pool_vals.p; pa.pool_len = B->pool_len; pa.n_keys = B->model.n_keys;
   launch_pack(pa, s);
   HIP_TRY(hipGetLastError());
   if (beam) {

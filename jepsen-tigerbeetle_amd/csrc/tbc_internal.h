@@ -80,6 +80,9 @@ struct PackArgs {
   uint32_t n_classes;
   uint32_t pad;
   uint32_t* dbg;
+  const int32_t* pool_vals;
+  uint32_t pool_len;
+  uint32_t n_keys;
 };
 
 struct SearchArgs {
@@ -104,6 +107,7 @@ struct SearchArgs {
   uint64_t max_steps;
   uint64_t time_limit_ticks;  // wall_clock64 ticks (100 MHz), 0 = none
   uint32_t* dbg;              // optional host-mapped progress words (TBC_DEBUG=1), else null
+  const int32_t* pool_vals;   // wide op values (multi-register micro-ops)
 };
 
 // ---- wide ("beam") schedule of the search: extra per-history layout built by pack_open_kernel
@@ -176,6 +180,7 @@ struct BeamArgs {
   uint64_t pool_words;
   uint32_t max_tab_log2;             // growth stops here (tbc_opts.max_visited_bytes)
   uint32_t pad2;
+  const int32_t* pool_vals;          // wide op values (multi-register micro-ops)
 };
 
 void launch_pack_open(const PackOpenArgs& a, void* stream);

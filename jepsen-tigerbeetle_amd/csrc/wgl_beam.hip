@@ -92,7 +92,7 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
   // K parents per iteration, G = 64 / K lanes (candidate slots) per parent per round
   const uint32_t K = A.width, gshift = 6u - (31u - (uint32_t)__builtin_clz(K)), G = 1u << gshift;
   DevResult* out = A.results + hidx;
-  Model model{A.model_kind, A.table, A.n_classes};
+  Model model{A.model_kind, A.table, A.n_classes, A.pool_vals};
 
   uint64_t* p_k0 = reinterpret_cast<uint64_t*>(lds);
   uint64_t* p_M = p_k0 + 16;
@@ -286,7 +286,7 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
       bool lin = false;
 #pragma unroll
       for (int j = 0; j < MW; j++) if ((p >> 6) == (uint32_t)j) lin = (Mp[j] >> (p & 63u)) & 1ull;
-      const bool viable = act && !lin && model.ok(st, f, oi.a);
+      const bool viable = act && !lin && model.ok(st, f, oi.a, oi.b);
       int32_t st2 = st;
       uint32_t fi2 = fi;
       uint64_t M2[MW];

@@ -92,6 +92,8 @@ class Encoded:
                     raise ValueError(f"op {op['f']!r} is not understood by {model!r}")
                 f[r] = fmap[op["f"]]
             self.native_model = core.make_model(N.MODEL_MUTEX, 1 if model.locked else 0)
+        elif isinstance(model, M.MultiRegister) and self._multi_register_direct(model, hist, typ, f, a, b):
+            pass
         else:
             # any other Model: knossos.model.memo -> transition table
             self.intern = None
@@ -104,6 +106,49 @@ class Encoded:
             self.native_model = core.make_model(N.MODEL_TABLE, 0, info["table"])
         self.events = EventColumns(typ, proc, f, a, b)
         self.ops = pair_events(self.events)
+        if getattr(self, "pool", None) is not None:
+            self.ops.pool = self.pool
+
+    def _multi_register_direct(self, model, hist, typ, f, a, b):
+        """Device multi-register: <= 8 keys, <= 14 distinct values; txn micro-ops go to the value pool
+        as {f, key, value} triples (op a = offset, b = count).  Returns False to fall back to the memo table."""
+        keys, vals = {}, [v for _, v in model.values]
+        for k, _ in model.values:
+            keys.setdefault(k, len(keys))
+        for op in hist:
+            if op["f"] != "txn":
+                raise ValueError(f"op {op['f']!r} is not understood by {model!r}")
+            for mf, k, v in (op.get("value") or []):
+                if mf not in ("r", "read", "w", "write"):
+                    raise ValueError(f"unknown micro-op {mf!r}")
+                keys.setdefault(k, len(keys))
+                vals.append(v)
+        self.intern = _Interner(vals)
+        if not self.intern.identity:
+            dense = self.intern
+        else:   # small ints may still be out of the 0..13 range: intern them densely as well
+            dense = _Interner([("v", v) for v in vals if v is not None])
+            dense.enc0, dense.dec0 = dense.enc, dense.dec
+            dense.enc = lambda v: N.NIL if v is None else dense.enc0(("v", v))
+            dense.dec = lambda x: None if x == N.NIL else dense.dec0(x)[1]
+            self.intern = dense
+        if len(keys) > 8 or len(dense.back) > 14:
+            return False
+        pool = []
+        for r, op in enumerate(hist):
+            f[r] = N.F_TXN
+            a[r] = len(pool)
+            mops = op.get("value") or []
+            b[r] = len(mops)
+            for mf, k, v in mops:
+                pool += [0 if mf in ("r", "read") else 1, keys[k], dense.enc(v)]
+        self.pool = np.array(pool, np.int32)
+        self.mr_keys = keys
+        init = 0
+        for k, v in model.values:
+            init |= (dense.enc(v) + 1) << (4 * keys[k]) if v is not None else 0
+        self.native_model = core.make_model(N.MODEL_MULTI_REGISTER, init, n_keys=max(1, len(keys)))
+        return True
 
     # ---- decoding helpers
     def op_invocation(self, i):
@@ -118,6 +163,13 @@ class Encoded:
             return self.table_info["states"][s]
         if isinstance(self.model, M.Mutex):
             return M.Mutex(bool(s))
+        if isinstance(self.model, M.MultiRegister):
+            vals = {}
+            for k, i in self.mr_keys.items():
+                nib = (s >> (4 * i)) & 15
+                if nib:
+                    vals[k] = self.intern.dec(nib - 1)
+            return M.MultiRegister(tuple(sorted(vals.items())))
         return type(self.model)(self.intern.dec(s))
 
 

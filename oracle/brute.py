@@ -22,7 +22,8 @@ from itertools import permutations
 NIL = -(2 ** 31)
 CRASHED = 0xFFFFFFFF
 READ, WRITE, CAS, ACQUIRE, RELEASE, CLASS = 0, 1, 2, 3, 4, 8
-REGISTER, CAS_REGISTER, MUTEX, TABLE = 0, 1, 2, 3
+REGISTER, CAS_REGISTER, MUTEX, TABLE, MULTI_REGISTER = 0, 1, 2, 3, 4
+TXN = 6
 
 
 def step(model, state, f, a, b):
@@ -42,6 +43,18 @@ def step(model, state, f, a, b):
         if f == RELEASE:
             return 0 if state == 1 else None
         return None
+    if kind == MULTI_REGISTER:
+        if f != TXN:
+            return None
+        s, pool, ok = state, model["pool"], True
+        for i in range(b):
+            mf, k, v = (int(x) for x in pool[a + 3 * i: a + 3 * i + 3])
+            cur = (s >> (4 * k)) & 15
+            if mf == 0:
+                ok = ok and (v == NIL or cur == v + 1)
+            else:
+                s = (s & ~(15 << (4 * k))) | ((v + 1) << (4 * k))
+        return s if ok else None
     if kind == TABLE:
         t = model["table"][state][a]
         return None if t == 0xFFFF else t

@@ -20,6 +20,8 @@
  *   cas-register  + :cas [cur new] -> new iff cur = value, else inconsistent
  *   mutex         :acquire inconsistent if held ; :release inconsistent if free
  *   table         next = table[state*n_classes + class] (knossos.model.memo)
+ *   multi-register :txn [[f k v] ...] applied atomically; a micro-read is ok iff v is
+ *                 nil or equals the key's value.  State = 4 bits per key (0 nil, v+1).
  */
 #ifndef ORACLE_MODEL_H
 #define ORACLE_MODEL_H
@@ -28,13 +30,15 @@
 #define O_NIL INT32_MIN
 #define O_CRASHED 0xFFFFFFFFu
 enum { O_READ = 0, O_WRITE = 1, O_CAS = 2, O_ACQUIRE = 3, O_RELEASE = 4, O_CLASS = 8 };
-enum { O_REGISTER = 0, O_CAS_REGISTER = 1, O_MUTEX = 2, O_TABLE = 3 };
+enum { O_REGISTER = 0, O_CAS_REGISTER = 1, O_MUTEX = 2, O_TABLE = 3, O_MULTI_REGISTER = 4 };
+enum { O_TXN = 6 };
 
 typedef struct oracle_model {
   uint32_t kind;
   int32_t init;
   const uint16_t* table;
   uint32_t n_states, n_classes;
+  const int32_t* pool;   /* multi-register: {f, key, value} triples; op a = offset, b = count */
 } oracle_model;
 
 /* returns 1 and sets *next if op (f,a,b) may be applied in `state`, else 0 */
@@ -51,6 +55,18 @@ static inline int oracle_step(const oracle_model* m, int32_t state, uint8_t f,
       if (f == O_ACQUIRE) { *next = 1; return state == 0; }
       if (f == O_RELEASE) { *next = 0; return state == 1; }
       return 0;
+    case O_MULTI_REGISTER: {
+      if (f != O_TXN) return 0;
+      uint32_t s = (uint32_t)state; int ok = 1;
+      for (int32_t i = 0; i < b; i++) {
+        int32_t mf = m->pool[a + 3 * i], k = m->pool[a + 3 * i + 1], v = m->pool[a + 3 * i + 2];
+        uint32_t cur = (s >> (4 * k)) & 15u;
+        if (mf == 0) { if (!(v == O_NIL || cur == (uint32_t)(v + 1))) ok = 0; }
+        else s = (s & ~(15u << (4 * k))) | ((uint32_t)(v + 1) << (4 * k));
+      }
+      *next = (int32_t)s;
+      return ok;
+    }
     case O_TABLE: {
       if (f != O_CLASS || (uint32_t)a >= m->n_classes || (uint32_t)state >= m->n_states) return 0;
       uint16_t t = m->table[(uint32_t)state * m->n_classes + (uint32_t)a];

@@ -21,7 +21,7 @@ CRASHED = 0xFFFFFFFF
 class OracleModel(C.Structure):
     _fields_ = [("kind", C.c_uint32), ("init", C.c_int32),
                 ("table", C.POINTER(C.c_uint16)),
-                ("n_states", C.c_uint32), ("n_classes", C.c_uint32)]
+                ("n_states", C.c_uint32), ("n_classes", C.c_uint32), ("pool", C.POINTER(C.c_int32))]
 
 
 class OracleResult(C.Structure):
@@ -58,6 +58,10 @@ def _model(model):
         m.n_states, m.n_classes = t.shape
         m.table = t.ctypes.data_as(C.POINTER(C.c_uint16))
         keep = t
+    if model.get("pool") is not None:
+        p = np.ascontiguousarray(model["pool"], dtype=np.int32)
+        m.pool = p.ctypes.data_as(C.POINTER(C.c_int32))
+        keep = (keep, p)
     return m, keep
 
 

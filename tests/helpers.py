@@ -29,3 +29,66 @@ def oracle_model(name):
 def op_tuples(ops):
     return [(int(ops.f[i]), int(ops.a[i]), int(ops.b[i]), int(ops.inv_pos[i]), int(ops.ret_pos[i]))
             for i in range(len(ops))]
+
+
+def multi_register_history(n_ops, n_procs, seed, n_keys=4, n_values=4, busy=0.4, info=0.0, corrupt=False):
+    """Seeded Jepsen-shaped multi-register history (:f :txn, value [[f k v] ...]) from a simulated
+    atomic store: each txn takes effect at a random instant inside its interval (valid by
+    construction unless `corrupt` plants an impossible read)."""
+    import heapq
+    import random
+    rng = random.Random(seed)
+    state = {}
+    heap, seq, hist = [], 0, []
+    think = (1.0 - busy) / busy
+    pid = list(range(n_procs))
+    next_pid = n_procs
+    for w in range(n_procs):
+        heapq.heappush(heap, (rng.expovariate(1.0 / (think + 0.05)), seq, w, "inv")); seq += 1
+    cur = {}
+    issued = 0
+    while heap:
+        t, _, w, kind = heapq.heappop(heap)
+        if kind == "inv":
+            if issued >= n_ops:
+                continue
+            issued += 1
+            mops = []
+            for _ in range(rng.randint(1, 3)):
+                k = "k%d" % rng.randrange(n_keys)
+                mops.append(["r", k, None] if rng.random() < 0.5 else ["w", k, rng.randrange(n_values)])
+            crashed = rng.random() < info
+            cur[w] = {"mops": mops, "crashed": crashed, "effect": (rng.random() < 0.5) if crashed else True, "res": None}
+            hist.append({"type": "invoke", "f": "txn", "value": [list(m) for m in mops], "process": pid[w]})
+            L = 0.02 + rng.expovariate(1.0)
+            heapq.heappush(heap, (t + rng.random() * L, seq, w, "eff")); seq += 1
+            heapq.heappush(heap, (t + L, seq, w, "ret")); seq += 1
+        elif kind == "eff":
+            c = cur[w]
+            if c["effect"]:
+                res = []
+                for f, k, v in c["mops"]:
+                    if f == "r":
+                        res.append(["r", k, state.get(k)])
+                    else:
+                        state[k] = v
+                        res.append(["w", k, v])
+                c["res"] = res
+        else:
+            c = cur[w]
+            if c["crashed"]:
+                hist.append({"type": "info", "f": "txn", "value": [list(m) for m in c["mops"]], "process": pid[w]})
+                pid[w] = next_pid
+                next_pid += 1
+            else:
+                hist.append({"type": "ok", "f": "txn", "value": c["res"], "process": pid[w]})
+            heapq.heappush(heap, (t + rng.expovariate(1.0 / think) + 1e-9, seq, w, "inv")); seq += 1
+    if corrupt:
+        oks = [i for i, o in enumerate(hist) if o["type"] == "ok" and any(m[0] == "r" for m in o["value"])]
+        if oks:
+            i = oks[len(oks) * 2 // 3]
+            for m in hist[i]["value"]:
+                if m[0] == "r":
+                    m[2] = n_values + 3     # a value nobody writes
+                    break
+    return hist
