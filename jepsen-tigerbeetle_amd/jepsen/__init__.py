@@ -3,4 +3,4 @@ jepsen.checker (Checker, linearizable, compose) and jepsen.independent
 (tuple, checker) -- the call sites the reference composes its checkers with
 (/root/reference/src/tigerbeetle/core.clj:139-146,
 workloads/set_full.clj:155-158, tests/ledger.clj:363-367)."""
-from . import checker, independent  # noqa: F401
+from . import checker, edn, independent  # noqa: F401
