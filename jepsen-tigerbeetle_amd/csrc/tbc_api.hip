@@ -115,6 +115,7 @@ struct tbc_batch {
   DevBuf<uint16_t> d_table;
   DevBuf<int32_t> d_pool_vals;
   uint32_t pool_len = 0;
+  DevBuf<uint64_t> d_cfg;           // configs at the failing front, kCfgCap records per history
   // wide schedule (search_width > 1)
   uint32_t width = 1;
   std::vector<BeamHist> bh;
@@ -135,7 +136,7 @@ struct tbc_batch {
     d_f.release(); d_a.release(); d_b.release(); d_proc.release(); d_inv.release(); d_ret.release();
     d_hist.release(); d_rec.release(); d_seg.release(); d_ret_slot.release(); d_ret_op.release();
     d_bitmap.release(); d_wpre.release(); d_frames.release(); d_witness.release(); d_work.release();
-    d_queue.release(); d_tab.release(); d_results.release(); d_table.release(); d_pool_vals.release();
+    d_queue.release(); d_tab.release(); d_results.release(); d_table.release(); d_pool_vals.release(); d_cfg.release();
     d_bh.release(); d_off.release(); d_ncr.release(); d_lst.release(); d_crashed.release(); d_stack.release();
     d_occ.release(); d_btab.release(); d_opinfo.release(); d_pool.release(); d_pool_cursor.release();
     for (auto& e : ev) if (e) (void)hipEventDestroy(e);
@@ -271,6 +272,7 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
       if ((s = B->d_pool.alloc(words))) return s;
     }
   }
+  if ((s = B->d_cfg.alloc((uint64_t)nh * kCfgCap * (2 + B->mask_words)))) return s;
   B->pool_len = desc->cols.pool ? desc->cols.pool_len : 0;
   if ((s = B->d_pool_vals.alloc(B->pool_len))) return s;
   if (B->pool_len) HIP_TRY(hipMemcpy(B->d_pool_vals.p, desc->cols.pool, (size_t)B->pool_len * 4, hipMemcpyHostToDevice));
@@ -352,6 +354,7 @@ static SearchArgs make_search_args(tbc_batch* B, uint64_t* tab, uint32_t n_work)
   a.time_limit_ticks = B->opts.time_limit_ms * 100000ull;   // wall_clock64 runs at 100 MHz
   a.dbg = debug_words();
   a.pool_vals = B->d_pool_vals.p;
+  a.cfg = B->d_cfg.p;
   return a;
 }
 
@@ -372,6 +375,7 @@ static BeamArgs make_beam_args(tbc_batch* B, uint64_t* tab, uint32_t* stack, uin
   a.time_limit_ticks = B->opts.time_limit_ms * 100000ull;
   a.dbg = debug_words();
   a.pool_vals = B->d_pool_vals.p;
+  a.cfg = B->d_cfg.p;
   a.pool = B->d_pool.p; a.pool_cursor = B->d_pool_cursor.p; a.pool_words = B->d_pool.n;
   {
     const uint64_t max_bytes = B->opts.max_visited_bytes ? B->opts.max_visited_bytes : (1ull << 30);
@@ -430,6 +434,53 @@ static tbc_status scratch_pass(tbc_batch* B, const std::vector<uint32_t>& grp, c
   if (e == hipSuccess) e = hipStreamSynchronize(s);
   big.release(); bstack.release();
   if (e != hipSuccess) { set_error("scratch pass failed: %s", hipGetErrorString(e)); return TBC_ERR_HIP; }
+  return TBC_OK;
+}
+
+// :configs of an invalid verdict: the (state, linearized pending calls) pairs stuck at the failing
+// completion, sorted, first TBC_MAX_FINAL_CONFIGS.  The pending calls are recomputed from the op
+// columns of that one history (copied back on demand -- invalid verdicts are rare).
+static tbc_status fill_configs(tbc_batch* B, uint32_t h, const DevResult& d, tbc_result* r) {
+  const uint32_t MW = B->mask_words, RW = 2 + MW;
+  const uint32_t got = std::min<uint32_t>(d.n_configs, kCfgCap);
+  if (got == 0 || d.fail_op == TBC_NO_OP) return TBC_OK;
+  std::vector<uint64_t> rec((size_t)got * RW);
+  HIP_TRY(hipMemcpy(rec.data(), B->d_cfg.p + (uint64_t)h * kCfgCap * RW, rec.size() * 8, hipMemcpyDeviceToHost));
+  const Hist& H = B->hist[h];
+  const uint32_t n = H.n_ops;
+  std::vector<int32_t> proc(n);
+  std::vector<uint32_t> inv(n), ret(n);
+  HIP_TRY(hipMemcpy(proc.data(), B->d_proc.p + H.op_off, (size_t)n * 4, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(inv.data(), B->d_inv.p + H.op_off, (size_t)n * 4, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(ret.data(), B->d_ret.p + H.op_off, (size_t)n * 4, hipMemcpyDeviceToHost));
+  const uint32_t P = ret[d.fail_op];                 // history position of the failing completion
+  std::vector<uint32_t> pending;                     // calls open at that position, invocation order
+  for (uint32_t i = 0; i < n && inv[i] < P; i++)
+    if (ret[i] == TBC_POS_CRASHED || ret[i] >= P) pending.push_back(i);
+  std::vector<uint32_t> order(got);
+  for (uint32_t i = 0; i < got; i++) order[i] = i;
+  std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+    const uint64_t* a = &rec[(size_t)x * RW]; const uint64_t* b = &rec[(size_t)y * RW];
+    const int32_t sa = (int32_t)(a[0] >> 32), sb = (int32_t)(b[0] >> 32);
+    if (sa != sb) return sa < sb;
+    for (uint32_t j = 0; j < MW; j++) if (a[1 + j] != b[1 + j]) return a[1 + j] < b[1 + j];
+    return false;
+  });
+  r->n_configs = std::min<uint32_t>(got, TBC_MAX_FINAL_CONFIGS);
+  for (uint32_t c = 0; c < r->n_configs; c++) {
+    const uint64_t* e = &rec[(size_t)order[c] * RW];
+    tbc_config& o = r->configs[c];
+    o.state = (int32_t)(e[0] >> 32);
+    o.last_op = (uint32_t)e[1 + MW];
+    o.n_pending = (uint32_t)pending.size();
+    o.n_linearized = 0; o.linearized_mask = 0;
+    for (size_t k = 0; k < pending.size(); k++) {
+      const uint32_t p = (uint32_t)proc[pending[k]];
+      const bool lin = (e[1 + (p >> 6)] >> (p & 63u)) & 1ull;
+      if (k < 16) { o.pending[k] = pending[k]; if (lin) o.linearized_mask |= 1u << k; }
+      o.n_linearized += lin;
+    }
+  }
   return TBC_OK;
 }
 
@@ -599,7 +650,11 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results) {
     r.valid = d.valid; r.cause = d.cause;
     r.analyzer = B->opts.algorithm == TBC_ALG_LINEAR ? TBC_ALG_LINEAR : TBC_ALG_WGL;
     r.fail_op = TBC_NO_OP; r.prev_ok_op = TBC_NO_OP;
-    if (d.valid == TBC_INVALID) { r.fail_op = d.fail_op; r.prev_ok_op = d.prev_ok_op; }
+    if (d.valid == TBC_INVALID) {
+      r.fail_op = d.fail_op; r.prev_ok_op = d.prev_ok_op;
+      tbc_status cs = fill_configs(B, h, d, &r);
+      if (cs != TBC_OK) return cs;
+    }
     if (d.valid == TBC_VALID) {
       r.final_state = d.final_state; r.n_witness = d.depth;
       if (B->opts.want_witness) r.witness = B->witness_host.data() + B->hist[h].op_off;

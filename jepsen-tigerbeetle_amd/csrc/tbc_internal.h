@@ -13,6 +13,7 @@ constexpr uint32_t kMaxSlots = 1024;       // 16 mask words x 64 lanes
 constexpr uint32_t kWavesPerBlock = 4;
 constexpr uint32_t kBlock = 64 * kWavesPerBlock;
 constexpr uint8_t kFNone = 0xFF;           // sentinel record: never a candidate
+constexpr uint32_t kCfgCap = 256;          // configs at the failing front copied back per invalid history
 
 // One op in the slot-major ("per process, in time order") layout the search
 // kernel walks.  32 bytes = two dwordx4 loads per cursor move.
@@ -108,6 +109,7 @@ struct SearchArgs {
   uint64_t time_limit_ticks;  // wall_clock64 ticks (100 MHz), 0 = none
   uint32_t* dbg;              // optional host-mapped progress words (TBC_DEBUG=1), else null
   const int32_t* pool_vals;   // wide op values (multi-register micro-ops)
+  uint64_t* cfg;              // kCfgCap records of (2 + mask_words) u64 per history: k0, M[], last op
 };
 
 // ---- wide ("beam") schedule of the search: extra per-history layout built by pack_open_kernel
@@ -181,6 +183,7 @@ struct BeamArgs {
   uint32_t max_tab_log2;             // growth stops here (tbc_opts.max_visited_bytes)
   uint32_t pad2;
   const int32_t* pool_vals;          // wide op values (multi-register micro-ops)
+  uint64_t* cfg;                     // as SearchArgs.cfg
 };
 
 void launch_pack_open(const PackOpenArgs& a, void* stream);

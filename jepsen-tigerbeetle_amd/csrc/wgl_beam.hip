@@ -406,6 +406,30 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) maxf = max(maxf, (uint32_t)__shfl_xor(maxf, d));
   maxf = rfl(maxf);
+  // ---- invalid: the configs stuck at the failing completion (knossos :configs), by a scan of the visited set
+  uint32_t n_cfg = 0;
+  if (verdict == TBC_INVALID && A.cfg) {
+    uint64_t* cfg = A.cfg + (uint64_t)hidx * kCfgCap * (2 + MW);
+    const uint64_t ncap = 1ull << cap_log2;
+    for (uint64_t s0 = 0; s0 < ncap; s0 += 64) {
+      const uint64_t* e = tab + (s0 + lane) * EW;
+      const uint64_t k0 = ld64(e);
+      const bool hit = (uint32_t)k0 == maxf + 1u;
+      const uint64_t hb = __ballot(hit);
+      if (hit) {
+        const uint32_t pos = n_cfg + (uint32_t)__popcll(hb & ((1ull << lane) - 1ull));
+        if (pos < kCfgCap) {
+          uint64_t* o = cfg + (uint64_t)pos * (2 + MW);
+          o[0] = k0;
+#pragma unroll
+          for (int j = 0; j < MW; j++) o[1 + j] = ld64(e + 1 + j);
+          const uint64_t pw = ld64(e + 1 + MW);
+          o[1 + MW] = (uint32_t)pw == kNone ? (uint64_t)TBC_NO_OP : (pw >> 32) - 1ull;
+        }
+      }
+      n_cfg += (uint32_t)__popcll(hb);
+    }
+  }
   uint32_t wlen = 0;
   if (verdict == TBC_VALID && R != 0) {
     // witness = ops along the parent chain of the winning config, then the winning op
@@ -433,7 +457,7 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
   }
   if (lane == 0) {
     out->valid = verdict; out->cause = cause; out->max_front = maxf; out->depth = wlen;
-    out->final_state = win_state; out->n_configs = 0;
+    out->final_state = win_state; out->n_configs = n_cfg;
     out->fail_op = TBC_NO_OP; out->prev_ok_op = TBC_NO_OP;
     if (verdict == TBC_INVALID) {
       const uint32_t* ret_op = A.ret_op + ret_off;

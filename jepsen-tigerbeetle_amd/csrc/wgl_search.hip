@@ -295,6 +295,28 @@ __device__ void search_one(const SearchArgs& A, const uint32_t hidx, uint32_t* r
     }
   }
 
+  // ---- invalid: the configs stuck at the failing completion (knossos :configs), by a scan of the visited set
+  uint32_t n_cfg = 0;
+  if (verdict == TBC_INVALID && A.cfg) {
+    uint64_t* cfg = A.cfg + (uint64_t)hidx * kCfgCap * (2 + MW);
+    for (uint64_t s0 = 0; s0 < cap; s0 += 64) {
+      const uint64_t* e = tab + (s0 + lane) * KW;
+      const uint64_t k0 = e[0];
+      const bool hit = (uint32_t)k0 == maxf + 1u;
+      const uint64_t hb = __ballot(hit);
+      if (hit) {
+        const uint32_t pos = n_cfg + (uint32_t)__popcll(hb & ((1ull << lane) - 1ull));
+        if (pos < kCfgCap) {
+          uint64_t* o = cfg + (uint64_t)pos * (2 + MW);
+          o[0] = k0;
+#pragma unroll
+          for (int j = 0; j < MW; j++) o[1 + j] = e[1 + j];
+          o[1 + MW] = (uint64_t)TBC_NO_OP;
+        }
+      }
+      n_cfg += (uint32_t)__popcll(hb);
+    }
+  }
   // ---- results
   if (A.dbg && lane == 0) { A.dbg[4] = 0x200u + hidx; A.dbg[16] = (uint32_t)verdict; A.dbg[17] = (uint32_t)steps; }
   if (verdict == TBC_VALID && A.witness) {
@@ -303,13 +325,14 @@ __device__ void search_one(const SearchArgs& A, const uint32_t hidx, uint32_t* r
   }
   if (lane == 0) {
     out->valid = verdict; out->cause = cause; out->max_front = maxf; out->depth = depth;
-    out->final_state = st; out->n_configs = 0;
+    out->final_state = st;
     out->fail_op = TBC_NO_OP; out->prev_ok_op = TBC_NO_OP;
     if (verdict == TBC_INVALID) {
       const uint32_t* ret_op = A.ret_op + ret_off;
       out->fail_op = ret_op[maxf];
       if (maxf) out->prev_ok_op = ret_op[maxf - 1];
     }
+    out->n_configs = n_cfg;
     out->steps = steps; out->visited = visited; out->probes = probes; out->backtracks = backtracks;
     out->max_depth = max_depth; out->bucket_reads = bucket_reads;
   }

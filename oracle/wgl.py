@@ -164,3 +164,24 @@ def check_beam(ops, model, width=16, max_probes=0, want_witness=True):
     for name, _ in BeamStats._fields_:
         out[name] = getattr(st, name)
     return out
+
+
+def last_configs(which="window", max_rows=4096):
+    """(total, rows) of the configs stuck at the failing completion in the LAST invalid run of
+    check(..., "window") / check_beam: rows = [state, mask_word0, ...] sorted by (state, mask)."""
+    fn = lib().wgl_window_last_configs if which == "window" else lib().wgl_beam_last_configs
+    fn.restype = C.c_uint32
+    buf = np.zeros((max_rows, 17), np.uint64)
+    flat = np.zeros(max_rows * 17, np.uint64)
+    kw = C.c_uint32(0)
+    total = fn(_p(flat, C.c_uint64), C.c_uint32(max_rows), C.byref(kw))
+    k = kw.value
+    rows = flat[: min(total, max_rows) * k].reshape(-1, k).copy() if k else np.zeros((0, 1), np.uint64)
+    out = []
+    for r in rows:
+        st = int(r[0] >> np.uint64(32))
+        if st >= 2 ** 31:
+            st -= 2 ** 32
+        out.append([st] + [int(x) for x in r[1:]])
+    del buf
+    return total, out

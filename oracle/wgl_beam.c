@@ -99,6 +99,22 @@ static uint32_t arena_add(arena* a, const uint64_t* k, uint32_t parent, uint32_t
   return id;
 }
 
+static uint64_t* g_bcfg = NULL; static uint32_t g_bcfg_n = 0, g_bcfg_kw = 0;
+static size_t g_bsort_kw;
+static int cmp_bcfg(const void* x, const void* y) {
+  const uint64_t* a = (const uint64_t*)x; const uint64_t* b = (const uint64_t*)y;
+  int32_t sa = (int32_t)(a[0] >> 32), sb = (int32_t)(b[0] >> 32);
+  if (sa != sb) return sa < sb ? -1 : 1;
+  for (size_t i = 1; i < g_bsort_kw; i++) if (a[i] != b[i]) return a[i] < b[i] ? -1 : 1;
+  return 0;
+}
+/* as wgl_window_last_configs, for the last invalid wide-schedule run */
+uint32_t wgl_beam_last_configs(uint64_t* out, uint32_t max, uint32_t* kw) {
+  *kw = g_bcfg_kw;
+  for (uint32_t i = 0; i < g_bcfg_n && i < max; i++) memcpy(out + (size_t)i * g_bcfg_kw, g_bcfg + (size_t)i * g_bcfg_kw, g_bcfg_kw * 8);
+  return g_bcfg_n;
+}
+
 int wgl_beam_check(uint32_t n, const uint8_t* f, const int32_t* a, const int32_t* b,
                    const int32_t* process, uint32_t n_process,
                    const uint32_t* inv_pos, const uint32_t* ret_pos,
@@ -251,6 +267,12 @@ int wgl_beam_check(uint32_t n, const uint8_t* f, const int32_t* a, const int32_t
   } else if (verdict == 0) {
     out->fail_op = ret_op[maxf];
     out->prev_ok_op = maxf ? ret_op[maxf - 1] : 0xFFFFFFFFu;
+    free(g_bcfg); g_bcfg_n = 0; g_bcfg_kw = KW;
+    g_bcfg = (uint64_t*)malloc(ar.n * KW * 8);
+    for (size_t i = 1; i < ar.n; i++)
+      if ((uint32_t)ar.keys[i * KW] == maxf + 1) { memcpy(g_bcfg + (size_t)g_bcfg_n * KW, ar.keys + i * KW, KW * 8); g_bcfg_n++; }
+    g_bsort_kw = KW;
+    qsort(g_bcfg, g_bcfg_n, KW * 8, cmp_bcfg);
   }
   free(rets); free(ret_rank); free(inv_rank); free(ret_op); free(off); free(ncr); free(lst); free(fill); free(crashed);
   free(ar.keys); free(ar.parent); free(ar.op); free(ar.slots); free(stack); free(key); free(ck);

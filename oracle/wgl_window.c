@@ -67,6 +67,23 @@ static int wset_add(wset* s, const uint64_t* k) {
   return wset_add_nogrow(s, k);
 }
 
+/* configs stuck at the failing completion of the LAST invalid run (test infrastructure: not re-entrant) */
+static uint64_t* g_cfg = NULL; static uint32_t g_cfg_n = 0, g_cfg_kw = 0;
+static size_t g_sort_kw;
+static int cmp_cfg(const void* x, const void* y) {
+  const uint64_t* a = (const uint64_t*)x; const uint64_t* b = (const uint64_t*)y;
+  int32_t sa = (int32_t)(a[0] >> 32), sb = (int32_t)(b[0] >> 32);
+  if (sa != sb) return sa < sb ? -1 : 1;
+  for (size_t i = 1; i < g_sort_kw; i++) if (a[i] != b[i]) return a[i] < b[i] ? -1 : 1;
+  return 0;
+}
+/* copies up to max rows of kw words (k0 = front+1 | state<<32, mask words), sorted by (state, mask); returns the total */
+uint32_t wgl_window_last_configs(uint64_t* out, uint32_t max, uint32_t* kw) {
+  *kw = g_cfg_kw;
+  for (uint32_t i = 0; i < g_cfg_n && i < max; i++) memcpy(out + (size_t)i * g_cfg_kw, g_cfg + (size_t)i * g_cfg_kw, g_cfg_kw * 8);
+  return g_cfg_n;
+}
+
 /*
  * Same contract as wgl_ref_check plus the process column (dense ids) and
  * n_process.  Returns 0 ok; 2 malformed history (unsorted, overlapping ops on
@@ -206,6 +223,14 @@ int wgl_window_check(uint32_t n, const uint8_t* f, const int32_t* a, const int32
   } else if (verdict == 0) {
     out->fail_op = ret_op[maxf];
     out->prev_ok_op = maxf ? ret_op[maxf - 1] : 0xFFFFFFFFu;
+    free(g_cfg); g_cfg = NULL; g_cfg_n = 0; g_cfg_kw = KW;
+    size_t cnt = 0;
+    for (size_t j = 0; j < vs.cap; j++) if ((uint32_t)vs.tab[j * KW] == maxf + 1) cnt++;
+    g_cfg = (uint64_t*)malloc((cnt ? cnt : 1) * KW * 8);
+    for (size_t j = 0; j < vs.cap; j++)
+      if ((uint32_t)vs.tab[j * KW] == maxf + 1) { memcpy(g_cfg + (size_t)g_cfg_n * KW, vs.tab + j * KW, KW * 8); g_cfg_n++; }
+    g_sort_kw = KW;
+    qsort(g_cfg, g_cfg_n, KW * 8, cmp_cfg);
   }
   free(rets); free(ret_rank); free(inv_rank); free(ret_op); free(seg); free(fill); free(slot_ops);
   free(cursor); free(fr_fi); free(fr_s); free(fr_op); free(fr_m); free(M); free(M2); free(key); free(vs.tab);

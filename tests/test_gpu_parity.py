@@ -231,3 +231,30 @@ def test_jepsen_checker_surface(native):
                        "wgl": jc.linearizable({"model": M.cas_register()})})
     r2 = comp.check({}, independent.subhistory(1, h), {})
     assert r2["valid?"] is True and r2["linear"]["analyzer"] == "linear"
+
+
+@pytest.mark.parametrize("alg", [N.ALG_WGL, N.ALG_COMPETITION])
+def test_invalid_verdict_carries_the_stuck_configs(native, oracle, alg):
+    """knossos :configs on failure: the (model state, linearized pending calls) pairs stuck at the
+    failing completion -- the same set whatever the schedule, sorted, first 10."""
+    for seed in range(4):
+        ops = columns.pair_events(synth.register_events(n_ops=1000, n_procs=16, seed=seed, busy=0.2, corrupt=0.6))
+        exp = oracle.check(ops.as_dict(), CAS, "window")
+        assert exp["valid"] == 0
+        total, rows = oracle.last_configs("window")
+        got = core.check_ops(ops, gm(), core.make_opts(time_limit_ms=60000, algorithm=alg))
+        assert got["valid"] == N.INVALID and got["fail_op"] == exp["fail_op"]
+        assert len(got["configs"]) == min(total, 10) and total <= 256
+        for c, row in zip(got["configs"], rows):
+            assert c["state"] == row[0]
+            assert c["n_pending"] <= 16
+            mask = 0
+            for k, op in enumerate(c["pending"]):
+                assert ops.inv_pos[op] < ops.ret_pos[exp["fail_op"]] and (ops.ret_pos[op] >= ops.ret_pos[exp["fail_op"]])
+                if c["linearized_mask"] >> k & 1:
+                    mask |= 1 << int(ops.process[op])
+            assert mask == row[1]
+        assert exp["fail_op"] in got["configs"][0]["pending"]          # the failing call is open, never linearized
+    a = wgl.analysis(M.cas_register(), [kop.invoke(0, "write", 1), kop.ok(0, "write", 1), kop.invoke(1, "read", None), kop.ok(1, "read", 2)])
+    assert a["valid?"] is False and a["configs"] and a["configs"][0]["model"] == M.CASRegister(1)
+    assert [o["f"] for o in a["configs"][0]["pending"]] == ["read"]
