@@ -34,6 +34,11 @@ struct Model {
   const uint16_t* table;
   uint32_t n_classes;
   const int32_t* pool;     // wide op values (multi-register micro-ops: {f, key, value} triples)
+  int32_t aux;             // commutative models: pool offset of the per-front table
+  uint32_t n_keys;         // bank: number of accounts
+
+  // set / bank: the state is a function of WHICH calls are linearized, so configs carry none
+  __device__ __forceinline__ bool commutative() const { return kind == TBC_MODEL_SET || kind == TBC_MODEL_BANK; }
 
   // multi-register: :f :txn, value = [[f k v] ...], atomic.  State = 4 bits per key (0 = nil, v+1).
   __device__ __forceinline__ bool txn(int32_t st, int32_t a, int32_t b, int32_t* out) const {

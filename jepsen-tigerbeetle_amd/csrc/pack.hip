@@ -53,6 +53,8 @@ __device__ __forceinline__ bool op_ok_for_model(uint32_t kind, uint32_t f, int32
     case TBC_MODEL_CAS_REGISTER: return f == TBC_F_READ || f == TBC_F_WRITE || f == TBC_F_CAS;
     case TBC_MODEL_MUTEX: return f == TBC_F_ACQUIRE || f == TBC_F_RELEASE;
     case TBC_MODEL_TABLE: return f == TBC_F_CLASS && (uint32_t)a < n_classes;
+    case TBC_MODEL_SET: return f == TBC_F_ADD || f == TBC_F_READ;
+    case TBC_MODEL_BANK: return f == TBC_F_TRANSFER || f == TBC_F_READ;
     default: return false;
   }
 }

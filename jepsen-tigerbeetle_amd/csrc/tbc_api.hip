@@ -171,6 +171,11 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
   HIP_TRY(hipSetDevice(B->device));
   switch (model->kind) {
     case TBC_MODEL_REGISTER: case TBC_MODEL_CAS_REGISTER: case TBC_MODEL_MUTEX: break;
+    case TBC_MODEL_SET: case TBC_MODEL_BANK:
+      if (!desc->cols.pool || desc->cols.pool_len == 0) { set_error("set / bank models need the value pool (see knossos/_analysis.py)"); return TBC_ERR_INVALID_ARG; }
+      if (model->kind == TBC_MODEL_BANK && (model->n_keys == 0 || model->n_keys > 16)) { set_error("bank: 1..16 accounts"); return TBC_ERR_MODEL; }
+      if (model->kind == TBC_MODEL_BANK && (model->flags & TBC_MODEL_F_NO_NEGATIVE)) { set_error("bank with :negative-balances? false does not commute: use the memo table"); return TBC_ERR_UNSUPPORTED; }
+      break;
     case TBC_MODEL_MULTI_REGISTER:
       if (model->n_keys == 0 || model->n_keys > 8) { set_error("multi-register: 1..8 keys on the device (more: use the memo table)"); return TBC_ERR_MODEL; }
       if (desc->cols.pool_len && !desc->cols.pool) { set_error("multi-register needs the value pool"); return TBC_ERR_INVALID_ARG; }
@@ -203,6 +208,11 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
   if (width > 16) width = 16;
   while (width & (width - 1)) width &= width - 1;   // the wide kernel takes a power of two (lanes per parent = 64 / width)
   if (B->mask_words > 4) width = 1;          // very wide windows: sequential kernel only
+  const bool commutative = model->kind == TBC_MODEL_SET || model->kind == TBC_MODEL_BANK;
+  if (commutative) {                          // state-free models exist in the wide kernel only
+    if (B->mask_words > 4) { set_error("set / bank: at most 256 processes (incl. crashed) on the device"); return TBC_ERR_WINDOW_TOO_WIDE; }
+    if (width < 2) width = 4;
+  }
   B->width = width;
   const bool beam = width > 1;
   const uint32_t EW = B->mask_words + 2;     // u64 words per wide-schedule entry
@@ -369,7 +379,9 @@ static BeamArgs make_beam_args(tbc_batch* B, uint64_t* tab, uint32_t* stack, uin
   a.stack = stack; a.tab = tab; a.results = B->d_results.p;
   a.witness = B->opts.want_witness ? B->d_witness.p : nullptr;
   a.work = B->d_work.p; a.table = B->d_table.p; a.n_work = n_work; a.model_kind = B->model.kind;
-  a.init_state = B->model.kind == TBC_MODEL_MUTEX ? 0 : B->model.init;
+  const bool comm = B->model.kind == TBC_MODEL_SET || B->model.kind == TBC_MODEL_BANK;
+  a.init_state = (B->model.kind == TBC_MODEL_MUTEX || comm) ? 0 : B->model.init;
+  a.model_aux = B->model.init; a.n_keys = B->model.n_keys;
   a.n_classes = B->model.n_classes; a.width = B->width;
   a.max_steps = B->opts.max_steps;
   a.time_limit_ticks = B->opts.time_limit_ms * 100000ull;
@@ -562,6 +574,10 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results) {
     std::vector<uint32_t> fb, lg;
     for (uint32_t h = 0; h < nh; h++)
       if (hist_back[h].status == 0 && bh_back[h].status != 0) {
+        if (B->model.kind == TBC_MODEL_SET || B->model.kind == TBC_MODEL_BANK) {
+          set_error("history %u: open-call lists exceed their arena and set / bank have no sequential kernel", h);
+          return TBC_ERR_UNSUPPORTED;
+        }
         uint32_t l = B->hist[h].tab_log2;
         fb.push_back(h); lg.push_back(l); final_log2[h] = l; is_seq[h] = 1;
       }

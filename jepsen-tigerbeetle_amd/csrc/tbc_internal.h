@@ -184,6 +184,8 @@ struct BeamArgs {
   uint32_t pad2;
   const int32_t* pool_vals;          // wide op values (multi-register micro-ops)
   uint64_t* cfg;                     // as SearchArgs.cfg
+  int32_t model_aux;                 // commutative models: pool offset of the per-front table
+  uint32_t n_keys;                   // bank: number of accounts
 };
 
 void launch_pack_open(const PackOpenArgs& a, void* stream);

@@ -74,7 +74,7 @@ __device__ void search_one(const SearchArgs& A, const uint32_t hidx, uint32_t* r
   const uint64_t cap_mask = cap - 1;
   const uint64_t full_at = cap - (cap >> 2);       // 75 % load => give up (host retries bigger)
   DevResult* out = A.results + hidx;
-  Model model{A.model_kind, A.table, A.n_classes, A.pool_vals};
+  Model model{A.model_kind, A.table, A.n_classes, A.pool_vals, 0, 0};
 
   uint64_t steps = 0, visited = 0, probes = 0, backtracks = 0, max_depth = 0, bucket_reads = 0;
   int32_t verdict = -2, cause = TBC_CAUSE_NONE;

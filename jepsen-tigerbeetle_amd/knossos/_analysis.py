@@ -94,6 +94,10 @@ class Encoded:
             self.native_model = core.make_model(N.MODEL_MUTEX, 1 if model.locked else 0)
         elif isinstance(model, M.MultiRegister) and self._multi_register_direct(model, hist, typ, f, a, b):
             pass
+        elif isinstance(model, M.SetModel) and self._set_direct(model, hist, typ, f, a, b):
+            pass
+        elif isinstance(model, M.Bank) and self._bank_direct(model, hist, typ, f, a, b):
+            pass
         else:
             # any other Model: knossos.model.memo -> transition table
             self.intern = None
@@ -108,6 +112,141 @@ class Encoded:
         self.ops = pair_events(self.events)
         if getattr(self, "pool", None) is not None:
             self.ops.pool = self.pool
+
+    @staticmethod
+    def _pairs(hist):
+        """(invoke row, completion row or None, completion type) per client op, in invocation order."""
+        open_by_proc, out = {}, []
+        for r, op in enumerate(hist):
+            p = op["process"]
+            if op["type"] == "invoke":
+                open_by_proc[p] = len(out)
+                out.append([r, None, None])
+            elif p in open_by_proc:
+                i = open_by_proc.pop(p)
+                out[i][1], out[i][2] = r, op["type"]
+        return out
+
+    def _set_direct(self, model, hist, typ, f, a, b):
+        """knossos.model/set as a COMMUTATIVE device model (TBC_MODEL_SET): the state is the set of
+        linearized adds, so configs carry no state; a read is checked against the adds completed
+        before the front plus the open adds already linearized.  Needs unique elements and an
+        empty initial set; otherwise the memo table (small histories) is used."""
+        if model.s:
+            return False
+        pairs = self._pairs(hist)
+        adds = [(i, pr) for i, pr in enumerate(pairs) if hist[pr[0]]["f"] == "add"]
+        if any(hist[pr[0]]["f"] not in ("add", "read") for pr in pairs):
+            raise ValueError(f"op not understood by {model!r}")
+        elems = [memo_ns._freeze(hist[pr[0]]["value"]) for _, pr in adds if pr[2] != "fail"]
+        if len(set(elems)) != len(elems):
+            return False
+        # adds in completion order (crashed ones last, by invocation); failed adds never happened
+        live = [(pr[1], pr) for _, pr in adds if pr[2] == "ok"]
+        crashed = [pr for _, pr in adds if pr[2] not in ("ok", "fail")]
+        order = [pr for _, pr in sorted(live, key=lambda t: t[0])] + crashed
+        j_of = {memo_ns._freeze(hist[pr[0]]["value"]): j for j, pr in enumerate(order)}
+        n_adds = len(order)
+        nwords = max(1, (n_adds + 31) // 32)
+        # completions (of ops that are kept) in row order -> nadds_before[F]
+        comp_rows = sorted((pr[1], hist[pr[0]]["f"] == "add") for pr in pairs if pr[2] == "ok")
+        nb = [0]
+        for _, is_add in comp_rows:
+            nb.append(nb[-1] + (1 if is_add else 0))
+        pool = list(nb)
+        for pr in pairs:
+            r0, r1, ctype = pr
+            op0 = hist[r0]
+            if op0["f"] == "add":
+                j = j_of.get(memo_ns._freeze(op0["value"]), 0)
+                for r in (r0, r1):
+                    if r is not None:
+                        f[r] = N.F_ADD; a[r] = j
+            else:
+                f[r0] = N.F_READ; a[r0] = N.NIL
+                if r1 is not None:
+                    f[r1] = N.F_READ
+                    v = hist[r1].get("value") if ctype == "ok" else None
+                    if v is None:
+                        a[r1] = N.NIL
+                    else:
+                        words = [0] * nwords
+                        ok = True
+                        for e in v:
+                            j = j_of.get(memo_ns._freeze(e))
+                            if j is None:
+                                ok = False
+                            else:
+                                words[j >> 5] |= 1 << (j & 31)
+                        lead = 0
+                        while lead < n_adds and words[lead >> 5] >> (lead & 31) & 1:
+                            lead += 1
+                        a[r1] = len(pool)
+                        pool += [len(set(memo_ns._freeze(e) for e in v)) if ok else -1, lead]
+                        pool += [w - (1 << 32) if w >= (1 << 31) else w for w in words]
+        self.intern = None
+        self.pool = np.array(pool, np.int32)
+        self.set_order = [hist[pr[0]]["value"] for pr in order]
+        self.n_adds = n_adds
+        self.native_model = core.make_model(N.MODEL_SET, 0)
+        return True
+
+    def _bank_direct(self, model, hist, typ, f, a, b):
+        """The bank model (new: Knossos has none; reference mapping tests/ledger.clj:89-114) as a
+        COMMUTATIVE device model (TBC_MODEL_BANK) when negative balances are allowed: transfers
+        commute, so configs carry no state and a read is checked against the balances after the
+        transfers completed before the front plus the open transfers already linearized."""
+        if not model.neg or any(v != 0 for _, v in model.balances):
+            return False
+        accts = {acct: i for i, (acct, _) in enumerate(model.balances)}
+        A = len(accts)
+        if A > 16:
+            return False
+        pairs = self._pairs(hist)
+        comp = sorted((pr[1], pr) for pr in pairs if pr[2] == "ok")
+        bal = [0] * A
+        pool = list(bal)                                # bal_before[0]
+        for _, pr in comp:
+            op0 = hist[pr[0]]
+            if op0["f"] == "transfer":
+                v = op0["value"]
+                if v["debit-acct"] not in accts or v["credit-acct"] not in accts:
+                    raise ValueError(f"unknown account in {v}")
+                bal[accts[v["debit-acct"]]] -= v["amount"]
+                bal[accts[v["credit-acct"]]] += v["amount"]
+            pool += bal                                 # bal_before[F + 1]
+        for pr in pairs:
+            r0, r1, ctype = pr
+            op0 = hist[r0]
+            if op0["f"] == "transfer":
+                v = op0["value"]
+                if v["debit-acct"] not in accts or v["credit-acct"] not in accts:
+                    raise ValueError(f"unknown account in {v}")
+                off = len(pool)
+                pool += [accts[v["debit-acct"]], accts[v["credit-acct"]], int(v["amount"])]
+                for r in (r0, r1):
+                    if r is not None:
+                        f[r] = N.F_TRANSFER; a[r] = off
+            elif op0["f"] == "read":
+                f[r0] = N.F_READ; a[r0] = N.NIL
+                if r1 is not None:
+                    f[r1] = N.F_READ
+                    v = hist[r1].get("value") if ctype == "ok" else None
+                    if v is None:
+                        a[r1] = N.NIL
+                    else:
+                        v = dict(v)
+                        if set(v) != set(accts):
+                            raise ValueError(f"read of accounts {sorted(v)} but the model has {sorted(accts)}")
+                        a[r1] = len(pool)
+                        pool += [int(v[acct]) for acct in accts]
+            else:
+                raise ValueError(f"op {op0['f']!r} is not understood by {model!r}")
+        self.intern = None
+        self.pool = np.array(pool, np.int32)
+        self.bank_accts = list(accts)
+        self.native_model = core.make_model(N.MODEL_BANK, 0, n_keys=A)
+        return True
 
     def _multi_register_direct(self, model, hist, typ, f, a, b):
         """Device multi-register: <= 8 keys, <= 14 distinct values; txn micro-ops go to the value pool
@@ -163,6 +302,8 @@ class Encoded:
             return self.table_info["states"][s]
         if isinstance(self.model, M.Mutex):
             return M.Mutex(bool(s))
+        if isinstance(self.model, (M.SetModel, M.Bank)):
+            return self.model          # commutative device models carry no state in the config
         if isinstance(self.model, M.MultiRegister):
             vals = {}
             for k, i in self.mr_keys.items():

@@ -22,8 +22,8 @@ from itertools import permutations
 NIL = -(2 ** 31)
 CRASHED = 0xFFFFFFFF
 READ, WRITE, CAS, ACQUIRE, RELEASE, CLASS = 0, 1, 2, 3, 4, 8
-REGISTER, CAS_REGISTER, MUTEX, TABLE, MULTI_REGISTER = 0, 1, 2, 3, 4
-TXN = 6
+REGISTER, CAS_REGISTER, MUTEX, TABLE, MULTI_REGISTER, SET, BANK = 0, 1, 2, 3, 4, 5, 6
+ADD, TXN, TRANSFER = 5, 6, 7
 
 
 def step(model, state, f, a, b):
@@ -55,6 +55,33 @@ def step(model, state, f, a, b):
             else:
                 s = (s & ~(15 << (4 * k))) | ((v + 1) << (4 * k))
         return s if ok else None
+    if kind == SET:      # ordinary stateful semantics (state = set of add indices): independent of the
+        pool = model["pool"]   # commutativity trick the kernels use
+        state = frozenset() if state == 0 else state
+        if f == ADD:
+            return state | {a}
+        if f == READ:
+            if a == NIL:
+                return state
+            nR, nwords = int(pool[a]), (model["n_adds"] + 31) // 32
+            if nR < 0:
+                return None
+            R = frozenset(j for j in range(model["n_adds"]) if int(pool[a + 2 + (j >> 5)]) >> (j & 31) & 1)
+            del nwords
+            return state if R == state else None
+        return None
+    if kind == BANK:
+        pool, A = model["pool"], model["n_accounts"]
+        state = tuple([0] * A) if state == 0 else state
+        if f == TRANSFER:
+            d, c, amt = (int(x) for x in pool[a:a + 3])
+            s = list(state); s[d] -= amt; s[c] += amt
+            return tuple(s)
+        if f == READ:
+            if a == NIL:
+                return state
+            return state if tuple(int(x) for x in pool[a:a + A]) == state else None
+        return None
     if kind == TABLE:
         t = model["table"][state][a]
         return None if t == 0xFFFF else t

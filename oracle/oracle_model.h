@@ -22,6 +22,13 @@
  *   table         next = table[state*n_classes + class] (knossos.model.memo)
  *   multi-register :txn [[f k v] ...] applied atomically; a micro-read is ok iff v is
  *                 nil or equals the key's value.  State = 4 bits per key (0 nil, v+1).
+ *   set / bank    COMMUTATIVE models: the state is a function of WHICH calls are linearized,
+ *                 not of their order, so configs carry no state (state word 0) and a read is
+ *                 checked against (completions before the front) + (open calls linearized):
+ *                 see oracle_cfg_step below.  set = knossos.model/set (:add v, :read s ok iff s
+ *                 equals the state exactly; elements unique per history); bank = the model the
+ *                 reference's ledger->bank mapping implies (tests/ledger.clj:89-114), negative
+ *                 balances allowed (so transfers commute).
  */
 #ifndef ORACLE_MODEL_H
 #define ORACLE_MODEL_H
@@ -30,8 +37,8 @@
 #define O_NIL INT32_MIN
 #define O_CRASHED 0xFFFFFFFFu
 enum { O_READ = 0, O_WRITE = 1, O_CAS = 2, O_ACQUIRE = 3, O_RELEASE = 4, O_CLASS = 8 };
-enum { O_REGISTER = 0, O_CAS_REGISTER = 1, O_MUTEX = 2, O_TABLE = 3, O_MULTI_REGISTER = 4 };
-enum { O_TXN = 6 };
+enum { O_REGISTER = 0, O_CAS_REGISTER = 1, O_MUTEX = 2, O_TABLE = 3, O_MULTI_REGISTER = 4, O_SET = 5, O_BANK = 6 };
+enum { O_ADD = 5, O_TXN = 6, O_TRANSFER = 7 };
 
 typedef struct oracle_model {
   uint32_t kind;
@@ -74,6 +81,56 @@ static inline int oracle_step(const oracle_model* m, int32_t state, uint8_t f,
       *next = (int32_t)t;
       return 1;
     }
+  }
+  return 0;
+}
+
+/*
+ * Config-dependent step for the commutative models.  `front` = completions already passed,
+ * open[0..n_open) = ops open at the front, lin[i] = open[i] already linearized.  Pool layout
+ * (written by the host encoder, knossos/_analysis.py):
+ *   set : model->init = offset of nadds_before[0..R]; :add a = index j of the add in completion
+ *         order; :read a = O_NIL or offset of {nR, lead, words...} (bitset over adds in j order,
+ *         nR = |R| or -1 if R holds an element nobody adds, lead = number of leading ones).
+ *   bank: model->init = offset of bal_before[(R+1) * n_states] (n_states = #accounts);
+ *         :transfer a = offset of {debit idx, credit idx, amount}; :read a = O_NIL or offset of
+ *         the balances read.
+ */
+static inline int oracle_is_cfg_model(const oracle_model* m) { return m->kind == O_SET || m->kind == O_BANK; }
+static inline int oracle_cfg_step(const oracle_model* m, uint32_t front, const uint32_t* open, const uint8_t* lin,
+                                  uint32_t n_open, const uint8_t* f, const int32_t* a, uint32_t op) {
+  const int32_t* pool = m->pool;
+  if (m->kind == O_SET) {
+    if (f[op] == O_ADD) return 1;
+    if (f[op] != O_READ) return 0;
+    if (a[op] == O_NIL) return 1;
+    const int32_t* rec = pool + a[op];
+    const int32_t nR = rec[0], lead = rec[1];
+    const uint32_t* words = (const uint32_t*)(rec + 2);
+    int32_t count = pool[m->init + (int32_t)front];
+    if (nR < 0 || count > lead) return 0;
+    for (uint32_t i = 0; i < n_open; i++) {
+      if (!lin[i] || f[open[i]] != O_ADD) continue;
+      uint32_t j = (uint32_t)a[open[i]];
+      if (!(words[j >> 5] >> (j & 31) & 1u)) return 0;
+      count++;
+    }
+    return count == nR;
+  }
+  if (m->kind == O_BANK) {
+    if (f[op] == O_TRANSFER) return 1;
+    if (f[op] != O_READ) return 0;
+    if (a[op] == O_NIL) return 1;
+    const uint32_t A = m->n_states;
+    int32_t bal[16];
+    for (uint32_t k = 0; k < A; k++) bal[k] = pool[m->init + (int32_t)(front * A + k)];
+    for (uint32_t i = 0; i < n_open; i++) {
+      if (!lin[i] || f[open[i]] != O_TRANSFER) continue;
+      const int32_t* t = pool + a[open[i]];
+      bal[t[0]] -= t[2]; bal[t[1]] += t[2];
+    }
+    for (uint32_t k = 0; k < A; k++) if (bal[k] != pool[a[op] + (int32_t)k]) return 0;
+    return 1;
   }
   return 0;
 }

@@ -58,6 +58,8 @@ def _model(model):
         m.n_states, m.n_classes = t.shape
         m.table = t.ctypes.data_as(C.POINTER(C.c_uint16))
         keep = t
+    if model.get("n_accounts"):
+        m.n_states = int(model["n_accounts"])
     if model.get("pool") is not None:
         p = np.ascontiguousarray(model["pool"], dtype=np.int32)
         m.pool = p.ctypes.data_as(C.POINTER(C.c_int32))

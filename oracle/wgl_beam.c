@@ -129,8 +129,11 @@ int wgl_beam_check(uint32_t n, const uint8_t* f, const int32_t* a, const int32_t
     if (process[i] < 0 || (uint32_t)process[i] >= n_process) return 2;
     if (ret_pos[i] != O_CRASHED) { if (ret_pos[i] <= inv_pos[i]) return 2; R++; }
   }
-  if (R == 0) { out->valid = 1; out->final_state = model->init; return 0; }
+  const int cfgm = oracle_is_cfg_model(model);
+  if (R == 0) { out->valid = 1; out->final_state = cfgm ? 0 : model->init; return 0; }
   const uint32_t W = n_process, MW = (W + 63) / 64, KW = 1 + MW;
+  uint32_t* open_ops = (uint32_t*)malloc(4 * ((size_t)n + 1));
+  uint8_t* open_lin = (uint8_t*)malloc((size_t)n + 1);
 
   posop* rets = (posop*)malloc(sizeof(posop) * R);
   uint32_t* ret_rank = (uint32_t*)malloc(4 * n);
@@ -176,7 +179,7 @@ int wgl_beam_check(uint32_t n, const uint8_t* f, const int32_t* a, const int32_t
   size_t scap = 1 << 16, sp = 0;
   uint32_t* stack = (uint32_t*)malloc(scap * 4);
   uint64_t* key = (uint64_t*)calloc(KW, 8);
-  key[0] = 1ull | ((uint64_t)(uint32_t)model->init << 32);
+  key[0] = 1ull | ((uint64_t)(uint32_t)(cfgm ? 0 : model->init) << 32);
   stack[sp++] = arena_add(&ar, key, 0, 0xFFFFFFFFu);
   st->visited = 1; st->max_stack = 1;
   uint32_t maxf = 0;
@@ -216,7 +219,16 @@ int wgl_beam_check(uint32_t n, const uint8_t* f, const int32_t* a, const int32_t
         cviable[l] = 0; cop[l] = op; cpar[l] = par[q];
         if (pk[1 + (p >> 6)] >> (p & 63) & 1) continue;
         int32_t s2;
-        if (!oracle_step(model, s, f[op], a[op], b[op], &s2)) continue;
+        if (cfgm) {
+          uint32_t no = 0;
+          for (uint32_t cc = 0; cc < pcnt[q]; cc++) {
+            uint32_t x = cc < nlive ? lst[off[fi] + cc] : crashed[cc - nlive];
+            uint32_t px = (uint32_t)process[x];
+            open_ops[no] = x; open_lin[no] = (uint8_t)(pk[1 + (px >> 6)] >> (px & 63) & 1); no++;
+          }
+          if (!oracle_cfg_step(model, fi, open_ops, open_lin, no, f, a, op)) continue;
+          s2 = 0;
+        } else if (!oracle_step(model, s, f[op], a[op], b[op], &s2)) continue;
         uint64_t* c2 = ck + (size_t)l * KW;
         memcpy(c2, pk, KW * 8);
         c2[1 + (p >> 6)] |= 1ull << (p & 63);
@@ -275,6 +287,7 @@ int wgl_beam_check(uint32_t n, const uint8_t* f, const int32_t* a, const int32_t
     qsort(g_bcfg, g_bcfg_n, KW * 8, cmp_bcfg);
   }
   free(rets); free(ret_rank); free(inv_rank); free(ret_op); free(off); free(ncr); free(lst); free(fill); free(crashed);
+  free(open_ops); free(open_lin);
   free(ar.keys); free(ar.parent); free(ar.op); free(ar.slots); free(stack); free(key); free(ck);
   return 0;
 }

@@ -102,7 +102,7 @@ int wgl_window_check(uint32_t n, const uint8_t* f, const int32_t* a, const int32
     if (process[i] < 0 || (uint32_t)process[i] >= n_process) return 2;
     if (ret_pos[i] != O_CRASHED) { if (ret_pos[i] <= inv_pos[i]) return 2; R++; }
   }
-  if (R == 0) { out->valid = 1; out->final_state = model->init; return 0; }
+  if (R == 0) { out->valid = 1; out->final_state = oracle_is_cfg_model(model) ? 0 : model->init; return 0; }
 
   const uint32_t W = n_process, MW = (W + 63) / 64, KW = 1 + MW;
   posop* rets = (posop*)malloc(sizeof(posop) * R);
@@ -148,7 +148,10 @@ int wgl_window_check(uint32_t n, const uint8_t* f, const int32_t* a, const int32
   wset vs = {(uint64_t*)calloc((size_t)4096 * KW, 8), 4096, 0, KW};
 
   uint32_t fi = 0, depth = 0, maxf = 0;
-  int32_t s = model->init;
+  const int cfgm = oracle_is_cfg_model(model);
+  uint32_t* open_ops = (uint32_t*)malloc(4 * (W + 1));
+  uint8_t* open_lin = (uint8_t*)malloc(W + 1);
+  int32_t s = cfgm ? 0 : model->init;
   int64_t from = -1;        /* only candidates with op index > from */
   int verdict = -2;
 
@@ -160,6 +163,7 @@ int wgl_window_check(uint32_t n, const uint8_t* f, const int32_t* a, const int32
     }
     if (fi > maxf) maxf = fi;
     int descended = 0;
+    uint32_t n_open = 0xFFFFFFFFu;
     for (;;) {
       /* first candidate in invocation order after `from` */
       int64_t best = -1; uint32_t bestp = 0; int32_t best_s2 = 0;
@@ -171,7 +175,19 @@ int wgl_window_check(uint32_t n, const uint8_t* f, const int32_t* a, const int32
         if ((int64_t)op <= from) continue;
         if (best >= 0 && (int64_t)op > best) continue;
         int32_t s2;
-        if (!oracle_step(model, s, f[op], a[op], b[op], &s2)) continue;
+        if (cfgm) {
+          if (n_open == 0xFFFFFFFFu) {          /* open calls of this config, gathered once per node */
+            n_open = 0;
+            for (uint32_t pp = 0; pp < W; pp++) {
+              if (cursor[pp] < (int64_t)seg[pp]) continue;
+              uint32_t x = slot_ops[cursor[pp]];
+              if (ret_rank[x] < fi) continue;
+              open_ops[n_open] = x; open_lin[n_open] = (uint8_t)(M[pp >> 6] >> (pp & 63) & 1); n_open++;
+            }
+          }
+          if (!oracle_cfg_step(model, fi, open_ops, open_lin, n_open, f, a, op)) continue;
+          s2 = 0;
+        } else if (!oracle_step(model, s, f[op], a[op], b[op], &s2)) continue;
         best = op; bestp = p; best_s2 = s2;
       }
       if (best < 0) break;
@@ -233,6 +249,7 @@ int wgl_window_check(uint32_t n, const uint8_t* f, const int32_t* a, const int32
     qsort(g_cfg, g_cfg_n, KW * 8, cmp_cfg);
   }
   free(rets); free(ret_rank); free(inv_rank); free(ret_op); free(seg); free(fill); free(slot_ops);
+  free(open_ops); free(open_lin);
   free(cursor); free(fr_fi); free(fr_s); free(fr_op); free(fr_m); free(M); free(M2); free(key); free(vs.tab);
   return 0;
 }

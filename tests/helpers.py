@@ -92,3 +92,101 @@ def multi_register_history(n_ops, n_procs, seed, n_keys=4, n_values=4, busy=0.4,
                     m[2] = n_values + 3     # a value nobody writes
                     break
     return hist
+
+
+def _simulate(n_ops, n_procs, seed, busy, info, make_op, apply_op):
+    """Generic discrete-event simulation of one atomic object (see multi_register_history)."""
+    import heapq
+    import random
+    rng = random.Random(seed)
+    heap, seq, hist = [], 0, []
+    think = (1.0 - busy) / busy
+    pid = list(range(n_procs))
+    next_pid = n_procs
+    for w in range(n_procs):
+        heapq.heappush(heap, (rng.expovariate(1.0 / (think + 0.05)), seq, w, "inv")); seq += 1
+    cur, issued = {}, 0
+    while heap:
+        t, _, w, kind = heapq.heappop(heap)
+        if kind == "inv":
+            if issued >= n_ops:
+                continue
+            issued += 1
+            f, value = make_op(rng, issued)
+            crashed = rng.random() < info
+            cur[w] = {"f": f, "value": value, "crashed": crashed, "effect": (rng.random() < 0.5) if crashed else True, "res": value}
+            hist.append({"type": "invoke", "f": f, "value": value, "process": pid[w]})
+            L = 0.02 + rng.expovariate(1.0)
+            heapq.heappush(heap, (t + rng.random() * L, seq, w, "eff")); seq += 1
+            heapq.heappush(heap, (t + L, seq, w, "ret")); seq += 1
+        elif kind == "eff":
+            c = cur[w]
+            if c["effect"]:
+                c["res"] = apply_op(c["f"], c["value"])
+        else:
+            c = cur[w]
+            if c["crashed"]:
+                hist.append({"type": "info", "f": c["f"], "value": c["value"], "process": pid[w], "error": "timeout"})
+                pid[w] = next_pid
+                next_pid += 1
+            else:
+                hist.append({"type": "ok", "f": c["f"], "value": c["res"], "process": pid[w]})
+            heapq.heappush(heap, (t + rng.expovariate(1.0 / think) + 1e-9, seq, w, "inv")); seq += 1
+    return hist
+
+
+def set_history(n_ops, n_procs, seed, busy=0.3, info=0.0, corrupt=None):
+    """Grow-only set, the reference's set-full shapes (set_full.clj:29-31,42-45,113-116,128-134):
+    :add of globally increasing ids (from 9: set_full.clj:159), :read returns the whole sorted set;
+    timeouts are :info.  corrupt = "lost" drops an element from a late read, "phantom" adds one."""
+    state = set()
+    nxt = [9]
+
+    def make_op(rng, _):
+        if rng.random() < 0.5:
+            nxt[0] += 1
+            return "add", nxt[0] - 1
+        return "read", None
+
+    def apply_op(f, v):
+        if f == "add":
+            state.add(v)
+            return v
+        return sorted(state)
+
+    hist = _simulate(n_ops, n_procs, seed, busy, info, make_op, apply_op)
+    if corrupt:
+        reads = [o for o in hist if o["type"] == "ok" and o["f"] == "read" and o["value"]]
+        if reads:
+            o = reads[len(reads) * 2 // 3]
+            o["value"] = o["value"][:-1] if corrupt == "lost" else o["value"] + [10 ** 6]
+    return hist
+
+
+def bank_history(n_ops, n_procs, seed, accounts=range(1, 9), busy=0.3, info=0.0, corrupt=False):
+    """Bank ops as the reference's ledger->bank mapping produces them (tests/ledger.clj:89-114;
+    README.md:41-50): :transfer {:debit-acct :credit-acct :amount 1..5}, :read -> {acct balance}."""
+    accounts = list(accounts)
+    bal = {a: 0 for a in accounts}
+
+    def make_op(rng, _):
+        if rng.random() < 0.5:
+            d, c = rng.sample(accounts, 2)
+            return "transfer", {"debit-acct": d, "credit-acct": c, "amount": rng.randint(1, 5)}
+        return "read", None
+
+    def apply_op(f, v):
+        if f == "transfer":
+            bal[v["debit-acct"]] -= v["amount"]
+            bal[v["credit-acct"]] += v["amount"]
+            return v
+        return dict(bal)
+
+    hist = _simulate(n_ops, n_procs, seed, busy, info, make_op, apply_op)
+    if corrupt:
+        reads = [o for o in hist if o["type"] == "ok" and o["f"] == "read" and o["value"]]
+        if reads:
+            o = reads[len(reads) * 2 // 3]
+            o["value"] = dict(o["value"])
+            o["value"][accounts[0]] += 1          # the sum is off by one: no interleaving explains it
+    return hist
