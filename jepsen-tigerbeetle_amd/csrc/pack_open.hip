@@ -10,7 +10,9 @@
 //            (position of p's call = popcount(occ[F] below p): no sorting needed)
 //   crashed[] the :info calls in invocation order, ncr[F] = how many of them were
 //            invoked before completion F (they stay open for ever, so they are
-//            kept out of the per-front lists)
+//            kept out of the per-front lists).  Crashed READS (value nil) are left
+//            out altogether: no effect on the model, no constraint, but each would
+//            double the config space (oracle/wgl_beam.c)
 //   opinfo[] 16 B per op {ret_rank, f | slot<<8, a, b}: one load per candidate
 //
 // This is knossos.linear.config's "pending calls by process" materialised for
@@ -88,7 +90,7 @@ __global__ __launch_bounds__(256) void pack_open_kernel(PackOpenArgs A) {
       OpInfo o; o.ret_rank = rr; o.f_slot = (uint32_t)f[i] | (p << 8); o.a = a[i]; o.b = b[i];
       info[i] = o;
       if (rr == kInf) {
-        if (ir < R) atomicAdd(&ncr[ir], 1u);
+        if (ir < R && !(f[i] == TBC_F_READ && a[i] == TBC_NIL)) atomicAdd(&ncr[ir], 1u);
       } else {
         const unsigned long long bit = 1ull << (p & 63u);
         for (uint32_t fr = ir; fr <= rr; fr++)
@@ -146,7 +148,7 @@ __global__ __launch_bounds__(256) void pack_open_kernel(PackOpenArgs A) {
       const uint32_t chunk = (n + 255) / 256;
       const uint32_t lo = min(tid * chunk, n), hi = min(lo + chunk, n);
       uint32_t cnt = 0;
-      for (uint32_t i = lo; i < hi; i++) cnt += sc_ret[i] == kInf;
+      for (uint32_t i = lo; i < hi; i++) cnt += sc_ret[i] == kInf && !(f[i] == TBC_F_READ && a[i] == TBC_NIL);
       s_part[tid] = cnt;
       __syncthreads();
       if (tid == 0) {
@@ -156,7 +158,7 @@ __global__ __launch_bounds__(256) void pack_open_kernel(PackOpenArgs A) {
       }
       __syncthreads();
       uint32_t run = s_part[tid];
-      for (uint32_t i = lo; i < hi; i++) if (sc_ret[i] == kInf) crashed[run++] = i;
+      for (uint32_t i = lo; i < hi; i++) if (sc_ret[i] == kInf && !(f[i] == TBC_F_READ && a[i] == TBC_NIL)) crashed[run++] = i;
       __syncthreads();
     }
   }

@@ -14,7 +14,12 @@
  * of THIS schedule, which is fully deterministic and specified here:
  *
  *   open(F)  = live ops with inv_rank <= F <= ret_rank in order of process slot,
- *              then crashed ops with inv_rank <= F in invocation order.
+ *              then crashed ops with inv_rank <= F in invocation order -- except crashed
+ *              reads (value nil: they never completed), which are never candidates: such
+ *              a call has no effect on the model and constrains nothing, so linearizing it
+ *              or not changes neither the verdict nor the failing op, but every one of
+ *              them would double the number of configs (the sequential restatements keep
+ *              them, as Knossos does).
  *   iteration: pop np = min(K, |stack|) configs P_0 (top) .. P_{np-1};
  *     pairs are enumerated parent-bottom-first (P_{np-1} .. P_0), and within a
  *     parent from its LAST open op to its first; pair number r = 0, 1, ...;
@@ -152,7 +157,10 @@ int wgl_beam_check(uint32_t n, const uint8_t* f, const int32_t* a, const int32_t
   uint32_t* ncr = (uint32_t*)calloc((size_t)R + 1, 4);   /* crashed ops with inv_rank <= F */
   uint32_t n_crashed = 0;
   for (uint32_t i = 0; i < n; i++) {
-    if (ret_rank[i] == 0xFFFFFFFFu) { n_crashed++; if (inv_rank[i] < R) ncr[inv_rank[i]]++; continue; }
+    if (ret_rank[i] == 0xFFFFFFFFu) {
+      if (f[i] == O_READ && a[i] == O_NIL) continue;             /* crashed no-op read: never a candidate */
+      n_crashed++; if (inv_rank[i] < R) ncr[inv_rank[i]]++; continue;
+    }
     for (uint32_t fr = inv_rank[i]; fr <= ret_rank[i]; fr++) off[fr + 1]++;
   }
   for (uint32_t r = 0; r < R; r++) off[r + 1] += off[r];
@@ -163,7 +171,7 @@ int wgl_beam_check(uint32_t n, const uint8_t* f, const int32_t* a, const int32_t
   uint32_t* crashed = (uint32_t*)malloc(4 * ((size_t)n_crashed + 1));
   { uint32_t c = 0;
     for (uint32_t i = 0; i < n; i++) {
-      if (ret_rank[i] == 0xFFFFFFFFu) { crashed[c++] = i; continue; }
+      if (ret_rank[i] == 0xFFFFFFFFu) { if (!(f[i] == O_READ && a[i] == O_NIL)) crashed[c++] = i; continue; }
       for (uint32_t fr = inv_rank[i]; fr <= ret_rank[i]; fr++) lst[fill[fr]++] = i;
     }
     for (uint32_t fr = 0; fr < R; fr++)          /* each front's live list in process-slot order */
