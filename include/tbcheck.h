@@ -254,6 +254,9 @@ typedef struct tbc_batch_desc {
   const uint32_t* n_events;   /* per history                                     */
   const uint32_t* n_process;  /* per history                                     */
   tbc_ops cols;               /* concatenated columns; cols.n = total ops        */
+  const int32_t* model_aux;   /* optional, per history: overrides tbc_model.init  */
+                              /* (set / bank: pool offset of the history's own    */
+                              /* per-front table when histories share one pool)   */
 } tbc_batch_desc;
 
 tbc_status tbc_batch_create(const tbc_batch_desc* desc, const tbc_model* model,

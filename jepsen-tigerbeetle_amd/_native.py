@@ -93,7 +93,7 @@ class Result(C.Structure):
 
 class BatchDesc(C.Structure):
     _fields_ = [("n_hist", C.c_uint32), ("op_off", C.POINTER(C.c_uint64)), ("n_events", C.POINTER(C.c_uint32)),
-                ("n_process", C.POINTER(C.c_uint32)), ("cols", Ops)]
+                ("n_process", C.POINTER(C.c_uint32)), ("cols", Ops), ("model_aux", C.POINTER(C.c_int32))]
 
 
 class SynthParams(C.Structure):

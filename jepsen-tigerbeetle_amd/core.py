@@ -94,16 +94,29 @@ class Batch:
         self._cols = OpColumns(cat("f", np.uint8), cat("a", np.int32), cat("b", np.int32),
                                cat("process", np.int32), cat("inv_pos", np.uint32), cat("ret_pos", np.uint32),
                                n_events=0, n_process=0)
+        self._aux = None
         if any(h.pool is not None and len(h.pool) for h in histories):
-            # one pool for the batch: shift each history's offsets (wide ops keep their pool offset in `a`)
-            pools, shift, a_cols = [], 0, []
+            # one pool for the batch: shift the pool offsets held in column `a` (txn micro-ops; set / bank
+            # reads and transfers) and give every history the offset of its own per-front table
+            kind = self._m.kind
+            pools, shift, a_cols, aux = [], 0, [], []
             for h in histories:
                 p = h.pool if h.pool is not None else np.zeros(0, np.int32)
-                a_cols.append(np.where(h.f == N.F_TXN, h.a + shift, h.a).astype(np.int32))
+                if kind == N.MODEL_MULTI_REGISTER:
+                    in_pool = h.f == N.F_TXN
+                elif kind == N.MODEL_SET:
+                    in_pool = (h.f == N.F_READ) & (h.a != N.NIL)
+                elif kind == N.MODEL_BANK:
+                    in_pool = (h.f == N.F_TRANSFER) | ((h.f == N.F_READ) & (h.a != N.NIL))
+                else:
+                    in_pool = np.zeros(len(h), bool)
+                a_cols.append(np.where(in_pool, h.a + shift, h.a).astype(np.int32))
+                aux.append(shift + int(self._m.init) if kind in (N.MODEL_SET, N.MODEL_BANK) else int(self._m.init))
                 pools.append(np.asarray(p, np.int32))
                 shift += len(p)
             self._cols.a = np.concatenate(a_cols)
             self._cols.pool = np.ascontiguousarray(np.concatenate(pools))
+            self._aux = np.array(aux, np.int32)
         for name in ("f", "a", "b", "process", "inv_pos", "ret_pos"):
             setattr(self._cols, name, np.ascontiguousarray(getattr(self._cols, name)))
         d = N.BatchDesc()
@@ -112,6 +125,7 @@ class Batch:
         d.n_events = _p(self.n_events, C.c_uint32)
         d.n_process = _p(self.n_process, C.c_uint32)
         d.cols = self._cols.struct()
+        d.model_aux = _p(self._aux, C.c_int32) if self._aux is not None else None
         self._h = C.c_void_p()
         st = N.lib().tbc_batch_create(C.byref(d), C.byref(self._m), C.byref(self._o), C.byref(self._h))
         N.check_status(st)

@@ -232,6 +232,7 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
     H.n_ops = (uint32_t)n;
     H.n_events = desc->n_events[h];
     H.n_slots = std::max(1u, desc->n_process[h]);
+    H.aux = desc->model_aux ? desc->model_aux[h] : model->init;
     H.rec_off = rec_n; rec_n += n + 2ull * H.n_slots;
     H.seg_off = seg_n; seg_n += H.n_slots + 1;
     H.ret_off = H.op_off;

@@ -43,7 +43,8 @@ struct __attribute__((aligned(16))) Hist {
   uint32_t tab_log2;   // visited-set capacity = 1 << tab_log2 entries
   uint32_t n_ret;      // pack: number of completions
   uint32_t status;     // pack: 0 ok, else tbc_status
-  uint32_t pad0, pad1;
+  int32_t aux;         // commutative models: pool offset of this history's per-front table
+  uint32_t pad1;
 };
 
 struct __attribute__((aligned(8))) DevResult {

@@ -92,7 +92,7 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
   // K parents per iteration, G = 64 / K lanes (candidate slots) per parent per round
   const uint32_t K = A.width, gshift = 6u - (31u - (uint32_t)__builtin_clz(K)), G = 1u << gshift;
   DevResult* out = A.results + hidx;
-  Model model{A.model_kind, A.table, A.n_classes, A.pool_vals, A.model_aux, A.n_keys};
+  Model model{A.model_kind, A.table, A.n_classes, A.pool_vals, (int32_t)rfl((uint32_t)H->aux), A.n_keys};
 
   uint64_t* p_k0 = reinterpret_cast<uint64_t*>(lds);
   uint64_t* p_M = p_k0 + 16;

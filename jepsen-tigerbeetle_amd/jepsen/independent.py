@@ -76,7 +76,7 @@ class IndependentChecker(jc.Checker):
         lin = self.inner
         encs = [_analysis.Encoded(lin.model, subs[k]) for k in keys]
         kinds = {e.native_model[0].kind for e in encs}
-        if len(kinds) != 1 or N.MODEL_TABLE in kinds:
+        if len(kinds) != 1 or N.MODEL_TABLE in kinds or len({e.native_model[0].n_keys for e in encs}) != 1:
             # table models have one table per key: check them one by one
             return {k: lin.check(None, subs[k], None) for k in keys}
         o = core.make_opts(algorithm=_analysis._ALG[lin.algorithm],

@@ -153,7 +153,12 @@ class Encoded:
         nb = [0]
         for _, is_add in comp_rows:
             nb.append(nb[-1] + (1 if is_add else 0))
-        pool = list(nb)
+        chunks, pool_len = [np.array(nb, np.int32)], len(nb)
+        ints = all(isinstance(k, int) and not isinstance(k, bool) for k in j_of)
+        if ints and j_of:
+            elem_arr = np.array(sorted(j_of), np.int64)
+            j_arr = np.array([j_of[int(x)] for x in elem_arr], np.int64)
+        nbits = nwords * 32
         for pr in pairs:
             r0, r1, ctype = pr
             op0 = hist[r0]
@@ -169,21 +174,35 @@ class Encoded:
                     v = hist[r1].get("value") if ctype == "ok" else None
                     if v is None:
                         a[r1] = N.NIL
+                        continue
+                    v = list(v)
+                    bits = np.zeros(nbits, bool)
+                    if ints and j_of and all(isinstance(x, int) and not isinstance(x, bool) for x in v[:1]):
+                        arr = np.asarray(v, np.int64) if v else np.zeros(0, np.int64)
+                        pos = np.searchsorted(elem_arr, arr)
+                        pos_c = np.minimum(pos, len(elem_arr) - 1)
+                        hit = elem_arr[pos_c] == arr
+                        ok = bool(hit.all())
+                        bits[j_arr[pos_c[hit]]] = True
+                        n_distinct = len(np.unique(arr))
                     else:
-                        words = [0] * nwords
                         ok = True
                         for e in v:
                             j = j_of.get(memo_ns._freeze(e))
                             if j is None:
                                 ok = False
                             else:
-                                words[j >> 5] |= 1 << (j & 31)
-                        lead = 0
-                        while lead < n_adds and words[lead >> 5] >> (lead & 31) & 1:
-                            lead += 1
-                        a[r1] = len(pool)
-                        pool += [len(set(memo_ns._freeze(e) for e in v)) if ok else -1, lead]
-                        pool += [w - (1 << 32) if w >= (1 << 31) else w for w in words]
+                                bits[j] = True
+                        n_distinct = len(set(memo_ns._freeze(e) for e in v))
+                    head = bits[:n_adds]
+                    lead = int(n_adds if head.all() else np.argmin(head))
+                    words = np.packbits(bits, bitorder="little").view(np.uint32).astype(np.int64)
+                    words = np.where(words >= (1 << 31), words - (1 << 32), words).astype(np.int32)
+                    a[r1] = pool_len
+                    rec = np.concatenate([np.array([n_distinct if ok else -1, lead], np.int32), words])
+                    chunks.append(rec)
+                    pool_len += len(rec)
+        pool = np.concatenate(chunks)
         self.intern = None
         self.pool = np.array(pool, np.int32)
         self.set_order = [hist[pr[0]]["value"] for pr in order]
