@@ -134,6 +134,25 @@ tbc_status tbc_pair_events(const tbc_events* ev,
  * (tests/ledger.clj:89-114; balance = credits - debits, :102-103).
  * TBC_MODEL_TABLE is knossos.model.memo/memo: a dense transition table
  * next = table[state * n_classes + class], 0xFFFF = inconsistent.
+ *
+ * Value pool (tbc_ops.pool, int32) layouts, written by the caller's encoder
+ * (jepsen-tigerbeetle_amd/knossos/_analysis.py is the tested one):
+ *   MULTI_REGISTER  :txn op: a = offset, b = #micro-ops of {f (0 read / 1 write),
+ *                   key (0..n_keys-1, n_keys <= 8), value (0..13 or TBC_NIL for a
+ *                   read)} triples.  State = 4 bits per key; tbc_model.init = packed
+ *                   initial state (0 = all nil).
+ *   SET             commutative, state-free.  tbc_model.init (or
+ *                   tbc_batch_desc.model_aux[h]) = offset of nadds_before[0..R]
+ *                   (R = number of :ok completions of the history, in row order).
+ *                   :add op: a = index j of the add in completion order (crashed adds
+ *                   last); :read op: a = TBC_NIL or offset of {nR, lead, bitset words}
+ *                   (bitset over adds in j order; nR = |R| or -1 if R holds an element
+ *                   nobody adds; lead = number of leading ones).  Elements unique.
+ *   BANK            commutative (negative balances allowed), state-free.  n_keys =
+ *                   #accounts (<= 16); init / model_aux = offset of
+ *                   bal_before[(R+1) * n_keys]; :transfer a = offset of {debit index,
+ *                   credit index, amount}; :read a = TBC_NIL or offset of the balances.
+ * SET and BANK exist in the wide schedule only (search_width >= 2 is forced).
  */
 enum {
   TBC_MODEL_REGISTER = 0,
