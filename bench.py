@@ -48,6 +48,8 @@ def main():
     ap.add_argument("--width", type=int, default=int(os.environ.get("TBC_BENCH_WIDTH", "4")),
                     help="configs expanded per iteration: 1 = sequential knossos.wgl order, 2..16 = wide schedule")
     ap.add_argument("--visited-per-op", type=int, default=32, help="first visited-set capacity per op (0 = library default 64)")
+    ap.add_argument("--round-budget", type=int, default=40000,
+                    help="histories needing more rounds than this are re-run at width 16 after the batch (0 = off)")
     ap.add_argument("--cpu-sample", type=int, default=256, help="histories timed on the CPU oracle (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
@@ -85,7 +87,8 @@ def main():
     t_gen = time.time() - t_gen
     model = core.make_model(N.MODEL_CAS_REGISTER, N.NIL)
     opts = core.make_opts(device=local_rank, time_limit_ms=600000, want_witness=False,
-                          algorithm=N.ALG_COMPETITION, search_width=args.width, visited_per_op=args.visited_per_op)
+                          algorithm=N.ALG_COMPETITION, search_width=args.width, visited_per_op=args.visited_per_op,
+                          round_budget=args.round_budget)
     batch = core.Batch(hists, model, opts)        # H2D happens here: inputs resident before timing
 
     for _ in range(args.warmup):
@@ -136,7 +139,7 @@ def main():
             "dtype": "u64", "data": "synthetic",
             "config": {"workload": WORKLOAD, "histories_per_gpu": B, "ops_after_pairing": int(batch.total_ops // B),
                        "processes": args.procs, "busy": args.busy, "info_rate": args.info,
-                       "search_width": args.width,
+                       "search_width": args.width, "round_budget": args.round_budget,
                        "parallelism": f"independent histories sharded over {world} GPU(s), no collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,

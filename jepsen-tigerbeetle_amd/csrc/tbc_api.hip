@@ -384,6 +384,7 @@ static BeamArgs make_beam_args(tbc_batch* B, uint64_t* tab, uint32_t* stack, uin
   a.init_state = (B->model.kind == TBC_MODEL_MUTEX || comm) ? 0 : B->model.init;
   a.model_aux = B->model.init; a.n_keys = B->model.n_keys;
   a.n_classes = B->model.n_classes; a.width = B->width;
+  a.round_budget = 0;
   a.max_steps = B->opts.max_steps;
   a.time_limit_ticks = B->opts.time_limit_ms * 100000ull;
   a.dbg = debug_words();
@@ -402,7 +403,8 @@ static BeamArgs make_beam_args(tbc_batch* B, uint64_t* tab, uint32_t* stack, uin
 // One extra pass over the histories in `grp` with per-history visited sets of 2^lg[i] entries in a
 // scratch arena (overflow retries, and wide-schedule histories that fall back to the sequential kernel).
 static tbc_status scratch_pass(tbc_batch* B, const std::vector<uint32_t>& grp, const std::vector<uint32_t>& lg,
-                               bool beam, const std::vector<Hist>& hist_back, const std::vector<BeamHist>& bh_back) {
+                               bool beam, const std::vector<Hist>& hist_back, const std::vector<BeamHist>& bh_back,
+                               uint32_t width_override = 0) {
   hipStream_t s = B->stream;
   const uint32_t KW = 1 + B->mask_words, EW = B->mask_words + 2;
   const uint64_t words_per_entry = beam ? EW : KW;
@@ -432,7 +434,9 @@ static tbc_status scratch_pass(tbc_batch* B, const std::vector<uint32_t>& grp, c
   if (e == hipSuccess) e = hipMemcpyAsync(B->d_work.p, grp.data(), grp.size() * 4, hipMemcpyHostToDevice, s);
   if (e == hipSuccess) {
     const uint32_t nw = (uint32_t)grp.size();
-    if (beam) { BeamArgs ba = make_beam_args(B, big.p, bstack.p, nw); ba.pool = nullptr; ba.pool_words = 0; launch_beam(ba, B->mask_words, search_blocks(nw), s); }
+    if (beam) { BeamArgs ba = make_beam_args(B, big.p, bstack.p, nw); ba.pool = nullptr; ba.pool_words = 0;
+      if (width_override) ba.width = width_override;
+      launch_beam(ba, B->mask_words, search_blocks(nw), s); }
     else { SearchArgs ra = make_search_args(B, big.p, nw); launch_search(ra, B->mask_words, search_blocks(nw), s); }
     e = hipGetLastError();
   }
@@ -547,6 +551,7 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results) {
 
   if (beam) {
     BeamArgs ba = make_beam_args(B, B->d_btab.p, B->d_stack.p, nh);
+    if (B->width < 16) ba.round_budget = B->opts.round_budget;
     if (!launch_beam(ba, B->mask_words, search_blocks(nh), s)) { set_error("unsupported mask width"); return TBC_ERR_UNSUPPORTED; }
   } else {
     SearchArgs sa = make_search_args(B, B->d_tab.p, nh);
@@ -589,6 +594,31 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results) {
       touched_work = true;
     }
   }
+  // stragglers of the wide schedule: re-run at width 16, alone on the device (fewer dependent rounds,
+  // unloaded latency); their visited sets start at the size the first pass had reached
+  std::vector<uint32_t> width_of(nh, B->width);
+  if (beam && B->width < 16 && B->opts.round_budget) {
+    std::vector<uint32_t> esc, lg;
+    for (uint32_t h = 0; h < nh; h++)
+      if (B->res_host[h].valid == TBC_UNKNOWN && B->res_host[h].cause == TBC_CAUSE_ROUND_BUDGET) {
+        uint32_t l = std::max(final_log2[h], B->res_host[h].tab_log2) + 1;
+        while (l > 10 && (1ull << l) * EW * 8 > max_bytes) l--;
+        esc.push_back(h); lg.push_back(l); final_log2[h] = l; width_of[h] = 16;
+      }
+    size_t pos = 0;
+    while (pos < esc.size()) {
+      std::vector<uint32_t> grp, glg;
+      uint64_t bytes = 0;
+      while (pos < esc.size()) {
+        const uint64_t need = (1ull << lg[pos]) * (EW + 1) * 8;
+        if (!grp.empty() && bytes + need > (32ull << 30)) break;
+        grp.push_back(esc[pos]); glg.push_back(lg[pos]); bytes += need; pos++;
+      }
+      tbc_status st = scratch_pass(B, grp, glg, true, hist_back, bh_back, 16);
+      if (st != TBC_OK) return st;
+      touched_work = true;
+    }
+  }
   // overflow retries: 16x larger visited set each time, up to max_visited_bytes
   const uint64_t arena_budget = 32ull << 30;
   for (;;) {
@@ -614,11 +644,11 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results) {
         uint64_t bytes = 0;
         while (pos < pend.size()) {
           const uint64_t need = (1ull << lgs[pos]) * wpe * 8;
-          if (!grp.empty() && bytes + need > arena_budget) break;
+          if (!grp.empty() && (bytes + need > arena_budget || (pass == 1 && width_of[pend[pos]] != width_of[grp[0]]))) break;
           grp.push_back(pend[pos]); glg.push_back(lgs[pos]); final_log2[pend[pos]] = lgs[pos];
           bytes += need; pos++;
         }
-        tbc_status st = scratch_pass(B, grp, glg, pass == 1, hist_back, bh_back);
+        tbc_status st = scratch_pass(B, grp, glg, pass == 1, hist_back, bh_back, pass == 1 ? width_of[grp[0]] : 0);
         if (st != TBC_OK) return st;
         touched_work = true;
       }

@@ -186,6 +186,7 @@ struct BeamArgs {
   const int32_t* pool_vals;          // wide op values (multi-register micro-ops)
   uint64_t* cfg;                     // as SearchArgs.cfg
   int32_t model_aux;                 // commutative models: pool offset of the per-front table
+  uint32_t round_budget;             // 0 = none; exceeded => TBC_CAUSE_ROUND_BUDGET (host escalates)
   uint32_t n_keys;                   // bank: number of accounts
 };
 

@@ -447,6 +447,7 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
     }
     if (verdict == -2) {
       if (A.max_steps && probes > A.max_steps) { verdict = TBC_UNKNOWN; cause = TBC_CAUSE_STEP_LIMIT; }
+      else if (A.round_budget && rounds > A.round_budget) { verdict = TBC_UNKNOWN; cause = TBC_CAUSE_ROUND_BUDGET; }
       else if (A.time_limit_ticks && (iterations & 63u) == 0 && (uint64_t)wall_clock64() - t0 > A.time_limit_ticks) {
         verdict = TBC_UNKNOWN; cause = TBC_CAUSE_TIME_LIMIT;
       }

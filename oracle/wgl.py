@@ -43,7 +43,7 @@ def lib():
     global _LIB
     if _LIB is None:
         _LIB = C.CDLL(build())
-        for fn in (_LIB.wgl_ref_check, _LIB.wgl_window_check, _LIB.linear_ref_check, _LIB.wgl_beam_check):
+        for fn in (_LIB.wgl_ref_check, _LIB.wgl_window_check, _LIB.linear_ref_check, _LIB.wgl_beam_check, _LIB.wgl_beam_check_rp):
             fn.restype = C.c_int
     return _LIB
 
@@ -143,7 +143,7 @@ class BeamStats(C.Structure):
                 ("expanded", C.c_uint64), ("max_stack", C.c_uint64), ("rounds", C.c_uint64)]
 
 
-def check_beam(ops, model, width=16, max_probes=0, want_witness=True):
+def check_beam(ops, model, width=16, max_probes=0, want_witness=True, round_pairs=64):
     """The wide (K configs per iteration) schedule of the same search: wgl_beam.c."""
     n = len(ops["f"])
     f = np.ascontiguousarray(ops["f"], np.uint8)
@@ -155,10 +155,10 @@ def check_beam(ops, model, width=16, max_probes=0, want_witness=True):
     m, keep = _model(model)
     res, st = OracleResult(), BeamStats()
     wit = np.zeros(max(n, 1), np.uint32)
-    rc = lib().wgl_beam_check(C.c_uint32(n), _p(f, C.c_uint8), _p(a, C.c_int32), _p(b, C.c_int32),
-                              _p(proc, C.c_int32), C.c_uint32(int(ops["n_process"])), _p(inv, C.c_uint32),
-                              _p(ret, C.c_uint32), C.byref(m), C.c_uint32(width), C.c_uint64(max_probes),
-                              _p(wit, C.c_uint32), C.byref(res), C.byref(st))
+    rc = lib().wgl_beam_check_rp(C.c_uint32(n), _p(f, C.c_uint8), _p(a, C.c_int32), _p(b, C.c_int32),
+                                 _p(proc, C.c_int32), C.c_uint32(int(ops["n_process"])), _p(inv, C.c_uint32),
+                                 _p(ret, C.c_uint32), C.byref(m), C.c_uint32(width), C.c_uint32(round_pairs),
+                                 C.c_uint64(max_probes), _p(wit, C.c_uint32), C.byref(res), C.byref(st))
     if rc != 0:
         raise ValueError(f"oracle rejected history (rc={rc})")
     out = {k: getattr(res, k) for k, _ in OracleResult._fields_}

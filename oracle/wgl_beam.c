@@ -120,14 +120,30 @@ uint32_t wgl_beam_last_configs(uint64_t* out, uint32_t max, uint32_t* kw) {
   return g_bcfg_n;
 }
 
+/* round_pairs: pairs per round (64 = one wavefront; 256 = the workgroup-cooperative kernel) */
+int wgl_beam_check_rp(uint32_t n, const uint8_t* f, const int32_t* a, const int32_t* b,
+                      const int32_t* process, uint32_t n_process,
+                      const uint32_t* inv_pos, const uint32_t* ret_pos,
+                      const oracle_model* model, uint32_t K, uint32_t round_pairs, uint64_t max_probes,
+                      uint32_t* witness, oracle_result* out, beam_stats* st);
+
 int wgl_beam_check(uint32_t n, const uint8_t* f, const int32_t* a, const int32_t* b,
                    const int32_t* process, uint32_t n_process,
                    const uint32_t* inv_pos, const uint32_t* ret_pos,
                    const oracle_model* model, uint32_t K, uint64_t max_probes,
                    uint32_t* witness, oracle_result* out, beam_stats* st) {
+  return wgl_beam_check_rp(n, f, a, b, process, n_process, inv_pos, ret_pos, model, K, 64, max_probes, witness, out, st);
+}
+
+int wgl_beam_check_rp(uint32_t n, const uint8_t* f, const int32_t* a, const int32_t* b,
+                      const int32_t* process, uint32_t n_process,
+                      const uint32_t* inv_pos, const uint32_t* ret_pos,
+                      const oracle_model* model, uint32_t K, uint32_t round_pairs, uint64_t max_probes,
+                      uint32_t* witness, oracle_result* out, beam_stats* st) {
   memset(out, 0, sizeof *out); memset(st, 0, sizeof *st);
   out->fail_op = out->prev_ok_op = 0xFFFFFFFFu;
-  if (K == 0 || K > 64) return 1;
+  if (K == 0 || K > 64 || round_pairs == 0 || round_pairs > 1024) return 1;
+  const uint32_t RP = round_pairs;
   uint32_t R = 0;
   for (uint32_t i = 0; i < n; i++) {
     if (i && inv_pos[i] <= inv_pos[i - 1]) return 2;
@@ -196,8 +212,8 @@ int wgl_beam_check(uint32_t n, const uint8_t* f, const int32_t* a, const int32_t
 
   uint32_t par[64], pcnt[64], pstart[65];
   /* per-round scratch */
-  uint64_t* ck = (uint64_t*)malloc(64 * KW * 8);
-  uint32_t cop[64], cpar[64]; int cviable[64]; uint32_t cfront[64]; int32_t cstate[64];
+  uint64_t* ck = (uint64_t*)malloc((size_t)RP * KW * 8);
+  uint32_t cop[1024], cpar[1024]; int cviable[1024]; uint32_t cfront[1024]; int32_t cstate[1024];
 
   while (verdict == -2) {
     if (sp == 0) { verdict = 0; break; }
@@ -212,8 +228,8 @@ int wgl_beam_check(uint32_t n, const uint8_t* f, const int32_t* a, const int32_t
       pstart[q] = T; T += pcnt[q];
     }
     pstart[np] = T;
-    for (uint32_t base = 0; base < T && verdict == -2; base += 64) {
-      uint32_t m = T - base < 64 ? T - base : 64;
+    for (uint32_t base = 0; base < T && verdict == -2; base += RP) {
+      uint32_t m = T - base < RP ? T - base : RP;
       int success = -1;
       for (uint32_t l = 0; l < m; l++) {
         uint32_t r = base + l, q = 0;

@@ -258,3 +258,26 @@ def test_invalid_verdict_carries_the_stuck_configs(native, oracle, alg):
     a = wgl.analysis(M.cas_register(), [kop.invoke(0, "write", 1), kop.ok(0, "write", 1), kop.invoke(1, "read", None), kop.ok(1, "read", 2)])
     assert a["valid?"] is False and a["configs"] and a["configs"][0]["model"] == M.CASRegister(1)
     assert [o["f"] for o in a["configs"][0]["pending"]] == ["read"]
+
+
+def test_round_budget_escalates_stragglers_to_width_16(native, oracle):
+    """tbc_opts.round_budget: a history that needs more rounds than the budget at the batch's width is
+    re-run at width 16; the others keep their result.  Both are the deterministic schedules of
+    oracle/wgl_beam.c, so every result is still bit-exact."""
+    hists = [columns.pair_events(synth.register_events(n_ops=1500, n_procs=24, seed=s, busy=0.25, info=0.01)) for s in range(24)]
+    exp4 = [oracle.check_beam(h.as_dict(), CAS, 4) for h in hists]
+    rounds = sorted(e["rounds"] for e in exp4)
+    budget = rounds[len(rounds) * 2 // 3]            # about a third of the histories exceed it
+    opts = core.make_opts(time_limit_ms=60000, algorithm=N.ALG_COMPETITION, search_width=4, round_budget=budget)
+    with core.Batch(hists, gm(), opts) as b:
+        res = b.run().results()
+    n_esc = 0
+    for h, got, e4 in zip(hists, res, exp4):
+        exp = e4
+        if e4["rounds"] > budget:
+            exp = oracle.check_beam(h.as_dict(), CAS, 16)
+            n_esc += 1
+        assert got["valid"] == exp["valid"] == 1 and got["cause"] == 0
+        assert np.array_equal(got["witness"], exp["witness"])
+        assert (got["probes"], got["visited"]) == (exp["probes"], exp["visited"])
+    assert 3 <= n_esc <= 12
