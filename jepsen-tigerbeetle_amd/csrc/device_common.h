@@ -70,4 +70,87 @@ struct Model {
 };
 
 
+// May the open call `oi` be linearized next in the config (fi, Mp, st)?  State-based models ask
+// Model::ok; the commutative ones (set, bank) look at the calls completed before the front (per-front
+// tables in the pool) and at the open calls already linearized (the parent's open-call list).
+template <int MW>
+__device__ __forceinline__ bool pair_viable(const Model& model, int32_t st, uint32_t fi, const uint64_t (&Mp)[MW],
+                                            uint32_t poff, uint32_t nlive, uint32_t cnt, const uint32_t* lst,
+                                            const uint32_t* crashed, const OpInfo* opinfo, const OpInfo& oi) {
+  const uint32_t f = oi.f_slot & 0xFFu;
+  if (!model.commutative()) return model.ok(st, f, oi.a, oi.b);
+  if (model.kind == TBC_MODEL_SET) {
+    // knossos.model/set, state-free: a read of R is consistent iff the adds completed before the
+    // front plus the open adds already linearized are exactly R (pool layout: include/tbcheck.h)
+    if (f != TBC_F_READ || oi.a == TBC_NIL) return f == TBC_F_ADD || f == TBC_F_READ;
+    const int32_t* rp = model.pool + oi.a;
+    const int32_t nR = rp[0], lead = rp[1];
+    int32_t count = model.pool[model.aux + (int32_t)fi];
+    bool viable = nR >= 0 && count <= lead;
+    for (uint32_t cc = 0; viable && cc < cnt; cc++) {
+      const uint32_t x = cc < nlive ? lst[poff + cc] : crashed[cc - nlive];
+      const OpInfo ox = opinfo[x];
+      const uint32_t px = ox.f_slot >> 8;
+      bool lx = false;
+#pragma unroll
+      for (int j = 0; j < MW; j++) if ((px >> 6) == (uint32_t)j) lx = (Mp[j] >> (px & 63u)) & 1ull;
+      if (!lx || (ox.f_slot & 0xFFu) != TBC_F_ADD) continue;
+      const uint32_t jx = (uint32_t)ox.a;
+      if (!(((uint32_t)rp[2 + (jx >> 5)] >> (jx & 31u)) & 1u)) viable = false;
+      count++;
+    }
+    return viable && count == nR;
+  }
+  // bank (negative balances allowed => transfers commute): balances = table of the transfers
+  // completed before the front + the open transfers already linearized
+  if (f != TBC_F_READ || oi.a == TBC_NIL) return f == TBC_F_TRANSFER || f == TBC_F_READ;
+  int32_t bal[16];
+  const uint32_t NA = model.n_keys;
+  for (uint32_t a2 = 0; a2 < NA; a2++) bal[a2] = model.pool[model.aux + (int32_t)(fi * NA + a2)];
+  for (uint32_t cc = 0; cc < cnt; cc++) {
+    const uint32_t x = cc < nlive ? lst[poff + cc] : crashed[cc - nlive];
+    const OpInfo ox = opinfo[x];
+    const uint32_t px = ox.f_slot >> 8;
+    bool lx = false;
+#pragma unroll
+    for (int j = 0; j < MW; j++) if ((px >> 6) == (uint32_t)j) lx = (Mp[j] >> (px & 63u)) & 1ull;
+    if (!lx || (ox.f_slot & 0xFFu) != TBC_F_TRANSFER) continue;
+    const int32_t* tp = model.pool + ox.a;
+    const int32_t amt = tp[2];
+    for (uint32_t a2 = 0; a2 < NA; a2++) { if ((int32_t)a2 == tp[0]) bal[a2] -= amt; if ((int32_t)a2 == tp[1]) bal[a2] += amt; }
+  }
+  bool viable = true;
+  for (uint32_t a2 = 0; a2 < NA; a2++) viable = viable && bal[a2] == model.pool[oi.a + (int32_t)a2];
+  return viable;
+}
+
+// The config reached by linearizing `oi` in (fi, Mp, st): set its process bit, step the model, and if it
+// was the front's own call move the front past every completion already linearized (clearing their bits).
+template <int MW>
+__device__ __forceinline__ void make_child(const Model& model, bool viable, int32_t st, uint32_t fi, uint32_t R,
+                                           const uint32_t* ret_slot, uint32_t next_slot, const OpInfo& oi,
+                                           const uint64_t (&Mp)[MW], uint64_t (&M2)[MW], int32_t& st2, uint32_t& fi2) {
+  const uint32_t f = oi.f_slot & 0xFFu, p = oi.f_slot >> 8;
+  st2 = st; fi2 = fi;
+#pragma unroll
+  for (int j = 0; j < MW; j++) M2[j] = Mp[j];
+  if (!viable) return;
+  st2 = model.commutative() ? 0 : model.apply(st, f, oi.a, oi.b);
+#pragma unroll
+  for (int j = 0; j < MW; j++) if ((p >> 6) == (uint32_t)j) M2[j] |= 1ull << (p & 63u);
+  if (oi.ret_rank != fi) return;
+  uint32_t pp = p;
+  for (;;) {
+#pragma unroll
+    for (int j = 0; j < MW; j++) if ((pp >> 6) == (uint32_t)j) M2[j] &= ~(1ull << (pp & 63u));
+    fi2++;
+    if (fi2 == R) break;
+    pp = (fi2 == fi + 1u) ? next_slot : ret_slot[fi2];
+    bool bit = false;
+#pragma unroll
+    for (int j = 0; j < MW; j++) if ((pp >> 6) == (uint32_t)j) bit = (M2[j] >> (pp & 63u)) & 1ull;
+    if (!bit) break;
+  }
+}
+
 }  // namespace tbc

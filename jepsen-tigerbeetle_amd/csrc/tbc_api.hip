@@ -118,6 +118,7 @@ struct tbc_batch {
   DevBuf<uint64_t> d_cfg;           // configs at the failing front, kCfgCap records per history
   // wide schedule (search_width > 1)
   uint32_t width = 1;
+  bool wg = false;                  // width 32 / 64: one workgroup per history (wgl_beam_wg.hip)
   std::vector<BeamHist> bh;
   DevBuf<BeamHist> d_bh;
   DevBuf<uint32_t> d_off, d_ncr, d_lst, d_crashed, d_stack;
@@ -205,8 +206,8 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
   B->frame_words = search_frame_words(B->mask_words);
   const uint32_t KW = 1 + B->mask_words;
   uint32_t width = opts->search_width ? opts->search_width : (opts->algorithm == TBC_ALG_WGL ? 1u : 16u);
-  if (width > 16) width = 16;
-  while (width & (width - 1)) width &= width - 1;   // the wide kernel takes a power of two (lanes per parent = 64 / width)
+  if (width > 64) width = 64;
+  while (width & (width - 1)) width &= width - 1;   // the wide kernels take a power of two
   if (B->mask_words > 4) width = 1;          // very wide windows: sequential kernel only
   const bool commutative = model->kind == TBC_MODEL_SET || model->kind == TBC_MODEL_BANK;
   if (commutative) {                          // state-free models exist in the wide kernel only
@@ -214,8 +215,9 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
     if (width < 2) width = 4;
   }
   B->width = width;
+  B->wg = width > 16;
   const bool beam = width > 1;
-  const uint32_t EW = B->mask_words + 2;     // u64 words per wide-schedule entry
+  const uint32_t EW = B->wg ? beam_wg_entry_words(B->mask_words) : B->mask_words + 2;   // u64 words per wide-schedule entry
 
   const uint64_t default_cap_bytes = 1ull << 30;
   const uint64_t max_bytes = opts->max_visited_bytes ? opts->max_visited_bytes : default_cap_bytes;
@@ -406,7 +408,9 @@ static tbc_status scratch_pass(tbc_batch* B, const std::vector<uint32_t>& grp, c
                                bool beam, const std::vector<Hist>& hist_back, const std::vector<BeamHist>& bh_back,
                                uint32_t width_override = 0) {
   hipStream_t s = B->stream;
-  const uint32_t KW = 1 + B->mask_words, EW = B->mask_words + 2;
+  const uint32_t pass_width = width_override ? width_override : B->width;
+  const bool wg = beam && pass_width > 16;
+  const uint32_t KW = 1 + B->mask_words, EW = wg ? beam_wg_entry_words(B->mask_words) : B->mask_words + 2;
   const uint64_t words_per_entry = beam ? EW : KW;
   uint64_t entries = 0;
   std::vector<Hist> ph(grp.size());
@@ -436,7 +440,7 @@ static tbc_status scratch_pass(tbc_batch* B, const std::vector<uint32_t>& grp, c
     const uint32_t nw = (uint32_t)grp.size();
     if (beam) { BeamArgs ba = make_beam_args(B, big.p, bstack.p, nw); ba.pool = nullptr; ba.pool_words = 0;
       if (width_override) ba.width = width_override;
-      launch_beam(ba, B->mask_words, search_blocks(nw), s); }
+      if (wg) launch_beam_wg(ba, B->mask_words, nw, s); else launch_beam(ba, B->mask_words, search_blocks(nw), s); }
     else { SearchArgs ra = make_search_args(B, big.p, nw); launch_search(ra, B->mask_words, search_blocks(nw), s); }
     e = hipGetLastError();
   }
@@ -507,7 +511,7 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results) {
   const uint32_t nh = B->n_hist;
   hipStream_t s = B->stream;
   const bool beam = B->width > 1;
-  const uint32_t KW = 1 + B->mask_words, EW = B->mask_words + 2;
+  const uint32_t KW = 1 + B->mask_words, EW = B->wg ? beam_wg_entry_words(B->mask_words) : B->mask_words + 2;
 
   TRACE("run: begin");
   HIP_TRY(hipEventRecord(B->ev[0], s));
@@ -552,7 +556,7 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results) {
   if (beam) {
     BeamArgs ba = make_beam_args(B, B->d_btab.p, B->d_stack.p, nh);
     if (B->width < 16) ba.round_budget = B->opts.round_budget;
-    if (!launch_beam(ba, B->mask_words, search_blocks(nh), s)) { set_error("unsupported mask width"); return TBC_ERR_UNSUPPORTED; }
+    if (B->wg ? !launch_beam_wg(ba, B->mask_words, nh, s) : !launch_beam(ba, B->mask_words, search_blocks(nh), s)) { set_error("unsupported mask width"); return TBC_ERR_UNSUPPORTED; }
   } else {
     SearchArgs sa = make_search_args(B, B->d_tab.p, nh);
     if (!launch_search(sa, B->mask_words, search_blocks(nh), s)) { set_error("unsupported mask width"); return TBC_ERR_UNSUPPORTED; }
@@ -594,8 +598,8 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results) {
       touched_work = true;
     }
   }
-  // stragglers of the wide schedule: re-run at width 16, alone on the device (fewer dependent rounds,
-  // unloaded latency); their visited sets start at the size the first pass had reached
+  // stragglers of the wide schedule: re-run with one 256-lane workgroup each at width 32 (4-6x fewer
+  // dependent rounds, unloaded latency); their visited sets start at the size the first pass had reached
   std::vector<uint32_t> width_of(nh, B->width);
   if (beam && B->width < 16 && B->opts.round_budget) {
     std::vector<uint32_t> esc, lg;
@@ -603,18 +607,18 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results) {
       if (B->res_host[h].valid == TBC_UNKNOWN && B->res_host[h].cause == TBC_CAUSE_ROUND_BUDGET) {
         uint32_t l = std::max(final_log2[h], B->res_host[h].tab_log2) + 1;
         while (l > 10 && (1ull << l) * EW * 8 > max_bytes) l--;
-        esc.push_back(h); lg.push_back(l); final_log2[h] = l; width_of[h] = 16;
+        esc.push_back(h); lg.push_back(l); final_log2[h] = l; width_of[h] = 32;
       }
     size_t pos = 0;
     while (pos < esc.size()) {
       std::vector<uint32_t> grp, glg;
       uint64_t bytes = 0;
       while (pos < esc.size()) {
-        const uint64_t need = (1ull << lg[pos]) * (EW + 1) * 8;
+        const uint64_t need = (1ull << lg[pos]) * (beam_wg_entry_words(B->mask_words) + 1) * 8;
         if (!grp.empty() && bytes + need > (32ull << 30)) break;
         grp.push_back(esc[pos]); glg.push_back(lg[pos]); bytes += need; pos++;
       }
-      tbc_status st = scratch_pass(B, grp, glg, true, hist_back, bh_back, 16);
+      tbc_status st = scratch_pass(B, grp, glg, true, hist_back, bh_back, 32);
       if (st != TBC_OK) return st;
       touched_work = true;
     }

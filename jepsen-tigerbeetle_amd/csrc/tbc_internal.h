@@ -192,6 +192,9 @@ struct BeamArgs {
 
 void launch_pack_open(const PackOpenArgs& a, void* stream);
 bool launch_beam(const BeamArgs& a, uint32_t mask_words, uint32_t n_blocks, void* stream);
+// one 256-lane workgroup per history (search_width 32 / 64); entries have one more word
+bool launch_beam_wg(const BeamArgs& a, uint32_t mask_words, uint32_t n_hist, void* stream);
+uint32_t beam_wg_entry_words(uint32_t mask_words);
 
 // kernel launchers (defined in the .hip files)
 void launch_pack(const PackArgs& a, void* stream);

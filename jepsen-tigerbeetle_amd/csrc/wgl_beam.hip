@@ -41,7 +41,6 @@ namespace tbc {
 
 namespace {
 
-constexpr uint32_t kMaxWidth = 16;
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 
 __device__ __forceinline__ uint64_t ld64(const uint64_t* p) {
@@ -281,88 +280,16 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
       uint32_t op = 0;
       OpInfo oi; oi.ret_rank = 0; oi.f_slot = kFNone; oi.a = 0; oi.b = 0;
       if (act) { op = c < nlive ? lst[poff + c] : crashed[c - nlive]; oi = opinfo[op]; }
-      const uint32_t f = oi.f_slot & 0xFFu, p = oi.f_slot >> 8;
+      const uint32_t p = oi.f_slot >> 8;
       if (prof) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); SEG(1); }
       bool lin = false;
 #pragma unroll
       for (int j = 0; j < MW; j++) if ((p >> 6) == (uint32_t)j) lin = (Mp[j] >> (p & 63u)) & 1ull;
-      bool viable = act && !lin;
-      if (viable) {
-        if (!model.commutative()) {
-          viable = model.ok(st, f, oi.a, oi.b);
-        } else if (model.kind == TBC_MODEL_SET) {
-          // knossos.model/set, state-free: a read of R is consistent iff the adds completed before the
-          // front plus the open adds already linearized are exactly R (pool layout: knossos/_analysis.py)
-          if (f == TBC_F_READ && oi.a != TBC_NIL) {
-            const int32_t* rp = model.pool + oi.a;
-            const int32_t nR = rp[0], lead = rp[1];
-            int32_t count = model.pool[model.aux + (int32_t)fi];
-            viable = nR >= 0 && count <= lead;
-            for (uint32_t cc = 0; viable && cc < cnt; cc++) {
-              const uint32_t x = cc < nlive ? lst[poff + cc] : crashed[cc - nlive];
-              const OpInfo ox = opinfo[x];
-              const uint32_t px = ox.f_slot >> 8;
-              bool lx = false;
-#pragma unroll
-              for (int j = 0; j < MW; j++) if ((px >> 6) == (uint32_t)j) lx = (Mp[j] >> (px & 63u)) & 1ull;
-              if (!lx || (ox.f_slot & 0xFFu) != TBC_F_ADD) continue;
-              const uint32_t jx = (uint32_t)ox.a;
-              if (!(((uint32_t)rp[2 + (jx >> 5)] >> (jx & 31u)) & 1u)) viable = false;
-              count++;
-            }
-            viable = viable && count == nR;
-          } else {
-            viable = f == TBC_F_ADD || f == TBC_F_READ;
-          }
-        } else {
-          // bank (negative balances allowed => transfers commute): balances = table of the transfers
-          // completed before the front + the open transfers already linearized
-          if (f == TBC_F_READ && oi.a != TBC_NIL) {
-            int32_t bal[16];
-            const uint32_t NA = model.n_keys;
-            for (uint32_t a2 = 0; a2 < NA; a2++) bal[a2] = model.pool[model.aux + (int32_t)(fi * NA + a2)];
-            for (uint32_t cc = 0; cc < cnt; cc++) {
-              const uint32_t x = cc < nlive ? lst[poff + cc] : crashed[cc - nlive];
-              const OpInfo ox = opinfo[x];
-              const uint32_t px = ox.f_slot >> 8;
-              bool lx = false;
-#pragma unroll
-              for (int j = 0; j < MW; j++) if ((px >> 6) == (uint32_t)j) lx = (Mp[j] >> (px & 63u)) & 1ull;
-              if (!lx || (ox.f_slot & 0xFFu) != TBC_F_TRANSFER) continue;
-              const int32_t* tp = model.pool + ox.a;
-              const int32_t amt = tp[2];
-              for (uint32_t a2 = 0; a2 < NA; a2++) { if ((int32_t)a2 == tp[0]) bal[a2] -= amt; if ((int32_t)a2 == tp[1]) bal[a2] += amt; }
-            }
-            for (uint32_t a2 = 0; a2 < NA; a2++) viable = viable && bal[a2] == model.pool[oi.a + (int32_t)a2];
-          } else {
-            viable = f == TBC_F_TRANSFER || f == TBC_F_READ;
-          }
-        }
-      }
+      const bool viable = act && !lin && pair_viable<MW>(model, st, fi, Mp, poff, nlive, cnt, lst, crashed, opinfo, oi);
       int32_t st2 = st;
       uint32_t fi2 = fi;
       uint64_t M2[MW];
-#pragma unroll
-      for (int j = 0; j < MW; j++) M2[j] = Mp[j];
-      if (viable) {
-        st2 = model.commutative() ? 0 : model.apply(st, f, oi.a, oi.b);
-#pragma unroll
-        for (int j = 0; j < MW; j++) if ((p >> 6) == (uint32_t)j) M2[j] |= 1ull << (p & 63u);
-        if (oi.ret_rank == fi) {   // the front's own call: the front moves past every completion already linearized
-          uint32_t pp = p;
-          for (;;) {
-#pragma unroll
-            for (int j = 0; j < MW; j++) if ((pp >> 6) == (uint32_t)j) M2[j] &= ~(1ull << (pp & 63u));
-            fi2++;
-            if (fi2 == R) break;
-            pp = (fi2 == fi + 1u) ? next_slot : ret_slot[fi2];
-            bool bit = false;
-#pragma unroll
-            for (int j = 0; j < MW; j++) if ((pp >> 6) == (uint32_t)j) bit = (M2[j] >> (pp & 63u)) & 1ull;
-            if (!bit) break;
-          }
-        }
-      }
+      make_child<MW>(model, viable, st, fi, R, ret_slot, next_slot, oi, Mp, M2, st2, fi2);
       SEG(2);
       rounds++;
       const uint64_t succ = __ballot(viable && fi2 == R);

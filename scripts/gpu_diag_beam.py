@@ -30,7 +30,7 @@ stages = [(8, 3, 0.0, 0.0, 0.5), (8, 3, 0.1, 0.5, 0.8), (40, 4, 0.0, 0.0, 0.5), 
 allok = True
 for (n, p, info, corrupt, busy) in stages:
     ops = columns.pair_events(synth.register_events(n_ops=n, n_procs=p, seed=1, busy=busy, info=info, corrupt=corrupt))
-    exp = wgl.check_beam(ops.as_dict(), model, K)
+    exp = wgl.check_beam(ops.as_dict(), model, K, round_pairs=(256 if K > 16 else 64))
     print(f"stage n={n} p={p} info={info} corrupt={corrupt}: ops={len(ops)} W={ops.n_process} oracle valid={exp['valid']} iters={exp['iterations']} rounds={exp['rounds']} probes={exp['probes']} visited={exp['visited']}", flush=True)
     t = time.time()
     try:
