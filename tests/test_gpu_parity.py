@@ -260,10 +260,31 @@ def test_invalid_verdict_carries_the_stuck_configs(native, oracle, alg):
     assert [o["f"] for o in a["configs"][0]["pending"]] == ["read"]
 
 
-def test_round_budget_escalates_stragglers_to_width_16(native, oracle):
+@pytest.mark.parametrize("width", [32, 64])
+def test_workgroup_kernel_matches_its_oracle(native, oracle, width):
+    """search_width 32 / 64: one 256-lane workgroup per history (wgl_beam_wg.hip), the schedule of
+    oracle/wgl_beam.c with 256 pairs per round -- duplicates across wavefronts resolved by owner tags."""
+    cases = [(8, 3, 0.1, 0.5, 0.8), (200, 8, 0.02, 0.0, 0.5), (200, 8, 0.0, 0.6, 0.3), (1000, 16, 0.02, 0.0, 0.5),
+             (1000, 16, 0.0, 0.6, 0.2), (3000, 64, 0.02, 0.0, 0.1), (3000, 64, 0.0, 0.6, 0.05)]
+    hists = [columns.pair_events(synth.register_events(n_ops=n, n_procs=p, seed=s, busy=busy, info=info, corrupt=corrupt))
+             for (n, p, info, corrupt, busy) in cases for s in range(2)]
+    with core.Batch(hists, gm(), core.make_opts(time_limit_ms=60000, search_width=width, algorithm=N.ALG_COMPETITION)) as b:
+        res = b.run().results()
+    for i, (h, got) in enumerate(zip(hists, res)):
+        exp = oracle.check_beam(h.as_dict(), CAS, width, round_pairs=256)
+        assert got["valid"] == exp["valid"], i
+        assert (got["probes"], got["visited"], got["backtracks"], got["max_depth"]) == \
+               (exp["probes"], exp["visited"], exp["expanded"], exp["max_stack"]), i
+        if exp["valid"] == 1:
+            assert np.array_equal(got["witness"], exp["witness"]) and got["final_state"] == exp["final_state"], i
+        else:
+            assert got["fail_op"] == exp["fail_op"], i
+
+
+def test_round_budget_escalates_stragglers_to_the_workgroup_kernel(native, oracle):
     """tbc_opts.round_budget: a history that needs more rounds than the budget at the batch's width is
-    re-run at width 16; the others keep their result.  Both are the deterministic schedules of
-    oracle/wgl_beam.c, so every result is still bit-exact."""
+    re-run by the workgroup kernel at width 32; the others keep their result.  Both are deterministic
+    schedules of oracle/wgl_beam.c, so every result is still bit-exact."""
     hists = [columns.pair_events(synth.register_events(n_ops=1500, n_procs=24, seed=s, busy=0.25, info=0.01)) for s in range(24)]
     exp4 = [oracle.check_beam(h.as_dict(), CAS, 4) for h in hists]
     rounds = sorted(e["rounds"] for e in exp4)
@@ -275,7 +296,7 @@ def test_round_budget_escalates_stragglers_to_width_16(native, oracle):
     for h, got, e4 in zip(hists, res, exp4):
         exp = e4
         if e4["rounds"] > budget:
-            exp = oracle.check_beam(h.as_dict(), CAS, 16)
+            exp = oracle.check_beam(h.as_dict(), CAS, 32, round_pairs=256)
             n_esc += 1
         assert got["valid"] == exp["valid"] == 1 and got["cause"] == 0
         assert np.array_equal(got["witness"], exp["witness"])
