@@ -317,6 +317,9 @@ uint32_t tbc_version(void);             /* TBC_ABI_VERSION                      
 const char* tbc_strerror(int status);
 const char* tbc_last_error(void);       /* thread-local detail of the last error */
 int32_t tbc_device_count(void);         /* gfx950 devices visible; 0 if none     */
+/* diagnostics: with TBC_DEBUG=1 in the environment the kernels mirror their progress into
+ * host-mapped words; this copies up to n (<= 64) of them.  Returns 0 when disabled. */
+int tbc_debug_peek(uint32_t* out, uint32_t n);
 
 #ifdef __cplusplus
 }

@@ -123,6 +123,7 @@ SYMBOLS = {
     "tbc_strerror": (C.c_char_p, [C.c_int]),
     "tbc_last_error": (C.c_char_p, []),
     "tbc_device_count": (C.c_int32, []),
+    "tbc_debug_peek": (C.c_int, [C.POINTER(C.c_uint32), C.c_uint32]),
     "tbs_gen_register": (C.c_int, [C.POINTER(SynthParams), C.POINTER(C.c_uint8), C.POINTER(C.c_int32),
                                    C.POINTER(C.c_uint8), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                    C.POINTER(C.c_uint32)]),

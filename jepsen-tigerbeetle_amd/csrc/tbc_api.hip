@@ -127,7 +127,6 @@ struct tbc_batch {
   DevBuf<OpInfo> d_opinfo;
   // last run
   std::vector<DevResult> res_host;
-  std::vector<uint32_t> fail_host;   // 2 per history: fail_op, prev_ok_op
   std::vector<uint32_t> witness_host;
   uint64_t timing_ns[4] = {0, 0, 0, 0};
   tbc_counters sum{};

@@ -8,7 +8,6 @@ from jepsen_tigerbeetle_amd import _native as N, columns, core, synth
 from oracle import wgl
 
 lib = N.lib()
-lib.tbc_debug_peek.restype = C.c_int
 stop = False
 def watch():
     buf = (C.c_uint32 * 24)()

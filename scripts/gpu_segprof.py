@@ -3,8 +3,7 @@ os.environ["TBC_DEBUG"] = "1"
 sys.path.insert(0, ".")
 import jepsen_tigerbeetle_amd
 from jepsen_tigerbeetle_amd import _native as N, columns, core, synth
-lib = N.lib(); lib.tbc_debug_peek.restype = C.c_int
-gm = core.make_model(N.MODEL_CAS_REGISTER, N.NIL)
+lib = N.lib(); gm = core.make_model(N.MODEL_CAS_REGISTER, N.NIL)
 for K in (8, 4, 16):
     for seed in (1, 3):
         ops = columns.pair_events(synth.register_events(n_ops=10000, n_procs=64, seed=seed, busy=0.1))

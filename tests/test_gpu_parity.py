@@ -302,3 +302,26 @@ def test_round_budget_escalates_stragglers_to_the_workgroup_kernel(native, oracl
         assert np.array_equal(got["witness"], exp["witness"])
         assert (got["probes"], got["visited"]) == (exp["probes"], exp["visited"])
     assert 3 <= n_esc <= 12
+
+
+def test_against_committed_golden_fixtures(native):
+    """The HIP kernels against tests/golden/synth_golden.json alone (no live oracle in the loop)."""
+    import hashlib
+    import json
+    import os
+    from helpers import GOLDEN
+    cases = json.load(open(os.path.join(GOLDEN, "synth_golden.json")))["cases"]
+    hists = [columns.pair_events(synth.register_events(**g["case"])) for g in cases]
+    sha = lambda w: hashlib.sha256(np.asarray(w).astype("<u4").tobytes()).hexdigest()[:16]
+    for opts, key in ((core.make_opts(time_limit_ms=60000), "sequential"),
+                      (core.make_opts(time_limit_ms=60000, algorithm=N.ALG_COMPETITION, search_width=8), "wide8")):
+        with core.Batch(hists, gm(), opts) as b:
+            res = b.run().results()
+        for g, got in zip(cases, res):
+            assert got["valid"] == g["valid"]
+            if g["valid"] == 1:
+                assert got["final_state"] == g[key]["final_state"] and sha(got["witness"]) == g[key]["witness_sha"]
+            else:
+                assert got["fail_op"] == g["fail_op"]
+            assert got["visited"] == g[key]["visited"]
+            assert got["probes"] == (g[key]["steps"] if key == "sequential" else g[key]["probes"])

@@ -75,3 +75,25 @@ def test_windowed_form_equals_published_form(native, oracle, n_ops, procs, info,
             assert np.array_equal(a["witness"], b["witness"])
             # a witness is a legal run that respects real-time order
             brute.check_witness(m, op_tuples(ops), list(a["witness"]))
+
+
+def test_committed_golden_fixtures_still_hold(native, oracle):
+    """tests/golden/synth_golden.json (made by tests/golden/make_synth_golden.py): the oracle and the
+    seeded generator have not drifted."""
+    import hashlib
+    import json
+    import os
+    from helpers import GOLDEN
+    cases = json.load(open(os.path.join(GOLDEN, "synth_golden.json")))["cases"]
+    m = {"kind": 1, "init": N.NIL}
+    for g in cases:
+        ops = columns.pair_events(synth.register_events(**g["case"]))
+        assert len(ops) == g["n_ops"] and ops.n_process == g["n_process"]
+        r = oracle.check(ops.as_dict(), m, "window")
+        assert r["valid"] == g["valid"] and r["steps"] == g["sequential"]["steps"]
+        if r["valid"] == 1:
+            assert hashlib.sha256(r["witness"].astype("<u4").tobytes()).hexdigest()[:16] == g["sequential"]["witness_sha"]
+        else:
+            assert r["fail_op"] == g["fail_op"]
+        w = oracle.check_beam(ops.as_dict(), m, 8)
+        assert (w["probes"], w["visited"]) == (g["wide8"]["probes"], g["wide8"]["visited"])
