@@ -49,7 +49,7 @@ def main():
                     help="configs expanded per iteration: 1 = sequential knossos.wgl order, 2..16 = wide schedule")
     ap.add_argument("--visited-per-op", type=int, default=32, help="first visited-set capacity per op (0 = library default 64)")
     ap.add_argument("--round-budget", type=int, default=0,
-                    help="histories needing more rounds than this are re-run by the workgroup kernel after the batch (0 = off; measured: no gain on this workload, the slowest history is slow under every schedule)")
+                    help="a history that has used more rounds than this continues at width 16 (0 = off)")
     ap.add_argument("--cpu-sample", type=int, default=256, help="histories timed on the CPU oracle (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()

@@ -196,10 +196,10 @@ typedef struct tbc_opts {
                              /* (same verdict / failing op, one (config, call)    */
                              /* pair per lane).  0 = default: 1 for TBC_ALG_WGL,  */
                              /* 16 for TBC_ALG_LINEAR / TBC_ALG_COMPETITION       */
-  uint32_t round_budget;     /* wide schedule, 0 = off: a history that needs more   */
-                             /* rounds than this is re-run at search_width 16 once  */
-                             /* the rest of the batch is done (stragglers then run  */
-                             /* on an idle device and with fewer dependent rounds)  */
+  uint32_t round_budget;     /* wide schedule, 0 = off: a history that has used     */
+                             /* more rounds than this continues at search_width 16  */
+                             /* (a batch's stragglers then need far fewer dependent */
+                             /* rounds; the schedule stays deterministic)           */
 } tbc_opts;
 
 /* ------------------------------------------------------------------ result */
@@ -208,8 +208,7 @@ enum {
   TBC_CAUSE_NONE = 0,
   TBC_CAUSE_TIME_LIMIT = 1,
   TBC_CAUSE_STEP_LIMIT = 2,
-  TBC_CAUSE_VISITED_FULL = 3,  /* visited set hit max_visited_bytes              */
-  TBC_CAUSE_ROUND_BUDGET = 4   /* internal: never returned to the caller          */
+  TBC_CAUSE_VISITED_FULL = 3   /* visited set hit max_visited_bytes              */
 };
 
 #define TBC_MAX_FINAL_CONFIGS 10   /* jepsen.checker/linearizable truncates to 10 */

@@ -385,7 +385,7 @@ static BeamArgs make_beam_args(tbc_batch* B, uint64_t* tab, uint32_t* stack, uin
   a.init_state = (B->model.kind == TBC_MODEL_MUTEX || comm) ? 0 : B->model.init;
   a.model_aux = B->model.init; a.n_keys = B->model.n_keys;
   a.n_classes = B->model.n_classes; a.width = B->width;
-  a.round_budget = 0;
+  a.round_budget = B->opts.round_budget;
   a.max_steps = B->opts.max_steps;
   a.time_limit_ticks = B->opts.time_limit_ms * 100000ull;
   a.dbg = debug_words();
@@ -554,7 +554,6 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results) {
 
   if (beam) {
     BeamArgs ba = make_beam_args(B, B->d_btab.p, B->d_stack.p, nh);
-    if (B->width < 16) ba.round_budget = B->opts.round_budget;
     if (B->wg ? !launch_beam_wg(ba, B->mask_words, nh, s) : !launch_beam(ba, B->mask_words, search_blocks(nh), s)) { set_error("unsupported mask width"); return TBC_ERR_UNSUPPORTED; }
   } else {
     SearchArgs sa = make_search_args(B, B->d_tab.p, nh);
@@ -597,31 +596,7 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results) {
       touched_work = true;
     }
   }
-  // stragglers of the wide schedule: re-run with one 256-lane workgroup each at width 32 (4-6x fewer
-  // dependent rounds, unloaded latency); their visited sets start at the size the first pass had reached
   std::vector<uint32_t> width_of(nh, B->width);
-  if (beam && B->width < 16 && B->opts.round_budget) {
-    std::vector<uint32_t> esc, lg;
-    for (uint32_t h = 0; h < nh; h++)
-      if (B->res_host[h].valid == TBC_UNKNOWN && B->res_host[h].cause == TBC_CAUSE_ROUND_BUDGET) {
-        uint32_t l = std::max(final_log2[h], B->res_host[h].tab_log2) + 1;
-        while (l > 10 && (1ull << l) * EW * 8 > max_bytes) l--;
-        esc.push_back(h); lg.push_back(l); final_log2[h] = l; width_of[h] = 32;
-      }
-    size_t pos = 0;
-    while (pos < esc.size()) {
-      std::vector<uint32_t> grp, glg;
-      uint64_t bytes = 0;
-      while (pos < esc.size()) {
-        const uint64_t need = (1ull << lg[pos]) * (beam_wg_entry_words(B->mask_words) + 1) * 8;
-        if (!grp.empty() && bytes + need > (32ull << 30)) break;
-        grp.push_back(esc[pos]); glg.push_back(lg[pos]); bytes += need; pos++;
-      }
-      tbc_status st = scratch_pass(B, grp, glg, true, hist_back, bh_back, 32);
-      if (st != TBC_OK) return st;
-      touched_work = true;
-    }
-  }
   // overflow retries: 16x larger visited set each time, up to max_visited_bytes
   const uint64_t arena_budget = 32ull << 30;
   for (;;) {

@@ -88,8 +88,9 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
   uint32_t cap_log2 = rfl(B->tab_log2);
   uint32_t cap_mask = (uint32_t)((1ull << cap_log2) - 1ull);
   uint32_t full_at = (uint32_t)((1ull << cap_log2) - (1ull << (cap_log2 - 2)));
-  // K parents per iteration, G = 64 / K lanes (candidate slots) per parent per round
-  const uint32_t K = A.width, gshift = 6u - (31u - (uint32_t)__builtin_clz(K)), G = 1u << gshift;
+  // K parents per iteration, G = 64 / K lanes (candidate slots) per parent per round.  A history that has
+  // used more than round_budget rounds continues at K = 16: stragglers then need far fewer dependent rounds.
+  uint32_t K = A.width, gshift = 6u - (31u - (uint32_t)__builtin_clz(K)), G = 1u << gshift;
   DevResult* out = A.results + hidx;
   Model model{A.model_kind, A.table, A.n_classes, A.pool_vals, (int32_t)rfl((uint32_t)H->aux), A.n_keys};
 
@@ -141,6 +142,7 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
 
   while (verdict == -2) {
     if (sp == 0) { verdict = TBC_INVALID; break; }
+    if (A.round_budget && rounds > A.round_budget && K < 16u) { K = 16u; gshift = 2u; G = 4u; }
     const uint32_t np = min(K, sp);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -374,7 +376,6 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
     }
     if (verdict == -2) {
       if (A.max_steps && probes > A.max_steps) { verdict = TBC_UNKNOWN; cause = TBC_CAUSE_STEP_LIMIT; }
-      else if (A.round_budget && rounds > A.round_budget) { verdict = TBC_UNKNOWN; cause = TBC_CAUSE_ROUND_BUDGET; }
       else if (A.time_limit_ticks && (iterations & 63u) == 0 && (uint64_t)wall_clock64() - t0 > A.time_limit_ticks) {
         verdict = TBC_UNKNOWN; cause = TBC_CAUSE_TIME_LIMIT;
       }

@@ -143,7 +143,7 @@ class BeamStats(C.Structure):
                 ("expanded", C.c_uint64), ("max_stack", C.c_uint64), ("rounds", C.c_uint64)]
 
 
-def check_beam(ops, model, width=16, max_probes=0, want_witness=True, round_pairs=64):
+def check_beam(ops, model, width=16, max_probes=0, want_witness=True, round_pairs=64, widen_after=0):
     """The wide (K configs per iteration) schedule of the same search: wgl_beam.c."""
     n = len(ops["f"])
     f = np.ascontiguousarray(ops["f"], np.uint8)
@@ -155,6 +155,7 @@ def check_beam(ops, model, width=16, max_probes=0, want_witness=True, round_pair
     m, keep = _model(model)
     res, st = OracleResult(), BeamStats()
     wit = np.zeros(max(n, 1), np.uint32)
+    lib().wgl_beam_set_widen_after(C.c_uint32(widen_after))
     rc = lib().wgl_beam_check_rp(C.c_uint32(n), _p(f, C.c_uint8), _p(a, C.c_int32), _p(b, C.c_int32),
                                  _p(proc, C.c_int32), C.c_uint32(int(ops["n_process"])), _p(inv, C.c_uint32),
                                  _p(ret, C.c_uint32), C.byref(m), C.c_uint32(width), C.c_uint32(round_pairs),

@@ -127,6 +127,11 @@ int wgl_beam_check_rp(uint32_t n, const uint8_t* f, const int32_t* a, const int3
                       const oracle_model* model, uint32_t K, uint32_t round_pairs, uint64_t max_probes,
                       uint32_t* witness, oracle_result* out, beam_stats* st);
 
+/* widen_after: 0 = never; otherwise a history that has used more than this many rounds continues
+ * with K = 16 (tbc_opts.round_budget): the stragglers of a batch need far fewer dependent rounds */
+static uint32_t g_widen_after = 0;
+void wgl_beam_set_widen_after(uint32_t r) { g_widen_after = r; }
+
 int wgl_beam_check(uint32_t n, const uint8_t* f, const int32_t* a, const int32_t* b,
                    const int32_t* process, uint32_t n_process,
                    const uint32_t* inv_pos, const uint32_t* ret_pos,
@@ -217,7 +222,8 @@ int wgl_beam_check_rp(uint32_t n, const uint8_t* f, const int32_t* a, const int3
 
   while (verdict == -2) {
     if (sp == 0) { verdict = 0; break; }
-    uint32_t np = sp < K ? (uint32_t)sp : K;
+    const uint32_t Kc = (g_widen_after && st->rounds > g_widen_after && K < 16) ? 16 : K;
+    uint32_t np = sp < Kc ? (uint32_t)sp : Kc;
     for (uint32_t q = 0; q < np; q++) par[q] = stack[sp - np + q];      /* q = 0 is the bottom-most popped */
     sp -= np;
     st->iterations++; st->expanded += np;

@@ -281,27 +281,26 @@ def test_workgroup_kernel_matches_its_oracle(native, oracle, width):
             assert got["fail_op"] == exp["fail_op"], i
 
 
-def test_round_budget_escalates_stragglers_to_the_workgroup_kernel(native, oracle):
-    """tbc_opts.round_budget: a history that needs more rounds than the budget at the batch's width is
-    re-run by the workgroup kernel at width 32; the others keep their result.  Both are deterministic
-    schedules of oracle/wgl_beam.c, so every result is still bit-exact."""
+def test_round_budget_widens_stragglers_in_place(native, oracle):
+    """tbc_opts.round_budget: a history that has used more rounds than the budget continues at width 16
+    (same table, same stack).  Still the deterministic schedule of oracle/wgl_beam.c (widen_after)."""
     hists = [columns.pair_events(synth.register_events(n_ops=1500, n_procs=24, seed=s, busy=0.25, info=0.01)) for s in range(24)]
     exp4 = [oracle.check_beam(h.as_dict(), CAS, 4) for h in hists]
     rounds = sorted(e["rounds"] for e in exp4)
-    budget = rounds[len(rounds) * 2 // 3]            # about a third of the histories exceed it
+    budget = rounds[len(rounds) // 3]               # most histories cross it
     opts = core.make_opts(time_limit_ms=60000, algorithm=N.ALG_COMPETITION, search_width=4, round_budget=budget)
     with core.Batch(hists, gm(), opts) as b:
         res = b.run().results()
-    n_esc = 0
+    n_wide = 0
     for h, got, e4 in zip(hists, res, exp4):
-        exp = e4
-        if e4["rounds"] > budget:
-            exp = oracle.check_beam(h.as_dict(), CAS, 32, round_pairs=256)
-            n_esc += 1
+        exp = oracle.check_beam(h.as_dict(), CAS, 4, widen_after=budget)
+        n_wide += e4["rounds"] > budget
         assert got["valid"] == exp["valid"] == 1 and got["cause"] == 0
         assert np.array_equal(got["witness"], exp["witness"])
-        assert (got["probes"], got["visited"]) == (exp["probes"], exp["visited"])
-    assert 3 <= n_esc <= 12
+        assert (got["probes"], got["visited"], got["backtracks"]) == (exp["probes"], exp["visited"], exp["expanded"])
+        if e4["rounds"] > budget:
+            assert exp["probes"] != e4["probes"]      # the schedule really changed
+    assert n_wide >= 8
 
 
 def test_against_committed_golden_fixtures(native):
