@@ -14,7 +14,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libtbcheck.so")
+LIB_PATH = os.environ.get("TBC_LIB_PATH") or os.path.join(CSRC, "libtbcheck.so")
 
 NIL = -(2 ** 31)
 POS_CRASHED = 0xFFFFFFFF

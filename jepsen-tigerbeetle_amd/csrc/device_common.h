@@ -73,12 +73,14 @@ struct Model {
 // May the open call `oi` be linearized next in the config (fi, Mp, st)?  State-based models ask
 // Model::ok; the commutative ones (set, bank) look at the calls completed before the front (per-front
 // tables in the pool) and at the open calls already linearized (the parent's open-call list).
-template <int MW>
+template <int MW, bool COMM>
 __device__ __forceinline__ bool pair_viable(const Model& model, int32_t st, uint32_t fi, const uint64_t (&Mp)[MW],
                                             uint32_t poff, uint32_t nlive, uint32_t cnt, const uint32_t* lst,
                                             const uint32_t* crashed, const OpInfo* opinfo, const OpInfo& oi) {
   const uint32_t f = oi.f_slot & 0xFFu;
-  if (!model.commutative()) return model.ok(st, f, oi.a, oi.b);
+  if constexpr (!COMM) {
+    return model.ok(st, f, oi.a, oi.b);
+  } else {
   if (model.kind == TBC_MODEL_SET) {
     // knossos.model/set, state-free: a read of R is consistent iff the adds completed before the
     // front plus the open adds already linearized are exactly R (pool layout: include/tbcheck.h)
@@ -122,11 +124,12 @@ __device__ __forceinline__ bool pair_viable(const Model& model, int32_t st, uint
   bool viable = true;
   for (uint32_t a2 = 0; a2 < NA; a2++) viable = viable && bal[a2] == model.pool[oi.a + (int32_t)a2];
   return viable;
+  }
 }
 
 // The config reached by linearizing `oi` in (fi, Mp, st): set its process bit, step the model, and if it
 // was the front's own call move the front past every completion already linearized (clearing their bits).
-template <int MW>
+template <int MW, bool COMM>
 __device__ __forceinline__ void make_child(const Model& model, bool viable, int32_t st, uint32_t fi, uint32_t R,
                                            const uint32_t* ret_slot, uint32_t next_slot, const OpInfo& oi,
                                            const uint64_t (&Mp)[MW], uint64_t (&M2)[MW], int32_t& st2, uint32_t& fi2) {
@@ -135,7 +138,7 @@ __device__ __forceinline__ void make_child(const Model& model, bool viable, int3
 #pragma unroll
   for (int j = 0; j < MW; j++) M2[j] = Mp[j];
   if (!viable) return;
-  st2 = model.commutative() ? 0 : model.apply(st, f, oi.a, oi.b);
+  if constexpr (COMM) st2 = 0; else st2 = model.apply(st, f, oi.a, oi.b);
 #pragma unroll
   for (int j = 0; j < MW; j++) if ((p >> 6) == (uint32_t)j) M2[j] |= 1ull << (p & 63u);
   if (oi.ret_rank != fi) return;

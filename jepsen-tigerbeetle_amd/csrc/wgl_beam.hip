@@ -67,7 +67,64 @@ __device__ __forceinline__ uint32_t key_hash32(uint64_t k0, const uint64_t* M, i
   return h;
 }
 
+// Cold path: move a history to a 4x larger visited set (and stack) taken from the batch's growth pool -- re-insert every entry, then
+// translate the slot numbers held by parent links, the stack and this iteration's parents.
 template <int MW>
+__device__ __forceinline__ bool grow_visited_set(const BeamArgs& A, uint64_t* tab, uint32_t* stack, uint32_t cap_log2,
+                                                           uint32_t sp, uint32_t np, uint32_t* p_slot, uint32_t* r_pos,
+                                                           uint32_t lane, uint64_t** ntab_out, uint32_t** nstack_out) {
+  constexpr uint32_t EW = MW + 2;
+  const uint64_t old_cap = 1ull << cap_log2, new_cap = old_cap << 2;
+  const uint64_t need = new_cap * EW + new_cap / 2 + old_cap / 2;      // table, stack, slot translation
+  unsigned long long base = 0;
+  if (lane == 0) base = (A.pool && cap_log2 + 2 <= A.max_tab_log2) ? atomicAdd(A.pool_cursor, (unsigned long long)need) : ~0ull;
+  base = ru64(base);
+  if (!A.pool || cap_log2 + 2 > 31 || cap_log2 + 2 > A.max_tab_log2 || base + need > A.pool_words) return false;
+  uint64_t* ntab = A.pool + base;
+  uint32_t* nstack = reinterpret_cast<uint32_t*>(ntab + new_cap * EW);
+  uint32_t* remap = nstack + new_cap;
+  const uint32_t nmask = (uint32_t)(new_cap - 1);
+#pragma unroll 1
+  for (uint64_t s = lane; s < old_cap; s += 64) {
+    const uint64_t* e = tab + s * EW;
+    const uint64_t k0 = ld64(e);
+    if ((uint32_t)k0 == 0u) continue;
+    uint64_t Mx[MW];
+#pragma unroll
+    for (int j = 0; j < MW; j++) Mx[j] = ld64(e + 1 + j);
+    const uint64_t pw = ld64(e + 1 + MW);
+    uint32_t idx = key_hash32(k0, Mx, MW) & nmask;
+    for (;;) {
+      uint64_t* ne = ntab + (uint64_t)idx * EW;
+      if (atomicCAS((unsigned long long*)ne, 0ull, (unsigned long long)k0) == 0ull) {
+#pragma unroll
+        for (int j = 0; j < MW; j++) st64(ne + 1 + j, Mx[j]);
+        st64(ne + 1 + MW, pw);
+        break;
+      }
+      idx = (idx + 1u) & nmask;
+    }
+    __hip_atomic_store(remap + s, idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __threadfence();
+#pragma unroll 1
+  for (uint64_t s = lane; s < old_cap; s += 64) {       // parent links -> new slot numbers
+    if ((uint32_t)ld64(tab + s * EW) == 0u) continue;
+    uint64_t* ne = ntab + (uint64_t)ld32(remap + s) * EW + 1 + MW;
+    const uint64_t pw = ld64(ne);
+    if ((uint32_t)pw != kNone) st64(ne, (uint64_t)ld32(remap + (uint32_t)pw) | (pw & 0xFFFFFFFF00000000ull));
+  }
+#pragma unroll 1
+  for (uint32_t i = lane; i < sp; i += 64)    // sp was already lowered by np: the popped run ...
+    __hip_atomic_store(nstack + i, ld32(remap + ld32(stack + i)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (lane < np) p_slot[lane] = ld32(remap + p_slot[lane]);   // ... lives in p_slot
+  if (lane < 16) r_pos[lane] = kNone;          // the ring held old slot numbers
+  __threadfence();
+  *ntab_out = ntab; *nstack_out = nstack;
+  return true;
+}
+
+template <int MW, bool COMM>
 __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, const uint32_t lane) {
   constexpr uint32_t EW = MW + 2;   // u64 words per entry
 
@@ -116,9 +173,14 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
   uint32_t win_parent = kNone, win_op = kNone;
   int32_t win_state = A.init_state;
   const uint64_t t0 = A.time_limit_ticks ? wall_clock64() : 0;
+#ifdef TBC_SEGPROF   // per-segment cycle counters (scripts/gpu_segprof.py); costs ~20 VGPRs, off in production
   const bool prof = A.dbg != nullptr;
   uint64_t seg[6] = {0, 0, 0, 0, 0, 0}, tlast = prof ? __builtin_readcyclecounter() : 0;
 #define SEG(i) do { if (prof) { const uint64_t tn_ = __builtin_readcyclecounter(); seg[i] += tn_ - tlast; tlast = tn_; } } while (0)
+#else
+  constexpr bool prof = false;
+#define SEG(i) do {} while (0)
+#endif
 
   if (status != 0) verdict = TBC_UNKNOWN;
   else if (R == 0) verdict = TBC_VALID;
@@ -200,50 +262,11 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
     {
       const uint32_t worst = grouped ? np * G : T;
       bool failed = false;
-      while (!failed && (uint64_t)visited + worst > full_at) {
-        const uint64_t old_cap = 1ull << cap_log2, new_cap = old_cap << 2;
-        const uint64_t need = new_cap * EW + new_cap / 2 + old_cap / 2;      // table, stack, slot translation
-        unsigned long long base = 0;
-        if (lane == 0) base = (A.pool && cap_log2 + 2 <= A.max_tab_log2) ? atomicAdd(A.pool_cursor, (unsigned long long)need) : ~0ull;
-        base = ru64(base);
-        if (!A.pool || cap_log2 + 2 > 31 || cap_log2 + 2 > A.max_tab_log2 || base + need > A.pool_words) { failed = true; break; }
-        uint64_t* ntab = A.pool + base;
-        uint32_t* nstack = reinterpret_cast<uint32_t*>(ntab + new_cap * EW);
-        uint32_t* remap = nstack + new_cap;
+      while (__builtin_expect(!failed && (uint64_t)visited + worst > full_at, 0)) {
+        uint64_t* ntab = nullptr; uint32_t* nstack = nullptr;
+        if (!grow_visited_set<MW>(A, tab, stack, cap_log2, sp, np, p_slot, r_pos, lane, &ntab, &nstack)) { failed = true; break; }
+        const uint64_t new_cap = 1ull << (cap_log2 + 2);
         const uint32_t nmask = (uint32_t)(new_cap - 1);
-        for (uint64_t s = lane; s < old_cap; s += 64) {
-          const uint64_t* e = tab + s * EW;
-          const uint64_t k0 = ld64(e);
-          if ((uint32_t)k0 == 0u) continue;
-          uint64_t Mx[MW];
-#pragma unroll
-          for (int j = 0; j < MW; j++) Mx[j] = ld64(e + 1 + j);
-          const uint64_t pw = ld64(e + 1 + MW);
-          uint32_t idx = key_hash32(k0, Mx, MW) & nmask;
-          for (;;) {
-            uint64_t* ne = ntab + (uint64_t)idx * EW;
-            if (atomicCAS((unsigned long long*)ne, 0ull, (unsigned long long)k0) == 0ull) {
-#pragma unroll
-              for (int j = 0; j < MW; j++) st64(ne + 1 + j, Mx[j]);
-              st64(ne + 1 + MW, pw);
-              break;
-            }
-            idx = (idx + 1u) & nmask;
-          }
-          __hip_atomic_store(remap + s, idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        __threadfence();
-        for (uint64_t s = lane; s < old_cap; s += 64) {       // parent links -> new slot numbers
-          if ((uint32_t)ld64(tab + s * EW) == 0u) continue;
-          uint64_t* ne = ntab + (uint64_t)ld32(remap + s) * EW + 1 + MW;
-          const uint64_t pw = ld64(ne);
-          if ((uint32_t)pw != kNone) st64(ne, (uint64_t)ld32(remap + (uint32_t)pw) | (pw & 0xFFFFFFFF00000000ull));
-        }
-        for (uint32_t i = lane; i < sp; i += 64)                // sp was already lowered by np: the popped run ...
-          __hip_atomic_store(nstack + i, ld32(remap + ld32(stack + i)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (lane < np) p_slot[lane] = ld32(remap + p_slot[lane]);   // ... lives in p_slot
-        if (lane < 16) r_pos[lane] = kNone;                      // the ring held old slot numbers
-        __threadfence();
         tab = ntab; stack = nstack; cap_log2 += 2; cap_mask = nmask;
         full_at = (uint32_t)(new_cap - (new_cap >> 2));
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -287,11 +310,11 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
       bool lin = false;
 #pragma unroll
       for (int j = 0; j < MW; j++) if ((p >> 6) == (uint32_t)j) lin = (Mp[j] >> (p & 63u)) & 1ull;
-      const bool viable = act && !lin && pair_viable<MW>(model, st, fi, Mp, poff, nlive, cnt, lst, crashed, opinfo, oi);
+      const bool viable = act && !lin && pair_viable<MW, COMM>(model, st, fi, Mp, poff, nlive, cnt, lst, crashed, opinfo, oi);
       int32_t st2 = st;
       uint32_t fi2 = fi;
       uint64_t M2[MW];
-      make_child<MW>(model, viable, st, fi, R, ret_slot, next_slot, oi, Mp, M2, st2, fi2);
+      make_child<MW, COMM>(model, viable, st, fi, R, ret_slot, next_slot, oi, Mp, M2, st2, fi2);
       SEG(2);
       rounds++;
       const uint64_t succ = __ballot(viable && fi2 == R);
@@ -450,24 +473,34 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
   }
   if (A.dbg && lane == 0) {
     A.dbg[4] = 0x300u + hidx; A.dbg[16] = (uint32_t)verdict; A.dbg[17] = (uint32_t)iterations;
+#ifdef TBC_SEGPROF
     for (int i = 0; i < 5; i++) { A.dbg[20 + 2 * i] = (uint32_t)seg[i]; A.dbg[21 + 2 * i] = (uint32_t)(seg[i] >> 32); }
+#endif
     A.dbg[30] = (uint32_t)rounds;
   }
 #undef SEG
 }
 
-template <int MW>
+// Register budget (MW = 1, state-carrying models): 94 VGPRs -> 5 wavefronts per SIMD.  Forcing 6 with a
+// min-blocks launch bound spills in the round loop and measures slower; without the growth path the loop
+// needs 74, and that build is only 3-5 % faster (profiles/r01_vgpr_ab.txt), so growth stays inline.
+template <int MW, bool COMM>
 __global__ __launch_bounds__(kBlock) void wgl_beam_kernel(BeamArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   const uint32_t lane = threadIdx.x & 63u, wv = rfl(threadIdx.x >> 6);
   const uint32_t w = blockIdx.x * kWavesPerBlock + wv;
-  if (w < A.n_work) beam_one<MW>(A, rfl(A.work[w]), lds + wv * beam_lds_words(MW), lane);
+  if (w < A.n_work) beam_one<MW, COMM>(A, rfl(A.work[w]), lds + wv * beam_lds_words(MW), lane);
 }
 
 template <int MW>
 void launch_beam_mw(const BeamArgs& a, uint32_t n_blocks, hipStream_t s) {
   const size_t lds = (size_t)kWavesPerBlock * beam_lds_words(MW) * 4;
-  hipLaunchKernelGGL(wgl_beam_kernel<MW>, dim3(n_blocks), dim3(kBlock), lds, s, a);
+  // the commutative (set / bank) models get their own instantiation: their evaluation code would
+  // otherwise double the register budget of the register-family kernel
+  if (a.model_kind == TBC_MODEL_SET || a.model_kind == TBC_MODEL_BANK)
+    hipLaunchKernelGGL((wgl_beam_kernel<MW, true>), dim3(n_blocks), dim3(kBlock), lds, s, a);
+  else
+    hipLaunchKernelGGL((wgl_beam_kernel<MW, false>), dim3(n_blocks), dim3(kBlock), lds, s, a);
 }
 
 }  // namespace

@@ -51,7 +51,7 @@ __device__ __forceinline__ uint32_t key_hash32w(uint64_t k0, const uint64_t* M, 
   return h;
 }
 
-template <int MW>
+template <int MW, bool COMM>
 __global__ __launch_bounds__(kNT) void wgl_beam_wg_kernel(BeamArgs A) {
   constexpr uint32_t EW = MW + 3;
   __shared__ uint64_t p_k0[kMaxK];
@@ -171,9 +171,9 @@ __global__ __launch_bounds__(kNT) void wgl_beam_wg_kernel(BeamArgs A) {
       bool lin = false;
 #pragma unroll
       for (int j = 0; j < MW; j++) if ((p >> 6) == (uint32_t)j) lin = (Mp[j] >> (p & 63u)) & 1ull;
-      const bool viable = act && !lin && pair_viable<MW>(model, st, fi, Mp, poff, nlive, cnt, lst, crashed, opinfo, oi);
+      const bool viable = act && !lin && pair_viable<MW, COMM>(model, st, fi, Mp, poff, nlive, cnt, lst, crashed, opinfo, oi);
       int32_t st2; uint32_t fi2; uint64_t M2[MW];
-      make_child<MW>(model, viable, st, fi, R, ret_slot, next_slot, oi, Mp, M2, st2, fi2);
+      make_child<MW, COMM>(model, viable, st, fi, R, ret_slot, next_slot, oi, Mp, M2, st2, fi2);
 
       if (viable && fi2 == R) atomicMin(&s_win, r);
       const uint64_t vb = __ballot(viable);
@@ -340,12 +340,19 @@ uint32_t beam_wg_entry_words(uint32_t mask_words) { return mask_words + 3; }
 
 bool launch_beam_wg(const BeamArgs& a, uint32_t mask_words, uint32_t n_hist, void* stream) {
   hipStream_t s = (hipStream_t)stream;
+  const bool comm = a.model_kind == TBC_MODEL_SET || a.model_kind == TBC_MODEL_BANK;
+#define TBC_LAUNCH_WG(MWV)                                                                              \
+  do {                                                                                                  \
+    if (comm) hipLaunchKernelGGL((wgl_beam_wg_kernel<MWV, true>), dim3(n_hist), dim3(kNT), 0, s, a);   \
+    else hipLaunchKernelGGL((wgl_beam_wg_kernel<MWV, false>), dim3(n_hist), dim3(kNT), 0, s, a);       \
+  } while (0)
   switch (mask_words) {
-    case 1: hipLaunchKernelGGL(wgl_beam_wg_kernel<1>, dim3(n_hist), dim3(kNT), 0, s, a); return true;
-    case 2: hipLaunchKernelGGL(wgl_beam_wg_kernel<2>, dim3(n_hist), dim3(kNT), 0, s, a); return true;
-    case 4: hipLaunchKernelGGL(wgl_beam_wg_kernel<4>, dim3(n_hist), dim3(kNT), 0, s, a); return true;
+    case 1: TBC_LAUNCH_WG(1); return true;
+    case 2: TBC_LAUNCH_WG(2); return true;
+    case 4: TBC_LAUNCH_WG(4); return true;
     default: return false;
   }
+#undef TBC_LAUNCH_WG
 }
 
 }  // namespace tbc
