@@ -75,8 +75,8 @@ struct Model {
 // tables in the pool) and at the open calls already linearized (the parent's open-call list).
 template <int MW, bool COMM>
 __device__ __forceinline__ bool pair_viable(const Model& model, int32_t st, uint32_t fi, const uint64_t (&Mp)[MW],
-                                            uint32_t poff, uint32_t nlive, uint32_t cnt, const uint32_t* lst,
-                                            const uint32_t* crashed, const OpInfo* opinfo, const OpInfo& oi) {
+                                            uint32_t poff, uint32_t nlive, uint32_t cnt, const OpRec* lst,
+                                            const OpRec* crashed, const OpRec& oi) {
   const uint32_t f = oi.f_slot & 0xFFu;
   if constexpr (!COMM) {
     return model.ok(st, f, oi.a, oi.b);
@@ -90,9 +90,8 @@ __device__ __forceinline__ bool pair_viable(const Model& model, int32_t st, uint
     int32_t count = model.pool[model.aux + (int32_t)fi];
     bool viable = nR >= 0 && count <= lead;
     for (uint32_t cc = 0; viable && cc < cnt; cc++) {
-      const uint32_t x = cc < nlive ? lst[poff + cc] : crashed[cc - nlive];
-      const OpInfo ox = opinfo[x];
-      const uint32_t px = ox.f_slot >> 8;
+      const OpRec ox = cc < nlive ? lst[poff + cc] : crashed[cc - nlive];
+      const uint32_t px = (ox.f_slot >> 8) & kSlotMask;
       bool lx = false;
 #pragma unroll
       for (int j = 0; j < MW; j++) if ((px >> 6) == (uint32_t)j) lx = (Mp[j] >> (px & 63u)) & 1ull;
@@ -110,9 +109,8 @@ __device__ __forceinline__ bool pair_viable(const Model& model, int32_t st, uint
   const uint32_t NA = model.n_keys;
   for (uint32_t a2 = 0; a2 < NA; a2++) bal[a2] = model.pool[model.aux + (int32_t)(fi * NA + a2)];
   for (uint32_t cc = 0; cc < cnt; cc++) {
-    const uint32_t x = cc < nlive ? lst[poff + cc] : crashed[cc - nlive];
-    const OpInfo ox = opinfo[x];
-    const uint32_t px = ox.f_slot >> 8;
+    const OpRec ox = cc < nlive ? lst[poff + cc] : crashed[cc - nlive];
+    const uint32_t px = (ox.f_slot >> 8) & kSlotMask;
     bool lx = false;
 #pragma unroll
     for (int j = 0; j < MW; j++) if ((px >> 6) == (uint32_t)j) lx = (Mp[j] >> (px & 63u)) & 1ull;
@@ -129,11 +127,12 @@ __device__ __forceinline__ bool pair_viable(const Model& model, int32_t st, uint
 
 // The config reached by linearizing `oi` in (fi, Mp, st): set its process bit, step the model, and if it
 // was the front's own call move the front past every completion already linearized (clearing their bits).
-template <int MW, bool COMM>
+// slot_at(r) = process slot of the call completing at rank r (the caller decides how it is fetched).
+template <int MW, bool COMM, class SlotAt>
 __device__ __forceinline__ void make_child(const Model& model, bool viable, int32_t st, uint32_t fi, uint32_t R,
-                                           const uint32_t* ret_slot, uint32_t next_slot, const OpInfo& oi,
+                                           SlotAt slot_at, const OpRec& oi,
                                            const uint64_t (&Mp)[MW], uint64_t (&M2)[MW], int32_t& st2, uint32_t& fi2) {
-  const uint32_t f = oi.f_slot & 0xFFu, p = oi.f_slot >> 8;
+  const uint32_t f = oi.f_slot & 0xFFu, p = (oi.f_slot >> 8) & kSlotMask;
   st2 = st; fi2 = fi;
 #pragma unroll
   for (int j = 0; j < MW; j++) M2[j] = Mp[j];
@@ -141,14 +140,14 @@ __device__ __forceinline__ void make_child(const Model& model, bool viable, int3
   if constexpr (COMM) st2 = 0; else st2 = model.apply(st, f, oi.a, oi.b);
 #pragma unroll
   for (int j = 0; j < MW; j++) if ((p >> 6) == (uint32_t)j) M2[j] |= 1ull << (p & 63u);
-  if (oi.ret_rank != fi) return;
+  if (!(oi.f_slot & kAtFront)) return;
   uint32_t pp = p;
   for (;;) {
 #pragma unroll
     for (int j = 0; j < MW; j++) if ((pp >> 6) == (uint32_t)j) M2[j] &= ~(1ull << (pp & 63u));
     fi2++;
     if (fi2 == R) break;
-    pp = (fi2 == fi + 1u) ? next_slot : ret_slot[fi2];
+    pp = slot_at(fi2);
     bool bit = false;
 #pragma unroll
     for (int j = 0; j < MW; j++) if ((pp >> 6) == (uint32_t)j) bit = (M2[j] >> (pp & 63u)) & 1ull;

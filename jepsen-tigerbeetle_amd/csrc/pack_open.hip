@@ -6,14 +6,16 @@
 //
 //   occ[F]   bit p set  <=>  process p has a LIVE (eventually completed) call open at F
 //   off[F]   CSR offsets, off[F+1]-off[F] = popcount(occ[F])
-//   lst[]    the live open calls of front F in process-slot order
-//            (position of p's call = popcount(occ[F] below p): no sorting needed)
+//   lst[]    the live open calls of front F in process-slot order, as whole 16 B records
+//            {op, f | slot << 8 | at-front flag, a, b}: a lane of the search reaches its candidate
+//            with one load (position of p's call = popcount(occ[F] below p): no sorting needed)
 //   crashed[] the :info calls in invocation order, ncr[F] = how many of them were
 //            invoked before completion F (they stay open for ever, so they are
 //            kept out of the per-front lists).  Crashed READS (value nil) are left
 //            out altogether: no effect on the model, no constraint, but each would
 //            double the config space (oracle/wgl_beam.c)
-//   opinfo[] 16 B per op {ret_rank, f | slot<<8, a, b}: one load per candidate
+//   slot8[]  process slot of the call completing at each rank, one byte each: the search
+//            prefetches a 16-rank window of it for the front advance
 //
 // This is knossos.linear.config's "pending calls by process" materialised for
 // every point of the history.  One 256-thread workgroup per
@@ -79,16 +81,16 @@ __global__ __launch_bounds__(256) void pack_open_kernel(PackOpenArgs A) {
     uint32_t* off = A.off + B->off_off;      // R + 1 entries used
     uint32_t* ncr = A.ncr + B->off_off;      // R entries used
     uint64_t* occ = A.occ + B->occ_off;      // R * MW words used
-    uint32_t* lst = A.lst + B->lst_off;
-    uint32_t* crashed = A.crashed + H->op_off;
-    OpInfo* info = A.opinfo + H->op_off;
+    OpRec* lst = A.lst + B->lst_off;
+    OpRec* crashed = A.crashed + H->op_off;
+    const uint32_t* ret_slot = A.ret_slot + H->ret_off;
+    uint8_t* slot8 = A.slot8 + slot8_off(H->op_off, h);
 
-    // A: occupancy bits of live calls; crashed-call counts by front; op records
+    // A: occupancy bits of live calls; crashed-call counts by front; completion slots as bytes
+    for (uint32_t r = tid; r < R + 16u; r += 256) slot8[r] = r < R ? (uint8_t)ret_slot[r] : (uint8_t)0;
     for (uint32_t i = tid; i < n; i += 256) {
       const uint32_t ir = sc_inv[i], rr = sc_ret[i];
       const uint32_t p = (uint32_t)proc[i];
-      OpInfo o; o.ret_rank = rr; o.f_slot = (uint32_t)f[i] | (p << 8); o.a = a[i]; o.b = b[i];
-      info[i] = o;
       if (rr == kInf) {
         if (ir < R && !(f[i] == TBC_F_READ && a[i] == TBC_NIL)) atomicAdd(&ncr[ir], 1u);
       } else {
@@ -136,11 +138,13 @@ __global__ __launch_bounds__(256) void pack_open_kernel(PackOpenArgs A) {
       const uint32_t ir = sc_inv[i], rr = sc_ret[i];
       if (rr == kInf) continue;
       const uint32_t p = (uint32_t)proc[i];
+      OpRec o; o.op = i; o.f_slot = (uint32_t)f[i] | (p << 8); o.a = a[i]; o.b = b[i];
       for (uint32_t fr = ir; fr <= rr; fr++) {
         uint32_t pos = ld_agent(&off[fr]);
         for (uint32_t w = 0; w < (p >> 6); w++) pos += __popcll(ld_agent64(&occ[(uint64_t)fr * MW + w]));
         pos += __popcll(ld_agent64(&occ[(uint64_t)fr * MW + (p >> 6)]) & ((1ull << (p & 63u)) - 1ull));
-        lst[pos] = i;
+        if (fr == rr) o.f_slot |= kAtFront;
+        lst[pos] = o;
       }
     }
     // D: crashed calls in invocation order (stable compaction)
@@ -158,7 +162,10 @@ __global__ __launch_bounds__(256) void pack_open_kernel(PackOpenArgs A) {
       }
       __syncthreads();
       uint32_t run = s_part[tid];
-      for (uint32_t i = lo; i < hi; i++) if (sc_ret[i] == kInf && !(f[i] == TBC_F_READ && a[i] == TBC_NIL)) crashed[run++] = i;
+      for (uint32_t i = lo; i < hi; i++) if (sc_ret[i] == kInf && !(f[i] == TBC_F_READ && a[i] == TBC_NIL)) {
+        OpRec o; o.op = i; o.f_slot = (uint32_t)f[i] | ((uint32_t)proc[i] << 8); o.a = a[i]; o.b = b[i];
+        crashed[run++] = o;
+      }
       __syncthreads();
     }
   }

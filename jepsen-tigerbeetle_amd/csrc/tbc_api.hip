@@ -33,6 +33,29 @@ inline uint32_t ceil_log2(uint64_t x) {
   return l;
 }
 
+// Entries of a history's per-front open-call lists: every live call appears once per front it is open
+// at (the completions positioned between its invocation and its completion, plus its own).  Exact when
+// the positions are event indices; anything else falls back to the worst case (every slot at every front).
+uint64_t open_list_entries(const tbc_ops& c, uint64_t op_off, uint64_t n, uint32_t n_events, uint32_t n_slots,
+                           std::vector<uint32_t>& pre) {
+  const uint64_t worst = std::max<uint64_t>(n, 1) * std::max(1u, n_slots);
+  if (n == 0) return 1;
+  if ((uint64_t)n_events > 64 * n + 1024) return worst;
+  const uint32_t* inv = c.inv_pos + op_off;
+  const uint32_t* ret = c.ret_pos + op_off;
+  pre.assign((size_t)n_events + 1, 0u);              // pre[x] = completions positioned before x
+  for (uint64_t i = 0; i < n; i++) {
+    if (ret[i] == TBC_POS_CRASHED) continue;
+    if (ret[i] >= n_events || inv[i] > ret[i]) return worst;
+    pre[ret[i] + 1] = 1;
+  }
+  for (uint32_t x = 1; x <= n_events; x++) pre[x] += pre[x - 1];
+  uint64_t total = 0;
+  for (uint64_t i = 0; i < n; i++)
+    if (ret[i] != TBC_POS_CRASHED) total += pre[ret[i]] - pre[inv[i]] + 1;
+  return std::min(worst, std::max<uint64_t>(total, 1));
+}
+
 bool device_is_gfx950(int dev) {
   hipDeviceProp_t p;
   if (hipGetDeviceProperties(&p, dev) != hipSuccess) return false;
@@ -121,10 +144,11 @@ struct tbc_batch {
   bool wg = false;                  // width 32 / 64: one workgroup per history (wgl_beam_wg.hip)
   std::vector<BeamHist> bh;
   DevBuf<BeamHist> d_bh;
-  DevBuf<uint32_t> d_off, d_ncr, d_lst, d_crashed, d_stack;
+  DevBuf<uint32_t> d_off, d_ncr, d_stack;
+  DevBuf<OpRec> d_lst, d_crashed;   // per-front open-call lists / crashed calls, whole records
+  DevBuf<uint8_t> d_slot8;          // completion slots as bytes
   DevBuf<uint64_t> d_occ, d_btab, d_pool;
   DevBuf<unsigned long long> d_pool_cursor;
-  DevBuf<OpInfo> d_opinfo;
   // last run
   std::vector<DevResult> res_host;
   std::vector<uint32_t> witness_host;
@@ -138,7 +162,7 @@ struct tbc_batch {
     d_bitmap.release(); d_wpre.release(); d_frames.release(); d_witness.release(); d_work.release();
     d_queue.release(); d_tab.release(); d_results.release(); d_table.release(); d_pool_vals.release(); d_cfg.release();
     d_bh.release(); d_off.release(); d_ncr.release(); d_lst.release(); d_crashed.release(); d_stack.release();
-    d_occ.release(); d_btab.release(); d_opinfo.release(); d_pool.release(); d_pool_cursor.release();
+    d_occ.release(); d_btab.release(); d_slot8.release(); d_pool.release(); d_pool_cursor.release();
     for (auto& e : ev) if (e) (void)hipEventDestroy(e);
     if (stream) (void)hipStreamDestroy(stream);
   }
@@ -223,6 +247,7 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
   B->hist.resize(nh);
   if (beam) B->bh.resize(nh);
   uint64_t boff_n = 0, bocc_n = 0, blst_n = 0, bstack_n = 0, btab_n = 0;
+  std::vector<uint32_t> rank_scratch;
   uint64_t rec_n = 0, seg_n = 0, bm_n = 0, frame_n = 0, tab_n = 0;
   for (uint32_t h = 0; h < nh; h++) {
     Hist& H = B->hist[h];
@@ -249,11 +274,11 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
       BeamHist& Q = B->bh[h];
       std::memset(&Q, 0, sizeof Q);
       uint32_t blg = lg;
-      while (blg > 10 && (1ull << blg) * EW * 8 > max_bytes) blg--;
+      while (blg > 10 && ((1ull << blg) * EW * 8 > max_bytes || blg > kBeamMaxTabLog2)) blg--;
       Q.tab_log2 = blg;
       Q.off_off = boff_n; boff_n += n + 2;
       Q.occ_off = bocc_n; bocc_n += (n + 1) * B->mask_words;
-      Q.lst_cap = (uint32_t)std::min<uint64_t>(0xFFFFFFF0ull, std::max<uint64_t>(n, 1) * std::min(H.n_slots, 32u));
+      Q.lst_cap = (uint32_t)std::min<uint64_t>(0xFFFFFFF0ull, open_list_entries(desc->cols, H.op_off, n, H.n_events, H.n_slots, rank_scratch));
       Q.lst_off = blst_n; blst_n += Q.lst_cap;
       Q.stack_off = bstack_n; bstack_n += (1ull << blg);
       Q.tab_off = btab_n; btab_n += (1ull << blg);
@@ -272,7 +297,7 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
   if (beam) {
     if ((s = B->d_bh.alloc(nh)) || (s = B->d_off.alloc(boff_n)) || (s = B->d_ncr.alloc(boff_n)) ||
         (s = B->d_occ.alloc(bocc_n)) || (s = B->d_lst.alloc(blst_n)) || (s = B->d_crashed.alloc(T)) ||
-        (s = B->d_opinfo.alloc(T)) || (s = B->d_stack.alloc(bstack_n)) || (s = B->d_btab.alloc(btab_n * EW)) ||
+        (s = B->d_slot8.alloc(slot8_bytes(T, nh))) || (s = B->d_stack.alloc(bstack_n)) || (s = B->d_btab.alloc(btab_n * EW)) ||
         (s = B->d_pool_cursor.alloc(1)))
       return s;
     // growth pool: a quarter of the visited-set arena, at least room for one history to grow twice, at most 32 GiB
@@ -300,7 +325,7 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
                     B->d_ret_op.bytes() + B->d_bitmap.bytes() + B->d_wpre.bytes() + B->d_frames.bytes() +
                     B->d_tab.bytes() + B->d_results.bytes() + B->d_work.bytes() + B->d_witness.bytes();
   if (beam) B->device_bytes += B->d_bh.bytes() + B->d_off.bytes() + B->d_ncr.bytes() + B->d_occ.bytes() + B->d_lst.bytes() +
-                               B->d_crashed.bytes() + B->d_opinfo.bytes() + B->d_stack.bytes() + B->d_btab.bytes() + B->d_pool.bytes();
+                               B->d_crashed.bytes() + B->d_slot8.bytes() + B->d_stack.bytes() + B->d_btab.bytes() + B->d_pool.bytes();
 
   HIP_TRY(hipStreamCreateWithFlags(&B->stream, hipStreamNonBlocking));
   for (auto& e : B->ev) HIP_TRY(hipEventCreate(&e));
@@ -377,7 +402,7 @@ static uint32_t search_blocks(uint32_t n_work) {
 static BeamArgs make_beam_args(tbc_batch* B, uint64_t* tab, uint32_t* stack, uint32_t n_work) {
   BeamArgs a{};
   a.hist = B->d_hist.p; a.bh = B->d_bh.p; a.off = B->d_off.p; a.ncr = B->d_ncr.p; a.lst = B->d_lst.p;
-  a.crashed = B->d_crashed.p; a.opinfo = B->d_opinfo.p; a.ret_slot = B->d_ret_slot.p; a.ret_op = B->d_ret_op.p;
+  a.crashed = B->d_crashed.p; a.slot8 = B->d_slot8.p; a.ret_slot = B->d_ret_slot.p; a.ret_op = B->d_ret_op.p;
   a.stack = stack; a.tab = tab; a.results = B->d_results.p;
   a.witness = B->opts.want_witness ? B->d_witness.p : nullptr;
   a.work = B->d_work.p; a.table = B->d_table.p; a.n_work = n_work; a.model_kind = B->model.kind;
@@ -395,7 +420,7 @@ static BeamArgs make_beam_args(tbc_batch* B, uint64_t* tab, uint32_t* stack, uin
   {
     const uint64_t max_bytes = B->opts.max_visited_bytes ? B->opts.max_visited_bytes : (1ull << 30);
     uint32_t lg = 10;
-    while (lg < 31 && (1ull << (lg + 1)) * (B->mask_words + 2) * 8 <= max_bytes) lg++;
+    while (lg < kBeamMaxTabLog2 && (1ull << (lg + 1)) * (B->mask_words + 2) * 8 <= max_bytes) lg++;
     a.max_tab_log2 = lg;
   }
   return a;
@@ -544,7 +569,7 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results) {
     PackOpenArgs po{};
     po.hist = B->d_hist.p; po.bh = B->d_bh.p; po.f = B->d_f.p; po.a = B->d_a.p; po.b = B->d_b.p; po.process = B->d_proc.p;
     po.scratch = B->d_frames.p; po.off = B->d_off.p; po.ncr = B->d_ncr.p; po.occ = B->d_occ.p; po.lst = B->d_lst.p;
-    po.crashed = B->d_crashed.p; po.opinfo = B->d_opinfo.p; po.n_hist = nh; po.mask_words = B->mask_words;
+    po.crashed = B->d_crashed.p; po.ret_slot = B->d_ret_slot.p; po.slot8 = B->d_slot8.p; po.n_hist = nh; po.mask_words = B->mask_words;
     launch_pack_open(po, s);
     HIP_TRY(hipGetLastError());
   }
@@ -605,7 +630,7 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results) {
       if (B->res_host[h].valid == TBC_UNKNOWN && B->res_host[h].cause == TBC_CAUSE_VISITED_FULL) {
         const uint64_t wpe = is_seq[h] ? KW : EW;
         uint32_t lg = final_log2[h] + 4;
-        while (lg > final_log2[h] && (1ull << lg) * wpe * 8 > max_bytes) lg--;
+        while (lg > final_log2[h] && ((1ull << lg) * wpe * 8 > max_bytes || (!is_seq[h] && lg > kBeamMaxTabLog2))) lg--;
         if (lg > final_log2[h]) {
           if (is_seq[h]) { pend_seq.push_back(h); lg_seq.push_back(lg); }
           else { pend_beam.push_back(h); lg_beam.push_back(lg); }

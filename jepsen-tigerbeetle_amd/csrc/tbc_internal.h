@@ -13,6 +13,7 @@ constexpr uint32_t kMaxSlots = 1024;       // 16 mask words x 64 lanes
 constexpr uint32_t kWavesPerBlock = 4;
 constexpr uint32_t kBlock = 64 * kWavesPerBlock;
 constexpr uint8_t kFNone = 0xFF;           // sentinel record: never a candidate
+constexpr uint32_t kBeamMaxTabLog2 = 28;   // wide kernel: the 16 B keys of one history stay below 4 GiB (32-bit byte offsets)
 constexpr uint32_t kCfgCap = 256;          // configs at the failing front copied back per invalid history
 
 // One op in the slot-major ("per process, in time order") layout the search
@@ -114,17 +115,21 @@ struct SearchArgs {
 };
 
 // ---- wide ("beam") schedule of the search: extra per-history layout built by pack_open_kernel
-struct __attribute__((aligned(16))) OpInfo {   // indexed by op (invocation order)
-  uint32_t ret_rank;    // kInf if crashed
-  uint32_t f_slot;      // f | slot << 8
+// One candidate of one front: the open-call lists hold the whole record, so a lane reaches its
+// candidate with ONE load (list entry -> op record would be two dependent trips to HBM).
+struct __attribute__((aligned(16))) OpRec {
+  uint32_t op;          // index in the caller's op columns
+  uint32_t f_slot;      // f | slot << 8 | kAtFront if this front is the call's own completion
   int32_t a, b;
 };
-static_assert(sizeof(OpInfo) == 16, "OpInfo must be 16 bytes");
+static_assert(sizeof(OpRec) == 16, "OpRec must be 16 bytes");
+constexpr uint32_t kAtFront = 0x80000000u;
+constexpr uint32_t kSlotMask = 0xFFFFu;     // (f_slot >> 8) & kSlotMask = process slot
 
 struct __attribute__((aligned(16))) BeamHist {
   uint64_t off_off;     // u32 units: off[] (n_ops + 2), ncr[] at the same offset in its own arena
   uint64_t occ_off;     // u64 units: occ[] ((n_ops + 1) * mask_words)
-  uint64_t lst_off;     // u32 units
+  uint64_t lst_off;     // OpRec units
   uint64_t stack_off;   // u32 units (capacity = table capacity)
   uint64_t tab_off;     // entry units
   uint32_t lst_cap;     // entries available in lst
@@ -145,25 +150,30 @@ struct PackOpenArgs {
   uint32_t* off;
   uint32_t* ncr;
   uint64_t* occ;
-  uint32_t* lst;
-  uint32_t* crashed;         // n_ops entries per history at op_off
-  OpInfo* opinfo;            // n_ops entries per history at op_off
+  OpRec* lst;
+  OpRec* crashed;            // n_ops entries per history at op_off
+  const uint32_t* ret_slot;  // pack_kernel: process slot of the call completing at each rank (at ret_off)
+  uint8_t* slot8;            // the same as bytes (mask_words <= 4), at slot8_off(op_off, h): windowed prefetch
   uint32_t n_hist;
   uint32_t mask_words;
 };
+
+// byte offset of history h's slot8[] (n_ret entries + 16 of padding), 8-byte aligned
+__host__ __device__ inline uint64_t slot8_off(uint64_t op_off, uint64_t h) { return (op_off + 24ull * h) & ~7ull; }
+__host__ __device__ inline uint64_t slot8_bytes(uint64_t total_ops, uint64_t n_hist) { return total_ops + 24ull * n_hist + 32ull; }
 
 struct BeamArgs {
   const Hist* hist;
   const BeamHist* bh;
   const uint32_t* off;
   const uint32_t* ncr;
-  const uint32_t* lst;
-  const uint32_t* crashed;
-  const OpInfo* opinfo;
+  const OpRec* lst;
+  const OpRec* crashed;
+  const uint8_t* slot8;
   const uint32_t* ret_slot;
   const uint32_t* ret_op;
   uint32_t* stack;
-  uint64_t* tab;             // entries of (2 + mask_words) u64 words: k0, M[], {parent | op << 32}
+  uint64_t* tab;             // (2 + mask_words) u64 words per entry; layout is the kernel's own (wgl_beam.hip / wgl_beam_wg.hip)
   DevResult* results;
   uint32_t* witness;         // n_ops per history at op_off, may be null
   const uint32_t* work;

@@ -28,11 +28,17 @@
 // the CAS and the others lose it on that very slot) and the lowest lane keeps
 // the config; everything else follows program order of one wavefront.
 //
-// Visited-set entry (MW = mask words): k0 = front+1 | state<<32, M[MW],
-// {parent entry | op<<32}: 24 B at MW = 1.  The 16 most recent pushes are
-// mirrored in an LDS ring so the next iteration's parents come from LDS.  A history is owned by
-// one wavefront; entries are read/written with agent-scope (sc1) accesses so
-// a lane never sees a stale L1 line of an entry another lane just claimed.
+// Visited set (MW = mask words): keys k0 = front+1 | state<<32, M[MW] -- 16 B at
+// MW = 1, four to a 64 B bucket that one probe reads whole -- and, in a separate
+// array, {parent entry | op<<32}.  The 64 most recent pushes are mirrored in an
+// LDS ring so the next iterations' parents come from LDS.  Every dependent trip to
+// memory is a round's latency, and a round is the unit the whole search is made
+// of, so the data is laid out for ONE trip per step: candidate = one 16 B record
+// of the front's open-call list (pack_open.hip), front advance = a 16-rank window
+// of completion slots fetched with it, probe = one bucket (+ the CAS for a new
+// config).  A history is owned by one wavefront; entries are read/written with
+// agent-scope (sc1) accesses so a lane never sees a stale L1 line of an entry
+// another lane just claimed.
 #include <hip/hip_runtime.h>
 #include "tbc_internal.h"
 #include "device_common.h"
@@ -43,19 +49,54 @@ namespace {
 
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 
-__device__ __forceinline__ uint64_t ld64(const uint64_t* p) {
+// The visited set and the stack are addressed through pointers that pass through LDS (parked search
+// state) or come out of the growth pool: name their address space, or every access turns into a flat_*.
+typedef __attribute__((address_space(1))) uint64_t gu64;
+typedef __attribute__((address_space(1))) uint32_t gu32;
+
+__device__ __forceinline__ uint64_t ld64(const gu64* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void st64(uint64_t* p, uint64_t v) {
+__device__ __forceinline__ void st64(gu64* p, uint64_t v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ uint32_t ld32(const uint32_t* p) {
+__device__ __forceinline__ uint32_t ld32(const gu32* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+__device__ __forceinline__ void st32(gu32* p, uint32_t v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// claim an empty entry: returns what was there (0 = claimed)
+__device__ __forceinline__ uint64_t cas64_from_zero(gu64* p, uint64_t desired) {
+  uint64_t expected = 0ull;
+  __hip_atomic_compare_exchange_strong(p, &expected, desired, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return expected;
+}
 
-// LDS words per wave: parents p_k0[16] p_M[16*MW] (u64) p_slot p_off p_nlive p_cnt (u32 x16),
-// ring of the 16 most recent pushes r_k0[16] r_M[16*MW] (u64) r_pos r_idx r_off r_nlive r_cnt (u32 x16)
-__host__ __device__ constexpr uint32_t beam_lds_words(uint32_t mw) { return 2 * (32 + 32 * mw) + 16 * 9 + 20; }
+constexpr uint32_t kRing = 64;     // most recent pushes mirrored in LDS
+
+// The lane number, opaque to the optimiser.  Everything an iteration derives from it (LDS addresses,
+// lane masks, shuffle indices: ~25 VGPRs) is then recomputed per iteration -- a few VALU ops against
+// thousands of cycles of memory latency -- instead of being hoisted out of the search loop and kept
+// alive across it, where it adds to the register peak of the cold growth path: 110 -> see below.
+__device__ __forceinline__ uint32_t opaque_lane(uint32_t lane) {
+  asm volatile("" : "+v"(lane));
+  return lane;
+}
+
+// max over lanes 0..15 (row 0 of the wave) with DPP row rotations; valid in lanes 0..15
+__device__ __forceinline__ uint32_t row_max_u32(uint32_t v) {
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x128, 0xf, 0xf, false));  // row_ror:8
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x124, 0xf, 0xf, false));  // row_ror:4
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x122, 0xf, 0xf, false));  // row_ror:2
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x121, 0xf, 0xf, false));  // row_ror:1
+  return v;
+}
+
+// LDS words per wave: parents p_k0[16] p_M[16*MW] (u64), ring r_k0[kRing] r_M[kRing*MW] (u64),
+// p_slot p_off p_nlive p_cnt (u32 x16), r_pos r_idx r_off r_nlive r_cnt (u32 x kRing), p_start (17 -> 20),
+// search state (24, see SearchState)
+__host__ __device__ constexpr uint32_t beam_lds_words(uint32_t mw) { return (16 + kRing) * (2 + 2 * mw) + 16 * 4 + kRing * 5 + 20 + 24; }
 
 __device__ __forceinline__ uint32_t key_hash32(uint64_t k0, const uint64_t* M, int mw) {
   uint32_t h = (uint32_t)k0 * 0x9E3779B1u ^ (uint32_t)(k0 >> 32) * 0x85EBCA77u;
@@ -67,66 +108,146 @@ __device__ __forceinline__ uint32_t key_hash32(uint64_t k0, const uint64_t* M, i
   return h;
 }
 
-// Cold path: move a history to a 4x larger visited set (and stack) taken from the batch's growth pool -- re-insert every entry, then
-// translate the slot numbers held by parent links, the stack and this iteration's parents.
+// ---- visited set -----------------------------------------------------------------------------------
+// cap = 2^cap_log2 entries.  keys[cap]: (1 + MW) u64 each (k0, M[]), in BUCKETS of four consecutive
+// entries -- 64 B, one cache line, at MW = 1; par[cap]: {parent entry | (op + 1) << 32}, behind the keys.
+// A probe reads a whole bucket with four 16 B loads in flight (one trip to L2/HBM), looks for the key,
+// else claims the bucket's first empty entry with a CAS on k0; a full bucket sends it to the next one.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// four agent-scope (sc1: never a stale line of this CU's L1) 16 B loads of one 64 B bucket, addressed as
+// uniform base (SGPR pair) + 32-bit byte offset (one VGPR): the keys of one history stay below 4 GiB
+__device__ __forceinline__ void ld_bucket16(const gu64* keys, uint32_t byte_off, u32x4& e0, u32x4& e1, u32x4& e2, u32x4& e3) {
+  asm volatile(
+      "global_load_dwordx4 %0, %4, %5 sc1\n\t"
+      "global_load_dwordx4 %1, %4, %5 offset:16 sc1\n\t"
+      "global_load_dwordx4 %2, %4, %5 offset:32 sc1\n\t"
+      "global_load_dwordx4 %3, %4, %5 offset:48 sc1\n\t"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(e0), "=&v"(e1), "=&v"(e2), "=&v"(e3)
+      : "v"(byte_off), "s"(keys)
+      : "memory");
+}
+
+// look at bucket `b`: returns match | empty << 4, bit t of `match` = entry t holds (k0, M), bit t of
+// `empty` = entry t is free (k0 is never 0: it carries front + 1)
 template <int MW>
-__device__ __forceinline__ bool grow_visited_set(const BeamArgs& A, uint64_t* tab, uint32_t* stack, uint32_t cap_log2,
-                                                           uint32_t sp, uint32_t np, uint32_t* p_slot, uint32_t* r_pos,
-                                                           uint32_t lane, uint64_t** ntab_out, uint32_t** nstack_out) {
-  constexpr uint32_t EW = MW + 2;
+__device__ __forceinline__ uint32_t scan_bucket(const gu64* tab, uint32_t b, uint64_t k0, const uint64_t (&M)[MW]) {
+  constexpr uint32_t KW = MW + 1;
+  const gu64* bp = tab + (uint64_t)b * (4 * KW);
+  uint32_t match = 0, empty = 0;
+  if constexpr (MW == 1) {
+    u32x4 e0, e1, e2, e3;
+    ld_bucket16(tab, b * 64u, e0, e1, e2, e3);
+    const uint32_t k0l = (uint32_t)k0, k0h = (uint32_t)(k0 >> 32), ml = (uint32_t)M[0], mh = (uint32_t)(M[0] >> 32);
+    empty = (e0.x == 0u ? 1u : 0u) | (e1.x == 0u ? 2u : 0u) | (e2.x == 0u ? 4u : 0u) | (e3.x == 0u ? 8u : 0u);
+    match = ((e0.x == k0l && e0.y == k0h && e0.z == ml && e0.w == mh) ? 1u : 0u) |
+            ((e1.x == k0l && e1.y == k0h && e1.z == ml && e1.w == mh) ? 2u : 0u) |
+            ((e2.x == k0l && e2.y == k0h && e2.z == ml && e2.w == mh) ? 4u : 0u) |
+            ((e3.x == k0l && e3.y == k0h && e3.z == ml && e3.w == mh) ? 8u : 0u);
+  } else {
+    uint64_t kk[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) kk[t] = ld64(bp + t * KW);
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      if ((uint32_t)kk[t] == 0u) empty |= 1u << t;
+      else if (kk[t] == k0) {
+        bool same = true;
+#pragma unroll
+        for (int j = 0; j < MW; j++) same = same && ld64(bp + t * KW + 1 + j) == M[j];
+        match |= same ? 1u << t : 0u;
+      }
+    }
+  }
+  return match | empty << 4;
+}
+
+// ---- search state ------------------------------------------------------------------------------------
+// Everything the round loop carries from one iteration to the next, parked in LDS whenever the loop is
+// left (to grow the visited set, or for good).  Inside the loop the visited set's address and size are
+// then loop-INVARIANT scalars; growing it in place made them (and, through the compiler's SGPR->VGPR
+// demotion of the whole web, every counter next to them) per-lane values: 65 -> 107 VGPRs, 8 -> 4
+// wavefronts per SIMD.  The accesses are volatile so nothing is forwarded around the growth code.
+enum : uint32_t {
+  S_TAB = 0, S_STACK = 2, S_CAP = 4, S_SP = 5, S_MAXSP = 6, S_MAXF = 7, S_K = 8, S_VERDICT = 9, S_CAUSE = 10,
+  S_WINPAR = 11, S_WINOP = 12, S_WINSTATE = 13, S_PROBES = 14, S_VISITED = 16, S_EXPANDED = 18, S_ITER = 20,
+  S_ROUNDS = 22, S_WORDS = 24
+};
+typedef __attribute__((address_space(3))) volatile uint32_t* state_ptr;   // LDS, named so: volatile accesses keep the generic (flat) form otherwise
+__device__ __forceinline__ uint32_t sld(state_ptr S, uint32_t i) { return rfl(S[i]); }
+__device__ __forceinline__ uint64_t sld64(state_ptr S, uint32_t i) {
+  return (uint64_t)rfl(S[i]) | ((uint64_t)rfl(S[i + 1]) << 32);
+}
+__device__ __forceinline__ void sst(state_ptr S, uint32_t i, uint32_t v) { S[i] = v; }
+__device__ __forceinline__ void sst64(state_ptr S, uint32_t i, uint64_t v) { S[i] = (uint32_t)v; S[i + 1] = (uint32_t)(v >> 32); }
+
+// Cold path: move a history to a 4x larger visited set (and stack) taken from the batch's growth pool --
+// re-insert every entry, then translate the slot numbers held by parent links and the stack.  Called
+// between iterations (nothing popped); reads and updates the parked search state.
+template <int MW>
+__device__ __forceinline__ bool grow_visited_set(const BeamArgs& A, state_ptr S, uint32_t* r_pos, uint32_t lane) {
+  constexpr uint32_t KW = MW + 1, EW = MW + 2;
+  const gu64* tab = (const gu64*)sld64(S, S_TAB);
+  const gu32* stack = (const gu32*)sld64(S, S_STACK);
+  const uint32_t cap_log2 = sld(S, S_CAP), sp = sld(S, S_SP);
   const uint64_t old_cap = 1ull << cap_log2, new_cap = old_cap << 2;
-  const uint64_t need = new_cap * EW + new_cap / 2 + old_cap / 2;      // table, stack, slot translation
+  const uint64_t need = new_cap * EW + new_cap / 2 + old_cap / 2;      // keys + parents, stack, slot translation
   unsigned long long base = 0;
   if (lane == 0) base = (A.pool && cap_log2 + 2 <= A.max_tab_log2) ? atomicAdd(A.pool_cursor, (unsigned long long)need) : ~0ull;
   base = ru64(base);
   if (!A.pool || cap_log2 + 2 > 31 || cap_log2 + 2 > A.max_tab_log2 || base + need > A.pool_words) return false;
-  uint64_t* ntab = A.pool + base;
-  uint32_t* nstack = reinterpret_cast<uint32_t*>(ntab + new_cap * EW);
-  uint32_t* remap = nstack + new_cap;
-  const uint32_t nmask = (uint32_t)(new_cap - 1);
+  gu64* ntab = (gu64*)A.pool + base;
+  gu64* npar = ntab + new_cap * KW;
+  const gu64* opar = tab + old_cap * KW;
+  gu32* nstack = (gu32*)(ntab + new_cap * EW);
+  gu32* remap = nstack + new_cap;
+  const uint32_t nbmask = (uint32_t)((new_cap >> 2) - 1);
 #pragma unroll 1
   for (uint64_t s = lane; s < old_cap; s += 64) {
-    const uint64_t* e = tab + s * EW;
+    const gu64* e = tab + s * KW;
     const uint64_t k0 = ld64(e);
     if ((uint32_t)k0 == 0u) continue;
     uint64_t Mx[MW];
 #pragma unroll
     for (int j = 0; j < MW; j++) Mx[j] = ld64(e + 1 + j);
-    const uint64_t pw = ld64(e + 1 + MW);
-    uint32_t idx = key_hash32(k0, Mx, MW) & nmask;
-    for (;;) {
-      uint64_t* ne = ntab + (uint64_t)idx * EW;
-      if (atomicCAS((unsigned long long*)ne, 0ull, (unsigned long long)k0) == 0ull) {
+    uint32_t b = key_hash32(k0, Mx, MW) & nbmask, idx = 0;
+    for (bool placed = false; !placed; b = (b + 1u) & nbmask) {
+#pragma unroll 1
+      for (uint32_t t = 0; t < 4 && !placed; t++) {
+        gu64* ne = ntab + ((uint64_t)b * 4 + t) * KW;
+        if (cas64_from_zero(ne, k0) == 0ull) {
 #pragma unroll
-        for (int j = 0; j < MW; j++) st64(ne + 1 + j, Mx[j]);
-        st64(ne + 1 + MW, pw);
-        break;
+          for (int j = 0; j < MW; j++) st64(ne + 1 + j, Mx[j]);
+          idx = b * 4 + t; placed = true;
+        }
       }
-      idx = (idx + 1u) & nmask;
     }
-    __hip_atomic_store(remap + s, idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    st32(remap + s, idx);
   }
   __threadfence();
 #pragma unroll 1
   for (uint64_t s = lane; s < old_cap; s += 64) {       // parent links -> new slot numbers
-    if ((uint32_t)ld64(tab + s * EW) == 0u) continue;
-    uint64_t* ne = ntab + (uint64_t)ld32(remap + s) * EW + 1 + MW;
-    const uint64_t pw = ld64(ne);
-    if ((uint32_t)pw != kNone) st64(ne, (uint64_t)ld32(remap + (uint32_t)pw) | (pw & 0xFFFFFFFF00000000ull));
+    if ((uint32_t)ld64(tab + s * KW) == 0u) continue;
+    const uint64_t pw = ld64(opar + s);
+    const uint64_t npw = (uint32_t)pw != kNone ? ((uint64_t)ld32(remap + (uint32_t)pw) | (pw & 0xFFFFFFFF00000000ull)) : pw;
+    st64(npar + ld32(remap + s), npw);
   }
 #pragma unroll 1
-  for (uint32_t i = lane; i < sp; i += 64)    // sp was already lowered by np: the popped run ...
-    __hip_atomic_store(nstack + i, ld32(remap + ld32(stack + i)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (lane < np) p_slot[lane] = ld32(remap + p_slot[lane]);   // ... lives in p_slot
-  if (lane < 16) r_pos[lane] = kNone;          // the ring held old slot numbers
+  for (uint32_t i = lane; i < sp; i += 64)
+    st32(nstack + i, ld32(remap + ld32(stack + i)));
+  if (lane < kRing) r_pos[lane] = kNone;       // the ring held old slot numbers
   __threadfence();
-  *ntab_out = ntab; *nstack_out = nstack;
+  if (lane == 0) {
+    sst64(S, S_TAB, (uint64_t)ntab); sst64(S, S_STACK, (uint64_t)nstack);
+    sst(S, S_CAP, cap_log2 + 2u);
+  }
   return true;
 }
 
 template <int MW, bool COMM>
 __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, const uint32_t lane) {
-  constexpr uint32_t EW = MW + 2;   // u64 words per entry
+  constexpr uint32_t KW = MW + 1;   // u64 words per key
 
   const Hist* H = A.hist + hidx;
   const BeamHist* B = A.bh + hidx;
@@ -135,43 +256,32 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
   const uint64_t off_off = ru64(B->off_off);
   const uint32_t* off = A.off + off_off;
   const uint32_t* ncr = A.ncr + off_off;
-  const uint32_t* lst = A.lst + ru64(B->lst_off);
-  const uint32_t* crashed = A.crashed + op_off;
-  const OpInfo* opinfo = A.opinfo + op_off;
-  const uint32_t* ret_slot = A.ret_slot + ret_off;
-  uint32_t* stack = A.stack + ru64(B->stack_off);
-  uint64_t* tab = A.tab + ru64(B->tab_off) * EW;   // both move when the visited set grows
+  const OpRec* lst = A.lst + ru64(B->lst_off);
+  const OpRec* crashed = A.crashed + op_off;
+  const uint8_t* slot8 = A.slot8 + slot8_off(op_off, hidx);
   const uint32_t R = rfl(H->n_ret), status = rfl(H->status) | rfl(B->status);
-  uint32_t cap_log2 = rfl(B->tab_log2);
-  uint32_t cap_mask = (uint32_t)((1ull << cap_log2) - 1ull);
-  uint32_t full_at = (uint32_t)((1ull << cap_log2) - (1ull << (cap_log2 - 2)));
   // K parents per iteration, G = 64 / K lanes (candidate slots) per parent per round.  A history that has
   // used more than round_budget rounds continues at K = 16: stragglers then need far fewer dependent rounds.
-  uint32_t K = A.width, gshift = 6u - (31u - (uint32_t)__builtin_clz(K)), G = 1u << gshift;
   DevResult* out = A.results + hidx;
   Model model{A.model_kind, A.table, A.n_classes, A.pool_vals, (int32_t)rfl((uint32_t)H->aux), A.n_keys};
 
   uint64_t* p_k0 = reinterpret_cast<uint64_t*>(lds);
   uint64_t* p_M = p_k0 + 16;
   uint64_t* r_k0 = p_M + 16 * MW;
-  uint64_t* r_M = r_k0 + 16;
-  uint32_t* p_slot = reinterpret_cast<uint32_t*>(r_M + 16 * MW);
+  uint64_t* r_M = r_k0 + kRing;
+  uint32_t* p_slot = reinterpret_cast<uint32_t*>(r_M + kRing * MW);
   uint32_t* p_off = p_slot + 16;
   uint32_t* p_nlive = p_off + 16;
   uint32_t* p_cnt = p_nlive + 16;
   uint32_t* r_pos = p_cnt + 16;      // stack position mirrored in this ring slot (kNone = empty)
-  uint32_t* r_idx = r_pos + 16;
-  uint32_t* r_off = r_idx + 16;
-  uint32_t* r_nlive = r_off + 16;
-  uint32_t* r_cnt = r_nlive + 16;
-  uint32_t* p_start = r_cnt + 16;    // 17 entries: pair-number prefix, general mapping only
-  if (lane < 16) r_pos[lane] = kNone;
+  uint32_t* r_idx = r_pos + kRing;
+  uint32_t* r_off = r_idx + kRing;
+  uint32_t* r_nlive = r_off + kRing;
+  uint32_t* r_cnt = r_nlive + kRing;
+  uint32_t* p_start = r_cnt + kRing;  // 17 entries: pair-number prefix, general mapping only
+  state_ptr S = (state_ptr)(p_start + 20);   // parked search state (S_* words)
+  if (lane < kRing) r_pos[lane] = kNone;
 
-  uint64_t probes = 0, visited = 0, expanded = 0, iterations = 0, rounds = 0;
-  uint32_t sp = 0, max_sp = 0, lane_maxf = 0;
-  int32_t verdict = -2, cause = TBC_CAUSE_NONE;
-  uint32_t win_parent = kNone, win_op = kNone;
-  int32_t win_state = A.init_state;
   const uint64_t t0 = A.time_limit_ticks ? wall_clock64() : 0;
 #ifdef TBC_SEGPROF   // per-segment cycle counters (scripts/gpu_segprof.py); costs ~20 VGPRs, off in production
   const bool prof = A.dbg != nullptr;
@@ -182,61 +292,92 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
 #define SEG(i) do {} while (0)
 #endif
 
-  if (status != 0) verdict = TBC_UNKNOWN;
-  else if (R == 0) verdict = TBC_VALID;
-  else {
-    // root config
-    const uint64_t k0 = 1ull | ((uint64_t)(uint32_t)A.init_state << 32);
-    uint64_t zero[MW];
+  {   // initial state -> LDS
+    gu32* stack0 = (gu32*)A.stack + ru64(B->stack_off);
+    gu64* tab0 = (gu64*)A.tab + ru64(B->tab_off) * (KW + 1);
+    const uint32_t cap0 = rfl(B->tab_log2);
+    int32_t verdict0 = -2;
+    uint32_t sp0 = 0;
+    if (status != 0) verdict0 = TBC_UNKNOWN;
+    else if (R == 0) verdict0 = TBC_VALID;
+    else {
+      // root config: first entry of its bucket
+      const uint64_t k0 = 1ull | ((uint64_t)(uint32_t)A.init_state << 32);
+      uint64_t zero[MW];
 #pragma unroll
-    for (int j = 0; j < MW; j++) zero[j] = 0;
-    const uint32_t idx = key_hash32(k0, zero, MW) & cap_mask;
-    if (lane == 0) {
-      uint64_t* e = tab + (uint64_t)idx * EW;
-      st64(e + 0, k0);
+      for (int j = 0; j < MW; j++) zero[j] = 0;
+      const uint32_t idx = (key_hash32(k0, zero, MW) & (uint32_t)((1ull << (cap0 - 2)) - 1ull)) * 4u;
+      if (lane == 0) {
+        gu64* e = tab0 + (uint64_t)idx * KW;
+        st64(e + 0, k0);
 #pragma unroll
-      for (int j = 0; j < MW; j++) st64(e + 1 + j, 0ull);
-      st64(e + 1 + MW, (uint64_t)kNone | ((uint64_t)kNone << 32));
-      __hip_atomic_store(stack, idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int j = 0; j < MW; j++) st64(e + 1 + j, 0ull);
+        st64(tab0 + ((uint64_t)KW << cap0) + idx, (uint64_t)kNone | ((uint64_t)kNone << 32));
+        st32(stack0, idx);
+      }
+      sp0 = 1;
     }
-    sp = 1; visited = 1; max_sp = 1;
+    if (lane == 0) {
+      sst64(S, S_TAB, (uint64_t)tab0); sst64(S, S_STACK, (uint64_t)stack0);
+      sst(S, S_CAP, cap0); sst(S, S_SP, sp0); sst(S, S_MAXSP, sp0); sst(S, S_MAXF, 0u); sst(S, S_K, A.width);
+      sst(S, S_VERDICT, (uint32_t)verdict0); sst(S, S_CAUSE, (uint32_t)TBC_CAUSE_NONE);
+      sst(S, S_WINPAR, kNone); sst(S, S_WINOP, kNone); sst(S, S_WINSTATE, (uint32_t)A.init_state);
+      sst64(S, S_PROBES, 0ull); sst64(S, S_VISITED, (uint64_t)sp0); sst64(S, S_EXPANDED, 0ull);
+      sst64(S, S_ITER, 0ull); sst64(S, S_ROUNDS, 0ull);
+    }
   }
+
+  for (;;) {   // search until done; leave the round loop (state parked) whenever the visited set must grow
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  gu64* const tab = (gu64*)sld64(S, S_TAB);
+  gu32* const stack = (gu32*)sld64(S, S_STACK);
+  const uint32_t cap_log2 = sld(S, S_CAP);
+  const uint32_t bmask = (uint32_t)((1ull << (cap_log2 - 2)) - 1ull);       // bucket index mask
+  const uint32_t full_at = (uint32_t)((1ull << cap_log2) - (1ull << (cap_log2 - 2)));
+  gu64* const par = tab + ((uint64_t)KW << cap_log2);
+  uint32_t K = sld(S, S_K), gshift = 6u - (31u - (uint32_t)__builtin_clz(K)), G = 1u << gshift;
+  uint64_t probes = sld64(S, S_PROBES), visited = sld64(S, S_VISITED), expanded = sld64(S, S_EXPANDED);
+  uint64_t iterations = sld64(S, S_ITER), rounds = sld64(S, S_ROUNDS);
+  uint32_t sp = sld(S, S_SP), max_sp = sld(S, S_MAXSP), lane_maxf = sld(S, S_MAXF);
+  int32_t verdict = (int32_t)sld(S, S_VERDICT), cause = (int32_t)sld(S, S_CAUSE);
+  uint32_t win_parent = sld(S, S_WINPAR), win_op = sld(S, S_WINOP);
+  int32_t win_state = (int32_t)sld(S, S_WINSTATE);
+  bool need_grow = false;
 
   while (verdict == -2) {
     if (sp == 0) { verdict = TBC_INVALID; break; }
     if (A.round_budget && rounds > A.round_budget && K < 16u) { K = 16u; gshift = 2u; G = 4u; }
     const uint32_t np = min(K, sp);
+    const uint32_t ln = opaque_lane(lane);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     // ---- pop the np most recent configs: lane l < np loads the l-th from the bottom of the popped run
     uint32_t my_cnt = 0;
-    if (lane < np) {
-      const uint32_t spos = sp - np + lane, rs = spos & 15u;
+    if (ln < np) {
+      const uint32_t spos = sp - np + ln, rs = spos & (kRing - 1u);
       if (r_pos[rs] == spos) {                  // pushed recently: config (and its front's list) still in the ring
-        p_k0[lane] = r_k0[rs];
+        p_k0[ln] = r_k0[rs];
 #pragma unroll
-        for (int j = 0; j < MW; j++) p_M[lane * MW + j] = r_M[rs * MW + j];
-        p_slot[lane] = r_idx[rs]; p_off[lane] = r_off[rs]; p_nlive[lane] = r_nlive[rs];
+        for (int j = 0; j < MW; j++) p_M[ln * MW + j] = r_M[rs * MW + j];
+        p_slot[ln] = r_idx[rs]; p_off[ln] = r_off[rs]; p_nlive[ln] = r_nlive[rs];
         my_cnt = r_cnt[rs];
       } else {
         const uint32_t idx = ld32(stack + spos);
-        const uint64_t* e = tab + (uint64_t)idx * EW;
+        const gu64* e = tab + (uint64_t)idx * KW;
         const uint64_t k0 = ld64(e);
-        p_k0[lane] = k0;
+        p_k0[ln] = k0;
 #pragma unroll
-        for (int j = 0; j < MW; j++) p_M[lane * MW + j] = ld64(e + 1 + j);
+        for (int j = 0; j < MW; j++) p_M[ln * MW + j] = ld64(e + 1 + j);
         const uint32_t fi = (uint32_t)k0 - 1u;
         const uint32_t o0 = off[fi], o1 = off[fi + 1], nc = ncr[fi];
-        p_slot[lane] = idx; p_off[lane] = o0; p_nlive[lane] = o1 - o0;
+        p_slot[ln] = idx; p_off[ln] = o0; p_nlive[ln] = o1 - o0;
         my_cnt = (o1 - o0) + nc;
       }
-      p_cnt[lane] = my_cnt;
+      p_cnt[ln] = my_cnt;
     }
     sp -= np;
-    uint32_t maxcnt = my_cnt;                   // lanes >= np hold 0
-#pragma unroll
-    for (int d = 8; d >= 1; d >>= 1) maxcnt = max(maxcnt, (uint32_t)__shfl_xor(maxcnt, d));
-    maxcnt = rl(maxcnt, 0);
+    const uint32_t maxcnt = rl(row_max_u32(my_cnt), 0);   // lanes >= np hold 0
     // Pair order (oracle/wgl_beam.c): parents bottom-first, each parent's open calls last-to-first,
     // 64 consecutive pairs per round.  When every parent has at most G = 64/K open calls all pairs
     // fit one round and lane = parent*G + i realises that order directly; otherwise pairs are
@@ -248,32 +389,18 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
 #pragma unroll
       for (int d = 1; d < 16; d <<= 1) {
         const uint32_t y = __shfl_up(x, d);
-        if (lane >= (uint32_t)d) x += y;
+        if (ln >= (uint32_t)d) x += y;
       }
-      if (lane < np) p_start[lane] = x - my_cnt;
+      if (ln < np) p_start[ln] = x - my_cnt;
       T = rl(x, np - 1);
-      if (lane == 0) p_start[np] = T;
+      if (ln == 0) p_start[np] = T;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    // ---- room for every pair of this iteration?  If not, move to a 4x larger visited set (and stack)
-    // taken from the batch's growth pool: re-insert every entry, then translate the slot numbers held
-    // by parent links, the stack and this iteration's parents.  Results do not depend on the layout.
-    {
-      const uint32_t worst = grouped ? np * G : T;
-      bool failed = false;
-      while (__builtin_expect(!failed && (uint64_t)visited + worst > full_at, 0)) {
-        uint64_t* ntab = nullptr; uint32_t* nstack = nullptr;
-        if (!grow_visited_set<MW>(A, tab, stack, cap_log2, sp, np, p_slot, r_pos, lane, &ntab, &nstack)) { failed = true; break; }
-        const uint64_t new_cap = 1ull << (cap_log2 + 2);
-        const uint32_t nmask = (uint32_t)(new_cap - 1);
-        tab = ntab; stack = nstack; cap_log2 += 2; cap_mask = nmask;
-        full_at = (uint32_t)(new_cap - (new_cap >> 2));
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-      }
-      if (failed) { sp += np; verdict = TBC_UNKNOWN; cause = TBC_CAUSE_VISITED_FULL; break; }
-    }
+    // ---- room for every pair of this iteration?  If not, put the popped configs back and leave: the
+    // visited set moves to a 4x larger one, and the iteration is taken again from its start.
+    if (__builtin_expect((uint64_t)visited + (grouped ? np * G : T) > full_at, 0)) { sp += np; need_grow = true; break; }
+    const uint32_t lr = opaque_lane(lane);
     iterations++; expanded += np;
     SEG(0);
 
@@ -282,9 +409,9 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
       uint32_t q, cd;
       bool has_parent;
       if (grouped) {
-        q = lane >> gshift; cd = lane & (G - 1u); has_parent = q < np;
+        q = lr >> gshift; cd = lr & (G - 1u); has_parent = q < np;
       } else {
-        const uint32_t r = base + lane;
+        const uint32_t r = base + lr;
         q = 0;
 #pragma unroll
         for (uint32_t t = 1; t < 16; t++) q += (t < np && p_start[t] <= r) ? 1u : 0u;
@@ -300,21 +427,34 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
       const uint32_t pslot = has_parent ? p_slot[q] : 0u, poff = has_parent ? p_off[q] : 0u;
       const uint32_t nlive = has_parent ? p_nlive[q] : 0u, cnt = has_parent ? p_cnt[q] : 0u;
       const bool act = has_parent && cd < cnt;
-      const uint32_t next_slot = (act && fi + 1u < R) ? ret_slot[fi + 1u] : 0u;   // first step of a front advance
       const uint32_t c = cnt - 1u - cd;
-      uint32_t op = 0;
-      OpInfo oi; oi.ret_rank = 0; oi.f_slot = kFNone; oi.a = 0; oi.b = 0;
-      if (act) { op = c < nlive ? lst[poff + c] : crashed[c - nlive]; oi = opinfo[op]; }
-      const uint32_t p = oi.f_slot >> 8;
+      // one trip: the candidate's record, and the completion slots of the next 9..16 ranks (front advance)
+      OpRec oi; oi.op = 0; oi.f_slot = kFNone; oi.a = 0; oi.b = 0;
+      const uint32_t wbase = (fi + 1u) & ~7u;
+      uint64_t w0 = 0, w1 = 0;
+      if (act) {
+        oi = c < nlive ? lst[poff + c] : crashed[c - nlive];
+        const uint64_t* wp = reinterpret_cast<const uint64_t*>(slot8 + wbase);
+        w0 = wp[0]; w1 = wp[1];
+      }
+      const uint32_t op = oi.op;
+      const uint32_t p = (oi.f_slot >> 8) & kSlotMask;
       if (prof) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); SEG(1); }
       bool lin = false;
 #pragma unroll
       for (int j = 0; j < MW; j++) if ((p >> 6) == (uint32_t)j) lin = (Mp[j] >> (p & 63u)) & 1ull;
-      const bool viable = act && !lin && pair_viable<MW, COMM>(model, st, fi, Mp, poff, nlive, cnt, lst, crashed, opinfo, oi);
+      const bool viable = act && !lin && pair_viable<MW, COMM>(model, st, fi, Mp, poff, nlive, cnt, lst, crashed, oi);
       int32_t st2 = st;
       uint32_t fi2 = fi;
       uint64_t M2[MW];
-      make_child<MW, COMM>(model, viable, st, fi, R, ret_slot, next_slot, oi, Mp, M2, st2, fi2);
+      make_child<MW, COMM>(model, viable, st, fi, R,
+                           [=](uint32_t r) -> uint32_t {
+                             const uint32_t d = r - wbase;
+                             if (d < 8u) return (uint32_t)(w0 >> (8u * d)) & 0xFFu;
+                             if (d < 16u) return (uint32_t)(w1 >> (8u * (d - 8u))) & 0xFFu;
+                             return (uint32_t)slot8[r];
+                           },
+                           oi, Mp, M2, st2, fi2);
       SEG(2);
       rounds++;
       const uint64_t succ = __ballot(viable && fi2 == R);
@@ -331,37 +471,38 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
       uint32_t co0 = 0, co1 = 0, cnc = 0;
       if (viable) { co0 = off[fi2]; co1 = off[fi2 + 1u]; cnc = ncr[fi2]; }
 
-      // ---- visited set: claim-or-find with one CAS per probe step.  Equal keys probe in lockstep.
+      // ---- visited set: find the key in its bucket chain, else claim the first empty entry met.
+      // Equal keys probe in lockstep: they look at the same bucket, go for the same entry, one wins the
+      // CAS, and the others find the key there on their next look (`lost` then tells it is new).
       const uint64_t k0 = (uint64_t)(fi2 + 1u) | ((uint64_t)(uint32_t)st2 << 32);
-      uint32_t idx = key_hash32(k0, M2, MW) & cap_mask;
+      uint32_t b = key_hash32(k0, M2, MW) & bmask, idx = 0, full_buckets = 0;
       bool pending = viable, fresh = false, won = false, lost = false;
       while (__ballot(pending)) {
         if (pending) {
-          uint64_t* e = tab + (uint64_t)idx * EW;
-          const uint64_t k0e = ld64(e);
-          if ((uint32_t)k0e == 0u) {
-            const uint64_t old = atomicCAS((unsigned long long*)e, 0ull, (unsigned long long)k0);
-            if (old == 0ull) {                       // claimed an empty entry
+          const uint32_t me = scan_bucket<MW>(tab, b, k0, M2), match = me & 15u, empty = me >> 4;
+          if (match) {
+            idx = b * 4u + (uint32_t)__builtin_ctz(match);
+            fresh = lost;      // a lost CAS followed by a match in that bucket: inserted in THIS round
+            pending = false;   //   by a sibling lane
+          } else if (empty) {
+            idx = b * 4u + (uint32_t)__builtin_ctz(empty);
+            gu64* e = tab + (uint64_t)idx * KW;
+            const uint64_t old = cas64_from_zero(e, k0);
+            if (old == 0ull) {                         // claimed an empty entry
 #pragma unroll
               for (int j = 0; j < MW; j++) st64(e + 1 + j, M2[j]);
               won = true; fresh = true; pending = false;
             } else {
-              lost = true;     // claimed by another lane in this very step: look at the same entry again
+              lost = true;     // claimed by another lane in this very step: look at the same bucket again
             }
           } else {
-            bool same = k0e == k0;
-#pragma unroll
-            for (int j = 0; j < MW; j++) same = same && ld64(e + 1 + j) == M2[j];
-            if (same) {
-              fresh = lost;    // equal keys probe in lockstep: a lost CAS followed by a match on that slot
-              pending = false; //   means the config was inserted in THIS round by a sibling lane
-            } else {
-              lost = false;
-              idx = (idx + 1u) & cap_mask;
-            }
+            lost = false;
+            b = (b + 1u) & bmask;
+            if (++full_buckets > bmask) pending = false;   // every bucket full: cannot happen below the 3/4 fill bound
           }
         }
       }
+      if (__ballot(full_buckets > bmask)) { verdict = TBC_UNKNOWN; cause = TBC_CAUSE_VISITED_FULL; break; }
       SEG(3);
       // the lowest lane among the lanes that produced one and the same new config keeps it
       bool is_new = fresh;
@@ -371,17 +512,17 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
         const uint32_t i0 = rl(idx, l0);
         const uint64_t grp = __ballot(fresh && idx == i0);
         const uint32_t winner = (uint32_t)__builtin_ctzll(grp);
-        if ((grp >> lane) & 1ull) is_new = lane == winner;
+        if ((grp >> lr) & 1ull) is_new = lr == winner;
         dupl &= ~grp;
       }
-      if (is_new) st64(tab + (uint64_t)idx * EW + 1 + MW, (uint64_t)pslot | ((uint64_t)(op + 1u) << 32));
+      if (is_new) st64(par + idx, (uint64_t)pslot | ((uint64_t)(op + 1u) << 32));
       const uint64_t nb = __ballot(is_new);
       const uint32_t nn = (uint32_t)__popcll(nb);
       if (is_new) {
-        const uint32_t pos = sp + (uint32_t)__popcll(nb & ((1ull << lane) - 1ull));
-        __hip_atomic_store(stack + pos, idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (pos + 16u >= sp + nn) {               // one of the 16 topmost: mirror it in the LDS ring
-          const uint32_t rs = pos & 15u;
+        const uint32_t pos = sp + (uint32_t)__popcll(nb & ((1ull << lr) - 1ull));
+        st32(stack + pos, idx);
+        {                                           // mirror it in the LDS ring (nn <= 64 = kRing: no clash)
+          const uint32_t rs = pos & (kRing - 1u);
           r_pos[rs] = pos; r_idx[rs] = idx; r_k0[rs] = k0;
 #pragma unroll
           for (int j = 0; j < MW; j++) r_M[rs * MW + j] = M2[j];
@@ -393,7 +534,7 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
       SEG(4);
     }
     max_sp = max(max_sp, sp);
-    if (A.dbg && lane == 0 && (iterations & 255u) == 1u) {
+    if (A.dbg && lr == 0 && (iterations & 255u) == 1u) {
       A.dbg[8] = hidx; A.dbg[9] = (uint32_t)iterations; A.dbg[10] = sp; A.dbg[11] = (uint32_t)probes;
       A.dbg[12] = (uint32_t)visited; A.dbg[13] = maxcnt; A.dbg[14] = np; A.dbg[15] = (uint32_t)rounds;
     }
@@ -405,18 +546,47 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
     }
   }
 
-  // ---- results
-  uint32_t maxf = lane_maxf;
+  // ---- park the state
+  {
+    uint32_t mf = lane_maxf;
 #pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) maxf = max(maxf, (uint32_t)__shfl_xor(maxf, d));
-  maxf = rfl(maxf);
+    for (int d = 32; d >= 1; d >>= 1) mf = max(mf, (uint32_t)__shfl_xor(mf, d));
+    if (lane == 0) {
+      sst(S, S_SP, sp); sst(S, S_MAXSP, max_sp); sst(S, S_MAXF, mf); sst(S, S_K, K);
+      sst(S, S_VERDICT, (uint32_t)verdict); sst(S, S_CAUSE, (uint32_t)cause);
+      sst(S, S_WINPAR, win_parent); sst(S, S_WINOP, win_op); sst(S, S_WINSTATE, (uint32_t)win_state);
+      sst64(S, S_PROBES, probes); sst64(S, S_VISITED, visited); sst64(S, S_EXPANDED, expanded);
+      sst64(S, S_ITER, iterations); sst64(S, S_ROUNDS, rounds);
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  if (!need_grow) break;
+  if (!grow_visited_set<MW>(A, S, r_pos, lane)) {
+    if (lane == 0) { sst(S, S_VERDICT, (uint32_t)TBC_UNKNOWN); sst(S, S_CAUSE, (uint32_t)TBC_CAUSE_VISITED_FULL); }
+    break;
+  }
+  }   // for (;;)
+
+  // ---- results
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const gu64* tab = (const gu64*)sld64(S, S_TAB);
+  const uint32_t cap_log2 = sld(S, S_CAP);
+  const gu64* par = tab + ((uint64_t)KW << cap_log2);
+  const int32_t verdict = (int32_t)sld(S, S_VERDICT), cause = (int32_t)sld(S, S_CAUSE);
+  const uint32_t maxf = sld(S, S_MAXF), win_parent = sld(S, S_WINPAR), win_op = sld(S, S_WINOP);
+  const int32_t win_state = (int32_t)sld(S, S_WINSTATE);
+  const uint64_t probes = sld64(S, S_PROBES), visited = sld64(S, S_VISITED), expanded = sld64(S, S_EXPANDED);
+  const uint64_t iterations = sld64(S, S_ITER), rounds = sld64(S, S_ROUNDS);
+  const uint32_t max_sp = sld(S, S_MAXSP);
   // ---- invalid: the configs stuck at the failing completion (knossos :configs), by a scan of the visited set
   uint32_t n_cfg = 0;
   if (verdict == TBC_INVALID && A.cfg) {
     uint64_t* cfg = A.cfg + (uint64_t)hidx * kCfgCap * (2 + MW);
     const uint64_t ncap = 1ull << cap_log2;
     for (uint64_t s0 = 0; s0 < ncap; s0 += 64) {
-      const uint64_t* e = tab + (s0 + lane) * EW;
+      const gu64* e = tab + (s0 + lane) * KW;
       const uint64_t k0 = ld64(e);
       const bool hit = (uint32_t)k0 == maxf + 1u;
       const uint64_t hb = __ballot(hit);
@@ -427,7 +597,7 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
           o[0] = k0;
 #pragma unroll
           for (int j = 0; j < MW; j++) o[1 + j] = ld64(e + 1 + j);
-          const uint64_t pw = ld64(e + 1 + MW);
+          const uint64_t pw = ld64(par + s0 + lane);
           o[1 + MW] = (uint32_t)pw == kNone ? (uint64_t)TBC_NO_OP : (pw >> 32) - 1ull;
         }
       }
@@ -440,9 +610,9 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
     wlen = 1;
     uint32_t id = win_parent;
     for (;;) {
-      const uint32_t par = (uint32_t)ld64(tab + (uint64_t)id * EW + 1 + MW);
-      if (par == kNone) break;
-      wlen++; id = par;
+      const uint32_t pr = (uint32_t)ld64(par + id);
+      if (pr == kNone) break;
+      wlen++; id = pr;
     }
     if (A.witness) {
       uint32_t* wit = A.witness + op_off;
@@ -450,12 +620,12 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
       if (lane == 0) wit[w] = win_op;
       id = win_parent;
       for (;;) {
-        const uint64_t po = ld64(tab + (uint64_t)id * EW + 1 + MW);
-        const uint32_t par = (uint32_t)po;
-        if (par == kNone) break;
+        const uint64_t po = ld64(par + id);
+        const uint32_t pr = (uint32_t)po;
+        if (pr == kNone) break;
         w--;
         if (lane == 0) wit[w] = (uint32_t)(po >> 32) - 1u;
-        id = par;
+        id = pr;
       }
     }
   }
@@ -481,11 +651,16 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
 #undef SEG
 }
 
-// Register budget (MW = 1, state-carrying models): 94 VGPRs -> 5 wavefronts per SIMD.  Forcing 6 with a
-// min-blocks launch bound spills in the round loop and measures slower; without the growth path the loop
-// needs 74, and that build is only 3-5 % faster (profiles/r01_vgpr_ab.txt), so growth stays inline.
+// Register budget (MW = 1, state-carrying models): 67 VGPRs on its own, 64 under the min-blocks bound (two
+// spilled values) -> 8 wavefronts per SIMD; measured 350 -> 291 ms on the 8192-history probe against 7
+// (profiles/r01_vgpr_ab.txt has the whole history: 116 with segment profiling compiled in, 94 without, 107
+// with the bucket probe until the search state was parked in LDS around the growth path).  The commutative
+// models' kernels need ~90 and are left to the register allocator.
+#ifndef TBC_BEAM_MIN_BLOCKS
+#define TBC_BEAM_MIN_BLOCKS 8
+#endif
 template <int MW, bool COMM>
-__global__ __launch_bounds__(kBlock) void wgl_beam_kernel(BeamArgs A) {
+__global__ __launch_bounds__(kBlock, COMM ? 1 : TBC_BEAM_MIN_BLOCKS) void wgl_beam_kernel(BeamArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   const uint32_t lane = threadIdx.x & 63u, wv = rfl(threadIdx.x >> 6);
   const uint32_t w = blockIdx.x * kWavesPerBlock + wv;

@@ -67,9 +67,8 @@ __global__ __launch_bounds__(kNT) void wgl_beam_wg_kernel(BeamArgs A) {
   const uint64_t op_off = H->op_off, ret_off = H->ret_off, off_off = B->off_off;
   const uint32_t* off = A.off + off_off;
   const uint32_t* ncr = A.ncr + off_off;
-  const uint32_t* lst = A.lst + B->lst_off;
-  const uint32_t* crashed = A.crashed + op_off;
-  const OpInfo* opinfo = A.opinfo + op_off;
+  const OpRec* lst = A.lst + B->lst_off;
+  const OpRec* crashed = A.crashed + op_off;
   const uint32_t* ret_slot = A.ret_slot + ret_off;
   uint32_t* stack = A.stack + B->stack_off;
   uint64_t* tab = A.tab + B->tab_off * EW;
@@ -164,16 +163,18 @@ __global__ __launch_bounds__(kNT) void wgl_beam_wg_kernel(BeamArgs A) {
       const bool act = has && cd < cnt;
       const uint32_t next_slot = (act && fi + 1u < R) ? ret_slot[fi + 1u] : 0u;
       const uint32_t c = cnt - 1u - cd;
-      uint32_t op = 0;
-      OpInfo oi; oi.ret_rank = 0; oi.f_slot = kFNone; oi.a = 0; oi.b = 0;
-      if (act) { op = c < nlive ? lst[poff + c] : crashed[c - nlive]; oi = opinfo[op]; }
-      const uint32_t p = oi.f_slot >> 8;
+      OpRec oi; oi.op = 0; oi.f_slot = kFNone; oi.a = 0; oi.b = 0;
+      if (act) oi = c < nlive ? lst[poff + c] : crashed[c - nlive];
+      const uint32_t op = oi.op;
+      const uint32_t p = (oi.f_slot >> 8) & kSlotMask;
       bool lin = false;
 #pragma unroll
       for (int j = 0; j < MW; j++) if ((p >> 6) == (uint32_t)j) lin = (Mp[j] >> (p & 63u)) & 1ull;
-      const bool viable = act && !lin && pair_viable<MW, COMM>(model, st, fi, Mp, poff, nlive, cnt, lst, crashed, opinfo, oi);
+      const bool viable = act && !lin && pair_viable<MW, COMM>(model, st, fi, Mp, poff, nlive, cnt, lst, crashed, oi);
       int32_t st2; uint32_t fi2; uint64_t M2[MW];
-      make_child<MW, COMM>(model, viable, st, fi, R, ret_slot, next_slot, oi, Mp, M2, st2, fi2);
+      make_child<MW, COMM>(model, viable, st, fi, R,
+                           [=](uint32_t rk) -> uint32_t { return rk == fi + 1u ? next_slot : ret_slot[rk]; },
+                           oi, Mp, M2, st2, fi2);
 
       if (viable && fi2 == R) atomicMin(&s_win, r);
       const uint64_t vb = __ballot(viable);
