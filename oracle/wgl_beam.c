@@ -131,6 +131,22 @@ int wgl_beam_check_rp(uint32_t n, const uint8_t* f, const int32_t* a, const int3
  * with K = 16 (tbc_opts.round_budget): the stragglers of a batch need far fewer dependent rounds */
 static uint32_t g_widen_after = 0;
 void wgl_beam_set_widen_after(uint32_t r) { g_widen_after = r; }
+/* list_order: how each front's live open calls are ordered (the FIRST one is tried first by the
+ * depth-first search): 0 = by process slot, 1 = by completion (the front's own call first),
+ * 2 = by invocation, 3 = by completion, latest first.  Both sides of a parity test use the same one. */
+/* progress trace (experiments only): maxf and stack depth sampled every 256 rounds */
+static uint32_t* g_trace = NULL; static uint32_t g_trace_cap = 0, g_trace_n = 0;
+void wgl_beam_set_trace(uint32_t* buf, uint32_t cap) { g_trace = buf; g_trace_cap = cap; g_trace_n = 0; }
+uint32_t wgl_beam_trace_len(void) { return g_trace_n; }
+/* stagnation escape (see the schedule text above): stall_rounds = 0 disables it */
+static uint32_t g_stall_rounds = 0, g_stall_width = 64, g_stall_mode = 0;
+void wgl_beam_set_stall(uint32_t rounds, uint32_t width, uint32_t mode) { g_stall_rounds = rounds; g_stall_width = width; g_stall_mode = mode; }
+/* lookahead pruning experiment: drop a child whose front call can never be linearized */
+static uint32_t g_lookahead = 0; static uint64_t g_pruned = 0;
+void wgl_beam_set_lookahead(uint32_t on) { g_lookahead = on; }
+uint64_t wgl_beam_pruned(void) { return g_pruned; }
+static uint32_t g_list_order = 0;
+void wgl_beam_set_list_order(uint32_t o) { g_list_order = o; }
 
 int wgl_beam_check(uint32_t n, const uint8_t* f, const int32_t* a, const int32_t* b,
                    const int32_t* process, uint32_t n_process,
@@ -195,10 +211,12 @@ int wgl_beam_check_rp(uint32_t n, const uint8_t* f, const int32_t* a, const int3
       if (ret_rank[i] == 0xFFFFFFFFu) { if (!(f[i] == O_READ && a[i] == O_NIL)) crashed[c++] = i; continue; }
       for (uint32_t fr = inv_rank[i]; fr <= ret_rank[i]; fr++) lst[fill[fr]++] = i;
     }
-    for (uint32_t fr = 0; fr < R; fr++)          /* each front's live list in process-slot order */
+#define LIST_KEY(o) (g_list_order == 0 ? (uint32_t)process[o] : g_list_order == 1 ? ret_rank[o] : \
+                     g_list_order == 2 ? inv_rank[o] * 1024u + (uint32_t)process[o] : 0xFFFFFFFEu - ret_rank[o])
+    for (uint32_t fr = 0; fr < R; fr++)          /* each front's live list in the chosen order */
       for (uint32_t x = off[fr] + 1; x < off[fr + 1]; x++) {
         uint32_t v = lst[x], y = x;
-        while (y > off[fr] && process[lst[y - 1]] > process[v]) { lst[y] = lst[y - 1]; y--; }
+        while (y > off[fr] && LIST_KEY(lst[y - 1]) > LIST_KEY(v)) { lst[y] = lst[y - 1]; y--; }
         lst[y] = v;
       } }
 
@@ -220,8 +238,25 @@ int wgl_beam_check_rp(uint32_t n, const uint8_t* f, const int32_t* a, const int3
   uint64_t* ck = (uint64_t*)malloc((size_t)RP * KW * 8);
   uint32_t cop[1024], cpar[1024]; int cviable[1024]; uint32_t cfront[1024]; int32_t cstate[1024];
 
+  uint64_t last_progress = 0; uint32_t seen_maxf = 0, stall_w = g_stall_width;
   while (verdict == -2) {
     if (sp == 0) { verdict = 0; break; }
+    if (g_stall_rounds) {
+      if (maxf > seen_maxf) { seen_maxf = maxf; last_progress = st->rounds; stall_w = g_stall_width; }
+      else if (st->rounds - last_progress > g_stall_rounds) {
+        /* stuck below one completion: bring older pending configs to the top */
+        size_t w = stall_w < sp ? stall_w : sp;
+        if (g_stall_mode == 0) {            /* reverse the top w entries */
+          for (size_t i = 0; i < w / 2; i++) { uint32_t t = stack[sp - 1 - i]; stack[sp - 1 - i] = stack[sp - w + i]; stack[sp - w + i] = t; }
+        } else {                            /* rotate: the w-th entry from the top becomes the top */
+          uint32_t t = stack[sp - w];
+          memmove(stack + sp - w, stack + sp - w + 1, (w - 1) * 4);
+          stack[sp - 1] = t;
+        }
+        last_progress = st->rounds;
+        if (stall_w < (1u << 20)) stall_w *= 2;
+      }
+    }
     const uint32_t Kc = (g_widen_after && st->rounds > g_widen_after && K < 16) ? 16 : K;
     uint32_t np = sp < Kc ? (uint32_t)sp : Kc;
     for (uint32_t q = 0; q < np; q++) par[q] = stack[sp - np + q];      /* q = 0 is the bottom-most popped */
@@ -274,10 +309,34 @@ int wgl_beam_check_rp(uint32_t n, const uint8_t* f, const int32_t* a, const int3
           }
         }
         c2[0] = (uint64_t)(fi2 + 1) | ((uint64_t)(uint32_t)s2 << 32);
+        if (g_lookahead && !cfgm && fi2 < R && (model->kind == O_REGISTER || model->kind == O_CAS_REGISTER)) {
+          int dead = 0;
+          for (uint32_t j = 0; j < g_lookahead && fi2 + j < R && !dead; j++) {
+            uint32_t fop = ret_op[fi2 + j], pf = (uint32_t)process[fop];
+            if (c2[1 + (pf >> 6)] >> (pf & 63) & 1) continue;            /* already linearized */
+            int need = (f[fop] == O_READ && a[fop] != O_NIL) || f[fop] == O_CAS;
+            if (!need || a[fop] == s2) continue;
+            int32_t v = a[fop]; int ok = 0;
+            for (uint32_t jj = 0; jj <= j && !ok; jj++) {                /* producers: calls open somewhere in [fi2, fi2+j] */
+              uint32_t F2 = fi2 + jj;
+              uint32_t nl = off[F2 + 1] - off[F2], tot = nl + (jj == j ? ncr[F2] : 0);
+              for (uint32_t cc = 0; cc < tot && !ok; cc++) {
+                uint32_t x = cc < nl ? lst[off[F2] + cc] : crashed[cc - nl];
+                uint32_t px = (uint32_t)process[x];
+                if (x == fop) continue;
+                if (inv_rank[x] <= fi2 && (c2[1 + (px >> 6)] >> (px & 63) & 1)) continue;   /* open now and linearized */
+                if ((f[x] == O_WRITE && a[x] == v) || (f[x] == O_CAS && b[x] == v)) ok = 1;
+              }
+            }
+            if (!ok) dead = 1;
+          }
+          if (dead) { g_pruned++; if (fi2 > maxf) maxf = fi2; continue; }
+        }
         cviable[l] = 1; cfront[l] = fi2; cstate[l] = s2;
         if (fi2 == R && success < 0) success = (int)l;
       }
       st->rounds++;
+      if (g_trace && (st->rounds & 255) == 0 && g_trace_n + 2 <= g_trace_cap) { g_trace[g_trace_n++] = maxf; g_trace[g_trace_n++] = (uint32_t)sp; }
       if (success >= 0) { verdict = 1; win_parent = cpar[success]; win_op = cop[success]; win_state = cstate[success]; break; }
       for (uint32_t l = 0; l < m; l++) {
         if (!cviable[l]) continue;
