@@ -70,7 +70,8 @@ class Opts(C.Structure):
     _fields_ = [("algorithm", C.c_uint32), ("device", C.c_uint32), ("time_limit_ms", C.c_uint64),
                 ("max_steps", C.c_uint64), ("max_visited_bytes", C.c_uint64),
                 ("want_witness", C.c_uint32), ("visited_per_op", C.c_uint32),
-                ("search_width", C.c_uint32), ("round_budget", C.c_uint32)]
+                ("search_width", C.c_uint32), ("round_budget", C.c_uint32),
+                ("lookahead", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class Config(C.Structure):

@@ -16,6 +16,8 @@
 //            double the config space (oracle/wgl_beam.c)
 //   slot8[]  process slot of the call completing at each rank, one byte each: the search
 //            prefetches a 16-rank window of it for the front advance
+//   look[]   one lookahead record per completion rank (layout: tbc_internal.h): what the call
+//            completing there needs, and which other calls could provide it
 //
 // This is knossos.linear.config's "pending calls by process" materialised for
 // every point of the history.  One 256-thread workgroup per
@@ -54,6 +56,15 @@ __device__ uint32_t block_exclusive_scan(uint32_t* v, uint32_t m, uint32_t* part
   for (uint32_t i = lo; i < hi; i++) { uint32_t x = ld_agent(&v[i]); v[i] = run; run += x; }
   __syncthreads();
   return *total_slot;
+}
+
+// register value a call must find / leaves behind, as a lookahead byte (0..31, else kLookNone)
+__device__ __forceinline__ uint32_t look_val(int32_t v) { return (v >= 0 && v < 32) ? (uint32_t)v : kLookNone; }
+__device__ __forceinline__ uint32_t look_need(uint32_t f, int32_t a) {
+  return ((f == TBC_F_READ && a != TBC_NIL) || f == TBC_F_CAS) ? look_val(a) : kLookNone;
+}
+__device__ __forceinline__ uint32_t look_prod(uint32_t f, int32_t a, int32_t b) {
+  return f == TBC_F_WRITE ? look_val(a) : (f == TBC_F_CAS ? look_val(b) : kLookNone);
 }
 
 }  // namespace
@@ -165,6 +176,59 @@ __global__ __launch_bounds__(256) void pack_open_kernel(PackOpenArgs A) {
       for (uint32_t i = lo; i < hi; i++) if (sc_ret[i] == kInf && !(f[i] == TBC_F_READ && a[i] == TBC_NIL)) {
         OpRec o; o.op = i; o.f_slot = (uint32_t)f[i] | ((uint32_t)proc[i] << 8); o.a = a[i]; o.b = b[i];
         crashed[run++] = o;
+      }
+      __syncthreads();
+    }
+    // E-G: lookahead records (register family only; A.look is null otherwise)
+    if (A.look) {
+      const uint32_t LW = 1 + MW;
+      uint64_t* look = A.look + look_off(H->op_off, h, MW);
+      const uint32_t* ret_op = A.ret_op + H->ret_off;
+      uint32_t* tmp = A.tmp + H->op_off;
+      __threadfence_block();
+      // E: per rank -- need / prod / dinv, and the producers of `need` open at that front
+      for (uint32_t t = tid; t < R + kLookPad; t += 256) {
+        uint64_t w0 = (uint64_t)(kLookNone << 16 | kLookNone << 24) | (255ull << 32) | (255ull << 40);
+        uint64_t pm[16];
+        for (uint32_t w = 0; w < MW; w++) pm[w] = 0;
+        if (t < R) {
+          const uint32_t op = ret_op[t];
+          const uint32_t need = look_need(f[op], a[op]), prod = look_prod(f[op], a[op], b[op]);
+          const uint32_t di = min(t - sc_inv[op], 255u);
+          w0 = (uint64_t)((uint32_t)proc[op] & 0xFFFFu) | (uint64_t)need << 16 | (uint64_t)prod << 24 |
+               (uint64_t)di << 32 | (255ull << 40);
+          if (need != kLookNone) {
+            const uint32_t o0 = ld_agent(&off[t]), o1 = ld_agent(&off[t + 1]), nc = ld_agent(&ncr[t]);
+            for (uint32_t c = 0; c < (o1 - o0) + nc; c++) {
+              const OpRec x = c < o1 - o0 ? lst[o0 + c] : crashed[c - (o1 - o0)];
+              const uint32_t xf = x.f_slot & 0xFFu, xs = (x.f_slot >> 8) & kSlotMask;
+              if (x.op != op && look_prod(xf, x.a, x.b) == need) pm[xs >> 6] |= 1ull << (xs & 63u);
+            }
+          }
+          tmp[t] = 255u;
+        }
+        look[(uint64_t)t * LW] = w0;
+        for (uint32_t w = 0; w < MW; w++) look[(uint64_t)t * LW + 1 + w] = pm[w];
+      }
+      __syncthreads();
+      // F: every producer tells the ranks right after its invocation how recent it is
+      for (uint32_t i = tid; i < n; i += 256) {
+        const uint32_t pv = look_prod(f[i], a[i], b[i]);
+        if (pv == kLookNone || (sc_ret[i] == kInf && f[i] == TBC_F_READ)) continue;
+        const uint32_t ir = sc_inv[i];
+        for (uint32_t t = ir; t < R && t < ir + kLookahead; t++) {
+          const uint32_t need = (uint32_t)(ld_agent64(&look[(uint64_t)t * LW]) >> 16) & 0xFFu;
+          if (need == pv && ret_op[t] != i) atomicMin(&tmp[t], t - ir);
+        }
+      }
+      __syncthreads();
+      // G: fold dprod into the records
+      for (uint32_t t = tid; t < R; t += 256) {
+        const uint32_t d = ld_agent(&tmp[t]);
+        if (d < 255u) {
+          const uint64_t w0 = ld_agent64(&look[(uint64_t)t * LW]);
+          look[(uint64_t)t * LW] = (w0 & ~(255ull << 40)) | ((uint64_t)d << 40);
+        }
       }
       __syncthreads();
     }

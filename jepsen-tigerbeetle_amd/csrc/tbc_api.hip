@@ -147,6 +147,9 @@ struct tbc_batch {
   DevBuf<uint32_t> d_off, d_ncr, d_stack;
   DevBuf<OpRec> d_lst, d_crashed;   // per-front open-call lists / crashed calls, whole records
   DevBuf<uint8_t> d_slot8;          // completion slots as bytes
+  bool lookahead = false;           // wide single-wave schedule, register family, tbc_opts.lookahead != 1
+  DevBuf<uint64_t> d_look;          // lookahead records per completion rank
+  DevBuf<uint32_t> d_looktmp;
   DevBuf<uint64_t> d_occ, d_btab, d_pool;
   DevBuf<unsigned long long> d_pool_cursor;
   // last run
@@ -162,7 +165,7 @@ struct tbc_batch {
     d_bitmap.release(); d_wpre.release(); d_frames.release(); d_witness.release(); d_work.release();
     d_queue.release(); d_tab.release(); d_results.release(); d_table.release(); d_pool_vals.release(); d_cfg.release();
     d_bh.release(); d_off.release(); d_ncr.release(); d_lst.release(); d_crashed.release(); d_stack.release();
-    d_occ.release(); d_btab.release(); d_slot8.release(); d_pool.release(); d_pool_cursor.release();
+    d_occ.release(); d_btab.release(); d_slot8.release(); d_look.release(); d_looktmp.release(); d_pool.release(); d_pool_cursor.release();
     for (auto& e : ev) if (e) (void)hipEventDestroy(e);
     if (stream) (void)hipStreamDestroy(stream);
   }
@@ -239,6 +242,8 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
   }
   B->width = width;
   B->wg = width > 16;
+  B->lookahead = width > 1 && width <= 16 && opts->lookahead != 1 &&
+                 (model->kind == TBC_MODEL_REGISTER || model->kind == TBC_MODEL_CAS_REGISTER);
   const bool beam = width > 1;
   const uint32_t EW = B->wg ? beam_wg_entry_words(B->mask_words) : B->mask_words + 2;   // u64 words per wide-schedule entry
 
@@ -300,6 +305,7 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
         (s = B->d_slot8.alloc(slot8_bytes(T, nh))) || (s = B->d_stack.alloc(bstack_n)) || (s = B->d_btab.alloc(btab_n * EW)) ||
         (s = B->d_pool_cursor.alloc(1)))
       return s;
+    if (B->lookahead && ((s = B->d_look.alloc(look_words(T, nh, B->mask_words))) || (s = B->d_looktmp.alloc(T)))) return s;
     // growth pool: a quarter of the visited-set arena, at least room for one history to grow twice, at most 32 GiB
     {
       uint64_t biggest = 0;
@@ -325,7 +331,7 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
                     B->d_ret_op.bytes() + B->d_bitmap.bytes() + B->d_wpre.bytes() + B->d_frames.bytes() +
                     B->d_tab.bytes() + B->d_results.bytes() + B->d_work.bytes() + B->d_witness.bytes();
   if (beam) B->device_bytes += B->d_bh.bytes() + B->d_off.bytes() + B->d_ncr.bytes() + B->d_occ.bytes() + B->d_lst.bytes() +
-                               B->d_crashed.bytes() + B->d_slot8.bytes() + B->d_stack.bytes() + B->d_btab.bytes() + B->d_pool.bytes();
+                               B->d_crashed.bytes() + B->d_slot8.bytes() + B->d_look.bytes() + B->d_looktmp.bytes() + B->d_stack.bytes() + B->d_btab.bytes() + B->d_pool.bytes();
 
   HIP_TRY(hipStreamCreateWithFlags(&B->stream, hipStreamNonBlocking));
   for (auto& e : B->ev) HIP_TRY(hipEventCreate(&e));
@@ -402,7 +408,7 @@ static uint32_t search_blocks(uint32_t n_work) {
 static BeamArgs make_beam_args(tbc_batch* B, uint64_t* tab, uint32_t* stack, uint32_t n_work) {
   BeamArgs a{};
   a.hist = B->d_hist.p; a.bh = B->d_bh.p; a.off = B->d_off.p; a.ncr = B->d_ncr.p; a.lst = B->d_lst.p;
-  a.crashed = B->d_crashed.p; a.slot8 = B->d_slot8.p; a.ret_slot = B->d_ret_slot.p; a.ret_op = B->d_ret_op.p;
+  a.crashed = B->d_crashed.p; a.slot8 = B->d_slot8.p; a.look = B->lookahead ? B->d_look.p : nullptr; a.ret_slot = B->d_ret_slot.p; a.ret_op = B->d_ret_op.p;
   a.stack = stack; a.tab = tab; a.results = B->d_results.p;
   a.witness = B->opts.want_witness ? B->d_witness.p : nullptr;
   a.work = B->d_work.p; a.table = B->d_table.p; a.n_work = n_work; a.model_kind = B->model.kind;
@@ -430,6 +436,7 @@ static BeamArgs make_beam_args(tbc_batch* B, uint64_t* tab, uint32_t* stack, uin
 // scratch arena (overflow retries, and wide-schedule histories that fall back to the sequential kernel).
 static tbc_status scratch_pass(tbc_batch* B, const std::vector<uint32_t>& grp, const std::vector<uint32_t>& lg,
                                bool beam, const std::vector<Hist>& hist_back, const std::vector<BeamHist>& bh_back,
+                               bool exact,
                                uint32_t width_override = 0) {
   hipStream_t s = B->stream;
   const uint32_t pass_width = width_override ? width_override : B->width;
@@ -464,6 +471,7 @@ static tbc_status scratch_pass(tbc_batch* B, const std::vector<uint32_t>& grp, c
     const uint32_t nw = (uint32_t)grp.size();
     if (beam) { BeamArgs ba = make_beam_args(B, big.p, bstack.p, nw); ba.pool = nullptr; ba.pool_words = 0;
       if (width_override) ba.width = width_override;
+      if (exact) ba.look = nullptr;
       if (wg) launch_beam_wg(ba, B->mask_words, nw, s); else launch_beam(ba, B->mask_words, search_blocks(nw), s); }
     else { SearchArgs ra = make_search_args(B, big.p, nw); launch_search(ra, B->mask_words, search_blocks(nw), s); }
     e = hipGetLastError();
@@ -569,7 +577,8 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results) {
     PackOpenArgs po{};
     po.hist = B->d_hist.p; po.bh = B->d_bh.p; po.f = B->d_f.p; po.a = B->d_a.p; po.b = B->d_b.p; po.process = B->d_proc.p;
     po.scratch = B->d_frames.p; po.off = B->d_off.p; po.ncr = B->d_ncr.p; po.occ = B->d_occ.p; po.lst = B->d_lst.p;
-    po.crashed = B->d_crashed.p; po.ret_slot = B->d_ret_slot.p; po.slot8 = B->d_slot8.p; po.n_hist = nh; po.mask_words = B->mask_words;
+    po.crashed = B->d_crashed.p; po.ret_slot = B->d_ret_slot.p; po.slot8 = B->d_slot8.p;
+    po.ret_op = B->d_ret_op.p; po.look = B->lookahead ? B->d_look.p : nullptr; po.tmp = B->d_looktmp.p; po.n_hist = nh; po.mask_words = B->mask_words;
     launch_pack_open(po, s);
     HIP_TRY(hipGetLastError());
   }
@@ -616,17 +625,27 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results) {
       }
     if (!fb.empty()) {
       // the sequential kernel reads Hist.status only; clear the wide-schedule flag for it
-      tbc_status st = scratch_pass(B, fb, lg, false, hist_back, bh_back);
+      tbc_status st = scratch_pass(B, fb, lg, false, hist_back, bh_back, false);
       if (st != TBC_OK) return st;
       touched_work = true;
     }
   }
   std::vector<uint32_t> width_of(nh, B->width);
+  // Lookahead never changes a verdict, but an invalid history's failing op and :configs are defined by
+  // the configs that get as far as they can: such a history is searched once more without it.
+  std::vector<uint8_t> exact(nh, 0);
   // overflow retries: 16x larger visited set each time, up to max_visited_bytes
   const uint64_t arena_budget = 32ull << 30;
   for (;;) {
     std::vector<uint32_t> pend_seq, lg_seq, pend_beam, lg_beam;
-    for (uint32_t h = 0; h < nh; h++)
+    for (uint32_t h = 0; h < nh; h++) {
+      if (B->lookahead && !is_seq[h] && !exact[h] && B->res_host[h].valid == TBC_INVALID) {
+        exact[h] = 1;
+        uint32_t lg = std::max(final_log2[h], B->res_host[h].tab_log2);
+        if (lg + 2 <= kBeamMaxTabLog2 && (1ull << (lg + 2)) * EW * 8 <= max_bytes) lg += 2;
+        pend_beam.push_back(h); lg_beam.push_back(lg);
+        continue;
+      }
       if (B->res_host[h].valid == TBC_UNKNOWN && B->res_host[h].cause == TBC_CAUSE_VISITED_FULL) {
         const uint64_t wpe = is_seq[h] ? KW : EW;
         uint32_t lg = final_log2[h] + 4;
@@ -636,6 +655,7 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results) {
           else { pend_beam.push_back(h); lg_beam.push_back(lg); }
         }
       }
+    }
     if (pend_seq.empty() && pend_beam.empty()) break;
     for (int pass = 0; pass < 2; pass++) {
       const std::vector<uint32_t>& pend = pass ? pend_beam : pend_seq;
@@ -647,11 +667,13 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results) {
         uint64_t bytes = 0;
         while (pos < pend.size()) {
           const uint64_t need = (1ull << lgs[pos]) * wpe * 8;
-          if (!grp.empty() && (bytes + need > arena_budget || (pass == 1 && width_of[pend[pos]] != width_of[grp[0]]))) break;
+          if (!grp.empty() && (bytes + need > arena_budget ||
+                               (pass == 1 && (width_of[pend[pos]] != width_of[grp[0]] || exact[pend[pos]] != exact[grp[0]])))) break;
           grp.push_back(pend[pos]); glg.push_back(lgs[pos]); final_log2[pend[pos]] = lgs[pos];
           bytes += need; pos++;
         }
-        tbc_status st = scratch_pass(B, grp, glg, pass == 1, hist_back, bh_back, pass == 1 ? width_of[grp[0]] : 0);
+        tbc_status st = scratch_pass(B, grp, glg, pass == 1, hist_back, bh_back, pass == 1 && exact[grp[0]],
+                                     pass == 1 ? width_of[grp[0]] : 0);
         if (st != TBC_OK) return st;
         touched_work = true;
       }

@@ -124,6 +124,24 @@ struct __attribute__((aligned(16))) OpRec {
 };
 static_assert(sizeof(OpRec) == 16, "OpRec must be 16 bytes");
 constexpr uint32_t kAtFront = 0x80000000u;
+
+// Lookahead records, one per completion rank t (register / cas-register, wide schedule): what the call
+// completing at t needs, what it produces, and who else could produce that value.  (1 + mask_words) u64:
+//   word 0: slot (16) | need (8) << 16 | prod (8) << 24 | dinv (8) << 32 | dprod (8) << 40
+//           need / prod: register values 0..31, kLookNone otherwise (then the rank constrains nothing here)
+//           dinv  = min(t - inv_rank(call), 255): the call is open at front F  <=>  dinv >= t - F
+//           dprod = min(t - inv_rank(x), 255) over the other calls x that produce `need` and are invoked
+//                   no later than completion t: one of them is invoked after front F  <=>  dprod < t - F
+//   words 1..: slots of the other calls open at front t (crashed ones included) that produce `need`
+constexpr uint32_t kLookahead = 8;          // completions looked at per new config
+constexpr uint32_t kLookNone = 0xFFu;
+constexpr uint32_t kLookPad = 16;           // records past the last rank (all kLookNone) per history
+__host__ __device__ inline uint64_t look_off(uint64_t op_off, uint64_t h, uint32_t mask_words) {
+  return (op_off + (uint64_t)kLookPad * h) * (1u + mask_words);
+}
+__host__ __device__ inline uint64_t look_words(uint64_t total_ops, uint64_t n_hist, uint32_t mask_words) {
+  return (total_ops + (uint64_t)kLookPad * (n_hist + 1)) * (1u + mask_words);
+}
 constexpr uint32_t kSlotMask = 0xFFFFu;     // (f_slot >> 8) & kSlotMask = process slot
 
 struct __attribute__((aligned(16))) BeamHist {
@@ -153,6 +171,9 @@ struct PackOpenArgs {
   OpRec* lst;
   OpRec* crashed;            // n_ops entries per history at op_off
   const uint32_t* ret_slot;  // pack_kernel: process slot of the call completing at each rank (at ret_off)
+  const uint32_t* ret_op;    // pack_kernel: the call completing at each rank (at ret_off)
+  uint64_t* look;            // lookahead records at look_off(), or null (lookahead off / other models)
+  uint32_t* tmp;             // n_ops words per history at op_off: scratch for the records
   uint8_t* slot8;            // the same as bytes (mask_words <= 4), at slot8_off(op_off, h): windowed prefetch
   uint32_t n_hist;
   uint32_t mask_words;
@@ -169,6 +190,7 @@ struct BeamArgs {
   const uint32_t* ncr;
   const OpRec* lst;
   const OpRec* crashed;
+  const uint64_t* look;      // lookahead records, null = lookahead off
   const uint8_t* slot8;
   const uint32_t* ret_slot;
   const uint32_t* ret_op;

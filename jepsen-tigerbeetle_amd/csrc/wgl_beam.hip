@@ -95,8 +95,8 @@ __device__ __forceinline__ uint32_t row_max_u32(uint32_t v) {
 
 // LDS words per wave: parents p_k0[16] p_M[16*MW] (u64), ring r_k0[kRing] r_M[kRing*MW] (u64),
 // p_slot p_off p_nlive p_cnt (u32 x16), r_pos r_idx r_off r_nlive r_cnt (u32 x kRing), p_start (17 -> 20),
-// search state (24, see SearchState)
-__host__ __device__ constexpr uint32_t beam_lds_words(uint32_t mw) { return (16 + kRing) * (2 + 2 * mw) + 16 * 4 + kRing * 5 + 20 + 24; }
+// search state (24, S_* words), this round's new configs for the lookahead c_M[64*MW] (u64) c_fi c_st (u32 x64)
+__host__ __device__ constexpr uint32_t beam_lds_words(uint32_t mw) { return (16 + kRing) * (2 + 2 * mw) + 16 * 4 + kRing * 5 + 20 + 24 + 64 * (2 + 2 * mw); }
 
 __device__ __forceinline__ uint32_t key_hash32(uint64_t k0, const uint64_t* M, int mw) {
   uint32_t h = (uint32_t)k0 * 0x9E3779B1u ^ (uint32_t)(k0 >> 32) * 0x85EBCA77u;
@@ -280,6 +280,10 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
   uint32_t* r_cnt = r_nlive + kRing;
   uint32_t* p_start = r_cnt + kRing;  // 17 entries: pair-number prefix, general mapping only
   state_ptr S = (state_ptr)(p_start + 20);   // parked search state (S_* words)
+  uint64_t* c_M = reinterpret_cast<uint64_t*>(p_start + 20 + S_WORDS);   // lookahead: the round's new configs
+  uint32_t* c_fi = reinterpret_cast<uint32_t*>(c_M + 64 * MW);
+  uint32_t* c_st = c_fi + 64;
+  const uint64_t* look = A.look ? A.look + look_off(op_off, hidx, MW) : nullptr;
   if (lane < kRing) r_pos[lane] = kNone;
 
   const uint64_t t0 = A.time_limit_ticks ? wall_clock64() : 0;
@@ -516,9 +520,66 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
         dupl &= ~grp;
       }
       if (is_new) st64(par + idx, (uint64_t)pslot | ((uint64_t)(op + 1u) << 32));
-      const uint64_t nb = __ballot(is_new);
+      const uint64_t nb0 = __ballot(is_new);
+      // ---- lookahead (register / cas-register): a new config is dead if the call completing at one of the
+      // next kLookahead ranks can never be linearized from it: not linearized yet, it needs a value that is
+      // neither the state nor produced by any call still to be linearized before that completion (calls
+      // invoked later, open calls not yet linearized, the calls completing in between).  Dead configs stay
+      // in the visited set but are not pushed.  8 lanes per config, one rank each: one trip, L1-resident.
+      bool dead = false;
+      if (look != nullptr && nb0) {
+        const uint32_t ci = (uint32_t)__popcll(nb0 & ((1ull << lr) - 1ull)), nn0 = (uint32_t)__popcll(nb0);
+        if (is_new) {
+          c_fi[ci] = fi2; c_st[ci] = (uint32_t)st2;
+#pragma unroll
+          for (int j = 0; j < MW; j++) c_M[ci * MW + j] = M2[j];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t cb = 0; cb < nn0; cb += 8u) {
+          const uint32_t c = cb + (lr >> 3), j = lr & 7u;
+          const bool val = c < nn0;
+          const uint32_t cF = val ? c_fi[c] : 0u;
+          const int32_t cs = val ? (int32_t)c_st[c] : 0;
+          uint64_t Mc[MW], pm[MW];
+#pragma unroll
+          for (int w = 0; w < MW; w++) { Mc[w] = val ? c_M[c * MW + w] : 0ull; pm[w] = 0ull; }
+          uint64_t w0 = (uint64_t)(kLookNone << 16 | kLookNone << 24);
+          if (val) {
+            const uint64_t* rec = look + (uint64_t)(cF + j) * (MW + 1);
+            w0 = rec[0];
+#pragma unroll
+            for (int w = 0; w < MW; w++) pm[w] = rec[1 + w];
+          }
+          const uint32_t slot = (uint32_t)w0 & 0xFFFFu, need = (uint32_t)(w0 >> 16) & 0xFFu, prod = (uint32_t)(w0 >> 24) & 0xFFu;
+          const uint32_t dinv = (uint32_t)(w0 >> 32) & 0xFFu, dprod = (uint32_t)(w0 >> 40) & 0xFFu;
+          bool bit = false, pmhit = false;
+#pragma unroll
+          for (int w = 0; w < MW; w++) {
+            if ((slot >> 6) == (uint32_t)w) bit = (Mc[w] >> (slot & 63u)) & 1ull;
+            pmhit = pmhit || (pm[w] & ~Mc[w]) != 0ull;
+          }
+          const bool linz = dinv >= j && bit;                       // open at the config's front and linearized
+          // values the calls completing at the ranks before this one can still provide (prefix-OR over the group)
+          uint32_t acc = (prod != kLookNone && !linz) ? 1u << prod : 0u;
+          uint32_t x = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)acc, 0x111, 0xf, 0xf, true);   // row_shr:1
+          if (j >= 1u) acc |= x;
+          x = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)acc, 0x112, 0xf, 0xf, true);            // row_shr:2
+          if (j >= 2u) acc |= x;
+          x = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)acc, 0x114, 0xf, 0xf, true);            // row_shr:4
+          if (j >= 4u) acc |= x;
+          uint32_t before = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)acc, 0x111, 0xf, 0xf, true);
+          if (j == 0u) before = 0u;
+          const bool ok = need == kLookNone || linz || (int32_t)need == cs || dprod < j || pmhit || ((before >> need) & 1u);
+          const uint64_t bad = __ballot(val && !ok);
+          if (is_new && ci >= cb && ci < cb + 8u) dead = ((bad >> (8u * (ci - cb))) & 0xFFull) != 0ull;
+        }
+      }
+      const bool keep = is_new && !dead;
+      const uint64_t nb = __ballot(keep);
       const uint32_t nn = (uint32_t)__popcll(nb);
-      if (is_new) {
+      if (is_new) lane_maxf = max(lane_maxf, fi2);
+      if (keep) {
         const uint32_t pos = sp + (uint32_t)__popcll(nb & ((1ull << lr) - 1ull));
         st32(stack + pos, idx);
         {                                           // mirror it in the LDS ring (nn <= 64 = kRing: no clash)
@@ -528,9 +589,8 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
           for (int j = 0; j < MW; j++) r_M[rs * MW + j] = M2[j];
           r_off[rs] = co0; r_nlive[rs] = co1 - co0; r_cnt[rs] = (co1 - co0) + cnc;
         }
-        lane_maxf = max(lane_maxf, fi2);
       }
-      sp += nn; visited += nn;
+      sp += nn; visited += (uint32_t)__popcll(nb0);
       SEG(4);
     }
     max_sp = max(max_sp, sp);

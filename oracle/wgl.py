@@ -143,8 +143,22 @@ class BeamStats(C.Structure):
                 ("expanded", C.c_uint64), ("max_stack", C.c_uint64), ("rounds", C.c_uint64)]
 
 
-def check_beam(ops, model, width=16, max_probes=0, want_witness=True, round_pairs=64, widen_after=0):
-    """The wide (K configs per iteration) schedule of the same search: wgl_beam.c."""
+def check_beam(ops, model, width=16, max_probes=0, want_witness=True, round_pairs=64, widen_after=0, lookahead=None):
+    """The wide (K configs per iteration) schedule of the same search: wgl_beam.c.
+
+    lookahead: None = what the library does by default (on for register / cas-register under the
+    single-wavefront wide schedule, i.e. round_pairs == 64); an INVALID verdict found with it is
+    searched again without it, as tbc_batch_run does, so the failing op and the configs are exact."""
+    if lookahead is None:
+        lookahead = round_pairs == 64 and model["kind"] in (0, 1)
+    if lookahead:
+        out = _check_beam(ops, model, width, max_probes, want_witness, round_pairs, widen_after, True)
+        if out["valid"] != 0:
+            return out
+    return _check_beam(ops, model, width, max_probes, want_witness, round_pairs, widen_after, False)
+
+
+def _check_beam(ops, model, width, max_probes, want_witness, round_pairs, widen_after, lookahead):
     n = len(ops["f"])
     f = np.ascontiguousarray(ops["f"], np.uint8)
     a = np.ascontiguousarray(ops["a"], np.int32)
@@ -156,6 +170,7 @@ def check_beam(ops, model, width=16, max_probes=0, want_witness=True, round_pair
     res, st = OracleResult(), BeamStats()
     wit = np.zeros(max(n, 1), np.uint32)
     lib().wgl_beam_set_widen_after(C.c_uint32(widen_after))
+    lib().wgl_beam_set_lookahead(C.c_uint32(1 if lookahead else 0))
     rc = lib().wgl_beam_check_rp(C.c_uint32(n), _p(f, C.c_uint8), _p(a, C.c_int32), _p(b, C.c_int32),
                                  _p(proc, C.c_int32), C.c_uint32(int(ops["n_process"])), _p(inv, C.c_uint32),
                                  _p(ret, C.c_uint32), C.byref(m), C.c_uint32(width), C.c_uint32(round_pairs),

@@ -141,7 +141,7 @@ uint32_t wgl_beam_trace_len(void) { return g_trace_n; }
 /* stagnation escape (see the schedule text above): stall_rounds = 0 disables it */
 static uint32_t g_stall_rounds = 0, g_stall_width = 64, g_stall_mode = 0;
 void wgl_beam_set_stall(uint32_t rounds, uint32_t width, uint32_t mode) { g_stall_rounds = rounds; g_stall_width = width; g_stall_mode = mode; }
-/* lookahead pruning experiment: drop a child whose front call can never be linearized */
+/* lookahead (tbc_opts.lookahead; rule stated where it is applied): 0 = off */
 static uint32_t g_lookahead = 0; static uint64_t g_pruned = 0;
 void wgl_beam_set_lookahead(uint32_t on) { g_lookahead = on; }
 uint64_t wgl_beam_pruned(void) { return g_pruned; }
@@ -309,29 +309,6 @@ int wgl_beam_check_rp(uint32_t n, const uint8_t* f, const int32_t* a, const int3
           }
         }
         c2[0] = (uint64_t)(fi2 + 1) | ((uint64_t)(uint32_t)s2 << 32);
-        if (g_lookahead && !cfgm && fi2 < R && (model->kind == O_REGISTER || model->kind == O_CAS_REGISTER)) {
-          int dead = 0;
-          for (uint32_t j = 0; j < g_lookahead && fi2 + j < R && !dead; j++) {
-            uint32_t fop = ret_op[fi2 + j], pf = (uint32_t)process[fop];
-            if (c2[1 + (pf >> 6)] >> (pf & 63) & 1) continue;            /* already linearized */
-            int need = (f[fop] == O_READ && a[fop] != O_NIL) || f[fop] == O_CAS;
-            if (!need || a[fop] == s2) continue;
-            int32_t v = a[fop]; int ok = 0;
-            for (uint32_t jj = 0; jj <= j && !ok; jj++) {                /* producers: calls open somewhere in [fi2, fi2+j] */
-              uint32_t F2 = fi2 + jj;
-              uint32_t nl = off[F2 + 1] - off[F2], tot = nl + (jj == j ? ncr[F2] : 0);
-              for (uint32_t cc = 0; cc < tot && !ok; cc++) {
-                uint32_t x = cc < nl ? lst[off[F2] + cc] : crashed[cc - nl];
-                uint32_t px = (uint32_t)process[x];
-                if (x == fop) continue;
-                if (inv_rank[x] <= fi2 && (c2[1 + (px >> 6)] >> (px & 63) & 1)) continue;   /* open now and linearized */
-                if ((f[x] == O_WRITE && a[x] == v) || (f[x] == O_CAS && b[x] == v)) ok = 1;
-              }
-            }
-            if (!ok) dead = 1;
-          }
-          if (dead) { g_pruned++; if (fi2 > maxf) maxf = fi2; continue; }
-        }
         cviable[l] = 1; cfront[l] = fi2; cstate[l] = s2;
         if (fi2 == R && success < 0) success = (int)l;
       }
@@ -345,6 +322,38 @@ int wgl_beam_check_rp(uint32_t n, const uint8_t* f, const int32_t* a, const int3
         if (!id) continue;
         st->visited++;
         if (cfront[l] > maxf) maxf = cfront[l];
+        if (g_lookahead && !cfgm && (model->kind == O_REGISTER || model->kind == O_CAS_REGISTER)) {
+          /* lookahead: the new config is dead if the call completing at one of the next 8 ranks can never
+           * be linearized from it -- it is not linearized yet and needs a register value (0..31) that is
+           * neither the state nor produced (:write v / :cas [_ v]) by any OTHER call that can still be
+           * linearized before that completion: a call invoked after this front and before the completion,
+           * or a call open at this front (crashed ones included) and not linearized.  Dead configs stay
+           * in the visited set but are not pushed. */
+          const uint64_t* c2 = ck + (size_t)l * KW;
+          const uint32_t F = cfront[l]; const int32_t s2 = cstate[l];
+          int dead = 0;
+          for (uint32_t j = 0; j < 8 && F + j < R && !dead; j++) {
+            const uint32_t t = F + j, fop = ret_op[t], pf = (uint32_t)process[fop];
+            if (!((f[fop] == O_READ && a[fop] != O_NIL) || f[fop] == O_CAS)) continue;
+            const int32_t v = a[fop];
+            if (v < 0 || v >= 32) continue;
+            if (inv_rank[fop] <= F && (c2[1 + (pf >> 6)] >> (pf & 63) & 1)) continue;   /* already linearized */
+            if (v == s2) continue;
+            int ok = 0;
+            for (uint32_t F2 = F; F2 <= t && !ok; F2++) {                /* calls open somewhere in [F, t] */
+              const uint32_t nl = off[F2 + 1] - off[F2], tot = nl + (F2 == t ? ncr[F2] : 0);
+              for (uint32_t cc = 0; cc < tot && !ok; cc++) {
+                const uint32_t x = cc < nl ? lst[off[F2] + cc] : crashed[cc - nl];
+                const uint32_t px = (uint32_t)process[x];
+                if (x == fop) continue;
+                if (inv_rank[x] <= F && (c2[1 + (px >> 6)] >> (px & 63) & 1)) continue;   /* open at F, linearized */
+                if ((f[x] == O_WRITE && a[x] == v) || (f[x] == O_CAS && b[x] == v)) ok = 1;
+              }
+            }
+            if (!ok) dead = 1;
+          }
+          if (dead) { g_pruned++; continue; }
+        }
         if (sp == scap) { scap *= 2; stack = (uint32_t*)realloc(stack, scap * 4); }
         stack[sp++] = id;
       }

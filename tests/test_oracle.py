@@ -97,3 +97,30 @@ def test_committed_golden_fixtures_still_hold(native, oracle):
             assert r["fail_op"] == g["fail_op"]
         w = oracle.check_beam(ops.as_dict(), m, 8)
         assert (w["probes"], w["visited"]) == (g["wide8"]["probes"], g["wide8"]["visited"])
+
+
+def test_lookahead_never_changes_a_verdict(oracle):
+    """tbc_opts.lookahead drops configs from which one of the next 8 completions can never be
+    linearized: the verdict must be the one of the plain search (and of the sequential oracle) on
+    valid and invalid histories alike, and it must save work."""
+    from jepsen_tigerbeetle_amd import columns, synth
+    m = {"kind": 1, "init": N.NIL}
+    saved = 0
+    for (n, p, busy, info, corrupt) in [(40, 4, 0.5, 0.05, 0.0), (60, 8, 0.8, 0.2, 0.0), (60, 6, 0.6, 0.1, 0.3),
+                                        (300, 16, 0.3, 0.05, 0.0), (300, 8, 0.4, 0.02, 0.2), (1000, 32, 0.15, 0.02, 0.0)]:
+        for s in range(12 if n <= 300 else 4):
+            d = columns.pair_events(synth.register_events(n_ops=n, n_procs=p, seed=500 + s, busy=busy, info=info, corrupt=corrupt)).as_dict()
+            seq = oracle.check(d, m, "window", max_steps=3_000_000, want_witness=False)
+            for K in (2, 16):
+                a = oracle.check_beam(d, m, K, max_probes=3_000_000, want_witness=False, lookahead=True)
+                b = oracle.check_beam(d, m, K, max_probes=3_000_000, want_witness=False, lookahead=False)
+                if -1 in (a["valid"], b["valid"]):
+                    continue
+                assert a["valid"] == b["valid"], (n, p, s, K)
+                if seq["valid"] != -1:
+                    assert a["valid"] == seq["valid"], (n, p, s, K)
+                if a["valid"] == 0:
+                    assert a["fail_op"] == b["fail_op"] == seq["fail_op"]
+                else:
+                    saved += b["probes"] - a["probes"]
+    assert saved > 0
