@@ -38,7 +38,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("TBC_BENCH_BATCH", "16384")),
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("TBC_BENCH_BATCH", "32768")),
                     help="histories per GPU per step")
     ap.add_argument("--ops", type=int, default=10000)
     ap.add_argument("--procs", type=int, default=64)
@@ -47,7 +47,7 @@ def main():
     ap.add_argument("--info", type=float, default=0.0, help="crashed-op (:info) rate")
     ap.add_argument("--width", type=int, default=int(os.environ.get("TBC_BENCH_WIDTH", "4")),
                     help="configs expanded per iteration: 1 = sequential knossos.wgl order, 2..16 = wide schedule")
-    ap.add_argument("--visited-per-op", type=int, default=32, help="first visited-set capacity per op (0 = library default 64)")
+    ap.add_argument("--visited-per-op", type=int, default=16, help="first visited-set capacity per op (0 = library default 64)")
     ap.add_argument("--round-budget", type=int, default=0,
                     help="a history that has used more rounds than this continues at width 16 (0 = off)")
     ap.add_argument("--cpu-sample", type=int, default=256, help="histories timed on the CPU oracle (rank 0, N=1)")
@@ -178,12 +178,23 @@ def main():
             tb = time.perf_counter()
             rbo = wgl.check(bad.as_dict(), om, "window", want_witness=False)
             tb = time.perf_counter() - tb
+            # the SAME schedule the kernel runs (wide, K configs per iteration, lookahead), on one host thread:
+            # how much of the speed-up is the algorithm and how much the GPU
+            S2 = min(64, S)
+            tw = time.perf_counter()
+            okw = 0
+            for i in range(S2):
+                okw += wgl.check_beam(hists[i].as_dict(), om, args.width if args.width > 1 else 4, want_witness=False)["valid"] == 1
+            tw = time.perf_counter() - tw
             line["cpu_baseline"] = {"value": round(S / tc, 3), "unit": "histories/s", "cores": 1, "kind": "port",
                                     "sample": f"first {S} histories of this batch, oracle/wgl_window.c (C, gcc -O2), 1 thread; "
                                               f"not stock Knossos (no JVM here)",
                                     "ms_per_history": round(tc / S * 1e3, 3),
                                     "invalid_example_ms": round(tb * 1e3, 3), "invalid_example_verdict": rbo["valid"],
+                                    "same_schedule_as_kernel": {"value": round(S2 / tw, 3), "unit": "histories/s", "cores": 1,
+                                                                "sample": f"first {S2} histories, oracle/wgl_beam.c with lookahead"},
                                     "host_cores_available": os.cpu_count()}
+            assert okw == sum(int(v == N.VALID) for v in verdicts[:S2]), "GPU and wide oracle disagree on the sample"
             assert ok == sum(int(v == N.VALID) for v in verdicts[:S]), "GPU and oracle disagree on the sample"
         print(json.dumps(line), flush=True)
     batch.close()

@@ -195,7 +195,7 @@ typedef struct tbc_opts {
                              /* published algorithm's); 2..16 = the wide schedule */
                              /* (same verdict / failing op, one (config, call)    */
                              /* pair per lane).  0 = default: 1 for TBC_ALG_WGL,  */
-                             /* 16 for TBC_ALG_LINEAR / TBC_ALG_COMPETITION       */
+                             /* 4 for TBC_ALG_LINEAR / TBC_ALG_COMPETITION        */
   uint32_t round_budget;     /* wide schedule, 0 = off: a history that has used     */
                              /* more rounds than this continues at search_width 16  */
                              /* (a batch's stragglers then need far fewer dependent */

@@ -231,7 +231,7 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
   B->mask_words = mw <= 1 ? 1 : mw <= 2 ? 2 : mw <= 4 ? 4 : mw <= 8 ? 8 : 16;
   B->frame_words = search_frame_words(B->mask_words);
   const uint32_t KW = 1 + B->mask_words;
-  uint32_t width = opts->search_width ? opts->search_width : (opts->algorithm == TBC_ALG_WGL ? 1u : 16u);
+  uint32_t width = opts->search_width ? opts->search_width : (opts->algorithm == TBC_ALG_WGL ? 1u : 4u);   // 4: fewest rounds per history, measured
   if (width > 64) width = 64;
   while (width & (width - 1)) width &= width - 1;   // the wide kernels take a power of two
   if (B->mask_words > 4) width = 1;          // very wide windows: sequential kernel only

@@ -712,40 +712,48 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
 }
 
 // Register budget (MW = 1, state-carrying models): 67 VGPRs on its own, 64 under the min-blocks bound (two
-// spilled values) -> 8 wavefronts per SIMD; measured 350 -> 291 ms on the 8192-history probe against 7
+// spilled values) -> 8 wavefronts per SIMD (__launch_bounds__' second argument is wavefronts per SIMD); measured 350 -> 291 ms on the 8192-history probe against 7
 // (profiles/r01_vgpr_ab.txt has the whole history: 116 with segment profiling compiled in, 94 without, 107
 // with the bucket probe until the search state was parked in LDS around the growth path).  The commutative
 // models' kernels need ~90 and are left to the register allocator.
-#ifndef TBC_BEAM_MIN_BLOCKS
-#define TBC_BEAM_MIN_BLOCKS 8
+#ifndef TBC_BEAM_MIN_WAVES
+#define TBC_BEAM_MIN_WAVES 8
 #endif
+// Wavefronts per workgroup.  A workgroup's slots are handed back only when its last wavefront ends and
+// histories differ 5x in how long they take, so fewer is better for the tail of a batch -- but one-wavefront
+// workgroups measured slower (profiles/r01_vgpr_ab.txt), so this is a build-time knob with its A/B on file.
+#ifndef TBC_BEAM_WAVES
+#define TBC_BEAM_WAVES 4
+#endif
+constexpr uint32_t kBeamWaves = TBC_BEAM_WAVES;
 template <int MW, bool COMM>
-__global__ __launch_bounds__(kBlock, COMM ? 1 : TBC_BEAM_MIN_BLOCKS) void wgl_beam_kernel(BeamArgs A) {
+__global__ __launch_bounds__(64 * kBeamWaves, COMM ? 1 : TBC_BEAM_MIN_WAVES) void wgl_beam_kernel(BeamArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   const uint32_t lane = threadIdx.x & 63u, wv = rfl(threadIdx.x >> 6);
-  const uint32_t w = blockIdx.x * kWavesPerBlock + wv;
+  const uint32_t w = blockIdx.x * kBeamWaves + wv;
   if (w < A.n_work) beam_one<MW, COMM>(A, rfl(A.work[w]), lds + wv * beam_lds_words(MW), lane);
 }
 
 template <int MW>
-void launch_beam_mw(const BeamArgs& a, uint32_t n_blocks, hipStream_t s) {
-  const size_t lds = (size_t)kWavesPerBlock * beam_lds_words(MW) * 4;
+void launch_beam_mw(const BeamArgs& a, hipStream_t s) {
+  const size_t lds = (size_t)kBeamWaves * beam_lds_words(MW) * 4;
+  const uint32_t n_blocks = (a.n_work + kBeamWaves - 1) / kBeamWaves;
   // the commutative (set / bank) models get their own instantiation: their evaluation code would
   // otherwise double the register budget of the register-family kernel
   if (a.model_kind == TBC_MODEL_SET || a.model_kind == TBC_MODEL_BANK)
-    hipLaunchKernelGGL((wgl_beam_kernel<MW, true>), dim3(n_blocks), dim3(kBlock), lds, s, a);
+    hipLaunchKernelGGL((wgl_beam_kernel<MW, true>), dim3(n_blocks), dim3(64 * kBeamWaves), lds, s, a);
   else
-    hipLaunchKernelGGL((wgl_beam_kernel<MW, false>), dim3(n_blocks), dim3(kBlock), lds, s, a);
+    hipLaunchKernelGGL((wgl_beam_kernel<MW, false>), dim3(n_blocks), dim3(64 * kBeamWaves), lds, s, a);
 }
 
 }  // namespace
 
-bool launch_beam(const BeamArgs& a, uint32_t mask_words, uint32_t n_blocks, void* stream) {
+bool launch_beam(const BeamArgs& a, uint32_t mask_words, uint32_t /*n_blocks: derived from n_work*/, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   switch (mask_words) {
-    case 1: launch_beam_mw<1>(a, n_blocks, s); return true;
-    case 2: launch_beam_mw<2>(a, n_blocks, s); return true;
-    case 4: launch_beam_mw<4>(a, n_blocks, s); return true;
+    case 1: launch_beam_mw<1>(a, s); return true;
+    case 2: launch_beam_mw<2>(a, s); return true;
+    case 4: launch_beam_mw<4>(a, s); return true;
     default: return false;
   }
 }

@@ -241,7 +241,7 @@ int wgl_beam_check_rp(uint32_t n, const uint8_t* f, const int32_t* a, const int3
   uint64_t last_progress = 0; uint32_t seen_maxf = 0, stall_w = g_stall_width;
   while (verdict == -2) {
     if (sp == 0) { verdict = 0; break; }
-    if (g_stall_rounds) {
+    if (g_stall_rounds && g_stall_mode < 2) {
       if (maxf > seen_maxf) { seen_maxf = maxf; last_progress = st->rounds; stall_w = g_stall_width; }
       else if (st->rounds - last_progress > g_stall_rounds) {
         /* stuck below one completion: bring older pending configs to the top */
@@ -257,7 +257,11 @@ int wgl_beam_check_rp(uint32_t n, const uint8_t* f, const int32_t* a, const int3
         if (stall_w < (1u << 20)) stall_w *= 2;
       }
     }
-    const uint32_t Kc = (g_widen_after && st->rounds > g_widen_after && K < 16) ? 16 : K;
+    if (maxf > seen_maxf) { seen_maxf = maxf; last_progress = st->rounds; }
+    /* stall widening (tbc_opts.stall_rounds): while the greatest front has not moved for that many rounds the
+     * search is exhausting a dead region -- take stall_width configs per iteration until it moves again */
+    const uint32_t Ks = (g_stall_rounds && g_stall_mode == 2 && st->rounds - last_progress > g_stall_rounds && K < g_stall_width) ? g_stall_width : K;
+    const uint32_t Kc = (g_widen_after && st->rounds > g_widen_after && Ks < 16) ? 16 : Ks;
     uint32_t np = sp < Kc ? (uint32_t)sp : Kc;
     for (uint32_t q = 0; q < np; q++) par[q] = stack[sp - np + q];      /* q = 0 is the bottom-most popped */
     sp -= np;
