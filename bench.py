@@ -125,8 +125,8 @@ def main():
         try:   # HBM bytes per launch from the committed rocprofv3 PMC passes, when they cover this very config
             with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as fh:
                 for e in json.load(fh)["entries"]:
-                    if (e["histories_per_gpu"], e["search_width"], e["visited_per_op"], e["ops"], e["procs"], e["busy"], e["info"]) == \
-                       (B, args.width, args.visited_per_op, args.ops, args.procs, args.busy, args.info):
+                    key = (e["histories_per_gpu"], e["search_width"], e["visited_per_op"], e["ops"], e["procs"], e["busy"], e["info"])
+                    if not e.get("retired") and key == (B, args.width, args.visited_per_op, args.ops, args.procs, args.busy, args.info):
                         traffic = e["traffic_bytes"]
         except (OSError, KeyError, ValueError):
             pass
