@@ -142,7 +142,8 @@ uint32_t wgl_beam_trace_len(void) { return g_trace_n; }
 static uint32_t g_stall_rounds = 0, g_stall_width = 64, g_stall_mode = 0;
 void wgl_beam_set_stall(uint32_t rounds, uint32_t width, uint32_t mode) { g_stall_rounds = rounds; g_stall_width = width; g_stall_mode = mode; }
 /* lookahead (tbc_opts.lookahead; rule stated where it is applied): 0 = off */
-static uint32_t g_lookahead = 0; static uint64_t g_pruned = 0;
+static uint32_t g_lookahead = 0, g_lookahead_depth = 8; static uint64_t g_pruned = 0;
+void wgl_beam_set_lookahead_depth(uint32_t d) { g_lookahead_depth = d; }   /* experiments; the kernel's is 8 */
 void wgl_beam_set_lookahead(uint32_t on) { g_lookahead = on; }
 uint64_t wgl_beam_pruned(void) { return g_pruned; }
 static uint32_t g_list_order = 0;
@@ -336,7 +337,7 @@ int wgl_beam_check_rp(uint32_t n, const uint8_t* f, const int32_t* a, const int3
           const uint64_t* c2 = ck + (size_t)l * KW;
           const uint32_t F = cfront[l]; const int32_t s2 = cstate[l];
           int dead = 0;
-          for (uint32_t j = 0; j < 8 && F + j < R && !dead; j++) {
+          for (uint32_t j = 0; j < g_lookahead_depth && F + j < R && !dead; j++) {
             const uint32_t t = F + j, fop = ret_op[t], pf = (uint32_t)process[fop];
             if (!((f[fop] == O_READ && a[fop] != O_NIL) || f[fop] == O_CAS)) continue;
             const int32_t v = a[fop];

@@ -328,3 +328,34 @@ def test_against_committed_golden_fixtures(native):
                 assert got["fail_op"] == g["fail_op"]
             assert got["visited"] == g[key]["visited"]
             assert got["probes"] == (g[key]["steps"] if key == "sequential" else g[key]["probes"])
+
+
+@pytest.mark.gpu
+def test_lookahead_value_range_crashed_writers_and_plain_register(native, oracle):
+    """Lookahead corner cases, kernel records (pack_open.hip) against the oracle's definition: register
+    values outside 0..31 (those ranks constrain nothing), many crashed calls (crashed writers stay
+    producers for ever; the mask grows past one word), a plain register, and heavy concurrency."""
+    cases = [dict(n_ops=1500, n_procs=16, n_values=40, busy=0.3, info=0.0),
+             dict(n_ops=1500, n_procs=16, n_values=40, busy=0.3, info=0.02, corrupt=0.3),
+             dict(n_ops=600, n_procs=24, n_values=3, busy=0.3, info=0.08),
+             dict(n_ops=400, n_procs=16, n_values=3, busy=0.3, info=0.04, corrupt=0.4),
+             dict(n_ops=2000, n_procs=64, n_values=2, busy=0.15, info=0.01),
+             dict(n_ops=800, n_procs=8, n_values=5, busy=0.5, read=0.5, write=0.5)]          # plain register
+    for ci, c in enumerate(cases):
+        model_kind = N.MODEL_REGISTER if c.get("read", 0) + c.get("write", 0) == 1 else N.MODEL_CAS_REGISTER
+        om = {"kind": 0 if model_kind == N.MODEL_REGISTER else 1, "init": N.NIL}
+        hists = [columns.pair_events(synth.register_events(seed=40 + s, **c)) for s in range(4)]
+        for width in (4, 16):
+            with core.Batch(hists, core.make_model(model_kind, N.NIL),
+                            core.make_opts(time_limit_ms=60000, search_width=width, algorithm=N.ALG_COMPETITION)) as b:
+                res = b.run().results()
+            for i, (h, got) in enumerate(zip(hists, res)):
+                exp = oracle.check_beam(h.as_dict(), om, width, max_probes=20_000_000)
+                if exp["valid"] == -1:
+                    continue
+                assert got["valid"] == exp["valid"], (ci, width, i)
+                assert (got["probes"], got["visited"], got["backtracks"]) == (exp["probes"], exp["visited"], exp["expanded"]), (ci, width, i)
+                if exp["valid"] == 1:
+                    assert np.array_equal(got["witness"], exp["witness"]), (ci, width, i)
+                else:
+                    assert got["fail_op"] == exp["fail_op"], (ci, width, i)
