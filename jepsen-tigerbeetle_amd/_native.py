@@ -14,6 +14,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
+# TBC_LIB_PATH: load another build of the SAME library (A/B runs of kernel variants on the GPU box)
 LIB_PATH = os.environ.get("TBC_LIB_PATH") or os.path.join(CSRC, "libtbcheck.so")
 
 NIL = -(2 ** 31)

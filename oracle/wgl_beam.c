@@ -33,7 +33,8 @@
  *         inserted);
  *       - otherwise, in ascending r, each viable pair probes the visited set;
  *         a child that is new is inserted (remembering parent and op) and
- *         pushed.
+ *         pushed -- unless the lookahead (below, register / cas-register only,
+ *         tbc_opts.lookahead) finds it dead: then it is inserted but not pushed.
  *   empty stack  =>  INVALID; the failing op is the completion of the greatest
  *   front ever inserted (the first completion whose prefix cannot be
  *   linearized), as in wgl_ref.c.
@@ -127,27 +128,32 @@ int wgl_beam_check_rp(uint32_t n, const uint8_t* f, const int32_t* a, const int3
                       const oracle_model* model, uint32_t K, uint32_t round_pairs, uint64_t max_probes,
                       uint32_t* witness, oracle_result* out, beam_stats* st);
 
-/* widen_after: 0 = never; otherwise a history that has used more than this many rounds continues
- * with K = 16 (tbc_opts.round_budget): the stragglers of a batch need far fewer dependent rounds */
+/* ---- options that are part of the specified schedule (the kernel has the same ones) ------------------
+ * widen_after: 0 = never; otherwise a history that has used more than this many rounds continues
+ *   with K = 16 (tbc_opts.round_budget).
+ * lookahead:   tbc_opts.lookahead; the rule is stated where it is applied.  0 = off. */
 static uint32_t g_widen_after = 0;
 void wgl_beam_set_widen_after(uint32_t r) { g_widen_after = r; }
-/* list_order: how each front's live open calls are ordered (the FIRST one is tried first by the
- * depth-first search): 0 = by process slot, 1 = by completion (the front's own call first),
- * 2 = by invocation, 3 = by completion, latest first.  Both sides of a parity test use the same one. */
-/* progress trace (experiments only): maxf and stack depth sampled every 256 rounds */
+static uint32_t g_lookahead = 0, g_lookahead_depth = 8; static uint64_t g_pruned = 0;
+void wgl_beam_set_lookahead(uint32_t on) { g_lookahead = on; }
+uint64_t wgl_beam_pruned(void) { return g_pruned; }
+
+/* ---- experiment knobs (all off by default; NOT part of the specified schedule, no kernel counterpart).
+ * They produced the negative results recorded in DESIGN.md section 6 (the tail of a batch):
+ * list_order:  order of each front's live open calls (the FIRST is tried first): 0 = by process slot
+ *              (the specified one), 1 = by completion, 2 = by invocation, 3 = by completion, latest first.
+ * stall:       when the greatest front has not moved for `rounds` rounds: mode 0 reverse / mode 1 rotate the
+ *              top `width` stack entries (doubling), mode 2 take `width` configs per iteration while stalled.
+ * lookahead_depth: completions looked at (the kernel's is 8).
+ * trace:       greatest front and stack depth sampled every 256 rounds. */
+void wgl_beam_set_lookahead_depth(uint32_t d) { g_lookahead_depth = d; }
+static uint32_t g_list_order = 0;
+void wgl_beam_set_list_order(uint32_t o) { g_list_order = o; }
+static uint32_t g_stall_rounds = 0, g_stall_width = 64, g_stall_mode = 0;
+void wgl_beam_set_stall(uint32_t rounds, uint32_t width, uint32_t mode) { g_stall_rounds = rounds; g_stall_width = width; g_stall_mode = mode; }
 static uint32_t* g_trace = NULL; static uint32_t g_trace_cap = 0, g_trace_n = 0;
 void wgl_beam_set_trace(uint32_t* buf, uint32_t cap) { g_trace = buf; g_trace_cap = cap; g_trace_n = 0; }
 uint32_t wgl_beam_trace_len(void) { return g_trace_n; }
-/* stagnation escape (see the schedule text above): stall_rounds = 0 disables it */
-static uint32_t g_stall_rounds = 0, g_stall_width = 64, g_stall_mode = 0;
-void wgl_beam_set_stall(uint32_t rounds, uint32_t width, uint32_t mode) { g_stall_rounds = rounds; g_stall_width = width; g_stall_mode = mode; }
-/* lookahead (tbc_opts.lookahead; rule stated where it is applied): 0 = off */
-static uint32_t g_lookahead = 0, g_lookahead_depth = 8; static uint64_t g_pruned = 0;
-void wgl_beam_set_lookahead_depth(uint32_t d) { g_lookahead_depth = d; }   /* experiments; the kernel's is 8 */
-void wgl_beam_set_lookahead(uint32_t on) { g_lookahead = on; }
-uint64_t wgl_beam_pruned(void) { return g_pruned; }
-static uint32_t g_list_order = 0;
-void wgl_beam_set_list_order(uint32_t o) { g_list_order = o; }
 
 int wgl_beam_check(uint32_t n, const uint8_t* f, const int32_t* a, const int32_t* b,
                    const int32_t* process, uint32_t n_process,
