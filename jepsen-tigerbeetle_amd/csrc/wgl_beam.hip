@@ -75,10 +75,9 @@ __device__ __forceinline__ uint64_t cas64_from_zero(gu64* p, uint64_t desired) {
 
 constexpr uint32_t kRing = 64;     // most recent pushes mirrored in LDS
 
-// The lane number, opaque to the optimiser.  Everything an iteration derives from it (LDS addresses,
-// lane masks, shuffle indices: ~25 VGPRs) is then recomputed per iteration -- a few VALU ops against
-// thousands of cycles of memory latency -- instead of being hoisted out of the search loop and kept
-// alive across it, where it adds to the register peak of the cold growth path: 110 -> see below.
+// The lane number, opaque to the optimiser.  What an iteration derives from it (LDS addresses, lane
+// masks, shuffle indices) is then recomputed per iteration instead of being hoisted out of the search
+// loop and kept alive across all of it: a few VALU ops per iteration for a handful of VGPRs.
 __device__ __forceinline__ uint32_t opaque_lane(uint32_t lane) {
   asm volatile("" : "+v"(lane));
   return lane;
