@@ -201,11 +201,11 @@ typedef struct tbc_opts {
                              /* (a batch's stragglers then need far fewer dependent */
                              /* rounds; the schedule stays deterministic)           */
   uint32_t lookahead;        /* wide schedule, register / cas-register: a new config  */
-                             /* is dropped when one of the next 8 completions can     */
+                             /* is SET ASIDE when one of the next 8 completions can   */
                              /* never be linearized from it (its call needs a value   */
                              /* that neither the state nor any call still to be       */
-                             /* linearized provides).  Never changes a verdict; an    */
-                             /* invalid history is searched again without it so the   */
+                             /* linearized provides); set-aside configs are expanded  */
+                             /* only if the search would otherwise end invalid, so the*/
                              /* failing op and :configs stay exact.  0 = on, 1 = off  */
   uint32_t reserved;         /* must be 0                                             */
 } tbc_opts;

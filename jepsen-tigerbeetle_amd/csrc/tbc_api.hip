@@ -149,6 +149,7 @@ struct tbc_batch {
   DevBuf<uint8_t> d_slot8;          // completion slots as bytes
   bool lookahead = false;           // wide single-wave schedule, register family, tbc_opts.lookahead != 1
   DevBuf<uint64_t> d_look;          // lookahead records per completion rank
+  DevBuf<uint32_t> d_dstack;        // second stack per history: configs the lookahead set aside
   DevBuf<uint32_t> d_looktmp;
   DevBuf<uint64_t> d_occ, d_btab, d_pool;
   DevBuf<unsigned long long> d_pool_cursor;
@@ -165,7 +166,7 @@ struct tbc_batch {
     d_bitmap.release(); d_wpre.release(); d_frames.release(); d_witness.release(); d_work.release();
     d_queue.release(); d_tab.release(); d_results.release(); d_table.release(); d_pool_vals.release(); d_cfg.release();
     d_bh.release(); d_off.release(); d_ncr.release(); d_lst.release(); d_crashed.release(); d_stack.release();
-    d_occ.release(); d_btab.release(); d_slot8.release(); d_look.release(); d_looktmp.release(); d_pool.release(); d_pool_cursor.release();
+    d_occ.release(); d_btab.release(); d_slot8.release(); d_look.release(); d_looktmp.release(); d_dstack.release(); d_pool.release(); d_pool_cursor.release();
     for (auto& e : ev) if (e) (void)hipEventDestroy(e);
     if (stream) (void)hipStreamDestroy(stream);
   }
@@ -305,12 +306,13 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
         (s = B->d_slot8.alloc(slot8_bytes(T, nh))) || (s = B->d_stack.alloc(bstack_n)) || (s = B->d_btab.alloc(btab_n * EW)) ||
         (s = B->d_pool_cursor.alloc(1)))
       return s;
-    if (B->lookahead && ((s = B->d_look.alloc(look_words(T, nh, B->mask_words))) || (s = B->d_looktmp.alloc(T)))) return s;
+    if (B->lookahead && ((s = B->d_look.alloc(look_words(T, nh, B->mask_words))) || (s = B->d_looktmp.alloc(T)) ||
+                         (s = B->d_dstack.alloc(bstack_n)))) return s;
     // growth pool: a quarter of the visited-set arena, at least room for one history to grow twice, at most 32 GiB
     {
       uint64_t biggest = 0;
       for (uint32_t h = 0; h < nh; h++) biggest = std::max<uint64_t>(biggest, 1ull << B->bh[h].tab_log2);
-      uint64_t words = std::max<uint64_t>(btab_n * EW / 4, biggest * (4 + 16) * (EW + 1));
+      uint64_t words = std::max<uint64_t>(btab_n * EW * 3 / 10, biggest * (4 + 16) * (EW + 1));
       words = std::min<uint64_t>(words, (32ull << 30) / 8);
       if ((s = B->d_pool.alloc(words))) return s;
     }
@@ -331,7 +333,7 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
                     B->d_ret_op.bytes() + B->d_bitmap.bytes() + B->d_wpre.bytes() + B->d_frames.bytes() +
                     B->d_tab.bytes() + B->d_results.bytes() + B->d_work.bytes() + B->d_witness.bytes();
   if (beam) B->device_bytes += B->d_bh.bytes() + B->d_off.bytes() + B->d_ncr.bytes() + B->d_occ.bytes() + B->d_lst.bytes() +
-                               B->d_crashed.bytes() + B->d_slot8.bytes() + B->d_look.bytes() + B->d_looktmp.bytes() + B->d_stack.bytes() + B->d_btab.bytes() + B->d_pool.bytes();
+                               B->d_crashed.bytes() + B->d_slot8.bytes() + B->d_look.bytes() + B->d_looktmp.bytes() + B->d_dstack.bytes() + B->d_stack.bytes() + B->d_btab.bytes() + B->d_pool.bytes();
 
   HIP_TRY(hipStreamCreateWithFlags(&B->stream, hipStreamNonBlocking));
   for (auto& e : B->ev) HIP_TRY(hipEventCreate(&e));
@@ -405,11 +407,11 @@ static uint32_t search_blocks(uint32_t n_work) {
   return std::max(1u, (n_work + kWavesPerBlock - 1) / kWavesPerBlock);
 }
 
-static BeamArgs make_beam_args(tbc_batch* B, uint64_t* tab, uint32_t* stack, uint32_t n_work) {
+static BeamArgs make_beam_args(tbc_batch* B, uint64_t* tab, uint32_t* stack, uint32_t* dstack, uint32_t n_work) {
   BeamArgs a{};
   a.hist = B->d_hist.p; a.bh = B->d_bh.p; a.off = B->d_off.p; a.ncr = B->d_ncr.p; a.lst = B->d_lst.p;
   a.crashed = B->d_crashed.p; a.slot8 = B->d_slot8.p; a.look = B->lookahead ? B->d_look.p : nullptr; a.ret_slot = B->d_ret_slot.p; a.ret_op = B->d_ret_op.p;
-  a.stack = stack; a.tab = tab; a.results = B->d_results.p;
+  a.stack = stack; a.dstack = B->lookahead ? dstack : nullptr; a.tab = tab; a.results = B->d_results.p;
   a.witness = B->opts.want_witness ? B->d_witness.p : nullptr;
   a.work = B->d_work.p; a.table = B->d_table.p; a.n_work = n_work; a.model_kind = B->model.kind;
   const bool comm = B->model.kind == TBC_MODEL_SET || B->model.kind == TBC_MODEL_BANK;
@@ -436,7 +438,6 @@ static BeamArgs make_beam_args(tbc_batch* B, uint64_t* tab, uint32_t* stack, uin
 // scratch arena (overflow retries, and wide-schedule histories that fall back to the sequential kernel).
 static tbc_status scratch_pass(tbc_batch* B, const std::vector<uint32_t>& grp, const std::vector<uint32_t>& lg,
                                bool beam, const std::vector<Hist>& hist_back, const std::vector<BeamHist>& bh_back,
-                               bool exact,
                                uint32_t width_override = 0) {
   hipStream_t s = B->stream;
   const uint32_t pass_width = width_override ? width_override : B->width;
@@ -457,10 +458,11 @@ static tbc_status scratch_pass(tbc_batch* B, const std::vector<uint32_t>& grp, c
     entries += 1ull << lg[i];
   }
   DevBuf<uint64_t> big;
-  DevBuf<uint32_t> bstack;
+  DevBuf<uint32_t> bstack, bdstack;
   tbc_status st = big.alloc(entries * words_per_entry);
   if (st != TBC_OK) return st;
   if (beam && (st = bstack.alloc(entries)) != TBC_OK) { big.release(); return st; }
+  if (beam && B->lookahead && (st = bdstack.alloc(entries)) != TBC_OK) { big.release(); bstack.release(); return st; }
   hipError_t e = hipMemsetAsync(big.p, 0, entries * words_per_entry * 8, s);
   for (size_t i = 0; i < grp.size() && e == hipSuccess; i++) {
     e = hipMemcpyAsync(B->d_hist.p + grp[i], &ph[i], sizeof(Hist), hipMemcpyHostToDevice, s);
@@ -469,9 +471,8 @@ static tbc_status scratch_pass(tbc_batch* B, const std::vector<uint32_t>& grp, c
   if (e == hipSuccess) e = hipMemcpyAsync(B->d_work.p, grp.data(), grp.size() * 4, hipMemcpyHostToDevice, s);
   if (e == hipSuccess) {
     const uint32_t nw = (uint32_t)grp.size();
-    if (beam) { BeamArgs ba = make_beam_args(B, big.p, bstack.p, nw); ba.pool = nullptr; ba.pool_words = 0;
+    if (beam) { BeamArgs ba = make_beam_args(B, big.p, bstack.p, bdstack.p, nw); ba.pool = nullptr; ba.pool_words = 0;
       if (width_override) ba.width = width_override;
-      if (exact) ba.look = nullptr;
       if (wg) launch_beam_wg(ba, B->mask_words, nw, s); else launch_beam(ba, B->mask_words, search_blocks(nw), s); }
     else { SearchArgs ra = make_search_args(B, big.p, nw); launch_search(ra, B->mask_words, search_blocks(nw), s); }
     e = hipGetLastError();
@@ -485,7 +486,7 @@ static tbc_status scratch_pass(tbc_batch* B, const std::vector<uint32_t>& grp, c
     if (beam && e == hipSuccess) e = hipMemcpyAsync(B->d_bh.p + grp[i], &bh_back[grp[i]], sizeof(BeamHist), hipMemcpyHostToDevice, s);
   }
   if (e == hipSuccess) e = hipStreamSynchronize(s);
-  big.release(); bstack.release();
+  big.release(); bstack.release(); bdstack.release();
   if (e != hipSuccess) { set_error("scratch pass failed: %s", hipGetErrorString(e)); return TBC_ERR_HIP; }
   return TBC_OK;
 }
@@ -587,7 +588,7 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results) {
   HIP_TRY(hipEventRecord(B->ev[2], s));
 
   if (beam) {
-    BeamArgs ba = make_beam_args(B, B->d_btab.p, B->d_stack.p, nh);
+    BeamArgs ba = make_beam_args(B, B->d_btab.p, B->d_stack.p, B->d_dstack.p, nh);
     if (B->wg ? !launch_beam_wg(ba, B->mask_words, nh, s) : !launch_beam(ba, B->mask_words, search_blocks(nh), s)) { set_error("unsupported mask width"); return TBC_ERR_UNSUPPORTED; }
   } else {
     SearchArgs sa = make_search_args(B, B->d_tab.p, nh);
@@ -625,27 +626,17 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results) {
       }
     if (!fb.empty()) {
       // the sequential kernel reads Hist.status only; clear the wide-schedule flag for it
-      tbc_status st = scratch_pass(B, fb, lg, false, hist_back, bh_back, false);
+      tbc_status st = scratch_pass(B, fb, lg, false, hist_back, bh_back);
       if (st != TBC_OK) return st;
       touched_work = true;
     }
   }
   std::vector<uint32_t> width_of(nh, B->width);
-  // Lookahead never changes a verdict, but an invalid history's failing op and :configs are defined by
-  // the configs that get as far as they can: such a history is searched once more without it.
-  std::vector<uint8_t> exact(nh, 0);
   // overflow retries: 16x larger visited set each time, up to max_visited_bytes
   const uint64_t arena_budget = 32ull << 30;
   for (;;) {
     std::vector<uint32_t> pend_seq, lg_seq, pend_beam, lg_beam;
     for (uint32_t h = 0; h < nh; h++) {
-      if (B->lookahead && !is_seq[h] && !exact[h] && B->res_host[h].valid == TBC_INVALID) {
-        exact[h] = 1;
-        uint32_t lg = std::max(final_log2[h], B->res_host[h].tab_log2);
-        if (lg + 2 <= kBeamMaxTabLog2 && (1ull << (lg + 2)) * EW * 8 <= max_bytes) lg += 2;
-        pend_beam.push_back(h); lg_beam.push_back(lg);
-        continue;
-      }
       if (B->res_host[h].valid == TBC_UNKNOWN && B->res_host[h].cause == TBC_CAUSE_VISITED_FULL) {
         const uint64_t wpe = is_seq[h] ? KW : EW;
         uint32_t lg = final_log2[h] + 4;
@@ -660,20 +651,18 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results) {
     for (int pass = 0; pass < 2; pass++) {
       const std::vector<uint32_t>& pend = pass ? pend_beam : pend_seq;
       const std::vector<uint32_t>& lgs = pass ? lg_beam : lg_seq;
-      const uint64_t wpe = pass ? (uint64_t)EW + 1 : KW;     // + the stack word
+      const uint64_t wpe = pass ? (uint64_t)EW + 1 : KW;     // + the stack words
       size_t pos = 0;
       while (pos < pend.size()) {
         std::vector<uint32_t> grp, glg;
         uint64_t bytes = 0;
         while (pos < pend.size()) {
           const uint64_t need = (1ull << lgs[pos]) * wpe * 8;
-          if (!grp.empty() && (bytes + need > arena_budget ||
-                               (pass == 1 && (width_of[pend[pos]] != width_of[grp[0]] || exact[pend[pos]] != exact[grp[0]])))) break;
+          if (!grp.empty() && (bytes + need > arena_budget || (pass == 1 && width_of[pend[pos]] != width_of[grp[0]]))) break;
           grp.push_back(pend[pos]); glg.push_back(lgs[pos]); final_log2[pend[pos]] = lgs[pos];
           bytes += need; pos++;
         }
-        tbc_status st = scratch_pass(B, grp, glg, pass == 1, hist_back, bh_back, pass == 1 && exact[grp[0]],
-                                     pass == 1 ? width_of[grp[0]] : 0);
+        tbc_status st = scratch_pass(B, grp, glg, pass == 1, hist_back, bh_back, pass == 1 ? width_of[grp[0]] : 0);
         if (st != TBC_OK) return st;
         touched_work = true;
       }

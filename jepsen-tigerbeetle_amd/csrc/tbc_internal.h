@@ -195,6 +195,7 @@ struct BeamArgs {
   const uint32_t* ret_slot;
   const uint32_t* ret_op;
   uint32_t* stack;
+  uint32_t* dstack;          // second stack (same layout as stack): configs set aside by the lookahead, or null
   uint64_t* tab;             // (2 + mask_words) u64 words per entry; layout is the kernel's own (wgl_beam.hip / wgl_beam_wg.hip)
   DevResult* results;
   uint32_t* witness;         // n_ops per history at op_off, may be null

@@ -94,8 +94,8 @@ __device__ __forceinline__ uint32_t row_max_u32(uint32_t v) {
 
 // LDS words per wave: parents p_k0[16] p_M[16*MW] (u64), ring r_k0[kRing] r_M[kRing*MW] (u64),
 // p_slot p_off p_nlive p_cnt (u32 x16), r_pos r_idx r_off r_nlive r_cnt (u32 x kRing), p_start (17 -> 20),
-// search state (24, S_* words), this round's new configs for the lookahead c_M[64*MW] (u64) c_fi c_st (u32 x64)
-__host__ __device__ constexpr uint32_t beam_lds_words(uint32_t mw) { return (16 + kRing) * (2 + 2 * mw) + 16 * 4 + kRing * 5 + 20 + 24 + 64 * (2 + 2 * mw); }
+// search state (28, S_* words), this round's new configs for the lookahead c_M[64*MW] (u64) c_fi c_st (u32 x64)
+__host__ __device__ constexpr uint32_t beam_lds_words(uint32_t mw) { return (16 + kRing) * (2 + 2 * mw) + 16 * 4 + kRing * 5 + 20 + 28 + 64 * (2 + 2 * mw); }
 
 __device__ __forceinline__ uint32_t key_hash32(uint64_t k0, const uint64_t* M, int mw) {
   uint32_t h = (uint32_t)k0 * 0x9E3779B1u ^ (uint32_t)(k0 >> 32) * 0x85EBCA77u;
@@ -171,7 +171,7 @@ __device__ __forceinline__ uint32_t scan_bucket(const gu64* tab, uint32_t b, uin
 enum : uint32_t {
   S_TAB = 0, S_STACK = 2, S_CAP = 4, S_SP = 5, S_MAXSP = 6, S_MAXF = 7, S_K = 8, S_VERDICT = 9, S_CAUSE = 10,
   S_WINPAR = 11, S_WINOP = 12, S_WINSTATE = 13, S_PROBES = 14, S_VISITED = 16, S_EXPANDED = 18, S_ITER = 20,
-  S_ROUNDS = 22, S_WORDS = 24
+  S_ROUNDS = 22, S_DSTACK = 24, S_DSP = 26, S_EXACT = 27, S_WORDS = 28
 };
 typedef __attribute__((address_space(3))) volatile uint32_t* state_ptr;   // LDS, named so: volatile accesses keep the generic (flat) form otherwise
 __device__ __forceinline__ uint32_t sld(state_ptr S, uint32_t i) { return rfl(S[i]); }
@@ -189,9 +189,10 @@ __device__ __forceinline__ bool grow_visited_set(const BeamArgs& A, state_ptr S,
   constexpr uint32_t KW = MW + 1, EW = MW + 2;
   const gu64* tab = (const gu64*)sld64(S, S_TAB);
   const gu32* stack = (const gu32*)sld64(S, S_STACK);
-  const uint32_t cap_log2 = sld(S, S_CAP), sp = sld(S, S_SP);
+  const gu32* dstack = (const gu32*)sld64(S, S_DSTACK);          // configs set aside by the lookahead (may be null)
+  const uint32_t cap_log2 = sld(S, S_CAP), sp = sld(S, S_SP), dsp = sld(S, S_DSP);
   const uint64_t old_cap = 1ull << cap_log2, new_cap = old_cap << 2;
-  const uint64_t need = new_cap * EW + new_cap / 2 + old_cap / 2;      // keys + parents, stack, slot translation
+  const uint64_t need = new_cap * EW + new_cap / 2 + (dstack ? new_cap / 2 : 0) + old_cap / 2;   // keys + parents, stack(s), slot translation
   unsigned long long base = 0;
   if (lane == 0) base = (A.pool && cap_log2 + 2 <= A.max_tab_log2) ? atomicAdd(A.pool_cursor, (unsigned long long)need) : ~0ull;
   base = ru64(base);
@@ -200,7 +201,8 @@ __device__ __forceinline__ bool grow_visited_set(const BeamArgs& A, state_ptr S,
   gu64* npar = ntab + new_cap * KW;
   const gu64* opar = tab + old_cap * KW;
   gu32* nstack = (gu32*)(ntab + new_cap * EW);
-  gu32* remap = nstack + new_cap;
+  gu32* ndstack = dstack ? nstack + new_cap : nullptr;
+  gu32* remap = nstack + new_cap + (dstack ? new_cap : 0);
   const uint32_t nbmask = (uint32_t)((new_cap >> 2) - 1);
 #pragma unroll 1
   for (uint64_t s = lane; s < old_cap; s += 64) {
@@ -235,10 +237,13 @@ __device__ __forceinline__ bool grow_visited_set(const BeamArgs& A, state_ptr S,
 #pragma unroll 1
   for (uint32_t i = lane; i < sp; i += 64)
     st32(nstack + i, ld32(remap + ld32(stack + i)));
+#pragma unroll 1
+  for (uint32_t i = lane; i < dsp; i += 64)
+    st32(ndstack + i, ld32(remap + ld32(dstack + i)));
   if (lane < kRing) r_pos[lane] = kNone;       // the ring held old slot numbers
   __threadfence();
   if (lane == 0) {
-    sst64(S, S_TAB, (uint64_t)ntab); sst64(S, S_STACK, (uint64_t)nstack);
+    sst64(S, S_TAB, (uint64_t)ntab); sst64(S, S_STACK, (uint64_t)nstack); sst64(S, S_DSTACK, (uint64_t)ndstack);
     sst(S, S_CAP, cap_log2 + 2u);
   }
   return true;
@@ -322,6 +327,8 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
     }
     if (lane == 0) {
       sst64(S, S_TAB, (uint64_t)tab0); sst64(S, S_STACK, (uint64_t)stack0);
+      sst64(S, S_DSTACK, (look && A.dstack) ? (uint64_t)((gu32*)A.dstack + ru64(B->stack_off)) : 0ull);
+      sst(S, S_DSP, 0u); sst(S, S_EXACT, (look && A.dstack) ? 0u : 1u);
       sst(S, S_CAP, cap0); sst(S, S_SP, sp0); sst(S, S_MAXSP, sp0); sst(S, S_MAXF, 0u); sst(S, S_K, A.width);
       sst(S, S_VERDICT, (uint32_t)verdict0); sst(S, S_CAUSE, (uint32_t)TBC_CAUSE_NONE);
       sst(S, S_WINPAR, kNone); sst(S, S_WINOP, kNone); sst(S, S_WINSTATE, (uint32_t)A.init_state);
@@ -346,10 +353,19 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
   int32_t verdict = (int32_t)sld(S, S_VERDICT), cause = (int32_t)sld(S, S_CAUSE);
   uint32_t win_parent = sld(S, S_WINPAR), win_op = sld(S, S_WINOP);
   int32_t win_state = (int32_t)sld(S, S_WINSTATE);
-  bool need_grow = false;
+  gu32* const dstack = (gu32*)sld64(S, S_DSTACK);
+  uint32_t dsp = sld(S, S_DSP);
+  const bool look_on = sld(S, S_EXACT) == 0u;     // false once the set-aside configs are being expanded
+  bool need_grow = false, need_switch = false;
 
   while (verdict == -2) {
-    if (sp == 0) { verdict = TBC_INVALID; break; }
+    if (sp == 0) {
+      // no linearization through the live configs.  Those the lookahead set aside become the stack and the
+      // search goes on without lookahead: an INVALID verdict has then expanded every reachable config
+      // exactly once -- failing op, :configs and visited / probes / expanded are the plain search's
+      if (dsp != 0u) { need_switch = true; break; }
+      verdict = TBC_INVALID; break;
+    }
     if (A.round_budget && rounds > A.round_budget && K < 16u) { K = 16u; gshift = 2u; G = 4u; }
     const uint32_t np = min(K, sp);
     const uint32_t ln = opaque_lane(lane);
@@ -524,9 +540,10 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
       // next kLookahead ranks can never be linearized from it: not linearized yet, it needs a value that is
       // neither the state nor produced by any call still to be linearized before that completion (calls
       // invoked later, open calls not yet linearized, the calls completing in between).  Dead configs stay
-      // in the visited set but are not pushed.  8 lanes per config, one rank each: one trip, L1-resident.
+      // in the visited set and are set aside on a second stack (expanded only if the live ones lead to no
+      // linearization).  8 lanes per config, one rank each: one trip, L1-resident.
       bool dead = false;
-      if (look != nullptr && nb0) {
+      if (look_on && nb0) {
         const uint32_t ci = (uint32_t)__popcll(nb0 & ((1ull << lr) - 1ull)), nn0 = (uint32_t)__popcll(nb0);
         if (is_new) {
           c_fi[ci] = fi2; c_st[ci] = (uint32_t)st2;
@@ -575,6 +592,11 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
         }
       }
       const bool keep = is_new && !dead;
+      const uint64_t db = __ballot(is_new && dead);
+      if (db) {                                   // set aside, in pair order
+        if (is_new && dead) st32(dstack + dsp + (uint32_t)__popcll(db & ((1ull << lr) - 1ull)), idx);
+        dsp += (uint32_t)__popcll(db);
+      }
       const uint64_t nb = __ballot(keep);
       const uint32_t nn = (uint32_t)__popcll(nb);
       if (is_new) lane_maxf = max(lane_maxf, fi2);
@@ -611,7 +633,7 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) mf = max(mf, (uint32_t)__shfl_xor(mf, d));
     if (lane == 0) {
-      sst(S, S_SP, sp); sst(S, S_MAXSP, max_sp); sst(S, S_MAXF, mf); sst(S, S_K, K);
+      sst(S, S_SP, sp); sst(S, S_MAXSP, max_sp); sst(S, S_MAXF, mf); sst(S, S_K, K); sst(S, S_DSP, dsp);
       sst(S, S_VERDICT, (uint32_t)verdict); sst(S, S_CAUSE, (uint32_t)cause);
       sst(S, S_WINPAR, win_parent); sst(S, S_WINOP, win_op); sst(S, S_WINSTATE, (uint32_t)win_state);
       sst64(S, S_PROBES, probes); sst64(S, S_VISITED, visited); sst64(S, S_EXPANDED, expanded);
@@ -620,6 +642,15 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
+  if (need_switch) {       // the set-aside configs become the stack; no lookahead from here on
+    if (lane == 0) {
+      const uint64_t a = S[S_STACK] | ((uint64_t)S[S_STACK + 1] << 32), b = S[S_DSTACK] | ((uint64_t)S[S_DSTACK + 1] << 32);
+      sst64(S, S_STACK, b); sst64(S, S_DSTACK, a);
+      sst(S, S_SP, S[S_DSP]); sst(S, S_DSP, 0u); sst(S, S_EXACT, 1u);
+    }
+    if (lane < kRing) r_pos[lane] = kNone;     // ring entries are keyed by stack position
+    continue;
+  }
   if (!need_grow) break;
   if (!grow_visited_set<MW>(A, S, r_pos, lane)) {
     if (lane == 0) { sst(S, S_VERDICT, (uint32_t)TBC_UNKNOWN); sst(S, S_CAUSE, (uint32_t)TBC_CAUSE_VISITED_FULL); }

@@ -147,15 +147,11 @@ def check_beam(ops, model, width=16, max_probes=0, want_witness=True, round_pair
     """The wide (K configs per iteration) schedule of the same search: wgl_beam.c.
 
     lookahead: None = what the library does by default (on for register / cas-register under the
-    single-wavefront wide schedule, i.e. round_pairs == 64); an INVALID verdict found with it is
-    searched again without it, as tbc_batch_run does, so the failing op and the configs are exact."""
+    single-wavefront wide schedule, i.e. round_pairs == 64).  Configs it finds dead are set aside and
+    expanded only if the search would otherwise end INVALID, so results are exact either way."""
     if lookahead is None:
         lookahead = round_pairs == 64 and model["kind"] in (0, 1)
-    if lookahead:
-        out = _check_beam(ops, model, width, max_probes, want_witness, round_pairs, widen_after, True)
-        if out["valid"] != 0:
-            return out
-    return _check_beam(ops, model, width, max_probes, want_witness, round_pairs, widen_after, False)
+    return _check_beam(ops, model, width, max_probes, want_witness, round_pairs, widen_after, bool(lookahead))
 
 
 def _check_beam(ops, model, width, max_probes, want_witness, round_pairs, widen_after, lookahead):

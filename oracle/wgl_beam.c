@@ -34,7 +34,10 @@
  *       - otherwise, in ascending r, each viable pair probes the visited set;
  *         a child that is new is inserted (remembering parent and op) and
  *         pushed -- unless the lookahead (below, register / cas-register only,
- *         tbc_opts.lookahead) finds it dead: then it is inserted but not pushed.
+ *         tbc_opts.lookahead) finds it dead: then it is inserted and SET ASIDE on a second stack.
+ *   empty stack, configs set aside  =>  they become the stack, lookahead is switched off for the rest
+ *         of the search (so an INVALID verdict has expanded every reachable config exactly once: same
+ *         failing op, configs and visited / probes / expanded as without lookahead);
  *   empty stack  =>  INVALID; the failing op is the completion of the greatest
  *   front ever inserted (the first completion whose prefix cannot be
  *   linearized), as in wgl_ref.c.
@@ -232,6 +235,10 @@ int wgl_beam_check_rp(uint32_t n, const uint8_t* f, const int32_t* a, const int3
   ar.slots = (uint32_t*)calloc(ar.nslots, 4);
   size_t scap = 1 << 16, sp = 0;
   uint32_t* stack = (uint32_t*)malloc(scap * 4);
+  /* configs the lookahead found dead: set aside, expanded only if the search would otherwise end INVALID */
+  size_t dcap = 1 << 12, dsp = 0;
+  uint32_t* dstack = (uint32_t*)malloc(dcap * 4);
+  int look_on = g_lookahead && !cfgm && (model->kind == O_REGISTER || model->kind == O_CAS_REGISTER);
   uint64_t* key = (uint64_t*)calloc(KW, 8);
   key[0] = 1ull | ((uint64_t)(uint32_t)(cfgm ? 0 : model->init) << 32);
   stack[sp++] = arena_add(&ar, key, 0, 0xFFFFFFFFu);
@@ -247,7 +254,14 @@ int wgl_beam_check_rp(uint32_t n, const uint8_t* f, const int32_t* a, const int3
 
   uint64_t last_progress = 0; uint32_t seen_maxf = 0, stall_w = g_stall_width;
   while (verdict == -2) {
-    if (sp == 0) { verdict = 0; break; }
+    if (sp == 0) {
+      if (dsp == 0) { verdict = 0; break; }
+      /* no linearization through the live configs: the set-aside ones become the stack (in the order they
+       * were set aside) and the search goes on WITHOUT lookahead, so every reachable config is expanded
+       * exactly once overall -- failing op, configs, visited / probes / expanded are the plain search's */
+      { uint32_t* t = stack; stack = dstack; dstack = t; size_t c = scap; scap = dcap; dcap = c; }
+      sp = dsp; dsp = 0; look_on = 0;
+    }
     if (g_stall_rounds && g_stall_mode < 2) {
       if (maxf > seen_maxf) { seen_maxf = maxf; last_progress = st->rounds; stall_w = g_stall_width; }
       else if (st->rounds - last_progress > g_stall_rounds) {
@@ -333,13 +347,13 @@ int wgl_beam_check_rp(uint32_t n, const uint8_t* f, const int32_t* a, const int3
         if (!id) continue;
         st->visited++;
         if (cfront[l] > maxf) maxf = cfront[l];
-        if (g_lookahead && !cfgm && (model->kind == O_REGISTER || model->kind == O_CAS_REGISTER)) {
+        if (look_on) {
           /* lookahead: the new config is dead if the call completing at one of the next 8 ranks can never
            * be linearized from it -- it is not linearized yet and needs a register value (0..31) that is
            * neither the state nor produced (:write v / :cas [_ v]) by any OTHER call that can still be
            * linearized before that completion: a call invoked after this front and before the completion,
-           * or a call open at this front (crashed ones included) and not linearized.  Dead configs stay
-           * in the visited set but are not pushed. */
+           * or a call open at this front (crashed ones included) and not linearized.  No linearization goes
+           * through a dead config, so it is set aside instead of pushed (see the top of the loop). */
           const uint64_t* c2 = ck + (size_t)l * KW;
           const uint32_t F = cfront[l]; const int32_t s2 = cstate[l];
           int dead = 0;
@@ -363,7 +377,12 @@ int wgl_beam_check_rp(uint32_t n, const uint8_t* f, const int32_t* a, const int3
             }
             if (!ok) dead = 1;
           }
-          if (dead) { g_pruned++; continue; }
+          if (dead) {
+            g_pruned++;
+            if (dsp == dcap) { dcap *= 2; dstack = (uint32_t*)realloc(dstack, dcap * 4); }
+            dstack[dsp++] = id;
+            continue;
+          }
         }
         if (sp == scap) { scap *= 2; stack = (uint32_t*)realloc(stack, scap * 4); }
         stack[sp++] = id;
@@ -397,6 +416,6 @@ int wgl_beam_check_rp(uint32_t n, const uint8_t* f, const int32_t* a, const int3
   }
   free(rets); free(ret_rank); free(inv_rank); free(ret_op); free(off); free(ncr); free(lst); free(fill); free(crashed);
   free(open_ops); free(open_lin);
-  free(ar.keys); free(ar.parent); free(ar.op); free(ar.slots); free(stack); free(key); free(ck);
+  free(ar.keys); free(ar.parent); free(ar.op); free(ar.slots); free(stack); free(dstack); free(key); free(ck);
   return 0;
 }

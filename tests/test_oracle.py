@@ -100,9 +100,11 @@ def test_committed_golden_fixtures_still_hold(native, oracle):
 
 
 def test_lookahead_never_changes_a_verdict(oracle):
-    """tbc_opts.lookahead drops configs from which one of the next 8 completions can never be
-    linearized: the verdict must be the one of the plain search (and of the sequential oracle) on
-    valid and invalid histories alike, and it must save work."""
+    """tbc_opts.lookahead sets aside configs from which one of the next 8 completions can never be
+    linearized and expands them only if the search would otherwise end INVALID: the verdict must be
+    the one of the plain search (and of the sequential oracle) on valid and invalid histories alike,
+    an invalid history must end with the plain search's failing op and counters, and valid ones
+    must get cheaper."""
     from jepsen_tigerbeetle_amd import columns, synth
     m = {"kind": 1, "init": N.NIL}
     saved = 0
@@ -120,7 +122,9 @@ def test_lookahead_never_changes_a_verdict(oracle):
                 if seq["valid"] != -1:
                     assert a["valid"] == seq["valid"], (n, p, s, K)
                 if a["valid"] == 0:
+                    # set-aside configs are expanded before the verdict: the exact search's numbers
                     assert a["fail_op"] == b["fail_op"] == seq["fail_op"]
+                    assert (a["visited"], a["probes"], a["expanded"]) == (b["visited"], b["probes"], b["expanded"])
                 else:
                     saved += b["probes"] - a["probes"]
     assert saved > 0
