@@ -16,7 +16,8 @@ opts = core.make_opts(time_limit_ms=5000, want_witness=True, algorithm=N.ALG_COM
 seeds = range(int(sys.argv[1]) if len(sys.argv) > 1 else 10)
 print(__doc__)
 print("%-5s %-9s | %-34s | %-34s" % ("info", "history", "GPU tbc_check ms (median / max), verdicts", "CPU port ms (median / max), verdicts"))
-for info in (0.0, 0.01, 0.05):
+tiers = [float(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0.0, 0.01, 0.05]
+for info in tiers:
     for inject in (False, True):
         g_ms, c_ms, g_v, c_v, agree = [], [], [], [], 0
         for s in seeds:
