@@ -140,6 +140,10 @@ void wgl_beam_set_widen_after(uint32_t r) { g_widen_after = r; }
 static uint32_t g_lookahead = 0, g_lookahead_depth = 8; static uint64_t g_pruned = 0;
 void wgl_beam_set_lookahead(uint32_t on) { g_lookahead = on; }
 uint64_t wgl_beam_pruned(void) { return g_pruned; }
+/* searches that found their linearization only AFTER the set-aside configs were taken up: must stay 0,
+ * or the lookahead rule called a live config dead (the verdict would still be right) */
+static uint64_t g_late_valid = 0;
+uint64_t wgl_beam_late_valid(void) { return g_late_valid; }
 
 /* ---- experiment knobs (all off by default; NOT part of the specified schedule, no kernel counterpart).
  * They produced the negative results recorded in DESIGN.md section 6 (the tail of a batch):
@@ -339,6 +343,7 @@ int wgl_beam_check_rp(uint32_t n, const uint8_t* f, const int32_t* a, const int3
       }
       st->rounds++;
       if (g_trace && (st->rounds & 255) == 0 && g_trace_n + 2 <= g_trace_cap) { g_trace[g_trace_n++] = maxf; g_trace[g_trace_n++] = (uint32_t)sp; }
+      if (success >= 0 && g_lookahead && !look_on && !cfgm && (model->kind == O_REGISTER || model->kind == O_CAS_REGISTER)) g_late_valid++;
       if (success >= 0) { verdict = 1; win_parent = cpar[success]; win_op = cop[success]; win_state = cstate[success]; break; }
       for (uint32_t l = 0; l < m; l++) {
         if (!cviable[l]) continue;

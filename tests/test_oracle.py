@@ -128,3 +128,9 @@ def test_lookahead_never_changes_a_verdict(oracle):
                 else:
                     saved += b["probes"] - a["probes"]
     assert saved > 0
+    # and the rule itself never called a live config dead: no linearization was found only after the
+    # set-aside configs had to be taken up (randomized sweeps of 17,000 histories while developing: 0)
+    import ctypes as C
+    late = oracle.lib().wgl_beam_late_valid
+    late.restype = C.c_uint64
+    assert late() == 0
