@@ -308,11 +308,11 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
       return s;
     if (B->lookahead && ((s = B->d_look.alloc(look_words(T, nh, B->mask_words))) || (s = B->d_looktmp.alloc(T)) ||
                          (s = B->d_dstack.alloc(bstack_n)))) return s;
-    // growth pool: a quarter of the visited-set arena, at least room for one history to grow twice, at most 32 GiB
+    // growth pool: 30 % of the visited-set arena, at least room for one history to grow twice (4x, then 16x: keys, parents, two stacks, slot translation), at most 32 GiB
     {
       uint64_t biggest = 0;
       for (uint32_t h = 0; h < nh; h++) biggest = std::max<uint64_t>(biggest, 1ull << B->bh[h].tab_log2);
-      uint64_t words = std::max<uint64_t>(btab_n * EW * 3 / 10, biggest * (4 + 16) * (EW + 1));
+      uint64_t words = std::max<uint64_t>(btab_n * EW * 3 / 10, biggest * (4 + 16 + 4) * (EW + 1));
       words = std::min<uint64_t>(words, (32ull << 30) / 8);
       if ((s = B->d_pool.alloc(words))) return s;
     }
