@@ -124,6 +124,13 @@ uint32_t wgl_beam_last_configs(uint64_t* out, uint32_t max, uint32_t* kw) {
   return g_bcfg_n;
 }
 
+/* eager reads: mark every open, not yet linearized read whose value is nil or the state `s` as linearized
+ * (in list order), move the front past every completion now linearized, and repeat while that opens new
+ * calls.  Returns the new front; appends the absorbed ops to wit[*nw...] when wit is given. */
+static uint32_t absorb_reads(uint64_t* c2, uint32_t fi2, int32_t s, uint32_t R, const uint32_t* off, const uint32_t* lst,
+                             const int32_t* process, const uint32_t* ret_op, const uint8_t* f, const int32_t* a,
+                             uint32_t* wit, uint32_t* nw);
+
 /* round_pairs: pairs per round (64 = one wavefront; 256 = the workgroup-cooperative kernel) */
 int wgl_beam_check_rp(uint32_t n, const uint8_t* f, const int32_t* a, const int32_t* b,
                       const int32_t* process, uint32_t n_process,
@@ -156,6 +163,12 @@ uint64_t wgl_beam_late_valid(void) { return g_late_valid; }
 void wgl_beam_set_lookahead_depth(uint32_t d) { g_lookahead_depth = d; }
 static uint32_t g_list_order = 0;
 void wgl_beam_set_list_order(uint32_t o) { g_list_order = o; }
+/* eager reads (experiment for the next round, register family): a read that is viable NOW can be linearized
+ * now without loss of generality (it does not change the state, so any later schedule stays possible): every
+ * child absorbs all of them, again after each step of the front.  Witness reconstruction is not done here. */
+static uint32_t g_eager_reads = 0; static uint64_t g_absorbed = 0;
+void wgl_beam_set_eager_reads(uint32_t on) { g_eager_reads = on; }
+uint64_t wgl_beam_absorbed(void) { return g_absorbed; }
 static uint32_t g_stall_rounds = 0, g_stall_width = 64, g_stall_mode = 0;
 void wgl_beam_set_stall(uint32_t rounds, uint32_t width, uint32_t mode) { g_stall_rounds = rounds; g_stall_width = width; g_stall_mode = mode; }
 static uint32_t* g_trace = NULL; static uint32_t g_trace_cap = 0, g_trace_n = 0;
@@ -168,6 +181,32 @@ int wgl_beam_check(uint32_t n, const uint8_t* f, const int32_t* a, const int32_t
                    const oracle_model* model, uint32_t K, uint64_t max_probes,
                    uint32_t* witness, oracle_result* out, beam_stats* st) {
   return wgl_beam_check_rp(n, f, a, b, process, n_process, inv_pos, ret_pos, model, K, 64, max_probes, witness, out, st);
+}
+
+static uint32_t absorb_reads(uint64_t* c2, uint32_t fi2, int32_t s, uint32_t R, const uint32_t* off, const uint32_t* lst,
+                             const int32_t* process, const uint32_t* ret_op, const uint8_t* f, const int32_t* a,
+                             uint32_t* wit, uint32_t* nw) {
+  int again = 1;
+  while (again && fi2 < R) {
+    again = 0;
+    const uint32_t nl = off[fi2 + 1] - off[fi2];
+    for (uint32_t cc = 0; cc < nl; cc++) {
+      const uint32_t x = lst[off[fi2] + cc], px = (uint32_t)process[x];
+      if (c2[1 + (px >> 6)] >> (px & 63) & 1) continue;
+      if (f[x] != O_READ || !(a[x] == O_NIL || a[x] == s)) continue;
+      c2[1 + (px >> 6)] |= 1ull << (px & 63); g_absorbed++;
+      if (wit) wit[(*nw)++] = x;
+    }
+    /* the front moves past every completion now linearized; new calls open up: look again */
+    uint32_t pp = (uint32_t)process[ret_op[fi2]];
+    while (c2[1 + (pp >> 6)] >> (pp & 63) & 1) {
+      c2[1 + (pp >> 6)] &= ~(1ull << (pp & 63));
+      fi2++; again = 1;
+      if (fi2 == R) break;
+      pp = (uint32_t)process[ret_op[fi2]];
+    }
+  }
+  return fi2;
 }
 
 int wgl_beam_check_rp(uint32_t n, const uint8_t* f, const int32_t* a, const int32_t* b,
@@ -337,6 +376,8 @@ int wgl_beam_check_rp(uint32_t n, const uint8_t* f, const int32_t* a, const int3
             if (!(c2[1 + (pp >> 6)] >> (pp & 63) & 1)) break;
           }
         }
+        if (g_eager_reads && !cfgm && (model->kind == O_REGISTER || model->kind == O_CAS_REGISTER))
+          fi2 = absorb_reads(c2, fi2, s2, R, off, lst, process, ret_op, f, a, NULL, NULL);
         c2[0] = (uint64_t)(fi2 + 1) | ((uint64_t)(uint32_t)s2 << 32);
         cviable[l] = 1; cfront[l] = fi2; cstate[l] = s2;
         if (fi2 == R && success < 0) success = (int)l;
@@ -408,6 +449,32 @@ int wgl_beam_check_rp(uint32_t n, const uint8_t* f, const int32_t* a, const int3
     if (witness) {
       uint32_t w = len - 1; witness[w] = win_op; id = win_parent;
       while (ar.parent[id]) { witness[--w] = ar.op[id]; id = ar.parent[id]; }
+      if (g_eager_reads && !cfgm && (model->kind == O_REGISTER || model->kind == O_CAS_REGISTER)) {
+        /* the chain holds the branching ops only: replay it from the root, absorbing reads as the search did */
+        uint32_t* chain = (uint32_t*)malloc(4 * (size_t)len);
+        memcpy(chain, witness, 4 * (size_t)len);
+        uint64_t* c2 = (uint64_t*)calloc(KW, 8);
+        uint32_t fr = 0, nw = 0; int32_t s = model->init;
+        for (uint32_t i = 0; i < len; i++) {
+          const uint32_t op = chain[i], p = (uint32_t)process[op];
+          int32_t s2 = s; (void)oracle_step(model, s, f[op], a[op], b[op], &s2); s = s2;
+          witness[nw++] = op;
+          c2[1 + (p >> 6)] |= 1ull << (p & 63);
+          if (ret_rank[op] == fr) {
+            uint32_t pp = p;
+            for (;;) {
+              c2[1 + (pp >> 6)] &= ~(1ull << (pp & 63));
+              fr++;
+              if (fr == R) break;
+              pp = (uint32_t)process[ret_op[fr]];
+              if (!(c2[1 + (pp >> 6)] >> (pp & 63) & 1)) break;
+            }
+          }
+          fr = absorb_reads(c2, fr, s, R, off, lst, process, ret_op, f, a, witness, &nw);
+        }
+        out->n_witness = nw;
+        free(chain); free(c2);
+      }
     }
   } else if (verdict == 0) {
     out->fail_op = ret_op[maxf];

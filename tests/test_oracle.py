@@ -134,3 +134,32 @@ def test_lookahead_never_changes_a_verdict(oracle):
     late = oracle.lib().wgl_beam_late_valid
     late.restype = C.c_uint64
     assert late() == 0
+
+
+def test_eager_reads_rule_for_the_next_round(oracle):
+    """Specified on the CPU first (no kernel counterpart yet): a read that is viable now
+    can be linearized now without loss of generality, so every child absorbs all of them.  Same verdict
+    and failing op as the plain search, witnesses that replay legally under the independent checker,
+    and far less work with no heavy tail."""
+    from jepsen_tigerbeetle_amd import columns, synth
+    m = {"kind": 1, "init": N.NIL}
+    for (n, p, busy, info, corrupt) in [(40, 4, 0.5, 0.05, 0.0), (60, 8, 0.8, 0.2, 0.3), (300, 16, 0.3, 0.05, 0.0),
+                                        (300, 8, 0.4, 0.02, 0.3), (1000, 32, 0.15, 0.02, 0.0)]:
+        for s in range(10 if n <= 300 else 4):
+            ops = columns.pair_events(synth.register_events(n_ops=n, n_procs=p, seed=300 + s, busy=busy, info=info, corrupt=corrupt))
+            d = ops.as_dict()
+            plain = oracle.check_beam(d, m, 4, max_probes=3_000_000, lookahead=False)
+            for la in (False, True):
+                e = oracle.check_beam(d, m, 4, max_probes=3_000_000, lookahead=la, eager_reads=True)
+                if -1 in (plain["valid"], e["valid"]):
+                    continue
+                assert e["valid"] == plain["valid"], (n, p, s, la)
+                if e["valid"] == 0:
+                    assert e["fail_op"] == plain["fail_op"], (n, p, s, la)
+                else:
+                    w = [int(x) for x in e["witness"]]
+                    assert brute.check_witness(m, op_tuples(ops), w) == e["final_state"], (n, p, s, la)
+    big = columns.pair_events(synth.register_events(n_ops=10000, n_procs=64, seed=3659, busy=0.1)).as_dict()   # hardest of 4,096 seeds
+    a = oracle.check_beam(big, m, 4, want_witness=False)
+    b = oracle.check_beam(big, m, 4, want_witness=False, eager_reads=True)
+    assert a["valid"] == b["valid"] == 1 and b["rounds"] * 4 < a["rounds"]
