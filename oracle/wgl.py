@@ -143,7 +143,7 @@ class BeamStats(C.Structure):
                 ("expanded", C.c_uint64), ("max_stack", C.c_uint64), ("rounds", C.c_uint64)]
 
 
-def check_beam(ops, model, width=16, max_probes=0, want_witness=True, round_pairs=64, widen_after=0, lookahead=None, eager_reads=False):
+def check_beam(ops, model, width=16, max_probes=0, want_witness=True, round_pairs=64, widen_after=0, lookahead=None, eager_reads=False, twin_rule=False):
     """The wide (K configs per iteration) schedule of the same search: wgl_beam.c.
 
     lookahead: None = what the library does by default (on for register / cas-register under the
@@ -153,10 +153,12 @@ def check_beam(ops, model, width=16, max_probes=0, want_witness=True, round_pair
         lookahead = round_pairs == 64 and model["kind"] in (0, 1)
     # eager_reads: next round's rule, specified and tested here first (no kernel counterpart yet)
     lib().wgl_beam_set_eager_reads(C.c_uint32(1 if eager_reads else 0))
+    lib().wgl_beam_set_twin_rule(C.c_uint32(1 if twin_rule else 0))
     try:
         return _check_beam(ops, model, width, max_probes, want_witness, round_pairs, widen_after, bool(lookahead))
     finally:
         lib().wgl_beam_set_eager_reads(C.c_uint32(0))
+        lib().wgl_beam_set_twin_rule(C.c_uint32(0))
 
 
 def _check_beam(ops, model, width, max_probes, want_witness, round_pairs, widen_after, lookahead):

@@ -167,6 +167,10 @@ void wgl_beam_set_list_order(uint32_t o) { g_list_order = o; }
  * now without loss of generality (it does not change the state, so any later schedule stays possible): every
  * child absorbs all of them, again after each step of the front.  Witness reconstruction is not done here. */
 static uint32_t g_eager_reads = 0; static uint64_t g_absorbed = 0;
+/* twin writes (experiment, register family): of several open, not yet linearized calls with the same effect
+ * (:write v, or :cas [a b] with equal a and b) the one completing first goes first, without loss of generality */
+static uint32_t g_twin_rule = 0;
+void wgl_beam_set_twin_rule(uint32_t on) { g_twin_rule = on; }
 void wgl_beam_set_eager_reads(uint32_t on) { g_eager_reads = on; }
 uint64_t wgl_beam_absorbed(void) { return g_absorbed; }
 static uint32_t g_stall_rounds = 0, g_stall_width = 64, g_stall_mode = 0;
@@ -351,6 +355,17 @@ int wgl_beam_check_rp(uint32_t n, const uint8_t* f, const int32_t* a, const int3
         uint32_t p = (uint32_t)process[op];
         cviable[l] = 0; cop[l] = op; cpar[l] = par[q];
         if (pk[1 + (p >> 6)] >> (p & 63) & 1) continue;
+        if (g_twin_rule && !cfgm && (f[op] == O_WRITE || f[op] == O_CAS)) {
+          int dominated = 0;
+          for (uint32_t cc = 0; cc < pcnt[q] && !dominated; cc++) {
+            uint32_t y = cc < nlive ? lst[off[fi] + cc] : crashed[cc - nlive];
+            uint32_t py = (uint32_t)process[y];
+            if (y == op || f[y] != f[op] || a[y] != a[op] || (f[op] == O_CAS && b[y] != b[op])) continue;
+            if (pk[1 + (py >> 6)] >> (py & 63) & 1) continue;
+            if (ret_rank[y] < ret_rank[op] || (ret_rank[y] == ret_rank[op] && y < op)) dominated = 1;
+          }
+          if (dominated) continue;
+        }
         int32_t s2;
         if (cfgm) {
           uint32_t no = 0;

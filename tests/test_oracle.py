@@ -149,13 +149,14 @@ def test_eager_reads_rule_for_the_next_round(oracle):
             ops = columns.pair_events(synth.register_events(n_ops=n, n_procs=p, seed=300 + s, busy=busy, info=info, corrupt=corrupt))
             d = ops.as_dict()
             plain = oracle.check_beam(d, m, 4, max_probes=3_000_000, lookahead=False)
-            for la in (False, True):
-                e = oracle.check_beam(d, m, 4, max_probes=3_000_000, lookahead=la, eager_reads=True)
+            for la, twin in ((False, False), (True, False), (True, True)):
+                # twin rule: of several open calls with the same effect the one completing first goes first
+                e = oracle.check_beam(d, m, 4, max_probes=3_000_000, lookahead=la, eager_reads=True, twin_rule=twin)
                 if -1 in (plain["valid"], e["valid"]):
                     continue
-                assert e["valid"] == plain["valid"], (n, p, s, la)
+                assert e["valid"] == plain["valid"], (n, p, s, la, twin)
                 if e["valid"] == 0:
-                    assert e["fail_op"] == plain["fail_op"], (n, p, s, la)
+                    assert e["fail_op"] == plain["fail_op"], (n, p, s, la, twin)
                 else:
                     w = [int(x) for x in e["witness"]]
                     assert brute.check_witness(m, op_tuples(ops), w) == e["final_state"], (n, p, s, la)
