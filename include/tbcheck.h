@@ -207,8 +207,17 @@ typedef struct tbc_opts {
                              /* linearized provides); set-aside configs are expanded  */
                              /* only if the search would otherwise end invalid, so the*/
                              /* failing op and :configs stay exact.  0 = on, 1 = off  */
-  uint32_t reserved;         /* must be 0                                             */
+  uint32_t dominance;        /* wide schedule / level sweep, register / cas-register:  */
+                             /* two rules that drop configs without changing a verdict */
+                             /* or a failing op (TBC_DOM_*); 0 = both on               */
 } tbc_opts;
+
+/* tbc_opts.dominance bits (set = rule OFF).  Eager reads: an open read whose value is nil or
+ * the current state is linearized at once (it changes nothing, so every later schedule stays
+ * possible); the search then branches over :write / :cas only.  Twin rule: of several open,
+ * not yet linearized calls with the same effect the one completing first goes first.  Both
+ * need register values in 0..30; a history outside that range is searched without them. */
+enum { TBC_DOM_NO_EAGER_READS = 1u, TBC_DOM_NO_TWIN_RULE = 2u };
 
 /* ------------------------------------------------------------------ result */
 enum { TBC_VALID = 1, TBC_INVALID = 0, TBC_UNKNOWN = -1 };

@@ -33,6 +33,7 @@ ALG_COMPETITION, ALG_WGL, ALG_LINEAR = 0, 1, 2
 # verdicts / causes
 VALID, INVALID, UNKNOWN = 1, 0, -1
 CAUSE_NONE, CAUSE_TIME_LIMIT, CAUSE_STEP_LIMIT, CAUSE_VISITED_FULL = 0, 1, 2, 3
+DOM_NO_EAGER_READS, DOM_NO_TWIN_RULE = 1, 2
 # status
 (OK_STATUS, ERR_INVALID_ARG, ERR_BAD_HISTORY, ERR_NO_DEVICE, ERR_OOM, ERR_WINDOW_TOO_WIDE,
  ERR_MODEL, ERR_HIP, ERR_UNSUPPORTED) = range(9)
@@ -72,7 +73,7 @@ class Opts(C.Structure):
                 ("max_steps", C.c_uint64), ("max_visited_bytes", C.c_uint64),
                 ("want_witness", C.c_uint32), ("visited_per_op", C.c_uint32),
                 ("search_width", C.c_uint32), ("round_budget", C.c_uint32),
-                ("lookahead", C.c_uint32), ("reserved", C.c_uint32)]
+                ("lookahead", C.c_uint32), ("dominance", C.c_uint32)]
 
 
 class Config(C.Structure):

@@ -28,7 +28,8 @@ def make_model(kind, init=N.NIL, table=None, n_keys=0):
 
 
 def make_opts(algorithm=N.ALG_WGL, device=0, time_limit_ms=0, max_steps=0, max_visited_bytes=0,
-              want_witness=True, visited_per_op=0, search_width=0, round_budget=0, lookahead=True):
+              want_witness=True, visited_per_op=0, search_width=0, round_budget=0, lookahead=True,
+              eager_reads=True, twin_rule=True):
     o = N.Opts()
     o.algorithm = algorithm
     o.device = device
@@ -40,6 +41,7 @@ def make_opts(algorithm=N.ALG_WGL, device=0, time_limit_ms=0, max_steps=0, max_v
     o.search_width = int(search_width)
     o.round_budget = int(round_budget)
     o.lookahead = 0 if lookahead else 1     # C-ABI: 0 = on (default), 1 = off
+    o.dominance = (0 if eager_reads else N.DOM_NO_EAGER_READS) | (0 if twin_rule else N.DOM_NO_TWIN_RULE)
     return o
 
 

@@ -179,6 +179,44 @@ __global__ __launch_bounds__(256) void pack_open_kernel(PackOpenArgs A) {
       }
       __syncthreads();
     }
+    // H: dominance tables (register family; tbc_internal.h) -- one thread per front reads that front's list
+    //    once: rdm row = slots of its open reads by value, twn = per entry the slots of the calls with the
+    //    same effect that complete earlier
+    if (A.rdm) {
+      __threadfence_block();
+      const uint32_t V = A.vpad;
+      uint64_t* rdm = A.rdm + H->op_off * V * MW;
+      uint64_t* twn = A.twn + B->lst_off * MW;
+      for (uint32_t fr = tid; fr < R; fr += 256) {
+        const uint32_t o0 = ld_agent(&off[fr]), o1 = ld_agent(&off[fr + 1]);
+        for (uint32_t vi = 0; vi < V; vi++) {
+          uint64_t m[4] = {0, 0, 0, 0};
+          for (uint32_t c = o0; c < o1; c++) {
+            const OpRec x = lst[c];
+            const uint32_t xs = (x.f_slot >> 8) & kSlotMask;
+            if ((x.f_slot & 0xFFu) == TBC_F_READ && rdm_index(x.a, V) == vi && (vi != 0 || x.a == TBC_NIL)) m[xs >> 6] |= 1ull << (xs & 63u);
+          }
+          for (uint32_t w = 0; w < MW; w++) rdm[((uint64_t)fr * V + vi) * MW + w] = m[w];
+        }
+        for (uint32_t c = o0; c < o1; c++) {
+          const OpRec y = lst[c];
+          const uint32_t yf = y.f_slot & 0xFFu;
+          uint64_t m[4] = {0, 0, 0, 0};
+          if (yf == TBC_F_WRITE || yf == TBC_F_CAS) {
+            const uint32_t yr = sc_ret[y.op];
+            for (uint32_t d = o0; d < o1; d++) {
+              if (d == c) continue;
+              const OpRec z = lst[d];
+              if ((z.f_slot & 0xFFu) != yf || z.a != y.a || (yf == TBC_F_CAS && z.b != y.b)) continue;
+              const uint32_t zr = sc_ret[z.op];
+              if (zr < yr || (zr == yr && z.op < y.op)) { const uint32_t zs = (z.f_slot >> 8) & kSlotMask; m[zs >> 6] |= 1ull << (zs & 63u); }
+            }
+          }
+          for (uint32_t w = 0; w < MW; w++) twn[(uint64_t)c * MW + w] = m[w];
+        }
+      }
+      __syncthreads();
+    }
     // E-G: lookahead records (register family only; A.look is null otherwise)
     if (A.look) {
       const uint32_t LW = 1 + MW;

@@ -151,6 +151,9 @@ struct tbc_batch {
   DevBuf<uint64_t> d_look;          // lookahead records per completion rank
   DevBuf<uint32_t> d_dstack;        // second stack per history: configs the lookahead set aside
   DevBuf<uint32_t> d_looktmp;
+  uint32_t rules = 0;               // kRuleEager | kRuleTwin: wide single-wave schedule, register family, values 0..kMaxRuleValue
+  uint32_t vpad = 0;                // entries per rdm row (nil + values), power of two
+  DevBuf<uint64_t> d_twn, d_rdm;    // dominance tables (tbc_internal.h)
   DevBuf<uint64_t> d_occ, d_btab, d_pool;
   DevBuf<unsigned long long> d_pool_cursor;
   // last run
@@ -166,7 +169,7 @@ struct tbc_batch {
     d_bitmap.release(); d_wpre.release(); d_frames.release(); d_witness.release(); d_work.release();
     d_queue.release(); d_tab.release(); d_results.release(); d_table.release(); d_pool_vals.release(); d_cfg.release();
     d_bh.release(); d_off.release(); d_ncr.release(); d_lst.release(); d_crashed.release(); d_stack.release();
-    d_occ.release(); d_btab.release(); d_slot8.release(); d_look.release(); d_looktmp.release(); d_dstack.release(); d_pool.release(); d_pool_cursor.release();
+    d_occ.release(); d_btab.release(); d_slot8.release(); d_look.release(); d_looktmp.release(); d_twn.release(); d_rdm.release(); d_dstack.release(); d_pool.release(); d_pool_cursor.release();
     for (auto& e : ev) if (e) (void)hipEventDestroy(e);
     if (stream) (void)hipStreamDestroy(stream);
   }
@@ -246,6 +249,21 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
   B->lookahead = width > 1 && width <= 16 && opts->lookahead != 1 &&
                  (model->kind == TBC_MODEL_REGISTER || model->kind == TBC_MODEL_CAS_REGISTER);
   const bool beam = width > 1;
+  // dominance rules: same scope as the lookahead, and every register value must index the per-front read table
+  if (B->lookahead || (width > 1 && width <= 16 && (model->kind == TBC_MODEL_REGISTER || model->kind == TBC_MODEL_CAS_REGISTER))) {
+    int32_t vmax = model->init == TBC_NIL ? -1 : model->init;
+    bool in_range = model->init == TBC_NIL || model->init >= 0;
+    const tbc_ops& c = desc->cols;
+    for (uint64_t i = 0; i < c.n && in_range; i++) {
+      const int32_t a = c.a[i];
+      if (a != TBC_NIL) { in_range = a >= 0; vmax = std::max(vmax, a); }
+      if (c.f[i] == TBC_F_CAS) { const int32_t b = c.b[i]; in_range = in_range && b >= 0; vmax = std::max(vmax, b); }
+    }
+    if (in_range && vmax <= kMaxRuleValue) {
+      B->rules = ((opts->dominance & TBC_DOM_NO_EAGER_READS) ? 0u : kRuleEager) | ((opts->dominance & TBC_DOM_NO_TWIN_RULE) ? 0u : kRuleTwin);
+      B->vpad = 2; while (B->vpad < (uint32_t)(vmax + 2)) B->vpad <<= 1;
+    }
+  }
   const uint32_t EW = B->wg ? beam_wg_entry_words(B->mask_words) : B->mask_words + 2;   // u64 words per wide-schedule entry
 
   const uint64_t default_cap_bytes = 1ull << 30;
@@ -306,6 +324,7 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
         (s = B->d_slot8.alloc(slot8_bytes(T, nh))) || (s = B->d_stack.alloc(bstack_n)) || (s = B->d_btab.alloc(btab_n * EW)) ||
         (s = B->d_pool_cursor.alloc(1)))
       return s;
+    if (B->rules && ((s = B->d_twn.alloc(blst_n * B->mask_words)) || (s = B->d_rdm.alloc(T * B->vpad * B->mask_words)))) return s;
     if (B->lookahead && ((s = B->d_look.alloc(look_words(T, nh, B->mask_words))) || (s = B->d_looktmp.alloc(T)) ||
                          (s = B->d_dstack.alloc(bstack_n)))) return s;
     // growth pool: 30 % of the visited-set arena, at least room for one history to grow twice (4x, then 16x: keys, parents, two stacks, slot translation), at most 32 GiB
@@ -333,7 +352,7 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
                     B->d_ret_op.bytes() + B->d_bitmap.bytes() + B->d_wpre.bytes() + B->d_frames.bytes() +
                     B->d_tab.bytes() + B->d_results.bytes() + B->d_work.bytes() + B->d_witness.bytes();
   if (beam) B->device_bytes += B->d_bh.bytes() + B->d_off.bytes() + B->d_ncr.bytes() + B->d_occ.bytes() + B->d_lst.bytes() +
-                               B->d_crashed.bytes() + B->d_slot8.bytes() + B->d_look.bytes() + B->d_looktmp.bytes() + B->d_dstack.bytes() + B->d_stack.bytes() + B->d_btab.bytes() + B->d_pool.bytes();
+                               B->d_crashed.bytes() + B->d_slot8.bytes() + B->d_twn.bytes() + B->d_rdm.bytes() + B->d_look.bytes() + B->d_looktmp.bytes() + B->d_dstack.bytes() + B->d_stack.bytes() + B->d_btab.bytes() + B->d_pool.bytes();
 
   HIP_TRY(hipStreamCreateWithFlags(&B->stream, hipStreamNonBlocking));
   for (auto& e : B->ev) HIP_TRY(hipEventCreate(&e));
@@ -419,6 +438,7 @@ static BeamArgs make_beam_args(tbc_batch* B, uint64_t* tab, uint32_t* stack, uin
   a.model_aux = B->model.init; a.n_keys = B->model.n_keys;
   a.n_classes = B->model.n_classes; a.width = B->width;
   a.round_budget = B->opts.round_budget;
+  a.rules = B->rules; a.twn = B->d_twn.p; a.rdm = B->d_rdm.p; a.vpad = B->vpad;
   a.max_steps = B->opts.max_steps;
   a.time_limit_ticks = B->opts.time_limit_ms * 100000ull;
   a.dbg = debug_words();
@@ -538,6 +558,64 @@ static tbc_status fill_configs(tbc_batch* B, uint32_t h, const DevResult& d, tbc
   return TBC_OK;
 }
 
+// Eager reads: the wide search branches over :write / :cas only and its parent chain holds just those calls.
+// The full linearization is the chain replayed from the initial state with the rule applied as the search
+// applies it: after every chain call the front moves past the completions now linearized, then every open live
+// read (process-slot order) whose value is nil or the state is linearized, again after each move of the front.
+// wit[0..len) = the chain in, the whole witness out (at most n_ops entries: the caller's slice has that room).
+static tbc_status expand_eager_witness(tbc_batch* B, uint32_t h, uint32_t* wit, uint32_t* len) {
+  const Hist& H = B->hist[h];
+  const uint32_t n = H.n_ops;
+  std::vector<uint8_t> f(n);
+  std::vector<int32_t> a(n), b(n), proc(n);
+  std::vector<uint32_t> inv(n), ret(n);
+  HIP_TRY(hipMemcpy(f.data(), B->d_f.p + H.op_off, (size_t)n, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(a.data(), B->d_a.p + H.op_off, (size_t)n * 4, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(b.data(), B->d_b.p + H.op_off, (size_t)n * 4, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(proc.data(), B->d_proc.p + H.op_off, (size_t)n * 4, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(inv.data(), B->d_inv.p + H.op_off, (size_t)n * 4, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(ret.data(), B->d_ret.p + H.op_off, (size_t)n * 4, hipMemcpyDeviceToHost));
+  std::vector<uint32_t> by_ret;                      // completed calls in completion order
+  for (uint32_t i = 0; i < n; i++) if (ret[i] != TBC_POS_CRASHED) by_ret.push_back(i);
+  std::sort(by_ret.begin(), by_ret.end(), [&](uint32_t x, uint32_t y) { return ret[x] < ret[y]; });
+  const uint32_t R = (uint32_t)by_ret.size();
+  std::vector<uint32_t> opens_at(n);                 // number of completions before the call's invocation
+  { uint32_t r = 0; for (uint32_t i = 0; i < n; i++) { while (r < R && ret[by_ret[r]] < inv[i]) r++; opens_at[i] = r; } }
+  std::vector<uint8_t> done(n, 0);
+  std::vector<int64_t> open_by_slot(std::max(1u, H.n_slots), -1);   // live call open on each process slot at the front
+  std::vector<uint32_t> chain(wit, wit + *len), out;
+  out.reserve(n);
+  uint32_t front = 0, next_inv = 0;
+  int32_t state = B->model.init;
+  auto open_calls = [&]() {
+    while (next_inv < n && opens_at[next_inv] <= front) {
+      if (ret[next_inv] != TBC_POS_CRASHED) open_by_slot[(uint32_t)proc[next_inv]] = next_inv;
+      next_inv++;
+    }
+  };
+  auto advance = [&]() -> bool {
+    bool moved = false;
+    while (front < R && done[by_ret[front]]) { open_by_slot[(uint32_t)proc[by_ret[front]]] = -1; front++; moved = true; open_calls(); }
+    return moved;
+  };
+  open_calls();
+  for (uint32_t op : chain) {
+    if (op >= n || done[op]) { set_error("history %u: malformed witness chain", h); return TBC_ERR_HIP; }
+    state = f[op] == TBC_F_WRITE ? a[op] : (f[op] == TBC_F_CAS ? b[op] : state);
+    done[op] = 1; out.push_back(op);
+    advance();
+    for (bool again = true; again && front < R;) {
+      for (int64_t x : open_by_slot)
+        if (x >= 0 && !done[x] && f[x] == TBC_F_READ && (a[x] == TBC_NIL || a[x] == state)) { done[x] = 1; out.push_back((uint32_t)x); }
+      again = advance();
+    }
+  }
+  if (out.size() > n) { set_error("history %u: witness longer than the history", h); return TBC_ERR_HIP; }
+  std::copy(out.begin(), out.end(), wit);
+  *len = (uint32_t)out.size();
+  return TBC_OK;
+}
+
 static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results) {
   HIP_TRY(hipSetDevice(B->device));
   const uint64_t t_start = now_ns();
@@ -580,6 +658,7 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results) {
     po.scratch = B->d_frames.p; po.off = B->d_off.p; po.ncr = B->d_ncr.p; po.occ = B->d_occ.p; po.lst = B->d_lst.p;
     po.crashed = B->d_crashed.p; po.ret_slot = B->d_ret_slot.p; po.slot8 = B->d_slot8.p;
     po.ret_op = B->d_ret_op.p; po.look = B->lookahead ? B->d_look.p : nullptr; po.tmp = B->d_looktmp.p; po.n_hist = nh; po.mask_words = B->mask_words;
+    po.twn = B->rules ? B->d_twn.p : nullptr; po.rdm = B->rules ? B->d_rdm.p : nullptr; po.vpad = B->vpad;
     launch_pack_open(po, s);
     HIP_TRY(hipGetLastError());
   }
@@ -718,7 +797,13 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results) {
     }
     if (d.valid == TBC_VALID) {
       r.final_state = d.final_state; r.n_witness = d.depth;
-      if (B->opts.want_witness) r.witness = B->witness_host.data() + B->hist[h].op_off;
+      if (B->opts.want_witness) {
+        r.witness = B->witness_host.data() + B->hist[h].op_off;
+        if ((B->rules & kRuleEager) && !is_seq[h] && d.depth) {
+          tbc_status ws = expand_eager_witness(B, h, r.witness, &r.n_witness);
+          if (ws != TBC_OK) return ws;
+        }
+      }
     }
     r.counters.steps = d.steps; r.counters.visited = d.visited; r.counters.probes = d.probes;
     r.counters.backtracks = d.backtracks; r.counters.max_depth = d.max_depth;

@@ -144,6 +144,22 @@ __host__ __device__ inline uint64_t look_words(uint64_t total_ops, uint64_t n_hi
 }
 constexpr uint32_t kSlotMask = 0xFFFFu;     // (f_slot >> 8) & kSlotMask = process slot
 
+// Dominance rules of the wide schedule and of the level sweep (register / cas-register), tbc_opts.dominance:
+//   eager reads: an open read whose value is nil or the current state is linearized at once -- it changes
+//                nothing, so every later schedule stays possible (configs are kept in that normal form);
+//   twin rule:   of several open, not yet linearized calls with the same effect (:write v, or :cas with equal
+//                arguments) the one completing first goes first.
+// Both are decided from two tables pack_open builds next to the per-front open-call lists:
+//   rdm[(F * vpad + vi) * mask_words + w]  slots of the live reads open at front F whose value is nil (vi = 0)
+//                                          or vi - 1 (vi = 1 .. vpad - 1); vpad = power of two >= max value + 2
+//   twn[e * mask_words + w]                for entry e of lst[] (a live call at one of its fronts): slots of the
+//                                          live calls open at that front with the same effect that complete earlier
+constexpr uint32_t kRuleEager = 1u, kRuleTwin = 2u;
+constexpr int32_t kMaxRuleValue = 30;       // register values 0..30 (vpad <= 32); anything else switches the rules off
+__host__ __device__ inline uint32_t rdm_index(int32_t v, uint32_t vpad) {   // row entry of state / read value v
+  return (v == TBC_NIL || (uint32_t)(v + 1) >= vpad) ? 0u : (uint32_t)(v + 1);
+}
+
 struct __attribute__((aligned(16))) BeamHist {
   uint64_t off_off;     // u32 units: off[] (n_ops + 2), ncr[] at the same offset in its own arena
   uint64_t occ_off;     // u64 units: occ[] ((n_ops + 1) * mask_words)
@@ -177,6 +193,10 @@ struct PackOpenArgs {
   uint8_t* slot8;            // the same as bytes (mask_words <= 4), at slot8_off(op_off, h): windowed prefetch
   uint32_t n_hist;
   uint32_t mask_words;
+  uint64_t* twn;             // twin masks, one per lst[] entry (x mask_words), or null
+  uint64_t* rdm;             // open-read masks, vpad x mask_words per front at op_off * vpad * mask_words, or null
+  uint32_t vpad;
+  uint32_t pad;
 };
 
 // byte offset of history h's slot8[] (n_ret entries + 16 of padding), 8-byte aligned
@@ -221,6 +241,11 @@ struct BeamArgs {
   int32_t model_aux;                 // commutative models: pool offset of the per-front table
   uint32_t round_budget;             // 0 = none; exceeded => TBC_CAUSE_ROUND_BUDGET (host escalates)
   uint32_t n_keys;                   // bank: number of accounts
+  uint32_t rules;                    // kRuleEager | kRuleTwin (register family, single-wavefront wide schedule)
+  const uint64_t* twn;               // as PackOpenArgs
+  const uint64_t* rdm;
+  uint32_t vpad;
+  uint32_t pad3;
 };
 
 void launch_pack_open(const PackOpenArgs& a, void* stream);

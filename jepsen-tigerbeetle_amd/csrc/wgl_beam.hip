@@ -288,6 +288,10 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
   uint32_t* c_fi = reinterpret_cast<uint32_t*>(c_M + 64 * MW);
   uint32_t* c_st = c_fi + 64;
   const uint64_t* look = A.look ? A.look + look_off(op_off, hidx, MW) : nullptr;
+  // dominance rules (tbc_internal.h): open-read masks per (front, value), twin masks per list entry
+  const uint32_t rules = COMM ? 0u : A.rules, vpad = A.vpad;
+  const uint64_t* rdm = A.rdm + op_off * vpad * MW;
+  const uint64_t* twn = A.twn + ru64(B->lst_off) * MW;
   if (lane < kRing) r_pos[lane] = kNone;
 
   const uint64_t t0 = A.time_limit_ticks ? wall_clock64() : 0;
@@ -456,24 +460,76 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
         const uint64_t* wp = reinterpret_cast<const uint64_t*>(slot8 + wbase);
         w0 = wp[0]; w1 = wp[1];
       }
+      // twin rule: the slots of the open calls with this call's effect that complete earlier travel with its
+      // list entry (same trip); dominated while one of them is not linearized yet
+      bool dominated = false;
+      if constexpr (!COMM) {
+        if ((rules & kRuleTwin) && act && c < nlive) {
+#pragma unroll
+          for (int j = 0; j < MW; j++) dominated = dominated || (twn[(uint64_t)(poff + c) * MW + j] & ~Mp[j]) != 0ull;
+        }
+      }
       const uint32_t op = oi.op;
       const uint32_t p = (oi.f_slot >> 8) & kSlotMask;
       if (prof) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); SEG(1); }
       bool lin = false;
 #pragma unroll
       for (int j = 0; j < MW; j++) if ((p >> 6) == (uint32_t)j) lin = (Mp[j] >> (p & 63u)) & 1ull;
-      const bool viable = act && !lin && pair_viable<MW, COMM>(model, st, fi, Mp, poff, nlive, cnt, lst, crashed, oi);
+      if constexpr (!COMM) {
+        // a crashed call has no per-front entry: its twins are every live open call with its effect (they all
+        // complete earlier) and the crashed ones invoked before it -- walk the list (crash-heavy histories only)
+        const uint32_t cf = oi.f_slot & 0xFFu;
+        if ((rules & kRuleTwin) && act && !lin && c >= nlive && (cf == TBC_F_WRITE || cf == TBC_F_CAS)) {
+          for (uint32_t cc = 0; cc < c && !dominated; cc++) {
+            const OpRec y = cc < nlive ? lst[poff + cc] : crashed[cc - nlive];
+            if ((y.f_slot & 0xFFu) != cf || y.a != oi.a || (cf == TBC_F_CAS && y.b != oi.b)) continue;
+            const uint32_t py = (y.f_slot >> 8) & kSlotMask;
+            bool ly = false;
+#pragma unroll
+            for (int j = 0; j < MW; j++) if ((py >> 6) == (uint32_t)j) ly = (Mp[j] >> (py & 63u)) & 1ull;
+            dominated = !ly;
+          }
+        }
+      }
+      const bool viable = act && !lin && !dominated && pair_viable<MW, COMM>(model, st, fi, Mp, poff, nlive, cnt, lst, crashed, oi);
       int32_t st2 = st;
       uint32_t fi2 = fi;
       uint64_t M2[MW];
-      make_child<MW, COMM>(model, viable, st, fi, R,
-                           [=](uint32_t r) -> uint32_t {
-                             const uint32_t d = r - wbase;
-                             if (d < 8u) return (uint32_t)(w0 >> (8u * d)) & 0xFFu;
-                             if (d < 16u) return (uint32_t)(w1 >> (8u * (d - 8u))) & 0xFFu;
-                             return (uint32_t)slot8[r];
-                           },
-                           oi, Mp, M2, st2, fi2);
+      const auto slot_at = [=](uint32_t r) -> uint32_t {
+        const uint32_t d = r - wbase;
+        if (d < 8u) return (uint32_t)(w0 >> (8u * d)) & 0xFFu;
+        if (d < 16u) return (uint32_t)(w1 >> (8u * (d - 8u))) & 0xFFu;
+        return (uint32_t)slot8[r];
+      };
+      make_child<MW, COMM>(model, viable, st, fi, R, slot_at, oi, Mp, M2, st2, fi2);
+      if constexpr (!COMM) {
+        // eager reads: the child takes every open read its state allows (value nil or the state), the front moves
+        // past the completions that linearizes, and the calls open at the new front are looked at again
+        if ((rules & kRuleEager) && viable && fi2 < R) {
+          for (;;) {
+            const uint64_t* row = rdm + (uint64_t)fi2 * vpad * MW;
+            const uint32_t vi = rdm_index(st2, vpad);
+#pragma unroll
+            for (int j = 0; j < MW; j++) M2[j] |= row[j] | row[vi * MW + j];
+            uint32_t pp = slot_at(fi2);
+            bool bit = false;
+#pragma unroll
+            for (int j = 0; j < MW; j++) if ((pp >> 6) == (uint32_t)j) bit = (M2[j] >> (pp & 63u)) & 1ull;
+            if (!bit) break;
+            do {
+#pragma unroll
+              for (int j = 0; j < MW; j++) if ((pp >> 6) == (uint32_t)j) M2[j] &= ~(1ull << (pp & 63u));
+              fi2++;
+              if (fi2 == R) break;
+              pp = slot_at(fi2);
+              bit = false;
+#pragma unroll
+              for (int j = 0; j < MW; j++) if ((pp >> 6) == (uint32_t)j) bit = (M2[j] >> (pp & 63u)) & 1ull;
+            } while (bit);
+            if (fi2 == R) break;
+          }
+        }
+      }
       SEG(2);
       rounds++;
       const uint64_t succ = __ballot(viable && fi2 == R);

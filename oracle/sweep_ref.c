@@ -1,0 +1,365 @@
+/*
+ * TEST INFRASTRUCTURE -- NOT PRODUCT CODE (see oracle_model.h for the rules
+ * and the PARITY UNPINNED statement).
+ *
+ * sweep_ref.c -- scalar CPU statement of the LEVEL SWEEP that
+ * jepsen-tigerbeetle_amd/csrc/jit_sweep.hip runs: Lowe's just-in-time
+ * linearization (the algorithm behind knossos.linear/analysis, SURVEY.md
+ * section 8a rows `knossos.linear/analysis + knossos.linear.config`), with the two
+ * dominance rules of wgl_beam.c (eager reads, twin rule) applied to the config
+ * set, and -- the reason it exists -- cut into SEGMENTS that are swept
+ * independently of each other and composed afterwards, so that ONE history is
+ * checked by many wavefronts at once.
+ *
+ * Level F (F = 0..R, R = number of completions) holds the set of configs
+ * (mask, state) reachable with exactly the first F completions passed:
+ *   mask  = one bit per process slot, "the call this process has open at front F
+ *           is already linearized";
+ *   state = model state;
+ *   normal form: every open live read whose value is nil or the state is linearized
+ *           (eager reads: such a read can be linearized now without loss of generality).
+ * Transition F -> F+1, X = the call completing at rank F:
+ *   sub-round 0: configs that have X linearized return it (bit cleared) and enter level F+1
+ *                -- normalised again, because calls invoked between the two completions are
+ *                open now; the others form P_0;
+ *   sub-round j: every config of P_(j-1) is expanded over its open, not yet linearized calls y
+ *                (live ones in slot order, then crashed ones in invocation order; never a read
+ *                -- a read that could be linearized is linearized already -- and never a call
+ *                dominated under the twin rule): child = normal form of (mask + y, step(state, y));
+ *                a child that has X linearized enters level F+1 as above, any other child
+ *                joins P_j (exact de-duplication inside P_j and inside level F+1);
+ *   P_j empty: the level is done.  Level F+1 empty  =>  NOT linearizable, failing completion = X.
+ * Linearizing only up to X is complete: every linearization can be rearranged so that each call
+ * takes effect immediately before some completion that needs it (Lowe 2017, section 5).
+ * All R levels passed  =>  linearizable.
+ *
+ * Segments.  The fronts are cut at C_0 = 0 < C_1 < ... < C_S = R.  Segment i sweeps levels
+ * C_i .. C_(i+1) starting from EVERY config that is possible at front C_i at all -- each
+ * (subset of the calls open at C_i, model state) in normal form, numbered 0..n_origins-1 -- and
+ * carries with every config the set of origins it is reachable from (a 64-bit mask; duplicates OR
+ * their masks -- sub-rounds go by number of calls linearized, so a config's mask is final before it
+ * is expanded).  What a segment hands on is its relation {origin -> configs at front C_(i+1)}.
+ * Composition walks the segments in order: live set := {initial config}; for each segment the
+ * live end configs are those whose origin mask meets the live set; they are translated into
+ * origin numbers of the next segment.  An empty live set in segment i => NOT linearizable, and
+ * the failing completion is the greatest level of segment i that some live origin still reached
+ * (+ C_i): per origin the sweep records the last level at which a config carrying it existed.
+ * Cuts are placed at fronts where few calls are open and none is crashed-and-open ... see
+ * choose_cuts below (n_origins <= 64 is required; a history that offers no such front keeps one
+ * segment, which is then the plain sweep).
+ *
+ * Outputs that are properties of (model, history): verdict, failing op, previous-ok op.  Outputs
+ * that are properties of the sweep and compared bit for bit with the kernel: the size of every
+ * level of every segment summed (configs_total), the largest level, the number of expansions
+ * (probes) and of sub-rounds.
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include "oracle_model.h"
+
+typedef struct { uint32_t pos, op; } posop;
+static int cmp_posop(const void* x, const void* y) {
+  uint32_t a = ((const posop*)x)->pos, b = ((const posop*)y)->pos;
+  return a < b ? -1 : a > b;
+}
+static uint64_t mix64(uint64_t x) {
+  x ^= x >> 33; x *= 0xFF51AFD7ED558CCDull;
+  x ^= x >> 33; x *= 0xC4CEB9FE1A85EC53ull;
+  x ^= x >> 33; return x;
+}
+
+typedef struct sweep_stats {
+  uint64_t configs_total;   /* sum over all levels of all segments of the level's size */
+  uint64_t max_level;       /* largest level */
+  uint64_t probes;          /* expansions: (config, call) pairs whose model step is consistent */
+  uint64_t subrounds;       /* expansion sub-rounds over all levels */
+  uint64_t levels;          /* levels swept (all segments) */
+  uint64_t n_segments;
+  uint64_t max_origins;
+  uint64_t max_pending;     /* largest P_j */
+} sweep_stats;
+
+/* ordered exact set of configs: entries (KW words key: [state+1 | 0][mask...]) + origin mask, insertion order kept */
+typedef struct { uint64_t* key; uint64_t* org; uint32_t* slots; size_t n, cap, nslots, kw; } cset;
+static void cs_init(cset* s, size_t kw) {
+  s->kw = kw; s->cap = 64; s->n = 0; s->nslots = 256;
+  s->key = (uint64_t*)malloc(s->cap * kw * 8); s->org = (uint64_t*)malloc(s->cap * 8);
+  s->slots = (uint32_t*)calloc(s->nslots, 4);
+}
+static void cs_free(cset* s) { free(s->key); free(s->org); free(s->slots); }
+static void cs_clear(cset* s) { memset(s->slots, 0, s->nslots * 4); s->n = 0; }
+static uint64_t cs_hash(const uint64_t* k, size_t kw) {
+  uint64_t h = mix64(k[0]);
+  for (size_t i = 1; i < kw; i++) h = mix64(h ^ k[i]) + 0x9E3779B97F4A7C15ull;
+  return h;
+}
+/* returns 1 if new */
+static int cs_add(cset* s, const uint64_t* k, uint64_t org) {
+  size_t j = cs_hash(k, s->kw) & (s->nslots - 1);
+  while (s->slots[j]) {
+    const size_t e = s->slots[j] - 1;
+    if (memcmp(s->key + e * s->kw, k, s->kw * 8) == 0) { s->org[e] |= org; return 0; }
+    j = (j + 1) & (s->nslots - 1);
+  }
+  if (s->n == s->cap) {
+    s->cap *= 2;
+    s->key = (uint64_t*)realloc(s->key, s->cap * s->kw * 8); s->org = (uint64_t*)realloc(s->org, s->cap * 8);
+  }
+  memcpy(s->key + s->n * s->kw, k, s->kw * 8); s->org[s->n] = org;
+  s->slots[j] = (uint32_t)++s->n;
+  if (s->n * 2 > s->nslots) {
+    free(s->slots); s->nslots *= 4; s->slots = (uint32_t*)calloc(s->nslots, 4);
+    for (size_t e = 0; e < s->n; e++) {
+      size_t q = cs_hash(s->key + e * s->kw, s->kw) & (s->nslots - 1);
+      while (s->slots[q]) q = (q + 1) & (s->nslots - 1);
+      s->slots[q] = (uint32_t)(e + 1);
+    }
+  }
+  return 1;
+}
+
+/* knobs of the specified sweep */
+static uint32_t g_eager = 1, g_twin = 1, g_seg_target = 0, g_max_cut_open = 3;
+void sweep_set_rules(uint32_t eager, uint32_t twin) { g_eager = eager; g_twin = twin; }
+/* seg_target: wanted segment length in completions (0 = one segment); a cut is placed at the first front
+ * at or after each multiple of it where at most max_cut_open calls are open and none of them is crashed */
+void sweep_set_segments(uint32_t seg_target, uint32_t max_cut_open) { g_seg_target = seg_target; g_max_cut_open = max_cut_open; }
+
+typedef struct {
+  uint32_t n, R, W, MW, KW;
+  const uint8_t* f; const int32_t* a; const int32_t* b; const int32_t* process;
+  uint32_t *ret_rank, *inv_rank, *ret_op, *off, *ncr, *lst, *crashed;
+  const oracle_model* model;
+} hist_t;
+
+static inline int bit(const uint64_t* m, uint32_t p) { return (int)(m[p >> 6] >> (p & 63) & 1); }
+static inline void setb(uint64_t* m, uint32_t p) { m[p >> 6] |= 1ull << (p & 63); }
+static inline void clrb(uint64_t* m, uint32_t p) { m[p >> 6] &= ~(1ull << (p & 63)); }
+
+/* normal form at front F: linearize every open live read the state allows */
+static void normalise(const hist_t* H, uint64_t* key, uint32_t F) {
+  if (!g_eager) return;
+  const int32_t s = (int32_t)(uint32_t)(key[0] >> 32);
+  for (uint32_t c = H->off[F]; c < H->off[F + 1]; c++) {
+    const uint32_t x = H->lst[c];
+    if (H->f[x] == O_READ && (H->a[x] == O_NIL || H->a[x] == s)) setb(key + 1, (uint32_t)H->process[x]);
+  }
+}
+
+/* a config that has X (slot px) linearized passes completion F: into level F+1 (front F+1 < R) or the end set */
+static void pass_level(const hist_t* H, cset* nxt, const uint64_t* key, uint64_t org, uint32_t px, uint32_t F, uint64_t* tmp) {
+  memcpy(tmp, key, H->KW * 8);
+  clrb(tmp + 1, px);
+  if (F + 1 < H->R) normalise(H, tmp, F + 1);
+  cs_add(nxt, tmp, org);
+}
+
+int sweep_ref_check(uint32_t n, const uint8_t* f, const int32_t* a, const int32_t* b,
+                    const int32_t* process, uint32_t n_process,
+                    const uint32_t* inv_pos, const uint32_t* ret_pos,
+                    const oracle_model* model, uint64_t max_level_limit,
+                    uint32_t* level_sizes /* R entries or NULL */,
+                    oracle_result* out, sweep_stats* st) {
+  memset(out, 0, sizeof *out); memset(st, 0, sizeof *st);
+  out->fail_op = out->prev_ok_op = 0xFFFFFFFFu;
+  if (!(model->kind == O_REGISTER || model->kind == O_CAS_REGISTER || model->kind == O_MUTEX || model->kind == O_TABLE ||
+        model->kind == O_MULTI_REGISTER)) return 3;
+  const int regfam = model->kind == O_REGISTER || model->kind == O_CAS_REGISTER;
+  uint32_t R = 0;
+  for (uint32_t i = 0; i < n; i++) {
+    if (i && inv_pos[i] <= inv_pos[i - 1]) return 2;
+    if (process[i] < 0 || (uint32_t)process[i] >= n_process) return 2;
+    if (ret_pos[i] != O_CRASHED) { if (ret_pos[i] <= inv_pos[i]) return 2; R++; }
+  }
+  if (R == 0) { out->valid = 1; out->final_state = model->init; return 0; }
+  hist_t H; H.n = n; H.R = R; H.W = n_process; H.MW = (n_process + 63) / 64; H.KW = 1 + H.MW;
+  H.f = f; H.a = a; H.b = b; H.process = process; H.model = model;
+  const uint32_t KW = H.KW;
+  posop* rets = (posop*)malloc(sizeof(posop) * R);
+  H.ret_rank = (uint32_t*)malloc(4 * (size_t)n); H.inv_rank = (uint32_t*)malloc(4 * (size_t)n); H.ret_op = (uint32_t*)malloc(4 * (size_t)R);
+  uint32_t k = 0;
+  for (uint32_t i = 0; i < n; i++) if (ret_pos[i] != O_CRASHED) { rets[k].pos = ret_pos[i]; rets[k].op = i; k++; }
+  qsort(rets, R, sizeof(posop), cmp_posop);
+  for (uint32_t r = 0; r < R; r++) { H.ret_rank[rets[r].op] = r; H.ret_op[r] = rets[r].op; }
+  { uint32_t r = 0;
+    for (uint32_t i = 0; i < n; i++) { while (r < R && rets[r].pos < inv_pos[i]) r++; H.inv_rank[i] = r; } }
+  for (uint32_t i = 0; i < n; i++) if (ret_pos[i] == O_CRASHED) H.ret_rank[i] = 0xFFFFFFFFu;
+  H.off = (uint32_t*)calloc((size_t)R + 1, 4); H.ncr = (uint32_t*)calloc((size_t)R + 1, 4);
+  uint32_t n_crashed = 0;
+  const int eager_on = g_eager && regfam;
+  for (uint32_t i = 0; i < n; i++) {
+    if (H.ret_rank[i] == 0xFFFFFFFFu) {
+      if (regfam && f[i] == O_READ && a[i] == O_NIL) continue;       /* crashed read: no effect, no constraint */
+      n_crashed++; if (H.inv_rank[i] < R) H.ncr[H.inv_rank[i]]++; continue;
+    }
+    for (uint32_t fr = H.inv_rank[i]; fr <= H.ret_rank[i]; fr++) H.off[fr + 1]++;
+  }
+  for (uint32_t r = 0; r < R; r++) H.off[r + 1] += H.off[r];
+  for (uint32_t r = 1; r < R; r++) H.ncr[r] += H.ncr[r - 1];
+  H.lst = (uint32_t*)malloc(4 * ((size_t)H.off[R] + 1));
+  uint32_t* fill = (uint32_t*)malloc(4 * ((size_t)R + 1));
+  memcpy(fill, H.off, 4 * ((size_t)R + 1));
+  H.crashed = (uint32_t*)malloc(4 * ((size_t)n_crashed + 1));
+  { uint32_t c = 0;
+    for (uint32_t i = 0; i < n; i++) {
+      if (H.ret_rank[i] == 0xFFFFFFFFu) { if (!(regfam && f[i] == O_READ && a[i] == O_NIL)) H.crashed[c++] = i; continue; }
+      for (uint32_t fr = H.inv_rank[i]; fr <= H.ret_rank[i]; fr++) H.lst[fill[fr]++] = i;
+    }
+    for (uint32_t fr = 0; fr < R; fr++)          /* slot order */
+      for (uint32_t x = H.off[fr] + 1; x < H.off[fr + 1]; x++) {
+        uint32_t v = H.lst[x], y = x;
+        while (y > H.off[fr] && process[H.lst[y - 1]] > process[v]) { H.lst[y] = H.lst[y - 1]; y--; }
+        H.lst[y] = v;
+      } }
+  const uint32_t save_eager = g_eager; g_eager = (uint32_t)eager_on;
+
+  /* ---- cuts */
+  uint32_t* cuts = (uint32_t*)malloc(4 * ((size_t)R + 2));
+  uint32_t S = 0;
+  cuts[S++] = 0;
+  if (g_seg_target) {
+    uint32_t next = g_seg_target;
+    for (uint32_t F = 1; F < R; F++) {
+      if (F < next) continue;
+      const uint32_t no = H.off[F + 1] - H.off[F];
+      if (no <= g_max_cut_open && H.ncr[F] == 0) { cuts[S++] = F; next = F + g_seg_target; }
+    }
+  }
+  cuts[S] = R;
+  st->n_segments = S;
+
+  /* ---- state domain for origins: init + everything a call can leave behind (register family) */
+  int32_t* dom = (int32_t*)malloc(4 * ((size_t)2 * n + 2)); uint32_t nd = 0;
+  dom[nd++] = model->init;
+  if (S > 1) {
+    if (!regfam) { S = 1; cuts[1] = R; st->n_segments = 1; }
+    else for (uint32_t i = 0; i < n; i++) {
+      int32_t v; int has = 0;
+      if (f[i] == O_WRITE) { v = a[i]; has = 1; } else if (f[i] == O_CAS) { v = b[i]; has = 1; }
+      if (!has) continue;
+      int seen = 0; for (uint32_t q = 0; q < nd; q++) if (dom[q] == v) { seen = 1; break; }
+      if (!seen) dom[nd++] = v;
+    }
+  }
+
+  cset cur, nxt, pa, pb;
+  cs_init(&cur, KW); cs_init(&nxt, KW); cs_init(&pa, KW); cs_init(&pb, KW);
+  uint64_t* key = (uint64_t*)calloc(KW, 8); uint64_t* tmp = (uint64_t*)calloc(KW, 8);
+  /* live set carried by the composition: configs at the current cut */
+  cset live; cs_init(&live, KW);
+  key[0] = (uint64_t)(uint32_t)model->init << 32;
+  normalise(&H, key, 0);
+  cs_add(&live, key, 1);
+  int verdict = 1;
+  uint32_t fail_level = 0;
+
+  for (uint32_t sg = 0; sg < S && verdict == 1; sg++) {
+    const uint32_t F0 = cuts[sg], F1 = cuts[sg + 1];
+    /* origins of this segment: every (subset of calls open at F0, state) in normal form, de-duplicated */
+    cs_clear(&cur);
+    uint32_t norg = 0;
+    if (S == 1) { cs_add(&cur, live.key, 1); norg = 1; }
+    else {
+      const uint32_t no = H.off[F0 + 1] - H.off[F0];   /* no crashed calls open at a cut */
+      for (uint32_t q = 0; q < nd && norg <= 64; q++)
+        for (uint32_t sub = 0; sub < (1u << no) && norg <= 64; sub++) {
+          memset(key, 0, KW * 8);
+          key[0] = (uint64_t)(uint32_t)dom[q] << 32;
+          for (uint32_t c = 0; c < no; c++) if (sub >> c & 1) setb(key + 1, (uint32_t)process[H.lst[H.off[F0] + c]]);
+          normalise(&H, key, F0);
+          if (cs_add(&cur, key, 0)) { if (norg < 64) cur.org[cur.n - 1] = 1ull << norg; norg++; }
+        }
+      if (norg > 64) { verdict = -2; break; }            /* cut chosen badly: cannot happen with max_cut_open <= 3 and <= 8 states */
+    }
+    if (norg > st->max_origins) st->max_origins = norg;
+    /* which origins are live: translate the composition's live set */
+    uint64_t live_mask = 0;
+    if (S == 1) live_mask = 1;
+    else for (size_t e = 0; e < live.n; e++) {
+      int found = 0;
+      for (size_t q = 0; q < cur.n; q++) if (memcmp(cur.key + q * KW, live.key + e * KW, KW * 8) == 0) { live_mask |= cur.org[q]; found = 1; break; }
+      if (!found) { verdict = -3; }                       /* a reachable config must be among the origins */
+    }
+    if (verdict != 1) break;
+    uint32_t last_level[64]; for (uint32_t q = 0; q < 64; q++) last_level[q] = F0;
+
+    for (uint32_t F = F0; F < F1 && verdict == 1; F++) {
+      const uint32_t x = H.ret_op[F], px = (uint32_t)process[x];
+      cs_clear(&nxt); cs_clear(&pa);
+      for (size_t e = 0; e < cur.n; e++) {
+        const uint64_t* c = cur.key + e * KW;
+        if (bit(c + 1, px)) pass_level(&H, &nxt, c, cur.org[e], px, F, tmp);
+        else cs_add(&pa, c, cur.org[e]);
+      }
+      cset* P = &pa; cset* Q = &pb;
+      const uint32_t nlive = H.off[F + 1] - H.off[F], tot = nlive + H.ncr[F];
+      while (P->n) {
+        st->subrounds++;
+        if (P->n > st->max_pending) st->max_pending = P->n;
+        cs_clear(Q);
+        for (size_t e = 0; e < P->n; e++) {
+          const uint64_t* c = P->key + e * KW; const uint64_t org = P->org[e];
+          const int32_t s = (int32_t)(uint32_t)(c[0] >> 32);
+          for (uint32_t cc = 0; cc < tot; cc++) {
+            const uint32_t y = cc < nlive ? H.lst[H.off[F] + cc] : H.crashed[cc - nlive], py = (uint32_t)process[y];
+            if (bit(c + 1, py)) continue;
+            if (eager_on && f[y] == O_READ && y != x) continue;      /* could it be linearized it would be already */
+            if (g_twin && regfam && (f[y] == O_WRITE || f[y] == O_CAS)) {
+              int dominated = 0;
+              for (uint32_t dd = 0; dd < tot && !dominated; dd++) {
+                const uint32_t z = dd < nlive ? H.lst[H.off[F] + dd] : H.crashed[dd - nlive];
+                if (z == y || f[z] != f[y] || a[z] != a[y] || (f[y] == O_CAS && b[z] != b[y])) continue;
+                if (bit(c + 1, (uint32_t)process[z])) continue;
+                if (H.ret_rank[z] < H.ret_rank[y] || (H.ret_rank[z] == H.ret_rank[y] && z < y)) dominated = 1;
+              }
+              if (dominated) continue;
+            }
+            int32_t s2;
+            if (!oracle_step(model, s, f[y], a[y], b[y], &s2)) continue;
+            st->probes++;
+            memcpy(key, c, KW * 8);
+            setb(key + 1, py);
+            key[0] = (uint64_t)(uint32_t)s2 << 32;
+            normalise(&H, key, F);
+            if (bit(key + 1, px)) pass_level(&H, &nxt, key, org, px, F, tmp);
+            else cs_add(Q, key, org);
+          }
+        }
+        { cset* t = P; P = Q; Q = t; }
+      }
+      st->levels++;
+      st->configs_total += nxt.n;
+      if (nxt.n > st->max_level) st->max_level = nxt.n;
+      if (level_sizes && S == 1) level_sizes[F] = (uint32_t)nxt.n;
+      if (max_level_limit && nxt.n > max_level_limit) { verdict = -1; break; }
+      { uint64_t any = 0; for (size_t e = 0; e < nxt.n; e++) any |= nxt.org[e];
+        for (uint32_t q = 0; q < 64; q++) if (any >> q & 1) last_level[q] = F + 1; }
+      { cset t = cur; cur = nxt; nxt = t; }
+      if (cur.n == 0 || (S == 1 && cur.n == 0)) {
+        /* nobody passes completion F from any origin: the live ones die here at the latest */
+        break;
+      }
+    }
+    if (verdict != 1) break;
+    /* composition */
+    cs_clear(&live);
+    for (size_t e = 0; e < cur.n; e++) if (cur.org[e] & live_mask) cs_add(&live, cur.key + e * KW, 1);
+    uint32_t reached = F0;
+    for (uint32_t q = 0; q < 64; q++) if ((live_mask >> q & 1) && last_level[q] > reached) reached = last_level[q];
+    if (reached < F1 || live.n == 0) { verdict = 0; fail_level = reached; }
+  }
+
+  out->valid = verdict < -1 ? -1 : verdict;
+  if (verdict == 1) out->final_state = (int32_t)(uint32_t)(live.key[0] >> 32);
+  if (verdict == 0) {
+    out->fail_op = H.ret_op[fail_level];
+    out->prev_ok_op = fail_level ? H.ret_op[fail_level - 1] : 0xFFFFFFFFu;
+  }
+  out->probes = st->probes; out->visited = st->configs_total; out->steps = st->subrounds;
+  g_eager = save_eager;
+  cs_free(&cur); cs_free(&nxt); cs_free(&pa); cs_free(&pb); cs_free(&live);
+  free(key); free(tmp); free(dom); free(cuts); free(rets); free(fill);
+  free(H.ret_rank); free(H.inv_rank); free(H.ret_op); free(H.off); free(H.ncr); free(H.lst); free(H.crashed);
+  return verdict == -2 ? 4 : verdict == -3 ? 5 : 0;
+}

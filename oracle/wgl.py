@@ -33,7 +33,7 @@ class OracleResult(C.Structure):
 
 def build(force: bool = False) -> str:
     so = os.path.join(_HERE, "liboracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("wgl_ref.c", "wgl_window.c", "linear_ref.c", "wgl_beam.c", "oracle_model.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("wgl_ref.c", "wgl_window.c", "linear_ref.c", "wgl_beam.c", "sweep_ref.c", "oracle_model.h")]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s", "liboracle.so"])
     return so
@@ -43,7 +43,7 @@ def lib():
     global _LIB
     if _LIB is None:
         _LIB = C.CDLL(build())
-        for fn in (_LIB.wgl_ref_check, _LIB.wgl_window_check, _LIB.linear_ref_check, _LIB.wgl_beam_check, _LIB.wgl_beam_check_rp):
+        for fn in (_LIB.wgl_ref_check, _LIB.wgl_window_check, _LIB.linear_ref_check, _LIB.wgl_beam_check, _LIB.wgl_beam_check_rp, _LIB.sweep_ref_check):
             fn.restype = C.c_int
     return _LIB
 
@@ -143,7 +143,23 @@ class BeamStats(C.Structure):
                 ("expanded", C.c_uint64), ("max_stack", C.c_uint64), ("rounds", C.c_uint64)]
 
 
-def check_beam(ops, model, width=16, max_probes=0, want_witness=True, round_pairs=64, widen_after=0, lookahead=None, eager_reads=False, twin_rule=False):
+def rules_apply(ops, model, round_pairs=64):
+    """Where the library applies the dominance rules (eager reads, twin rule) by default: register /
+    cas-register under the single-wavefront wide schedule, every register value in 0..30."""
+    if round_pairs != 64 or model["kind"] not in (0, 1):
+        return False
+    init = model.get("init", NIL)
+    vals = [np.asarray(ops["a"], np.int64)]
+    f = np.asarray(ops["f"])
+    vals.append(np.asarray(ops["b"], np.int64)[f == 2])
+    v = np.concatenate(vals)
+    v = v[v != NIL]
+    if init != NIL:
+        v = np.append(v, init)
+    return bool(len(v) == 0 or (v.min() >= 0 and v.max() <= 30))
+
+
+def check_beam(ops, model, width=16, max_probes=0, want_witness=True, round_pairs=64, widen_after=0, lookahead=None, eager_reads=None, twin_rule=None):
     """The wide (K configs per iteration) schedule of the same search: wgl_beam.c.
 
     lookahead: None = what the library does by default (on for register / cas-register under the
@@ -151,7 +167,13 @@ def check_beam(ops, model, width=16, max_probes=0, want_witness=True, round_pair
     expanded only if the search would otherwise end INVALID, so results are exact either way."""
     if lookahead is None:
         lookahead = round_pairs == 64 and model["kind"] in (0, 1)
-    # eager_reads: next round's rule, specified and tested here first (no kernel counterpart yet)
+    # eager_reads / twin_rule: None = what the library does by default (tbc_opts.dominance = 0)
+    if eager_reads is None or twin_rule is None:
+        dflt = rules_apply(ops, model, round_pairs)
+        eager_reads = dflt if eager_reads is None else eager_reads
+        twin_rule = dflt if twin_rule is None else twin_rule
+    elif (eager_reads or twin_rule) and not rules_apply(ops, model, round_pairs):
+        eager_reads = twin_rule = False
     lib().wgl_beam_set_eager_reads(C.c_uint32(1 if eager_reads else 0))
     lib().wgl_beam_set_twin_rule(C.c_uint32(1 if twin_rule else 0))
     try:
@@ -206,3 +228,39 @@ def last_configs(which="window", max_rows=4096):
         out.append([st] + [int(x) for x in r[1:]])
     del buf
     return total, out
+
+
+class SweepStats(C.Structure):
+    _fields_ = [("configs_total", C.c_uint64), ("max_level", C.c_uint64), ("probes", C.c_uint64),
+                ("subrounds", C.c_uint64), ("levels", C.c_uint64), ("n_segments", C.c_uint64),
+                ("max_origins", C.c_uint64), ("max_pending", C.c_uint64)]
+
+
+def check_sweep(ops, model, eager_reads=True, twin_rule=True, seg_target=0, max_cut_open=3, max_level=0, want_levels=False):
+    """The segmented level sweep (sweep_ref.c): knossos.linear's just-in-time linearization with the
+    dominance rules, cut into independently swept segments that are composed afterwards."""
+    n = len(ops["f"])
+    f = np.ascontiguousarray(ops["f"], np.uint8)
+    a = np.ascontiguousarray(ops["a"], np.int32)
+    b = np.ascontiguousarray(ops["b"], np.int32)
+    inv = np.ascontiguousarray(ops["inv_pos"], np.uint32)
+    ret = np.ascontiguousarray(ops["ret_pos"], np.uint32)
+    proc = np.ascontiguousarray(ops["process"], np.int32)
+    m, keep = _model(model)
+    res, st = OracleResult(), SweepStats()
+    lv = np.zeros(max(n, 1), np.uint32)
+    L = lib()
+    L.sweep_set_rules(C.c_uint32(1 if eager_reads else 0), C.c_uint32(1 if twin_rule else 0))
+    L.sweep_set_segments(C.c_uint32(seg_target), C.c_uint32(max_cut_open))
+    rc = L.sweep_ref_check(C.c_uint32(n), _p(f, C.c_uint8), _p(a, C.c_int32), _p(b, C.c_int32),
+                           _p(proc, C.c_int32), C.c_uint32(int(ops["n_process"])), _p(inv, C.c_uint32),
+                           _p(ret, C.c_uint32), C.byref(m), C.c_uint64(max_level),
+                           _p(lv, C.c_uint32) if want_levels else None, C.byref(res), C.byref(st))
+    if rc != 0:
+        raise ValueError(f"oracle rejected history (rc={rc})")
+    out = {k: getattr(res, k) for k, _ in OracleResult._fields_}
+    for name, _ in SweepStats._fields_:
+        out[name] = getattr(st, name)
+    if want_levels:
+        out["level_sizes"] = lv
+    return out

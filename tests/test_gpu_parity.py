@@ -65,26 +65,37 @@ def test_single_history_matches_oracle(native, oracle, n_ops, procs, info, corru
         assert_same(got, exp, f"seed{seed}")
 
 
+@pytest.mark.parametrize("rules", [True, False])
 @pytest.mark.parametrize("lookahead", [True, False])
 @pytest.mark.parametrize("width", [2, 8, 16])
-def test_wide_schedule_matches_its_oracle(native, oracle, width, lookahead):
+def test_wide_schedule_matches_its_oracle(native, oracle, width, lookahead, rules):
     """search_width > 1: the (config, open call)-pair-per-lane kernel against oracle/wgl_beam.c --
     verdict, failing op, witness, final state and counters, bit for bit; and the verdict /
     failing op also against the sequential oracle (they are properties of the history).  With the
     lookahead (tbc_opts.lookahead, default on) the kernel decides deadness from the per-rank records
     pack_open builds, the oracle from the definition; an invalid verdict is re-searched without it on
-    both sides, so failing op and counters of invalid histories are the exact search's."""
+    both sides, so failing op and counters of invalid histories are the exact search's.
+    rules = tbc_opts.dominance (eager reads + twin rule, the library default): the kernel absorbs reads
+    through the per-front read masks and tests twins through the per-entry twin masks of pack_open, the
+    oracle walks the open-call lists; the witness is the kernel's chain of branching calls expanded by
+    the host (tbc_api.hip) against the oracle's own replay."""
     cases = [(8, 3, 0.1, 0.5, 0.8), (40, 4, 0.05, 0.0, 0.5), (200, 8, 0.02, 0.0, 0.5), (200, 8, 0.0, 0.6, 0.3),
              (1000, 16, 0.02, 0.0, 0.5), (1000, 16, 0.0, 0.6, 0.2), (3000, 64, 0.02, 0.0, 0.1), (3000, 64, 0.0, 0.6, 0.05)]
+    if rules:   # the concurrency the rules make feasible: 6, 19 and 32 calls in flight of 64 processes
+        cases += [(2000, 64, 0.0, 0.0, 0.1), (2000, 64, 0.0, 0.0, 0.3), (2000, 64, 0.0, 0.0, 0.5), (2000, 64, 0.01, 0.0, 0.3),
+                  (1500, 64, 0.0, 0.5, 0.3)]
     hists = [columns.pair_events(synth.register_events(n_ops=n, n_procs=p, seed=s, busy=busy, info=info, corrupt=corrupt))
              for (n, p, info, corrupt, busy) in cases for s in range(3)]
-    opts = core.make_opts(time_limit_ms=60000, search_width=width, algorithm=N.ALG_COMPETITION, lookahead=lookahead)
+    opts = core.make_opts(time_limit_ms=60000, search_width=width, algorithm=N.ALG_COMPETITION, lookahead=lookahead,
+                          eager_reads=rules, twin_rule=rules)
     with core.Batch(hists, gm(), opts) as b:
         res = b.run().results()
     single = core.check_ops(hists[5], gm(), opts)
     for i, (h, got) in enumerate(zip(hists, res)):
-        exp = oracle.check_beam(h.as_dict(), CAS, width, lookahead=lookahead)
+        exp = oracle.check_beam(h.as_dict(), CAS, width, lookahead=lookahead, eager_reads=rules, twin_rule=rules, max_probes=20_000_000)
         seq = oracle.check(h.as_dict(), CAS, "window", max_steps=5_000_000, want_witness=False)
+        if exp["valid"] == -1:
+            continue
         assert got["valid"] == exp["valid"], i
         if seq["valid"] != -1:
             assert got["valid"] == seq["valid"], i
@@ -317,7 +328,8 @@ def test_against_committed_golden_fixtures(native):
     hists = [columns.pair_events(synth.register_events(**g["case"])) for g in cases]
     sha = lambda w: hashlib.sha256(np.asarray(w).astype("<u4").tobytes()).hexdigest()[:16]
     for opts, key in ((core.make_opts(time_limit_ms=60000), "sequential"),
-                      (core.make_opts(time_limit_ms=60000, algorithm=N.ALG_COMPETITION, search_width=8), "wide8")):
+                      (core.make_opts(time_limit_ms=60000, algorithm=N.ALG_COMPETITION, search_width=8, eager_reads=False, twin_rule=False), "wide8"),
+                      (core.make_opts(time_limit_ms=60000, algorithm=N.ALG_COMPETITION, search_width=8), "wide8_rules")):
         with core.Batch(hists, gm(), opts) as b:
             res = b.run().results()
         for g, got in zip(cases, res):
@@ -359,3 +371,26 @@ def test_lookahead_value_range_crashed_writers_and_plain_register(native, oracle
                     assert np.array_equal(got["witness"], exp["witness"]), (ci, width, i)
                 else:
                     assert got["fail_op"] == exp["fail_op"], (ci, width, i)
+
+
+def test_each_dominance_rule_alone(native, oracle):
+    """tbc_opts.dominance bit by bit: eager reads without the twin rule and the twin rule without eager
+    reads are schedules of their own (oracle/wgl_beam.c flags) and must match bit for bit as well."""
+    cases = [(300, 8, 0.03, 0.0, 0.5), (300, 8, 0.0, 0.5, 0.4), (1500, 32, 0.01, 0.0, 0.3), (1500, 64, 0.0, 0.0, 0.4)]
+    hists = [columns.pair_events(synth.register_events(n_ops=n, n_procs=p, seed=70 + s, busy=busy, info=info, corrupt=corrupt))
+             for (n, p, info, corrupt, busy) in cases for s in range(3)]
+    for eager, twin in ((True, False), (False, True)):
+        opts = core.make_opts(time_limit_ms=60000, search_width=4, algorithm=N.ALG_COMPETITION, eager_reads=eager, twin_rule=twin)
+        with core.Batch(hists, gm(), opts) as b:
+            res = b.run().results()
+        for i, (h, got) in enumerate(zip(hists, res)):
+            exp = oracle.check_beam(h.as_dict(), CAS, 4, eager_reads=eager, twin_rule=twin, max_probes=20_000_000)
+            if exp["valid"] == -1:
+                continue
+            assert got["valid"] == exp["valid"], (eager, twin, i)
+            assert (got["probes"], got["visited"], got["backtracks"]) == (exp["probes"], exp["visited"], exp["expanded"]), (eager, twin, i)
+            if exp["valid"] == 1:
+                assert np.array_equal(got["witness"], exp["witness"]), (eager, twin, i)
+                assert brute.check_witness(CAS, op_tuples(h), [int(x) for x in got["witness"]]) == got["final_state"]
+            else:
+                assert got["fail_op"] == exp["fail_op"], (eager, twin, i)

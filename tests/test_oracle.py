@@ -95,8 +95,12 @@ def test_committed_golden_fixtures_still_hold(native, oracle):
             assert hashlib.sha256(r["witness"].astype("<u4").tobytes()).hexdigest()[:16] == g["sequential"]["witness_sha"]
         else:
             assert r["fail_op"] == g["fail_op"]
-        w = oracle.check_beam(ops.as_dict(), m, 8)
+        w = oracle.check_beam(ops.as_dict(), m, 8, eager_reads=False, twin_rule=False)
         assert (w["probes"], w["visited"]) == (g["wide8"]["probes"], g["wide8"]["visited"])
+        w = oracle.check_beam(ops.as_dict(), m, 8)          # library default: + eager reads + twin rule
+        assert (w["probes"], w["visited"]) == (g["wide8_rules"]["probes"], g["wide8_rules"]["visited"])
+        if w["valid"] == 1:
+            assert hashlib.sha256(w["witness"].astype("<u4").tobytes()).hexdigest()[:16] == g["wide8_rules"]["witness_sha"]
 
 
 def test_lookahead_never_changes_a_verdict(oracle):
@@ -114,8 +118,8 @@ def test_lookahead_never_changes_a_verdict(oracle):
             d = columns.pair_events(synth.register_events(n_ops=n, n_procs=p, seed=500 + s, busy=busy, info=info, corrupt=corrupt)).as_dict()
             seq = oracle.check(d, m, "window", max_steps=3_000_000, want_witness=False)
             for K in (2, 16):
-                a = oracle.check_beam(d, m, K, max_probes=3_000_000, want_witness=False, lookahead=True)
-                b = oracle.check_beam(d, m, K, max_probes=3_000_000, want_witness=False, lookahead=False)
+                a = oracle.check_beam(d, m, K, max_probes=3_000_000, want_witness=False, lookahead=True, eager_reads=False, twin_rule=False)
+                b = oracle.check_beam(d, m, K, max_probes=3_000_000, want_witness=False, lookahead=False, eager_reads=False, twin_rule=False)
                 if -1 in (a["valid"], b["valid"]):
                     continue
                 assert a["valid"] == b["valid"], (n, p, s, K)
@@ -136,8 +140,8 @@ def test_lookahead_never_changes_a_verdict(oracle):
     assert late() == 0
 
 
-def test_eager_reads_rule_for_the_next_round(oracle):
-    """Specified on the CPU first (no kernel counterpart yet): a read that is viable now
+def test_dominance_rules_never_change_a_verdict(oracle):
+    """tbc_opts.dominance (eager reads, twin rule; kernel: wgl_beam.hip): a read that is viable now
     can be linearized now without loss of generality, so every child absorbs all of them.  Same verdict
     and failing op as the plain search, witnesses that replay legally under the independent checker,
     and far less work with no heavy tail."""
@@ -148,7 +152,7 @@ def test_eager_reads_rule_for_the_next_round(oracle):
         for s in range(10 if n <= 300 else 4):
             ops = columns.pair_events(synth.register_events(n_ops=n, n_procs=p, seed=300 + s, busy=busy, info=info, corrupt=corrupt))
             d = ops.as_dict()
-            plain = oracle.check_beam(d, m, 4, max_probes=3_000_000, lookahead=False)
+            plain = oracle.check_beam(d, m, 4, max_probes=3_000_000, lookahead=False, eager_reads=False, twin_rule=False)
             for la, twin in ((False, False), (True, False), (True, True)):
                 # twin rule: of several open calls with the same effect the one completing first goes first
                 e = oracle.check_beam(d, m, 4, max_probes=3_000_000, lookahead=la, eager_reads=True, twin_rule=twin)
@@ -161,6 +165,6 @@ def test_eager_reads_rule_for_the_next_round(oracle):
                     w = [int(x) for x in e["witness"]]
                     assert brute.check_witness(m, op_tuples(ops), w) == e["final_state"], (n, p, s, la)
     big = columns.pair_events(synth.register_events(n_ops=10000, n_procs=64, seed=3659, busy=0.1)).as_dict()   # hardest of 4,096 seeds
-    a = oracle.check_beam(big, m, 4, want_witness=False)
-    b = oracle.check_beam(big, m, 4, want_witness=False, eager_reads=True)
+    a = oracle.check_beam(big, m, 4, want_witness=False, eager_reads=False, twin_rule=False)
+    b = oracle.check_beam(big, m, 4, want_witness=False, eager_reads=True, twin_rule=False)
     assert a["valid"] == b["valid"] == 1 and b["rounds"] * 4 < a["rounds"]
