@@ -100,7 +100,9 @@ def test_wide_schedule_matches_its_oracle(native, oracle, width, lookahead, rule
         if seq["valid"] != -1:
             assert got["valid"] == seq["valid"], i
         if exp["valid"] == 0:
-            assert got["fail_op"] == exp["fail_op"] == seq["fail_op"], i
+            assert got["fail_op"] == exp["fail_op"], i
+            if seq["valid"] != -1:
+                assert got["fail_op"] == seq["fail_op"], i
             assert got["prev_ok_op"] == (None if exp["prev_ok_op"] == N.NO_OP else exp["prev_ok_op"]), i
         if exp["valid"] == 1:
             assert got["final_state"] == exp["final_state"], i
