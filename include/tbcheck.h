@@ -311,6 +311,21 @@ tbc_status tbc_batch_last_timing(const tbc_batch* b, uint64_t ns[4]);
 /* sum of tbc_counters over the last run (probes, visited ...) */
 tbc_status tbc_batch_last_counters(const tbc_batch* b, tbc_counters* out);
 uint64_t tbc_batch_device_bytes(const tbc_batch* b);
+/* how the last run was answered when the level sweep (knossos.linear; jit_sweep.hip) is in play:
+ * TBC_ALG_LINEAR always asks for it, TBC_ALG_COMPETITION on small batches that want no witness.
+ * The sweep cuts a history into segments of about seg_target completions at fronts with at most
+ * cut_open open calls and sweeps them concurrently; histories it cannot finish (a config set
+ * outgrows on-chip memory, > 64 process slots, set / bank) are answered by the depth-first
+ * search instead -- tbc_result.analyzer says which (TBC_ALG_LINEAR = the sweep). */
+typedef struct tbc_sweep_info {
+  uint32_t enabled;       /* this batch runs the sweep first                              */
+  uint32_t seg_target;    /* wanted segment length in completions (0 = one segment)       */
+  uint32_t max_segs;      /* segments per history at most                                 */
+  uint32_t cut_open;      /* a cut needs at most this many open calls                     */
+  uint32_t n_segments;    /* last run: segments swept                                     */
+  uint32_t n_fallback;    /* last run: histories handed to the depth-first search         */
+} tbc_sweep_info;
+tbc_status tbc_batch_sweep_info(const tbc_batch* b, tbc_sweep_info* out);
 void tbc_batch_destroy(tbc_batch* b);
 
 /* ----------------------------------------------------------------- memo

@@ -99,6 +99,11 @@ class BatchDesc(C.Structure):
                 ("n_process", C.POINTER(C.c_uint32)), ("cols", Ops), ("model_aux", C.POINTER(C.c_int32))]
 
 
+class SweepInfo(C.Structure):
+    _fields_ = [("enabled", C.c_uint32), ("seg_target", C.c_uint32), ("max_segs", C.c_uint32),
+                ("cut_open", C.c_uint32), ("n_segments", C.c_uint32), ("n_fallback", C.c_uint32)]
+
+
 class SynthParams(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("n_ops", C.c_uint32), ("n_procs", C.c_uint32), ("n_values", C.c_uint32),
                 ("busy_permille", C.c_uint32), ("info_permille", C.c_uint32), ("read_permille", C.c_uint32),
@@ -119,6 +124,7 @@ SYMBOLS = {
     "tbc_batch_last_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "tbc_batch_last_counters": (C.c_int, [C.c_void_p, C.POINTER(Counters)]),
     "tbc_batch_device_bytes": (C.c_uint64, [C.c_void_p]),
+    "tbc_batch_sweep_info": (C.c_int, [C.c_void_p, C.POINTER(SweepInfo)]),
     "tbc_batch_destroy": (None, [C.c_void_p]),
     "tbc_memo_build": (C.c_int, [C.c_int64, C.c_uint32, STEP_FN, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint16),
                                  C.POINTER(C.c_int64), C.POINTER(C.c_uint32)]),

@@ -160,6 +160,11 @@ class Batch:
         N.check_status(N.lib().tbc_batch_last_counters(self._h, C.byref(c)))
         return {k: getattr(c, k) for k, _ in N.Counters._fields_}
 
+    def sweep_info(self):
+        i = N.SweepInfo()
+        N.check_status(N.lib().tbc_batch_sweep_info(self._h, C.byref(i)))
+        return {k: getattr(i, k) for k, _ in N.SweepInfo._fields_}
+
     def device_bytes(self):
         return int(N.lib().tbc_batch_device_bytes(self._h))
 

@@ -1,0 +1,433 @@
+// jit_sweep.hip -- K6: knossos.linear/analysis as a SEGMENTED LEVEL SWEEP (gfx950).
+//
+// Lowe's just-in-time linearization (the algorithm behind knossos.linear, SURVEY.md section 8a rows
+// `knossos.linear/analysis + knossos.linear.config`): sweep the completions in order carrying the SET of
+// reachable configs (mask of linearized open calls, model state); at the completion of call X every config
+// must get X linearized -- configs that have it pass, the others are expanded over their open calls until X
+// is in (sub-rounds), configs that cannot are dropped; an empty set = not linearizable at that completion.
+// The config set is kept in the normal form of the two dominance rules (tbc_internal.h: eager reads, twin
+// rule), which is what keeps it narrow: ~9 configs per level on the 10k-op / 64-process bench histories
+// where the plain sweep carries ~60 and the plain depth-first search visits 2*10^5.
+//
+// What makes it a GPU algorithm is the cut into SEGMENTS.  A depth-first search of one history is a chain
+// of >= 10^4 dependent steps whatever the hardware; the sweep's levels are just as
+// dependent -- but a level set is small enough to be started from EVERY config that is possible at a front
+// at all.  So the history is cut at fronts where at most m calls are open (sweep_cuts_kernel), each segment
+// is swept by its own wavefront from all nd * 2^m <= 32 possible configs of its first front ("origins"),
+// every config carrying the 32-bit set of origins it is reachable from (duplicates OR their sets; sub-rounds
+// go by calls linearized, so a set is final before its config is expanded), and a segment hands on a 32 x 32
+// bit relation origin -> origin of the next segment.  The host composes the relations in order (a few
+// hundred word operations).  One 10k-op history is then checked by ~150 wavefronts at once, each walking
+// ~50 levels, instead of by one wavefront walking 10^4 rounds.
+//
+// Everything a level touches lives in LDS: four config sets (this level, the next, two sub-round sets),
+// two open-addressed hash tables of entry numbers (generation-tagged, never cleared), the level's open-call
+// records and twin masks, the two read-mask rows.  HBM sees one streaming pass over the per-front lists
+// pack_open built -- no visited set, no atomics, no random access.  Exact keys throughout (a hash only
+// picks the slot).  Insertion: a lane claims an empty slot provisionally (CAS with its lane number), lanes
+// that meet a provisional slot compare with the claimant's staged key; winners are appended in lane order.
+//
+// The schedule is specified in oracle/sweep_ref.c; verdict, failing op, and the sweep's own statistics
+// (level sizes summed, largest level, expansions, sub-rounds) are compared bit for bit.  A set that
+// outgrows its LDS capacity ends the segment with status OVERFLOW and the host hands that history to the
+// wide depth-first kernel (wgl_beam.hip) -- which is what knossos.competition does with its two searches.
+#include <hip/hip_runtime.h>
+#include "tbc_internal.h"
+#include "device_common.h"
+
+namespace tbc {
+
+namespace {
+
+constexpr uint32_t kCap = kSweepCap;          // configs per set
+constexpr uint32_t kHS = 2 * kCap;            // hash slots per table
+constexpr uint32_t kCand = kSweepCandMax;     // open calls per level
+constexpr uint32_t kProv = 1u << 16;          // slot holds a lane number (this round's claimant), not an entry
+constexpr uint32_t kGenShift = 17;
+
+struct __attribute__((aligned(16))) Ent { uint32_t mlo, mhi, st, org; };
+
+__device__ __forceinline__ void lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ uint32_t key_slot(uint32_t mlo, uint32_t mhi, uint32_t st) {
+  uint32_t h = mlo * 0x9E3779B1u ^ mhi * 0x85EBCA77u ^ st * 0xC2B2AE3Du;
+  h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 13;
+  return h & (kHS - 1u);
+}
+
+// One set being built: entries + its hash table + the table's generation.
+struct Build {
+  Ent* e;
+  uint32_t* tab;
+  uint32_t n;       // wave-uniform
+  uint32_t gen;     // wave-uniform, != 0
+};
+
+// Start a new set in table `tab`: a new generation makes every old slot read as empty.
+__device__ __forceinline__ void build_begin(Build& b, Ent* e, uint32_t* tab, uint32_t& gen_counter, uint32_t lane) {
+  gen_counter++;
+  if (gen_counter >= (1u << (32 - kGenShift))) {       // generation wrapped: really clear
+    for (uint32_t i = lane; i < kHS; i += 64) tab[i] = 0u;
+    gen_counter = 1;
+    lds_sync();
+  }
+  b.e = e; b.tab = tab; b.n = 0; b.gen = gen_counter;
+}
+
+// Insert up to 64 configs (one per active lane) into the set, OR-ing origin sets of equal keys.
+// Returns false if the set outgrew kCap.
+__device__ __forceinline__ bool build_insert(Build& b, bool act, uint32_t mlo, uint32_t mhi, uint32_t st, uint32_t org,
+                                             Ent* stage, uint32_t lane) {
+  if (!__ballot(act)) return true;
+  stage[lane] = Ent{mlo, mhi, st, act ? org : 0u};
+  lds_sync();
+  const uint32_t gtag = b.gen << kGenShift;
+  uint32_t h = key_slot(mlo, mhi, st), mine = 0;
+  bool pend = act, won = false;
+  while (__ballot(pend)) {
+    if (pend) {
+      uint32_t s = b.tab[h];
+      if ((s >> kGenShift) != b.gen) {                    // empty: claim it with the lane number
+        const uint32_t old = atomicCAS(&b.tab[h], s, gtag | kProv | lane);
+        if (old == s) { won = true; mine = h; pend = false; }
+        else s = old;                                     // claimed in this very step by another lane
+      }
+      if (pend) {
+        const Ent k = (s & kProv) ? stage[s & 63u] : b.e[s & 0xFFFFu];
+        if (k.mlo == mlo && k.mhi == mhi && k.st == st) {
+          if (s & kProv) atomicOr(&stage[s & 63u].org, org); else atomicOr(&b.e[s & 0xFFFFu].org, org);
+          pend = false;
+        } else {
+          h = (h + 1u) & (kHS - 1u);
+        }
+      }
+    }
+  }
+  lds_sync();
+  const uint64_t wb = __ballot(won);
+  const uint32_t idx = b.n + (uint32_t)__popcll(wb & ((1ull << lane) - 1ull));
+  const uint32_t total = b.n + (uint32_t)__popcll(wb);
+  if (total > kCap) return false;
+  if (won) {
+    b.e[idx] = Ent{mlo, mhi, st, stage[lane].org};
+    b.tab[mine] = gtag | idx;
+  }
+  b.n = total;
+  lds_sync();
+  return true;
+}
+
+// entry number of a key in a finished set, or kNoEnt
+constexpr uint32_t kNoEnt = 0xFFFFFFFFu;
+__device__ __forceinline__ uint32_t build_find(const Build& b, uint32_t mlo, uint32_t mhi, uint32_t st) {
+  uint32_t h = key_slot(mlo, mhi, st);
+  for (uint32_t i = 0; i < kHS; i++) {
+    const uint32_t s = b.tab[h];
+    if ((s >> kGenShift) != b.gen) return kNoEnt;
+    const Ent k = b.e[s & 0xFFFFu];
+    if (k.mlo == mlo && k.mhi == mhi && k.st == st) return s & 0xFFFFu;
+    h = (h + 1u) & (kHS - 1u);
+  }
+  return kNoEnt;
+}
+
+__device__ __forceinline__ uint64_t mask_of(const Ent& e) { return (uint64_t)e.mlo | ((uint64_t)e.mhi << 32); }
+
+// LDS words per wavefront
+constexpr uint32_t kLdsWords = 4 * kCap * 4 + 2 * kHS + 64 * 4 + kCand * 4 + kCand * 2 + 2 * 32 * 2 + kCap / 2 + 64;
+
+}  // namespace
+
+// ---- cut placement: thread k of history h looks for the first front in [k*T, (k+1)*T) with at most m calls
+// open and no crashed call invoked yet (oracle/sweep_ref.c states the rule)
+__global__ __launch_bounds__(256) void sweep_cuts_kernel(SweepArgs A) {
+  const uint32_t h = blockIdx.x;
+  if (h >= A.n_hist) return;
+  const Hist* H = A.hist + h;
+  const BeamHist* B = A.bh + h;
+  const uint32_t R = H->n_ret;
+  const uint32_t* off = A.off + B->off_off;
+  const uint32_t* ncr = A.ncr + B->off_off;
+  uint32_t* cuts = A.cuts + (uint64_t)h * A.max_segs;
+  for (uint32_t k = threadIdx.x; k < A.max_segs; k += 256) {
+    uint32_t cut = kInf;
+    if (k == 0) cut = (H->status == 0 && B->status == 0 && R != 0) ? 0u : kInf;
+    else if (A.seg_target && H->status == 0 && B->status == 0) {
+      const uint64_t lo = (uint64_t)k * A.seg_target;
+      const uint64_t hi = lo + A.seg_target < R ? lo + A.seg_target : R;
+      for (uint64_t F = lo; F < hi; F++)
+        if (off[F + 1] - off[F] <= A.cut_open && ncr[F] == 0u) { cut = (uint32_t)F; break; }
+    }
+    cuts[k] = cut;
+  }
+}
+
+// ---- the sweep: one wavefront per (history, cut)
+__global__ __launch_bounds__(64) void jit_sweep_kernel(SweepArgs A) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  const uint32_t lane = threadIdx.x;
+  const uint32_t w = blockIdx.x;
+  // dump pass (A.dump_cfg): ONE wavefront re-sweeps segment (dump_hist, dump_seg) up to level stop_level and
+  // writes that level's configs reachable from the live origins -- knossos.linear's :configs of an invalid verdict
+  const bool dump = A.dump_cfg != nullptr;
+  const uint32_t h = dump ? A.dump_hist : w / A.max_segs, k = dump ? A.dump_seg : w - h * A.max_segs;
+  if (h >= A.n_hist) return;
+  const uint32_t* cuts = A.cuts + (uint64_t)h * A.max_segs;
+  SegResult* out = A.seg + (uint64_t)h * A.max_segs + k;
+  const uint32_t F0 = rfl(cuts[k]);
+  if (F0 == kInf) { if (lane == 0 && !dump) out->status = kSegNone; return; }
+  const Hist* H = A.hist + h;
+  const BeamHist* B = A.bh + h;
+  const uint32_t R = rfl(H->n_ret);
+  uint32_t F1 = R;
+  for (uint32_t k2 = k + 1; k2 < A.max_segs; k2++) { const uint32_t c = rfl(cuts[k2]); if (c != kInf) { F1 = c; break; } }
+  const uint64_t op_off = ru64(H->op_off);
+  const uint64_t off_off = ru64(B->off_off);
+  const uint32_t* off = A.off + off_off;
+  const uint32_t* ncr = A.ncr + off_off;
+  const OpRec* lst = A.lst + ru64(B->lst_off);
+  const OpRec* crashed = A.crashed + op_off;
+  const uint64_t* twn = A.twn ? A.twn + ru64(B->lst_off) : nullptr;
+  const uint32_t V = A.vpad;
+  const uint64_t* rdm = A.rdm ? A.rdm + op_off * V : nullptr;
+  const uint8_t* slot8 = A.slot8 + slot8_off(op_off, h);
+  const bool eager = (A.rules & kRuleEager) != 0u, twin = (A.rules & kRuleTwin) != 0u;
+  Model model{A.model_kind, A.table, A.n_classes, A.pool_vals, 0, A.n_keys};
+
+  // LDS carve-up
+  Ent* set0 = reinterpret_cast<Ent*>(lds);
+  Ent* set1 = set0 + kCap;
+  Ent* set2 = set1 + kCap;
+  Ent* set3 = set2 + kCap;
+  uint32_t* tab_nxt = reinterpret_cast<uint32_t*>(set3 + kCap);
+  uint32_t* tab_q = tab_nxt + kHS;
+  Ent* stage = reinterpret_cast<Ent*>(tab_q + kHS);
+  OpRec* cand = reinterpret_cast<OpRec*>(stage + 64);
+  uint64_t* cand_tw = reinterpret_cast<uint64_t*>(cand + kCand);
+  uint64_t* row_a = cand_tw + kCand;          // read masks of the current level's front
+  uint64_t* row_b = row_a + 32;               // ... of the next front
+  uint16_t* expl = reinterpret_cast<uint16_t*>(row_b + 32);   // entries of `cur` that still need X
+  uint32_t* Mrel = reinterpret_cast<uint32_t*>(expl + kCap);  // 32 words: origin -> origins of the next segment
+  for (uint32_t i = lane; i < 2 * kHS; i += 64) tab_nxt[i] = 0u;
+  if (lane < 32) Mrel[lane] = 0u;
+  lds_sync();
+  uint32_t gen_nxt = 0, gen_q = 0;
+
+  uint32_t status = kSegOk;
+  uint64_t configs_total = 0, probes = 0;
+  uint32_t subrounds = 0, max_level = 0, last_level = F0;   // last_level: lane o < 32 keeps origin o's
+
+  // read-mask row of front F into LDS (lane vi loads entry vi); all zero without the rule
+  auto load_row = [&](uint64_t* row, uint32_t F) {
+    if (lane < 32) row[lane] = (eager && lane < V && F < R) ? rdm[(uint64_t)F * V + lane] : 0ull;
+  };
+  // the level's open calls into LDS
+  auto load_cands = [&](uint32_t F, uint32_t& nlive, uint32_t& C) -> bool {
+    const uint32_t o0 = rfl(off[F]), o1 = rfl(off[F + 1]), nc = rfl(ncr[F]);
+    nlive = o1 - o0; C = nlive + nc;
+    if (C > kCand) return false;
+    for (uint32_t c = lane; c < C; c += 64) {
+      cand[c] = c < nlive ? lst[o0 + c] : crashed[c - nlive];
+      cand_tw[c] = (twin && twn && c < nlive) ? twn[o0 + c] : 0ull;
+    }
+    lds_sync();
+    if (twin && nc) {     // a crashed call's twins: every live call with its effect and the crashed ones before it
+      for (uint32_t c = nlive + lane; c < C; c += 64) {
+        const OpRec y = cand[c];
+        const uint32_t yf = y.f_slot & 0xFFu;
+        uint64_t m = 0;
+        if (yf == TBC_F_WRITE || yf == TBC_F_CAS)
+          for (uint32_t d = 0; d < c; d++) {
+            const OpRec z = cand[d];
+            if ((z.f_slot & 0xFFu) == yf && z.a == y.a && (yf != TBC_F_CAS || z.b == y.b)) m |= 1ull << ((z.f_slot >> 8) & 63u);
+          }
+        cand_tw[c] = m;
+      }
+      lds_sync();
+    }
+    return true;
+  };
+
+  // ---- origins: segment 0 starts from the initial config; every other segment from every config possible at
+  // its first front -- (state of the domain, subset of the calls open there), in normal form
+  Build cur, nxt, q;
+  Ent* cur_e = set0; Ent* nxt_e = set1; Ent* qa_e = set2; Ent* qb_e = set3;
+  uint32_t n_org = 0;
+  auto make_origins = [&](Build& dst, Ent* dst_e, uint32_t* dst_tab, uint32_t& dst_gen, uint32_t F, uint64_t* row, bool first) -> bool {
+    build_begin(dst, dst_e, dst_tab, dst_gen, lane);
+    load_row(row, F);
+    uint32_t nlive = 0, C = 0;
+    if (!load_cands(F, nlive, C)) return false;
+    lds_sync();
+    bool act; uint32_t st; uint64_t m = 0;
+    if (first) {
+      act = lane == 0; st = (uint32_t)A.init_state;
+    } else {
+      const uint32_t sub = lane & ((1u << nlive) - 1u), qd = lane >> nlive;
+      act = nlive <= 5u && lane < (A.n_dom << nlive) && lane < 32u;
+      st = qd == 0 ? (uint32_t)TBC_NIL : qd - 1u;
+      for (uint32_t c = 0; c < nlive && c < 5u; c++) if ((sub >> c) & 1u) m |= 1ull << ((cand[c].f_slot >> 8) & 63u);
+    }
+    if (eager) m |= row[0] | row[rdm_index((int32_t)st, V)];
+    if (!build_insert(dst, act, (uint32_t)m, (uint32_t)(m >> 32), st, 0u, stage, lane)) return false;
+    if (lane < dst.n && lane < 32u) dst.e[lane].org = 1u << lane;
+    lds_sync();
+    return dst.n <= 32u;
+  };
+  if (!make_origins(cur, cur_e, tab_q, gen_q, F0, row_a, k == 0)) status = kSegOverflow;
+  n_org = cur.n;
+
+  // ---- levels
+  for (uint32_t F = F0; F < F1 && status == kSegOk; F++) {
+    if (dump && F == A.stop_level) {
+      uint32_t nd = 0;
+      for (uint32_t base = 0; base < cur.n; base += 64) {
+        const uint32_t i = base + lane;
+        const Ent e = i < cur.n ? cur.e[i] : Ent{0, 0, 0, 0};
+        const bool hit = i < cur.n && (e.org & A.live_mask) != 0u;
+        const uint64_t hb = __ballot(hit);
+        const uint32_t pos = nd + (uint32_t)__popcll(hb & ((1ull << lane) - 1ull));
+        if (hit && pos < kCfgCap) {
+          A.dump_cfg[3 * pos] = (uint64_t)(F + 1u) | ((uint64_t)e.st << 32);
+          A.dump_cfg[3 * pos + 1] = mask_of(e);
+          A.dump_cfg[3 * pos + 2] = (uint64_t)TBC_NO_OP;
+        }
+        nd += (uint32_t)__popcll(hb);
+      }
+      if (lane == 0) *A.dump_count = nd;
+      return;
+    }
+    const uint32_t px = (uint32_t)slot8[F];
+    uint32_t nlive = 0, C = 0;
+    if (F != F0) {                                  // row_a / cand of F0 are in place already
+      { uint64_t* t = row_a; row_a = row_b; row_b = t; }
+      if (!load_cands(F, nlive, C)) { status = kSegOverflow; break; }
+    } else {
+      nlive = rfl(off[F + 1]) - rfl(off[F]); C = nlive + rfl(ncr[F]);
+    }
+    load_row(row_b, F + 1);
+    lds_sync();
+    const uint64_t xbit = 1ull << (px & 63u);
+    build_begin(nxt, nxt_e, tab_nxt, gen_nxt, lane);
+    // a config that has X linearized passes the completion: X's bit is cleared and the reads open at the next
+    // front are absorbed
+    auto pass = [&](bool act, uint64_t m, uint32_t st, uint32_t org) -> bool {
+      uint64_t m2 = m & ~xbit;
+      if (eager) m2 |= row_b[0] | row_b[rdm_index((int32_t)st, V)];
+      return build_insert(nxt, act, (uint32_t)m2, (uint32_t)(m2 >> 32), st, org, stage, lane);
+    };
+    // sub-round 0: pass, or remember the entry for expansion
+    uint32_t n_exp = 0;
+    for (uint32_t base = 0; base < cur.n && status == kSegOk; base += 64) {
+      const uint32_t i = base + lane;
+      const bool val = i < cur.n;
+      const Ent e = val ? cur.e[i] : Ent{0, 0, 0, 0};
+      const uint64_t m = mask_of(e);
+      const bool has = val && (m & xbit) != 0ull;
+      if (!pass(has, m, e.st, e.org)) status = kSegOverflow;
+      const uint64_t nb = __ballot(val && !has);
+      if (val && !has) expl[n_exp + (uint32_t)__popcll(nb & ((1ull << lane) - 1ull))] = (uint16_t)i;
+      n_exp += (uint32_t)__popcll(nb);
+    }
+    lds_sync();
+    // sub-rounds: expand what still needs X, (config, open call) pair per lane, G lanes per config
+    uint32_t gshift = 0;
+    while ((1u << gshift) < C) gshift++;
+    const Ent* src = cur.e;
+    uint32_t n_src = n_exp;
+    bool via_list = true;
+    Ent* q_e = qa_e; Ent* q_other = qb_e;
+    while (n_src != 0 && status == kSegOk) {
+      subrounds++;
+      build_begin(q, q_e, tab_q, gen_q, lane);
+      const uint32_t total = n_src << gshift;
+      for (uint32_t base = 0; base < total && status == kSegOk; base += 64) {
+        const uint32_t r = base + lane, ci = r >> gshift, kc = r & ((1u << gshift) - 1u);
+        const bool val = r < total && kc < C;
+        const Ent e = val ? src[via_list ? (uint32_t)expl[ci] : ci] : Ent{0, 0, 0, 0};
+        const OpRec y = val ? cand[kc] : OpRec{0, kFNone, 0, 0};
+        const uint64_t tw = val ? cand_tw[kc] : 0ull;
+        const uint64_t m = mask_of(e);
+        const uint32_t yf = y.f_slot & 0xFFu, ys = (y.f_slot >> 8) & 63u;
+        const int32_t st = (int32_t)e.st;
+        const bool viable = val && !((m >> ys) & 1ull) && !(eager && yf == TBC_F_READ) && (tw & ~m) == 0ull &&
+                            model.ok(st, yf, y.a, y.b);
+        probes += (uint64_t)__popcll(__ballot(viable));
+        const int32_t st2 = viable ? model.apply(st, yf, y.a, y.b) : st;
+        uint64_t m2 = m | (1ull << ys);
+        if (eager) m2 |= row_a[0] | row_a[rdm_index(st2, V)];
+        const bool has = viable && (m2 & xbit) != 0ull;
+        if (!pass(has, m2, (uint32_t)st2, e.org)) status = kSegOverflow;
+        if (!build_insert(q, viable && !has, (uint32_t)m2, (uint32_t)(m2 >> 32), (uint32_t)st2, e.org, stage, lane)) status = kSegOverflow;
+      }
+      src = q.e; n_src = q.n; via_list = false;
+      { Ent* t = q_e; q_e = q_other; q_other = t; }
+    }
+    if (status != kSegOk) break;
+    // level F+1 is complete
+    configs_total += nxt.n;
+    max_level = max(max_level, nxt.n);
+    {   // which origins are still alive
+      uint32_t any = 0;
+      for (uint32_t base = 0; base < nxt.n; base += 64) { const uint32_t i = base + lane; any |= i < nxt.n ? nxt.e[i].org : 0u; }
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) any |= (uint32_t)__shfl_xor((int)any, d);
+      if (lane < 32 && ((any >> lane) & 1u)) last_level = F + 1;
+    }
+    { Build t = cur; cur = nxt; nxt = t; Ent* te = cur_e; cur_e = nxt_e; nxt_e = te; }
+    // (nxt's table keeps serving the new `cur` for lookups; the next build_begin on tab_nxt retires it)
+    if (cur.n == 0) break;                           // nobody passes completion F
+  }
+
+  // ---- the relation this segment hands on
+  if (status == kSegOk && cur.n != 0) {
+    if (F1 == R) {
+      // last segment: M[o] = the final states origin o reaches, as bits (register family: nil = bit 0, value v =
+      // bit v + 1; other models: bit 0, the state itself goes out as end_state)
+      for (uint32_t base = 0; base < cur.n; base += 64) {
+        const uint32_t i = base + lane;
+        uint32_t org = i < cur.n ? cur.e[i].org : 0u;
+        const uint32_t sb = (i < cur.n && V > 1u) ? 1u << rdm_index((int32_t)cur.e[i].st, 32u) : 1u;
+        while (org) { const uint32_t o = (uint32_t)__builtin_ctz(org); atomicOr(&Mrel[o], sb); org &= org - 1u; }
+      }
+    } else {
+      // number the end configs as origins of the next segment (same enumeration, same order of insertion)
+      Build nx;
+      uint32_t* spare_tab = cur.tab == tab_nxt ? tab_q : tab_nxt;
+      uint32_t& spare_gen = cur.tab == tab_nxt ? gen_q : gen_nxt;
+      if (!make_origins(nx, qa_e, spare_tab, spare_gen, F1, row_a, false)) status = kSegOverflow;
+      for (uint32_t base = 0; base < cur.n && status == kSegOk; base += 64) {
+        const uint32_t i = base + lane;
+        const bool val = i < cur.n;
+        const Ent e = val ? cur.e[i] : Ent{0, 0, 0, 0};
+        const uint32_t idx = val ? build_find(nx, e.mlo, e.mhi, e.st) : 0u;
+        if (__ballot(val && idx == kNoEnt)) { status = kSegOverflow; break; }    // a reachable config must be an origin
+        uint32_t org = val ? e.org : 0u;
+        while (org) { const uint32_t o = (uint32_t)__builtin_ctz(org); atomicOr(&Mrel[o], 1u << idx); org &= org - 1u; }
+      }
+    }
+  }
+  lds_sync();
+  if (dump) return;
+  if (lane < 32) { out->M[lane] = Mrel[lane]; out->last_level[lane] = last_level; }
+  if (lane == 0) {
+    out->status = status; out->F0 = F0; out->F1 = F1; out->n_org = n_org;
+    out->max_level = max_level; out->subrounds = subrounds; out->configs_total = configs_total; out->probes = probes;
+    out->n_end = cur.n; out->end_state = (status == kSegOk && cur.n) ? cur.e[0].st : 0u;
+  }
+}
+
+void launch_sweep(const SweepArgs& a, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (a.dump_cfg) {        // cuts are in place from the sweep proper
+    hipLaunchKernelGGL(jit_sweep_kernel, dim3(1), dim3(64), kLdsWords * 4, s, a);
+    return;
+  }
+  hipLaunchKernelGGL(sweep_cuts_kernel, dim3(a.n_hist), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(jit_sweep_kernel, dim3(a.n_hist * a.max_segs), dim3(64), kLdsWords * 4, s, a);
+}
+
+}  // namespace tbc

@@ -189,27 +189,38 @@ __global__ __launch_bounds__(256) void pack_open_kernel(PackOpenArgs A) {
       uint64_t* twn = A.twn + B->lst_off * MW;
       for (uint32_t fr = tid; fr < R; fr += 256) {
         const uint32_t o0 = ld_agent(&off[fr]), o1 = ld_agent(&off[fr + 1]);
-        for (uint32_t vi = 0; vi < V; vi++) {
-          uint64_t m[4] = {0, 0, 0, 0};
-          for (uint32_t c = o0; c < o1; c++) {
-            const OpRec x = lst[c];
-            const uint32_t xs = (x.f_slot >> 8) & kSlotMask;
-            if ((x.f_slot & 0xFFu) == TBC_F_READ && rdm_index(x.a, V) == vi && (vi != 0 || x.a == TBC_NIL)) m[xs >> 6] |= 1ull << (xs & 63u);
+        uint64_t* row = rdm + (uint64_t)fr * V * MW;
+        for (uint32_t e = 0; e < V * MW; e++) row[e] = 0ull;
+        // one pass over the front's list: reads go into the row (this thread's own words: plain read-modify-
+        // write); writes / cas leave a signature bit per effect -- two calls on one bit MAY be twins
+        uint64_t sig = 0ull;
+        bool maybe_twins = false;
+        for (uint32_t c = o0; c < o1; c++) {
+          const OpRec x = lst[c];
+          const uint32_t xf = x.f_slot & 0xFFu, xs = (x.f_slot >> 8) & kSlotMask;
+          if (xf == TBC_F_READ) {
+            const uint32_t vi = rdm_index(x.a, V);
+            if (vi != 0 || x.a == TBC_NIL) row[vi * MW + (xs >> 6)] |= 1ull << (xs & 63u);
+          } else if (xf == TBC_F_WRITE || xf == TBC_F_CAS) {
+            const uint64_t bit = 1ull << (((uint32_t)x.a * 7u + (xf == TBC_F_CAS ? (uint32_t)x.b * 13u + 31u : 0u)) & 63u);
+            maybe_twins = maybe_twins || (sig & bit) != 0ull;
+            sig |= bit;
           }
-          for (uint32_t w = 0; w < MW; w++) rdm[((uint64_t)fr * V + vi) * MW + w] = m[w];
         }
         for (uint32_t c = o0; c < o1; c++) {
-          const OpRec y = lst[c];
-          const uint32_t yf = y.f_slot & 0xFFu;
           uint64_t m[4] = {0, 0, 0, 0};
-          if (yf == TBC_F_WRITE || yf == TBC_F_CAS) {
-            const uint32_t yr = sc_ret[y.op];
-            for (uint32_t d = o0; d < o1; d++) {
-              if (d == c) continue;
-              const OpRec z = lst[d];
-              if ((z.f_slot & 0xFFu) != yf || z.a != y.a || (yf == TBC_F_CAS && z.b != y.b)) continue;
-              const uint32_t zr = sc_ret[z.op];
-              if (zr < yr || (zr == yr && z.op < y.op)) { const uint32_t zs = (z.f_slot >> 8) & kSlotMask; m[zs >> 6] |= 1ull << (zs & 63u); }
+          if (maybe_twins) {
+            const OpRec y = lst[c];
+            const uint32_t yf = y.f_slot & 0xFFu;
+            if (yf == TBC_F_WRITE || yf == TBC_F_CAS) {
+              const uint32_t yr = sc_ret[y.op];
+              for (uint32_t d = o0; d < o1; d++) {
+                if (d == c) continue;
+                const OpRec z = lst[d];
+                if ((z.f_slot & 0xFFu) != yf || z.a != y.a || (yf == TBC_F_CAS && z.b != y.b)) continue;
+                const uint32_t zr = sc_ret[z.op];
+                if (zr < yr || (zr == yr && z.op < y.op)) { const uint32_t zs = (z.f_slot >> 8) & kSlotMask; m[zs >> 6] |= 1ull << (zs & 63u); }
+              }
             }
           }
           for (uint32_t w = 0; w < MW; w++) twn[(uint64_t)c * MW + w] = m[w];

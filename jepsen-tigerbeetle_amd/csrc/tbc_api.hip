@@ -151,6 +151,13 @@ struct tbc_batch {
   DevBuf<uint64_t> d_look;          // lookahead records per completion rank
   DevBuf<uint32_t> d_dstack;        // second stack per history: configs the lookahead set aside
   DevBuf<uint32_t> d_looktmp;
+  // level sweep (jit_sweep.hip): TBC_ALG_LINEAR, and TBC_ALG_COMPETITION on small batches that want no witness
+  bool sweep = false;
+  uint32_t max_segs = 1, seg_target = 0, cut_open = 0, n_dom = 1;
+  DevBuf<uint32_t> d_cuts;
+  DevBuf<SegResult> d_sres;
+  std::vector<SegResult> seg_host;
+  uint32_t last_segments = 0, last_fallback = 0;
   uint32_t rules = 0;               // kRuleEager | kRuleTwin: wide single-wave schedule, register family, values 0..kMaxRuleValue
   uint32_t vpad = 0;                // entries per rdm row (nil + values), power of two
   DevBuf<uint64_t> d_twn, d_rdm;    // dominance tables (tbc_internal.h)
@@ -169,7 +176,7 @@ struct tbc_batch {
     d_bitmap.release(); d_wpre.release(); d_frames.release(); d_witness.release(); d_work.release();
     d_queue.release(); d_tab.release(); d_results.release(); d_table.release(); d_pool_vals.release(); d_cfg.release();
     d_bh.release(); d_off.release(); d_ncr.release(); d_lst.release(); d_crashed.release(); d_stack.release();
-    d_occ.release(); d_btab.release(); d_slot8.release(); d_look.release(); d_looktmp.release(); d_twn.release(); d_rdm.release(); d_dstack.release(); d_pool.release(); d_pool_cursor.release();
+    d_occ.release(); d_btab.release(); d_slot8.release(); d_look.release(); d_looktmp.release(); d_twn.release(); d_rdm.release(); d_cuts.release(); d_sres.release(); d_dstack.release(); d_pool.release(); d_pool_cursor.release();
     for (auto& e : ev) if (e) (void)hipEventDestroy(e);
     if (stream) (void)hipStreamDestroy(stream);
   }
@@ -244,9 +251,21 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
     if (B->mask_words > 4) { set_error("set / bank: at most 256 processes (incl. crashed) on the device"); return TBC_ERR_WINDOW_TOO_WIDE; }
     if (width < 2) width = 4;
   }
+  // knossos.linear = the level sweep; knossos.competition takes it when nobody asked for a witness or a
+  // particular schedule and the batch is small enough to be latency-bound (a big batch is throughput-bound:
+  // the wide depth-first kernel does less work per history).  It needs a state-carrying model and <= 64 slots;
+  // a history it cannot finish (a level outgrows LDS) goes to the wide kernel.
+  {
+    const char* env = std::getenv("TBC_SWEEP");          // 0 = never, 1 = whenever possible (experiments)
+    const bool forced = env && env[0] == '1', never = env && env[0] == '0';
+    const bool asked = opts->algorithm == TBC_ALG_LINEAR ||
+                       (opts->algorithm == TBC_ALG_COMPETITION && !opts->want_witness && opts->search_width == 0 && nh <= 256);
+    B->sweep = !never && (asked || forced) && !commutative && B->mask_words == 1 && width <= 16;
+    if (B->sweep && width < 2) width = 4;                // the fallback's schedule; the per-front lists are the wide kernel's
+  }
   B->width = width;
   B->wg = width > 16;
-  B->lookahead = width > 1 && width <= 16 && opts->lookahead != 1 &&
+  B->lookahead = !B->sweep && width > 1 && width <= 16 && opts->lookahead != 1 &&
                  (model->kind == TBC_MODEL_REGISTER || model->kind == TBC_MODEL_CAS_REGISTER);
   const bool beam = width > 1;
   // dominance rules: same scope as the lookahead, and every register value must index the per-front read table
@@ -260,11 +279,30 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
       if (c.f[i] == TBC_F_CAS) { const int32_t b = c.b[i]; in_range = in_range && b >= 0; vmax = std::max(vmax, b); }
     }
     if (in_range && vmax <= kMaxRuleValue) {
+      B->n_dom = (uint32_t)(vmax + 2);                   // nil + 0..vmax: the states a register can be in
       B->rules = ((opts->dominance & TBC_DOM_NO_EAGER_READS) ? 0u : kRuleEager) | ((opts->dominance & TBC_DOM_NO_TWIN_RULE) ? 0u : kRuleTwin);
       B->vpad = 2; while (B->vpad < (uint32_t)(vmax + 2)) B->vpad <<= 1;
     }
   }
   const uint32_t EW = B->wg ? beam_wg_entry_words(B->mask_words) : B->mask_words + 2;   // u64 words per wide-schedule entry
+  if (B->sweep) {
+    // segments: enough wavefronts to fill the GPU several times over, none shorter than 32 completions; cuts need the
+    // register family's value domain (nil + 0..vmax = vpad's range) to enumerate the configs possible at a front
+    uint64_t max_n = 1;
+    for (uint32_t h = 0; h < nh; h++) max_n = std::max<uint64_t>(max_n, desc->op_off[h + 1] - desc->op_off[h]);
+    const char* env = std::getenv("TBC_SWEEP_SEG");
+    uint64_t T = env ? std::strtoull(env, nullptr, 10) : std::max<uint64_t>(32, (max_n * nh + 4095) / 4096);
+    const bool regfam = model->kind == TBC_MODEL_REGISTER || model->kind == TBC_MODEL_CAS_REGISTER;
+    if (!regfam || B->vpad == 0 || T == 0 || T >= max_n) { B->seg_target = 0; B->max_segs = 1; }
+    else {
+      B->seg_target = (uint32_t)T;
+      B->max_segs = (uint32_t)std::min<uint64_t>(kSweepMaxSegs, (max_n + T - 1) / T);
+      // the last window takes whatever the cap leaves over: raise T if the cap bites
+      while ((uint64_t)B->max_segs * B->seg_target < max_n) B->seg_target++;
+      B->cut_open = 0;
+      while (B->cut_open < 3 && (B->n_dom << (B->cut_open + 1)) <= 32) B->cut_open++;
+    }
+  }
 
   const uint64_t default_cap_bytes = 1ull << 30;
   const uint64_t max_bytes = opts->max_visited_bytes ? opts->max_visited_bytes : default_cap_bytes;
@@ -309,6 +347,7 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
     }
   }
 
+  if (B->sweep) { bstack_n = 0; btab_n = 0; }     // the sweep has no visited set; its fallback takes scratch arenas
   tbc_status s;
   const uint64_t T = B->total_ops;
   if ((s = B->d_f.alloc(T)) || (s = B->d_a.alloc(T)) || (s = B->d_b.alloc(T)) || (s = B->d_proc.alloc(T)) ||
@@ -324,6 +363,8 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
         (s = B->d_slot8.alloc(slot8_bytes(T, nh))) || (s = B->d_stack.alloc(bstack_n)) || (s = B->d_btab.alloc(btab_n * EW)) ||
         (s = B->d_pool_cursor.alloc(1)))
       return s;
+    if (B->sweep && ((s = B->d_cuts.alloc((uint64_t)nh * B->max_segs)) || (s = B->d_sres.alloc((uint64_t)nh * B->max_segs)))) return s;
+    if (B->sweep) B->seg_host.resize((size_t)nh * B->max_segs);
     if (B->rules && ((s = B->d_twn.alloc(blst_n * B->mask_words)) || (s = B->d_rdm.alloc(T * B->vpad * B->mask_words)))) return s;
     if (B->lookahead && ((s = B->d_look.alloc(look_words(T, nh, B->mask_words))) || (s = B->d_looktmp.alloc(T)) ||
                          (s = B->d_dstack.alloc(bstack_n)))) return s;
@@ -333,6 +374,7 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
       for (uint32_t h = 0; h < nh; h++) biggest = std::max<uint64_t>(biggest, 1ull << B->bh[h].tab_log2);
       uint64_t words = std::max<uint64_t>(btab_n * EW * 3 / 10, biggest * (4 + 16 + 4) * (EW + 1));
       words = std::min<uint64_t>(words, (32ull << 30) / 8);
+      if (B->sweep) words = 1;
       if ((s = B->d_pool.alloc(words))) return s;
     }
   }
@@ -666,7 +708,17 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results) {
   SYNC_TRACE("pack");
   HIP_TRY(hipEventRecord(B->ev[2], s));
 
-  if (beam) {
+  SweepArgs swa{};
+  if (B->sweep) {
+    swa.hist = B->d_hist.p; swa.bh = B->d_bh.p; swa.off = B->d_off.p; swa.ncr = B->d_ncr.p; swa.lst = B->d_lst.p;
+    swa.crashed = B->d_crashed.p; swa.twn = B->rules ? B->d_twn.p : nullptr; swa.rdm = B->rules ? B->d_rdm.p : nullptr;
+    swa.slot8 = B->d_slot8.p; swa.cuts = B->d_cuts.p; swa.seg = B->d_sres.p; swa.table = B->d_table.p;
+    swa.pool_vals = B->d_pool_vals.p; swa.n_hist = nh; swa.max_segs = B->max_segs; swa.seg_target = B->seg_target;
+    swa.cut_open = B->cut_open; swa.n_dom = B->n_dom; swa.vpad = B->vpad ? B->vpad : 1; swa.rules = B->rules;
+    swa.model_kind = B->model.kind; swa.init_state = B->model.kind == TBC_MODEL_MUTEX ? 0 : B->model.init;
+    swa.n_classes = B->model.n_classes; swa.n_keys = B->model.n_keys;
+    launch_sweep(swa, s);
+  } else if (beam) {
     BeamArgs ba = make_beam_args(B, B->d_btab.p, B->d_stack.p, B->d_dstack.p, nh);
     if (B->wg ? !launch_beam_wg(ba, B->mask_words, nh, s) : !launch_beam(ba, B->mask_words, search_blocks(nh), s)) { set_error("unsupported mask width"); return TBC_ERR_UNSUPPORTED; }
   } else {
@@ -677,7 +729,8 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results) {
   TRACE("run: search launched");
   SYNC_TRACE("search");
   HIP_TRY(hipEventRecord(B->ev[3], s));
-  HIP_TRY(hipMemcpyAsync(B->res_host.data(), B->d_results.p, nh * sizeof(DevResult), hipMemcpyDeviceToHost, s));
+  if (!B->sweep) HIP_TRY(hipMemcpyAsync(B->res_host.data(), B->d_results.p, nh * sizeof(DevResult), hipMemcpyDeviceToHost, s));
+  else HIP_TRY(hipMemcpyAsync(B->seg_host.data(), B->d_sres.p, B->seg_host.size() * sizeof(SegResult), hipMemcpyDeviceToHost, s));
   std::vector<Hist> hist_back(nh);
   std::vector<BeamHist> bh_back(beam ? nh : 0);
   HIP_TRY(hipMemcpyAsync(hist_back.data(), B->d_hist.p, nh * sizeof(Hist), hipMemcpyDeviceToHost, s));
@@ -688,9 +741,74 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results) {
   const uint64_t max_bytes = B->opts.max_visited_bytes ? B->opts.max_visited_bytes : (1ull << 30);
   std::vector<uint32_t> final_log2(nh);
   std::vector<uint8_t> is_seq(nh, beam ? 0 : 1);       // which kernel owns the history's result
+  std::vector<uint8_t> by_sweep(nh, 0);                // answered by the level sweep (analyzer :linear)
   for (uint32_t h = 0; h < nh; h++) final_log2[h] = beam ? B->bh[h].tab_log2 : B->hist[h].tab_log2;
   HIP_TRY(hipEventRecord(B->ev[4], s));
   bool touched_work = false;
+  if (B->sweep) {
+    // compose the segments' relations in order; what the sweep could not finish goes to the wide kernel
+    std::vector<uint32_t> fb, lg;
+    for (uint32_t h = 0; h < nh; h++) {
+      DevResult& d = B->res_host[h];
+      std::memset(&d, 0, sizeof d);
+      d.fail_op = TBC_NO_OP; d.prev_ok_op = TBC_NO_OP; d.final_state = B->model.init;
+      if (hist_back[h].status != 0) { d.valid = TBC_UNKNOWN; continue; }
+      if (hist_back[h].n_ret == 0) { d.valid = TBC_VALID; by_sweep[h] = 1; continue; }
+      const SegResult* sg = &B->seg_host[(size_t)h * B->max_segs];
+      bool give_up = bh_back[h].status != 0;
+      uint32_t live = 1u, fail_seg = kInf, fail_level = 0;
+      bool ended = false;
+      for (uint32_t k = 0; k < B->max_segs && !give_up && fail_seg == kInf; k++) {
+        const SegResult& g = sg[k];
+        if (g.status == kSegNone) continue;
+        if (g.status != kSegOk) { give_up = true; break; }
+        d.steps += g.probes; d.probes += g.probes; d.visited += g.configs_total; d.backtracks += g.subrounds;
+        d.max_depth = std::max<uint64_t>(d.max_depth, g.max_level);
+        uint32_t next = 0, reached = g.F0;
+        for (uint32_t o = 0; o < 32; o++) if ((live >> o) & 1u) { next |= g.M[o]; reached = std::max(reached, g.last_level[o]); }
+        if (next == 0) { fail_seg = k; fail_level = reached; }
+        live = next;
+        ended = g.F1 == hist_back[h].n_ret;
+      }
+      if (give_up || (fail_seg == kInf && !ended)) { fb.push_back(h); lg.push_back(B->bh[h].tab_log2); continue; }
+      by_sweep[h] = 1;
+      if (fail_seg == kInf) {
+        d.valid = TBC_VALID;
+        const bool regfam = B->model.kind == TBC_MODEL_REGISTER || B->model.kind == TBC_MODEL_CAS_REGISTER;
+        if (regfam && B->vpad > 1) { const uint32_t sb = (uint32_t)__builtin_ctz(live); d.final_state = sb == 0 ? TBC_NIL : (int32_t)sb - 1; }
+        else for (uint32_t k = B->max_segs; k-- > 0;) if (sg[k].status == kSegOk) { d.final_state = (int32_t)sg[k].end_state; break; }
+        continue;
+      }
+      d.valid = TBC_INVALID; d.max_front = fail_level;
+      const uint32_t first = fail_level ? fail_level - 1 : 0;
+      uint32_t two[2] = {TBC_NO_OP, TBC_NO_OP};
+      HIP_TRY(hipMemcpyAsync(two, B->d_ret_op.p + hist_back[h].ret_off + first, (fail_level ? 2 : 1) * 4, hipMemcpyDeviceToHost, s));
+      // :configs = the level in front of the failing completion, restricted to what the live origins reach
+      uint32_t live_in = 1u;
+      for (uint32_t k = 0; k < fail_seg; k++) if (sg[k].status == kSegOk) {
+        uint32_t nx = 0; for (uint32_t o = 0; o < 32; o++) if ((live_in >> o) & 1u) nx |= sg[k].M[o];
+        live_in = nx;
+      }
+      SweepArgs da = swa;
+      da.dump_hist = h; da.dump_seg = fail_seg; da.stop_level = fail_level; da.live_mask = live_in;
+      da.dump_cfg = B->d_cfg.p + (uint64_t)h * kCfgCap * (2 + B->mask_words);
+      da.dump_count = &B->d_results.p[h].n_configs;
+      launch_sweep(da, s);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipMemcpyAsync(&d.n_configs, &B->d_results.p[h].n_configs, 4, hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipStreamSynchronize(s));
+      d.fail_op = fail_level ? two[1] : two[0];
+      d.prev_ok_op = fail_level ? two[0] : TBC_NO_OP;
+    }
+    B->last_fallback = (uint32_t)fb.size(); B->last_segments = 0;
+    for (const SegResult& g : B->seg_host) B->last_segments += g.status == kSegOk;
+    if (!fb.empty()) {
+      for (uint32_t h : fb) final_log2[h] = B->bh[h].tab_log2;
+      tbc_status st = scratch_pass(B, fb, lg, true, hist_back, bh_back);
+      if (st != TBC_OK) return st;
+      touched_work = true;
+    }
+  }
   // wide-schedule histories whose open-call lists did not fit: sequential kernel
   if (beam) {
     std::vector<uint32_t> fb, lg;
@@ -788,7 +906,8 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results) {
     tbc_result& r = results[h];
     std::memset(&r, 0, sizeof r);
     r.valid = d.valid; r.cause = d.cause;
-    r.analyzer = B->opts.algorithm == TBC_ALG_LINEAR ? TBC_ALG_LINEAR : TBC_ALG_WGL;
+    r.analyzer = B->sweep ? (by_sweep[h] ? TBC_ALG_LINEAR : TBC_ALG_WGL)
+                          : (B->opts.algorithm == TBC_ALG_LINEAR ? TBC_ALG_LINEAR : TBC_ALG_WGL);
     r.fail_op = TBC_NO_OP; r.prev_ok_op = TBC_NO_OP;
     if (d.valid == TBC_INVALID) {
       r.fail_op = d.fail_op; r.prev_ok_op = d.prev_ok_op;
@@ -799,7 +918,8 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results) {
       r.final_state = d.final_state; r.n_witness = d.depth;
       if (B->opts.want_witness) {
         r.witness = B->witness_host.data() + B->hist[h].op_off;
-        if ((B->rules & kRuleEager) && !is_seq[h] && d.depth) {
+        if (by_sweep[h]) { r.witness = nullptr; r.n_witness = 0; }      // knossos.linear returns configs, not a linearization
+        else if ((B->rules & kRuleEager) && !is_seq[h] && d.depth) {
           tbc_status ws = expand_eager_witness(B, h, r.witness, &r.n_witness);
           if (ws != TBC_OK) return ws;
         }
@@ -842,6 +962,13 @@ tbc_status tbc_batch_last_counters(const tbc_batch* b, tbc_counters* out) {
 }
 
 uint64_t tbc_batch_device_bytes(const tbc_batch* b) { return b ? b->device_bytes : 0; }
+
+tbc_status tbc_batch_sweep_info(const tbc_batch* b, tbc_sweep_info* out) {
+  if (!b || !out) return TBC_ERR_INVALID_ARG;
+  out->enabled = b->sweep ? 1u : 0u; out->seg_target = b->seg_target; out->max_segs = b->max_segs;
+  out->cut_open = b->cut_open; out->n_segments = b->last_segments; out->n_fallback = b->last_fallback;
+  return TBC_OK;
+}
 
 void tbc_batch_destroy(tbc_batch* b) {
   if (!b) return;

@@ -248,6 +248,56 @@ struct BeamArgs {
   uint32_t pad3;
 };
 
+// ---- level sweep (jit_sweep.hip): knossos.linear as segments swept by one wavefront each
+constexpr uint32_t kSweepCap = 512;        // configs per LDS set; a larger level ends the segment with kSegOverflow
+constexpr uint32_t kSweepCandMax = 128;    // open calls (live + crashed) per level held in LDS
+constexpr uint32_t kSweepMaxSegs = 512;    // cuts per history
+enum : uint32_t { kSegNone = 0, kSegOk = 1, kSegOverflow = 2 };
+struct __attribute__((aligned(8))) SegResult {
+  uint32_t status;          // kSeg*
+  uint32_t F0, F1;          // levels swept: [F0, F1)
+  uint32_t n_org;           // origins (configs possible at front F0), <= 32
+  uint32_t max_level;       // largest level
+  uint32_t subrounds;
+  uint32_t n_end;           // configs at front F1
+  uint32_t end_state;       // state of the first of them (single-origin segments of non-register models)
+  uint64_t configs_total;   // sum of the level sizes
+  uint64_t probes;          // expansions (model-consistent (config, call) pairs)
+  uint32_t M[32];           // M[o] = origins of the NEXT segment reachable from origin o (last segment: bit 0 = reaches the end)
+  uint32_t last_level[32];  // greatest level at which a config reachable from origin o existed
+};
+struct SweepArgs {
+  const Hist* hist;
+  const BeamHist* bh;
+  const uint32_t* off;
+  const uint32_t* ncr;
+  const OpRec* lst;
+  const OpRec* crashed;
+  const uint64_t* twn;       // may be null (no twin rule)
+  const uint64_t* rdm;       // may be null (no eager reads)
+  const uint8_t* slot8;
+  uint32_t* cuts;            // max_segs per history: first front of segment k, kInf = no such segment
+  SegResult* seg;            // max_segs per history
+  const uint16_t* table;
+  const int32_t* pool_vals;
+  uint32_t n_hist;
+  uint32_t max_segs;
+  uint32_t seg_target;       // wanted segment length in completions, 0 = one segment
+  uint32_t cut_open;         // m: a cut needs <= m open calls (n_dom << m <= 32)
+  uint32_t n_dom;            // states of the origin domain: nil + 0..vmax
+  uint32_t vpad;
+  uint32_t rules;
+  uint32_t model_kind;
+  int32_t init_state;
+  uint32_t n_classes;
+  uint32_t n_keys;
+  // dump pass
+  uint32_t dump_hist, dump_seg, stop_level, live_mask, pad;
+  uint64_t* dump_cfg;        // records {front + 1 | state << 32, mask, TBC_NO_OP} as SearchArgs.cfg, kCfgCap at most
+  uint32_t* dump_count;      // number of configs at that level (may exceed kCfgCap)
+};
+void launch_sweep(const SweepArgs& a, void* stream);
+
 void launch_pack_open(const PackOpenArgs& a, void* stream);
 bool launch_beam(const BeamArgs& a, uint32_t mask_words, uint32_t n_blocks, void* stream);
 // one 256-lane workgroup per history (search_width 32 / 64); entries have one more word

@@ -371,6 +371,8 @@ def analysis(model, history, algorithm="wgl", **opts):
                        time_limit_ms=int(opts.get("time-limit", opts.get("time_limit", 0)) or 0),
                        max_steps=opts.get("max-steps", opts.get("max_steps", 0)) or 0,
                        max_visited_bytes=opts.get("max-visited-bytes", opts.get("max_visited_bytes", 0)) or 0,
-                       want_witness=True)
+                       # knossos.linear / competition return configs, not a linearization: asking for one
+                       # ("witness": True) keeps the answer with the depth-first search
+                       want_witness=bool(opts.get("witness", algorithm == "wgl")))
     res = core.check_ops(enc.ops, enc.native_model, o)
     return result_map(enc, res, algorithm)

@@ -36,7 +36,7 @@
  * Segments.  The fronts are cut at C_0 = 0 < C_1 < ... < C_S = R.  Segment i sweeps levels
  * C_i .. C_(i+1) starting from EVERY config that is possible at front C_i at all -- each
  * (subset of the calls open at C_i, model state) in normal form, numbered 0..n_origins-1 -- and
- * carries with every config the set of origins it is reachable from (a 64-bit mask; duplicates OR
+ * carries with every config the set of origins it is reachable from (a 32-bit mask; duplicates OR
  * their masks -- sub-rounds go by number of calls linearized, so a config's mask is final before it
  * is expanded).  What a segment hands on is its relation {origin -> configs at front C_(i+1)}.
  * Composition walks the segments in order: live set := {initial config}; for each segment the
@@ -44,9 +44,13 @@
  * origin numbers of the next segment.  An empty live set in segment i => NOT linearizable, and
  * the failing completion is the greatest level of segment i that some live origin still reached
  * (+ C_i): per origin the sweep records the last level at which a config carrying it existed.
- * Cuts are placed at fronts where few calls are open and none is crashed-and-open ... see
- * choose_cuts below (n_origins <= 64 is required; a history that offers no such front keeps one
- * segment, which is then the plain sweep).
+ * Cuts (parallel by construction -- the kernel places each one with its own thread): with T = the
+ * wanted segment length, cut k = 1, 2, ... is the FIRST front F in [k*T, (k+1)*T) at which at most m
+ * calls are open and none of them is crashed (a crashed call stays open for ever, so there are no
+ * cuts after the first crash); a window without such a front has no cut.  The state domain of the
+ * origins is {nil, 0 .. vmax} (vmax = the greatest register value in the history or the model),
+ * nd = vmax + 2 states; m = the greatest value <= max_cut_open with nd * 2^m <= 32 (origin sets are
+ * 32-bit masks); nd > 32 => one segment.  Only the register family is cut.
  *
  * Outputs that are properties of (model, history): verdict, failing op, previous-ok op.  Outputs
  * that are properties of the sweep and compared bit for bit with the kernel: the size of every
@@ -214,34 +218,32 @@ int sweep_ref_check(uint32_t n, const uint8_t* f, const int32_t* a, const int32_
       } }
   const uint32_t save_eager = g_eager; g_eager = (uint32_t)eager_on;
 
+  /* ---- state domain of the origins: nil + 0..vmax (what the kernel's per-front read table is indexed by) */
+  int32_t vmax = model->init == O_NIL ? -1 : model->init;
+  if (regfam) for (uint32_t i = 0; i < n; i++) {
+    if (a[i] != O_NIL && a[i] > vmax) vmax = a[i];
+    if (f[i] == O_CAS && b[i] > vmax) vmax = b[i];
+  }
+  const uint32_t nd = (uint32_t)(vmax + 2);
+  uint32_t m_open = 0;
+  int cut_ok = regfam && g_seg_target && nd <= 32;
+  if (cut_ok) while (m_open < g_max_cut_open && (nd << (m_open + 1)) <= 32) m_open++;
   /* ---- cuts */
   uint32_t* cuts = (uint32_t*)malloc(4 * ((size_t)R + 2));
   uint32_t S = 0;
   cuts[S++] = 0;
-  if (g_seg_target) {
-    uint32_t next = g_seg_target;
-    for (uint32_t F = 1; F < R; F++) {
-      if (F < next) continue;
-      const uint32_t no = H.off[F + 1] - H.off[F];
-      if (no <= g_max_cut_open && H.ncr[F] == 0) { cuts[S++] = F; next = F + g_seg_target; }
+  if (cut_ok) {
+    for (uint32_t k = 1; (uint64_t)k * g_seg_target < R; k++) {
+      const uint32_t lo = k * g_seg_target, hi = lo + g_seg_target < R ? lo + g_seg_target : R;
+      for (uint32_t F = lo; F < hi; F++)
+        if (H.off[F + 1] - H.off[F] <= m_open && H.ncr[F] == 0) { cuts[S++] = F; break; }
     }
   }
   cuts[S] = R;
   st->n_segments = S;
-
-  /* ---- state domain for origins: init + everything a call can leave behind (register family) */
-  int32_t* dom = (int32_t*)malloc(4 * ((size_t)2 * n + 2)); uint32_t nd = 0;
-  dom[nd++] = model->init;
-  if (S > 1) {
-    if (!regfam) { S = 1; cuts[1] = R; st->n_segments = 1; }
-    else for (uint32_t i = 0; i < n; i++) {
-      int32_t v; int has = 0;
-      if (f[i] == O_WRITE) { v = a[i]; has = 1; } else if (f[i] == O_CAS) { v = b[i]; has = 1; }
-      if (!has) continue;
-      int seen = 0; for (uint32_t q = 0; q < nd; q++) if (dom[q] == v) { seen = 1; break; }
-      if (!seen) dom[nd++] = v;
-    }
-  }
+  int32_t* dom = (int32_t*)malloc(4 * ((size_t)nd + 1));
+  dom[0] = O_NIL;
+  for (uint32_t q = 1; q < nd; q++) dom[q] = (int32_t)q - 1;
 
   cset cur, nxt, pa, pb;
   cs_init(&cur, KW); cs_init(&nxt, KW); cs_init(&pa, KW); cs_init(&pb, KW);
@@ -259,23 +261,23 @@ int sweep_ref_check(uint32_t n, const uint8_t* f, const int32_t* a, const int32_
     /* origins of this segment: every (subset of calls open at F0, state) in normal form, de-duplicated */
     cs_clear(&cur);
     uint32_t norg = 0;
-    if (S == 1) { cs_add(&cur, live.key, 1); norg = 1; }
+    if (S == 1 || sg == 0) { cs_add(&cur, live.key, 1); norg = 1; }      /* segment 0: the initial config is the only origin */
     else {
       const uint32_t no = H.off[F0 + 1] - H.off[F0];   /* no crashed calls open at a cut */
-      for (uint32_t q = 0; q < nd && norg <= 64; q++)
-        for (uint32_t sub = 0; sub < (1u << no) && norg <= 64; sub++) {
+      for (uint32_t q = 0; q < nd && norg <= 32; q++)
+        for (uint32_t sub = 0; sub < (1u << no) && norg <= 32; sub++) {
           memset(key, 0, KW * 8);
           key[0] = (uint64_t)(uint32_t)dom[q] << 32;
           for (uint32_t c = 0; c < no; c++) if (sub >> c & 1) setb(key + 1, (uint32_t)process[H.lst[H.off[F0] + c]]);
           normalise(&H, key, F0);
-          if (cs_add(&cur, key, 0)) { if (norg < 64) cur.org[cur.n - 1] = 1ull << norg; norg++; }
+          if (cs_add(&cur, key, 0)) { if (norg < 32) cur.org[cur.n - 1] = 1ull << norg; norg++; }
         }
-      if (norg > 64) { verdict = -2; break; }            /* cut chosen badly: cannot happen with max_cut_open <= 3 and <= 8 states */
+      if (norg > 32) { verdict = -2; break; }            /* cannot happen: nd * 2^m_open <= 32 */
     }
     if (norg > st->max_origins) st->max_origins = norg;
     /* which origins are live: translate the composition's live set */
     uint64_t live_mask = 0;
-    if (S == 1) live_mask = 1;
+    if (S == 1 || sg == 0) live_mask = 1;
     else for (size_t e = 0; e < live.n; e++) {
       int found = 0;
       for (size_t q = 0; q < cur.n; q++) if (memcmp(cur.key + q * KW, live.key + e * KW, KW * 8) == 0) { live_mask |= cur.org[q]; found = 1; break; }

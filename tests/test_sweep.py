@@ -1,0 +1,110 @@
+"""The level sweep (knossos.linear/analysis; jit_sweep.hip) against its CPU statement
+(oracle/sweep_ref.c): verdict, failing op, previous-ok op and the sweep's own statistics
+(level sizes summed, largest level, expansions, sub-rounds) bit for bit, with the history cut
+into the same segments; and the verdict / failing op against the sequential WGL oracle and the
+wide depth-first oracle, which they are properties of."""
+import numpy as np
+import pytest
+
+from jepsen_tigerbeetle_amd import _native as N, columns, core, synth
+from jepsen_tigerbeetle_amd.knossos import linear, model as M, op as kop
+
+CAS = {"kind": 1, "init": N.NIL}
+
+
+def gm():
+    return core.make_model(N.MODEL_CAS_REGISTER, N.NIL)
+
+
+def test_sweep_oracle_agrees_with_the_search_oracles(oracle):
+    """CPU only: the segmented sweep, the unsegmented sweep, the sequential search and the wide search
+    give one verdict and one failing op, on valid and invalid histories, with and without crashed calls."""
+    n_cmp = 0
+    for (n, p, busy, info, corrupt) in [(40, 4, 0.5, 0.05, 0.0), (60, 8, 0.8, 0.1, 0.3), (300, 16, 0.3, 0.02, 0.0),
+                                        (300, 8, 0.4, 0.0, 0.3), (1000, 32, 0.15, 0.0, 0.0), (1000, 32, 0.15, 0.0, 0.5),
+                                        (2000, 64, 0.1, 0.0, 0.4)]:
+        for s in range(8 if n <= 300 else 3):
+            d = columns.pair_events(synth.register_events(n_ops=n, n_procs=p, seed=900 + s, busy=busy, info=info, corrupt=corrupt)).as_dict()
+            seq = oracle.check(d, CAS, "window", max_steps=3_000_000, want_witness=False)
+            if seq["valid"] == -1:
+                continue
+            one = oracle.check_sweep(d, CAS, seg_target=0)
+            assert (one["valid"], one["fail_op"], one["prev_ok_op"]) == (seq["valid"], seq["fail_op"], seq["prev_ok_op"]), (n, p, s)
+            for T in (8, 32):
+                cut = oracle.check_sweep(d, CAS, seg_target=T)
+                assert (cut["valid"], cut["fail_op"], cut["prev_ok_op"]) == (seq["valid"], seq["fail_op"], seq["prev_ok_op"]), (n, p, s, T)
+                n_cmp += cut["n_segments"] > 1
+            plain = oracle.check_sweep(d, CAS, seg_target=0, eager_reads=False, twin_rule=False, max_level=200_000)
+            if plain["valid"] != -1:      # the sweep without the rules is knossos.linear as published
+                assert (plain["valid"], plain["fail_op"]) == (seq["valid"], seq["fail_op"])
+                lin = oracle.check_linear(d, CAS, max_configs=200_000)
+                assert lin["valid"] == seq["valid"] and (lin["valid"] != 0 or lin["fail_op"] == seq["fail_op"])
+    assert n_cmp > 20
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rules", [True, False])
+def test_sweep_matches_its_oracle(native, oracle, rules):
+    cases = [(8, 3, 0.1, 0.5, 0.8), (40, 4, 0.05, 0.0, 0.5), (200, 8, 0.0, 0.0, 0.5), (200, 8, 0.0, 0.6, 0.3),
+             (1000, 16, 0.0, 0.0, 0.3), (1000, 16, 0.0, 0.6, 0.2), (3000, 64, 0.0, 0.0, 0.1), (3000, 64, 0.0, 0.6, 0.05),
+             (1000, 16, 0.01, 0.0, 0.2), (1000, 16, 0.01, 0.5, 0.2)]
+    if not rules:      # without the rules the level sets are knossos.linear's: keep them inside LDS
+        cases = [(8, 3, 0.1, 0.5, 0.8), (40, 4, 0.05, 0.0, 0.5), (200, 8, 0.0, 0.0, 0.3), (200, 8, 0.0, 0.6, 0.3), (600, 16, 0.0, 0.0, 0.1)]
+    hists = [columns.pair_events(synth.register_events(n_ops=n, n_procs=p, seed=s, busy=busy, info=info, corrupt=corrupt))
+             for (n, p, info, corrupt, busy) in cases for s in range(3)]
+    hists = [h for h in hists if h.n_process <= 64]
+    opts = core.make_opts(time_limit_ms=60000, algorithm=N.ALG_LINEAR, want_witness=False, eager_reads=rules, twin_rule=rules)
+    with core.Batch(hists, gm(), opts) as b:
+        res = b.run().results()
+        info = b.sweep_info()
+        again = b.run().results()
+    assert info["enabled"] == 1 and info["seg_target"] >= 1
+    n_sweep = 0
+    for i, (h, got) in enumerate(zip(hists, res)):
+        seq = oracle.check(h.as_dict(), CAS, "window", max_steps=5_000_000, want_witness=False)
+        if seq["valid"] != -1:
+            assert got["valid"] == seq["valid"], i
+            if seq["valid"] == 0:
+                assert got["fail_op"] == seq["fail_op"], i
+        assert (got["valid"], got["fail_op"], got["visited"], got["probes"]) == \
+               (again[i]["valid"], again[i]["fail_op"], again[i]["visited"], again[i]["probes"]), i
+        if got["analyzer"] != N.ALG_LINEAR:
+            continue                                   # handed to the depth-first search (a level outgrew LDS)
+        n_sweep += 1
+        exp = oracle.check_sweep(h.as_dict(), CAS, eager_reads=rules, twin_rule=rules, seg_target=info["seg_target"])
+        assert got["valid"] == exp["valid"], i
+        if exp["valid"] == 0:
+            assert got["fail_op"] == exp["fail_op"], i
+            assert got["prev_ok_op"] == (None if exp["prev_ok_op"] == N.NO_OP else exp["prev_ok_op"]), i
+            assert got["configs"], i
+        assert (got["visited"], got["probes"], got["backtracks"], got["max_depth"]) == \
+               (exp["configs_total"], exp["probes"], exp["subrounds"], exp["max_level"]), i
+    assert n_sweep >= len(hists) - 3
+
+
+@pytest.mark.gpu
+def test_sweep_segments_of_one_10k_history(native, oracle):
+    """BASELINE.json config 2 shape, one history: cut into > 100 segments swept concurrently, composed
+    on the host; same verdict / failing op as the sequential oracle, statistics as sweep_ref.c."""
+    for seed, corrupt in ((0, 0.0), (1, 0.0), (2, 0.6), (3, 0.3)):
+        h = columns.pair_events(synth.register_events(n_ops=10000, n_procs=64, seed=seed, busy=0.1, corrupt=corrupt))
+        with core.Batch([h], gm(), core.make_opts(algorithm=N.ALG_LINEAR, want_witness=False)) as b:
+            got = b.run().results()[0]
+            info = b.sweep_info()
+        seq = oracle.check(h.as_dict(), CAS, "window", want_witness=False)
+        assert got["valid"] == seq["valid"] and got["fail_op"] == (None if seq["valid"] else seq["fail_op"])
+        if got["analyzer"] == N.ALG_LINEAR:
+            assert info["n_segments"] > 50 or seq["valid"] == 0
+            exp = oracle.check_sweep(h.as_dict(), CAS, seg_target=info["seg_target"])
+            assert (got["visited"], got["probes"], got["backtracks"]) == (exp["configs_total"], exp["probes"], exp["subrounds"])
+
+
+@pytest.mark.gpu
+def test_linear_analysis_surface(native):
+    """knossos.linear/analysis through the mirror: :analyzer :linear, :configs on an invalid verdict."""
+    h = [kop.invoke(0, "write", 1), kop.ok(0, "write", 1), kop.invoke(1, "read", None), kop.ok(1, "read", 2)]
+    a = linear.analysis(M.cas_register(), h)
+    assert a["valid?"] is False and a["analyzer"] == "linear" and a["op"]["value"] == 2
+    assert a["configs"] and a["configs"][0]["model"] == M.CASRegister(1)
+    ok = [kop.invoke(0, "write", 1), kop.invoke(1, "read", None), kop.ok(0, "write", 1), kop.ok(1, "read", 1)]
+    assert linear.analysis(M.cas_register(), ok)["valid?"] is True
