@@ -322,6 +322,7 @@ typedef struct tbc_sweep_info {
   uint32_t seg_target;    /* wanted segment length in completions (0 = one segment)       */
   uint32_t max_segs;      /* segments per history at most                                 */
   uint32_t cut_open;      /* a cut needs at most this many open calls                     */
+  uint32_t n_dom;         /* states a segment may start in: nil + 0..greatest value of the batch */
   uint32_t n_segments;    /* last run: segments swept                                     */
   uint32_t n_fallback;    /* last run: histories handed to the depth-first search         */
 } tbc_sweep_info;

@@ -101,7 +101,7 @@ class BatchDesc(C.Structure):
 
 class SweepInfo(C.Structure):
     _fields_ = [("enabled", C.c_uint32), ("seg_target", C.c_uint32), ("max_segs", C.c_uint32),
-                ("cut_open", C.c_uint32), ("n_segments", C.c_uint32), ("n_fallback", C.c_uint32)]
+                ("cut_open", C.c_uint32), ("n_dom", C.c_uint32), ("n_segments", C.c_uint32), ("n_fallback", C.c_uint32)]
 
 
 class SynthParams(C.Structure):

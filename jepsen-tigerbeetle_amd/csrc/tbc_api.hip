@@ -966,7 +966,7 @@ uint64_t tbc_batch_device_bytes(const tbc_batch* b) { return b ? b->device_bytes
 tbc_status tbc_batch_sweep_info(const tbc_batch* b, tbc_sweep_info* out) {
   if (!b || !out) return TBC_ERR_INVALID_ARG;
   out->enabled = b->sweep ? 1u : 0u; out->seg_target = b->seg_target; out->max_segs = b->max_segs;
-  out->cut_open = b->cut_open; out->n_segments = b->last_segments; out->n_fallback = b->last_fallback;
+  out->cut_open = b->cut_open; out->n_dom = b->n_dom; out->n_segments = b->last_segments; out->n_fallback = b->last_fallback;
   return TBC_OK;
 }
 

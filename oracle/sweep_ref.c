@@ -129,6 +129,10 @@ void sweep_set_rules(uint32_t eager, uint32_t twin) { g_eager = eager; g_twin = 
 /* seg_target: wanted segment length in completions (0 = one segment); a cut is placed at the first front
  * at or after each multiple of it where at most max_cut_open calls are open and none of them is crashed */
 void sweep_set_segments(uint32_t seg_target, uint32_t max_cut_open) { g_seg_target = seg_target; g_max_cut_open = max_cut_open; }
+/* n_dom: states of the origin domain (nil + 0..n_dom-2); 0 = from the history's own greatest value.  A batch of
+ * histories shares one domain in the library (the greatest value of the whole batch). */
+static uint32_t g_n_dom = 0;
+void sweep_set_domain(uint32_t n_dom) { g_n_dom = n_dom; }
 
 typedef struct {
   uint32_t n, R, W, MW, KW;
@@ -224,7 +228,7 @@ int sweep_ref_check(uint32_t n, const uint8_t* f, const int32_t* a, const int32_
     if (a[i] != O_NIL && a[i] > vmax) vmax = a[i];
     if (f[i] == O_CAS && b[i] > vmax) vmax = b[i];
   }
-  const uint32_t nd = (uint32_t)(vmax + 2);
+  const uint32_t nd = g_n_dom ? g_n_dom : (uint32_t)(vmax + 2);
   uint32_t m_open = 0;
   int cut_ok = regfam && g_seg_target && nd <= 32;
   if (cut_ok) while (m_open < g_max_cut_open && (nd << (m_open + 1)) <= 32) m_open++;

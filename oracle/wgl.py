@@ -236,7 +236,7 @@ class SweepStats(C.Structure):
                 ("max_origins", C.c_uint64), ("max_pending", C.c_uint64)]
 
 
-def check_sweep(ops, model, eager_reads=True, twin_rule=True, seg_target=0, max_cut_open=3, max_level=0, want_levels=False):
+def check_sweep(ops, model, eager_reads=True, twin_rule=True, seg_target=0, max_cut_open=3, max_level=0, want_levels=False, n_dom=0):
     """The segmented level sweep (sweep_ref.c): knossos.linear's just-in-time linearization with the
     dominance rules, cut into independently swept segments that are composed afterwards."""
     n = len(ops["f"])
@@ -252,6 +252,7 @@ def check_sweep(ops, model, eager_reads=True, twin_rule=True, seg_target=0, max_
     L = lib()
     L.sweep_set_rules(C.c_uint32(1 if eager_reads else 0), C.c_uint32(1 if twin_rule else 0))
     L.sweep_set_segments(C.c_uint32(seg_target), C.c_uint32(max_cut_open))
+    L.sweep_set_domain(C.c_uint32(n_dom))
     rc = L.sweep_ref_check(C.c_uint32(n), _p(f, C.c_uint8), _p(a, C.c_int32), _p(b, C.c_int32),
                            _p(proc, C.c_int32), C.c_uint32(int(ops["n_process"])), _p(inv, C.c_uint32),
                            _p(ret, C.c_uint32), C.byref(m), C.c_uint64(max_level),

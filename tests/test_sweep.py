@@ -71,7 +71,7 @@ def test_sweep_matches_its_oracle(native, oracle, rules):
         if got["analyzer"] != N.ALG_LINEAR:
             continue                                   # handed to the depth-first search (a level outgrew LDS)
         n_sweep += 1
-        exp = oracle.check_sweep(h.as_dict(), CAS, eager_reads=rules, twin_rule=rules, seg_target=info["seg_target"])
+        exp = oracle.check_sweep(h.as_dict(), CAS, eager_reads=rules, twin_rule=rules, seg_target=info["seg_target"], n_dom=info["n_dom"])
         assert got["valid"] == exp["valid"], i
         if exp["valid"] == 0:
             assert got["fail_op"] == exp["fail_op"], i
@@ -95,7 +95,7 @@ def test_sweep_segments_of_one_10k_history(native, oracle):
         assert got["valid"] == seq["valid"] and got["fail_op"] == (None if seq["valid"] else seq["fail_op"])
         if got["analyzer"] == N.ALG_LINEAR:
             assert info["n_segments"] > 50 or seq["valid"] == 0
-            exp = oracle.check_sweep(h.as_dict(), CAS, seg_target=info["seg_target"])
+            exp = oracle.check_sweep(h.as_dict(), CAS, seg_target=info["seg_target"], n_dom=info["n_dom"])
             assert (got["visited"], got["probes"], got["backtracks"]) == (exp["configs_total"], exp["probes"], exp["subrounds"])
 
 
