@@ -20,12 +20,18 @@
 // hundred word operations).  One 10k-op history is then checked by ~150 wavefronts at once, each walking
 // ~50 levels, instead of by one wavefront walking 10^4 rounds.
 //
-// Everything a level touches lives in LDS: four config sets (this level, the next, two sub-round sets),
-// two open-addressed hash tables of entry numbers (generation-tagged, never cleared), the level's open-call
-// records and twin masks, the two read-mask rows.  HBM sees one streaming pass over the per-front lists
-// pack_open built -- no visited set, no atomics, no random access.  Exact keys throughout (a hash only
-// picks the slot).  Insertion: a lane claims an empty slot provisionally (CAS with its lane number), lanes
-// that meet a provisional slot compare with the claimant's staged key; winners are appended in lane order.
+// Everything a level touches lives in LDS: three config sets (this level, the next, the sub-round set -- the
+// sub-rounds alternate between the third set and the first, dead after its own expansion), two open-addressed
+// hash tables of entry numbers (generation-tagged, never cleared), the level's open-call records and twin
+// masks, the two read-mask rows.  HBM sees one streaming pass over the per-front lists pack_open built -- no
+// visited set, no global atomics, no random access -- and that pass is PREFETCHED: the records, twin masks
+// and read masks of level F+1 are requested at the top of level F and parked in registers, the per-front
+// scalars (list offsets, crashed counts, completion slots) come 64 fronts at a time, so a level waits for LDS
+// only.  Exact keys throughout (a hash only picks the slot).  Insertion: a lane claims an empty slot
+// provisionally (CAS with its lane number), lanes that meet a provisional slot compare with the claimant's
+// staged key; winners are appended in lane order; one probe loop serves both target sets of a round.
+// Two instantiations: 512 configs per set (38 KB of LDS, four wavefronts per CU) for every segment, and 2,048
+// (134 KB, one per CU) for the segments that overflowed the first.
 //
 // The schedule is specified in oracle/sweep_ref.c; verdict, failing op, and the sweep's own statistics
 // (level sizes summed, largest level, expansions, sub-rounds) are compared bit for bit.  A set that
@@ -39,8 +45,6 @@ namespace tbc {
 
 namespace {
 
-constexpr uint32_t kCap = kSweepCap;          // configs per set
-constexpr uint32_t kHS = 2 * kCap;            // hash slots per table
 constexpr uint32_t kCand = kSweepCandMax;     // open calls per level
 constexpr uint32_t kProv = 1u << 16;          // slot holds a lane number (this round's claimant), not an entry
 constexpr uint32_t kGenShift = 17;
@@ -52,10 +56,11 @@ __device__ __forceinline__ void lds_sync() {
   __builtin_amdgcn_wave_barrier();
 }
 
+template <uint32_t HS>
 __device__ __forceinline__ uint32_t key_slot(uint32_t mlo, uint32_t mhi, uint32_t st) {
   uint32_t h = mlo * 0x9E3779B1u ^ mhi * 0x85EBCA77u ^ st * 0xC2B2AE3Du;
   h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 13;
-  return h & (kHS - 1u);
+  return h & (HS - 1u);
 }
 
 // One set being built: entries + its hash table + the table's generation.
@@ -67,77 +72,85 @@ struct Build {
 };
 
 // Start a new set in table `tab`: a new generation makes every old slot read as empty.
+template <uint32_t HS>
 __device__ __forceinline__ void build_begin(Build& b, Ent* e, uint32_t* tab, uint32_t& gen_counter, uint32_t lane) {
   gen_counter++;
   if (gen_counter >= (1u << (32 - kGenShift))) {       // generation wrapped: really clear
-    for (uint32_t i = lane; i < kHS; i += 64) tab[i] = 0u;
+    for (uint32_t i = lane; i < HS; i += 64) tab[i] = 0u;
     gen_counter = 1;
     lds_sync();
   }
   b.e = e; b.tab = tab; b.n = 0; b.gen = gen_counter;
 }
 
-// Insert up to 64 configs (one per active lane) into the set, OR-ing origin sets of equal keys.
-// Returns false if the set outgrew kCap.
-__device__ __forceinline__ bool build_insert(Build& b, bool act, uint32_t mlo, uint32_t mhi, uint32_t st, uint32_t org,
-                                             Ent* stage, uint32_t lane) {
-  if (!__ballot(act)) return true;
-  stage[lane] = Ent{mlo, mhi, st, act ? org : 0u};
+// Insert up to 64 configs, one per lane, each into set A (sel 1) or set B (sel 2), OR-ing the origin sets of
+// equal keys.  Returns false if a set outgrew CAP.
+template <uint32_t CAP>
+__device__ __forceinline__ bool build_insert2(Build& A, Build& B, uint32_t sel, uint32_t mlo, uint32_t mhi, uint32_t st,
+                                              uint32_t org, Ent* stage, uint32_t lane) {
+  constexpr uint32_t HS = 2 * CAP;
+  if (!__ballot(sel != 0u)) return true;
+  stage[lane] = Ent{mlo, mhi, st, sel ? org : 0u};
   lds_sync();
-  const uint32_t gtag = b.gen << kGenShift;
-  uint32_t h = key_slot(mlo, mhi, st), mine = 0;
-  bool pend = act, won = false;
+  uint32_t* const tab = sel == 2u ? B.tab : A.tab;
+  Ent* const ent = sel == 2u ? B.e : A.e;
+  const uint32_t gen = sel == 2u ? B.gen : A.gen, gtag = gen << kGenShift;
+  uint32_t h = key_slot<HS>(mlo, mhi, st), mine = 0;
+  bool pend = sel != 0u, won = false;
   while (__ballot(pend)) {
     if (pend) {
-      uint32_t s = b.tab[h];
-      if ((s >> kGenShift) != b.gen) {                    // empty: claim it with the lane number
-        const uint32_t old = atomicCAS(&b.tab[h], s, gtag | kProv | lane);
+      uint32_t s = tab[h];
+      if ((s >> kGenShift) != gen) {                      // empty: claim it with the lane number
+        const uint32_t old = atomicCAS(&tab[h], s, gtag | kProv | lane);
         if (old == s) { won = true; mine = h; pend = false; }
         else s = old;                                     // claimed in this very step by another lane
       }
       if (pend) {
-        const Ent k = (s & kProv) ? stage[s & 63u] : b.e[s & 0xFFFFu];
+        const Ent k = (s & kProv) ? stage[s & 63u] : ent[s & 0xFFFFu];
         if (k.mlo == mlo && k.mhi == mhi && k.st == st) {
-          if (s & kProv) atomicOr(&stage[s & 63u].org, org); else atomicOr(&b.e[s & 0xFFFFu].org, org);
+          if (s & kProv) atomicOr(&stage[s & 63u].org, org); else atomicOr(&ent[s & 0xFFFFu].org, org);
           pend = false;
         } else {
-          h = (h + 1u) & (kHS - 1u);
+          h = (h + 1u) & (HS - 1u);
         }
       }
     }
   }
   lds_sync();
-  const uint64_t wb = __ballot(won);
-  const uint32_t idx = b.n + (uint32_t)__popcll(wb & ((1ull << lane) - 1ull));
-  const uint32_t total = b.n + (uint32_t)__popcll(wb);
-  if (total > kCap) return false;
+  const uint64_t wa = __ballot(won && sel == 1u), wb = __ballot(won && sel == 2u);
+  const uint64_t below = (1ull << lane) - 1ull;
+  const uint32_t idx = sel == 2u ? B.n + (uint32_t)__popcll(wb & below) : A.n + (uint32_t)__popcll(wa & below);
+  const uint32_t ta = A.n + (uint32_t)__popcll(wa), tb = B.n + (uint32_t)__popcll(wb);
+  if (ta > CAP || tb > CAP) return false;
   if (won) {
-    b.e[idx] = Ent{mlo, mhi, st, stage[lane].org};
-    b.tab[mine] = gtag | idx;
+    ent[idx] = Ent{mlo, mhi, st, stage[lane].org};
+    tab[mine] = gtag | idx;
   }
-  b.n = total;
+  A.n = ta; B.n = tb;
   lds_sync();
   return true;
 }
 
 // entry number of a key in a finished set, or kNoEnt
 constexpr uint32_t kNoEnt = 0xFFFFFFFFu;
+template <uint32_t HS>
 __device__ __forceinline__ uint32_t build_find(const Build& b, uint32_t mlo, uint32_t mhi, uint32_t st) {
-  uint32_t h = key_slot(mlo, mhi, st);
-  for (uint32_t i = 0; i < kHS; i++) {
+  uint32_t h = key_slot<HS>(mlo, mhi, st);
+  for (uint32_t i = 0; i < HS; i++) {
     const uint32_t s = b.tab[h];
     if ((s >> kGenShift) != b.gen) return kNoEnt;
     const Ent k = b.e[s & 0xFFFFu];
     if (k.mlo == mlo && k.mhi == mhi && k.st == st) return s & 0xFFFFu;
-    h = (h + 1u) & (kHS - 1u);
+    h = (h + 1u) & (HS - 1u);
   }
   return kNoEnt;
 }
 
 __device__ __forceinline__ uint64_t mask_of(const Ent& e) { return (uint64_t)e.mlo | ((uint64_t)e.mhi << 32); }
 
-// LDS words per wavefront
-constexpr uint32_t kLdsWords = 4 * kCap * 4 + 2 * kHS + 64 * 4 + kCand * 4 + kCand * 2 + 2 * 32 * 2 + kCap / 2 + 64;
+// LDS words per wavefront: 3 sets, 2 tables, stage, open-call records + twin masks, 2 read-mask rows, expansion list, relation
+template <uint32_t CAP>
+constexpr uint32_t sweep_lds_words() { return 3 * CAP * 4 + 2 * (2 * CAP) + 64 * 4 + kCand * 4 + kCand * 2 + 2 * 32 * 2 + CAP / 2 + 64; }
 
 }  // namespace
 
@@ -166,14 +179,20 @@ __global__ __launch_bounds__(256) void sweep_cuts_kernel(SweepArgs A) {
 }
 
 // ---- the sweep: one wavefront per (history, cut)
+template <uint32_t CAP>
 __global__ __launch_bounds__(64) void jit_sweep_kernel(SweepArgs A) {
+  constexpr uint32_t HS = 2 * CAP;
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   const uint32_t lane = threadIdx.x;
   const uint32_t w = blockIdx.x;
   // dump pass (A.dump_cfg): ONE wavefront re-sweeps segment (dump_hist, dump_seg) up to level stop_level and
-  // writes that level's configs reachable from the live origins -- knossos.linear's :configs of an invalid verdict
+  // writes that level's configs reachable from the live origins -- knossos.linear's :configs of an invalid verdict.
+  // second pass (A.seg_list): the listed (history, segment) pairs only (the ones that overflowed the small sets)
   const bool dump = A.dump_cfg != nullptr;
-  const uint32_t h = dump ? A.dump_hist : w / A.max_segs, k = dump ? A.dump_seg : w - h * A.max_segs;
+  uint32_t h, k;
+  if (dump) { h = A.dump_hist; k = A.dump_seg; }
+  else if (A.seg_list) { h = rfl(A.seg_list[2 * w]); k = rfl(A.seg_list[2 * w + 1]); }
+  else { h = w / A.max_segs; k = w - h * A.max_segs; }
   if (h >= A.n_hist) return;
   const uint32_t* cuts = A.cuts + (uint64_t)h * A.max_segs;
   SegResult* out = A.seg + (uint64_t)h * A.max_segs + k;
@@ -194,24 +213,21 @@ __global__ __launch_bounds__(64) void jit_sweep_kernel(SweepArgs A) {
   const uint32_t V = A.vpad;
   const uint64_t* rdm = A.rdm ? A.rdm + op_off * V : nullptr;
   const uint8_t* slot8 = A.slot8 + slot8_off(op_off, h);
-  const bool eager = (A.rules & kRuleEager) != 0u, twin = (A.rules & kRuleTwin) != 0u;
+  const bool eager = (A.rules & kRuleEager) != 0u, twin = (A.rules & kRuleTwin) != 0u && twn != nullptr;
   Model model{A.model_kind, A.table, A.n_classes, A.pool_vals, 0, A.n_keys};
 
   // LDS carve-up
-  Ent* set0 = reinterpret_cast<Ent*>(lds);
-  Ent* set1 = set0 + kCap;
-  Ent* set2 = set1 + kCap;
-  Ent* set3 = set2 + kCap;
-  uint32_t* tab_nxt = reinterpret_cast<uint32_t*>(set3 + kCap);
-  uint32_t* tab_q = tab_nxt + kHS;
-  Ent* stage = reinterpret_cast<Ent*>(tab_q + kHS);
+  Ent* sets = reinterpret_cast<Ent*>(lds);
+  uint32_t* tab_nxt = reinterpret_cast<uint32_t*>(sets + 3 * CAP);
+  uint32_t* tab_q = tab_nxt + HS;
+  Ent* stage = reinterpret_cast<Ent*>(tab_q + HS);
   OpRec* cand = reinterpret_cast<OpRec*>(stage + 64);
   uint64_t* cand_tw = reinterpret_cast<uint64_t*>(cand + kCand);
   uint64_t* row_a = cand_tw + kCand;          // read masks of the current level's front
   uint64_t* row_b = row_a + 32;               // ... of the next front
   uint16_t* expl = reinterpret_cast<uint16_t*>(row_b + 32);   // entries of `cur` that still need X
-  uint32_t* Mrel = reinterpret_cast<uint32_t*>(expl + kCap);  // 32 words: origin -> origins of the next segment
-  for (uint32_t i = lane; i < 2 * kHS; i += 64) tab_nxt[i] = 0u;
+  uint32_t* Mrel = reinterpret_cast<uint32_t*>(expl + CAP);   // 32 words: origin -> origins of the next segment
+  for (uint32_t i = lane; i < 2 * HS; i += 64) tab_nxt[i] = 0u;
   if (lane < 32) Mrel[lane] = 0u;
   lds_sync();
   uint32_t gen_nxt = 0, gen_q = 0;
@@ -220,48 +236,67 @@ __global__ __launch_bounds__(64) void jit_sweep_kernel(SweepArgs A) {
   uint64_t configs_total = 0, probes = 0;
   uint32_t subrounds = 0, max_level = 0, last_level = F0;   // last_level: lane o < 32 keeps origin o's
 
+  // ---- per-front scalars, 64 fronts at a time: lane l holds those of front wbase + l
+  uint32_t wbase = F0, w_off = 0, w_ncr = 0, w_px = 0;
+  auto load_window = [&](uint32_t base) {
+    wbase = base;
+    const uint32_t f = base + lane;
+    w_off = off[min(f, R)];
+    w_ncr = ncr[min(f, R - 1u)];
+    w_px = (uint32_t)slot8[min(f, R + 15u)];
+  };
+  load_window(F0);
+  auto need_window = [&](uint32_t F) { if (F + 2u - wbase > 63u) load_window(F); };   // F, F+1, F+2 must be inside
+  auto off_at = [&](uint32_t F) -> uint32_t { return rl(w_off, F - wbase); };
+  auto ncr_at = [&](uint32_t F) -> uint32_t { return rl(w_ncr, F - wbase); };
+  auto px_at = [&](uint32_t F) -> uint32_t { return rl(w_px, F - wbase); };
+
   // read-mask row of front F into LDS (lane vi loads entry vi); all zero without the rule
   auto load_row = [&](uint64_t* row, uint32_t F) {
     if (lane < 32) row[lane] = (eager && lane < V && F < R) ? rdm[(uint64_t)F * V + lane] : 0ull;
   };
-  // the level's open calls into LDS
-  auto load_cands = [&](uint32_t F, uint32_t& nlive, uint32_t& C) -> bool {
-    const uint32_t o0 = rfl(off[F]), o1 = rfl(off[F + 1]), nc = rfl(ncr[F]);
-    nlive = o1 - o0; C = nlive + nc;
-    if (C > kCand) return false;
-    for (uint32_t c = lane; c < C; c += 64) {
-      cand[c] = c < nlive ? lst[o0 + c] : crashed[c - nlive];
-      cand_tw[c] = (twin && twn && c < nlive) ? twn[o0 + c] : 0ull;
+  // a crashed call's twins: every live call with its effect and the crashed ones before it (the level's records are in LDS)
+  auto crashed_twins = [&](uint32_t nlive, uint32_t C) {
+    if (!(twin && C > nlive)) return;
+    for (uint32_t c = nlive + lane; c < C; c += 64) {
+      const OpRec y = cand[c];
+      const uint32_t yf = y.f_slot & 0xFFu;
+      uint64_t m = 0;
+      if (yf == TBC_F_WRITE || yf == TBC_F_CAS)
+        for (uint32_t d = 0; d < c; d++) {
+          const OpRec z = cand[d];
+          if ((z.f_slot & 0xFFu) == yf && z.a == y.a && (yf != TBC_F_CAS || z.b == y.b)) m |= 1ull << ((z.f_slot >> 8) & 63u);
+        }
+      cand_tw[c] = m;
     }
     lds_sync();
-    if (twin && nc) {     // a crashed call's twins: every live call with its effect and the crashed ones before it
-      for (uint32_t c = nlive + lane; c < C; c += 64) {
-        const OpRec y = cand[c];
-        const uint32_t yf = y.f_slot & 0xFFu;
-        uint64_t m = 0;
-        if (yf == TBC_F_WRITE || yf == TBC_F_CAS)
-          for (uint32_t d = 0; d < c; d++) {
-            const OpRec z = cand[d];
-            if ((z.f_slot & 0xFFu) == yf && z.a == y.a && (yf != TBC_F_CAS || z.b == y.b)) m |= 1ull << ((z.f_slot >> 8) & 63u);
-          }
-        cand_tw[c] = m;
-      }
-      lds_sync();
+  };
+  // the level's open calls into LDS (not prefetched: first level of a segment, and calls beyond the 64th)
+  auto load_cands = [&](uint32_t F, uint32_t from, uint32_t& nlive, uint32_t& C) -> bool {
+    const uint32_t o0 = off_at(F), o1 = off_at(F + 1u), nc = ncr_at(F);
+    nlive = o1 - o0; C = nlive + nc;
+    if (C > kCand) return false;
+    for (uint32_t c = from + lane; c < C; c += 64) {
+      cand[c] = c < nlive ? lst[o0 + c] : crashed[c - nlive];
+      cand_tw[c] = (twin && c < nlive) ? twn[o0 + c] : 0ull;
     }
+    lds_sync();
     return true;
   };
 
   // ---- origins: segment 0 starts from the initial config; every other segment from every config possible at
   // its first front -- (state of the domain, subset of the calls open there), in normal form
-  Build cur, nxt, q;
-  Ent* cur_e = set0; Ent* nxt_e = set1; Ent* qa_e = set2; Ent* qb_e = set3;
+  Ent* cur_e = sets; Ent* nxt_e = sets + CAP; Ent* q_e = sets + 2 * CAP;
+  Build cur, nxt, q, none;
+  none.e = sets; none.tab = tab_q; none.n = 0; none.gen = 0;
   uint32_t n_org = 0;
   auto make_origins = [&](Build& dst, Ent* dst_e, uint32_t* dst_tab, uint32_t& dst_gen, uint32_t F, uint64_t* row, bool first) -> bool {
-    build_begin(dst, dst_e, dst_tab, dst_gen, lane);
+    build_begin<HS>(dst, dst_e, dst_tab, dst_gen, lane);
+    need_window(F);
     load_row(row, F);
     uint32_t nlive = 0, C = 0;
-    if (!load_cands(F, nlive, C)) return false;
-    lds_sync();
+    if (!load_cands(F, 0u, nlive, C)) return false;
+    crashed_twins(nlive, C);
     bool act; uint32_t st; uint64_t m = 0;
     if (first) {
       act = lane == 0; st = (uint32_t)A.init_state;
@@ -272,13 +307,16 @@ __global__ __launch_bounds__(64) void jit_sweep_kernel(SweepArgs A) {
       for (uint32_t c = 0; c < nlive && c < 5u; c++) if ((sub >> c) & 1u) m |= 1ull << ((cand[c].f_slot >> 8) & 63u);
     }
     if (eager) m |= row[0] | row[rdm_index((int32_t)st, V)];
-    if (!build_insert(dst, act, (uint32_t)m, (uint32_t)(m >> 32), st, 0u, stage, lane)) return false;
+    Build unused = none;
+    if (!build_insert2<CAP>(dst, unused, act ? 1u : 0u, (uint32_t)m, (uint32_t)(m >> 32), st, 0u, stage, lane)) return false;
     if (lane < dst.n && lane < 32u) dst.e[lane].org = 1u << lane;
     lds_sync();
     return dst.n <= 32u;
   };
   if (!make_origins(cur, cur_e, tab_q, gen_q, F0, row_a, k == 0)) status = kSegOverflow;
   n_org = cur.n;
+  if (F0 + 1u < R) load_row(row_b, F0 + 1u); else if (lane < 32) row_b[lane] = 0ull;
+  lds_sync();
 
   // ---- levels
   for (uint32_t F = F0; F < F1 && status == kSegOk; F++) {
@@ -300,26 +338,28 @@ __global__ __launch_bounds__(64) void jit_sweep_kernel(SweepArgs A) {
       if (lane == 0) *A.dump_count = nd;
       return;
     }
-    const uint32_t px = (uint32_t)slot8[F];
-    uint32_t nlive = 0, C = 0;
-    if (F != F0) {                                  // row_a / cand of F0 are in place already
-      { uint64_t* t = row_a; row_a = row_b; row_b = t; }
-      if (!load_cands(F, nlive, C)) { status = kSegOverflow; break; }
-    } else {
-      nlive = rfl(off[F + 1]) - rfl(off[F]); C = nlive + rfl(ncr[F]);
+    need_window(F);
+    const uint32_t px = px_at(F);
+    const uint32_t nlive = off_at(F + 1u) - off_at(F), C = nlive + ncr_at(F);
+    // ---- request level F+1 now (records, twin masks) and the read masks of front F+2: they arrive while this level
+    // works in LDS and are parked in registers until its records are dead
+    const bool pre = F + 1u < F1;
+    OpRec p_rec{0, kFNone, 0, 0};
+    uint64_t p_tw = 0ull, p_row = 0ull;
+    uint32_t p_nlive = 0, p_C = 0;
+    if (pre) {
+      const uint32_t o0n = off_at(F + 1u), o1n = off_at(F + 2u);
+      p_nlive = o1n - o0n; p_C = p_nlive + ncr_at(F + 1u);
+      if (lane < p_C) {
+        p_rec = lane < p_nlive ? lst[o0n + lane] : crashed[lane - p_nlive];
+        if (twin && lane < p_nlive) p_tw = twn[o0n + lane];
+      }
+      if (lane < 32 && eager && lane < V && F + 2u < R) p_row = rdm[(uint64_t)(F + 2u) * V + lane];
     }
-    load_row(row_b, F + 1);
-    lds_sync();
     const uint64_t xbit = 1ull << (px & 63u);
-    build_begin(nxt, nxt_e, tab_nxt, gen_nxt, lane);
-    // a config that has X linearized passes the completion: X's bit is cleared and the reads open at the next
-    // front are absorbed
-    auto pass = [&](bool act, uint64_t m, uint32_t st, uint32_t org) -> bool {
-      uint64_t m2 = m & ~xbit;
-      if (eager) m2 |= row_b[0] | row_b[rdm_index((int32_t)st, V)];
-      return build_insert(nxt, act, (uint32_t)m2, (uint32_t)(m2 >> 32), st, org, stage, lane);
-    };
-    // sub-round 0: pass, or remember the entry for expansion
+    build_begin<HS>(nxt, nxt_e, tab_nxt, gen_nxt, lane);
+    // sub-round 0: a config that has X linearized passes the completion -- X's bit is cleared and the reads open at
+    // the next front are absorbed; the others are remembered for expansion
     uint32_t n_exp = 0;
     for (uint32_t base = 0; base < cur.n && status == kSegOk; base += 64) {
       const uint32_t i = base + lane;
@@ -327,22 +367,26 @@ __global__ __launch_bounds__(64) void jit_sweep_kernel(SweepArgs A) {
       const Ent e = val ? cur.e[i] : Ent{0, 0, 0, 0};
       const uint64_t m = mask_of(e);
       const bool has = val && (m & xbit) != 0ull;
-      if (!pass(has, m, e.st, e.org)) status = kSegOverflow;
+      uint64_t m2 = m & ~xbit;
+      if (eager) m2 |= row_b[0] | row_b[rdm_index((int32_t)e.st, V)];
+      Build unused = none;
+      if (!build_insert2<CAP>(nxt, unused, has ? 1u : 0u, (uint32_t)m2, (uint32_t)(m2 >> 32), e.st, e.org, stage, lane)) status = kSegOverflow;
       const uint64_t nb = __ballot(val && !has);
       if (val && !has) expl[n_exp + (uint32_t)__popcll(nb & ((1ull << lane) - 1ull))] = (uint16_t)i;
       n_exp += (uint32_t)__popcll(nb);
     }
     lds_sync();
-    // sub-rounds: expand what still needs X, (config, open call) pair per lane, G lanes per config
+    // sub-rounds: expand what still needs X, (config, open call) pair per lane, G lanes per config.  Children that
+    // have X go to level F+1, the others to the next sub-round's set -- one probe loop for both.
     uint32_t gshift = 0;
     while ((1u << gshift) < C) gshift++;
     const Ent* src = cur.e;
     uint32_t n_src = n_exp;
     bool via_list = true;
-    Ent* q_e = qa_e; Ent* q_other = qb_e;
+    Ent* dst_e = q_e; Ent* dst_other = cur_e;       // `cur` is dead once its own expansion is done
     while (n_src != 0 && status == kSegOk) {
       subrounds++;
-      build_begin(q, q_e, tab_q, gen_q, lane);
+      build_begin<HS>(q, dst_e, tab_q, gen_q, lane);
       const uint32_t total = n_src << gshift;
       for (uint32_t base = 0; base < total && status == kSegOk; base += 64) {
         const uint32_t r = base + lane, ci = r >> gshift, kc = r & ((1u << gshift) - 1u);
@@ -360,11 +404,12 @@ __global__ __launch_bounds__(64) void jit_sweep_kernel(SweepArgs A) {
         uint64_t m2 = m | (1ull << ys);
         if (eager) m2 |= row_a[0] | row_a[rdm_index(st2, V)];
         const bool has = viable && (m2 & xbit) != 0ull;
-        if (!pass(has, m2, (uint32_t)st2, e.org)) status = kSegOverflow;
-        if (!build_insert(q, viable && !has, (uint32_t)m2, (uint32_t)(m2 >> 32), (uint32_t)st2, e.org, stage, lane)) status = kSegOverflow;
+        if (has) { m2 &= ~xbit; if (eager) m2 |= row_b[0] | row_b[rdm_index(st2, V)]; }
+        if (!build_insert2<CAP>(nxt, q, viable ? (has ? 1u : 2u) : 0u, (uint32_t)m2, (uint32_t)(m2 >> 32), (uint32_t)st2, e.org, stage, lane))
+          status = kSegOverflow;
       }
       src = q.e; n_src = q.n; via_list = false;
-      { Ent* t = q_e; q_e = q_other; q_other = t; }
+      { Ent* t = dst_e; dst_e = dst_other; dst_other = t; }
     }
     if (status != kSegOk) break;
     // level F+1 is complete
@@ -377,13 +422,26 @@ __global__ __launch_bounds__(64) void jit_sweep_kernel(SweepArgs A) {
       for (int d = 32; d >= 1; d >>= 1) any |= (uint32_t)__shfl_xor((int)any, d);
       if (lane < 32 && ((any >> lane) & 1u)) last_level = F + 1;
     }
-    { Build t = cur; cur = nxt; nxt = t; Ent* te = cur_e; cur_e = nxt_e; nxt_e = te; }
-    // (nxt's table keeps serving the new `cur` for lookups; the next build_begin on tab_nxt retires it)
+    {   // the set just built becomes `cur`; the other two are free
+      Build t = cur; cur = nxt; nxt = t;
+      Ent* old_cur = cur_e; cur_e = nxt_e; nxt_e = old_cur;     // q_e keeps its place
+    }
+    // (tab_nxt keeps serving the new `cur` for lookups; the next build_begin on it retires it)
     if (cur.n == 0) break;                           // nobody passes completion F
+    // ---- park the prefetched level in LDS
+    if (pre) {
+      if (p_C > kCand) { status = kSegOverflow; break; }
+      if (lane < p_C) { cand[lane] = p_rec; cand_tw[lane] = p_tw; }
+      { uint64_t* t = row_a; row_a = row_b; row_b = t; }
+      if (lane < 32) row_b[lane] = p_row;
+      lds_sync();
+      if (p_C > 64u) { uint32_t nl, cc; need_window(F + 1u); if (!load_cands(F + 1u, 64u, nl, cc)) { status = kSegOverflow; break; } }
+      crashed_twins(p_nlive, p_C);
+    }
   }
 
   // ---- the relation this segment hands on
-  if (status == kSegOk && cur.n != 0) {
+  if (status == kSegOk && cur.n != 0 && !dump) {
     if (F1 == R) {
       // last segment: M[o] = the final states origin o reaches, as bits (register family: nil = bit 0, value v =
       // bit v + 1; other models: bit 0, the state itself goes out as end_state)
@@ -396,14 +454,12 @@ __global__ __launch_bounds__(64) void jit_sweep_kernel(SweepArgs A) {
     } else {
       // number the end configs as origins of the next segment (same enumeration, same order of insertion)
       Build nx;
-      uint32_t* spare_tab = cur.tab == tab_nxt ? tab_q : tab_nxt;
-      uint32_t& spare_gen = cur.tab == tab_nxt ? gen_q : gen_nxt;
-      if (!make_origins(nx, qa_e, spare_tab, spare_gen, F1, row_a, false)) status = kSegOverflow;
+      if (!make_origins(nx, q_e, tab_q, gen_q, F1, row_a, false)) status = kSegOverflow;
       for (uint32_t base = 0; base < cur.n && status == kSegOk; base += 64) {
         const uint32_t i = base + lane;
         const bool val = i < cur.n;
         const Ent e = val ? cur.e[i] : Ent{0, 0, 0, 0};
-        const uint32_t idx = val ? build_find(nx, e.mlo, e.mhi, e.st) : 0u;
+        const uint32_t idx = val ? build_find<HS>(nx, e.mlo, e.mhi, e.st) : 0u;
         if (__ballot(val && idx == kNoEnt)) { status = kSegOverflow; break; }    // a reachable config must be an origin
         uint32_t org = val ? e.org : 0u;
         while (org) { const uint32_t o = (uint32_t)__builtin_ctz(org); atomicOr(&Mrel[o], 1u << idx); org &= org - 1u; }
@@ -420,14 +476,24 @@ __global__ __launch_bounds__(64) void jit_sweep_kernel(SweepArgs A) {
   }
 }
 
-void launch_sweep(const SweepArgs& a, void* stream) {
+bool launch_sweep(const SweepArgs& a, void* stream) {
   hipStream_t s = (hipStream_t)stream;
-  if (a.dump_cfg) {        // cuts are in place from the sweep proper
-    hipLaunchKernelGGL(jit_sweep_kernel, dim3(1), dim3(64), kLdsWords * 4, s, a);
-    return;
+  constexpr uint32_t kSmall = kSweepCap, kBig = kSweepCapBig;
+  static bool big_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&jit_sweep_kernel<kBig>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, sweep_lds_words<kBig>() * 4) == hipSuccess;
+  if (a.dump_cfg) {        // cuts are in place from the sweep proper; the big sets hold whatever the sweep held
+    if (big_ok) hipLaunchKernelGGL(jit_sweep_kernel<kBig>, dim3(1), dim3(64), sweep_lds_words<kBig>() * 4, s, a);
+    else hipLaunchKernelGGL(jit_sweep_kernel<kSmall>, dim3(1), dim3(64), sweep_lds_words<kSmall>() * 4, s, a);
+    return true;
+  }
+  if (a.seg_list) {        // second pass over the segments that overflowed the small sets
+    if (!big_ok) return false;
+    hipLaunchKernelGGL(jit_sweep_kernel<kBig>, dim3(a.n_list), dim3(64), sweep_lds_words<kBig>() * 4, s, a);
+    return true;
   }
   hipLaunchKernelGGL(sweep_cuts_kernel, dim3(a.n_hist), dim3(256), 0, s, a);
-  hipLaunchKernelGGL(jit_sweep_kernel, dim3(a.n_hist * a.max_segs), dim3(64), kLdsWords * 4, s, a);
+  hipLaunchKernelGGL(jit_sweep_kernel<kSmall>, dim3(a.n_hist * a.max_segs), dim3(64), sweep_lds_words<kSmall>() * 4, s, a);
+  return true;
 }
 
 }  // namespace tbc

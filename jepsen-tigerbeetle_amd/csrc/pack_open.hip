@@ -20,7 +20,7 @@
 //            completing there needs, and which other calls could provide it
 //
 // This is knossos.linear.config's "pending calls by process" materialised for
-// every point of the history.  One 256-thread workgroup per
+// every point of the history.  One workgroup (256 threads in a big batch, 1,024 when a few histories must be quick) per
 // history.  off/ncr/occ arenas are zeroed by the host before the launch.
 #include <hip/hip_runtime.h>
 #include "tbc_internal.h"
@@ -36,21 +36,33 @@ __device__ __forceinline__ uint64_t ld_agent64(const uint64_t* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// in-place exclusive scan of v[0..m) by a 256-thread block; returns the total.
-// `part` is 256 words of LDS.  Every element is read and written by one thread only.
+// exclusive scan of part[0..NT) in place by the first wavefront (NT a multiple of 64): each lane scans its
+// NT/64 consecutive entries, a wavefront scan joins the lanes.  All threads call it between two barriers.
+__device__ __forceinline__ void scan_parts(uint32_t* part, uint32_t NT, uint32_t* total_slot) {
+  if (threadIdx.x < 64) {
+    const uint32_t lane = threadIdx.x, per = NT / 64, lo = lane * per;
+    uint32_t sum = 0;
+    for (uint32_t i = 0; i < per; i++) sum += part[lo + i];
+    uint32_t x = sum;
+    for (uint32_t d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(x, d); if (lane >= d) x += y; }
+    uint32_t run = x - sum;
+    for (uint32_t i = 0; i < per; i++) { const uint32_t v = part[lo + i]; part[lo + i] = run; run += v; }
+    if (lane == 63 && total_slot) *total_slot = x;
+  }
+}
+
+// in-place exclusive scan of v[0..m) by the block; returns the total.
+// `part` is blockDim.x words of LDS.  Every element is read and written by one thread only.
 __device__ uint32_t block_exclusive_scan(uint32_t* v, uint32_t m, uint32_t* part, uint32_t* total_slot) {
   const uint32_t tid = threadIdx.x;
-  const uint32_t chunk = (m + 255) / 256;
+  const uint32_t NT = blockDim.x;
+  const uint32_t chunk = (m + NT - 1) / NT;
   const uint32_t lo = min(tid * chunk, m), hi = min(lo + chunk, m);
   uint32_t sum = 0;
   for (uint32_t i = lo; i < hi; i++) sum += ld_agent(&v[i]);
   part[tid] = sum;
   __syncthreads();
-  if (tid == 0) {
-    uint32_t run = 0;
-    for (uint32_t t = 0; t < 256; t++) { uint32_t x = part[t]; part[t] = run; run += x; }
-    *total_slot = run;
-  }
+  scan_parts(part, NT, total_slot);
   __syncthreads();
   uint32_t run = part[tid];
   for (uint32_t i = lo; i < hi; i++) { uint32_t x = ld_agent(&v[i]); v[i] = run; run += x; }
@@ -69,8 +81,9 @@ __device__ __forceinline__ uint32_t look_prod(uint32_t f, int32_t a, int32_t b) 
 
 }  // namespace
 
-__global__ __launch_bounds__(256) void pack_open_kernel(PackOpenArgs A) {
-  __shared__ uint32_t s_part[256];
+__global__ __launch_bounds__(1024) void pack_open_kernel(PackOpenArgs A) {
+  __shared__ uint32_t s_part[1024];
+  const uint32_t NT = blockDim.x;
   __shared__ uint32_t s_total;
   const uint32_t tid = threadIdx.x;
   const uint32_t MW = A.mask_words;
@@ -98,8 +111,8 @@ __global__ __launch_bounds__(256) void pack_open_kernel(PackOpenArgs A) {
     uint8_t* slot8 = A.slot8 + slot8_off(H->op_off, h);
 
     // A: occupancy bits of live calls; crashed-call counts by front; completion slots as bytes
-    for (uint32_t r = tid; r < R + 16u; r += 256) slot8[r] = r < R ? (uint8_t)ret_slot[r] : (uint8_t)0;
-    for (uint32_t i = tid; i < n; i += 256) {
+    for (uint32_t r = tid; r < R + 16u; r += NT) slot8[r] = r < R ? (uint8_t)ret_slot[r] : (uint8_t)0;
+    for (uint32_t i = tid; i < n; i += NT) {
       const uint32_t ir = sc_inv[i], rr = sc_ret[i];
       const uint32_t p = (uint32_t)proc[i];
       if (rr == kInf) {
@@ -112,7 +125,7 @@ __global__ __launch_bounds__(256) void pack_open_kernel(PackOpenArgs A) {
     }
     __syncthreads();
     // B: live count per front -> off[F+1]; then exclusive scan -> CSR offsets
-    for (uint32_t fr = tid; fr < R; fr += 256) {
+    for (uint32_t fr = tid; fr < R; fr += NT) {
       uint32_t c = 0;
       for (uint32_t w = 0; w < MW; w++) c += __popcll(ld_agent64(&occ[(uint64_t)fr * MW + w]));
       off[fr] = c;
@@ -124,16 +137,13 @@ __global__ __launch_bounds__(256) void pack_open_kernel(PackOpenArgs A) {
     {
       // exclusive scan then add own count: do it as exclusive scan of a shifted view
       // (ncr[F] currently = #crashed with inv_rank == F)
-      const uint32_t chunk = (R + 255) / 256;
+      const uint32_t chunk = (R + NT - 1) / NT;
       const uint32_t lo = min(tid * chunk, R), hi = min(lo + chunk, R);
       uint32_t sum = 0;
       for (uint32_t i = lo; i < hi; i++) sum += ld_agent(&ncr[i]);
       s_part[tid] = sum;
       __syncthreads();
-      if (tid == 0) {
-        uint32_t run = 0;
-        for (uint32_t t = 0; t < 256; t++) { uint32_t x = s_part[t]; s_part[t] = run; run += x; }
-      }
+      scan_parts(s_part, NT, nullptr);
       __syncthreads();
       uint32_t run = s_part[tid];
       for (uint32_t i = lo; i < hi; i++) { run += ld_agent(&ncr[i]); ncr[i] = run; }
@@ -145,7 +155,7 @@ __global__ __launch_bounds__(256) void pack_open_kernel(PackOpenArgs A) {
       continue;
     }
     // C: fill the per-front lists in process-slot order
-    for (uint32_t i = tid; i < n; i += 256) {
+    for (uint32_t i = tid; i < n; i += NT) {
       const uint32_t ir = sc_inv[i], rr = sc_ret[i];
       if (rr == kInf) continue;
       const uint32_t p = (uint32_t)proc[i];
@@ -160,18 +170,15 @@ __global__ __launch_bounds__(256) void pack_open_kernel(PackOpenArgs A) {
     }
     // D: crashed calls in invocation order (stable compaction)
     {
-      const uint32_t chunk = (n + 255) / 256;
+      const uint32_t chunk = (n + NT - 1) / NT;
       const uint32_t lo = min(tid * chunk, n), hi = min(lo + chunk, n);
       uint32_t cnt = 0;
       for (uint32_t i = lo; i < hi; i++) cnt += sc_ret[i] == kInf && !(f[i] == TBC_F_READ && a[i] == TBC_NIL);
       s_part[tid] = cnt;
       __syncthreads();
-      if (tid == 0) {
-        uint32_t run = 0;
-        for (uint32_t t = 0; t < 256; t++) { uint32_t x = s_part[t]; s_part[t] = run; run += x; }
-        B->n_crashed = run; B->status = 0;
-      }
+      scan_parts(s_part, NT, &s_total);
       __syncthreads();
+      if (tid == 0) { B->n_crashed = s_total; B->status = 0; }
       uint32_t run = s_part[tid];
       for (uint32_t i = lo; i < hi; i++) if (sc_ret[i] == kInf && !(f[i] == TBC_F_READ && a[i] == TBC_NIL)) {
         OpRec o; o.op = i; o.f_slot = (uint32_t)f[i] | ((uint32_t)proc[i] << 8); o.a = a[i]; o.b = b[i];
@@ -187,7 +194,7 @@ __global__ __launch_bounds__(256) void pack_open_kernel(PackOpenArgs A) {
       const uint32_t V = A.vpad;
       uint64_t* rdm = A.rdm + H->op_off * V * MW;
       uint64_t* twn = A.twn + B->lst_off * MW;
-      for (uint32_t fr = tid; fr < R; fr += 256) {
+      for (uint32_t fr = tid; fr < R; fr += NT) {
         const uint32_t o0 = ld_agent(&off[fr]), o1 = ld_agent(&off[fr + 1]);
         uint64_t* row = rdm + (uint64_t)fr * V * MW;
         for (uint32_t e = 0; e < V * MW; e++) row[e] = 0ull;
@@ -236,7 +243,7 @@ __global__ __launch_bounds__(256) void pack_open_kernel(PackOpenArgs A) {
       uint32_t* tmp = A.tmp + H->op_off;
       __threadfence_block();
       // E: per rank -- need / prod / dinv, and the producers of `need` open at that front
-      for (uint32_t t = tid; t < R + kLookPad; t += 256) {
+      for (uint32_t t = tid; t < R + kLookPad; t += NT) {
         uint64_t w0 = (uint64_t)(kLookNone << 16 | kLookNone << 24) | (255ull << 32) | (255ull << 40);
         uint64_t pm[16];
         for (uint32_t w = 0; w < MW; w++) pm[w] = 0;
@@ -261,7 +268,7 @@ __global__ __launch_bounds__(256) void pack_open_kernel(PackOpenArgs A) {
       }
       __syncthreads();
       // F: every producer tells the ranks right after its invocation how recent it is
-      for (uint32_t i = tid; i < n; i += 256) {
+      for (uint32_t i = tid; i < n; i += NT) {
         const uint32_t pv = look_prod(f[i], a[i], b[i]);
         if (pv == kLookNone || (sc_ret[i] == kInf && f[i] == TBC_F_READ)) continue;
         const uint32_t ir = sc_inv[i];
@@ -272,7 +279,7 @@ __global__ __launch_bounds__(256) void pack_open_kernel(PackOpenArgs A) {
       }
       __syncthreads();
       // G: fold dprod into the records
-      for (uint32_t t = tid; t < R; t += 256) {
+      for (uint32_t t = tid; t < R; t += NT) {
         const uint32_t d = ld_agent(&tmp[t]);
         if (d < 255u) {
           const uint64_t w0 = ld_agent64(&look[(uint64_t)t * LW]);
@@ -286,7 +293,8 @@ __global__ __launch_bounds__(256) void pack_open_kernel(PackOpenArgs A) {
 
 void launch_pack_open(const PackOpenArgs& a, void* stream) {
   uint32_t grid = a.n_hist < 4096 ? a.n_hist : 4096;
-  hipLaunchKernelGGL(pack_open_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+  // few histories: latency matters (tbc_check), give each the widest workgroup; many: occupancy matters
+  hipLaunchKernelGGL(pack_open_kernel, dim3(grid), dim3(a.n_hist <= 64 ? 1024 : 256), 0, (hipStream_t)stream, a);
 }
 
 }  // namespace tbc

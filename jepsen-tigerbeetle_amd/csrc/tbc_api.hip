@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 #include "tbc_internal.h"
@@ -62,19 +63,70 @@ bool device_is_gfx950(int dev) {
   return std::strncmp(p.gcnArchName, "gfx950", 6) == 0;
 }
 
+// ---- persistent device contexts for tbc_check.  A single-history call used to pay ~35 hipMalloc / hipFree, a
+// stream and six events -- more than its kernels.  A context keeps one device slab, a stream and the events alive
+// between calls; a call takes a context from the pool (so concurrent callers -- jepsen.checker/compose runs its
+// checkers on several JVM threads -- each get their own), carves its arenas out of the slab with a bump pointer
+// and hands the context back.  A call that needs more than the slab holds falls back to hipMalloc for the rest
+// and the slab is re-sized for the next call.
+struct Ctx {
+  int device = 0;
+  char* slab = nullptr;
+  size_t cap = 0, used = 0, wanted = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[6] = {};
+};
+thread_local Ctx* t_ctx = nullptr;      // the context the calling thread's DevBufs draw from (tbc_check only)
+std::mutex g_ctx_mu;
+std::vector<Ctx*> g_ctx_free;
+
 template <typename T>
 struct DevBuf {
   T* p = nullptr;
   size_t n = 0;
+  bool owned = false;
   tbc_status alloc(size_t count) {
     n = count;
     if (count == 0) count = 1;
+    const size_t bytes = (count * sizeof(T) + 255) & ~(size_t)255;
+    if (t_ctx) {
+      t_ctx->wanted += bytes;
+      if (t_ctx->used + bytes <= t_ctx->cap) { p = (T*)(t_ctx->slab + t_ctx->used); t_ctx->used += bytes; owned = false; return TBC_OK; }
+    }
     HIP_TRY(hipMalloc((void**)&p, count * sizeof(T)));
+    owned = true;
     return TBC_OK;
   }
-  void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+  void release() { if (p && owned) (void)hipFree(p); p = nullptr; n = 0; owned = false; }
   size_t bytes() const { return (n ? n : 1) * sizeof(T); }
 };
+
+Ctx* ctx_acquire(int device) {
+  {
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    for (size_t i = 0; i < g_ctx_free.size(); i++) if (g_ctx_free[i]->device == device) {
+      Ctx* c = g_ctx_free[i]; g_ctx_free.erase(g_ctx_free.begin() + (long)i); return c;
+    }
+  }
+  Ctx* c = new (std::nothrow) Ctx();
+  if (!c) return nullptr;
+  c->device = device;
+  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return nullptr; }
+  for (auto& e : c->ev) if (hipEventCreate(&e) != hipSuccess) { delete c; return nullptr; }
+  return c;
+}
+void ctx_release(Ctx* c) {
+  // size the slab for the next call of this kind (1.25 x what this one asked for), within reason
+  if (c->wanted > c->cap && c->wanted < (8ull << 30)) {
+    if (c->slab) (void)hipFree(c->slab);
+    c->slab = nullptr; c->cap = 0;
+    const size_t want = c->wanted + c->wanted / 4;
+    if (hipMalloc((void**)&c->slab, want) == hipSuccess) c->cap = want;
+  }
+  c->used = 0; c->wanted = 0;
+  std::lock_guard<std::mutex> lk(g_ctx_mu);
+  g_ctx_free.push_back(c);
+}
 
 uint64_t now_ns();
 #define SYNC_TRACE(msg) do { if (std::getenv("TBC_SYNC_EACH")) { hipError_t e__ = hipStreamSynchronize(s); std::fprintf(stderr, "[tbc sync] %s -> %s\n", msg, hipGetErrorString(e__)); std::fflush(stderr); } } while (0)
@@ -154,7 +206,7 @@ struct tbc_batch {
   // level sweep (jit_sweep.hip): TBC_ALG_LINEAR, and TBC_ALG_COMPETITION on small batches that want no witness
   bool sweep = false;
   uint32_t max_segs = 1, seg_target = 0, cut_open = 0, n_dom = 1;
-  DevBuf<uint32_t> d_cuts;
+  DevBuf<uint32_t> d_cuts, d_seglist;
   DevBuf<SegResult> d_sres;
   std::vector<SegResult> seg_host;
   uint32_t last_segments = 0, last_fallback = 0;
@@ -170,15 +222,18 @@ struct tbc_batch {
   tbc_counters sum{};
   uint64_t device_bytes = 0;
 
+  bool borrowed = false;            // stream and events belong to a persistent context (tbc_check)
   ~tbc_batch() {
     d_f.release(); d_a.release(); d_b.release(); d_proc.release(); d_inv.release(); d_ret.release();
     d_hist.release(); d_rec.release(); d_seg.release(); d_ret_slot.release(); d_ret_op.release();
     d_bitmap.release(); d_wpre.release(); d_frames.release(); d_witness.release(); d_work.release();
     d_queue.release(); d_tab.release(); d_results.release(); d_table.release(); d_pool_vals.release(); d_cfg.release();
     d_bh.release(); d_off.release(); d_ncr.release(); d_lst.release(); d_crashed.release(); d_stack.release();
-    d_occ.release(); d_btab.release(); d_slot8.release(); d_look.release(); d_looktmp.release(); d_twn.release(); d_rdm.release(); d_cuts.release(); d_sres.release(); d_dstack.release(); d_pool.release(); d_pool_cursor.release();
-    for (auto& e : ev) if (e) (void)hipEventDestroy(e);
-    if (stream) (void)hipStreamDestroy(stream);
+    d_occ.release(); d_btab.release(); d_slot8.release(); d_look.release(); d_looktmp.release(); d_twn.release(); d_rdm.release(); d_cuts.release(); d_seglist.release(); d_sres.release(); d_dstack.release(); d_pool.release(); d_pool_cursor.release();
+    if (!borrowed) {
+      for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+      if (stream) (void)hipStreamDestroy(stream);
+    }
   }
 };
 
@@ -363,7 +418,7 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
         (s = B->d_slot8.alloc(slot8_bytes(T, nh))) || (s = B->d_stack.alloc(bstack_n)) || (s = B->d_btab.alloc(btab_n * EW)) ||
         (s = B->d_pool_cursor.alloc(1)))
       return s;
-    if (B->sweep && ((s = B->d_cuts.alloc((uint64_t)nh * B->max_segs)) || (s = B->d_sres.alloc((uint64_t)nh * B->max_segs)))) return s;
+    if (B->sweep && ((s = B->d_cuts.alloc((uint64_t)nh * B->max_segs)) || (s = B->d_sres.alloc((uint64_t)nh * B->max_segs)) || (s = B->d_seglist.alloc((uint64_t)nh * B->max_segs * 2)))) return s;
     if (B->sweep) B->seg_host.resize((size_t)nh * B->max_segs);
     if (B->rules && ((s = B->d_twn.alloc(blst_n * B->mask_words)) || (s = B->d_rdm.alloc(T * B->vpad * B->mask_words)))) return s;
     if (B->lookahead && ((s = B->d_look.alloc(look_words(T, nh, B->mask_words))) || (s = B->d_looktmp.alloc(T)) ||
@@ -396,8 +451,13 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
   if (beam) B->device_bytes += B->d_bh.bytes() + B->d_off.bytes() + B->d_ncr.bytes() + B->d_occ.bytes() + B->d_lst.bytes() +
                                B->d_crashed.bytes() + B->d_slot8.bytes() + B->d_twn.bytes() + B->d_rdm.bytes() + B->d_look.bytes() + B->d_looktmp.bytes() + B->d_dstack.bytes() + B->d_stack.bytes() + B->d_btab.bytes() + B->d_pool.bytes();
 
-  HIP_TRY(hipStreamCreateWithFlags(&B->stream, hipStreamNonBlocking));
-  for (auto& e : B->ev) HIP_TRY(hipEventCreate(&e));
+  if (t_ctx) {
+    B->borrowed = true; B->stream = t_ctx->stream;
+    for (int i = 0; i < 6; i++) B->ev[i] = t_ctx->ev[i];
+  } else {
+    HIP_TRY(hipStreamCreateWithFlags(&B->stream, hipStreamNonBlocking));
+    for (auto& e : B->ev) HIP_TRY(hipEventCreate(&e));
+  }
 
   // inputs become resident
   if (T) {
@@ -717,7 +777,7 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results) {
     swa.cut_open = B->cut_open; swa.n_dom = B->n_dom; swa.vpad = B->vpad ? B->vpad : 1; swa.rules = B->rules;
     swa.model_kind = B->model.kind; swa.init_state = B->model.kind == TBC_MODEL_MUTEX ? 0 : B->model.init;
     swa.n_classes = B->model.n_classes; swa.n_keys = B->model.n_keys;
-    launch_sweep(swa, s);
+    if (!launch_sweep(swa, s)) { set_error("level sweep launch failed"); return TBC_ERR_HIP; }
   } else if (beam) {
     BeamArgs ba = make_beam_args(B, B->d_btab.p, B->d_stack.p, B->d_dstack.p, nh);
     if (B->wg ? !launch_beam_wg(ba, B->mask_words, nh, s) : !launch_beam(ba, B->mask_words, search_blocks(nh), s)) { set_error("unsupported mask width"); return TBC_ERR_UNSUPPORTED; }
@@ -746,6 +806,23 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results) {
   HIP_TRY(hipEventRecord(B->ev[4], s));
   bool touched_work = false;
   if (B->sweep) {
+    // segments whose config sets outgrew the small LDS sets: once more with the big ones (one wavefront per CU)
+    {
+      std::vector<uint32_t> again;
+      for (uint32_t h = 0; h < nh; h++) if (hist_back[h].status == 0 && bh_back[h].status == 0)
+        for (uint32_t k = 0; k < B->max_segs; k++)
+          if (B->seg_host[(size_t)h * B->max_segs + k].status == kSegOverflow) { again.push_back(h); again.push_back(k); }
+      if (!again.empty()) {
+        HIP_TRY(hipMemcpyAsync(B->d_seglist.p, again.data(), again.size() * 4, hipMemcpyHostToDevice, s));
+        SweepArgs sa2 = swa;
+        sa2.seg_list = B->d_seglist.p; sa2.n_list = (uint32_t)(again.size() / 2);
+        if (launch_sweep(sa2, s)) {
+          HIP_TRY(hipGetLastError());
+          HIP_TRY(hipMemcpyAsync(B->seg_host.data(), B->d_sres.p, B->seg_host.size() * sizeof(SegResult), hipMemcpyDeviceToHost, s));
+        }
+        HIP_TRY(hipStreamSynchronize(s));
+      }
+    }
     // compose the segments' relations in order; what the sweep could not finish goes to the wide kernel
     std::vector<uint32_t> fb, lg;
     for (uint32_t h = 0; h < nh; h++) {
@@ -770,6 +847,16 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results) {
         live = next;
         ended = g.F1 == hist_back[h].n_ret;
       }
+      if (std::getenv("TBC_DEBUG")) {
+        uint32_t ns = 0, longest = 0, lp = 0, novf = 0, ovf_len = 0, ml = 0; uint64_t pr = 0;
+        for (uint32_t k = 0; k < B->max_segs; k++) if (sg[k].status != kSegNone) {
+          ns++; pr += sg[k].probes; ml = std::max(ml, sg[k].max_level);
+          if (sg[k].F1 - sg[k].F0 > longest) { longest = sg[k].F1 - sg[k].F0; lp = (uint32_t)sg[k].probes; }
+          if (sg[k].status == kSegOverflow) { novf++; ovf_len = sg[k].F1 - sg[k].F0; }
+        }
+        std::fprintf(stderr, "[tbc sweep] history %u: %u segments, longest %u levels (%u probes), %llu probes in all, largest level %u, %u overflowed (last one %u levels long), bh status %u\n",
+                     h, ns, longest, lp, (unsigned long long)pr, ml, novf, ovf_len, bh_back[h].status);
+      }
       if (give_up || (fail_seg == kInf && !ended)) { fb.push_back(h); lg.push_back(B->bh[h].tab_log2); continue; }
       by_sweep[h] = 1;
       if (fail_seg == kInf) {
@@ -793,7 +880,8 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results) {
       da.dump_hist = h; da.dump_seg = fail_seg; da.stop_level = fail_level; da.live_mask = live_in;
       da.dump_cfg = B->d_cfg.p + (uint64_t)h * kCfgCap * (2 + B->mask_words);
       da.dump_count = &B->d_results.p[h].n_configs;
-      launch_sweep(da, s);
+      da.seg_list = nullptr;
+      (void)launch_sweep(da, s);
       HIP_TRY(hipGetLastError());
       HIP_TRY(hipMemcpyAsync(&d.n_configs, &B->d_results.p[h].n_configs, 4, hipMemcpyDeviceToHost, s));
       HIP_TRY(hipStreamSynchronize(s));
@@ -983,20 +1071,24 @@ tbc_status tbc_check(const tbc_ops* ops, const tbc_model* model, const tbc_opts*
   tbc_batch_desc d{};
   d.n_hist = 1; d.op_off = op_off; d.n_events = &ops->n_events; d.n_process = &ops->n_process; d.cols = *ops;
   tbc_batch* B = nullptr;
+  Ctx* ctx = ctx_acquire((int)opts->device);      // null (no device ...): the create below reports why
+  t_ctx = ctx;
   tbc_status s = tbc_batch_create(&d, model, opts, &B);
-  if (s != TBC_OK) return s;
+  if (s != TBC_OK) { t_ctx = nullptr; if (ctx) ctx_release(ctx); return s; }
   TRACE("check: batch created");
   s = tbc_batch_run(B, out);
   TRACE("check: run returned");
   if (s == TBC_OK && out->witness) {   // hand the witness over: the batch dies here
     uint32_t* w = (uint32_t*)std::malloc((size_t)std::max(1u, out->n_witness) * 4);
-    if (!w) { tbc_batch_destroy(B); return TBC_ERR_OOM; }
+    if (!w) { tbc_batch_destroy(B); t_ctx = nullptr; if (ctx) ctx_release(ctx); return TBC_ERR_OOM; }
     std::memcpy(w, out->witness, (size_t)out->n_witness * 4);
     out->witness = w;
   } else {
     out->witness = nullptr;
   }
   tbc_batch_destroy(B);
+  t_ctx = nullptr;
+  if (ctx) ctx_release(ctx);
   TRACE("check: destroyed");
   out->counters.ns_total = now_ns() - t0;
   return s;

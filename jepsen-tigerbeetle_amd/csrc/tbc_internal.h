@@ -249,7 +249,8 @@ struct BeamArgs {
 };
 
 // ---- level sweep (jit_sweep.hip): knossos.linear as segments swept by one wavefront each
-constexpr uint32_t kSweepCap = 512;        // configs per LDS set; a larger level ends the segment with kSegOverflow
+constexpr uint32_t kSweepCap = 512;        // configs per LDS set; a larger level ends the segment with kSegOverflow ...
+constexpr uint32_t kSweepCapBig = 2048;    // ... and the segment is swept again with sets of this size (one wavefront per CU)
 constexpr uint32_t kSweepCandMax = 128;    // open calls (live + crashed) per level held in LDS
 constexpr uint32_t kSweepMaxSegs = 512;    // cuts per history
 enum : uint32_t { kSegNone = 0, kSegOk = 1, kSegOverflow = 2 };
@@ -293,10 +294,12 @@ struct SweepArgs {
   uint32_t n_keys;
   // dump pass
   uint32_t dump_hist, dump_seg, stop_level, live_mask, pad;
+  const uint32_t* seg_list;  // second pass: n_list (history, segment) pairs to sweep with the big sets, else null
+  uint32_t n_list, pad4;
   uint64_t* dump_cfg;        // records {front + 1 | state << 32, mask, TBC_NO_OP} as SearchArgs.cfg, kCfgCap at most
   uint32_t* dump_count;      // number of configs at that level (may exceed kCfgCap)
 };
-void launch_sweep(const SweepArgs& a, void* stream);
+bool launch_sweep(const SweepArgs& a, void* stream);
 
 void launch_pack_open(const PackOpenArgs& a, void* stream);
 bool launch_beam(const BeamArgs& a, uint32_t mask_words, uint32_t n_blocks, void* stream);
