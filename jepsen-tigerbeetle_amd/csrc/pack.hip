@@ -103,6 +103,38 @@ __global__ __launch_bounds__(256) void pack_kernel(PackArgs A) {
       atomicAdd(&s_cnt[p], 1u);
     }
     __syncthreads();
+    // phase 1b: set / bank keep their values in the pool -- every offset the search will dereference
+    // (device_common.h pair_viable) is checked here against pool_len, the add count and the account count
+    if (!s_err && (A.model_kind == TBC_MODEL_SET || A.model_kind == TBC_MODEL_BANK)) {
+      const uint64_t PL = A.pool_len, Rn = s_done;
+      const int64_t aux = H->aux;
+      if (A.model_kind == TBC_MODEL_SET) {
+        if (tid == 0) s_total = 0;
+        __syncthreads();
+        uint32_t mine = 0;
+        for (uint32_t i = tid; i < n; i += 256) mine += f[i] == TBC_F_ADD;
+        if (mine) atomicAdd(&s_total, mine);
+        __syncthreads();
+        const uint64_t n_adds = s_total, nwords = n_adds ? (n_adds + 31) / 32 : 1;
+        bool bad = aux < 0 || (uint64_t)aux + Rn + 1 > PL;
+        for (uint32_t i = tid; i < n && !bad; i += 256) {
+          if (f[i] == TBC_F_ADD) bad = a[i] < 0 || (uint64_t)a[i] >= n_adds;
+          else if (a[i] != TBC_NIL) bad = a[i] < 0 || (uint64_t)a[i] + 2 + nwords > PL;
+        }
+        if (bad) atomicOr(&s_err, 0x100u | (uint32_t)TBC_ERR_MODEL);
+      } else {
+        const uint64_t NA = A.n_keys;
+        bool bad = NA == 0 || NA > 16 || aux < 0 || (uint64_t)aux + (Rn + 1) * NA > PL;
+        for (uint32_t i = tid; i < n && !bad; i += 256) {
+          if (f[i] == TBC_F_TRANSFER) {
+            bad = a[i] < 0 || (uint64_t)a[i] + 3 > PL;
+            if (!bad) { const int32_t d = A.pool_vals[a[i]], c = A.pool_vals[a[i] + 1]; bad = d < 0 || c < 0 || (uint64_t)d >= NA || (uint64_t)c >= NA; }
+          } else if (a[i] != TBC_NIL) bad = a[i] < 0 || (uint64_t)a[i] + NA > PL;
+        }
+        if (bad) atomicOr(&s_err, 0x100u | (uint32_t)TBC_ERR_MODEL);
+      }
+      __syncthreads();
+    }
     if (s_err) {
       if (tid == 0) { H->n_ret = 0; H->status = (s_err & 0x100u) ? (uint32_t)TBC_ERR_MODEL : (uint32_t)TBC_ERR_BAD_HISTORY; }
       __syncthreads();

@@ -263,7 +263,10 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
   }
   HIP_TRY(hipSetDevice(B->device));
   switch (model->kind) {
-    case TBC_MODEL_REGISTER: case TBC_MODEL_CAS_REGISTER: case TBC_MODEL_MUTEX: break;
+    case TBC_MODEL_REGISTER: case TBC_MODEL_CAS_REGISTER: break;
+    case TBC_MODEL_MUTEX:          // tbc_model.init: 0 = free, 1 = held (knossos.model/mutex starts free)
+      if (model->init != 0 && model->init != 1) { set_error("mutex: init must be 0 (free) or 1 (held)"); return TBC_ERR_MODEL; }
+      break;
     case TBC_MODEL_SET: case TBC_MODEL_BANK:
       if (!desc->cols.pool || desc->cols.pool_len == 0) { set_error("set / bank models need the value pool (see knossos/_analysis.py)"); return TBC_ERR_INVALID_ARG; }
       if (model->kind == TBC_MODEL_BANK && (model->n_keys == 0 || model->n_keys > 16)) { set_error("bank: 1..16 accounts"); return TBC_ERR_MODEL; }
@@ -514,7 +517,7 @@ static SearchArgs make_search_args(tbc_batch* B, uint64_t* tab, uint32_t n_work)
   a.witness = B->opts.want_witness ? B->d_witness.p : nullptr;
   a.work = B->d_work.p; a.queue = B->d_queue.p;
   a.table = B->d_table.p; a.n_work = n_work; a.model_kind = B->model.kind;
-  a.init_state = B->model.kind == TBC_MODEL_MUTEX ? 0 : B->model.init;
+  a.init_state = B->model.init;
   a.n_classes = B->model.n_classes; a.n_states = B->model.n_states;
   a.max_steps = B->opts.max_steps;
   a.time_limit_ticks = B->opts.time_limit_ms * 100000ull;   // wall_clock64 runs at 100 MHz
@@ -536,7 +539,7 @@ static BeamArgs make_beam_args(tbc_batch* B, uint64_t* tab, uint32_t* stack, uin
   a.witness = B->opts.want_witness ? B->d_witness.p : nullptr;
   a.work = B->d_work.p; a.table = B->d_table.p; a.n_work = n_work; a.model_kind = B->model.kind;
   const bool comm = B->model.kind == TBC_MODEL_SET || B->model.kind == TBC_MODEL_BANK;
-  a.init_state = (B->model.kind == TBC_MODEL_MUTEX || comm) ? 0 : B->model.init;
+  a.init_state = comm ? 0 : B->model.init;
   a.model_aux = B->model.init; a.n_keys = B->model.n_keys;
   a.n_classes = B->model.n_classes; a.width = B->width;
   a.round_budget = B->opts.round_budget;
@@ -775,7 +778,7 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results) {
     swa.slot8 = B->d_slot8.p; swa.cuts = B->d_cuts.p; swa.seg = B->d_sres.p; swa.table = B->d_table.p;
     swa.pool_vals = B->d_pool_vals.p; swa.n_hist = nh; swa.max_segs = B->max_segs; swa.seg_target = B->seg_target;
     swa.cut_open = B->cut_open; swa.n_dom = B->n_dom; swa.vpad = B->vpad ? B->vpad : 1; swa.rules = B->rules;
-    swa.model_kind = B->model.kind; swa.init_state = B->model.kind == TBC_MODEL_MUTEX ? 0 : B->model.init;
+    swa.model_kind = B->model.kind; swa.init_state = B->model.init;
     swa.n_classes = B->model.n_classes; swa.n_keys = B->model.n_keys;
     if (!launch_sweep(swa, s)) { set_error("level sweep launch failed"); return TBC_ERR_HIP; }
   } else if (beam) {
@@ -924,6 +927,7 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results) {
     for (uint32_t h = 0; h < nh; h++) {
       if (B->res_host[h].valid == TBC_UNKNOWN && B->res_host[h].cause == TBC_CAUSE_VISITED_FULL) {
         const uint64_t wpe = is_seq[h] ? KW : EW;
+        if (!is_seq[h]) final_log2[h] = std::max(final_log2[h], B->res_host[h].tab_log2);   // grown inside the kernel already
         uint32_t lg = final_log2[h] + 4;
         while (lg > final_log2[h] && ((1ull << lg) * wpe * 8 > max_bytes || (!is_seq[h] && lg > kBeamMaxTabLog2))) lg--;
         if (lg > final_log2[h]) {

@@ -194,9 +194,10 @@ __device__ __forceinline__ bool grow_visited_set(const BeamArgs& A, state_ptr S,
   const uint64_t old_cap = 1ull << cap_log2, new_cap = old_cap << 2;
   const uint64_t need = new_cap * EW + new_cap / 2 + (dstack ? new_cap / 2 : 0) + old_cap / 2;   // keys + parents, stack(s), slot translation
   unsigned long long base = 0;
-  if (lane == 0) base = (A.pool && cap_log2 + 2 <= A.max_tab_log2) ? atomicAdd(A.pool_cursor, (unsigned long long)need) : ~0ull;
+  if (!A.pool || cap_log2 + 2 > 31 || cap_log2 + 2 > A.max_tab_log2) return false;   // refused before any pool words are taken
+  if (lane == 0) base = atomicAdd(A.pool_cursor, (unsigned long long)need);
   base = ru64(base);
-  if (!A.pool || cap_log2 + 2 > 31 || cap_log2 + 2 > A.max_tab_log2 || base + need > A.pool_words) return false;
+  if (base + need > A.pool_words) return false;
   gu64* ntab = (gu64*)A.pool + base;
   gu64* npar = ntab + new_cap * KW;
   const gu64* opar = tab + old_cap * KW;

@@ -74,21 +74,29 @@ class IndependentChecker(jc.Checker):
 
     def _check_batched(self, keys, subs):
         lin = self.inner
-        encs = [_analysis.Encoded(lin.model, subs[k]) for k in keys]
+        shared = None
+        if isinstance(lin.model, (_analysis.M.Register, _analysis.M.CASRegister)):
+            # ONE model struct serves the whole batch: intern the values of all keys together, so that the encoded
+            # initial value (and every other value) means the same thing in every key's columns
+            shared = [v for k in keys for v in _analysis.register_values(subs[k])]
+        encs = [_analysis.Encoded(lin.model, subs[k], shared_values=shared) for k in keys]
         kinds = {e.native_model[0].kind for e in encs}
-        if len(kinds) != 1 or N.MODEL_TABLE in kinds or len({e.native_model[0].n_keys for e in encs}) != 1:
-            # table models have one table per key: check them one by one
+        if (len(kinds) != 1 or N.MODEL_TABLE in kinds or len({e.native_model[0].n_keys for e in encs}) != 1
+                or len({e.native_model[0].init for e in encs}) != 1 and N.MODEL_SET not in kinds and N.MODEL_BANK not in kinds):
+            # table models have one table per key, and keys that do not agree on the encoded model: one by one
             return {k: lin.check(None, subs[k], None) for k in keys}
-        o = core.make_opts(algorithm=_analysis._ALG[lin.algorithm],
-                           time_limit_ms=int(lin.opts.get("time-limit", 0) or 0), want_witness=True)
+        want_witness = bool(lin.opts.get("witness", lin.algorithm == "wgl"))
+        o = _analysis.make_opts_from(lin.algorithm, lin.opts, want_witness)
         with core.Batch([e.ops for e in encs], encs[0].native_model, o) as b:
-            b.run()
+            b.run(tolerate_bad_histories=True)
             res = b.results()
         out = {}
         for k, e, r in zip(keys, encs, res):
+            if r["valid"] == N.UNKNOWN and r["cause"] == N.CAUSE_NONE:
+                # rejected by the device-side validation (malformed rows): this key only, not the batch
+                out[k] = {"valid?": "unknown", "cause": "malformed-history", "analyzer": "wgl", "configs": [], "final-paths": []}
+                continue
             a = _analysis.result_map(e, r, lin.algorithm)
-            if lin.algorithm == "linear":
-                a["analyzer"] = "linear"
             a["final-paths"] = a["final-paths"][:10]
             a["configs"] = a["configs"][:10]
             out[k] = a

@@ -48,7 +48,9 @@ class _Interner:
 class Encoded:
     """A history ready for the C-ABI plus what is needed to decode the verdict."""
 
-    def __init__(self, model, history):
+    def __init__(self, model, history, shared_values=None):
+        """shared_values: values every history of one batch must agree on (jepsen.independent checks all keys in
+        one launch with ONE model struct, so the register values of all keys are interned together)."""
         self.model = model
         hist = [op for op in H.index(list(history)) if H.client_op(op)]
         self.rows = hist                       # row r of the event columns == hist[r]
@@ -63,7 +65,7 @@ class Encoded:
             typ[r] = _TYPE[op["type"]]
             proc[r] = op["process"]
         if isinstance(model, (M.Register, M.CASRegister)):
-            vals = [model.value]
+            vals = [model.value] + list(shared_values or [])
             for op in hist:
                 v = op.get("value")
                 if op["f"] == "cas" and v is not None:
@@ -177,7 +179,7 @@ class Encoded:
                         continue
                     v = list(v)
                     bits = np.zeros(nbits, bool)
-                    if ints and j_of and all(isinstance(x, int) and not isinstance(x, bool) for x in v[:1]):
+                    if ints and j_of and all(isinstance(x, int) and not isinstance(x, bool) for x in v):
                         arr = np.asarray(v, np.int64) if v else np.zeros(0, np.int64)
                         pos = np.searchsorted(elem_arr, arr)
                         pos_c = np.minimum(pos, len(elem_arr) - 1)
@@ -363,6 +365,26 @@ def result_map(enc: Encoded, res: dict, algorithm):
     out["stats"] = {k: res[k] for k in ("steps", "visited", "probes", "backtracks", "max_depth",
                                         "table_slots", "ns_pack", "ns_search", "ns_total")}
     return out
+
+
+def register_values(history):
+    """Every value a register-family history mentions (for Encoded's shared_values)."""
+    out = []
+    for op in history:
+        v = op.get("value")
+        if op.get("f") == "cas" and v is not None:
+            out.extend(v)
+        else:
+            out.append(v)
+    return out
+
+
+def make_opts_from(algorithm, opts, want_witness):
+    return core.make_opts(algorithm=_ALG[algorithm], device=opts.get("device", 0),
+                          time_limit_ms=int(opts.get("time-limit", opts.get("time_limit", 0)) or 0),
+                          max_steps=opts.get("max-steps", opts.get("max_steps", 0)) or 0,
+                          max_visited_bytes=opts.get("max-visited-bytes", opts.get("max_visited_bytes", 0)) or 0,
+                          want_witness=want_witness)
 
 
 def analysis(model, history, algorithm="wgl", **opts):

@@ -119,8 +119,11 @@ def test_wide_schedule_overflow_retry_and_default_algorithm(native, oracle):
     got = core.check_ops(ops, gm(), core.make_opts(time_limit_ms=60000, algorithm=N.ALG_COMPETITION, visited_per_op=4))
     assert got["valid"] == exp["valid"] == 0 and got["fail_op"] == exp["fail_op"]
     assert got["visited"] == exp["visited"] and got["table_slots"] > 16 * len(ops)
-    small = core.check_ops(ops, gm(), core.make_opts(algorithm=N.ALG_LINEAR, max_visited_bytes=64 * 1024))
+    small = core.check_ops(ops, gm(), core.make_opts(algorithm=N.ALG_COMPETITION, max_visited_bytes=64 * 1024))
     assert small["valid"] == N.UNKNOWN and small["cause"] == N.CAUSE_VISITED_FULL
+    # knossos.linear (the level sweep) keeps no visited set: the same cap does not concern it
+    lin = core.check_ops(ops, gm(), core.make_opts(algorithm=N.ALG_LINEAR, max_visited_bytes=64 * 1024, want_witness=False))
+    assert lin["valid"] == 0 and lin["fail_op"] == exp["fail_op"] and lin["analyzer"] == N.ALG_LINEAR
 
 
 def test_batch_matches_oracle_and_single(native, oracle):
@@ -396,3 +399,48 @@ def test_each_dominance_rule_alone(native, oracle):
                 assert brute.check_witness(CAS, op_tuples(h), [int(x) for x in got["witness"]]) == got["final_state"]
             else:
                 assert got["fail_op"] == exp["fail_op"], (eager, twin, i)
+
+
+def test_independent_keys_share_one_value_encoding(native):
+    """jepsen.independent checks all keys in ONE batch with ONE model struct: the register values of all keys are
+    interned together, so a key that sees a string does not shift the meaning of the initial value for the others
+    (round-1 advisor finding), and the remaining options (max-steps) reach the batch."""
+    T = independent.tuple_
+    h = []
+    def op(p, f, k, v_inv, v_ok):
+        h.append(kop.invoke(p, f, T(k, v_inv))); h.append(kop.ok(p, f, T(k, v_ok)))
+    op(0, "read", "a", None, 5)          # key a: ints only; the initial value 5 is readable
+    op(0, "write", "a", 1, 1); op(1, "read", "a", None, 1)
+    op(2, "read", "b", None, 5)          # key b: a string among its values; the initial value is still 5
+    op(2, "write", "b", "x", "x"); op(3, "read", "b", None, "x")
+    op(4, "read", "c", None, 7)          # key c: 7 was never written and is not the initial value
+    for alg in ("wgl", "linear", None):
+        r = independent.checker(jc.linearizable({"model": M.register(5), "algorithm": alg})).check(None, h, None)
+        assert r["results"]["a"]["valid?"] is True, alg
+        assert r["results"]["b"]["valid?"] is True, alg
+        assert r["results"]["c"]["valid?"] is False and r["failures"] == ["c"], alg
+    # a budget of a single step: every key must come back :unknown (the option used to be dropped on this path)
+    r = independent.checker(jc.linearizable({"model": M.register(5), "algorithm": "wgl", "max-steps": 1})).check(None, h, None)
+    assert r["results"]["a"]["valid?"] == "unknown" and r["results"]["a"]["cause"] == "step-limit"
+
+
+def test_pack_rejects_out_of_range_pool_references(native):
+    """Malformed C-ABI input for the pool-backed models must end as TBC_ERR_MODEL, not as an out-of-bounds read
+    (round-1 advisor finding): a set read whose record runs past the pool, an add index past the add count, a bank
+    transfer between accounts that do not exist."""
+    from jepsen_tigerbeetle_amd.knossos import _analysis as A
+    hs = [kop.invoke(0, "add", 1), kop.ok(0, "add", 1), kop.invoke(1, "read", None), kop.ok(1, "read", [1])]
+    e = A.Encoded(M.SetModel(), hs)
+    good = core.check_ops(e.ops, e.native_model, core.make_opts(algorithm=N.ALG_COMPETITION))
+    assert good["valid"] == N.VALID
+    for mutate in ("read_offset", "add_index"):
+        ops = columns.OpColumns(e.ops.f.copy(), e.ops.a.copy(), e.ops.b.copy(), e.ops.process.copy(), e.ops.inv_pos.copy(),
+                                e.ops.ret_pos.copy(), e.ops.n_events, e.ops.n_process)
+        ops.pool = e.ops.pool.copy()
+        if mutate == "read_offset":
+            ops.a[ops.f == N.F_READ] = len(ops.pool) - 1
+        else:
+            ops.a[ops.f == N.F_ADD] = 1000
+        with pytest.raises(N.TbcError) as err:
+            core.check_ops(ops, e.native_model, core.make_opts(algorithm=N.ALG_COMPETITION))
+        assert err.value.status == N.ERR_MODEL, mutate
