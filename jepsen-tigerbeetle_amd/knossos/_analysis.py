@@ -359,12 +359,49 @@ def result_map(enc: Encoded, res: dict, algorithm):
             out["configs"].append({"model": enc.model_of_state(c["state"]),
                                    "last-op": enc.op_invocation(c["last_op"]) if c["last_op"] is not None else None,
                                    "pending": [enc.op_invocation(i) for i in c["pending"]]})
+        out["final-paths"] = final_paths(enc, res)
     else:
         out["valid?"] = "unknown"
         out["cause"] = _CAUSE.get(res["cause"], "unknown")
     out["stats"] = {k: res[k] for k in ("steps", "visited", "probes", "backtracks", "max_depth",
                                         "table_slots", "ns_pack", "ns_search", "ns_total")}
     return out
+
+
+def final_paths(enc: Encoded, res: dict, limit=10):
+    """knossos.linear's :final-paths of an invalid verdict (recalled shape; the Jepsen tutorial prints
+    `[{:op {... :f :write, :value 4} :model {:value 4}} {:op {... :f :read, :value 3} :model {:msg "can't read 3 from
+    register 4"}}]`): for each config stuck in front of the failing completion, the ways its last steps end in an
+    inconsistent model -- the failing op applied directly, or after one more pending call the model accepts.
+    Built on the host from the <= 10 configs the device returns and the Python model's own step (so :msg is the
+    model's wording).  The state-free device models (set, bank) carry no state in their configs: no paths."""
+    if isinstance(enc.model, (M.SetModel, M.Bank)) or res.get("fail_op") is None:
+        return []
+    x = enc.op_completion(res["fail_op"])
+    paths = []
+    for c in res.get("configs", []):
+        m = enc.model_of_state(c["state"])
+        prefix = []
+        if c["last_op"] is not None:
+            prefix = [{"op": enc.op_completion(c["last_op"]) or enc.op_invocation(c["last_op"]), "model": m}]
+        mx = m.step(x)
+        if M.inconsistent_p(mx):
+            paths.append(prefix + [{"op": x, "model": mx}])
+        for k, i in enumerate(c["pending"]):
+            if len(paths) >= limit:
+                break
+            if (c["linearized_mask"] >> k) & 1 or i == res["fail_op"]:
+                continue
+            y = enc.op_completion(i) or enc.op_invocation(i)
+            m1 = m.step(y)
+            if M.inconsistent_p(m1):
+                continue
+            m2 = m1.step(x)
+            if M.inconsistent_p(m2):
+                paths.append(prefix + [{"op": y, "model": m1}, {"op": x, "model": m2}])
+        if len(paths) >= limit:
+            break
+    return paths[:limit]
 
 
 def register_values(history):

@@ -1,0 +1,51 @@
+;; knossos_crosscheck.clj -- pins this repository's expectations against STOCK Knossos, from outside.
+;;
+;; Nothing in this repository's environment can run Clojure (no JVM; SURVEY.md section 0, F4), so parity with
+;; stock Knossos is "unpinned" (DESIGN.md).  Anyone with a JVM can close that gap:
+;;
+;;   clojure -Sdeps '{:deps {knossos/knossos {:mvn/version "0.3.8"} cheshire/cheshire {:mvn/version "5.11.0"}}}' \
+;;           -M scripts/knossos_crosscheck.clj tests/golden/edn > stock-knossos.json
+;;   python scripts/compare_crosscheck.py stock-knossos.json        ; prints every disagreement
+;;
+;; For every history file it runs knossos.wgl/analysis and knossos.linear/analysis with the model named in
+;; expected.json and prints one JSON object per file: {file, model, valid?, op-index, analyzer results}.
+;; op-index = the :index of the :op Knossos reports for an invalid history (the completion that cannot be
+;; linearized).  The history files hold one op map per line, exactly what jepsen.store writes to history.edn
+;; (the reference keeps them under store/, /root/reference/.gitignore:7).
+(require '[clojure.edn :as edn]
+         '[clojure.java.io :as io]
+         '[clojure.string :as str]
+         '[cheshire.core :as json]
+         '[knossos.model :as model]
+         '[knossos.wgl :as wgl]
+         '[knossos.linear :as linear])
+
+(def models {"cas-register" #(model/cas-register)
+             "register"     #(model/register)
+             "mutex"        #(model/mutex)})
+
+(defn read-history [file]
+  (with-open [r (io/reader file)]
+    (->> (line-seq r)
+         (remove str/blank?)
+         (map edn/read-string)
+         (filter #(integer? (:process %)))      ; the reference drops :nemesis rows the same way (tests/ledger.clj:94)
+         vec)))
+
+(defn summarize [a]
+  {:valid? (:valid? a)
+   :op-index (some-> a :op :index)
+   :previous-ok-index (some-> a :previous-ok :index)
+   :configs (count (:configs a))
+   :final-paths (count (:final-paths a))})
+
+(let [dir      (or (first *command-line-args*) "tests/golden/edn")
+      expected (json/parse-string (slurp (io/file dir "expected.json")) true)]
+  (doseq [{:keys [file model]} (:cases expected)]
+    (let [h (read-history (io/file dir file))
+          m ((models model))
+          w (summarize (wgl/analysis m h))
+          l (summarize (linear/analysis m h))]
+      (println (json/generate-string {:file file :model model :provenance "stock-knossos"
+                                      :valid? (:valid? l) :op-index (:op-index l)
+                                      :wgl w :linear l})))))

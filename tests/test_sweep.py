@@ -108,3 +108,20 @@ def test_linear_analysis_surface(native):
     assert a["configs"] and a["configs"][0]["model"] == M.CASRegister(1)
     ok = [kop.invoke(0, "write", 1), kop.invoke(1, "read", None), kop.ok(0, "write", 1), kop.ok(1, "read", 1)]
     assert linear.analysis(M.cas_register(), ok)["valid?"] is True
+
+
+@pytest.mark.gpu
+def test_final_paths_of_the_tutorial_history(native):
+    """jepsen.checker/linearizable's failure report: :final-paths end in the model's own message (the Jepsen
+    tutorial's "can't read 3 from register 4"), for :linear (sweep), :wgl and competition."""
+    from helpers import load_kats
+    from jepsen_tigerbeetle_amd.jepsen import checker as jc
+    kat = [k for k in load_kats() if k[0] == "tutorial-cant-read-3-from-4"][0]
+    for alg in ("linear", "wgl", None):
+        a = jc.linearizable({"model": M.cas_register(), "algorithm": alg}).check(None, kat[2], None)
+        assert a["valid?"] is False and a["op"]["index"] == 7
+        assert a["final-paths"], alg
+        last = a["final-paths"][0][-1]
+        assert last["op"]["f"] == "read" and last["op"]["value"] == 3
+        assert last["model"].msg == "can't read 3 from register 4", alg
+        assert len(a["final-paths"]) <= 10 and len(a["configs"]) <= 10
