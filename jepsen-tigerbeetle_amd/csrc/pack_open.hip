@@ -1,27 +1,36 @@
-// pack_open.hip -- K1b: open-call lists for the wide search kernel (gfx950).
+// pack_open.hip -- K1b: open-call lists for the wide search kernel and the level sweep (gfx950).
 //
-// Runs after pack_kernel (which left every op's inv_rank / ret_rank in the
-// scratch arena).  For every front F (= rank of a completion) the wide search
-// needs the calls that are open at F.  This kernel builds, per history:
+// Runs after pack_kernel (which left every op's inv_rank / ret_rank in the scratch arena and the per-process
+// record lists rec[] / seg[]).  For every front F (= rank of a completion) the searches need the calls that
+// are open at F.  Built per history:
 //
-//   occ[F]   bit p set  <=>  process p has a LIVE (eventually completed) call open at F
-//   off[F]   CSR offsets, off[F+1]-off[F] = popcount(occ[F])
+//   off[F]   CSR offsets, off[F+1]-off[F] = number of live (eventually completed) calls open at F
 //   lst[]    the live open calls of front F in process-slot order, as whole 16 B records
-//            {op, f | slot << 8 | at-front flag, a, b}: a lane of the search reaches its candidate
-//            with one load (position of p's call = popcount(occ[F] below p): no sorting needed)
-//   crashed[] the :info calls in invocation order, ncr[F] = how many of them were
-//            invoked before completion F (they stay open for ever, so they are
-//            kept out of the per-front lists).  Crashed READS (value nil) are left
-//            out altogether: no effect on the model, no constraint, but each would
-//            double the config space (oracle/wgl_beam.c)
-//   slot8[]  process slot of the call completing at each rank, one byte each: the search
-//            prefetches a 16-rank window of it for the front advance
-//   look[]   one lookahead record per completion rank (layout: tbc_internal.h): what the call
-//            completing there needs, and which other calls could provide it
+//            {op, f | slot << 8 | at-front flag, a, b}: a lane of the search reaches its candidate with one load
+//   crashed[] the :info calls in invocation order, ncr[F] = how many of them were invoked before completion F
+//            (they stay open for ever, so they are kept out of the per-front lists).  Crashed READS (value
+//            nil) are left out altogether: no effect on the model, no constraint, but each would double the
+//            config space (oracle/wgl_beam.c)
+//   slot8[]  process slot of the call completing at each rank, one byte each
+//   twn[] rdm[]  the dominance tables (tbc_internal.h): twin masks per list entry, open-read masks per front
+//   look[]   one lookahead record per completion rank (layout: tbc_internal.h)
 //
-// This is knossos.linear.config's "pending calls by process" materialised for
-// every point of the history.  One workgroup (256 threads in a big batch, 1,024 when a few histories must be quick) per
-// history.  off/ncr/occ arenas are zeroed by the host before the launch.
+// This is knossos.linear.config's "pending calls by process" materialised for every point of the history
+// (SURVEY.md section 8a).  Three kernels:
+//   open_counts_kernel  one workgroup per history: how many calls are open at each front -- a histogram of
+//                       invocation ranks and two scans (open(F) = calls invoked by F minus the F completed) --
+//                       the crashed-call list, slot8;
+//   open_walk_kernel    one WAVEFRONT PER 64 FRONTS, LANE = PROCESS SLOT: each lane keeps the call its process
+//                       has open (a cursor into the process's record list, the next record prefetched) and the
+//                       wavefront walks its fronts in order; at every front one ballot is the occupancy mask,
+//                       a popcount below the lane is the call's position in the front's list, V ballots are the
+//                       read masks, the twins are found by broadcasting the (few) open writes / cas, the lookahead
+//                       record comes from the lane of the completing call.  Streaming writes only, no atomics,
+//                       every chunk of every history independent -- so one history is spread over the GPU and a
+//                       batch costs one pass over what it writes;
+//   open_dprod_kernel   lookahead only: how recently a producer of the needed value was invoked (scattered by
+//                       the producers with atomicMin).
+// The off / ncr arenas are zeroed by the host before the launch.
 #include <hip/hip_runtime.h>
 #include "tbc_internal.h"
 
@@ -51,25 +60,6 @@ __device__ __forceinline__ void scan_parts(uint32_t* part, uint32_t NT, uint32_t
   }
 }
 
-// in-place exclusive scan of v[0..m) by the block; returns the total.
-// `part` is blockDim.x words of LDS.  Every element is read and written by one thread only.
-__device__ uint32_t block_exclusive_scan(uint32_t* v, uint32_t m, uint32_t* part, uint32_t* total_slot) {
-  const uint32_t tid = threadIdx.x;
-  const uint32_t NT = blockDim.x;
-  const uint32_t chunk = (m + NT - 1) / NT;
-  const uint32_t lo = min(tid * chunk, m), hi = min(lo + chunk, m);
-  uint32_t sum = 0;
-  for (uint32_t i = lo; i < hi; i++) sum += ld_agent(&v[i]);
-  part[tid] = sum;
-  __syncthreads();
-  scan_parts(part, NT, total_slot);
-  __syncthreads();
-  uint32_t run = part[tid];
-  for (uint32_t i = lo; i < hi; i++) { uint32_t x = ld_agent(&v[i]); v[i] = run; run += x; }
-  __syncthreads();
-  return *total_slot;
-}
-
 // register value a call must find / leaves behind, as a lookahead byte (0..31, else kLookNone)
 __device__ __forceinline__ uint32_t look_val(int32_t v) { return (v >= 0 && v < 32) ? (uint32_t)v : kLookNone; }
 __device__ __forceinline__ uint32_t look_need(uint32_t f, int32_t a) {
@@ -81,7 +71,7 @@ __device__ __forceinline__ uint32_t look_prod(uint32_t f, int32_t a, int32_t b) 
 
 }  // namespace
 
-__global__ __launch_bounds__(1024) void pack_open_kernel(PackOpenArgs A) {
+__global__ __launch_bounds__(1024) void open_counts_kernel(PackOpenArgs A) {
   __shared__ uint32_t s_part[1024];
   const uint32_t NT = blockDim.x;
   __shared__ uint32_t s_total;
@@ -104,39 +94,50 @@ __global__ __launch_bounds__(1024) void pack_open_kernel(PackOpenArgs A) {
     const uint32_t* sc_ret = sc_inv + n;
     uint32_t* off = A.off + B->off_off;      // R + 1 entries used
     uint32_t* ncr = A.ncr + B->off_off;      // R entries used
-    uint64_t* occ = A.occ + B->occ_off;      // R * MW words used
-    OpRec* lst = A.lst + B->lst_off;
     OpRec* crashed = A.crashed + H->op_off;
     const uint32_t* ret_slot = A.ret_slot + H->ret_off;
     uint8_t* slot8 = A.slot8 + slot8_off(H->op_off, h);
 
-    // A: occupancy bits of live calls; crashed-call counts by front; completion slots as bytes
+    // A: histogram of the live calls' invocation ranks (in off[]), crashed-call counts by front, completion slots as bytes
     for (uint32_t r = tid; r < R + 16u; r += NT) slot8[r] = r < R ? (uint8_t)ret_slot[r] : (uint8_t)0;
     for (uint32_t i = tid; i < n; i += NT) {
       const uint32_t ir = sc_inv[i], rr = sc_ret[i];
-      const uint32_t p = (uint32_t)proc[i];
       if (rr == kInf) {
         if (ir < R && !(f[i] == TBC_F_READ && a[i] == TBC_NIL)) atomicAdd(&ncr[ir], 1u);
       } else {
-        const unsigned long long bit = 1ull << (p & 63u);
-        for (uint32_t fr = ir; fr <= rr; fr++)
-          atomicOr((unsigned long long*)&occ[(uint64_t)fr * MW + (p >> 6)], bit);
+        atomicAdd(&off[ir], 1u);
       }
     }
     __syncthreads();
-    // B: live count per front -> off[F+1]; then exclusive scan -> CSR offsets
-    for (uint32_t fr = tid; fr < R; fr += NT) {
-      uint32_t c = 0;
-      for (uint32_t w = 0; w < MW; w++) c += __popcll(ld_agent64(&occ[(uint64_t)fr * MW + w]));
-      off[fr] = c;
+    // B: open(F) = (live calls invoked at rank <= F) - F, since exactly F calls have completed before front F;
+    //    off[] = exclusive scan of open().  Two block scans over per-thread chunks, in place.
+    uint32_t total;
+    {
+      const uint32_t chunk = (R + NT - 1) / NT;
+      const uint32_t lo = min(tid * chunk, R), hi = min(lo + chunk, R);
+      uint32_t sum = 0;
+      for (uint32_t i = lo; i < hi; i++) sum += ld_agent(&off[i]);
+      s_part[tid] = sum;
+      __syncthreads();
+      scan_parts(s_part, NT, nullptr);
+      __syncthreads();
+      const uint32_t base_inv = s_part[tid];          // live calls invoked before this chunk's first rank
+      __syncthreads();
+      uint32_t run = base_inv, open_sum = 0;
+      for (uint32_t i = lo; i < hi; i++) { run += ld_agent(&off[i]); open_sum += run - i; }
+      s_part[tid] = open_sum;
+      __syncthreads();
+      scan_parts(s_part, NT, &s_total);
+      __syncthreads();
+      uint32_t pos = s_part[tid];
+      run = base_inv;
+      for (uint32_t i = lo; i < hi; i++) { run += ld_agent(&off[i]); off[i] = pos; pos += run - i; }
+      total = s_total;
+      if (tid == 0) off[R] = total;
+      __syncthreads();
     }
-    if (tid == 0) off[R] = 0;
-    __syncthreads();
-    const uint32_t total = block_exclusive_scan(off, R + 1, s_part, &s_total);
     // ncr[F] = crashed calls invoked before completion F (inclusive prefix)
     {
-      // exclusive scan then add own count: do it as exclusive scan of a shifted view
-      // (ncr[F] currently = #crashed with inv_rank == F)
       const uint32_t chunk = (R + NT - 1) / NT;
       const uint32_t lo = min(tid * chunk, R), hi = min(lo + chunk, R);
       uint32_t sum = 0;
@@ -153,20 +154,6 @@ __global__ __launch_bounds__(1024) void pack_open_kernel(PackOpenArgs A) {
       if (tid == 0) { B->status = 1; B->n_crashed = 0; }
       __syncthreads();
       continue;
-    }
-    // C: fill the per-front lists in process-slot order
-    for (uint32_t i = tid; i < n; i += NT) {
-      const uint32_t ir = sc_inv[i], rr = sc_ret[i];
-      if (rr == kInf) continue;
-      const uint32_t p = (uint32_t)proc[i];
-      OpRec o; o.op = i; o.f_slot = (uint32_t)f[i] | (p << 8); o.a = a[i]; o.b = b[i];
-      for (uint32_t fr = ir; fr <= rr; fr++) {
-        uint32_t pos = ld_agent(&off[fr]);
-        for (uint32_t w = 0; w < (p >> 6); w++) pos += __popcll(ld_agent64(&occ[(uint64_t)fr * MW + w]));
-        pos += __popcll(ld_agent64(&occ[(uint64_t)fr * MW + (p >> 6)]) & ((1ull << (p & 63u)) - 1ull));
-        if (fr == rr) o.f_slot |= kAtFront;
-        lst[pos] = o;
-      }
     }
     // D: crashed calls in invocation order (stable compaction)
     {
@@ -186,115 +173,238 @@ __global__ __launch_bounds__(1024) void pack_open_kernel(PackOpenArgs A) {
       }
       __syncthreads();
     }
-    // H: dominance tables (register family; tbc_internal.h) -- one thread per front reads that front's list
-    //    once: rdm row = slots of its open reads by value, twn = per entry the slots of the calls with the
-    //    same effect that complete earlier
-    if (A.rdm) {
-      __threadfence_block();
-      const uint32_t V = A.vpad;
-      uint64_t* rdm = A.rdm + H->op_off * V * MW;
-      uint64_t* twn = A.twn + B->lst_off * MW;
-      for (uint32_t fr = tid; fr < R; fr += NT) {
-        const uint32_t o0 = ld_agent(&off[fr]), o1 = ld_agent(&off[fr + 1]);
-        uint64_t* row = rdm + (uint64_t)fr * V * MW;
-        for (uint32_t e = 0; e < V * MW; e++) row[e] = 0ull;
-        // one pass over the front's list: reads go into the row (this thread's own words: plain read-modify-
-        // write); writes / cas leave a signature bit per effect -- two calls on one bit MAY be twins
-        uint64_t sig = 0ull;
-        bool maybe_twins = false;
-        for (uint32_t c = o0; c < o1; c++) {
-          const OpRec x = lst[c];
-          const uint32_t xf = x.f_slot & 0xFFu, xs = (x.f_slot >> 8) & kSlotMask;
-          if (xf == TBC_F_READ) {
-            const uint32_t vi = rdm_index(x.a, V);
-            if (vi != 0 || x.a == TBC_NIL) row[vi * MW + (xs >> 6)] |= 1ull << (xs & 63u);
-          } else if (xf == TBC_F_WRITE || xf == TBC_F_CAS) {
-            const uint64_t bit = 1ull << (((uint32_t)x.a * 7u + (xf == TBC_F_CAS ? (uint32_t)x.b * 13u + 31u : 0u)) & 63u);
-            maybe_twins = maybe_twins || (sig & bit) != 0ull;
-            sig |= bit;
-          }
-        }
-        for (uint32_t c = o0; c < o1; c++) {
-          uint64_t m[4] = {0, 0, 0, 0};
-          if (maybe_twins) {
-            const OpRec y = lst[c];
-            const uint32_t yf = y.f_slot & 0xFFu;
-            if (yf == TBC_F_WRITE || yf == TBC_F_CAS) {
-              const uint32_t yr = sc_ret[y.op];
-              for (uint32_t d = o0; d < o1; d++) {
-                if (d == c) continue;
-                const OpRec z = lst[d];
-                if ((z.f_slot & 0xFFu) != yf || z.a != y.a || (yf == TBC_F_CAS && z.b != y.b)) continue;
-                const uint32_t zr = sc_ret[z.op];
-                if (zr < yr || (zr == yr && z.op < y.op)) { const uint32_t zs = (z.f_slot >> 8) & kSlotMask; m[zs >> 6] |= 1ull << (zs & 63u); }
-              }
-            }
-          }
-          for (uint32_t w = 0; w < MW; w++) twn[(uint64_t)c * MW + w] = m[w];
-        }
-      }
-      __syncthreads();
-    }
-    // E-G: lookahead records (register family only; A.look is null otherwise)
+    // lookahead records past the last rank: nothing is needed there
     if (A.look) {
       const uint32_t LW = 1 + MW;
       uint64_t* look = A.look + look_off(H->op_off, h, MW);
-      const uint32_t* ret_op = A.ret_op + H->ret_off;
-      uint32_t* tmp = A.tmp + H->op_off;
-      __threadfence_block();
-      // E: per rank -- need / prod / dinv, and the producers of `need` open at that front
-      for (uint32_t t = tid; t < R + kLookPad; t += NT) {
-        uint64_t w0 = (uint64_t)(kLookNone << 16 | kLookNone << 24) | (255ull << 32) | (255ull << 40);
-        uint64_t pm[16];
-        for (uint32_t w = 0; w < MW; w++) pm[w] = 0;
-        if (t < R) {
-          const uint32_t op = ret_op[t];
-          const uint32_t need = look_need(f[op], a[op]), prod = look_prod(f[op], a[op], b[op]);
-          const uint32_t di = min(t - sc_inv[op], 255u);
-          w0 = (uint64_t)((uint32_t)proc[op] & 0xFFFFu) | (uint64_t)need << 16 | (uint64_t)prod << 24 |
-               (uint64_t)di << 32 | (255ull << 40);
-          if (need != kLookNone) {
-            const uint32_t o0 = ld_agent(&off[t]), o1 = ld_agent(&off[t + 1]), nc = ld_agent(&ncr[t]);
-            for (uint32_t c = 0; c < (o1 - o0) + nc; c++) {
-              const OpRec x = c < o1 - o0 ? lst[o0 + c] : crashed[c - (o1 - o0)];
-              const uint32_t xf = x.f_slot & 0xFFu, xs = (x.f_slot >> 8) & kSlotMask;
-              if (x.op != op && look_prod(xf, x.a, x.b) == need) pm[xs >> 6] |= 1ull << (xs & 63u);
-            }
-          }
-          tmp[t] = 255u;
-        }
-        look[(uint64_t)t * LW] = w0;
-        for (uint32_t w = 0; w < MW; w++) look[(uint64_t)t * LW + 1 + w] = pm[w];
+      for (uint32_t t = R + tid; t < R + kLookPad; t += NT) {
+        look[(uint64_t)t * LW] = (uint64_t)(kLookNone << 16 | kLookNone << 24) | (255ull << 32) | (255ull << 40);
+        for (uint32_t w = 0; w < MW; w++) look[(uint64_t)t * LW + 1 + w] = 0ull;
       }
-      __syncthreads();
-      // F: every producer tells the ranks right after its invocation how recent it is
-      for (uint32_t i = tid; i < n; i += NT) {
-        const uint32_t pv = look_prod(f[i], a[i], b[i]);
-        if (pv == kLookNone || (sc_ret[i] == kInf && f[i] == TBC_F_READ)) continue;
-        const uint32_t ir = sc_inv[i];
-        for (uint32_t t = ir; t < R && t < ir + kLookahead; t++) {
-          const uint32_t need = (uint32_t)(ld_agent64(&look[(uint64_t)t * LW]) >> 16) & 0xFFu;
-          if (need == pv && ret_op[t] != i) atomicMin(&tmp[t], t - ir);
-        }
-      }
-      __syncthreads();
-      // G: fold dprod into the records
-      for (uint32_t t = tid; t < R; t += NT) {
-        const uint32_t d = ld_agent(&tmp[t]);
-        if (d < 255u) {
-          const uint64_t w0 = ld_agent64(&look[(uint64_t)t * LW]);
-          look[(uint64_t)t * LW] = (w0 & ~(255ull << 40)) | ((uint64_t)d << 40);
-        }
-      }
-      __syncthreads();
     }
   }
 }
 
+// ---- the walk: one wavefront per 64 fronts of one history, lane = process slot (+ 64 per mask word)
+namespace {
+struct Cur { uint32_t inv, ret, op, f; int32_t a, b; };
+__device__ __forceinline__ Cur load_cur(const Rec* r) {
+  const Rec x = *r;
+  return Cur{x.inv_rank, x.ret_rank, x.opidx, x.f, x.a, x.b};
+}
+}  // namespace
+
+template <int MW>
+__global__ __launch_bounds__(256) void open_walk_kernel(PackOpenArgs A) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wid = blockIdx.x * 4u + (threadIdx.x >> 6);
+  const uint32_t cph = A.chunks_per_hist;
+  const uint32_t h = wid / cph, c = wid - h * cph;
+  if (h >= A.n_hist) return;
+  const Hist* H = &A.hist[h];
+  const BeamHist* B = &A.bh[h];
+  const uint32_t R = H->n_ret;
+  const uint32_t F_lo = c * 64u;
+  if (H->status != 0 || B->status != 0 || F_lo >= R) return;
+  const uint32_t F_hi = min(F_lo + 64u, R);
+  const uint32_t W = H->n_slots;
+  const Rec* rec = A.rec + H->rec_off;
+  const uint32_t* seg = A.seg + H->seg_off;
+  const uint32_t* off = A.off + B->off_off;
+  OpRec* lst = A.lst + B->lst_off;
+  const uint32_t* ret_slot = A.ret_slot + H->ret_off;
+  uint64_t* twn = A.twn ? A.twn + B->lst_off * MW : nullptr;
+  const uint32_t V = A.vpad;
+  uint64_t* rdm = A.rdm ? A.rdm + H->op_off * V * MW : nullptr;
+  uint64_t* look = A.look ? A.look + look_off(H->op_off, h, MW) : nullptr;
+  uint32_t* tmp = A.tmp ? A.tmp + H->op_off : nullptr;
+
+  // cursors: the first call of each slot that has not completed before F_lo, and the one after it
+  Cur cur[MW], nxt[MW];
+  uint32_t at[MW], tail[MW];
+#pragma unroll
+  for (int j = 0; j < MW; j++) {
+    const uint32_t p = lane + 64u * (uint32_t)j;
+    cur[j] = Cur{kInf, kInf, kInf, kFNone, 0, 0}; nxt[j] = cur[j]; at[j] = 0; tail[j] = 0;
+    if (p < W) {
+      uint32_t lo = seg[p] + 1u, hi = seg[p + 1] - 1u;     // [lo, hi): the slot's calls; hi = its tail sentinel
+      tail[j] = hi;
+      while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (rec[mid].ret_rank >= F_lo) hi = mid; else lo = mid + 1u;
+      }
+      at[j] = lo;
+      cur[j] = load_cur(rec + lo);
+      nxt[j] = load_cur(rec + min(lo + 1u, tail[j]));
+    }
+  }
+  const uint32_t w_off = off[min(F_lo + lane, R)];
+  const uint32_t w_slot = ret_slot[min(F_lo + lane, R - 1u)];
+  const uint64_t below = (1ull << lane) - 1ull;
+
+  for (uint32_t F = F_lo; F < F_hi; F++) {
+    const uint32_t base = __builtin_amdgcn_readlane(w_off, F - F_lo);
+    const uint32_t px = __builtin_amdgcn_readlane(w_slot, F - F_lo);
+    bool live[MW], crashed_open[MW];
+    uint64_t occ[MW];
+#pragma unroll
+    for (int j = 0; j < MW; j++) {
+      const bool here = cur[j].f != kFNone && cur[j].inv <= F;
+      live[j] = here && cur[j].ret != kInf;
+      crashed_open[j] = here && cur[j].ret == kInf && !(cur[j].f == TBC_F_READ && cur[j].a == TBC_NIL);
+      occ[j] = __ballot(live[j]);
+    }
+    // the front's list, in slot order
+    uint32_t before = 0, mypos[MW];
+#pragma unroll
+    for (int j = 0; j < MW; j++) {
+      mypos[j] = base + before + (uint32_t)__popcll(occ[j] & below);
+      before += (uint32_t)__popcll(occ[j]);
+      if (live[j]) {
+        OpRec o; o.op = cur[j].op; o.f_slot = cur[j].f | ((lane + 64u * (uint32_t)j) << 8) | (cur[j].ret == F ? kAtFront : 0u);
+        o.a = cur[j].a; o.b = cur[j].b;
+        lst[mypos[j]] = o;
+      }
+    }
+    // twin masks: the open writes / cas are few -- broadcast each, every lane compares
+    if (twn) {
+      uint64_t tw[MW][MW];
+      uint64_t cw[MW];
+      uint32_t ncw = 0;
+#pragma unroll
+      for (int j = 0; j < MW; j++) {
+        cw[j] = __ballot(live[j] && (cur[j].f == TBC_F_WRITE || cur[j].f == TBC_F_CAS));
+        ncw += (uint32_t)__popcll(cw[j]);
+#pragma unroll
+        for (int w = 0; w < MW; w++) tw[j][w] = 0ull;
+      }
+      if (ncw >= 2u) {
+#pragma unroll
+        for (int jj = 0; jj < MW; jj++) {
+          uint64_t m = cw[jj];
+          while (m) {
+            const uint32_t l = (uint32_t)__builtin_ctzll(m);
+            m &= m - 1ull;
+            const uint32_t zf = __builtin_amdgcn_readlane(cur[jj].f, l), zr = __builtin_amdgcn_readlane(cur[jj].ret, l);
+            const uint32_t zo = __builtin_amdgcn_readlane(cur[jj].op, l);
+            const int32_t za = (int32_t)__builtin_amdgcn_readlane((uint32_t)cur[jj].a, l), zb = (int32_t)__builtin_amdgcn_readlane((uint32_t)cur[jj].b, l);
+#pragma unroll
+            for (int j = 0; j < MW; j++) {
+              const bool same = live[j] && cur[j].f == zf && cur[j].a == za && (zf != TBC_F_CAS || cur[j].b == zb) && cur[j].op != zo;
+              if (same && (zr < cur[j].ret || (zr == cur[j].ret && zo < cur[j].op))) tw[j][jj] |= 1ull << l;
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < MW; j++) if (live[j]) {
+#pragma unroll
+        for (int w = 0; w < MW; w++) twn[(uint64_t)mypos[j] * MW + w] = tw[j][w];
+      }
+    }
+    // open-read masks by value: lane vi keeps row entry vi
+    if (rdm) {
+      uint64_t mine[MW];
+#pragma unroll
+      for (int j = 0; j < MW; j++) mine[j] = 0ull;
+      for (uint32_t vi = 0; vi < V; vi++) {
+#pragma unroll
+        for (int j = 0; j < MW; j++) {
+          const uint64_t m = __ballot(live[j] && cur[j].f == TBC_F_READ && rdm_index(cur[j].a, V) == vi && (vi != 0u || cur[j].a == TBC_NIL));
+          if (lane == vi) mine[j] = m;
+        }
+      }
+      if (lane < V) {
+#pragma unroll
+        for (int j = 0; j < MW; j++) rdm[((uint64_t)F * V + lane) * MW + j] = mine[j];
+      }
+    }
+    // lookahead record of rank F: what the completing call needs / produces, who else open here produces it
+    if (look) {
+      const uint32_t jx = px >> 6, lx = px & 63u;
+      uint32_t xf = kFNone, xinv = 0; int32_t xa = 0, xb = 0;
+#pragma unroll
+      for (int j = 0; j < MW; j++) if (jx == (uint32_t)j) {
+        xf = __builtin_amdgcn_readlane(cur[j].f, lx); xinv = __builtin_amdgcn_readlane(cur[j].inv, lx);
+        xa = (int32_t)__builtin_amdgcn_readlane((uint32_t)cur[j].a, lx); xb = (int32_t)__builtin_amdgcn_readlane((uint32_t)cur[j].b, lx);
+      }
+      const uint32_t need = look_need(xf, xa), prod = look_prod(xf, xa, xb), di = min(F - xinv, 255u);
+      const uint64_t w0 = (uint64_t)(px & 0xFFFFu) | (uint64_t)need << 16 | (uint64_t)prod << 24 | (uint64_t)di << 32 | (255ull << 40);
+      const uint32_t LW = 1 + MW;
+#pragma unroll
+      for (int j = 0; j < MW; j++) {
+        const bool other = (live[j] || crashed_open[j]) && !(jx == (uint32_t)j && lane == lx);
+        const uint64_t pm = need == kLookNone ? 0ull : __ballot(other && look_prod(cur[j].f, cur[j].a, cur[j].b) == need);
+        if (lane == 0) look[(uint64_t)F * LW + 1 + j] = pm;
+      }
+      if (lane == 0) { look[(uint64_t)F * LW] = w0; tmp[F] = 255u; }
+    }
+    // the call completing here leaves: its process's next call takes the lane
+#pragma unroll
+    for (int j = 0; j < MW; j++) {
+      if ((px >> 6) == (uint32_t)j && lane == (px & 63u)) {
+        cur[j] = nxt[j];
+        at[j] = min(at[j] + 1u, tail[j]);
+        nxt[j] = load_cur(rec + min(at[j] + 1u, tail[j]));
+      }
+    }
+  }
+}
+
+// ---- lookahead: how recently another producer of the needed value was invoked
+__global__ __launch_bounds__(1024) void open_dprod_kernel(PackOpenArgs A) {
+  const uint32_t NT = blockDim.x, tid = threadIdx.x, MW = A.mask_words;
+  for (uint32_t h = blockIdx.x; h < A.n_hist; h += gridDim.x) {
+    const Hist* H = &A.hist[h];
+    const BeamHist* B = &A.bh[h];
+    const uint32_t n = H->n_ops, R = H->n_ret;
+    if (H->status != 0 || B->status != 0 || R == 0) continue;
+    const uint8_t* f = A.f + H->op_off;
+    const int32_t* a = A.a + H->op_off;
+    const int32_t* b = A.b + H->op_off;
+    const uint32_t* sc_inv = A.scratch + H->frame_off;
+    const uint32_t* sc_ret = sc_inv + n;
+    const uint32_t LW = 1 + MW;
+    uint64_t* look = A.look + look_off(H->op_off, h, MW);
+    const uint32_t* ret_op = A.ret_op + H->ret_off;
+    uint32_t* tmp = A.tmp + H->op_off;
+    // F: every producer tells the ranks right after its invocation how recent it is
+    for (uint32_t i = tid; i < n; i += NT) {
+      const uint32_t pv = look_prod(f[i], a[i], b[i]);
+      if (pv == kLookNone || (sc_ret[i] == kInf && f[i] == TBC_F_READ)) continue;
+      const uint32_t ir = sc_inv[i];
+      for (uint32_t t = ir; t < R && t < ir + kLookahead; t++) {
+        const uint32_t need = (uint32_t)(ld_agent64(&look[(uint64_t)t * LW]) >> 16) & 0xFFu;
+        if (need == pv && ret_op[t] != i) atomicMin(&tmp[t], t - ir);
+      }
+    }
+    __syncthreads();
+    // G: fold dprod into the records
+    for (uint32_t t = tid; t < R; t += NT) {
+      const uint32_t d = ld_agent(&tmp[t]);
+      if (d < 255u) {
+        const uint64_t w0 = ld_agent64(&look[(uint64_t)t * LW]);
+        look[(uint64_t)t * LW] = (w0 & ~(255ull << 40)) | ((uint64_t)d << 40);
+      }
+    }
+    __syncthreads();
+  }
+}
+
 void launch_pack_open(const PackOpenArgs& a, void* stream) {
-  uint32_t grid = a.n_hist < 4096 ? a.n_hist : 4096;
+  hipStream_t s = (hipStream_t)stream;
+  const uint32_t grid = a.n_hist < 4096 ? a.n_hist : 4096;
   // few histories: latency matters (tbc_check), give each the widest workgroup; many: occupancy matters
-  hipLaunchKernelGGL(pack_open_kernel, dim3(grid), dim3(a.n_hist <= 64 ? 1024 : 256), 0, (hipStream_t)stream, a);
+  const uint32_t nt = a.n_hist <= 64 ? 1024 : 256;
+  hipLaunchKernelGGL(open_counts_kernel, dim3(grid), dim3(nt), 0, s, a);
+  const uint64_t waves = (uint64_t)a.n_hist * a.chunks_per_hist;
+  const uint32_t wgrid = (uint32_t)((waves + 3) / 4);
+  switch (a.mask_words) {
+    case 1: hipLaunchKernelGGL(open_walk_kernel<1>, dim3(wgrid), dim3(256), 0, s, a); break;
+    case 2: hipLaunchKernelGGL(open_walk_kernel<2>, dim3(wgrid), dim3(256), 0, s, a); break;
+    default: hipLaunchKernelGGL(open_walk_kernel<4>, dim3(wgrid), dim3(256), 0, s, a); break;
+  }
+  if (a.look) hipLaunchKernelGGL(open_dprod_kernel, dim3(grid), dim3(nt), 0, s, a);
 }
 
 }  // namespace tbc

@@ -171,7 +171,7 @@ struct tbc_batch {
   hipStream_t stream = nullptr;
   hipEvent_t ev[6] = {};
   uint32_t n_hist = 0;
-  uint64_t total_ops = 0;
+  uint64_t total_ops = 0, max_ops = 1;
   uint32_t mask_words = 1;
   uint32_t frame_words = 6;
   tbc_model model{};
@@ -376,6 +376,7 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
     if (desc->op_off[h + 1] < desc->op_off[h] || n > 0x7FFFFFFFull) { set_error("history %u: bad op_off", h); return TBC_ERR_INVALID_ARG; }
     H.op_off = desc->op_off[h];
     H.n_ops = (uint32_t)n;
+    B->max_ops = std::max<uint64_t>(B->max_ops, n);
     H.n_events = desc->n_events[h];
     H.n_slots = std::max(1u, desc->n_process[h]);
     H.aux = desc->model_aux ? desc->model_aux[h] : model->init;
@@ -417,7 +418,7 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
     return s;
   if (beam) {
     if ((s = B->d_bh.alloc(nh)) || (s = B->d_off.alloc(boff_n)) || (s = B->d_ncr.alloc(boff_n)) ||
-        (s = B->d_occ.alloc(bocc_n)) || (s = B->d_lst.alloc(blst_n)) || (s = B->d_crashed.alloc(T)) ||
+        (s = B->d_lst.alloc(blst_n)) || (s = B->d_crashed.alloc(T)) ||
         (s = B->d_slot8.alloc(slot8_bytes(T, nh))) || (s = B->d_stack.alloc(bstack_n)) || (s = B->d_btab.alloc(btab_n * EW)) ||
         (s = B->d_pool_cursor.alloc(1)))
       return s;
@@ -451,7 +452,7 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
                     B->d_ret.bytes() + B->d_hist.bytes() + B->d_rec.bytes() + B->d_seg.bytes() + B->d_ret_slot.bytes() +
                     B->d_ret_op.bytes() + B->d_bitmap.bytes() + B->d_wpre.bytes() + B->d_frames.bytes() +
                     B->d_tab.bytes() + B->d_results.bytes() + B->d_work.bytes() + B->d_witness.bytes();
-  if (beam) B->device_bytes += B->d_bh.bytes() + B->d_off.bytes() + B->d_ncr.bytes() + B->d_occ.bytes() + B->d_lst.bytes() +
+  if (beam) B->device_bytes += B->d_bh.bytes() + B->d_off.bytes() + B->d_ncr.bytes() + B->d_lst.bytes() +
                                B->d_crashed.bytes() + B->d_slot8.bytes() + B->d_twn.bytes() + B->d_rdm.bytes() + B->d_look.bytes() + B->d_looktmp.bytes() + B->d_dstack.bytes() + B->d_stack.bytes() + B->d_btab.bytes() + B->d_pool.bytes();
 
   if (t_ctx) {
@@ -738,7 +739,6 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results) {
     HIP_TRY(hipMemsetAsync(B->d_pool_cursor.p, 0, sizeof(unsigned long long), s));
     HIP_TRY(hipMemsetAsync(B->d_off.p, 0, B->d_off.bytes(), s));
     HIP_TRY(hipMemsetAsync(B->d_ncr.p, 0, B->d_ncr.bytes(), s));
-    HIP_TRY(hipMemsetAsync(B->d_occ.p, 0, B->d_occ.bytes(), s));
     HIP_TRY(hipMemcpyAsync(B->d_bh.p, B->bh.data(), nh * sizeof(BeamHist), hipMemcpyHostToDevice, s));
   } else {
     HIP_TRY(hipMemsetAsync(B->d_tab.p, 0, B->d_tab.bytes(), s));
@@ -760,7 +760,8 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results) {
   if (beam) {
     PackOpenArgs po{};
     po.hist = B->d_hist.p; po.bh = B->d_bh.p; po.f = B->d_f.p; po.a = B->d_a.p; po.b = B->d_b.p; po.process = B->d_proc.p;
-    po.scratch = B->d_frames.p; po.off = B->d_off.p; po.ncr = B->d_ncr.p; po.occ = B->d_occ.p; po.lst = B->d_lst.p;
+    po.scratch = B->d_frames.p; po.off = B->d_off.p; po.ncr = B->d_ncr.p; po.lst = B->d_lst.p;
+    po.rec = B->d_rec.p; po.seg = B->d_seg.p; po.chunks_per_hist = (uint32_t)((B->max_ops + 63) / 64);
     po.crashed = B->d_crashed.p; po.ret_slot = B->d_ret_slot.p; po.slot8 = B->d_slot8.p;
     po.ret_op = B->d_ret_op.p; po.look = B->lookahead ? B->d_look.p : nullptr; po.tmp = B->d_looktmp.p; po.n_hist = nh; po.mask_words = B->mask_words;
     po.twn = B->rules ? B->d_twn.p : nullptr; po.rdm = B->rules ? B->d_rdm.p : nullptr; po.vpad = B->vpad;

@@ -162,7 +162,7 @@ __host__ __device__ inline uint32_t rdm_index(int32_t v, uint32_t vpad) {   // r
 
 struct __attribute__((aligned(16))) BeamHist {
   uint64_t off_off;     // u32 units: off[] (n_ops + 2), ncr[] at the same offset in its own arena
-  uint64_t occ_off;     // u64 units: occ[] ((n_ops + 1) * mask_words)
+  uint64_t occ_off;     // (unused since the open-call lists are built by walking the fronts)
   uint64_t lst_off;     // OpRec units
   uint64_t stack_off;   // u32 units (capacity = table capacity)
   uint64_t tab_off;     // entry units
@@ -181,9 +181,12 @@ struct PackOpenArgs {
   const int32_t* b;
   const int32_t* process;
   const uint32_t* scratch;   // pack_kernel's per-op inv_rank / ret_rank (frames arena)
+  const Rec* rec;            // pack_kernel's per-process record lists (at Hist.rec_off) ...
+  const uint32_t* seg;       // ... and their starts (at Hist.seg_off)
+  uint32_t chunks_per_hist;  // ceil(most ops of a history / 64): wavefronts the walk launches per history
+  uint32_t pad0;
   uint32_t* off;
   uint32_t* ncr;
-  uint64_t* occ;
   OpRec* lst;
   OpRec* crashed;            // n_ops entries per history at op_off
   const uint32_t* ret_slot;  // pack_kernel: process slot of the call completing at each rank (at ret_off)
