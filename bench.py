@@ -14,8 +14,12 @@
              (16 B per visited-set probe that finds a duplicate,
              32 B per probe that inserts a new config) / the kernel's average
              duration, measured with HIP events on the library's own stream
-  cpu_baseline : the CPU restatement of the same search (oracle/wgl_window.c,
-             "port", 1 thread) on a bounded sample of the same histories
+  cpu_baseline : the CPU restatement of the same search (oracle/wgl_window.c, "port") on a bounded
+             sample of the same histories: on all host cores (pthread pool, oracle/many.c) = `value`,
+             and on one thread (`single_thread`)
+  extra    : time-to-verdict of ONE history through tbc_check (the level sweep, jit_sweep.hip), the
+             crashed-op tiers of BASELINE.md section 3, a second workload at 50 % duty ("64 concurrent
+             processes", ~32 calls in flight) with its own value / roofline, the H2D-inclusive rate
 
 Usage: python bench.py --gpus N --steps K --warmup W   (N>1 via torch.distributed.run)
 """
@@ -67,7 +71,7 @@ def main():
                     help="a history that has used more rounds than this continues at width 16 (0 = off)")
     ap.add_argument("--cpu-sample", type=int, default=256, help="histories timed on the CPU oracle (rank 0, N=1)")
     ap.add_argument("--busy2", type=float, default=0.5, help="second workload: duty cycle of the '64 concurrent processes' reading (0 = skip)")
-    ap.add_argument("--batch2", type=int, default=1024, help="second workload: histories per GPU")
+    ap.add_argument("--batch2", type=int, default=4096, help="second workload: histories per GPU")
     ap.add_argument("--no-tiers", action="store_true", help="skip the crashed-op tiers (extra.tiers)")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
@@ -210,15 +214,15 @@ def main():
             tc = time.perf_counter()
             ok1 = sum(wgl.check(d, om, "window", want_witness=False)["valid"] == 1 for d in dicts[:S1])
             tc = time.perf_counter() - tc
-            # all host cores: the same sample split over a thread pool (the C oracle runs outside the GIL)
+            # all host cores: the same sample on a pthread pool inside the C oracle (oracle/many.c), one history per
+            # thread at a time -- how stock Knossos would spread independent keys over a thread pool
             cores = os.cpu_count() or 1
             reps = max(1, (4 * cores + S - 1) // S)
             work = dicts * reps
-            with ThreadPoolExecutor(cores) as ex:
-                list(ex.map(lambda d: wgl.check(d, om, "window", want_witness=False)["valid"], work[:cores]))   # spin up
-                ta = time.perf_counter()
-                oka = list(ex.map(lambda d: wgl.check(d, om, "window", want_witness=False)["valid"], work))
-                ta = time.perf_counter() - ta
+            wgl.check_many(work[:cores], om, cores)                                     # spin up / page in
+            ta = time.perf_counter()
+            oka, started = wgl.check_many(work, om, cores)
+            ta = time.perf_counter() - ta
             tb = time.perf_counter()
             rbo = wgl.check(bad.as_dict(), om, "window", want_witness=False, max_steps=50_000_000)
             tb = time.perf_counter() - tb
@@ -232,7 +236,7 @@ def main():
             ts = time.perf_counter() - ts
             line["cpu_baseline"] = {"value": round(len(work) / ta, 3), "unit": "histories/s", "cores": cores, "kind": "port",
                                     "sample": f"first {S} histories of this batch x {reps}, oracle/wgl_window.c (C restatement of "
-                                              f"knossos.wgl, gcc -O2) on a pool of {cores} threads; not stock Knossos (no JVM here)",
+                                              f"knossos.wgl, gcc -O2) on {started} pthreads (oracle/many.c); not stock Knossos (no JVM here)",
                                     "single_thread": {"value": round(S1 / tc, 3), "unit": "histories/s", "cores": 1,
                                                       "ms_per_history": round(tc / S1 * 1e3, 3), "sample": f"first {S1} histories"},
                                     "ms_per_history": round(tc / S1 * 1e3, 3),
@@ -274,7 +278,7 @@ def main():
             B2 = args.batch2
             h2 = synth.register_ops_many(range(10_000_000, 10_000_000 + B2), n_ops=args.ops, n_procs=args.procs, busy=args.busy2, info=0.0)
             o2 = core.make_opts(device=local_rank, time_limit_ms=600000, want_witness=False, algorithm=N.ALG_COMPETITION,
-                                search_width=args.width, visited_per_op=256)
+                                search_width=args.width, visited_per_op=64)
             with core.Batch(h2, model, o2) as b2:
                 b2.run()
                 t2 = time.perf_counter(); b2.run(); t2 = time.perf_counter() - t2

@@ -53,19 +53,26 @@ struct Model {
     *out = (int32_t)s;
     return ok;
   }
-  // knossos.model/step: may op (f,a,b) be applied in state st?
+  // knossos.model/step: may op (f,a,b) be applied in state st?  REGF = the caller's kernel is the register-family
+  // instantiation (register, cas-register, mutex): the table / multi-register paths are compiled out of it.
+  // One formula serves register, cas-register and mutex: pack lets a history carry only its model's own ops
+  // (:acquire / :release for a mutex, never :cas for a plain register), and f never matches another model's codes.
+  template <bool REGF = false>
   __device__ __forceinline__ bool ok(int32_t st, uint32_t f, int32_t a, int32_t b) const {
-    if (kind == TBC_MODEL_MUTEX) return (f == TBC_F_ACQUIRE && st == 0) || (f == TBC_F_RELEASE && st == 1);
-    if (kind == TBC_MODEL_TABLE) return f == TBC_F_CLASS && table[(uint32_t)st * n_classes + (uint32_t)a] != TBC_TABLE_INCONSISTENT;
-    if (kind == TBC_MODEL_MULTI_REGISTER) { int32_t s2; return f == TBC_F_TXN && txn(st, a, b, &s2); }
-    // register / cas-register (pack rejected :cas for plain registers)
-    return f == TBC_F_WRITE || (f == TBC_F_READ && (a == TBC_NIL || a == st)) || (f == TBC_F_CAS && a == st);
+    if constexpr (!REGF) {
+      if (kind == TBC_MODEL_TABLE) return f == TBC_F_CLASS && table[(uint32_t)st * n_classes + (uint32_t)a] != TBC_TABLE_INCONSISTENT;
+      if (kind == TBC_MODEL_MULTI_REGISTER) { int32_t s2; return f == TBC_F_TXN && txn(st, a, b, &s2); }
+    }
+    return f == TBC_F_WRITE || (f == TBC_F_READ && (a == TBC_NIL || a == st)) || (f == TBC_F_CAS && a == st) ||
+           (f == TBC_F_ACQUIRE && st == 0) || (f == TBC_F_RELEASE && st == 1);
   }
+  template <bool REGF = false>
   __device__ __forceinline__ int32_t apply(int32_t st, uint32_t f, int32_t a, int32_t b) const {
-    if (kind == TBC_MODEL_MUTEX) return f == TBC_F_ACQUIRE ? 1 : 0;
-    if (kind == TBC_MODEL_TABLE) return (int32_t)table[(uint32_t)st * n_classes + (uint32_t)a];
-    if (kind == TBC_MODEL_MULTI_REGISTER) { int32_t s2 = st; (void)txn(st, a, b, &s2); return s2; }
-    return f == TBC_F_WRITE ? a : (f == TBC_F_CAS ? b : st);
+    if constexpr (!REGF) {
+      if (kind == TBC_MODEL_TABLE) return (int32_t)table[(uint32_t)st * n_classes + (uint32_t)a];
+      if (kind == TBC_MODEL_MULTI_REGISTER) { int32_t s2 = st; (void)txn(st, a, b, &s2); return s2; }
+    }
+    return f == TBC_F_WRITE ? a : (f == TBC_F_CAS ? b : (f == TBC_F_ACQUIRE ? 1 : (f == TBC_F_RELEASE ? 0 : st)));
   }
 };
 
@@ -73,13 +80,13 @@ struct Model {
 // May the open call `oi` be linearized next in the config (fi, Mp, st)?  State-based models ask
 // Model::ok; the commutative ones (set, bank) look at the calls completed before the front (per-front
 // tables in the pool) and at the open calls already linearized (the parent's open-call list).
-template <int MW, bool COMM>
+template <int MW, bool COMM, bool REGF = false>
 __device__ __forceinline__ bool pair_viable(const Model& model, int32_t st, uint32_t fi, const uint64_t (&Mp)[MW],
                                             uint32_t poff, uint32_t nlive, uint32_t cnt, const OpRec* lst,
                                             const OpRec* crashed, const OpRec& oi) {
   const uint32_t f = oi.f_slot & 0xFFu;
   if constexpr (!COMM) {
-    return model.ok(st, f, oi.a, oi.b);
+    return model.template ok<REGF>(st, f, oi.a, oi.b);
   } else {
   if (model.kind == TBC_MODEL_SET) {
     // knossos.model/set, state-free: a read of R is consistent iff the adds completed before the
@@ -128,7 +135,7 @@ __device__ __forceinline__ bool pair_viable(const Model& model, int32_t st, uint
 // The config reached by linearizing `oi` in (fi, Mp, st): set its process bit, step the model, and if it
 // was the front's own call move the front past every completion already linearized (clearing their bits).
 // slot_at(r) = process slot of the call completing at rank r (the caller decides how it is fetched).
-template <int MW, bool COMM, class SlotAt>
+template <int MW, bool COMM, bool REGF = false, class SlotAt>
 __device__ __forceinline__ void make_child(const Model& model, bool viable, int32_t st, uint32_t fi, uint32_t R,
                                            SlotAt slot_at, const OpRec& oi,
                                            const uint64_t (&Mp)[MW], uint64_t (&M2)[MW], int32_t& st2, uint32_t& fi2) {
@@ -137,7 +144,7 @@ __device__ __forceinline__ void make_child(const Model& model, bool viable, int3
 #pragma unroll
   for (int j = 0; j < MW; j++) M2[j] = Mp[j];
   if (!viable) return;
-  if constexpr (COMM) st2 = 0; else st2 = model.apply(st, f, oi.a, oi.b);
+  if constexpr (COMM) st2 = 0; else st2 = model.template apply<REGF>(st, f, oi.a, oi.b);
 #pragma unroll
   for (int j = 0; j < MW; j++) if ((p >> 6) == (uint32_t)j) M2[j] |= 1ull << (p & 63u);
   if (!(oi.f_slot & kAtFront)) return;

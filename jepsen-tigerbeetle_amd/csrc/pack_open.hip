@@ -304,14 +304,19 @@ __global__ __launch_bounds__(256) void open_walk_kernel(PackOpenArgs A) {
     }
     // open-read masks by value: lane vi keeps row entry vi
     if (rdm) {
+      // (the open reads are few: each one drops its bit into the lane that keeps its value's entry)
       uint64_t mine[MW];
 #pragma unroll
       for (int j = 0; j < MW; j++) mine[j] = 0ull;
-      for (uint32_t vi = 0; vi < V; vi++) {
 #pragma unroll
-        for (int j = 0; j < MW; j++) {
-          const uint64_t m = __ballot(live[j] && cur[j].f == TBC_F_READ && rdm_index(cur[j].a, V) == vi && (vi != 0u || cur[j].a == TBC_NIL));
-          if (lane == vi) mine[j] = m;
+      for (int j = 0; j < MW; j++) {
+        uint64_t rd = __ballot(live[j] && cur[j].f == TBC_F_READ);
+        while (rd) {
+          const uint32_t l = (uint32_t)__builtin_ctzll(rd);
+          rd &= rd - 1ull;
+          const int32_t va = (int32_t)__builtin_amdgcn_readlane((uint32_t)cur[j].a, l);
+          const uint32_t vi = rdm_index(va, V);
+          if (lane == vi && (vi != 0u || va == TBC_NIL)) mine[j] |= 1ull << l;
         }
       }
       if (lane < V) {

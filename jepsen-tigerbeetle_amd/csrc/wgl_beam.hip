@@ -250,7 +250,7 @@ __device__ __forceinline__ bool grow_visited_set(const BeamArgs& A, state_ptr S,
   return true;
 }
 
-template <int MW, bool COMM>
+template <int MW, bool COMM, bool REGF>
 __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, const uint32_t lane) {
   constexpr uint32_t KW = MW + 1;   // u64 words per key
 
@@ -268,7 +268,9 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
   // K parents per iteration, G = 64 / K lanes (candidate slots) per parent per round.  A history that has
   // used more than round_budget rounds continues at K = 16: stragglers then need far fewer dependent rounds.
   DevResult* out = A.results + hidx;
-  Model model{A.model_kind, A.table, A.n_classes, A.pool_vals, (int32_t)rfl((uint32_t)H->aux), A.n_keys};
+  // the register family (register, cas-register, mutex) steps on immediates: its kernel carries no table / pool pointers
+  const Model model = REGF ? Model{A.model_kind, nullptr, 0u, nullptr, 0, 0u}
+                           : Model{A.model_kind, A.table, A.n_classes, A.pool_vals, (int32_t)rfl((uint32_t)H->aux), A.n_keys};
 
   uint64_t* p_k0 = reinterpret_cast<uint64_t*>(lds);
   uint64_t* p_M = p_k0 + 16;
@@ -352,12 +354,14 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
   const uint32_t full_at = (uint32_t)((1ull << cap_log2) - (1ull << (cap_log2 - 2)));
   gu64* const par = tab + ((uint64_t)KW << cap_log2);
   uint32_t K = sld(S, S_K), gshift = 6u - (31u - (uint32_t)__builtin_clz(K)), G = 1u << gshift;
-  uint64_t probes = sld64(S, S_PROBES), visited = sld64(S, S_VISITED), expanded = sld64(S, S_EXPANDED);
-  uint64_t iterations = sld64(S, S_ITER), rounds = sld64(S, S_ROUNDS);
+  // counters: 32-bit inside the loop (what happened since the state was last parked), 64-bit totals in LDS.  The
+  // visited-set fill is an absolute count (it never exceeds the capacity, < 2^28).
+  uint32_t probes = 0, expanded = 0, iterations = 0, rounds = 0;
+  uint32_t visited = (uint32_t)sld64(S, S_VISITED);
+  const uint64_t probes0 = sld64(S, S_PROBES), rounds0 = sld64(S, S_ROUNDS);
+  bool need_park = false;
   uint32_t sp = sld(S, S_SP), max_sp = sld(S, S_MAXSP), lane_maxf = sld(S, S_MAXF);
   int32_t verdict = (int32_t)sld(S, S_VERDICT), cause = (int32_t)sld(S, S_CAUSE);
-  uint32_t win_parent = sld(S, S_WINPAR), win_op = sld(S, S_WINOP);
-  int32_t win_state = (int32_t)sld(S, S_WINSTATE);
   gu32* const dstack = (gu32*)sld64(S, S_DSTACK);
   uint32_t dsp = sld(S, S_DSP);
   const bool look_on = sld(S, S_EXACT) == 0u;     // false once the set-aside configs are being expanded
@@ -371,7 +375,8 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
       if (dsp != 0u) { need_switch = true; break; }
       verdict = TBC_INVALID; break;
     }
-    if (A.round_budget && rounds > A.round_budget && K < 16u) { K = 16u; gshift = 2u; G = 4u; }
+    if (A.round_budget && rounds0 + rounds > A.round_budget && K < 16u) { K = 16u; gshift = 2u; G = 4u; }
+    if (__builtin_expect(probes > 0x7FFFFFFFu, 0)) { need_park = true; break; }      // fold the deltas into the 64-bit totals
     const uint32_t np = min(K, sp);
     const uint32_t ln = opaque_lane(lane);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -423,7 +428,7 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
     __builtin_amdgcn_wave_barrier();
     // ---- room for every pair of this iteration?  If not, put the popped configs back and leave: the
     // visited set moves to a 4x larger one, and the iteration is taken again from its start.
-    if (__builtin_expect((uint64_t)visited + (grouped ? np * G : T) > full_at, 0)) { sp += np; need_grow = true; break; }
+    if (__builtin_expect(visited + (grouped ? np * G : T) > full_at, 0)) { sp += np; need_grow = true; break; }
     const uint32_t lr = opaque_lane(lane);
     iterations++; expanded += np;
     SEG(0);
@@ -492,7 +497,7 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
           }
         }
       }
-      const bool viable = act && !lin && !dominated && pair_viable<MW, COMM>(model, st, fi, Mp, poff, nlive, cnt, lst, crashed, oi);
+      const bool viable = act && !lin && !dominated && pair_viable<MW, COMM, REGF>(model, st, fi, Mp, poff, nlive, cnt, lst, crashed, oi);
       int32_t st2 = st;
       uint32_t fi2 = fi;
       uint64_t M2[MW];
@@ -502,7 +507,7 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
         if (d < 16u) return (uint32_t)(w1 >> (8u * (d - 8u))) & 0xFFu;
         return (uint32_t)slot8[r];
       };
-      make_child<MW, COMM>(model, viable, st, fi, R, slot_at, oi, Mp, M2, st2, fi2);
+      make_child<MW, COMM, REGF>(model, viable, st, fi, R, slot_at, oi, Mp, M2, st2, fi2);
       if constexpr (!COMM) {
         // eager reads: the child takes every open read its state allows (value nil or the state), the front moves
         // past the completions that linearizes, and the calls open at the new front are looked at again
@@ -536,12 +541,12 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
       const uint64_t succ = __ballot(viable && fi2 == R);
       if (succ) {   // linearizable: lowest pair wins, nothing of this round is inserted
         const uint32_t wl = (uint32_t)__builtin_ctzll(succ);
-        win_parent = rl(pslot, wl); win_op = rl(op, wl); win_state = (int32_t)rl((uint32_t)st2, wl);
+        if (lane == 0) { sst(S, S_WINPAR, rl(pslot, wl)); sst(S, S_WINOP, rl(op, wl)); sst(S, S_WINSTATE, rl((uint32_t)st2, wl)); }
         verdict = TBC_VALID;
         break;
       }
       const uint64_t vb = __ballot(viable);
-      probes += (uint64_t)__popcll(vb);
+      probes += (uint32_t)__popcll(vb);
 
       // the child's front: its open-call list (issued now, consumed at push; hidden under the probe)
       uint32_t co0 = 0, co1 = 0, cnc = 0;
@@ -673,11 +678,11 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
     }
     max_sp = max(max_sp, sp);
     if (A.dbg && lr == 0 && (iterations & 255u) == 1u) {
-      A.dbg[8] = hidx; A.dbg[9] = (uint32_t)iterations; A.dbg[10] = sp; A.dbg[11] = (uint32_t)probes;
-      A.dbg[12] = (uint32_t)visited; A.dbg[13] = maxcnt; A.dbg[14] = np; A.dbg[15] = (uint32_t)rounds;
+      A.dbg[8] = hidx; A.dbg[9] = iterations; A.dbg[10] = sp; A.dbg[11] = probes;
+      A.dbg[12] = visited; A.dbg[13] = maxcnt; A.dbg[14] = np; A.dbg[15] = rounds;
     }
     if (verdict == -2) {
-      if (A.max_steps && probes > A.max_steps) { verdict = TBC_UNKNOWN; cause = TBC_CAUSE_STEP_LIMIT; }
+      if (A.max_steps && probes0 + probes > A.max_steps) { verdict = TBC_UNKNOWN; cause = TBC_CAUSE_STEP_LIMIT; }
       else if (A.time_limit_ticks && (iterations & 63u) == 0 && (uint64_t)wall_clock64() - t0 > A.time_limit_ticks) {
         verdict = TBC_UNKNOWN; cause = TBC_CAUSE_TIME_LIMIT;
       }
@@ -692,9 +697,8 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
     if (lane == 0) {
       sst(S, S_SP, sp); sst(S, S_MAXSP, max_sp); sst(S, S_MAXF, mf); sst(S, S_K, K); sst(S, S_DSP, dsp);
       sst(S, S_VERDICT, (uint32_t)verdict); sst(S, S_CAUSE, (uint32_t)cause);
-      sst(S, S_WINPAR, win_parent); sst(S, S_WINOP, win_op); sst(S, S_WINSTATE, (uint32_t)win_state);
-      sst64(S, S_PROBES, probes); sst64(S, S_VISITED, visited); sst64(S, S_EXPANDED, expanded);
-      sst64(S, S_ITER, iterations); sst64(S, S_ROUNDS, rounds);
+      sst64(S, S_PROBES, probes0 + probes); sst64(S, S_VISITED, (uint64_t)visited); sst64(S, S_EXPANDED, sld64(S, S_EXPANDED) + expanded);
+      sst64(S, S_ITER, sld64(S, S_ITER) + iterations); sst64(S, S_ROUNDS, rounds0 + rounds);
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -708,6 +712,7 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
     if (lane < kRing) r_pos[lane] = kNone;     // ring entries are keyed by stack position
     continue;
   }
+  if (need_park) continue;
   if (!need_grow) break;
   if (!grow_visited_set<MW>(A, S, r_pos, lane)) {
     if (lane == 0) { sst(S, S_VERDICT, (uint32_t)TBC_UNKNOWN); sst(S, S_CAUSE, (uint32_t)TBC_CAUSE_VISITED_FULL); }
@@ -813,12 +818,12 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
 #define TBC_BEAM_WAVES 4
 #endif
 constexpr uint32_t kBeamWaves = TBC_BEAM_WAVES;
-template <int MW, bool COMM>
+template <int MW, bool COMM, bool REGF>
 __global__ __launch_bounds__(64 * kBeamWaves, COMM ? 1 : TBC_BEAM_MIN_WAVES) void wgl_beam_kernel(BeamArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   const uint32_t lane = threadIdx.x & 63u, wv = rfl(threadIdx.x >> 6);
   const uint32_t w = blockIdx.x * kBeamWaves + wv;
-  if (w < A.n_work) beam_one<MW, COMM>(A, rfl(A.work[w]), lds + wv * beam_lds_words(MW), lane);
+  if (w < A.n_work) beam_one<MW, COMM, REGF>(A, rfl(A.work[w]), lds + wv * beam_lds_words(MW), lane);
 }
 
 template <int MW>
@@ -828,9 +833,11 @@ void launch_beam_mw(const BeamArgs& a, hipStream_t s) {
   // the commutative (set / bank) models get their own instantiation: their evaluation code would
   // otherwise double the register budget of the register-family kernel
   if (a.model_kind == TBC_MODEL_SET || a.model_kind == TBC_MODEL_BANK)
-    hipLaunchKernelGGL((wgl_beam_kernel<MW, true>), dim3(n_blocks), dim3(64 * kBeamWaves), lds, s, a);
+    hipLaunchKernelGGL((wgl_beam_kernel<MW, true, false>), dim3(n_blocks), dim3(64 * kBeamWaves), lds, s, a);
+  else if (a.model_kind == TBC_MODEL_REGISTER || a.model_kind == TBC_MODEL_CAS_REGISTER || a.model_kind == TBC_MODEL_MUTEX)
+    hipLaunchKernelGGL((wgl_beam_kernel<MW, false, true>), dim3(n_blocks), dim3(64 * kBeamWaves), lds, s, a);
   else
-    hipLaunchKernelGGL((wgl_beam_kernel<MW, false>), dim3(n_blocks), dim3(64 * kBeamWaves), lds, s, a);
+    hipLaunchKernelGGL((wgl_beam_kernel<MW, false, false>), dim3(n_blocks), dim3(64 * kBeamWaves), lds, s, a);
 }
 
 }  // namespace

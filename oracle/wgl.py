@@ -33,7 +33,7 @@ class OracleResult(C.Structure):
 
 def build(force: bool = False) -> str:
     so = os.path.join(_HERE, "liboracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("wgl_ref.c", "wgl_window.c", "linear_ref.c", "wgl_beam.c", "sweep_ref.c", "oracle_model.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("wgl_ref.c", "wgl_window.c", "linear_ref.c", "wgl_beam.c", "sweep_ref.c", "many.c", "oracle_model.h")]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s", "liboracle.so"])
     return so
@@ -265,3 +265,28 @@ def check_sweep(ops, model, eager_reads=True, twin_rule=True, seg_target=0, max_
     if want_levels:
         out["level_sizes"] = lv
     return out
+
+
+def check_many(ops_list, model, n_threads, max_steps=0):
+    """wgl_window_check over many histories on a pthread pool (many.c): verdicts as an int32 array."""
+    nh = len(ops_list)
+    keep = []
+
+    def col(name, dt, ct):
+        arrs = [np.ascontiguousarray(o[name], dt) for o in ops_list]
+        keep.append(arrs)
+        return (C.POINTER(ct) * nh)(*[_p(x, ct) for x in arrs])
+
+    n = np.array([len(o["f"]) for o in ops_list], np.uint32)
+    npr = np.array([int(o["n_process"]) for o in ops_list], np.uint32)
+    f, a, b = col("f", np.uint8, C.c_uint8), col("a", np.int32, C.c_int32), col("b", np.int32, C.c_int32)
+    pr = col("process", np.int32, C.c_int32)
+    inv, ret = col("inv_pos", np.uint32, C.c_uint32), col("ret_pos", np.uint32, C.c_uint32)
+    m, keep_m = _model(model)
+    valid = np.zeros(nh, np.int32)
+    fn = lib().wgl_window_check_many
+    fn.restype = C.c_int
+    started = fn(C.c_uint32(nh), _p(n, C.c_uint32), _p(npr, C.c_uint32), f, a, b, pr, inv, ret, C.byref(m),
+                 C.c_uint64(max_steps), C.c_uint32(n_threads), _p(valid, C.c_int32))
+    del keep, keep_m
+    return valid, started
