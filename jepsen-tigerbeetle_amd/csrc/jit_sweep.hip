@@ -12,13 +12,14 @@
 // What makes it a GPU algorithm is the cut into SEGMENTS.  A depth-first search of one history is a chain
 // of >= 10^4 dependent steps whatever the hardware; the sweep's levels are just as
 // dependent -- but a level set is small enough to be started from EVERY config that is possible at a front
-// at all.  So the history is cut at fronts where at most m calls are open (sweep_cuts_kernel), each segment
-// is swept by its own wavefront from all nd * 2^m <= 32 possible configs of its first front ("origins"),
-// every config carrying the 32-bit set of origins it is reachable from (duplicates OR their sets; sub-rounds
-// go by calls linearized, so a set is final before its config is expanded), and a segment hands on a 32 x 32
-// bit relation origin -> origin of the next segment.  The host composes the relations in order (a few
-// hundred word operations).  One 10k-op history is then checked by ~150 wavefronts at once, each walking
-// ~50 levels, instead of by one wavefront walking 10^4 rounds.
+// at all.  So the history is cut, in every window of T fronts, at the front where the fewest calls are open
+// (sweep_cuts_kernel; at most m), the configs possible there -- (state of the domain) x (subset of the open
+// calls), nd * 2^m <= 128 "origins", numbered arithmetically -- are dealt to wavefronts 32 at a time, every
+// config carries the 32-bit set of its wavefront's origins it is reachable from (duplicates OR their sets;
+// sub-rounds go by calls linearized, so a set is final before its config is expanded), and a wavefront hands
+// on a 32 x 128 bit relation origin -> origin ids of the next segment.  The host composes the relations in
+// order (a few hundred word operations).  One 10k-op history is then checked by ~350 wavefronts at once,
+// each walking < 100 levels, instead of by one wavefront walking 10^4 rounds.
 //
 // Everything a level touches lives in LDS: three config sets (this level, the next, the sub-round set -- the
 // sub-rounds alternate between the third set and the first, dead after its own expansion), two open-addressed
@@ -131,31 +132,16 @@ __device__ __forceinline__ bool build_insert2(Build& A, Build& B, uint32_t sel, 
   return true;
 }
 
-// entry number of a key in a finished set, or kNoEnt
-constexpr uint32_t kNoEnt = 0xFFFFFFFFu;
-template <uint32_t HS>
-__device__ __forceinline__ uint32_t build_find(const Build& b, uint32_t mlo, uint32_t mhi, uint32_t st) {
-  uint32_t h = key_slot<HS>(mlo, mhi, st);
-  for (uint32_t i = 0; i < HS; i++) {
-    const uint32_t s = b.tab[h];
-    if ((s >> kGenShift) != b.gen) return kNoEnt;
-    const Ent k = b.e[s & 0xFFFFu];
-    if (k.mlo == mlo && k.mhi == mhi && k.st == st) return s & 0xFFFFu;
-    h = (h + 1u) & (HS - 1u);
-  }
-  return kNoEnt;
-}
-
 __device__ __forceinline__ uint64_t mask_of(const Ent& e) { return (uint64_t)e.mlo | ((uint64_t)e.mhi << 32); }
 
 // LDS words per wavefront: 3 sets, 2 tables, stage, open-call records + twin masks, 2 read-mask rows, expansion list, relation
 template <uint32_t CAP>
-constexpr uint32_t sweep_lds_words() { return 3 * CAP * 4 + 2 * (2 * CAP) + 64 * 4 + kCand * 4 + kCand * 2 + 2 * 32 * 2 + CAP / 2 + 64; }
+constexpr uint32_t sweep_lds_words() { return 3 * CAP * 4 + 2 * (2 * CAP) + 64 * 4 + kCand * 4 + kCand * 2 + 2 * 32 * 2 + CAP / 2 + 128; }
 
 }  // namespace
 
-// ---- cut placement: thread k of history h looks for the first front in [k*T, (k+1)*T) with at most m calls
-// open and no crashed call invoked yet (oracle/sweep_ref.c states the rule)
+// ---- cut placement: thread k of history h takes, in the window [k*T, (k+1)*T), the front with the fewest calls
+// open among those where no crashed call is open (the first such front), if that is <= m (oracle/sweep_ref.c)
 __global__ __launch_bounds__(256) void sweep_cuts_kernel(SweepArgs A) {
   const uint32_t h = blockIdx.x;
   if (h >= A.n_hist) return;
@@ -171,14 +157,18 @@ __global__ __launch_bounds__(256) void sweep_cuts_kernel(SweepArgs A) {
     else if (A.seg_target && H->status == 0 && B->status == 0) {
       const uint64_t lo = (uint64_t)k * A.seg_target;
       const uint64_t hi = lo + A.seg_target < R ? lo + A.seg_target : R;
-      for (uint64_t F = lo; F < hi; F++)
-        if (off[F + 1] - off[F] <= A.cut_open && ncr[F] == 0u) { cut = (uint32_t)F; break; }
+      uint32_t best = kInf;
+      for (uint64_t F = lo; F < hi; F++) {
+        const uint32_t no = off[F + 1] - off[F];
+        if (ncr[F] == 0u && no < best) { best = no; cut = (uint32_t)F; }
+      }
+      if (best > A.cut_open) cut = kInf;
     }
     cuts[k] = cut;
   }
 }
 
-// ---- the sweep: one wavefront per (history, cut)
+// ---- the sweep: one wavefront per (history, cut, 32 origins)
 template <uint32_t CAP>
 __global__ __launch_bounds__(64) void jit_sweep_kernel(SweepArgs A) {
   constexpr uint32_t HS = 2 * CAP;
@@ -189,13 +179,13 @@ __global__ __launch_bounds__(64) void jit_sweep_kernel(SweepArgs A) {
   // writes that level's configs reachable from the live origins -- knossos.linear's :configs of an invalid verdict.
   // second pass (A.seg_list): the listed (history, segment) pairs only (the ones that overflowed the small sets)
   const bool dump = A.dump_cfg != nullptr;
-  uint32_t h, k;
-  if (dump) { h = A.dump_hist; k = A.dump_seg; }
-  else if (A.seg_list) { h = rfl(A.seg_list[2 * w]); k = rfl(A.seg_list[2 * w + 1]); }
-  else { h = w / A.max_segs; k = w - h * A.max_segs; }
+  uint32_t h, k, sl;
+  if (dump) { h = A.dump_hist; k = A.dump_seg; sl = A.dump_slice; }
+  else if (A.seg_list) { h = rfl(A.seg_list[3 * w]); k = rfl(A.seg_list[3 * w + 1]); sl = rfl(A.seg_list[3 * w + 2]); }
+  else { const uint32_t per = A.max_segs * kSweepSlices; h = w / per; const uint32_t r = w - h * per; k = r / kSweepSlices; sl = r % kSweepSlices; }
   if (h >= A.n_hist) return;
   const uint32_t* cuts = A.cuts + (uint64_t)h * A.max_segs;
-  SegResult* out = A.seg + (uint64_t)h * A.max_segs + k;
+  SegResult* out = A.seg + ((uint64_t)h * A.max_segs + k) * kSweepSlices + sl;
   const uint32_t F0 = rfl(cuts[k]);
   if (F0 == kInf) { if (lane == 0 && !dump) out->status = kSegNone; return; }
   const Hist* H = A.hist + h;
@@ -226,9 +216,9 @@ __global__ __launch_bounds__(64) void jit_sweep_kernel(SweepArgs A) {
   uint64_t* row_a = cand_tw + kCand;          // read masks of the current level's front
   uint64_t* row_b = row_a + 32;               // ... of the next front
   uint16_t* expl = reinterpret_cast<uint16_t*>(row_b + 32);   // entries of `cur` that still need X
-  uint32_t* Mrel = reinterpret_cast<uint32_t*>(expl + CAP);   // 32 words: origin -> origins of the next segment
+  uint32_t* Mrel = reinterpret_cast<uint32_t*>(expl + CAP);   // 32 x 4 words: origin -> origin ids of the next segment
   for (uint32_t i = lane; i < 2 * HS; i += 64) tab_nxt[i] = 0u;
-  if (lane < 32) Mrel[lane] = 0u;
+  Mrel[lane] = 0u; Mrel[64 + lane] = 0u;
   lds_sync();
   uint32_t gen_nxt = 0, gen_q = 0;
 
@@ -284,44 +274,44 @@ __global__ __launch_bounds__(64) void jit_sweep_kernel(SweepArgs A) {
     return true;
   };
 
-  // ---- origins: segment 0 starts from the initial config; every other segment from every config possible at
-  // its first front -- (state of the domain, subset of the calls open there), in normal form
+  // ---- origins: segment 0 starts from the initial config; every other segment from every config possible at its
+  // first front.  Id = state index * 2^no + (bit c = the c-th call open there is linearized); this wavefront takes
+  // ids 32 * sl .. 32 * sl + 31, lane = id, and only the ids that are configs -- in normal form -- count.
   Ent* cur_e = sets; Ent* nxt_e = sets + CAP; Ent* q_e = sets + 2 * CAP;
   Build cur, nxt, q, none;
   none.e = sets; none.tab = tab_q; none.n = 0; none.gen = 0;
   uint32_t n_org = 0;
-  auto make_origins = [&](Build& dst, Ent* dst_e, uint32_t* dst_tab, uint32_t& dst_gen, uint32_t F, uint64_t* row, bool first) -> bool {
-    build_begin<HS>(dst, dst_e, dst_tab, dst_gen, lane);
-    need_window(F);
-    load_row(row, F);
+  {
+    build_begin<HS>(cur, cur_e, tab_q, gen_q, lane);
+    load_row(row_a, F0);
     uint32_t nlive = 0, C = 0;
-    if (!load_cands(F, 0u, nlive, C)) return false;
-    crashed_twins(nlive, C);
-    bool act; uint32_t st; uint64_t m = 0;
-    if (first) {
-      act = lane == 0; st = (uint32_t)A.init_state;
+    bool okc = load_cands(F0, 0u, nlive, C);
+    if (okc) crashed_twins(nlive, C);
+    bool act = false; uint32_t st = (uint32_t)A.init_state; uint64_t m = 0;
+    if (!okc) status = kSegOverflow;
+    else if (k == 0) {
+      act = lane == 0 && sl == 0;
+      if (eager) m |= row_a[0] | row_a[rdm_index((int32_t)st, V)];
     } else {
-      const uint32_t sub = lane & ((1u << nlive) - 1u), qd = lane >> nlive;
-      act = nlive <= 5u && lane < (A.n_dom << nlive) && lane < 32u;
+      const uint32_t id = 32u * sl + lane;
+      act = lane < 32u && nlive <= 6u && id < (A.n_dom << nlive);
+      const uint32_t qd = id >> nlive;
       st = qd == 0 ? (uint32_t)TBC_NIL : qd - 1u;
-      for (uint32_t c = 0; c < nlive && c < 5u; c++) if ((sub >> c) & 1u) m |= 1ull << ((cand[c].f_slot >> 8) & 63u);
+      for (uint32_t c = 0; c < nlive && c < 6u; c++) if ((id >> c) & 1u) m |= 1ull << ((cand[c].f_slot >> 8) & 63u);
+      if (eager) act = act && ((row_a[0] | row_a[rdm_index((int32_t)st, V)]) & ~m) == 0ull;     // in normal form already?
     }
-    if (eager) m |= row[0] | row[rdm_index((int32_t)st, V)];
     Build unused = none;
-    if (!build_insert2<CAP>(dst, unused, act ? 1u : 0u, (uint32_t)m, (uint32_t)(m >> 32), st, 0u, stage, lane)) return false;
-    if (lane < dst.n && lane < 32u) dst.e[lane].org = 1u << lane;
-    lds_sync();
-    return dst.n <= 32u;
-  };
-  if (!make_origins(cur, cur_e, tab_q, gen_q, F0, row_a, k == 0)) status = kSegOverflow;
+    if (!build_insert2<CAP>(cur, unused, act ? 1u : 0u, (uint32_t)m, (uint32_t)(m >> 32), st, 1u << (lane & 31u), stage, lane)) status = kSegOverflow;
+  }
   n_org = cur.n;
+  if (n_org == 0 && status == kSegOk) { if (lane == 0 && !dump) out->status = kSegNone; return; }   // none of these ids is a config
   if (F0 + 1u < R) load_row(row_b, F0 + 1u); else if (lane < 32) row_b[lane] = 0ull;
   lds_sync();
 
   // ---- levels
   for (uint32_t F = F0; F < F1 && status == kSegOk; F++) {
     if (dump && F == A.stop_level) {
-      uint32_t nd = 0;
+      uint32_t nd = rfl(*A.dump_count);           // the slices of one segment append one after the other (stream order)
       for (uint32_t base = 0; base < cur.n; base += 64) {
         const uint32_t i = base + lane;
         const Ent e = i < cur.n ? cur.e[i] : Ent{0, 0, 0, 0};
@@ -440,35 +430,40 @@ __global__ __launch_bounds__(64) void jit_sweep_kernel(SweepArgs A) {
     }
   }
 
-  // ---- the relation this segment hands on
+  // ---- the relation this wavefront hands on: origin -> ids of the next segment's origin space
   if (status == kSegOk && cur.n != 0 && !dump) {
-    if (F1 == R) {
-      // last segment: M[o] = the final states origin o reaches, as bits (register family: nil = bit 0, value v =
-      // bit v + 1; other models: bit 0, the state itself goes out as end_state)
-      for (uint32_t base = 0; base < cur.n; base += 64) {
-        const uint32_t i = base + lane;
-        uint32_t org = i < cur.n ? cur.e[i].org : 0u;
-        const uint32_t sb = (i < cur.n && V > 1u) ? 1u << rdm_index((int32_t)cur.e[i].st, 32u) : 1u;
-        while (org) { const uint32_t o = (uint32_t)__builtin_ctz(org); atomicOr(&Mrel[o], sb); org &= org - 1u; }
+    uint32_t no1 = 0;
+    if (F1 != R) {
+      uint32_t nl = 0, cc = 0;
+      need_window(F1);
+      if (!load_cands(F1, 0u, nl, cc) || nl > 6u) status = kSegOverflow;
+      no1 = nl;
+    }
+    for (uint32_t base = 0; base < cur.n && status == kSegOk; base += 64) {
+      const uint32_t i = base + lane;
+      const bool val = i < cur.n;
+      const Ent e = val ? cur.e[i] : Ent{0, 0, 0, 0};
+      uint32_t org = val ? e.org : 0u;
+      // last segment: word 0 = the final states reached, as bits (register family: nil = bit 0, value v = bit v + 1;
+      // other models: bit 0, the state itself goes out as end_state)
+      uint32_t id2 = V > 1u ? rdm_index((int32_t)e.st, 32u) : 0u;
+      if (F1 != R) {
+        const uint32_t sidx = e.st == (uint32_t)TBC_NIL ? 0u : e.st + 1u;
+        if (__ballot(val && sidx >= A.n_dom)) { status = kSegOverflow; break; }     // a state outside the domain: cannot be numbered
+        const uint64_t m = mask_of(e);
+        id2 = sidx << no1;
+        for (uint32_t c = 0; c < no1; c++) if ((m >> ((cand[c].f_slot >> 8) & 63u)) & 1ull) id2 |= 1u << c;
       }
-    } else {
-      // number the end configs as origins of the next segment (same enumeration, same order of insertion)
-      Build nx;
-      if (!make_origins(nx, q_e, tab_q, gen_q, F1, row_a, false)) status = kSegOverflow;
-      for (uint32_t base = 0; base < cur.n && status == kSegOk; base += 64) {
-        const uint32_t i = base + lane;
-        const bool val = i < cur.n;
-        const Ent e = val ? cur.e[i] : Ent{0, 0, 0, 0};
-        const uint32_t idx = val ? build_find<HS>(nx, e.mlo, e.mhi, e.st) : 0u;
-        if (__ballot(val && idx == kNoEnt)) { status = kSegOverflow; break; }    // a reachable config must be an origin
-        uint32_t org = val ? e.org : 0u;
-        while (org) { const uint32_t o = (uint32_t)__builtin_ctz(org); atomicOr(&Mrel[o], 1u << idx); org &= org - 1u; }
-      }
+      while (org) { const uint32_t o = (uint32_t)__builtin_ctz(org); atomicOr(&Mrel[o * kSweepSlices + (id2 >> 5)], 1u << (id2 & 31u)); org &= org - 1u; }
     }
   }
   lds_sync();
   if (dump) return;
-  if (lane < 32) { out->M[lane] = Mrel[lane]; out->last_level[lane] = last_level; }
+  if (lane < 32) {
+#pragma unroll
+    for (uint32_t wd = 0; wd < kSweepSlices; wd++) out->M[lane][wd] = Mrel[lane * kSweepSlices + wd];
+    out->last_level[lane] = last_level;
+  }
   if (lane == 0) {
     out->status = status; out->F0 = F0; out->F1 = F1; out->n_org = n_org;
     out->max_level = max_level; out->subrounds = subrounds; out->configs_total = configs_total; out->probes = probes;
@@ -492,7 +487,7 @@ bool launch_sweep(const SweepArgs& a, void* stream) {
     return true;
   }
   hipLaunchKernelGGL(sweep_cuts_kernel, dim3(a.n_hist), dim3(256), 0, s, a);
-  hipLaunchKernelGGL(jit_sweep_kernel<kSmall>, dim3(a.n_hist * a.max_segs), dim3(64), sweep_lds_words<kSmall>() * 4, s, a);
+  hipLaunchKernelGGL(jit_sweep_kernel<kSmall>, dim3(a.n_hist * a.max_segs * kSweepSlices), dim3(64), sweep_lds_words<kSmall>() * 4, s, a);
   return true;
 }
 

@@ -358,7 +358,7 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
       // the last window takes whatever the cap leaves over: raise T if the cap bites
       while ((uint64_t)B->max_segs * B->seg_target < max_n) B->seg_target++;
       B->cut_open = 0;
-      while (B->cut_open < 3 && (B->n_dom << (B->cut_open + 1)) <= 32) B->cut_open++;
+      while (B->cut_open < 4 && (B->n_dom << (B->cut_open + 1)) <= 32 * kSweepSlices) B->cut_open++;
     }
   }
 
@@ -422,8 +422,8 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
         (s = B->d_slot8.alloc(slot8_bytes(T, nh))) || (s = B->d_stack.alloc(bstack_n)) || (s = B->d_btab.alloc(btab_n * EW)) ||
         (s = B->d_pool_cursor.alloc(1)))
       return s;
-    if (B->sweep && ((s = B->d_cuts.alloc((uint64_t)nh * B->max_segs)) || (s = B->d_sres.alloc((uint64_t)nh * B->max_segs)) || (s = B->d_seglist.alloc((uint64_t)nh * B->max_segs * 2)))) return s;
-    if (B->sweep) B->seg_host.resize((size_t)nh * B->max_segs);
+    if (B->sweep && ((s = B->d_cuts.alloc((uint64_t)nh * B->max_segs)) || (s = B->d_sres.alloc((uint64_t)nh * B->max_segs * kSweepSlices)) || (s = B->d_seglist.alloc((uint64_t)nh * B->max_segs * kSweepSlices * 3)))) return s;
+    if (B->sweep) B->seg_host.resize((size_t)nh * B->max_segs * kSweepSlices);
     if (B->rules && ((s = B->d_twn.alloc(blst_n * B->mask_words)) || (s = B->d_rdm.alloc(T * B->vpad * B->mask_words)))) return s;
     if (B->lookahead && ((s = B->d_look.alloc(look_words(T, nh, B->mask_words))) || (s = B->d_looktmp.alloc(T)) ||
                          (s = B->d_dstack.alloc(bstack_n)))) return s;
@@ -722,6 +722,11 @@ static tbc_status expand_eager_witness(tbc_batch* B, uint32_t h, uint32_t* wit, 
   return TBC_OK;
 }
 
+static bool k_has_segment(const SegResult* sg, uint32_t k, uint32_t SL) {
+  for (uint32_t j = 0; j < SL; j++) if (sg[(size_t)k * SL + j].status != kSegNone) return true;
+  return false;
+}
+
 static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results) {
   HIP_TRY(hipSetDevice(B->device));
   const uint64_t t_start = now_ns();
@@ -810,16 +815,17 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results) {
   HIP_TRY(hipEventRecord(B->ev[4], s));
   bool touched_work = false;
   if (B->sweep) {
-    // segments whose config sets outgrew the small LDS sets: once more with the big ones (one wavefront per CU)
+    // wavefronts whose config sets outgrew the small LDS sets: once more with the big ones (one wavefront per CU)
+    const uint32_t SL = kSweepSlices;
     {
       std::vector<uint32_t> again;
       for (uint32_t h = 0; h < nh; h++) if (hist_back[h].status == 0 && bh_back[h].status == 0)
-        for (uint32_t k = 0; k < B->max_segs; k++)
-          if (B->seg_host[(size_t)h * B->max_segs + k].status == kSegOverflow) { again.push_back(h); again.push_back(k); }
+        for (uint32_t k = 0; k < B->max_segs; k++) for (uint32_t j = 0; j < SL; j++)
+          if (B->seg_host[((size_t)h * B->max_segs + k) * SL + j].status == kSegOverflow) { again.push_back(h); again.push_back(k); again.push_back(j); }
       if (!again.empty()) {
         HIP_TRY(hipMemcpyAsync(B->d_seglist.p, again.data(), again.size() * 4, hipMemcpyHostToDevice, s));
         SweepArgs sa2 = swa;
-        sa2.seg_list = B->d_seglist.p; sa2.n_list = (uint32_t)(again.size() / 2);
+        sa2.seg_list = B->d_seglist.p; sa2.n_list = (uint32_t)(again.size() / 3);
         if (launch_sweep(sa2, s)) {
           HIP_TRY(hipGetLastError());
           HIP_TRY(hipMemcpyAsync(B->seg_host.data(), B->d_sres.p, B->seg_host.size() * sizeof(SegResult), hipMemcpyDeviceToHost, s));
@@ -827,7 +833,8 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results) {
         HIP_TRY(hipStreamSynchronize(s));
       }
     }
-    // compose the segments' relations in order; what the sweep could not finish goes to the wide kernel
+    // compose the relations in order: the live set is a set of origin ids (<= 128) of the current segment; what the
+    // sweep could not finish goes to the wide kernel
     std::vector<uint32_t> fb, lg;
     for (uint32_t h = 0; h < nh; h++) {
       DevResult& d = B->res_host[h];
@@ -835,58 +842,62 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results) {
       d.fail_op = TBC_NO_OP; d.prev_ok_op = TBC_NO_OP; d.final_state = B->model.init;
       if (hist_back[h].status != 0) { d.valid = TBC_UNKNOWN; continue; }
       if (hist_back[h].n_ret == 0) { d.valid = TBC_VALID; by_sweep[h] = 1; continue; }
-      const SegResult* sg = &B->seg_host[(size_t)h * B->max_segs];
+      const SegResult* sg = &B->seg_host[(size_t)h * B->max_segs * SL];
       bool give_up = bh_back[h].status != 0;
-      uint32_t live = 1u, fail_seg = kInf, fail_level = 0;
+      uint32_t live[kSweepSlices] = {1u, 0u, 0u, 0u}, live_in[kSweepSlices] = {1u, 0u, 0u, 0u};
+      uint32_t fail_seg = kInf, fail_level = 0, last_end_state = 0;
       bool ended = false;
+      uint32_t dbg_ns = 0, dbg_longest = 0, dbg_big = 0, dbg_ml = 0; uint64_t dbg_maxp = 0;
       for (uint32_t k = 0; k < B->max_segs && !give_up && fail_seg == kInf; k++) {
-        const SegResult& g = sg[k];
-        if (g.status == kSegNone) continue;
-        if (g.status != kSegOk) { give_up = true; break; }
-        d.steps += g.probes; d.probes += g.probes; d.visited += g.configs_total; d.backtracks += g.subrounds;
-        d.max_depth = std::max<uint64_t>(d.max_depth, g.max_level);
-        uint32_t next = 0, reached = g.F0;
-        for (uint32_t o = 0; o < 32; o++) if ((live >> o) & 1u) { next |= g.M[o]; reached = std::max(reached, g.last_level[o]); }
-        if (next == 0) { fail_seg = k; fail_level = reached; }
-        live = next;
-        ended = g.F1 == hist_back[h].n_ret;
-      }
-      if (std::getenv("TBC_DEBUG")) {
-        uint32_t ns = 0, longest = 0, lp = 0, novf = 0, ovf_len = 0, ml = 0; uint64_t pr = 0;
-        for (uint32_t k = 0; k < B->max_segs; k++) if (sg[k].status != kSegNone) {
-          ns++; pr += sg[k].probes; ml = std::max(ml, sg[k].max_level);
-          if (sg[k].F1 - sg[k].F0 > longest) { longest = sg[k].F1 - sg[k].F0; lp = (uint32_t)sg[k].probes; }
-          if (sg[k].status == kSegOverflow) { novf++; ovf_len = sg[k].F1 - sg[k].F0; }
+        uint32_t next[kSweepSlices] = {0u, 0u, 0u, 0u}, reached = 0, F1 = 0;
+        bool any = false;
+        for (uint32_t j = 0; j < SL && !give_up; j++) {
+          const SegResult& g = sg[(size_t)k * SL + j];
+          if (g.status == kSegNone) { if (live[j] && k_has_segment(sg, k, SL)) give_up = true; continue; }
+          if (g.status != kSegOk) { give_up = true; break; }
+          any = true; F1 = g.F1; reached = std::max(reached, g.F0); last_end_state = g.end_state;
+          d.steps += g.probes; d.probes += g.probes; d.visited += g.configs_total; d.backtracks += g.subrounds;
+          d.max_depth = std::max<uint64_t>(d.max_depth, g.max_level);
+          dbg_ns++; dbg_longest = std::max(dbg_longest, g.F1 - g.F0); dbg_ml = std::max(dbg_ml, g.max_level); dbg_maxp = std::max<uint64_t>(dbg_maxp, g.probes);
+          for (uint32_t o = 0; o < 32; o++) if ((live[j] >> o) & 1u) {
+            for (uint32_t w = 0; w < SL; w++) next[w] |= g.M[o][w];
+            reached = std::max(reached, g.last_level[o]);
+          }
         }
-        std::fprintf(stderr, "[tbc sweep] history %u: %u segments, longest %u levels (%u probes), %llu probes in all, largest level %u, %u overflowed (last one %u levels long), bh status %u\n",
-                     h, ns, longest, lp, (unsigned long long)pr, ml, novf, ovf_len, bh_back[h].status);
+        if (!any || give_up) continue;
+        if (!(next[0] | next[1] | next[2] | next[3])) { fail_seg = k; fail_level = reached; for (uint32_t w = 0; w < SL; w++) live_in[w] = live[w]; break; }
+        for (uint32_t w = 0; w < SL; w++) live[w] = next[w];
+        ended = F1 == hist_back[h].n_ret;
       }
+      (void)dbg_big;
+      if (std::getenv("TBC_DEBUG"))
+        std::fprintf(stderr, "[tbc sweep] history %u: %u wavefronts, longest segment %u levels, most probes in one %llu, largest level %u, gave up %d\n",
+                     h, dbg_ns, dbg_longest, (unsigned long long)dbg_maxp, dbg_ml, (int)give_up);
       if (give_up || (fail_seg == kInf && !ended)) { fb.push_back(h); lg.push_back(B->bh[h].tab_log2); continue; }
       by_sweep[h] = 1;
       if (fail_seg == kInf) {
         d.valid = TBC_VALID;
         const bool regfam = B->model.kind == TBC_MODEL_REGISTER || B->model.kind == TBC_MODEL_CAS_REGISTER;
-        if (regfam && B->vpad > 1) { const uint32_t sb = (uint32_t)__builtin_ctz(live); d.final_state = sb == 0 ? TBC_NIL : (int32_t)sb - 1; }
-        else for (uint32_t k = B->max_segs; k-- > 0;) if (sg[k].status == kSegOk) { d.final_state = (int32_t)sg[k].end_state; break; }
+        if (regfam && B->vpad > 1) { const uint32_t sb = (uint32_t)__builtin_ctz(live[0]); d.final_state = sb == 0 ? TBC_NIL : (int32_t)sb - 1; }
+        else d.final_state = (int32_t)last_end_state;
         continue;
       }
       d.valid = TBC_INVALID; d.max_front = fail_level;
       const uint32_t first = fail_level ? fail_level - 1 : 0;
       uint32_t two[2] = {TBC_NO_OP, TBC_NO_OP};
       HIP_TRY(hipMemcpyAsync(two, B->d_ret_op.p + hist_back[h].ret_off + first, (fail_level ? 2 : 1) * 4, hipMemcpyDeviceToHost, s));
-      // :configs = the level in front of the failing completion, restricted to what the live origins reach
-      uint32_t live_in = 1u;
-      for (uint32_t k = 0; k < fail_seg; k++) if (sg[k].status == kSegOk) {
-        uint32_t nx = 0; for (uint32_t o = 0; o < 32; o++) if ((live_in >> o) & 1u) nx |= sg[k].M[o];
-        live_in = nx;
+      // :configs = the level in front of the failing completion, restricted to what the live origins reach: every
+      // slice of the failing segment that holds a live origin appends its part
+      HIP_TRY(hipMemsetAsync(&B->d_results.p[h].n_configs, 0, 4, s));
+      for (uint32_t j = 0; j < SL; j++) if (live_in[j] && sg[(size_t)fail_seg * SL + j].status == kSegOk) {
+        SweepArgs da = swa;
+        da.dump_hist = h; da.dump_seg = fail_seg; da.dump_slice = j; da.stop_level = fail_level; da.live_mask = live_in[j];
+        da.dump_cfg = B->d_cfg.p + (uint64_t)h * kCfgCap * (2 + B->mask_words);
+        da.dump_count = &B->d_results.p[h].n_configs;
+        da.seg_list = nullptr;
+        (void)launch_sweep(da, s);
+        HIP_TRY(hipGetLastError());
       }
-      SweepArgs da = swa;
-      da.dump_hist = h; da.dump_seg = fail_seg; da.stop_level = fail_level; da.live_mask = live_in;
-      da.dump_cfg = B->d_cfg.p + (uint64_t)h * kCfgCap * (2 + B->mask_words);
-      da.dump_count = &B->d_results.p[h].n_configs;
-      da.seg_list = nullptr;
-      (void)launch_sweep(da, s);
-      HIP_TRY(hipGetLastError());
       HIP_TRY(hipMemcpyAsync(&d.n_configs, &B->d_results.p[h].n_configs, 4, hipMemcpyDeviceToHost, s));
       HIP_TRY(hipStreamSynchronize(s));
       d.fail_op = fail_level ? two[1] : two[0];

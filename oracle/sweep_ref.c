@@ -36,7 +36,7 @@
  * Segments.  The fronts are cut at C_0 = 0 < C_1 < ... < C_S = R.  Segment i sweeps levels
  * C_i .. C_(i+1) starting from EVERY config that is possible at front C_i at all -- each
  * (subset of the calls open at C_i, model state) in normal form, numbered 0..n_origins-1 -- and
- * carries with every config the set of origins it is reachable from (a 32-bit mask; duplicates OR
+ * carries with every config the set of origins it is reachable from (a bit set; duplicates OR
  * their masks -- sub-rounds go by number of calls linearized, so a config's mask is final before it
  * is expanded).  What a segment hands on is its relation {origin -> configs at front C_(i+1)}.
  * Composition walks the segments in order: live set := {initial config}; for each segment the
@@ -45,12 +45,12 @@
  * the failing completion is the greatest level of segment i that some live origin still reached
  * (+ C_i): per origin the sweep records the last level at which a config carrying it existed.
  * Cuts (parallel by construction -- the kernel places each one with its own thread): with T = the
- * wanted segment length, cut k = 1, 2, ... is the FIRST front F in [k*T, (k+1)*T) at which at most m
- * calls are open and none of them is crashed (a crashed call stays open for ever, so there are no
+ * wanted segment length, cut k = 1, 2, ... is the front F in [k*T, (k+1)*T) with the FEWEST calls open (the
+ * first of them) among those where no crashed call is open, provided at most m calls are open there (a crashed call stays open for ever, so there are no
  * cuts after the first crash); a window without such a front has no cut.  The state domain of the
  * origins is {nil, 0 .. vmax} (vmax = the greatest register value in the history or the model),
- * nd = vmax + 2 states; m = the greatest value <= max_cut_open with nd * 2^m <= 32 (origin sets are
- * 32-bit masks); nd > 32 => one segment.  Only the register family is cut.
+ * nd = vmax + 2 states; m = the greatest value <= max_cut_open with nd * 2^m <= 128 (the kernel gives every
+ * 32 origins of a segment a wavefront of their own); nd > 128 => one segment.  Only the register family is cut.
  *
  * Outputs that are properties of (model, history): verdict, failing op, previous-ok op.  Outputs
  * that are properties of the sweep and compared bit for bit with the kernel: the size of every
@@ -82,13 +82,17 @@ typedef struct sweep_stats {
   uint64_t n_segments;
   uint64_t max_origins;
   uint64_t max_pending;     /* largest P_j */
+  uint64_t longest_segment; /* levels */
+  uint64_t n_waves;         /* wavefronts the kernel uses: one per 32 origins of each segment */
+  uint64_t max_segment_probes;
 } sweep_stats;
 
 /* ordered exact set of configs: entries (KW words key: [state+1 | 0][mask...]) + origin mask, insertion order kept */
-typedef struct { uint64_t* key; uint64_t* org; uint32_t* slots; size_t n, cap, nslots, kw; } cset;
+typedef unsigned __int128 orgset;     /* up to 128 origins per segment (the kernel splits them over wavefronts, 32 each) */
+typedef struct { uint64_t* key; orgset* org; uint32_t* slots; size_t n, cap, nslots, kw; } cset;
 static void cs_init(cset* s, size_t kw) {
   s->kw = kw; s->cap = 64; s->n = 0; s->nslots = 256;
-  s->key = (uint64_t*)malloc(s->cap * kw * 8); s->org = (uint64_t*)malloc(s->cap * 8);
+  s->key = (uint64_t*)malloc(s->cap * kw * 8); s->org = (orgset*)malloc(s->cap * sizeof(orgset));
   s->slots = (uint32_t*)calloc(s->nslots, 4);
 }
 static void cs_free(cset* s) { free(s->key); free(s->org); free(s->slots); }
@@ -99,7 +103,7 @@ static uint64_t cs_hash(const uint64_t* k, size_t kw) {
   return h;
 }
 /* returns 1 if new */
-static int cs_add(cset* s, const uint64_t* k, uint64_t org) {
+static int cs_add(cset* s, const uint64_t* k, orgset org) {
   size_t j = cs_hash(k, s->kw) & (s->nslots - 1);
   while (s->slots[j]) {
     const size_t e = s->slots[j] - 1;
@@ -108,7 +112,7 @@ static int cs_add(cset* s, const uint64_t* k, uint64_t org) {
   }
   if (s->n == s->cap) {
     s->cap *= 2;
-    s->key = (uint64_t*)realloc(s->key, s->cap * s->kw * 8); s->org = (uint64_t*)realloc(s->org, s->cap * 8);
+    s->key = (uint64_t*)realloc(s->key, s->cap * s->kw * 8); s->org = (orgset*)realloc(s->org, s->cap * sizeof(orgset));
   }
   memcpy(s->key + s->n * s->kw, k, s->kw * 8); s->org[s->n] = org;
   s->slots[j] = (uint32_t)++s->n;
@@ -156,7 +160,7 @@ static void normalise(const hist_t* H, uint64_t* key, uint32_t F) {
 }
 
 /* a config that has X (slot px) linearized passes completion F: into level F+1 (front F+1 < R) or the end set */
-static void pass_level(const hist_t* H, cset* nxt, const uint64_t* key, uint64_t org, uint32_t px, uint32_t F, uint64_t* tmp) {
+static void pass_level(const hist_t* H, cset* nxt, const uint64_t* key, orgset org, uint32_t px, uint32_t F, uint64_t* tmp) {
   memcpy(tmp, key, H->KW * 8);
   clrb(tmp + 1, px);
   if (F + 1 < H->R) normalise(H, tmp, F + 1);
@@ -230,17 +234,19 @@ int sweep_ref_check(uint32_t n, const uint8_t* f, const int32_t* a, const int32_
   }
   const uint32_t nd = g_n_dom ? g_n_dom : (uint32_t)(vmax + 2);
   uint32_t m_open = 0;
-  int cut_ok = regfam && g_seg_target && nd <= 32;
-  if (cut_ok) while (m_open < g_max_cut_open && (nd << (m_open + 1)) <= 32) m_open++;
-  /* ---- cuts */
+  int cut_ok = regfam && g_seg_target && nd <= 128;
+  if (cut_ok) while (m_open < g_max_cut_open && (nd << (m_open + 1)) <= 128) m_open++;
+  /* ---- cuts: in every window the front with the FEWEST open calls (the first of them), if that is <= m_open */
   uint32_t* cuts = (uint32_t*)malloc(4 * ((size_t)R + 2));
   uint32_t S = 0;
   cuts[S++] = 0;
   if (cut_ok) {
     for (uint32_t k = 1; (uint64_t)k * g_seg_target < R; k++) {
       const uint32_t lo = k * g_seg_target, hi = lo + g_seg_target < R ? lo + g_seg_target : R;
+      uint32_t best = 0xFFFFFFFFu, bestF = 0;
       for (uint32_t F = lo; F < hi; F++)
-        if (H.off[F + 1] - H.off[F] <= m_open && H.ncr[F] == 0) { cuts[S++] = F; break; }
+        if (H.ncr[F] == 0 && H.off[F + 1] - H.off[F] < best) { best = H.off[F + 1] - H.off[F]; bestF = F; }
+      if (best <= m_open) cuts[S++] = bestF;
     }
   }
   cuts[S] = R;
@@ -252,119 +258,140 @@ int sweep_ref_check(uint32_t n, const uint8_t* f, const int32_t* a, const int32_
   cset cur, nxt, pa, pb;
   cs_init(&cur, KW); cs_init(&nxt, KW); cs_init(&pa, KW); cs_init(&pb, KW);
   uint64_t* key = (uint64_t*)calloc(KW, 8); uint64_t* tmp = (uint64_t*)calloc(KW, 8);
-  /* live set carried by the composition: configs at the current cut */
-  cset live; cs_init(&live, KW);
-  key[0] = (uint64_t)(uint32_t)model->init << 32;
-  normalise(&H, key, 0);
-  cs_add(&live, key, 1);
   int verdict = 1;
   uint32_t fail_level = 0;
+  int32_t final_state = model->init;
+  /* the composition's live set: ids of the current segment's origin space (<= 128), segment 0: id 0 = the initial config */
+  orgset live = 1;
 
   for (uint32_t sg = 0; sg < S && verdict == 1; sg++) {
     const uint32_t F0 = cuts[sg], F1 = cuts[sg + 1];
-    /* origins of this segment: every (subset of calls open at F0, state) in normal form, de-duplicated */
-    cs_clear(&cur);
-    uint32_t norg = 0;
-    if (S == 1 || sg == 0) { cs_add(&cur, live.key, 1); norg = 1; }      /* segment 0: the initial config is the only origin */
-    else {
-      const uint32_t no = H.off[F0 + 1] - H.off[F0];   /* no crashed calls open at a cut */
-      for (uint32_t q = 0; q < nd && norg <= 32; q++)
-        for (uint32_t sub = 0; sub < (1u << no) && norg <= 32; sub++) {
-          memset(key, 0, KW * 8);
-          key[0] = (uint64_t)(uint32_t)dom[q] << 32;
-          for (uint32_t c = 0; c < no; c++) if (sub >> c & 1) setb(key + 1, (uint32_t)process[H.lst[H.off[F0] + c]]);
-          normalise(&H, key, F0);
-          if (cs_add(&cur, key, 0)) { if (norg < 32) cur.org[cur.n - 1] = 1ull << norg; norg++; }
+    /* origin space of this segment: id = state index * 2^no + (bit c = the c-th call open at F0 is linearized); the
+     * kernel gives every 32 consecutive ids a wavefront of their own ("slice"), and so does this restatement -- the
+     * statistics count a config once per slice it is reachable in.  Ids that are not in normal form are nobody's config. */
+    const uint32_t no0 = sg ? H.off[F0 + 1] - H.off[F0] : 0;
+    const uint32_t n_ids = sg ? nd << no0 : 1, n_slices = (n_ids + 31) / 32;
+    const uint32_t no1 = F1 < R ? H.off[F1 + 1] - H.off[F1] : 0;
+    if (n_ids > st->max_origins) st->max_origins = n_ids;
+    if (F1 - F0 > st->longest_segment) st->longest_segment = F1 - F0;
+    orgset next_live = 0;
+    uint32_t reached = F0;
+    for (uint32_t sl = 0; sl < n_slices && verdict == 1; sl++) {
+      cs_clear(&cur);
+      for (uint32_t l = 0; l < 32; l++) {
+        const uint32_t id = 32 * sl + l;
+        if (id >= n_ids) break;
+        memset(key, 0, KW * 8);
+        if (sg == 0) key[0] = (uint64_t)(uint32_t)model->init << 32;
+        else {
+          key[0] = (uint64_t)(uint32_t)dom[id >> no0] << 32;
+          for (uint32_t c = 0; c < no0; c++) if (id >> c & 1) setb(key + 1, (uint32_t)process[H.lst[H.off[F0] + c]]);
         }
-      if (norg > 32) { verdict = -2; break; }            /* cannot happen: nd * 2^m_open <= 32 */
-    }
-    if (norg > st->max_origins) st->max_origins = norg;
-    /* which origins are live: translate the composition's live set */
-    uint64_t live_mask = 0;
-    if (S == 1 || sg == 0) live_mask = 1;
-    else for (size_t e = 0; e < live.n; e++) {
-      int found = 0;
-      for (size_t q = 0; q < cur.n; q++) if (memcmp(cur.key + q * KW, live.key + e * KW, KW * 8) == 0) { live_mask |= cur.org[q]; found = 1; break; }
-      if (!found) { verdict = -3; }                       /* a reachable config must be among the origins */
-    }
-    if (verdict != 1) break;
-    uint32_t last_level[64]; for (uint32_t q = 0; q < 64; q++) last_level[q] = F0;
+        memcpy(tmp, key, KW * 8);
+        normalise(&H, tmp, F0);
+        if (sg == 0) memcpy(key, tmp, KW * 8);                       /* the initial config is taken in normal form */
+        else if (memcmp(tmp, key, KW * 8) != 0) continue;             /* not in normal form: no config has this id */
+        cs_add(&cur, key, (orgset)1 << l);
+      }
+      if (cur.n == 0) continue;                                       /* the kernel's wavefront has nothing to sweep */
+      st->n_waves++;
+      const uint64_t probes_before = st->probes;
+      uint32_t last_level[32]; for (uint32_t q = 0; q < 32; q++) last_level[q] = F0;
+      uint32_t M[32][4]; memset(M, 0, sizeof M);
 
-    for (uint32_t F = F0; F < F1 && verdict == 1; F++) {
-      const uint32_t x = H.ret_op[F], px = (uint32_t)process[x];
-      cs_clear(&nxt); cs_clear(&pa);
+      for (uint32_t F = F0; F < F1 && verdict == 1; F++) {
+        const uint32_t x = H.ret_op[F], px = (uint32_t)process[x];
+        cs_clear(&nxt); cs_clear(&pa);
+        for (size_t e = 0; e < cur.n; e++) {
+          const uint64_t* c = cur.key + e * KW;
+          if (bit(c + 1, px)) pass_level(&H, &nxt, c, cur.org[e], px, F, tmp);
+          else cs_add(&pa, c, cur.org[e]);
+        }
+        cset* P = &pa; cset* Q = &pb;
+        const uint32_t nlive = H.off[F + 1] - H.off[F], tot = nlive + H.ncr[F];
+        while (P->n) {
+          st->subrounds++;
+          if (P->n > st->max_pending) st->max_pending = P->n;
+          cs_clear(Q);
+          for (size_t e = 0; e < P->n; e++) {
+            const uint64_t* c = P->key + e * KW; const orgset org = P->org[e];
+            const int32_t s0 = (int32_t)(uint32_t)(c[0] >> 32);
+            for (uint32_t cc = 0; cc < tot; cc++) {
+              const uint32_t y = cc < nlive ? H.lst[H.off[F] + cc] : H.crashed[cc - nlive], py = (uint32_t)process[y];
+              if (bit(c + 1, py)) continue;
+              if (eager_on && f[y] == O_READ) continue;                 /* could it be linearized it would be already */
+              if (g_twin && regfam && (f[y] == O_WRITE || f[y] == O_CAS)) {
+                int dominated = 0;
+                for (uint32_t dd = 0; dd < tot && !dominated; dd++) {
+                  const uint32_t z = dd < nlive ? H.lst[H.off[F] + dd] : H.crashed[dd - nlive];
+                  if (z == y || f[z] != f[y] || a[z] != a[y] || (f[y] == O_CAS && b[z] != b[y])) continue;
+                  if (bit(c + 1, (uint32_t)process[z])) continue;
+                  if (H.ret_rank[z] < H.ret_rank[y] || (H.ret_rank[z] == H.ret_rank[y] && z < y)) dominated = 1;
+                }
+                if (dominated) continue;
+              }
+              int32_t s2;
+              if (!oracle_step(model, s0, f[y], a[y], b[y], &s2)) continue;
+              st->probes++;
+              memcpy(key, c, KW * 8);
+              setb(key + 1, py);
+              key[0] = (uint64_t)(uint32_t)s2 << 32;
+              normalise(&H, key, F);
+              if (bit(key + 1, px)) pass_level(&H, &nxt, key, org, px, F, tmp);
+              else cs_add(Q, key, org);
+            }
+          }
+          { cset* t = P; P = Q; Q = t; }
+        }
+        st->levels++;
+        st->configs_total += nxt.n;
+        if (nxt.n > st->max_level) st->max_level = nxt.n;
+        if (level_sizes && S == 1) level_sizes[F] = (uint32_t)nxt.n;
+        if (max_level_limit && nxt.n > max_level_limit) { verdict = -1; break; }
+        { orgset any = 0; for (size_t e = 0; e < nxt.n; e++) any |= nxt.org[e];
+          for (uint32_t q = 0; q < 32; q++) if (any >> q & 1) last_level[q] = F + 1; }
+        { cset t = cur; cur = nxt; nxt = t; }
+        if (cur.n == 0) break;                             /* nobody of this slice passes completion F */
+      }
+      if (verdict != 1) break;
+      if (st->probes - probes_before > st->max_segment_probes) st->max_segment_probes = st->probes - probes_before;
+      /* the relation this slice hands on: origin -> ids of the next segment's origin space (last segment: final states) */
       for (size_t e = 0; e < cur.n; e++) {
         const uint64_t* c = cur.key + e * KW;
-        if (bit(c + 1, px)) pass_level(&H, &nxt, c, cur.org[e], px, F, tmp);
-        else cs_add(&pa, c, cur.org[e]);
-      }
-      cset* P = &pa; cset* Q = &pb;
-      const uint32_t nlive = H.off[F + 1] - H.off[F], tot = nlive + H.ncr[F];
-      while (P->n) {
-        st->subrounds++;
-        if (P->n > st->max_pending) st->max_pending = P->n;
-        cs_clear(Q);
-        for (size_t e = 0; e < P->n; e++) {
-          const uint64_t* c = P->key + e * KW; const uint64_t org = P->org[e];
-          const int32_t s = (int32_t)(uint32_t)(c[0] >> 32);
-          for (uint32_t cc = 0; cc < tot; cc++) {
-            const uint32_t y = cc < nlive ? H.lst[H.off[F] + cc] : H.crashed[cc - nlive], py = (uint32_t)process[y];
-            if (bit(c + 1, py)) continue;
-            if (eager_on && f[y] == O_READ && y != x) continue;      /* could it be linearized it would be already */
-            if (g_twin && regfam && (f[y] == O_WRITE || f[y] == O_CAS)) {
-              int dominated = 0;
-              for (uint32_t dd = 0; dd < tot && !dominated; dd++) {
-                const uint32_t z = dd < nlive ? H.lst[H.off[F] + dd] : H.crashed[dd - nlive];
-                if (z == y || f[z] != f[y] || a[z] != a[y] || (f[y] == O_CAS && b[z] != b[y])) continue;
-                if (bit(c + 1, (uint32_t)process[z])) continue;
-                if (H.ret_rank[z] < H.ret_rank[y] || (H.ret_rank[z] == H.ret_rank[y] && z < y)) dominated = 1;
-              }
-              if (dominated) continue;
-            }
-            int32_t s2;
-            if (!oracle_step(model, s, f[y], a[y], b[y], &s2)) continue;
-            st->probes++;
-            memcpy(key, c, KW * 8);
-            setb(key + 1, py);
-            key[0] = (uint64_t)(uint32_t)s2 << 32;
-            normalise(&H, key, F);
-            if (bit(key + 1, px)) pass_level(&H, &nxt, key, org, px, F, tmp);
-            else cs_add(Q, key, org);
-          }
+        const int32_t sv = (int32_t)(uint32_t)(c[0] >> 32);
+        uint32_t sidx = 0xFFFFFFFFu;
+        for (uint32_t q = 0; q < nd; q++) if (dom[q] == sv) { sidx = q; break; }
+        uint32_t id2;
+        if (F1 == R) id2 = regfam && sidx != 0xFFFFFFFFu && sidx < 32 ? sidx : 0;
+        else {
+          if (sidx == 0xFFFFFFFFu) { verdict = -3; break; }
+          id2 = sidx << no1;
+          for (uint32_t cc = 0; cc < no1; cc++) if (bit(c + 1, (uint32_t)process[H.lst[H.off[F1] + cc]])) id2 |= 1u << cc;
         }
-        { cset* t = P; P = Q; Q = t; }
+        for (uint32_t q = 0; q < 32; q++) if (cur.org[e] >> q & 1) M[q][id2 >> 5] |= 1u << (id2 & 31);
       }
-      st->levels++;
-      st->configs_total += nxt.n;
-      if (nxt.n > st->max_level) st->max_level = nxt.n;
-      if (level_sizes && S == 1) level_sizes[F] = (uint32_t)nxt.n;
-      if (max_level_limit && nxt.n > max_level_limit) { verdict = -1; break; }
-      { uint64_t any = 0; for (size_t e = 0; e < nxt.n; e++) any |= nxt.org[e];
-        for (uint32_t q = 0; q < 64; q++) if (any >> q & 1) last_level[q] = F + 1; }
-      { cset t = cur; cur = nxt; nxt = t; }
-      if (cur.n == 0 || (S == 1 && cur.n == 0)) {
-        /* nobody passes completion F from any origin: the live ones die here at the latest */
-        break;
+      /* composition over this slice's live origins */
+      for (uint32_t q = 0; q < 32; q++) if (live >> (32 * sl + q) & 1) {
+        for (uint32_t w = 0; w < 4; w++) next_live |= (orgset)M[q][w] << (32 * w);
+        if (last_level[q] > reached) reached = last_level[q];
       }
     }
     if (verdict != 1) break;
-    /* composition */
-    cs_clear(&live);
-    for (size_t e = 0; e < cur.n; e++) if (cur.org[e] & live_mask) cs_add(&live, cur.key + e * KW, 1);
-    uint32_t reached = F0;
-    for (uint32_t q = 0; q < 64; q++) if ((live_mask >> q & 1) && last_level[q] > reached) reached = last_level[q];
-    if (reached < F1 || live.n == 0) { verdict = 0; fail_level = reached; }
+    if (next_live == 0) { verdict = 0; fail_level = reached; break; }
+    if (F1 == R) { for (uint32_t q = 0; q < 32; q++) if (next_live >> q & 1) { final_state = regfam ? dom[q < nd ? q : 0] : model->init; break; } }
+    live = next_live;
   }
+  if (verdict == 1 && !regfam) final_state = cur.n ? (int32_t)(uint32_t)(cur.key[0] >> 32) : model->init;
 
   out->valid = verdict < -1 ? -1 : verdict;
-  if (verdict == 1) out->final_state = (int32_t)(uint32_t)(live.key[0] >> 32);
+  if (verdict == 1) out->final_state = final_state;
   if (verdict == 0) {
     out->fail_op = H.ret_op[fail_level];
     out->prev_ok_op = fail_level ? H.ret_op[fail_level - 1] : 0xFFFFFFFFu;
   }
   out->probes = st->probes; out->visited = st->configs_total; out->steps = st->subrounds;
   g_eager = save_eager;
-  cs_free(&cur); cs_free(&nxt); cs_free(&pa); cs_free(&pb); cs_free(&live);
+  cs_free(&cur); cs_free(&nxt); cs_free(&pa); cs_free(&pb);
   free(key); free(tmp); free(dom); free(cuts); free(rets); free(fill);
   free(H.ret_rank); free(H.inv_rank); free(H.ret_op); free(H.off); free(H.ncr); free(H.lst); free(H.crashed);
   return verdict == -2 ? 4 : verdict == -3 ? 5 : 0;
