@@ -327,6 +327,60 @@ typedef struct tbc_sweep_info {
   uint32_t n_fallback;    /* last run: histories handed to the depth-first search         */
 } tbc_sweep_info;
 tbc_status tbc_batch_sweep_info(const tbc_batch* b, tbc_sweep_info* out);
+
+/* ---------------------------------------------- one history over several GPUs
+ *
+ * BASELINE.json's north_star asks for the search frontier of ONE history to be sharded over the
+ * GPUs of a node.  With the level sweep that is a property of the algorithm: a history is a chain
+ * of segments, every (segment, 32-origin slice) is swept by its own wavefront and hands on a
+ * relation {origin -> origin ids of the next segment}; WHERE a wavefront runs does not matter.
+ * So rank r of w sweeps the wavefronts with (segment * 4 + slice) % w == r
+ * (tbc_batch_set_shard + tbc_batch_sweep_partial), the ranks exchange their relation tables --
+ * ONE all-gather of tbc_batch_sweep_table() bytes over RCCL (jepsen-tigerbeetle_amd/shard.py),
+ * entries a rank does not own are all zero, so the merged table is the bitwise OR -- and every rank
+ * composes the merged table (tbc_batch_sweep_finish).  The inputs are replicated (a history is a
+ * few hundred KB); pack runs on every rank.  A wavefront the sweep cannot finish (status 2) makes
+ * the finishing rank fall back to its own depth-first search, as in the single-GPU path.
+ */
+#define TBC_SWEEP_SLICES 4u
+typedef struct tbc_sweep_rel {   /* one per (history, segment, slice) */
+  uint32_t status;               /* 0 = no such wavefront (or not this rank's), 1 = swept, 2 = overflow */
+  uint32_t F0, F1;               /* levels swept: [F0, F1)                                         */
+  uint32_t n_org;                /* origins of this slice that are configs                         */
+  uint32_t max_level;            /* largest level                                                  */
+  uint32_t subrounds;
+  uint32_t n_end;                /* configs at front F1                                            */
+  uint32_t end_state;            /* state of the first of them (non-register models)               */
+  uint64_t configs_total;        /* sum of the level sizes                                         */
+  uint64_t probes;               /* expansions                                                     */
+  uint32_t M[32][TBC_SWEEP_SLICES]; /* M[o] = origin ids of the NEXT segment reachable from origin  */
+                                 /* 32 * slice + o (128-bit set); last segment: word 0 = final states */
+  uint32_t last_level[32];       /* greatest level at which a config reachable from origin o existed */
+} tbc_sweep_rel;
+
+typedef struct tbc_sweep_verdict {
+  int32_t valid;                 /* TBC_VALID / TBC_INVALID / TBC_UNKNOWN (a wavefront missing or overflowed) */
+  uint32_t fail_level;           /* invalid: rank of the completion nobody passes                  */
+  uint32_t fail_seg;             /* invalid: the segment it lies in                                */
+  uint32_t live_in[TBC_SWEEP_SLICES];  /* invalid: origin ids of that segment reachable from the start */
+  uint32_t final_bits;           /* valid: final states reached (register family: nil = bit 0, v = bit v + 1) */
+  uint32_t end_state;            /* valid, other models: the state                                 */
+  uint32_t n_wavefronts;         /* relations composed                                             */
+  uint64_t probes, configs_total, subrounds, max_level;
+} tbc_sweep_verdict;
+
+/* compose the relations of ONE history (max_segs * TBC_SWEEP_SLICES records, segment-major) in order.
+ * Pure host code, no device needed. */
+tbc_status tbc_sweep_compose(const tbc_sweep_rel* rel, uint32_t max_segs, uint32_t n_completions,
+                             tbc_sweep_verdict* out);
+
+tbc_status tbc_batch_set_shard(tbc_batch* b, uint32_t rank, uint32_t world);
+/* pack + sweep of this rank's wavefronts; no verdicts yet */
+tbc_status tbc_batch_sweep_partial(tbc_batch* b);
+/* the relation table of the last partial run: DEVICE pointer (for a collective straight out of HBM) and size */
+tbc_status tbc_batch_sweep_table(const tbc_batch* b, void** device_ptr, uint64_t* bytes);
+/* verdicts from a merged relation table in HOST memory (bytes as above) */
+tbc_status tbc_batch_sweep_finish(tbc_batch* b, const void* merged, tbc_result* results);
 void tbc_batch_destroy(tbc_batch* b);
 
 /* ----------------------------------------------------------------- memo

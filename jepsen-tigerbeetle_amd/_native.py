@@ -104,6 +104,23 @@ class SweepInfo(C.Structure):
                 ("cut_open", C.c_uint32), ("n_dom", C.c_uint32), ("n_segments", C.c_uint32), ("n_fallback", C.c_uint32)]
 
 
+class SweepRel(C.Structure):
+    """tbc_sweep_rel: what one wavefront of the level sweep hands on (exchanged between ranks as raw bytes)."""
+    _fields_ = [("status", C.c_uint32), ("F0", C.c_uint32), ("F1", C.c_uint32), ("n_org", C.c_uint32),
+                ("max_level", C.c_uint32), ("subrounds", C.c_uint32), ("n_end", C.c_uint32), ("end_state", C.c_uint32),
+                ("configs_total", C.c_uint64), ("probes", C.c_uint64),
+                ("M", (C.c_uint32 * 4) * 32), ("last_level", C.c_uint32 * 32)]
+
+
+class SweepVerdict(C.Structure):
+    _fields_ = [("valid", C.c_int32), ("fail_level", C.c_uint32), ("fail_seg", C.c_uint32), ("live_in", C.c_uint32 * 4),
+                ("final_bits", C.c_uint32), ("end_state", C.c_uint32), ("n_wavefronts", C.c_uint32),
+                ("probes", C.c_uint64), ("configs_total", C.c_uint64), ("subrounds", C.c_uint64), ("max_level", C.c_uint64)]
+
+
+SWEEP_SLICES = 4
+
+
 class SynthParams(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("n_ops", C.c_uint32), ("n_procs", C.c_uint32), ("n_values", C.c_uint32),
                 ("busy_permille", C.c_uint32), ("info_permille", C.c_uint32), ("read_permille", C.c_uint32),
@@ -125,6 +142,11 @@ SYMBOLS = {
     "tbc_batch_last_counters": (C.c_int, [C.c_void_p, C.POINTER(Counters)]),
     "tbc_batch_device_bytes": (C.c_uint64, [C.c_void_p]),
     "tbc_batch_sweep_info": (C.c_int, [C.c_void_p, C.POINTER(SweepInfo)]),
+    "tbc_sweep_compose": (C.c_int, [C.POINTER(SweepRel), C.c_uint32, C.c_uint32, C.POINTER(SweepVerdict)]),
+    "tbc_batch_set_shard": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),
+    "tbc_batch_sweep_partial": (C.c_int, [C.c_void_p]),
+    "tbc_batch_sweep_table": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
+    "tbc_batch_sweep_finish": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Result)]),
     "tbc_batch_destroy": (None, [C.c_void_p]),
     "tbc_memo_build": (C.c_int, [C.c_int64, C.c_uint32, STEP_FN, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint16),
                                  C.POINTER(C.c_int64), C.POINTER(C.c_uint32)]),

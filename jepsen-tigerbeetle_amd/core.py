@@ -163,6 +163,25 @@ class Batch:
         N.check_status(N.lib().tbc_batch_last_counters(self._h, C.byref(c)))
         return {k: getattr(c, k) for k, _ in N.Counters._fields_}
 
+    # ---- one history (or a small batch) over several GPUs: jepsen-tigerbeetle_amd/shard.py drives these
+    def set_shard(self, rank, world):
+        N.check_status(N.lib().tbc_batch_set_shard(self._h, rank, world))
+
+    def sweep_partial(self):
+        N.check_status(N.lib().tbc_batch_sweep_partial(self._h))
+
+    def sweep_table(self):
+        """(device pointer, bytes) of the relation table of the last sweep_partial()."""
+        p, n = C.c_void_p(), C.c_uint64()
+        N.check_status(N.lib().tbc_batch_sweep_table(self._h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def sweep_finish(self, merged: np.ndarray):
+        m = np.ascontiguousarray(merged, np.uint8)
+        st = N.lib().tbc_batch_sweep_finish(self._h, m.ctypes.data_as(C.c_void_p), self._res)
+        N.check_status(st)
+        return self
+
     def sweep_info(self):
         i = N.SweepInfo()
         N.check_status(N.lib().tbc_batch_sweep_info(self._h, C.byref(i)))

@@ -184,6 +184,7 @@ __global__ __launch_bounds__(64) void jit_sweep_kernel(SweepArgs A) {
   else if (A.seg_list) { h = rfl(A.seg_list[3 * w]); k = rfl(A.seg_list[3 * w + 1]); sl = rfl(A.seg_list[3 * w + 2]); }
   else { const uint32_t per = A.max_segs * kSweepSlices; h = w / per; const uint32_t r = w - h * per; k = r / kSweepSlices; sl = r % kSweepSlices; }
   if (h >= A.n_hist) return;
+  if (!dump && A.shard_world > 1u && (k * kSweepSlices + sl) % A.shard_world != A.shard_rank) return;   // another rank's (its record stays zero)
   const uint32_t* cuts = A.cuts + (uint64_t)h * A.max_segs;
   SegResult* out = A.seg + ((uint64_t)h * A.max_segs + k) * kSweepSlices + sl;
   const uint32_t F0 = rfl(cuts[k]);

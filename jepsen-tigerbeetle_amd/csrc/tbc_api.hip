@@ -210,6 +210,9 @@ struct tbc_batch {
   DevBuf<SegResult> d_sres;
   std::vector<SegResult> seg_host;
   uint32_t last_segments = 0, last_fallback = 0;
+  uint32_t shard_rank = 0, shard_world = 1;      // tbc_batch_set_shard: this rank's share of the sweep's wavefronts
+  std::vector<Hist> hist_back_m;                 // descriptors as the pack kernels left them (kept between
+  std::vector<BeamHist> bh_back_m;               //   tbc_batch_sweep_partial and tbc_batch_sweep_finish)
   uint32_t rules = 0;               // kRuleEager | kRuleTwin: wide single-wave schedule, register family, values 0..kMaxRuleValue
   uint32_t vpad = 0;                // entries per rdm row (nil + values), power of two
   DevBuf<uint64_t> d_twn, d_rdm;    // dominance tables (tbc_internal.h)
@@ -722,18 +725,29 @@ static tbc_status expand_eager_witness(tbc_batch* B, uint32_t h, uint32_t* wit, 
   return TBC_OK;
 }
 
-static bool k_has_segment(const SegResult* sg, uint32_t k, uint32_t SL) {
-  for (uint32_t j = 0; j < SL; j++) if (sg[(size_t)k * SL + j].status != kSegNone) return true;
-  return false;
-}
-
-static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results) {
+// phase 0: the whole run.  phase 1 (tbc_batch_sweep_partial): pack + this rank's share of the sweep, stop before the
+// verdicts.  phase 2 (tbc_batch_sweep_finish): verdicts from the merged relation table already placed in seg_host.
+static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results, int phase = 0) {
   HIP_TRY(hipSetDevice(B->device));
   const uint64_t t_start = now_ns();
   const uint32_t nh = B->n_hist;
   hipStream_t s = B->stream;
   const bool beam = B->width > 1;
   const uint32_t KW = 1 + B->mask_words, EW = B->wg ? beam_wg_entry_words(B->mask_words) : B->mask_words + 2;
+  std::vector<Hist>& hist_back = B->hist_back_m;
+  std::vector<BeamHist>& bh_back = B->bh_back_m;
+  SweepArgs swa{};
+  if (B->sweep) {
+    swa.hist = B->d_hist.p; swa.bh = B->d_bh.p; swa.off = B->d_off.p; swa.ncr = B->d_ncr.p; swa.lst = B->d_lst.p;
+    swa.crashed = B->d_crashed.p; swa.twn = B->rules ? B->d_twn.p : nullptr; swa.rdm = B->rules ? B->d_rdm.p : nullptr;
+    swa.slot8 = B->d_slot8.p; swa.cuts = B->d_cuts.p; swa.seg = B->d_sres.p; swa.table = B->d_table.p;
+    swa.pool_vals = B->d_pool_vals.p; swa.n_hist = nh; swa.max_segs = B->max_segs; swa.seg_target = B->seg_target;
+    swa.cut_open = B->cut_open; swa.n_dom = B->n_dom; swa.vpad = B->vpad ? B->vpad : 1; swa.rules = B->rules;
+    swa.model_kind = B->model.kind; swa.init_state = B->model.init;
+    swa.n_classes = B->model.n_classes; swa.n_keys = B->model.n_keys;
+    swa.shard_rank = 0; swa.shard_world = 1;
+  }
+  if (phase != 2) {
 
   TRACE("run: begin");
   HIP_TRY(hipEventRecord(B->ev[0], s));
@@ -777,16 +791,13 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results) {
   SYNC_TRACE("pack");
   HIP_TRY(hipEventRecord(B->ev[2], s));
 
-  SweepArgs swa{};
   if (B->sweep) {
-    swa.hist = B->d_hist.p; swa.bh = B->d_bh.p; swa.off = B->d_off.p; swa.ncr = B->d_ncr.p; swa.lst = B->d_lst.p;
-    swa.crashed = B->d_crashed.p; swa.twn = B->rules ? B->d_twn.p : nullptr; swa.rdm = B->rules ? B->d_rdm.p : nullptr;
-    swa.slot8 = B->d_slot8.p; swa.cuts = B->d_cuts.p; swa.seg = B->d_sres.p; swa.table = B->d_table.p;
-    swa.pool_vals = B->d_pool_vals.p; swa.n_hist = nh; swa.max_segs = B->max_segs; swa.seg_target = B->seg_target;
-    swa.cut_open = B->cut_open; swa.n_dom = B->n_dom; swa.vpad = B->vpad ? B->vpad : 1; swa.rules = B->rules;
-    swa.model_kind = B->model.kind; swa.init_state = B->model.init;
-    swa.n_classes = B->model.n_classes; swa.n_keys = B->model.n_keys;
-    if (!launch_sweep(swa, s)) { set_error("level sweep launch failed"); return TBC_ERR_HIP; }
+    SweepArgs mine = swa;
+    if (phase == 1 && B->shard_world > 1) {     // another rank's records must read as zero in the exchanged table
+      mine.shard_rank = B->shard_rank; mine.shard_world = B->shard_world;
+      HIP_TRY(hipMemsetAsync(B->d_sres.p, 0, B->d_sres.bytes(), s));
+    }
+    if (!launch_sweep(mine, s)) { set_error("level sweep launch failed"); return TBC_ERR_HIP; }
   } else if (beam) {
     BeamArgs ba = make_beam_args(B, B->d_btab.p, B->d_stack.p, B->d_dstack.p, nh);
     if (B->wg ? !launch_beam_wg(ba, B->mask_words, nh, s) : !launch_beam(ba, B->mask_words, search_blocks(nh), s)) { set_error("unsupported mask width"); return TBC_ERR_UNSUPPORTED; }
@@ -800,12 +811,19 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results) {
   HIP_TRY(hipEventRecord(B->ev[3], s));
   if (!B->sweep) HIP_TRY(hipMemcpyAsync(B->res_host.data(), B->d_results.p, nh * sizeof(DevResult), hipMemcpyDeviceToHost, s));
   else HIP_TRY(hipMemcpyAsync(B->seg_host.data(), B->d_sres.p, B->seg_host.size() * sizeof(SegResult), hipMemcpyDeviceToHost, s));
-  std::vector<Hist> hist_back(nh);
-  std::vector<BeamHist> bh_back(beam ? nh : 0);
+  hist_back.resize(nh);
+  bh_back.resize(beam ? nh : 0);
   HIP_TRY(hipMemcpyAsync(hist_back.data(), B->d_hist.p, nh * sizeof(Hist), hipMemcpyDeviceToHost, s));
   if (beam) HIP_TRY(hipMemcpyAsync(bh_back.data(), B->d_bh.p, nh * sizeof(BeamHist), hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   TRACE("run: first pass synced");
+  }   // phase != 2
+  if (phase == 1) return TBC_OK;
+  if (phase == 2) {
+    if (!B->sweep || hist_back.size() != nh) { set_error("tbc_batch_sweep_finish without tbc_batch_sweep_partial"); return TBC_ERR_INVALID_ARG; }
+    // the device table becomes the merged one, so a second pass over overflowed wavefronts updates it in place
+    HIP_TRY(hipMemcpyAsync(B->d_sres.p, B->seg_host.data(), B->seg_host.size() * sizeof(SegResult), hipMemcpyHostToDevice, s));
+  }
 
   const uint64_t max_bytes = B->opts.max_visited_bytes ? B->opts.max_visited_bytes : (1ull << 30);
   std::vector<uint32_t> final_log2(nh);
@@ -833,8 +851,7 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results) {
         HIP_TRY(hipStreamSynchronize(s));
       }
     }
-    // compose the relations in order: the live set is a set of origin ids (<= 128) of the current segment; what the
-    // sweep could not finish goes to the wide kernel
+    // compose the relations in order (tbc_sweep_compose, tbc_host.cpp); what the sweep could not finish goes to the wide kernel
     std::vector<uint32_t> fb, lg;
     for (uint32_t h = 0; h < nh; h++) {
       DevResult& d = B->res_host[h];
@@ -843,43 +860,26 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results) {
       if (hist_back[h].status != 0) { d.valid = TBC_UNKNOWN; continue; }
       if (hist_back[h].n_ret == 0) { d.valid = TBC_VALID; by_sweep[h] = 1; continue; }
       const SegResult* sg = &B->seg_host[(size_t)h * B->max_segs * SL];
-      bool give_up = bh_back[h].status != 0;
-      uint32_t live[kSweepSlices] = {1u, 0u, 0u, 0u}, live_in[kSweepSlices] = {1u, 0u, 0u, 0u};
-      uint32_t fail_seg = kInf, fail_level = 0, last_end_state = 0;
-      bool ended = false;
-      uint32_t dbg_ns = 0, dbg_longest = 0, dbg_big = 0, dbg_ml = 0; uint64_t dbg_maxp = 0;
-      for (uint32_t k = 0; k < B->max_segs && !give_up && fail_seg == kInf; k++) {
-        uint32_t next[kSweepSlices] = {0u, 0u, 0u, 0u}, reached = 0, F1 = 0;
-        bool any = false;
-        for (uint32_t j = 0; j < SL && !give_up; j++) {
-          const SegResult& g = sg[(size_t)k * SL + j];
-          if (g.status == kSegNone) { if (live[j] && k_has_segment(sg, k, SL)) give_up = true; continue; }
-          if (g.status != kSegOk) { give_up = true; break; }
-          any = true; F1 = g.F1; reached = std::max(reached, g.F0); last_end_state = g.end_state;
-          d.steps += g.probes; d.probes += g.probes; d.visited += g.configs_total; d.backtracks += g.subrounds;
-          d.max_depth = std::max<uint64_t>(d.max_depth, g.max_level);
-          dbg_ns++; dbg_longest = std::max(dbg_longest, g.F1 - g.F0); dbg_ml = std::max(dbg_ml, g.max_level); dbg_maxp = std::max<uint64_t>(dbg_maxp, g.probes);
-          for (uint32_t o = 0; o < 32; o++) if ((live[j] >> o) & 1u) {
-            for (uint32_t w = 0; w < SL; w++) next[w] |= g.M[o][w];
-            reached = std::max(reached, g.last_level[o]);
-          }
-        }
-        if (!any || give_up) continue;
-        if (!(next[0] | next[1] | next[2] | next[3])) { fail_seg = k; fail_level = reached; for (uint32_t w = 0; w < SL; w++) live_in[w] = live[w]; break; }
-        for (uint32_t w = 0; w < SL; w++) live[w] = next[w];
-        ended = F1 == hist_back[h].n_ret;
+      tbc_sweep_verdict v{};
+      (void)tbc_sweep_compose(sg, B->max_segs, hist_back[h].n_ret, &v);
+      const bool give_up = bh_back[h].status != 0 || v.valid == TBC_UNKNOWN;
+      const uint32_t fail_seg = v.valid == TBC_INVALID ? v.fail_seg : kInf, fail_level = v.fail_level;
+      const bool ended = v.valid == TBC_VALID;
+      const uint32_t* live_in = v.live_in;
+      d.steps = v.probes; d.probes = v.probes; d.visited = v.configs_total; d.backtracks = v.subrounds; d.max_depth = v.max_level;
+      if (std::getenv("TBC_DEBUG")) {
+        uint32_t longest = 0; uint64_t maxp = 0;
+        for (uint32_t q = 0; q < B->max_segs * SL; q++) if (sg[q].status == kSegOk) { longest = std::max(longest, sg[q].F1 - sg[q].F0); maxp = std::max<uint64_t>(maxp, sg[q].probes); }
+        std::fprintf(stderr, "[tbc sweep] history %u: %u wavefronts, longest segment %u levels, most probes in one %llu, largest level %llu, verdict %d\n",
+                     h, v.n_wavefronts, longest, (unsigned long long)maxp, (unsigned long long)v.max_level, v.valid);
       }
-      (void)dbg_big;
-      if (std::getenv("TBC_DEBUG"))
-        std::fprintf(stderr, "[tbc sweep] history %u: %u wavefronts, longest segment %u levels, most probes in one %llu, largest level %u, gave up %d\n",
-                     h, dbg_ns, dbg_longest, (unsigned long long)dbg_maxp, dbg_ml, (int)give_up);
       if (give_up || (fail_seg == kInf && !ended)) { fb.push_back(h); lg.push_back(B->bh[h].tab_log2); continue; }
       by_sweep[h] = 1;
       if (fail_seg == kInf) {
         d.valid = TBC_VALID;
         const bool regfam = B->model.kind == TBC_MODEL_REGISTER || B->model.kind == TBC_MODEL_CAS_REGISTER;
-        if (regfam && B->vpad > 1) { const uint32_t sb = (uint32_t)__builtin_ctz(live[0]); d.final_state = sb == 0 ? TBC_NIL : (int32_t)sb - 1; }
-        else d.final_state = (int32_t)last_end_state;
+        if (regfam && B->vpad > 1 && v.final_bits) { const uint32_t sb = (uint32_t)__builtin_ctz(v.final_bits); d.final_state = sb == 0 ? TBC_NIL : (int32_t)sb - 1; }
+        else d.final_state = (int32_t)v.end_state;
         continue;
       }
       d.valid = TBC_INVALID; d.max_front = fail_level;
@@ -1051,6 +1051,37 @@ tbc_status tbc_batch_run(tbc_batch* b, tbc_result* results) {
     set_error("unexpected exception");
     return TBC_ERR_HIP;
   }
+}
+
+tbc_status tbc_batch_set_shard(tbc_batch* b, uint32_t rank, uint32_t world) {
+  if (!b || world == 0 || rank >= world) { set_error("tbc_batch_set_shard: bad rank / world"); return TBC_ERR_INVALID_ARG; }
+  if (!b->sweep) { set_error("tbc_batch_set_shard: this batch does not run the level sweep (TBC_ALG_LINEAR, <= 64 process slots)"); return TBC_ERR_UNSUPPORTED; }
+  b->shard_rank = rank; b->shard_world = world;
+  return TBC_OK;
+}
+
+tbc_status tbc_batch_sweep_partial(tbc_batch* b) {
+  if (!b || !b->sweep) { set_error("tbc_batch_sweep_partial: not a sweep batch"); return TBC_ERR_INVALID_ARG; }
+  try { return batch_run_impl(b, nullptr, 1); }
+  catch (const std::bad_alloc&) { set_error("host allocation failed"); return TBC_ERR_OOM; }
+  catch (...) { set_error("unexpected exception"); return TBC_ERR_HIP; }
+}
+
+tbc_status tbc_batch_sweep_table(const tbc_batch* b, void** device_ptr, uint64_t* bytes) {
+  if (!b || !b->sweep || !device_ptr || !bytes) { set_error("tbc_batch_sweep_table: not a sweep batch"); return TBC_ERR_INVALID_ARG; }
+  *device_ptr = b->d_sres.p;
+  *bytes = (uint64_t)b->seg_host.size() * sizeof(SegResult);
+  return TBC_OK;
+}
+
+tbc_status tbc_batch_sweep_finish(tbc_batch* b, const void* merged, tbc_result* results) {
+  if (!b || !b->sweep || !merged) { set_error("tbc_batch_sweep_finish: not a sweep batch"); return TBC_ERR_INVALID_ARG; }
+  try {
+    std::memcpy(b->seg_host.data(), merged, b->seg_host.size() * sizeof(SegResult));
+    return batch_run_impl(b, results, 2);
+  }
+  catch (const std::bad_alloc&) { set_error("host allocation failed"); return TBC_ERR_OOM; }
+  catch (...) { set_error("unexpected exception"); return TBC_ERR_HIP; }
 }
 
 tbc_status tbc_batch_last_timing(const tbc_batch* b, uint64_t ns[4]) {

@@ -121,6 +121,46 @@ tbc_status tbc_pair_events(const tbc_events* ev, uint8_t* f, int32_t* a, int32_t
   return TBC_OK;
 }
 
+// Composition of the level sweep's relations (jit_sweep.hip): the live set is a set of origin ids (<= 128) of the
+// current segment; every slice that holds a live origin contributes the next segment's ids its live origins reach.
+tbc_status tbc_sweep_compose(const tbc_sweep_rel* rel, uint32_t max_segs, uint32_t n_completions, tbc_sweep_verdict* out) {
+  if (!rel || !out || max_segs == 0) { tbc::set_error("tbc_sweep_compose: null argument"); return TBC_ERR_INVALID_ARG; }
+  std::memset(out, 0, sizeof *out);
+  constexpr uint32_t SL = TBC_SWEEP_SLICES;
+  uint32_t live[SL] = {1u, 0u, 0u, 0u};
+  bool ended = false;
+  out->valid = TBC_UNKNOWN;
+  for (uint32_t k = 0; k < max_segs; k++) {
+    const tbc_sweep_rel* g = rel + (size_t)k * SL;
+    bool any = false;
+    for (uint32_t j = 0; j < SL; j++) any = any || g[j].status != 0;
+    if (!any) continue;                                  // no cut in this window
+    uint32_t next[SL] = {0u, 0u, 0u, 0u}, reached = 0, F1 = 0;
+    for (uint32_t j = 0; j < SL; j++) {
+      if (g[j].status == 0) { if (live[j]) return TBC_OK; continue; }    // a live origin without its wavefront: unknown
+      if (g[j].status != 1) return TBC_OK;                                // overflow: unknown, the caller falls back
+      out->n_wavefronts++; out->probes += g[j].probes; out->configs_total += g[j].configs_total; out->subrounds += g[j].subrounds;
+      if (g[j].max_level > out->max_level) out->max_level = g[j].max_level;
+      F1 = g[j].F1; if (g[j].F0 > reached) reached = g[j].F0;
+      if (g[j].n_end) out->end_state = g[j].end_state;
+      for (uint32_t o = 0; o < 32; o++) if ((live[j] >> o) & 1u) {
+        for (uint32_t w = 0; w < SL; w++) next[w] |= g[j].M[o][w];
+        if (g[j].last_level[o] > reached) reached = g[j].last_level[o];
+      }
+    }
+    if (!(next[0] | next[1] | next[2] | next[3])) {
+      out->valid = TBC_INVALID; out->fail_level = reached; out->fail_seg = k;
+      for (uint32_t w = 0; w < SL; w++) out->live_in[w] = live[w];
+      return TBC_OK;
+    }
+    for (uint32_t w = 0; w < SL; w++) live[w] = next[w];
+    ended = F1 == n_completions;
+    if (ended) break;
+  }
+  if (ended) { out->valid = TBC_VALID; out->final_bits = live[0]; }
+  return TBC_OK;
+}
+
 tbc_status tbc_memo_build(int64_t init_state, uint32_t n_classes, tbc_step_fn step, void* user,
                           uint32_t max_states, uint16_t* table, int64_t* handles, uint32_t* n_states) {
   if (!step || !table || !handles || !n_states || n_classes == 0 || max_states == 0 || max_states > 0xFFFEu) {

@@ -257,21 +257,8 @@ constexpr uint32_t kSweepCapBig = 2048;    // ... and the segment is swept again
 constexpr uint32_t kSweepCandMax = 128;    // open calls (live + crashed) per level held in LDS
 constexpr uint32_t kSweepMaxSegs = 512;    // cuts per history
 enum : uint32_t { kSegNone = 0, kSegOk = 1, kSegOverflow = 2 };
-constexpr uint32_t kSweepSlices = 4;       // wavefronts per segment at most: 32 origins each, <= 128 origins per segment
-struct __attribute__((aligned(8))) SegResult {     // one per (history, segment, slice)
-  uint32_t status;          // kSeg*
-  uint32_t F0, F1;          // levels swept: [F0, F1)
-  uint32_t n_org;           // origins of this slice that are configs (ids in normal form)
-  uint32_t max_level;       // largest level
-  uint32_t subrounds;
-  uint32_t n_end;           // configs at front F1
-  uint32_t end_state;       // state of the first of them (single-origin segments of non-register models)
-  uint64_t configs_total;   // sum of the level sizes
-  uint64_t probes;          // expansions (model-consistent (config, call) pairs)
-  uint32_t M[32][kSweepSlices];   // M[o] = ids of the NEXT segment's origin space reachable from origin 32 * slice + o, as a
-                                  // 128-bit set (last segment: word 0 = the final states reached)
-  uint32_t last_level[32];  // greatest level at which a config reachable from origin o existed
-};
+constexpr uint32_t kSweepSlices = TBC_SWEEP_SLICES;   // wavefronts per segment at most: 32 origins each, <= 128 origins per segment
+using SegResult = tbc_sweep_rel;           // one per (history, segment, slice); public because ranks exchange it (include/tbcheck.h)
 struct SweepArgs {
   const Hist* hist;
   const BeamHist* bh;
@@ -299,6 +286,7 @@ struct SweepArgs {
   uint32_t n_keys;
   // dump pass
   uint32_t dump_hist, dump_seg, dump_slice, stop_level, live_mask;
+  uint32_t shard_rank, shard_world;   // this rank sweeps the wavefronts with (segment * kSweepSlices + slice) % world == rank
   const uint32_t* seg_list;  // second pass: n_list (history, segment, slice) triples to sweep with the big sets, else null
   uint32_t n_list, pad4;
   uint64_t* dump_cfg;        // records {front + 1 | state << 32, mask, TBC_NO_OP} as SearchArgs.cfg, kCfgCap at most

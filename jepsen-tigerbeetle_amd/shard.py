@@ -1,7 +1,15 @@
-"""Multi-GPU layout of the batch path: histories (and jepsen.independent keys) are
-independent units, so rank r of N simply owns every N-th history -- no data-path
-collective.  torch.distributed (RCCL on the GPU box, gloo in the CPU tests) is used
-only to agree on the verdict summary and on the max-over-ranks clock."""
+"""Multi-GPU layouts.
+
+Batch path: histories (and jepsen.independent keys) are independent units, so rank r of N simply owns every
+N-th history -- no data-path collective; torch.distributed (RCCL on the GPU box, gloo in the CPU tests) only
+agrees on the verdict summary and on the max-over-ranks clock.
+
+One history over several GPUs (BASELINE.json's north_star: "the search frontier shards across the GPUs"):
+the level sweep (csrc/jit_sweep.hip) cuts a history into segments whose wavefronts are independent; rank r
+sweeps every N-th wavefront, ONE all-gather of the relation tables (a few hundred KB, straight out of HBM over
+RCCL / xGMI) gives every rank the whole chain, and every rank composes it (`check_sharded`).  Unlike a
+hash-partitioned visited set with an all-to-all per search level (>= 10^4 dependent
+collectives of tens of microseconds each), the exchange happens once."""
 from __future__ import annotations
 
 import numpy as np
@@ -37,3 +45,46 @@ def max_over_ranks(seconds: float, world: int, dist=None) -> float:
         t = t.cuda()
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+class _DeviceBytes:
+    """A view of library-owned device memory that torch can wrap without a copy (__cuda_array_interface__)."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
+def merge_relation_tables(tables) -> np.ndarray:
+    """Every (history, segment, slice) record is written by exactly one rank and all zero on the others: the merged
+    table is the bitwise OR."""
+    out = np.zeros_like(np.asarray(tables[0], np.uint8))
+    for t in tables:
+        out |= np.asarray(t, np.uint8)
+    return out
+
+
+def gather_relation_tables(local, world: int, dist=None):
+    """all_gather of one uint8 table per rank -> list of `world` numpy arrays (on every rank).  `local` is a numpy
+    array (gloo / CPU stand-in) or a torch CUDA tensor (RCCL, straight out of the library's HBM table)."""
+    import torch
+    if world == 1:
+        return [local.cpu().numpy() if isinstance(local, torch.Tensor) else np.asarray(local, np.uint8)]
+    t = local if isinstance(local, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(local, np.uint8))
+    if dist.get_backend() == "nccl" and not t.is_cuda:
+        t = t.cuda()
+    out = torch.empty(world * t.numel(), dtype=torch.uint8, device=t.device)
+    dist.all_gather_into_tensor(out, t.contiguous().view(-1))
+    return [x for x in out.view(world, -1).cpu().numpy()]
+
+
+def check_sharded(batch, rank: int, world: int, dist=None):
+    """One small batch (typically ONE history) over `world` GPUs: `batch` is this rank's core.Batch over the SAME
+    histories (inputs are replicated), created with algorithm=N.ALG_LINEAR.  Returns batch.results() on every rank."""
+    import torch
+    batch.set_shard(rank, world)
+    batch.sweep_partial()
+    ptr, nbytes = batch.sweep_table()
+    local = torch.as_tensor(_DeviceBytes(ptr, nbytes), device=torch.device("cuda", torch.cuda.current_device()))
+    merged = merge_relation_tables(gather_relation_tables(local, world, dist))
+    batch.sweep_finish(merged)
+    return batch.results()

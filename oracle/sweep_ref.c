@@ -61,6 +61,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include "oracle_model.h"
+#include "../include/tbcheck.h"      /* tbc_sweep_rel: the record ranks exchange (the multi-GPU stand-in below writes it) */
 
 typedef struct { uint32_t pos, op; } posop;
 static int cmp_posop(const void* x, const void* y) {
@@ -137,6 +138,13 @@ void sweep_set_segments(uint32_t seg_target, uint32_t max_cut_open) { g_seg_targ
  * histories shares one domain in the library (the greatest value of the whole batch). */
 static uint32_t g_n_dom = 0;
 void sweep_set_domain(uint32_t n_dom) { g_n_dom = n_dom; }
+/* Multi-GPU stand-in (tests/test_distributed_gloo.py): instead of composing, write the relation of every wavefront
+ * with (segment * 4 + slice) % world == rank into rel[segment * 4 + slice] -- exactly what rank `rank` of `world`
+ * GPUs leaves in its table after tbc_batch_sweep_partial -- and sweep nothing else.  rel = NULL switches it off. */
+static tbc_sweep_rel* g_rel = NULL; static uint32_t g_rel_segs = 0, g_rel_rank = 0, g_rel_world = 1;
+void sweep_set_export(void* rel, uint32_t max_segs, uint32_t rank, uint32_t world) {
+  g_rel = (tbc_sweep_rel*)rel; g_rel_segs = max_segs; g_rel_rank = rank; g_rel_world = world ? world : 1;
+}
 
 typedef struct {
   uint32_t n, R, W, MW, KW;
@@ -238,15 +246,16 @@ int sweep_ref_check(uint32_t n, const uint8_t* f, const int32_t* a, const int32_
   if (cut_ok) while (m_open < g_max_cut_open && (nd << (m_open + 1)) <= 128) m_open++;
   /* ---- cuts: in every window the front with the FEWEST open calls (the first of them), if that is <= m_open */
   uint32_t* cuts = (uint32_t*)malloc(4 * ((size_t)R + 2));
+  uint32_t* cutk = (uint32_t*)malloc(4 * ((size_t)R + 2));     /* window number of each cut = the kernel's segment number */
   uint32_t S = 0;
-  cuts[S++] = 0;
+  cutk[S] = 0; cuts[S++] = 0;
   if (cut_ok) {
     for (uint32_t k = 1; (uint64_t)k * g_seg_target < R; k++) {
       const uint32_t lo = k * g_seg_target, hi = lo + g_seg_target < R ? lo + g_seg_target : R;
       uint32_t best = 0xFFFFFFFFu, bestF = 0;
       for (uint32_t F = lo; F < hi; F++)
         if (H.ncr[F] == 0 && H.off[F + 1] - H.off[F] < best) { best = H.off[F + 1] - H.off[F]; bestF = F; }
-      if (best <= m_open) cuts[S++] = bestF;
+      if (best <= m_open) { cutk[S] = k; cuts[S++] = bestF; }
     }
   }
   cuts[S] = R;
@@ -277,6 +286,10 @@ int sweep_ref_check(uint32_t n, const uint8_t* f, const int32_t* a, const int32_
     orgset next_live = 0;
     uint32_t reached = F0;
     for (uint32_t sl = 0; sl < n_slices && verdict == 1; sl++) {
+      if (g_rel && (cutk[sg] * 4 + sl) % g_rel_world != g_rel_rank) continue;      /* another rank's wavefront */
+      if (g_rel && cutk[sg] >= g_rel_segs) { verdict = -3; break; }
+      const uint64_t cfg_before = st->configs_total, sub_before = st->subrounds;
+      uint32_t slice_max = 0;
       cs_clear(&cur);
       for (uint32_t l = 0; l < 32; l++) {
         const uint32_t id = 32 * sl + l;
@@ -346,6 +359,7 @@ int sweep_ref_check(uint32_t n, const uint8_t* f, const int32_t* a, const int32_
         st->levels++;
         st->configs_total += nxt.n;
         if (nxt.n > st->max_level) st->max_level = nxt.n;
+        if (nxt.n > slice_max) slice_max = (uint32_t)nxt.n;
         if (level_sizes && S == 1) level_sizes[F] = (uint32_t)nxt.n;
         if (max_level_limit && nxt.n > max_level_limit) { verdict = -1; break; }
         { orgset any = 0; for (size_t e = 0; e < nxt.n; e++) any |= nxt.org[e];
@@ -370,6 +384,16 @@ int sweep_ref_check(uint32_t n, const uint8_t* f, const int32_t* a, const int32_
         }
         for (uint32_t q = 0; q < 32; q++) if (cur.org[e] >> q & 1) M[q][id2 >> 5] |= 1u << (id2 & 31);
       }
+      if (g_rel) {
+        tbc_sweep_rel* r = g_rel + (size_t)cutk[sg] * 4 + sl;
+        memset(r, 0, sizeof *r);
+        r->status = 1; r->F0 = F0; r->F1 = F1; r->n_org = 0; r->max_level = slice_max;
+        r->subrounds = (uint32_t)(st->subrounds - sub_before); r->n_end = (uint32_t)cur.n;
+        r->end_state = cur.n ? (uint32_t)(cur.key[0] >> 32) : 0u;
+        r->configs_total = st->configs_total - cfg_before; r->probes = st->probes - probes_before;
+        memcpy(r->M, M, sizeof M); memcpy(r->last_level, last_level, sizeof last_level);
+        continue;
+      }
       /* composition over this slice's live origins */
       for (uint32_t q = 0; q < 32; q++) if (live >> (32 * sl + q) & 1) {
         for (uint32_t w = 0; w < 4; w++) next_live |= (orgset)M[q][w] << (32 * w);
@@ -377,12 +401,14 @@ int sweep_ref_check(uint32_t n, const uint8_t* f, const int32_t* a, const int32_
       }
     }
     if (verdict != 1) break;
+    if (g_rel) continue;                                   /* relations only: the ranks compose after the exchange */
     if (next_live == 0) { verdict = 0; fail_level = reached; break; }
     if (F1 == R) { for (uint32_t q = 0; q < 32; q++) if (next_live >> q & 1) { final_state = regfam ? dom[q < nd ? q : 0] : model->init; break; } }
     live = next_live;
   }
   if (verdict == 1 && !regfam) final_state = cur.n ? (int32_t)(uint32_t)(cur.key[0] >> 32) : model->init;
 
+  if (g_rel && verdict == 1) verdict = -1;
   out->valid = verdict < -1 ? -1 : verdict;
   if (verdict == 1) out->final_state = final_state;
   if (verdict == 0) {
@@ -392,7 +418,7 @@ int sweep_ref_check(uint32_t n, const uint8_t* f, const int32_t* a, const int32_
   out->probes = st->probes; out->visited = st->configs_total; out->steps = st->subrounds;
   g_eager = save_eager;
   cs_free(&cur); cs_free(&nxt); cs_free(&pa); cs_free(&pb);
-  free(key); free(tmp); free(dom); free(cuts); free(rets); free(fill);
+  free(key); free(tmp); free(dom); free(cuts); free(cutk); free(rets); free(fill);
   free(H.ret_rank); free(H.inv_rank); free(H.ret_op); free(H.off); free(H.ncr); free(H.lst); free(H.crashed);
   return verdict == -2 ? 4 : verdict == -3 ? 5 : 0;
 }

@@ -291,3 +291,16 @@ def check_many(ops_list, model, n_threads, max_steps=0):
                  C.c_uint64(max_steps), C.c_uint32(n_threads), _p(valid, C.c_int32))
     del keep, keep_m
     return valid, started
+
+
+def sweep_relations(ops, model, seg_target, n_dom, max_segs, rank=0, world=1, rel_bytes=688):
+    """What rank `rank` of `world` GPUs leaves in its relation table after tbc_batch_sweep_partial, computed by
+    the CPU restatement: max_segs * 4 tbc_sweep_rel records as a uint8 array (records of other ranks all zero)."""
+    buf = np.zeros(max_segs * 4 * rel_bytes, np.uint8)
+    L = lib()
+    L.sweep_set_export(buf.ctypes.data_as(C.c_void_p), C.c_uint32(max_segs), C.c_uint32(rank), C.c_uint32(world))
+    try:
+        check_sweep(ops, model, seg_target=seg_target, n_dom=n_dom)
+    finally:
+        L.sweep_set_export(None, C.c_uint32(0), C.c_uint32(0), C.c_uint32(1))
+    return buf

@@ -60,3 +60,55 @@ def test_history_sharding_world_size_2(tmp_path, native, oracle):
         expect.append(oracle.check(ops.as_dict(), {"kind": 1, "init": N.NIL}, "window", want_witness=False)["valid"])
     assert v0.tolist() == expect and 0 in expect and 1 in expect
     assert np.load(tmp_path / "t0.npy")[0] == np.load(tmp_path / "t1.npy")[0] == 2.0   # max over ranks
+
+
+# ---- one history over several GPUs: the level sweep's wavefronts dealt to the ranks, one all-gather of the relation
+# tables, every rank composes.  The per-rank sweep here is the CPU restatement writing the very records
+# (tbc_sweep_rel) a GPU rank leaves in its table; the exchange is shard.gather_relation_tables over gloo; the
+# composition is the library's own host code (tbc_sweep_compose), so everything but the kernel is the product path.
+def _sweep_worker(rank, world, port, cases, seg_target, n_dom, max_segs, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import ctypes as C
+    import jepsen_tigerbeetle_amd  # noqa: F401
+    from jepsen_tigerbeetle_amd import _native as N, columns, shard, synth
+    from oracle import wgl
+    out = []
+    for c in cases:
+        ops = columns.pair_events(synth.register_events(**c)).as_dict()
+        mine = wgl.sweep_relations(ops, {"kind": 1, "init": N.NIL}, seg_target, n_dom, max_segs, rank, world, C.sizeof(N.SweepRel))
+        merged = shard.merge_relation_tables(shard.gather_relation_tables(mine, world, dist))
+        rel = (N.SweepRel * (max_segs * N.SWEEP_SLICES)).from_buffer_copy(merged.tobytes())
+        v = N.SweepVerdict()
+        n_ret = int((ops["ret_pos"] != N.POS_CRASHED).sum())
+        assert N.lib().tbc_sweep_compose(rel, max_segs, n_ret, C.byref(v)) == 0
+        own = sum(1 for i in range(max_segs * N.SWEEP_SLICES) if (N.SweepRel * 1).from_buffer_copy(mine[i * C.sizeof(N.SweepRel):(i + 1) * C.sizeof(N.SweepRel)].tobytes())[0].status)
+        out.append([v.valid, v.fail_level, v.n_wavefronts, own, v.probes, v.configs_total])
+    np.save(os.path.join(out_dir, f"s{rank}.npy"), np.array(out, np.int64))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_one_history_sharded_over_two_ranks(tmp_path, native, oracle):
+    from jepsen_tigerbeetle_amd import _native as N, columns, synth
+    cases = [dict(n_ops=2000, n_procs=32, seed=3, busy=0.15), dict(n_ops=2000, n_procs=32, seed=4, busy=0.15, corrupt=0.5),
+             dict(n_ops=600, n_procs=8, seed=5, busy=0.3, corrupt=0.3), dict(n_ops=3000, n_procs=64, seed=6, busy=0.1)]
+    seg_target, n_dom, max_segs, world = 16, 6 + 8, 200, 2          # n_dom: nil + 0..12 (the planted impossible value is 12)
+    mp.spawn(_sweep_worker, args=(world, _free_port(), cases, seg_target, n_dom, max_segs, str(tmp_path)), nprocs=world, join=True)
+    s0, s1 = np.load(tmp_path / "s0.npy"), np.load(tmp_path / "s1.npy")
+    assert np.array_equal(s0[:, [0, 1, 2, 4, 5]], s1[:, [0, 1, 2, 4, 5]])          # every rank reaches the same verdict
+    for c, row0, row1 in zip(cases, s0, s1):
+        ops = columns.pair_events(synth.register_events(**c)).as_dict()
+        ref = oracle.check_sweep(ops, {"kind": 1, "init": N.NIL}, seg_target=seg_target, n_dom=n_dom)
+        seq = oracle.check(ops, {"kind": 1, "init": N.NIL}, "window", want_witness=False)
+        assert row0[0] == ref["valid"] == seq["valid"]
+        if ref["valid"] == 0:
+            rets = np.sort(ops["ret_pos"][ops["ret_pos"] != N.POS_CRASHED])
+            assert int(ops["ret_pos"][ref["fail_op"]]) == int(rets[row0[1]])       # the failing completion, by rank
+        assert row0[3] > 0 and row1[3] > 0                                         # the wavefronts were really split ...
+        if ref["valid"] == 1:
+            assert row0[2] == row0[3] + row1[3]                                    # ... and all of them composed
+        assert (row0[4], row0[5]) == (ref["probes"], ref["configs_total"])         # nothing swept twice, nothing lost

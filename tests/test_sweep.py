@@ -125,3 +125,41 @@ def test_final_paths_of_the_tutorial_history(native):
         assert last["op"]["f"] == "read" and last["op"]["value"] == 3
         assert last["model"].msg == "can't read 3 from register 4", alg
         assert len(a["final-paths"]) <= 10 and len(a["configs"]) <= 10
+
+
+@pytest.mark.gpu
+def test_sharded_sweep_on_one_gpu(native, oracle):
+    """The multi-GPU path of ONE history (tbc_batch_set_shard / sweep_partial / sweep_table / sweep_finish,
+    shard.check_sharded) without a second GPU: (a) world 1 through shard.check_sharded -- the relation table is
+    read straight out of the library's HBM as a torch tensor; (b) two 'ranks' as two batches on the same device,
+    their tables merged on the host as the all-gather would: verdict, failing op and statistics equal the
+    unsharded run's, on a valid and an invalid history."""
+    import torch
+    from jepsen_tigerbeetle_amd import shard
+    torch.cuda.set_device(0)
+    for corrupt in (0.0, 0.5):
+        h = columns.pair_events(synth.register_events(n_ops=6000, n_procs=64, seed=11, busy=0.1, corrupt=corrupt))
+        opts = core.make_opts(algorithm=N.ALG_LINEAR, want_witness=False)
+        with core.Batch([h], gm(), opts) as b:
+            whole = b.run().results()[0]
+        with core.Batch([h], gm(), opts) as b:
+            one = shard.check_sharded(b, 0, 1, None)[0]
+        ranks = [core.Batch([h], gm(), opts) for _ in range(2)]
+        tables = []
+        for r, b in enumerate(ranks):
+            b.set_shard(r, 2)
+            b.sweep_partial()
+            ptr, nbytes = b.sweep_table()
+            tables.append(torch.as_tensor(shard._DeviceBytes(ptr, nbytes), device="cuda:0").cpu().numpy().copy())
+        merged = shard.merge_relation_tables(tables)
+        assert (tables[0] != 0).any() and (tables[1] != 0).any() and not (tables[0] & tables[1]).any()   # disjoint shares
+        two = [b.sweep_finish(merged).results()[0] for b in ranks]
+        for b in ranks:
+            b.close()
+        for got in [one] + two:
+            assert got["analyzer"] == N.ALG_LINEAR
+            assert (got["valid"], got["fail_op"], got["prev_ok_op"]) == (whole["valid"], whole["fail_op"], whole["prev_ok_op"])
+            assert (got["visited"], got["probes"], got["backtracks"]) == (whole["visited"], whole["probes"], whole["backtracks"])
+            if whole["valid"] == 0:
+                assert got["configs"] and len(got["configs"]) == len(whole["configs"])
+        assert whole["valid"] == (0 if corrupt else 1)
