@@ -74,6 +74,9 @@ def main():
     ap.add_argument("--batch2", type=int, default=4096, help="second workload: histories per GPU")
     ap.add_argument("--no-tiers", action="store_true", help="skip the crashed-op tiers (extra.tiers)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--sharded-ttv", action="store_true",
+                    help="N > 1 only: also time ONE history swept by all N GPUs (shard.check_sharded: wavefronts dealt to the ranks, "
+                         "one RCCL all-gather of the relation tables); off by default -- it adds a collective to the run")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -128,6 +131,19 @@ def main():
     elapsed = time.perf_counter() - t0
     elapsed = shard.max_over_ranks(elapsed, world, dist)
 
+    sharded_ms = None
+    if world > 1 and args.sharded_ttv:
+        o_lin = core.make_opts(device=local_rank, want_witness=False, algorithm=N.ALG_LINEAR)
+        one = synth.register_ops_many([424242], n_ops=args.ops, n_procs=args.procs, busy=args.busy, info=0.0)   # the same history on every rank
+        times = []
+        for _ in range(4):
+            with core.Batch(one, model, o_lin) as b1:
+                barrier()
+                t1 = time.perf_counter()
+                r1 = shard.check_sharded(b1, rank, world, dist)
+                times.append(shard.max_over_ranks(time.perf_counter() - t1, world, dist) * 1e3)
+        sharded_ms = {"median_ms": round(statistics.median(times[1:]), 3), "valid": r1[0]["valid"], "gpus": world}
+
     verdicts = batch.verdicts()
     counters = batch.counters()
     n_valid = int((verdicts == N.VALID).sum())
@@ -181,6 +197,8 @@ def main():
                       "h2d_inclusive_hist_per_s": round(B / (t_create + elapsed / args.steps), 2),
                       "create_h2d_s": round(t_create, 3), "kernel_sha": kernel_sha()},
         }
+        if sharded_ms is not None:
+            line["extra"]["one_history_over_all_gpus"] = sharded_ms
         # time-to-verdict for ONE history through tbc_check (host columns in -> verdict out: H2D + kernels + D2H), rank 0.
         # knossos.competition without a witness = the level sweep (jit_sweep.hip); with a witness = the depth-first search
         batch.close()

@@ -113,7 +113,7 @@ def _simulate(n_ops, n_procs, seed, busy, info, make_op, apply_op):
                 continue
             issued += 1
             f, value = make_op(rng, issued)
-            crashed = rng.random() < info
+            crashed = rng.random() < (info(issued) if callable(info) else info)
             cur[w] = {"f": f, "value": value, "crashed": crashed, "effect": (rng.random() < 0.5) if crashed else True, "res": value}
             hist.append({"type": "invoke", "f": f, "value": value, "process": pid[w]})
             L = 0.02 + rng.expovariate(1.0)
@@ -135,10 +135,17 @@ def _simulate(n_ops, n_procs, seed, busy, info, make_op, apply_op):
     return hist
 
 
+def partition_windows(windows, rate):
+    """:info probability as a function of the op number: `rate` inside the given [lo, hi) windows (a partition:
+    the reference's clients time out and report :info, set_full.clj:107-110), 0 outside."""
+    return lambda issued: rate if any(lo <= issued < hi for lo, hi in windows) else 0.0
+
+
 def set_history(n_ops, n_procs, seed, busy=0.3, info=0.0, corrupt=None):
     """Grow-only set, the reference's set-full shapes (set_full.clj:29-31,42-45,113-116,128-134):
     :add of globally increasing ids (from 9: set_full.clj:159), :read returns the whole sorted set;
-    timeouts are :info.  corrupt = "lost" drops an element from a late read, "phantom" adds one."""
+    timeouts are :info (`info` = a rate, or a function of the op number: partition_windows).
+    corrupt = "lost" drops an element from a late read, "phantom" adds one."""
     state = set()
     nxt = [9]
 
