@@ -66,12 +66,12 @@ def main():
     ap.add_argument("--info", type=float, default=0.0, help="crashed-op (:info) rate")
     ap.add_argument("--width", type=int, default=int(os.environ.get("TBC_BENCH_WIDTH", "4")),
                     help="configs expanded per iteration: 1 = sequential knossos.wgl order, 2..16 = wide schedule")
-    ap.add_argument("--visited-per-op", type=int, default=16, help="first visited-set capacity per op (0 = library default 64)")
+    ap.add_argument("--visited-per-op", type=int, default=8, help="first visited-set capacity per op (0 = library default 64)")
     ap.add_argument("--round-budget", type=int, default=0,
                     help="a history that has used more rounds than this continues at width 16 (0 = off)")
     ap.add_argument("--cpu-sample", type=int, default=256, help="histories timed on the CPU oracle (rank 0, N=1)")
     ap.add_argument("--busy2", type=float, default=0.5, help="second workload: duty cycle of the '64 concurrent processes' reading (0 = skip)")
-    ap.add_argument("--batch2", type=int, default=4096, help="second workload: histories per GPU")
+    ap.add_argument("--batch2", type=int, default=2048, help="second workload: histories per GPU")
     ap.add_argument("--no-tiers", action="store_true", help="skip the crashed-op tiers (extra.tiers)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--sharded-ttv", action="store_true",
@@ -296,7 +296,7 @@ def main():
             B2 = args.batch2
             h2 = synth.register_ops_many(range(10_000_000, 10_000_000 + B2), n_ops=args.ops, n_procs=args.procs, busy=args.busy2, info=0.0)
             o2 = core.make_opts(device=local_rank, time_limit_ms=600000, want_witness=False, algorithm=N.ALG_COMPETITION,
-                                search_width=args.width, visited_per_op=64)
+                                search_width=args.width, visited_per_op=256)     # ~4*10^5 configs per history: start big, no retries
             with core.Batch(h2, model, o2) as b2:
                 b2.run()
                 t2 = time.perf_counter(); b2.run(); t2 = time.perf_counter() - t2

@@ -474,9 +474,11 @@ __global__ __launch_bounds__(64) void jit_sweep_kernel(SweepArgs A) {
 
 bool launch_sweep(const SweepArgs& a, void* stream) {
   hipStream_t s = (hipStream_t)stream;
-  constexpr uint32_t kSmall = kSweepCap, kBig = kSweepCapBig;
+  constexpr uint32_t kSmall = kSweepCap, kMid = kSweepCapMid, kBig = kSweepCapBig;
   static bool big_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&jit_sweep_kernel<kBig>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, sweep_lds_words<kBig>() * 4) == hipSuccess;
+  static bool mid_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&jit_sweep_kernel<kMid>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, sweep_lds_words<kMid>() * 4) == hipSuccess;
   if (a.dump_cfg) {        // cuts are in place from the sweep proper; the big sets hold whatever the sweep held
     if (big_ok) hipLaunchKernelGGL(jit_sweep_kernel<kBig>, dim3(1), dim3(64), sweep_lds_words<kBig>() * 4, s, a);
     else hipLaunchKernelGGL(jit_sweep_kernel<kSmall>, dim3(1), dim3(64), sweep_lds_words<kSmall>() * 4, s, a);
@@ -488,7 +490,11 @@ bool launch_sweep(const SweepArgs& a, void* stream) {
     return true;
   }
   hipLaunchKernelGGL(sweep_cuts_kernel, dim3(a.n_hist), dim3(256), 0, s, a);
-  hipLaunchKernelGGL(jit_sweep_kernel<kSmall>, dim3(a.n_hist * a.max_segs * kSweepSlices), dim3(64), sweep_lds_words<kSmall>() * 4, s, a);
+  const uint32_t waves = a.n_hist * a.max_segs * kSweepSlices;
+  // a few histories: latency is what counts and the CUs are not full -- take the larger sets, so that a burst of
+  // concurrency does not cost a second pass; many: four wavefronts per CU
+  if (mid_ok && waves <= 4096u) hipLaunchKernelGGL(jit_sweep_kernel<kMid>, dim3(waves), dim3(64), sweep_lds_words<kMid>() * 4, s, a);
+  else hipLaunchKernelGGL(jit_sweep_kernel<kSmall>, dim3(waves), dim3(64), sweep_lds_words<kSmall>() * 4, s, a);
   return true;
 }
 

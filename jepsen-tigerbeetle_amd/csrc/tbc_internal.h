@@ -252,8 +252,9 @@ struct BeamArgs {
 };
 
 // ---- level sweep (jit_sweep.hip): knossos.linear as segments swept by one wavefront each
-constexpr uint32_t kSweepCap = 512;        // configs per LDS set; a larger level ends the segment with kSegOverflow ...
-constexpr uint32_t kSweepCapBig = 2048;    // ... and the segment is swept again with sets of this size (one wavefront per CU)
+constexpr uint32_t kSweepCap = 512;        // configs per LDS set when many wavefronts must share a CU (38 KB, four per CU) ...
+constexpr uint32_t kSweepCapMid = 1024;    // ... when a few histories must be quick (70 KB, two per CU): fewer second passes;
+constexpr uint32_t kSweepCapBig = 2048;    // a larger level ends the segment with kSegOverflow and it is swept again with sets of this size
 constexpr uint32_t kSweepCandMax = 128;    // open calls (live + crashed) per level held in LDS
 constexpr uint32_t kSweepMaxSegs = 512;    // cuts per history
 enum : uint32_t { kSegNone = 0, kSegOk = 1, kSegOverflow = 2 };
