@@ -46,7 +46,7 @@ def kernel_sha():
     was measured on (profiles/*_traffic.json carries the sha it was taken at)."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("wgl_beam.hip", "device_common.h", "tbc_internal.h", "pack_open.hip"):
+    for f in ("wgl_beam.hip", "device_common.h", "pack_open.hip"):
         with open(os.path.join(ROOT, "jepsen-tigerbeetle_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]

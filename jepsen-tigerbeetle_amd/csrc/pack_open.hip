@@ -187,10 +187,15 @@ __global__ __launch_bounds__(1024) void open_counts_kernel(PackOpenArgs A) {
 
 // ---- the walk: one wavefront per 64 fronts of one history, lane = process slot (+ 64 per mask word)
 namespace {
-struct Cur { uint32_t inv, ret, op, f; int32_t a, b; };
+// The call a lane holds, with what the walk asks of it at every front worked out once, when the cursor moves:
+// cls bit 0 = a call at all, 1 = live (completes), 2 = crashed and a candidate (not a nil read), 3 = write / cas, 4 = read
+struct Cur { uint32_t inv, ret, op, f; int32_t a, b; uint32_t cls, prod; };
 __device__ __forceinline__ Cur load_cur(const Rec* r) {
   const Rec x = *r;
-  return Cur{x.inv_rank, x.ret_rank, x.opidx, x.f, x.a, x.b};
+  const bool any = x.f != kFNone, crashed = x.ret_rank == kInf;
+  const uint32_t cls = (any ? 1u : 0u) | (any && !crashed ? 2u : 0u) | (any && crashed && !(x.f == TBC_F_READ && x.a == TBC_NIL) ? 4u : 0u) |
+                       ((x.f == TBC_F_WRITE || x.f == TBC_F_CAS) ? 8u : 0u) | (x.f == TBC_F_READ ? 16u : 0u);
+  return Cur{x.inv_rank, x.ret_rank, x.opidx, x.f, x.a, x.b, cls, look_prod(x.f, x.a, x.b)};
 }
 }  // namespace
 
@@ -225,7 +230,7 @@ __global__ __launch_bounds__(256) void open_walk_kernel(PackOpenArgs A) {
 #pragma unroll
   for (int j = 0; j < MW; j++) {
     const uint32_t p = lane + 64u * (uint32_t)j;
-    cur[j] = Cur{kInf, kInf, kInf, kFNone, 0, 0}; nxt[j] = cur[j]; at[j] = 0; tail[j] = 0;
+    cur[j] = Cur{kInf, kInf, kInf, kFNone, 0, 0, 0u, kLookNone}; nxt[j] = cur[j]; at[j] = 0; tail[j] = 0;
     if (p < W) {
       uint32_t lo = seg[p] + 1u, hi = seg[p + 1] - 1u;     // [lo, hi): the slot's calls; hi = its tail sentinel
       tail[j] = hi;
@@ -249,9 +254,9 @@ __global__ __launch_bounds__(256) void open_walk_kernel(PackOpenArgs A) {
     uint64_t occ[MW];
 #pragma unroll
     for (int j = 0; j < MW; j++) {
-      const bool here = cur[j].f != kFNone && cur[j].inv <= F;
-      live[j] = here && cur[j].ret != kInf;
-      crashed_open[j] = here && cur[j].ret == kInf && !(cur[j].f == TBC_F_READ && cur[j].a == TBC_NIL);
+      const bool here = cur[j].inv <= F;            // (a lane without a call holds inv = kInf)
+      live[j] = here && (cur[j].cls & 2u);
+      crashed_open[j] = here && (cur[j].cls & 4u);
       occ[j] = __ballot(live[j]);
     }
     // the front's list, in slot order
@@ -273,7 +278,7 @@ __global__ __launch_bounds__(256) void open_walk_kernel(PackOpenArgs A) {
       uint32_t ncw = 0;
 #pragma unroll
       for (int j = 0; j < MW; j++) {
-        cw[j] = __ballot(live[j] && (cur[j].f == TBC_F_WRITE || cur[j].f == TBC_F_CAS));
+        cw[j] = __ballot(live[j] && (cur[j].cls & 8u));
         ncw += (uint32_t)__popcll(cw[j]);
 #pragma unroll
         for (int w = 0; w < MW; w++) tw[j][w] = 0ull;
@@ -310,7 +315,7 @@ __global__ __launch_bounds__(256) void open_walk_kernel(PackOpenArgs A) {
       for (int j = 0; j < MW; j++) mine[j] = 0ull;
 #pragma unroll
       for (int j = 0; j < MW; j++) {
-        uint64_t rd = __ballot(live[j] && cur[j].f == TBC_F_READ);
+        uint64_t rd = __ballot(live[j] && (cur[j].cls & 16u));
         while (rd) {
           const uint32_t l = (uint32_t)__builtin_ctzll(rd);
           rd &= rd - 1ull;
@@ -339,7 +344,7 @@ __global__ __launch_bounds__(256) void open_walk_kernel(PackOpenArgs A) {
 #pragma unroll
       for (int j = 0; j < MW; j++) {
         const bool other = (live[j] || crashed_open[j]) && !(jx == (uint32_t)j && lane == lx);
-        const uint64_t pm = need == kLookNone ? 0ull : __ballot(other && look_prod(cur[j].f, cur[j].a, cur[j].b) == need);
+        const uint64_t pm = need == kLookNone ? 0ull : __ballot(other && cur[j].prod == need);
         if (lane == 0) look[(uint64_t)F * LW + 1 + j] = pm;
       }
       if (lane == 0) { look[(uint64_t)F * LW] = w0; tmp[F] = 255u; }

@@ -1,6 +1,6 @@
 """Quick throughput probe: B valid 10k-op/64-proc cas-register histories, batch mode."""
-import sys, time
-sys.path.insert(0, ".")
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import jepsen_tigerbeetle_amd
 from jepsen_tigerbeetle_amd import _native as N, columns, core, synth
