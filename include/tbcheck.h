@@ -398,6 +398,48 @@ tbc_status tbc_memo_build(int64_t init_state, uint32_t n_classes,
                           int64_t* state_handles /* max_states */,
                           uint32_t* n_states);
 
+/* ------------------------------------------------------- checker/set-full
+ *
+ * jepsen.checker/set-full -- the checker the reference actually runs for its set-full workload
+ * (/root/reference/src/tigerbeetle/workloads/set_full.clj:157, `(checker/set-full {:linearizable? true})`;
+ * SURVEY.md section 8f row 3).  Per element of the set three history indices decide everything
+ * (recalled from jepsen.checker; restated in oracle/set_full.py):
+ *   known         first op that proved the element exists: its add's :ok, or the :ok of a read containing it
+ *   last_present  invocation of the latest-invoked :ok read that contained it
+ *   last_absent   invocation of the latest-invoked :ok read that did not
+ * (only reads completing after the element's add was invoked count).  The device part is the scan of the
+ * reads x elements membership matrix that yields those three per element -- a streaming pass, the one
+ * kernel on this path with a real HBM roofline; outcomes (:stable / :lost / :never-read, latencies,
+ * :valid?) are a few operations per element on the host (jepsen-tigerbeetle_amd/jepsen/set_full.py).
+ *
+ * Inputs (caller-owned): elements numbered in order of their first :add invocation (add_invoke ascending),
+ * reads = the :ok reads in order of invocation (read_invoke ascending); present = n_reads rows of
+ * words_per_row 32-bit words, bit e of row r = read r's value contains element e.
+ */
+typedef struct tbc_setfull_in {
+  uint32_t n_elements, n_reads, words_per_row, device;
+  const uint32_t* add_invoke;    /* [n_elements] history index of the element's :add invocation  */
+  const uint32_t* add_ok;        /* [n_elements] index of that add's :ok, TBC_NO_OP if none      */
+  const uint32_t* read_invoke;   /* [n_reads]                                                    */
+  const uint32_t* read_ok;       /* [n_reads]                                                    */
+  const uint32_t* present;       /* [n_reads * words_per_row]                                    */
+} tbc_setfull_in;
+
+typedef struct tbc_setfull_out {   /* arrays caller-allocated, n_elements each; TBC_NO_OP = none */
+  uint32_t* known;
+  uint32_t* last_present;
+  uint32_t* last_absent;
+  uint64_t ns_scan;              /* device time of the scan kernel (HIP events)                  */
+  uint64_t bytes_scanned;        /* matrix bytes the scan loaded                                 */
+  uint64_t bytes_matrix;         /* n_reads * words_per_row * 4                                  */
+} tbc_setfull_out;
+
+typedef struct tbc_setfull tbc_setfull;
+/* inputs become resident in HBM (H2D here); run scans them; results copied into `out` */
+tbc_status tbc_setfull_create(const tbc_setfull_in* in, tbc_setfull** handle);
+tbc_status tbc_setfull_run(tbc_setfull* handle, tbc_setfull_out* out);
+void tbc_setfull_destroy(tbc_setfull* handle);
+
 /* ------------------------------------------------------------------- misc */
 uint32_t tbc_version(void);             /* TBC_ABI_VERSION                       */
 const char* tbc_strerror(int status);

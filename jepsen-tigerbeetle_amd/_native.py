@@ -121,6 +121,17 @@ class SweepVerdict(C.Structure):
 SWEEP_SLICES = 4
 
 
+class SetFullIn(C.Structure):
+    _fields_ = [("n_elements", C.c_uint32), ("n_reads", C.c_uint32), ("words_per_row", C.c_uint32), ("device", C.c_uint32),
+                ("add_invoke", C.POINTER(C.c_uint32)), ("add_ok", C.POINTER(C.c_uint32)), ("read_invoke", C.POINTER(C.c_uint32)),
+                ("read_ok", C.POINTER(C.c_uint32)), ("present", C.POINTER(C.c_uint32))]
+
+
+class SetFullOut(C.Structure):
+    _fields_ = [("known", C.POINTER(C.c_uint32)), ("last_present", C.POINTER(C.c_uint32)), ("last_absent", C.POINTER(C.c_uint32)),
+                ("ns_scan", C.c_uint64), ("bytes_scanned", C.c_uint64), ("bytes_matrix", C.c_uint64)]
+
+
 class SynthParams(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("n_ops", C.c_uint32), ("n_procs", C.c_uint32), ("n_values", C.c_uint32),
                 ("busy_permille", C.c_uint32), ("info_permille", C.c_uint32), ("read_permille", C.c_uint32),
@@ -147,6 +158,9 @@ SYMBOLS = {
     "tbc_batch_sweep_partial": (C.c_int, [C.c_void_p]),
     "tbc_batch_sweep_table": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
     "tbc_batch_sweep_finish": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Result)]),
+    "tbc_setfull_create": (C.c_int, [C.POINTER(SetFullIn), C.POINTER(C.c_void_p)]),
+    "tbc_setfull_run": (C.c_int, [C.c_void_p, C.POINTER(SetFullOut)]),
+    "tbc_setfull_destroy": (None, [C.c_void_p]),
     "tbc_batch_destroy": (None, [C.c_void_p]),
     "tbc_memo_build": (C.c_int, [C.c_int64, C.c_uint32, STEP_FN, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint16),
                                  C.POINTER(C.c_int64), C.POINTER(C.c_uint32)]),

@@ -49,6 +49,23 @@ def linearizable(opts):
     return Linearizable(opts)
 
 
+class SetFull(Checker):
+    """(checker/set-full {:linearizable? bool}) -- per-element timing analysis of a grow-only set; the scan of the
+    reads x elements matrix runs on the GPU (jepsen/set_full.py, csrc/set_full.hip).  The reference's own use:
+    workloads/set_full.clj:157."""
+
+    def __init__(self, opts=None):
+        self.linearizable = bool((opts or {}).get("linearizable?", False))
+
+    def check(self, test, history, opts=None):
+        from . import set_full as sf
+        return sf.check(history, self.linearizable, device=(opts or {}).get("device", 0))
+
+
+def set_full(opts=None):
+    return SetFull(opts)
+
+
 class Compose(Checker):
     def __init__(self, checkers):
         self.checkers = dict(checkers)

@@ -1,0 +1,160 @@
+"""jepsen.checker/set-full on the MI355X -- the checker the reference runs for its set-full workload
+(/root/reference/src/tigerbeetle/workloads/set_full.clj:155-158:
+`(independent/checker (checker/compose {:set-full (checker/set-full {:linearizable? true}) ...}))`).
+
+Host side: flatten the history into the reads x elements membership matrix and four index columns, call
+`tbc_setfull_*` (csrc/set_full.hip scans the matrix for known / last-present / last-absent per element), turn the
+three indices into jepsen's result map (:valid? :attempt-count :stable-count :lost :never-read :stale :worst-stale
+...).  The semantics are recalled from jepsen.checker (jepsen is not in /root/reference and cannot run here) and
+restated independently in oracle/set_full.py, which the tests compare with.  No CPU fallback: without a GPU
+`check` raises NoDeviceError."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from .. import _native as N
+from ..columns import _p
+from ..knossos import history as H
+
+NONE = 0xFFFFFFFF
+
+
+class Encoded:
+    """reads x elements bit matrix + index columns of one history (one key)."""
+
+    def __init__(self, history):
+        hist = [op for op in H.index(list(history)) if H.client_op(op)]
+        self.times = {op["index"]: op.get("time", op["index"]) for op in hist}
+        elems, order = {}, []
+        add_ok, reads, open_reads = {}, [], {}
+        for op in hist:
+            i = op["index"]
+            if op["f"] == "add":
+                v = _freeze(op["value"])
+                if op["type"] == "invoke":
+                    if v not in elems:
+                        elems[v] = (len(order), i)
+                        order.append(op["value"])
+                elif op["type"] == "ok" and v in elems and v not in add_ok:
+                    add_ok[v] = i
+            elif op["f"] == "read":
+                if op["type"] == "invoke":
+                    open_reads[op["process"]] = i
+                elif op["type"] == "ok":
+                    inv = open_reads.pop(op["process"], None)
+                    if inv is not None and op.get("value") is not None:
+                        reads.append((inv, i, op["value"]))
+        reads.sort(key=lambda r: r[0])
+        self.elements = order
+        E, R = len(order), len(reads)
+        self.E, self.R = E, R
+        self.wpr = max(1, (E + 31) // 32)
+        self.add_invoke = np.array([elems[_freeze(v)][1] for v in order], np.uint32)
+        self.add_ok = np.array([add_ok.get(_freeze(v), NONE) for v in order], np.uint32)
+        self.read_invoke = np.array([r[0] for r in reads], np.uint32)
+        self.read_ok = np.array([r[1] for r in reads], np.uint32)
+        bits = np.zeros((max(R, 1), self.wpr * 32), bool)
+        ints = all(isinstance(v, int) and not isinstance(v, bool) for v in order)
+        if ints and E:
+            keys = np.array(order, np.int64)
+            srt = np.argsort(keys)
+            ks = keys[srt]
+        for r, (_, _, val) in enumerate(reads):
+            vals = list(val)
+            if not vals:
+                continue
+            if ints and E and all(isinstance(x, int) and not isinstance(x, bool) for x in vals):
+                arr = np.asarray(vals, np.int64)
+                pos = np.minimum(np.searchsorted(ks, arr), E - 1)
+                hit = ks[pos] == arr                       # values nobody added are not columns: jepsen ignores them here too
+                bits[r, srt[pos[hit]]] = True
+            else:
+                for x in vals:
+                    e = elems.get(_freeze(x))
+                    if e is not None:
+                        bits[r, e[0]] = True
+        self.present = np.ascontiguousarray(np.packbits(bits, axis=1, bitorder="little").view(np.uint32))
+
+
+def _freeze(v):
+    return tuple(v) if isinstance(v, list) else v
+
+
+class Scan:
+    """tbc_setfull_*: the matrix resident in HBM, `run()` scans it."""
+
+    def __init__(self, enc_or_arrays, device=0):
+        a = enc_or_arrays
+        self._keep = a
+        s = N.SetFullIn()
+        s.n_elements, s.n_reads, s.words_per_row, s.device = a.E, a.R, a.wpr, device
+        s.add_invoke, s.add_ok = _p(a.add_invoke, C.c_uint32), _p(a.add_ok, C.c_uint32)
+        s.read_invoke, s.read_ok = _p(a.read_invoke, C.c_uint32), _p(a.read_ok, C.c_uint32)
+        s.present = _p(a.present, C.c_uint32)
+        self.E = a.E
+        self._h = C.c_void_p()
+        N.check_status(N.lib().tbc_setfull_create(C.byref(s), C.byref(self._h)))
+
+    def run(self):
+        n = max(1, self.E)
+        known, lp, la = np.zeros(n, np.uint32), np.zeros(n, np.uint32), np.zeros(n, np.uint32)
+        o = N.SetFullOut()
+        o.known, o.last_present, o.last_absent = _p(known, C.c_uint32), _p(lp, C.c_uint32), _p(la, C.c_uint32)
+        N.check_status(N.lib().tbc_setfull_run(self._h, C.byref(o)))
+        return {"known": known[:self.E], "last_present": lp[:self.E], "last_absent": la[:self.E],
+                "ns_scan": o.ns_scan, "bytes_scanned": o.bytes_scanned, "bytes_matrix": o.bytes_matrix}
+
+    def close(self):
+        if self._h:
+            N.lib().tbc_setfull_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
+def result_map(enc: Encoded, st: dict, linearizable: bool):
+    """jepsen.checker/set-full's result from the three indices per element (vectorised: a few operations each)."""
+    k = st["known"].astype(np.int64)
+    lp = np.where(st["last_present"] == NONE, -1, st["last_present"].astype(np.int64))
+    la = np.where(st["last_absent"] == NONE, -1, st["last_absent"].astype(np.int64))
+    known = st["known"] != NONE
+    stable = (lp >= 0) & (la < lp)
+    lost = known & (la >= 0) & (lp < la) & (k < la)
+    never = ~(stable | lost)
+    t = enc.times
+    tk = np.array([t[int(x)] if kn else 0 for x, kn in zip(k, known)], np.int64)
+    t_la = np.array([t[int(x)] + 1 if x >= 0 else 0 for x in la], np.int64)
+    t_lp = np.array([t[int(x)] + 1 if x >= 0 else 0 for x in lp], np.int64)
+    stable_lat = np.maximum(0, t_la - tk)
+    lost_lat = np.maximum(0, t_lp - tk)
+    el = enc.elements
+    idx = lambda m: [el[i] for i in np.nonzero(m)[0]]
+    stale = stable & (stable_lat > 0)
+    worst = sorted(np.nonzero(stale)[0], key=lambda i: -int(stable_lat[i]))[:8]
+    valid = False if lost.any() else ("unknown" if not stable.any() else (False if (linearizable and stale.any()) else True))
+    return {"valid?": valid, "attempt-count": enc.E, "stable-count": int(stable.sum()), "lost-count": int(lost.sum()),
+            "lost": _sorted(idx(lost)), "never-read-count": int(never.sum()), "never-read": _sorted(idx(never)),
+            "stale-count": int(stale.sum()), "stale": _sorted(idx(stale)),
+            "worst-stale": [{"element": el[i], "outcome": "stable", "stable-latency": int(stable_lat[i]), "lost-latency": None,
+                             "known": int(k[i]), "last-absent": int(la[i]) if la[i] >= 0 else None} for i in worst],
+            "lost-latencies": sorted(int(x) for x in lost_lat[lost]), "stable-latencies": sorted(int(x) for x in stable_lat[stable])}
+
+
+def _sorted(xs):
+    try:
+        return sorted(xs)
+    except TypeError:
+        return xs
+
+
+def check(history, linearizable=False, device=0):
+    enc = Encoded(history)
+    with Scan(enc, device) as s:
+        st = s.run()
+    return result_map(enc, st, linearizable)
