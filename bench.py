@@ -73,6 +73,7 @@ def main():
     ap.add_argument("--busy2", type=float, default=0.5, help="second workload: duty cycle of the '64 concurrent processes' reading (0 = skip)")
     ap.add_argument("--batch2", type=int, default=2048, help="second workload: histories per GPU")
     ap.add_argument("--no-tiers", action="store_true", help="skip the crashed-op tiers (extra.tiers)")
+    ap.add_argument("--no-set-full", action="store_true", help="skip the checker/set-full scan (extra.set_full)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--sharded-ttv", action="store_true",
                     help="N > 1 only: also time ONE history swept by all N GPUs (shard.check_sharded: wavefronts dealt to the ranks, "
@@ -87,6 +88,7 @@ def main():
             raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
         args.gpus = world
 
+    import numpy as np
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
@@ -311,6 +313,41 @@ def main():
                              "frac": round(alg2 / (k2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 6), "traffic": None, "kernel": "wgl_beam_kernel",
                              "kernel_ms": round(k2, 3), "probes_per_launch": c2["probes"], "new_configs_per_launch": c2["visited"]},
                 "device_ms": {k: round(x / 1e6, 3) for k, x in tm2.items()}}
+        if world == 1 and not args.no_set_full:
+            # checker/set-full (the checker the reference runs: set_full.clj:157): the reads x elements membership scan,
+            # the one streaming kernel of the path.  Synthetic: 262,144 elements x 32,768 reads (1 GB of bits), an element
+            # is visible from about its acknowledgement on, 300 elements vanish in the last quarter (lost), sparse holes
+            # right after the add (stale reads).  roofline = matrix bytes the scan loaded / its time, against 8 TB/s.
+            from jepsen_tigerbeetle_amd.jepsen import set_full as sf
+            rng = np.random.default_rng(7)
+            E, R = 262144, 32768
+            add_invoke = (np.sort(rng.choice(4 * (E + R), E, replace=False)) * 2).astype(np.uint32)
+            read_invoke = (np.sort(rng.choice(4 * (E + R), R, replace=False)) * 2 + 1).astype(np.uint32)
+            read_ok = read_invoke + (rng.integers(1, 2000, R) * 2).astype(np.uint32)
+            add_ok = (add_invoke + 2001).astype(np.uint32)
+            p = np.searchsorted(add_ok, read_invoke).astype(np.int64)            # row r sees the elements acknowledged before it began
+            w = np.arange(E // 32, dtype=np.int64)
+            M = np.where(32 * (w + 1)[None, :] <= p[:, None], 0xFFFFFFFF,
+                         np.where(32 * w[None, :] >= p[:, None], 0, (1 << np.clip(p[:, None] - 32 * w[None, :], 0, 31)) - 1)).astype(np.uint32)
+            for e in rng.choice(E // 2, 300, replace=False):
+                M[R * 3 // 4:, e // 32] &= np.uint32(~(1 << (e % 32)) & 0xFFFFFFFF)
+            holes_r = rng.integers(0, R, 200000); holes_e = np.clip(p[holes_r] - rng.integers(1, 2000, 200000), 0, E - 1)
+            np.bitwise_and.at(M, (holes_r, holes_e // 32), (~(np.uint32(1) << (holes_e % 32).astype(np.uint32))).astype(np.uint32))
+
+            class A:
+                pass
+            a = A(); a.E, a.R, a.wpr = E, R, E // 32
+            a.add_invoke, a.add_ok, a.read_invoke, a.read_ok, a.present = add_invoke, add_ok, read_invoke, read_ok, np.ascontiguousarray(M)
+            with sf.Scan(a, device=local_rank) as sc:
+                sc.run()
+                runs = [sc.run() for _ in range(5)]
+            ms = statistics.mean(r["ns_scan"] for r in runs) / 1e6
+            lost = int(((runs[0]["last_present"].astype(np.int64) < runs[0]["last_absent"].astype(np.int64)) & (runs[0]["last_absent"] != N.NO_OP)).sum())
+            gbs = runs[0]["bytes_scanned"] / (ms * 1e-3) / 1e9
+            line["extra"]["set_full"] = {"elements": E, "reads": R, "matrix_GB": round(runs[0]["bytes_matrix"] / 1e9, 3),
+                                         "scan_ms": round(ms, 3), "bytes_scanned": int(runs[0]["bytes_scanned"]), "lost_elements_found": lost,
+                                         "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                      "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "setfull_scan_kernel"}}
         print(json.dumps(line), flush=True)
     batch.close()
     if world > 1:
