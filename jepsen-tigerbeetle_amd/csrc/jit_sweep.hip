@@ -136,7 +136,7 @@ __device__ __forceinline__ uint64_t mask_of(const Ent& e) { return (uint64_t)e.m
 
 // LDS words per wavefront: 3 sets, 2 tables, stage, open-call records + twin masks, 2 read-mask rows, expansion list, relation
 template <uint32_t CAP>
-constexpr uint32_t sweep_lds_words() { return 3 * CAP * 4 + 2 * (2 * CAP) + 64 * 4 + kCand * 4 + kCand * 2 + 2 * 32 * 2 + CAP / 2 + 128; }
+constexpr uint32_t sweep_lds_words() { return 3 * CAP * 4 + 2 * (2 * CAP) + 64 * 4 + kCand * 4 + kCand * 2 + 2 * 32 * 2 + CAP / 2 + 128 + 128 * 4 + 128; }
 
 }  // namespace
 
@@ -218,6 +218,8 @@ __global__ __launch_bounds__(64) void jit_sweep_kernel(SweepArgs A) {
   uint64_t* row_b = row_a + 32;               // ... of the next front
   uint16_t* expl = reinterpret_cast<uint16_t*>(row_b + 32);   // entries of `cur` that still need X
   uint32_t* Mrel = reinterpret_cast<uint32_t*>(expl + CAP);   // 32 x 4 words: origin -> origin ids of the next segment
+  Ent* wq = reinterpret_cast<Ent*>(Mrel + 128);               // ring of 128 children waiting for a full insert round (bursts)
+  uint32_t* wq_sel = reinterpret_cast<uint32_t*>(wq + 128);
   for (uint32_t i = lane; i < 2 * HS; i += 64) tab_nxt[i] = 0u;
   Mrel[lane] = 0u; Mrel[64 + lane] = 0u;
   lds_sync();
@@ -379,6 +381,11 @@ __global__ __launch_bounds__(64) void jit_sweep_kernel(SweepArgs A) {
       subrounds++;
       build_begin<HS>(q, dst_e, tab_q, gen_q, lane);
       const uint32_t total = n_src << gshift;
+      // A burst of concurrency makes sub-rounds of thousands of pairs of which a third yield a child.  The insertion
+      // (staging, probe loop, commit: three LDS synchronisations) is the expensive half of a round, so a long sub-round
+      // is pipelined: children are compacted into a ring and inserted 64 at a time; a short one inserts directly.
+      const bool pipelined = total > 64u;
+      uint32_t qh = 0, qn = 0;
       for (uint32_t base = 0; base < total && status == kSegOk; base += 64) {
         const uint32_t r = base + lane, ci = r >> gshift, kc = r & ((1u << gshift) - 1u);
         const bool val = r < total && kc < C;
@@ -396,8 +403,32 @@ __global__ __launch_bounds__(64) void jit_sweep_kernel(SweepArgs A) {
         if (eager) m2 |= row_a[0] | row_a[rdm_index(st2, V)];
         const bool has = viable && (m2 & xbit) != 0ull;
         if (has) { m2 &= ~xbit; if (eager) m2 |= row_b[0] | row_b[rdm_index(st2, V)]; }
-        if (!build_insert2<CAP>(nxt, q, viable ? (has ? 1u : 2u) : 0u, (uint32_t)m2, (uint32_t)(m2 >> 32), (uint32_t)st2, e.org, stage, lane))
-          status = kSegOverflow;
+        const uint32_t sel = viable ? (has ? 1u : 2u) : 0u;
+        if (!pipelined) {
+          if (!build_insert2<CAP>(nxt, q, sel, (uint32_t)m2, (uint32_t)(m2 >> 32), (uint32_t)st2, e.org, stage, lane)) status = kSegOverflow;
+          continue;
+        }
+        const uint64_t vb = __ballot(viable);
+        if (viable) {
+          const uint32_t pos = (qh + qn + (uint32_t)__popcll(vb & ((1ull << lane) - 1ull))) & 127u;
+          wq[pos] = Ent{(uint32_t)m2, (uint32_t)(m2 >> 32), (uint32_t)st2, e.org};
+          wq_sel[pos] = sel;
+        }
+        qn += (uint32_t)__popcll(vb);
+        lds_sync();
+        while (qn >= 64u && status == kSegOk) {
+          const uint32_t at = (qh + lane) & 127u;
+          const Ent c = wq[at];
+          const uint32_t cs = wq_sel[at];
+          if (!build_insert2<CAP>(nxt, q, cs, c.mlo, c.mhi, c.st, c.org, stage, lane)) status = kSegOverflow;
+          qh = (qh + 64u) & 127u; qn -= 64u;
+        }
+      }
+      if (pipelined && qn && status == kSegOk) {        // what is left in the ring
+        const uint32_t at = (qh + lane) & 127u;
+        const Ent c = wq[at];
+        const uint32_t cs = lane < qn ? wq_sel[at] : 0u;
+        if (!build_insert2<CAP>(nxt, q, cs, c.mlo, c.mhi, c.st, c.org, stage, lane)) status = kSegOverflow;
       }
       src = q.e; n_src = q.n; via_list = false;
       { Ent* t = dst_e; dst_e = dst_other; dst_other = t; }

@@ -84,8 +84,11 @@ __global__ __launch_bounds__(256) void setfull_scan_kernel(const uint32_t* __res
       loaded++;
       uint32_t hits = word & valid;
       const uint32_t ok = read_ok[r];
-      if (hits & ~seen) until = max(until, ok);
-      seen |= hits;
+      // a bit seen before already holds a completion <= `until`: only a read that completed EARLIER can improve it
+      const uint32_t fresh = hits & ~seen;
+      if (ok >= until) hits = fresh;
+      if (fresh) until = max(until, ok);
+      seen |= fresh | hits;
       while (hits) { const uint32_t b = (uint32_t)__builtin_ctz(hits); hits &= hits - 1u; atomicMin(&known[32u * w + b], ok); }
     }
   }
