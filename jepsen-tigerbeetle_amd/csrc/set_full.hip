@@ -12,16 +12,19 @@
 // of 262,144 elements) and is read about half once.
 //
 // Layout: rows = reads in invocation order, words_per_row 32-bit words each; a wavefront's 64 lanes take 64
-// consecutive words of a row (256 B coalesced), a thread owns ONE word column (32 elements) of ONE chunk of
-// rows, grid = columns x chunks.  Bit-parallel: a thread walks its rows from the latest down keeping two
-// 32-bit "found" masks; a bit newly seen present (absent) fixes that element's last_present (last_absent)
-// for this chunk -- one atomicMax, the latest chunk wins -- and the walk stops when all 32 bits have both.
-// Elements are numbered by add invocation, so "reads completing after e's add was invoked" is a PREFIX of the
-// elements for each row (p[r], one binary search per row in setfull_prefix_kernel) and a chunk whose reads all
-// precede a column's adds is skipped without a load: the all-zero triangle below the diagonal is never read.
-// known: the same walk upwards; the first read (in invocation order) containing e need not be the first to
-// complete, so the walk keeps offering later rows' read_ok (atomicMin) while they were invoked before the
-// latest first-completion seen -- a window bounded by the number of concurrent readers.
+// consecutive words of a row (256 B coalesced).  Two passes, no atomics:
+//   setfull_any_kernel      grid = word columns x chunks of rows: a thread ORs "present" and "absent" over ONE word
+//                           column (32 elements) of ONE chunk, eight rows in flight, and stops when both words are
+//                           saturated -- the streaming pass, two coalesced words written per thread;
+//   setfull_resolve_kernel  one thread per word column: the chunk summaries say WHICH chunk holds each element's last
+//                           present / last absent / first present read; only those chunks are walked again, bit-parallel
+//                           (a 32-bit "still wanted" mask per direction), and the thread writes its own 32 results.
+// Elements are numbered by add invocation, so "reads completing after e's add was invoked" is a PREFIX of the elements
+// for each row (p[r], one binary search per row in setfull_prefix_kernel) and a chunk whose reads all precede a
+// column's adds is skipped without a load: the all-zero triangle below the diagonal is never read.
+// known: the first read (in invocation order) containing e need not be the first to complete, so the walk keeps
+// offering later rows' read_ok while they were invoked before the latest first-completion seen -- a window bounded by
+// the number of concurrent readers.
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstring>
@@ -33,6 +36,7 @@ using namespace tbc;
 namespace {
 
 constexpr uint32_t kNoneU = 0xFFFFFFFFu;
+constexpr uint32_t kSetFullRows = 2048;      // rows per chunk at most (their metadata is staged in LDS)
 
 __global__ __launch_bounds__(256) void setfull_prefix_kernel(const uint32_t* add_invoke, const uint32_t* read_ok, uint32_t E, uint32_t R,
                                                              uint32_t rows_per_chunk, uint32_t* P, uint32_t* pmax) {
@@ -49,50 +53,169 @@ __device__ __forceinline__ uint32_t prefix_mask(uint32_t p, uint32_t w) {       
   return p >= 32u * w + 32u ? 0xFFFFFFFFu : (p <= 32u * w ? 0u : (1u << (p - 32u * w)) - 1u);
 }
 
-__global__ __launch_bounds__(256) void setfull_scan_kernel(const uint32_t* __restrict__ M, const uint32_t* __restrict__ P,
-                                                           const uint32_t* __restrict__ pmax, const uint32_t* __restrict__ read_invoke,
-                                                           const uint32_t* __restrict__ read_ok, uint32_t E, uint32_t R, uint32_t WPR,
-                                                           uint32_t rows_per_chunk, uint32_t* lp1, uint32_t* la1, uint32_t* known,
-                                                           unsigned long long* words_loaded) {
+// ---- pass 1: per (word column, chunk of rows) -- is any bit of the column present / absent in the chunk?  The streaming
+// pass: eight rows requested at a time (whether to go on depends on what was loaded), the chunk's row metadata in LDS,
+// two coalesced words written per thread, no atomics.
+__global__ __launch_bounds__(256) void setfull_any_kernel(const uint32_t* __restrict__ M, const uint32_t* __restrict__ P,
+                                                          const uint32_t* __restrict__ pmax, uint32_t E, uint32_t R, uint32_t WPR,
+                                                          uint32_t rows_per_chunk, uint32_t* __restrict__ any_p, uint32_t* __restrict__ any_a,
+                                                          unsigned long long* words_loaded) {
   const uint32_t w = blockIdx.x * 256u + threadIdx.x, c = blockIdx.y;
   uint32_t loaded = 0;
-  if (w < WPR && pmax[c] > 32u * w) {
-    const uint32_t r0 = c * rows_per_chunk, r1 = min(r0 + rows_per_chunk, R);
-    const uint32_t full = E - 32u * w >= 32u ? 0xFFFFFFFFu : (1u << (E - 32u * w)) - 1u;
-    // ---- from the latest read down: last_present / last_absent (stored + 1, 0 = none; atomicMax over the chunks)
-    uint32_t found_p = 0, found_a = 0;
-    for (uint32_t r = r1; r-- > r0;) {
-      const uint32_t valid = prefix_mask(P[r], w) & full;
-      if (!valid) continue;
-      const uint32_t word = M[(uint64_t)r * WPR + w];
-      loaded++;
-      uint32_t np = word & valid & ~found_p, na = ~word & valid & ~found_a;
-      const uint32_t inv1 = read_invoke[r] + 1u;
-      found_p |= np; found_a |= na;
-      while (np) { const uint32_t b = (uint32_t)__builtin_ctz(np); np &= np - 1u; atomicMax(&lp1[32u * w + b], inv1); }
-      while (na) { const uint32_t b = (uint32_t)__builtin_ctz(na); na &= na - 1u; atomicMax(&la1[32u * w + b], inv1); }
-      if ((found_p & found_a) == full) break;
+  __shared__ uint32_t s_P[kSetFullRows];
+  const uint32_t r0 = min(c * rows_per_chunk, R), r1 = min(r0 + rows_per_chunk, R);     // (a trailing chunk may be empty)
+  for (uint32_t i = threadIdx.x; i < r1 - r0; i += 256u) s_P[i] = P[r0 + i];
+  __syncthreads();
+  if (w < WPR) {
+    uint32_t pa = 0, aa = 0;
+    if (pmax[c] > 32u * w) {
+      const uint32_t full = E - 32u * w >= 32u ? 0xFFFFFFFFu : (1u << (E - 32u * w)) - 1u;
+      for (uint32_t hi = r1; hi > r0 && (pa & aa) != full;) {
+        const uint32_t lo8 = hi - r0 >= 8u ? hi - 8u : r0;
+        uint32_t wd[8], vm[8];
+#pragma unroll
+        for (uint32_t q = 0; q < 8; q++) {
+          const uint32_t r = hi - 1u - q;
+          vm[q] = hi - lo8 > q ? prefix_mask(s_P[r - r0], w) & full : 0u;
+          wd[q] = vm[q] ? M[(uint64_t)r * WPR + w] : 0u;
+        }
+#pragma unroll
+        for (uint32_t q = 0; q < 8; q++) { pa |= wd[q] & vm[q]; aa |= ~wd[q] & vm[q]; loaded += vm[q] ? 1u : 0u; }
+        hi = lo8;
+      }
     }
-    // ---- from the earliest read up: known.  `until` = the latest completion among the reads that were first to
-    // contain some element: any read invoked before it may still complete earlier and must be offered too.
-    uint32_t seen = 0, until = 0;
-    for (uint32_t r = r0; r < r1; r++) {
-      if (seen == full && read_invoke[r] > until) break;
-      const uint32_t valid = prefix_mask(P[r], w) & full;
-      if (!valid) continue;
-      const uint32_t word = M[(uint64_t)r * WPR + w];
-      loaded++;
-      uint32_t hits = word & valid;
-      const uint32_t ok = read_ok[r];
-      // a bit seen before already holds a completion <= `until`: only a read that completed EARLIER can improve it
-      const uint32_t fresh = hits & ~seen;
-      if (ok >= until) hits = fresh;
-      if (fresh) until = max(until, ok);
-      seen |= fresh | hits;
-      while (hits) { const uint32_t b = (uint32_t)__builtin_ctz(hits); hits &= hits - 1u; atomicMin(&known[32u * w + b], ok); }
+    any_p[(uint64_t)c * WPR + w] = pa;
+    any_a[(uint64_t)c * WPR + w] = aa;
+  }
+  unsigned long long tot = loaded;
+  for (int d = 32; d >= 1; d >>= 1) tot += __shfl_xor(tot, d);
+  if ((threadIdx.x & 63u) == 0 && tot) atomicAdd(words_loaded, tot);
+}
+
+// ---- pass 2: one WAVEFRONT per word column resolves its 32 elements.  The chunk summaries say WHICH chunk holds an
+// element's last present / last absent / first present read: lanes hold the summaries of 64 chunks each, a ballot finds
+// the deciding chunk, and that chunk is walked again with lane = row (64 rows loaded at once, one ballot per wanted bit
+// finds the row).  No atomics, no serial chain of loads.  lp1 / la1 hold invocation index + 1 (0 = none).
+__device__ __forceinline__ uint32_t wave_min_u32_all(uint32_t v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, d));
+  return v;
+}
+
+// walk chunk c from its latest row down, lane = row: for every bit of `want` find the latest row where the bit is present
+// (present = true) or absent; store read_invoke + 1 there; returns the bits found
+__device__ __forceinline__ uint32_t setfull_last_in_chunk(const uint32_t* __restrict__ M, const uint32_t* __restrict__ P,
+                                                          const uint32_t* __restrict__ read_invoke, uint32_t WPR, uint32_t w, uint32_t full,
+                                                          uint32_t r0, uint32_t r1, uint32_t want, bool present, uint32_t* out1, uint32_t lane,
+                                                          uint32_t& loaded) {
+  uint32_t found = 0;
+  for (uint32_t hi = r1; hi > r0 && (want & ~found); hi = hi - r0 > 64u ? hi - 64u : r0) {
+    const uint32_t base = hi - r0 > 64u ? hi - 64u : r0;       // rows [base, hi), lane l = row base + l
+    const uint32_t r = base + lane;
+    const bool in = r < hi;
+    const uint32_t valid = in ? prefix_mask(P[r], w) & full : 0u;
+    const uint32_t word = valid ? M[(uint64_t)r * WPR + w] : 0u;
+    const uint32_t inv1 = in ? read_invoke[r] + 1u : 0u;
+    loaded += valid ? 1u : 0u;
+    const uint32_t x = (present ? word : ~word) & valid;
+    uint32_t todo = want & ~found;
+    while (todo) {
+      const uint32_t b = (uint32_t)__builtin_ctz(todo);
+      todo &= todo - 1u;
+      const uint64_t bal = __ballot((x >> b) & 1u);
+      if (bal) {
+        const uint32_t l = 63u - (uint32_t)__builtin_clzll(bal);
+        const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)inv1, l);
+        if (lane == 0) out1[32u * w + b] = v;
+        found |= 1u << b;
+      }
     }
   }
-  // words loaded, one atomic per wavefront
+  return found;
+}
+
+__global__ __launch_bounds__(256) void setfull_resolve_kernel(const uint32_t* __restrict__ M, const uint32_t* __restrict__ P,
+                                                              const uint32_t* __restrict__ read_invoke, const uint32_t* __restrict__ read_ok,
+                                                              const uint32_t* __restrict__ any_p, const uint32_t* __restrict__ any_a,
+                                                              uint32_t E, uint32_t R, uint32_t WPR, uint32_t rows_per_chunk, uint32_t chunks,
+                                                              uint32_t* lp1, uint32_t* la1, uint32_t* known, unsigned long long* words_loaded) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t w = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
+  uint32_t loaded = 0;
+  if (w < WPR) {
+    const uint32_t full = E - 32u * w >= 32u ? 0xFFFFFFFFu : (1u << (E - 32u * w)) - 1u;
+    // the summaries of up to 256 chunks: lane l holds chunks l, l + 64, l + 128, l + 192
+    uint32_t ap[4], aa[4];
+#pragma unroll
+    for (uint32_t g = 0; g < 4; g++) {
+      const uint32_t c = lane + 64u * g;
+      ap[g] = c < chunks ? any_p[(uint64_t)c * WPR + w] : 0u;
+      aa[g] = c < chunks ? any_a[(uint64_t)c * WPR + w] : 0u;
+    }
+    // last present / last absent: the latest chunk that has the bit decides; inside it, the latest row
+#pragma unroll
+    for (int pass = 0; pass < 2; pass++) {
+      uint32_t need = full;
+#pragma unroll
+      for (int g = 3; g >= 0 && need; g--) {
+        const uint32_t mine = pass == 0 ? ap[g] : aa[g];
+        uint64_t cand = __ballot((mine & need) != 0u);
+        while (cand && need) {
+          const uint32_t l = 63u - (uint32_t)__builtin_clzll(cand);
+          const uint32_t c = l + 64u * (uint32_t)g;
+          const uint32_t mc = (uint32_t)__builtin_amdgcn_readlane((int)mine, l) & need;
+          const uint32_t r0 = min(c * rows_per_chunk, R), r1 = min(r0 + rows_per_chunk, R);
+          (void)setfull_last_in_chunk(M, P, read_invoke, WPR, w, full, r0, r1, mc, pass == 0, pass == 0 ? lp1 : la1, lane, loaded);
+          need &= ~mc;
+          cand = __ballot((mine & need) != 0u) & ((1ull << l) - 1ull);
+        }
+      }
+    }
+    // known: min read_ok over the reads containing the element.  The earliest chunk that has the bit holds its first
+    // containing read (in invocation order); a read invoked before that one completed may still complete earlier, so the
+    // walk goes on, 64 rows at a time, while rows were invoked before `until` (the latest first completion seen).
+    uint32_t ever = 0;
+#pragma unroll
+    for (uint32_t g = 0; g < 4; g++) {
+      uint32_t o = ap[g];
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) o |= (uint32_t)__shfl_xor((int)o, d);
+      ever |= o;
+    }
+    ever &= full;
+    if (ever) {
+      uint32_t first_c = chunks;
+#pragma unroll
+      for (int g = 3; g >= 0; g--) { const uint64_t bl = __ballot((ap[g] & ever) != 0u); if (bl) first_c = (uint32_t)__builtin_ctzll(bl) + 64u * (uint32_t)g; }
+      uint32_t seen = 0, until = 0;
+      uint32_t best = 0xFFFFFFFFu;                              // lane b < 32 keeps element b's minimum
+      for (uint32_t base = first_c * rows_per_chunk; base < R; base += 64u) {
+        const uint32_t r = base + lane;
+        const bool in = r < R;
+        const uint32_t inv = in ? read_invoke[r] : 0xFFFFFFFFu;
+        const uint32_t inv_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)inv);
+        if (seen == ever && inv_first > until) break;
+        const uint32_t valid = in ? prefix_mask(P[r], w) & full : 0u;
+        const uint32_t word = valid ? M[(uint64_t)r * WPR + w] : 0u;
+        const uint32_t ok = in ? read_ok[r] : 0xFFFFFFFFu;
+        loaded += valid ? 1u : 0u;
+        const uint32_t hits = word & valid;
+        uint32_t any_hits = hits;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) any_hits |= (uint32_t)__shfl_xor((int)any_hits, d);
+        uint32_t todo = any_hits;
+        while (todo) {
+          const uint32_t b = (uint32_t)__builtin_ctz(todo);
+          todo &= todo - 1u;
+          const uint32_t m = wave_min_u32_all(((hits >> b) & 1u) ? ok : 0xFFFFFFFFu);
+          if (lane == b) best = min(best, m);
+          if (!((seen >> b) & 1u)) until = max(until, m);      // (the first batch's minimum bounds the first containing read's completion)
+        }
+        seen |= any_hits;
+      }
+      if (lane < 32u && ((ever >> lane) & 1u)) known[32u * w + lane] = min(known[32u * w + lane], best);
+    }
+  }
   unsigned long long tot = loaded;
   for (int d = 32; d >= 1; d >>= 1) tot += __shfl_xor(tot, d);
   if ((threadIdx.x & 63u) == 0 && tot) atomicAdd(words_loaded, tot);
@@ -121,13 +244,13 @@ struct tbc_setfull {
   int device = 0;
   uint32_t E = 0, R = 0, WPR = 0, chunks = 1, rows_per_chunk = 1;
   uint32_t *d_add_invoke = nullptr, *d_add_ok = nullptr, *d_read_invoke = nullptr, *d_read_ok = nullptr, *d_M = nullptr;
-  uint32_t *d_P = nullptr, *d_pmax = nullptr, *d_lp = nullptr, *d_la = nullptr, *d_known = nullptr;
+  uint32_t *d_P = nullptr, *d_pmax = nullptr, *d_lp = nullptr, *d_la = nullptr, *d_known = nullptr, *d_anyp = nullptr, *d_anya = nullptr;
   unsigned long long* d_words = nullptr;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   ~tbc_setfull() {
     for (void* p : {(void*)d_add_invoke, (void*)d_add_ok, (void*)d_read_invoke, (void*)d_read_ok, (void*)d_M, (void*)d_P, (void*)d_pmax,
-                    (void*)d_lp, (void*)d_la, (void*)d_known, (void*)d_words}) if (p) (void)hipFree(p);
+                    (void*)d_lp, (void*)d_la, (void*)d_known, (void*)d_anyp, (void*)d_anya, (void*)d_words}) if (p) (void)hipFree(p);
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
     if (stream) (void)hipStreamDestroy(stream);
@@ -150,8 +273,9 @@ static tbc_status setfull_create_impl(const tbc_setfull_in* in, tbc_setfull* S) 
   SF_TRY(hipSetDevice(S->device));
   // enough chunks to fill the GPU with wavefronts that each stream a good stretch of rows
   const uint32_t col_blocks = (S->WPR + 255) / 256;
-  uint32_t chunks = std::max(1u, std::min(256u, 4096u / std::max(1u, col_blocks)));
+  uint32_t chunks = std::max(1u, std::min(256u, 8192u / std::max(1u, col_blocks)));     // short chunks: what pass 2 walks again is one chunk
   while (chunks > 1 && S->R / chunks < 64) chunks >>= 1;
+  while ((S->R + chunks - 1) / chunks > kSetFullRows) chunks <<= 1;
   S->chunks = chunks; S->rows_per_chunk = std::max(1u, (S->R + chunks - 1) / chunks);
   const size_t e4 = (size_t)std::max(1u, S->E) * 4, r4 = (size_t)std::max(1u, S->R) * 4, m4 = std::max<size_t>(4, (size_t)S->R * S->WPR * 4);
   SF_TRY(hipMalloc((void**)&S->d_add_invoke, e4)); SF_TRY(hipMalloc((void**)&S->d_add_ok, e4));
@@ -160,6 +284,7 @@ static tbc_status setfull_create_impl(const tbc_setfull_in* in, tbc_setfull* S) 
   const size_t ew = (size_t)std::max(1u, S->WPR) * 32 * 4;       // per-element outputs padded to whole words
   SF_TRY(hipMalloc((void**)&S->d_lp, ew)); SF_TRY(hipMalloc((void**)&S->d_la, ew)); SF_TRY(hipMalloc((void**)&S->d_known, ew));
   SF_TRY(hipMalloc((void**)&S->d_words, 8));
+  SF_TRY(hipMalloc((void**)&S->d_anyp, (size_t)S->chunks * std::max(1u, S->WPR) * 4)); SF_TRY(hipMalloc((void**)&S->d_anya, (size_t)S->chunks * std::max(1u, S->WPR) * 4));
   SF_TRY(hipStreamCreateWithFlags(&S->stream, hipStreamNonBlocking));
   SF_TRY(hipEventCreate(&S->ev0)); SF_TRY(hipEventCreate(&S->ev1));
   if (S->E) {
@@ -171,6 +296,12 @@ static tbc_status setfull_create_impl(const tbc_setfull_in* in, tbc_setfull* S) 
     SF_TRY(hipMemcpyAsync(S->d_read_ok, in->read_ok, (size_t)S->R * 4, hipMemcpyHostToDevice, S->stream));
     SF_TRY(hipMemcpyAsync(S->d_M, in->present, (size_t)S->R * S->WPR * 4, hipMemcpyHostToDevice, S->stream));
   }
+  // p[r] (how many elements had been invoked when read r completed) and the chunks' maxima depend on the inputs only
+  SF_TRY(hipMemsetAsync(S->d_pmax, 0, (size_t)S->chunks * 4, S->stream));
+  if (S->R && S->E)
+    hipLaunchKernelGGL(setfull_prefix_kernel, dim3((S->R + 255) / 256), dim3(256), 0, S->stream, S->d_add_invoke, S->d_read_ok, S->E, S->R,
+                       S->rows_per_chunk, S->d_P, S->d_pmax);
+  SF_TRY(hipGetLastError());
   SF_TRY(hipStreamSynchronize(S->stream));
   return TBC_OK;
 }
@@ -198,13 +329,13 @@ tbc_status tbc_setfull_run(tbc_setfull* S, tbc_setfull_out* out) {
   const size_t ew = (size_t)std::max(1u, S->WPR) * 32 * 4;
   SF_TRY(hipMemsetAsync(S->d_lp, 0, ew, s)); SF_TRY(hipMemsetAsync(S->d_la, 0, ew, s));
   SF_TRY(hipMemsetAsync(S->d_known, 0xFF, ew, s));
-  SF_TRY(hipMemsetAsync(S->d_pmax, 0, (size_t)S->chunks * 4, s)); SF_TRY(hipMemsetAsync(S->d_words, 0, 8, s));
+  SF_TRY(hipMemsetAsync(S->d_words, 0, 8, s));
   SF_TRY(hipEventRecord(S->ev0, s));
   if (S->R && S->E) {
-    hipLaunchKernelGGL(setfull_prefix_kernel, dim3((S->R + 255) / 256), dim3(256), 0, s, S->d_add_invoke, S->d_read_ok, S->E, S->R,
-                       S->rows_per_chunk, S->d_P, S->d_pmax);
-    hipLaunchKernelGGL(setfull_scan_kernel, dim3((S->WPR + 255) / 256, S->chunks), dim3(256), 0, s, S->d_M, S->d_P, S->d_pmax, S->d_read_invoke,
-                       S->d_read_ok, S->E, S->R, S->WPR, S->rows_per_chunk, S->d_lp, S->d_la, S->d_known, S->d_words);
+    hipLaunchKernelGGL(setfull_any_kernel, dim3((S->WPR + 255) / 256, S->chunks), dim3(256), 0, s, S->d_M, S->d_P, S->d_pmax, S->E, S->R, S->WPR,
+                       S->rows_per_chunk, S->d_anyp, S->d_anya, S->d_words);
+    hipLaunchKernelGGL(setfull_resolve_kernel, dim3((S->WPR + 3) / 4), dim3(256), 0, s, S->d_M, S->d_P, S->d_read_invoke, S->d_read_ok, S->d_anyp,
+                       S->d_anya, S->E, S->R, S->WPR, S->rows_per_chunk, S->chunks, S->d_lp, S->d_la, S->d_known, S->d_words);
   }
   if (S->E) hipLaunchKernelGGL(setfull_finish_kernel, dim3((S->E + 255) / 256), dim3(256), 0, s, S->d_lp, S->d_la, S->d_known, S->d_add_ok, S->E);
   SF_TRY(hipGetLastError());
