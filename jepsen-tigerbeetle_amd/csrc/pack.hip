@@ -16,7 +16,7 @@
 //      -- each list bracketed by a head and a tail sentinel so
 //     the per-lane cursors of the search kernel need no bounds checks.
 //
-// One 256-thread workgroup per history, grid-strided over the batch.  The
+// One workgroup per history (256 threads in a big batch, 1,024 when a few histories must be quick), grid-strided over the batch.  The
 // column reads are coalesced (lane i reads row base+i of each column); the
 // record scatter is 32 B per op.  Algorithmic HBM bytes per op: 21 B of
 // columns read + 32 B record + 8 B ret_slot/ret_op written (+ 12 B scratch
@@ -61,11 +61,12 @@ __device__ __forceinline__ bool op_ok_for_model(uint32_t kind, uint32_t f, int32
 
 }  // namespace
 
-__global__ __launch_bounds__(256) void pack_kernel(PackArgs A) {
+__global__ __launch_bounds__(1024) void pack_kernel(PackArgs A) {
+  const uint32_t NT = blockDim.x;
   __shared__ uint32_t s_cnt[kMaxSlots];
   __shared__ uint32_t s_seg[kMaxSlots + 1];
   __shared__ uint32_t s_mark[kMaxSlots];
-  __shared__ uint32_t s_part[256];
+  __shared__ uint32_t s_part[1024];
   __shared__ uint32_t s_err, s_total, s_done;
   const uint32_t tid = threadIdx.x;
 
@@ -87,11 +88,11 @@ __global__ __launch_bounds__(256) void pack_kernel(PackArgs A) {
     Rec* rec = A.rec + H->rec_off;
 
     if (tid == 0) { s_err = 0; s_done = 0; if (A.dbg) { A.dbg[0] = 0x10u; A.dbg[1] = h; } }
-    for (uint32_t p = tid; p < W; p += 256) { s_cnt[p] = 0; s_mark[p] = kInf; }
+    for (uint32_t p = tid; p < W; p += NT) { s_cnt[p] = 0; s_mark[p] = kInf; }
     __syncthreads();
 
     // phase 1: validate rows, set completion bits, count ops per process
-    for (uint32_t i = tid; i < n; i += 256) {
+    for (uint32_t i = tid; i < n; i += NT) {
       const uint32_t iv = inv[i], rt = ret[i];
       const int32_t p = proc[i];
       bool bad = iv >= E || p < 0 || (uint32_t)p >= W || (i > 0 && inv[i - 1] >= iv);
@@ -112,12 +113,12 @@ __global__ __launch_bounds__(256) void pack_kernel(PackArgs A) {
         if (tid == 0) s_total = 0;
         __syncthreads();
         uint32_t mine = 0;
-        for (uint32_t i = tid; i < n; i += 256) mine += f[i] == TBC_F_ADD;
+        for (uint32_t i = tid; i < n; i += NT) mine += f[i] == TBC_F_ADD;
         if (mine) atomicAdd(&s_total, mine);
         __syncthreads();
         const uint64_t n_adds = s_total, nwords = n_adds ? (n_adds + 31) / 32 : 1;
         bool bad = aux < 0 || (uint64_t)aux + Rn + 1 > PL;
-        for (uint32_t i = tid; i < n && !bad; i += 256) {
+        for (uint32_t i = tid; i < n && !bad; i += NT) {
           if (f[i] == TBC_F_ADD) bad = a[i] < 0 || (uint64_t)a[i] >= n_adds;
           else if (a[i] != TBC_NIL) bad = a[i] < 0 || (uint64_t)a[i] + 2 + nwords > PL;
         }
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(256) void pack_kernel(PackArgs A) {
       } else {
         const uint64_t NA = A.n_keys;
         bool bad = NA == 0 || NA > 16 || aux < 0 || (uint64_t)aux + (Rn + 1) * NA > PL;
-        for (uint32_t i = tid; i < n && !bad; i += 256) {
+        for (uint32_t i = tid; i < n && !bad; i += NT) {
           if (f[i] == TBC_F_TRANSFER) {
             bad = a[i] < 0 || (uint64_t)a[i] + 3 > PL;
             if (!bad) { const int32_t d = A.pool_vals[a[i]], c = A.pool_vals[a[i] + 1]; bad = d < 0 || c < 0 || (uint64_t)d >= NA || (uint64_t)c >= NA; }
@@ -143,7 +144,7 @@ __global__ __launch_bounds__(256) void pack_kernel(PackArgs A) {
 
     if (tid == 0 && A.dbg) A.dbg[0] = 0x20u;
     // phase 2: exclusive popcount prefix per bitmap word
-    const uint32_t chunk = (nw + 255) / 256;
+    const uint32_t chunk = (nw + NT - 1) / NT;
     const uint32_t lo = min(tid * chunk, nw), hi = min(lo + chunk, nw);
     uint32_t sum = 0;
     for (uint32_t w = lo; w < hi; w++) sum += __popc(ld_agent(&bm[w]));
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(256) void pack_kernel(PackArgs A) {
     __syncthreads();
     if (tid == 0) {
       uint32_t run = 0;
-      for (uint32_t t = 0; t < 256; t++) { uint32_t x = s_part[t]; s_part[t] = run; run += x; }
+      for (uint32_t t = 0; t < NT; t++) { uint32_t x = s_part[t]; s_part[t] = run; run += x; }
       s_total = run;
     }
     __syncthreads();
@@ -169,7 +170,7 @@ __global__ __launch_bounds__(256) void pack_kernel(PackArgs A) {
 
     if (tid == 0 && A.dbg) A.dbg[0] = 0x30u;
     // phase 3: ranks; completion order tables
-    for (uint32_t i = tid; i < n; i += 256) {
+    for (uint32_t i = tid; i < n; i += NT) {
       const uint32_t iv = inv[i], rt = ret[i];
       const uint32_t ir = ld_agent(&wpre[iv >> 5]) + __popc(ld_agent(&bm[iv >> 5]) & ((1u << (iv & 31)) - 1u));
       uint32_t rr = kInf;
@@ -189,8 +190,8 @@ __global__ __launch_bounds__(256) void pack_kernel(PackArgs A) {
       s_seg[W] = run;
     }
     __syncthreads();
-    for (uint32_t p = tid; p <= W; p += 256) A.seg[H->seg_off + p] = s_seg[p];
-    for (uint32_t p = tid; p < W; p += 256) s_cnt[p] = 0;   // now: ops placed so far
+    for (uint32_t p = tid; p <= W; p += NT) A.seg[H->seg_off + p] = s_seg[p];
+    for (uint32_t p = tid; p < W; p += NT) s_cnt[p] = 0;   // now: ops placed so far
     __syncthreads();
 
     if (tid == 0 && A.dbg) A.dbg[0] = 0x40u;
@@ -227,13 +228,13 @@ __global__ __launch_bounds__(256) void pack_kernel(PackArgs A) {
 
     if (tid == 0 && A.dbg) A.dbg[0] = 0x50u;
     // phase 6: scatter the records, write the sentinels
-    for (uint32_t i = tid; i < n; i += 256) {
+    for (uint32_t i = tid; i < n; i += NT) {
       Rec r;
       r.inv_rank = sc_inv[i]; r.ret_rank = sc_ret[i]; r.opidx = i; r.f = f[i];
       r.a = a[i]; r.b = b[i]; r.pad0 = 0; r.pad1 = 0;
       rec[ld_agent(&sc_dst[i])] = r;
     }
-    for (uint32_t p = tid; p < W; p += 256) {
+    for (uint32_t p = tid; p < W; p += NT) {
       Rec hd; hd.inv_rank = 0; hd.ret_rank = 0; hd.opidx = kInf; hd.f = kFNone; hd.a = 0; hd.b = 0; hd.pad0 = 0; hd.pad1 = 0;
       Rec tl = hd; tl.inv_rank = kInf; tl.ret_rank = kInf;
       rec[s_seg[p]] = hd;
@@ -244,7 +245,7 @@ __global__ __launch_bounds__(256) void pack_kernel(PackArgs A) {
     if (tid == 0 && A.dbg) A.dbg[0] = 0x60u;
     // phase 7: one open op per process: the previous op of the same process
     // must have completed before this one was invoked
-    for (uint32_t i = tid; i < n; i += 256) {
+    for (uint32_t i = tid; i < n; i += NT) {
       const uint32_t d = ld_agent(&sc_dst[i]);
       const uint32_t* prev = reinterpret_cast<const uint32_t*>(&rec[d - 1]);
       const uint32_t prev_ret = ld_agent(prev + 1), prev_f = ld_agent(prev + 3);
@@ -258,7 +259,7 @@ __global__ __launch_bounds__(256) void pack_kernel(PackArgs A) {
 
 void launch_pack(const PackArgs& a, void* stream) {
   uint32_t grid = a.n_hist < 4096 ? a.n_hist : 4096;
-  hipLaunchKernelGGL(pack_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(pack_kernel, dim3(grid), dim3(a.n_hist <= 64 ? 1024 : 256), 0, (hipStream_t)stream, a);
 }
 
 }  // namespace tbc
