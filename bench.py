@@ -64,8 +64,9 @@ def main():
     ap.add_argument("--busy", type=float, default=0.1,
                     help="fraction of time a process has an op open (64 x 0.1 = 6.4 ops in flight on average)")
     ap.add_argument("--info", type=float, default=0.0, help="crashed-op (:info) rate")
-    ap.add_argument("--width", type=int, default=int(os.environ.get("TBC_BENCH_WIDTH", "4")),
-                    help="configs expanded per iteration: 1 = sequential knossos.wgl order, 2..16 = wide schedule")
+    ap.add_argument("--width", type=int, default=int(os.environ.get("TBC_BENCH_WIDTH", "0")),
+                    help="configs expanded per iteration: 0 = the library's choice (2 at low concurrency under the dominance rules, "
+                         "else 4), 1 = sequential knossos.wgl order, 2..16 = wide schedule")
     ap.add_argument("--visited-per-op", type=int, default=8, help="first visited-set capacity per op (0 = library default 64)")
     ap.add_argument("--round-budget", type=int, default=0,
                     help="a history that has used more rounds than this continues at width 16 (0 = off)")
@@ -119,6 +120,7 @@ def main():
     t_create = time.perf_counter()
     batch = core.Batch(hists, model, opts)        # H2D happens here: inputs resident before timing
     t_create = time.perf_counter() - t_create
+    width = batch.search_width()                  # what --width 0 became for this batch
 
     for _ in range(args.warmup):
         batch.run()
@@ -168,7 +170,7 @@ def main():
             with open(os.path.join(ROOT, "profiles", "r02_traffic.json")) as fh:
                 for e in json.load(fh)["entries"]:
                     key = (e["histories_per_gpu"], e["search_width"], e["visited_per_op"], e["ops"], e["procs"], e["busy"], e["info"])
-                    if e.get("kernel_sha") == kernel_sha() and key == (B, args.width, args.visited_per_op, args.ops, args.procs, args.busy, args.info):
+                    if e.get("kernel_sha") == kernel_sha() and key == (B, width, args.visited_per_op, args.ops, args.procs, args.busy, args.info):
                         traffic = e["traffic_bytes"]
         except (OSError, KeyError, ValueError):
             pass
@@ -181,11 +183,11 @@ def main():
             "dtype": "u64", "data": "synthetic",
             "config": {"workload": workload_name(args.ops, args.procs, args.busy, args.info), "histories_per_gpu": B, "ops_after_pairing": int(batch.total_ops // B),
                        "processes": args.procs, "busy": args.busy, "info_rate": args.info,
-                       "search_width": args.width, "round_budget": args.round_budget,
+                       "search_width": width, "search_width_asked": args.width, "round_budget": args.round_budget,
                        "parallelism": f"independent histories sharded over {world} GPU(s), no collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
-                         "kernel": "wgl_search_kernel" if args.width == 1 else "wgl_beam_kernel", "kernel_ms": round(k_ms, 3),
+                         "kernel": "wgl_search_kernel" if width == 1 else "wgl_beam_kernel", "kernel_ms": round(k_ms, 3),
                          "probes_per_launch": counters["probes"], "new_configs_per_launch": counters["visited"],
                          "algorithmic_bytes_per_launch": alg_bytes},
             "extra": {"valid": n_valid, "unknown": n_unknown,
@@ -204,6 +206,20 @@ def main():
         # time-to-verdict for ONE history through tbc_check (host columns in -> verdict out: H2D + kernels + D2H), rank 0.
         # knossos.competition without a witness = the level sweep (jit_sweep.hip); with a witness = the depth-first search
         batch.close()
+        if world == 1 and args.width == 0 and width != 4:
+            # the same batch at 4 configs per round (the default until the width followed the concurrency): it attempts
+            # about twice the probes -- more algorithmic bytes per second, a higher roofline fraction -- and needs longer
+            # for the same verdicts.  Reported so that the fraction above can be read against it; never `value`.
+            with core.Batch(hists, model, core.make_opts(device=local_rank, time_limit_ms=600000, want_witness=False, algorithm=N.ALG_COMPETITION,
+                                                         search_width=4, visited_per_op=args.visited_per_op)) as b4:
+                b4.run()
+                t4 = time.perf_counter(); b4.run(); t4 = time.perf_counter() - t4
+                c4, tm4 = b4.counters(), b4.timing_ns()
+            alg4 = 16 * (c4["probes"] - c4["visited"]) + 32 * c4["visited"]
+            line["extra"]["same_batch_at_width_4"] = {
+                "value": round(B / t4, 2), "unit": "histories/s", "ms_per_step": round(t4 * 1e3, 3), "kernel_ms": round(tm4["search"] / 1e6, 3),
+                "probes_per_launch": c4["probes"], "new_configs_per_launch": c4["visited"], "algorithmic_bytes_per_launch": alg4,
+                "roofline_frac": round(alg4 / (tm4["search"] * 1e-9) / 1e9 / HBM_PEAK_GBS, 6)}
         ttv, ttv_dfs, analyzers = [], [], []
         o_sweep = core.make_opts(device=local_rank, want_witness=False, algorithm=N.ALG_COMPETITION)
         o_dfs = core.make_opts(device=local_rank, want_witness=True, algorithm=N.ALG_COMPETITION, search_width=args.width)
@@ -249,7 +265,7 @@ def main():
             # the SAME schedule the kernel runs (wide, K configs per iteration, lookahead, eager reads, twin rule) on one
             # host thread: how much of the speed-up is the algorithm and how much the GPU
             tw = time.perf_counter()
-            okw = sum(wgl.check_beam(d, om, args.width if args.width > 1 else 4, want_witness=False)["valid"] == 1 for d in dicts[:S1])
+            okw = sum(wgl.check_beam(d, om, width if width > 1 else 4, want_witness=False)["valid"] == 1 for d in dicts[:S1])
             tw = time.perf_counter() - tw
             ts = time.perf_counter()
             oks = sum(wgl.check_sweep(d, om)["valid"] == 1 for d in dicts[:S1])
@@ -300,13 +316,14 @@ def main():
             o2 = core.make_opts(device=local_rank, time_limit_ms=600000, want_witness=False, algorithm=N.ALG_COMPETITION,
                                 search_width=args.width, visited_per_op=256)     # ~4*10^5 configs per history: start big, no retries
             with core.Batch(h2, model, o2) as b2:
+                width2 = b2.search_width()
                 b2.run()
                 t2 = time.perf_counter(); b2.run(); t2 = time.perf_counter() - t2
                 c2 = b2.counters(); tm2 = b2.timing_ns(); v2 = b2.verdicts()
             alg2 = 16 * (c2["probes"] - c2["visited"]) + 32 * c2["visited"]
             k2 = (tm2["search"] + tm2["retries"]) / 1e6
             line["extra"]["workload_2"] = {
-                "workload": workload_name(args.ops, args.procs, args.busy2, 0.0), "histories_per_gpu": B2,
+                "workload": workload_name(args.ops, args.procs, args.busy2, 0.0), "histories_per_gpu": B2, "search_width": width2,
                 "value": round(B2 / t2, 2), "unit": "histories/s", "ms_per_step": round(t2 * 1e3, 3),
                 "valid": int((v2 == N.VALID).sum()), "unknown": int((v2 == N.UNKNOWN).sum()),
                 "roofline": {"bound": "hbm", "achieved": round(alg2 / (k2 * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",

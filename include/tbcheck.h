@@ -194,8 +194,11 @@ typedef struct tbc_opts {
                              /* knossos.wgl order (witness and counters equal the */
                              /* published algorithm's); 2..16 = the wide schedule */
                              /* (same verdict / failing op, one (config, call)    */
-                             /* pair per lane).  0 = default: 1 for TBC_ALG_WGL,  */
-                             /* 4 for TBC_ALG_LINEAR / TBC_ALG_COMPETITION        */
+                             /* pair per lane).  0 = default: 1 for TBC_ALG_WGL;  */
+                             /* else 4, or 2 when the batch is a register /       */
+                             /* cas-register one under the dominance rules with   */
+                             /* at most 10 calls in flight on average (fewer      */
+                             /* configs expanded in vain; tbc_batch_search_width) */
   uint32_t round_budget;     /* wide schedule, 0 = off: a history that has used     */
                              /* more rounds than this continues at search_width 16  */
                              /* (a batch's stragglers then need far fewer dependent */
@@ -260,6 +263,8 @@ typedef struct tbc_result {
   uint32_t prev_ok_op;       /* invalid: op completing just before it (:previous-ok) */
   int32_t final_state;       /* valid: model state after the witness             */
   uint32_t n_witness;        /* valid: ops linearized                            */
+  uint32_t search_width;     /* configs per round of the depth-first search of   */
+                             /* this call (what tbc_opts.search_width 0 became)  */
   uint32_t* witness;         /* valid && want_witness: op indices, library-owned */
   uint32_t n_configs;        /* final configs (<= TBC_MAX_FINAL_CONFIGS)         */
   tbc_config configs[TBC_MAX_FINAL_CONFIGS];
@@ -311,6 +316,8 @@ tbc_status tbc_batch_last_timing(const tbc_batch* b, uint64_t ns[4]);
 /* sum of tbc_counters over the last run (probes, visited ...) */
 tbc_status tbc_batch_last_counters(const tbc_batch* b, tbc_counters* out);
 uint64_t tbc_batch_device_bytes(const tbc_batch* b);
+/* the search_width this batch runs the depth-first search at (what tbc_opts.search_width = 0 resolved to) */
+uint32_t tbc_batch_search_width(const tbc_batch* b);
 /* how the last run was answered when the level sweep (knossos.linear; jit_sweep.hip) is in play:
  * TBC_ALG_LINEAR always asks for it, TBC_ALG_COMPETITION on small batches that want no witness.
  * The sweep cuts a history into segments of about seg_target completions at fronts with at most

@@ -90,7 +90,7 @@ class Counters(C.Structure):
 class Result(C.Structure):
     _fields_ = [("valid", C.c_int32), ("cause", C.c_int32), ("analyzer", C.c_uint32),
                 ("fail_op", C.c_uint32), ("prev_ok_op", C.c_uint32), ("final_state", C.c_int32),
-                ("n_witness", C.c_uint32), ("witness", C.POINTER(C.c_uint32)), ("n_configs", C.c_uint32),
+                ("n_witness", C.c_uint32), ("search_width", C.c_uint32), ("witness", C.POINTER(C.c_uint32)), ("n_configs", C.c_uint32),
                 ("configs", Config * MAX_FINAL_CONFIGS), ("counters", Counters)]
 
 
@@ -152,6 +152,7 @@ SYMBOLS = {
     "tbc_batch_last_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "tbc_batch_last_counters": (C.c_int, [C.c_void_p, C.POINTER(Counters)]),
     "tbc_batch_device_bytes": (C.c_uint64, [C.c_void_p]),
+    "tbc_batch_search_width": (C.c_uint32, [C.c_void_p]),
     "tbc_batch_sweep_info": (C.c_int, [C.c_void_p, C.POINTER(SweepInfo)]),
     "tbc_sweep_compose": (C.c_int, [C.POINTER(SweepRel), C.c_uint32, C.c_uint32, C.POINTER(SweepVerdict)]),
     "tbc_batch_set_shard": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),

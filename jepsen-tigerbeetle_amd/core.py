@@ -50,7 +50,7 @@ def _result_dict(r: N.Result, copy_witness=True):
         "valid": r.valid, "cause": r.cause, "analyzer": r.analyzer,
         "fail_op": None if r.fail_op == N.NO_OP else r.fail_op,
         "prev_ok_op": None if r.prev_ok_op == N.NO_OP else r.prev_ok_op,
-        "final_state": r.final_state, "n_witness": r.n_witness, "witness": None,
+        "final_state": r.final_state, "n_witness": r.n_witness, "witness": None, "search_width": r.search_width,
         "configs": [],
     }
     if r.valid == N.VALID and bool(r.witness) and copy_witness:
@@ -189,6 +189,10 @@ class Batch:
 
     def device_bytes(self):
         return int(N.lib().tbc_batch_device_bytes(self._h))
+
+    def search_width(self):
+        """Configs per round of the depth-first search (what search_width=0 resolved to for this batch)."""
+        return int(N.lib().tbc_batch_search_width(self._h))
 
     def close(self):
         if self._h:

@@ -345,6 +345,25 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
       B->vpad = 2; while (B->vpad < (uint32_t)(vmax + 2)) B->vpad <<= 1;
     }
   }
+  // Nobody named a width: 4 configs per round, or 2 where that is measured faster -- a register / cas-register batch
+  // under both dominance rules at low concurrency, where the depth-first order rarely backtracks and the third and
+  // fourth config of a round are mostly expanded in vain (32,768 histories at 6.4 calls in flight: 5.6*10^8 probes and
+  // 171 ms against 1.07*10^9 and 198 ms; at 19 in flight 4 is 9 % faster; profiles/r02_k5_width_ab.txt).  Calls in
+  // flight are averaged over a sample of the batch's histories: positions from invocation to completion (a crashed
+  // call stays open to the end) over the history's length.
+  if (opts->search_width == 0 && B->width == 4 && B->rules == (kRuleEager | kRuleTwin)) {
+    uint64_t open_sum = 0, events = 0;
+    const uint32_t stride = std::max<uint32_t>(1, nh / 64);
+    for (uint32_t h = 0; h < nh; h += stride) {
+      const uint32_t ne = desc->n_events[h];
+      for (uint64_t i = desc->op_off[h]; i < desc->op_off[h + 1]; i++) {
+        const uint32_t inv = desc->cols.inv_pos[i], ret = desc->cols.ret_pos[i];
+        open_sum += (ret == TBC_POS_CRASHED || ret > ne ? ne : ret) - std::min(inv, ne);   // malformed rows are the pack kernel's to reject
+      }
+      events += ne;
+    }
+    if (events && open_sum <= 10 * events) B->width = 2;
+  }
   const uint32_t EW = B->wg ? beam_wg_entry_words(B->mask_words) : B->mask_words + 2;   // u64 words per wide-schedule entry
   if (B->sweep) {
     // segments: enough wavefronts to fill the GPU several times over, none shorter than 32 completions; cuts need the
@@ -1012,7 +1031,7 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results, int phase = 
     r.valid = d.valid; r.cause = d.cause;
     r.analyzer = B->sweep ? (by_sweep[h] ? TBC_ALG_LINEAR : TBC_ALG_WGL)
                           : (B->opts.algorithm == TBC_ALG_LINEAR ? TBC_ALG_LINEAR : TBC_ALG_WGL);
-    r.fail_op = TBC_NO_OP; r.prev_ok_op = TBC_NO_OP;
+    r.fail_op = TBC_NO_OP; r.prev_ok_op = TBC_NO_OP; r.search_width = B->width;
     if (d.valid == TBC_INVALID) {
       r.fail_op = d.fail_op; r.prev_ok_op = d.prev_ok_op;
       tbc_status cs = fill_configs(B, h, d, &r);
@@ -1097,6 +1116,7 @@ tbc_status tbc_batch_last_counters(const tbc_batch* b, tbc_counters* out) {
 }
 
 uint64_t tbc_batch_device_bytes(const tbc_batch* b) { return b ? b->device_bytes : 0; }
+uint32_t tbc_batch_search_width(const tbc_batch* b) { return b ? b->width : 0; }
 
 tbc_status tbc_batch_sweep_info(const tbc_batch* b, tbc_sweep_info* out) {
   if (!b || !out) return TBC_ERR_INVALID_ARG;

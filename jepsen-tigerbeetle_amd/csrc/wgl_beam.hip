@@ -95,7 +95,7 @@ __device__ __forceinline__ uint32_t row_max_u32(uint32_t v) {
 // LDS words per wave: parents p_k0[16] p_M[16*MW] (u64), ring r_k0[kRing] r_M[kRing*MW] (u64),
 // p_slot p_off p_nlive p_cnt (u32 x16), r_pos r_idx r_off r_nlive r_cnt (u32 x kRing), p_start (17 -> 20),
 // search state (28, S_* words), this round's new configs for the lookahead c_M[64*MW] (u64) c_fi c_st (u32 x64)
-__host__ __device__ constexpr uint32_t beam_lds_words(uint32_t mw) { return (16 + kRing) * (2 + 2 * mw) + 16 * 4 + kRing * 5 + 20 + 28 + 64 * (2 + 2 * mw); }
+__host__ __device__ constexpr uint32_t beam_lds_words(uint32_t mw) { return (16 + kRing) * (2 + 2 * mw) + 16 * 4 + kRing * 5 + 20 + 30 + 64 * (2 + 2 * mw); }
 
 __device__ __forceinline__ uint32_t key_hash32(uint64_t k0, const uint64_t* M, int mw) {
   uint32_t h = (uint32_t)k0 * 0x9E3779B1u ^ (uint32_t)(k0 >> 32) * 0x85EBCA77u;
@@ -171,7 +171,7 @@ __device__ __forceinline__ uint32_t scan_bucket(const gu64* tab, uint32_t b, uin
 enum : uint32_t {
   S_TAB = 0, S_STACK = 2, S_CAP = 4, S_SP = 5, S_MAXSP = 6, S_MAXF = 7, S_K = 8, S_VERDICT = 9, S_CAUSE = 10,
   S_WINPAR = 11, S_WINOP = 12, S_WINSTATE = 13, S_PROBES = 14, S_VISITED = 16, S_EXPANDED = 18, S_ITER = 20,
-  S_ROUNDS = 22, S_DSTACK = 24, S_DSP = 26, S_EXACT = 27, S_WORDS = 28
+  S_ROUNDS = 22, S_DSTACK = 24, S_DSP = 26, S_EXACT = 27, S_T0 = 28, S_WORDS = 30
 };
 typedef __attribute__((address_space(3))) volatile uint32_t* state_ptr;   // LDS, named so: volatile accesses keep the generic (flat) form otherwise
 __device__ __forceinline__ uint32_t sld(state_ptr S, uint32_t i) { return rfl(S[i]); }
@@ -181,11 +181,22 @@ __device__ __forceinline__ uint64_t sld64(state_ptr S, uint32_t i) {
 __device__ __forceinline__ void sst(state_ptr S, uint32_t i, uint32_t v) { S[i] = v; }
 __device__ __forceinline__ void sst64(state_ptr S, uint32_t i, uint64_t v) { S[i] = (uint32_t)v; S[i + 1] = (uint32_t)(v >> 32); }
 
+// Arguments only the cold paths read (limits, growth pool, results, debug words) are fetched from the kernarg
+// segment where they are needed.  Read from the by-value struct they are loaded at kernel entry, stay live across
+// the round loop and -- the loop needs every scalar register it can get -- are spilled to VGPR lanes and
+// reloaded around it; the empty asm keeps the loads where they are written.
+typedef const __attribute__((address_space(4))) BeamArgs* cold_args_ptr;
+__device__ __forceinline__ cold_args_ptr cold_args() {
+  cold_args_ptr p = (cold_args_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(p));
+  return p;
+}
+
 // Cold path: move a history to a 4x larger visited set (and stack) taken from the batch's growth pool --
 // re-insert every entry, then translate the slot numbers held by parent links and the stack.  Called
 // between iterations (nothing popped); reads and updates the parked search state.
 template <int MW>
-__device__ __forceinline__ bool grow_visited_set(const BeamArgs& A, state_ptr S, uint32_t* r_pos, uint32_t lane) {
+__device__ __forceinline__ bool grow_visited_set(state_ptr S, uint32_t* r_pos, uint32_t lane) {
   constexpr uint32_t KW = MW + 1, EW = MW + 2;
   const gu64* tab = (const gu64*)sld64(S, S_TAB);
   const gu32* stack = (const gu32*)sld64(S, S_STACK);
@@ -194,11 +205,13 @@ __device__ __forceinline__ bool grow_visited_set(const BeamArgs& A, state_ptr S,
   const uint64_t old_cap = 1ull << cap_log2, new_cap = old_cap << 2;
   const uint64_t need = new_cap * EW + new_cap / 2 + (dstack ? new_cap / 2 : 0) + old_cap / 2;   // keys + parents, stack(s), slot translation
   unsigned long long base = 0;
-  if (!A.pool || cap_log2 + 2 > 31 || cap_log2 + 2 > A.max_tab_log2) return false;   // refused before any pool words are taken
-  if (lane == 0) base = atomicAdd(A.pool_cursor, (unsigned long long)need);
+  const cold_args_ptr C = cold_args();
+  uint64_t* const pool = C->pool;
+  if (!pool || cap_log2 + 2 > 31 || cap_log2 + 2 > C->max_tab_log2) return false;   // refused before any pool words are taken
+  if (lane == 0) base = atomicAdd(C->pool_cursor, (unsigned long long)need);
   base = ru64(base);
-  if (base + need > A.pool_words) return false;
-  gu64* ntab = (gu64*)A.pool + base;
+  if (base + need > C->pool_words) return false;
+  gu64* ntab = (gu64*)pool + base;
   gu64* npar = ntab + new_cap * KW;
   const gu64* opar = tab + old_cap * KW;
   gu32* nstack = (gu32*)(ntab + new_cap * EW);
@@ -257,7 +270,6 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
   const Hist* H = A.hist + hidx;
   const BeamHist* B = A.bh + hidx;
   const uint64_t op_off = ru64(H->op_off);
-  const uint64_t ret_off = ru64(H->ret_off);
   const uint64_t off_off = ru64(B->off_off);
   const uint32_t* off = A.off + off_off;
   const uint32_t* ncr = A.ncr + off_off;
@@ -267,7 +279,6 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
   const uint32_t R = rfl(H->n_ret), status = rfl(H->status) | rfl(B->status);
   // K parents per iteration, G = 64 / K lanes (candidate slots) per parent per round.  A history that has
   // used more than round_budget rounds continues at K = 16: stragglers then need far fewer dependent rounds.
-  DevResult* out = A.results + hidx;
   // the register family (register, cas-register, mutex) steps on immediates: its kernel carries no table / pool pointers
   const Model model = REGF ? Model{A.model_kind, nullptr, 0u, nullptr, 0, 0u}
                            : Model{A.model_kind, A.table, A.n_classes, A.pool_vals, (int32_t)rfl((uint32_t)H->aux), A.n_keys};
@@ -297,7 +308,6 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
   const uint64_t* twn = A.twn + ru64(B->lst_off) * MW;
   if (lane < kRing) r_pos[lane] = kNone;
 
-  const uint64_t t0 = A.time_limit_ticks ? wall_clock64() : 0;
 #ifdef TBC_SEGPROF   // per-segment cycle counters (scripts/gpu_segprof.py); costs ~20 VGPRs, off in production
   const bool prof = A.dbg != nullptr;
   uint64_t seg[6] = {0, 0, 0, 0, 0, 0}, tlast = prof ? __builtin_readcyclecounter() : 0;
@@ -341,6 +351,7 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
       sst(S, S_WINPAR, kNone); sst(S, S_WINOP, kNone); sst(S, S_WINSTATE, (uint32_t)A.init_state);
       sst64(S, S_PROBES, 0ull); sst64(S, S_VISITED, (uint64_t)sp0); sst64(S, S_EXPANDED, 0ull);
       sst64(S, S_ITER, 0ull); sst64(S, S_ROUNDS, 0ull);
+      sst64(S, S_T0, A.time_limit_ticks ? (uint64_t)wall_clock64() : 0ull);
     }
   }
 
@@ -360,6 +371,15 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
   uint32_t visited = (uint32_t)sld64(S, S_VISITED);
   const uint64_t probes0 = sld64(S, S_PROBES), rounds0 = sld64(S, S_ROUNDS);
   bool need_park = false;
+  // how far the 32-bit deltas may go before the loop is left to look at the 64-bit totals: the step limit (or the
+  // fold at 2^31), and the round budget after which a straggler continues at K = 16
+  uint32_t probe_room = 0x7FFFFFFFu, round_room = 0xFFFFFFFFu;
+  {
+    const cold_args_ptr C = cold_args();
+    const uint64_t ms = C->max_steps, rb = C->round_budget;
+    if (ms && ms - min(ms, probes0) < (uint64_t)probe_room) probe_room = (uint32_t)(ms - min(ms, probes0));
+    if (rb) round_room = (uint32_t)min(rb - min(rb, rounds0), (uint64_t)0xFFFFFFFEu);
+  }
   uint32_t sp = sld(S, S_SP), max_sp = sld(S, S_MAXSP), lane_maxf = sld(S, S_MAXF);
   int32_t verdict = (int32_t)sld(S, S_VERDICT), cause = (int32_t)sld(S, S_CAUSE);
   gu32* const dstack = (gu32*)sld64(S, S_DSTACK);
@@ -368,6 +388,8 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
   bool need_grow = false, need_switch = false;
 
   while (verdict == -2) {
+    // step limit (as after the iteration that exceeded it), or 2^31 probes to fold into the 64-bit totals
+    if (__builtin_expect(probes > probe_room, 0)) { need_park = true; break; }
     if (sp == 0) {
       // no linearization through the live configs.  Those the lookahead set aside become the stack and the
       // search goes on without lookahead: an INVALID verdict has then expanded every reachable config
@@ -375,8 +397,7 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
       if (dsp != 0u) { need_switch = true; break; }
       verdict = TBC_INVALID; break;
     }
-    if (A.round_budget && rounds0 + rounds > A.round_budget && K < 16u) { K = 16u; gshift = 2u; G = 4u; }
-    if (__builtin_expect(probes > 0x7FFFFFFFu, 0)) { need_park = true; break; }      // fold the deltas into the 64-bit totals
+    if (__builtin_expect(rounds > round_room, 0) && K < 16u) { K = 16u; gshift = 2u; G = 4u; }
     const uint32_t np = min(K, sp);
     const uint32_t ln = opaque_lane(lane);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -422,7 +443,7 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
       }
       if (ln < np) p_start[ln] = x - my_cnt;
       T = rl(x, np - 1);
-      if (ln == 0) p_start[np] = T;
+      if (ln >= np && ln <= 16u) p_start[ln] = ln == np ? T : 0xFFFFFFFFu;     // no pair number reaches these
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -443,8 +464,9 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
         const uint32_t r = base + lr;
         q = 0;
 #pragma unroll
-        for (uint32_t t = 1; t < 16; t++) q += (t < np && p_start[t] <= r) ? 1u : 0u;
+        for (uint32_t t = 1; t < 16; t++) q += p_start[t] <= r ? 1u : 0u;
         has_parent = r < T;
+        q = has_parent ? q : 0u;
         cd = has_parent ? r - p_start[q] : 0u;
       }
       const uint64_t k0p = has_parent ? p_k0[q] : 1ull;
@@ -677,16 +699,22 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
       SEG(4);
     }
     max_sp = max(max_sp, sp);
-    if (A.dbg && lr == 0 && (iterations & 255u) == 1u) {
-      A.dbg[8] = hidx; A.dbg[9] = iterations; A.dbg[10] = sp; A.dbg[11] = probes;
-      A.dbg[12] = visited; A.dbg[13] = maxcnt; A.dbg[14] = np; A.dbg[15] = rounds;
-    }
-    if (verdict == -2) {
-      if (A.max_steps && probes0 + probes > A.max_steps) { verdict = TBC_UNKNOWN; cause = TBC_CAUSE_STEP_LIMIT; }
-      else if (A.time_limit_ticks && (iterations & 63u) == 0 && (uint64_t)wall_clock64() - t0 > A.time_limit_ticks) {
+    if (__builtin_expect((iterations & 63u) == 0u, 0)) {      // the clock, and the progress words of a debug run
+      const cold_args_ptr C = cold_args();
+      uint32_t* const dbg = C->dbg;
+      if (dbg && lr == 0 && (iterations & 255u) == 0u) {
+        dbg[8] = hidx; dbg[9] = iterations; dbg[10] = sp; dbg[11] = probes;
+        dbg[12] = visited; dbg[13] = maxcnt; dbg[14] = np; dbg[15] = rounds;
+      }
+      const uint64_t limit = C->time_limit_ticks;
+      if (verdict == -2 && limit && probes <= probe_room && (uint64_t)wall_clock64() - sld64(S, S_T0) > limit) {
         verdict = TBC_UNKNOWN; cause = TBC_CAUSE_TIME_LIMIT;
       }
     }
+  }
+  if (need_park && verdict == -2) {       // left to look at the totals: over the step limit?
+    const uint64_t ms = cold_args()->max_steps;
+    if (ms && probes0 + probes > ms) { verdict = TBC_UNKNOWN; cause = TBC_CAUSE_STEP_LIMIT; }
   }
 
   // ---- park the state
@@ -714,7 +742,7 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
   }
   if (need_park) continue;
   if (!need_grow) break;
-  if (!grow_visited_set<MW>(A, S, r_pos, lane)) {
+  if (!grow_visited_set<MW>(S, r_pos, lane)) {
     if (lane == 0) { sst(S, S_VERDICT, (uint32_t)TBC_UNKNOWN); sst(S, S_CAUSE, (uint32_t)TBC_CAUSE_VISITED_FULL); }
     break;
   }
@@ -732,10 +760,17 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
   const uint64_t probes = sld64(S, S_PROBES), visited = sld64(S, S_VISITED), expanded = sld64(S, S_EXPANDED);
   const uint64_t iterations = sld64(S, S_ITER), rounds = sld64(S, S_ROUNDS);
   const uint32_t max_sp = sld(S, S_MAXSP);
+  // what the result needs of the arguments and of the history's header is fetched again here rather than kept
+  // across the round loop
+  const cold_args_ptr C = cold_args();
+  const Hist* const Hc = C->hist + hidx;
+  const uint64_t op_off_c = ru64(Hc->op_off), ret_off_c = ru64(Hc->ret_off);
+  const uint32_t Rc = rfl(Hc->n_ret);
+  DevResult* const out = C->results + hidx;
   // ---- invalid: the configs stuck at the failing completion (knossos :configs), by a scan of the visited set
   uint32_t n_cfg = 0;
-  if (verdict == TBC_INVALID && A.cfg) {
-    uint64_t* cfg = A.cfg + (uint64_t)hidx * kCfgCap * (2 + MW);
+  if (verdict == TBC_INVALID && C->cfg) {
+    uint64_t* cfg = C->cfg + (uint64_t)hidx * kCfgCap * (2 + MW);
     const uint64_t ncap = 1ull << cap_log2;
     for (uint64_t s0 = 0; s0 < ncap; s0 += 64) {
       const gu64* e = tab + (s0 + lane) * KW;
@@ -757,7 +792,7 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
     }
   }
   uint32_t wlen = 0;
-  if (verdict == TBC_VALID && R != 0) {
+  if (verdict == TBC_VALID && Rc != 0) {
     // witness = ops along the parent chain of the winning config, then the winning op
     wlen = 1;
     uint32_t id = win_parent;
@@ -766,8 +801,8 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
       if (pr == kNone) break;
       wlen++; id = pr;
     }
-    if (A.witness) {
-      uint32_t* wit = A.witness + op_off;
+    if (C->witness) {
+      uint32_t* wit = C->witness + op_off_c;
       uint32_t w = wlen - 1;
       if (lane == 0) wit[w] = win_op;
       id = win_parent;
@@ -786,19 +821,20 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
     out->final_state = win_state; out->n_configs = n_cfg;
     out->fail_op = TBC_NO_OP; out->prev_ok_op = TBC_NO_OP;
     if (verdict == TBC_INVALID) {
-      const uint32_t* ret_op = A.ret_op + ret_off;
+      const uint32_t* ret_op = C->ret_op + ret_off_c;
       out->fail_op = ret_op[maxf];
       if (maxf) out->prev_ok_op = ret_op[maxf - 1];
     }
     out->steps = probes; out->visited = visited; out->probes = probes; out->backtracks = expanded;
     out->max_depth = max_sp; out->bucket_reads = rounds; out->tab_log2 = cap_log2;
   }
-  if (A.dbg && lane == 0) {
-    A.dbg[4] = 0x300u + hidx; A.dbg[16] = (uint32_t)verdict; A.dbg[17] = (uint32_t)iterations;
+  uint32_t* const dbg = C->dbg;
+  if (dbg && lane == 0) {
+    dbg[4] = 0x300u + hidx; dbg[16] = (uint32_t)verdict; dbg[17] = (uint32_t)iterations;
 #ifdef TBC_SEGPROF
-    for (int i = 0; i < 5; i++) { A.dbg[20 + 2 * i] = (uint32_t)seg[i]; A.dbg[21 + 2 * i] = (uint32_t)(seg[i] >> 32); }
+    for (int i = 0; i < 5; i++) { dbg[20 + 2 * i] = (uint32_t)seg[i]; dbg[21 + 2 * i] = (uint32_t)(seg[i] >> 32); }
 #endif
-    A.dbg[30] = (uint32_t)rounds;
+    dbg[30] = (uint32_t)rounds;
   }
 #undef SEG
 }

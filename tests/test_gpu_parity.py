@@ -115,8 +115,9 @@ def test_wide_schedule_matches_its_oracle(native, oracle, width, lookahead, rule
 
 def test_wide_schedule_overflow_retry_and_default_algorithm(native, oracle):
     ops = columns.pair_events(synth.register_events(n_ops=1000, n_procs=16, seed=1, busy=0.5, info=0.01, corrupt=0.5))
-    exp = oracle.check_beam(ops.as_dict(), CAS, 4)           # the library's default width
     got = core.check_ops(ops, gm(), core.make_opts(time_limit_ms=60000, algorithm=N.ALG_COMPETITION, visited_per_op=4))
+    assert got["search_width"] == 2          # nobody named a width: 16 processes at 50 % duty = 8 calls in flight -> 2 configs per round
+    exp = oracle.check_beam(ops.as_dict(), CAS, got["search_width"])
     assert got["valid"] == exp["valid"] == 0 and got["fail_op"] == exp["fail_op"]
     assert got["visited"] == exp["visited"] and got["table_slots"] > 16 * len(ops)
     small = core.check_ops(ops, gm(), core.make_opts(algorithm=N.ALG_COMPETITION, max_visited_bytes=64 * 1024))
@@ -261,14 +262,15 @@ def test_invalid_verdict_carries_the_stuck_configs(native, oracle, alg):
     (reads absorbed, twins ordered), a subset -- each against the oracle of its own schedule."""
     for seed in range(4):
         ops = columns.pair_events(synth.register_events(n_ops=1000, n_procs=16, seed=seed, busy=0.2, corrupt=0.6))
+        got = core.check_ops(ops, gm(), core.make_opts(time_limit_ms=60000, algorithm=alg))
         if alg == N.ALG_WGL:
             exp = oracle.check(ops.as_dict(), CAS, "window")
             total, rows = oracle.last_configs("window")
         else:
-            exp = oracle.check_beam(ops.as_dict(), CAS, 4)
+            assert got["search_width"] == 2                  # 3 calls in flight: the narrow default
+            exp = oracle.check_beam(ops.as_dict(), CAS, got["search_width"])
             total, rows = oracle.last_configs("beam")
         assert exp["valid"] == 0
-        got = core.check_ops(ops, gm(), core.make_opts(time_limit_ms=60000, algorithm=alg))
         assert got["valid"] == N.INVALID and got["fail_op"] == exp["fail_op"]
         assert len(got["configs"]) == min(total, 10) and total <= 256
         for c, row in zip(got["configs"], rows):
@@ -284,6 +286,27 @@ def test_invalid_verdict_carries_the_stuck_configs(native, oracle, alg):
     a = wgl.analysis(M.cas_register(), [kop.invoke(0, "write", 1), kop.ok(0, "write", 1), kop.invoke(1, "read", None), kop.ok(1, "read", 2)])
     assert a["valid?"] is False and a["configs"] and a["configs"][0]["model"] == M.CASRegister(1)
     assert [o["f"] for o in a["configs"][0]["pending"]] == ["read"]
+
+
+def test_default_width_follows_the_calls_in_flight(native, oracle):
+    """tbc_opts.search_width = 0: 2 configs per round for a register-family batch under both dominance rules at no
+    more than 10 calls in flight on average, else 4; a named width is taken as named.  Whatever it becomes is reported
+    (tbc_result.search_width, tbc_batch_search_width) and is the oracle's schedule at that width, bit for bit."""
+    quiet = [columns.pair_events(synth.register_events(n_ops=2000, n_procs=64, seed=s, busy=0.1)) for s in range(3)]     # 6.4 in flight
+    busy = [columns.pair_events(synth.register_events(n_ops=2000, n_procs=64, seed=s, busy=0.3)) for s in range(3)]     # 19 in flight
+    for hists, kw, want in ((quiet, {}, 2), (busy, {}, 4), (quiet, {"search_width": 8}, 8), (quiet, {"twin_rule": False}, 4),
+                            (quiet, {"algorithm": N.ALG_WGL}, 1)):
+        opts = core.make_opts(**{"time_limit_ms": 60000, "algorithm": N.ALG_COMPETITION, **kw})
+        with core.Batch(hists, gm(), opts) as b:
+            assert b.search_width() == want, (kw, b.search_width())
+            res = b.run().results()
+        if want == 1:
+            continue
+        for h, got in zip(hists, res):
+            exp = oracle.check_beam(h.as_dict(), CAS, want, twin_rule=kw.get("twin_rule", True))
+            assert got["search_width"] == want and got["valid"] == exp["valid"] == 1
+            assert np.array_equal(got["witness"], exp["witness"])
+            assert (got["probes"], got["visited"], got["backtracks"]) == (exp["probes"], exp["visited"], exp["expanded"])
 
 
 @pytest.mark.parametrize("width", [32, 64])
