@@ -61,11 +61,10 @@ __device__ __forceinline__ bool op_ok_for_model(uint32_t kind, uint32_t f, int32
 
 }  // namespace
 
-__global__ __launch_bounds__(1024) void pack_kernel(PackArgs A) {
+__global__ __launch_bounds__(1024, 6) void pack_kernel(PackArgs A) {
   const uint32_t NT = blockDim.x;
   __shared__ uint32_t s_cnt[kMaxSlots];
   __shared__ uint32_t s_seg[kMaxSlots + 1];
-  __shared__ uint32_t s_mark[kMaxSlots];
   __shared__ uint32_t s_part[1024];
   __shared__ uint32_t s_err, s_total, s_done;
   const uint32_t tid = threadIdx.x;
@@ -88,20 +87,36 @@ __global__ __launch_bounds__(1024) void pack_kernel(PackArgs A) {
     Rec* rec = A.rec + H->rec_off;
 
     if (tid == 0) { s_err = 0; s_done = 0; if (A.dbg) { A.dbg[0] = 0x10u; A.dbg[1] = h; } }
-    for (uint32_t p = tid; p < W; p += NT) { s_cnt[p] = 0; s_mark[p] = kInf; }
+    for (uint32_t p = tid; p < W; p += NT) s_cnt[p] = 0;
     __syncthreads();
 
     // phase 1: validate rows, set completion bits, count ops per process
-    for (uint32_t i = tid; i < n; i += NT) {
-      const uint32_t iv = inv[i], rt = ret[i];
-      const int32_t p = proc[i];
-      bool bad = iv >= E || p < 0 || (uint32_t)p >= W || (i > 0 && inv[i - 1] >= iv);
-      if (rt != TBC_POS_CRASHED) bad = bad || rt <= iv || rt >= E;
-      if (bad) { atomicOr(&s_err, (uint32_t)TBC_ERR_BAD_HISTORY); continue; }
-      if (!(A.model_kind == TBC_MODEL_MULTI_REGISTER ? (f[i] == TBC_F_TXN && txn_ok(A, a[i], b[i]))
-                                                    : op_ok_for_model(A.model_kind, f[i], a[i], A.n_classes))) { atomicOr(&s_err, 0x100u | (uint32_t)TBC_ERR_MODEL); continue; }
-      if (rt != TBC_POS_CRASHED) { atomicOr(&bm[rt >> 5], 1u << (rt & 31)); atomicAdd(&s_done, 1u); }
-      atomicAdd(&s_cnt[p], 1u);
+    // (the kernel is bound by memory latency, not issue slots: four rows' columns are requested before the first is
+    // looked at -- the atomics below would otherwise keep every row's loads behind the previous row's)
+    for (uint32_t i0 = tid; i0 < n; i0 += 4u * NT) {
+      uint32_t ivs[4], rts[4], pvs[4]; int32_t ps[4], as[4], bs[4]; uint8_t fs[4];
+#pragma unroll
+      for (uint32_t k = 0; k < 4; k++) {
+        const uint32_t i = i0 + k * NT;
+        const bool in = i < n;
+        ivs[k] = in ? inv[i] : 0u; rts[k] = in ? ret[i] : 0u; ps[k] = in ? proc[i] : 0;
+        pvs[k] = (in && i > 0) ? inv[i - 1] : 0u;
+        fs[k] = in ? f[i] : (uint8_t)0; as[k] = in ? a[i] : 0; bs[k] = in ? b[i] : 0;
+      }
+#pragma unroll
+      for (uint32_t k = 0; k < 4; k++) {
+        const uint32_t i = i0 + k * NT;
+        if (i >= n) continue;
+        const uint32_t iv = ivs[k], rt = rts[k];
+        const int32_t p = ps[k];
+        bool bad = iv >= E || p < 0 || (uint32_t)p >= W || (i > 0 && pvs[k] >= iv);
+        if (rt != TBC_POS_CRASHED) bad = bad || rt <= iv || rt >= E;
+        if (bad) { atomicOr(&s_err, (uint32_t)TBC_ERR_BAD_HISTORY); continue; }
+        if (!(A.model_kind == TBC_MODEL_MULTI_REGISTER ? (fs[k] == TBC_F_TXN && txn_ok(A, as[k], bs[k]))
+                                                      : op_ok_for_model(A.model_kind, fs[k], as[k], A.n_classes))) { atomicOr(&s_err, 0x100u | (uint32_t)TBC_ERR_MODEL); continue; }
+        if (rt != TBC_POS_CRASHED) { atomicOr(&bm[rt >> 5], 1u << (rt & 31)); atomicAdd(&s_done, 1u); }
+        atomicAdd(&s_cnt[p], 1u);
+      }
     }
     __syncthreads();
     // phase 1b: set / bank keep their values in the pool -- every offset the search will dereference
@@ -170,17 +185,35 @@ __global__ __launch_bounds__(1024) void pack_kernel(PackArgs A) {
 
     if (tid == 0 && A.dbg) A.dbg[0] = 0x30u;
     // phase 3: ranks; completion order tables
-    for (uint32_t i = tid; i < n; i += NT) {
-      const uint32_t iv = inv[i], rt = ret[i];
-      const uint32_t ir = ld_agent(&wpre[iv >> 5]) + __popc(ld_agent(&bm[iv >> 5]) & ((1u << (iv & 31)) - 1u));
-      uint32_t rr = kInf;
-      if (rt != TBC_POS_CRASHED) {
-        rr = ld_agent(&wpre[rt >> 5]) + __popc(ld_agent(&bm[rt >> 5]) & ((1u << (rt & 31)) - 1u));
-        A.ret_slot[H->ret_off + rr] = (uint32_t)proc[i];
-        A.ret_op[H->ret_off + rr] = i;
+    for (uint32_t i0 = tid; i0 < n; i0 += 2u * NT) {            // two rows per trip: positions, then the words they index
+      uint32_t ivs[2], rts[2], wi[2], bi[2], wr[2], br[2]; int32_t ps[2];
+#pragma unroll
+      for (uint32_t k = 0; k < 2; k++) {
+        const uint32_t i = i0 + k * NT;
+        const bool in = i < n;
+        ivs[k] = in ? inv[i] : 0u; rts[k] = in ? ret[i] : TBC_POS_CRASHED; ps[k] = in ? proc[i] : 0;
       }
-      sc_inv[i] = ir;
-      sc_ret[i] = rr;
+#pragma unroll
+      for (uint32_t k = 0; k < 2; k++) {
+        const bool live = rts[k] != TBC_POS_CRASHED;
+        wi[k] = ld_agent(&wpre[ivs[k] >> 5]); bi[k] = ld_agent(&bm[ivs[k] >> 5]);
+        wr[k] = live ? ld_agent(&wpre[rts[k] >> 5]) : 0u; br[k] = live ? ld_agent(&bm[rts[k] >> 5]) : 0u;
+      }
+#pragma unroll
+      for (uint32_t k = 0; k < 2; k++) {
+        const uint32_t i = i0 + k * NT;
+        if (i >= n) continue;
+        const uint32_t iv = ivs[k], rt = rts[k];
+        const uint32_t ir = wi[k] + __popc(bi[k] & ((1u << (iv & 31)) - 1u));
+        uint32_t rr = kInf;
+        if (rt != TBC_POS_CRASHED) {
+          rr = wr[k] + __popc(br[k] & ((1u << (rt & 31)) - 1u));
+          A.ret_slot[H->ret_off + rr] = (uint32_t)ps[k];
+          A.ret_op[H->ret_off + rr] = i;
+        }
+        sc_inv[i] = ir;
+        sc_ret[i] = rr;
+      }
     }
 
     // phase 4: segment starts (each list gets a head and a tail sentinel)
@@ -195,30 +228,25 @@ __global__ __launch_bounds__(1024) void pack_kernel(PackArgs A) {
     __syncthreads();
 
     if (tid == 0 && A.dbg) A.dbg[0] = 0x40u;
-    // phase 5: stable position of every op inside its process list.  One wave
-    // walks the ops in invocation order, 64 at a time; lanes of one process
-    // inside a chunk are ranked by repeated LDS min (round r elects the r-th
-    // lowest lane), which a single wave executes in program order.
+    // phase 5: stable position of every op inside its process list.  One wave walks the ops in invocation order, 64
+    // at a time: an op's place = the ops of its process placed by earlier chunks (s_cnt) + the lower lanes of this
+    // chunk that hold an op of the same process (64 broadcasts, counted in registers).  The next chunk's column is
+    // requested before this one is worked on.
     if (tid < 64) {
       const uint32_t lane = tid;
+      uint32_t p_next = lane < n ? (uint32_t)proc[lane] : 0xFFFFFFFFu;
       for (uint32_t base = 0; base < n; base += 64) {
         const uint32_t i = base + lane;
         const bool valid = i < n;
-        const uint32_t p = valid ? (uint32_t)proc[i] : 0u;
-        bool unresolved = valid;
-        uint32_t r = 0, my = 0;
-        while (__ballot(unresolved)) {
-          if (unresolved) atomicMin(&s_mark[p], lane);
-          __builtin_amdgcn_wave_barrier();
-          if (unresolved && __hip_atomic_load(&s_mark[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == lane) {
-            my = __hip_atomic_load(&s_cnt[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + r;
-            unresolved = false;
-            __hip_atomic_store(&s_mark[p], kInf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          }
-          __builtin_amdgcn_wave_barrier();
-          r++;
+        const uint32_t p = p_next;                                   // 0xFFFFFFFF past the end: equal to no process
+        p_next = i + 64u < n ? (uint32_t)proc[i + 64u] : 0xFFFFFFFFu;
+        uint32_t before = 0;
+#pragma unroll 8
+        for (uint32_t l = 0; l < 64; l++) {
+          const uint32_t pl = __builtin_amdgcn_readlane(p, l);
+          before += (pl == p && l < lane) ? 1u : 0u;
         }
-        if (valid) sc_dst[i] = s_seg[p] + 1 + my;
+        if (valid) sc_dst[i] = s_seg[p] + 1u + __hip_atomic_load(&s_cnt[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + before;
         __builtin_amdgcn_wave_barrier();
         if (valid) atomicAdd(&s_cnt[p], 1u);
         __builtin_amdgcn_wave_barrier();
@@ -228,14 +256,22 @@ __global__ __launch_bounds__(1024) void pack_kernel(PackArgs A) {
 
     if (tid == 0 && A.dbg) A.dbg[0] = 0x50u;
     // phase 6: scatter the records, write the sentinels
-    for (uint32_t i = tid; i < n; i += NT) {
-      Rec r;
-      r.inv_rank = sc_inv[i]; r.ret_rank = sc_ret[i]; r.opidx = i; r.f = f[i];
-      r.a = a[i]; r.b = b[i]; r.pad0 = 0; r.pad1 = 0;
-      rec[ld_agent(&sc_dst[i])] = r;
+    for (uint32_t i0 = tid; i0 < n; i0 += 4u * NT) {            // four records per trip
+      Rec r[4]; uint32_t dst[4];
+#pragma unroll
+      for (uint32_t k = 0; k < 4; k++) {
+        const uint32_t i = i0 + k * NT;
+        const bool in = i < n;
+        r[k].inv_rank = in ? sc_inv[i] : 0u; r[k].ret_rank = in ? sc_ret[i] : 0u; r[k].opidx = i; r[k].f = in ? f[i] : 0u;
+        r[k].a = in ? a[i] : 0; r[k].b = in ? b[i] : 0;
+        r[k].cls = rec_cls(r[k].f, r[k].a, r[k].ret_rank == kInf); r[k].prod = look_prod(r[k].f, r[k].a, r[k].b);
+        dst[k] = in ? ld_agent(&sc_dst[i]) : 0u;
+      }
+#pragma unroll
+      for (uint32_t k = 0; k < 4; k++) if (i0 + k * NT < n) rec[dst[k]] = r[k];
     }
     for (uint32_t p = tid; p < W; p += NT) {
-      Rec hd; hd.inv_rank = 0; hd.ret_rank = 0; hd.opidx = kInf; hd.f = kFNone; hd.a = 0; hd.b = 0; hd.pad0 = 0; hd.pad1 = 0;
+      Rec hd; hd.inv_rank = 0; hd.ret_rank = 0; hd.opidx = kInf; hd.f = kFNone; hd.a = 0; hd.b = 0; hd.cls = 0; hd.prod = kLookNone;
       Rec tl = hd; tl.inv_rank = kInf; tl.ret_rank = kInf;
       rec[s_seg[p]] = hd;
       rec[s_seg[p + 1] - 1] = tl;
@@ -245,11 +281,22 @@ __global__ __launch_bounds__(1024) void pack_kernel(PackArgs A) {
     if (tid == 0 && A.dbg) A.dbg[0] = 0x60u;
     // phase 7: one open op per process: the previous op of the same process
     // must have completed before this one was invoked
-    for (uint32_t i = tid; i < n; i += NT) {
-      const uint32_t d = ld_agent(&sc_dst[i]);
-      const uint32_t* prev = reinterpret_cast<const uint32_t*>(&rec[d - 1]);
-      const uint32_t prev_ret = ld_agent(prev + 1), prev_f = ld_agent(prev + 3);
-      if (prev_f != kFNone && !(prev_ret < sc_inv[i])) atomicOr(&s_err, (uint32_t)TBC_ERR_BAD_HISTORY);
+    for (uint32_t i0 = tid; i0 < n; i0 += 4u * NT) {            // four ops per trip (two dependent trips each)
+      uint32_t d[4], mine[4], prev_ret[4], prev_f[4];
+#pragma unroll
+      for (uint32_t k = 0; k < 4; k++) {
+        const uint32_t i = i0 + k * NT;
+        d[k] = i < n ? ld_agent(&sc_dst[i]) : 1u;           // (record 0 of the history is a head sentinel: d - 1 stays in range)
+        mine[k] = i < n ? sc_inv[i] : 0u;
+      }
+#pragma unroll
+      for (uint32_t k = 0; k < 4; k++) {
+        const uint32_t* prev = reinterpret_cast<const uint32_t*>(&rec[d[k] - 1]);
+        prev_ret[k] = ld_agent(prev + 1); prev_f[k] = ld_agent(prev + 3);
+      }
+#pragma unroll
+      for (uint32_t k = 0; k < 4; k++)
+        if (i0 + k * NT < n && prev_f[k] != kFNone && !(prev_ret[k] < mine[k])) atomicOr(&s_err, (uint32_t)TBC_ERR_BAD_HISTORY);
     }
     __syncthreads();
     if (tid == 0) { H->n_ret = R; H->status = s_err ? (uint32_t)TBC_ERR_BAD_HISTORY : 0u; if (A.dbg) A.dbg[0] = 0x90u; }

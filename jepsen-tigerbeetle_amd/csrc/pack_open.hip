@@ -60,13 +60,19 @@ __device__ __forceinline__ void scan_parts(uint32_t* part, uint32_t NT, uint32_t
   }
 }
 
-// register value a call must find / leaves behind, as a lookahead byte (0..31, else kLookNone)
-__device__ __forceinline__ uint32_t look_val(int32_t v) { return (v >= 0 && v < 32) ? (uint32_t)v : kLookNone; }
-__device__ __forceinline__ uint32_t look_need(uint32_t f, int32_t a) {
-  return ((f == TBC_F_READ && a != TBC_NIL) || f == TBC_F_CAS) ? look_val(a) : kLookNone;
-}
-__device__ __forceinline__ uint32_t look_prod(uint32_t f, int32_t a, int32_t b) {
-  return f == TBC_F_WRITE ? look_val(a) : (f == TBC_F_CAS ? look_val(b) : kLookNone);
+// The per-history kernels below are bound by memory latency, not by issue slots (3-9 % vector ALU use): a thread that
+// waits for every load before it asks for the next spends a pass of 30 elements on 30 trips.  These helpers put up to
+// eight loads in flight before the first is consumed; the passes keep their order of operations.
+constexpr uint32_t kBatch = 8;
+template <class F>
+__device__ __forceinline__ void chunk_loads(const uint32_t* p, uint32_t lo, uint32_t hi, F&& each) {
+  for (uint32_t i = lo; i < hi; i += kBatch) {
+    uint32_t v[kBatch];
+#pragma unroll
+    for (uint32_t k = 0; k < kBatch; k++) v[k] = i + k < hi ? ld_agent(&p[i + k]) : 0u;
+#pragma unroll
+    for (uint32_t k = 0; k < kBatch; k++) if (i + k < hi) each(i + k, v[k]);
+  }
 }
 
 }  // namespace
@@ -100,12 +106,23 @@ __global__ __launch_bounds__(1024) void open_counts_kernel(PackOpenArgs A) {
 
     // A: histogram of the live calls' invocation ranks (in off[]), crashed-call counts by front, completion slots as bytes
     for (uint32_t r = tid; r < R + 16u; r += NT) slot8[r] = r < R ? (uint8_t)ret_slot[r] : (uint8_t)0;
-    for (uint32_t i = tid; i < n; i += NT) {
-      const uint32_t ir = sc_inv[i], rr = sc_ret[i];
-      if (rr == kInf) {
-        if (ir < R && !(f[i] == TBC_F_READ && a[i] == TBC_NIL)) atomicAdd(&ncr[ir], 1u);
-      } else {
-        atomicAdd(&off[ir], 1u);
+    for (uint32_t i0 = tid; i0 < n; i0 += 4u * NT) {          // four ops per trip
+      uint32_t ir[4], rr[4]; bool nilread[4];
+#pragma unroll
+      for (uint32_t k = 0; k < 4; k++) {
+        const uint32_t i = i0 + k * NT;
+        const bool in = i < n;
+        ir[k] = in ? sc_inv[i] : 0u; rr[k] = in ? sc_ret[i] : 0u;
+        nilread[k] = in && f[i] == TBC_F_READ && a[i] == TBC_NIL;
+      }
+#pragma unroll
+      for (uint32_t k = 0; k < 4; k++) {
+        if (i0 + k * NT >= n) continue;
+        if (rr[k] == kInf) {
+          if (ir[k] < R && !nilread[k]) atomicAdd(&ncr[ir[k]], 1u);
+        } else {
+          atomicAdd(&off[ir[k]], 1u);
+        }
       }
     }
     __syncthreads();
@@ -116,7 +133,7 @@ __global__ __launch_bounds__(1024) void open_counts_kernel(PackOpenArgs A) {
       const uint32_t chunk = (R + NT - 1) / NT;
       const uint32_t lo = min(tid * chunk, R), hi = min(lo + chunk, R);
       uint32_t sum = 0;
-      for (uint32_t i = lo; i < hi; i++) sum += ld_agent(&off[i]);
+      chunk_loads(off, lo, hi, [&](uint32_t, uint32_t v) { sum += v; });
       s_part[tid] = sum;
       __syncthreads();
       scan_parts(s_part, NT, nullptr);
@@ -124,14 +141,14 @@ __global__ __launch_bounds__(1024) void open_counts_kernel(PackOpenArgs A) {
       const uint32_t base_inv = s_part[tid];          // live calls invoked before this chunk's first rank
       __syncthreads();
       uint32_t run = base_inv, open_sum = 0;
-      for (uint32_t i = lo; i < hi; i++) { run += ld_agent(&off[i]); open_sum += run - i; }
+      chunk_loads(off, lo, hi, [&](uint32_t i, uint32_t v) { run += v; open_sum += run - i; });
       s_part[tid] = open_sum;
       __syncthreads();
       scan_parts(s_part, NT, &s_total);
       __syncthreads();
       uint32_t pos = s_part[tid];
       run = base_inv;
-      for (uint32_t i = lo; i < hi; i++) { run += ld_agent(&off[i]); off[i] = pos; pos += run - i; }
+      chunk_loads(off, lo, hi, [&](uint32_t i, uint32_t v) { run += v; off[i] = pos; pos += run - i; });
       total = s_total;
       if (tid == 0) off[R] = total;
       __syncthreads();
@@ -141,13 +158,13 @@ __global__ __launch_bounds__(1024) void open_counts_kernel(PackOpenArgs A) {
       const uint32_t chunk = (R + NT - 1) / NT;
       const uint32_t lo = min(tid * chunk, R), hi = min(lo + chunk, R);
       uint32_t sum = 0;
-      for (uint32_t i = lo; i < hi; i++) sum += ld_agent(&ncr[i]);
+      chunk_loads(ncr, lo, hi, [&](uint32_t, uint32_t v) { sum += v; });
       s_part[tid] = sum;
       __syncthreads();
       scan_parts(s_part, NT, nullptr);
       __syncthreads();
       uint32_t run = s_part[tid];
-      for (uint32_t i = lo; i < hi; i++) { run += ld_agent(&ncr[i]); ncr[i] = run; }
+      chunk_loads(ncr, lo, hi, [&](uint32_t i, uint32_t v) { run += v; ncr[i] = run; });
       __syncthreads();
     }
     if (total > B->lst_cap) {
@@ -159,17 +176,41 @@ __global__ __launch_bounds__(1024) void open_counts_kernel(PackOpenArgs A) {
     {
       const uint32_t chunk = (n + NT - 1) / NT;
       const uint32_t lo = min(tid * chunk, n), hi = min(lo + chunk, n);
+      // which of this thread's ops are crashed candidates: one bit each (a chunk is at most 64 ops, else the slow way)
+      const bool small = hi - lo <= 64u;
+      uint64_t mine = 0;
       uint32_t cnt = 0;
-      for (uint32_t i = lo; i < hi; i++) cnt += sc_ret[i] == kInf && !(f[i] == TBC_F_READ && a[i] == TBC_NIL);
+      if (small) {
+        for (uint32_t i = lo; i < hi; i += kBatch) {
+          uint32_t rr[kBatch]; uint8_t ff[kBatch]; int32_t aa[kBatch];
+#pragma unroll
+          for (uint32_t k = 0; k < kBatch; k++) { const bool in = i + k < hi; rr[k] = in ? sc_ret[i + k] : 0u; ff[k] = in ? f[i + k] : (uint8_t)0; aa[k] = in ? a[i + k] : 0; }
+#pragma unroll
+          for (uint32_t k = 0; k < kBatch; k++)
+            if (i + k < hi && rr[k] == kInf && !(ff[k] == TBC_F_READ && aa[k] == TBC_NIL)) mine |= 1ull << (i + k - lo);
+        }
+        cnt = (uint32_t)__popcll(mine);
+      } else {
+        for (uint32_t i = lo; i < hi; i++) cnt += sc_ret[i] == kInf && !(f[i] == TBC_F_READ && a[i] == TBC_NIL);
+      }
       s_part[tid] = cnt;
       __syncthreads();
       scan_parts(s_part, NT, &s_total);
       __syncthreads();
       if (tid == 0) { B->n_crashed = s_total; B->status = 0; }
       uint32_t run = s_part[tid];
-      for (uint32_t i = lo; i < hi; i++) if (sc_ret[i] == kInf && !(f[i] == TBC_F_READ && a[i] == TBC_NIL)) {
-        OpRec o; o.op = i; o.f_slot = (uint32_t)f[i] | ((uint32_t)proc[i] << 8); o.a = a[i]; o.b = b[i];
-        crashed[run++] = o;
+      if (small) {
+        while (mine) {
+          const uint32_t i = lo + (uint32_t)__builtin_ctzll(mine);
+          mine &= mine - 1ull;
+          OpRec o; o.op = i; o.f_slot = (uint32_t)f[i] | ((uint32_t)proc[i] << 8); o.a = a[i]; o.b = b[i];
+          crashed[run++] = o;
+        }
+      } else {
+        for (uint32_t i = lo; i < hi; i++) if (sc_ret[i] == kInf && !(f[i] == TBC_F_READ && a[i] == TBC_NIL)) {
+          OpRec o; o.op = i; o.f_slot = (uint32_t)f[i] | ((uint32_t)proc[i] << 8); o.a = a[i]; o.b = b[i];
+          crashed[run++] = o;
+        }
       }
       __syncthreads();
     }
@@ -191,11 +232,8 @@ namespace {
 // cls bit 0 = a call at all, 1 = live (completes), 2 = crashed and a candidate (not a nil read), 3 = write / cas, 4 = read
 struct Cur { uint32_t inv, ret, op, f; int32_t a, b; uint32_t cls, prod; };
 __device__ __forceinline__ Cur load_cur(const Rec* r) {
-  const Rec x = *r;
-  const bool any = x.f != kFNone, crashed = x.ret_rank == kInf;
-  const uint32_t cls = (any ? 1u : 0u) | (any && !crashed ? 2u : 0u) | (any && crashed && !(x.f == TBC_F_READ && x.a == TBC_NIL) ? 4u : 0u) |
-                       ((x.f == TBC_F_WRITE || x.f == TBC_F_CAS) ? 8u : 0u) | (x.f == TBC_F_READ ? 16u : 0u);
-  return Cur{x.inv_rank, x.ret_rank, x.opidx, x.f, x.a, x.b, cls, look_prod(x.f, x.a, x.b)};
+  const Rec x = *r;            // cls / prod come with the record (pack.hip phase 6)
+  return Cur{x.inv_rank, x.ret_rank, x.opidx, x.f, x.a, x.b, x.cls, x.prod};
 }
 }  // namespace
 
@@ -383,18 +421,34 @@ __global__ __launch_bounds__(1024) void open_dprod_kernel(PackOpenArgs A) {
       const uint32_t pv = look_prod(f[i], a[i], b[i]);
       if (pv == kLookNone || (sc_ret[i] == kInf && f[i] == TBC_F_READ)) continue;
       const uint32_t ir = sc_inv[i];
-      for (uint32_t t = ir; t < R && t < ir + kLookahead; t++) {
-        const uint32_t need = (uint32_t)(ld_agent64(&look[(uint64_t)t * LW]) >> 16) & 0xFFu;
-        if (need == pv && ret_op[t] != i) atomicMin(&tmp[t], t - ir);
+      uint64_t w[kLookahead]; uint32_t ro[kLookahead];          // the records and completing ops of the next ranks: one trip
+#pragma unroll
+      for (uint32_t k = 0; k < kLookahead; k++) {
+        const uint32_t t = ir + k;
+        const bool in = t < R;
+        w[k] = in ? ld_agent64(&look[(uint64_t)t * LW]) : 0ull;
+        ro[k] = in ? ret_op[t] : 0u;
+      }
+#pragma unroll
+      for (uint32_t k = 0; k < kLookahead; k++) {
+        const uint32_t t = ir + k;
+        if (t < R && ((uint32_t)(w[k] >> 16) & 0xFFu) == pv && ro[k] != i) atomicMin(&tmp[t], k);
       }
     }
     __syncthreads();
     // G: fold dprod into the records
-    for (uint32_t t = tid; t < R; t += NT) {
-      const uint32_t d = ld_agent(&tmp[t]);
-      if (d < 255u) {
-        const uint64_t w0 = ld_agent64(&look[(uint64_t)t * LW]);
-        look[(uint64_t)t * LW] = (w0 & ~(255ull << 40)) | ((uint64_t)d << 40);
+    for (uint32_t t0 = tid; t0 < R; t0 += 4u * NT) {            // four ranks per trip
+      uint32_t d[4]; uint64_t w0[4];
+#pragma unroll
+      for (uint32_t k = 0; k < 4; k++) {
+        const uint32_t t = t0 + k * NT;
+        d[k] = t < R ? ld_agent(&tmp[t]) : 255u;
+        w0[k] = t < R ? ld_agent64(&look[(uint64_t)t * LW]) : 0ull;
+      }
+#pragma unroll
+      for (uint32_t k = 0; k < 4; k++) {
+        const uint32_t t = t0 + k * NT;
+        if (t < R && d[k] < 255u) look[(uint64_t)t * LW] = (w0[k] & ~(255ull << 40)) | ((uint64_t)d[k] << 40);
       }
     }
     __syncthreads();

@@ -24,7 +24,8 @@ struct __attribute__((aligned(16))) Rec {
   uint32_t opidx;      // index in the caller's op columns (= invocation order)
   uint32_t f;          // TBC_F_* or kFNone
   int32_t a, b;
-  uint32_t pad0, pad1;
+  uint32_t cls;        // what the front walk (pack_open.hip) asks of the call at every front, worked out once: rec_cls()
+  uint32_t prod;       // the register value it leaves behind as a lookahead byte (look_prod()), kLookNone if none
 };
 static_assert(sizeof(Rec) == 32, "Rec must be 32 bytes");
 
@@ -135,6 +136,22 @@ constexpr uint32_t kAtFront = 0x80000000u;
 //   words 1..: slots of the other calls open at front t (crashed ones included) that produce `need`
 constexpr uint32_t kLookahead = 8;          // completions looked at per new config
 constexpr uint32_t kLookNone = 0xFFu;
+#ifdef __HIPCC__
+// register value a call must find / leaves behind, as a lookahead byte (0..31, else kLookNone)
+__host__ __device__ inline uint32_t look_val(int32_t v) { return (v >= 0 && v < 32) ? (uint32_t)v : kLookNone; }
+__host__ __device__ inline uint32_t look_need(uint32_t f, int32_t a) {
+  return ((f == TBC_F_READ && a != TBC_NIL) || f == TBC_F_CAS) ? look_val(a) : kLookNone;
+}
+__host__ __device__ inline uint32_t look_prod(uint32_t f, int32_t a, int32_t b) {
+  return f == TBC_F_WRITE ? look_val(a) : (f == TBC_F_CAS ? look_val(b) : kLookNone);
+}
+// Rec.cls: bit 0 = a call at all (not a sentinel), 1 = live (completes), 2 = crashed and a candidate (not a nil read),
+// 3 = write / cas, 4 = read
+__host__ __device__ inline uint32_t rec_cls(uint32_t f, int32_t a, bool crashed) {
+  return 1u | (!crashed ? 2u : 0u) | (crashed && !(f == TBC_F_READ && a == TBC_NIL) ? 4u : 0u) |
+         ((f == TBC_F_WRITE || f == TBC_F_CAS) ? 8u : 0u) | (f == TBC_F_READ ? 16u : 0u);
+}
+#endif
 constexpr uint32_t kLookPad = 16;           // records past the last rank (all kLookNone) per history
 __host__ __device__ inline uint64_t look_off(uint64_t op_off, uint64_t h, uint32_t mask_words) {
   return (op_off + (uint64_t)kLookPad * h) * (1u + mask_words);

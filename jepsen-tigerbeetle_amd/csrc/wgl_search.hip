@@ -49,7 +49,7 @@ __device__ __forceinline__ Rec load_rec(const Rec* p) {
   const uint4 x = q[0], y = q[1];
   Rec r;
   r.inv_rank = x.x; r.ret_rank = x.y; r.opidx = x.z; r.f = x.w;
-  r.a = (int32_t)y.x; r.b = (int32_t)y.y; r.pad0 = 0; r.pad1 = 0;
+  r.a = (int32_t)y.x; r.b = (int32_t)y.y; r.cls = 0; r.prod = 0;
   return r;
 }
 
