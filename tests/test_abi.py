@@ -56,6 +56,29 @@ int main(void){ printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(tbc_e
     assert mine == sizes
 
 
+def test_result_offsets_the_jna_shim_reads(native):
+    """INTEGRATION.md's Clojure shim reads tbc_result by byte offset; tbc_result.search_width took the padding hole in
+    front of the witness pointer this round -- nothing else may have moved."""
+    prog = r'''
+#include <stdio.h>
+#include "tbcheck.h"
+int main(void){ printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", offsetof(tbc_result, valid), offsetof(tbc_result, cause),
+  offsetof(tbc_result, analyzer), offsetof(tbc_result, fail_op), offsetof(tbc_result, prev_ok_op), offsetof(tbc_result, final_state),
+  offsetof(tbc_result, n_witness), offsetof(tbc_result, search_width), offsetof(tbc_result, witness), offsetof(tbc_result, n_configs),
+  offsetof(tbc_result, configs)); return 0; }
+'''
+    with tempfile.TemporaryDirectory() as d:
+        src = os.path.join(d, "o.c")
+        open(src, "w").write(prog)
+        exe = os.path.join(d, "o")
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), src, "-o", exe])
+        offs = [int(x) for x in subprocess.check_output([exe]).split()]
+    assert offs == [0, 4, 8, 12, 16, 20, 24, 28, 32, 40, 44]
+    R = native.Result
+    assert [R.valid.offset, R.fail_op.offset, R.search_width.offset, R.witness.offset, R.n_configs.offset, R.configs.offset] == [0, 12, 28, 32, 40, 44]
+    assert C.sizeof(R) == 960
+
+
 @pytest.mark.skipif(has_gpu(), reason="only meaningful on a box without a GPU")
 def test_no_cpu_fallback(native):
     from jepsen_tigerbeetle_amd import columns, core, synth
