@@ -159,7 +159,8 @@ def rules_apply(ops, model, round_pairs=64):
     return bool(len(v) == 0 or (v.min() >= 0 and v.max() <= 30))
 
 
-def check_beam(ops, model, width=16, max_probes=0, want_witness=True, round_pairs=64, widen_after=0, lookahead=None, eager_reads=None, twin_rule=None):
+def check_beam(ops, model, width=16, max_probes=0, want_witness=True, round_pairs=64, widen_after=0, lookahead=None, eager_reads=None, twin_rule=None,
+               twin_selfcheck=False):
     """The wide (K configs per iteration) schedule of the same search: wgl_beam.c.
 
     lookahead: None = what the library does by default (on for register / cas-register under the
@@ -176,11 +177,20 @@ def check_beam(ops, model, width=16, max_probes=0, want_witness=True, round_pair
         eager_reads = twin_rule = False
     lib().wgl_beam_set_eager_reads(C.c_uint32(1 if eager_reads else 0))
     lib().wgl_beam_set_twin_rule(C.c_uint32(1 if twin_rule else 0))
+    # twin_selfcheck: evaluate every twin test of a crashed candidate also by the previous-crashed-twin shortcut
+    # (wgl_beam.c) and report how many were compared / disagreed as twin_checked / twin_mismatch
+    lib().wgl_beam_set_twin_selfcheck(C.c_uint32(1 if twin_selfcheck else 0))
     try:
-        return _check_beam(ops, model, width, max_probes, want_witness, round_pairs, widen_after, bool(lookahead))
+        r = _check_beam(ops, model, width, max_probes, want_witness, round_pairs, widen_after, bool(lookahead))
+        if twin_selfcheck:
+            lib().wgl_beam_twin_checked.restype = C.c_uint64
+            lib().wgl_beam_twin_mismatch.restype = C.c_uint64
+            r["twin_checked"], r["twin_mismatch"] = int(lib().wgl_beam_twin_checked()), int(lib().wgl_beam_twin_mismatch())
+        return r
     finally:
         lib().wgl_beam_set_eager_reads(C.c_uint32(0))
         lib().wgl_beam_set_twin_rule(C.c_uint32(0))
+        lib().wgl_beam_set_twin_selfcheck(C.c_uint32(0))
 
 
 def _check_beam(ops, model, width, max_probes, want_witness, round_pairs, widen_after, lookahead):

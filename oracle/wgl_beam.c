@@ -151,6 +151,16 @@ uint64_t wgl_beam_pruned(void) { return g_pruned; }
  * or the lookahead rule called a live config dead (the verdict would still be right) */
 static uint64_t g_late_valid = 0;
 uint64_t wgl_beam_late_valid(void) { return g_late_valid; }
+/* Self-check of a cheaper twin test for CRASHED candidates (not what the kernel does yet):
+ * crashed calls of one effect are linearized in invocation order under the rule, so among the crashed ones only the
+ * PREVIOUS call of the same effect has to be looked at -- the walk over the front's list shrinks to its live entries.
+ * When switched on, every twin test of a crashed candidate is evaluated both ways; the counters say how often and
+ * whether the two ever disagreed. */
+static uint32_t g_twin_selfcheck = 0;
+static uint64_t g_twin_checked = 0, g_twin_mismatch = 0;
+void wgl_beam_set_twin_selfcheck(uint32_t on) { g_twin_selfcheck = on; g_twin_checked = 0; g_twin_mismatch = 0; }
+uint64_t wgl_beam_twin_checked(void) { return g_twin_checked; }
+uint64_t wgl_beam_twin_mismatch(void) { return g_twin_mismatch; }
 
 /* ---- experiment knobs (all off by default; NOT part of the specified schedule, no kernel counterpart).
  * They produced the negative results recorded in DESIGN.md section 6 (the tail of a batch):
@@ -277,6 +287,20 @@ int wgl_beam_check_rp(uint32_t n, const uint8_t* f, const int32_t* a, const int3
         lst[y] = v;
       } }
 
+  /* previous crashed call of the same effect (index into crashed[], 0xFFFFFFFF = none): the self-check above */
+  uint32_t* prev_twin = NULL;
+  if (g_twin_selfcheck) {
+    prev_twin = (uint32_t*)malloc(4 * ((size_t)n_crashed + 1));
+    for (uint32_t k = 0; k < n_crashed; k++) {
+      const uint32_t x = crashed[k];
+      prev_twin[k] = 0xFFFFFFFFu;
+      for (uint32_t j = k; j-- > 0;) {
+        const uint32_t y = crashed[j];
+        if (f[y] == f[x] && a[y] == a[x] && (f[x] != O_CAS || b[y] == b[x])) { prev_twin[k] = j; break; }
+      }
+    }
+  }
+
   arena ar; ar.kw = KW; ar.cap = 4096; ar.n = 1; ar.nslots = 8192;
   ar.keys = (uint64_t*)calloc(ar.cap * KW, 8); ar.parent = (uint32_t*)calloc(ar.cap, 4); ar.op = (uint32_t*)calloc(ar.cap, 4);
   ar.slots = (uint32_t*)calloc(ar.nslots, 4);
@@ -363,6 +387,22 @@ int wgl_beam_check_rp(uint32_t n, const uint8_t* f, const int32_t* a, const int3
             if (y == op || f[y] != f[op] || a[y] != a[op] || (f[op] == O_CAS && b[y] != b[op])) continue;
             if (pk[1 + (py >> 6)] >> (py & 63) & 1) continue;
             if (ret_rank[y] < ret_rank[op] || (ret_rank[y] == ret_rank[op] && y < op)) dominated = 1;
+          }
+          if (g_twin_selfcheck && c >= nlive) {
+            int fast = 0;
+            for (uint32_t cc = 0; cc < nlive && !fast; cc++) {          /* live calls of the same effect: all complete earlier */
+              uint32_t y = lst[off[fi] + cc];
+              uint32_t py = (uint32_t)process[y];
+              if (f[y] != f[op] || a[y] != a[op] || (f[op] == O_CAS && b[y] != b[op])) continue;
+              if (!(pk[1 + (py >> 6)] >> (py & 63) & 1)) fast = 1;
+            }
+            const uint32_t pt = prev_twin[c - nlive];
+            if (!fast && pt != 0xFFFFFFFFu) {
+              uint32_t py = (uint32_t)process[crashed[pt]];
+              if (!(pk[1 + (py >> 6)] >> (py & 63) & 1)) fast = 1;
+            }
+            g_twin_checked++;
+            if (fast != dominated) g_twin_mismatch++;
           }
           if (dominated) continue;
         }
@@ -501,7 +541,7 @@ int wgl_beam_check_rp(uint32_t n, const uint8_t* f, const int32_t* a, const int3
     g_bsort_kw = KW;
     qsort(g_bcfg, g_bcfg_n, KW * 8, cmp_bcfg);
   }
-  free(rets); free(ret_rank); free(inv_rank); free(ret_op); free(off); free(ncr); free(lst); free(fill); free(crashed);
+  free(rets); free(ret_rank); free(inv_rank); free(ret_op); free(off); free(ncr); free(lst); free(fill); free(crashed); free(prev_twin);
   free(open_ops); free(open_lin);
   free(ar.keys); free(ar.parent); free(ar.op); free(ar.slots); free(stack); free(dstack); free(key); free(ck);
   return 0;

@@ -168,3 +168,20 @@ def test_dominance_rules_never_change_a_verdict(oracle):
     a = oracle.check_beam(big, m, 4, want_witness=False, eager_reads=False, twin_rule=False)
     b = oracle.check_beam(big, m, 4, want_witness=False, eager_reads=True, twin_rule=False)
     assert a["valid"] == b["valid"] == 1 and b["rounds"] * 4 < a["rounds"]
+
+
+def test_crashed_twin_shortcut_agrees_with_the_list_walk(oracle):
+    """Groundwork for the next kernel change: under the twin rule crashed calls of one effect are
+    linearized in invocation order, so a crashed candidate only has to look at the live entries of its front and at
+    the PREVIOUS crashed call of its effect.  wgl_beam.c evaluates both forms on every such test when asked to."""
+    from jepsen_tigerbeetle_amd import columns, synth
+    m = {"kind": 1, "init": -2147483648}
+    checked = 0
+    for seed in range(4):
+        for (n, p, info, busy, corrupt) in ((1500, 24, 0.03, 0.3, 0.0), (1000, 16, 0.05, 0.5, 0.3)):
+            ops = columns.pair_events(synth.register_events(n_ops=n, n_procs=p, seed=seed, busy=busy, info=info, corrupt=corrupt))
+            for w in (2, 16):
+                r = oracle.check_beam(ops.as_dict(), m, w, max_probes=1_000_000, want_witness=False, twin_selfcheck=True)
+                checked += r["twin_checked"]
+                assert r["twin_mismatch"] == 0
+    assert checked > 100_000
