@@ -52,6 +52,34 @@ def kernel_sha():
     return h.hexdigest()[:16]
 
 
+def usable_cores():
+    """Host threads this process can actually keep busy: the CPUs it may run on, capped by the container's CPU-time
+    quota (cgroup v2 cpu.max / v1 cpu.cfs_quota_us) -- os.cpu_count() reports the machine, not the allowance (the GPU
+    boxes of this pool show 256 CPUs under a quota of 16)."""
+    import math
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    quota = None
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = int(q) / int(period)
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / period
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        n = max(1, min(n, int(math.ceil(quota))))
+    return n, (os.cpu_count() or 1), quota
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -252,8 +280,8 @@ def main():
             tc = time.perf_counter() - tc
             # all host cores: the same sample on a pthread pool inside the C oracle (oracle/many.c), one history per
             # thread at a time -- how stock Knossos would spread independent keys over a thread pool
-            cores = os.cpu_count() or 1
-            reps = max(1, (4 * cores + S - 1) // S)
+            cores, cores_visible, cpu_quota = usable_cores()
+            reps = max(1, (64 * cores + S - 1) // S)
             work = dicts * reps
             wgl.check_many(work[:cores], om, cores)                                     # spin up / page in
             ta = time.perf_counter()
@@ -272,7 +300,8 @@ def main():
             ts = time.perf_counter() - ts
             line["cpu_baseline"] = {"value": round(len(work) / ta, 3), "unit": "histories/s", "cores": cores, "kind": "port",
                                     "sample": f"first {S} histories of this batch x {reps}, oracle/wgl_window.c (C restatement of "
-                                              f"knossos.wgl, gcc -O2) on {started} pthreads (oracle/many.c); not stock Knossos (no JVM here)",
+                                              f"knossos.wgl, gcc -O2) on {started} pthreads (oracle/many.c) = the CPUs this container may use "
+                                              f"({cores_visible} visible, CPU-time quota {cpu_quota}); not stock Knossos (no JVM here)",
                                     "single_thread": {"value": round(S1 / tc, 3), "unit": "histories/s", "cores": 1,
                                                       "ms_per_history": round(tc / S1 * 1e3, 3), "sample": f"first {S1} histories"},
                                     "ms_per_history": round(tc / S1 * 1e3, 3),
@@ -281,7 +310,7 @@ def main():
                                                                 "sample": f"first {S1} histories, oracle/wgl_beam.c with lookahead + eager reads + twin rule"},
                                     "level_sweep_on_cpu": {"value": round(S1 / ts, 3), "unit": "histories/s", "cores": 1,
                                                            "sample": f"first {S1} histories, oracle/sweep_ref.c"},
-                                    "host_cores_available": cores}
+                                    "host_cores_visible": cores_visible, "host_cpu_quota": cpu_quota}
             assert okw == oks == ok1 == sum(int(v == N.VALID) for v in verdicts[:S1]), "GPU and oracles disagree on the sample"
             assert sum(int(v == 1) for v in oka[:S]) == sum(int(v == N.VALID) for v in verdicts[:S]), "GPU and oracle disagree on the sample"
             line["extra"]["time_to_verdict_ms"]["vs_cpu_port_single_thread"] = round((tc / S1 * 1e3) / statistics.median(ttv), 2)
