@@ -295,6 +295,10 @@ def main():
             tw = time.perf_counter()
             okw = sum(wgl.check_beam(d, om, width if width > 1 else 4, want_witness=False)["valid"] == 1 for d in dicts[:S1])
             tw = time.perf_counter() - tw
+            # ... and on every CPU this container may use (oracle/many.c runs wgl_beam.c on the same thread pool)
+            twa = time.perf_counter()
+            okwa, _ = wgl.check_many(work, om, cores, beam_width=width if width > 1 else 4)
+            twa = time.perf_counter() - twa
             ts = time.perf_counter()
             oks = sum(wgl.check_sweep(d, om)["valid"] == 1 for d in dicts[:S1])
             ts = time.perf_counter() - ts
@@ -307,12 +311,15 @@ def main():
                                     "ms_per_history": round(tc / S1 * 1e3, 3),
                                     "invalid_example_ms": round(tb * 1e3, 3), "invalid_example_verdict": rbo["valid"],
                                     "same_schedule_as_kernel": {"value": round(S1 / tw, 3), "unit": "histories/s", "cores": 1,
-                                                                "sample": f"first {S1} histories, oracle/wgl_beam.c with lookahead + eager reads + twin rule"},
+                                                                "sample": f"first {S1} histories, oracle/wgl_beam.c with lookahead + eager reads + twin rule",
+                                                                "all_cores": {"value": round(len(work) / twa, 3), "unit": "histories/s", "cores": cores,
+                                                                              "sample": f"the all-cores sample ({len(work)} histories) on {cores} pthreads"}},
                                     "level_sweep_on_cpu": {"value": round(S1 / ts, 3), "unit": "histories/s", "cores": 1,
                                                            "sample": f"first {S1} histories, oracle/sweep_ref.c"},
                                     "host_cores_visible": cores_visible, "host_cpu_quota": cpu_quota}
             assert okw == oks == ok1 == sum(int(v == N.VALID) for v in verdicts[:S1]), "GPU and oracles disagree on the sample"
             assert sum(int(v == 1) for v in oka[:S]) == sum(int(v == N.VALID) for v in verdicts[:S]), "GPU and oracle disagree on the sample"
+            assert sum(int(v == 1) for v in okwa[:S]) == sum(int(v == N.VALID) for v in verdicts[:S]), "GPU and oracle (wide schedule, thread pool) disagree on the sample"
             line["extra"]["time_to_verdict_ms"]["vs_cpu_port_single_thread"] = round((tc / S1 * 1e3) / statistics.median(ttv), 2)
 
             if not args.no_tiers:

@@ -5,7 +5,9 @@
  * (the sequential knossos.wgl restatement) over a list of histories with a pthread pool, so the
  * "one MI355X vs this host" ratio is not limited by Python's dispatch.  Each worker takes the next
  * history off a shared counter; every history is checked by exactly one thread, as stock Knossos
- * would check independent keys on a thread pool (jepsen.independent/checker).
+ * would check independent keys on a thread pool (jepsen.independent/checker).  wgl_beam_check_many does the same
+ * with the wide schedule the GPU kernel runs (wgl_beam.c: lookahead, eager reads, twin rule as switched on by the
+ * caller beforehand) -- the strongest CPU competitor this repository has.
  */
 #define _GNU_SOURCE
 #include <pthread.h>
@@ -19,6 +21,13 @@ int wgl_window_check(uint32_t n, const uint8_t* f, const int32_t* a, const int32
                      const oracle_model* model, uint64_t max_steps,
                      uint32_t* witness, oracle_result* out);
 
+typedef struct beam_stats { uint64_t iterations, probes, visited, expanded, max_stack, rounds; } beam_stats;
+int wgl_beam_check_rp(uint32_t n, const uint8_t* f, const int32_t* a, const int32_t* b,
+                      const int32_t* process, uint32_t n_process,
+                      const uint32_t* inv_pos, const uint32_t* ret_pos,
+                      const oracle_model* model, uint32_t K, uint32_t round_pairs, uint64_t max_probes,
+                      uint32_t* witness, oracle_result* out, beam_stats* st);
+
 typedef struct {
   uint32_t n_hist;
   const uint32_t* n; const uint32_t* n_process;
@@ -27,6 +36,7 @@ typedef struct {
   const oracle_model* model; uint64_t max_steps;
   int32_t* valid;
   volatile uint32_t next;
+  uint32_t beam_width;      /* 0 = wgl_window_check, else wgl_beam_check_rp at this many configs per round */
 } many_job;
 
 static void* many_worker(void* p) {
@@ -35,19 +45,35 @@ static void* many_worker(void* p) {
     const uint32_t i = __atomic_fetch_add(&j->next, 1u, __ATOMIC_RELAXED);
     if (i >= j->n_hist) break;
     oracle_result r;
-    int rc = wgl_window_check(j->n[i], j->f[i], j->a[i], j->b[i], j->process[i], j->n_process[i], j->inv_pos[i], j->ret_pos[i],
-                              j->model, j->max_steps, NULL, &r);
+    beam_stats bs;
+    int rc = j->beam_width
+      ? wgl_beam_check_rp(j->n[i], j->f[i], j->a[i], j->b[i], j->process[i], j->n_process[i], j->inv_pos[i], j->ret_pos[i],
+                          j->model, j->beam_width, 64, j->max_steps, NULL, &r, &bs)
+      : wgl_window_check(j->n[i], j->f[i], j->a[i], j->b[i], j->process[i], j->n_process[i], j->inv_pos[i], j->ret_pos[i],
+                         j->model, j->max_steps, NULL, &r);
     j->valid[i] = rc ? -2 : r.valid;
   }
   return NULL;
 }
+
+int wgl_check_many(uint32_t n_hist, const uint32_t* n, const uint32_t* n_process,
+                   const uint8_t* const* f, const int32_t* const* a, const int32_t* const* b, const int32_t* const* process,
+                   const uint32_t* const* inv_pos, const uint32_t* const* ret_pos,
+                   const oracle_model* model, uint64_t max_steps, uint32_t n_threads, uint32_t beam_width, int32_t* valid);
 
 /* valid[i] = verdict of history i (-2 = rejected).  Returns the number of threads actually started. */
 int wgl_window_check_many(uint32_t n_hist, const uint32_t* n, const uint32_t* n_process,
                           const uint8_t* const* f, const int32_t* const* a, const int32_t* const* b, const int32_t* const* process,
                           const uint32_t* const* inv_pos, const uint32_t* const* ret_pos,
                           const oracle_model* model, uint64_t max_steps, uint32_t n_threads, int32_t* valid) {
-  many_job j = {n_hist, n, n_process, f, a, b, process, inv_pos, ret_pos, model, max_steps, valid, 0};
+  return wgl_check_many(n_hist, n, n_process, f, a, b, process, inv_pos, ret_pos, model, max_steps, n_threads, 0, valid);
+}
+
+int wgl_check_many(uint32_t n_hist, const uint32_t* n, const uint32_t* n_process,
+                   const uint8_t* const* f, const int32_t* const* a, const int32_t* const* b, const int32_t* const* process,
+                   const uint32_t* const* inv_pos, const uint32_t* const* ret_pos,
+                   const oracle_model* model, uint64_t max_steps, uint32_t n_threads, uint32_t beam_width, int32_t* valid) {
+  many_job j = {n_hist, n, n_process, f, a, b, process, inv_pos, ret_pos, model, max_steps, valid, 0, beam_width};
   if (n_threads == 0) n_threads = 1;
   pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * n_threads);
   uint32_t started = 0;

@@ -278,8 +278,10 @@ def check_sweep(ops, model, eager_reads=True, twin_rule=True, seg_target=0, max_
     return out
 
 
-def check_many(ops_list, model, n_threads, max_steps=0):
-    """wgl_window_check over many histories on a pthread pool (many.c): verdicts as an int32 array."""
+def check_many(ops_list, model, n_threads, max_steps=0, beam_width=0):
+    """Many histories on a pthread pool (many.c): verdicts as an int32 array.  beam_width = 0: wgl_window_check (the
+    sequential knossos.wgl restatement); > 0: wgl_beam.c at that many configs per round with the library's default
+    rules (lookahead, eager reads, twin rule where they apply to the FIRST history's model and values)."""
     nh = len(ops_list)
     keep = []
 
@@ -295,10 +297,21 @@ def check_many(ops_list, model, n_threads, max_steps=0):
     inv, ret = col("inv_pos", np.uint32, C.c_uint32), col("ret_pos", np.uint32, C.c_uint32)
     m, keep_m = _model(model)
     valid = np.zeros(nh, np.int32)
-    fn = lib().wgl_window_check_many
+    fn = lib().wgl_check_many
     fn.restype = C.c_int
-    started = fn(C.c_uint32(nh), _p(n, C.c_uint32), _p(npr, C.c_uint32), f, a, b, pr, inv, ret, C.byref(m),
-                 C.c_uint64(max_steps), C.c_uint32(n_threads), _p(valid, C.c_int32))
+    rules = bool(beam_width) and nh > 0 and rules_apply(ops_list[0], model, 64)
+    if beam_width:
+        lib().wgl_beam_set_widen_after(C.c_uint32(0))
+        lib().wgl_beam_set_lookahead(C.c_uint32(1 if model["kind"] in (0, 1) else 0))
+        lib().wgl_beam_set_eager_reads(C.c_uint32(1 if rules else 0))
+        lib().wgl_beam_set_twin_rule(C.c_uint32(1 if rules else 0))
+    try:
+        started = fn(C.c_uint32(nh), _p(n, C.c_uint32), _p(npr, C.c_uint32), f, a, b, pr, inv, ret, C.byref(m),
+                     C.c_uint64(max_steps), C.c_uint32(n_threads), C.c_uint32(beam_width), _p(valid, C.c_int32))
+    finally:
+        if beam_width:
+            lib().wgl_beam_set_eager_reads(C.c_uint32(0))
+            lib().wgl_beam_set_twin_rule(C.c_uint32(0))
     del keep, keep_m
     return valid, started
 

@@ -108,8 +108,10 @@ static uint32_t arena_add(arena* a, const uint64_t* k, uint32_t parent, uint32_t
   return id;
 }
 
-static uint64_t* g_bcfg = NULL; static uint32_t g_bcfg_n = 0, g_bcfg_kw = 0;
-static size_t g_bsort_kw;
+/* what a run writes is thread-local (many.c checks histories on a thread pool); the switches below are process-wide
+ * and set before the pool starts */
+static _Thread_local uint64_t* g_bcfg = NULL; static _Thread_local uint32_t g_bcfg_n = 0, g_bcfg_kw = 0;
+static _Thread_local size_t g_bsort_kw;
 static int cmp_bcfg(const void* x, const void* y) {
   const uint64_t* a = (const uint64_t*)x; const uint64_t* b = (const uint64_t*)y;
   int32_t sa = (int32_t)(a[0] >> 32), sb = (int32_t)(b[0] >> 32);
@@ -144,12 +146,12 @@ int wgl_beam_check_rp(uint32_t n, const uint8_t* f, const int32_t* a, const int3
  * lookahead:   tbc_opts.lookahead; the rule is stated where it is applied.  0 = off. */
 static uint32_t g_widen_after = 0;
 void wgl_beam_set_widen_after(uint32_t r) { g_widen_after = r; }
-static uint32_t g_lookahead = 0, g_lookahead_depth = 8; static uint64_t g_pruned = 0;
+static uint32_t g_lookahead = 0, g_lookahead_depth = 8; static _Thread_local uint64_t g_pruned = 0;
 void wgl_beam_set_lookahead(uint32_t on) { g_lookahead = on; }
 uint64_t wgl_beam_pruned(void) { return g_pruned; }
 /* searches that found their linearization only AFTER the set-aside configs were taken up: must stay 0,
  * or the lookahead rule called a live config dead (the verdict would still be right) */
-static uint64_t g_late_valid = 0;
+static _Thread_local uint64_t g_late_valid = 0;
 uint64_t wgl_beam_late_valid(void) { return g_late_valid; }
 /* Self-check of a cheaper twin test for CRASHED candidates (not what the kernel does yet):
  * crashed calls of one effect are linearized in invocation order under the rule, so among the crashed ones only the
@@ -157,7 +159,7 @@ uint64_t wgl_beam_late_valid(void) { return g_late_valid; }
  * When switched on, every twin test of a crashed candidate is evaluated both ways; the counters say how often and
  * whether the two ever disagreed. */
 static uint32_t g_twin_selfcheck = 0;
-static uint64_t g_twin_checked = 0, g_twin_mismatch = 0;
+static _Thread_local uint64_t g_twin_checked = 0, g_twin_mismatch = 0;
 void wgl_beam_set_twin_selfcheck(uint32_t on) { g_twin_selfcheck = on; g_twin_checked = 0; g_twin_mismatch = 0; }
 uint64_t wgl_beam_twin_checked(void) { return g_twin_checked; }
 uint64_t wgl_beam_twin_mismatch(void) { return g_twin_mismatch; }
@@ -176,7 +178,7 @@ void wgl_beam_set_list_order(uint32_t o) { g_list_order = o; }
 /* eager reads (experiment for the next round, register family): a read that is viable NOW can be linearized
  * now without loss of generality (it does not change the state, so any later schedule stays possible): every
  * child absorbs all of them, again after each step of the front.  Witness reconstruction is not done here. */
-static uint32_t g_eager_reads = 0; static uint64_t g_absorbed = 0;
+static uint32_t g_eager_reads = 0; static _Thread_local uint64_t g_absorbed = 0;
 /* twin writes (experiment, register family): of several open, not yet linearized calls with the same effect
  * (:write v, or :cas [a b] with equal a and b) the one completing first goes first, without loss of generality */
 static uint32_t g_twin_rule = 0;

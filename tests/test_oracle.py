@@ -185,3 +185,17 @@ def test_crashed_twin_shortcut_agrees_with_the_list_walk(oracle):
                 checked += r["twin_checked"]
                 assert r["twin_mismatch"] == 0
     assert checked > 100_000
+
+
+def test_thread_pool_runs_both_restatements(oracle):
+    """oracle/many.c: the sequential restatement and the wide schedule on a pthread pool give the verdicts of the
+    one-at-a-time calls (bench.py's cpu_baseline uses both)."""
+    from jepsen_tigerbeetle_amd import columns, synth
+    m = {"kind": 1, "init": -2147483648}
+    hs = [columns.pair_events(synth.register_events(n_ops=600, n_procs=12, seed=s, busy=0.3, info=0.01 if s % 3 == 0 else 0.0,
+                                                    corrupt=0.5 if s % 4 == 1 else 0.0)).as_dict() for s in range(24)]
+    one = [oracle.check(h, m, "window", want_witness=False)["valid"] for h in hs]
+    assert 0 in one and 1 in one
+    for bw in (0, 2, 4):
+        v, started = oracle.check_many(hs, m, 4, beam_width=bw)
+        assert started >= 1 and list(v) == one, bw
