@@ -160,16 +160,24 @@ def rules_apply(ops, model, round_pairs=64):
 
 
 def check_beam(ops, model, width=16, max_probes=0, want_witness=True, round_pairs=64, widen_after=0, lookahead=None, eager_reads=None, twin_rule=None,
-               twin_selfcheck=False):
+               twin_selfcheck=False, rules_at_any_round_size=False):
     """The wide (K configs per iteration) schedule of the same search: wgl_beam.c.
 
     lookahead: None = what the library does by default (on for register / cas-register under the
     single-wavefront wide schedule, i.e. round_pairs == 64).  Configs it finds dead are set aside and
     expanded only if the search would otherwise end INVALID, so results are exact either way."""
-    if lookahead is None:
+    if lookahead is None and not rules_at_any_round_size:
         lookahead = round_pairs == 64 and model["kind"] in (0, 1)
     # eager_reads / twin_rule: None = what the library does by default (tbc_opts.dominance = 0)
-    if eager_reads is None or twin_rule is None:
+    # rules_at_any_round_size: the library applies the dominance rules only under its 64-pair rounds; the schedules with
+    # narrower rounds (several histories per wavefront, DESIGN.md section 8) are specified with them all the same
+    if rules_at_any_round_size:
+        ok = rules_apply(ops, model, 64)
+        eager_reads = ok if eager_reads is None else (eager_reads and ok)
+        twin_rule = ok if twin_rule is None else (twin_rule and ok)
+        if lookahead is None:
+            lookahead = model["kind"] in (0, 1)
+    elif eager_reads is None or twin_rule is None:
         dflt = rules_apply(ops, model, round_pairs)
         eager_reads = dflt if eager_reads is None else eager_reads
         twin_rule = dflt if twin_rule is None else twin_rule

@@ -199,3 +199,34 @@ def test_thread_pool_runs_both_restatements(oracle):
     for bw in (0, 2, 4):
         v, started = oracle.check_many(hs, m, 4, beam_width=bw)
         assert started >= 1 and list(v) == one, bw
+
+
+def test_narrow_round_schedules_keep_verdict_and_failing_op(oracle):
+    """The schedules a wavefront shared by several histories would run: 8 / 16 / 32 pairs per round,
+    1 or 2 configs per round, lookahead + eager reads + twin rule.  Against the sequential restatement on histories
+    it finishes (and brute force through it, test_oracles_match_brute_force): same verdict, same failing op, a legal
+    witness; and the round size changes rounds only -- probes, new configs and the witness are the 64-pair schedule's."""
+    from helpers import op_tuples
+    from jepsen_tigerbeetle_amd import columns, synth
+    m = {"kind": 1, "init": N.NIL}
+    n_checked = 0
+    for (n, p, busy, info, corrupt) in [(60, 6, 0.6, 0.1, 0.3), (300, 16, 0.3, 0.02, 0.0), (300, 8, 0.4, 0.0, 0.3), (1500, 32, 0.15, 0.0, 0.0)]:
+        for s in range(6 if n <= 300 else 3):
+            ops = columns.pair_events(synth.register_events(n_ops=n, n_procs=p, seed=900 + s, busy=busy, info=info, corrupt=corrupt))
+            d = ops.as_dict()
+            seq = oracle.check(d, m, "window", max_steps=3_000_000, want_witness=False)
+            if seq["valid"] == -1:
+                continue
+            for K in (1, 2):
+                ref = oracle.check_beam(d, m, K, max_probes=3_000_000, rules_at_any_round_size=True)
+                for rp in (8, 16, 32):
+                    r = oracle.check_beam(d, m, K, max_probes=3_000_000, round_pairs=rp, rules_at_any_round_size=True)
+                    assert r["valid"] == seq["valid"] == ref["valid"], (n, p, s, K, rp)
+                    if r["valid"] == 0:
+                        assert r["fail_op"] == seq["fail_op"]
+                    else:
+                        brute.check_witness(m, op_tuples(ops), [int(x) for x in r["witness"]])
+                    if info == 0.0 and r["valid"] == 1:      # (with crashed calls a round's pairs are cut differently: counters may differ)
+                        assert (r["probes"], r["visited"]) == (ref["probes"], ref["visited"]) and r["rounds"] >= ref["rounds"]
+                    n_checked += 1
+    assert n_checked > 60
