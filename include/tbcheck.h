@@ -386,8 +386,9 @@ tbc_status tbc_batch_set_shard(tbc_batch* b, uint32_t rank, uint32_t world);
 tbc_status tbc_batch_sweep_partial(tbc_batch* b);
 /* the relation table of the last partial run: DEVICE pointer (for a collective straight out of HBM) and size */
 tbc_status tbc_batch_sweep_table(const tbc_batch* b, void** device_ptr, uint64_t* bytes);
-/* verdicts from a merged relation table in HOST memory (bytes as above) */
-tbc_status tbc_batch_sweep_finish(tbc_batch* b, const void* merged, tbc_result* results);
+/* verdicts from a merged relation table in HOST memory; merged_bytes must equal tbc_batch_sweep_table()'s size
+ * (anything else is TBC_ERR_INVALID_ARG, as is a finish that no tbc_batch_sweep_partial precedes) */
+tbc_status tbc_batch_sweep_finish(tbc_batch* b, const void* merged, uint64_t merged_bytes, tbc_result* results);
 void tbc_batch_destroy(tbc_batch* b);
 
 /* ----------------------------------------------------------------- memo

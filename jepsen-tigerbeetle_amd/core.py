@@ -178,7 +178,7 @@ class Batch:
 
     def sweep_finish(self, merged: np.ndarray):
         m = np.ascontiguousarray(merged, np.uint8)
-        st = N.lib().tbc_batch_sweep_finish(self._h, m.ctypes.data_as(C.c_void_p), self._res)
+        st = N.lib().tbc_batch_sweep_finish(self._h, m.ctypes.data_as(C.c_void_p), C.c_uint64(m.nbytes), self._res)
         N.check_status(st)
         return self
 

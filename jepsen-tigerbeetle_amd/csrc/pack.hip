@@ -121,7 +121,11 @@ __global__ __launch_bounds__(1024, 6) void pack_kernel(PackArgs A) {
     __syncthreads();
     // phase 1b: set / bank keep their values in the pool -- every offset the search will dereference
     // (device_common.h pair_viable) is checked here against pool_len, the add count and the account count
-    if (!s_err && (A.model_kind == TBC_MODEL_SET || A.model_kind == TBC_MODEL_BANK)) {
+    // (the condition is latched before anyone may write s_err again: a fast wavefront's atomicOr below must not
+    // make a slow one skip the block and its barriers)
+    const bool do1b = !s_err && (A.model_kind == TBC_MODEL_SET || A.model_kind == TBC_MODEL_BANK);
+    __syncthreads();
+    if (do1b) {
       const uint64_t PL = A.pool_len, Rn = s_done;
       const int64_t aux = H->aux;
       if (A.model_kind == TBC_MODEL_SET) {

@@ -144,25 +144,20 @@ __global__ __launch_bounds__(256) void setfull_resolve_kernel(const uint32_t* __
   uint32_t loaded = 0;
   if (w < WPR) {
     const uint32_t full = E - 32u * w >= 32u ? 0xFFFFFFFFu : (1u << (E - 32u * w)) - 1u;
-    // the summaries of up to 256 chunks: lane l holds chunks l, l + 64, l + 128, l + 192
-    uint32_t ap[4], aa[4];
-#pragma unroll
-    for (uint32_t g = 0; g < 4; g++) {
-      const uint32_t c = lane + 64u * g;
-      ap[g] = c < chunks ? any_p[(uint64_t)c * WPR + w] : 0u;
-      aa[g] = c < chunks ? any_a[(uint64_t)c * WPR + w] : 0u;
-    }
+    // the chunk summaries, 64 chunks (one per lane) at a time; any number of chunks
+    const uint32_t G = (chunks + 63u) / 64u;
     // last present / last absent: the latest chunk that has the bit decides; inside it, the latest row
 #pragma unroll
     for (int pass = 0; pass < 2; pass++) {
+      const uint32_t* __restrict__ any = pass == 0 ? any_p : any_a;
       uint32_t need = full;
-#pragma unroll
-      for (int g = 3; g >= 0 && need; g--) {
-        const uint32_t mine = pass == 0 ? ap[g] : aa[g];
+      for (uint32_t gi = G; gi-- > 0 && need;) {
+        const uint32_t cl = lane + 64u * gi;
+        const uint32_t mine = cl < chunks ? any[(uint64_t)cl * WPR + w] : 0u;
         uint64_t cand = __ballot((mine & need) != 0u);
         while (cand && need) {
           const uint32_t l = 63u - (uint32_t)__builtin_clzll(cand);
-          const uint32_t c = l + 64u * (uint32_t)g;
+          const uint32_t c = l + 64u * gi;
           const uint32_t mc = (uint32_t)__builtin_amdgcn_readlane((int)mine, l) & need;
           const uint32_t r0 = min(c * rows_per_chunk, R), r1 = min(r0 + rows_per_chunk, R);
           (void)setfull_last_in_chunk(M, P, read_invoke, WPR, w, full, r0, r1, mc, pass == 0, pass == 0 ? lp1 : la1, lane, loaded);
@@ -171,22 +166,21 @@ __global__ __launch_bounds__(256) void setfull_resolve_kernel(const uint32_t* __
         }
       }
     }
-    // known: min read_ok over the reads containing the element.  The earliest chunk that has the bit holds its first
-    // containing read (in invocation order); a read invoked before that one completed may still complete earlier, so the
-    // walk goes on, 64 rows at a time, while rows were invoked before `until` (the latest first completion seen).
-    uint32_t ever = 0;
-#pragma unroll
-    for (uint32_t g = 0; g < 4; g++) {
-      uint32_t o = ap[g];
+    // known: min read_ok over the reads containing the element.  The earliest chunk that has a bit of the column holds
+    // the first containing read (in invocation order) of some element; a read invoked before that one completed may still
+    // complete earlier, so the walk goes on, 64 rows at a time, while rows were invoked before `until` (the latest first
+    // completion seen).
+    uint32_t ever = 0, first_c = chunks;
+    for (uint32_t gi = 0; gi < G; gi++) {
+      const uint32_t cl = lane + 64u * gi;
+      uint32_t o = cl < chunks ? any_p[(uint64_t)cl * WPR + w] & full : 0u;
+      const uint64_t bl = __ballot(o != 0u);
+      if (bl && first_c == chunks) first_c = (uint32_t)__builtin_ctzll(bl) + 64u * gi;
 #pragma unroll
       for (int d = 32; d >= 1; d >>= 1) o |= (uint32_t)__shfl_xor((int)o, d);
       ever |= o;
     }
-    ever &= full;
     if (ever) {
-      uint32_t first_c = chunks;
-#pragma unroll
-      for (int g = 3; g >= 0; g--) { const uint64_t bl = __ballot((ap[g] & ever) != 0u); if (bl) first_c = (uint32_t)__builtin_ctzll(bl) + 64u * (uint32_t)g; }
       uint32_t seen = 0, until = 0;
       uint32_t best = 0xFFFFFFFFu;                              // lane b < 32 keeps element b's minimum
       for (uint32_t base = first_c * rows_per_chunk; base < R; base += 64u) {
@@ -270,6 +264,9 @@ static tbc_status setfull_create_impl(const tbc_setfull_in* in, tbc_setfull* S) 
   }
   S->device = (int)in->device; S->E = in->n_elements; S->R = in->n_reads; S->WPR = in->words_per_row;
   if ((uint64_t)S->WPR * 32 < S->E) { set_error("tbc_setfull: words_per_row too small for n_elements"); return TBC_ERR_INVALID_ARG; }
+  // the prefix search per row and "the latest row" both rest on the documented orders
+  for (uint32_t e = 1; e < S->E; e++) if (in->add_invoke[e] <= in->add_invoke[e - 1]) { set_error("tbc_setfull: add_invoke must be strictly ascending (element %u)", e); return TBC_ERR_INVALID_ARG; }
+  for (uint32_t r = 1; r < S->R; r++) if (in->read_invoke[r] <= in->read_invoke[r - 1]) { set_error("tbc_setfull: read_invoke must be strictly ascending (read %u)", r); return TBC_ERR_INVALID_ARG; }
   SF_TRY(hipSetDevice(S->device));
   // enough chunks to fill the GPU with wavefronts that each stream a good stretch of rows
   const uint32_t col_blocks = (S->WPR + 255) / 256;

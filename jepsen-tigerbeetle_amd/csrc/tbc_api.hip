@@ -193,7 +193,6 @@ struct tbc_batch {
   DevBuf<uint64_t> d_cfg;           // configs at the failing front, kCfgCap records per history
   // wide schedule (search_width > 1)
   uint32_t width = 1;
-  bool wg = false;                  // width 32 / 64: one workgroup per history (wgl_beam_wg.hip)
   std::vector<BeamHist> bh;
   DevBuf<BeamHist> d_bh;
   DevBuf<uint32_t> d_off, d_ncr, d_stack;
@@ -211,6 +210,7 @@ struct tbc_batch {
   std::vector<SegResult> seg_host;
   uint32_t last_segments = 0, last_fallback = 0;
   uint32_t shard_rank = 0, shard_world = 1;      // tbc_batch_set_shard: this rank's share of the sweep's wavefronts
+  bool partial_done = false;                     // a tbc_batch_sweep_partial is waiting for its tbc_batch_sweep_finish
   std::vector<Hist> hist_back_m;                 // descriptors as the pack kernels left them (kept between
   std::vector<BeamHist> bh_back_m;               //   tbc_batch_sweep_partial and tbc_batch_sweep_finish)
   uint32_t rules = 0;               // kRuleEager | kRuleTwin: wide single-wave schedule, register family, values 0..kMaxRuleValue
@@ -296,6 +296,14 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
   B->n_hist = nh;
   B->total_ops = desc->op_off[nh];
   if (B->total_ops != desc->cols.n) { set_error("op_off[n_hist] (%llu) != cols.n (%u)", (unsigned long long)B->total_ops, desc->cols.n); return TBC_ERR_INVALID_ARG; }
+  // the offsets index the op columns from here on (width heuristic, value scan, sweep sizing): check them first
+  for (uint32_t h = 0; h < nh; h++) {
+    if (desc->op_off[h + 1] < desc->op_off[h] || desc->op_off[h + 1] > B->total_ops || desc->op_off[h + 1] - desc->op_off[h] > 0x7FFFFFFFull) {
+      set_error("history %u: bad op_off", h);
+      return TBC_ERR_INVALID_ARG;
+    }
+  }
+  if (desc->op_off[0] != 0) { set_error("op_off[0] must be 0"); return TBC_ERR_INVALID_ARG; }
   uint32_t maxW = 1;
   for (uint32_t h = 0; h < nh; h++) maxW = std::max(maxW, desc->n_process[h]);
   if (maxW > kMaxSlots) { set_error("%u open processes > %u supported", maxW, kMaxSlots); return TBC_ERR_WINDOW_TOO_WIDE; }
@@ -304,7 +312,7 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
   B->frame_words = search_frame_words(B->mask_words);
   const uint32_t KW = 1 + B->mask_words;
   uint32_t width = opts->search_width ? opts->search_width : (opts->algorithm == TBC_ALG_WGL ? 1u : 4u);   // 4: fewest rounds per history, measured
-  if (width > 64) width = 64;
+  if (width > 16) width = 16;           // one wavefront per history: at most 16 configs per round
   while (width & (width - 1)) width &= width - 1;   // the wide kernels take a power of two
   if (B->mask_words > 4) width = 1;          // very wide windows: sequential kernel only
   const bool commutative = model->kind == TBC_MODEL_SET || model->kind == TBC_MODEL_BANK;
@@ -325,7 +333,6 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
     if (B->sweep && width < 2) width = 4;                // the fallback's schedule; the per-front lists are the wide kernel's
   }
   B->width = width;
-  B->wg = width > 16;
   B->lookahead = !B->sweep && width > 1 && width <= 16 && opts->lookahead != 1 &&
                  (model->kind == TBC_MODEL_REGISTER || model->kind == TBC_MODEL_CAS_REGISTER);
   const bool beam = width > 1;
@@ -364,7 +371,7 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
     }
     if (events && open_sum <= 10 * events) B->width = 2;
   }
-  const uint32_t EW = B->wg ? beam_wg_entry_words(B->mask_words) : B->mask_words + 2;   // u64 words per wide-schedule entry
+  const uint32_t EW = B->mask_words + 2;   // u64 words per wide-schedule entry
   if (B->sweep) {
     // segments: enough wavefronts to fill the GPU several times over, none shorter than 32 completions; cuts need the
     // register family's value domain (nil + 0..vmax = vpad's range) to enumerate the configs possible at a front
@@ -588,9 +595,7 @@ static tbc_status scratch_pass(tbc_batch* B, const std::vector<uint32_t>& grp, c
                                bool beam, const std::vector<Hist>& hist_back, const std::vector<BeamHist>& bh_back,
                                uint32_t width_override = 0) {
   hipStream_t s = B->stream;
-  const uint32_t pass_width = width_override ? width_override : B->width;
-  const bool wg = beam && pass_width > 16;
-  const uint32_t KW = 1 + B->mask_words, EW = wg ? beam_wg_entry_words(B->mask_words) : B->mask_words + 2;
+  const uint32_t KW = 1 + B->mask_words, EW = B->mask_words + 2;
   const uint64_t words_per_entry = beam ? EW : KW;
   uint64_t entries = 0;
   std::vector<Hist> ph(grp.size());
@@ -621,7 +626,7 @@ static tbc_status scratch_pass(tbc_batch* B, const std::vector<uint32_t>& grp, c
     const uint32_t nw = (uint32_t)grp.size();
     if (beam) { BeamArgs ba = make_beam_args(B, big.p, bstack.p, bdstack.p, nw); ba.pool = nullptr; ba.pool_words = 0;
       if (width_override) ba.width = width_override;
-      if (wg) launch_beam_wg(ba, B->mask_words, nw, s); else launch_beam(ba, B->mask_words, search_blocks(nw), s); }
+      launch_beam(ba, B->mask_words, search_blocks(nw), s); }
     else { SearchArgs ra = make_search_args(B, big.p, nw); launch_search(ra, B->mask_words, search_blocks(nw), s); }
     e = hipGetLastError();
   }
@@ -752,7 +757,7 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results, int phase = 
   const uint32_t nh = B->n_hist;
   hipStream_t s = B->stream;
   const bool beam = B->width > 1;
-  const uint32_t KW = 1 + B->mask_words, EW = B->wg ? beam_wg_entry_words(B->mask_words) : B->mask_words + 2;
+  const uint32_t KW = 1 + B->mask_words, EW = B->mask_words + 2;
   std::vector<Hist>& hist_back = B->hist_back_m;
   std::vector<BeamHist>& bh_back = B->bh_back_m;
   SweepArgs swa{};
@@ -819,7 +824,7 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results, int phase = 
     if (!launch_sweep(mine, s)) { set_error("level sweep launch failed"); return TBC_ERR_HIP; }
   } else if (beam) {
     BeamArgs ba = make_beam_args(B, B->d_btab.p, B->d_stack.p, B->d_dstack.p, nh);
-    if (B->wg ? !launch_beam_wg(ba, B->mask_words, nh, s) : !launch_beam(ba, B->mask_words, search_blocks(nh), s)) { set_error("unsupported mask width"); return TBC_ERR_UNSUPPORTED; }
+    if (!launch_beam(ba, B->mask_words, search_blocks(nh), s)) { set_error("unsupported mask width"); return TBC_ERR_UNSUPPORTED; }
   } else {
     SearchArgs sa = make_search_args(B, B->d_tab.p, nh);
     if (!launch_search(sa, B->mask_words, search_blocks(nh), s)) { set_error("unsupported mask width"); return TBC_ERR_UNSUPPORTED; }
@@ -837,6 +842,7 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results, int phase = 
   HIP_TRY(hipStreamSynchronize(s));
   TRACE("run: first pass synced");
   }   // phase != 2
+  B->partial_done = phase == 1;
   if (phase == 1) return TBC_OK;
   if (phase == 2) {
     if (!B->sweep || hist_back.size() != nh) { set_error("tbc_batch_sweep_finish without tbc_batch_sweep_partial"); return TBC_ERR_INVALID_ARG; }
@@ -1093,8 +1099,14 @@ tbc_status tbc_batch_sweep_table(const tbc_batch* b, void** device_ptr, uint64_t
   return TBC_OK;
 }
 
-tbc_status tbc_batch_sweep_finish(tbc_batch* b, const void* merged, tbc_result* results) {
+tbc_status tbc_batch_sweep_finish(tbc_batch* b, const void* merged, uint64_t merged_bytes, tbc_result* results) {
   if (!b || !b->sweep || !merged) { set_error("tbc_batch_sweep_finish: not a sweep batch"); return TBC_ERR_INVALID_ARG; }
+  if (merged_bytes != (uint64_t)b->seg_host.size() * sizeof(SegResult)) {
+    set_error("tbc_batch_sweep_finish: merged table is %llu bytes, this batch's table is %llu (tbc_batch_sweep_table)",
+              (unsigned long long)merged_bytes, (unsigned long long)(b->seg_host.size() * sizeof(SegResult)));
+    return TBC_ERR_INVALID_ARG;
+  }
+  if (!b->partial_done) { set_error("tbc_batch_sweep_finish without tbc_batch_sweep_partial"); return TBC_ERR_INVALID_ARG; }
   try {
     std::memcpy(b->seg_host.data(), merged, b->seg_host.size() * sizeof(SegResult));
     return batch_run_impl(b, results, 2);

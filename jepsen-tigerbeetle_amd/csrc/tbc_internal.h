@@ -236,7 +236,7 @@ struct BeamArgs {
   const uint32_t* ret_op;
   uint32_t* stack;
   uint32_t* dstack;          // second stack (same layout as stack): configs set aside by the lookahead, or null
-  uint64_t* tab;             // (2 + mask_words) u64 words per entry; layout is the kernel's own (wgl_beam.hip / wgl_beam_wg.hip)
+  uint64_t* tab;             // (2 + mask_words) u64 words per entry; layout is the kernel's own (wgl_beam.hip)
   DevResult* results;
   uint32_t* witness;         // n_ops per history at op_off, may be null
   const uint32_t* work;
@@ -314,9 +314,6 @@ bool launch_sweep(const SweepArgs& a, void* stream);
 
 void launch_pack_open(const PackOpenArgs& a, void* stream);
 bool launch_beam(const BeamArgs& a, uint32_t mask_words, uint32_t n_blocks, void* stream);
-// one 256-lane workgroup per history (search_width 32 / 64); entries have one more word
-bool launch_beam_wg(const BeamArgs& a, uint32_t mask_words, uint32_t n_hist, void* stream);
-uint32_t beam_wg_entry_words(uint32_t mask_words);
 
 // kernel launchers (defined in the .hip files)
 void launch_pack(const PackArgs& a, void* stream);

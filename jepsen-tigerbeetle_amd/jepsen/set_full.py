@@ -22,31 +22,41 @@ NONE = 0xFFFFFFFF
 
 
 class Encoded:
-    """reads x elements bit matrix + index columns of one history (one key)."""
+    """reads x elements bit matrix + index columns of one history (one key).
+
+    Recalled jepsen.checker/set-full details kept here: an :add INVOCATION creates the element's state, so adding an
+    element again starts it afresh (its column is numbered by its LAST add invocation and only reads completing after
+    that count); an element that occurs more than once in one read's value is a duplicate (`duplicated`: element ->
+    greatest multiplicity seen), which makes the result invalid."""
 
     def __init__(self, history):
         hist = [op for op in H.index(list(history)) if H.client_op(op)]
+        self.has_time = all("time" in op for op in hist) and bool(hist)
         self.times = {op["index"]: op.get("time", op["index"]) for op in hist}
-        elems, order = {}, []
-        add_ok, reads, open_reads = {}, [], {}
+        last_invoke, add_ok, reads, open_reads = {}, {}, [], {}
+        self.duplicated = {}
         for op in hist:
             i = op["index"]
             if op["f"] == "add":
                 v = _freeze(op["value"])
                 if op["type"] == "invoke":
-                    if v not in elems:
-                        elems[v] = (len(order), i)
-                        order.append(op["value"])
-                elif op["type"] == "ok" and v in elems and v not in add_ok:
+                    last_invoke[v] = (i, op["value"])
+                    add_ok.pop(v, None)                        # a fresh element state: nothing known yet
+                elif op["type"] == "ok" and v in last_invoke and v not in add_ok:
                     add_ok[v] = i
             elif op["f"] == "read":
                 if op["type"] == "invoke":
                     open_reads[op["process"]] = i
+                elif op["type"] == "fail":
+                    open_reads.pop(op["process"], None)
                 elif op["type"] == "ok":
                     inv = open_reads.pop(op["process"], None)
                     if inv is not None and op.get("value") is not None:
                         reads.append((inv, i, op["value"]))
         reads.sort(key=lambda r: r[0])
+        by_invoke = sorted(last_invoke.items(), key=lambda kv: kv[1][0])
+        order = [val for _, (_, val) in by_invoke]
+        elems = {k: (n, inv) for n, (k, (inv, _)) in enumerate(by_invoke)}
         self.elements = order
         E, R = len(order), len(reads)
         self.E, self.R = E, R
@@ -67,14 +77,24 @@ class Encoded:
                 continue
             if ints and E and all(isinstance(x, int) and not isinstance(x, bool) for x in vals):
                 arr = np.asarray(vals, np.int64)
+                if len(arr) > 1:
+                    u, c = np.unique(arr, return_counts=True)
+                    for x, n in zip(u[c > 1].tolist(), c[c > 1].tolist()):
+                        self.duplicated[x] = max(self.duplicated.get(x, 0), n)
                 pos = np.minimum(np.searchsorted(ks, arr), E - 1)
                 hit = ks[pos] == arr                       # values nobody added are not columns: jepsen ignores them here too
                 bits[r, srt[pos[hit]]] = True
             else:
+                seen = {}
                 for x in vals:
-                    e = elems.get(_freeze(x))
+                    fx = _freeze(x)
+                    seen[fx] = seen.get(fx, 0) + 1
+                    e = elems.get(fx)
                     if e is not None:
                         bits[r, e[0]] = True
+                for fx, n in seen.items():
+                    if n > 1:
+                        self.duplicated[fx] = max(self.duplicated.get(fx, 0), n)
         self.present = np.ascontiguousarray(np.packbits(bits, axis=1, bitorder="little").view(np.uint32))
 
 
@@ -118,8 +138,18 @@ class Scan:
         self.close()
 
 
+def frequency_distribution(points, xs):
+    """jepsen.checker's latency summary (recalled): {point: the value at floor(n * point) of the sorted sample, clamped}."""
+    srt = sorted(xs)
+    n = len(srt)
+    return {p: srt[min(n - 1, int(n * p))] for p in points} if n else None
+
+
 def result_map(enc: Encoded, st: dict, linearizable: bool):
-    """jepsen.checker/set-full's result from the three indices per element (vectorised: a few operations each)."""
+    """jepsen.checker/set-full's result from the three indices per element (vectorised: a few operations each).
+    Latencies as jepsen computes them: max(0, dt) in nanoseconds -> whole milliseconds (util/nanos->ms, then long)
+    when the ops carry :time; histories without :time (hand-written ones) keep the index difference.  So a gap
+    below one millisecond is not a stale read, exactly as in jepsen."""
     k = st["known"].astype(np.int64)
     lp = np.where(st["last_present"] == NONE, -1, st["last_present"].astype(np.int64))
     la = np.where(st["last_absent"] == NONE, -1, st["last_absent"].astype(np.int64))
@@ -131,19 +161,29 @@ def result_map(enc: Encoded, st: dict, linearizable: bool):
     tk = np.array([t[int(x)] if kn else 0 for x, kn in zip(k, known)], np.int64)
     t_la = np.array([t[int(x)] + 1 if x >= 0 else 0 for x in la], np.int64)
     t_lp = np.array([t[int(x)] + 1 if x >= 0 else 0 for x in lp], np.int64)
-    stable_lat = np.maximum(0, t_la - tk)
-    lost_lat = np.maximum(0, t_lp - tk)
+    unit = 1_000_000 if getattr(enc, "has_time", False) else 1
+    stable_lat = np.maximum(0, t_la - tk) // unit
+    lost_lat = np.maximum(0, t_lp - tk) // unit
     el = enc.elements
     idx = lambda m: [el[i] for i in np.nonzero(m)[0]]
     stale = stable & (stable_lat > 0)
     worst = sorted(np.nonzero(stale)[0], key=lambda i: -int(stable_lat[i]))[:8]
+    dups = dict(sorted(getattr(enc, "duplicated", {}).items(), key=lambda kv: repr(kv[0])))
     valid = False if lost.any() else ("unknown" if not stable.any() else (False if (linearizable and stale.any()) else True))
-    return {"valid?": valid, "attempt-count": enc.E, "stable-count": int(stable.sum()), "lost-count": int(lost.sum()),
-            "lost": _sorted(idx(lost)), "never-read-count": int(never.sum()), "never-read": _sorted(idx(never)),
-            "stale-count": int(stale.sum()), "stale": _sorted(idx(stale)),
-            "worst-stale": [{"element": el[i], "outcome": "stable", "stable-latency": int(stable_lat[i]), "lost-latency": None,
-                             "known": int(k[i]), "last-absent": int(la[i]) if la[i] >= 0 else None} for i in worst],
-            "lost-latencies": sorted(int(x) for x in lost_lat[lost]), "stable-latencies": sorted(int(x) for x in stable_lat[stable])}
+    if dups:
+        valid = False                                   # (and (empty? dups) (:valid? results)): nil / :unknown -> falsey
+    points = (0, 0.5, 0.95, 0.99, 1)
+    out = {"valid?": valid, "attempt-count": enc.E, "stable-count": int(stable.sum()), "lost-count": int(lost.sum()),
+           "lost": _sorted(idx(lost)), "never-read-count": int(never.sum()), "never-read": _sorted(idx(never)),
+           "stale-count": int(stale.sum()), "stale": _sorted(idx(stale)),
+           "worst-stale": [{"element": el[i], "outcome": "stable", "stable-latency": int(stable_lat[i]), "lost-latency": None,
+                            "known": int(k[i]), "last-absent": int(la[i]) if la[i] >= 0 else None} for i in worst],
+           "duplicated-count": len(dups), "duplicated": dups}
+    if stable.any():
+        out["stable-latencies"] = frequency_distribution(points, [int(x) for x in stable_lat[stable]])
+    if lost.any():
+        out["lost-latencies"] = frequency_distribution(points, [int(x) for x in lost_lat[lost]])
+    return out
 
 
 def _sorted(xs):

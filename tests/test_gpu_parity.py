@@ -309,27 +309,6 @@ def test_default_width_follows_the_calls_in_flight(native, oracle):
             assert (got["probes"], got["visited"], got["backtracks"]) == (exp["probes"], exp["visited"], exp["expanded"])
 
 
-@pytest.mark.parametrize("width", [32, 64])
-def test_workgroup_kernel_matches_its_oracle(native, oracle, width):
-    """search_width 32 / 64: one 256-lane workgroup per history (wgl_beam_wg.hip), the schedule of
-    oracle/wgl_beam.c with 256 pairs per round -- duplicates across wavefronts resolved by owner tags."""
-    cases = [(8, 3, 0.1, 0.5, 0.8), (200, 8, 0.02, 0.0, 0.5), (200, 8, 0.0, 0.6, 0.3), (1000, 16, 0.02, 0.0, 0.5),
-             (1000, 16, 0.0, 0.6, 0.2), (3000, 64, 0.02, 0.0, 0.1), (3000, 64, 0.0, 0.6, 0.05)]
-    hists = [columns.pair_events(synth.register_events(n_ops=n, n_procs=p, seed=s, busy=busy, info=info, corrupt=corrupt))
-             for (n, p, info, corrupt, busy) in cases for s in range(2)]
-    with core.Batch(hists, gm(), core.make_opts(time_limit_ms=60000, search_width=width, algorithm=N.ALG_COMPETITION)) as b:
-        res = b.run().results()
-    for i, (h, got) in enumerate(zip(hists, res)):
-        exp = oracle.check_beam(h.as_dict(), CAS, width, round_pairs=256)
-        assert got["valid"] == exp["valid"], i
-        assert (got["probes"], got["visited"], got["backtracks"], got["max_depth"]) == \
-               (exp["probes"], exp["visited"], exp["expanded"], exp["max_stack"]), i
-        if exp["valid"] == 1:
-            assert np.array_equal(got["witness"], exp["witness"]) and got["final_state"] == exp["final_state"], i
-        else:
-            assert got["fail_op"] == exp["fail_op"], i
-
-
 def test_round_budget_widens_stragglers_in_place(native, oracle):
     """tbc_opts.round_budget: a history that has used more rounds than the budget continues at width 16
     (same table, same stack).  Still the deterministic schedule of oracle/wgl_beam.c (widen_after)."""

@@ -142,3 +142,85 @@ def test_large_matrix_against_numpy(native):
     assert np.array_equal(np.where(st["known"] == N.NO_OP, 2 ** 40, st["known"].astype(np.int64)), kn)
     assert np.array_equal(st["known"], st2["known"]) and st["bytes_scanned"] == st2["bytes_scanned"]     # idempotent
     assert 0.2 * st["bytes_matrix"] < st["bytes_scanned"] < 1.6 * st["bytes_matrix"]
+
+
+@pytest.mark.gpu
+def test_more_than_256_chunks_of_reads(native):
+    """n_reads > 256 * 2048: the resolve pass must consult every chunk's summary, not the first 256 (round 2 held four
+    summaries per lane).  600,000 reads of 64 elements; the deciding rows lie in the LAST chunks: every element is
+    present in all late reads, one is absent in the very last read, one appears only in the last 1,000 reads."""
+    rng = np.random.default_rng(11)
+    E, R = 64, 600_000
+    add_invoke = (np.arange(E, dtype=np.uint32) * 2)
+    add_ok = add_invoke + 1
+    read_invoke = (2 * E + np.arange(R, dtype=np.uint32) * 4).astype(np.uint32)
+    read_ok = read_invoke + rng.integers(1, 40, R).astype(np.uint32) * 4 + 1      # overlapping reads
+    present = np.ones((R, E), bool)
+    present[: R - 1000, 7] = False            # element 7 is seen late only
+    present[R - 1, 9] = False                 # element 9 is missing from the very last read (lost)
+    present[R // 2, 11] = False               # a hole half way: last_absent in a middle chunk
+    class A:
+        pass
+    a = A(); a.E, a.R, a.wpr = E, R, E // 32
+    a.add_invoke, a.add_ok, a.read_invoke, a.read_ok = add_invoke, add_ok, read_invoke, read_ok
+    a.present = np.ascontiguousarray(np.packbits(present, axis=1, bitorder="little").view(np.uint32))
+    with sf.Scan(a) as s:
+        st = s.run()
+    inv = read_invoke.astype(np.int64)[:, None]
+    lp = np.where(present, inv, -1).max(axis=0)
+    la = np.where(~present, inv, -1).max(axis=0)
+    kn = np.minimum(np.where(present, read_ok.astype(np.int64)[:, None], 2 ** 40).min(axis=0), add_ok.astype(np.int64))
+    assert np.array_equal(np.where(st["last_present"] == N.NO_OP, -1, st["last_present"].astype(np.int64)), lp)
+    assert np.array_equal(np.where(st["last_absent"] == N.NO_OP, -1, st["last_absent"].astype(np.int64)), la)
+    assert np.array_equal(np.where(st["known"] == N.NO_OP, 2 ** 40, st["known"].astype(np.int64)), kn)
+    assert lp[9] == read_invoke[R - 2] and la[9] == read_invoke[R - 1] and la[7] == read_invoke[R - 1001]
+
+
+def test_unsorted_inputs_are_rejected_before_any_device_work(native_lib_loaded=None):
+    """tbc_setfull_create checks the documented orders (add_invoke / read_invoke strictly ascending) -- on a machine without
+    a GPU it answers TBC_ERR_NO_DEVICE first, which is fine: nothing is computed either way."""
+    import ctypes as C
+    lib = N.lib()
+    ai = np.array([4, 2], np.uint32); ao = np.array([5, 3], np.uint32)
+    ri = np.array([6], np.uint32); ro = np.array([7], np.uint32); pr = np.array([3], np.uint32)
+    inp = N.SetFullIn(2, 1, 1, 0, ai.ctypes.data_as(C.POINTER(C.c_uint32)), ao.ctypes.data_as(C.POINTER(C.c_uint32)),
+                      ri.ctypes.data_as(C.POINTER(C.c_uint32)), ro.ctypes.data_as(C.POINTER(C.c_uint32)), pr.ctypes.data_as(C.POINTER(C.c_uint32)))
+    h = C.c_void_p()
+    st = lib.tbc_setfull_create(C.byref(inp), C.byref(h))
+    assert st in (N.ERR_INVALID_ARG, N.ERR_NO_DEVICE)
+    if lib.tbc_device_count() > 0:
+        assert st == N.ERR_INVALID_ARG and b"ascending" in lib.tbc_last_error()
+
+
+def test_recalled_jepsen_details_latency_duplicates_readd():
+    """ADVICE round 2: (1) latencies are whole milliseconds of :time (a sub-millisecond gap is not a stale read);
+    (2) an element twice in one read -> :duplicated, :valid? false; (3) adding an element again starts it afresh."""
+    ms = 1_000_000
+    rows = [("invoke", "add", 1, 0, 0), ("ok", "add", 1, 0, 10), ("invoke", "read", None, 1, 20), ("ok", "read", [], 1, 30),
+            ("invoke", "read", None, 1, 40), ("ok", "read", [1], 1, 50)]
+    h = [{"type": t, "f": f, "value": v, "process": p, "index": i, "time": tm} for i, (t, f, v, p, tm) in enumerate(rows)]
+    r = osf.check(h, linearizable=True)                      # absent 10 ns after the ack: 0 ms -> not stale
+    assert r["valid?"] is True and r["stale"] == [] and r["stable-latencies"] == {0: 0, 0.5: 0, 0.95: 0, 0.99: 0, 1: 0}
+    slow = [dict(o, time=o["time"] * ms) for o in h]          # the same gaps in milliseconds: stale by 10 ms (20 ms + 1 ns - 10 ms, truncated)
+    r = osf.check(slow, linearizable=True)
+    assert r["valid?"] is False and r["stale"] == [1] and r["worst-stale"][0]["stable-latency"] == 10
+    enc = sf.Encoded(slow)
+    st = {"known": np.array([1], np.uint32), "last_present": np.array([4], np.uint32), "last_absent": np.array([2], np.uint32)}
+    g = sf.result_map(enc, st, True)
+    assert g["valid?"] is False and g["stale"] == [1] and g["worst-stale"][0]["stable-latency"] == 10
+    assert sf.result_map(sf.Encoded(h), st, True)["valid?"] is True
+    # duplicates
+    d = _h([("invoke", "add", 1, 0), ("ok", "add", 1, 0), ("invoke", "read", None, 1), ("ok", "read", [1, 1, 1], 1)])
+    r = osf.check(d)
+    assert r["valid?"] is False and r["duplicated"] == {1: 3} and r["duplicated-count"] == 1 and r["stable-count"] == 1
+    e = sf.Encoded(d)
+    assert e.duplicated == {1: 3}
+    g = sf.result_map(e, {"known": np.array([1], np.uint32), "last_present": np.array([2], np.uint32), "last_absent": np.array([N.NO_OP], np.uint32)}, False)
+    assert g["valid?"] is False and g["duplicated"] == {1: 3}
+    # re-adding: the read before the second :add invocation no longer counts for the element
+    ra = _h([("invoke", "add", 5, 0), ("ok", "add", 5, 0), ("invoke", "read", None, 1), ("ok", "read", [], 1),
+             ("invoke", "add", 5, 0), ("ok", "add", 5, 0), ("invoke", "read", None, 1), ("ok", "read", [5], 1)])
+    s5 = osf.element_states(ra)[0]
+    assert (s5["add_invoke"], s5["known"], s5["last_absent"], s5["last_present"]) == (4, 5, osf.NONE, 6)
+    e = sf.Encoded(ra)
+    assert e.add_invoke.tolist() == [4] and e.add_ok.tolist() == [5]
