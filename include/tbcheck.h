@@ -213,6 +213,18 @@ typedef struct tbc_opts {
   uint32_t dominance;        /* wide schedule / level sweep, register / cas-register:  */
                              /* two rules that drop configs without changing a verdict */
                              /* or a failing op (TBC_DOM_*); 0 = both on               */
+  uint32_t lanes_per_history;/* depth-first search, register / cas-register / mutex:    */
+                             /* 8, 16 or 32 = SEVERAL HISTORIES PER WAVEFRONT (64 / n of */
+                             /* them, n lanes each; wgl_narrow.hip): one config per      */
+                             /* iteration, n (config, call) pairs per round -- the       */
+                             /* schedule for big batches at low concurrency, where a     */
+                             /* round has few pairs.  64 = one history per wavefront     */
+                             /* (search_width configs per round).  0 = the library       */
+                             /* chooses: 8 for a batch of >= 4096 register-family        */
+                             /* histories under both dominance rules with at most 10     */
+                             /* calls in flight, if search_width is 0 too; else 64.      */
+                             /* tbc_batch_lanes_per_history() says what was chosen.      */
+  uint32_t reserved0;        /* must be 0                                                */
 } tbc_opts;
 
 /* tbc_opts.dominance bits (set = rule OFF).  Eager reads: an open read whose value is nil or
@@ -262,7 +274,7 @@ typedef struct tbc_result {
   uint32_t fail_op;          /* invalid: op whose completion cannot be passed    */
   uint32_t prev_ok_op;       /* invalid: op completing just before it (:previous-ok) */
   int32_t final_state;       /* valid: model state after the witness             */
-  uint32_t n_witness;        /* valid: ops linearized                            */
+  uint32_t n_witness;        /* valid && want_witness: ops in `witness`, else 0  */
   uint32_t search_width;     /* configs per round of the depth-first search of   */
                              /* this call (what tbc_opts.search_width 0 became)  */
   uint32_t* witness;         /* valid && want_witness: op indices, library-owned */
@@ -316,8 +328,11 @@ tbc_status tbc_batch_last_timing(const tbc_batch* b, uint64_t ns[4]);
 /* sum of tbc_counters over the last run (probes, visited ...) */
 tbc_status tbc_batch_last_counters(const tbc_batch* b, tbc_counters* out);
 uint64_t tbc_batch_device_bytes(const tbc_batch* b);
-/* the search_width this batch runs the depth-first search at (what tbc_opts.search_width = 0 resolved to) */
+/* the search_width this batch runs the depth-first search at (what tbc_opts.search_width = 0 resolved to; 1 when
+ * several histories share a wavefront) */
 uint32_t tbc_batch_search_width(const tbc_batch* b);
+/* lanes per history of the depth-first search: 8 / 16 / 32 (several histories per wavefront) or 64 */
+uint32_t tbc_batch_lanes_per_history(const tbc_batch* b);
 /* how the last run was answered when the level sweep (knossos.linear; jit_sweep.hip) is in play:
  * TBC_ALG_LINEAR always asks for it, TBC_ALG_COMPETITION on small batches that want no witness.
  * The sweep cuts a history into segments of about seg_target completions at fronts with at most

@@ -73,7 +73,7 @@ class Opts(C.Structure):
                 ("max_steps", C.c_uint64), ("max_visited_bytes", C.c_uint64),
                 ("want_witness", C.c_uint32), ("visited_per_op", C.c_uint32),
                 ("search_width", C.c_uint32), ("round_budget", C.c_uint32),
-                ("lookahead", C.c_uint32), ("dominance", C.c_uint32)]
+                ("lookahead", C.c_uint32), ("dominance", C.c_uint32), ("lanes_per_history", C.c_uint32), ("reserved0", C.c_uint32)]
 
 
 class Config(C.Structure):
@@ -153,6 +153,7 @@ SYMBOLS = {
     "tbc_batch_last_counters": (C.c_int, [C.c_void_p, C.POINTER(Counters)]),
     "tbc_batch_device_bytes": (C.c_uint64, [C.c_void_p]),
     "tbc_batch_search_width": (C.c_uint32, [C.c_void_p]),
+    "tbc_batch_lanes_per_history": (C.c_uint32, [C.c_void_p]),
     "tbc_batch_sweep_info": (C.c_int, [C.c_void_p, C.POINTER(SweepInfo)]),
     "tbc_sweep_compose": (C.c_int, [C.POINTER(SweepRel), C.c_uint32, C.c_uint32, C.POINTER(SweepVerdict)]),
     "tbc_batch_set_shard": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),

@@ -29,7 +29,7 @@ def make_model(kind, init=N.NIL, table=None, n_keys=0):
 
 def make_opts(algorithm=N.ALG_WGL, device=0, time_limit_ms=0, max_steps=0, max_visited_bytes=0,
               want_witness=True, visited_per_op=0, search_width=0, round_budget=0, lookahead=True,
-              eager_reads=True, twin_rule=True):
+              eager_reads=True, twin_rule=True, lanes_per_history=0):
     o = N.Opts()
     o.algorithm = algorithm
     o.device = device
@@ -42,6 +42,8 @@ def make_opts(algorithm=N.ALG_WGL, device=0, time_limit_ms=0, max_steps=0, max_v
     o.round_budget = int(round_budget)
     o.lookahead = 0 if lookahead else 1     # C-ABI: 0 = on (default), 1 = off
     o.dominance = (0 if eager_reads else N.DOM_NO_EAGER_READS) | (0 if twin_rule else N.DOM_NO_TWIN_RULE)
+    o.lanes_per_history = int(lanes_per_history)     # 8 / 16 / 32: several histories per wavefront; 64: one; 0: the library's choice
+    o.reserved0 = 0
     return o
 
 
@@ -193,6 +195,10 @@ class Batch:
     def search_width(self):
         """Configs per round of the depth-first search (what search_width=0 resolved to for this batch)."""
         return int(N.lib().tbc_batch_search_width(self._h))
+
+    def lanes_per_history(self):
+        """8 / 16 / 32 when several histories share a wavefront (one config per iteration), else 64."""
+        return int(N.lib().tbc_batch_lanes_per_history(self._h))
 
     def close(self):
         if self._h:

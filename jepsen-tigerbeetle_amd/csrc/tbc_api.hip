@@ -193,6 +193,7 @@ struct tbc_batch {
   DevBuf<uint64_t> d_cfg;           // configs at the failing front, kCfgCap records per history
   // wide schedule (search_width > 1)
   uint32_t width = 1;
+  uint32_t lanes = 0;               // 8 / 16 / 32: several histories per wavefront (wgl_narrow.hip), one config per iteration; 0 = one per wavefront
   std::vector<BeamHist> bh;
   DevBuf<BeamHist> d_bh;
   DevBuf<uint32_t> d_off, d_ncr, d_stack;
@@ -371,6 +372,25 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
     }
     if (events && open_sum <= 10 * events) B->width = 2;
   }
+  // Several histories per wavefront (tbc_opts.lanes_per_history).  Asked for by name it must be possible; left to the
+  // library it is taken for a big register-family batch at low concurrency under both rules (the batch the width-2 choice
+  // above is made for): a wavefront then carries 8 searches instead of one whose rounds fill 4 of its 64 lanes.
+  {
+    const uint32_t asked = opts->lanes_per_history;
+    if (asked != 0 && asked != 8 && asked != 16 && asked != 32 && asked != 64) { set_error("lanes_per_history must be 0, 8, 16, 32 or 64"); return TBC_ERR_INVALID_ARG; }
+    if (opts->reserved0 != 0) { set_error("tbc_opts.reserved0 must be 0"); return TBC_ERR_INVALID_ARG; }
+    const bool regfam3 = model->kind == TBC_MODEL_REGISTER || model->kind == TBC_MODEL_CAS_REGISTER || model->kind == TBC_MODEL_MUTEX;
+    // the narrow kernel addresses a history's tables with 32-bit element offsets
+    const bool can = beam && !B->sweep && regfam3 && narrow_supported(B->mask_words, 8) && opts->algorithm != TBC_ALG_WGL &&
+                     B->total_ops * std::max(1u, B->vpad) * B->mask_words < (1ull << 32) && look_words(B->total_ops, nh, B->mask_words) < (1ull << 32);
+    if (asked != 0 && asked != 64) {
+      if (!can) { set_error("lanes_per_history %u: needs the depth-first search of a register / cas-register / mutex batch with at most 256 process slots (not TBC_ALG_WGL, not the level sweep)", asked); return TBC_ERR_UNSUPPORTED; }
+      if (opts->search_width > 1) { set_error("lanes_per_history %u expands one config per iteration: leave search_width 0 or 1", asked); return TBC_ERR_INVALID_ARG; }
+      B->lanes = asked;
+    } else if (asked == 0 && can && opts->search_width == 0 && B->width == 2 && nh >= 4096) {
+      B->lanes = 8;
+    }
+  }
   const uint32_t EW = B->mask_words + 2;   // u64 words per wide-schedule entry
   if (B->sweep) {
     // segments: enough wavefronts to fill the GPU several times over, none shorter than 32 completions; cuts need the
@@ -435,6 +455,10 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
     }
   }
 
+  if (B->lanes && (blst_n >= (1ull << 32) || boff_n >= (1ull << 32))) {      // 32-bit element offsets (wgl_narrow_impl.h)
+    if (opts->lanes_per_history) { set_error("lanes_per_history: the batch's open-call lists exceed 2^32 entries; split the batch"); return TBC_ERR_UNSUPPORTED; }
+    B->lanes = 0;
+  }
   if (B->sweep) { bstack_n = 0; btab_n = 0; }     // the sweep has no visited set; its fallback takes scratch arenas
   tbc_status s;
   const uint64_t T = B->total_ops;
@@ -626,7 +650,7 @@ static tbc_status scratch_pass(tbc_batch* B, const std::vector<uint32_t>& grp, c
     const uint32_t nw = (uint32_t)grp.size();
     if (beam) { BeamArgs ba = make_beam_args(B, big.p, bstack.p, bdstack.p, nw); ba.pool = nullptr; ba.pool_words = 0;
       if (width_override) ba.width = width_override;
-      launch_beam(ba, B->mask_words, search_blocks(nw), s); }
+      if (B->lanes && !width_override) launch_narrow(ba, B->mask_words, B->lanes, s); else launch_beam(ba, B->mask_words, search_blocks(nw), s); }
     else { SearchArgs ra = make_search_args(B, big.p, nw); launch_search(ra, B->mask_words, search_blocks(nw), s); }
     e = hipGetLastError();
   }
@@ -824,7 +848,7 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results, int phase = 
     if (!launch_sweep(mine, s)) { set_error("level sweep launch failed"); return TBC_ERR_HIP; }
   } else if (beam) {
     BeamArgs ba = make_beam_args(B, B->d_btab.p, B->d_stack.p, B->d_dstack.p, nh);
-    if (!launch_beam(ba, B->mask_words, search_blocks(nh), s)) { set_error("unsupported mask width"); return TBC_ERR_UNSUPPORTED; }
+    if (B->lanes ? !launch_narrow(ba, B->mask_words, B->lanes, s) : !launch_beam(ba, B->mask_words, search_blocks(nh), s)) { set_error("unsupported mask width"); return TBC_ERR_UNSUPPORTED; }
   } else {
     SearchArgs sa = make_search_args(B, B->d_tab.p, nh);
     if (!launch_search(sa, B->mask_words, search_blocks(nh), s)) { set_error("unsupported mask width"); return TBC_ERR_UNSUPPORTED; }
@@ -1037,7 +1061,7 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results, int phase = 
     r.valid = d.valid; r.cause = d.cause;
     r.analyzer = B->sweep ? (by_sweep[h] ? TBC_ALG_LINEAR : TBC_ALG_WGL)
                           : (B->opts.algorithm == TBC_ALG_LINEAR ? TBC_ALG_LINEAR : TBC_ALG_WGL);
-    r.fail_op = TBC_NO_OP; r.prev_ok_op = TBC_NO_OP; r.search_width = B->width;
+    r.fail_op = TBC_NO_OP; r.prev_ok_op = TBC_NO_OP; r.search_width = (B->lanes && !is_seq[h] && !by_sweep[h]) ? 1u : B->width;
     if (d.valid == TBC_INVALID) {
       r.fail_op = d.fail_op; r.prev_ok_op = d.prev_ok_op;
       tbc_status cs = fill_configs(B, h, d, &r);
@@ -1128,7 +1152,8 @@ tbc_status tbc_batch_last_counters(const tbc_batch* b, tbc_counters* out) {
 }
 
 uint64_t tbc_batch_device_bytes(const tbc_batch* b) { return b ? b->device_bytes : 0; }
-uint32_t tbc_batch_search_width(const tbc_batch* b) { return b ? b->width : 0; }
+uint32_t tbc_batch_search_width(const tbc_batch* b) { return b ? (b->lanes ? 1u : b->width) : 0; }
+uint32_t tbc_batch_lanes_per_history(const tbc_batch* b) { return b ? (b->lanes ? b->lanes : 64u) : 0; }
 
 tbc_status tbc_batch_sweep_info(const tbc_batch* b, tbc_sweep_info* out) {
   if (!b || !out) return TBC_ERR_INVALID_ARG;

@@ -314,6 +314,9 @@ bool launch_sweep(const SweepArgs& a, void* stream);
 
 void launch_pack_open(const PackOpenArgs& a, void* stream);
 bool launch_beam(const BeamArgs& a, uint32_t mask_words, uint32_t n_blocks, void* stream);
+// several histories per wavefront (wgl_narrow.hip): `lanes` = 8 / 16 / 32 lanes per history, one config per iteration
+bool narrow_supported(uint32_t mask_words, uint32_t lanes);
+bool launch_narrow(const BeamArgs& a, uint32_t mask_words, uint32_t lanes, void* stream);
 
 // kernel launchers (defined in the .hip files)
 void launch_pack(const PackArgs& a, void* stream);

@@ -792,8 +792,10 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
     }
   }
   uint32_t wlen = 0;
-  if (verdict == TBC_VALID && Rc != 0) {
-    // witness = ops along the parent chain of the winning config, then the winning op
+  if (verdict == TBC_VALID && Rc != 0 && C->witness) {
+    // witness = ops along the parent chain of the winning config, then the winning op.  Only when it is wanted: the
+    // chain is thousands of dependent loads (a tenth of the whole search of a 10k-op history), and its length means
+    // nothing to a caller who does not get the ops
     wlen = 1;
     uint32_t id = win_parent;
     for (;;) {
@@ -801,7 +803,7 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
       if (pr == kNone) break;
       wlen++; id = pr;
     }
-    if (C->witness) {
+    {
       uint32_t* wit = C->witness + op_off_c;
       uint32_t w = wlen - 1;
       if (lane == 0) wit[w] = win_op;

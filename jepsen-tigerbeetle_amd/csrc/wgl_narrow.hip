@@ -1,0 +1,54 @@
+// wgl_narrow.hip -- K5n: the search with several histories per wavefront (gfx950); the body is wgl_narrow_impl.h.
+//
+// Launch: 4 wavefronts per workgroup, each with its own slice of LDS and its own H = 64 / L histories (work items
+// w * H .. w * H + H - 1); wavefronts never talk to each other.  Register family (register, cas-register, mutex) only:
+// the models that step on immediates and have the dominance rules that make a narrow round enough.
+#include <hip/hip_runtime.h>
+#include "tbc_internal.h"
+#include "wgl_narrow_impl.h"
+
+namespace tbc {
+
+namespace {
+
+constexpr uint32_t kNarrowWaves = 4;
+
+#ifndef TBC_NARROW_MIN_WAVES
+#define TBC_NARROW_MIN_WAVES 4
+#endif
+
+template <int MW, int L>
+__global__ __launch_bounds__(64 * kNarrowWaves, TBC_NARROW_MIN_WAVES) void wgl_narrow_kernel(BeamArgs A) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wv_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const uint32_t w = blockIdx.x * kNarrowWaves + wv_;
+  if ((uint64_t)w * (64u / L) < A.n_work) narrow::narrow_wave<MW, L>(A, w, lds + wv_ * narrow::narrow_lds_words(MW, L), lane);
+}
+
+template <int MW, int L>
+void launch_one(const BeamArgs& a, hipStream_t s) {
+  const uint32_t H = 64u / L;
+  const uint32_t waves = (a.n_work + H - 1) / H;
+  const uint32_t blocks = (waves + kNarrowWaves - 1) / kNarrowWaves;
+  const size_t lds = (size_t)kNarrowWaves * narrow::narrow_lds_words(MW, L) * 4;
+  hipLaunchKernelGGL((wgl_narrow_kernel<MW, L>), dim3(blocks), dim3(64 * kNarrowWaves), lds, s, a);
+}
+
+}  // namespace
+
+bool narrow_supported(uint32_t mask_words, uint32_t lanes) {
+  return (mask_words == 1 || mask_words == 2 || mask_words == 4) && (lanes == 8 || lanes == 16 || lanes == 32);
+}
+
+bool launch_narrow(const BeamArgs& a, uint32_t mask_words, uint32_t lanes, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+#define NARROW_CASE(MWV, LV) if (mask_words == MWV && lanes == LV) { launch_one<MWV, LV>(a, s); return true; }
+  NARROW_CASE(1, 8) NARROW_CASE(1, 16) NARROW_CASE(1, 32)
+  NARROW_CASE(2, 8) NARROW_CASE(2, 16) NARROW_CASE(2, 32)
+  NARROW_CASE(4, 8) NARROW_CASE(4, 16) NARROW_CASE(4, 32)
+#undef NARROW_CASE
+  return false;
+}
+
+}  // namespace tbc

@@ -1,0 +1,677 @@
+// wgl_narrow_impl.h -- K5n: the Wing-Gong/Lowe search with SEVERAL HISTORIES PER WAVEFRONT (gfx950).
+//
+// wgl_beam.hip gives a history a whole wavefront; under the dominance rules the search has become nearly greedy
+// (about one round per :write / :cas of the history) and at ~6 calls in flight a round keeps ~4 of the 64 lanes
+// busy: the kernel is bound by the ~460 vector instructions a round issues for those 4 lanes.  Here a wavefront is
+// cut into H = 64 / L groups of L lanes (L = 8 or 16, or 32) and every group searches its own history: the
+// instruction stream and the memory trips of a round serve H searches.
+//
+// A group runs the schedule oracle/wgl_beam.c specifies for ONE config per iteration and L pairs per round
+// (wgl_beam_check_rp(K = 1, round_pairs = L)): pop the most recent config; its open calls, last to first, are its
+// pairs, L consecutive pairs a round, one (config, open call) pair per lane; a round's new configs are pushed in
+// pair order.  Eager reads, twin rule and lookahead as in wgl_beam.hip.  Verdict, failing op, witness and every
+// counter are that schedule's, bit for bit (tests/: the emulated build on the CPU, the device build on the GPU).
+// With one parent per round no two pairs of a round produce the same config, so the "same new config from two
+// lanes" resolution of the wide kernel has nothing to do here.
+//
+// What used to be wave-uniform scalars (stack depth, visited-set address and size, the parent config, counters) is
+// uniform per GROUP and lives in vector registers (each lane holds its group's copy) or, when only one lane needs
+// it, in the group's slice of LDS: 64-bit counters are LDS adds without return by the group's first lane.  Groups
+// advance independently: each wave iteration is one round for every group that has a parent, a pop for those that
+// need one; ballots are read per group (bits gbase .. gbase + L - 1).  Cold paths (growing a visited set, the
+// results) are done for one group at a time by the whole wavefront.
+//
+// The body is plain per-lane C++ over the primitives of wave_env.h, so tests/emu/ can run this very file on the CPU.
+#pragma once
+#include "tbc_internal.h"
+#include "wave_env.h"
+
+namespace tbc {
+namespace narrow {
+
+constexpr uint32_t kNone = 0xFFFFFFFFu;
+
+// group flags
+enum : uint32_t { F_ACTIVE = 1u, F_NEED_POP = 2u, F_LOOK = 4u, F_NEED_GROW = 8u };
+
+// LDS words of a group: counters and results, then the ring of the most recent pushes
+enum : uint32_t {
+  G_DSTACK = 0, G_PROBES = 2, G_EXPANDED = 4, G_ROUNDS = 6, G_VERDICT = 8, G_CAUSE = 9, G_MAXF = 10, G_MAXSP = 11,
+  G_WINPAR = 12, G_WINOP = 13, G_WINSTATE = 14, G_RING = 16
+};
+WV_HD constexpr uint32_t ring_size(uint32_t L) { return L < 16u ? 16u : L; }
+WV_HD constexpr uint32_t group_words(uint32_t mw, uint32_t L) { return G_RING + ring_size(L) * (5u + 2u + 2u * mw); }
+// + the lookahead staging of a round (wave-wide): c_fi c_st c_lo (u32 x 64), c_M (u64 x 64 x mw)
+WV_HD constexpr uint32_t narrow_lds_words(uint32_t mw, uint32_t L) { return (64u / L) * group_words(mw, L) + 64u * 3u + 64u * 2u * mw; }
+
+WV_DEV uint32_t key_hash32(uint64_t k0, const uint64_t* M, int mw) {      // as wgl_beam.hip (a table a wide run grew is the same table)
+  uint32_t h = (uint32_t)k0 * 0x9E3779B1u ^ (uint32_t)(k0 >> 32) * 0x85EBCA77u;
+  for (int j = 0; j < mw; j++) {
+    h = (h << 13) | (h >> 19);
+    h ^= (uint32_t)M[j] * 0xC2B2AE3Du ^ (uint32_t)(M[j] >> 32) * 0x27D4EB2Fu;
+  }
+  h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15;
+  return h;
+}
+
+// look at one bucket (four entries of KW u64): match | empty << 4
+template <int MW>
+WV_DEV uint32_t scan_bucket(const wv::gu64* bp, uint64_t k0, const uint64_t (&M)[MW]) {
+  constexpr uint32_t KW = MW + 1;
+  uint32_t match = 0, empty = 0;
+  if constexpr (MW == 1) {
+    wv::u32x4 e0, e1, e2, e3;
+    wv::ld_bucket16(bp, e0, e1, e2, e3);
+    const uint32_t k0l = (uint32_t)k0, k0h = (uint32_t)(k0 >> 32), ml = (uint32_t)M[0], mh = (uint32_t)(M[0] >> 32);
+    empty = (e0.x == 0u ? 1u : 0u) | (e1.x == 0u ? 2u : 0u) | (e2.x == 0u ? 4u : 0u) | (e3.x == 0u ? 8u : 0u);
+    match = ((e0.x == k0l && e0.y == k0h && e0.z == ml && e0.w == mh) ? 1u : 0u) |
+            ((e1.x == k0l && e1.y == k0h && e1.z == ml && e1.w == mh) ? 2u : 0u) |
+            ((e2.x == k0l && e2.y == k0h && e2.z == ml && e2.w == mh) ? 4u : 0u) |
+            ((e3.x == k0l && e3.y == k0h && e3.z == ml && e3.w == mh) ? 8u : 0u);
+  } else {
+    uint64_t kk[4];
+    WV_UNROLL
+    for (int t = 0; t < 4; t++) kk[t] = wv::ld64(bp + t * KW);
+    WV_UNROLL
+    for (int t = 0; t < 4; t++) {
+      if ((uint32_t)kk[t] == 0u) empty |= 1u << t;
+      else if (kk[t] == k0) {
+        bool same = true;
+        WV_UNROLL
+        for (int j = 0; j < MW; j++) same = same && wv::ld64(bp + t * KW + 1 + j) == M[j];
+        match |= same ? 1u << t : 0u;
+      }
+    }
+  }
+  return match | empty << 4;
+}
+
+template <int MW>
+WV_DEV bool mask_bit(const uint64_t (&M)[MW], uint32_t p) {
+  bool b = false;
+  WV_UNROLL
+  for (int j = 0; j < MW; j++) if ((p >> 6) == (uint32_t)j) b = (M[j] >> (p & 63u)) & 1ull;
+  return b;
+}
+template <int MW>
+WV_DEV void mask_set(uint64_t (&M)[MW], uint32_t p) {
+  WV_UNROLL
+  for (int j = 0; j < MW; j++) if ((p >> 6) == (uint32_t)j) M[j] |= 1ull << (p & 63u);
+}
+template <int MW>
+WV_DEV void mask_clear(uint64_t (&M)[MW], uint32_t p) {
+  WV_UNROLL
+  for (int j = 0; j < MW; j++) if ((p >> 6) == (uint32_t)j) M[j] &= ~(1ull << (p & 63u));
+}
+
+// register / cas-register / mutex on immediates (device_common.h Model::ok / apply, REGF form)
+WV_DEV bool reg_ok(int32_t st, uint32_t f, int32_t a) {
+  return f == TBC_F_WRITE || (f == TBC_F_READ && (a == TBC_NIL || a == st)) || (f == TBC_F_CAS && a == st) ||
+         (f == TBC_F_ACQUIRE && st == 0) || (f == TBC_F_RELEASE && st == 1);
+}
+WV_DEV int32_t reg_apply(int32_t st, uint32_t f, int32_t a, int32_t b) {
+  return f == TBC_F_WRITE ? a : (f == TBC_F_CAS ? b : (f == TBC_F_ACQUIRE ? 1 : (f == TBC_F_RELEASE ? 0 : st)));
+}
+
+// ---- cold path: group `gsel`'s history moves to a 4x larger visited set (and stacks) from the batch's growth pool, done
+// by the whole wavefront (as wgl_beam.hip's grow_visited_set).  In / out: the group's table, stack, second stack and
+// capacity, wave-uniform.  Slot numbers change: the caller empties the group's ring.
+template <int MW, class ColdArgs>
+WV_DEV bool grow_group(ColdArgs C, wv::gu64*& tab_u, wv::gu32*& stack_u, wv::gu32*& dstack_u, uint32_t& cap_log2_u,
+                       uint32_t sp, uint32_t dsp, uint32_t lane) {
+  constexpr uint32_t KW = MW + 1, EW = MW + 2;
+  const wv::gu64* tab = tab_u;
+  const wv::gu32* stack = stack_u;
+  const wv::gu32* dstack = dstack_u;
+  const uint32_t cap_log2 = cap_log2_u;
+  const uint64_t old_cap = 1ull << cap_log2, new_cap = old_cap << 2;
+  const uint64_t need = new_cap * EW + new_cap / 2 + (dstack ? new_cap / 2 : 0) + old_cap / 2;   // keys + parents, stack(s), slot translation
+  uint64_t* const pool = C->pool;
+  if (!pool || cap_log2 + 2 > 31 || cap_log2 + 2 > C->max_tab_log2) return false;
+  unsigned long long base = 0;
+  if (lane == 0) base = atomicAdd(C->pool_cursor, (unsigned long long)need);
+  base = wv::readlane64(base, 0);
+  if (base + need > C->pool_words) return false;
+  wv::gu64* ntab = (wv::gu64*)pool + base;
+  wv::gu64* npar = ntab + new_cap * KW;
+  const wv::gu64* opar = tab + old_cap * KW;
+  wv::gu32* nstack = (wv::gu32*)(ntab + new_cap * EW);
+  wv::gu32* ndstack = dstack ? nstack + new_cap : nullptr;
+  wv::gu32* remap = nstack + new_cap + (dstack ? new_cap : 0);
+  const uint32_t nbmask = (uint32_t)((new_cap >> 2) - 1);
+  WV_NOUNROLL
+  for (uint64_t s = lane; s < old_cap; s += 64) {
+    const wv::gu64* e = tab + s * KW;
+    const uint64_t k0 = wv::ld64(e);
+    if ((uint32_t)k0 == 0u) continue;
+    uint64_t Mx[MW];
+    WV_UNROLL
+    for (int j = 0; j < MW; j++) Mx[j] = wv::ld64(e + 1 + j);
+    uint32_t b = key_hash32(k0, Mx, MW) & nbmask, idx = 0;
+    for (bool placed = false; !placed; b = (b + 1u) & nbmask) {
+      WV_NOUNROLL
+      for (uint32_t t = 0; t < 4 && !placed; t++) {
+        wv::gu64* ne = ntab + ((uint64_t)b * 4 + t) * KW;
+        if (wv::cas64_from_zero(ne, k0) == 0ull) {
+          WV_UNROLL
+          for (int j = 0; j < MW; j++) wv::st64(ne + 1 + j, Mx[j]);
+          idx = b * 4 + t; placed = true;
+        }
+      }
+    }
+    wv::st32(remap + s, idx);
+  }
+  wv::threadfence();
+  wv::barrier();
+  WV_NOUNROLL
+  for (uint64_t s = lane; s < old_cap; s += 64) {       // parent links -> new slot numbers
+    if ((uint32_t)wv::ld64(tab + s * KW) == 0u) continue;
+    const uint64_t pw = wv::ld64(opar + s);
+    const uint64_t npw = (uint32_t)pw != kNone ? ((uint64_t)wv::ld32(remap + (uint32_t)pw) | (pw & 0xFFFFFFFF00000000ull)) : pw;
+    wv::st64(npar + wv::ld32(remap + s), npw);
+  }
+  WV_NOUNROLL
+  for (uint32_t i = lane; i < sp; i += 64) wv::st32(nstack + i, wv::ld32(remap + wv::ld32(stack + i)));
+  WV_NOUNROLL
+  for (uint32_t i = lane; i < dsp; i += 64) wv::st32(ndstack + i, wv::ld32(remap + wv::ld32(dstack + i)));
+  wv::threadfence();
+  wv::barrier();
+  tab_u = ntab; stack_u = nstack; dstack_u = ndstack; cap_log2_u = cap_log2 + 2u;
+  return true;
+}
+
+// One wavefront: H = 64 / L histories, work items wave_idx * H .. + H - 1 of A.work.
+template <int MW, int L>
+WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* lds, const uint32_t lane) {
+  using wv::gu32;
+  using wv::gu64;
+  constexpr uint32_t H = 64u / L, RS = ring_size(L), KW = MW + 1, GW = group_words(MW, L);
+  static_assert(L == 4 || L == 8 || L == 16 || L == 32, "lanes per history");
+  const uint32_t li = lane & (L - 1u), gbase = lane & ~(L - 1u), g = lane / L;
+  const uint32_t below = (1u << li) - 1u;                       // the group's lower lanes, as group bits
+  constexpr uint32_t GMASK = L >= 32 ? 0xFFFFFFFFu : ((1u << (L & 31)) - 1u);
+  const auto grp = [gbase](uint64_t bal) -> uint32_t { return (uint32_t)(bal >> gbase) & GMASK; };
+
+  uint32_t* const GS = lds + g * GW;
+  uint32_t* const r_pos = GS + G_RING;          // stack position mirrored in this ring slot (kNone = empty)
+  uint32_t* const r_idx = r_pos + RS;
+  uint32_t* const r_off = r_idx + RS;
+  uint32_t* const r_nlive = r_off + RS;
+  uint32_t* const r_cnt = r_nlive + RS;
+  uint64_t* const r_k0 = reinterpret_cast<uint64_t*>(r_cnt + RS);
+  uint64_t* const r_M = r_k0 + RS;
+  uint32_t* const c_fi = lds + H * GW;          // this round's new configs for the lookahead, wave-wide
+  uint32_t* const c_st = c_fi + 64;
+  uint32_t* const c_lo = c_st + 64;
+  uint64_t* const c_M = reinterpret_cast<uint64_t*>(c_lo + 64);
+
+  // ---- the group's history
+  const uint32_t wslot = wave_idx * H + g;
+  const bool has = wslot < A.n_work;
+  const uint32_t hidx = has ? A.work[wslot] : 0u;
+  const Hist* const Hd = A.hist + hidx;
+  const BeamHist* const Bd = A.bh + hidx;
+  const uint32_t op_off = has ? (uint32_t)Hd->op_off : 0u;
+  const uint32_t R = has ? Hd->n_ret : 0u;
+  const uint32_t status = has ? (Hd->status | Bd->status) : 0u;
+  const uint32_t lst_off = has ? (uint32_t)Bd->lst_off : 0u, off_off = has ? (uint32_t)Bd->off_off : 0u;
+  const uint32_t rules = A.rules, vpad = A.vpad;
+  gu64* tab = (gu64*)A.tab + (has ? Bd->tab_off : 0ull) * (KW + 1);
+  gu32* stack = (gu32*)A.stack + (has ? Bd->stack_off : 0ull);
+  uint32_t cap_log2 = has ? Bd->tab_log2 : 10u;
+  const bool look_avail = A.look != nullptr && A.dstack != nullptr;
+  const uint32_t look_lo = (uint32_t)look_off(op_off, hidx, MW);           // u64 units into A.look
+  const uint64_t slot8_lo = slot8_off(op_off, hidx);
+
+  // ---- initial state
+  uint32_t flags = 0, sp = 0, dsp = 0, visited = 0;
+  {
+    int32_t verdict0 = -2;
+    if (!has) verdict0 = TBC_UNKNOWN;               // (no history: nothing is written for this group)
+    else if (status != 0) verdict0 = TBC_UNKNOWN;
+    else if (R == 0) verdict0 = TBC_VALID;
+    else {
+      const uint64_t k0 = 1ull | ((uint64_t)(uint32_t)A.init_state << 32);
+      uint64_t zero[MW];
+      WV_UNROLL
+      for (int j = 0; j < MW; j++) zero[j] = 0;
+      const uint32_t idx = (key_hash32(k0, zero, MW) & (uint32_t)((1ull << (cap_log2 - 2)) - 1ull)) * 4u;
+      if (li == 0) {                                // root config: first entry of its bucket, on the stack
+        gu64* e = tab + (uint64_t)idx * KW;
+        wv::st64(e, k0);
+        WV_UNROLL
+        for (int j = 0; j < MW; j++) wv::st64(e + 1 + j, 0ull);
+        wv::st64(tab + ((uint64_t)KW << cap_log2) + idx, (uint64_t)kNone | ((uint64_t)kNone << 32));
+        wv::st32(stack, idx);
+      }
+      sp = 1; visited = 1;
+      flags = F_ACTIVE | F_NEED_POP | (look_avail ? F_LOOK : 0u);
+    }
+    if (li == 0) {
+      const uint64_t ds = (look_avail && has) ? (uint64_t)((gu32*)A.dstack + Bd->stack_off) : 0ull;
+      GS[G_DSTACK] = (uint32_t)ds; GS[G_DSTACK + 1] = (uint32_t)(ds >> 32);
+      GS[G_PROBES] = 0; GS[G_PROBES + 1] = 0; GS[G_EXPANDED] = 0; GS[G_EXPANDED + 1] = 0; GS[G_ROUNDS] = 0; GS[G_ROUNDS + 1] = 0;
+      GS[G_VERDICT] = (uint32_t)verdict0; GS[G_CAUSE] = (uint32_t)TBC_CAUSE_NONE; GS[G_MAXF] = 0; GS[G_MAXSP] = sp;
+      GS[G_WINPAR] = kNone; GS[G_WINOP] = kNone; GS[G_WINSTATE] = (uint32_t)A.init_state;
+    }
+    for (uint32_t i = li; i < RS; i += L) r_pos[i] = kNone;
+  }
+  // the parent config of the group (a copy in every lane of the group)
+  uint32_t p_fi = 0, pslot = 0, poff = 0, nlive = 0, cnt = 0, base = 0;
+  int32_t p_st = 0;
+  uint64_t Mp[MW];
+  WV_UNROLL
+  for (int j = 0; j < MW; j++) Mp[j] = 0;
+  // step limit: probes left before it, saturated (refreshed from the 64-bit total every 64 iterations); time limit
+  uint32_t room = 0x7FFFFFFFu;
+  uint64_t t0 = 0;
+  {
+    const auto C = wv::cold(A);
+    const uint64_t ms = C->max_steps;
+    if (ms && ms < (uint64_t)room) room = (uint32_t)ms;
+    if (C->time_limit_ticks) t0 = wv::clock100mhz();
+  }
+  uint32_t iter = 0;
+
+  for (;;) {
+    wv::barrier();                                 // ring writes of the last round, LDS results
+    if (!wv::ballot((flags & F_ACTIVE) != 0u)) break;
+    iter++;
+    const uint32_t ln = wv::opaque(lane);
+    (void)ln;
+
+    // ---- cold: visited sets that must grow first (the parent that did not fit is still on the stack)
+    const uint64_t gb = wv::ballot((flags & F_NEED_GROW) != 0u);
+    if (gb) {
+      const auto C = wv::cold(A);
+      for (uint32_t gg = 0; gg < H; gg++) {
+        if (!((gb >> (gg * L)) & 1ull)) continue;
+        const uint32_t src = gg * L;
+        gu64* t_u = (gu64*)wv::readlane64((uint64_t)tab, src);
+        gu32* s_u = (gu32*)wv::readlane64((uint64_t)stack, src);
+        uint32_t* const GSg = lds + gg * GW;
+        gu32* d_u = (gu32*)((uint64_t)GSg[G_DSTACK] | ((uint64_t)GSg[G_DSTACK + 1] << 32));
+        uint32_t cap_u = wv::readlane(cap_log2, src);
+        const uint32_t sp_u = wv::readlane(sp, src), dsp_u = wv::readlane(dsp, src);
+        const bool ok = grow_group<MW>(C, t_u, s_u, d_u, cap_u, sp_u, dsp_u, lane);
+        if (g == gg) {
+          if (ok) {
+            tab = t_u; stack = s_u; cap_log2 = cap_u;
+            if (li == 0) { GS[G_DSTACK] = (uint32_t)(uint64_t)d_u; GS[G_DSTACK + 1] = (uint32_t)((uint64_t)d_u >> 32); }
+            for (uint32_t i = li; i < RS; i += L) r_pos[i] = kNone;       // the ring held old slot numbers
+            flags &= ~F_NEED_GROW;
+          } else {
+            flags &= ~(F_ACTIVE | F_NEED_GROW);
+            if (li == 0) { GS[G_VERDICT] = (uint32_t)TBC_UNKNOWN; GS[G_CAUSE] = (uint32_t)TBC_CAUSE_VISITED_FULL; }
+          }
+        }
+      }
+      wv::barrier();
+    }
+
+    const uint32_t bmask = (uint32_t)((1ull << (cap_log2 - 2)) - 1ull);       // bucket index mask
+    const uint32_t full_at = (uint32_t)((1ull << cap_log2) - (1ull << (cap_log2 - 2)));
+    gu64* const par = tab + ((uint64_t)KW << cap_log2);
+
+    // ---- pop: the most recent config becomes the group's parent
+    if ((flags & (F_ACTIVE | F_NEED_POP)) == (F_ACTIVE | F_NEED_POP)) {
+      if (sp == 0u && dsp != 0u) {
+        // no linearization through the live configs: those the lookahead set aside become the stack (in the order
+        // they were set aside) and the search goes on without lookahead -- an INVALID verdict has then expanded
+        // every reachable config exactly once.  The pop follows in the next iteration (the ring is emptied first).
+        // (G_DSTACK keeps naming that array: nothing is set aside any more, so it is not written again)
+        gu32* const ds = (gu32*)((uint64_t)GS[G_DSTACK] | ((uint64_t)GS[G_DSTACK + 1] << 32));
+        if (li == 0) wv::lds_max32(GS + G_MAXSP, dsp - 1u);                // (the deepest stack counts what is left after a pop)
+        stack = ds; sp = dsp; dsp = 0u; flags &= ~F_LOOK;
+        for (uint32_t i = li; i < RS; i += L) r_pos[i] = kNone;           // ring entries are keyed by stack position
+      } else if (sp == 0u) {
+        flags &= ~F_ACTIVE;
+        if (li == 0) GS[G_VERDICT] = (uint32_t)TBC_INVALID;
+      } else {
+        const uint32_t pos = sp - 1u, rs = pos & (RS - 1u);
+        uint64_t k0;
+        if (r_pos[rs] == pos) {                  // pushed recently: config (and its front's list) still in the ring
+          k0 = r_k0[rs];
+          WV_UNROLL
+          for (int j = 0; j < MW; j++) Mp[j] = r_M[rs * MW + j];
+          pslot = r_idx[rs]; poff = r_off[rs]; nlive = r_nlive[rs]; cnt = r_cnt[rs];
+        } else {
+          const uint32_t idx = wv::ld32(stack + pos);
+          const gu64* e = tab + (uint64_t)idx * KW;
+          k0 = wv::ld64(e);
+          WV_UNROLL
+          for (int j = 0; j < MW; j++) Mp[j] = wv::ld64(e + 1 + j);
+          const uint32_t fi = (uint32_t)k0 - 1u;
+          const uint32_t o0 = A.off[(uint64_t)off_off + fi], o1 = A.off[(uint64_t)off_off + fi + 1u], nc = A.ncr[(uint64_t)off_off + fi];
+          pslot = idx; poff = o0; nlive = o1 - o0; cnt = (o1 - o0) + nc;
+        }
+        p_fi = (uint32_t)k0 - 1u; p_st = (int32_t)(uint32_t)(k0 >> 32);
+        if (visited + cnt > full_at) {
+          flags |= F_NEED_GROW;                  // room for every pair of this parent?  If not it stays on the stack
+        } else {
+          sp = pos; base = 0u; flags &= ~F_NEED_POP;
+          if (li == 0) wv::lds_add64(GS + G_EXPANDED, 1ull);
+        }
+      }
+    }
+
+    // ---- the round: lane li takes pair base + li of the parent = its open call number cnt - 1 - (base + li)
+    const bool inround = (flags & (F_ACTIVE | F_NEED_POP | F_NEED_GROW)) == F_ACTIVE;
+    const uint32_t cd = base + li;
+    const bool act = inround && cd < cnt;
+    const uint32_t c = cnt - 1u - cd;
+    const uint32_t fi = p_fi;
+    const int32_t st = p_st;
+    // one trip: the candidate's record, its twin mask, and the completion slots of the next 9..16 ranks (front advance)
+    OpRec oi; oi.op = 0; oi.f_slot = kFNone; oi.a = 0; oi.b = 0;
+    const uint32_t wbase = (fi + 1u) & ~7u;
+    uint64_t w0 = 0, w1 = 0;
+    bool dominated = false;
+    const bool live = c < nlive;
+    if (act) {
+      const OpRec* rp = live ? A.lst + ((uint64_t)lst_off + poff + c) : A.crashed + ((uint64_t)op_off + (c - nlive));
+      oi = *rp;
+      const uint64_t* wp = reinterpret_cast<const uint64_t*>(A.slot8 + slot8_lo + wbase);
+      w0 = wp[0]; w1 = wp[1];
+      if ((rules & kRuleTwin) && live) {
+        const uint64_t* tw = A.twn + ((uint64_t)lst_off + poff + c) * MW;
+        WV_UNROLL
+        for (int j = 0; j < MW; j++) dominated = dominated || (tw[j] & ~Mp[j]) != 0ull;
+      }
+    }
+    const uint32_t op = oi.op;
+    const uint32_t f = oi.f_slot & 0xFFu, p = (oi.f_slot >> 8) & kSlotMask;
+    const bool lin = mask_bit<MW>(Mp, p);
+    // a crashed call has no per-front entry: its twins are every live open call with its effect (they all complete
+    // earlier) and the crashed ones invoked before it -- walk the list (crash-heavy histories only)
+    if ((rules & kRuleTwin) && act && !lin && !live && (f == TBC_F_WRITE || f == TBC_F_CAS)) {
+      for (uint32_t cc = 0; cc < c && !dominated; cc++) {
+        const OpRec y = cc < nlive ? A.lst[(uint64_t)lst_off + poff + cc] : A.crashed[(uint64_t)op_off + (cc - nlive)];
+        if ((y.f_slot & 0xFFu) != f || y.a != oi.a || (f == TBC_F_CAS && y.b != oi.b)) continue;
+        dominated = !mask_bit<MW>(Mp, (y.f_slot >> 8) & kSlotMask);
+      }
+    }
+    const bool viable = act && !lin && !dominated && reg_ok(st, f, oi.a);
+    // the child: linearize; if it was the front's own call the front moves past every completion already linearized
+    int32_t st2 = st;
+    uint32_t fi2 = fi;
+    uint64_t M2[MW];
+    WV_UNROLL
+    for (int j = 0; j < MW; j++) M2[j] = Mp[j];
+    const auto slot_at = [&](uint32_t r) -> uint32_t {
+      const uint32_t d = r - wbase;
+      if (d < 8u) return (uint32_t)(w0 >> (8u * d)) & 0xFFu;
+      if (d < 16u) return (uint32_t)(w1 >> (8u * (d - 8u))) & 0xFFu;
+      return (uint32_t)A.slot8[slot8_lo + r];
+    };
+    if (viable) {
+      st2 = reg_apply(st, f, oi.a, oi.b);
+      mask_set<MW>(M2, p);
+      if (oi.f_slot & kAtFront) {
+        uint32_t pp = p;
+        for (;;) {
+          mask_clear<MW>(M2, pp);
+          fi2++;
+          if (fi2 == R) break;
+          pp = slot_at(fi2);
+          if (!mask_bit<MW>(M2, pp)) break;
+        }
+      }
+      // eager reads: the child takes every open read its state allows (value nil or the state), the front moves past
+      // the completions that linearizes, and the calls open at the new front are looked at again
+      if ((rules & kRuleEager) && fi2 < R) {
+        for (;;) {
+          const uint64_t* row = A.rdm + ((uint64_t)op_off + fi2) * vpad * MW;
+          const uint32_t vi = rdm_index(st2, vpad);
+          WV_UNROLL
+          for (int j = 0; j < MW; j++) M2[j] |= row[j] | row[vi * MW + j];
+          uint32_t pp = slot_at(fi2);
+          if (!mask_bit<MW>(M2, pp)) break;
+          do {
+            mask_clear<MW>(M2, pp);
+            fi2++;
+            if (fi2 == R) break;
+            pp = slot_at(fi2);
+          } while (mask_bit<MW>(M2, pp));
+          if (fi2 == R) break;
+        }
+      }
+    }
+    if (inround && li == 0) wv::lds_add64(GS + G_ROUNDS, 1ull);
+    // linearizable: the group's lowest pair wins, nothing of this round is inserted
+    const uint32_t gsucc = grp(wv::ballot(viable && fi2 == R));
+    if (gsucc) {
+      if (li == (uint32_t)__builtin_ctz(gsucc)) {
+        GS[G_WINPAR] = pslot; GS[G_WINOP] = op; GS[G_WINSTATE] = (uint32_t)st2; GS[G_VERDICT] = (uint32_t)TBC_VALID;
+      }
+      flags &= ~F_ACTIVE;
+    }
+    const bool go = viable && !gsucc;
+    const uint32_t npr = (uint32_t)__builtin_popcount(grp(wv::ballot(go)));
+    if (li == 0 && npr) wv::lds_add64(GS + G_PROBES, (uint64_t)npr);
+    bool limit_hit = false;
+    if (npr > room) limit_hit = true; else room -= npr;
+
+    // the child's front: its open-call list (issued now, consumed at push; hidden under the probe)
+    uint32_t co0 = 0, co1 = 0, cnc = 0;
+    if (go) { co0 = A.off[(uint64_t)off_off + fi2]; co1 = A.off[(uint64_t)off_off + fi2 + 1u]; cnc = A.ncr[(uint64_t)off_off + fi2]; }
+
+    // ---- visited set: find the key in its bucket chain, else claim the first empty entry met (two lanes of the
+    // wavefront never hold the same key: one parent per group, one table per history; they can meet at one empty
+    // entry -- the CAS settles that and the loser looks at the bucket again)
+    const uint64_t k0c = (uint64_t)(fi2 + 1u) | ((uint64_t)(uint32_t)st2 << 32);
+    uint32_t b = key_hash32(k0c, M2, MW) & bmask, idx = 0, full_buckets = 0;
+    bool pending = go, fresh = false;
+    while (wv::ballot(pending)) {
+      if (pending) {
+        const uint32_t me = scan_bucket<MW>(tab + (uint64_t)b * (4 * KW), k0c, M2), match = me & 15u, empty = me >> 4;
+        if (match) {
+          idx = b * 4u + (uint32_t)__builtin_ctz(match);
+          pending = false;
+        } else if (empty) {
+          idx = b * 4u + (uint32_t)__builtin_ctz(empty);
+          gu64* e = tab + (uint64_t)idx * KW;
+          if (wv::cas64_from_zero(e, k0c) == 0ull) {         // claimed an empty entry
+            WV_UNROLL
+            for (int j = 0; j < MW; j++) wv::st64(e + 1 + j, M2[j]);
+            fresh = true; pending = false;
+          }                                                  // else: claimed by another lane in this very step: look again
+        } else {
+          b = (b + 1u) & bmask;
+          if (++full_buckets > bmask) pending = false;       // every bucket full: cannot happen below the 3/4 fill bound
+        }
+      }
+    }
+    if (grp(wv::ballot(full_buckets > bmask))) {
+      flags &= ~F_ACTIVE;
+      if (li == 0) { GS[G_VERDICT] = (uint32_t)TBC_UNKNOWN; GS[G_CAUSE] = (uint32_t)TBC_CAUSE_VISITED_FULL; }
+    }
+    const bool is_new = fresh;
+    if (is_new) {
+      wv::st64(par + idx, (uint64_t)pslot | ((uint64_t)(op + 1u) << 32));
+      wv::lds_max32(GS + G_MAXF, fi2);
+    }
+    const uint64_t nb0 = wv::ballot(is_new);
+
+    // ---- lookahead (register / cas-register): a new config is dead if the call completing at one of the next
+    // kLookahead ranks can never be linearized from it (wgl_beam.hip has the rule).  Staged wave-wide: 8 lanes per
+    // config, one rank each, whichever group the config belongs to.
+    bool dead = false;
+    const uint64_t lk = wv::ballot(is_new && (flags & F_LOOK));
+    if (lk) {
+      const uint32_t ci = (uint32_t)__builtin_popcountll(lk & ((1ull << lane) - 1ull)), nn0 = (uint32_t)__builtin_popcountll(lk);
+      const bool mine = is_new && (flags & F_LOOK);
+      if (mine) {
+        c_fi[ci] = fi2; c_st[ci] = (uint32_t)st2; c_lo[ci] = look_lo;
+        WV_UNROLL
+        for (int j = 0; j < MW; j++) c_M[ci * MW + j] = M2[j];
+      }
+      wv::barrier();
+      for (uint32_t cb = 0; cb < nn0; cb += 8u) {
+        const uint32_t cc = cb + (lane >> 3), j = lane & 7u;
+        const bool val = cc < nn0;
+        const uint32_t cF = val ? c_fi[cc] : 0u;
+        const int32_t cs = val ? (int32_t)c_st[cc] : 0;
+        uint64_t Mc[MW], pm[MW];
+        WV_UNROLL
+        for (int w = 0; w < MW; w++) { Mc[w] = val ? c_M[cc * MW + w] : 0ull; pm[w] = 0ull; }
+        uint64_t lw0 = (uint64_t)(kLookNone << 16 | kLookNone << 24);
+        if (val) {
+          const uint64_t* rec = A.look + (uint64_t)c_lo[cc] + (uint64_t)(cF + j) * (MW + 1);
+          lw0 = rec[0];
+          WV_UNROLL
+          for (int w = 0; w < MW; w++) pm[w] = rec[1 + w];
+        }
+        const uint32_t slot = (uint32_t)lw0 & 0xFFFFu, need = (uint32_t)(lw0 >> 16) & 0xFFu, prod = (uint32_t)(lw0 >> 24) & 0xFFu;
+        const uint32_t dinv = (uint32_t)(lw0 >> 32) & 0xFFu, dprod = (uint32_t)(lw0 >> 40) & 0xFFu;
+        bool pmhit = false;
+        WV_UNROLL
+        for (int w = 0; w < MW; w++) pmhit = pmhit || (pm[w] & ~Mc[w]) != 0ull;
+        const bool linz = dinv >= j && mask_bit<MW>(Mc, slot);     // open at the config's front and linearized
+        // values the calls completing at the ranks before this one can still provide (prefix-OR over the 8 lanes)
+        uint32_t acc = (prod != kLookNone && !linz) ? 1u << prod : 0u;
+        uint32_t x = wv::row_shr0<1>(acc);
+        if (j >= 1u) acc |= x;
+        x = wv::row_shr0<2>(acc);
+        if (j >= 2u) acc |= x;
+        x = wv::row_shr0<4>(acc);
+        if (j >= 4u) acc |= x;
+        uint32_t before = wv::row_shr0<1>(acc);
+        if (j == 0u) before = 0u;
+        const bool ok = need == kLookNone || linz || (int32_t)need == cs || dprod < j || pmhit || ((before >> need) & 1u);
+        const uint64_t bad = wv::ballot(val && !ok);
+        if (mine && ci >= cb && ci < cb + 8u) dead = ((bad >> (8u * (ci - cb))) & 0xFFull) != 0ull;
+      }
+    }
+    // ---- push the new configs in pair order: the dead ones aside, the others onto the stack (and into the ring)
+    const bool keep = is_new && !dead;
+    const uint32_t gdb = grp(wv::ballot(is_new && dead));
+    if (is_new && dead) {
+      gu32* const ds = (gu32*)((uint64_t)GS[G_DSTACK] | ((uint64_t)GS[G_DSTACK + 1] << 32));
+      wv::st32(ds + dsp + (uint32_t)__builtin_popcount(gdb & below), idx);
+    }
+    dsp += (uint32_t)__builtin_popcount(gdb);
+    const uint32_t gnb = grp(wv::ballot(keep));
+    if (keep) {
+      const uint32_t pos = sp + (uint32_t)__builtin_popcount(gnb & below);
+      wv::st32(stack + pos, idx);
+      const uint32_t rs = pos & (RS - 1u);          // at most L <= RS pushes a round: no clash
+      r_pos[rs] = pos; r_idx[rs] = idx; r_k0[rs] = k0c;
+      WV_UNROLL
+      for (int j = 0; j < MW; j++) r_M[rs * MW + j] = M2[j];
+      r_off[rs] = co0; r_nlive[rs] = co1 - co0; r_cnt[rs] = (co1 - co0) + cnc;
+    }
+    sp += (uint32_t)__builtin_popcount(gnb);
+    visited += (uint32_t)__builtin_popcount(grp(nb0));
+    if (li == 0 && gnb) wv::lds_max32(GS + G_MAXSP, sp);
+    if (inround) {
+      base += L;
+      if (base >= cnt) flags |= F_NEED_POP;
+    }
+    if (limit_hit && (flags & F_ACTIVE)) {             // the step limit, as after the round that exceeded it
+      flags &= ~F_ACTIVE;
+      if (li == 0) { GS[G_VERDICT] = (uint32_t)TBC_UNKNOWN; GS[G_CAUSE] = (uint32_t)TBC_CAUSE_STEP_LIMIT; }
+    }
+    if ((iter & 63u) == 0u) {                          // the clock, and the step room from the 64-bit total
+      const auto C = wv::cold(A);
+      const uint64_t ms = C->max_steps, limit = C->time_limit_ticks;
+      wv::barrier();
+      if (ms) {
+        const uint64_t done = (uint64_t)GS[G_PROBES] | ((uint64_t)GS[G_PROBES + 1] << 32);
+        const uint64_t left = ms - (done < ms ? done : ms);
+        room = left < 0x7FFFFFFFull ? (uint32_t)left : 0x7FFFFFFFu;
+      }
+      if (limit && (flags & F_ACTIVE) && wv::clock100mhz() - t0 > limit) {
+        flags &= ~F_ACTIVE;
+        if (li == 0) { GS[G_VERDICT] = (uint32_t)TBC_UNKNOWN; GS[G_CAUSE] = (uint32_t)TBC_CAUSE_TIME_LIMIT; }
+      }
+    }
+  }
+
+  // ---- results.  The witness (only when asked for: the parent chain is thousands of dependent loads) is walked by
+  // all groups at once, each lane following its own group's chain; the configs of an invalid verdict are collected
+  // for one group at a time by the whole wavefront.
+  wv::barrier();
+  const auto C = wv::cold(A);
+  const int32_t verdict = (int32_t)GS[G_VERDICT];
+  gu64* const par = tab + ((uint64_t)KW << cap_log2);
+  uint32_t wlen = 0;
+  if (C->witness != nullptr) {
+    const bool walk = has && verdict == TBC_VALID && R != 0u;
+    const uint32_t win_parent = GS[G_WINPAR], win_op = GS[G_WINOP];
+    uint32_t id = win_parent;
+    bool more = walk;
+    wlen = walk ? 1u : 0u;
+    while (wv::ballot(more)) {
+      if (more) {
+        const uint32_t pr = (uint32_t)wv::ld64(par + id);
+        if (pr == kNone) more = false; else { wlen++; id = pr; }
+      }
+    }
+    uint32_t* const wit = C->witness + op_off;
+    uint32_t w = wlen ? wlen - 1u : 0u;
+    if (walk && li == 0) wit[w] = win_op;
+    id = win_parent; more = walk;
+    while (wv::ballot(more)) {
+      if (more) {
+        const uint64_t po = wv::ld64(par + id);
+        const uint32_t pr = (uint32_t)po;
+        if (pr == kNone) more = false;
+        else { w--; if (li == 0) wit[w] = (uint32_t)(po >> 32) - 1u; id = pr; }
+      }
+    }
+  }
+  uint32_t n_cfg = 0;
+  const uint32_t maxf = GS[G_MAXF];
+  {
+    const uint64_t ib = wv::ballot(has && verdict == TBC_INVALID && C->cfg != nullptr);
+    for (uint32_t gg = 0; gg < H; gg++) {
+      if (!((ib >> (gg * L)) & 1ull)) continue;
+      const uint32_t src = gg * L;
+      const gu64* t_u = (const gu64*)wv::readlane64((uint64_t)tab, src);
+      const uint32_t cap_u = wv::readlane(cap_log2, src), h_u = wv::readlane(hidx, src), mf_u = wv::readlane(maxf, src);
+      const gu64* par_u = t_u + ((uint64_t)KW << cap_u);
+      uint64_t* cfg = C->cfg + (uint64_t)h_u * kCfgCap * (2 + MW);
+      const uint64_t ncap = 1ull << cap_u;
+      uint32_t n = 0;
+      for (uint64_t s0 = 0; s0 < ncap; s0 += 64) {
+        const gu64* e = t_u + (s0 + lane) * KW;
+        const uint64_t k0 = wv::ld64(e);
+        const bool hit = (uint32_t)k0 == mf_u + 1u;
+        const uint64_t hb = wv::ballot(hit);
+        if (hit) {
+          const uint32_t pos = n + (uint32_t)__builtin_popcountll(hb & ((1ull << lane) - 1ull));
+          if (pos < kCfgCap) {
+            uint64_t* o = cfg + (uint64_t)pos * (2 + MW);
+            o[0] = k0;
+            WV_UNROLL
+            for (int j = 0; j < MW; j++) o[1 + j] = wv::ld64(e + 1 + j);
+            const uint64_t pw = wv::ld64(par_u + s0 + lane);
+            o[1 + MW] = (uint32_t)pw == kNone ? (uint64_t)TBC_NO_OP : (pw >> 32) - 1ull;
+          }
+        }
+        n += (uint32_t)__builtin_popcountll(hb);
+      }
+      if (g == gg) n_cfg = n;
+    }
+  }
+  if (has && li == 0) {
+    DevResult* const out = C->results + hidx;
+    const uint64_t probes = (uint64_t)GS[G_PROBES] | ((uint64_t)GS[G_PROBES + 1] << 32);
+    const uint64_t expanded = (uint64_t)GS[G_EXPANDED] | ((uint64_t)GS[G_EXPANDED + 1] << 32);
+    const uint64_t rounds = (uint64_t)GS[G_ROUNDS] | ((uint64_t)GS[G_ROUNDS + 1] << 32);
+    out->valid = verdict; out->cause = (int32_t)GS[G_CAUSE]; out->max_front = maxf; out->depth = wlen;
+    out->final_state = (int32_t)GS[G_WINSTATE]; out->n_configs = n_cfg;
+    out->fail_op = TBC_NO_OP; out->prev_ok_op = TBC_NO_OP;
+    if (verdict == TBC_INVALID) {
+      const uint32_t* ret_op = C->ret_op + Hd->ret_off;
+      out->fail_op = ret_op[maxf];
+      if (maxf) out->prev_ok_op = ret_op[maxf - 1];
+    }
+    out->steps = probes; out->visited = (uint64_t)visited; out->probes = probes; out->backtracks = expanded;
+    out->max_depth = (uint64_t)GS[G_MAXSP]; out->bucket_reads = rounds; out->tab_log2 = cap_log2; out->pad = 0;
+  }
+}
+
+}  // namespace narrow
+}  // namespace tbc

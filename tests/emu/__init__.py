@@ -1,0 +1,110 @@
+"""TEST INFRASTRUCTURE -- NOT PRODUCT CODE.  The wavefront emulator: builds tests/emu/_build/libemu_narrow.so with g++ from
+emu_narrow.cpp + the product's own kernel body (jepsen-tigerbeetle_amd/csrc/wgl_narrow_impl.h compiled with TBC_EMU) and
+runs it through ctypes.  Nothing in the product imports this package."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(os.path.dirname(_HERE))
+_CSRC = os.path.join(_ROOT, "jepsen-tigerbeetle_amd", "csrc")
+_SO = os.path.join(_HERE, "_build", "libemu_narrow.so")
+_LIB = None
+
+
+class DevResult(C.Structure):
+    _fields_ = [("valid", C.c_int32), ("cause", C.c_int32), ("max_front", C.c_uint32), ("depth", C.c_uint32),
+                ("final_state", C.c_int32), ("n_configs", C.c_uint32), ("fail_op", C.c_uint32), ("prev_ok_op", C.c_uint32),
+                ("tab_log2", C.c_uint32), ("pad", C.c_uint32), ("steps", C.c_uint64), ("visited", C.c_uint64),
+                ("probes", C.c_uint64), ("backtracks", C.c_uint64), ("max_depth", C.c_uint64), ("bucket_reads", C.c_uint64)]
+
+
+def build(force=False):
+    srcs = [os.path.join(_HERE, "emu_narrow.cpp"), os.path.join(_HERE, "wave_env_emu.h"),
+            os.path.join(_CSRC, "wgl_narrow_impl.h"), os.path.join(_CSRC, "tbc_internal.h"), os.path.join(_CSRC, "wave_env.h")]
+    if force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs):
+        os.makedirs(os.path.dirname(_SO), exist_ok=True)
+        subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas",
+                               "-I", _HERE, "-I", _CSRC, "-o", _SO, srcs[0]])
+    return _SO
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        _LIB.emu_narrow_run.restype = C.c_int
+    return _LIB
+
+
+def _p(a, ct):
+    return a.ctypes.data_as(C.POINTER(ct))
+
+
+def rules_for(hists, model_kind, init, nil=-(2 ** 31)):
+    """(rules, vpad) as libtbcheck chooses them for a register-family batch (tbc_api.hip): both rules when every value is 0..30."""
+    if model_kind not in (0, 1):
+        return 0, 0
+    vmax = -1 if init == nil else init
+    ok = init == nil or init >= 0
+    for h in hists:
+        d = h if isinstance(h, dict) else h.as_dict()
+        a = np.asarray(d["a"], np.int64); f = np.asarray(d["f"]); b = np.asarray(d["b"], np.int64)
+        av = a[a != nil]
+        if len(av):
+            ok = ok and av.min() >= 0
+            vmax = max(vmax, int(av.max()))
+        bv = b[f == 2]
+        if len(bv):
+            ok = ok and bv.min() >= 0
+            vmax = max(vmax, int(bv.max()))
+    if not ok or vmax > 30:
+        return 0, 0
+    vpad = 2
+    while vpad < vmax + 2:
+        vpad <<= 1
+    return 3, vpad
+
+
+def run(hists, model_kind, init, L, rules=None, lookahead=True, entries_per_op=8, max_steps=0, pool_words=0, want_witness=True):
+    """hists: list of op-column dicts (f,a,b,process,inv_pos,ret_pos,n_process).  Returns one result dict per history."""
+    ds = [h if isinstance(h, dict) else h.as_dict() for h in hists]
+    nh = len(ds)
+    op_off = np.zeros(nh + 1, np.uint64)
+    for i, d in enumerate(ds):
+        op_off[i + 1] = op_off[i] + len(d["f"])
+    cat = lambda k, dt: np.ascontiguousarray(np.concatenate([np.asarray(d[k], dt) for d in ds]) if nh else np.zeros(0, dt), dt)
+    f, a, b = cat("f", np.uint8), cat("a", np.int32), cat("b", np.int32)
+    pr, inv, ret = cat("process", np.int32), cat("inv_pos", np.uint32), cat("ret_pos", np.uint32)
+    npr = np.array([int(d["n_process"]) for d in ds], np.uint32)
+    mw = max(1, (int(npr.max()) + 63) // 64)
+    mw = 1 if mw <= 1 else 2 if mw <= 2 else 4
+    r, vpad = rules_for(ds, model_kind, init)
+    if rules is not None:
+        r &= rules
+    look = bool(lookahead) and model_kind in (0, 1)
+    res = (DevResult * nh)()
+    total = int(op_off[-1])
+    wit = np.zeros(total + 1, np.uint32)
+    cfg = np.zeros(nh * 256 * (2 + mw) + 1, np.uint64)
+    rc = lib().emu_narrow_run(C.c_uint32(nh), _p(op_off, C.c_uint64), _p(npr, C.c_uint32), _p(f, C.c_uint8), _p(a, C.c_int32), _p(b, C.c_int32),
+                              _p(pr, C.c_int32), _p(inv, C.c_uint32), _p(ret, C.c_uint32), C.c_uint32(model_kind), C.c_int32(init),
+                              C.c_uint32(L), C.c_uint32(mw), C.c_uint32(r), C.c_uint32(vpad), C.c_uint32(1 if look else 0),
+                              C.c_uint32(entries_per_op), C.c_uint64(max_steps), C.c_uint64(pool_words), C.c_uint32(1 if want_witness else 0),
+                              res, _p(wit, C.c_uint32), _p(cfg, C.c_uint64))
+    if rc != 0:
+        raise RuntimeError(f"emu_narrow_run rc={rc}")
+    out = []
+    for i in range(nh):
+        d = {k: getattr(res[i], k) for k, _ in DevResult._fields_}
+        o = int(op_off[i])
+        d["chain"] = wit[o:o + d["depth"]].copy() if (d["valid"] == 1 and want_witness) else None
+        rec = cfg[i * 256 * (2 + mw):(i + 1) * 256 * (2 + mw)].reshape(256, 2 + mw)
+        d["cfg"] = rec[:min(d["n_configs"], 256)].copy()
+        d["rules"], d["vpad"], d["mw"] = r, vpad, mw
+        out.append(d)
+    return out

@@ -1,0 +1,190 @@
+// TEST INFRASTRUCTURE -- NOT PRODUCT CODE.  emu_narrow.cpp: runs the narrow search kernel's body
+// (jepsen-tigerbeetle_amd/csrc/wgl_narrow_impl.h, the very file hipcc compiles into libtbcheck.so) on the CPU under
+// the wavefront emulator of wave_env_emu.h, on tables built here ON THE HOST FROM THEIR DEFINITIONS
+// (csrc/tbc_internal.h, csrc/pack_open.hip's header): a second, independent formulation of what pack_kernel /
+// open_counts / open_walk / open_dprod leave in HBM.  tests/test_narrow_emu.py compares the results with the oracle
+// (oracle/wgl_beam.c at one config per iteration and L pairs per round).  Built by tests/emu/build.py with g++;
+// nothing under jepsen-tigerbeetle_amd/ links or loads it.
+#define TBC_EMU 1
+#define __HIPCC__ 1          // tbc_internal.h's look_val / look_need / look_prod / rec_cls helpers
+#include "wave_env_emu.h"
+#include "../../jepsen-tigerbeetle_amd/csrc/wgl_narrow_impl.h"
+
+#include <algorithm>
+#include <vector>
+
+using namespace tbc;
+
+namespace {
+
+struct Tables {
+  std::vector<Hist> hist;
+  std::vector<BeamHist> bh;
+  std::vector<uint32_t> off, ncr, ret_op, ret_slot;
+  std::vector<OpRec> lst, crashed;
+  std::vector<uint64_t> twn, rdm, look;
+  std::vector<uint8_t> slot8;
+};
+
+// the per-front tables of every history of the batch, from the definitions
+bool build_tables(uint32_t nh, const uint64_t* op_off, const uint32_t* n_process, const uint8_t* f, const int32_t* a, const int32_t* b,
+                  const int32_t* process, const uint32_t* inv_pos, const uint32_t* ret_pos, uint32_t MW, uint32_t vpad,
+                  uint32_t tab_log2_per_op, Tables& T) {
+  const uint64_t total = op_off[nh];
+  T.hist.assign(nh, Hist{}); T.bh.assign(nh, BeamHist{});
+  T.ret_op.assign(total + 1, 0); T.ret_slot.assign(total + 1, 0);
+  T.crashed.assign(total + 1, OpRec{0, kFNone, 0, 0});
+  T.slot8.assign(slot8_bytes(total, nh), 0);
+  T.rdm.assign(total * vpad * MW + 1, 0);
+  T.look.assign(look_words(total, nh, MW), 0);
+  uint64_t off_n = 0, lst_n = 0, tab_n = 0;
+  for (uint32_t h = 0; h < nh; h++) {
+    const uint64_t o = op_off[h];
+    const uint32_t n = (uint32_t)(op_off[h + 1] - o);
+    Hist& H = T.hist[h]; BeamHist& B = T.bh[h];
+    H.op_off = o; H.ret_off = o; H.n_ops = n; H.n_slots = n_process[h]; H.status = 0;
+    if (n_process[h] > 64 * MW) return false;
+    // ranks
+    std::vector<std::pair<uint32_t, uint32_t>> rets;
+    for (uint32_t i = 0; i < n; i++) if (ret_pos[o + i] != TBC_POS_CRASHED) rets.push_back({ret_pos[o + i], i});
+    std::sort(rets.begin(), rets.end());
+    const uint32_t R = (uint32_t)rets.size();
+    H.n_ret = R;
+    std::vector<uint32_t> ret_rank(n, kInf), inv_rank(n, 0);
+    for (uint32_t r = 0; r < R; r++) { ret_rank[rets[r].second] = r; T.ret_op[o + r] = rets[r].second; T.ret_slot[o + r] = (uint32_t)process[o + rets[r].second]; }
+    { uint32_t r = 0; for (uint32_t i = 0; i < n; i++) { while (r < R && rets[r].first < inv_pos[o + i]) r++; inv_rank[i] = r; } }
+    // per-front lists
+    B.off_off = off_n; B.lst_off = lst_n;
+    T.off.resize(off_n + n + 2, 0); T.ncr.resize(off_n + n + 2, 0);
+    uint32_t* off = T.off.data() + off_n; uint32_t* ncr = T.ncr.data() + off_n;
+    uint32_t ncrash = 0;
+    for (uint32_t i = 0; i < n; i++) if (ret_rank[i] == kInf && !(f[o + i] == TBC_F_READ && a[o + i] == TBC_NIL)) {
+      T.crashed[o + ncrash++] = OpRec{i, (uint32_t)f[o + i] | ((uint32_t)process[o + i] << 8), a[o + i], b[o + i]};
+      if (inv_rank[i] < R) ncr[inv_rank[i]]++;
+    }
+    for (uint32_t r = 1; r < R; r++) ncr[r] += ncr[r - 1];
+    B.n_crashed = ncrash;
+    std::vector<std::vector<uint32_t>> open(R);
+    for (uint32_t i = 0; i < n; i++) if (ret_rank[i] != kInf) for (uint32_t F = inv_rank[i]; F <= ret_rank[i]; F++) open[F].push_back(i);
+    uint32_t run = 0;
+    for (uint32_t F = 0; F < R; F++) {
+      off[F] = run;
+      std::sort(open[F].begin(), open[F].end(), [&](uint32_t x, uint32_t y) { return process[o + x] < process[o + y]; });
+      run += (uint32_t)open[F].size();
+    }
+    off[R] = run;
+    T.lst.resize(lst_n + run + 1); T.twn.resize((lst_n + run + 1) * MW, 0);
+    for (uint32_t F = 0; F < R; F++) {
+      for (uint32_t k = 0; k < open[F].size(); k++) {
+        const uint32_t x = open[F][k];
+        const uint32_t px = (uint32_t)process[o + x];
+        T.lst[lst_n + off[F] + k] = OpRec{x, (uint32_t)f[o + x] | (px << 8) | (ret_rank[x] == F ? kAtFront : 0u), a[o + x], b[o + x]};
+        // twins: the live calls open here with the same effect that complete earlier
+        if (f[o + x] == TBC_F_WRITE || f[o + x] == TBC_F_CAS)
+          for (uint32_t y : open[F]) {
+            if (y == x || f[o + y] != f[o + x] || a[o + y] != a[o + x] || (f[o + x] == TBC_F_CAS && b[o + y] != b[o + x])) continue;
+            if (ret_rank[y] < ret_rank[x]) { const uint32_t py = (uint32_t)process[o + y]; T.twn[(lst_n + off[F] + k) * MW + (py >> 6)] |= 1ull << (py & 63); }
+          }
+        // open-read masks by value
+        if (f[o + x] == TBC_F_READ && vpad) {
+          const uint32_t vi = rdm_index(a[o + x], vpad);
+          if (vi != 0u || a[o + x] == TBC_NIL) T.rdm[((o + F) * vpad + vi) * MW + (px >> 6)] |= 1ull << (px & 63);
+        }
+      }
+    }
+    // completion slots as bytes
+    uint8_t* s8 = T.slot8.data() + slot8_off(o, h);
+    for (uint32_t r = 0; r < R + 16; r++) s8[r] = r < R ? (uint8_t)process[o + rets[r].second] : 0;
+    // lookahead records
+    uint64_t* look = T.look.data() + look_off(o, h, MW);
+    const uint32_t LW = 1 + MW;
+    for (uint32_t t = 0; t < R + kLookPad; t++) {
+      if (t >= R) { look[(uint64_t)t * LW] = (uint64_t)(kLookNone << 16 | kLookNone << 24) | (255ull << 32) | (255ull << 40); continue; }
+      const uint32_t x = rets[t].second, px = (uint32_t)process[o + x];
+      const uint32_t need = look_need(f[o + x], a[o + x]), prod = look_prod(f[o + x], a[o + x], b[o + x]);
+      const uint32_t dinv = std::min(t - inv_rank[x], 255u);
+      uint32_t dprod = 255;
+      if (need != kLookNone) {
+        for (uint32_t i = 0; i < n; i++) {
+          if (i == x || look_prod(f[o + i], a[o + i], b[o + i]) != need) continue;
+          if (ret_rank[i] == kInf && f[o + i] == TBC_F_READ) continue;
+          if (inv_rank[i] <= t && t - inv_rank[i] < kLookahead) dprod = std::min(dprod, t - inv_rank[i]);
+          // open at front t (live, or crashed and a candidate) and producing the needed value
+          const bool open_here = inv_rank[i] <= t && (ret_rank[i] == kInf || ret_rank[i] >= t);
+          if (open_here) { const uint32_t pi = (uint32_t)process[o + i]; look[(uint64_t)t * LW + 1 + (pi >> 6)] |= 1ull << (pi & 63); }
+        }
+      }
+      look[(uint64_t)t * LW] = (uint64_t)(px & 0xFFFFu) | (uint64_t)need << 16 | (uint64_t)prod << 24 | (uint64_t)dinv << 32 | (uint64_t)dprod << 40;
+    }
+    // visited set + stacks
+    uint32_t lg = 10;
+    while ((1ull << lg) < (uint64_t)tab_log2_per_op * std::max(n, 1u)) lg++;
+    B.tab_log2 = lg; B.tab_off = tab_n; B.stack_off = tab_n; B.lst_cap = run; B.status = 0;
+    tab_n += 1ull << lg;
+    off_n += n + 2; lst_n += run;
+  }
+  T.lst.resize(lst_n + 1); T.twn.resize((lst_n + 1) * MW);
+  return true;
+}
+
+template <int MW, int L>
+struct WaveCall { const BeamArgs* A; uint32_t wave; uint32_t* lds; };
+template <int MW, int L>
+void wave_entry(void* p, uint32_t lane) {
+  auto* c = (WaveCall<MW, L>*)p;
+  narrow::narrow_wave<MW, L>(*c->A, c->wave, c->lds, lane);
+}
+template <int MW, int L>
+void run_all(const BeamArgs& A) {
+  const uint32_t H = 64 / L;
+  const uint32_t waves = (A.n_work + H - 1) / H;
+  std::vector<uint32_t> lds(narrow::narrow_lds_words(MW, L) + 16);
+  for (uint32_t w = 0; w < waves; w++) {
+    std::fill(lds.begin(), lds.end(), 0xDEADBEEFu);          // LDS is not zeroed on the device either
+    WaveCall<MW, L> c{&A, w, lds.data()};
+    wv::run_wave(&wave_entry<MW, L>, &c);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+// tables only (for comparing with what the device kernels wrote): returns sizes through out_n[8] and copies into caller buffers when given
+int emu_narrow_run(uint32_t nh, const uint64_t* op_off, const uint32_t* n_process, const uint8_t* f, const int32_t* a, const int32_t* b,
+                   const int32_t* process, const uint32_t* inv_pos, const uint32_t* ret_pos, uint32_t model_kind, int32_t init,
+                   uint32_t L, uint32_t MW, uint32_t rules, uint32_t vpad, uint32_t lookahead, uint32_t entries_per_op, uint64_t max_steps,
+                   uint64_t pool_words, uint32_t want_witness, DevResult* results, uint32_t* witness, uint64_t* cfg_out) {
+  Tables T;
+  if (!build_tables(nh, op_off, n_process, f, a, b, process, inv_pos, ret_pos, MW, vpad ? vpad : 1, entries_per_op, T)) return 1;
+  const uint64_t total = op_off[nh];
+  uint64_t entries = 0;
+  for (uint32_t h = 0; h < nh; h++) entries += 1ull << T.bh[h].tab_log2;
+  const uint32_t EW = MW + 2;
+  std::vector<uint64_t> tab(entries * EW + 1, 0), pool(pool_words + 1, 0), cfg((uint64_t)nh * kCfgCap * (2 + MW) + 1, 0);
+  std::vector<uint32_t> stack(entries + 1, 0), dstack(entries + 1, 0), work(nh), wit(total + 1, 0);
+  unsigned long long cursor = 0;
+  for (uint32_t h = 0; h < nh; h++) work[h] = h;
+  std::vector<DevResult> res(nh);
+  memset(res.data(), 0xFF, nh * sizeof(DevResult));
+  BeamArgs A{};
+  A.hist = T.hist.data(); A.bh = T.bh.data(); A.off = T.off.data(); A.ncr = T.ncr.data(); A.lst = T.lst.data(); A.crashed = T.crashed.data();
+  A.look = lookahead ? T.look.data() : nullptr; A.slot8 = T.slot8.data(); A.ret_slot = T.ret_slot.data(); A.ret_op = T.ret_op.data();
+  A.stack = stack.data(); A.dstack = lookahead ? dstack.data() : nullptr; A.tab = tab.data(); A.results = res.data();
+  A.witness = want_witness ? wit.data() : nullptr; A.work = work.data(); A.table = nullptr; A.n_work = nh; A.model_kind = model_kind;
+  A.init_state = init; A.width = 1; A.max_steps = max_steps; A.time_limit_ticks = 0; A.dbg = nullptr;
+  A.pool = pool_words ? pool.data() : nullptr; A.pool_cursor = &cursor; A.pool_words = pool_words; A.max_tab_log2 = 28;
+  A.pool_vals = nullptr; A.cfg = cfg.data(); A.rules = rules; A.twn = (rules & kRuleTwin) ? T.twn.data() : nullptr;
+  A.rdm = (rules & kRuleEager) ? T.rdm.data() : nullptr; A.vpad = vpad;
+#define RUN(MWV, LV) if (MW == MWV && L == LV) { run_all<MWV, LV>(A); ran = true; }
+  bool ran = false;
+  RUN(1, 4) RUN(1, 8) RUN(1, 16) RUN(1, 32) RUN(2, 8) RUN(2, 16) RUN(4, 8) RUN(4, 16)
+#undef RUN
+  if (!ran) return 2;
+  memcpy(results, res.data(), nh * sizeof(DevResult));
+  if (want_witness && witness) memcpy(witness, wit.data(), total * 4);
+  if (cfg_out) memcpy(cfg_out, cfg.data(), (uint64_t)nh * kCfgCap * (2 + MW) * 8);
+  return 0;
+}
+
+}  // extern "C"

@@ -452,3 +452,104 @@ def test_pack_rejects_out_of_range_pool_references(native):
         with pytest.raises(N.TbcError) as err:
             core.check_ops(ops, e.native_model, core.make_opts(algorithm=N.ALG_COMPETITION))
         assert err.value.status == N.ERR_MODEL, mutate
+
+
+# ---- K5n: several histories per wavefront (wgl_narrow.hip; the same body runs emulated in tests/test_narrow_emu.py)
+NARROW_SHAPES = [(8, 3, 0.1, 0.0, 0.8), (8, 3, 0.1, 0.5, 0.8), (40, 4, 0.0, 0.0, 0.5), (40, 4, 0.05, 0.5, 0.5), (200, 8, 0.02, 0.0, 0.5),
+                 (200, 8, 0.0, 0.6, 0.3), (1000, 16, 0.0, 0.0, 0.5), (1000, 16, 0.01, 0.0, 0.3), (1000, 16, 0.0, 0.6, 0.2),
+                 (3000, 64, 0.0, 0.0, 0.1), (3000, 64, 0.0, 0.6, 0.05)]
+
+
+def _narrow_expect(oracle, h, L, **kw):
+    return oracle.check_beam(h.as_dict(), CAS, 1, round_pairs=L, rules_at_any_round_size=True, **kw)
+
+
+def _assert_narrow(got, exp, tag):
+    assert got["valid"] == exp["valid"], (tag, got["valid"], exp["valid"], got["cause"])
+    assert got["search_width"] == 1, tag
+    assert (got["probes"], got["visited"], got["backtracks"], got["max_depth"]) == (exp["probes"], exp["visited"], exp["expanded"], exp["max_stack"]), tag
+    if exp["valid"] == 1:
+        assert got["final_state"] == exp["final_state"], tag
+        if got["witness"] is not None:
+            assert np.array_equal(got["witness"], exp["witness"]), tag
+    elif exp["valid"] == 0:
+        assert got["fail_op"] == exp["fail_op"], tag
+
+
+@pytest.mark.parametrize("L", [8, 16, 32])
+def test_narrow_kernel_matches_its_oracle(native, oracle, L):
+    """lanes_per_history = L: 64 / L histories per wavefront, each on the oracle's schedule for one config per iteration and
+    L pairs per round -- every shape x 3 seeds in ONE launch, so wavefronts mix lengths, verdicts and ends."""
+    hists = [columns.pair_events(synth.register_events(n_ops=n, n_procs=p, seed=s, busy=busy, info=info, corrupt=corrupt))
+             for (n, p, info, corrupt, busy) in NARROW_SHAPES for s in range(3)]
+    with core.Batch(hists, gm(), core.make_opts(time_limit_ms=60000, algorithm=N.ALG_COMPETITION, lanes_per_history=L)) as b:
+        assert b.lanes_per_history() == L and b.search_width() == 1
+        res = b.run().results()
+        again = b.run().results()
+    for i, (h, got) in enumerate(zip(hists, res)):
+        _assert_narrow(got, _narrow_expect(oracle, h, L), (L, i))
+        assert (again[i]["valid"], again[i]["probes"], again[i]["visited"]) == (got["valid"], got["probes"], got["visited"])      # idempotent
+
+
+def test_narrow_kernel_rules_lookahead_growth_and_limits(native, oracle):
+    hists = [columns.pair_events(synth.register_events(n_ops=600, n_procs=8, seed=s, busy=0.3, info=0.01, corrupt=c)) for s in range(6) for c in (0.0, 0.5)]
+    for kw, okw in (({"eager_reads": False}, {"eager_reads": False}), ({"twin_rule": False}, {"twin_rule": False}), ({"lookahead": False}, {"lookahead": False}),
+                    ({"eager_reads": False, "twin_rule": False, "lookahead": False}, {"eager_reads": False, "twin_rule": False, "lookahead": False})):
+        with core.Batch(hists, gm(), core.make_opts(time_limit_ms=60000, algorithm=N.ALG_COMPETITION, lanes_per_history=8, **kw)) as b:
+            res = b.run().results()
+        for i, (h, got) in enumerate(zip(hists, res)):
+            _assert_narrow(got, _narrow_expect(oracle, h, 8, **okw), (str(kw), i))
+    # first visited sets of one entry per op: histories of one wavefront outgrow theirs inside the kernel (growth pool)
+    big = [columns.pair_events(synth.register_events(n_ops=2500, n_procs=16, seed=s, busy=0.25, corrupt=c)) for s in range(8) for c in (0.0, 0.4)]
+    with core.Batch(big, gm(), core.make_opts(time_limit_ms=60000, algorithm=N.ALG_COMPETITION, lanes_per_history=8, visited_per_op=1)) as b:
+        res = b.run().results()
+    for i, (h, got) in enumerate(zip(big, res)):
+        _assert_narrow(got, _narrow_expect(oracle, h, 8), ("grow", i))
+    assert max(r["table_slots"] for r in res) >= 4 * 4096
+    # the step limit, counted as the oracle counts it (after the round that exceeded it)
+    with core.Batch(hists, gm(), core.make_opts(algorithm=N.ALG_COMPETITION, lanes_per_history=16, max_steps=57, want_witness=False)) as b:
+        res = b.run().results()
+    for i, (h, got) in enumerate(zip(hists, res)):
+        exp = _narrow_expect(oracle, h, 16, max_probes=57)
+        assert got["valid"] == exp["valid"] and (exp["valid"] != -1 or got["cause"] == N.CAUSE_STEP_LIMIT), i
+        assert (got["probes"], got["visited"]) == (exp["probes"], exp["visited"]), i
+
+
+def test_narrow_kernel_wide_masks_and_other_models(native, oracle):
+    h2 = [columns.pair_events(synth.register_events(n_ops=1200, n_procs=24, seed=s, busy=0.15, info=0.05)) for s in range(4)]
+    assert all(64 < h.n_process <= 128 for h in h2)
+    h4 = [columns.pair_events(synth.register_events(n_ops=2000, n_procs=32, seed=s, busy=0.1, info=0.08)) for s in range(3)]
+    assert all(128 < h.n_process <= 256 for h in h4)
+    for hists, L in ((h2, 8), (h2, 16), (h4, 8)):
+        with core.Batch(hists, gm(), core.make_opts(time_limit_ms=60000, algorithm=N.ALG_COMPETITION, lanes_per_history=L, max_steps=60000)) as b:
+            res = b.run().results()
+        for i, (h, got) in enumerate(zip(hists, res)):
+            _assert_narrow(got, _narrow_expect(oracle, h, L, max_probes=60000), (L, h.n_process, i))
+    # plain register (no :cas): the same kernel
+    reg = [columns.pair_events(synth.register_events(n_ops=500, n_procs=8, seed=s, busy=0.3, info=0.01, corrupt=c, read=0.5, write=0.5)) for s in range(4) for c in (0.0, 0.5)]
+    with core.Batch(reg, core.make_model(N.MODEL_REGISTER, N.NIL), core.make_opts(time_limit_ms=60000, algorithm=N.ALG_COMPETITION, lanes_per_history=8)) as b:
+        res = b.run().results()
+    for i, (h, got) in enumerate(zip(reg, res)):
+        exp = oracle.check_beam(h.as_dict(), {"kind": 0, "init": N.NIL}, 1, round_pairs=8, rules_at_any_round_size=True)
+        _assert_narrow(got, exp, ("register", i))
+    # what the narrow kernel does not do is refused by name, not answered some other way
+    with pytest.raises(N.TbcError):
+        core.Batch(reg, core.make_model(N.MODEL_REGISTER, N.NIL), core.make_opts(algorithm=N.ALG_WGL, lanes_per_history=8))
+    with pytest.raises(N.TbcError):
+        core.Batch(reg, core.make_model(N.MODEL_REGISTER, N.NIL), core.make_opts(algorithm=N.ALG_COMPETITION, lanes_per_history=8, search_width=4))
+
+
+def test_big_quiet_batches_take_the_narrow_kernel_by_default(native, oracle):
+    """tbc_opts.lanes_per_history = 0 and search_width = 0: a batch of >= 4096 register-family histories at low concurrency
+    under both rules runs 8 to a wavefront; smaller or busier batches keep a wavefront each."""
+    base = [columns.pair_events(synth.register_events(n_ops=300, n_procs=16, seed=s, busy=0.2)) for s in range(64)]
+    opts = core.make_opts(time_limit_ms=60000, algorithm=N.ALG_COMPETITION, want_witness=False)
+    with core.Batch([base[i % 64] for i in range(4096)], gm(), opts) as b:
+        assert (b.lanes_per_history(), b.search_width()) == (8, 1)
+        res = b.run().results()
+    for i in range(64):
+        exp = _narrow_expect(oracle, base[i], 8)
+        for k in range(0, 4096, 64 * 13):
+            _assert_narrow(res[i + k], exp, (i, k))
+    with core.Batch(base, gm(), opts) as b:
+        assert (b.lanes_per_history(), b.search_width()) == (64, 2)

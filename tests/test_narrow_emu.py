@@ -1,0 +1,138 @@
+"""K5n on the CPU: the narrow search kernel's own body (jepsen-tigerbeetle_amd/csrc/wgl_narrow_impl.h, several histories
+per wavefront) compiled for the wavefront emulator of tests/emu/ and compared with the oracle's schedule for one config per
+iteration and L pairs per round (oracle/wgl_beam.c, wgl_beam_check_rp(K = 1, round_pairs = L)) -- verdict, failing op,
+witness chain, final state and every counter, bit for bit.  The tables the kernel reads are built on the host from their
+definitions (tests/emu/emu_narrow.cpp), a second formulation of what the pack kernels write.  The same comparisons run on
+the device in tests/test_gpu_parity.py; here a schedule bug costs seconds to find and needs no GPU.
+
+The emulator is test infrastructure: only this file and tests/emu/ use it; libtbcheck.so has no CPU path."""
+import numpy as np
+import pytest
+
+import emu
+from jepsen_tigerbeetle_amd import _native as N, columns, synth
+from oracle import wgl
+
+CAS = {"kind": 1, "init": N.NIL}
+
+
+def expand_chain(d, chain, model, eager):
+    """The chain of branching calls replayed from the initial state, absorbing reads as the search does (a third
+    formulation, besides oracle/wgl_beam.c's and tbc_api.hip's expand_eager_witness)."""
+    if not eager:
+        return [int(x) for x in chain]
+    f, a, b, proc = (np.asarray(d[k]) for k in ("f", "a", "b", "process"))
+    inv, ret = np.asarray(d["inv_pos"], np.int64), np.asarray(d["ret_pos"], np.int64)
+    n = len(f)
+    live = [i for i in range(n) if ret[i] != 0xFFFFFFFF]
+    by_ret = sorted(live, key=lambda i: ret[i])
+    R = len(by_ret)
+    rank_of_pos = {int(ret[i]): r for r, i in enumerate(by_ret)}
+    inv_rank = [sum(1 for i2 in by_ret if ret[i2] < inv[i]) for i in range(n)] if n < 400 else None
+    if inv_rank is None:
+        rets = np.sort(ret[live])
+        inv_rank = np.searchsorted(rets, inv, side="left").tolist()
+    ret_rank = {i: rank_of_pos[int(ret[i])] for i in live}
+    done, out = set(), []
+    front, state = 0, model["init"]
+
+    def advance():
+        nonlocal front
+        moved = False
+        while front < R and by_ret[front] in done:
+            front += 1
+            moved = True
+        return moved
+
+    for op in chain:
+        op = int(op)
+        state = int(a[op]) if f[op] == 1 else (int(b[op]) if f[op] == 2 else state)
+        done.add(op); out.append(op)
+        advance()
+        again = True
+        while again and front < R:
+            opens = sorted((i for i in live if i not in done and inv_rank[i] <= front <= ret_rank[i]), key=lambda i: proc[i])
+            for x in opens:
+                if f[x] == 0 and (a[x] == N.NIL or a[x] == state):
+                    done.add(x); out.append(x)
+            again = advance()
+    return out
+
+
+def compare(hists, model, L, kind=1, tag="", **kw):
+    ds = [h.as_dict() for h in hists]
+    got = emu.run(ds, kind, model["init"], L, **kw)
+    for i, (d, g) in enumerate(zip(ds, got)):
+        e = wgl.check_beam(d, model, 1, round_pairs=L, rules_at_any_round_size=True, lookahead=kw.get("lookahead", True),
+                           eager_reads=bool(g["rules"] & 1), twin_rule=bool(g["rules"] & 2), max_probes=kw.get("max_steps", 0))
+        t = (tag, i, L)
+        assert g["valid"] == e["valid"], (t, g["valid"], e["valid"], g["cause"])
+        for a_, b_ in (("probes", "probes"), ("visited", "visited"), ("backtracks", "expanded"), ("max_depth", "max_stack"), ("bucket_reads", "rounds")):
+            assert g[a_] == e[b_], (t, a_, g[a_], e[b_])
+        if e["valid"] == 0:
+            assert (g["fail_op"], g["prev_ok_op"]) == (e["fail_op"], e["prev_ok_op"]), t
+        if e["valid"] == 1 and len(d["f"]):
+            assert g["final_state"] == e["final_state"], t
+            assert expand_chain(d, g["chain"], model, bool(g["rules"] & 1)) == [int(x) for x in e["witness"]], t
+    return got
+
+
+SHAPES = [(8, 3, 0.1, 0.0, 0.8), (8, 3, 0.1, 0.5, 0.8), (40, 4, 0.0, 0.0, 0.5), (40, 4, 0.05, 0.5, 0.5), (200, 8, 0.02, 0.0, 0.5),
+          (200, 8, 0.0, 0.6, 0.3), (1000, 16, 0.0, 0.0, 0.5), (1000, 16, 0.01, 0.0, 0.3), (1000, 16, 0.0, 0.6, 0.2), (2000, 64, 0.0, 0.0, 0.1)]
+
+
+@pytest.mark.parametrize("L", [8, 16])
+def test_every_shape_one_batch_per_width(L):
+    """all shapes x 3 seeds in ONE launch: wavefronts hold histories of different lengths, verdicts and ends"""
+    hists = [columns.pair_events(synth.register_events(n_ops=n, n_procs=p, seed=s, busy=busy, info=info, corrupt=corrupt))
+             for (n, p, info, corrupt, busy) in SHAPES for s in range(3)]
+    compare(hists, CAS, L, tag="shapes", pool_words=4_000_000)
+
+
+@pytest.mark.parametrize("L", [4, 32])
+def test_other_group_sizes(L):
+    hists = [columns.pair_events(synth.register_events(n_ops=n, n_procs=p, seed=s, busy=busy, info=info, corrupt=corrupt))
+             for (n, p, info, corrupt, busy) in SHAPES[:7] for s in range(2)]
+    compare(hists, CAS, L, tag="sizes", pool_words=4_000_000)
+
+
+def test_rules_and_lookahead_switched_off_one_by_one():
+    hists = [columns.pair_events(synth.register_events(n_ops=300, n_procs=6, seed=s, busy=0.3, info=0.01, corrupt=c)) for s in range(4) for c in (0.0, 0.5)]
+    for rules in (0, 1, 2, 3):
+        for look in (True, False):
+            compare(hists, CAS, 8, tag=f"rules{rules}look{look}", rules=rules, lookahead=look, pool_words=4_000_000)
+
+
+def test_visited_sets_grow_inside_the_kernel():
+    """first visited sets of 1 entry per op (1,024 at least): several histories of a wavefront outgrow theirs, some twice"""
+    hists = [columns.pair_events(synth.register_events(n_ops=2500, n_procs=16, seed=s, busy=0.25, info=0.0, corrupt=c)) for s in range(5) for c in (0.0, 0.4)]
+    got = compare(hists, CAS, 8, tag="grow", entries_per_op=1, pool_words=8_000_000)
+    first = [max(10, int(np.ceil(np.log2(max(1, len(h.as_dict()["f"])))))) for h in hists]
+    assert sum(g["tab_log2"] > f0 for g, f0 in zip(got, first)) >= 5 and max(g["tab_log2"] - f0 for g, f0 in zip(got, first)) >= 2
+    # without a pool a history that outgrows its set ends UNKNOWN / VISITED_FULL (the host then retries with a larger one)
+    small = emu.run([h.as_dict() for h in hists[:3]], 1, N.NIL, 8, entries_per_op=1, pool_words=0)
+    assert all(g["valid"] == N.UNKNOWN and g["cause"] == N.CAUSE_VISITED_FULL for g in small)
+
+
+def test_step_limit_as_the_oracle_counts_it():
+    hists = [columns.pair_events(synth.register_events(n_ops=600, n_procs=8, seed=s, busy=0.4, info=0.0, corrupt=0.0)) for s in range(6)]
+    for limit in (1, 57, 300):
+        got = compare(hists, CAS, 8, tag=f"limit{limit}", max_steps=limit, pool_words=1_000_000)
+        assert all(g["valid"] == N.UNKNOWN and g["cause"] == N.CAUSE_STEP_LIMIT for g in got)
+
+
+def test_plain_register():
+    reg = {"kind": 0, "init": N.NIL}
+    hists = [columns.pair_events(synth.register_events(n_ops=400, n_procs=8, seed=s, busy=0.3, info=0.01, corrupt=c, read=0.5, write=0.5)) for s in range(3) for c in (0.0, 0.5)]
+    compare(hists, reg, 8, kind=0, tag="register", pool_words=1_000_000)
+
+
+def test_wide_masks_many_crashed_processes():
+    """crashed calls retire their process slot: 2 and 4 mask words; the crashed candidates' twin walk"""
+    h2 = [columns.pair_events(synth.register_events(n_ops=1200, n_procs=24, seed=s, busy=0.15, info=0.05, corrupt=0.0)) for s in range(3)]
+    assert all(64 < h.n_process <= 128 for h in h2), [h.n_process for h in h2]
+    compare(h2, CAS, 8, tag="mw2", pool_words=4_000_000, max_steps=60_000)
+    compare(h2, CAS, 16, tag="mw2", pool_words=4_000_000, max_steps=60_000)
+    h4 = [columns.pair_events(synth.register_events(n_ops=2000, n_procs=32, seed=s, busy=0.1, info=0.08, corrupt=0.0)) for s in range(2)]
+    assert all(128 < h.n_process <= 256 for h in h4), [h.n_process for h in h4]
+    compare(h4, CAS, 8, tag="mw4", pool_words=4_000_000, max_steps=40_000)
