@@ -329,7 +329,8 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
     const char* env = std::getenv("TBC_SWEEP");          // 0 = never, 1 = whenever possible (experiments)
     const bool forced = env && env[0] == '1', never = env && env[0] == '0';
     const bool asked = opts->algorithm == TBC_ALG_LINEAR ||
-                       (opts->algorithm == TBC_ALG_COMPETITION && !opts->want_witness && opts->search_width == 0 && nh <= 256);
+                       (opts->algorithm == TBC_ALG_COMPETITION && !opts->want_witness && opts->search_width == 0 && nh <= 256 &&
+                        (opts->lanes_per_history == 0 || opts->lanes_per_history == 64));      // (a named depth-first schedule is not the sweep)
     B->sweep = !never && (asked || forced) && !commutative && B->mask_words == 1 && width <= 16;
     if (B->sweep && width < 2) width = 4;                // the fallback's schedule; the per-front lists are the wide kernel's
   }
@@ -650,7 +651,8 @@ static tbc_status scratch_pass(tbc_batch* B, const std::vector<uint32_t>& grp, c
     const uint32_t nw = (uint32_t)grp.size();
     if (beam) { BeamArgs ba = make_beam_args(B, big.p, bstack.p, bdstack.p, nw); ba.pool = nullptr; ba.pool_words = 0;
       if (width_override) ba.width = width_override;
-      if (B->lanes && !width_override) launch_narrow(ba, B->mask_words, B->lanes, s); else launch_beam(ba, B->mask_words, search_blocks(nw), s); }
+      // (a retry runs the schedule of the first pass: several histories per wavefront stay so)
+      if (B->lanes && (!width_override || width_override == B->width)) launch_narrow(ba, B->mask_words, B->lanes, s); else launch_beam(ba, B->mask_words, search_blocks(nw), s); }
     else { SearchArgs ra = make_search_args(B, big.p, nw); launch_search(ra, B->mask_words, search_blocks(nw), s); }
     e = hipGetLastError();
   }
