@@ -12,6 +12,7 @@
 //            nil) are left out altogether: no effect on the model, no constraint, but each would double the
 //            config space (oracle/wgl_beam.c)
 //   slot8[]  process slot of the call completing at each rank, one byte each
+//   rk8[]    (narrow kernel) per rank: 0xFF = the completing call is not a read, else the rdm index of its value
 //   twn[] rdm[]  the dominance tables (tbc_internal.h): twin masks per list entry, open-read masks per front
 //   look[]   one lookahead record per completion rank (layout: tbc_internal.h)
 //
@@ -106,6 +107,15 @@ __global__ __launch_bounds__(1024) void open_counts_kernel(PackOpenArgs A) {
 
     // A: histogram of the live calls' invocation ranks (in off[]), crashed-call counts by front, completion slots as bytes
     for (uint32_t r = tid; r < R + 16u; r += NT) slot8[r] = r < R ? (uint8_t)ret_slot[r] : (uint8_t)0;
+    if (A.rk8) {          // what kind of call completes at each rank, for the narrow kernel's register-only front advance
+      uint8_t* rk8 = A.rk8 + slot8_off(H->op_off, h);
+      const uint32_t* ret_op = A.ret_op + H->ret_off;
+      for (uint32_t r = tid; r < R + 16u; r += NT) {
+        uint8_t k = 0xFF;
+        if (r < R) { const uint32_t x = ret_op[r]; if (f[x] == TBC_F_READ) k = (uint8_t)rdm_index(a[x], A.vpad); }
+        rk8[r] = k;
+      }
+    }
     for (uint32_t i0 = tid; i0 < n; i0 += 4u * NT) {          // four ops per trip
       uint32_t ir[4], rr[4]; bool nilread[4];
 #pragma unroll
@@ -258,7 +268,8 @@ __global__ __launch_bounds__(256) void open_walk_kernel(PackOpenArgs A) {
   const uint32_t* ret_slot = A.ret_slot + H->ret_off;
   uint64_t* twn = A.twn ? A.twn + B->lst_off * MW : nullptr;
   const uint32_t V = A.vpad;
-  uint64_t* rdm = A.rdm ? A.rdm + H->op_off * V * MW : nullptr;
+  const uint32_t FW = A.front_words ? A.front_words : V * MW;            // u64 words per front: a plain row, or a front record
+  uint64_t* rdm = A.rdm ? A.rdm + H->op_off * FW : nullptr;
   uint64_t* look = A.look ? A.look + look_off(H->op_off, h, MW) : nullptr;
   uint32_t* tmp = A.tmp ? A.tmp + H->op_off : nullptr;
 
@@ -364,7 +375,7 @@ __global__ __launch_bounds__(256) void open_walk_kernel(PackOpenArgs A) {
       }
       if (lane < V) {
 #pragma unroll
-        for (int j = 0; j < MW; j++) rdm[((uint64_t)F * V + lane) * MW + j] = mine[j];
+        for (int j = 0; j < MW; j++) rdm[(uint64_t)F * FW + lane * MW + j] = mine[j];
       }
     }
     // lookahead record of rank F: what the completing call needs / produces, who else open here produces it
@@ -455,6 +466,33 @@ __global__ __launch_bounds__(1024) void open_dprod_kernel(PackOpenArgs A) {
   }
 }
 
+// ---- front records (narrow kernel): the part of each record that is not the read masks -- where the front's list is, how
+// many calls are open, and the windows of completion slots / read kinds of ranks F .. F + 15.  One thread per front, streaming:
+// every input is an array the counts kernel wrote (neighbouring threads read neighbouring words), 48 B written per front.
+__global__ __launch_bounds__(256) void front_meta_kernel(PackOpenArgs A) {
+  const uint32_t cph = A.chunks_per_hist * 64u;                 // fronts per history at most, rounded up to the walk's chunks
+  const uint64_t gid = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+  const uint32_t h = (uint32_t)(gid / cph), F = (uint32_t)(gid - (uint64_t)h * cph);
+  if (h >= A.n_hist) return;
+  const Hist* H = &A.hist[h];
+  const BeamHist* B = &A.bh[h];
+  if (H->status != 0 || B->status != 0 || F >= H->n_ret) return;
+  const uint32_t* off = A.off + B->off_off;
+  const uint32_t o0 = off[F], o1 = off[F + 1u], nc = A.ncr[B->off_off + F];
+  const uint8_t* s8 = A.slot8 + slot8_off(H->op_off, h) + F;
+  const uint8_t* k8 = A.rk8 + slot8_off(H->op_off, h) + F;
+  uint64_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (uint32_t l = 0; l < 16; l++) {                          // (both arrays are padded 16 past the last rank)
+    w[l >> 3] |= (uint64_t)s8[l] << (8u * (l & 7u));
+    w[2 + (l >> 3)] |= (uint64_t)k8[l] << (8u * (l & 7u));
+  }
+  uint64_t* rec = A.rdm + (H->op_off + F) * A.front_words + A.vpad * A.mask_words;
+  rec[0] = (uint64_t)o0 | ((uint64_t)(o1 - o0) << 32);
+  rec[1] = (uint64_t)((o1 - o0) + nc);
+  rec[2] = w[0]; rec[3] = w[1]; rec[4] = w[2]; rec[5] = w[3];
+}
+
 void launch_pack_open(const PackOpenArgs& a, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   const uint32_t grid = a.n_hist < 4096 ? a.n_hist : 4096;
@@ -469,6 +507,10 @@ void launch_pack_open(const PackOpenArgs& a, void* stream) {
     default: hipLaunchKernelGGL(open_walk_kernel<4>, dim3(wgrid), dim3(256), 0, s, a); break;
   }
   if (a.look) hipLaunchKernelGGL(open_dprod_kernel, dim3(grid), dim3(nt), 0, s, a);
+  if (a.front_words) {
+    const uint64_t fronts = (uint64_t)a.n_hist * a.chunks_per_hist * 64u;
+    hipLaunchKernelGGL(front_meta_kernel, dim3((uint32_t)((fronts + 255) / 256)), dim3(256), 0, s, a);
+  }
 }
 
 }  // namespace tbc

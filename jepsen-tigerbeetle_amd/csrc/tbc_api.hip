@@ -199,6 +199,7 @@ struct tbc_batch {
   DevBuf<uint32_t> d_off, d_ncr, d_stack;
   DevBuf<OpRec> d_lst, d_crashed;   // per-front open-call lists / crashed calls, whole records
   DevBuf<uint8_t> d_slot8;          // completion slots as bytes
+  DevBuf<uint8_t> d_rk8;            // narrow kernel: read kind per rank
   bool lookahead = false;           // wide single-wave schedule, register family, tbc_opts.lookahead != 1
   DevBuf<uint64_t> d_look;          // lookahead records per completion rank
   DevBuf<uint32_t> d_dstack;        // second stack per history: configs the lookahead set aside
@@ -233,7 +234,7 @@ struct tbc_batch {
     d_bitmap.release(); d_wpre.release(); d_frames.release(); d_witness.release(); d_work.release();
     d_queue.release(); d_tab.release(); d_results.release(); d_table.release(); d_pool_vals.release(); d_cfg.release();
     d_bh.release(); d_off.release(); d_ncr.release(); d_lst.release(); d_crashed.release(); d_stack.release();
-    d_occ.release(); d_btab.release(); d_slot8.release(); d_look.release(); d_looktmp.release(); d_twn.release(); d_rdm.release(); d_cuts.release(); d_seglist.release(); d_sres.release(); d_dstack.release(); d_pool.release(); d_pool_cursor.release();
+    d_occ.release(); d_btab.release(); d_slot8.release(); d_rk8.release(); d_look.release(); d_looktmp.release(); d_twn.release(); d_rdm.release(); d_cuts.release(); d_seglist.release(); d_sres.release(); d_dstack.release(); d_pool.release(); d_pool_cursor.release();
     if (!borrowed) {
       for (auto& e : ev) if (e) (void)hipEventDestroy(e);
       if (stream) (void)hipStreamDestroy(stream);
@@ -383,7 +384,7 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
     const bool regfam3 = model->kind == TBC_MODEL_REGISTER || model->kind == TBC_MODEL_CAS_REGISTER || model->kind == TBC_MODEL_MUTEX;
     // the narrow kernel addresses a history's tables with 32-bit element offsets
     const bool can = beam && !B->sweep && regfam3 && narrow_supported(B->mask_words, 8) && opts->algorithm != TBC_ALG_WGL &&
-                     B->total_ops * std::max(1u, B->vpad) * B->mask_words < (1ull << 32) && look_words(B->total_ops, nh, B->mask_words) < (1ull << 32);
+                     look_words(B->total_ops, nh, B->mask_words) < (1ull << 32);
     if (asked != 0 && asked != 64) {
       if (!can) { set_error("lanes_per_history %u: needs the depth-first search of a register / cas-register / mutex batch with at most 256 process slots (not TBC_ALG_WGL, not the level sweep)", asked); return TBC_ERR_UNSUPPORTED; }
       if (opts->search_width > 1) { set_error("lanes_per_history %u expands one config per iteration: leave search_width 0 or 1", asked); return TBC_ERR_INVALID_ARG; }
@@ -478,7 +479,10 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
       return s;
     if (B->sweep && ((s = B->d_cuts.alloc((uint64_t)nh * B->max_segs)) || (s = B->d_sres.alloc((uint64_t)nh * B->max_segs * kSweepSlices)) || (s = B->d_seglist.alloc((uint64_t)nh * B->max_segs * kSweepSlices * 3)))) return s;
     if (B->sweep) B->seg_host.resize((size_t)nh * B->max_segs * kSweepSlices);
-    if (B->rules && ((s = B->d_twn.alloc(blst_n * B->mask_words)) || (s = B->d_rdm.alloc(T * B->vpad * B->mask_words)))) return s;
+    if (B->lanes && (s = B->d_rk8.alloc(slot8_bytes(T, nh)))) return s;
+    if (B->rules && ((s = B->d_twn.alloc(blst_n * B->mask_words)) || (s = B->d_rdm.alloc(B->lanes ? 1 : T * B->vpad * B->mask_words)))) return s;
+    // several histories per wavefront: front records (tbc_internal.h) instead of plain rows, with or without the rules
+    if (B->lanes) { B->d_rdm.release(); if ((s = B->d_rdm.alloc(T * front_stride(B->vpad, B->mask_words)))) return s; }
     if (B->lookahead && ((s = B->d_look.alloc(look_words(T, nh, B->mask_words))) || (s = B->d_looktmp.alloc(T)) ||
                          (s = B->d_dstack.alloc(bstack_n)))) return s;
     // growth pool: 30 % of the visited-set arena, at least room for one history to grow twice (4x, then 16x: keys, parents, two stacks, slot translation), at most 32 GiB
@@ -507,7 +511,7 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
                     B->d_ret_op.bytes() + B->d_bitmap.bytes() + B->d_wpre.bytes() + B->d_frames.bytes() +
                     B->d_tab.bytes() + B->d_results.bytes() + B->d_work.bytes() + B->d_witness.bytes();
   if (beam) B->device_bytes += B->d_bh.bytes() + B->d_off.bytes() + B->d_ncr.bytes() + B->d_lst.bytes() +
-                               B->d_crashed.bytes() + B->d_slot8.bytes() + B->d_twn.bytes() + B->d_rdm.bytes() + B->d_look.bytes() + B->d_looktmp.bytes() + B->d_dstack.bytes() + B->d_stack.bytes() + B->d_btab.bytes() + B->d_pool.bytes();
+                               B->d_crashed.bytes() + B->d_slot8.bytes() + B->d_rk8.bytes() + B->d_twn.bytes() + B->d_rdm.bytes() + B->d_look.bytes() + B->d_looktmp.bytes() + B->d_dstack.bytes() + B->d_stack.bytes() + B->d_btab.bytes() + B->d_pool.bytes();
 
   if (t_ctx) {
     B->borrowed = true; B->stream = t_ctx->stream;
@@ -598,7 +602,7 @@ static BeamArgs make_beam_args(tbc_batch* B, uint64_t* tab, uint32_t* stack, uin
   a.model_aux = B->model.init; a.n_keys = B->model.n_keys;
   a.n_classes = B->model.n_classes; a.width = B->width;
   a.round_budget = B->opts.round_budget;
-  a.rules = B->rules; a.twn = B->d_twn.p; a.rdm = B->d_rdm.p; a.vpad = B->vpad;
+  a.rules = B->rules; a.twn = B->d_twn.p; a.rdm = B->d_rdm.p; a.vpad = B->vpad; a.rk8 = B->d_rk8.p; a.front_words = B->lanes ? front_stride(B->vpad, B->mask_words) : 0u; a.next_work = B->d_queue.p;
   a.max_steps = B->opts.max_steps;
   a.time_limit_ticks = B->opts.time_limit_ms * 100000ull;
   a.dbg = debug_words();
@@ -833,7 +837,8 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results, int phase = 
     po.rec = B->d_rec.p; po.seg = B->d_seg.p; po.chunks_per_hist = (uint32_t)((B->max_ops + 63) / 64);
     po.crashed = B->d_crashed.p; po.ret_slot = B->d_ret_slot.p; po.slot8 = B->d_slot8.p;
     po.ret_op = B->d_ret_op.p; po.look = B->lookahead ? B->d_look.p : nullptr; po.tmp = B->d_looktmp.p; po.n_hist = nh; po.mask_words = B->mask_words;
-    po.twn = B->rules ? B->d_twn.p : nullptr; po.rdm = B->rules ? B->d_rdm.p : nullptr; po.vpad = B->vpad;
+    po.rk8 = B->lanes ? B->d_rk8.p : nullptr; po.front_words = B->lanes ? front_stride(B->vpad, B->mask_words) : 0u;
+    po.twn = B->rules ? B->d_twn.p : nullptr; po.rdm = (B->rules || B->lanes) ? B->d_rdm.p : nullptr; po.vpad = B->vpad;
     launch_pack_open(po, s);
     HIP_TRY(hipGetLastError());
   }

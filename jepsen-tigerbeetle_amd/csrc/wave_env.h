@@ -49,6 +49,15 @@ WV_DEV uint64_t ld64(const gu64* p) { return __hip_atomic_load(p, __ATOMIC_RELAX
 WV_DEV void st64(gu64* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 WV_DEV uint32_t ld32(const gu32* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 WV_DEV void st32(gu32* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// the same memory when ONE wavefront owns it for the whole launch (a history's visited set and stacks in wgl_narrow): plain
+// accesses.  They stay coherent inside the compute unit (every access of its waves goes through its L1), several loads of one
+// line become one request to L2 (an sc1 load is a request of its own: a bucket read as 4-8 of them was 4-8 requests), and a
+// plain store leaves the line in L2 to be merged with its neighbours' (an sc1 store writes its sector through to memory).
+WV_DEV uint64_t own_ld64(const gu64* p) { return *p; }
+WV_DEV void own_st64(gu64* p, uint64_t v) { *p = v; }
+WV_DEV uint32_t own_ld32(const gu32* p) { return *p; }
+WV_DEV void own_st32(gu32* p, uint32_t v) { *p = v; }
+WV_DEV u32x4 own_ld128(const gu64* p) { return *reinterpret_cast<const WV_GLOBAL u32x4*>(p); }
 // claim an empty entry: returns what was there (0 = claimed)
 WV_DEV uint64_t cas64_from_zero(gu64* p, uint64_t desired) {
   uint64_t expected = 0ull;
@@ -68,12 +77,18 @@ WV_DEV void ld_bucket16(const gu64* bucket, u32x4& e0, u32x4& e1, u32x4& e2, u32
       : "memory");
 }
 
+// every store of this wavefront has reached memory (gfx9: stores count in vmcnt)
+WV_DEV void wait_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 // ---- LDS counters: read-modify-write without a return value (ds_add / ds_max), one lane per word at a time
 WV_DEV void lds_add32(uint32_t* p, uint32_t v) { (void)__hip_atomic_fetch_add((WV_LDS uint32_t*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
 WV_DEV void lds_add64(uint32_t* p, uint64_t v) { (void)__hip_atomic_fetch_add((WV_LDS uint64_t*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
 WV_DEV void lds_max32(uint32_t* p, uint32_t v) { (void)__hip_atomic_fetch_max((WV_LDS uint32_t*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
 
 WV_DEV uint64_t clock100mhz() { return (uint64_t)wall_clock64(); }
+
+// schedule statistics of an emulated run (tests/emu): nothing on the device
+WV_DEV void stat(uint32_t, uint64_t) {}
 
 // arguments only cold paths read come from the kernarg segment where they are used (kept out of the loop's registers)
 template <class Args>

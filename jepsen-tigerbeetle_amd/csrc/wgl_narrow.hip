@@ -14,7 +14,7 @@ namespace {
 constexpr uint32_t kNarrowWaves = 4;
 
 #ifndef TBC_NARROW_MIN_WAVES
-#define TBC_NARROW_MIN_WAVES 4
+#define TBC_NARROW_MIN_WAVES 3
 #endif
 
 template <int MW, int L>
@@ -23,16 +23,35 @@ __global__ __launch_bounds__(64 * kNarrowWaves, TBC_NARROW_MIN_WAVES) void wgl_n
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wv_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const uint32_t w = blockIdx.x * kNarrowWaves + wv_;
-  if ((uint64_t)w * (64u / L) < A.n_work) narrow::narrow_wave<MW, L>(A, w, lds + wv_ * narrow::narrow_lds_words(MW, L), lane);
+  narrow::narrow_wave<MW, L>(A, w, lds + wv_ * narrow::narrow_lds_words(MW, L), lane);
+}
+
+// Wavefronts the GPU keeps resident at once: the launch is sized to that, not to the batch -- a wavefront's groups take more
+// histories off the queue as they finish (BeamArgs.next_work), so no wavefront starts late into a half-empty machine and a
+// group whose history was short does not idle until its seven neighbours are done.
+uint32_t resident_waves(size_t lds_bytes_per_wave) {
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  uint32_t per_cu = 4u * TBC_NARROW_MIN_WAVES;
+  const uint32_t by_lds = (uint32_t)((160u * 1024u) / (lds_bytes_per_wave ? lds_bytes_per_wave : 1));
+  if (by_lds < per_cu) per_cu = by_lds;
+  per_cu = per_cu / kNarrowWaves * kNarrowWaves;
+  if (per_cu == 0) per_cu = kNarrowWaves;
+  return (uint32_t)cus * per_cu;
 }
 
 template <int MW, int L>
-void launch_one(const BeamArgs& a, hipStream_t s) {
+void launch_one(const BeamArgs& a_in, hipStream_t s) {
   const uint32_t H = 64u / L;
-  const uint32_t waves = (a.n_work + H - 1) / H;
+  const size_t lds_wave = (size_t)narrow::narrow_lds_words(MW, L) * 4;
+  uint32_t waves = (a_in.n_work + H - 1) / H;
+  const uint32_t fit = resident_waves(lds_wave);
+  if (waves > fit) waves = fit;
   const uint32_t blocks = (waves + kNarrowWaves - 1) / kNarrowWaves;
-  const size_t lds = (size_t)kNarrowWaves * narrow::narrow_lds_words(MW, L) * 4;
-  hipLaunchKernelGGL((wgl_narrow_kernel<MW, L>), dim3(blocks), dim3(64 * kNarrowWaves), lds, s, a);
+  BeamArgs a = a_in;
+  a.first_dynamic = blocks * kNarrowWaves * H;          // what the launch deals out; the queue hands out the rest
+  (void)hipMemsetAsync(a.next_work, 0, sizeof(unsigned int), s);
+  hipLaunchKernelGGL((wgl_narrow_kernel<MW, L>), dim3(blocks), dim3(64 * kNarrowWaves), lds_wave * kNarrowWaves, s, a);
 }
 
 }  // namespace

@@ -32,15 +32,21 @@ namespace narrow {
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 
 // group flags
-enum : uint32_t { F_ACTIVE = 1u, F_NEED_POP = 2u, F_LOOK = 4u, F_NEED_GROW = 8u };
+enum : uint32_t { F_ACTIVE = 1u, F_NEED_POP = 2u, F_LOOK = 4u, F_NEED_GROW = 8u, F_CAND = 16u };
 
 // LDS words of a group: counters and results, then the ring of the most recent pushes
 enum : uint32_t {
   G_DSTACK = 0, G_PROBES = 2, G_EXPANDED = 4, G_ROUNDS = 6, G_VERDICT = 8, G_CAUSE = 9, G_MAXF = 10, G_MAXSP = 11,
-  G_WINPAR = 12, G_WINOP = 13, G_WINSTATE = 14, G_RING = 16
+  G_WINPAR = 12, G_WINOP = 13, G_WINSTATE = 14,
+  G_T0 = 52,        // 2 words: when the history was taken up (time limit)
+  G_NEXT = 54,      // the work item a finished group takes next
+  G_PF = 16,        // 4 words: front, list offset, live and all open calls of the child whose candidates are fetched ahead
+  G_CLAIM = 20,     // 32 words: who takes the empty entry of a bucket (by bucket number mod 32) this round
+  G_RING = 56
 };
 WV_HD constexpr uint32_t ring_size(uint32_t L) { return L < 16u ? 16u : L; }
-WV_HD constexpr uint32_t group_words(uint32_t mw, uint32_t L) { return G_RING + ring_size(L) * (5u + 2u + 2u * mw); }
+// ring entry: pos idx off nlive cnt (u32), k0 (u64), M[mw] (u64), the four window words of the config's front (u64)
+WV_HD constexpr uint32_t group_words(uint32_t mw, uint32_t L) { return G_RING + ring_size(L) * (5u + 2u + 2u * mw + 8u); }
 // + the lookahead staging of a round (wave-wide): c_fi c_st c_lo (u32 x 64), c_M (u64 x 64 x mw)
 WV_HD constexpr uint32_t narrow_lds_words(uint32_t mw, uint32_t L) { return (64u / L) * group_words(mw, L) + 64u * 3u + 64u * 2u * mw; }
 
@@ -200,32 +206,37 @@ WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* ld
   uint32_t* const r_cnt = r_nlive + RS;
   uint64_t* const r_k0 = reinterpret_cast<uint64_t*>(r_cnt + RS);
   uint64_t* const r_M = r_k0 + RS;
+  uint64_t* const r_W = r_M + RS * MW;          // windows of completion slots / read kinds from the config's front on
   uint32_t* const c_fi = lds + H * GW;          // this round's new configs for the lookahead, wave-wide
   uint32_t* const c_st = c_fi + 64;
   uint32_t* const c_lo = c_st + 64;
   uint64_t* const c_M = reinterpret_cast<uint64_t*>(c_lo + 64);
 
-  // ---- the group's history
-  const uint32_t wslot = wave_idx * H + g;
-  const bool has = wslot < A.n_work;
-  const uint32_t hidx = has ? A.work[wslot] : 0u;
-  const Hist* const Hd = A.hist + hidx;
-  const BeamHist* const Bd = A.bh + hidx;
-  const uint32_t op_off = has ? (uint32_t)Hd->op_off : 0u;
-  const uint32_t R = has ? Hd->n_ret : 0u;
-  const uint32_t status = has ? (Hd->status | Bd->status) : 0u;
-  const uint32_t lst_off = has ? (uint32_t)Bd->lst_off : 0u, off_off = has ? (uint32_t)Bd->off_off : 0u;
+  // ---- the group's history (a group takes a new one whenever it has finished one: A.next_work)
   const uint32_t rules = A.rules, vpad = A.vpad;
-  gu64* tab = (gu64*)A.tab + (has ? Bd->tab_off : 0ull) * (KW + 1);
-  gu32* stack = (gu32*)A.stack + (has ? Bd->stack_off : 0ull);
-  uint32_t cap_log2 = has ? Bd->tab_log2 : 10u;
   const bool look_avail = A.look != nullptr && A.dstack != nullptr;
-  const uint32_t look_lo = (uint32_t)look_off(op_off, hidx, MW);           // u64 units into A.look
-  const uint64_t slot8_lo = slot8_off(op_off, hidx);
-
-  // ---- initial state
+  bool has = false;
+  uint32_t hidx = 0, op_off = 0, R = 0, lst_off = 0, look_lo = 0, cap_log2 = 10;
+  uint64_t slot8_lo = 0;
+  gu64* tab = (gu64*)A.tab;
+  gu32* stack = (gu32*)A.stack;
   uint32_t flags = 0, sp = 0, dsp = 0, visited = 0;
-  {
+  uint32_t room = 0x7FFFFFFFu;          // step limit: probes left before it, saturated (refreshed from the 64-bit total every 64 iterations)
+  const auto init_group = [&](uint32_t wslot) {
+    has = wslot < A.n_work;
+    hidx = has ? A.work[wslot] : 0u;
+    const Hist* const Hd = A.hist + hidx;
+    const BeamHist* const Bd = A.bh + hidx;
+    op_off = has ? (uint32_t)Hd->op_off : 0u;
+    R = has ? Hd->n_ret : 0u;
+    const uint32_t status = has ? (Hd->status | Bd->status) : 0u;
+    lst_off = has ? (uint32_t)Bd->lst_off : 0u;
+    tab = (gu64*)A.tab + (has ? Bd->tab_off : 0ull) * (KW + 1);
+    stack = (gu32*)A.stack + (has ? Bd->stack_off : 0ull);
+    cap_log2 = has ? Bd->tab_log2 : 10u;
+    look_lo = (uint32_t)look_off(op_off, hidx, MW);           // u64 units into A.look
+    slot8_lo = slot8_off(op_off, hidx);
+    flags = 0; sp = 0; dsp = 0; visited = 0;
     int32_t verdict0 = -2;
     if (!has) verdict0 = TBC_UNKNOWN;               // (no history: nothing is written for this group)
     else if (status != 0) verdict0 = TBC_UNKNOWN;
@@ -238,52 +249,179 @@ WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* ld
       const uint32_t idx = (key_hash32(k0, zero, MW) & (uint32_t)((1ull << (cap_log2 - 2)) - 1ull)) * 4u;
       if (li == 0) {                                // root config: first entry of its bucket, on the stack
         gu64* e = tab + (uint64_t)idx * KW;
-        wv::st64(e, k0);
+        wv::own_st64(e, k0);
         WV_UNROLL
-        for (int j = 0; j < MW; j++) wv::st64(e + 1 + j, 0ull);
-        wv::st64(tab + ((uint64_t)KW << cap_log2) + idx, (uint64_t)kNone | ((uint64_t)kNone << 32));
-        wv::st32(stack, idx);
+        for (int j = 0; j < MW; j++) wv::own_st64(e + 1 + j, 0ull);
+        wv::own_st64(tab + ((uint64_t)KW << cap_log2) + idx, (uint64_t)kNone | ((uint64_t)kNone << 32));
+        wv::own_st32(stack, idx);
       }
       sp = 1; visited = 1;
       flags = F_ACTIVE | F_NEED_POP | (look_avail ? F_LOOK : 0u);
     }
-    if (li == 0) {
-      const uint64_t ds = (look_avail && has) ? (uint64_t)((gu32*)A.dstack + Bd->stack_off) : 0ull;
-      GS[G_DSTACK] = (uint32_t)ds; GS[G_DSTACK + 1] = (uint32_t)(ds >> 32);
-      GS[G_PROBES] = 0; GS[G_PROBES + 1] = 0; GS[G_EXPANDED] = 0; GS[G_EXPANDED + 1] = 0; GS[G_ROUNDS] = 0; GS[G_ROUNDS + 1] = 0;
-      GS[G_VERDICT] = (uint32_t)verdict0; GS[G_CAUSE] = (uint32_t)TBC_CAUSE_NONE; GS[G_MAXF] = 0; GS[G_MAXSP] = sp;
-      GS[G_WINPAR] = kNone; GS[G_WINOP] = kNone; GS[G_WINSTATE] = (uint32_t)A.init_state;
+    {
+      const auto C = wv::cold(A);
+      const uint64_t ms = C->max_steps;
+      room = (ms && ms < 0x7FFFFFFFull) ? (uint32_t)ms : 0x7FFFFFFFu;
+      if (li == 0) {
+        const uint64_t ds = (look_avail && has) ? (uint64_t)((gu32*)A.dstack + Bd->stack_off) : 0ull;
+        const uint64_t t0 = C->time_limit_ticks ? wv::clock100mhz() : 0ull;
+        GS[G_DSTACK] = (uint32_t)ds; GS[G_DSTACK + 1] = (uint32_t)(ds >> 32);
+        GS[G_PROBES] = 0; GS[G_PROBES + 1] = 0; GS[G_EXPANDED] = 0; GS[G_EXPANDED + 1] = 0; GS[G_ROUNDS] = 0; GS[G_ROUNDS + 1] = 0;
+        GS[G_VERDICT] = (uint32_t)verdict0; GS[G_CAUSE] = (uint32_t)TBC_CAUSE_NONE; GS[G_MAXF] = 0; GS[G_MAXSP] = sp;
+        GS[G_WINPAR] = kNone; GS[G_WINOP] = kNone; GS[G_WINSTATE] = (uint32_t)A.init_state;
+        GS[G_T0] = (uint32_t)t0; GS[G_T0 + 1] = (uint32_t)(t0 >> 32);
+      }
     }
     for (uint32_t i = li; i < RS; i += L) r_pos[i] = kNone;
-  }
-  // the parent config of the group (a copy in every lane of the group)
+  };
+  init_group(wave_idx * H + g);
+  // the parent config of the group (a copy in every lane of the group) and the round it is in
   uint32_t p_fi = 0, pslot = 0, poff = 0, nlive = 0, cnt = 0, base = 0;
   int32_t p_st = 0;
   uint64_t Mp[MW];
   WV_UNROLL
   for (int j = 0; j < MW; j++) Mp[j] = 0;
-  // step limit: probes left before it, saturated (refreshed from the 64-bit total every 64 iterations); time limit
-  uint32_t room = 0x7FFFFFFFu;
-  uint64_t t0 = 0;
-  {
+  // this lane's candidate of the group's NEXT round (valid while F_CAND): the open call's record, its twin mask, and
+  // They are loaded one iteration ahead --
+  // in the probe's trip when the next (parent, round) can be told (same parent; or the highest viable child, if it is
+  // kept; or the entry below on the stack when nothing is viable), else by an iteration that does nothing else
+  OpRec c_oi; c_oi.op = 0; c_oi.f_slot = kFNone; c_oi.a = 0; c_oi.b = 0;
+  uint64_t c_tw[MW];
+  WV_UNROLL
+  for (int j = 0; j < MW; j++) c_tw[j] = 0;
+  // the windows of the parent's front (from its front record): process slots and read kinds of ranks p_fi .. p_fi + 15
+  uint64_t p_ws0 = 0, p_ws1 = 0, p_wk0 = ~0ull, p_wk1 = ~0ull;
+  const uint32_t FW = A.front_words, FM = vpad * MW;          // u64 words per front record; where its list location starts
+  const bool eager = (rules & kRuleEager) != 0u, twin = (rules & kRuleTwin) != 0u;
+  // Loads that are in flight across other work are issued UNCONDITIONALLY, from addresses clamped into the history's own
+  // arenas, and what they bring is judged where it is used: a load under a divergent `if` with a default on the other path
+  // makes the compiler merge the two right behind the load -- a full s_waitcnt there, the trip no longer overlaps anything.
+  const uint64_t* const tw_base = twin ? A.twn : (const uint64_t*)A.tab;            // (a valid address when the rule is off)
+  const uint64_t* const lk_base = look_avail ? A.look : (const uint64_t*)A.tab;
+  // candidate number cnt_ - 1 - (base_ + li) of the config at front F whose list starts at poff_ (ok_ = there is one)
+  const auto load_cand = [&](bool ok_, uint32_t poff_, uint32_t nlive_, uint32_t cnt_, uint32_t base_) {
+    const uint32_t cd_ = base_ + li;
+    const bool have = ok_ && cd_ < cnt_;
+    const uint32_t c_ = have ? cnt_ - 1u - cd_ : 0u;
+    const bool live_ = have ? c_ < nlive_ : true;
+    const uint32_t po = have ? poff_ : 0u;
+    const OpRec* rp = live_ ? A.lst + ((uint64_t)lst_off + po + c_) : A.crashed + ((uint64_t)op_off + (c_ - nlive_));
+    c_oi = *rp;
+    const uint64_t* tw = tw_base + ((twin && live_) ? ((uint64_t)lst_off + po + c_) * MW : 0ull);
+    WV_UNROLL
+    for (int j = 0; j < MW; j++) c_tw[j] = tw[j];
+  };
+  // ---- results of the groups that have just finished (sel: mine has).  The witness (only when asked for: the parent chain
+  // is thousands of dependent loads) is walked by all of them at once, each lane following its own group's chain; the configs
+  // of an invalid verdict are collected for one group at a time by the whole wavefront.
+  const auto report = [&](bool sel) {
+    wv::wait_stores();
+    wv::threadfence();
+    wv::barrier();
     const auto C = wv::cold(A);
-    const uint64_t ms = C->max_steps;
-    if (ms && ms < (uint64_t)room) room = (uint32_t)ms;
-    if (C->time_limit_ticks) t0 = wv::clock100mhz();
-  }
-  uint32_t iter = 0;
+    const int32_t verdict = (int32_t)GS[G_VERDICT];
+    gu64* const par = tab + ((uint64_t)KW << cap_log2);
+    uint32_t wlen = 0;
+    if (C->witness != nullptr) {
+      const bool walk = sel && verdict == TBC_VALID && R != 0u;
+      const uint32_t win_parent = GS[G_WINPAR], win_op = GS[G_WINOP];
+      uint32_t id = win_parent;
+      bool more = walk;
+      wlen = walk ? 1u : 0u;
+      while (wv::ballot(more)) {
+        if (more) {
+          const uint32_t pr = (uint32_t)wv::ld64(par + id);
+          if (pr == kNone) more = false; else { wlen++; id = pr; }
+        }
+      }
+      uint32_t* const wit = C->witness + op_off;
+      uint32_t w = wlen ? wlen - 1u : 0u;
+      if (walk && li == 0) wit[w] = win_op;
+      id = win_parent; more = walk;
+      while (wv::ballot(more)) {
+        if (more) {
+          const uint64_t po = wv::ld64(par + id);
+          const uint32_t pr = (uint32_t)po;
+          if (pr == kNone) more = false;
+          else { w--; if (li == 0) wit[w] = (uint32_t)(po >> 32) - 1u; id = pr; }
+        }
+      }
+    }
+    uint32_t n_cfg = 0;
+    const uint32_t maxf = GS[G_MAXF];
+    {
+      const uint64_t ib = wv::ballot(sel && verdict == TBC_INVALID && C->cfg != nullptr);
+      for (uint32_t gg = 0; gg < H; gg++) {
+        if (!((ib >> (gg * L)) & 1ull)) continue;
+        const uint32_t src = gg * L;
+        const gu64* t_u = (const gu64*)wv::readlane64((uint64_t)tab, src);
+        const uint32_t cap_u = wv::readlane(cap_log2, src), h_u = wv::readlane(hidx, src), mf_u = wv::readlane(maxf, src);
+        const gu64* par_u = t_u + ((uint64_t)KW << cap_u);
+        uint64_t* cfg = C->cfg + (uint64_t)h_u * kCfgCap * (2 + MW);
+        const uint64_t ncap = 1ull << cap_u;
+        uint32_t n = 0;
+        for (uint64_t s0 = 0; s0 < ncap; s0 += 64) {
+          const gu64* e = t_u + (s0 + lane) * KW;
+          const uint64_t k0 = wv::ld64(e);
+          const bool hit = (uint32_t)k0 == mf_u + 1u;
+          const uint64_t hb = wv::ballot(hit);
+          if (hit) {
+            const uint32_t pos = n + (uint32_t)__builtin_popcountll(hb & ((1ull << lane) - 1ull));
+            if (pos < kCfgCap) {
+              uint64_t* o = cfg + (uint64_t)pos * (2 + MW);
+              o[0] = k0;
+              WV_UNROLL
+              for (int j = 0; j < MW; j++) o[1 + j] = wv::ld64(e + 1 + j);
+              const uint64_t pw = wv::ld64(par_u + s0 + lane);
+              o[1 + MW] = (uint32_t)pw == kNone ? (uint64_t)TBC_NO_OP : (pw >> 32) - 1ull;
+            }
+          }
+          n += (uint32_t)__builtin_popcountll(hb);
+        }
+        if (g == gg) n_cfg = n;
+      }
+    }
+    if (sel && li == 0) {
+      DevResult* const out = C->results + hidx;
+      const uint64_t probes = (uint64_t)GS[G_PROBES] | ((uint64_t)GS[G_PROBES + 1] << 32);
+      const uint64_t expanded = (uint64_t)GS[G_EXPANDED] | ((uint64_t)GS[G_EXPANDED + 1] << 32);
+      const uint64_t rounds = (uint64_t)GS[G_ROUNDS] | ((uint64_t)GS[G_ROUNDS + 1] << 32);
+      out->valid = verdict; out->cause = (int32_t)GS[G_CAUSE]; out->max_front = maxf; out->depth = wlen;
+      out->final_state = (int32_t)GS[G_WINSTATE]; out->n_configs = n_cfg;
+      out->fail_op = TBC_NO_OP; out->prev_ok_op = TBC_NO_OP;
+      if (verdict == TBC_INVALID) {
+        const uint32_t* ret_op = C->ret_op + C->hist[hidx].ret_off;
+        out->fail_op = ret_op[maxf];
+        if (maxf) out->prev_ok_op = ret_op[maxf - 1];
+      }
+      out->steps = probes; out->visited = (uint64_t)visited; out->probes = probes; out->backtracks = expanded;
+      out->max_depth = (uint64_t)GS[G_MAXSP]; out->bucket_reads = rounds; out->tab_log2 = cap_log2; out->pad = 0;
+    }
+  };
+
+  uint32_t iter = 0, arb = 0;
+  for (uint32_t i = li; i < 32u; i += L) GS[G_CLAIM + i] = 0u;
 
   for (;;) {
     wv::barrier();                                 // ring writes of the last round, LDS results
+    // ---- groups that have finished their history report it and take the next one off the batch's queue
+    const bool fin = has && !(flags & F_ACTIVE);
+    if (wv::ballot(fin)) {
+      report(fin);
+      if (fin && li == 0) GS[G_NEXT] = A.first_dynamic + atomicAdd(A.next_work, 1u);
+      wv::barrier();
+      if (fin) init_group(GS[G_NEXT]);
+      wv::barrier();
+    }
     if (!wv::ballot((flags & F_ACTIVE) != 0u)) break;
     iter++;
-    const uint32_t ln = wv::opaque(lane);
-    (void)ln;
 
     // ---- cold: visited sets that must grow first (the parent that did not fit is still on the stack)
     const uint64_t gb = wv::ballot((flags & F_NEED_GROW) != 0u);
     if (gb) {
       const auto C = wv::cold(A);
+      wv::wait_stores();                           // the plain stores of the rounds so far are in L2 before the table is re-read
+      wv::threadfence();
       for (uint32_t gg = 0; gg < H; gg++) {
         if (!((gb >> (gg * L)) & 1ull)) continue;
         const uint32_t src = gg * L;
@@ -322,7 +460,7 @@ WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* ld
         // (G_DSTACK keeps naming that array: nothing is set aside any more, so it is not written again)
         gu32* const ds = (gu32*)((uint64_t)GS[G_DSTACK] | ((uint64_t)GS[G_DSTACK + 1] << 32));
         if (li == 0) wv::lds_max32(GS + G_MAXSP, dsp - 1u);                // (the deepest stack counts what is left after a pop)
-        stack = ds; sp = dsp; dsp = 0u; flags &= ~F_LOOK;
+        stack = ds; sp = dsp; dsp = 0u; flags &= ~(F_LOOK | F_CAND);
         for (uint32_t i = li; i < RS; i += L) r_pos[i] = kNone;           // ring entries are keyed by stack position
       } else if (sp == 0u) {
         flags &= ~F_ACTIVE;
@@ -335,15 +473,17 @@ WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* ld
           WV_UNROLL
           for (int j = 0; j < MW; j++) Mp[j] = r_M[rs * MW + j];
           pslot = r_idx[rs]; poff = r_off[rs]; nlive = r_nlive[rs]; cnt = r_cnt[rs];
+          p_ws0 = r_W[rs * 4]; p_ws1 = r_W[rs * 4 + 1]; p_wk0 = r_W[rs * 4 + 2]; p_wk1 = r_W[rs * 4 + 3];
         } else {
-          const uint32_t idx = wv::ld32(stack + pos);
+          const uint32_t idx = wv::own_ld32(stack + pos);
           const gu64* e = tab + (uint64_t)idx * KW;
-          k0 = wv::ld64(e);
+          k0 = wv::own_ld64(e);
           WV_UNROLL
-          for (int j = 0; j < MW; j++) Mp[j] = wv::ld64(e + 1 + j);
-          const uint32_t fi = (uint32_t)k0 - 1u;
-          const uint32_t o0 = A.off[(uint64_t)off_off + fi], o1 = A.off[(uint64_t)off_off + fi + 1u], nc = A.ncr[(uint64_t)off_off + fi];
-          pslot = idx; poff = o0; nlive = o1 - o0; cnt = (o1 - o0) + nc;
+          for (int j = 0; j < MW; j++) Mp[j] = wv::own_ld64(e + 1 + j);
+          const uint64_t* fr = A.rdm + ((uint64_t)op_off + ((uint32_t)k0 - 1u)) * FW + FM;      // its front's record
+          const uint64_t m0 = fr[0];
+          pslot = idx; poff = (uint32_t)m0; nlive = (uint32_t)(m0 >> 32); cnt = (uint32_t)fr[1];
+          p_ws0 = fr[2]; p_ws1 = fr[3]; p_wk0 = fr[4]; p_wk1 = fr[5];
         }
         p_fi = (uint32_t)k0 - 1u; p_st = (int32_t)(uint32_t)(k0 >> 32);
         if (visited + cnt > full_at) {
@@ -355,36 +495,33 @@ WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* ld
       }
     }
 
+    // ---- a group whose candidates were not fetched ahead sits this round out and fetches them with the others' (below)
+    const bool wants = (flags & (F_ACTIVE | F_NEED_POP | F_NEED_GROW)) == F_ACTIVE;
+    const bool inround = wants && (flags & F_CAND);
+    const bool fetch_now = wants && !(flags & F_CAND);
+    if (fetch_now && li == 0) wv::stat(22, 1);
+
     // ---- the round: lane li takes pair base + li of the parent = its open call number cnt - 1 - (base + li)
-    const bool inround = (flags & (F_ACTIVE | F_NEED_POP | F_NEED_GROW)) == F_ACTIVE;
     const uint32_t cd = base + li;
     const bool act = inround && cd < cnt;
     const uint32_t c = cnt - 1u - cd;
     const uint32_t fi = p_fi;
     const int32_t st = p_st;
-    // one trip: the candidate's record, its twin mask, and the completion slots of the next 9..16 ranks (front advance)
-    OpRec oi; oi.op = 0; oi.f_slot = kFNone; oi.a = 0; oi.b = 0;
-    const uint32_t wbase = (fi + 1u) & ~7u;
-    uint64_t w0 = 0, w1 = 0;
-    bool dominated = false;
     const bool live = c < nlive;
-    if (act) {
-      const OpRec* rp = live ? A.lst + ((uint64_t)lst_off + poff + c) : A.crashed + ((uint64_t)op_off + (c - nlive));
-      oi = *rp;
-      const uint64_t* wp = reinterpret_cast<const uint64_t*>(A.slot8 + slot8_lo + wbase);
-      w0 = wp[0]; w1 = wp[1];
-      if ((rules & kRuleTwin) && live) {
-        const uint64_t* tw = A.twn + ((uint64_t)lst_off + poff + c) * MW;
-        WV_UNROLL
-        for (int j = 0; j < MW; j++) dominated = dominated || (tw[j] & ~Mp[j]) != 0ull;
-      }
+    const OpRec oi = c_oi;
+    const uint32_t wbase = fi;
+    const uint64_t w0 = p_ws0, w1 = p_ws1, k0w = p_wk0, k1w = p_wk1;
+    bool dominated = false;
+    if (twin && act && live) {
+      WV_UNROLL
+      for (int j = 0; j < MW; j++) dominated = dominated || (c_tw[j] & ~Mp[j]) != 0ull;
     }
     const uint32_t op = oi.op;
     const uint32_t f = oi.f_slot & 0xFFu, p = (oi.f_slot >> 8) & kSlotMask;
     const bool lin = mask_bit<MW>(Mp, p);
     // a crashed call has no per-front entry: its twins are every live open call with its effect (they all complete
     // earlier) and the crashed ones invoked before it -- walk the list (crash-heavy histories only)
-    if ((rules & kRuleTwin) && act && !lin && !live && (f == TBC_F_WRITE || f == TBC_F_CAS)) {
+    if (twin && act && !lin && !live && (f == TBC_F_WRITE || f == TBC_F_CAS)) {
       for (uint32_t cc = 0; cc < c && !dominated; cc++) {
         const OpRec y = cc < nlive ? A.lst[(uint64_t)lst_off + poff + cc] : A.crashed[(uint64_t)op_off + (cc - nlive)];
         if ((y.f_slot & 0xFFu) != f || y.a != oi.a || (f == TBC_F_CAS && y.b != oi.b)) continue;
@@ -392,49 +529,35 @@ WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* ld
       }
     }
     const bool viable = act && !lin && !dominated && reg_ok(st, f, oi.a);
-    // the child: linearize; if it was the front's own call the front moves past every completion already linearized
+    // the child: linearize; the front moves past every completion whose call is linearized -- or, under the eager rule,
+    // is a read the child's state allows (value nil or the state: it is open, so the rule takes it).  Slots and read kinds
+    // of the next ranks came with the candidate: no memory access here.  The reads the rule takes that are still open at
+    // the child's front are one row entry (the trip below).
     int32_t st2 = st;
     uint32_t fi2 = fi;
     uint64_t M2[MW];
     WV_UNROLL
     for (int j = 0; j < MW; j++) M2[j] = Mp[j];
-    const auto slot_at = [&](uint32_t r) -> uint32_t {
+    const auto byte_at = [&](uint64_t x0, uint64_t x1, const uint8_t* arr, uint32_t r) -> uint32_t {
       const uint32_t d = r - wbase;
-      if (d < 8u) return (uint32_t)(w0 >> (8u * d)) & 0xFFu;
-      if (d < 16u) return (uint32_t)(w1 >> (8u * (d - 8u))) & 0xFFu;
-      return (uint32_t)A.slot8[slot8_lo + r];
+      if (d < 8u) return (uint32_t)(x0 >> (8u * d)) & 0xFFu;
+      if (d < 16u) return (uint32_t)(x1 >> (8u * (d - 8u))) & 0xFFu;
+      return (uint32_t)arr[slot8_lo + r];
     };
     if (viable) {
       st2 = reg_apply(st, f, oi.a, oi.b);
       mask_set<MW>(M2, p);
-      if (oi.f_slot & kAtFront) {
-        uint32_t pp = p;
-        for (;;) {
-          mask_clear<MW>(M2, pp);
-          fi2++;
-          if (fi2 == R) break;
-          pp = slot_at(fi2);
-          if (!mask_bit<MW>(M2, pp)) break;
+      const uint32_t vis = eager ? rdm_index(st2, vpad) : 0xFFFFu;
+      for (;;) {
+        const uint32_t pp = byte_at(w0, w1, A.slot8, fi2);
+        if (mask_bit<MW>(M2, pp)) mask_clear<MW>(M2, pp);
+        else {
+          if (!eager) break;
+          const uint32_t rk = byte_at(k0w, k1w, A.rk8, fi2);
+          if (!(rk == 0u || rk == vis)) break;
         }
-      }
-      // eager reads: the child takes every open read its state allows (value nil or the state), the front moves past
-      // the completions that linearizes, and the calls open at the new front are looked at again
-      if ((rules & kRuleEager) && fi2 < R) {
-        for (;;) {
-          const uint64_t* row = A.rdm + ((uint64_t)op_off + fi2) * vpad * MW;
-          const uint32_t vi = rdm_index(st2, vpad);
-          WV_UNROLL
-          for (int j = 0; j < MW; j++) M2[j] |= row[j] | row[vi * MW + j];
-          uint32_t pp = slot_at(fi2);
-          if (!mask_bit<MW>(M2, pp)) break;
-          do {
-            mask_clear<MW>(M2, pp);
-            fi2++;
-            if (fi2 == R) break;
-            pp = slot_at(fi2);
-          } while (mask_bit<MW>(M2, pp));
-          if (fi2 == R) break;
-        }
+        fi2++;
+        if (fi2 == R) break;
       }
     }
     if (inround && li == 0) wv::lds_add64(GS + G_ROUNDS, 1ull);
@@ -447,40 +570,181 @@ WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* ld
       flags &= ~F_ACTIVE;
     }
     const bool go = viable && !gsucc;
-    const uint32_t npr = (uint32_t)__builtin_popcount(grp(wv::ballot(go)));
+    const uint32_t gv = grp(wv::ballot(go));
+    const uint32_t npr = (uint32_t)__builtin_popcount(gv);
     if (li == 0 && npr) wv::lds_add64(GS + G_PROBES, (uint64_t)npr);
     bool limit_hit = false;
     if (npr > room) limit_hit = true; else room -= npr;
 
-    // the child's front: its open-call list (issued now, consumed at push; hidden under the probe)
-    uint32_t co0 = 0, co1 = 0, cnc = 0;
-    if (go) { co0 = A.off[(uint64_t)off_off + fi2]; co1 = A.off[(uint64_t)off_off + fi2 + 1u]; cnc = A.ncr[(uint64_t)off_off + fi2]; }
+    // ---- trip 1: the child's front's record -- the reads the eager rule takes there, where its open-call list is, and the
+    // windows its own children will advance over: one line
+    const uint32_t f3 = go ? fi2 : 0u;
+    const uint64_t* const fr = A.rdm + ((uint64_t)op_off + f3) * FW;
+    uint32_t co0, cnl, ccnt;
+    uint64_t cw[4];
+    {
+      const uint32_t vi = (eager && go) ? rdm_index(st2, vpad) : 0u;
+      uint64_t r0[MW], rv[MW];
+      const uint64_t m0 = fr[FM], m1 = fr[FM + 1];
+      WV_UNROLL
+      for (int t = 0; t < 4; t++) cw[t] = fr[FM + 2 + t];
+      WV_UNROLL
+      for (int j = 0; j < MW; j++) { r0[j] = eager ? fr[j] : 0ull; rv[j] = eager ? fr[vi * MW + j] : 0ull; }
+      WV_UNROLL
+      for (int j = 0; j < MW; j++) M2[j] |= go ? (r0[j] | rv[j]) : 0ull;
+      co0 = (uint32_t)m0; cnl = (uint32_t)(m0 >> 32); ccnt = (uint32_t)m1;
+    }
 
-    // ---- visited set: find the key in its bucket chain, else claim the first empty entry met (two lanes of the
-    // wavefront never hold the same key: one parent per group, one table per history; they can meet at one empty
-    // entry -- the CAS settles that and the loser looks at the bucket again)
+    // ---- trip 2, issue: the child's bucket of the visited set ...
     const uint64_t k0c = (uint64_t)(fi2 + 1u) | ((uint64_t)(uint32_t)st2 << 32);
     uint32_t b = key_hash32(k0c, M2, MW) & bmask, idx = 0, full_buckets = 0;
     bool pending = go, fresh = false;
-    while (wv::ballot(pending)) {
+    wv::u32x4 ke[4];                 // MW = 1: the bucket's four 16 B entries
+    uint64_t kk[4];                  // MW > 1: their first words
+    const auto load_bucket = [&]() {
+      const gu64* bp = tab + (uint64_t)b * (4 * KW);
+      if constexpr (MW == 1) {
+        WV_UNROLL
+        for (int t = 0; t < 4; t++) ke[t] = wv::own_ld128(bp + 2 * t);
+      } else {
+        WV_UNROLL
+        for (int t = 0; t < 4; t++) kk[t] = wv::own_ld64(bp + t * KW);
+      }
+    };
+    if (pending) load_bucket();
+    // ... the lookahead records of every viable child (8 lanes per child, one rank each, staged wave-wide) ...
+    bool dead = false;
+    const bool lkme = go && (flags & F_LOOK);
+    const uint64_t lk = wv::ballot(lkme);
+    const uint32_t ci = (uint32_t)__builtin_popcountll(lk & ((1ull << lane) - 1ull)), nn0 = (uint32_t)__builtin_popcountll(lk);
+    if (lkme) {
+      c_fi[ci] = fi2; c_st[ci] = (uint32_t)st2; c_lo[ci] = look_lo;
+      WV_UNROLL
+      for (int j = 0; j < MW; j++) c_M[ci * MW + j] = M2[j];
+    }
+    // ... and the candidates of the round this group runs next, where that can be told now:
+    //   the parent has pairs left -> its next L pairs;  else some child is viable -> the highest one's (it is on top of
+    //   the stack if it is kept: new and not dead);  else nothing will be pushed -> the entry below on the stack
+    const bool more = inround && !gsucc && base + L < cnt;
+    const bool to_child = inround && !gsucc && !more && gv != 0u;
+    const bool to_below = inround && !gsucc && !more && gv == 0u && sp != 0u;
+    const uint32_t hv = gv ? 31u - (uint32_t)__builtin_clz(gv) : 0u;
+    if (to_child && li == hv) { GS[G_PF] = fi2; GS[G_PF + 1] = co0; GS[G_PF + 2] = cnl; GS[G_PF + 3] = ccnt; }
+    wv::barrier();
+    bool cand_next = false;
+    {
+      // ONE candidate fetch per iteration, for everybody: the round a group runs next -- or, for a group that had none
+      // ready, the round it wanted to run now
+      uint32_t no = poff, nnl = nlive, nct = cnt, nb_ = fetch_now ? base : base + L;
+      bool ok_ = more || fetch_now;
+      if (to_child) { no = GS[G_PF + 1]; nnl = GS[G_PF + 2]; nct = GS[G_PF + 3]; nb_ = 0u; ok_ = true; }
+      if (to_below) {
+        const uint32_t pos = sp - 1u, rs = pos & (RS - 1u);
+        if (r_pos[rs] == pos) { no = r_off[rs]; nnl = r_nlive[rs]; nct = r_cnt[rs]; nb_ = 0u; ok_ = true; }
+      }
+      load_cand(ok_, no, nnl, nct, nb_);
+      cand_next = ok_;
+    }
+    uint64_t lw0[2], lpm[2][MW];
+    WV_UNROLL
+    for (int bt = 0; bt < 2; bt++) {
+      const uint32_t cc = 8u * bt + (lane >> 3), j = lane & 7u;
+      const bool val = cc < nn0;
+      const uint32_t lo_ = val ? c_lo[cc] : (look_avail ? look_lo : 0u), fr_ = val ? c_fi[cc] + j : 0u;
+      const uint64_t* rec = lk_base + (uint64_t)lo_ + (uint64_t)fr_ * (MW + 1);
+      lw0[bt] = rec[0];
+      WV_UNROLL
+      for (int w = 0; w < MW; w++) lpm[bt][w] = rec[1 + w];
+    }
+    // one batch of 8 children: lane (child cb + lane / 8, rank lane % 8) decides its rank; returns the lanes that found
+    // their child's call un-linearizable (wgl_beam.hip states the rule)
+    const auto look_batch = [&](uint32_t cb, uint64_t w_0, const uint64_t (&pm)[MW]) -> uint64_t {
+      const uint32_t cc = cb + (lane >> 3), j = lane & 7u;
+      const bool val = cc < nn0;
+      const int32_t cs = val ? (int32_t)c_st[cc] : 0;
+      uint64_t Mc[MW];
+      WV_UNROLL
+      for (int w = 0; w < MW; w++) Mc[w] = val ? c_M[cc * MW + w] : 0ull;
+      const uint32_t slot = (uint32_t)w_0 & 0xFFFFu, need = (uint32_t)(w_0 >> 16) & 0xFFu, prod = (uint32_t)(w_0 >> 24) & 0xFFu;
+      const uint32_t dinv = (uint32_t)(w_0 >> 32) & 0xFFu, dprod = (uint32_t)(w_0 >> 40) & 0xFFu;
+      bool pmhit = false;
+      WV_UNROLL
+      for (int w = 0; w < MW; w++) pmhit = pmhit || (pm[w] & ~Mc[w]) != 0ull;
+      const bool linz = dinv >= j && mask_bit<MW>(Mc, slot);     // open at the config's front and linearized
+      // values the calls completing at the ranks before this one can still provide (prefix-OR over the 8 lanes)
+      uint32_t acc = (prod != kLookNone && !linz) ? 1u << prod : 0u;
+      uint32_t x = wv::row_shr0<1>(acc);
+      if (j >= 1u) acc |= x;
+      x = wv::row_shr0<2>(acc);
+      if (j >= 2u) acc |= x;
+      x = wv::row_shr0<4>(acc);
+      if (j >= 4u) acc |= x;
+      uint32_t before = wv::row_shr0<1>(acc);
+      if (j == 0u) before = 0u;
+      const bool ok = need == kLookNone || linz || (int32_t)need == cs || dprod < j || pmhit || ((before >> need) & 1u);
+      return wv::ballot(val && !ok);
+    };
+
+    // ---- trip 2, consume.  Visited set: find the key in its bucket chain, else take the first empty entry met.  Lanes of
+    // different groups never meet (one table per history); two lanes of a group can want the same empty entry (two keys of
+    // one bucket, or -- at the root only -- one key twice): they settle it in LDS, the loser looks again.
+    for (;;) {
+      bool want = false;
       if (pending) {
-        const uint32_t me = scan_bucket<MW>(tab + (uint64_t)b * (4 * KW), k0c, M2), match = me & 15u, empty = me >> 4;
-        if (match) {
-          idx = b * 4u + (uint32_t)__builtin_ctz(match);
-          pending = false;
-        } else if (empty) {
-          idx = b * 4u + (uint32_t)__builtin_ctz(empty);
-          gu64* e = tab + (uint64_t)idx * KW;
-          if (wv::cas64_from_zero(e, k0c) == 0ull) {         // claimed an empty entry
-            WV_UNROLL
-            for (int j = 0; j < MW; j++) wv::st64(e + 1 + j, M2[j]);
-            fresh = true; pending = false;
-          }                                                  // else: claimed by another lane in this very step: look again
+        uint32_t match = 0, empty = 0;
+        if constexpr (MW == 1) {
+          const uint32_t k0l = (uint32_t)k0c, k0h = (uint32_t)(k0c >> 32), ml = (uint32_t)M2[0], mh = (uint32_t)(M2[0] >> 32);
+          WV_UNROLL
+          for (int t = 0; t < 4; t++) {
+            if (ke[t].x == 0u) empty |= 1u << t;
+            else if (ke[t].x == k0l && ke[t].y == k0h && ke[t].z == ml && ke[t].w == mh) match |= 1u << t;
+          }
         } else {
+          const gu64* bp = tab + (uint64_t)b * (4 * KW);
+          WV_UNROLL
+          for (int t = 0; t < 4; t++) {
+            if ((uint32_t)kk[t] == 0u) empty |= 1u << t;
+            else if (kk[t] == k0c) {
+              bool same = true;
+              WV_UNROLL
+              for (int j = 0; j < MW; j++) same = same && wv::own_ld64(bp + t * KW + 1 + j) == M2[j];
+              match |= same ? 1u << t : 0u;
+            }
+          }
+        }
+        if (match) { idx = b * 4u + (uint32_t)__builtin_ctz(match); pending = false; }
+        else if (empty) { idx = b * 4u + (uint32_t)__builtin_ctz(empty); want = true; }
+        else {
           b = (b + 1u) & bmask;
           if (++full_buckets > bmask) pending = false;       // every bucket full: cannot happen below the 3/4 fill bound
         }
       }
+      if (wv::ballot(want)) {
+        // the LOWEST lane that wants an entry of this bucket gets it (so two pairs of a round that produce one and the same
+        // config -- the root's nil reads under the eager rule -- resolve as the oracle's pair order does): an LDS max over
+        // {arbitration number, 255 - lane}; words of earlier arbitrations hold smaller numbers
+        arb++;
+        if ((arb & 0xFFFFFFu) == 0u) {                         // the number wraps: clear the claim words (every ~10^7 rounds)
+          arb++;
+          wv::barrier();
+          for (uint32_t i = li; i < 32u; i += L) GS[G_CLAIM + i] = 0u;
+          wv::barrier();
+        }
+        uint32_t* const claim = GS + G_CLAIM + (b & 31u);
+        const uint32_t ticket = (arb << 8) | (255u - li);
+        if (want) wv::lds_max32(claim, ticket);
+        wv::barrier();
+        if (want && *claim == ticket) {
+          gu64* e = tab + (uint64_t)idx * KW;
+          wv::own_st64(e, k0c);
+          WV_UNROLL
+          for (int j = 0; j < MW; j++) wv::own_st64(e + 1 + j, M2[j]);
+          fresh = true; pending = false;
+        }
+      }
+      if (!wv::ballot(pending)) break;
+      wv::wait_stores();                                      // a loser must see the winner's entry
+      if (pending) load_bucket();
     }
     if (grp(wv::ballot(full_buckets > bmask))) {
       flags &= ~F_ACTIVE;
@@ -488,59 +752,31 @@ WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* ld
     }
     const bool is_new = fresh;
     if (is_new) {
-      wv::st64(par + idx, (uint64_t)pslot | ((uint64_t)(op + 1u) << 32));
+      wv::own_st64(par + idx, (uint64_t)pslot | ((uint64_t)(op + 1u) << 32));
       wv::lds_max32(GS + G_MAXF, fi2);
     }
     const uint64_t nb0 = wv::ballot(is_new);
-
-    // ---- lookahead (register / cas-register): a new config is dead if the call completing at one of the next
-    // kLookahead ranks can never be linearized from it (wgl_beam.hip has the rule).  Staged wave-wide: 8 lanes per
-    // config, one rank each, whichever group the config belongs to.
-    bool dead = false;
-    const uint64_t lk = wv::ballot(is_new && (flags & F_LOOK));
-    if (lk) {
-      const uint32_t ci = (uint32_t)__builtin_popcountll(lk & ((1ull << lane) - 1ull)), nn0 = (uint32_t)__builtin_popcountll(lk);
-      const bool mine = is_new && (flags & F_LOOK);
-      if (mine) {
-        c_fi[ci] = fi2; c_st[ci] = (uint32_t)st2; c_lo[ci] = look_lo;
-        WV_UNROLL
-        for (int j = 0; j < MW; j++) c_M[ci * MW + j] = M2[j];
+    // the lookahead's verdicts (a duplicate's is not used)
+    if (nn0) {
+      const uint64_t bad0 = look_batch(0u, lw0[0], lpm[0]);
+      if (lkme && ci < 8u) dead = ((bad0 >> (8u * ci)) & 0xFFull) != 0ull;
+      if (nn0 > 8u) {
+        const uint64_t bad1 = look_batch(8u, lw0[1], lpm[1]);
+        if (lkme && ci >= 8u && ci < 16u) dead = ((bad1 >> (8u * (ci - 8u))) & 0xFFull) != 0ull;
       }
-      wv::barrier();
-      for (uint32_t cb = 0; cb < nn0; cb += 8u) {
+      for (uint32_t cb = 16u; cb < nn0; cb += 8u) {          // more than 16 viable children in the wavefront: rare
         const uint32_t cc = cb + (lane >> 3), j = lane & 7u;
-        const bool val = cc < nn0;
-        const uint32_t cF = val ? c_fi[cc] : 0u;
-        const int32_t cs = val ? (int32_t)c_st[cc] : 0;
-        uint64_t Mc[MW], pm[MW];
+        uint64_t xw0 = (uint64_t)(kLookNone << 16 | kLookNone << 24), xpm[MW];
         WV_UNROLL
-        for (int w = 0; w < MW; w++) { Mc[w] = val ? c_M[cc * MW + w] : 0ull; pm[w] = 0ull; }
-        uint64_t lw0 = (uint64_t)(kLookNone << 16 | kLookNone << 24);
-        if (val) {
-          const uint64_t* rec = A.look + (uint64_t)c_lo[cc] + (uint64_t)(cF + j) * (MW + 1);
-          lw0 = rec[0];
+        for (int w = 0; w < MW; w++) xpm[w] = 0ull;
+        if (cc < nn0) {
+          const uint64_t* rec = A.look + (uint64_t)c_lo[cc] + (uint64_t)(c_fi[cc] + j) * (MW + 1);
+          xw0 = rec[0];
           WV_UNROLL
-          for (int w = 0; w < MW; w++) pm[w] = rec[1 + w];
+          for (int w = 0; w < MW; w++) xpm[w] = rec[1 + w];
         }
-        const uint32_t slot = (uint32_t)lw0 & 0xFFFFu, need = (uint32_t)(lw0 >> 16) & 0xFFu, prod = (uint32_t)(lw0 >> 24) & 0xFFu;
-        const uint32_t dinv = (uint32_t)(lw0 >> 32) & 0xFFu, dprod = (uint32_t)(lw0 >> 40) & 0xFFu;
-        bool pmhit = false;
-        WV_UNROLL
-        for (int w = 0; w < MW; w++) pmhit = pmhit || (pm[w] & ~Mc[w]) != 0ull;
-        const bool linz = dinv >= j && mask_bit<MW>(Mc, slot);     // open at the config's front and linearized
-        // values the calls completing at the ranks before this one can still provide (prefix-OR over the 8 lanes)
-        uint32_t acc = (prod != kLookNone && !linz) ? 1u << prod : 0u;
-        uint32_t x = wv::row_shr0<1>(acc);
-        if (j >= 1u) acc |= x;
-        x = wv::row_shr0<2>(acc);
-        if (j >= 2u) acc |= x;
-        x = wv::row_shr0<4>(acc);
-        if (j >= 4u) acc |= x;
-        uint32_t before = wv::row_shr0<1>(acc);
-        if (j == 0u) before = 0u;
-        const bool ok = need == kLookNone || linz || (int32_t)need == cs || dprod < j || pmhit || ((before >> need) & 1u);
-        const uint64_t bad = wv::ballot(val && !ok);
-        if (mine && ci >= cb && ci < cb + 8u) dead = ((bad >> (8u * (ci - cb))) & 0xFFull) != 0ull;
+        const uint64_t badx = look_batch(cb, xw0, xpm);
+        if (lkme && ci >= cb && ci < cb + 8u) dead = ((badx >> (8u * (ci - cb))) & 0xFFull) != 0ull;
       }
     }
     // ---- push the new configs in pair order: the dead ones aside, the others onto the stack (and into the ring)
@@ -548,22 +784,31 @@ WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* ld
     const uint32_t gdb = grp(wv::ballot(is_new && dead));
     if (is_new && dead) {
       gu32* const ds = (gu32*)((uint64_t)GS[G_DSTACK] | ((uint64_t)GS[G_DSTACK + 1] << 32));
-      wv::st32(ds + dsp + (uint32_t)__builtin_popcount(gdb & below), idx);
+      wv::own_st32(ds + dsp + (uint32_t)__builtin_popcount(gdb & below), idx);
     }
     dsp += (uint32_t)__builtin_popcount(gdb);
     const uint32_t gnb = grp(wv::ballot(keep));
     if (keep) {
       const uint32_t pos = sp + (uint32_t)__builtin_popcount(gnb & below);
-      wv::st32(stack + pos, idx);
+      wv::own_st32(stack + pos, idx);
       const uint32_t rs = pos & (RS - 1u);          // at most L <= RS pushes a round: no clash
       r_pos[rs] = pos; r_idx[rs] = idx; r_k0[rs] = k0c;
       WV_UNROLL
       for (int j = 0; j < MW; j++) r_M[rs * MW + j] = M2[j];
-      r_off[rs] = co0; r_nlive[rs] = co1 - co0; r_cnt[rs] = (co1 - co0) + cnc;
+      r_off[rs] = co0; r_nlive[rs] = cnl; r_cnt[rs] = ccnt;
+      WV_UNROLL
+      for (int t = 0; t < 4; t++) r_W[rs * 4 + t] = cw[t];
     }
     sp += (uint32_t)__builtin_popcount(gnb);
     visited += (uint32_t)__builtin_popcount(grp(nb0));
     if (li == 0 && gnb) wv::lds_max32(GS + G_MAXSP, sp);
+    {
+      // were the candidates fetched above the next round's?  (the highest viable child is the next parent iff it was kept;
+      // a group that sat out fetched the round it wanted; anybody else has none)
+      const bool right = inround ? (cand_next && (more || to_below || ((gnb >> hv) & 1u))) : fetch_now;
+      flags = right ? (flags | F_CAND) : (flags & ~F_CAND);
+      if (inround && li == 0) wv::stat(right ? 23 : 24, 1);
+    }
     if (inround) {
       base += L;
       if (base >= cnt) flags |= F_NEED_POP;
@@ -581,95 +826,11 @@ WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* ld
         const uint64_t left = ms - (done < ms ? done : ms);
         room = left < 0x7FFFFFFFull ? (uint32_t)left : 0x7FFFFFFFu;
       }
-      if (limit && (flags & F_ACTIVE) && wv::clock100mhz() - t0 > limit) {
+      if (limit && (flags & F_ACTIVE) && wv::clock100mhz() - ((uint64_t)GS[G_T0] | ((uint64_t)GS[G_T0 + 1] << 32)) > limit) {
         flags &= ~F_ACTIVE;
         if (li == 0) { GS[G_VERDICT] = (uint32_t)TBC_UNKNOWN; GS[G_CAUSE] = (uint32_t)TBC_CAUSE_TIME_LIMIT; }
       }
     }
-  }
-
-  // ---- results.  The witness (only when asked for: the parent chain is thousands of dependent loads) is walked by
-  // all groups at once, each lane following its own group's chain; the configs of an invalid verdict are collected
-  // for one group at a time by the whole wavefront.
-  wv::barrier();
-  const auto C = wv::cold(A);
-  const int32_t verdict = (int32_t)GS[G_VERDICT];
-  gu64* const par = tab + ((uint64_t)KW << cap_log2);
-  uint32_t wlen = 0;
-  if (C->witness != nullptr) {
-    const bool walk = has && verdict == TBC_VALID && R != 0u;
-    const uint32_t win_parent = GS[G_WINPAR], win_op = GS[G_WINOP];
-    uint32_t id = win_parent;
-    bool more = walk;
-    wlen = walk ? 1u : 0u;
-    while (wv::ballot(more)) {
-      if (more) {
-        const uint32_t pr = (uint32_t)wv::ld64(par + id);
-        if (pr == kNone) more = false; else { wlen++; id = pr; }
-      }
-    }
-    uint32_t* const wit = C->witness + op_off;
-    uint32_t w = wlen ? wlen - 1u : 0u;
-    if (walk && li == 0) wit[w] = win_op;
-    id = win_parent; more = walk;
-    while (wv::ballot(more)) {
-      if (more) {
-        const uint64_t po = wv::ld64(par + id);
-        const uint32_t pr = (uint32_t)po;
-        if (pr == kNone) more = false;
-        else { w--; if (li == 0) wit[w] = (uint32_t)(po >> 32) - 1u; id = pr; }
-      }
-    }
-  }
-  uint32_t n_cfg = 0;
-  const uint32_t maxf = GS[G_MAXF];
-  {
-    const uint64_t ib = wv::ballot(has && verdict == TBC_INVALID && C->cfg != nullptr);
-    for (uint32_t gg = 0; gg < H; gg++) {
-      if (!((ib >> (gg * L)) & 1ull)) continue;
-      const uint32_t src = gg * L;
-      const gu64* t_u = (const gu64*)wv::readlane64((uint64_t)tab, src);
-      const uint32_t cap_u = wv::readlane(cap_log2, src), h_u = wv::readlane(hidx, src), mf_u = wv::readlane(maxf, src);
-      const gu64* par_u = t_u + ((uint64_t)KW << cap_u);
-      uint64_t* cfg = C->cfg + (uint64_t)h_u * kCfgCap * (2 + MW);
-      const uint64_t ncap = 1ull << cap_u;
-      uint32_t n = 0;
-      for (uint64_t s0 = 0; s0 < ncap; s0 += 64) {
-        const gu64* e = t_u + (s0 + lane) * KW;
-        const uint64_t k0 = wv::ld64(e);
-        const bool hit = (uint32_t)k0 == mf_u + 1u;
-        const uint64_t hb = wv::ballot(hit);
-        if (hit) {
-          const uint32_t pos = n + (uint32_t)__builtin_popcountll(hb & ((1ull << lane) - 1ull));
-          if (pos < kCfgCap) {
-            uint64_t* o = cfg + (uint64_t)pos * (2 + MW);
-            o[0] = k0;
-            WV_UNROLL
-            for (int j = 0; j < MW; j++) o[1 + j] = wv::ld64(e + 1 + j);
-            const uint64_t pw = wv::ld64(par_u + s0 + lane);
-            o[1 + MW] = (uint32_t)pw == kNone ? (uint64_t)TBC_NO_OP : (pw >> 32) - 1ull;
-          }
-        }
-        n += (uint32_t)__builtin_popcountll(hb);
-      }
-      if (g == gg) n_cfg = n;
-    }
-  }
-  if (has && li == 0) {
-    DevResult* const out = C->results + hidx;
-    const uint64_t probes = (uint64_t)GS[G_PROBES] | ((uint64_t)GS[G_PROBES + 1] << 32);
-    const uint64_t expanded = (uint64_t)GS[G_EXPANDED] | ((uint64_t)GS[G_EXPANDED + 1] << 32);
-    const uint64_t rounds = (uint64_t)GS[G_ROUNDS] | ((uint64_t)GS[G_ROUNDS + 1] << 32);
-    out->valid = verdict; out->cause = (int32_t)GS[G_CAUSE]; out->max_front = maxf; out->depth = wlen;
-    out->final_state = (int32_t)GS[G_WINSTATE]; out->n_configs = n_cfg;
-    out->fail_op = TBC_NO_OP; out->prev_ok_op = TBC_NO_OP;
-    if (verdict == TBC_INVALID) {
-      const uint32_t* ret_op = C->ret_op + Hd->ret_off;
-      out->fail_op = ret_op[maxf];
-      if (maxf) out->prev_ok_op = ret_op[maxf - 1];
-    }
-    out->steps = probes; out->visited = (uint64_t)visited; out->probes = probes; out->backtracks = expanded;
-    out->max_depth = (uint64_t)GS[G_MAXSP]; out->bucket_reads = rounds; out->tab_log2 = cap_log2; out->pad = 0;
   }
 }
 

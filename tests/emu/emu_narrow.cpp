@@ -23,19 +23,21 @@ struct Tables {
   std::vector<uint32_t> off, ncr, ret_op, ret_slot;
   std::vector<OpRec> lst, crashed;
   std::vector<uint64_t> twn, rdm, look;
-  std::vector<uint8_t> slot8;
+  std::vector<uint8_t> slot8, rk8;
 };
 
 // the per-front tables of every history of the batch, from the definitions
 bool build_tables(uint32_t nh, const uint64_t* op_off, const uint32_t* n_process, const uint8_t* f, const int32_t* a, const int32_t* b,
-                  const int32_t* process, const uint32_t* inv_pos, const uint32_t* ret_pos, uint32_t MW, uint32_t vpad,
+                  const int32_t* process, const uint32_t* inv_pos, const uint32_t* ret_pos, uint32_t MW, uint32_t vpad_in,
                   uint32_t tab_log2_per_op, Tables& T) {
+  const uint32_t vpad = vpad_in ? vpad_in : 1;
   const uint64_t total = op_off[nh];
   T.hist.assign(nh, Hist{}); T.bh.assign(nh, BeamHist{});
   T.ret_op.assign(total + 1, 0); T.ret_slot.assign(total + 1, 0);
   T.crashed.assign(total + 1, OpRec{0, kFNone, 0, 0});
-  T.slot8.assign(slot8_bytes(total, nh), 0);
-  T.rdm.assign(total * vpad * MW + 1, 0);
+  T.slot8.assign(slot8_bytes(total, nh), 0); T.rk8.assign(slot8_bytes(total, nh), 0xFF);
+  const uint32_t FS = front_stride(vpad_in, MW), FM = vpad_in * MW;      // front records (tbc_internal.h)
+  T.rdm.assign(total * FS + 1, 0);
   T.look.assign(look_words(total, nh, MW), 0);
   uint64_t off_n = 0, lst_n = 0, tab_n = 0;
   for (uint32_t h = 0; h < nh; h++) {
@@ -88,13 +90,23 @@ bool build_tables(uint32_t nh, const uint64_t* op_off, const uint32_t* n_process
         // open-read masks by value
         if (f[o + x] == TBC_F_READ && vpad) {
           const uint32_t vi = rdm_index(a[o + x], vpad);
-          if (vi != 0u || a[o + x] == TBC_NIL) T.rdm[((o + F) * vpad + vi) * MW + (px >> 6)] |= 1ull << (px & 63);
+          if (vpad_in && (vi != 0u || a[o + x] == TBC_NIL)) T.rdm[(o + F) * FS + vi * MW + (px >> 6)] |= 1ull << (px & 63);
         }
       }
     }
     // completion slots as bytes
     uint8_t* s8 = T.slot8.data() + slot8_off(o, h);
     for (uint32_t r = 0; r < R + 16; r++) s8[r] = r < R ? (uint8_t)process[o + rets[r].second] : 0;
+    uint8_t* k8 = T.rk8.data() + slot8_off(o, h);
+    for (uint32_t r = 0; r < R; r++) { const uint32_t x = rets[r].second; k8[r] = f[o + x] == TBC_F_READ ? (uint8_t)rdm_index(a[o + x], vpad_in) : (uint8_t)0xFF; }
+    // the rest of each front record: list location, windows of the next 16 ranks
+    for (uint32_t F = 0; F < R; F++) {
+      uint64_t* rec = T.rdm.data() + (o + F) * FS + FM;
+      rec[0] = (uint64_t)off[F] | ((uint64_t)(off[F + 1] - off[F]) << 32);
+      rec[1] = (uint64_t)((off[F + 1] - off[F]) + ncr[F]);
+      uint8_t* wb = reinterpret_cast<uint8_t*>(rec + 2);
+      for (uint32_t l = 0; l < 16; l++) { wb[l] = s8[F + l]; wb[16 + l] = F + l < R ? k8[F + l] : (uint8_t)0xFF; }
+    }
     // lookahead records
     uint64_t* look = T.look.data() + look_off(o, h, MW);
     const uint32_t LW = 1 + MW;
@@ -135,9 +147,13 @@ void wave_entry(void* p, uint32_t lane) {
   narrow::narrow_wave<MW, L>(*c->A, c->wave, c->lds, lane);
 }
 template <int MW, int L>
-void run_all(const BeamArgs& A) {
+void run_all(BeamArgs& A, uint32_t max_waves) {
   const uint32_t H = 64 / L;
-  const uint32_t waves = (A.n_work + H - 1) / H;
+  uint32_t waves = (A.n_work + H - 1) / H;
+  if (max_waves && waves > max_waves) waves = max_waves;      // fewer wavefronts than the batch needs: groups take more work as they finish
+  static unsigned int next_work;
+  next_work = 0;
+  A.first_dynamic = waves * H; A.next_work = &next_work;
   std::vector<uint32_t> lds(narrow::narrow_lds_words(MW, L) + 16);
   for (uint32_t w = 0; w < waves; w++) {
     std::fill(lds.begin(), lds.end(), 0xDEADBEEFu);          // LDS is not zeroed on the device either
@@ -150,13 +166,15 @@ void run_all(const BeamArgs& A) {
 
 extern "C" {
 
+void emu_stats(uint64_t* out, int reset) { for (int i = 0; i < 64; i++) { out[i] = wv::stats()[i]; if (reset) wv::stats()[i] = 0; } }
+
 // tables only (for comparing with what the device kernels wrote): returns sizes through out_n[8] and copies into caller buffers when given
 int emu_narrow_run(uint32_t nh, const uint64_t* op_off, const uint32_t* n_process, const uint8_t* f, const int32_t* a, const int32_t* b,
                    const int32_t* process, const uint32_t* inv_pos, const uint32_t* ret_pos, uint32_t model_kind, int32_t init,
                    uint32_t L, uint32_t MW, uint32_t rules, uint32_t vpad, uint32_t lookahead, uint32_t entries_per_op, uint64_t max_steps,
-                   uint64_t pool_words, uint32_t want_witness, DevResult* results, uint32_t* witness, uint64_t* cfg_out) {
+                   uint64_t pool_words, uint32_t want_witness, uint32_t max_waves, DevResult* results, uint32_t* witness, uint64_t* cfg_out) {
   Tables T;
-  if (!build_tables(nh, op_off, n_process, f, a, b, process, inv_pos, ret_pos, MW, vpad ? vpad : 1, entries_per_op, T)) return 1;
+  if (!build_tables(nh, op_off, n_process, f, a, b, process, inv_pos, ret_pos, MW, vpad, entries_per_op, T)) return 1;
   const uint64_t total = op_off[nh];
   uint64_t entries = 0;
   for (uint32_t h = 0; h < nh; h++) entries += 1ull << T.bh[h].tab_log2;
@@ -175,8 +193,8 @@ int emu_narrow_run(uint32_t nh, const uint64_t* op_off, const uint32_t* n_proces
   A.init_state = init; A.width = 1; A.max_steps = max_steps; A.time_limit_ticks = 0; A.dbg = nullptr;
   A.pool = pool_words ? pool.data() : nullptr; A.pool_cursor = &cursor; A.pool_words = pool_words; A.max_tab_log2 = 28;
   A.pool_vals = nullptr; A.cfg = cfg.data(); A.rules = rules; A.twn = (rules & kRuleTwin) ? T.twn.data() : nullptr;
-  A.rdm = (rules & kRuleEager) ? T.rdm.data() : nullptr; A.vpad = vpad;
-#define RUN(MWV, LV) if (MW == MWV && L == LV) { run_all<MWV, LV>(A); ran = true; }
+  A.rdm = T.rdm.data(); A.vpad = vpad; A.rk8 = T.rk8.data(); A.front_words = front_stride(vpad, MW);
+#define RUN(MWV, LV) if (MW == MWV && L == LV) { run_all<MWV, LV>(A, max_waves); ran = true; }
   bool ran = false;
   RUN(1, 4) RUN(1, 8) RUN(1, 16) RUN(1, 32) RUN(2, 8) RUN(2, 16) RUN(4, 8) RUN(4, 16)
 #undef RUN

@@ -122,6 +122,11 @@ inline uint64_t ld64(const gu64* p) { return *p; }
 inline void st64(gu64* p, uint64_t v) { *p = v; }
 inline uint32_t ld32(const gu32* p) { return *p; }
 inline void st32(gu32* p, uint32_t v) { *p = v; }
+inline uint64_t own_ld64(const gu64* p) { return *p; }
+inline void own_st64(gu64* p, uint64_t v) { *p = v; }
+inline uint32_t own_ld32(const gu32* p) { return *p; }
+inline void own_st32(gu32* p, uint32_t v) { *p = v; }
+inline u32x4 own_ld128(const gu64* p) { const uint32_t* q = reinterpret_cast<const uint32_t*>(p); return u32x4{q[0], q[1], q[2], q[3]}; }
 inline uint64_t cas64_from_zero(gu64* p, uint64_t desired) {
   const uint64_t old = *p;
   if (old == 0ull) *p = desired;
@@ -132,9 +137,12 @@ inline void ld_bucket16(const gu64* bucket, u32x4& e0, u32x4& e1, u32x4& e2, u32
   e0 = u32x4{q[0], q[1], q[2], q[3]}; e1 = u32x4{q[4], q[5], q[6], q[7]};
   e2 = u32x4{q[8], q[9], q[10], q[11]}; e3 = u32x4{q[12], q[13], q[14], q[15]};
 }
+inline void wait_stores() {}
 inline void lds_add32(uint32_t* p, uint32_t v) { *p += v; }
 inline void lds_add64(uint32_t* p, uint64_t v) { uint64_t x; memcpy(&x, p, 8); x += v; memcpy(p, &x, 8); }
 inline void lds_max32(uint32_t* p, uint32_t v) { if (v > *p) *p = v; }
+inline uint64_t* stats() { static uint64_t s[64]; return s; }
+inline void stat(uint32_t id, uint64_t v) { stats()[id & 63u] += v; }
 inline uint64_t clock100mhz() { return W()->clock += 1; }
 template <class Args>
 inline const Args* cold(const Args& a) { return &a; }
@@ -196,4 +204,5 @@ inline void run_wave(void (*fn)(void*, uint32_t), void* arg) {
 }  // namespace wv
 
 // what device code calls unqualified
+inline unsigned int atomicAdd(unsigned int* p, unsigned int v) { const unsigned int o = *p; *p += v; return o; }
 inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { const unsigned long long o = *p; *p += v; return o; }

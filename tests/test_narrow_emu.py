@@ -136,3 +136,13 @@ def test_wide_masks_many_crashed_processes():
     h4 = [columns.pair_events(synth.register_events(n_ops=2000, n_procs=32, seed=s, busy=0.1, info=0.08, corrupt=0.0)) for s in range(2)]
     assert all(128 < h.n_process <= 256 for h in h4), [h.n_process for h in h4]
     compare(h4, CAS, 8, tag="mw4", pool_words=4_000_000, max_steps=40_000)
+
+
+@pytest.mark.parametrize("L,waves", [(8, 1), (8, 2), (16, 3)])
+def test_groups_take_more_work_as_they_finish(L, waves):
+    """fewer wavefronts than the batch needs (a launch sized to the GPU, not to the batch): a group that has finished its
+    history reports it and takes the next one off the queue -- every history still gets its own schedule's answer"""
+    hists = [columns.pair_events(synth.register_events(n_ops=n, n_procs=p, seed=s, busy=busy, info=info, corrupt=corrupt))
+             for (n, p, info, corrupt, busy) in SHAPES for s in range(3)]
+    compare(hists, CAS, L, tag="refill", pool_words=4_000_000, max_waves=waves)
+    compare(hists[:20], CAS, L, tag="refill-small-tables", pool_words=4_000_000, max_waves=1, entries_per_op=1)
