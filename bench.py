@@ -10,7 +10,8 @@
              max-over-ranks clock only); histories are independent units, so they
              are sharded across ranks with NO data-path collective -- weak scaling
              (B per GPU fixed)
-  roofline : the search kernel (wgl_beam_kernel, or wgl_search_kernel at --width 1), HBM bound.  achieved = algorithmic bytes per launch
+  roofline : the search kernel (wgl_narrow_kernel when several histories share a wavefront -- the library's choice for this
+             batch --, wgl_beam_kernel, or wgl_search_kernel at --width 1), HBM bound.  achieved = algorithmic bytes per launch
              (16 B per visited-set probe that finds a duplicate,
              32 B per probe that inserts a new config) / the kernel's average
              duration, measured with HIP events on the library's own stream
@@ -46,7 +47,7 @@ def kernel_sha():
     was measured on (profiles/*_traffic.json carries the sha it was taken at)."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("wgl_beam.hip", "device_common.h", "pack_open.hip"):
+    for f in ("wgl_beam.hip", "wgl_narrow.hip", "wgl_narrow_impl.h", "wave_env.h", "device_common.h", "pack_open.hip"):
         with open(os.path.join(ROOT, "jepsen-tigerbeetle_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
@@ -95,12 +96,17 @@ def main():
     ap.add_argument("--width", type=int, default=int(os.environ.get("TBC_BENCH_WIDTH", "0")),
                     help="configs expanded per iteration: 0 = the library's choice (2 at low concurrency under the dominance rules, "
                          "else 4), 1 = sequential knossos.wgl order, 2..16 = wide schedule")
+    ap.add_argument("--lanes", type=int, default=int(os.environ.get("TBC_BENCH_LANES", "0")),
+                    help="lanes per history of the depth-first search: 0 = the library's choice (8 for this workload: eight histories per "
+                         "wavefront), 8 / 16 / 32, or 64 = one history per wavefront")
     ap.add_argument("--visited-per-op", type=int, default=8, help="first visited-set capacity per op (0 = library default 64)")
     ap.add_argument("--round-budget", type=int, default=0,
                     help="a history that has used more rounds than this continues at width 16 (0 = off)")
     ap.add_argument("--cpu-sample", type=int, default=256, help="histories timed on the CPU oracle (rank 0, N=1)")
     ap.add_argument("--busy2", type=float, default=0.5, help="second workload: duty cycle of the '64 concurrent processes' reading (0 = skip)")
-    ap.add_argument("--batch2", type=int, default=2048, help="second workload: histories per GPU")
+    ap.add_argument("--batch2", type=int, default=4096, help="second workload: histories per GPU (a 2^20-entry visited set each: 4,096 fill the memory)")
+    ap.add_argument("--busy3", type=float, default=0.3, help="a point in between: ~19 calls in flight (0 = skip)")
+    ap.add_argument("--batch3", type=int, default=8192, help="third workload: histories per GPU")
     ap.add_argument("--no-tiers", action="store_true", help="skip the crashed-op tiers (extra.tiers)")
     ap.add_argument("--no-set-full", action="store_true", help="skip the checker/set-full scan (extra.set_full)")
     ap.add_argument("--no-cpu", action="store_true")
@@ -144,11 +150,14 @@ def main():
     model = core.make_model(N.MODEL_CAS_REGISTER, N.NIL)
     opts = core.make_opts(device=local_rank, time_limit_ms=600000, want_witness=False,
                           algorithm=N.ALG_COMPETITION, search_width=args.width, visited_per_op=args.visited_per_op,
-                          round_budget=args.round_budget)
+                          round_budget=args.round_budget, lanes_per_history=args.lanes)
     t_create = time.perf_counter()
     batch = core.Batch(hists, model, opts)        # H2D happens here: inputs resident before timing
     t_create = time.perf_counter() - t_create
     width = batch.search_width()                  # what --width 0 became for this batch
+    lanes = batch.lanes_per_history()             # 8 / 16 / 32: several histories per wavefront (one config per iteration); 64: one
+    narrow = lanes != 64
+    kname = "wgl_narrow_kernel" if narrow else ("wgl_search_kernel" if width == 1 else "wgl_beam_kernel")
 
     for _ in range(args.warmup):
         batch.run()
@@ -195,10 +204,10 @@ def main():
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         traffic = None
         try:   # HBM bytes per launch from the committed rocprofv3 PMC passes: same config AND same kernel sources only
-            with open(os.path.join(ROOT, "profiles", "r02_traffic.json")) as fh:
+            with open(os.path.join(ROOT, "profiles", "r03_traffic.json")) as fh:
                 for e in json.load(fh)["entries"]:
-                    key = (e["histories_per_gpu"], e["search_width"], e["visited_per_op"], e["ops"], e["procs"], e["busy"], e["info"])
-                    if e.get("kernel_sha") == kernel_sha() and key == (B, width, args.visited_per_op, args.ops, args.procs, args.busy, args.info):
+                    key = (e["histories_per_gpu"], e["search_width"], e.get("lanes_per_history", 64), e["visited_per_op"], e["ops"], e["procs"], e["busy"], e["info"])
+                    if e.get("kernel_sha") == kernel_sha() and key == (B, width, lanes, args.visited_per_op, args.ops, args.procs, args.busy, args.info):
                         traffic = e["traffic_bytes"]
         except (OSError, KeyError, ValueError):
             pass
@@ -211,11 +220,12 @@ def main():
             "dtype": "u64", "data": "synthetic",
             "config": {"workload": workload_name(args.ops, args.procs, args.busy, args.info), "histories_per_gpu": B, "ops_after_pairing": int(batch.total_ops // B),
                        "processes": args.procs, "busy": args.busy, "info_rate": args.info,
-                       "search_width": width, "search_width_asked": args.width, "round_budget": args.round_budget,
+                       "search_width": width, "search_width_asked": args.width, "lanes_per_history": lanes, "histories_per_wavefront": 64 // lanes,
+                       "round_budget": args.round_budget,
                        "parallelism": f"independent histories sharded over {world} GPU(s), no collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
-                         "kernel": "wgl_search_kernel" if width == 1 else "wgl_beam_kernel", "kernel_ms": round(k_ms, 3),
+                         "kernel": kname, "kernel_ms": round(k_ms, 3),
                          "probes_per_launch": counters["probes"], "new_configs_per_launch": counters["visited"],
                          "algorithmic_bytes_per_launch": alg_bytes},
             "extra": {"valid": n_valid, "unknown": n_unknown,
@@ -234,18 +244,18 @@ def main():
         # time-to-verdict for ONE history through tbc_check (host columns in -> verdict out: H2D + kernels + D2H), rank 0.
         # knossos.competition without a witness = the level sweep (jit_sweep.hip); with a witness = the depth-first search
         batch.close()
-        if world == 1 and args.width == 0 and width != 4:
-            # the same batch at 4 configs per round (the default until the width followed the concurrency): it attempts
-            # about twice the probes -- more algorithmic bytes per second, a higher roofline fraction -- and needs longer
-            # for the same verdicts.  Reported so that the fraction above can be read against it; never `value`.
+        if world == 1 and narrow and args.lanes == 0:
+            # the same batch with ONE history per wavefront (round 2's kernel, wgl_beam_kernel at the width it chose then): what
+            # several histories per wavefront buy, measured in the same run.  Never `value`.
             with core.Batch(hists, model, core.make_opts(device=local_rank, time_limit_ms=600000, want_witness=False, algorithm=N.ALG_COMPETITION,
-                                                         search_width=4, visited_per_op=args.visited_per_op)) as b4:
+                                                         lanes_per_history=64, visited_per_op=args.visited_per_op)) as b4:
                 b4.run()
                 t4 = time.perf_counter(); b4.run(); t4 = time.perf_counter() - t4
-                c4, tm4 = b4.counters(), b4.timing_ns()
+                c4, tm4, w4 = b4.counters(), b4.timing_ns(), b4.search_width()
             alg4 = 16 * (c4["probes"] - c4["visited"]) + 32 * c4["visited"]
-            line["extra"]["same_batch_at_width_4"] = {
-                "value": round(B / t4, 2), "unit": "histories/s", "ms_per_step": round(t4 * 1e3, 3), "kernel_ms": round(tm4["search"] / 1e6, 3),
+            line["extra"]["same_batch_one_history_per_wavefront"] = {
+                "kernel": "wgl_beam_kernel", "search_width": w4, "value": round(B / t4, 2), "unit": "histories/s", "ms_per_step": round(t4 * 1e3, 3),
+                "kernel_ms": round(tm4["search"] / 1e6, 3), "pack_ms": round(tm4["pack"] / 1e6, 3),
                 "probes_per_launch": c4["probes"], "new_configs_per_launch": c4["visited"], "algorithmic_bytes_per_launch": alg4,
                 "roofline_frac": round(alg4 / (tm4["search"] * 1e-9) / 1e9 / HBM_PEAK_GBS, 6)}
         ttv, ttv_dfs, analyzers = [], [], []
@@ -292,12 +302,13 @@ def main():
             tb = time.perf_counter() - tb
             # the SAME schedule the kernel runs (wide, K configs per iteration, lookahead, eager reads, twin rule) on one
             # host thread: how much of the speed-up is the algorithm and how much the GPU
+            sk = dict(width=1, round_pairs=lanes, rules_at_any_round_size=True) if narrow else dict(width=width if width > 1 else 4)
             tw = time.perf_counter()
-            okw = sum(wgl.check_beam(d, om, width if width > 1 else 4, want_witness=False)["valid"] == 1 for d in dicts[:S1])
+            okw = sum(wgl.check_beam(d, om, want_witness=False, **sk)["valid"] == 1 for d in dicts[:S1])
             tw = time.perf_counter() - tw
             # ... and on every CPU this container may use (oracle/many.c runs wgl_beam.c on the same thread pool)
             twa = time.perf_counter()
-            okwa, _ = wgl.check_many(work, om, cores, beam_width=width if width > 1 else 4)
+            okwa, _ = wgl.check_many(work, om, cores, beam_width=sk["width"], round_pairs=lanes if narrow else 64)
             twa = time.perf_counter() - twa
             ts = time.perf_counter()
             oks = sum(wgl.check_sweep(d, om)["valid"] == 1 for d in dicts[:S1])
@@ -311,7 +322,7 @@ def main():
                                     "ms_per_history": round(tc / S1 * 1e3, 3),
                                     "invalid_example_ms": round(tb * 1e3, 3), "invalid_example_verdict": rbo["valid"],
                                     "same_schedule_as_kernel": {"value": round(S1 / tw, 3), "unit": "histories/s", "cores": 1,
-                                                                "sample": f"first {S1} histories, oracle/wgl_beam.c with lookahead + eager reads + twin rule",
+                                                                "sample": f"first {S1} histories, oracle/wgl_beam.c with lookahead + eager reads + twin rule, {sk['width']} config(s) per iteration, {lanes if narrow else 64} pairs per round",
                                                                 "all_cores": {"value": round(len(work) / twa, 3), "unit": "histories/s", "cores": cores,
                                                                               "sample": f"the all-cores sample ({len(work)} histories) on {cores} pthreads"}},
                                     "level_sweep_on_cpu": {"value": round(S1 / ts, 3), "unit": "histories/s", "cores": 1,
@@ -346,26 +357,45 @@ def main():
         if world == 1 and args.busy2 > 0:
             # second workload: BASELINE.json's "64 concurrent processes" read literally is infeasible for every known
             # algorithm; busy 0.5 (~32 calls in flight) is the closest reading the dominance rules make
-            # checkable.  Its own value and roofline; never mixed into `value`.
-            B2 = args.batch2
-            h2 = synth.register_ops_many(range(10_000_000, 10_000_000 + B2), n_ops=args.ops, n_procs=args.procs, busy=args.busy2, info=0.0)
-            o2 = core.make_opts(device=local_rank, time_limit_ms=600000, want_witness=False, algorithm=N.ALG_COMPETITION,
-                                search_width=args.width, visited_per_op=256)     # ~4*10^5 configs per history: start big, no retries
-            with core.Batch(h2, model, o2) as b2:
-                width2 = b2.search_width()
-                b2.run()
-                t2 = time.perf_counter(); b2.run(); t2 = time.perf_counter() - t2
-                c2 = b2.counters(); tm2 = b2.timing_ns(); v2 = b2.verdicts()
-            alg2 = 16 * (c2["probes"] - c2["visited"]) + 32 * c2["visited"]
-            k2 = (tm2["search"] + tm2["retries"]) / 1e6
-            line["extra"]["workload_2"] = {
-                "workload": workload_name(args.ops, args.procs, args.busy2, 0.0), "histories_per_gpu": B2, "search_width": width2,
-                "value": round(B2 / t2, 2), "unit": "histories/s", "ms_per_step": round(t2 * 1e3, 3),
-                "valid": int((v2 == N.VALID).sum()), "unknown": int((v2 == N.UNKNOWN).sum()),
-                "roofline": {"bound": "hbm", "achieved": round(alg2 / (k2 * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": round(alg2 / (k2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 6), "traffic": None, "kernel": "wgl_beam_kernel",
-                             "kernel_ms": round(k2, 3), "probes_per_launch": c2["probes"], "new_configs_per_launch": c2["visited"]},
-                "device_ms": {k: round(x / 1e6, 3) for k, x in tm2.items()}}
+            # checkable, busy 0.3 (~19 in flight) a point in between.  Each with its own value and roofline and the CPU restatement
+            # of the kernel's schedule on a sample beside it (thread pool, the CPUs this container may use); never mixed into `value`.
+            # A history at 32 in flight needs ~4*10^5 configs, i.e. a 2^20-entry visited set with its stacks = 33 MB: 4,096 of them are
+            # what 288 GB hold next to their tables, so that batch fills half of the GPU's wavefront slots (one history per wavefront).
+            def second(busy, B2, vpo, seed0, cpu_n, cpu_cap):
+                h2 = synth.register_ops_many(range(seed0, seed0 + B2), n_ops=args.ops, n_procs=args.procs, busy=busy, info=0.0)
+                o2 = core.make_opts(device=local_rank, time_limit_ms=600000, want_witness=False, algorithm=N.ALG_COMPETITION,
+                                    search_width=args.width, visited_per_op=vpo)
+                with core.Batch(h2, model, o2) as b2:
+                    width2, lanes2 = b2.search_width(), b2.lanes_per_history()
+                    b2.run()
+                    t2 = time.perf_counter(); b2.run(); t2 = time.perf_counter() - t2
+                    c2 = b2.counters(); tm2 = b2.timing_ns(); v2 = b2.verdicts()
+                alg2 = 16 * (c2["probes"] - c2["visited"]) + 32 * c2["visited"]
+                k2 = (tm2["search"] + tm2["retries"]) / 1e6
+                out = {"workload": workload_name(args.ops, args.procs, busy, 0.0), "histories_per_gpu": B2, "search_width": width2, "lanes_per_history": lanes2,
+                       "value": round(B2 / t2, 2), "unit": "histories/s", "ms_per_step": round(t2 * 1e3, 3),
+                       "valid": int((v2 == N.VALID).sum()), "unknown": int((v2 == N.UNKNOWN).sum()),
+                       "roofline": {"bound": "hbm", "achieved": round(alg2 / (k2 * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                    "frac": round(alg2 / (k2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 6), "traffic": None,
+                                    "kernel": "wgl_narrow_kernel" if lanes2 != 64 else "wgl_beam_kernel",
+                                    "kernel_ms": round(k2, 3), "probes_per_launch": c2["probes"], "new_configs_per_launch": c2["visited"]},
+                       "device_ms": {k: round(x / 1e6, 3) for k, x in tm2.items()}}
+                if not args.no_cpu:
+                    from oracle import wgl
+                    cores, _, _ = usable_cores()
+                    dd = [h2[i].as_dict() for i in range(min(cpu_n, B2))]
+                    tcp = time.perf_counter()
+                    vv, started = wgl.check_many(dd, {"kind": 1, "init": N.NIL}, cores, max_steps=cpu_cap, beam_width=width2 if width2 > 1 else 4)
+                    tcp = time.perf_counter() - tcp
+                    done = int((vv != -1).sum())
+                    assert all(int(vv[i]) in (-1, int(v2[i])) for i in range(len(dd))), "GPU and oracle disagree on the second workload's sample"
+                    out["cpu_baseline"] = {"value": round(done / tcp, 3), "unit": "histories/s", "cores": cores, "kind": "port",
+                                           "sample": f"first {len(dd)} histories, oracle/wgl_beam.c (the kernel's schedule, {width2} configs per round, lookahead + eager reads + "
+                                                     f"twin rule) on {started} pthreads, at most {cpu_cap:.0e} probes each: {done} finished (the others are not counted)"}
+                return out
+            line["extra"]["workload_2"] = second(args.busy2, args.batch2, 64, 10_000_000, 64, 60_000_000)
+            if args.busy3 > 0:
+                line["extra"]["workload_3"] = second(args.busy3, args.batch3, 32, 20_000_000, 128, 60_000_000)
         if world == 1 and not args.no_set_full:
             # checker/set-full (the checker the reference runs: set_full.clj:157): the reads x elements membership scan,
             # the one streaming kernel of the path.  Synthetic: 262,144 elements x 32,768 reads (1 GB of bits), an element
@@ -400,7 +430,7 @@ def main():
             line["extra"]["set_full"] = {"elements": E, "reads": R, "matrix_GB": round(runs[0]["bytes_matrix"] / 1e9, 3),
                                          "scan_ms": round(ms, 3), "bytes_scanned": int(runs[0]["bytes_scanned"]), "lost_elements_found": lost,
                                          "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                                      "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "setfull_scan_kernel"}}
+                                                      "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "setfull_any_kernel + setfull_resolve_kernel"}}
         print(json.dumps(line), flush=True)
     batch.close()
     if world > 1:

@@ -36,7 +36,8 @@ typedef struct {
   const oracle_model* model; uint64_t max_steps;
   int32_t* valid;
   volatile uint32_t next;
-  uint32_t beam_width;      /* 0 = wgl_window_check, else wgl_beam_check_rp at this many configs per round */
+  uint32_t beam_width;      /* 0 = wgl_window_check, else wgl_beam_check_rp at this many configs per round ... */
+  uint32_t round_pairs;     /* ... and this many pairs per round (64 = one history per wavefront; 8 / 16 / 32 = the narrow kernel's schedules) */
 } many_job;
 
 static void* many_worker(void* p) {
@@ -48,7 +49,7 @@ static void* many_worker(void* p) {
     beam_stats bs;
     int rc = j->beam_width
       ? wgl_beam_check_rp(j->n[i], j->f[i], j->a[i], j->b[i], j->process[i], j->n_process[i], j->inv_pos[i], j->ret_pos[i],
-                          j->model, j->beam_width, 64, j->max_steps, NULL, &r, &bs)
+                          j->model, j->beam_width, j->round_pairs ? j->round_pairs : 64u, j->max_steps, NULL, &r, &bs)
       : wgl_window_check(j->n[i], j->f[i], j->a[i], j->b[i], j->process[i], j->n_process[i], j->inv_pos[i], j->ret_pos[i],
                          j->model, j->max_steps, NULL, &r);
     j->valid[i] = rc ? -2 : r.valid;
@@ -59,21 +60,21 @@ static void* many_worker(void* p) {
 int wgl_check_many(uint32_t n_hist, const uint32_t* n, const uint32_t* n_process,
                    const uint8_t* const* f, const int32_t* const* a, const int32_t* const* b, const int32_t* const* process,
                    const uint32_t* const* inv_pos, const uint32_t* const* ret_pos,
-                   const oracle_model* model, uint64_t max_steps, uint32_t n_threads, uint32_t beam_width, int32_t* valid);
+                   const oracle_model* model, uint64_t max_steps, uint32_t n_threads, uint32_t beam_width, uint32_t round_pairs, int32_t* valid);
 
 /* valid[i] = verdict of history i (-2 = rejected).  Returns the number of threads actually started. */
 int wgl_window_check_many(uint32_t n_hist, const uint32_t* n, const uint32_t* n_process,
                           const uint8_t* const* f, const int32_t* const* a, const int32_t* const* b, const int32_t* const* process,
                           const uint32_t* const* inv_pos, const uint32_t* const* ret_pos,
                           const oracle_model* model, uint64_t max_steps, uint32_t n_threads, int32_t* valid) {
-  return wgl_check_many(n_hist, n, n_process, f, a, b, process, inv_pos, ret_pos, model, max_steps, n_threads, 0, valid);
+  return wgl_check_many(n_hist, n, n_process, f, a, b, process, inv_pos, ret_pos, model, max_steps, n_threads, 0, 64, valid);
 }
 
 int wgl_check_many(uint32_t n_hist, const uint32_t* n, const uint32_t* n_process,
                    const uint8_t* const* f, const int32_t* const* a, const int32_t* const* b, const int32_t* const* process,
                    const uint32_t* const* inv_pos, const uint32_t* const* ret_pos,
-                   const oracle_model* model, uint64_t max_steps, uint32_t n_threads, uint32_t beam_width, int32_t* valid) {
-  many_job j = {n_hist, n, n_process, f, a, b, process, inv_pos, ret_pos, model, max_steps, valid, 0, beam_width};
+                   const oracle_model* model, uint64_t max_steps, uint32_t n_threads, uint32_t beam_width, uint32_t round_pairs, int32_t* valid) {
+  many_job j = {n_hist, n, n_process, f, a, b, process, inv_pos, ret_pos, model, max_steps, valid, 0, beam_width, round_pairs};
   if (n_threads == 0) n_threads = 1;
   pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * n_threads);
   uint32_t started = 0;
