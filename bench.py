@@ -99,12 +99,12 @@ def main():
     ap.add_argument("--lanes", type=int, default=int(os.environ.get("TBC_BENCH_LANES", "0")),
                     help="lanes per history of the depth-first search: 0 = the library's choice (8 for this workload: eight histories per "
                          "wavefront), 8 / 16 / 32, or 64 = one history per wavefront")
-    ap.add_argument("--visited-per-op", type=int, default=8, help="first visited-set capacity per op (0 = library default 64)")
+    ap.add_argument("--visited-per-op", type=int, default=4, help="first visited-set capacity per op (0 = library default 64); a history that needs more grows its set inside the kernel")
     ap.add_argument("--round-budget", type=int, default=0,
                     help="a history that has used more rounds than this continues at width 16 (0 = off)")
     ap.add_argument("--cpu-sample", type=int, default=256, help="histories timed on the CPU oracle (rank 0, N=1)")
     ap.add_argument("--busy2", type=float, default=0.5, help="second workload: duty cycle of the '64 concurrent processes' reading (0 = skip)")
-    ap.add_argument("--batch2", type=int, default=4096, help="second workload: histories per GPU (a 2^20-entry visited set each: 4,096 fill the memory)")
+    ap.add_argument("--batch2", type=int, default=2048, help="second workload: histories per GPU (a 2^21-entry visited set each: no retries)")
     ap.add_argument("--busy3", type=float, default=0.3, help="a point in between: ~19 calls in flight (0 = skip)")
     ap.add_argument("--batch3", type=int, default=8192, help="third workload: histories per GPU")
     ap.add_argument("--no-tiers", action="store_true", help="skip the crashed-op tiers (extra.tiers)")
@@ -359,15 +359,17 @@ def main():
             # algorithm; busy 0.5 (~32 calls in flight) is the closest reading the dominance rules make
             # checkable, busy 0.3 (~19 in flight) a point in between.  Each with its own value and roofline and the CPU restatement
             # of the kernel's schedule on a sample beside it (thread pool, the CPUs this container may use); never mixed into `value`.
-            # A history at 32 in flight needs ~4*10^5 configs, i.e. a 2^20-entry visited set with its stacks = 33 MB: 4,096 of them are
-            # what 288 GB hold next to their tables, so that batch fills half of the GPU's wavefront slots (one history per wavefront).
-            def second(busy, B2, vpo, seed0, cpu_n, cpu_cap):
+            # A history at 32 in flight can need > 10^6 configs (the tail is heavy): 2^21-entry visited sets with their stacks = 67 MB
+            # each, 2,048 of them (137 GB) a batch -- a quarter of the GPU's wavefront slots; smaller first sets cost retries that take
+            # longer than the whole step (measured: 4,096 histories at 2^20 entries, 134 s of retries).
+            def second(busy, B2, vpo, seed0, cpu_n, cpu_cap, warm):
                 h2 = synth.register_ops_many(range(seed0, seed0 + B2), n_ops=args.ops, n_procs=args.procs, busy=busy, info=0.0)
                 o2 = core.make_opts(device=local_rank, time_limit_ms=600000, want_witness=False, algorithm=N.ALG_COMPETITION,
                                     search_width=args.width, visited_per_op=vpo)
                 with core.Batch(h2, model, o2) as b2:
                     width2, lanes2 = b2.search_width(), b2.lanes_per_history()
-                    b2.run()
+                    if warm:
+                        b2.run()
                     t2 = time.perf_counter(); b2.run(); t2 = time.perf_counter() - t2
                     c2 = b2.counters(); tm2 = b2.timing_ns(); v2 = b2.verdicts()
                 alg2 = 16 * (c2["probes"] - c2["visited"]) + 32 * c2["visited"]
@@ -393,9 +395,9 @@ def main():
                                            "sample": f"first {len(dd)} histories, oracle/wgl_beam.c (the kernel's schedule, {width2} configs per round, lookahead + eager reads + "
                                                      f"twin rule) on {started} pthreads, at most {cpu_cap:.0e} probes each: {done} finished (the others are not counted)"}
                 return out
-            line["extra"]["workload_2"] = second(args.busy2, args.batch2, 64, 10_000_000, 64, 60_000_000)
+            line["extra"]["workload_2"] = second(args.busy2, args.batch2, 256, 10_000_000, 64, 60_000_000, False)      # (a step is ~25 s: one run, no warm-up)
             if args.busy3 > 0:
-                line["extra"]["workload_3"] = second(args.busy3, args.batch3, 32, 20_000_000, 128, 60_000_000)
+                line["extra"]["workload_3"] = second(args.busy3, args.batch3, 32, 20_000_000, 128, 60_000_000, True)
         if world == 1 and not args.no_set_full:
             # checker/set-full (the checker the reference runs: set_full.clj:157): the reads x elements membership scan,
             # the one streaming kernel of the path.  Synthetic: 262,144 elements x 32,768 reads (1 GB of bits), an element

@@ -404,6 +404,9 @@ tbc_status tbc_batch_sweep_table(const tbc_batch* b, void** device_ptr, uint64_t
 /* verdicts from a merged relation table in HOST memory; merged_bytes must equal tbc_batch_sweep_table()'s size
  * (anything else is TBC_ERR_INVALID_ARG, as is a finish that no tbc_batch_sweep_partial precedes) */
 tbc_status tbc_batch_sweep_finish(tbc_batch* b, const void* merged, uint64_t merged_bytes, tbc_result* results);
+/* the same from the ranks' tables still in DEVICE memory, `world` of them back to back (what an all-gather over RCCL leaves):
+ * they are OR-ed on the device into this batch's table, then composed -- the exchanged bytes never pass through the host */
+tbc_status tbc_batch_sweep_merge(tbc_batch* b, const void* gathered_device, uint64_t gathered_bytes, uint32_t world, tbc_result* results);
 void tbc_batch_destroy(tbc_batch* b);
 
 /* ----------------------------------------------------------------- memo

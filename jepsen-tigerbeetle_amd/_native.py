@@ -160,6 +160,7 @@ SYMBOLS = {
     "tbc_batch_sweep_partial": (C.c_int, [C.c_void_p]),
     "tbc_batch_sweep_table": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
     "tbc_batch_sweep_finish": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(Result)]),
+    "tbc_batch_sweep_merge": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(Result)]),
     "tbc_setfull_create": (C.c_int, [C.POINTER(SetFullIn), C.POINTER(C.c_void_p)]),
     "tbc_setfull_run": (C.c_int, [C.c_void_p, C.POINTER(SetFullOut)]),
     "tbc_setfull_destroy": (None, [C.c_void_p]),

@@ -184,6 +184,21 @@ class Batch:
         N.check_status(st)
         return self
 
+    def sweep_table_tensor(self):
+        """The relation table of the last sweep_partial() as a torch uint8 tensor over the library's own HBM (no copy)."""
+        import torch
+        from .shard import _DeviceBytes
+        ptr, nbytes = self.sweep_table()
+        return torch.as_tensor(_DeviceBytes(ptr, nbytes), device=torch.device("cuda", torch.cuda.current_device()))
+
+    def sweep_merge(self, gathered, world):
+        """`gathered`: a torch CUDA uint8 tensor holding the `world` ranks' tables back to back (all_gather_into_tensor):
+        OR-ed on the device, composed; the exchanged bytes never pass through the host."""
+        st = N.lib().tbc_batch_sweep_merge(self._h, C.c_void_p(gathered.data_ptr()), C.c_uint64(gathered.numel() * gathered.element_size()),
+                                           C.c_uint32(world), self._res)
+        N.check_status(st)
+        return self
+
     def sweep_info(self):
         i = N.SweepInfo()
         N.check_status(N.lib().tbc_batch_sweep_info(self._h, C.byref(i)))

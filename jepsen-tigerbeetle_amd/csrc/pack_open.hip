@@ -295,6 +295,14 @@ __global__ __launch_bounds__(256) void open_walk_kernel(PackOpenArgs A) {
   const uint32_t w_off = off[min(F_lo + lane, R)];
   const uint32_t w_slot = ret_slot[min(F_lo + lane, R - 1u)];
   const uint64_t below = (1ull << lane) - 1ull;
+  uint64_t tw[MW][MW];                  // twin mask of the call each of this lane's registers holds (words over process slots)
+  bool known[MW];                       // ... and whether that call has been entered into the masks yet
+#pragma unroll
+  for (int j = 0; j < MW; j++) {
+    known[j] = false;
+#pragma unroll
+    for (int w = 0; w < MW; w++) tw[j][w] = 0ull;
+  }
 
   for (uint32_t F = F_lo; F < F_hi; F++) {
     const uint32_t base = __builtin_amdgcn_readlane(w_off, F - F_lo);
@@ -320,40 +328,36 @@ __global__ __launch_bounds__(256) void open_walk_kernel(PackOpenArgs A) {
         lst[mypos[j]] = o;
       }
     }
-    // twin masks: the open writes / cas are few -- broadcast each, every lane compares
+    // twin masks, kept from front to front: a call ENTERS the masks once, at the first front it is open at (it is added to
+    // the same-effect calls that complete later, and gets the ones that complete earlier as its own mask), and LEAVES them
+    // when the front passes its completion (below).  One broadcast per invoked write / cas instead of one per open
+    // write / cas per front -- the walk is bound by its vector instructions, and this loop was a third of them.
     if (twn) {
-      uint64_t tw[MW][MW];
-      uint64_t cw[MW];
-      uint32_t ncw = 0;
 #pragma unroll
-      for (int j = 0; j < MW; j++) {
-        cw[j] = __ballot(live[j] && (cur[j].cls & 8u));
-        ncw += (uint32_t)__popcll(cw[j]);
+      for (int jj = 0; jj < MW; jj++) {
+        uint64_t m = __ballot(live[jj] && (cur[jj].cls & 8u) && !known[jj]);
+        while (m) {
+          const uint32_t l = (uint32_t)__builtin_ctzll(m);
+          m &= m - 1ull;
+          const uint32_t zf = __builtin_amdgcn_readlane(cur[jj].f, l), zr = __builtin_amdgcn_readlane(cur[jj].ret, l);
+          const int32_t za = (int32_t)__builtin_amdgcn_readlane((uint32_t)cur[jj].a, l), zb = (int32_t)__builtin_amdgcn_readlane((uint32_t)cur[jj].b, l);
 #pragma unroll
-        for (int w = 0; w < MW; w++) tw[j][w] = 0ull;
-      }
-      if (ncw >= 2u) {
-#pragma unroll
-        for (int jj = 0; jj < MW; jj++) {
-          uint64_t m = cw[jj];
-          while (m) {
-            const uint32_t l = (uint32_t)__builtin_ctzll(m);
-            m &= m - 1ull;
-            const uint32_t zf = __builtin_amdgcn_readlane(cur[jj].f, l), zr = __builtin_amdgcn_readlane(cur[jj].ret, l);
-            const uint32_t zo = __builtin_amdgcn_readlane(cur[jj].op, l);
-            const int32_t za = (int32_t)__builtin_amdgcn_readlane((uint32_t)cur[jj].a, l), zb = (int32_t)__builtin_amdgcn_readlane((uint32_t)cur[jj].b, l);
-#pragma unroll
-            for (int j = 0; j < MW; j++) {
-              const bool same = live[j] && cur[j].f == zf && cur[j].a == za && (zf != TBC_F_CAS || cur[j].b == zb) && cur[j].op != zo;
-              if (same && (zr < cur[j].ret || (zr == cur[j].ret && zo < cur[j].op))) tw[j][jj] |= 1ull << l;
-            }
+          for (int j = 0; j < MW; j++) {
+            const bool same = live[j] && cur[j].f == zf && cur[j].a == za && (zf != TBC_F_CAS || cur[j].b == zb) && !(j == jj && lane == l);
+            if (same && zr < cur[j].ret) tw[j][jj] |= 1ull << l;
+            const uint64_t earlier = __ballot(same && cur[j].ret < zr);
+            if (lane == l) tw[jj][j] = earlier;
           }
         }
       }
 #pragma unroll
-      for (int j = 0; j < MW; j++) if (live[j]) {
+      for (int j = 0; j < MW; j++) {
+        const bool wc = live[j] && (cur[j].cls & 8u);
+        if (wc) known[j] = true;
+        if (live[j]) {
 #pragma unroll
-        for (int w = 0; w < MW; w++) twn[(uint64_t)mypos[j] * MW + w] = tw[j][w];
+          for (int w = 0; w < MW; w++) twn[(uint64_t)mypos[j] * MW + w] = wc ? tw[j][w] : 0ull;
+        }
       }
     }
     // open-read masks by value: lane vi keeps row entry vi
@@ -401,7 +405,16 @@ __global__ __launch_bounds__(256) void open_walk_kernel(PackOpenArgs A) {
     // the call completing here leaves: its process's next call takes the lane
 #pragma unroll
     for (int j = 0; j < MW; j++) {
+      if (twn) {                                    // the completed call leaves every mask
+#pragma unroll
+        for (int w = 0; w < MW; w++) if ((px >> 6) == (uint32_t)w) tw[j][w] &= ~(1ull << (px & 63u));
+      }
       if ((px >> 6) == (uint32_t)j && lane == (px & 63u)) {
+        if (twn) {
+#pragma unroll
+          for (int w = 0; w < MW; w++) tw[j][w] = 0ull;
+          known[j] = false;
+        }
         cur[j] = nxt[j];
         at[j] = min(at[j] + 1u, tail[j]);
         nxt[j] = load_cur(rec + min(at[j] + 1u, tail[j]));

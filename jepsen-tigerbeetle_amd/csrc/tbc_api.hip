@@ -1146,6 +1146,39 @@ tbc_status tbc_batch_sweep_finish(tbc_batch* b, const void* merged, uint64_t mer
   catch (...) { set_error("unexpected exception"); return TBC_ERR_HIP; }
 }
 
+namespace {
+// bitwise OR of `world` relation tables lying back to back in device memory into `dst` (every record is written by exactly
+// one rank and all zero on the others)
+__global__ void sweep_or_kernel(uint64_t* dst, const uint64_t* gathered, uint64_t words, uint32_t world) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= words) return;
+  uint64_t v = 0;
+  for (uint32_t r = 0; r < world; r++) v |= gathered[(uint64_t)r * words + i];
+  dst[i] = v;
+}
+}  // namespace
+
+tbc_status tbc_batch_sweep_merge(tbc_batch* b, const void* gathered_device, uint64_t gathered_bytes, uint32_t world, tbc_result* results) {
+  if (!b || !b->sweep || !gathered_device || world == 0) { set_error("tbc_batch_sweep_merge: not a sweep batch"); return TBC_ERR_INVALID_ARG; }
+  const uint64_t bytes = (uint64_t)b->seg_host.size() * sizeof(SegResult);
+  if (gathered_bytes != bytes * world) {
+    set_error("tbc_batch_sweep_merge: %llu bytes gathered, %u tables of %llu expected", (unsigned long long)gathered_bytes, world, (unsigned long long)bytes);
+    return TBC_ERR_INVALID_ARG;
+  }
+  if (!b->partial_done) { set_error("tbc_batch_sweep_merge without tbc_batch_sweep_partial"); return TBC_ERR_INVALID_ARG; }
+  try {
+    HIP_TRY(hipSetDevice(b->device));
+    const uint64_t words = bytes / 8;
+    hipLaunchKernelGGL(sweep_or_kernel, dim3((uint32_t)((words + 255) / 256)), dim3(256), 0, b->stream, (uint64_t*)b->d_sres.p, (const uint64_t*)gathered_device, words, world);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(b->seg_host.data(), b->d_sres.p, bytes, hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    return batch_run_impl(b, results, 2);
+  }
+  catch (const std::bad_alloc&) { set_error("host allocation failed"); return TBC_ERR_OOM; }
+  catch (...) { set_error("unexpected exception"); return TBC_ERR_HIP; }
+}
+
 tbc_status tbc_batch_last_timing(const tbc_batch* b, uint64_t ns[4]) {
   if (!b || !ns) return TBC_ERR_INVALID_ARG;
   for (int i = 0; i < 4; i++) ns[i] = b->timing_ns[i];

@@ -79,12 +79,21 @@ def gather_relation_tables(local, world: int, dist=None):
 
 def check_sharded(batch, rank: int, world: int, dist=None):
     """One small batch (typically ONE history) over `world` GPUs: `batch` is this rank's core.Batch over the SAME
-    histories (inputs are replicated), created with algorithm=N.ALG_LINEAR.  Returns batch.results() on every rank."""
+    histories (inputs are replicated), created with algorithm=N.ALG_LINEAR.  Returns batch.results() on every rank.
+
+    The exchange: every rank's relation table is a tensor over the library's own HBM (`sweep_table_tensor`), ONE
+    all_gather_into_tensor over RCCL puts the `world` tables back to back in device memory, and the library ORs them on
+    the device and composes (`sweep_merge`) -- nothing of the exchange passes through the host.  `batch` only has to
+    provide set_shard / sweep_partial / sweep_table_tensor / sweep_merge / results, which is how the CPU test drives this
+    very function over gloo with the CPU restatement standing in for the kernels (tests/test_distributed_gloo.py)."""
     import torch
     batch.set_shard(rank, world)
     batch.sweep_partial()
-    ptr, nbytes = batch.sweep_table()
-    local = torch.as_tensor(_DeviceBytes(ptr, nbytes), device=torch.device("cuda", torch.cuda.current_device()))
-    merged = merge_relation_tables(gather_relation_tables(local, world, dist))
-    batch.sweep_finish(merged)
+    local = batch.sweep_table_tensor().contiguous().view(-1)
+    if world == 1:
+        gathered = local
+    else:
+        gathered = torch.empty(world * local.numel(), dtype=torch.uint8, device=local.device)
+        dist.all_gather_into_tensor(gathered, local)
+    batch.sweep_merge(gathered, world)
     return batch.results()

@@ -79,6 +79,30 @@ int main(void){ printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", offsetof
     assert C.sizeof(R) == 960
 
 
+def test_setfull_and_opts_offsets_the_jna_shim_writes(native):
+    """INTEGRATION.md fills tbc_setfull_in / tbc_setfull_out and tbc_opts by byte offset (the set-full binding, lanes_per_history)."""
+    prog = r'''
+#include <stdio.h>
+#include "tbcheck.h"
+int main(void){ printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu  %zu %zu %zu %zu %zu %zu %zu  %zu %zu %zu\n",
+  sizeof(tbc_setfull_in), offsetof(tbc_setfull_in, n_elements), offsetof(tbc_setfull_in, n_reads), offsetof(tbc_setfull_in, words_per_row),
+  offsetof(tbc_setfull_in, device), offsetof(tbc_setfull_in, add_invoke), offsetof(tbc_setfull_in, add_ok), offsetof(tbc_setfull_in, read_invoke),
+  offsetof(tbc_setfull_in, read_ok), offsetof(tbc_setfull_in, present),
+  sizeof(tbc_setfull_out), offsetof(tbc_setfull_out, known), offsetof(tbc_setfull_out, last_present), offsetof(tbc_setfull_out, last_absent),
+  offsetof(tbc_setfull_out, ns_scan), offsetof(tbc_setfull_out, bytes_scanned), offsetof(tbc_setfull_out, bytes_matrix),
+  sizeof(tbc_opts), offsetof(tbc_opts, lanes_per_history), offsetof(tbc_opts, dominance)); return 0; }
+'''
+    with tempfile.TemporaryDirectory() as d:
+        src = os.path.join(d, "o.c")
+        open(src, "w").write(prog)
+        exe = os.path.join(d, "o")
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), src, "-o", exe])
+        offs = [int(x) for x in subprocess.check_output([exe]).split()]
+    assert offs == [56, 0, 4, 8, 12, 16, 24, 32, 40, 48, 48, 0, 8, 16, 24, 32, 40, 64, 56, 52]
+    assert C.sizeof(native.SetFullIn) == 56 and C.sizeof(native.SetFullOut) == 48 and C.sizeof(native.Opts) == 64
+    assert native.Opts.lanes_per_history.offset == 56
+
+
 @pytest.mark.skipif(has_gpu(), reason="only meaningful on a box without a GPU")
 def test_no_cpu_fallback(native):
     from jepsen_tigerbeetle_amd import columns, core, synth

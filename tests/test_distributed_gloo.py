@@ -112,3 +112,70 @@ def test_one_history_sharded_over_two_ranks(tmp_path, native, oracle):
         if ref["valid"] == 1:
             assert row0[2] == row0[3] + row1[3]                                    # ... and all of them composed
         assert (row0[4], row0[5]) == (ref["probes"], ref["configs_total"])         # nothing swept twice, nothing lost
+
+
+# ---- shard.check_sharded itself over gloo: the function a multi-GPU caller runs (set_shard -> sweep_partial -> table tensor ->
+# ONE all_gather_into_tensor -> merge -> results), with a stand-in batch whose "kernels" are the CPU restatement and whose merge
+# is the bitwise OR the device kernel does + the library's own tbc_sweep_compose.  What a GPU box adds is only where the bytes live.
+class _CpuSweepBatch:
+    def __init__(self, ops, seg_target, n_dom, max_segs):
+        self.ops, self.seg_target, self.n_dom, self.max_segs = ops, seg_target, n_dom, max_segs
+        self.rank, self.world, self._table, self._res = 0, 1, None, None
+
+    def set_shard(self, rank, world):
+        self.rank, self.world = rank, world
+
+    def sweep_partial(self):
+        import ctypes as C
+        from jepsen_tigerbeetle_amd import _native as N
+        from oracle import wgl
+        self._table = wgl.sweep_relations(self.ops, {"kind": 1, "init": N.NIL}, self.seg_target, self.n_dom, self.max_segs, self.rank, self.world, C.sizeof(N.SweepRel))
+
+    def sweep_table_tensor(self):
+        import torch
+        return torch.from_numpy(np.ascontiguousarray(self._table, np.uint8))
+
+    def sweep_merge(self, gathered, world):
+        import ctypes as C
+        from jepsen_tigerbeetle_amd import _native as N
+        merged = np.bitwise_or.reduce(gathered.numpy().reshape(world, -1), axis=0)          # what sweep_or_kernel does in HBM
+        rel = (N.SweepRel * (self.max_segs * N.SWEEP_SLICES)).from_buffer_copy(merged.tobytes())
+        v = N.SweepVerdict()
+        n_ret = int((self.ops["ret_pos"] != N.POS_CRASHED).sum())
+        assert N.lib().tbc_sweep_compose(rel, self.max_segs, n_ret, C.byref(v)) == 0
+        self._res = [{"valid": v.valid, "fail_level": v.fail_level, "probes": v.probes, "configs_total": v.configs_total}]
+        return self
+
+    def results(self):
+        return self._res
+
+
+def _check_sharded_worker(rank, world, port, cases, seg_target, n_dom, max_segs, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import jepsen_tigerbeetle_amd  # noqa: F401
+    from jepsen_tigerbeetle_amd import columns, shard, synth
+    out = []
+    for c in cases:
+        ops = columns.pair_events(synth.register_events(**c)).as_dict()
+        r = shard.check_sharded(_CpuSweepBatch(ops, seg_target, n_dom, max_segs), rank, world, dist)[0]
+        out.append([r["valid"], r["fail_level"], r["probes"], r["configs_total"]])
+    np.save(os.path.join(out_dir, f"c{rank}.npy"), np.array(out, np.int64))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_check_sharded_code_path_world_size_2(tmp_path, native, oracle):
+    from jepsen_tigerbeetle_amd import _native as N, columns, synth
+    cases = [dict(n_ops=1500, n_procs=32, seed=13, busy=0.15), dict(n_ops=1500, n_procs=32, seed=14, busy=0.15, corrupt=0.5)]
+    seg_target, n_dom, max_segs, world = 16, 14, 160, 2
+    mp.spawn(_check_sharded_worker, args=(world, _free_port(), cases, seg_target, n_dom, max_segs, str(tmp_path)), nprocs=world, join=True)
+    c0, c1 = np.load(tmp_path / "c0.npy"), np.load(tmp_path / "c1.npy")
+    assert np.array_equal(c0, c1)
+    for c, row in zip(cases, c0):
+        ops = columns.pair_events(synth.register_events(**c)).as_dict()
+        ref = oracle.check_sweep(ops, {"kind": 1, "init": N.NIL}, seg_target=seg_target, n_dom=n_dom)
+        assert row[0] == ref["valid"] and (row[2], row[3]) == (ref["probes"], ref["configs_total"])

@@ -154,6 +154,13 @@ def test_sharded_sweep_on_one_gpu(native, oracle):
         merged = shard.merge_relation_tables(tables)
         assert (tables[0] != 0).any() and (tables[1] != 0).any() and not (tables[0] & tables[1]).any()   # disjoint shares
         two = [b.sweep_finish(merged).results()[0] for b in ranks]
+        # ... and merged ON THE DEVICE, as an all_gather_into_tensor would leave them (tbc_batch_sweep_merge): back to back in HBM
+        for b in ranks:
+            b.sweep_partial()
+        gathered = torch.cat([b.sweep_table_tensor() for b in ranks]).contiguous()
+        two += [b.sweep_merge(gathered, 2).results()[0] for b in ranks]
+        with pytest.raises(N.TbcError):
+            ranks[0].sweep_merge(gathered[:-8], 2)                 # a table of the wrong size is refused, not read past its end
         for b in ranks:
             b.close()
         for got in [one] + two:
