@@ -248,7 +248,9 @@ enum {
 
 typedef struct tbc_config {      /* one knossos config: {:model :pending :last-op} */
   int32_t state;                 /* model state (value / table state id)          */
-  uint32_t last_op;              /* op index linearized last, or TBC_NO_OP        */
+  uint32_t last_op;              /* op index linearized last, or TBC_NO_OP (always  */
+                                 /* TBC_NO_OP from a several-histories-per-wavefront */
+                                 /* batch that wants no witness: it keeps no links)  */
   uint32_t n_pending;            /* open ops at the front ...                     */
   uint32_t n_linearized;         /* ... of which this many are already linearized */
   uint32_t pending[16];          /* first 16 open op indices                      */

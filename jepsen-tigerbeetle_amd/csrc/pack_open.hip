@@ -117,20 +117,21 @@ __global__ __launch_bounds__(1024) void open_counts_kernel(PackOpenArgs A) {
       }
     }
     for (uint32_t i0 = tid; i0 < n; i0 += 4u * NT) {          // four ops per trip
-      uint32_t ir[4], rr[4]; bool nilread[4];
+      uint32_t ir[4], rr[4]; bool nilread[4], isread[4];
 #pragma unroll
       for (uint32_t k = 0; k < 4; k++) {
         const uint32_t i = i0 + k * NT;
         const bool in = i < n;
         ir[k] = in ? sc_inv[i] : 0u; rr[k] = in ? sc_ret[i] : 0u;
-        nilread[k] = in && f[i] == TBC_F_READ && a[i] == TBC_NIL;
+        isread[k] = in && f[i] == TBC_F_READ;
+        nilread[k] = isread[k] && a[i] == TBC_NIL;
       }
 #pragma unroll
       for (uint32_t k = 0; k < 4; k++) {
         if (i0 + k * NT >= n) continue;
         if (rr[k] == kInf) {
           if (ir[k] < R && !nilread[k]) atomicAdd(&ncr[ir[k]], 1u);
-        } else {
+        } else if (!(A.branch_lists && isread[k])) {
           atomicAdd(&off[ir[k]], 1u);
         }
       }
@@ -142,23 +143,45 @@ __global__ __launch_bounds__(1024) void open_counts_kernel(PackOpenArgs A) {
     {
       const uint32_t chunk = (R + NT - 1) / NT;
       const uint32_t lo = min(tid * chunk, R), hi = min(lo + chunk, R);
+      // branch lists: a completed READ was never in a list, so the calls that have left the lists before front F are the
+      // F completions minus the reads among them -- the reads of this thread's ranks as a bit mask (rk8 was written above)
+      uint64_t rdbits = 0;
+      uint32_t base_rd = 0;
+      if (A.branch_lists) {
+        const uint8_t* rk8 = A.rk8 + slot8_off(H->op_off, h);
+        uint32_t nrd = 0;
+        if (hi - lo <= 64u) { for (uint32_t i = lo; i < hi; i++) if (rk8[i] != 0xFFu) rdbits |= 1ull << (i - lo); nrd = (uint32_t)__popcll(rdbits); }
+        else for (uint32_t i = lo; i < hi; i++) nrd += rk8[i] != 0xFFu;
+        s_part[tid] = nrd;
+        __syncthreads();
+        scan_parts(s_part, NT, nullptr);
+        __syncthreads();
+        base_rd = s_part[tid];
+        __syncthreads();
+      }
+      const bool wide_chunk = hi - lo > 64u;
+      const uint8_t* rk8w = A.rk8 ? A.rk8 + slot8_off(H->op_off, h) : nullptr;
+      const auto rd_at = [&](uint32_t i) -> uint32_t {          // is the call completing at rank i a read (branch lists only)
+        if (!A.branch_lists) return 0u;
+        return wide_chunk ? (uint32_t)(rk8w[i] != 0xFFu) : (uint32_t)((rdbits >> (i - lo)) & 1ull);
+      };
       uint32_t sum = 0;
       chunk_loads(off, lo, hi, [&](uint32_t, uint32_t v) { sum += v; });
       s_part[tid] = sum;
       __syncthreads();
       scan_parts(s_part, NT, nullptr);
       __syncthreads();
-      const uint32_t base_inv = s_part[tid];          // live calls invoked before this chunk's first rank
+      const uint32_t base_inv = s_part[tid];          // listed calls invoked before this chunk's first rank
       __syncthreads();
-      uint32_t run = base_inv, open_sum = 0;
-      chunk_loads(off, lo, hi, [&](uint32_t i, uint32_t v) { run += v; open_sum += run - i; });
+      uint32_t run = base_inv, open_sum = 0, rd = base_rd;
+      chunk_loads(off, lo, hi, [&](uint32_t i, uint32_t v) { run += v; open_sum += run - (i - rd); rd += rd_at(i); });
       s_part[tid] = open_sum;
       __syncthreads();
       scan_parts(s_part, NT, &s_total);
       __syncthreads();
       uint32_t pos = s_part[tid];
-      run = base_inv;
-      chunk_loads(off, lo, hi, [&](uint32_t i, uint32_t v) { run += v; off[i] = pos; pos += run - i; });
+      run = base_inv; rd = base_rd;
+      chunk_loads(off, lo, hi, [&](uint32_t i, uint32_t v) { run += v; off[i] = pos; pos += run - (i - rd); rd += rd_at(i); });
       total = s_total;
       if (tid == 0) off[R] = total;
       __syncthreads();
@@ -307,14 +330,15 @@ __global__ __launch_bounds__(256) void open_walk_kernel(PackOpenArgs A) {
   for (uint32_t F = F_lo; F < F_hi; F++) {
     const uint32_t base = __builtin_amdgcn_readlane(w_off, F - F_lo);
     const uint32_t px = __builtin_amdgcn_readlane(w_slot, F - F_lo);
-    bool live[MW], crashed_open[MW];
+    bool live[MW], crashed_open[MW], inl[MW];
     uint64_t occ[MW];
 #pragma unroll
     for (int j = 0; j < MW; j++) {
       const bool here = cur[j].inv <= F;            // (a lane without a call holds inv = kInf)
       live[j] = here && (cur[j].cls & 2u);
       crashed_open[j] = here && (cur[j].cls & 4u);
-      occ[j] = __ballot(live[j]);
+      inl[j] = live[j] && !(A.branch_lists && (cur[j].cls & 16u));      // in the front's list (branch lists: not the reads)
+      occ[j] = __ballot(inl[j]);
     }
     // the front's list, in slot order
     uint32_t before = 0, mypos[MW];
@@ -322,7 +346,7 @@ __global__ __launch_bounds__(256) void open_walk_kernel(PackOpenArgs A) {
     for (int j = 0; j < MW; j++) {
       mypos[j] = base + before + (uint32_t)__popcll(occ[j] & below);
       before += (uint32_t)__popcll(occ[j]);
-      if (live[j]) {
+      if (inl[j]) {
         OpRec o; o.op = cur[j].op; o.f_slot = cur[j].f | ((lane + 64u * (uint32_t)j) << 8) | (cur[j].ret == F ? kAtFront : 0u);
         o.a = cur[j].a; o.b = cur[j].b;
         lst[mypos[j]] = o;
@@ -354,7 +378,7 @@ __global__ __launch_bounds__(256) void open_walk_kernel(PackOpenArgs A) {
       for (int j = 0; j < MW; j++) {
         const bool wc = live[j] && (cur[j].cls & 8u);
         if (wc) known[j] = true;
-        if (live[j]) {
+        if (inl[j]) {
 #pragma unroll
           for (int w = 0; w < MW; w++) twn[(uint64_t)mypos[j] * MW + w] = wc ? tw[j][w] : 0ull;
         }
@@ -499,6 +523,18 @@ __global__ __launch_bounds__(256) void front_meta_kernel(PackOpenArgs A) {
   for (uint32_t l = 0; l < 16; l++) {                          // (both arrays are padded 16 past the last rank)
     w[l >> 3] |= (uint64_t)s8[l] << (8u * (l & 7u));
     w[2 + (l >> 3)] |= (uint64_t)k8[l] << (8u * (l & 7u));
+  }
+  if (A.front_compact) {          // 64 B records: list location in word 6, seven ranks of slot | kind << 6 in word 7
+    uint64_t* rec = A.rdm + (H->op_off + F) * kFrontCompactWords;
+    uint64_t win = 0;
+#pragma unroll
+    for (uint32_t l = 0; l < kFrontCompactRanks; l++) {
+      const uint32_t sl = (uint32_t)(w[0] >> (8u * l)) & 63u, k = (uint32_t)(w[2] >> (8u * l)) & 0xFFu;
+      win |= (uint64_t)(sl | ((k == 0xFFu ? 7u : (k & 7u)) << 6)) << (9u * l);
+    }
+    rec[6] = (uint64_t)o0 | ((uint64_t)((o1 - o0) & 0xFFu) << 32) | ((uint64_t)(((o1 - o0) + nc) & 0xFFFFFFu) << 40);
+    rec[7] = win;
+    return;
   }
   uint64_t* rec = A.rdm + (H->op_off + F) * A.front_words + A.vpad * A.mask_words;
   rec[0] = (uint64_t)o0 | ((uint64_t)(o1 - o0) << 32);

@@ -193,6 +193,8 @@ struct tbc_batch {
   DevBuf<uint64_t> d_cfg;           // configs at the failing front, kCfgCap records per history
   // wide schedule (search_width > 1)
   uint32_t width = 1;
+  // u64 words per front record (0 = plain rdm rows): the compact 64 B form where one mask word and six row entries do
+  uint32_t front_words() const { return !lanes ? 0u : ((rules & kRuleEager) && front_compact_ok(n_dom, mask_words)) ? kFrontCompactWords : front_stride(vpad, mask_words); }
   uint32_t lanes = 0;               // 8 / 16 / 32: several histories per wavefront (wgl_narrow.hip), one config per iteration; 0 = one per wavefront
   std::vector<BeamHist> bh;
   DevBuf<BeamHist> d_bh;
@@ -379,7 +381,7 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
   // above is made for): a wavefront then carries 8 searches instead of one whose rounds fill 4 of its 64 lanes.
   {
     const uint32_t asked = opts->lanes_per_history;
-    if (asked != 0 && asked != 8 && asked != 16 && asked != 32 && asked != 64) { set_error("lanes_per_history must be 0, 8, 16, 32 or 64"); return TBC_ERR_INVALID_ARG; }
+    if (asked != 0 && asked != 4 && asked != 8 && asked != 16 && asked != 32 && asked != 64) { set_error("lanes_per_history must be 0, 4, 8, 16, 32 or 64"); return TBC_ERR_INVALID_ARG; }
     if (opts->reserved0 != 0) { set_error("tbc_opts.reserved0 must be 0"); return TBC_ERR_INVALID_ARG; }
     const bool regfam3 = model->kind == TBC_MODEL_REGISTER || model->kind == TBC_MODEL_CAS_REGISTER || model->kind == TBC_MODEL_MUTEX;
     // the narrow kernel addresses a history's tables with 32-bit element offsets
@@ -392,6 +394,8 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
     } else if (asked == 0 && can && opts->search_width == 0 && B->width == 2 && nh >= 4096) {
       B->lanes = 8;
     }
+    // under the eager rule the narrow kernel branches over :write / :cas only: lists without reads, root in normal form
+    if (B->lanes && (B->rules & kRuleEager)) B->rules |= kRuleBranch;
   }
   const uint32_t EW = B->mask_words + 2;   // u64 words per wide-schedule entry
   if (B->sweep) {
@@ -459,7 +463,7 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
 
   if (B->lanes && (blst_n >= (1ull << 32) || boff_n >= (1ull << 32))) {      // 32-bit element offsets (wgl_narrow_impl.h)
     if (opts->lanes_per_history) { set_error("lanes_per_history: the batch's open-call lists exceed 2^32 entries; split the batch"); return TBC_ERR_UNSUPPORTED; }
-    B->lanes = 0;
+    B->lanes = 0; B->rules &= ~kRuleBranch;
   }
   if (B->sweep) { bstack_n = 0; btab_n = 0; }     // the sweep has no visited set; its fallback takes scratch arenas
   tbc_status s;
@@ -482,7 +486,7 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
     if (B->lanes && (s = B->d_rk8.alloc(slot8_bytes(T, nh)))) return s;
     if (B->rules && ((s = B->d_twn.alloc(blst_n * B->mask_words)) || (s = B->d_rdm.alloc(B->lanes ? 1 : T * B->vpad * B->mask_words)))) return s;
     // several histories per wavefront: front records (tbc_internal.h) instead of plain rows, with or without the rules
-    if (B->lanes) { B->d_rdm.release(); if ((s = B->d_rdm.alloc(T * front_stride(B->vpad, B->mask_words)))) return s; }
+    if (B->lanes) { B->d_rdm.release(); if ((s = B->d_rdm.alloc(T * B->front_words()))) return s; }
     if (B->lookahead && ((s = B->d_look.alloc(look_words(T, nh, B->mask_words))) || (s = B->d_looktmp.alloc(T)) ||
                          (s = B->d_dstack.alloc(bstack_n)))) return s;
     // growth pool: 30 % of the visited-set arena, at least room for one history to grow twice (4x, then 16x: keys, parents, two stacks, slot translation), at most 32 GiB
@@ -602,7 +606,7 @@ static BeamArgs make_beam_args(tbc_batch* B, uint64_t* tab, uint32_t* stack, uin
   a.model_aux = B->model.init; a.n_keys = B->model.n_keys;
   a.n_classes = B->model.n_classes; a.width = B->width;
   a.round_budget = B->opts.round_budget;
-  a.rules = B->rules; a.twn = B->d_twn.p; a.rdm = B->d_rdm.p; a.vpad = B->vpad; a.rk8 = B->d_rk8.p; a.front_words = B->lanes ? front_stride(B->vpad, B->mask_words) : 0u; a.next_work = B->d_queue.p;
+  a.rules = B->rules; a.twn = B->d_twn.p; a.rdm = B->d_rdm.p; a.vpad = B->vpad; a.rk8 = B->d_rk8.p; a.front_words = B->front_words(); a.next_work = B->d_queue.p;
   a.max_steps = B->opts.max_steps;
   a.time_limit_ticks = B->opts.time_limit_ms * 100000ull;
   a.dbg = debug_words();
@@ -762,6 +766,13 @@ static tbc_status expand_eager_witness(tbc_batch* B, uint32_t h, uint32_t* wit, 
     return moved;
   };
   open_calls();
+  if (B->rules & kRuleBranch) {      // the root itself starts in normal form: its reads come first
+    for (bool again = true; again && front < R;) {
+      for (int64_t x : open_by_slot)
+        if (x >= 0 && !done[x] && f[x] == TBC_F_READ && (a[x] == TBC_NIL || a[x] == state)) { done[x] = 1; out.push_back((uint32_t)x); }
+      again = advance();
+    }
+  }
   for (uint32_t op : chain) {
     if (op >= n || done[op]) { set_error("history %u: malformed witness chain", h); return TBC_ERR_HIP; }
     state = f[op] == TBC_F_WRITE ? a[op] : (f[op] == TBC_F_CAS ? b[op] : state);
@@ -837,7 +848,8 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results, int phase = 
     po.rec = B->d_rec.p; po.seg = B->d_seg.p; po.chunks_per_hist = (uint32_t)((B->max_ops + 63) / 64);
     po.crashed = B->d_crashed.p; po.ret_slot = B->d_ret_slot.p; po.slot8 = B->d_slot8.p;
     po.ret_op = B->d_ret_op.p; po.look = B->lookahead ? B->d_look.p : nullptr; po.tmp = B->d_looktmp.p; po.n_hist = nh; po.mask_words = B->mask_words;
-    po.rk8 = B->lanes ? B->d_rk8.p : nullptr; po.front_words = B->lanes ? front_stride(B->vpad, B->mask_words) : 0u;
+    po.branch_lists = (B->rules & kRuleBranch) ? 1u : 0u;
+    po.rk8 = B->lanes ? B->d_rk8.p : nullptr; po.front_words = B->front_words(); po.front_compact = B->front_words() == kFrontCompactWords ? 1u : 0u;
     po.twn = B->rules ? B->d_twn.p : nullptr; po.rdm = (B->rules || B->lanes) ? B->d_rdm.p : nullptr; po.vpad = B->vpad;
     launch_pack_open(po, s);
     HIP_TRY(hipGetLastError());

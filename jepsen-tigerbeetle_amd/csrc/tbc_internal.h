@@ -172,6 +172,9 @@ constexpr uint32_t kSlotMask = 0xFFFFu;     // (f_slot >> 8) & kSlotMask = proce
 //   twn[e * mask_words + w]                for entry e of lst[] (a live call at one of its fronts): slots of the
 //                                          live calls open at that front with the same effect that complete earlier
 constexpr uint32_t kRuleEager = 1u, kRuleTwin = 2u;
+// narrow kernel under the eager rule: the per-front lists hold the live :write / :cas calls only (a read is never a viable
+// candidate of a config in normal form; the rule itself finds the reads through rdm) and the root config starts in normal form
+constexpr uint32_t kRuleBranch = 4u;
 // FRONT RECORDS (narrow kernel, wgl_narrow.hip): the rdm row of a front, extended to everything else a search step needs of
 // that front, so that it costs ONE line of memory instead of a line of each of five arrays (off, ncr, slot8, rk8, rdm) that
 // fall out of L2 between the rounds of a history.  front_stride(vpad, mw) u64 words per front at rdm[(op_off + F) * stride]:
@@ -181,6 +184,12 @@ constexpr uint32_t kRuleEager = 1u, kRuleTwin = 2u;
 //   + 2,3 the process slots of the calls completing at ranks F .. F + 15, one byte each (0 past the end)
 //   + 4,5 the read kinds of those ranks (rk8: 0xFF = not a read, else the rdm index of the value read)
 __host__ __device__ inline uint32_t front_stride(uint32_t vpad, uint32_t mask_words) { return (vpad * mask_words + 6u + 7u) & ~7u; }
+// COMPACT front records: one mask word and at most six row entries in use (nil + values 0..4 -- the reference's registers):
+// 64 B, ONE memory transaction instead of two.  Words 0..5 the open-read masks, then
+//   6   off[F] | nlive << 32 | cnt << 40
+//   7   ranks F .. F + 6, nine bits each: process slot (6) | read kind (3: the rdm index of the value read, 7 = not a read)
+constexpr uint32_t kFrontCompactWords = 8, kFrontCompactRanks = 7;
+__host__ __device__ inline bool front_compact_ok(uint32_t n_dom, uint32_t mask_words) { return mask_words == 1 && n_dom >= 2 && n_dom <= 6; }
 constexpr int32_t kMaxRuleValue = 30;       // register values 0..30 (vpad <= 32); anything else switches the rules off
 __host__ __device__ inline uint32_t rdm_index(int32_t v, uint32_t vpad) {   // row entry of state / read value v
   return (v == TBC_NIL || (uint32_t)(v + 1) >= vpad) ? 0u : (uint32_t)(v + 1);
@@ -210,7 +219,7 @@ struct PackOpenArgs {
   const Rec* rec;            // pack_kernel's per-process record lists (at Hist.rec_off) ...
   const uint32_t* seg;       // ... and their starts (at Hist.seg_off)
   uint32_t chunks_per_hist;  // ceil(most ops of a history / 64): wavefronts the walk launches per history
-  uint32_t pad0;
+  uint32_t branch_lists;     // kRuleBranch: live reads are left out of lst[] / off[] (narrow kernel, eager rule)
   uint32_t* off;
   uint32_t* ncr;
   OpRec* lst;
@@ -220,8 +229,8 @@ struct PackOpenArgs {
   uint64_t* look;            // lookahead records at look_off(), or null (lookahead off / other models)
   uint32_t* tmp;             // n_ops words per history at op_off: scratch for the records
   uint8_t* slot8;            // the same as bytes (mask_words <= 4), at slot8_off(op_off, h): windowed prefetch
-  uint32_t front_words;      // 0, or front_stride(): rdm rows are front records (the walk adds list location and windows)
-  uint32_t pad2;
+  uint32_t front_words;      // 0, or front_stride() / kFrontCompactWords: rdm rows are front records (list location and windows behind the masks)
+  uint32_t front_compact;    // 1 = the compact 64 B form
   uint8_t* rk8;              // narrow kernel, eager reads: per rank 0xFF = the completing call is not a read, else the rdm index of the value it read (same offsets as slot8), or null
   uint32_t n_hist;
   uint32_t mask_words;
@@ -279,7 +288,7 @@ struct BeamArgs {
   uint32_t vpad;
   uint32_t pad3;
   const uint8_t* rk8;                // as PackOpenArgs (narrow kernel only)
-  uint32_t front_words;              // u64 words per front record in rdm (narrow kernel only)
+  uint32_t front_words;              // u64 words per front record in rdm (narrow kernel only; kFrontCompactWords = the compact form)
   uint32_t first_dynamic;            // narrow kernel: work items below this are dealt to the wavefronts at launch (wave w, group g: w * H + g) ...
   unsigned int* next_work;           // ... the others are taken from this counter (zeroed before the launch) as groups finish
 };

@@ -11,19 +11,19 @@ namespace tbc {
 
 namespace {
 
-constexpr uint32_t kNarrowWaves = 4;
+constexpr uint32_t kNarrowWaves = 2;
 
 #ifndef TBC_NARROW_MIN_WAVES
 #define TBC_NARROW_MIN_WAVES 3
 #endif
 
-template <int MW, int L>
+template <int MW, int L, bool CF>
 __global__ __launch_bounds__(64 * kNarrowWaves, TBC_NARROW_MIN_WAVES) void wgl_narrow_kernel(BeamArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wv_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const uint32_t w = blockIdx.x * kNarrowWaves + wv_;
-  narrow::narrow_wave<MW, L>(A, w, lds + wv_ * narrow::narrow_lds_words(MW, L), lane);
+  narrow::narrow_wave<MW, L, CF>(A, w, lds + wv_ * narrow::narrow_lds_words(MW, L, CF), lane);
 }
 
 // Wavefronts the GPU keeps resident at once: the launch is sized to that, not to the batch -- a wavefront's groups take more
@@ -40,10 +40,10 @@ uint32_t resident_waves(size_t lds_bytes_per_wave) {
   return (uint32_t)cus * per_cu;
 }
 
-template <int MW, int L>
-void launch_one(const BeamArgs& a_in, hipStream_t s) {
+template <int MW, int L, bool CF>
+void launch_cf(const BeamArgs& a_in, hipStream_t s) {
   const uint32_t H = 64u / L;
-  const size_t lds_wave = (size_t)narrow::narrow_lds_words(MW, L) * 4;
+  const size_t lds_wave = (size_t)narrow::narrow_lds_words(MW, L, CF) * 4;
   uint32_t waves = (a_in.n_work + H - 1) / H;
   const uint32_t fit = resident_waves(lds_wave);
   if (waves > fit) waves = fit;
@@ -51,21 +51,29 @@ void launch_one(const BeamArgs& a_in, hipStream_t s) {
   BeamArgs a = a_in;
   a.first_dynamic = blocks * kNarrowWaves * H;          // what the launch deals out; the queue hands out the rest
   (void)hipMemsetAsync(a.next_work, 0, sizeof(unsigned int), s);
-  hipLaunchKernelGGL((wgl_narrow_kernel<MW, L>), dim3(blocks), dim3(64 * kNarrowWaves), lds_wave * kNarrowWaves, s, a);
+  hipLaunchKernelGGL((wgl_narrow_kernel<MW, L, CF>), dim3(blocks), dim3(64 * kNarrowWaves), lds_wave * kNarrowWaves, s, a);
+}
+
+template <int MW, int L>
+void launch_one(const BeamArgs& a, hipStream_t s) {
+  if constexpr (MW == 1) {
+    if (a.front_words == kFrontCompactWords) { launch_cf<1, L, true>(a, s); return; }
+  }
+  launch_cf<MW, L, false>(a, s);
 }
 
 }  // namespace
 
 bool narrow_supported(uint32_t mask_words, uint32_t lanes) {
-  return (mask_words == 1 || mask_words == 2 || mask_words == 4) && (lanes == 8 || lanes == 16 || lanes == 32);
+  return (mask_words == 1 || mask_words == 2 || mask_words == 4) && (lanes == 4 || lanes == 8 || lanes == 16 || lanes == 32);
 }
 
 bool launch_narrow(const BeamArgs& a, uint32_t mask_words, uint32_t lanes, void* stream) {
   hipStream_t s = (hipStream_t)stream;
 #define NARROW_CASE(MWV, LV) if (mask_words == MWV && lanes == LV) { launch_one<MWV, LV>(a, s); return true; }
-  NARROW_CASE(1, 8) NARROW_CASE(1, 16) NARROW_CASE(1, 32)
-  NARROW_CASE(2, 8) NARROW_CASE(2, 16) NARROW_CASE(2, 32)
-  NARROW_CASE(4, 8) NARROW_CASE(4, 16) NARROW_CASE(4, 32)
+  NARROW_CASE(1, 4) NARROW_CASE(1, 8) NARROW_CASE(1, 16) NARROW_CASE(1, 32)
+  NARROW_CASE(2, 4) NARROW_CASE(2, 8) NARROW_CASE(2, 16) NARROW_CASE(2, 32)
+  NARROW_CASE(4, 4) NARROW_CASE(4, 8) NARROW_CASE(4, 16) NARROW_CASE(4, 32)
 #undef NARROW_CASE
   return false;
 }

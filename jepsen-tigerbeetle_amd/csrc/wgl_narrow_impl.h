@@ -44,11 +44,11 @@ enum : uint32_t {
   G_CLAIM = 20,     // 32 words: who takes the empty entry of a bucket (by bucket number mod 32) this round
   G_RING = 56
 };
-WV_HD constexpr uint32_t ring_size(uint32_t L) { return L < 16u ? 16u : L; }
-// ring entry: pos idx off nlive cnt (u32), k0 (u64), M[mw] (u64), the four window words of the config's front (u64)
-WV_HD constexpr uint32_t group_words(uint32_t mw, uint32_t L) { return G_RING + ring_size(L) * (5u + 2u + 2u * mw + 8u); }
+WV_HD constexpr uint32_t ring_size(uint32_t L) { return L <= 4u ? 8u : (L < 16u ? 16u : L); }      // (>= L: a round's pushes never clash)
+// ring entry: pos idx off nlive cnt (u32), k0 (u64), M[mw] (u64), the window word(s) of the config's front (u64: 4, or 1 compact)
+WV_HD constexpr uint32_t group_words(uint32_t mw, uint32_t L, bool cf = false) { return G_RING + ring_size(L) * (5u + 2u + 2u * mw + (cf ? 2u : 8u)); }
 // + the lookahead staging of a round (wave-wide): c_fi c_st c_lo (u32 x 64), c_M (u64 x 64 x mw)
-WV_HD constexpr uint32_t narrow_lds_words(uint32_t mw, uint32_t L) { return (64u / L) * group_words(mw, L) + 64u * 3u + 64u * 2u * mw; }
+WV_HD constexpr uint32_t narrow_lds_words(uint32_t mw, uint32_t L, bool cf = false) { return (64u / L) * group_words(mw, L, cf) + 64u * 3u + 64u * 2u * mw; }
 
 WV_DEV uint32_t key_hash32(uint64_t k0, const uint64_t* M, int mw) {      // as wgl_beam.hip (a table a wide run grew is the same table)
   uint32_t h = (uint32_t)k0 * 0x9E3779B1u ^ (uint32_t)(k0 >> 32) * 0x85EBCA77u;
@@ -187,11 +187,14 @@ WV_DEV bool grow_group(ColdArgs C, wv::gu64*& tab_u, wv::gu32*& stack_u, wv::gu3
 }
 
 // One wavefront: H = 64 / L histories, work items wave_idx * H .. + H - 1 of A.work.
-template <int MW, int L>
+// CF: the front records are the compact 64 B ones (tbc_internal.h; MW = 1)
+template <int MW, int L, bool CF = false>
 WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* lds, const uint32_t lane) {
+  static_assert(!CF || MW == 1, "compact front records have one mask word");
+  constexpr uint32_t WN = CF ? 1u : 4u;          // window words per config
   using wv::gu32;
   using wv::gu64;
-  constexpr uint32_t H = 64u / L, RS = ring_size(L), KW = MW + 1, GW = group_words(MW, L);
+  constexpr uint32_t H = 64u / L, RS = ring_size(L), KW = MW + 1, GW = group_words(MW, L, CF);
   static_assert(L == 4 || L == 8 || L == 16 || L == 32, "lanes per history");
   const uint32_t li = lane & (L - 1u), gbase = lane & ~(L - 1u), g = lane / L;
   const uint32_t below = (1u << li) - 1u;                       // the group's lower lanes, as group bits
@@ -238,25 +241,48 @@ WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* ld
     slot8_lo = slot8_off(op_off, hidx);
     flags = 0; sp = 0; dsp = 0; visited = 0;
     int32_t verdict0 = -2;
+    uint32_t f0 = 0;                                // the root's front
+    uint64_t M0[MW];
+    WV_UNROLL
+    for (int j = 0; j < MW; j++) M0[j] = 0;
     if (!has) verdict0 = TBC_UNKNOWN;               // (no history: nothing is written for this group)
     else if (status != 0) verdict0 = TBC_UNKNOWN;
     else if (R == 0) verdict0 = TBC_VALID;
     else {
-      const uint64_t k0 = 1ull | ((uint64_t)(uint32_t)A.init_state << 32);
-      uint64_t zero[MW];
-      WV_UNROLL
-      for (int j = 0; j < MW; j++) zero[j] = 0;
-      const uint32_t idx = (key_hash32(k0, zero, MW) & (uint32_t)((1ull << (cap_log2 - 2)) - 1ull)) * 4u;
-      if (li == 0) {                                // root config: first entry of its bucket, on the stack
-        gu64* e = tab + (uint64_t)idx * KW;
-        wv::own_st64(e, k0);
-        WV_UNROLL
-        for (int j = 0; j < MW; j++) wv::own_st64(e + 1 + j, 0ull);
-        wv::own_st64(tab + ((uint64_t)KW << cap_log2) + idx, (uint64_t)kNone | ((uint64_t)kNone << 32));
-        wv::own_st32(stack, idx);
+      if (rules & kRuleBranch) {
+        // branch lists: the root in normal form -- the front moves past every completion of a read the initial state allows,
+        // the reads of that kind still open at its front are linearized (every lane of the group walks the records alike)
+        const uint32_t vi0 = rdm_index(A.init_state, vpad);
+        for (bool going = true; going && f0 < R;) {
+          const uint64_t* fr = A.rdm + ((uint64_t)op_off + f0) * A.front_words + (CF ? 0u : vpad * MW);
+          const uint64_t wk[2] = {CF ? fr[7] : fr[4], CF ? 0ull : fr[5]};
+          uint32_t d = 0;
+          for (; d < (CF ? kFrontCompactRanks : 16u) && f0 < R; d++, f0++) {
+            const uint32_t rk = CF ? (uint32_t)(wk[0] >> (9u * d + 6u)) & 7u : (uint32_t)(wk[d >> 3] >> (8u * (d & 7u))) & 0xFFu;
+            if (!(rk == 0u || rk == vi0)) { going = false; break; }
+          }
+        }
+        if (f0 < R) {
+          const uint64_t* row = A.rdm + ((uint64_t)op_off + f0) * A.front_words;
+          WV_UNROLL
+          for (int j = 0; j < MW; j++) M0[j] = row[j] | row[vi0 * MW + j];
+        }
       }
-      sp = 1; visited = 1;
-      flags = F_ACTIVE | F_NEED_POP | (look_avail ? F_LOOK : 0u);
+      if (f0 == R) verdict0 = TBC_VALID;            // (only reads the initial state allows: nothing to search)
+      else {
+        const uint64_t k0 = (uint64_t)(f0 + 1u) | ((uint64_t)(uint32_t)A.init_state << 32);
+        const uint32_t idx = (key_hash32(k0, M0, MW) & (uint32_t)((1ull << (cap_log2 - 2)) - 1ull)) * 4u;
+        if (li == 0) {                              // root config: first entry of its bucket, on the stack
+          gu64* e = tab + (uint64_t)idx * KW;
+          wv::own_st64(e, k0);
+          WV_UNROLL
+          for (int j = 0; j < MW; j++) wv::own_st64(e + 1 + j, M0[j]);
+          wv::own_st64(tab + ((uint64_t)KW << cap_log2) + idx, (uint64_t)kNone | ((uint64_t)kNone << 32));
+          wv::own_st32(stack, idx);
+        }
+        sp = 1; visited = 1;
+        flags = F_ACTIVE | F_NEED_POP | (look_avail ? F_LOOK : 0u);
+      }
     }
     {
       const auto C = wv::cold(A);
@@ -267,7 +293,7 @@ WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* ld
         const uint64_t t0 = C->time_limit_ticks ? wv::clock100mhz() : 0ull;
         GS[G_DSTACK] = (uint32_t)ds; GS[G_DSTACK + 1] = (uint32_t)(ds >> 32);
         GS[G_PROBES] = 0; GS[G_PROBES + 1] = 0; GS[G_EXPANDED] = 0; GS[G_EXPANDED + 1] = 0; GS[G_ROUNDS] = 0; GS[G_ROUNDS + 1] = 0;
-        GS[G_VERDICT] = (uint32_t)verdict0; GS[G_CAUSE] = (uint32_t)TBC_CAUSE_NONE; GS[G_MAXF] = 0; GS[G_MAXSP] = sp;
+        GS[G_VERDICT] = (uint32_t)verdict0; GS[G_CAUSE] = (uint32_t)TBC_CAUSE_NONE; GS[G_MAXF] = f0 < R ? f0 : 0u; GS[G_MAXSP] = sp;
         GS[G_WINPAR] = kNone; GS[G_WINOP] = kNone; GS[G_WINSTATE] = (uint32_t)A.init_state;
         GS[G_T0] = (uint32_t)t0; GS[G_T0 + 1] = (uint32_t)(t0 >> 32);
       }
@@ -293,6 +319,9 @@ WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* ld
   uint64_t p_ws0 = 0, p_ws1 = 0, p_wk0 = ~0ull, p_wk1 = ~0ull;
   const uint32_t FW = A.front_words, FM = vpad * MW;          // u64 words per front record; where its list location starts
   const bool eager = (rules & kRuleEager) != 0u, twin = (rules & kRuleTwin) != 0u;
+  // parent links ({parent entry, op} per config, behind the keys) are what a witness is read from -- and nothing else is: a
+  // caller who wants no witness gets none written (an 8 B store to a line of its own per new config: 7 % of the launch)
+  const bool links = A.witness != nullptr;
   // Loads that are in flight across other work are issued UNCONDITIONALLY, from addresses clamped into the history's own
   // arenas, and what they bring is judged where it is used: a load under a divergent `if` with a default on the other path
   // makes the compiler merge the two right behind the load -- a full s_waitcnt there, the trip no longer overlaps anything.
@@ -323,8 +352,8 @@ WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* ld
     gu64* const par = tab + ((uint64_t)KW << cap_log2);
     uint32_t wlen = 0;
     if (C->witness != nullptr) {
-      const bool walk = sel && verdict == TBC_VALID && R != 0u;
       const uint32_t win_parent = GS[G_WINPAR], win_op = GS[G_WINOP];
+      const bool walk = sel && verdict == TBC_VALID && R != 0u && win_parent != kNone;      // (kNone: the root itself passed everything)
       uint32_t id = win_parent;
       bool more = walk;
       wlen = walk ? 1u : 0u;
@@ -372,7 +401,7 @@ WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* ld
               o[0] = k0;
               WV_UNROLL
               for (int j = 0; j < MW; j++) o[1 + j] = wv::ld64(e + 1 + j);
-              const uint64_t pw = wv::ld64(par_u + s0 + lane);
+              const uint64_t pw = links ? wv::ld64(par_u + s0 + lane) : (uint64_t)kNone;
               o[1 + MW] = (uint32_t)pw == kNone ? (uint64_t)TBC_NO_OP : (pw >> 32) - 1ull;
             }
           }
@@ -473,23 +502,26 @@ WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* ld
           WV_UNROLL
           for (int j = 0; j < MW; j++) Mp[j] = r_M[rs * MW + j];
           pslot = r_idx[rs]; poff = r_off[rs]; nlive = r_nlive[rs]; cnt = r_cnt[rs];
-          p_ws0 = r_W[rs * 4]; p_ws1 = r_W[rs * 4 + 1]; p_wk0 = r_W[rs * 4 + 2]; p_wk1 = r_W[rs * 4 + 3];
+          p_ws0 = r_W[rs * WN];
+          if constexpr (!CF) { p_ws1 = r_W[rs * 4 + 1]; p_wk0 = r_W[rs * 4 + 2]; p_wk1 = r_W[rs * 4 + 3]; }
         } else {
           const uint32_t idx = wv::own_ld32(stack + pos);
           const gu64* e = tab + (uint64_t)idx * KW;
           k0 = wv::own_ld64(e);
           WV_UNROLL
           for (int j = 0; j < MW; j++) Mp[j] = wv::own_ld64(e + 1 + j);
-          const uint64_t* fr = A.rdm + ((uint64_t)op_off + ((uint32_t)k0 - 1u)) * FW + FM;      // its front's record
+          const uint64_t* fr = A.rdm + ((uint64_t)op_off + ((uint32_t)k0 - 1u)) * FW + (CF ? 6u : FM);      // its front's record
           const uint64_t m0 = fr[0];
-          pslot = idx; poff = (uint32_t)m0; nlive = (uint32_t)(m0 >> 32); cnt = (uint32_t)fr[1];
-          p_ws0 = fr[2]; p_ws1 = fr[3]; p_wk0 = fr[4]; p_wk1 = fr[5];
+          pslot = idx; poff = (uint32_t)m0;
+          if constexpr (CF) { nlive = (uint32_t)(m0 >> 32) & 0xFFu; cnt = (uint32_t)(m0 >> 40); p_ws0 = fr[1]; }
+          else { nlive = (uint32_t)(m0 >> 32); cnt = (uint32_t)fr[1]; p_ws0 = fr[2]; p_ws1 = fr[3]; p_wk0 = fr[4]; p_wk1 = fr[5]; }
         }
         p_fi = (uint32_t)k0 - 1u; p_st = (int32_t)(uint32_t)(k0 >> 32);
         if (visited + cnt > full_at) {
           flags |= F_NEED_GROW;                  // room for every pair of this parent?  If not it stays on the stack
         } else {
-          sp = pos; base = 0u; flags &= ~F_NEED_POP;
+          sp = pos; base = 0u;
+          if (cnt != 0u) flags &= ~F_NEED_POP;       // (only the root can have no candidate at all: the others are not pushed)
           if (li == 0) wv::lds_add64(GS + G_EXPANDED, 1ull);
         }
       }
@@ -549,11 +581,18 @@ WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* ld
       mask_set<MW>(M2, p);
       const uint32_t vis = eager ? rdm_index(st2, vpad) : 0xFFFFu;
       for (;;) {
-        const uint32_t pp = byte_at(w0, w1, A.slot8, fi2);
+        uint32_t pp, rk;
+        if constexpr (CF) {
+          const uint32_t d = fi2 - wbase;
+          if (d < kFrontCompactRanks) { const uint32_t e = (uint32_t)(w0 >> (9u * d)) & 0x1FFu; pp = e & 63u; rk = e >> 6; }
+          else { pp = (uint32_t)A.slot8[slot8_lo + fi2]; rk = (uint32_t)A.rk8[slot8_lo + fi2]; }
+        } else {
+          pp = byte_at(w0, w1, A.slot8, fi2);
+          rk = eager ? byte_at(k0w, k1w, A.rk8, fi2) : 0xFFu;
+        }
         if (mask_bit<MW>(M2, pp)) mask_clear<MW>(M2, pp);
         else {
           if (!eager) break;
-          const uint32_t rk = byte_at(k0w, k1w, A.rk8, fi2);
           if (!(rk == 0u || rk == vis)) break;
         }
         fi2++;
@@ -577,85 +616,55 @@ WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* ld
     if (npr > room) limit_hit = true; else room -= npr;
 
     // ---- trip 1: the child's front's record -- the reads the eager rule takes there, where its open-call list is, and the
-    // windows its own children will advance over: one line
+    // windows its own children will advance over: one line -- and, in the same trip, the lookahead records of every viable
+    // child (8 lanes per child, one rank each, staged wave-wide: the fronts now, states and masks when the rows are in)
+    const bool lkme = go && (flags & F_LOOK);
+    const uint64_t lk = wv::ballot(lkme);
+    const uint32_t ci = (uint32_t)__builtin_popcountll(lk & ((1ull << lane) - 1ull)), nn0 = (uint32_t)__builtin_popcountll(lk);
+    if (lkme) { c_fi[ci] = fi2; c_lo[ci] = look_lo; }
+    wv::barrier();
     const uint32_t f3 = go ? fi2 : 0u;
     const uint64_t* const fr = A.rdm + ((uint64_t)op_off + f3) * FW;
     uint32_t co0, cnl, ccnt;
-    uint64_t cw[4];
+    uint64_t cw[WN];
+    uint64_t lw0[2], lpm[2][MW];
     {
       const uint32_t vi = (eager && go) ? rdm_index(st2, vpad) : 0u;
       uint64_t r0[MW], rv[MW];
-      const uint64_t m0 = fr[FM], m1 = fr[FM + 1];
       WV_UNROLL
-      for (int t = 0; t < 4; t++) cw[t] = fr[FM + 2 + t];
+      for (int bt = 0; bt < 2; bt++) {
+        const uint32_t cc = 8u * bt + (lane >> 3), jr = lane & 7u;
+        const bool val = cc < nn0;
+        const uint32_t lo_ = val ? c_lo[cc] : (look_avail ? look_lo : 0u), fr_ = val ? c_fi[cc] + jr : 0u;
+        const uint64_t* rec = lk_base + (uint64_t)lo_ + (uint64_t)fr_ * (MW + 1);
+        lw0[bt] = rec[0];
+        WV_UNROLL
+        for (int w = 0; w < MW; w++) lpm[bt][w] = rec[1 + w];
+      }
+      uint64_t m0, m1 = 0;
+      if constexpr (CF) { m0 = fr[6]; cw[0] = fr[7]; }
+      else {
+        m0 = fr[FM]; m1 = fr[FM + 1];
+        WV_UNROLL
+        for (int t = 0; t < 4; t++) cw[t] = fr[FM + 2 + t];
+      }
       WV_UNROLL
       for (int j = 0; j < MW; j++) { r0[j] = eager ? fr[j] : 0ull; rv[j] = eager ? fr[vi * MW + j] : 0ull; }
       WV_UNROLL
       for (int j = 0; j < MW; j++) M2[j] |= go ? (r0[j] | rv[j]) : 0ull;
-      co0 = (uint32_t)m0; cnl = (uint32_t)(m0 >> 32); ccnt = (uint32_t)m1;
+      co0 = (uint32_t)m0;
+      if constexpr (CF) { cnl = (uint32_t)(m0 >> 32) & 0xFFu; ccnt = (uint32_t)(m0 >> 40); }
+      else { cnl = (uint32_t)(m0 >> 32); ccnt = (uint32_t)m1; }
     }
-
-    // ---- trip 2, issue: the child's bucket of the visited set ...
-    const uint64_t k0c = (uint64_t)(fi2 + 1u) | ((uint64_t)(uint32_t)st2 << 32);
-    uint32_t b = key_hash32(k0c, M2, MW) & bmask, idx = 0, full_buckets = 0;
-    bool pending = go, fresh = false;
-    wv::u32x4 ke[4];                 // MW = 1: the bucket's four 16 B entries
-    uint64_t kk[4];                  // MW > 1: their first words
-    const auto load_bucket = [&]() {
-      const gu64* bp = tab + (uint64_t)b * (4 * KW);
-      if constexpr (MW == 1) {
-        WV_UNROLL
-        for (int t = 0; t < 4; t++) ke[t] = wv::own_ld128(bp + 2 * t);
-      } else {
-        WV_UNROLL
-        for (int t = 0; t < 4; t++) kk[t] = wv::own_ld64(bp + t * KW);
-      }
-    };
-    if (pending) load_bucket();
-    // ... the lookahead records of every viable child (8 lanes per child, one rank each, staged wave-wide) ...
+    // ---- the lookahead's verdicts, before the probe: a child it finds dead is set aside, so it is never the next parent --
+    // the candidates fetched below follow the highest child that is ALIVE
     bool dead = false;
-    const bool lkme = go && (flags & F_LOOK);
-    const uint64_t lk = wv::ballot(lkme);
-    const uint32_t ci = (uint32_t)__builtin_popcountll(lk & ((1ull << lane) - 1ull)), nn0 = (uint32_t)__builtin_popcountll(lk);
     if (lkme) {
-      c_fi[ci] = fi2; c_st[ci] = (uint32_t)st2; c_lo[ci] = look_lo;
+      c_st[ci] = (uint32_t)st2;
       WV_UNROLL
       for (int j = 0; j < MW; j++) c_M[ci * MW + j] = M2[j];
     }
-    // ... and the candidates of the round this group runs next, where that can be told now:
-    //   the parent has pairs left -> its next L pairs;  else some child is viable -> the highest one's (it is on top of
-    //   the stack if it is kept: new and not dead);  else nothing will be pushed -> the entry below on the stack
-    const bool more = inround && !gsucc && base + L < cnt;
-    const bool to_child = inround && !gsucc && !more && gv != 0u;
-    const bool to_below = inround && !gsucc && !more && gv == 0u && sp != 0u;
-    const uint32_t hv = gv ? 31u - (uint32_t)__builtin_clz(gv) : 0u;
-    if (to_child && li == hv) { GS[G_PF] = fi2; GS[G_PF + 1] = co0; GS[G_PF + 2] = cnl; GS[G_PF + 3] = ccnt; }
     wv::barrier();
-    bool cand_next = false;
-    {
-      // ONE candidate fetch per iteration, for everybody: the round a group runs next -- or, for a group that had none
-      // ready, the round it wanted to run now
-      uint32_t no = poff, nnl = nlive, nct = cnt, nb_ = fetch_now ? base : base + L;
-      bool ok_ = more || fetch_now;
-      if (to_child) { no = GS[G_PF + 1]; nnl = GS[G_PF + 2]; nct = GS[G_PF + 3]; nb_ = 0u; ok_ = true; }
-      if (to_below) {
-        const uint32_t pos = sp - 1u, rs = pos & (RS - 1u);
-        if (r_pos[rs] == pos) { no = r_off[rs]; nnl = r_nlive[rs]; nct = r_cnt[rs]; nb_ = 0u; ok_ = true; }
-      }
-      load_cand(ok_, no, nnl, nct, nb_);
-      cand_next = ok_;
-    }
-    uint64_t lw0[2], lpm[2][MW];
-    WV_UNROLL
-    for (int bt = 0; bt < 2; bt++) {
-      const uint32_t cc = 8u * bt + (lane >> 3), j = lane & 7u;
-      const bool val = cc < nn0;
-      const uint32_t lo_ = val ? c_lo[cc] : (look_avail ? look_lo : 0u), fr_ = val ? c_fi[cc] + j : 0u;
-      const uint64_t* rec = lk_base + (uint64_t)lo_ + (uint64_t)fr_ * (MW + 1);
-      lw0[bt] = rec[0];
-      WV_UNROLL
-      for (int w = 0; w < MW; w++) lpm[bt][w] = rec[1 + w];
-    }
     // one batch of 8 children: lane (child cb + lane / 8, rank lane % 8) decides its rank; returns the lanes that found
     // their child's call un-linearizable (wgl_beam.hip states the rule)
     const auto look_batch = [&](uint32_t cb, uint64_t w_0, const uint64_t (&pm)[MW]) -> uint64_t {
@@ -684,6 +693,68 @@ WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* ld
       const bool ok = need == kLookNone || linz || (int32_t)need == cs || dprod < j || pmhit || ((before >> need) & 1u);
       return wv::ballot(val && !ok);
     };
+    if (nn0) {
+      const uint64_t bad0 = look_batch(0u, lw0[0], lpm[0]);
+      if (lkme && ci < 8u) dead = ((bad0 >> (8u * ci)) & 0xFFull) != 0ull;
+      if (nn0 > 8u) {
+        const uint64_t bad1 = look_batch(8u, lw0[1], lpm[1]);
+        if (lkme && ci >= 8u && ci < 16u) dead = ((bad1 >> (8u * (ci - 8u))) & 0xFFull) != 0ull;
+      }
+      for (uint32_t cb = 16u; cb < nn0; cb += 8u) {          // more than 16 viable children in the wavefront: rare
+        const uint32_t cc = cb + (lane >> 3), jr = lane & 7u;
+        const bool val = cc < nn0;
+        const uint32_t lo_ = val ? c_lo[cc] : (look_avail ? look_lo : 0u), fr_ = val ? c_fi[cc] + jr : 0u;
+        const uint64_t* rec = lk_base + (uint64_t)lo_ + (uint64_t)fr_ * (MW + 1);
+        uint64_t xpm[MW];
+        const uint64_t xw0 = rec[0];
+        WV_UNROLL
+        for (int w = 0; w < MW; w++) xpm[w] = rec[1 + w];
+        const uint64_t badx = look_batch(cb, xw0, xpm);
+        if (lkme && ci >= cb && ci < cb + 8u) dead = ((badx >> (8u * (ci - cb))) & 0xFFull) != 0ull;
+      }
+    }
+
+    // ---- trip 2, issue: the child's bucket of the visited set ...
+    const uint64_t k0c = (uint64_t)(fi2 + 1u) | ((uint64_t)(uint32_t)st2 << 32);
+    uint32_t b = key_hash32(k0c, M2, MW) & bmask, idx = 0, full_buckets = 0;
+    bool pending = go, fresh = false;
+    wv::u32x4 ke[4];                 // MW = 1: the bucket's four 16 B entries
+    uint64_t kk[4];                  // MW > 1: their first words
+    const auto load_bucket = [&]() {
+      const gu64* bp = tab + (uint64_t)b * (4 * KW);
+      if constexpr (MW == 1) {
+        WV_UNROLL
+        for (int t = 0; t < 4; t++) ke[t] = wv::own_ld128(bp + 2 * t);
+      } else {
+        WV_UNROLL
+        for (int t = 0; t < 4; t++) kk[t] = wv::own_ld64(bp + t * KW);
+      }
+    };
+    if (pending) load_bucket();
+    // ... and the candidates of the round this group runs next, where that can be told now:
+    //   the parent has pairs left -> its next L pairs;  else some child is viable and alive -> the highest such one's (it is on
+    //   top of the stack unless it turns out a duplicate);  else nothing will be pushed -> the entry below on the stack
+    const uint32_t galive = grp(wv::ballot(go && !dead && ccnt != 0u));
+    const bool more = inround && !gsucc && base + L < cnt;
+    const bool to_child = inround && !gsucc && !more && galive != 0u;
+    const bool to_below = inround && !gsucc && !more && galive == 0u && sp != 0u;
+    const uint32_t hv = galive ? 31u - (uint32_t)__builtin_clz(galive) : 0u;
+    if (to_child && li == hv) { GS[G_PF] = fi2; GS[G_PF + 1] = co0; GS[G_PF + 2] = cnl; GS[G_PF + 3] = ccnt; }
+    wv::barrier();
+    bool cand_next = false;
+    {
+      // ONE candidate fetch per iteration, for everybody: the round a group runs next -- or, for a group that had none
+      // ready, the round it wanted to run now
+      uint32_t no = poff, nnl = nlive, nct = cnt, nb_ = fetch_now ? base : base + L;
+      bool ok_ = more || fetch_now;
+      if (to_child) { no = GS[G_PF + 1]; nnl = GS[G_PF + 2]; nct = GS[G_PF + 3]; nb_ = 0u; ok_ = true; }
+      if (to_below) {
+        const uint32_t pos = sp - 1u, rs = pos & (RS - 1u);
+        if (r_pos[rs] == pos) { no = r_off[rs]; nnl = r_nlive[rs]; nct = r_cnt[rs]; nb_ = 0u; ok_ = true; }
+      }
+      load_cand(ok_, no, nnl, nct, nb_);
+      cand_next = ok_;
+    }
 
     // ---- trip 2, consume.  Visited set: find the key in its bucket chain, else take the first empty entry met.  Lanes of
     // different groups never meet (one table per history); two lanes of a group can want the same empty entry (two keys of
@@ -752,35 +823,18 @@ WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* ld
     }
     const bool is_new = fresh;
     if (is_new) {
-      wv::own_st64(par + idx, (uint64_t)pslot | ((uint64_t)(op + 1u) << 32));
+      if (links) wv::own_st64(par + idx, (uint64_t)pslot | ((uint64_t)(op + 1u) << 32));
       wv::lds_max32(GS + G_MAXF, fi2);
     }
     const uint64_t nb0 = wv::ballot(is_new);
-    // the lookahead's verdicts (a duplicate's is not used)
-    if (nn0) {
-      const uint64_t bad0 = look_batch(0u, lw0[0], lpm[0]);
-      if (lkme && ci < 8u) dead = ((bad0 >> (8u * ci)) & 0xFFull) != 0ull;
-      if (nn0 > 8u) {
-        const uint64_t bad1 = look_batch(8u, lw0[1], lpm[1]);
-        if (lkme && ci >= 8u && ci < 16u) dead = ((bad1 >> (8u * (ci - 8u))) & 0xFFull) != 0ull;
-      }
-      for (uint32_t cb = 16u; cb < nn0; cb += 8u) {          // more than 16 viable children in the wavefront: rare
-        const uint32_t cc = cb + (lane >> 3), j = lane & 7u;
-        uint64_t xw0 = (uint64_t)(kLookNone << 16 | kLookNone << 24), xpm[MW];
-        WV_UNROLL
-        for (int w = 0; w < MW; w++) xpm[w] = 0ull;
-        if (cc < nn0) {
-          const uint64_t* rec = A.look + (uint64_t)c_lo[cc] + (uint64_t)(c_fi[cc] + j) * (MW + 1);
-          xw0 = rec[0];
-          WV_UNROLL
-          for (int w = 0; w < MW; w++) xpm[w] = rec[1 + w];
-        }
-        const uint64_t badx = look_batch(cb, xw0, xpm);
-        if (lkme && ci >= cb && ci < cb + 8u) dead = ((badx >> (8u * (ci - cb))) & 0xFFull) != 0ull;
-      }
-    }
-    // ---- push the new configs in pair order: the dead ones aside, the others onto the stack (and into the ring)
-    const bool keep = is_new && !dead;
+    // ---- push the new configs in pair order: the dead ones aside, the others onto the stack (and into the ring).  A new
+    // config whose front has no candidate (branch lists: only reads its state does not allow are open) has no successor:
+    // it counts as expanded on the spot and goes nowhere.
+    const bool barren = is_new && ccnt == 0u;
+    const uint32_t gbar = grp(wv::ballot(barren));
+    if (li == 0 && gbar) wv::lds_add64(GS + G_EXPANDED, (uint64_t)__builtin_popcount(gbar));
+    dead = dead && !barren;
+    const bool keep = is_new && !dead && !barren;
     const uint32_t gdb = grp(wv::ballot(is_new && dead));
     if (is_new && dead) {
       gu32* const ds = (gu32*)((uint64_t)GS[G_DSTACK] | ((uint64_t)GS[G_DSTACK + 1] << 32));
@@ -797,7 +851,7 @@ WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* ld
       for (int j = 0; j < MW; j++) r_M[rs * MW + j] = M2[j];
       r_off[rs] = co0; r_nlive[rs] = cnl; r_cnt[rs] = ccnt;
       WV_UNROLL
-      for (int t = 0; t < 4; t++) r_W[rs * 4 + t] = cw[t];
+      for (uint32_t t = 0; t < WN; t++) r_W[rs * WN + t] = cw[t];
     }
     sp += (uint32_t)__builtin_popcount(gnb);
     visited += (uint32_t)__builtin_popcount(grp(nb0));
@@ -805,9 +859,13 @@ WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* ld
     {
       // were the candidates fetched above the next round's?  (the highest viable child is the next parent iff it was kept;
       // a group that sat out fetched the round it wanted; anybody else has none)
-      const bool right = inround ? (cand_next && (more || to_below || ((gnb >> hv) & 1u))) : fetch_now;
+      // (to_below: every viable child was dead or barren -- none is pushed onto the stack -- unless a dead one... dead ones go aside)
+      const bool right = inround ? (cand_next && (more || (to_below && gnb == 0u) || (to_child && ((gnb >> hv) & 1u)))) : fetch_now;
       flags = right ? (flags | F_CAND) : (flags & ~F_CAND);
-      if (inround && li == 0) wv::stat(right ? 23 : 24, 1);
+      if (inround && li == 0) {
+        wv::stat(right ? 23 : 24, 1);
+        if (!right) wv::stat(to_child ? 25 : (to_below ? 26 : (gsucc ? 28 : 27)), 1);
+      }
     }
     if (inround) {
       base += L;

@@ -160,7 +160,7 @@ def rules_apply(ops, model, round_pairs=64):
 
 
 def check_beam(ops, model, width=16, max_probes=0, want_witness=True, round_pairs=64, widen_after=0, lookahead=None, eager_reads=None, twin_rule=None,
-               twin_selfcheck=False, rules_at_any_round_size=False):
+               twin_selfcheck=False, rules_at_any_round_size=False, branch_lists=False):
     """The wide (K configs per iteration) schedule of the same search: wgl_beam.c.
 
     lookahead: None = what the library does by default (on for register / cas-register under the
@@ -187,6 +187,9 @@ def check_beam(ops, model, width=16, max_probes=0, want_witness=True, round_pair
     lib().wgl_beam_set_twin_rule(C.c_uint32(1 if twin_rule else 0))
     # twin_selfcheck: evaluate every twin test of a crashed candidate also by the previous-crashed-twin shortcut
     # (wgl_beam.c) and report how many were compared / disagreed as twin_checked / twin_mismatch
+    # branch_lists: candidate lists hold the live :write / :cas calls only and the root starts in normal form (the narrow
+    # kernel's lists under the eager rule); without eager reads the switch does nothing
+    lib().wgl_beam_set_branch_lists(C.c_uint32(1 if (branch_lists and eager_reads) else 0))
     lib().wgl_beam_set_twin_selfcheck(C.c_uint32(1 if twin_selfcheck else 0))
     try:
         r = _check_beam(ops, model, width, max_probes, want_witness, round_pairs, widen_after, bool(lookahead))
@@ -199,6 +202,7 @@ def check_beam(ops, model, width=16, max_probes=0, want_witness=True, round_pair
         lib().wgl_beam_set_eager_reads(C.c_uint32(0))
         lib().wgl_beam_set_twin_rule(C.c_uint32(0))
         lib().wgl_beam_set_twin_selfcheck(C.c_uint32(0))
+        lib().wgl_beam_set_branch_lists(C.c_uint32(0))
 
 
 def _check_beam(ops, model, width, max_probes, want_witness, round_pairs, widen_after, lookahead):

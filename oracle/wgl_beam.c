@@ -182,6 +182,13 @@ static uint32_t g_eager_reads = 0; static _Thread_local uint64_t g_absorbed = 0;
 /* twin writes (experiment, register family): of several open, not yet linearized calls with the same effect
  * (:write v, or :cas [a b] with equal a and b) the one completing first goes first, without loss of generality */
 static uint32_t g_twin_rule = 0;
+/* branch lists without reads (the narrow kernel's lists under the eager rule, wgl_narrow.hip): every config of the search is
+ * in normal form -- every open read its state allows is linearized -- so a read is never a viable candidate; the per-front
+ * candidate lists then hold the live :write / :cas calls only (reads are still found by the eager rule itself), a round's
+ * pairs are numbered over those, and the ROOT is put into normal form before it is inserted (it is the one config the
+ * plain schedule leaves un-normalised).  Needs eager reads; changes pair numbers, hence rounds and counters, not answers. */
+static uint32_t g_branch_lists = 0;
+void wgl_beam_set_branch_lists(uint32_t on) { g_branch_lists = on; }
 void wgl_beam_set_twin_rule(uint32_t on) { g_twin_rule = on; }
 void wgl_beam_set_eager_reads(uint32_t on) { g_eager_reads = on; }
 uint64_t wgl_beam_absorbed(void) { return g_absorbed; }
@@ -289,6 +296,21 @@ int wgl_beam_check_rp(uint32_t n, const uint8_t* f, const int32_t* a, const int3
         lst[y] = v;
       } }
 
+  /* candidate lists: the full lists, or (branch lists) the live calls that are not reads */
+  const int regfam = !cfgm && (model->kind == O_REGISTER || model->kind == O_CAS_REGISTER);
+  const int branch = g_branch_lists && g_eager_reads && regfam;
+  uint32_t* coff = off; uint32_t* clst = lst;
+  if (branch) {
+    coff = (uint32_t*)calloc((size_t)R + 1, 4);
+    clst = (uint32_t*)malloc(4 * ((size_t)off[R] + 1));
+    uint32_t run = 0;
+    for (uint32_t fr = 0; fr < R; fr++) {
+      coff[fr] = run;
+      for (uint32_t x = off[fr]; x < off[fr + 1]; x++) if (f[lst[x]] != O_READ) clst[run++] = lst[x];
+    }
+    coff[R] = run;
+  }
+
   /* previous crashed call of the same effect (index into crashed[], 0xFFFFFFFF = none): the self-check above */
   uint32_t* prev_twin = NULL;
   if (g_twin_selfcheck) {
@@ -314,11 +336,18 @@ int wgl_beam_check_rp(uint32_t n, const uint8_t* f, const int32_t* a, const int3
   int look_on = g_lookahead && !cfgm && (model->kind == O_REGISTER || model->kind == O_CAS_REGISTER);
   uint64_t* key = (uint64_t*)calloc(KW, 8);
   key[0] = 1ull | ((uint64_t)(uint32_t)(cfgm ? 0 : model->init) << 32);
-  stack[sp++] = arena_add(&ar, key, 0, 0xFFFFFFFFu);
-  st->visited = 1; st->max_stack = 1;
   uint32_t maxf = 0;
   int verdict = -2;
   uint32_t win_parent = 0, win_op = 0; int32_t win_state = 0;
+  int root_wins = 0;
+  if (branch) {          /* the root in normal form (it may pass every completion: then there is nothing to search) */
+    const uint32_t f0 = absorb_reads(key, 0, model->init, R, off, lst, process, ret_op, f, a, NULL, NULL);
+    key[0] = (uint64_t)(f0 + 1) | ((uint64_t)(uint32_t)model->init << 32);
+    maxf = f0 < R ? f0 : R - 1;
+    if (f0 == R) { root_wins = 1; verdict = 1; win_state = model->init; }
+  }
+  stack[sp++] = arena_add(&ar, key, 0, 0xFFFFFFFFu);
+  st->visited = 1; st->max_stack = 1;
 
   uint32_t par[64], pcnt[64], pstart[65];
   /* per-round scratch */
@@ -363,7 +392,7 @@ int wgl_beam_check_rp(uint32_t n, const uint8_t* f, const int32_t* a, const int3
     uint32_t T = 0;
     for (uint32_t q = 0; q < np; q++) {
       uint32_t fi = (uint32_t)ar.keys[(size_t)par[q] * KW] - 1;
-      pcnt[q] = (off[fi + 1] - off[fi]) + ncr[fi];
+      pcnt[q] = (coff[fi + 1] - coff[fi]) + ncr[fi];
       pstart[q] = T; T += pcnt[q];
     }
     pstart[np] = T;
@@ -375,16 +404,16 @@ int wgl_beam_check_rp(uint32_t n, const uint8_t* f, const int32_t* a, const int3
         while (pstart[q + 1] <= r) q++;
         const uint64_t* pk = ar.keys + (size_t)par[q] * KW;
         uint32_t fi = (uint32_t)pk[0] - 1; int32_t s = (int32_t)(pk[0] >> 32);
-        uint32_t nlive = off[fi + 1] - off[fi];
+        uint32_t nlive = coff[fi + 1] - coff[fi];
         uint32_t c = pcnt[q] - 1 - (r - pstart[q]);
-        uint32_t op = c < nlive ? lst[off[fi] + c] : crashed[c - nlive];
+        uint32_t op = c < nlive ? clst[coff[fi] + c] : crashed[c - nlive];
         uint32_t p = (uint32_t)process[op];
         cviable[l] = 0; cop[l] = op; cpar[l] = par[q];
         if (pk[1 + (p >> 6)] >> (p & 63) & 1) continue;
         if (g_twin_rule && !cfgm && (f[op] == O_WRITE || f[op] == O_CAS)) {
           int dominated = 0;
           for (uint32_t cc = 0; cc < pcnt[q] && !dominated; cc++) {
-            uint32_t y = cc < nlive ? lst[off[fi] + cc] : crashed[cc - nlive];
+            uint32_t y = cc < nlive ? clst[coff[fi] + cc] : crashed[cc - nlive];
             uint32_t py = (uint32_t)process[y];
             if (y == op || f[y] != f[op] || a[y] != a[op] || (f[op] == O_CAS && b[y] != b[op])) continue;
             if (pk[1 + (py >> 6)] >> (py & 63) & 1) continue;
@@ -393,7 +422,7 @@ int wgl_beam_check_rp(uint32_t n, const uint8_t* f, const int32_t* a, const int3
           if (g_twin_selfcheck && c >= nlive) {
             int fast = 0;
             for (uint32_t cc = 0; cc < nlive && !fast; cc++) {          /* live calls of the same effect: all complete earlier */
-              uint32_t y = lst[off[fi] + cc];
+              uint32_t y = clst[coff[fi] + cc];
               uint32_t py = (uint32_t)process[y];
               if (f[y] != f[op] || a[y] != a[op] || (f[op] == O_CAS && b[y] != b[op])) continue;
               if (!(pk[1 + (py >> 6)] >> (py & 63) & 1)) fast = 1;
@@ -412,7 +441,7 @@ int wgl_beam_check_rp(uint32_t n, const uint8_t* f, const int32_t* a, const int3
         if (cfgm) {
           uint32_t no = 0;
           for (uint32_t cc = 0; cc < pcnt[q]; cc++) {
-            uint32_t x = cc < nlive ? lst[off[fi] + cc] : crashed[cc - nlive];
+            uint32_t x = cc < nlive ? clst[coff[fi] + cc] : crashed[cc - nlive];
             uint32_t px = (uint32_t)process[x];
             open_ops[no] = x; open_lin[no] = (uint8_t)(pk[1 + (px >> 6)] >> (px & 63) & 1); no++;
           }
@@ -450,6 +479,9 @@ int wgl_beam_check_rp(uint32_t n, const uint8_t* f, const int32_t* a, const int3
         if (!id) continue;
         st->visited++;
         if (cfront[l] > maxf) maxf = cfront[l];
+        /* branch lists: a config whose front has no candidate at all (only reads its state does not allow are open) has
+         * no successor -- it counts as expanded on the spot and is neither pushed nor set aside */
+        if (branch && (coff[cfront[l] + 1] - coff[cfront[l]]) + ncr[cfront[l]] == 0) { st->expanded++; continue; }
         if (look_on) {
           /* lookahead: the new config is dead if the call completing at one of the next 8 ranks can never
            * be linearized from it -- it is not linearized yet and needs a register value (0..31) that is
@@ -469,9 +501,9 @@ int wgl_beam_check_rp(uint32_t n, const uint8_t* f, const int32_t* a, const int3
             if (v == s2) continue;
             int ok = 0;
             for (uint32_t F2 = F; F2 <= t && !ok; F2++) {                /* calls open somewhere in [F, t] */
-              const uint32_t nl = off[F2 + 1] - off[F2], tot = nl + (F2 == t ? ncr[F2] : 0);
+              const uint32_t nl = coff[F2 + 1] - coff[F2], tot = nl + (F2 == t ? ncr[F2] : 0);
               for (uint32_t cc = 0; cc < tot && !ok; cc++) {
-                const uint32_t x = cc < nl ? lst[off[F2] + cc] : crashed[cc - nl];
+                const uint32_t x = cc < nl ? clst[coff[F2] + cc] : crashed[cc - nl];
                 const uint32_t px = (uint32_t)process[x];
                 if (x == fop) continue;
                 if (inv_rank[x] <= F && (c2[1 + (px >> 6)] >> (px & 63) & 1)) continue;   /* open at F, linearized */
@@ -499,19 +531,20 @@ int wgl_beam_check_rp(uint32_t n, const uint8_t* f, const int32_t* a, const int3
   out->steps = st->probes; out->probes = st->probes; out->visited = st->visited;
   out->backtracks = st->expanded; out->max_depth = st->max_stack;
   if (verdict == 1) {
-    /* witness: path root -> win_parent, then win_op */
-    uint32_t len = 1, id = win_parent;
-    while (ar.parent[id]) { len++; id = ar.parent[id]; }
+    /* witness: path root -> win_parent, then win_op (nothing at all when the normalised root passed every completion) */
+    uint32_t len = root_wins ? 0 : 1, id = win_parent;
+    while (!root_wins && ar.parent[id]) { len++; id = ar.parent[id]; }
     out->n_witness = len; out->final_state = win_state;
     if (witness) {
-      uint32_t w = len - 1; witness[w] = win_op; id = win_parent;
-      while (ar.parent[id]) { witness[--w] = ar.op[id]; id = ar.parent[id]; }
+      uint32_t w = len ? len - 1 : 0; id = win_parent;
+      if (!root_wins) { witness[w] = win_op; while (ar.parent[id]) { witness[--w] = ar.op[id]; id = ar.parent[id]; } }
       if (g_eager_reads && !cfgm && (model->kind == O_REGISTER || model->kind == O_CAS_REGISTER)) {
         /* the chain holds the branching ops only: replay it from the root, absorbing reads as the search did */
         uint32_t* chain = (uint32_t*)malloc(4 * (size_t)len);
         memcpy(chain, witness, 4 * (size_t)len);
         uint64_t* c2 = (uint64_t*)calloc(KW, 8);
         uint32_t fr = 0, nw = 0; int32_t s = model->init;
+        if (branch) fr = absorb_reads(c2, 0, s, R, off, lst, process, ret_op, f, a, witness, &nw);      /* the root's own reads first */
         for (uint32_t i = 0; i < len; i++) {
           const uint32_t op = chain[i], p = (uint32_t)process[op];
           int32_t s2 = s; (void)oracle_step(model, s, f[op], a[op], b[op], &s2); s = s2;
@@ -543,6 +576,7 @@ int wgl_beam_check_rp(uint32_t n, const uint8_t* f, const int32_t* a, const int3
     g_bsort_kw = KW;
     qsort(g_bcfg, g_bcfg_n, KW * 8, cmp_bcfg);
   }
+  if (branch) { free(coff); free(clst); }
   free(rets); free(ret_rank); free(inv_rank); free(ret_op); free(off); free(ncr); free(lst); free(fill); free(crashed); free(prev_twin);
   free(open_ops); free(open_lin);
   free(ar.keys); free(ar.parent); free(ar.op); free(ar.slots); free(stack); free(dstack); free(key); free(ck);

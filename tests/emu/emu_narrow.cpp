@@ -29,14 +29,14 @@ struct Tables {
 // the per-front tables of every history of the batch, from the definitions
 bool build_tables(uint32_t nh, const uint64_t* op_off, const uint32_t* n_process, const uint8_t* f, const int32_t* a, const int32_t* b,
                   const int32_t* process, const uint32_t* inv_pos, const uint32_t* ret_pos, uint32_t MW, uint32_t vpad_in,
-                  uint32_t tab_log2_per_op, Tables& T) {
+                  uint32_t tab_log2_per_op, bool branch, bool compact, Tables& T) {
   const uint32_t vpad = vpad_in ? vpad_in : 1;
   const uint64_t total = op_off[nh];
   T.hist.assign(nh, Hist{}); T.bh.assign(nh, BeamHist{});
   T.ret_op.assign(total + 1, 0); T.ret_slot.assign(total + 1, 0);
   T.crashed.assign(total + 1, OpRec{0, kFNone, 0, 0});
   T.slot8.assign(slot8_bytes(total, nh), 0); T.rk8.assign(slot8_bytes(total, nh), 0xFF);
-  const uint32_t FS = front_stride(vpad_in, MW), FM = vpad_in * MW;      // front records (tbc_internal.h)
+  const uint32_t FS = compact ? kFrontCompactWords : front_stride(vpad_in, MW), FM = vpad_in * MW;      // front records (tbc_internal.h)
   T.rdm.assign(total * FS + 1, 0);
   T.look.assign(look_words(total, nh, MW), 0);
   uint64_t off_n = 0, lst_n = 0, tab_n = 0;
@@ -67,7 +67,10 @@ bool build_tables(uint32_t nh, const uint64_t* op_off, const uint32_t* n_process
     for (uint32_t r = 1; r < R; r++) ncr[r] += ncr[r - 1];
     B.n_crashed = ncrash;
     std::vector<std::vector<uint32_t>> open(R);
-    for (uint32_t i = 0; i < n; i++) if (ret_rank[i] != kInf) for (uint32_t F = inv_rank[i]; F <= ret_rank[i]; F++) open[F].push_back(i);
+    std::vector<std::vector<uint32_t>> open_reads(R);        // (branch lists: live reads are not candidates, the eager rule finds them through rdm)
+    for (uint32_t i = 0; i < n; i++) if (ret_rank[i] != kInf) for (uint32_t F = inv_rank[i]; F <= ret_rank[i]; F++) {
+      if (branch && f[o + i] == TBC_F_READ) open_reads[F].push_back(i); else open[F].push_back(i);
+    }
     uint32_t run = 0;
     for (uint32_t F = 0; F < R; F++) {
       off[F] = run;
@@ -93,6 +96,10 @@ bool build_tables(uint32_t nh, const uint64_t* op_off, const uint32_t* n_process
           if (vpad_in && (vi != 0u || a[o + x] == TBC_NIL)) T.rdm[(o + F) * FS + vi * MW + (px >> 6)] |= 1ull << (px & 63);
         }
       }
+      for (uint32_t x : open_reads[F]) {
+        const uint32_t px = (uint32_t)process[o + x], vi = rdm_index(a[o + x], vpad);
+        if (vpad_in && (vi != 0u || a[o + x] == TBC_NIL)) T.rdm[(o + F) * FS + vi * MW + (px >> 6)] |= 1ull << (px & 63);
+      }
     }
     // completion slots as bytes
     uint8_t* s8 = T.slot8.data() + slot8_off(o, h);
@@ -100,7 +107,18 @@ bool build_tables(uint32_t nh, const uint64_t* op_off, const uint32_t* n_process
     uint8_t* k8 = T.rk8.data() + slot8_off(o, h);
     for (uint32_t r = 0; r < R; r++) { const uint32_t x = rets[r].second; k8[r] = f[o + x] == TBC_F_READ ? (uint8_t)rdm_index(a[o + x], vpad_in) : (uint8_t)0xFF; }
     // the rest of each front record: list location, windows of the next 16 ranks
-    for (uint32_t F = 0; F < R; F++) {
+    for (uint32_t F = 0; F < R && compact; F++) {          // the compact form: word 6 = where the list is, word 7 = seven ranks of slot | kind << 6
+      uint64_t* rec = T.rdm.data() + (o + F) * FS;
+      const uint32_t nl = off[F + 1] - off[F];
+      rec[6] = (uint64_t)off[F] | ((uint64_t)(nl & 0xFFu) << 32) | ((uint64_t)((nl + ncr[F]) & 0xFFFFFFu) << 40);
+      uint64_t win = 0;
+      for (uint32_t l = 0; l < kFrontCompactRanks; l++) {
+        const uint32_t k = F + l < R ? k8[F + l] : 0xFFu;
+        win |= (uint64_t)((s8[F + l] & 63u) | ((k == 0xFFu ? 7u : (k & 7u)) << 6)) << (9u * l);
+      }
+      rec[7] = win;
+    }
+    for (uint32_t F = 0; F < R && !compact; F++) {
       uint64_t* rec = T.rdm.data() + (o + F) * FS + FM;
       rec[0] = (uint64_t)off[F] | ((uint64_t)(off[F + 1] - off[F]) << 32);
       rec[1] = (uint64_t)((off[F + 1] - off[F]) + ncr[F]);
@@ -141,10 +159,10 @@ bool build_tables(uint32_t nh, const uint64_t* op_off, const uint32_t* n_process
 
 template <int MW, int L>
 struct WaveCall { const BeamArgs* A; uint32_t wave; uint32_t* lds; };
-template <int MW, int L>
+template <int MW, int L, bool CF>
 void wave_entry(void* p, uint32_t lane) {
   auto* c = (WaveCall<MW, L>*)p;
-  narrow::narrow_wave<MW, L>(*c->A, c->wave, c->lds, lane);
+  narrow::narrow_wave<MW, L, CF>(*c->A, c->wave, c->lds, lane);
 }
 template <int MW, int L>
 void run_all(BeamArgs& A, uint32_t max_waves) {
@@ -154,11 +172,13 @@ void run_all(BeamArgs& A, uint32_t max_waves) {
   static unsigned int next_work;
   next_work = 0;
   A.first_dynamic = waves * H; A.next_work = &next_work;
-  std::vector<uint32_t> lds(narrow::narrow_lds_words(MW, L) + 16);
+  const bool cf = MW == 1 && A.front_words == kFrontCompactWords;
+  std::vector<uint32_t> lds(narrow::narrow_lds_words(MW, L, cf) + 16);
   for (uint32_t w = 0; w < waves; w++) {
     std::fill(lds.begin(), lds.end(), 0xDEADBEEFu);          // LDS is not zeroed on the device either
     WaveCall<MW, L> c{&A, w, lds.data()};
-    wv::run_wave(&wave_entry<MW, L>, &c);
+    if constexpr (MW == 1) { if (cf) { wv::run_wave(&wave_entry<MW, L, true>, &c); continue; } }
+    wv::run_wave(&wave_entry<MW, L, false>, &c);
   }
 }
 
@@ -172,9 +192,13 @@ void emu_stats(uint64_t* out, int reset) { for (int i = 0; i < 64; i++) { out[i]
 int emu_narrow_run(uint32_t nh, const uint64_t* op_off, const uint32_t* n_process, const uint8_t* f, const int32_t* a, const int32_t* b,
                    const int32_t* process, const uint32_t* inv_pos, const uint32_t* ret_pos, uint32_t model_kind, int32_t init,
                    uint32_t L, uint32_t MW, uint32_t rules, uint32_t vpad, uint32_t lookahead, uint32_t entries_per_op, uint64_t max_steps,
-                   uint64_t pool_words, uint32_t want_witness, uint32_t max_waves, DevResult* results, uint32_t* witness, uint64_t* cfg_out) {
+                   uint64_t pool_words, uint32_t want_witness, uint32_t max_waves, uint32_t want_compact, DevResult* results, uint32_t* witness, uint64_t* cfg_out) {
   Tables T;
-  if (!build_tables(nh, op_off, n_process, f, a, b, process, inv_pos, ret_pos, MW, vpad, entries_per_op, T)) return 1;
+  // the compact front records where libtbcheck would take them (tbc_api.hip front_words()): eager rule, one mask word, values <= 4
+  uint32_t n_dom = 0;
+  if (vpad) { int32_t vmax = init == TBC_NIL ? -1 : init; for (uint64_t i = 0; i < op_off[nh]; i++) { if (a[i] != TBC_NIL && a[i] > vmax) vmax = a[i]; if (f[i] == TBC_F_CAS && b[i] > vmax) vmax = b[i]; } n_dom = (uint32_t)(vmax + 2); }
+  const bool compact = want_compact && (rules & kRuleEager) && front_compact_ok(n_dom, MW);
+  if (!build_tables(nh, op_off, n_process, f, a, b, process, inv_pos, ret_pos, MW, vpad, entries_per_op, (rules & kRuleBranch) != 0, compact, T)) return 1;
   const uint64_t total = op_off[nh];
   uint64_t entries = 0;
   for (uint32_t h = 0; h < nh; h++) entries += 1ull << T.bh[h].tab_log2;
@@ -193,7 +217,7 @@ int emu_narrow_run(uint32_t nh, const uint64_t* op_off, const uint32_t* n_proces
   A.init_state = init; A.width = 1; A.max_steps = max_steps; A.time_limit_ticks = 0; A.dbg = nullptr;
   A.pool = pool_words ? pool.data() : nullptr; A.pool_cursor = &cursor; A.pool_words = pool_words; A.max_tab_log2 = 28;
   A.pool_vals = nullptr; A.cfg = cfg.data(); A.rules = rules; A.twn = (rules & kRuleTwin) ? T.twn.data() : nullptr;
-  A.rdm = T.rdm.data(); A.vpad = vpad; A.rk8 = T.rk8.data(); A.front_words = front_stride(vpad, MW);
+  A.rdm = T.rdm.data(); A.vpad = vpad; A.rk8 = T.rk8.data(); A.front_words = compact ? kFrontCompactWords : front_stride(vpad, MW);
 #define RUN(MWV, LV) if (MW == MWV && L == LV) { run_all<MWV, LV>(A, max_waves); ran = true; }
   bool ran = false;
   RUN(1, 4) RUN(1, 8) RUN(1, 16) RUN(1, 32) RUN(2, 8) RUN(2, 16) RUN(4, 8) RUN(4, 16)

@@ -16,9 +16,10 @@ from oracle import wgl
 CAS = {"kind": 1, "init": N.NIL}
 
 
-def expand_chain(d, chain, model, eager):
+def expand_chain(d, chain, model, eager, branch=False):
     """The chain of branching calls replayed from the initial state, absorbing reads as the search does (a third
-    formulation, besides oracle/wgl_beam.c's and tbc_api.hip's expand_eager_witness)."""
+    formulation, besides oracle/wgl_beam.c's and tbc_api.hip's expand_eager_witness).  branch: the root starts in normal
+    form (its own reads come first)."""
     if not eager:
         return [int(x) for x in chain]
     f, a, b, proc = (np.asarray(d[k]) for k in ("f", "a", "b", "process"))
@@ -44,11 +45,12 @@ def expand_chain(d, chain, model, eager):
             moved = True
         return moved
 
-    for op in chain:
-        op = int(op)
-        state = int(a[op]) if f[op] == 1 else (int(b[op]) if f[op] == 2 else state)
-        done.add(op); out.append(op)
-        advance()
+    for op in ([None] if branch else []) + list(chain):
+        if op is not None:
+            op = int(op)
+            state = int(a[op]) if f[op] == 1 else (int(b[op]) if f[op] == 2 else state)
+            done.add(op); out.append(op)
+            advance()
         again = True
         while again and front < R:
             opens = sorted((i for i in live if i not in done and inv_rank[i] <= front <= ret_rank[i]), key=lambda i: proc[i])
@@ -64,7 +66,8 @@ def compare(hists, model, L, kind=1, tag="", **kw):
     got = emu.run(ds, kind, model["init"], L, **kw)
     for i, (d, g) in enumerate(zip(ds, got)):
         e = wgl.check_beam(d, model, 1, round_pairs=L, rules_at_any_round_size=True, lookahead=kw.get("lookahead", True),
-                           eager_reads=bool(g["rules"] & 1), twin_rule=bool(g["rules"] & 2), max_probes=kw.get("max_steps", 0))
+                           eager_reads=bool(g["rules"] & 1), twin_rule=bool(g["rules"] & 2), max_probes=kw.get("max_steps", 0),
+                           branch_lists=bool(g["rules"] & 4))
         t = (tag, i, L)
         assert g["valid"] == e["valid"], (t, g["valid"], e["valid"], g["cause"])
         for a_, b_ in (("probes", "probes"), ("visited", "visited"), ("backtracks", "expanded"), ("max_depth", "max_stack"), ("bucket_reads", "rounds")):
@@ -73,7 +76,8 @@ def compare(hists, model, L, kind=1, tag="", **kw):
             assert (g["fail_op"], g["prev_ok_op"]) == (e["fail_op"], e["prev_ok_op"]), t
         if e["valid"] == 1 and len(d["f"]):
             assert g["final_state"] == e["final_state"], t
-            assert expand_chain(d, g["chain"], model, bool(g["rules"] & 1)) == [int(x) for x in e["witness"]], t
+            if g["chain"] is not None:
+                    assert expand_chain(d, g["chain"], model, bool(g["rules"] & 1), bool(g["rules"] & 4)) == [int(x) for x in e["witness"]], t
     return got
 
 
@@ -94,6 +98,30 @@ def test_other_group_sizes(L):
     hists = [columns.pair_events(synth.register_events(n_ops=n, n_procs=p, seed=s, busy=busy, info=info, corrupt=corrupt))
              for (n, p, info, corrupt, busy) in SHAPES[:7] for s in range(2)]
     compare(hists, CAS, L, tag="sizes", pool_words=4_000_000)
+
+
+def test_without_a_witness_no_parent_links_are_kept():
+    """want_witness = 0: verdict, failing op and counters as ever; the kernel writes no parent links (and reads none)"""
+    hists = [columns.pair_events(synth.register_events(n_ops=n, n_procs=p, seed=s, busy=busy, info=info, corrupt=corrupt))
+             for (n, p, info, corrupt, busy) in SHAPES[:9] for s in range(2)]
+    got = compare(hists, CAS, 8, tag="no-links", pool_words=4_000_000, want_witness=False)
+    assert all(g["depth"] == 0 for g in got)
+
+
+def test_wide_front_records_too():
+    """compact = False: the 128 B front records (what batches with more than six register states, or more than 64 slots, get)"""
+    hists = [columns.pair_events(synth.register_events(n_ops=n, n_procs=p, seed=s, busy=busy, info=info, corrupt=corrupt))
+             for (n, p, info, corrupt, busy) in SHAPES[:9] for s in range(2)]
+    compare(hists, CAS, 8, tag="wide-records", pool_words=4_000_000, compact=False)
+    many = [columns.pair_events(synth.register_events(n_ops=500, n_procs=8, seed=s, busy=0.3, n_values=9)) for s in range(4)]      # values 0..8: no compact form
+    compare(many, CAS, 8, tag="nine-values", pool_words=4_000_000)
+
+
+def test_full_lists_too():
+    """branch lists off: the per-front lists hold every live open call (what the wide kernel and the sweep read), the root as given"""
+    hists = [columns.pair_events(synth.register_events(n_ops=n, n_procs=p, seed=s, busy=busy, info=info, corrupt=corrupt))
+             for (n, p, info, corrupt, busy) in SHAPES[:8] for s in range(2)]
+    compare(hists, CAS, 8, tag="full-lists", pool_words=4_000_000, branch_lists=False)
 
 
 def test_rules_and_lookahead_switched_off_one_by_one():
