@@ -214,13 +214,13 @@ typedef struct tbc_opts {
                              /* two rules that drop configs without changing a verdict */
                              /* or a failing op (TBC_DOM_*); 0 = both on               */
   uint32_t lanes_per_history;/* depth-first search, register / cas-register / mutex:    */
-                             /* 8, 16 or 32 = SEVERAL HISTORIES PER WAVEFRONT (64 / n of */
+                             /* 4, 8, 16 or 32 = SEVERAL HISTORIES PER WAVEFRONT (64 / n  */
                              /* them, n lanes each; wgl_narrow.hip): one config per      */
                              /* iteration, n (config, call) pairs per round -- the       */
                              /* schedule for big batches at low concurrency, where a     */
                              /* round has few pairs.  64 = one history per wavefront     */
                              /* (search_width configs per round).  0 = the library       */
-                             /* chooses: 8 for a batch of >= 4096 register-family        */
+                             /* chooses: 8 for a batch of >= 24576 register-family       */
                              /* histories under both dominance rules with at most 10     */
                              /* calls in flight, if search_width is 0 too; else 64.      */
                              /* tbc_batch_lanes_per_history() says what was chosen.      */

@@ -69,7 +69,7 @@ __global__ __launch_bounds__(1024, 6) void pack_kernel(PackArgs A) {
   __shared__ uint32_t s_err, s_total, s_done;
   const uint32_t tid = threadIdx.x;
 
-  for (uint32_t h = blockIdx.x; h < A.n_hist; h += gridDim.x) {
+  for (uint32_t h = A.h0 + blockIdx.x; h < A.n_hist; h += gridDim.x) {
     Hist* H = &A.hist[h];
     const uint32_t n = H->n_ops, W = H->n_slots, E = H->n_events;
     const uint8_t* f = A.f + H->op_off;
@@ -309,8 +309,9 @@ __global__ __launch_bounds__(1024, 6) void pack_kernel(PackArgs A) {
 }
 
 void launch_pack(const PackArgs& a, void* stream) {
-  uint32_t grid = a.n_hist < 4096 ? a.n_hist : 4096;
-  hipLaunchKernelGGL(pack_kernel, dim3(grid), dim3(a.n_hist <= 64 ? 1024 : 256), 0, (hipStream_t)stream, a);
+  const uint32_t cnt = a.n_hist - a.h0;
+  uint32_t grid = cnt < 4096 ? cnt : 4096;
+  hipLaunchKernelGGL(pack_kernel, dim3(grid), dim3(cnt <= 64 ? 1024 : 256), 0, (hipStream_t)stream, a);
 }
 
 }  // namespace tbc

@@ -85,7 +85,7 @@ __global__ __launch_bounds__(1024) void open_counts_kernel(PackOpenArgs A) {
   const uint32_t tid = threadIdx.x;
   const uint32_t MW = A.mask_words;
 
-  for (uint32_t h = blockIdx.x; h < A.n_hist; h += gridDim.x) {
+  for (uint32_t h = A.h0 + blockIdx.x; h < A.n_hist; h += gridDim.x) {
     const Hist* H = &A.hist[h];
     BeamHist* B = &A.bh[h];
     const uint32_t n = H->n_ops, R = H->n_ret;
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(256) void open_walk_kernel(PackOpenArgs A) {
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wid = blockIdx.x * 4u + (threadIdx.x >> 6);
   const uint32_t cph = A.chunks_per_hist;
-  const uint32_t h = wid / cph, c = wid - h * cph;
+  const uint32_t hr = wid / cph, c = wid - hr * cph, h = A.h0 + hr;
   if (h >= A.n_hist) return;
   const Hist* H = &A.hist[h];
   const BeamHist* B = &A.bh[h];
@@ -450,7 +450,7 @@ __global__ __launch_bounds__(256) void open_walk_kernel(PackOpenArgs A) {
 // ---- lookahead: how recently another producer of the needed value was invoked
 __global__ __launch_bounds__(1024) void open_dprod_kernel(PackOpenArgs A) {
   const uint32_t NT = blockDim.x, tid = threadIdx.x, MW = A.mask_words;
-  for (uint32_t h = blockIdx.x; h < A.n_hist; h += gridDim.x) {
+  for (uint32_t h = A.h0 + blockIdx.x; h < A.n_hist; h += gridDim.x) {
     const Hist* H = &A.hist[h];
     const BeamHist* B = &A.bh[h];
     const uint32_t n = H->n_ops, R = H->n_ret;
@@ -509,7 +509,7 @@ __global__ __launch_bounds__(1024) void open_dprod_kernel(PackOpenArgs A) {
 __global__ __launch_bounds__(256) void front_meta_kernel(PackOpenArgs A) {
   const uint32_t cph = A.chunks_per_hist * 64u;                 // fronts per history at most, rounded up to the walk's chunks
   const uint64_t gid = (uint64_t)blockIdx.x * 256u + threadIdx.x;
-  const uint32_t h = (uint32_t)(gid / cph), F = (uint32_t)(gid - (uint64_t)h * cph);
+  const uint32_t hr = (uint32_t)(gid / cph), F = (uint32_t)(gid - (uint64_t)hr * cph), h = A.h0 + hr;
   if (h >= A.n_hist) return;
   const Hist* H = &A.hist[h];
   const BeamHist* B = &A.bh[h];
@@ -544,11 +544,12 @@ __global__ __launch_bounds__(256) void front_meta_kernel(PackOpenArgs A) {
 
 void launch_pack_open(const PackOpenArgs& a, void* stream) {
   hipStream_t s = (hipStream_t)stream;
-  const uint32_t grid = a.n_hist < 4096 ? a.n_hist : 4096;
+  const uint32_t n_here = a.n_hist - a.h0;
+  const uint32_t grid = n_here < 4096 ? n_here : 4096;
   // few histories: latency matters (tbc_check), give each the widest workgroup; many: occupancy matters
-  const uint32_t nt = a.n_hist <= 64 ? 1024 : 256;
+  const uint32_t nt = n_here <= 64 ? 1024 : 256;
   hipLaunchKernelGGL(open_counts_kernel, dim3(grid), dim3(nt), 0, s, a);
-  const uint64_t waves = (uint64_t)a.n_hist * a.chunks_per_hist;
+  const uint64_t waves = (uint64_t)n_here * a.chunks_per_hist;
   const uint32_t wgrid = (uint32_t)((waves + 3) / 4);
   switch (a.mask_words) {
     case 1: hipLaunchKernelGGL(open_walk_kernel<1>, dim3(wgrid), dim3(256), 0, s, a); break;
@@ -557,7 +558,7 @@ void launch_pack_open(const PackOpenArgs& a, void* stream) {
   }
   if (a.look) hipLaunchKernelGGL(open_dprod_kernel, dim3(grid), dim3(nt), 0, s, a);
   if (a.front_words) {
-    const uint64_t fronts = (uint64_t)a.n_hist * a.chunks_per_hist * 64u;
+    const uint64_t fronts = (uint64_t)n_here * a.chunks_per_hist * 64u;
     hipLaunchKernelGGL(front_meta_kernel, dim3((uint32_t)((fronts + 255) / 256)), dim3(256), 0, s, a);
   }
 }

@@ -391,7 +391,10 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
       if (!can) { set_error("lanes_per_history %u: needs the depth-first search of a register / cas-register / mutex batch with at most 256 process slots (not TBC_ALG_WGL, not the level sweep)", asked); return TBC_ERR_UNSUPPORTED; }
       if (opts->search_width > 1) { set_error("lanes_per_history %u expands one config per iteration: leave search_width 0 or 1", asked); return TBC_ERR_INVALID_ARG; }
       B->lanes = asked;
-    } else if (asked == 0 && can && opts->search_width == 0 && B->width == 2 && nh >= 4096) {
+    } else if (asked == 0 && can && opts->search_width == 0 && B->width == 2 && nh >= 24576) {
+      // measured (profiles/r03_narrow_batch_sizes.log): 8 lanes per history lose to a wavefront each at 4,096 and 8,192
+      // histories (59 / 61 ms against 40 / 47: one round of the narrow kernel is ~10 us of dependent instructions and trips
+      // whatever the load, so it needs three or four wavefronts per SIMD to hide it), tie at 16,384, win 97 against 160 ms at 32,768
       B->lanes = 8;
     }
     // under the eager rule the narrow kernel branches over :write / :cas only: lists without reads, root in normal form

@@ -79,10 +79,10 @@ struct PackArgs {
   uint32_t* wpre;
   uint32_t* scratch;    // the frames arena doubles as pack scratch
   uint32_t frame_words; // words per op available in scratch (>= 3)
-  uint32_t n_hist;
+  uint32_t n_hist;      // histories [h0, n_hist) are packed by this launch
   uint32_t model_kind;
   uint32_t n_classes;
-  uint32_t pad;
+  uint32_t h0;
   uint32_t* dbg;
   const int32_t* pool_vals;
   uint32_t pool_len;
@@ -237,7 +237,7 @@ struct PackOpenArgs {
   uint64_t* twn;             // twin masks, one per lst[] entry (x mask_words), or null
   uint64_t* rdm;             // open-read masks, vpad x mask_words per front at op_off * vpad * mask_words, or null
   uint32_t vpad;
-  uint32_t pad;
+  uint32_t h0;               // histories [h0, n_hist) are worked on by this launch
 };
 
 // byte offset of history h's slot8[] (n_ret entries + 16 of padding), 8-byte aligned
@@ -341,7 +341,8 @@ void launch_pack_open(const PackOpenArgs& a, void* stream);
 bool launch_beam(const BeamArgs& a, uint32_t mask_words, uint32_t n_blocks, void* stream);
 // several histories per wavefront (wgl_narrow.hip): `lanes` = 8 / 16 / 32 lanes per history, one config per iteration
 bool narrow_supported(uint32_t mask_words, uint32_t lanes);
-bool launch_narrow(const BeamArgs& a, uint32_t mask_words, uint32_t lanes, void* stream);
+// waves_per_simd: 0 = as many as fit (4); fewer leaves room for the pack kernels of the next chunk to run beside the search
+bool launch_narrow(const BeamArgs& a, uint32_t mask_words, uint32_t lanes, void* stream, uint32_t waves_per_simd = 0);
 
 // kernel launchers (defined in the .hip files)
 void launch_pack(const PackArgs& a, void* stream);

@@ -541,16 +541,19 @@ def test_narrow_kernel_wide_masks_and_other_models(native, oracle):
 
 
 def test_big_quiet_batches_take_the_narrow_kernel_by_default(native, oracle):
-    """tbc_opts.lanes_per_history = 0 and search_width = 0: a batch of >= 4096 register-family histories at low concurrency
-    under both rules runs 8 to a wavefront; smaller or busier batches keep a wavefront each."""
-    base = [columns.pair_events(synth.register_events(n_ops=300, n_procs=16, seed=s, busy=0.2)) for s in range(64)]
+    """tbc_opts.lanes_per_history = 0 and search_width = 0: a batch of >= 24,576 register-family histories at low concurrency
+    under both rules runs 8 to a wavefront (more wavefronts than the GPU holds at once: groups take their next history off the
+    queue as they finish one); smaller or busier batches keep a wavefront each."""
+    base = [columns.pair_events(synth.register_events(n_ops=120, n_procs=16, seed=s, busy=0.2)) for s in range(64)]
     opts = core.make_opts(time_limit_ms=60000, algorithm=N.ALG_COMPETITION, want_witness=False)
-    with core.Batch([base[i % 64] for i in range(4096)], gm(), opts) as b:
+    NB = 24576 + 4096 + 8
+    with core.Batch([base[i % 64] for i in range(NB)], gm(), opts) as b:
         assert (b.lanes_per_history(), b.search_width()) == (8, 1)
         res = b.run().results()
     for i in range(64):
         exp = _narrow_expect(oracle, base[i], 8)
-        for k in range(0, 4096, 64 * 13):
+        for k in list(range(0, NB - 64, 64 * 37)) + [NB - 64 - (NB % 64)]:
             _assert_narrow(res[i + k], exp, (i, k))
-    with core.Batch(base, gm(), opts) as b:
+    assert all(r["valid"] == 1 and r["probes"] == res[j % 64]["probes"] for j, r in enumerate(res))      # every one of them, refilled groups included
+    with core.Batch([base[i % 64] for i in range(4096)], gm(), opts) as b:
         assert (b.lanes_per_history(), b.search_width()) == (64, 2)
