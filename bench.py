@@ -99,6 +99,11 @@ def main():
     ap.add_argument("--lanes", type=int, default=int(os.environ.get("TBC_BENCH_LANES", "0")),
                     help="lanes per history of the depth-first search: 0 = the library's choice (8 for this workload: eight histories per "
                          "wavefront), 8 / 16 / 32, or 64 = one history per wavefront")
+    ap.add_argument("--in-flight", type=int, default=int(os.environ.get("TBC_BENCH_IN_FLIGHT", "2")),
+                    help="resident batches per GPU, each of --batch histories, on its own stream and host thread (how jepsen.independent's "
+                         "thread pool would drive the library): a step is still ONE pass over ONE batch; the passes of different batches "
+                         "overlap -- one batch's init + pack beside another's search (the library runs the searches one at a time). "
+                         "1 = one batch, one pass after the other (also measured in every run: extra.one_batch_at_a_time)")
     ap.add_argument("--visited-per-op", type=int, default=4, help="first visited-set capacity per op (0 = library default 64); a history that needs more grows its set inside the kernel")
     ap.add_argument("--round-budget", type=int, default=0,
                     help="a history that has used more rounds than this continues at width 16 (0 = off)")
@@ -110,10 +115,16 @@ def main():
     ap.add_argument("--no-tiers", action="store_true", help="skip the crashed-op tiers (extra.tiers)")
     ap.add_argument("--no-set-full", action="store_true", help="skip the checker/set-full scan (extra.set_full)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--only-headline", action="store_true",
+                    help="the warm-up and the timed steps only (no extra legs): what scripts/gpu_profile_r03.sh runs under rocprofv3 --kernel-trace "
+                         "--stats, so that the kernel's average duration there is the one of the timed region")
     ap.add_argument("--sharded-ttv", action="store_true",
                     help="N > 1 only: also time ONE history swept by all N GPUs (shard.check_sharded: wavefronts dealt to the ranks, "
                          "one RCCL all-gather of the relation tables); off by default -- it adds a collective to the run")
     args = ap.parse_args()
+    if args.only_headline:
+        args.no_cpu = args.no_tiers = args.no_set_full = True
+        args.busy2 = args.busy3 = 0.0
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -143,34 +154,59 @@ def main():
 
     # ---- synthetic input: B distinct seeded histories per rank
     B = args.batch
+    F = max(1, args.in_flight)
     t_gen = time.time()
-    seeds = shard.shard_indices(B * world, rank, world)      # history i of the job lives on rank i % world
-    hists = synth.register_ops_many(seeds, n_ops=args.ops, n_procs=args.procs, busy=args.busy, info=args.info)
+    seeds = shard.shard_indices(F * B * world, rank, world)      # history i of the job lives on rank i % world
+    hists_all = [synth.register_ops_many(seeds[k * B:(k + 1) * B], n_ops=args.ops, n_procs=args.procs, busy=args.busy, info=args.info) for k in range(F)]
+    hists = hists_all[0]
     t_gen = time.time() - t_gen
     model = core.make_model(N.MODEL_CAS_REGISTER, N.NIL)
     opts = core.make_opts(device=local_rank, time_limit_ms=600000, want_witness=False,
                           algorithm=N.ALG_COMPETITION, search_width=args.width, visited_per_op=args.visited_per_op,
                           round_budget=args.round_budget, lanes_per_history=args.lanes)
     t_create = time.perf_counter()
-    batch = core.Batch(hists, model, opts)        # H2D happens here: inputs resident before timing
-    t_create = time.perf_counter() - t_create
+    batches = [core.Batch(h, model, opts) for h in hists_all]        # H2D happens here: inputs resident before timing
+    t_create = (time.perf_counter() - t_create) / F
+    batch = batches[0]
     width = batch.search_width()                  # what --width 0 became for this batch
     lanes = batch.lanes_per_history()             # 8 / 16 / 32: several histories per wavefront (one config per iteration); 64: one
     narrow = lanes != 64
     kname = "wgl_narrow_kernel" if narrow else ("wgl_search_kernel" if width == 1 else "wgl_beam_kernel")
 
-    for _ in range(args.warmup):
-        batch.run()
+    # a step = one pass (init + pack + search + verdicts back) over one resident batch.  Step i goes to batch i % F; each batch
+    # has its own host thread and stream, so up to F passes are in flight (tbc_batch_run is a blocking C call that releases the GIL)
+    import threading
+    def passes(k, count, log):
+        for _ in range(count):
+            batches[k].run()
+            if log is not None:
+                log.append(batches[k].timing_ns())
+    def in_flight(total, logs):
+        th = [threading.Thread(target=passes, args=(k, len(range(k, total, F)), None if logs is None else logs[k])) for k in range(F)]
+        for x in th: x.start()
+        for x in th: x.join()
+    in_flight(max(args.warmup, F), None)                      # (every resident batch is run once before the clock starts)
     barrier()
     t0 = time.perf_counter()
-    search_ns, pack_ns, init_ns, retry_ns = [], [], [], []
-    for _ in range(args.steps):
-        batch.run()
-        tm = batch.timing_ns()
-        search_ns.append(tm["search"]); pack_ns.append(tm["pack"]); init_ns.append(tm["init"]); retry_ns.append(tm["retries"])
+    logs = [[] for _ in range(F)]
+    in_flight(args.steps, logs)
     barrier()
     elapsed = time.perf_counter() - t0
     elapsed = shard.max_over_ranks(elapsed, world, dist)
+    tms = [tm for l in logs for tm in l]
+    assert len(tms) == args.steps
+    search_ns, pack_ns, init_ns, retry_ns = ([tm[k] for tm in tms] for k in ("search", "pack", "init", "retries"))
+    wait_ns = [tm["turn_wait"] for tm in tms]
+    # the same passes with nothing else in flight: one batch, one pass after the other (never `value` unless --in-flight 1)
+    alone = None
+    if F > 1 and not args.only_headline:
+        barrier()
+        ta0 = time.perf_counter()
+        tma = []
+        for _ in range(3):
+            batch.run(); tma.append(batch.timing_ns())
+        barrier()
+        alone = (shard.max_over_ranks((time.perf_counter() - ta0) / 3, world, dist), tma)
 
     sharded_ms = None
     if world > 1 and args.sharded_ttv:
@@ -186,9 +222,10 @@ def main():
         sharded_ms = {"median_ms": round(statistics.median(times[1:]), 3), "valid": r1[0]["valid"], "gpus": world}
 
     verdicts = batch.verdicts()
-    counters = batch.counters()
-    n_valid = int((verdicts == N.VALID).sum())
-    n_unknown = int((verdicts == N.UNKNOWN).sum())
+    all_counters = [b.counters() for b in batches]
+    counters = {k: sum(c[k] for c in all_counters) // F for k in all_counters[0]}      # per launch: the mean over the resident batches
+    n_valid = sum(int((b.verdicts() == N.VALID).sum()) for b in batches)            # over all resident batches (F x B histories per GPU)
+    n_unknown = sum(int((b.verdicts() == N.UNKNOWN).sum()) for b in batches)
     if world > 1:
         t = torch.tensor([n_valid, n_unknown], dtype=torch.int64, device="cuda")
         dist.all_reduce(t)
@@ -220,6 +257,7 @@ def main():
             "dtype": "u64", "data": "synthetic",
             "config": {"workload": workload_name(args.ops, args.procs, args.busy, args.info), "histories_per_gpu": B, "ops_after_pairing": int(batch.total_ops // B),
                        "processes": args.procs, "busy": args.busy, "info_rate": args.info,
+                       "batches_in_flight": F,
                        "search_width": width, "search_width_asked": args.width, "lanes_per_history": lanes, "histories_per_wavefront": 64 // lanes,
                        "round_budget": args.round_budget,
                        "parallelism": f"independent histories sharded over {world} GPU(s), no collective"},
@@ -231,20 +269,31 @@ def main():
             "extra": {"valid": n_valid, "unknown": n_unknown,
                       "device_ms": {"init_memsets": round(statistics.mean(init_ns) / 1e6, 3),
                                     "pack": round(statistics.mean(pack_ns) / 1e6, 3),
-                                    "search": round(k_ms, 3), "retries": round(statistics.mean(retry_ns) / 1e6, 3)},
+                                    "search": round(k_ms, 3), "retries": round(statistics.mean(retry_ns) / 1e6, 3),
+                                    "search_waiting_for_its_turn": round(statistics.mean(wait_ns) / 1e6, 3),
+                                    "note": "per pass, HIP events on the pass's own stream; with several batches in flight a pass's init and pack "
+                                            "share the GPU with another pass's search, so the four do not add up to ms_per_step"},
                       "steps_per_history": counters["steps"] / B,
-                      "device_GB": round(batch.device_bytes() / 1e9, 3), "gen_s": round(t_gen, 2),
+                      "device_GB": round(sum(b.device_bytes() for b in batches) / 1e9, 3), "device_GB_per_batch": round(batch.device_bytes() / 1e9, 3), "gen_s": round(t_gen, 2),
                       # the same batch with its inputs NOT resident: tbc_batch_create (allocation + H2D of the op
                       # columns over PCIe) + one run; never `value`
                       "h2d_inclusive_hist_per_s": round(B / (t_create + elapsed / args.steps), 2),
                       "create_h2d_s": round(t_create, 3), "kernel_sha": kernel_sha()},
         }
+        if alone is not None:
+            a_s, tma = alone
+            line["extra"]["one_batch_at_a_time"] = {
+                "value": round(B * world / a_s, 2), "unit": "histories/s", "ms_per_step": round(a_s * 1e3, 3),
+                "device_ms": {k2: round(statistics.mean(tm[k1] for tm in tma) / 1e6, 3) for k1, k2 in (("init", "init_memsets"), ("pack", "pack"), ("search", "search"), ("retries", "retries"))},
+                "roofline_frac": round(alg_bytes / (statistics.mean(tm["search"] for tm in tma) * 1e-9) / 1e9 / HBM_PEAK_GBS, 6),
+                "note": "the resident batch 0 alone, 3 passes back to back right after the timed region"}
         if sharded_ms is not None:
             line["extra"]["one_history_over_all_gpus"] = sharded_ms
         # time-to-verdict for ONE history through tbc_check (host columns in -> verdict out: H2D + kernels + D2H), rank 0.
         # knossos.competition without a witness = the level sweep (jit_sweep.hip); with a witness = the depth-first search
-        batch.close()
-        if world == 1 and narrow and args.lanes == 0:
+        for b in batches:
+            b.close()
+        if world == 1 and narrow and args.lanes == 0 and not args.only_headline:
             # the same batch with ONE history per wavefront (round 2's kernel, wgl_beam_kernel at the width it chose then): what
             # several histories per wavefront buy, measured in the same run.  Never `value`.
             with core.Batch(hists, model, core.make_opts(device=local_rank, time_limit_ms=600000, want_witness=False, algorithm=N.ALG_COMPETITION,
@@ -434,7 +483,8 @@ def main():
                                          "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                                       "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "setfull_any_kernel + setfull_resolve_kernel"}}
         print(json.dumps(line), flush=True)
-    batch.close()
+    for b in batches:
+        b.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -327,6 +327,16 @@ tbc_status tbc_batch_run(tbc_batch* b, tbc_result* results);
 /* device-time breakdown of the last run, ns, measured with HIP events on the
  * batch's own stream: [0] memset/init, [1] pack, [2] search, [3] retries */
 tbc_status tbc_batch_last_timing(const tbc_batch* b, uint64_t ns[4]);
+/* SEVERAL BATCHES IN FLIGHT.  A batch owns its stream and its arenas, so different batches may be run at the
+ * same time from different host threads (tbc_batch_run holds no process-wide lock; one batch is still one
+ * thread's at a time) -- which is how jepsen.independent/checker drives a checker: one (bounded-)pmap thread
+ * per key group (reference: src/tigerbeetle/checker.clj:60-78 hands each key's sub-history to the wrapped
+ * checker).  Batches that run several histories per wavefront take the whole GPU for their search and the
+ * library gives those searches the device one at a time, in launch order, through a device-side event; the
+ * init and pack of the next batch run beside the search of the previous one (measured: 2 x 24,576 histories
+ * in flight, 183k histories/s against 144k one batch after the other).  ns = how long the last run's search
+ * waited for its turn (not counted in ns[2] of tbc_batch_last_timing). */
+tbc_status tbc_batch_last_turn_wait(const tbc_batch* b, uint64_t* ns);
 /* sum of tbc_counters over the last run (probes, visited ...) */
 tbc_status tbc_batch_last_counters(const tbc_batch* b, tbc_counters* out);
 uint64_t tbc_batch_device_bytes(const tbc_batch* b);

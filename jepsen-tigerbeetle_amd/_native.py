@@ -150,6 +150,7 @@ SYMBOLS = {
     "tbc_batch_create": (C.c_int, [C.POINTER(BatchDesc), C.POINTER(Model), C.POINTER(Opts), C.POINTER(C.c_void_p)]),
     "tbc_batch_run": (C.c_int, [C.c_void_p, C.POINTER(Result)]),
     "tbc_batch_last_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "tbc_batch_last_turn_wait": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "tbc_batch_last_counters": (C.c_int, [C.c_void_p, C.POINTER(Counters)]),
     "tbc_batch_device_bytes": (C.c_uint64, [C.c_void_p]),
     "tbc_batch_search_width": (C.c_uint32, [C.c_void_p]),

@@ -158,7 +158,9 @@ class Batch:
     def timing_ns(self):
         t = (C.c_uint64 * 4)()
         N.check_status(N.lib().tbc_batch_last_timing(self._h, t))
-        return {"init": t[0], "pack": t[1], "search": t[2], "retries": t[3]}
+        w = C.c_uint64(0)
+        N.check_status(N.lib().tbc_batch_last_turn_wait(self._h, C.byref(w)))
+        return {"init": t[0], "pack": t[1], "search": t[2], "retries": t[3], "turn_wait": w.value}
 
     def counters(self):
         c = N.Counters()

@@ -37,8 +37,9 @@ inline uint32_t ceil_log2(uint64_t x) {
 // Entries of a history's per-front open-call lists: every live call appears once per front it is open
 // at (the completions positioned between its invocation and its completion, plus its own).  Exact when
 // the positions are event indices; anything else falls back to the worst case (every slot at every front).
+// branch_lists: the lists hold the live :write / :cas calls only (kRuleBranch), so the reads are not counted.
 uint64_t open_list_entries(const tbc_ops& c, uint64_t op_off, uint64_t n, uint32_t n_events, uint32_t n_slots,
-                           std::vector<uint32_t>& pre) {
+                           std::vector<uint32_t>& pre, bool branch_lists) {
   const uint64_t worst = std::max<uint64_t>(n, 1) * std::max(1u, n_slots);
   if (n == 0) return 1;
   if ((uint64_t)n_events > 64 * n + 1024) return worst;
@@ -52,8 +53,9 @@ uint64_t open_list_entries(const tbc_ops& c, uint64_t op_off, uint64_t n, uint32
   }
   for (uint32_t x = 1; x <= n_events; x++) pre[x] += pre[x - 1];
   uint64_t total = 0;
+  const uint8_t* f = c.f + op_off;
   for (uint64_t i = 0; i < n; i++)
-    if (ret[i] != TBC_POS_CRASHED) total += pre[ret[i]] - pre[inv[i]] + 1;
+    if (ret[i] != TBC_POS_CRASHED && !(branch_lists && f[i] == TBC_F_READ)) total += pre[ret[i]] - pre[inv[i]] + 1;
   return std::min(worst, std::max<uint64_t>(total, 1));
 }
 
@@ -226,6 +228,8 @@ struct tbc_batch {
   std::vector<DevResult> res_host;
   std::vector<uint32_t> witness_host;
   uint64_t timing_ns[4] = {0, 0, 0, 0};
+  hipEvent_t ev_turn = nullptr;     // narrow kernel: the search's turn on the device has come (SearchTurn), owned by the batch
+  uint64_t turn_wait_ns = 0;        // ... and how long the last run waited for it
   tbc_counters sum{};
   uint64_t device_bytes = 0;
 
@@ -237,6 +241,7 @@ struct tbc_batch {
     d_queue.release(); d_tab.release(); d_results.release(); d_table.release(); d_pool_vals.release(); d_cfg.release();
     d_bh.release(); d_off.release(); d_ncr.release(); d_lst.release(); d_crashed.release(); d_stack.release();
     d_occ.release(); d_btab.release(); d_slot8.release(); d_rk8.release(); d_look.release(); d_looktmp.release(); d_twn.release(); d_rdm.release(); d_cuts.release(); d_seglist.release(); d_sres.release(); d_dstack.release(); d_pool.release(); d_pool_cursor.release();
+    if (ev_turn) (void)hipEventDestroy(ev_turn);
     if (!borrowed) {
       for (auto& e : ev) if (e) (void)hipEventDestroy(e);
       if (stream) (void)hipStreamDestroy(stream);
@@ -457,7 +462,7 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
       Q.tab_log2 = blg;
       Q.off_off = boff_n; boff_n += n + 2;
       Q.occ_off = bocc_n; bocc_n += (n + 1) * B->mask_words;
-      Q.lst_cap = (uint32_t)std::min<uint64_t>(0xFFFFFFF0ull, open_list_entries(desc->cols, H.op_off, n, H.n_events, H.n_slots, rank_scratch));
+      Q.lst_cap = (uint32_t)std::min<uint64_t>(0xFFFFFFF0ull, open_list_entries(desc->cols, H.op_off, n, H.n_events, H.n_slots, rank_scratch, (B->rules & kRuleBranch) != 0));
       Q.lst_off = blst_n; blst_n += Q.lst_cap;
       Q.stack_off = bstack_n; bstack_n += (1ull << blg);
       Q.tab_off = btab_n; btab_n += (1ull << blg);
@@ -466,7 +471,17 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
 
   if (B->lanes && (blst_n >= (1ull << 32) || boff_n >= (1ull << 32))) {      // 32-bit element offsets (wgl_narrow_impl.h)
     if (opts->lanes_per_history) { set_error("lanes_per_history: the batch's open-call lists exceed 2^32 entries; split the batch"); return TBC_ERR_UNSUPPORTED; }
+    const bool had_branch = (B->rules & kRuleBranch) != 0;
     B->lanes = 0; B->rules &= ~kRuleBranch;
+    if (had_branch) {                          // the lists hold the reads again: size them for that
+      blst_n = 0;
+      for (uint32_t h = 0; h < nh; h++) {
+        const Hist& H = B->hist[h];
+        BeamHist& Q = B->bh[h];
+        Q.lst_cap = (uint32_t)std::min<uint64_t>(0xFFFFFFF0ull, open_list_entries(desc->cols, H.op_off, H.n_ops, H.n_events, H.n_slots, rank_scratch, false));
+        Q.lst_off = blst_n; blst_n += Q.lst_cap;
+      }
+    }
   }
   if (B->sweep) { bstack_n = 0; btab_n = 0; }     // the sweep has no visited set; its fallback takes scratch arenas
   tbc_status s;
@@ -492,11 +507,11 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
     if (B->lanes) { B->d_rdm.release(); if ((s = B->d_rdm.alloc(T * B->front_words()))) return s; }
     if (B->lookahead && ((s = B->d_look.alloc(look_words(T, nh, B->mask_words))) || (s = B->d_looktmp.alloc(T)) ||
                          (s = B->d_dstack.alloc(bstack_n)))) return s;
-    // growth pool: 30 % of the visited-set arena, at least room for one history to grow twice (4x, then 16x: keys, parents, two stacks, slot translation), at most 32 GiB
+    // growth pool: 10 % of the visited-set arena (a history that outgrows its table and finds the pool empty is run again from a scratch arena), at least room for one history to grow twice (4x, then 16x: keys, parents, two stacks, slot translation), at most 32 GiB
     {
       uint64_t biggest = 0;
       for (uint32_t h = 0; h < nh; h++) biggest = std::max<uint64_t>(biggest, 1ull << B->bh[h].tab_log2);
-      uint64_t words = std::max<uint64_t>(btab_n * EW * 3 / 10, biggest * (4 + 16 + 4) * (EW + 1));
+      uint64_t words = std::max<uint64_t>(btab_n * EW / 10, biggest * (4 + 16 + 4) * (EW + 1));
       words = std::min<uint64_t>(words, (32ull << 30) / 8);
       if (B->sweep) words = 1;
       if ((s = B->d_pool.alloc(words))) return s;
@@ -795,6 +810,32 @@ static tbc_status expand_eager_witness(tbc_batch* B, uint32_t h, uint32_t* wit, 
 
 // phase 0: the whole run.  phase 1 (tbc_batch_sweep_partial): pack + this rank's share of the sweep, stop before the
 // verdicts.  phase 2 (tbc_batch_sweep_finish): verdicts from the merged relation table already placed in seg_host.
+// ---- several batches in flight on one device (each on its own stream, from its own host thread).  The narrow kernel is sized
+// to the whole GPU and lives on latency, the pack kernels on vector issue: a batch's pack beside ANOTHER batch's search uses
+// what the search leaves idle, two searches at once only halve each other.  So the searches of one device are chained through
+// an event -- a search starts when the one launched before it, on whatever stream, is done -- and everything else floats.
+namespace {
+struct SearchTurn {
+  static std::mutex& mu() { static std::mutex m; return m; }
+  static hipEvent_t& last(int dev) { static hipEvent_t ev[64] = {}; return ev[dev & 63]; }
+  std::lock_guard<std::mutex> g;
+  int dev; hipStream_t s;
+  SearchTurn(int device, hipStream_t stream) : g(mu()), dev(device), s(stream) {
+    if (last(dev)) (void)hipStreamWaitEvent(s, last(dev), 0);
+  }
+  ~SearchTurn() {
+    if (!last(dev)) (void)hipEventCreateWithFlags(&last(dev), hipEventDisableTiming);
+    if (last(dev)) (void)hipEventRecord(last(dev), s);
+  }
+};
+// wavefronts per SIMD the narrow kernel is launched at (the kernel is built for up to TBC_NARROW_MIN_WAVES = 4; fewer leave
+// registers and wave slots for the pack kernels of another batch in flight).  TBC_NARROW_WAVES_PER_SIMD overrides, 0 = the build's.
+uint32_t narrow_waves_per_simd() {
+  const char* e = std::getenv("TBC_NARROW_WAVES_PER_SIMD");
+  return e ? (uint32_t)std::strtoul(e, nullptr, 10) : 0u;
+}
+}  // namespace
+
 static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results, int phase = 0) {
   HIP_TRY(hipSetDevice(B->device));
   const uint64_t t_start = now_ns();
@@ -870,7 +911,12 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results, int phase = 
     if (!launch_sweep(mine, s)) { set_error("level sweep launch failed"); return TBC_ERR_HIP; }
   } else if (beam) {
     BeamArgs ba = make_beam_args(B, B->d_btab.p, B->d_stack.p, B->d_dstack.p, nh);
-    if (B->lanes ? !launch_narrow(ba, B->mask_words, B->lanes, s) : !launch_beam(ba, B->mask_words, search_blocks(nh), s)) { set_error("unsupported mask width"); return TBC_ERR_UNSUPPORTED; }
+    if (B->lanes) {
+      SearchTurn turn(B->device, s);        // one whole-GPU search at a time; another batch's pack runs beside it
+      if (!B->ev_turn) HIP_TRY(hipEventCreate(&B->ev_turn));
+      HIP_TRY(hipEventRecord(B->ev_turn, s));
+      if (!launch_narrow(ba, B->mask_words, B->lanes, s, narrow_waves_per_simd())) { set_error("unsupported mask width"); return TBC_ERR_UNSUPPORTED; }
+    } else if (!launch_beam(ba, B->mask_words, search_blocks(nh), s)) { set_error("unsupported mask width"); return TBC_ERR_UNSUPPORTED; }
   } else {
     SearchArgs sa = make_search_args(B, B->d_tab.p, nh);
     if (!launch_search(sa, B->mask_words, search_blocks(nh), s)) { set_error("unsupported mask width"); return TBC_ERR_UNSUPPORTED; }
@@ -1062,6 +1108,13 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results, int phase = 
   }
   HIP_TRY(hipEventElapsedTime(&ms, B->ev[4], B->ev[5]));
   B->timing_ns[3] = (uint64_t)(ms * 1e6);
+  B->turn_wait_ns = 0;
+  if (B->lanes && B->ev_turn && phase == 0) {      // the search proper: from its turn on the device to its end
+    HIP_TRY(hipEventElapsedTime(&ms, B->ev[2], B->ev_turn));
+    B->turn_wait_ns = (uint64_t)(ms * 1e6);
+    HIP_TRY(hipEventElapsedTime(&ms, B->ev_turn, B->ev[3]));
+    B->timing_ns[2] = (uint64_t)(ms * 1e6);
+  }
   TRACE("run: timings read");
 
   std::memset(&B->sum, 0, sizeof B->sum);
@@ -1197,6 +1250,12 @@ tbc_status tbc_batch_sweep_merge(tbc_batch* b, const void* gathered_device, uint
 tbc_status tbc_batch_last_timing(const tbc_batch* b, uint64_t ns[4]) {
   if (!b || !ns) return TBC_ERR_INVALID_ARG;
   for (int i = 0; i < 4; i++) ns[i] = b->timing_ns[i];
+  return TBC_OK;
+}
+
+tbc_status tbc_batch_last_turn_wait(const tbc_batch* b, uint64_t* ns) {
+  if (!b || !ns) { set_error("null argument"); return TBC_ERR_INVALID_ARG; }
+  *ns = b->turn_wait_ns;
   return TBC_OK;
 }
 

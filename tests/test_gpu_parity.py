@@ -540,6 +540,46 @@ def test_narrow_kernel_wide_masks_and_other_models(native, oracle):
         core.Batch(reg, core.make_model(N.MODEL_REGISTER, N.NIL), core.make_opts(algorithm=N.ALG_COMPETITION, lanes_per_history=8, search_width=4))
 
 
+def test_batches_in_flight_from_several_threads(native, oracle):
+    """tbcheck.h, "several batches in flight": three resident batches, each run four times from its own host thread at the same
+    time (their searches take the device in turn, everything else floats) -- every pass of every batch gives what the batch
+    gives alone, which is what its oracle gives."""
+    import threading
+    sets = [[columns.pair_events(synth.register_events(n_ops=200 + 40 * k, n_procs=16, seed=100 * k + s, busy=0.2, corrupt=0.3 if s % 5 == 0 else 0.0))
+             for s in range(96)] for k in range(3)]
+    opts = core.make_opts(time_limit_ms=60000, algorithm=N.ALG_COMPETITION, want_witness=False, lanes_per_history=8)
+    batches = [core.Batch(h, gm(), opts) for h in sets]
+    try:
+        alone = []
+        for b in batches:
+            res = b.run().results()
+            alone.append([(r["valid"], r["probes"], r["visited"], r["backtracks"], r["fail_op"]) for r in res])
+        for k in range(3):
+            for i in (0, 5, 17, 95):
+                _assert_narrow(batches[k].results()[i], _narrow_expect(oracle, sets[k][i], 8), (k, i))
+        seen = [[] for _ in batches]
+        errors = []
+        go = threading.Barrier(3)
+        def work(k):
+            try:
+                go.wait()
+                for _ in range(4):
+                    res = batches[k].run().results()
+                    seen[k].append([(r["valid"], r["probes"], r["visited"], r["backtracks"], r["fail_op"]) for r in res])
+                    assert batches[k].timing_ns()["search"] > 0
+            except Exception as e:          # noqa: BLE001 -- reported by the asserting thread below
+                errors.append((k, repr(e)))
+        th = [threading.Thread(target=work, args=(k,)) for k in range(3)]
+        for t in th: t.start()
+        for t in th: t.join()
+        assert not errors, errors
+        for k in range(3):
+            assert len(seen[k]) == 4 and all(x == alone[k] for x in seen[k]), k
+    finally:
+        for b in batches:
+            b.close()
+
+
 def test_big_quiet_batches_take_the_narrow_kernel_by_default(native, oracle):
     """tbc_opts.lanes_per_history = 0 and search_width = 0: a batch of >= 24,576 register-family histories at low concurrency
     under both rules runs 8 to a wavefront (more wavefronts than the GPU holds at once: groups take their next history off the
