@@ -47,7 +47,7 @@ def kernel_sha():
     was measured on (profiles/*_traffic.json carries the sha it was taken at)."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("wgl_beam.hip", "wgl_narrow.hip", "wgl_narrow_impl.h", "wave_env.h", "device_common.h", "pack_open.hip"):
+    for f in ("wgl_beam.hip", "wgl_narrow.hip", "wgl_narrow_impl.h", "wave_env.h", "device_common.h", "pack_open.hip", "open_walk_impl.h"):
         with open(os.path.join(ROOT, "jepsen-tigerbeetle_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
@@ -84,8 +84,8 @@ def usable_cores():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=int(os.environ.get("TBC_BENCH_BATCH", "32768")),
                     help="histories per GPU per step")
     ap.add_argument("--ops", type=int, default=10000)

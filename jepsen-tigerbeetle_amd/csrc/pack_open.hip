@@ -33,7 +33,10 @@
 //                       the producers with atomicMin).
 // The off / ncr arenas are zeroed by the host before the launch.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
+#include <cstring>
 #include "tbc_internal.h"
+#include "open_walk_impl.h"
 
 namespace tbc {
 
@@ -447,6 +450,15 @@ __global__ __launch_bounds__(256) void open_walk_kernel(PackOpenArgs A) {
   }
 }
 
+// ---- the same walk with lane = front (open_walk_impl.h): up to 64 process slots, rows of up to VCAP entries
+template <int VCAP>
+__global__ __launch_bounds__(256) void open_walk_fronts_kernel(PackOpenArgs A) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t walk_lds[];
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wv_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  walk::walk_wave<VCAP>(A, blockIdx.x * 4u + wv_, walk_lds + wv_ * walk::walk_lds_words(), lane);
+}
+
 // ---- lookahead: how recently another producer of the needed value was invoked
 __global__ __launch_bounds__(1024) void open_dprod_kernel(PackOpenArgs A) {
   const uint32_t NT = blockDim.x, tid = threadIdx.x, MW = A.mask_words;
@@ -551,7 +563,15 @@ void launch_pack_open(const PackOpenArgs& a, void* stream) {
   hipLaunchKernelGGL(open_counts_kernel, dim3(grid), dim3(nt), 0, s, a);
   const uint64_t waves = (uint64_t)n_here * a.chunks_per_hist;
   const uint32_t wgrid = (uint32_t)((waves + 3) / 4);
-  switch (a.mask_words) {
+  // one mask word: the walk with lane = front (a fifth of the vector instructions); TBC_OPEN_WALK=slots keeps the walk with
+  // lane = process slot for it too (the A/B in tests/test_gpu_parity.py), which wider masks always take
+  const char* which = std::getenv("TBC_OPEN_WALK");
+  const bool by_front = a.mask_words == 1 && a.vpad <= 32 && !(which && std::strcmp(which, "slots") == 0);
+  const size_t walk_lds_bytes = 4u * walk::walk_lds_words() * sizeof(uint32_t);
+  if (by_front) {
+    if (a.vpad <= 8) hipLaunchKernelGGL(open_walk_fronts_kernel<8>, dim3(wgrid), dim3(256), walk_lds_bytes, s, a);
+    else hipLaunchKernelGGL(open_walk_fronts_kernel<32>, dim3(wgrid), dim3(256), walk_lds_bytes, s, a);
+  } else switch (a.mask_words) {
     case 1: hipLaunchKernelGGL(open_walk_kernel<1>, dim3(wgrid), dim3(256), 0, s, a); break;
     case 2: hipLaunchKernelGGL(open_walk_kernel<2>, dim3(wgrid), dim3(256), 0, s, a); break;
     default: hipLaunchKernelGGL(open_walk_kernel<4>, dim3(wgrid), dim3(256), 0, s, a); break;

@@ -68,8 +68,9 @@ static int wset_add(wset* s, const uint64_t* k) {
 }
 
 /* configs stuck at the failing completion of the LAST invalid run (test infrastructure: not re-entrant) */
-static uint64_t* g_cfg = NULL; static uint32_t g_cfg_n = 0, g_cfg_kw = 0;
-static size_t g_sort_kw;
+/* (thread-local: oracle/many.c runs this restatement on a pthread pool, and an invalid history replaces the buffer) */
+static _Thread_local uint64_t* g_cfg = NULL; static _Thread_local uint32_t g_cfg_n = 0, g_cfg_kw = 0;
+static _Thread_local size_t g_sort_kw;
 static int cmp_cfg(const void* x, const void* y) {
   const uint64_t* a = (const uint64_t*)x; const uint64_t* b = (const uint64_t*)y;
   int32_t sa = (int32_t)(a[0] >> 32), sb = (int32_t)(b[0] >> 32);

@@ -24,13 +24,55 @@ class DevResult(C.Structure):
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, "emu_narrow.cpp"), os.path.join(_HERE, "wave_env_emu.h"),
+    srcs = [os.path.join(_HERE, "emu_narrow.cpp"), os.path.join(_HERE, "wave_env_emu.h"), os.path.join(_HERE, "host_tables.h"),
             os.path.join(_CSRC, "wgl_narrow_impl.h"), os.path.join(_CSRC, "tbc_internal.h"), os.path.join(_CSRC, "wave_env.h")]
     if force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs):
         os.makedirs(os.path.dirname(_SO), exist_ok=True)
         subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas",
                                "-I", _HERE, "-I", _CSRC, "-o", _SO, srcs[0]])
     return _SO
+
+
+_SO_WALK = os.path.join(_HERE, "_build", "libemu_walk.so")
+_LIB_WALK = None
+
+
+def build_walk(force=False):
+    srcs = [os.path.join(_HERE, "emu_walk.cpp"), os.path.join(_HERE, "wave_env_emu.h"), os.path.join(_HERE, "host_tables.h"),
+            os.path.join(_CSRC, "open_walk_impl.h"), os.path.join(_CSRC, "tbc_internal.h"), os.path.join(_CSRC, "wave_env.h")]
+    if force or not os.path.exists(_SO_WALK) or any(os.path.getmtime(s) > os.path.getmtime(_SO_WALK) for s in srcs):
+        os.makedirs(os.path.dirname(_SO_WALK), exist_ok=True)
+        subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas",
+                               "-I", _HERE, "-I", _CSRC, "-o", _SO_WALK, srcs[0]])
+    return _SO_WALK
+
+
+def walk_check(hists, vpad, twin=True, look=True, branch=False, front="plain"):
+    """Run the front walk with lane = front (csrc/open_walk_impl.h) under the emulator on these histories (at most 64 process
+    slots each) and compare every word it writes with the host-built tables.  front: "plain" rows, "wide" or "compact" front
+    records.  Returns None when all agree, else (what, history, front, index, got, want)."""
+    global _LIB_WALK
+    if _LIB_WALK is None:
+        _LIB_WALK = C.CDLL(build_walk())
+        _LIB_WALK.emu_walk_check.restype = C.c_int
+    ds = [h if isinstance(h, dict) else h.as_dict() for h in hists]
+    nh = len(ds)
+    op_off = np.zeros(nh + 1, np.uint64)
+    for i, d in enumerate(ds):
+        op_off[i + 1] = op_off[i] + len(d["f"])
+    cat = lambda k, dt: np.ascontiguousarray(np.concatenate([np.asarray(d[k], dt) for d in ds]), dt)
+    f, a, b = cat("f", np.uint8), cat("a", np.int32), cat("b", np.int32)
+    pr, inv, ret = cat("process", np.int32), cat("inv_pos", np.uint32), cat("ret_pos", np.uint32)
+    npr = np.array([int(d["n_process"]) for d in ds], np.uint32)
+    assert int(npr.max()) <= 64
+    flags = (1 if twin else 0) | (2 if look else 0) | (4 if branch else 0) | {"plain": 0, "wide": 8, "compact": 24}[front]
+    diag = np.zeros(8, np.uint64)
+    rc = _LIB_WALK.emu_walk_check(C.c_uint32(nh), _p(op_off, C.c_uint64), _p(npr, C.c_uint32), _p(f, C.c_uint8), _p(a, C.c_int32), _p(b, C.c_int32),
+                                  _p(pr, C.c_int32), _p(inv, C.c_uint32), _p(ret, C.c_uint32), C.c_uint32(vpad), C.c_uint32(flags), _p(diag, C.c_uint64))
+    if rc == 0:
+        return None
+    what = {1: "lst", 2: "twn", 3: "rdm", 4: "look word 0", 5: "look mask", 6: "tmp", 9: "bad input"}.get(rc, str(rc))
+    return (what, int(diag[0]), int(diag[1]), int(diag[2]), hex(int(diag[3])), hex(int(diag[4])))
 
 
 def lib():

@@ -1,0 +1,50 @@
+"""The front walk with lane = front (csrc/open_walk_impl.h -- the file hipcc compiles into libtbcheck.so) on the CPU, under the
+lane-accurate wavefront emulator of tests/emu, against tables built on the host from the definitions (tests/emu/host_tables.h):
+every list entry, twin mask, open-read row / front-record mask word and lookahead record, word for word.  Test infrastructure
+only: the product has no CPU path."""
+import numpy as np
+import pytest
+
+import emu
+from jepsen_tigerbeetle_amd import columns, synth
+
+SHAPES = [  # n_ops, n_procs, busy, info, corrupt
+    (300, 16, 0.3, 0.0, 0.0), (500, 64, 0.1, 0.0, 0.0), (400, 64, 0.9, 0.0, 0.0), (260, 8, 1.0, 0.02, 0.0),
+    (350, 24, 0.5, 0.05, 0.2), (64, 3, 0.5, 0.0, 0.0), (65, 64, 1.0, 0.0, 0.0), (1, 1, 0.5, 0.0, 0.0), (700, 33, 0.2, 0.01, 0.0)]
+
+
+def _hists(seeds=(1, 2), shapes=SHAPES, **kw):
+    out = [columns.pair_events(synth.register_events(n_ops=n, n_procs=p, seed=s, busy=busy, info=info, corrupt=corrupt, **kw))
+           for (n, p, busy, info, corrupt) in shapes for s in seeds]
+    assert all(h.n_process <= 64 for h in out), [h.n_process for h in out]      # (a crashed call keeps its slot: new processes take new ones)
+    return out
+
+
+@pytest.mark.parametrize("front,branch", [("plain", False), ("wide", False), ("wide", True), ("compact", True), ("compact", False)])
+def test_every_word_of_the_walk(front, branch):
+    """all shapes in one batch (chunks of different histories, full and ragged last chunks, crashed calls, 1 .. 64 slots)"""
+    assert emu.walk_check(_hists(), 8, twin=True, look=True, branch=branch, front=front) is None
+
+
+def test_without_the_optional_tables():
+    h = _hists(seeds=(3,))
+    assert emu.walk_check(h, 8, twin=False, look=True, front="plain") is None
+    assert emu.walk_check(h, 8, twin=True, look=False, front="plain") is None
+    assert emu.walk_check(h, 0, twin=False, look=False, front="plain") is None          # no rows at all (rules off)
+    assert emu.walk_check(h, 0, twin=False, look=True, branch=False, front="wide") is None   # front records without masks
+
+
+def test_wider_rows():
+    """values up to 30: rows of 16 / 32 entries (the 32-entry instantiation)"""
+    for vmax, vpad in ((9, 16), (30, 32)):
+        h = [columns.pair_events(synth.register_events(n_ops=300, n_procs=24, seed=s, busy=0.6, n_values=vmax + 1)) for s in range(3)]
+        assert max(int(np.asarray(x.as_dict()["a"]).max()) for x in h) == vmax
+        assert emu.walk_check(h, vpad, front="plain") is None
+        assert emu.walk_check(h, vpad, branch=True, front="wide") is None
+
+
+def test_many_twins():
+    """two values only and every process busy: most open writes have a twin, often several"""
+    h = [columns.pair_events(synth.register_events(n_ops=400, n_procs=40, seed=s, busy=1.0, n_values=2)) for s in range(3)]
+    assert emu.walk_check(h, 8, front="plain") is None
+    assert emu.walk_check(h, 8, branch=True, front="compact") is None
