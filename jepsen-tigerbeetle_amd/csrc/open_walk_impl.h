@@ -28,15 +28,31 @@ namespace tbc {
 namespace walk {
 
 constexpr uint32_t kCandCap = 128;          // 64 completions in the chunk + one more call per slot (64 slots)
-constexpr uint32_t kCandWords = 8;          // inv_rank, ret_rank, opidx, f | a, b, cls | slot << 8, prod
+constexpr uint32_t kCandWords = 8;          // inv_rank, ret_rank, opidx, f | a, b, cls | slot << 8 | prod << 16, effect key
 constexpr uint32_t kScanWords = 64;
 WV_HD constexpr uint32_t walk_lds_words() { return kCandCap * kCandWords + kScanWords; }
 
-// m |= cond ? 1 << slot : 0 with a UNIFORM slot: one half of the mask, two vector instructions
+// m |= cond ? 1 << slot : 0 with a UNIFORM slot: one half of the mask, two vector instructions.  (wv::opaque keeps the branch
+// a branch: left alone, the compiler computes both halves and selects -- and turns the row update below, one of VCAP entries
+// chosen by a uniform index, into VCAP x 6 selects per open read: measured, a third of the kernel.)
 WV_DEV void or_slot(uint32_t& lo, uint32_t& hi, bool cond, uint32_t slot) {
-  if (slot < 32u) lo |= cond ? (1u << slot) : 0u;
-  else hi |= cond ? (1u << (slot - 32u)) : 0u;
+  if (slot < 32u) lo = wv::opaque(lo | (cond ? (1u << slot) : 0u));
+  else hi = wv::opaque(hi | (cond ? (1u << (slot - 32u)) : 0u));
 }
+// row[vi] |= cond ? 1 << slot : 0 with a UNIFORM vi: a chain of scalar compares, one entry touched
+template <int V0, int VCAP>
+WV_DEV void or_row(uint32_t (&lo)[VCAP], uint32_t (&hi)[VCAP], uint32_t vi, bool cond, uint32_t slot) {
+  if constexpr (V0 < VCAP) {
+    if (vi == (uint32_t)V0) or_slot(lo[V0], hi[V0], cond, slot);
+    else or_row<V0 + 1, VCAP>(lo, hi, vi, cond, slot);
+  }
+}
+// what "same effect" compares, in one word.  Twin masks are only built under the dominance rules, i.e. for register values
+// 0 .. kMaxRuleValue (tbc_api.hip switches the rules off for anything else): f, a and -- for a cas -- b fit 2 + 15 + 15 bits
+WV_DEV uint32_t effect_key(uint32_t f, int32_t a, int32_t b) {
+  return (f & 3u) | (((uint32_t)a & 0x7FFFu) << 2) | ((f == TBC_F_CAS ? ((uint32_t)b & 0x7FFFu) : 0u) << 17);
+}
+static_assert(kMaxRuleValue < 0x7FFF && TBC_F_READ < 4 && TBC_F_WRITE < 4 && TBC_F_CAS < 4, "effect_key packs f and two rule values into a word");
 
 // VCAP: row entries kept in registers (vpad <= VCAP)
 template <int VCAP>
@@ -107,24 +123,20 @@ WV_DEV void walk_wave(const PackOpenArgs& A, uint32_t wid, uint32_t* lds, uint32
     if (base + j < kCandCap) {
       uint32_t* e = cand + (base + j) * kCandWords;
       e[0] = r.inv_rank; e[1] = r.ret_rank; e[2] = r.opidx; e[3] = r.f;
-      e[4] = (uint32_t)r.a; e[5] = (uint32_t)r.b; e[6] = r.cls | (lane << 8); e[7] = r.prod;
+      e[4] = (uint32_t)r.a; e[5] = (uint32_t)r.b; e[6] = r.cls | (lane << 8) | (r.prod << 16);
+      e[7] = ((r.cls & 2u) && (r.cls & 8u)) ? effect_key(r.f, r.a, r.b) : 0xFFFFFFFFu;      // a live write / cas (no key has all bits set: f < 3)
     }
   }
   wv::barrier();
 
   // ---- B. the candidates once more, one per lane (two sets): what the static twin test asks of them
-  uint32_t c_fk[2] = {0xFFFFFFFFu, 0xFFFFFFFFu}, c_ret[2] = {0u, 0u};
-  int32_t c_a[2] = {0, 0}, c_bb[2] = {0, 0};
+  uint32_t c_key[2] = {0xFFFFFFFFu, 0xFFFFFFFFu}, c_ret[2] = {0u, 0u};
   if (twn) {
     WV_UNROLL
     for (int s = 0; s < 2; s++) {
       const uint32_t idx = lane + 64u * (uint32_t)s;
       const uint32_t* e = cand + (idx < NC ? idx : 0u) * kCandWords;
-      const uint32_t cls = e[6], ff = e[3];
-      const bool wc = idx < NC && (cls & 2u) && (cls & 8u);         // a live write / cas
-      c_fk[s] = wc ? ff : 0xFFFFFFFFu;
-      c_a[s] = (int32_t)e[4];
-      c_bb[s] = ff == TBC_F_CAS ? (int32_t)e[5] : 0;
+      c_key[s] = idx < NC ? e[7] : 0xFFFFFFFFu;
       c_ret[s] = e[1];
     }
   }
@@ -154,26 +166,25 @@ WV_DEV void walk_wave(const PackOpenArgs& A, uint32_t wid, uint32_t* lds, uint32
     const uint32_t* e = cand + t * kCandWords;
     const uint32_t inv = e[0], ret = e[1];
     const uint32_t cs = wv::readfirstlane(e[6]);
-    const uint32_t cls = cs & 0xFFu, slot = cs >> 8;
+    const uint32_t cls = cs & 0xFFu, slot = (cs >> 8) & 0xFFu;
     const bool member = active && inv <= F && F <= ret;             // open at this lane's front (a crashed call: ret = kInf)
     if (cls & 2u) {                                                 // live
       const bool isread = (cls & 16u) != 0u;
       if (!(A.branch_lists && isread)) {                            // in the fronts' lists (branch lists: not the reads)
         uint32_t tw_lo = 0u, tw_hi = 0u;
         if (twn && (cls & 8u)) {
-          const uint32_t f_t = wv::readfirstlane(e[3]);
-          const int32_t a_t = (int32_t)e[4], bb_t = f_t == TBC_F_CAS ? (int32_t)e[5] : 0;
+          const uint32_t key_t = e[7];
           // same effect, completes before t, still open when t is invoked: the same at every front
-          uint64_t s0 = wv::ballot(c_fk[0] == f_t && c_a[0] == a_t && c_bb[0] == bb_t && c_ret[0] < ret && c_ret[0] >= inv);
+          uint64_t s0 = wv::ballot(c_key[0] == key_t && c_ret[0] < ret && c_ret[0] >= inv);
           uint64_t s1 = 0ull;
-          if (NC > 64u) s1 = wv::ballot(c_fk[1] == f_t && c_a[1] == a_t && c_bb[1] == bb_t && c_ret[1] < ret && c_ret[1] >= inv);
+          if (NC > 64u) s1 = wv::ballot(c_key[1] == key_t && c_ret[1] < ret && c_ret[1] >= inv);
           while (s0 | s1) {
             uint32_t u;
             if (s0) { u = (uint32_t)__builtin_ctzll(s0); s0 &= s0 - 1ull; }
             else { u = 64u + (uint32_t)__builtin_ctzll(s1); s1 &= s1 - 1ull; }
             const uint32_t* eu = cand + u * kCandWords;
             const bool mu = eu[0] <= F && F <= eu[1];               // ... and open at THIS front
-            or_slot(tw_lo, tw_hi, mu, wv::readfirstlane(eu[6]) >> 8);
+            or_slot(tw_lo, tw_hi, mu, (wv::readfirstlane(eu[6]) >> 8) & 0xFFu);
           }
         }
         if (member) {
@@ -186,14 +197,11 @@ WV_DEV void walk_wave(const PackOpenArgs& A, uint32_t wid, uint32_t* lds, uint32
       if (isread && rdm) {                                          // open-read masks by value
         const int32_t va = (int32_t)wv::readfirstlane(e[4]);
         const uint32_t vi = rdm_index(va, V);
-        if (vi != 0u || va == TBC_NIL) {
-          WV_UNROLL
-          for (int v = 0; v < VCAP; v++) if (vi == (uint32_t)v) or_slot(mine_lo[v], mine_hi[v], member, slot);
-        }
+        if (vi != 0u || va == TBC_NIL) or_row<0, VCAP>(mine_lo, mine_hi, vi, member, slot);
       }
     }
     if (look && (cls & 6u)) {                                       // who else open here (live, or crashed and a candidate) produces what the completing call needs
-      const uint32_t prod = wv::readfirstlane(e[7]);
+      const uint32_t prod = cs >> 16;
       if (prod != kLookNone) or_slot(pm_lo, pm_hi, member && prod == need, slot);
     }
   }
