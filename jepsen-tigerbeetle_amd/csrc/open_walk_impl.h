@@ -1,21 +1,23 @@
 // open_walk_impl.h -- K1b's front walk with LANE = FRONT (gfx950; mask_words == 1, i.e. at most 64 process slots).
 //
-// What it writes is pack_open.hip's open_walk_kernel<1> word for word (lst / twn / rdm rows / look / tmp; the definitions are
-// in that file's header and tbc_internal.h).  How it gets there is turned round.  open_walk_kernel gives a wavefront 64 fronts
-// and walks them ONE AFTER THE OTHER with lane = process slot: every front costs ~140 vector instructions, and of the 64 lanes
-// each of them drives, the six that hold an open call do something (rocprofv3, round 3: SQ_ACTIVE_INST_VALU 95 % of the
-// kernel's 70 ms per 32,768 histories -- the walk is bound by vector issue and nothing else).  Here a wavefront still owns 64
-// consecutive fronts, but lane = front, and the loop runs over the CANDIDATES: the calls open at some front of the chunk.
-// A process has one call open at a time, so all but the last candidate of a slot complete inside the chunk: at most
-// 64 completions + one call per slot = 128 candidates, ~70 at six calls in flight.  The candidates sit in LDS in slot order
-// (32 B each); iteration t broadcasts candidate t to the 64 lanes and each lane decides for ITS front whether the call is open
-// there (inv <= F <= ret), appends it to its front's list, ors its slot into its read mask / lookahead mask.  Everything that
-// was per-front overhead -- list positions, record addresses, the lookahead word -- is now per lane, i.e. done for 64 fronts by
-// one instruction: ~20 vector instructions per candidate, ~22 per front instead of ~140.
+// What it leaves in HBM is what pack_open.hip's open_walk_kernel<1> + open_dprod_kernel + front_meta_kernel leave, word for
+// word (lst / twn / rdm rows or front records / look; the definitions are in that file's header and tbc_internal.h).  How it
+// gets there is turned round.  open_walk_kernel gives a wavefront 64 fronts and walks them ONE AFTER THE OTHER with lane =
+// process slot: every front costs ~140 vector instructions, and of the 64 lanes each of them drives, the six that hold an open
+// call do something (rocprofv3, round 3: SQ_ACTIVE_INST_VALU 95 % of the kernel's 70 ms per 32,768 histories -- the walk is
+// bound by vector issue and nothing else).  Here a wavefront still owns 64 consecutive fronts, but lane = front, and the loop
+// runs over the CANDIDATES: the calls open at some front of the chunk (plus, for the lookahead's producer distance, those that
+// completed within the seven ranks before it).  A process has one call open at a time, so all but the last candidate of a
+// slot complete inside ranks F_lo - 7 .. F_hi - 1: at most 71 completions + one call per slot = 135 candidates, ~75 at six
+// calls in flight.  The candidates sit in LDS in slot order (32 B each, with what the loop asks of them worked out once, as
+// flag bits); iteration t broadcasts candidate t to the 64 lanes and each lane decides for ITS front whether the call is open
+// there (inv <= F <= ret), appends it to its front's list, ors its slot into its read row / lookahead mask, keeps the nearest
+// producer.  Everything that was per-front overhead -- list positions, record addresses, the lookahead word, the front
+// record's windows -- is per lane, i.e. done for 64 fronts by one instruction.
 //
 // Twin masks (tbc_internal.h): entry (front F, call c) gets the slots of the calls open at F with c's effect that complete
 // before c.  "Same effect, completes earlier, lifetimes overlap" does not depend on the front: with the candidates ALSO held one
-// per lane (two register sets), one ballot per write / cas candidate finds its few static twins, and each of those costs the
+// per lane (three register sets), one ballot per write / cas candidate finds its few static twins, and each of those costs the
 // lanes one membership test.
 //
 // The body is written against wave_env.h like the narrow search kernel, so tests/emu runs it on the CPU (lane-accurate
@@ -27,32 +29,46 @@
 namespace tbc {
 namespace walk {
 
-constexpr uint32_t kCandCap = 128;          // 64 completions in the chunk + one more call per slot (64 slots)
-constexpr uint32_t kCandWords = 8;          // inv_rank, ret_rank, opidx, f | a, b, cls | slot << 8 | prod << 16, effect key
-constexpr uint32_t kScanWords = 64;
-WV_HD constexpr uint32_t walk_lds_words() { return kCandCap * kCandWords + kScanWords; }
+constexpr uint32_t kCandCap = 136;          // 71 completions (ranks F_lo - 7 .. F_hi - 1) + one more call per slot (64 slots), rounded up
+constexpr uint32_t kCandWords = 8;          // inv_rank, ret_rank, opidx, f | slot << 8;  a, b, flags (below), effect key
+constexpr uint32_t kAuxWords = 80;          // the scan of the per-slot counts; later the rank codes of the chunk + 6
+WV_HD constexpr uint32_t walk_lds_words() { return kCandCap * kCandWords + kAuxWords; }
+
+// candidate word 6: what the loop does with the call, decided once when the table is filled
+constexpr uint32_t kCList = 1u;             // live and in the fronts' lists (branch lists: not a read)
+constexpr uint32_t kCTwin = 2u;             // ... and its entries carry a twin mask (a write / cas, twin masks wanted)
+constexpr uint32_t kCRow = 4u;              // a live read whose value has a row entry: bits 4..8 = the entry
+constexpr uint32_t kCLook = 8u;             // produces a register value (bits 24..31): lookahead mask, producer distance
+//                                             bits 12..17 = the process slot
 
 // m |= cond ? 1 << slot : 0 with a UNIFORM slot: one half of the mask, two vector instructions.  (wv::opaque keeps the branch
-// a branch: left alone, the compiler computes both halves and selects -- and turns the row update below, one of VCAP entries
-// chosen by a uniform index, into VCAP x 6 selects per open read: measured, a third of the kernel.)
+// a branch: left alone, the compiler computes both halves and selects.)
 WV_DEV void or_slot(uint32_t& lo, uint32_t& hi, bool cond, uint32_t slot) {
   if (slot < 32u) lo = wv::opaque(lo | (cond ? (1u << slot) : 0u));
   else hi = wv::opaque(hi | (cond ? (1u << (slot - 32u)) : 0u));
-}
-// row[vi] |= cond ? 1 << slot : 0 with a UNIFORM vi: a chain of scalar compares, one entry touched
-template <int V0, int VCAP>
-WV_DEV void or_row(uint32_t (&lo)[VCAP], uint32_t (&hi)[VCAP], uint32_t vi, bool cond, uint32_t slot) {
-  if constexpr (V0 < VCAP) {
-    if (vi == (uint32_t)V0) or_slot(lo[V0], hi[V0], cond, slot);
-    else or_row<V0 + 1, VCAP>(lo, hi, vi, cond, slot);
-  }
 }
 // what "same effect" compares, in one word.  Twin masks are only built under the dominance rules, i.e. for register values
 // 0 .. kMaxRuleValue (tbc_api.hip switches the rules off for anything else): f, a and -- for a cas -- b fit 2 + 15 + 15 bits
 WV_DEV uint32_t effect_key(uint32_t f, int32_t a, int32_t b) {
   return (f & 3u) | (((uint32_t)a & 0x7FFFu) << 2) | ((f == TBC_F_CAS ? ((uint32_t)b & 0x7FFFu) : 0u) << 17);
 }
-static_assert(kMaxRuleValue < 0x7FFF && TBC_F_READ < 4 && TBC_F_WRITE < 4 && TBC_F_CAS < 4, "effect_key packs f and two rule values into a word");
+static_assert(kMaxRuleValue < 0x7FFF && TBC_F_READ < 3 && TBC_F_WRITE < 3 && TBC_F_CAS < 3, "effect_key packs f and two rule values into a word, and no key has all bits set");
+static_assert(kLookNone <= 0xFFu, "the produced value shares a word with the flags");
+
+// the nine bits a compact front record keeps per rank: process slot | read kind << 6 (7 = not a read)
+WV_DEV uint32_t rank_code(uint32_t slot, uint32_t f, int32_t a, uint32_t vpad) {
+  const uint32_t k8 = f == TBC_F_READ ? (rdm_index(a, vpad) & 0xFFu) : 0xFFu;
+  return (slot & 63u) | ((k8 == 0xFFu ? 7u : (k8 & 7u)) << 6);
+}
+
+// row[w] |= cond ? bit : 0 with a UNIFORM w: a chain of scalar compares, one word touched
+template <int W0, int NW>
+WV_DEV void or_word(uint32_t (&row)[NW], uint32_t w, bool cond, uint32_t bit) {
+  if constexpr (W0 < NW) {
+    if (w == (uint32_t)W0) row[W0] = wv::opaque(row[W0] | (cond ? bit : 0u));
+    else or_word<W0 + 1, NW>(row, w, cond, bit);
+  }
+}
 
 // VCAP: row entries kept in registers (vpad <= VCAP)
 template <int VCAP>
@@ -74,21 +90,22 @@ WV_DEV void walk_wave(const PackOpenArgs& A, uint32_t wid, uint32_t* lds, uint32
   uint64_t* twn = A.twn ? A.twn + B->lst_off : nullptr;
   const uint32_t V = A.vpad;
   const uint32_t FW = A.front_words ? A.front_words : V;             // u64 words per front: a plain row, or a front record
-  uint64_t* rdm = (A.rdm && V) ? A.rdm + H->op_off * FW : nullptr;
+  const bool compact = A.front_compact != 0u;                        // the 64 B record, written whole (masks, list location, windows)
+  uint64_t* rdm = (A.rdm && (V || compact)) ? A.rdm + H->op_off * FW : nullptr;
   uint64_t* look = A.look ? A.look + look_off(H->op_off, h, 1) : nullptr;
-  uint32_t* tmp = A.tmp ? A.tmp + H->op_off : nullptr;
   uint32_t* cand = lds;
-  uint32_t* scan = lds + kCandCap * kCandWords;
+  uint32_t* aux = lds + kCandCap * kCandWords;
 
-  // ---- A. lane = process slot: the slot's calls that are open at some front of the chunk are consecutive records -- from the
-  // first that has not completed before F_lo to the last invoked before the chunk's last front
+  // ---- A. lane = process slot: the slot's candidates are consecutive records -- from the first that has not completed before
+  // F_lo (lookahead: F_lo - 7, for the producer distance) to the last invoked before the chunk's last front
+  const uint32_t ret_from = look ? (F_lo >= kLookahead - 1u ? F_lo - (kLookahead - 1u) : 0u) : F_lo;
   uint32_t lo = 0, k = 0;
   if (lane < W) {
     uint32_t l = seg[lane] + 1u, hi = seg[lane + 1] - 1u;          // [l, hi): the slot's calls; hi = its tail sentinel (inv = ret = kInf)
     const uint32_t tail = hi;
     while (l < hi) {
       const uint32_t mid = (l + hi) >> 1;
-      if (rec[mid].ret_rank >= F_lo) hi = mid; else l = mid + 1u;
+      if (rec[mid].ret_rank >= ret_from) hi = mid; else l = mid + 1u;
     }
     lo = l;
     uint32_t i = lo;
@@ -109,9 +126,9 @@ WV_DEV void walk_wave(const PackOpenArgs& A, uint32_t wid, uint32_t* lds, uint32
   // where each slot's candidates start: inclusive scan of k over the lanes (through LDS)
   uint32_t incl = k;
   for (uint32_t d = 1; d < 64u; d <<= 1) {
-    scan[lane] = incl;
+    aux[lane] = incl;
     wv::barrier();
-    const uint32_t add = lane >= d ? scan[lane - d] : 0u;
+    const uint32_t add = lane >= d ? aux[lane - d] : 0u;
     wv::barrier();
     incl += add;
   }
@@ -121,19 +138,28 @@ WV_DEV void walk_wave(const PackOpenArgs& A, uint32_t wid, uint32_t* lds, uint32
   for (uint32_t j = 0; j < k; j++) {
     const Rec r = rec[lo + j];
     if (base + j < kCandCap) {
+      const bool live = (r.cls & 2u) != 0u, isread = (r.cls & 16u) != 0u, wc = (r.cls & 8u) != 0u;
+      const bool in_chunk = r.ret_rank >= F_lo;                     // (else: completed just before the chunk, a producer only)
+      const bool listed = live && in_chunk && !(A.branch_lists && isread);
+      const uint32_t vi = rdm_index(r.a, V);
+      uint32_t fl = (lane << 12) | (r.prod << 24);
+      if (listed) fl |= kCList;
+      if (listed && wc && twn) fl |= kCTwin;
+      if (live && in_chunk && isread && rdm && V && (vi != 0u || r.a == TBC_NIL)) fl |= kCRow | (vi << 4);
+      if (look && (r.cls & 6u) && r.prod != kLookNone) fl |= kCLook;
       uint32_t* e = cand + (base + j) * kCandWords;
-      e[0] = r.inv_rank; e[1] = r.ret_rank; e[2] = r.opidx; e[3] = r.f;
-      e[4] = (uint32_t)r.a; e[5] = (uint32_t)r.b; e[6] = r.cls | (lane << 8) | (r.prod << 16);
-      e[7] = ((r.cls & 2u) && (r.cls & 8u)) ? effect_key(r.f, r.a, r.b) : 0xFFFFFFFFu;      // a live write / cas (no key has all bits set: f < 3)
+      e[0] = r.inv_rank; e[1] = r.ret_rank; e[2] = r.opidx; e[3] = r.f | (lane << 8);
+      e[4] = (uint32_t)r.a; e[5] = (uint32_t)r.b; e[6] = fl;
+      e[7] = (live && wc && in_chunk) ? effect_key(r.f, r.a, r.b) : 0xFFFFFFFFu;
     }
   }
   wv::barrier();
 
-  // ---- B. the candidates once more, one per lane (two sets): what the static twin test asks of them
-  uint32_t c_key[2] = {0xFFFFFFFFu, 0xFFFFFFFFu}, c_ret[2] = {0u, 0u};
+  // ---- B. the candidates once more, one per lane (three sets): what the static twin test asks of them
+  uint32_t c_key[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, c_ret[3] = {0u, 0u, 0u};
   if (twn) {
     WV_UNROLL
-    for (int s = 0; s < 2; s++) {
+    for (int s = 0; s < 3; s++) {
       const uint32_t idx = lane + 64u * (uint32_t)s;
       const uint32_t* e = cand + (idx < NC ? idx : 0u) * kCandWords;
       c_key[s] = idx < NC ? e[7] : 0xFFFFFFFFu;
@@ -145,79 +171,109 @@ WV_DEV void walk_wave(const PackOpenArgs& A, uint32_t wid, uint32_t* lds, uint32
   const uint32_t F = F_lo + lane;
   const bool active = F < F_hi;
   const uint32_t Fc = active ? F : F_hi - 1u;                       // (loads of the idle lanes of the last chunk stay in range)
-  uint32_t pos = off[Fc];
+  const uint32_t pos0 = off[Fc];
+  uint32_t pos = pos0;
   const uint32_t px = A.ret_slot[H->ret_off + Fc];
-  uint32_t need = kLookNone, xprod = kLookNone, di = 0;
-  if (look) {            // the call completing at this front, from the op columns (pack_kernel copied the records from them)
-    const uint32_t x = A.ret_op[H->ret_off + Fc];
-    const uint32_t xf = A.f[H->op_off + x];
-    const int32_t xa = A.a[H->op_off + x], xb = A.b[H->op_off + x];
+  uint32_t need = kLookNone, xprod = kLookNone, di = 0, x = 0, xf = kFNone;
+  int32_t xa = 0;
+  if (look || compact) {     // the call completing at this front, from the op columns (pack_kernel copied the records from them)
+    x = A.ret_op[H->ret_off + Fc];
+    xf = A.f[H->op_off + x];
+    xa = A.a[H->op_off + x];
+  }
+  if (look) {
+    const int32_t xb = A.b[H->op_off + x];
     const uint32_t xinv = A.scratch[H->frame_off + x];
     need = look_need(xf, xa); xprod = look_prod(xf, xa, xb);
     di = F - xinv < 255u ? F - xinv : 255u;
   }
-  uint32_t mine_lo[VCAP], mine_hi[VCAP];
+  uint32_t mine[2 * VCAP];                  // the front's row: entry v = words 2v (slots 0..31) and 2v + 1
   WV_UNROLL
-  for (int v = 0; v < VCAP; v++) { mine_lo[v] = 0u; mine_hi[v] = 0u; }
-  uint32_t pm_lo = 0u, pm_hi = 0u;
+  for (int v = 0; v < 2 * VCAP; v++) mine[v] = 0u;
+  uint32_t pm_lo = 0u, pm_hi = 0u, dmin = 255u;
 
   WV_NOUNROLL
   for (uint32_t t = 0; t < NC; t++) {
     const uint32_t* e = cand + t * kCandWords;
     const uint32_t inv = e[0], ret = e[1];
-    const uint32_t cs = wv::readfirstlane(e[6]);
-    const uint32_t cls = cs & 0xFFu, slot = (cs >> 8) & 0xFFu;
+    const uint32_t fl = wv::readfirstlane(e[6]);
+    const uint32_t slot = (fl >> 12) & 63u;
     const bool member = active && inv <= F && F <= ret;             // open at this lane's front (a crashed call: ret = kInf)
-    if (cls & 2u) {                                                 // live
-      const bool isread = (cls & 16u) != 0u;
-      if (!(A.branch_lists && isread)) {                            // in the fronts' lists (branch lists: not the reads)
-        uint32_t tw_lo = 0u, tw_hi = 0u;
-        if (twn && (cls & 8u)) {
-          const uint32_t key_t = e[7];
-          // same effect, completes before t, still open when t is invoked: the same at every front
-          uint64_t s0 = wv::ballot(c_key[0] == key_t && c_ret[0] < ret && c_ret[0] >= inv);
-          uint64_t s1 = 0ull;
-          if (NC > 64u) s1 = wv::ballot(c_key[1] == key_t && c_ret[1] < ret && c_ret[1] >= inv);
-          while (s0 | s1) {
-            uint32_t u;
-            if (s0) { u = (uint32_t)__builtin_ctzll(s0); s0 &= s0 - 1ull; }
-            else { u = 64u + (uint32_t)__builtin_ctzll(s1); s1 &= s1 - 1ull; }
-            const uint32_t* eu = cand + u * kCandWords;
-            const bool mu = eu[0] <= F && F <= eu[1];               // ... and open at THIS front
-            or_slot(tw_lo, tw_hi, mu, (wv::readfirstlane(eu[6]) >> 8) & 0xFFu);
-          }
-        }
-        if (member) {
-          OpRec o; o.op = e[2]; o.f_slot = e[3] | (slot << 8) | (ret == F ? kAtFront : 0u); o.a = (int32_t)e[4]; o.b = (int32_t)e[5];
-          lst[pos] = o;
-          if (twn) twn[pos] = (uint64_t)tw_lo | ((uint64_t)tw_hi << 32);
-          pos++;
+    if (fl & kCList) {
+      uint32_t tw_lo = 0u, tw_hi = 0u;
+      if (fl & kCTwin) {
+        const uint32_t key_t = e[7];
+        // same effect, completes before t, still open when t is invoked: the same at every front
+        uint64_t s0 = wv::ballot(c_key[0] == key_t && c_ret[0] < ret && c_ret[0] >= inv);
+        uint64_t s1 = 0ull, s2 = 0ull;
+        if (NC > 64u) s1 = wv::ballot(c_key[1] == key_t && c_ret[1] < ret && c_ret[1] >= inv);
+        if (NC > 128u) s2 = wv::ballot(c_key[2] == key_t && c_ret[2] < ret && c_ret[2] >= inv);
+        while (s0 | s1 | s2) {
+          uint32_t u;
+          if (s0) { u = (uint32_t)__builtin_ctzll(s0); s0 &= s0 - 1ull; }
+          else if (s1) { u = 64u + (uint32_t)__builtin_ctzll(s1); s1 &= s1 - 1ull; }
+          else { u = 128u + (uint32_t)__builtin_ctzll(s2); s2 &= s2 - 1ull; }
+          const uint32_t* eu = cand + u * kCandWords;
+          const bool mu = eu[0] <= F && F <= eu[1];                 // ... and open at THIS front
+          or_slot(tw_lo, tw_hi, mu, (wv::readfirstlane(eu[6]) >> 12) & 63u);
         }
       }
-      if (isread && rdm) {                                          // open-read masks by value
-        const int32_t va = (int32_t)wv::readfirstlane(e[4]);
-        const uint32_t vi = rdm_index(va, V);
-        if (vi != 0u || va == TBC_NIL) or_row<0, VCAP>(mine_lo, mine_hi, vi, member, slot);
+      if (member) {
+        OpRec o; o.op = e[2]; o.f_slot = e[3] | (ret == F ? kAtFront : 0u); o.a = (int32_t)e[4]; o.b = (int32_t)e[5];
+        lst[pos] = o;
+        if (twn) twn[pos] = (uint64_t)tw_lo | ((uint64_t)tw_hi << 32);
+        pos++;
       }
     }
-    if (look && (cls & 6u)) {                                       // who else open here (live, or crashed and a candidate) produces what the completing call needs
-      const uint32_t prod = cs >> 16;
-      if (prod != kLookNone) or_slot(pm_lo, pm_hi, member && prod == need, slot);
+    if (fl & kCRow)                                                 // open-read masks by value: one word of one entry
+      or_word<0, 2 * VCAP>(mine, ((fl >> 4) & 31u) * 2u + (slot >> 5), member, 1u << (slot & 31u));
+    if (fl & kCLook) {                 // who else, open here, produces what the completing call needs; how recently such a call was invoked
+      const bool hit = (fl >> 24) == need;
+      or_slot(pm_lo, pm_hi, member && hit, slot);
+      const uint32_t dist = F - inv;                                // (invoked after this front: wraps past kLookahead)
+      if (hit && dist < kLookahead && e[2] != x) dmin = dist < dmin ? dist : dmin;
     }
   }
 
+  // ---- D. the rest of each front's record / row
+  uint64_t w6 = 0ull, w7 = 0ull;
+  if (compact) {           // list location and the window of the next seven ranks (tbc_internal.h), through LDS: codes of the chunk + 6 after
+    aux[lane] = active ? rank_code(px, xf, xa, V) : (7u << 6);
+    if (lane < kFrontCompactRanks - 1u) {
+      const uint32_t G = F_lo + 64u + lane;
+      uint32_t code = 7u << 6;                                      // (past the last rank: slot 0, not a read)
+      if (G < R) {
+        const uint32_t gx = A.ret_op[H->ret_off + G];
+        code = rank_code(A.ret_slot[H->ret_off + G], A.f[H->op_off + gx], A.a[H->op_off + gx], V);
+      }
+      aux[64u + lane] = code;
+    }
+    wv::barrier();
+    WV_UNROLL
+    for (uint32_t l = 0; l < kFrontCompactRanks; l++) w7 |= (uint64_t)aux[lane + l] << (9u * l);
+    const uint32_t nl = pos - pos0, nc = A.ncr[B->off_off + Fc];
+    w6 = (uint64_t)pos0 | ((uint64_t)(nl & 0xFFu) << 32) | ((uint64_t)((nl + nc) & 0xFFFFFFu) << 40);
+  }
   if (!active) return;
   if (rdm) {
-    WV_UNROLL
-    for (int v = 0; v < VCAP; v++) if ((uint32_t)v < V) rdm[(uint64_t)F * FW + (uint32_t)v] = (uint64_t)mine_lo[v] | ((uint64_t)mine_hi[v] << 32);
+    uint64_t* row = rdm + (uint64_t)F * FW;
+    if (compact) {
+      if constexpr (VCAP >= 6) {
+        WV_UNROLL
+        for (int v = 0; v < 6; v++) row[v] = (uint64_t)mine[2 * v] | ((uint64_t)mine[2 * v + 1] << 32);
+      }
+      row[6] = w6; row[7] = w7;
+    } else {
+      WV_UNROLL
+      for (int v = 0; v < VCAP; v++) if ((uint32_t)v < V) row[v] = (uint64_t)mine[2 * v] | ((uint64_t)mine[2 * v + 1] << 32);
+    }
   }
   if (look) {
     uint64_t pm = (uint64_t)pm_lo | ((uint64_t)pm_hi << 32);
     pm &= ~(1ull << (px & 63u));                                    // one call per slot is open at a front: this is the completing call itself
-    const uint64_t w0 = (uint64_t)(px & 0xFFFFu) | (uint64_t)need << 16 | (uint64_t)xprod << 24 | (uint64_t)di << 32 | (255ull << 40);
+    const uint64_t w0 = (uint64_t)(px & 0xFFFFu) | (uint64_t)need << 16 | (uint64_t)xprod << 24 | (uint64_t)di << 32 | ((uint64_t)dmin << 40);
     look[(uint64_t)F * 2u] = w0;
     look[(uint64_t)F * 2u + 1u] = pm;
-    tmp[F] = 255u;
   }
 }
 

@@ -452,7 +452,7 @@ __global__ __launch_bounds__(256) void open_walk_kernel(PackOpenArgs A) {
 
 // ---- the same walk with lane = front (open_walk_impl.h): up to 64 process slots, rows of up to VCAP entries
 template <int VCAP>
-__global__ __launch_bounds__(256) void open_walk_fronts_kernel(PackOpenArgs A) {
+__global__ __launch_bounds__(256, 2) void open_walk_fronts_kernel(PackOpenArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint32_t walk_lds[];
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wv_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -576,8 +576,9 @@ void launch_pack_open(const PackOpenArgs& a, void* stream) {
     case 2: hipLaunchKernelGGL(open_walk_kernel<2>, dim3(wgrid), dim3(256), 0, s, a); break;
     default: hipLaunchKernelGGL(open_walk_kernel<4>, dim3(wgrid), dim3(256), 0, s, a); break;
   }
-  if (a.look) hipLaunchKernelGGL(open_dprod_kernel, dim3(grid), dim3(nt), 0, s, a);
-  if (a.front_words) {
+  // (the walk by front leaves the producer distances in the lookahead records and writes compact front records whole)
+  if (a.look && !by_front) hipLaunchKernelGGL(open_dprod_kernel, dim3(grid), dim3(nt), 0, s, a);
+  if (a.front_words && !(by_front && a.front_compact)) {
     const uint64_t fronts = (uint64_t)n_here * a.chunks_per_hist * 64u;
     hipLaunchKernelGGL(front_meta_kernel, dim3((uint32_t)((fronts + 255) / 256)), dim3(256), 0, s, a);
   }

@@ -1,7 +1,7 @@
 // TEST INFRASTRUCTURE -- NOT PRODUCT CODE.  emu_walk.cpp: runs the front walk with lane = front
 // (jepsen-tigerbeetle_amd/csrc/open_walk_impl.h, the very file hipcc compiles into libtbcheck.so) on the CPU under the
 // wavefront emulator of wave_env_emu.h and compares EVERY WORD it writes -- the fronts' lists, the twin masks, the open-read
-// rows / front records, the lookahead records -- with the tables host_tables.h builds from the definitions.  Its inputs
+// rows / whole compact front records, the lookahead records with their producer distances -- with the tables host_tables.h builds from the definitions.  Its inputs
 // (pack_kernel's per-slot record lists with their sentinels, the ranks, off[] / ret_slot / ret_op) are built here the way
 // pack.hip and open_counts_kernel leave them.  Built by tests/emu with g++; nothing under jepsen-tigerbeetle_amd/ links it.
 #define TBC_EMU 1
@@ -95,15 +95,14 @@ int emu_walk_check(uint32_t nh, const uint64_t* op_off, const uint32_t* n_proces
         if (want_twn && twn[l0 + i] != T.twn[l0 + i]) return fail(2, h, F, i - off[F], twn[l0 + i], T.twn[l0 + i]);
       }
       for (uint32_t v = 0; v < vpad; v++) {
-        const uint64_t want = (compact && v >= 6) ? 0ull : T.rdm[(o + F) * FS + v];      // (words 6, 7 of a compact record: front_meta_kernel's, after the walk)
+        const uint64_t want = T.rdm[(o + F) * FS + v];      // (a compact record whole: words 6, 7 are the list location and the window of the next ranks)
         if (rdm[(o + F) * FW + v] != want) return fail(3, h, F, v, rdm[(o + F) * FW + v], want);
       }
       if (want_look) {
         const uint64_t lo = look_off(o, h, 1);
-        const uint64_t w0 = T.look[lo + (uint64_t)F * 2] | (255ull << 40);               // (the producer distance is open_dprod_kernel's)
+        const uint64_t w0 = T.look[lo + (uint64_t)F * 2];                                  // (with the producer distance)
         if (look[lo + (uint64_t)F * 2] != w0) return fail(4, h, F, 0, look[lo + (uint64_t)F * 2], w0);
         if (look[lo + (uint64_t)F * 2 + 1] != T.look[lo + (uint64_t)F * 2 + 1]) return fail(5, h, F, 0, look[lo + (uint64_t)F * 2 + 1], T.look[lo + (uint64_t)F * 2 + 1]);
-        if (tmp[o + F] != 255u) return fail(6, h, F, 0, tmp[o + F], 255);
       }
     }
     // nothing past the history's last list entry
