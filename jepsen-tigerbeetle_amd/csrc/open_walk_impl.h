@@ -61,13 +61,13 @@ WV_DEV uint32_t rank_code(uint32_t slot, uint32_t f, int32_t a, uint32_t vpad) {
   return (slot & 63u) | ((k8 == 0xFFu ? 7u : (k8 & 7u)) << 6);
 }
 
-// row[w] |= cond ? bit : 0 with a UNIFORM w: a chain of scalar compares, one word touched
-template <int W0, int NW>
-WV_DEV void or_word(uint32_t (&row)[NW], uint32_t w, bool cond, uint32_t bit) {
-  if constexpr (W0 < NW) {
-    if (w == (uint32_t)W0) row[W0] = wv::opaque(row[W0] | (cond ? bit : 0u));
-    else or_word<W0 + 1, NW>(row, w, cond, bit);
-  }
+// A front's open-read row lives in registers as u32x16 vectors (16 words = 8 entries each: entry v = words 2v, slots 0..31, and
+// 2v + 1), the word to touch picked by a UNIFORM index: s_set_gpr_idx, one indexed move each way.  (Plain locals on purpose: as
+// members of a struct the compiler moves them to scratch, and a chain of compares over an array made it copy the whole array.)
+template <int Q>
+WV_DEV void store_entries(const wv::u32x16& r, uint64_t* row, uint32_t n) {       // entries 8Q .. 8Q + 7 below n
+  WV_UNROLL
+  for (int v = 0; v < 8; v++) if ((uint32_t)(8 * Q + v) < n) row[8 * Q + v] = (uint64_t)r[2 * v] | ((uint64_t)r[2 * v + 1] << 32);
 }
 
 // VCAP: row entries kept in registers (vpad <= VCAP)
@@ -187,9 +187,9 @@ WV_DEV void walk_wave(const PackOpenArgs& A, uint32_t wid, uint32_t* lds, uint32
     need = look_need(xf, xa); xprod = look_prod(xf, xa, xb);
     di = F - xinv < 255u ? F - xinv : 255u;
   }
-  uint32_t mine[2 * VCAP];                  // the front's row: entry v = words 2v (slots 0..31) and 2v + 1
+  wv::u32x16 r0, r1, r2, r3;                // the front's row (r1 .. r3: rows of more than 8 entries only)
   WV_UNROLL
-  for (int v = 0; v < 2 * VCAP; v++) mine[v] = 0u;
+  for (int i = 0; i < 16; i++) { r0[i] = 0u; r1[i] = 0u; r2[i] = 0u; r3[i] = 0u; }
   uint32_t pm_lo = 0u, pm_hi = 0u, dmin = 255u;
 
   WV_NOUNROLL
@@ -226,7 +226,14 @@ WV_DEV void walk_wave(const PackOpenArgs& A, uint32_t wid, uint32_t* lds, uint32
       }
     }
     if (fl & kCRow)                                                 // open-read masks by value: one word of one entry
-      or_word<0, 2 * VCAP>(mine, ((fl >> 4) & 31u) * 2u + (slot >> 5), member, 1u << (slot & 31u));
+    {
+      const uint32_t w = ((fl >> 4) & 31u) * 2u + (slot >> 5), bit = member ? (1u << (slot & 31u)) : 0u;
+      if constexpr (VCAP <= 8) r0[w & 15u] |= bit;
+      else {
+        const uint32_t q = w >> 4;
+        if (q == 0u) r0[w & 15u] |= bit; else if (q == 1u) r1[w & 15u] |= bit; else if (q == 2u) r2[w & 15u] |= bit; else r3[w & 15u] |= bit;
+      }
+    }
     if (fl & kCLook) {                 // who else, open here, produces what the completing call needs; how recently such a call was invoked
       const bool hit = (fl >> 24) == need;
       or_slot(pm_lo, pm_hi, member && hit, slot);
@@ -257,16 +264,10 @@ WV_DEV void walk_wave(const PackOpenArgs& A, uint32_t wid, uint32_t* lds, uint32
   if (!active) return;
   if (rdm) {
     uint64_t* row = rdm + (uint64_t)F * FW;
-    if (compact) {
-      if constexpr (VCAP >= 6) {
-        WV_UNROLL
-        for (int v = 0; v < 6; v++) row[v] = (uint64_t)mine[2 * v] | ((uint64_t)mine[2 * v + 1] << 32);
-      }
-      row[6] = w6; row[7] = w7;
-    } else {
-      WV_UNROLL
-      for (int v = 0; v < VCAP; v++) if ((uint32_t)v < V) row[v] = (uint64_t)mine[2 * v] | ((uint64_t)mine[2 * v + 1] << 32);
-    }
+    const uint32_t n_row = compact ? 6u : V;
+    store_entries<0>(r0, row, n_row);
+    if constexpr (VCAP > 8) { store_entries<1>(r1, row, n_row); store_entries<2>(r2, row, n_row); store_entries<3>(r3, row, n_row); }
+    if (compact) { row[6] = w6; row[7] = w7; }
   }
   if (look) {
     uint64_t pm = (uint64_t)pm_lo | ((uint64_t)pm_hi << 32);

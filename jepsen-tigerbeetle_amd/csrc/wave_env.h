@@ -15,6 +15,7 @@
 #include <cstdint>
 
 #define WV_DEV __device__ __forceinline__
+#define WV_MEM __device__ __forceinline__          /* the same for member functions */
 #define WV_HD __host__ __device__
 #define WV_GLOBAL __attribute__((address_space(1)))
 #define WV_LDS __attribute__((address_space(3)))
@@ -24,6 +25,9 @@
 namespace wv {
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+// register arrays indexed by a UNIFORM index (s_set_gpr_idx: one indexed move each way, no select chain)
+typedef uint32_t u32x16 __attribute__((vector_size(64)));
+typedef uint32_t u32x32 __attribute__((vector_size(128)));
 typedef WV_GLOBAL uint64_t gu64;
 typedef WV_GLOBAL uint32_t gu32;
 

@@ -23,6 +23,7 @@
 #define __device__
 #endif
 #define WV_DEV static inline
+#define WV_MEM inline
 #define WV_HD
 #define WV_GLOBAL
 #define WV_LDS
@@ -32,6 +33,8 @@
 namespace wv {
 
 struct u32x4 { uint32_t x, y, z, w; };
+typedef uint32_t u32x16 __attribute__((vector_size(64)));
+typedef uint32_t u32x32 __attribute__((vector_size(128)));
 typedef uint64_t gu64;
 typedef uint32_t gu32;
 
