@@ -12,6 +12,8 @@
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <system_error>
+#include <thread>
 #include <vector>
 #include "tbc_internal.h"
 
@@ -432,6 +434,31 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
   uint64_t boff_n = 0, bocc_n = 0, blst_n = 0, bstack_n = 0, btab_n = 0;
   std::vector<uint32_t> rank_scratch;
   uint64_t rec_n = 0, seg_n = 0, bm_n = 0, frame_n = 0, tab_n = 0;
+  // how many entries each history's per-front lists hold: a pass over the history's events each (~50 us for a 10k-op
+  // history -- most of what creating a batch of 32,768 costs on one thread), so the histories are dealt to the host's threads
+  std::vector<uint32_t> list_caps;
+  if (beam) {
+    list_caps.assign(nh, 0u);
+    const bool branch = (B->rules & kRuleBranch) != 0;
+    const auto caps_of = [&](uint32_t h0, uint32_t h1) {
+      std::vector<uint32_t> scratch;
+      for (uint32_t h = h0; h < h1; h++) {
+        const uint64_t n = desc->op_off[h + 1] - desc->op_off[h];
+        list_caps[h] = (uint32_t)std::min<uint64_t>(0xFFFFFFF0ull, open_list_entries(desc->cols, desc->op_off[h], n, desc->n_events[h], std::max(1u, desc->n_process[h]), scratch, branch));
+      }
+    };
+    uint32_t nt = std::min<uint32_t>(std::min<uint32_t>(16u, std::max(1u, std::thread::hardware_concurrency())), nh / 256u);
+    if (nt <= 1) caps_of(0, nh);
+    else {
+      std::vector<std::thread> pool;
+      try {
+        for (uint32_t t = 0; t < nt; t++) pool.emplace_back(caps_of, (uint32_t)((uint64_t)nh * t / nt), (uint32_t)((uint64_t)nh * (t + 1) / nt));
+      } catch (const std::system_error&) {}          // fewer threads than asked for: the rest is done here
+      const uint32_t started = (uint32_t)pool.size();
+      if (started < nt) caps_of((uint32_t)((uint64_t)nh * started / nt), nh);
+      for (auto& th : pool) th.join();
+    }
+  }
   for (uint32_t h = 0; h < nh; h++) {
     Hist& H = B->hist[h];
     std::memset(&H, 0, sizeof H);
@@ -462,7 +489,7 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
       Q.tab_log2 = blg;
       Q.off_off = boff_n; boff_n += n + 2;
       Q.occ_off = bocc_n; bocc_n += (n + 1) * B->mask_words;
-      Q.lst_cap = (uint32_t)std::min<uint64_t>(0xFFFFFFF0ull, open_list_entries(desc->cols, H.op_off, n, H.n_events, H.n_slots, rank_scratch, (B->rules & kRuleBranch) != 0));
+      Q.lst_cap = list_caps[h];
       Q.lst_off = blst_n; blst_n += Q.lst_cap;
       Q.stack_off = bstack_n; bstack_n += (1ull << blg);
       Q.tab_off = btab_n; btab_n += (1ull << blg);
@@ -507,11 +534,13 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
     if (B->lanes) { B->d_rdm.release(); if ((s = B->d_rdm.alloc(T * B->front_words()))) return s; }
     if (B->lookahead && ((s = B->d_look.alloc(look_words(T, nh, B->mask_words))) || (s = B->d_looktmp.alloc(T)) ||
                          (s = B->d_dstack.alloc(bstack_n)))) return s;
-    // growth pool: 10 % of the visited-set arena (a history that outgrows its table and finds the pool empty is run again from a scratch arena), at least room for one history to grow twice (4x, then 16x: keys, parents, two stacks, slot translation), at most 32 GiB
+    // growth pool: 30 % of the visited-set arena -- 10 % for the big quiet batches that run several histories per wavefront, whose sets
+    // rarely grow (a history that outgrows its table and finds the pool empty is run again from a scratch arena: at 32 calls in
+    // flight a 10 % pool cost 22 s of such retries per 2,048 histories) --, at least room for one history to grow twice (4x, then 16x: keys, parents, two stacks, slot translation), at most 32 GiB
     {
       uint64_t biggest = 0;
       for (uint32_t h = 0; h < nh; h++) biggest = std::max<uint64_t>(biggest, 1ull << B->bh[h].tab_log2);
-      uint64_t words = std::max<uint64_t>(btab_n * EW / 10, biggest * (4 + 16 + 4) * (EW + 1));
+      uint64_t words = std::max<uint64_t>(btab_n * EW * (B->lanes ? 1u : 3u) / 10, biggest * (4 + 16 + 4) * (EW + 1));
       words = std::min<uint64_t>(words, (32ull << 30) / 8);
       if (B->sweep) words = 1;
       if ((s = B->d_pool.alloc(words))) return s;
