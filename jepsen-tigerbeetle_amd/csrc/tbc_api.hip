@@ -12,8 +12,6 @@
 #include <cstring>
 #include <mutex>
 #include <new>
-#include <system_error>
-#include <thread>
 #include <vector>
 #include "tbc_internal.h"
 
@@ -434,29 +432,16 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
   uint64_t boff_n = 0, bocc_n = 0, blst_n = 0, bstack_n = 0, btab_n = 0;
   std::vector<uint32_t> rank_scratch;
   uint64_t rec_n = 0, seg_n = 0, bm_n = 0, frame_n = 0, tab_n = 0;
-  // how many entries each history's per-front lists hold: a pass over the history's events each (~50 us for a 10k-op
-  // history -- most of what creating a batch of 32,768 costs on one thread), so the histories are dealt to the host's threads
+  // how many entries each history's per-front lists hold: a pass over the history's events each.  (On one thread: dealing the
+  // histories to 4 or 16 host threads made tbc_batch_create SLOWER, 2.3 -> 3.3-3.9 s for 32,768 histories --
+  // profiles/r03_create_threads_ab.log; the time is in the allocations and the copies, not here.)
   std::vector<uint32_t> list_caps;
   if (beam) {
     list_caps.assign(nh, 0u);
     const bool branch = (B->rules & kRuleBranch) != 0;
-    const auto caps_of = [&](uint32_t h0, uint32_t h1) {
-      std::vector<uint32_t> scratch;
-      for (uint32_t h = h0; h < h1; h++) {
-        const uint64_t n = desc->op_off[h + 1] - desc->op_off[h];
-        list_caps[h] = (uint32_t)std::min<uint64_t>(0xFFFFFFF0ull, open_list_entries(desc->cols, desc->op_off[h], n, desc->n_events[h], std::max(1u, desc->n_process[h]), scratch, branch));
-      }
-    };
-    uint32_t nt = std::min<uint32_t>(std::min<uint32_t>(16u, std::max(1u, std::thread::hardware_concurrency())), nh / 256u);
-    if (nt <= 1) caps_of(0, nh);
-    else {
-      std::vector<std::thread> pool;
-      try {
-        for (uint32_t t = 0; t < nt; t++) pool.emplace_back(caps_of, (uint32_t)((uint64_t)nh * t / nt), (uint32_t)((uint64_t)nh * (t + 1) / nt));
-      } catch (const std::system_error&) {}          // fewer threads than asked for: the rest is done here
-      const uint32_t started = (uint32_t)pool.size();
-      if (started < nt) caps_of((uint32_t)((uint64_t)nh * started / nt), nh);
-      for (auto& th : pool) th.join();
+    for (uint32_t h = 0; h < nh; h++) {
+      const uint64_t n = desc->op_off[h + 1] - desc->op_off[h];
+      list_caps[h] = (uint32_t)std::min<uint64_t>(0xFFFFFFF0ull, open_list_entries(desc->cols, desc->op_off[h], n, desc->n_events[h], std::max(1u, desc->n_process[h]), rank_scratch, branch));
     }
   }
   for (uint32_t h = 0; h < nh; h++) {
