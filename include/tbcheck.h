@@ -333,8 +333,8 @@ tbc_status tbc_batch_last_timing(const tbc_batch* b, uint64_t ns[4]);
  * per key group (reference: src/tigerbeetle/checker.clj:60-78 hands each key's sub-history to the wrapped
  * checker).  Batches that run several histories per wavefront take the whole GPU for their search and the
  * library gives those searches the device one at a time, in launch order, through a device-side event; the
- * init and pack of the next batch run beside the search of the previous one (measured: 2 x 24,576 histories
- * in flight, 183k histories/s against 144k one batch after the other).  ns = how long the last run's search
+ * init and pack of the next batch run beside the search of the previous one (measured: 2 x 32,768 histories
+ * in flight, 258k histories/s against 204k one batch after the other).  ns = how long the last run's search
  * waited for its turn (not counted in ns[2] of tbc_batch_last_timing). */
 tbc_status tbc_batch_last_turn_wait(const tbc_batch* b, uint64_t* ns);
 /* sum of tbc_counters over the last run (probes, visited ...) */
