@@ -5,7 +5,12 @@
              cas-register histories  (BASELINE.json `metric`, configs[1])
   step     : one pass of the hot path (pack kernel + WGL search kernel + verdict
              read-back) over one batch of B independent histories per GPU whose
-             op columns are already resident in HBM (C-ABI tbc_batch_run)
+             op columns are already resident in HBM (C-ABI tbc_batch_run).  --in-flight F (default 2)
+             resident batches per GPU take the steps in turn, each on its own host thread and stream:
+             step i is a pass over batch i % F, and the passes of different batches overlap (one
+             batch's init + pack beside another's search; the library runs the searches one at a
+             time).  value = B x K / the time K steps took; extra.one_batch_at_a_time is the same
+             measurement with nothing else in flight
   N > 1    : one process per GPU (torch.distributed / RCCL for the barrier and the
              max-over-ranks clock only); histories are independent units, so they
              are sharded across ranks with NO data-path collective -- weak scaling
@@ -14,7 +19,10 @@
              batch --, wgl_beam_kernel, or wgl_search_kernel at --width 1), HBM bound.  achieved = algorithmic bytes per launch
              (16 B per visited-set probe that finds a duplicate,
              32 B per probe that inserts a new config) / the kernel's average
-             duration, measured with HIP events on the library's own stream
+             duration, measured with HIP events on the pass's own stream (from the moment the search
+             has the device to its end: with two batches in flight that is the search beside the other
+             batch's pack); traffic = FETCH_SIZE + WRITE_SIZE of the committed rocprofv3 passes
+             (profiles/r03_traffic.json), copied only if kernel sources and configuration match
   cpu_baseline : the CPU restatement of the same search (oracle/wgl_window.c, "port") on a bounded
              sample of the same histories: on all host cores (pthread pool, oracle/many.c) = `value`,
              and on one thread (`single_thread`)
