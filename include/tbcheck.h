@@ -486,6 +486,13 @@ int32_t tbc_device_count(void);         /* gfx950 devices visible; 0 if none    
 /* diagnostics: with TBC_DEBUG=1 in the environment the kernels mirror their progress into
  * host-mapped words; this copies up to n (<= 64) of them.  Returns 0 when disabled. */
 int tbc_debug_peek(uint32_t* out, uint32_t n);
+/* Environment switches, read at launch time -- for experiments and A/B tests, never needed for correct results:
+ *   TBC_OPEN_WALK=slots           build the per-front tables with lane = process slot for batches of <= 64
+ *                                 slots too (default: lane = front, open_walk_impl.h); same tables either way
+ *   TBC_NARROW_WAVES_PER_SIMD=n   wavefronts per SIMD the several-histories-per-wavefront search is launched at
+ *                                 (default 4, the build's maximum)
+ *   TBC_SWEEP=0|1, TBC_SWEEP_SEG=n  never / whenever possible take the level sweep; its segment length
+ *   TBC_DEBUG=1, TBC_SYNC_EACH=1  progress words (above), a traced synchronisation after every launch */
 
 #ifdef __cplusplus
 }
