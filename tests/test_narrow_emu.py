@@ -174,3 +174,15 @@ def test_groups_take_more_work_as_they_finish(L, waves):
              for (n, p, info, corrupt, busy) in SHAPES for s in range(3)]
     compare(hists, CAS, L, tag="refill", pool_words=4_000_000, max_waves=waves)
     compare(hists[:20], CAS, L, tag="refill-small-tables", pool_words=4_000_000, max_waves=1, entries_per_op=1)
+
+
+def test_the_bench_configuration_at_full_size():
+    """BASELINE.json configs[1] as bench.py runs it: 10k-invocation / 64-process cas-register histories at 10 % duty, 8 lanes per
+    history, compact front records, branch lists, first visited sets of 4 entries per op, no witness -- 24 histories (three
+    wavefronts' worth, two of them waiting on the queue) against the oracle's schedule, every counter."""
+    hists = synth.register_ops_many(range(7000, 7024), n_ops=10000, n_procs=64, busy=0.1, info=0.0)
+    got = compare(hists, CAS, 8, tag="bench", entries_per_op=4, pool_words=8_000_000, want_witness=False, max_waves=1)
+    assert all(g["valid"] == 1 for g in got) and sum(g["probes"] for g in got) > 200_000
+    bad = [columns.pair_events(synth.register_events(n_ops=10000, n_procs=64, seed=s, busy=0.1, corrupt=0.5)) for s in (12345, 12346)]
+    got = compare(bad, CAS, 8, tag="bench-invalid", entries_per_op=4, pool_words=8_000_000, want_witness=False)
+    assert all(g["valid"] == 0 for g in got)

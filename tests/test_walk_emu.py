@@ -48,3 +48,12 @@ def test_many_twins():
     h = [columns.pair_events(synth.register_events(n_ops=400, n_procs=40, seed=s, busy=1.0, n_values=2)) for s in range(3)]
     assert emu.walk_check(h, 8, front="plain") is None
     assert emu.walk_check(h, 8, branch=True, front="compact") is None
+
+
+def test_full_size_histories():
+    """BASELINE.json configs[1]: 10k invocations / 64 processes (the bench's histories, 115 chunks each), every table format"""
+    h = synth.register_ops_many(range(7000, 7006), n_ops=10000, n_procs=64, busy=0.1, info=0.0)
+    busy = synth.register_ops_many(range(7100, 7102), n_ops=10000, n_procs=64, busy=0.5, info=0.0)      # ~32 calls in flight
+    assert emu.walk_check(h, 8, branch=True, front="compact") is None
+    assert emu.walk_check(h + busy, 8, branch=False, front="plain") is None
+    assert emu.walk_check(busy, 8, branch=True, front="wide") is None
