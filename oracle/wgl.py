@@ -33,7 +33,7 @@ class OracleResult(C.Structure):
 
 def build(force: bool = False) -> str:
     so = os.path.join(_HERE, "liboracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("wgl_ref.c", "wgl_window.c", "linear_ref.c", "wgl_beam.c", "sweep_ref.c", "many.c", "oracle_model.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("wgl_ref.c", "wgl_window.c", "linear_ref.c", "wgl_beam.c", "wgl_count.c", "sweep_ref.c", "many.c", "oracle_model.h")]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s", "liboracle.so"])
     return so
@@ -43,7 +43,7 @@ def lib():
     global _LIB
     if _LIB is None:
         _LIB = C.CDLL(build())
-        for fn in (_LIB.wgl_ref_check, _LIB.wgl_window_check, _LIB.linear_ref_check, _LIB.wgl_beam_check, _LIB.wgl_beam_check_rp, _LIB.sweep_ref_check):
+        for fn in (_LIB.wgl_ref_check, _LIB.wgl_window_check, _LIB.linear_ref_check, _LIB.wgl_beam_check, _LIB.wgl_beam_check_rp, _LIB.sweep_ref_check, _LIB.wgl_count_check):
             fn.restype = C.c_int
     return _LIB
 
@@ -340,3 +340,48 @@ def sweep_relations(ops, model, seg_target, n_dom, max_segs, rank=0, world=1, re
     finally:
         L.sweep_set_export(None, C.c_uint32(0), C.c_uint32(0), C.c_uint32(1))
     return buf
+
+
+class CountStats(C.Structure):
+    _fields_ = [("iterations", C.c_uint64), ("probes", C.c_uint64), ("visited", C.c_uint64),
+                ("expanded", C.c_uint64), ("max_stack", C.c_uint64), ("rounds", C.c_uint64),
+                ("dominated", C.c_uint64), ("hot", C.c_uint64), ("class_steps", C.c_uint64),
+                ("n_slots", C.c_uint32), ("n_classes", C.c_uint32), ("count_bits", C.c_uint32), ("n_crashed", C.c_uint32)]
+
+
+def check_count(ops, model, width=4, max_probes=0, want_witness=True, round_pairs=64, lookahead=True, want_slots=False, relaxed=False, target=0):
+    """The COUNT FORM of the wide schedule (wgl_count.c): crashed calls as a count per effect class, process slots
+    re-used, the lazy ("hot") rule and the Pareto rule.  Register / cas-register with values 0..30 only; returns None
+    when the form does not apply (other models, values out of range, more than 128 bits of counts)."""
+    n = len(ops["f"])
+    f = np.ascontiguousarray(ops["f"], np.uint8)
+    a = np.ascontiguousarray(ops["a"], np.int32)
+    b = np.ascontiguousarray(ops["b"], np.int32)
+    inv = np.ascontiguousarray(ops["inv_pos"], np.uint32)
+    ret = np.ascontiguousarray(ops["ret_pos"], np.uint32)
+    proc = np.ascontiguousarray(ops["process"], np.int32)
+    m, keep = _model(model)
+    res, st = OracleResult(), CountStats()
+    wit = np.zeros(max(n, 1), np.uint32)
+    slots = np.zeros(max(n, 1), np.uint32)
+    L = lib()
+    L.wgl_count_set_slots_out(_p(slots, C.c_uint32) if want_slots else None)
+    try:
+        rc = L.wgl_count_check(C.c_uint32(n), _p(f, C.c_uint8), _p(a, C.c_int32), _p(b, C.c_int32),
+                               _p(proc, C.c_int32), C.c_uint32(int(ops["n_process"])), _p(inv, C.c_uint32),
+                               _p(ret, C.c_uint32), C.byref(m), C.c_uint32(width), C.c_uint32(round_pairs),
+                               C.c_uint64(max_probes), C.c_uint32(1 if lookahead else 0), C.c_uint32(1 if relaxed else 0), C.c_uint32(target),
+                               _p(wit, C.c_uint32) if want_witness else None, C.byref(res), C.byref(st))
+    finally:
+        L.wgl_count_set_slots_out(None)
+    if rc == 3:
+        return None
+    if rc != 0:
+        raise ValueError(f"oracle rejected history (rc={rc})")
+    out = {k: getattr(res, k) for k, _ in OracleResult._fields_}
+    out["witness"] = wit[:res.n_witness].copy() if (res.valid == 1 and want_witness) else None
+    for name, _ in CountStats._fields_:
+        out[name] = getattr(st, name)
+    if want_slots:
+        out["slots"] = slots[:n].copy()
+    return out
