@@ -232,7 +232,16 @@ typedef struct tbc_opts {
  * possible); the search then branches over :write / :cas only.  Twin rule: of several open,
  * not yet linearized calls with the same effect the one completing first goes first.  Both
  * need register values in 0..30; a history outside that range is searched without them. */
-enum { TBC_DOM_NO_EAGER_READS = 1u, TBC_DOM_NO_TWIN_RULE = 2u };
+enum { TBC_DOM_NO_EAGER_READS = 1u, TBC_DOM_NO_TWIN_RULE = 2u,
+       /* COUNT FORM (knossos.competition on a register / cas-register history with crashed calls, both rules above on): crashed
+        * calls of one effect are linearized in invocation order, so a config keeps a COUNT per effect class instead of a mask bit
+        * per crashed call, process slots are re-used, a crashed call is only linearized right before a call that observes its
+        * value, and a config that has used no fewer crashed calls of any class than a visited one with the same (front, mask,
+        * state) is dropped.  A history the exact search does not decide within 32 probes per op is first refuted with every
+        * class an unlimited supply (a superset of the linearizations), then the prefix before the refuted completion is
+        * linearized: verdict and failing op are exact, :configs of such a verdict is empty.  Set = keep one mask bit per
+        * crashed call (the published form). */
+       TBC_DOM_NO_COUNT_FORM = 4u };
 
 /* ------------------------------------------------------------------ result */
 enum { TBC_VALID = 1, TBC_INVALID = 0, TBC_UNKNOWN = -1 };

@@ -72,6 +72,9 @@ __global__ __launch_bounds__(1024, 6) void pack_kernel(PackArgs A) {
   for (uint32_t h = A.h0 + blockIdx.x; h < A.n_hist; h += gridDim.x) {
     Hist* H = &A.hist[h];
     const uint32_t n = H->n_ops, W = H->n_slots, E = H->n_events;
+    // count form (tbc_internal.h, kRuleCount): the process column holds re-used slots and a crashed call holds none -- it gets its
+    // ranks here and nothing else (no place in a slot's record list: the classes of crashed calls are the host's to build)
+    const bool cf = (H->flags & kHistCount) != 0u;
     const uint8_t* f = A.f + H->op_off;
     const int32_t* a = A.a + H->op_off;
     const int32_t* b = A.b + H->op_off;
@@ -109,13 +112,14 @@ __global__ __launch_bounds__(1024, 6) void pack_kernel(PackArgs A) {
         if (i >= n) continue;
         const uint32_t iv = ivs[k], rt = rts[k];
         const int32_t p = ps[k];
-        bool bad = iv >= E || p < 0 || (uint32_t)p >= W || (i > 0 && pvs[k] >= iv);
+        const bool slotless = cf && rt == TBC_POS_CRASHED;
+        bool bad = iv >= E || (!slotless && (p < 0 || (uint32_t)p >= W)) || (i > 0 && pvs[k] >= iv);
         if (rt != TBC_POS_CRASHED) bad = bad || rt <= iv || rt >= E;
         if (bad) { atomicOr(&s_err, (uint32_t)TBC_ERR_BAD_HISTORY); continue; }
         if (!(A.model_kind == TBC_MODEL_MULTI_REGISTER ? (fs[k] == TBC_F_TXN && txn_ok(A, as[k], bs[k]))
                                                       : op_ok_for_model(A.model_kind, fs[k], as[k], A.n_classes))) { atomicOr(&s_err, 0x100u | (uint32_t)TBC_ERR_MODEL); continue; }
         if (rt != TBC_POS_CRASHED) { atomicOr(&bm[rt >> 5], 1u << (rt & 31)); atomicAdd(&s_done, 1u); }
-        atomicAdd(&s_cnt[p], 1u);
+        if (!slotless) atomicAdd(&s_cnt[p], 1u);
       }
     }
     __syncthreads();
@@ -238,12 +242,15 @@ __global__ __launch_bounds__(1024, 6) void pack_kernel(PackArgs A) {
     // requested before this one is worked on.
     if (tid < 64) {
       const uint32_t lane = tid;
-      uint32_t p_next = lane < n ? (uint32_t)proc[lane] : 0xFFFFFFFFu;
+      const auto slot_of = [&](uint32_t i) -> uint32_t {            // 0xFFFFFFFF past the end / for a slotless call: equal to no process
+        return (i < n && !(cf && ret[i] == TBC_POS_CRASHED)) ? (uint32_t)proc[i] : 0xFFFFFFFFu;
+      };
+      uint32_t p_next = slot_of(lane);
       for (uint32_t base = 0; base < n; base += 64) {
         const uint32_t i = base + lane;
-        const bool valid = i < n;
-        const uint32_t p = p_next;                                   // 0xFFFFFFFF past the end: equal to no process
-        p_next = i + 64u < n ? (uint32_t)proc[i + 64u] : 0xFFFFFFFFu;
+        const uint32_t p = p_next;
+        const bool valid = p != 0xFFFFFFFFu;
+        p_next = slot_of(i + 64u);
         uint32_t before = 0;
 #pragma unroll 8
         for (uint32_t l = 0; l < 64; l++) {
@@ -251,6 +258,7 @@ __global__ __launch_bounds__(1024, 6) void pack_kernel(PackArgs A) {
           before += (pl == p && l < lane) ? 1u : 0u;
         }
         if (valid) sc_dst[i] = s_seg[p] + 1u + __hip_atomic_load(&s_cnt[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + before;
+        else if (i < n) sc_dst[i] = kInf;                           // slotless: no record
         __builtin_amdgcn_wave_barrier();
         if (valid) atomicAdd(&s_cnt[p], 1u);
         __builtin_amdgcn_wave_barrier();
@@ -272,7 +280,7 @@ __global__ __launch_bounds__(1024, 6) void pack_kernel(PackArgs A) {
         dst[k] = in ? ld_agent(&sc_dst[i]) : 0u;
       }
 #pragma unroll
-      for (uint32_t k = 0; k < 4; k++) if (i0 + k * NT < n) rec[dst[k]] = r[k];
+      for (uint32_t k = 0; k < 4; k++) if (i0 + k * NT < n && dst[k] != kInf) rec[dst[k]] = r[k];
     }
     for (uint32_t p = tid; p < W; p += NT) {
       Rec hd; hd.inv_rank = 0; hd.ret_rank = 0; hd.opidx = kInf; hd.f = kFNone; hd.a = 0; hd.b = 0; hd.cls = 0; hd.prod = kLookNone;
@@ -291,6 +299,7 @@ __global__ __launch_bounds__(1024, 6) void pack_kernel(PackArgs A) {
       for (uint32_t k = 0; k < 4; k++) {
         const uint32_t i = i0 + k * NT;
         d[k] = i < n ? ld_agent(&sc_dst[i]) : 1u;           // (record 0 of the history is a head sentinel: d - 1 stays in range)
+        if (d[k] == kInf) d[k] = 1u;                        // slotless (record 0's successor has no predecessor call: never an error)
         mine[k] = i < n ? sc_inv[i] : 0u;
       }
 #pragma unroll

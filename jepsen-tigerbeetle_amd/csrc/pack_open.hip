@@ -96,6 +96,9 @@ __global__ __launch_bounds__(1024) void open_counts_kernel(PackOpenArgs A) {
       if (tid == 0) { B->status = 0; B->n_crashed = 0; }
       continue;
     }
+    // count form: crashed calls are not candidates one by one -- their classes (crashed[], cmem[]) are built by the host when the
+    // inputs become resident, and count_fronts_kernel below says how many classes each front can draw on
+    const bool cf = (H->flags & kHistCount) != 0u;
     const uint8_t* f = A.f + H->op_off;
     const int32_t* a = A.a + H->op_off;
     const int32_t* b = A.b + H->op_off;
@@ -133,7 +136,7 @@ __global__ __launch_bounds__(1024) void open_counts_kernel(PackOpenArgs A) {
       for (uint32_t k = 0; k < 4; k++) {
         if (i0 + k * NT >= n) continue;
         if (rr[k] == kInf) {
-          if (ir[k] < R && !nilread[k]) atomicAdd(&ncr[ir[k]], 1u);
+          if (!cf && ir[k] < R && !nilread[k]) atomicAdd(&ncr[ir[k]], 1u);
         } else if (!(A.branch_lists && isread[k])) {
           atomicAdd(&off[ir[k]], 1u);
         }
@@ -209,7 +212,10 @@ __global__ __launch_bounds__(1024) void open_counts_kernel(PackOpenArgs A) {
       continue;
     }
     // D: crashed calls in invocation order (stable compaction)
-    {
+    if (cf) {
+      if (tid == 0) { B->n_crashed = 0; B->status = 0; }
+      __syncthreads();
+    } else {
       const uint32_t chunk = (n + NT - 1) / NT;
       const uint32_t lo = min(tid * chunk, n), hi = min(lo + chunk, n);
       // which of this thread's ops are crashed candidates: one bit each (a chunk is at most 64 ops, else the slow way)
@@ -515,6 +521,36 @@ __global__ __launch_bounds__(1024) void open_dprod_kernel(PackOpenArgs A) {
   }
 }
 
+// ---- count form (tbc_internal.h, kRuleCount): what the fronts need of the classes of crashed calls.  One workgroup per history:
+//   ncr[F]   = classes with a member invoked by front F (the classes are in order of their first invocation)
+//   look[t]  bit 48 of word 0: a crashed call that produces the value the call completing at t needs was invoked by then (the
+//            lookahead takes such a producer as available whatever the counts: conservative, a dead config is dead)
+__global__ __launch_bounds__(256) void count_fronts_kernel(PackOpenArgs A) {
+  const uint32_t NT = blockDim.x, tid = threadIdx.x, LW = 1u + A.mask_words;
+  for (uint32_t h = A.h0 + blockIdx.x; h < A.n_hist; h += gridDim.x) {
+    const Hist* H = &A.hist[h];
+    const BeamHist* B = &A.bh[h];
+    const uint32_t R = H->n_ret, nc = B->n_classes;
+    if (!(H->flags & kHistCount) || H->status != 0 || B->status != 0 || R == 0 || nc == 0) continue;
+    const OpRec* cls = A.crashed + H->op_off;
+    const uint64_t* cmem = A.cmem + B->cmem_off;
+    uint32_t* ncr = A.ncr + B->off_off;
+    uint64_t* look = A.look ? A.look + look_off(H->op_off, h, A.mask_words) : nullptr;
+    for (uint32_t F = tid; F < R; F += NT) {
+      const uint32_t need = look ? (uint32_t)(look[(uint64_t)F * LW] >> 16) & 0xFFu : kLookNone;
+      uint32_t avail = 0; bool producer = false;
+      for (uint32_t c = 0; c < nc; c++) {
+        const OpRec o = cls[c];
+        if ((uint32_t)cmem[o.op] > F) break;                          // (first ranks ascend with the class number)
+        avail++;
+        producer = producer || look_prod(o.f_slot & 0xFFu, o.a, o.b) == need;
+      }
+      ncr[F] = avail;
+      if (producer && need != kLookNone) look[(uint64_t)F * LW] |= 1ull << 48;
+    }
+  }
+}
+
 // ---- front records (narrow kernel): the part of each record that is not the read masks -- where the front's list is, how
 // many calls are open, and the windows of completion slots / read kinds of ranks F .. F + 15.  One thread per front, streaming:
 // every input is an array the counts kernel wrote (neighbouring threads read neighbouring words), 48 B written per front.
@@ -578,6 +614,7 @@ void launch_pack_open(const PackOpenArgs& a, void* stream) {
   }
   // (the walk by front leaves the producer distances in the lookahead records and writes compact front records whole)
   if (a.look && !by_front) hipLaunchKernelGGL(open_dprod_kernel, dim3(grid), dim3(nt), 0, s, a);
+  if (a.cmem) hipLaunchKernelGGL(count_fronts_kernel, dim3(grid), dim3(256), 0, s, a);
   if (a.front_words && !(by_front && a.front_compact)) {
     const uint64_t fronts = (uint64_t)n_here * a.chunks_per_hist * 64u;
     hipLaunchKernelGGL(front_meta_kernel, dim3((uint32_t)((fronts + 255) / 256)), dim3(256), 0, s, a);

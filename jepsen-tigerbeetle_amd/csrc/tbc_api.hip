@@ -59,6 +59,69 @@ uint64_t open_list_entries(const tbc_ops& c, uint64_t op_off, uint64_t n, uint32
   return std::min(worst, std::max<uint64_t>(total, 1));
 }
 
+// ---- count form (tbc_internal.h, kRuleCount; specified in oracle/wgl_count.c): what the host works out of one history when the
+// inputs become resident -- the re-used process slots of the live calls, the classes of the crashed calls with their members'
+// invocation ranks, the layout of the count vector.  Returns false when the form does not apply (more than 128 bits of counts,
+// a process id out of range: the pack kernel will say what is wrong with such a history).
+struct CountHist {
+  std::vector<uint64_t> words;       // [2 * n_classes words of OpRec][members of class 0, sentinel, members of class 1, sentinel, ...]
+  uint32_t n_classes = 0, n_slots = 1;
+  uint64_t top[kCountWords] = {0, 0};
+};
+bool build_count_form(const tbc_ops& c, uint64_t o0, uint64_t n, uint32_t n_process, bool cas_model, int32_t* slot_col, CountHist& out,
+                      std::vector<uint32_t>& rets, std::vector<int32_t>& slot_of, std::vector<uint8_t>& used) {
+  const uint8_t* f = c.f + o0; const int32_t* a = c.a + o0; const int32_t* b = c.b + o0; const int32_t* proc = c.process + o0;
+  const uint32_t* inv = c.inv_pos + o0; const uint32_t* ret = c.ret_pos + o0;
+  out.words.clear(); out.n_classes = 0; out.n_slots = 1; out.top[0] = out.top[1] = 0;
+  rets.clear();
+  for (uint64_t i = 0; i < n; i++) if (ret[i] != TBC_POS_CRASHED) rets.push_back(ret[i]);
+  std::sort(rets.begin(), rets.end());
+  slot_of.assign((size_t)n_process + 1, -1);
+  used.assign((size_t)n_process + 2, 0);
+  struct Cls { uint32_t f; int32_t a, b; std::vector<uint64_t> mem; };
+  std::vector<Cls> cls;
+  for (uint64_t i = 0; i < n; i++) {
+    if (proc[i] < 0 || (uint32_t)proc[i] >= n_process) return false;
+    const uint32_t p = (uint32_t)proc[i];
+    if (ret[i] == TBC_POS_CRASHED) {
+      if (slot_of[p] >= 0) { used[(size_t)slot_of[p]] = 0; slot_of[p] = -1; }     // a process that crashes hands its slot back
+      slot_col[i] = 0;                                                            // (slotless: the pack kernel does not look at it)
+      if (!(f[i] == TBC_F_WRITE || (f[i] == TBC_F_CAS && cas_model && a[i] != b[i]))) continue;   // no effect: never a candidate
+      size_t k = 0;
+      while (k < cls.size() && !(cls[k].f == f[i] && cls[k].a == a[i] && (f[i] != TBC_F_CAS || cls[k].b == b[i]))) k++;
+      if (k == cls.size()) cls.push_back(Cls{f[i], a[i], f[i] == TBC_F_CAS ? b[i] : 0, {}});
+      const uint32_t inv_rank = (uint32_t)(std::lower_bound(rets.begin(), rets.end(), inv[i]) - rets.begin());
+      cls[k].mem.push_back((uint64_t)inv_rank | ((uint64_t)i << 32));
+      continue;
+    }
+    if (slot_of[p] < 0) {                                   // the lowest slot that is free when the process first invokes
+      uint32_t sl = 0;
+      while (used[sl]) sl++;
+      used[sl] = 1; slot_of[p] = (int32_t)sl;
+      out.n_slots = std::max(out.n_slots, sl + 1);
+    }
+    slot_col[i] = slot_of[p];
+  }
+  out.n_classes = (uint32_t)cls.size();
+  uint32_t bits = 0;
+  out.words.assign(2 * cls.size(), 0ull);
+  for (size_t k = 0; k < cls.size(); k++) {
+    uint32_t w = 0;
+    while ((1ull << w) <= cls[k].mem.size()) w++;
+    if ((bits & 63u) + w > 64u) bits = (bits + 63u) & ~63u;     // a field never straddles a word
+    if (bits + w > 64u * kCountWords || w > 31u) return false;
+    OpRec o; o.op = (uint32_t)out.words.size(); o.f_slot = cls[k].f | (bits << 8) | (w << 16); o.a = cls[k].a; o.b = cls[k].b;
+    std::memcpy(&out.words[2 * k], &o, sizeof o);
+    const uint32_t t = bits + w - 1;
+    out.top[t >> 6] |= 1ull << (t & 63u);
+    bits += w;
+    out.words.insert(out.words.end(), cls[k].mem.begin(), cls[k].mem.end());
+    out.words.push_back(~0ull);                                 // sentinel: no further member is ever invoked
+  }
+  if (out.words.size() & 1) out.words.push_back(~0ull);         // (the next history's class records stay 16 B aligned)
+  return true;
+}
+
 bool device_is_gfx950(int dev) {
   hipDeviceProp_t p;
   if (hipGetDeviceProperties(&p, dev) != hipSuccess) return false;
@@ -223,6 +286,11 @@ struct tbc_batch {
   uint32_t vpad = 0;                // entries per rdm row (nil + values), power of two
   DevBuf<uint64_t> d_twn, d_rdm;    // dominance tables (tbc_internal.h)
   DevBuf<uint64_t> d_occ, d_btab, d_pool;
+  // count form (tbc_internal.h, kRuleCount): crashed calls as counts per class; the classes and their members, per history
+  bool count_form = false;
+  DevBuf<uint64_t> d_cmem;
+  std::vector<CountHist> count_hist;       // (kept for the result marshalling: which crashed calls a count vector stands for)
+  uint32_t entry_words() const { return mask_words + 2u + (count_form ? kCountWords : 0u); }   // u64 words per wide-schedule entry
   DevBuf<unsigned long long> d_pool_cursor;
   // last run
   std::vector<DevResult> res_host;
@@ -240,7 +308,7 @@ struct tbc_batch {
     d_bitmap.release(); d_wpre.release(); d_frames.release(); d_witness.release(); d_work.release();
     d_queue.release(); d_tab.release(); d_results.release(); d_table.release(); d_pool_vals.release(); d_cfg.release();
     d_bh.release(); d_off.release(); d_ncr.release(); d_lst.release(); d_crashed.release(); d_stack.release();
-    d_occ.release(); d_btab.release(); d_slot8.release(); d_rk8.release(); d_look.release(); d_looktmp.release(); d_twn.release(); d_rdm.release(); d_cuts.release(); d_seglist.release(); d_sres.release(); d_dstack.release(); d_pool.release(); d_pool_cursor.release();
+    d_cmem.release(); d_occ.release(); d_btab.release(); d_slot8.release(); d_rk8.release(); d_look.release(); d_looktmp.release(); d_twn.release(); d_rdm.release(); d_cuts.release(); d_seglist.release(); d_sres.release(); d_dstack.release(); d_pool.release(); d_pool_cursor.release();
     if (ev_turn) (void)hipEventDestroy(ev_turn);
     if (!borrowed) {
       for (auto& e : ev) if (e) (void)hipEventDestroy(e);
@@ -313,12 +381,51 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
     }
   }
   if (desc->op_off[0] != 0) { set_error("op_off[0] must be 0"); return TBC_ERR_INVALID_ARG; }
+  // ---- count form (tbc_internal.h, kRuleCount): a register / cas-register batch with crashed calls that have an effect, under the
+  // default rules and knossos.competition (the published orders -- TBC_ALG_WGL, TBC_ALG_LINEAR -- keep a mask bit per crashed call).
+  // The process column is re-numbered (re-used slots; a crashed call holds none) and the crashed calls become classes with counts.
+  std::vector<int32_t> slot_col;
+  {
+    const bool regfam = model->kind == TBC_MODEL_REGISTER || model->kind == TBC_MODEL_CAS_REGISTER;
+    const tbc_ops& c = desc->cols;
+    bool want = regfam && opts->algorithm == TBC_ALG_COMPETITION && (opts->dominance & (TBC_DOM_NO_EAGER_READS | TBC_DOM_NO_TWIN_RULE | TBC_DOM_NO_COUNT_FORM)) == 0 &&
+                opts->search_width != 1 && (opts->lanes_per_history == 0 || opts->lanes_per_history == 64) && opts->lookahead != 1 &&
+                (model->init == TBC_NIL || (model->init >= 0 && model->init <= kMaxRuleValue));
+    bool any = false;
+    for (uint64_t i = 0; i < c.n && want; i++) {
+      const int32_t a = c.a[i];
+      if (a != TBC_NIL && (a < 0 || a > kMaxRuleValue)) want = false;
+      if (c.f[i] == TBC_F_CAS && (c.b[i] < 0 || c.b[i] > kMaxRuleValue)) want = false;
+      any = any || (c.ret_pos[i] == TBC_POS_CRASHED && (c.f[i] == TBC_F_WRITE || (c.f[i] == TBC_F_CAS && a != c.b[i])));
+    }
+    if (want && any) {
+      slot_col.resize((size_t)B->total_ops + 1);
+      B->count_hist.resize(nh);
+      std::vector<uint32_t> rets; std::vector<int32_t> slot_of; std::vector<uint8_t> used;
+      bool ok = true;
+      for (uint32_t h = 0; h < nh && ok; h++)
+        ok = build_count_form(c, desc->op_off[h], desc->op_off[h + 1] - desc->op_off[h], desc->n_process[h], model->kind == TBC_MODEL_CAS_REGISTER,
+                              slot_col.data() + desc->op_off[h], B->count_hist[h], rets, slot_of, used);
+      B->count_form = ok;
+      if (!ok) { slot_col.clear(); B->count_hist.clear(); }
+    }
+  }
+  const auto slots_of = [&](uint32_t h) -> uint32_t { return B->count_form ? B->count_hist[h].n_slots : desc->n_process[h]; };
   uint32_t maxW = 1;
-  for (uint32_t h = 0; h < nh; h++) maxW = std::max(maxW, desc->n_process[h]);
+  for (uint32_t h = 0; h < nh; h++) maxW = std::max(maxW, slots_of(h));
   if (maxW > kMaxSlots) { set_error("%u open processes > %u supported", maxW, kMaxSlots); return TBC_ERR_WINDOW_TOO_WIDE; }
   uint32_t mw = (maxW + 63) / 64;
   B->mask_words = mw <= 1 ? 1 : mw <= 2 ? 2 : mw <= 4 ? 4 : mw <= 8 ? 8 : 16;
   B->frame_words = search_frame_words(B->mask_words);
+  if (B->count_form && B->mask_words > 2) { B->count_form = false; slot_col.clear(); B->count_hist.clear(); }   // (the count form's kernel: one or two mask words)
+  if (!B->count_form && maxW != 1) {        // (the masks are the mask form's after all)
+    maxW = 1;
+    for (uint32_t h = 0; h < nh; h++) maxW = std::max(maxW, desc->n_process[h]);
+    if (maxW > kMaxSlots) { set_error("%u open processes > %u supported", maxW, kMaxSlots); return TBC_ERR_WINDOW_TOO_WIDE; }
+    mw = (maxW + 63) / 64;
+    B->mask_words = mw <= 1 ? 1 : mw <= 2 ? 2 : mw <= 4 ? 4 : mw <= 8 ? 8 : 16;
+    B->frame_words = search_frame_words(B->mask_words);
+  }
   const uint32_t KW = 1 + B->mask_words;
   uint32_t width = opts->search_width ? opts->search_width : (opts->algorithm == TBC_ALG_WGL ? 1u : 4u);   // 4: fewest rounds per history, measured
   if (width > 16) width = 16;           // one wavefront per history: at most 16 configs per round
@@ -339,7 +446,7 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
     const bool asked = opts->algorithm == TBC_ALG_LINEAR ||
                        (opts->algorithm == TBC_ALG_COMPETITION && !opts->want_witness && opts->search_width == 0 && nh <= 256 &&
                         (opts->lanes_per_history == 0 || opts->lanes_per_history == 64));      // (a named depth-first schedule is not the sweep)
-    B->sweep = !never && (asked || forced) && !commutative && B->mask_words == 1 && width <= 16;
+    B->sweep = !never && (asked || forced) && !commutative && B->mask_words == 1 && width <= 16 && !B->count_form;   // (the sweep's segments cannot start from count vectors)
     if (B->sweep && width < 2) width = 4;                // the fallback's schedule; the per-front lists are the wide kernel's
   }
   B->width = width;
@@ -359,6 +466,7 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
     if (in_range && vmax <= kMaxRuleValue) {
       B->n_dom = (uint32_t)(vmax + 2);                   // nil + 0..vmax: the states a register can be in
       B->rules = ((opts->dominance & TBC_DOM_NO_EAGER_READS) ? 0u : kRuleEager) | ((opts->dominance & TBC_DOM_NO_TWIN_RULE) ? 0u : kRuleTwin);
+      if (B->count_form) B->rules |= kRuleCount;
       B->vpad = 2; while (B->vpad < (uint32_t)(vmax + 2)) B->vpad <<= 1;
     }
   }
@@ -368,13 +476,15 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
   // 171 ms against 1.07*10^9 and 198 ms; at 19 in flight 4 is 9 % faster; profiles/r02_k5_width_ab.txt).  Calls in
   // flight are averaged over a sample of the batch's histories: positions from invocation to completion (a crashed
   // call stays open to the end) over the history's length.
-  if (opts->search_width == 0 && B->width == 4 && B->rules == (kRuleEager | kRuleTwin)) {
+  if (B->count_form && !(B->rules & kRuleCount)) { set_error("internal: count form without the rules"); return TBC_ERR_HIP; }
+  if (opts->search_width == 0 && B->width == 4 && (B->rules & ~kRuleCount) == (kRuleEager | kRuleTwin)) {
     uint64_t open_sum = 0, events = 0;
     const uint32_t stride = std::max<uint32_t>(1, nh / 64);
     for (uint32_t h = 0; h < nh; h += stride) {
       const uint32_t ne = desc->n_events[h];
       for (uint64_t i = desc->op_off[h]; i < desc->op_off[h + 1]; i++) {
         const uint32_t inv = desc->cols.inv_pos[i], ret = desc->cols.ret_pos[i];
+        if (B->count_form && ret == TBC_POS_CRASHED) continue;                               // (count form: a crashed call is no open call)
         open_sum += (ret == TBC_POS_CRASHED || ret > ne ? ne : ret) - std::min(inv, ne);   // malformed rows are the pack kernel's to reject
       }
       events += ne;
@@ -390,7 +500,7 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
     if (opts->reserved0 != 0) { set_error("tbc_opts.reserved0 must be 0"); return TBC_ERR_INVALID_ARG; }
     const bool regfam3 = model->kind == TBC_MODEL_REGISTER || model->kind == TBC_MODEL_CAS_REGISTER || model->kind == TBC_MODEL_MUTEX;
     // the narrow kernel addresses a history's tables with 32-bit element offsets
-    const bool can = beam && !B->sweep && regfam3 && narrow_supported(B->mask_words, 8) && opts->algorithm != TBC_ALG_WGL &&
+    const bool can = beam && !B->sweep && !B->count_form && regfam3 && narrow_supported(B->mask_words, 8) && opts->algorithm != TBC_ALG_WGL &&
                      look_words(B->total_ops, nh, B->mask_words) < (1ull << 32);
     if (asked != 0 && asked != 64) {
       if (!can) { set_error("lanes_per_history %u: needs the depth-first search of a register / cas-register / mutex batch with at most 256 process slots (not TBC_ALG_WGL, not the level sweep)", asked); return TBC_ERR_UNSUPPORTED; }
@@ -405,7 +515,7 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
     // under the eager rule the narrow kernel branches over :write / :cas only: lists without reads, root in normal form
     if (B->lanes && (B->rules & kRuleEager)) B->rules |= kRuleBranch;
   }
-  const uint32_t EW = B->mask_words + 2;   // u64 words per wide-schedule entry
+  const uint32_t EW = B->entry_words();   // u64 words per wide-schedule entry
   if (B->sweep) {
     // segments: enough wavefronts to fill the GPU several times over, none shorter than 32 completions; cuts need the
     // register family's value domain (nil + 0..vmax = vpad's range) to enumerate the configs possible at a front
@@ -441,7 +551,7 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
     const bool branch = (B->rules & kRuleBranch) != 0;
     for (uint32_t h = 0; h < nh; h++) {
       const uint64_t n = desc->op_off[h + 1] - desc->op_off[h];
-      list_caps[h] = (uint32_t)std::min<uint64_t>(0xFFFFFFF0ull, open_list_entries(desc->cols, desc->op_off[h], n, desc->n_events[h], std::max(1u, desc->n_process[h]), rank_scratch, branch));
+      list_caps[h] = (uint32_t)std::min<uint64_t>(0xFFFFFFF0ull, open_list_entries(desc->cols, desc->op_off[h], n, desc->n_events[h], std::max(1u, slots_of(h)), rank_scratch, branch));
     }
   }
   for (uint32_t h = 0; h < nh; h++) {
@@ -453,7 +563,8 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
     H.n_ops = (uint32_t)n;
     B->max_ops = std::max<uint64_t>(B->max_ops, n);
     H.n_events = desc->n_events[h];
-    H.n_slots = std::max(1u, desc->n_process[h]);
+    H.n_slots = std::max(1u, slots_of(h));
+    H.flags = B->count_form ? kHistCount : 0u;
     H.aux = desc->model_aux ? desc->model_aux[h] : model->init;
     H.rec_off = rec_n; rec_n += n + 2ull * H.n_slots;
     H.seg_off = seg_n; seg_n += H.n_slots + 1;
@@ -473,7 +584,11 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
       while (blg > 10 && ((1ull << blg) * EW * 8 > max_bytes || blg > kBeamMaxTabLog2)) blg--;
       Q.tab_log2 = blg;
       Q.off_off = boff_n; boff_n += n + 2;
-      Q.occ_off = bocc_n; bocc_n += (n + 1) * B->mask_words;
+      if (B->count_form) {
+        const CountHist& ch = B->count_hist[h];
+        Q.cmem_off = bocc_n; bocc_n += ch.words.size();
+        Q.n_classes = ch.n_classes; Q.top[0] = ch.top[0]; Q.top[1] = ch.top[1];
+      }
       Q.lst_cap = list_caps[h];
       Q.lst_off = blst_n; blst_n += Q.lst_cap;
       Q.stack_off = bstack_n; bstack_n += (1ull << blg);
@@ -507,7 +622,7 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
     return s;
   if (beam) {
     if ((s = B->d_bh.alloc(nh)) || (s = B->d_off.alloc(boff_n)) || (s = B->d_ncr.alloc(boff_n)) ||
-        (s = B->d_lst.alloc(blst_n)) || (s = B->d_crashed.alloc(T)) ||
+        (s = B->d_lst.alloc(blst_n)) || (s = B->d_crashed.alloc(B->count_form ? 0 : T)) || (s = B->d_cmem.alloc(B->count_form ? bocc_n : 0)) ||
         (s = B->d_slot8.alloc(slot8_bytes(T, nh))) || (s = B->d_stack.alloc(bstack_n)) || (s = B->d_btab.alloc(btab_n * EW)) ||
         (s = B->d_pool_cursor.alloc(1)))
       return s;
@@ -547,7 +662,7 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
                     B->d_ret_op.bytes() + B->d_bitmap.bytes() + B->d_wpre.bytes() + B->d_frames.bytes() +
                     B->d_tab.bytes() + B->d_results.bytes() + B->d_work.bytes() + B->d_witness.bytes();
   if (beam) B->device_bytes += B->d_bh.bytes() + B->d_off.bytes() + B->d_ncr.bytes() + B->d_lst.bytes() +
-                               B->d_crashed.bytes() + B->d_slot8.bytes() + B->d_rk8.bytes() + B->d_twn.bytes() + B->d_rdm.bytes() + B->d_look.bytes() + B->d_looktmp.bytes() + B->d_dstack.bytes() + B->d_stack.bytes() + B->d_btab.bytes() + B->d_pool.bytes();
+                               B->d_crashed.bytes() + B->d_slot8.bytes() + B->d_rk8.bytes() + B->d_twn.bytes() + B->d_rdm.bytes() + B->d_look.bytes() + B->d_looktmp.bytes() + B->d_dstack.bytes() + B->d_stack.bytes() + B->d_btab.bytes() + B->d_pool.bytes() + B->d_cmem.bytes();
 
   if (t_ctx) {
     B->borrowed = true; B->stream = t_ctx->stream;
@@ -562,9 +677,15 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
     HIP_TRY(hipMemcpyAsync(B->d_f.p, desc->cols.f, T, hipMemcpyHostToDevice, B->stream));
     HIP_TRY(hipMemcpyAsync(B->d_a.p, desc->cols.a, T * 4, hipMemcpyHostToDevice, B->stream));
     HIP_TRY(hipMemcpyAsync(B->d_b.p, desc->cols.b, T * 4, hipMemcpyHostToDevice, B->stream));
-    HIP_TRY(hipMemcpyAsync(B->d_proc.p, desc->cols.process, T * 4, hipMemcpyHostToDevice, B->stream));
+    HIP_TRY(hipMemcpyAsync(B->d_proc.p, B->count_form ? slot_col.data() : desc->cols.process, T * 4, hipMemcpyHostToDevice, B->stream));
     HIP_TRY(hipMemcpyAsync(B->d_inv.p, desc->cols.inv_pos, T * 4, hipMemcpyHostToDevice, B->stream));
     HIP_TRY(hipMemcpyAsync(B->d_ret.p, desc->cols.ret_pos, T * 4, hipMemcpyHostToDevice, B->stream));
+  }
+  std::vector<uint64_t> cmem_host;
+  if (B->count_form && bocc_n) {
+    cmem_host.reserve(bocc_n);
+    for (uint32_t h = 0; h < nh; h++) cmem_host.insert(cmem_host.end(), B->count_hist[h].words.begin(), B->count_hist[h].words.end());
+    HIP_TRY(hipMemcpyAsync(B->d_cmem.p, cmem_host.data(), cmem_host.size() * 8, hipMemcpyHostToDevice, B->stream));
   }
   HIP_TRY(hipMemcpyAsync(B->d_hist.p, B->hist.data(), nh * sizeof(Hist), hipMemcpyHostToDevice, B->stream));
   std::vector<uint32_t> work(nh);
@@ -638,6 +759,7 @@ static BeamArgs make_beam_args(tbc_batch* B, uint64_t* tab, uint32_t* stack, uin
   a.model_aux = B->model.init; a.n_keys = B->model.n_keys;
   a.n_classes = B->model.n_classes; a.width = B->width;
   a.round_budget = B->opts.round_budget;
+  a.cmem = B->d_cmem.p; a.count_mode = kCountExact;
   a.rules = B->rules; a.twn = B->d_twn.p; a.rdm = B->d_rdm.p; a.vpad = B->vpad; a.rk8 = B->d_rk8.p; a.front_words = B->front_words(); a.next_work = B->d_queue.p;
   a.max_steps = B->opts.max_steps;
   a.time_limit_ticks = B->opts.time_limit_ms * 100000ull;
@@ -648,7 +770,7 @@ static BeamArgs make_beam_args(tbc_batch* B, uint64_t* tab, uint32_t* stack, uin
   {
     const uint64_t max_bytes = B->opts.max_visited_bytes ? B->opts.max_visited_bytes : (1ull << 30);
     uint32_t lg = 10;
-    while (lg < kBeamMaxTabLog2 && (1ull << (lg + 1)) * (B->mask_words + 2) * 8 <= max_bytes) lg++;
+    while (lg < kBeamMaxTabLog2 && (1ull << (lg + 1)) * B->entry_words() * 8 <= max_bytes) lg++;
     a.max_tab_log2 = lg;
   }
   return a;
@@ -656,11 +778,13 @@ static BeamArgs make_beam_args(tbc_batch* B, uint64_t* tab, uint32_t* stack, uin
 
 // One extra pass over the histories in `grp` with per-history visited sets of 2^lg[i] entries in a
 // scratch arena (overflow retries, and wide-schedule histories that fall back to the sequential kernel).
+// count form: `count_mode` (exact / relaxed), per-history prefix targets and a step limit of the pass's own (steps_override >= 0).
 static tbc_status scratch_pass(tbc_batch* B, const std::vector<uint32_t>& grp, const std::vector<uint32_t>& lg,
                                bool beam, const std::vector<Hist>& hist_back, const std::vector<BeamHist>& bh_back,
-                               uint32_t width_override = 0) {
+                               uint32_t width_override = 0, uint32_t count_mode = kCountExact, const std::vector<uint32_t>* targets = nullptr,
+                               int64_t steps_override = -1) {
   hipStream_t s = B->stream;
-  const uint32_t KW = 1 + B->mask_words, EW = B->mask_words + 2;
+  const uint32_t KW = 1 + B->mask_words, EW = B->entry_words();
   const uint64_t words_per_entry = beam ? EW : KW;
   uint64_t entries = 0;
   std::vector<Hist> ph(grp.size());
@@ -670,6 +794,7 @@ static tbc_status scratch_pass(tbc_batch* B, const std::vector<uint32_t>& grp, c
     if (beam) {
       pb[i] = bh_back[grp[i]];
       pb[i].tab_off = entries; pb[i].stack_off = entries; pb[i].tab_log2 = lg[i];
+      pb[i].target = targets ? (*targets)[i] : 0u;
     } else {
       ph[i].tab_off = entries * KW; ph[i].tab_log2 = lg[i];
     }
@@ -691,6 +816,8 @@ static tbc_status scratch_pass(tbc_batch* B, const std::vector<uint32_t>& grp, c
     const uint32_t nw = (uint32_t)grp.size();
     if (beam) { BeamArgs ba = make_beam_args(B, big.p, bstack.p, bdstack.p, nw); ba.pool = nullptr; ba.pool_words = 0;
       if (width_override) ba.width = width_override;
+      ba.count_mode = count_mode;
+      if (steps_override >= 0) ba.max_steps = (uint64_t)steps_override;
       // (a retry runs the schedule of the first pass: several histories per wavefront stay so)
       if (B->lanes && (!width_override || width_override == B->width)) launch_narrow(ba, B->mask_words, B->lanes, s); else launch_beam(ba, B->mask_words, search_blocks(nw), s); }
     else { SearchArgs ra = make_search_args(B, big.p, nw); launch_search(ra, B->mask_words, search_blocks(nw), s); }
@@ -739,17 +866,19 @@ static tbc_status fill_configs(tbc_batch* B, uint32_t h, const DevResult& d, tbc
     for (uint32_t j = 0; j < MW; j++) if (a[1 + j] != b[1 + j]) return a[1 + j] < b[1 + j];
     return false;
   });
+  (void)0;
   r->n_configs = std::min<uint32_t>(got, TBC_MAX_FINAL_CONFIGS);
   for (uint32_t c = 0; c < r->n_configs; c++) {
     const uint64_t* e = &rec[(size_t)order[c] * RW];
     tbc_config& o = r->configs[c];
-    o.state = (int32_t)(e[0] >> 32);
+    o.state = B->count_form ? (int32_t)((uint32_t)(e[0] >> 32) & ~kHotBit) : (int32_t)(e[0] >> 32);
     o.last_op = (uint32_t)e[1 + MW];
     o.n_pending = (uint32_t)pending.size();
     o.n_linearized = 0; o.linearized_mask = 0;
     for (size_t k = 0; k < pending.size(); k++) {
       const uint32_t p = (uint32_t)proc[pending[k]];
-      const bool lin = (e[1 + (p >> 6)] >> (p & 63u)) & 1ull;
+      // (count form: a crashed call holds no slot; which of them a config has linearized is in its count vector, not reported here)
+      const bool lin = !(B->count_form && ret[pending[k]] == TBC_POS_CRASHED) && ((e[1 + (p >> 6)] >> (p & 63u)) & 1ull);
       if (k < 16) { o.pending[k] = pending[k]; if (lin) o.linearized_mask |= 1u << k; }
       o.n_linearized += lin;
     }
@@ -856,9 +985,12 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results, int phase = 
   const uint32_t nh = B->n_hist;
   hipStream_t s = B->stream;
   const bool beam = B->width > 1;
-  const uint32_t KW = 1 + B->mask_words, EW = B->mask_words + 2;
+  const uint32_t KW = 1 + B->mask_words, EW = B->entry_words();
   std::vector<Hist>& hist_back = B->hist_back_m;
   std::vector<BeamHist>& bh_back = B->bh_back_m;
+  // count form: the exact search runs under a budget of probes; what it does not finish goes through the relaxed refutation and
+  // the prefix search below (a caller who names max_steps gets one exact pass under that limit instead)
+  const uint64_t count_budget = (B->count_form && B->opts.max_steps == 0) ? 32ull * B->max_ops : 0ull;
   SweepArgs swa{};
   if (B->sweep) {
     swa.hist = B->d_hist.p; swa.bh = B->d_bh.p; swa.off = B->d_off.p; swa.ncr = B->d_ncr.p; swa.lst = B->d_lst.p;
@@ -909,6 +1041,7 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results, int phase = 
     po.branch_lists = (B->rules & kRuleBranch) ? 1u : 0u;
     po.rk8 = B->lanes ? B->d_rk8.p : nullptr; po.front_words = B->front_words(); po.front_compact = B->front_words() == kFrontCompactWords ? 1u : 0u;
     po.twn = B->rules ? B->d_twn.p : nullptr; po.rdm = (B->rules || B->lanes) ? B->d_rdm.p : nullptr; po.vpad = B->vpad;
+    po.cmem = B->count_form ? B->d_cmem.p : nullptr;
     launch_pack_open(po, s);
     HIP_TRY(hipGetLastError());
   }
@@ -925,6 +1058,7 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results, int phase = 
     if (!launch_sweep(mine, s)) { set_error("level sweep launch failed"); return TBC_ERR_HIP; }
   } else if (beam) {
     BeamArgs ba = make_beam_args(B, B->d_btab.p, B->d_stack.p, B->d_dstack.p, nh);
+    if (count_budget) ba.max_steps = count_budget;
     if (B->lanes) {
       SearchTurn turn(B->device, s);        // one whole-GPU search at a time; another batch's pack runs beside it
       if (!B->ev_turn) HIP_TRY(hipEventCreate(&B->ev_turn));
@@ -1094,10 +1228,96 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results, int phase = 
           grp.push_back(pend[pos]); glg.push_back(lgs[pos]); final_log2[pend[pos]] = lgs[pos];
           bytes += need; pos++;
         }
-        tbc_status st = scratch_pass(B, grp, glg, pass == 1, hist_back, bh_back, pass == 1 ? width_of[grp[0]] : 0);
+        tbc_status st = scratch_pass(B, grp, glg, pass == 1, hist_back, bh_back, pass == 1 ? width_of[grp[0]] : 0, kCountExact, nullptr,
+                                     (pass == 1 && count_budget) ? (int64_t)count_budget : -1);
         if (st != TBC_OK) return st;
         touched_work = true;
       }
+    }
+  }
+  // ---- count form: the histories the budgeted exact search left undecided (oracle/wgl_count.c; tests/test_count_form.py states the
+  // same pipeline over the oracle).  (1) The RELAXED search -- every class of crashed calls an unlimited supply, counts ignored: a
+  // superset of the linearizations over a config space no larger than a crash-free history's -- either finds a linearization (then
+  // the exact search simply needs longer: once more, without a budget) or ends INVALID at completion t: the history is invalid and
+  // its first bad completion is t or earlier.  (2) The exact search of the PREFIX of t completions: a linearization of it (one
+  // depth-first descent, not an exhaustion) pins the failing completion at t; if there is none its own exhaustion names an earlier one.
+  if (count_budget) {
+    std::vector<uint32_t> pend;
+    for (uint32_t h = 0; h < nh; h++)
+      if (!is_seq[h] && B->res_host[h].valid == TBC_UNKNOWN && B->res_host[h].cause == TBC_CAUSE_STEP_LIMIT) pend.push_back(h);
+    if (!pend.empty()) {
+      struct Acc { uint64_t steps, visited, probes, backtracks, max_depth; };
+      std::vector<Acc> acc(nh, Acc{0, 0, 0, 0, 0});
+      const auto bank = [&](const std::vector<uint32_t>& grp) {
+        for (uint32_t h : grp) { const DevResult& d = B->res_host[h]; Acc& a = acc[h]; a.steps += d.steps; a.visited += d.visited; a.probes += d.probes; a.backtracks += d.backtracks; a.max_depth = std::max(a.max_depth, d.max_depth); }
+      };
+      // one pass over `grp` in a scratch arena; a history whose visited set fills up is taken again with a 16x larger one
+      const auto run_pass = [&](const std::vector<uint32_t>& grp, uint32_t mode, const std::vector<uint32_t>* targets) -> tbc_status {
+        std::vector<uint32_t> todo = grp, tg, lgs;
+        if (targets) tg = *targets;
+        for (uint32_t h : todo) {
+          uint32_t lg = std::max(final_log2[h], ceil_log2(64ull * std::max<uint64_t>(B->hist[h].n_ops, 1)));
+          while (lg > 10 && ((1ull << lg) * EW * 8 > max_bytes || lg > kBeamMaxTabLog2)) lg--;
+          lgs.push_back(lg);
+        }
+        while (!todo.empty()) {
+          size_t pos = 0;
+          while (pos < todo.size()) {
+            std::vector<uint32_t> g, glg, gtg;
+            uint64_t bytes = 0;
+            while (pos < todo.size()) {
+              const uint64_t need = (1ull << lgs[pos]) * ((uint64_t)EW + 2) * 8;
+              if (!g.empty() && bytes + need > arena_budget) break;
+              g.push_back(todo[pos]); glg.push_back(lgs[pos]); if (targets) gtg.push_back(tg[pos]);
+              final_log2[todo[pos]] = lgs[pos]; bytes += need; pos++;
+            }
+            tbc_status st = scratch_pass(B, g, glg, true, hist_back, bh_back, 0, mode, targets ? &gtg : nullptr, 0);
+            if (st != TBC_OK) return st;
+          }
+          std::vector<uint32_t> again, alg, atg;
+          for (size_t i = 0; i < todo.size(); i++) {
+            const DevResult& d = B->res_host[todo[i]];
+            if (d.valid != TBC_UNKNOWN || d.cause != TBC_CAUSE_VISITED_FULL) continue;
+            uint32_t lg = lgs[i] + 4;
+            while (lg > lgs[i] && ((1ull << lg) * EW * 8 > max_bytes || lg > kBeamMaxTabLog2)) lg--;
+            if (lg > lgs[i]) { again.push_back(todo[i]); alg.push_back(lg); if (targets) atg.push_back(tg[i]); }
+          }
+          todo.swap(again); lgs.swap(alg); tg.swap(atg);
+        }
+        return TBC_OK;
+      };
+      bank(pend);
+      tbc_status st = run_pass(pend, kCountRelaxed, nullptr);
+      if (st != TBC_OK) return st;
+      bank(pend);
+      std::vector<uint32_t> longer, prefix, targets;
+      std::vector<DevResult> relaxed(nh);
+      for (uint32_t h : pend) {
+        const DevResult& r = B->res_host[h];
+        relaxed[h] = r;
+        if (r.valid == TBC_VALID) longer.push_back(h);
+        else if (r.valid == TBC_INVALID && r.max_front != 0) { prefix.push_back(h); targets.push_back(r.max_front); }
+        // (INVALID at the very first completion: nothing to pin; UNKNOWN -- a time limit -- stays UNKNOWN)
+      }
+      if (!longer.empty()) { if ((st = run_pass(longer, kCountExact, nullptr)) != TBC_OK) return st; }
+      if (!prefix.empty()) {
+        if ((st = run_pass(prefix, kCountExact, &targets)) != TBC_OK) return st;
+        for (uint32_t h : prefix) {
+          DevResult& d = B->res_host[h];
+          if (d.valid != TBC_VALID) continue;             // (its own exhaustion names an earlier completion, or it ran into a limit)
+          d.valid = TBC_INVALID; d.cause = TBC_CAUSE_NONE; d.depth = 0; d.n_configs = 0;
+          d.max_front = relaxed[h].max_front; d.fail_op = relaxed[h].fail_op; d.prev_ok_op = relaxed[h].prev_ok_op;
+        }
+      }
+      std::vector<uint8_t> third(nh, 0);
+      for (uint32_t h : longer) third[h] = 1;
+      for (uint32_t h : prefix) third[h] = 1;
+      for (uint32_t h : pend) {          // counters: the sum over the passes a history went through
+        DevResult& d = B->res_host[h]; const Acc& a = acc[h];
+        if (third[h]) { d.steps += a.steps; d.visited += a.visited; d.probes += a.probes; d.backtracks += a.backtracks; d.max_depth = std::max(d.max_depth, a.max_depth); }
+        else { d.steps = a.steps; d.visited = a.visited; d.probes = a.probes; d.backtracks = a.backtracks; d.max_depth = a.max_depth; }   // (the relaxed pass is banked already)
+      }
+      touched_work = true;
     }
   }
   if (touched_work) {   // restore the identity work list for the next run

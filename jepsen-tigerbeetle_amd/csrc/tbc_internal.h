@@ -46,8 +46,9 @@ struct __attribute__((aligned(16))) Hist {
   uint32_t n_ret;      // pack: number of completions
   uint32_t status;     // pack: 0 ok, else tbc_status
   int32_t aux;         // commutative models: pool offset of this history's per-front table
-  uint32_t pad1;
+  uint32_t flags;      // kHistCount: count form -- the process column holds re-used slots, crashed calls hold none
 };
+constexpr uint32_t kHistCount = 1u;
 
 struct __attribute__((aligned(8))) DevResult {
   int32_t valid;
@@ -175,6 +176,26 @@ constexpr uint32_t kRuleEager = 1u, kRuleTwin = 2u;
 // narrow kernel under the eager rule: the per-front lists hold the live :write / :cas calls only (a read is never a viable
 // candidate of a config in normal form; the rule itself finds the reads through rdm) and the root config starts in normal form
 constexpr uint32_t kRuleBranch = 4u;
+// COUNT FORM (register / cas-register with crashed calls; specified in oracle/wgl_count.c).  Crashed calls are grouped by effect
+// into CLASSES -- (:write v), (:cas [a b]) with a != b; crashed reads and (:cas [a a]) are never candidates -- and a config
+// records how many calls of each class are linearized (they go in invocation order): a 128-bit count vector C, class c in a
+// field of bit_length(n_c) bits that never straddles a word, instead of one mask bit per crashed call.  Process slots are
+// re-used (the host re-numbers the process column: a live call takes the lowest slot free when its process first invokes, a
+// process that crashes hands its slot back), so masks stay as wide as the processes alive at once.  Two more rules keep the
+// config space small: a crashed call is only linearized right before a call that OBSERVES its value (a config reached by a
+// crashed call no absorbed read observed is HOT: bit 30 of the state word; only calls whose precondition is the state are its
+// candidates), and a new config is dropped when a visited config with the same key has used no more of any class (Pareto).
+//   crashed[]  (at op_off, as before) holds one OpRec per CLASS, in order of the class's first invocation:
+//              {op = first member's index in cmem[], f | shift << 8 | width << 16, a, b};  ncr[F] = classes with a member invoked by F
+//   cmem[]     (at BeamHist.cmem_off) per class its members in invocation order, inv_rank | op << 32, then a sentinel (all ones)
+// Visited-set entries carry the count words behind the mask words; buckets are chosen by (k0, M) alone, so every config with
+// one key lies on one probe chain.
+constexpr uint32_t kRuleCount = 8u;
+constexpr uint32_t kHotBit = 0x40000000u;
+constexpr uint32_t kCountWords = 2;
+// BeamArgs.count_mode
+enum : uint32_t { kCountExact = 0, kCountRelaxed = 1 };   // relaxed: every class an unlimited supply (counts stay 0): a superset of the
+                                                          // linearizations, so its INVALID verdict bounds the failing completion from above
 // FRONT RECORDS (narrow kernel, wgl_narrow.hip): the rdm row of a front, extended to everything else a search step needs of
 // that front, so that it costs ONE line of memory instead of a line of each of five arrays (off, ncr, slot8, rk8, rdm) that
 // fall out of L2 between the rounds of a history.  front_stride(vpad, mw) u64 words per front at rdm[(op_off + F) * stride]:
@@ -197,7 +218,7 @@ __host__ __device__ inline uint32_t rdm_index(int32_t v, uint32_t vpad) {   // r
 
 struct __attribute__((aligned(16))) BeamHist {
   uint64_t off_off;     // u32 units: off[] (n_ops + 2), ncr[] at the same offset in its own arena
-  uint64_t occ_off;     // (unused since the open-call lists are built by walking the fronts)
+  uint64_t cmem_off;    // count form: u64 units into cmem[] (the members of the crashed-call classes)
   uint64_t lst_off;     // OpRec units
   uint64_t stack_off;   // u32 units (capacity = table capacity)
   uint64_t tab_off;     // entry units
@@ -205,7 +226,9 @@ struct __attribute__((aligned(16))) BeamHist {
   uint32_t tab_log2;
   uint32_t n_crashed;   // pack_open: number of crashed ops
   uint32_t status;      // pack_open: 0 ok, 1 = open lists do not fit lst_cap (use the sequential kernel)
-  uint32_t pad0, pad1;
+  uint32_t n_classes;   // count form: classes of crashed calls (OpRecs at crashed[])
+  uint32_t target;      // count form: the search ends VALID when a config has passed this many completions (0 = all of them)
+  uint64_t top[kCountWords];   // count form: the top bit of every class's field (field-wise compare of count vectors)
 };
 
 struct PackOpenArgs {
@@ -238,6 +261,7 @@ struct PackOpenArgs {
   uint64_t* rdm;             // open-read masks, vpad x mask_words per front at op_off * vpad * mask_words, or null
   uint32_t vpad;
   uint32_t h0;               // histories [h0, n_hist) are worked on by this launch
+  const uint64_t* cmem;      // count form: class members (inv_rank | op << 32), or null
 };
 
 // byte offset of history h's slot8[] (n_ret entries + 16 of padding), 8-byte aligned
@@ -289,6 +313,9 @@ struct BeamArgs {
   uint32_t pad3;
   const uint8_t* rk8;                // as PackOpenArgs (narrow kernel only)
   uint32_t front_words;              // u64 words per front record in rdm (narrow kernel only; kFrontCompactWords = the compact form)
+  const uint64_t* cmem;              // count form: class members (tbc_internal.h, kRuleCount)
+  uint32_t count_mode;               // kCountExact / kCountRelaxed
+  uint32_t pad4;
   uint32_t first_dynamic;            // narrow kernel: work items below this are dealt to the wavefronts at launch (wave w, group g: w * H + g) ...
   unsigned int* next_work;           // ... the others are taken from this counter (zeroed before the launch) as groups finish
 };

@@ -95,7 +95,10 @@ __device__ __forceinline__ uint32_t row_max_u32(uint32_t v) {
 // LDS words per wave: parents p_k0[16] p_M[16*MW] (u64), ring r_k0[kRing] r_M[kRing*MW] (u64),
 // p_slot p_off p_nlive p_cnt (u32 x16), r_pos r_idx r_off r_nlive r_cnt (u32 x kRing), p_start (17 -> 20),
 // search state (28, S_* words), this round's new configs for the lookahead c_M[64*MW] (u64) c_fi c_st (u32 x64)
-__host__ __device__ constexpr uint32_t beam_lds_words(uint32_t mw) { return (16 + kRing) * (2 + 2 * mw) + 16 * 4 + kRing * 5 + 20 + 30 + 64 * (2 + 2 * mw); }
+// count form (CNT): + the count vectors of the parents and of the ring, p_C[16 * 2] r_C[kRing * 2] (u64)
+__host__ __device__ constexpr uint32_t beam_lds_words(uint32_t mw, bool cnt = false) {
+  return (16 + kRing) * (2 + 2 * mw) + 16 * 4 + kRing * 5 + 20 + 30 + 64 * (2 + 2 * mw) + (cnt ? (16 + kRing) * 2 * kCountWords : 0u);
+}
 
 __device__ __forceinline__ uint32_t key_hash32(uint64_t k0, const uint64_t* M, int mw) {
   uint32_t h = (uint32_t)k0 * 0x9E3779B1u ^ (uint32_t)(k0 >> 32) * 0x85EBCA77u;
@@ -192,12 +195,27 @@ __device__ __forceinline__ cold_args_ptr cold_args() {
   return p;
 }
 
+// count form: field-wise x >= y over packed count vectors; top = the top bit of every field (oracle/wgl_count.c, counts_ge)
+__device__ __forceinline__ bool counts_ge(const uint64_t (&x)[kCountWords], const uint64_t (&y)[kCountWords], const uint64_t (&top)[kCountWords]) {
+  bool ge = true;
+#pragma unroll
+  for (uint32_t w = 0; w < kCountWords; w++) {
+    const uint64_t t = (x[w] | top[w]) - (y[w] & ~top[w]);
+    ge = ge && ((((x[w] & ~y[w]) | (~(x[w] ^ y[w]) & t)) & top[w]) == top[w]);
+  }
+  return ge;
+}
+__device__ __forceinline__ uint64_t rl64(uint64_t v, uint32_t lane) {
+  return (uint64_t)rl((uint32_t)v, lane) | ((uint64_t)rl((uint32_t)(v >> 32), lane) << 32);
+}
+
 // Cold path: move a history to a 4x larger visited set (and stack) taken from the batch's growth pool --
 // re-insert every entry, then translate the slot numbers held by parent links and the stack.  Called
 // between iterations (nothing popped); reads and updates the parked search state.
-template <int MW>
+template <int MW, bool CNT = false>
 __device__ __forceinline__ bool grow_visited_set(state_ptr S, uint32_t* r_pos, uint32_t lane) {
-  constexpr uint32_t KW = MW + 1, EW = MW + 2;
+  constexpr uint32_t CWn = CNT ? kCountWords : 0u;      // count form: the count words ride behind the mask words (not hashed)
+  constexpr uint32_t KW = MW + 1 + CWn, EW = KW + 1;
   const gu64* tab = (const gu64*)sld64(S, S_TAB);
   const gu32* stack = (const gu32*)sld64(S, S_STACK);
   const gu32* dstack = (const gu32*)sld64(S, S_DSTACK);          // configs set aside by the lookahead (may be null)
@@ -223,9 +241,9 @@ __device__ __forceinline__ bool grow_visited_set(state_ptr S, uint32_t* r_pos, u
     const gu64* e = tab + s * KW;
     const uint64_t k0 = ld64(e);
     if ((uint32_t)k0 == 0u) continue;
-    uint64_t Mx[MW];
+    uint64_t Mx[MW + CWn];
 #pragma unroll
-    for (int j = 0; j < MW; j++) Mx[j] = ld64(e + 1 + j);
+    for (int j = 0; j < MW + (int)CWn; j++) Mx[j] = ld64(e + 1 + j);
     uint32_t b = key_hash32(k0, Mx, MW) & nbmask, idx = 0;
     for (bool placed = false; !placed; b = (b + 1u) & nbmask) {
 #pragma unroll 1
@@ -233,7 +251,7 @@ __device__ __forceinline__ bool grow_visited_set(state_ptr S, uint32_t* r_pos, u
         gu64* ne = ntab + ((uint64_t)b * 4 + t) * KW;
         if (cas64_from_zero(ne, k0) == 0ull) {
 #pragma unroll
-          for (int j = 0; j < MW; j++) st64(ne + 1 + j, Mx[j]);
+          for (int j = 0; j < MW + (int)CWn; j++) st64(ne + 1 + j, Mx[j]);
           idx = b * 4 + t; placed = true;
         }
       }
@@ -263,9 +281,11 @@ __device__ __forceinline__ bool grow_visited_set(state_ptr S, uint32_t* r_pos, u
   return true;
 }
 
-template <int MW, bool COMM, bool REGF>
+template <int MW, bool COMM, bool REGF, bool CNT = false>
 __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, const uint32_t lane) {
-  constexpr uint32_t KW = MW + 1;   // u64 words per key
+  static_assert(!CNT || (REGF && !COMM), "the count form is the register family's");
+  constexpr uint32_t CWn = CNT ? kCountWords : 0u;   // count form (tbc_internal.h, kRuleCount): count words behind the mask words
+  constexpr uint32_t KW = MW + 1 + CWn;   // u64 words per key
 
   const Hist* H = A.hist + hidx;
   const BeamHist* B = A.bh + hidx;
@@ -301,6 +321,18 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
   uint64_t* c_M = reinterpret_cast<uint64_t*>(p_start + 20 + S_WORDS);   // lookahead: the round's new configs
   uint32_t* c_fi = reinterpret_cast<uint32_t*>(c_M + 64 * MW);
   uint32_t* c_st = c_fi + 64;
+  uint64_t* p_C = reinterpret_cast<uint64_t*>(c_st + 64);                // count form: the parents' / the ring's count vectors
+  uint64_t* r_C = p_C + 16 * kCountWords;
+  // count form: the classes' members, the top bit of every count field, the prefix target, exact / relaxed
+  const uint64_t* cmem = CNT ? A.cmem + ru64(B->cmem_off) : nullptr;
+  uint64_t top[kCountWords] = {0ull, 0ull};
+  uint32_t RT = R;
+  if constexpr (CNT) {
+    top[0] = ru64(B->top[0]); top[1] = ru64(B->top[1]);
+    const uint32_t tg = rfl(B->target);
+    if (tg != 0u && tg < R) RT = tg;
+  }
+  const bool relaxed = CNT && A.count_mode == kCountRelaxed;
   const uint64_t* look = A.look ? A.look + look_off(op_off, hidx, MW) : nullptr;
   // dominance rules (tbc_internal.h): open-read masks per (front, value), twin masks per list entry
   const uint32_t rules = COMM ? 0u : A.rules, vpad = A.vpad;
@@ -336,7 +368,7 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
         gu64* e = tab0 + (uint64_t)idx * KW;
         st64(e + 0, k0);
 #pragma unroll
-        for (int j = 0; j < MW; j++) st64(e + 1 + j, 0ull);
+        for (int j = 0; j < MW + (int)CWn; j++) st64(e + 1 + j, 0ull);
         st64(tab0 + ((uint64_t)KW << cap0) + idx, (uint64_t)kNone | ((uint64_t)kNone << 32));
         st32(stack0, idx);
       }
@@ -410,6 +442,7 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
         p_k0[ln] = r_k0[rs];
 #pragma unroll
         for (int j = 0; j < MW; j++) p_M[ln * MW + j] = r_M[rs * MW + j];
+        if constexpr (CNT) { p_C[ln * 2] = r_C[rs * 2]; p_C[ln * 2 + 1] = r_C[rs * 2 + 1]; }
         p_slot[ln] = r_idx[rs]; p_off[ln] = r_off[rs]; p_nlive[ln] = r_nlive[rs];
         my_cnt = r_cnt[rs];
       } else {
@@ -419,6 +452,7 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
         p_k0[ln] = k0;
 #pragma unroll
         for (int j = 0; j < MW; j++) p_M[ln * MW + j] = ld64(e + 1 + j);
+        if constexpr (CNT) { p_C[ln * 2] = ld64(e + 1 + MW); p_C[ln * 2 + 1] = ld64(e + 2 + MW); }
         const uint32_t fi = (uint32_t)k0 - 1u;
         const uint32_t o0 = off[fi], o1 = off[fi + 1], nc = ncr[fi];
         p_slot[ln] = idx; p_off[ln] = o0; p_nlive[ln] = o1 - o0;
@@ -471,7 +505,11 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
       }
       const uint64_t k0p = has_parent ? p_k0[q] : 1ull;
       const uint32_t fi = (uint32_t)k0p - 1u;
-      const int32_t st = (int32_t)(uint32_t)(k0p >> 32);
+      // count form: bit 30 of the state word says the config is hot (reached by a crashed call nobody has observed yet)
+      const bool hot = CNT && ((uint32_t)(k0p >> 32) & kHotBit) != 0u;
+      const int32_t st = CNT ? (int32_t)((uint32_t)(k0p >> 32) & ~kHotBit) : (int32_t)(uint32_t)(k0p >> 32);
+      uint64_t Cp[kCountWords] = {0ull, 0ull};
+      if constexpr (CNT) { Cp[0] = has_parent ? p_C[q * 2] : 0ull; Cp[1] = has_parent ? p_C[q * 2 + 1] : 0ull; }
       uint64_t Mp[MW];
 #pragma unroll
       for (int j = 0; j < MW; j++) Mp[j] = has_parent ? p_M[q * MW + j] : 0ull;
@@ -497,17 +535,27 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
           for (int j = 0; j < MW; j++) dominated = dominated || (twn[(uint64_t)(poff + c) * MW + j] & ~Mp[j]) != 0ull;
         }
       }
-      const uint32_t op = oi.op;
-      const uint32_t p = (oi.f_slot >> 8) & kSlotMask;
+      // count form: a candidate past the live calls is a CLASS of crashed calls; its next member (the count says which) must be invoked
+      const bool is_cls = CNT && act && c >= nlive;
+      const uint32_t cls_shift = (oi.f_slot >> 8) & 0xFFu, cls_width = (oi.f_slot >> 16) & 0xFFu;
+      uint64_t mem = ~0ull;
+      if constexpr (CNT) {
+        if (is_cls) {
+          const uint32_t kc = relaxed ? 0u : (uint32_t)(((cls_shift & 64u) ? Cp[1] : Cp[0]) >> (cls_shift & 63u)) & ((1u << cls_width) - 1u);
+          mem = cmem[oi.op + kc];                 // inv_rank | op << 32; the sentinel behind the last member is all ones
+        }
+      }
+      const uint32_t op = is_cls ? (uint32_t)(mem >> 32) : oi.op;
+      const uint32_t p = is_cls ? 0u : (oi.f_slot >> 8) & kSlotMask;
       if (prof) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); SEG(1); }
       bool lin = false;
 #pragma unroll
-      for (int j = 0; j < MW; j++) if ((p >> 6) == (uint32_t)j) lin = (Mp[j] >> (p & 63u)) & 1ull;
+      for (int j = 0; j < MW; j++) if (!is_cls && (p >> 6) == (uint32_t)j) lin = (Mp[j] >> (p & 63u)) & 1ull;
       if constexpr (!COMM) {
         // a crashed call has no per-front entry: its twins are every live open call with its effect (they all
         // complete earlier) and the crashed ones invoked before it -- walk the list (crash-heavy histories only)
         const uint32_t cf = oi.f_slot & 0xFFu;
-        if ((rules & kRuleTwin) && act && !lin && c >= nlive && (cf == TBC_F_WRITE || cf == TBC_F_CAS)) {
+        if (!CNT && (rules & kRuleTwin) && act && !lin && c >= nlive && (cf == TBC_F_WRITE || cf == TBC_F_CAS)) {
           for (uint32_t cc = 0; cc < c && !dominated; cc++) {
             const OpRec y = cc < nlive ? lst[poff + cc] : crashed[cc - nlive];
             if ((y.f_slot & 0xFFu) != cf || y.a != oi.a || (cf == TBC_F_CAS && y.b != oi.b)) continue;
@@ -519,17 +567,33 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
           }
         }
       }
-      const bool viable = act && !lin && !dominated && pair_viable<MW, COMM, REGF>(model, st, fi, Mp, poff, nlive, cnt, lst, crashed, oi);
+      bool viable = act && !lin && !dominated && !is_cls && pair_viable<MW, COMM, REGF>(model, st, fi, Mp, poff, nlive, cnt, lst, crashed, oi);
+      if constexpr (CNT) {
+        const uint32_t cf = oi.f_slot & 0xFFu;
+        // a hot config only takes calls whose precondition is its state; a crashed :write is not one, and never writes the state it finds
+        if (hot) viable = viable && (cf == TBC_F_READ || cf == TBC_F_CAS) && oi.a == st;
+        if (is_cls) viable = (uint32_t)mem <= fi && (cf == TBC_F_WRITE ? (!hot && oi.a != st) : oi.a == st);
+      }
       int32_t st2 = st;
       uint32_t fi2 = fi;
       uint64_t M2[MW];
+      uint64_t C2[kCountWords] = {Cp[0], Cp[1]};
       const auto slot_at = [=](uint32_t r) -> uint32_t {
         const uint32_t d = r - wbase;
         if (d < 8u) return (uint32_t)(w0 >> (8u * d)) & 0xFFu;
         if (d < 16u) return (uint32_t)(w1 >> (8u * (d - 8u))) & 0xFFu;
         return (uint32_t)slot8[r];
       };
-      make_child<MW, COMM, REGF>(model, viable, st, fi, R, slot_at, oi, Mp, M2, st2, fi2);
+      make_child<MW, COMM, REGF>(model, viable && !is_cls, st, fi, R, slot_at, oi, Mp, M2, st2, fi2);
+      bool observed = true;
+      if constexpr (CNT) {
+        if (viable && is_cls) {                     // a crashed call takes effect: no mask bit, the front stays, its class's count goes up
+          st2 = (oi.f_slot & 0xFFu) == TBC_F_WRITE ? oi.a : oi.b;
+          const uint64_t inc = relaxed ? 0ull : 1ull << (cls_shift & 63u);
+          if (cls_shift & 64u) C2[1] += inc; else C2[0] += inc;
+          observed = false;
+        }
+      }
       if constexpr (!COMM) {
         // eager reads: the child takes every open read its state allows (value nil or the state), the front moves
         // past the completions that linearizes, and the calls open at the new front are looked at again
@@ -537,6 +601,10 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
           for (;;) {
             const uint64_t* row = rdm + (uint64_t)fi2 * vpad * MW;
             const uint32_t vi = rdm_index(st2, vpad);
+            if constexpr (CNT) {                    // a read of exactly the produced value, absorbed now, observes the crashed call
+#pragma unroll
+              for (int j = 0; j < MW; j++) observed = observed || (row[vi * MW + j] & ~M2[j]) != 0ull;
+            }
 #pragma unroll
             for (int j = 0; j < MW; j++) M2[j] |= row[j] | row[vi * MW + j];
             uint32_t pp = slot_at(fi2);
@@ -560,7 +628,7 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
       }
       SEG(2);
       rounds++;
-      const uint64_t succ = __ballot(viable && fi2 == R);
+      const uint64_t succ = __ballot(viable && fi2 >= RT);      // (RT = R unless the count form checks a prefix)
       if (succ) {   // linearizable: lowest pair wins, nothing of this round is inserted
         const uint32_t wl = (uint32_t)__builtin_ctzll(succ);
         if (lane == 0) { sst(S, S_WINPAR, rl(pslot, wl)); sst(S, S_WINOP, rl(op, wl)); sst(S, S_WINSTATE, rl((uint32_t)st2, wl)); }
@@ -577,8 +645,72 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
       // ---- visited set: find the key in its bucket chain, else claim the first empty entry met.
       // Equal keys probe in lockstep: they look at the same bucket, go for the same entry, one wins the
       // CAS, and the others find the key there on their next look (`lost` then tells it is new).
-      const uint64_t k0 = (uint64_t)(fi2 + 1u) | ((uint64_t)(uint32_t)st2 << 32);
+      const uint64_t k0 = (uint64_t)(fi2 + 1u) | ((uint64_t)((uint32_t)st2 | ((CNT && !observed) ? kHotBit : 0u)) << 32);
       uint32_t b = key_hash32(k0, M2, MW) & bmask, idx = 0, full_buckets = 0;
+      bool is_new = false;
+      if constexpr (CNT) {
+        // ---- count form: the Pareto rule.  A child is dropped when a visited config with its key (k0, M) has used no more of any
+        // class; the pairs of a round count in pair order (oracle/wgl_count.c).  Three steps: (1) every lane walks its key's probe
+        // chain -- buckets from the hashed one up to the first with an empty entry -- and compares count vectors; (2) the lanes that
+        // survived are compared with each other, lowest lane first; (3) the survivors claim an empty entry each.
+        bool pending = viable, cand = false;
+        while (__ballot(pending)) {
+          if (pending) {
+            const gu64* bp = tab + (uint64_t)b * (4 * KW);
+            uint64_t kk[4];
+#pragma unroll
+            for (int t = 0; t < 4; t++) kk[t] = ld64(bp + t * KW);
+            bool dom = false, empty = false;
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+              if ((uint32_t)kk[t] == 0u) empty = true;
+              else if (kk[t] == k0) {
+                bool same = true;
+#pragma unroll
+                for (int j = 0; j < MW; j++) same = same && ld64(bp + t * KW + 1 + j) == M2[j];
+                if (same) {
+                  const uint64_t theirs[kCountWords] = {ld64(bp + t * KW + 1 + MW), ld64(bp + t * KW + 2 + MW)};
+                  dom = dom || counts_ge(C2, theirs, top);
+                }
+              }
+            }
+            if (dom) pending = false;
+            else if (empty) { cand = true; pending = false; }          // the chain ends here: nothing visited dominates it
+            else { b = (b + 1u) & bmask; if (++full_buckets > bmask) pending = false; }
+          }
+        }
+        uint64_t rem = __ballot(cand);
+        while (rem) {
+          const uint32_t l0 = (uint32_t)__builtin_ctzll(rem);
+          rem &= rem - 1ull;
+          const uint64_t bk0 = rl64(k0, l0);
+          bool same = k0 == bk0;
+#pragma unroll
+          for (int j = 0; j < MW; j++) same = same && M2[j] == rl64(M2[j], l0);
+          const uint64_t theirs[kCountWords] = {rl64(C2[0], l0), rl64(C2[1], l0)};
+          if (cand && lr > l0 && same && counts_ge(C2, theirs, top)) cand = false;
+        }
+        bool ins = cand;
+        while (__ballot(ins)) {
+          if (ins) {
+            gu64* bp = tab + (uint64_t)b * (4 * KW);
+            uint32_t empty = 0;
+#pragma unroll
+            for (int t = 0; t < 4; t++) if ((uint32_t)ld64(bp + t * KW) == 0u) empty |= 1u << t;
+            if (empty) {
+              const uint32_t t = (uint32_t)__builtin_ctz(empty);
+              gu64* e = bp + t * KW;
+              if (cas64_from_zero(e, k0) == 0ull) {
+#pragma unroll
+                for (int j = 0; j < MW; j++) st64(e + 1 + j, M2[j]);
+                st64(e + 1 + MW, C2[0]); st64(e + 2 + MW, C2[1]);
+                idx = b * 4u + t; ins = false;
+              }                                      // else another lane took it in this very step: look at the bucket again
+            } else { b = (b + 1u) & bmask; if (++full_buckets > bmask) ins = false; }
+          }
+        }
+        is_new = cand;
+      } else {
       bool pending = viable, fresh = false, won = false, lost = false;
       while (__ballot(pending)) {
         if (pending) {
@@ -605,10 +737,8 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
           }
         }
       }
-      if (__ballot(full_buckets > bmask)) { verdict = TBC_UNKNOWN; cause = TBC_CAUSE_VISITED_FULL; break; }
-      SEG(3);
       // the lowest lane among the lanes that produced one and the same new config keeps it
-      bool is_new = fresh;
+      is_new = fresh;
       uint64_t dupl = __ballot(fresh && !won);
       while (dupl) {
         const uint32_t l0 = (uint32_t)__builtin_ctzll(dupl);
@@ -618,6 +748,9 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
         if ((grp >> lr) & 1ull) is_new = lr == winner;
         dupl &= ~grp;
       }
+      }   // !CNT
+      if (__ballot(full_buckets > bmask)) { verdict = TBC_UNKNOWN; cause = TBC_CAUSE_VISITED_FULL; break; }
+      SEG(3);
       if (is_new) st64(par + idx, (uint64_t)pslot | ((uint64_t)(op + 1u) << 32));
       const uint64_t nb0 = __ballot(is_new);
       // ---- lookahead (register / cas-register): a new config is dead if the call completing at one of the
@@ -638,8 +771,9 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
         __builtin_amdgcn_wave_barrier();
         for (uint32_t cb = 0; cb < nn0; cb += 8u) {
           const uint32_t c = cb + (lr >> 3), j = lr & 7u;
-          const bool val = c < nn0;
-          const uint32_t cF = val ? c_fi[c] : 0u;
+          const uint32_t cF0 = c < nn0 ? c_fi[c] : 0u;
+          const bool val = c < nn0 && (!CNT || cF0 + j < RT);          // (completions past a prefix target constrain nothing; RT = R otherwise: the padding records say so themselves)
+          const uint32_t cF = val ? cF0 : 0u;
           const int32_t cs = val ? (int32_t)c_st[c] : 0;
           uint64_t Mc[MW], pm[MW];
 #pragma unroll
@@ -670,7 +804,8 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
           if (j >= 4u) acc |= x;
           uint32_t before = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)acc, 0x111, 0xf, 0xf, true);
           if (j == 0u) before = 0u;
-          const bool ok = need == kLookNone || linz || (int32_t)need == cs || dprod < j || pmhit || ((before >> need) & 1u);
+          // (count form: bit 48 = a crashed call producing `need` is invoked by that rank: available whatever the counts)
+          const bool ok = need == kLookNone || linz || (int32_t)need == cs || dprod < j || pmhit || ((before >> need) & 1u) || (CNT && ((w0 >> 48) & 1ull));
           const uint64_t bad = __ballot(val && !ok);
           if (is_new && ci >= cb && ci < cb + 8u) dead = ((bad >> (8u * (ci - cb))) & 0xFFull) != 0ull;
         }
@@ -692,6 +827,7 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
           r_pos[rs] = pos; r_idx[rs] = idx; r_k0[rs] = k0;
 #pragma unroll
           for (int j = 0; j < MW; j++) r_M[rs * MW + j] = M2[j];
+          if constexpr (CNT) { r_C[rs * 2] = C2[0]; r_C[rs * 2 + 1] = C2[1]; }
           r_off[rs] = co0; r_nlive[rs] = co1 - co0; r_cnt[rs] = (co1 - co0) + cnc;
         }
       }
@@ -742,7 +878,7 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
   }
   if (need_park) continue;
   if (!need_grow) break;
-  if (!grow_visited_set<MW>(S, r_pos, lane)) {
+  if (!grow_visited_set<MW, CNT>(S, r_pos, lane)) {
     if (lane == 0) { sst(S, S_VERDICT, (uint32_t)TBC_UNKNOWN); sst(S, S_CAUSE, (uint32_t)TBC_CAUSE_VISITED_FULL); }
     break;
   }
@@ -856,18 +992,23 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
 #define TBC_BEAM_WAVES 4
 #endif
 constexpr uint32_t kBeamWaves = TBC_BEAM_WAVES;
-template <int MW, bool COMM, bool REGF>
-__global__ __launch_bounds__(64 * kBeamWaves, COMM ? 1 : TBC_BEAM_MIN_WAVES) void wgl_beam_kernel(BeamArgs A) {
+template <int MW, bool COMM, bool REGF, bool CNT = false>
+__global__ __launch_bounds__(64 * kBeamWaves, (COMM || CNT) ? 1 : TBC_BEAM_MIN_WAVES) void wgl_beam_kernel(BeamArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   const uint32_t lane = threadIdx.x & 63u, wv = rfl(threadIdx.x >> 6);
   const uint32_t w = blockIdx.x * kBeamWaves + wv;
-  if (w < A.n_work) beam_one<MW, COMM, REGF>(A, rfl(A.work[w]), lds + wv * beam_lds_words(MW), lane);
+  if (w < A.n_work) beam_one<MW, COMM, REGF, CNT>(A, rfl(A.work[w]), lds + wv * beam_lds_words(MW, CNT), lane);
 }
 
 template <int MW>
 void launch_beam_mw(const BeamArgs& a, hipStream_t s) {
-  const size_t lds = (size_t)kBeamWaves * beam_lds_words(MW) * 4;
+  const bool cnt = (a.rules & kRuleCount) != 0u;       // count form: crashed calls as counts per class (register family only)
+  const size_t lds = (size_t)kBeamWaves * beam_lds_words(MW, cnt) * 4;
   const uint32_t n_blocks = (a.n_work + kBeamWaves - 1) / kBeamWaves;
+  if (cnt) {
+    if constexpr (MW <= 2) hipLaunchKernelGGL((wgl_beam_kernel<MW, false, true, true>), dim3(n_blocks), dim3(64 * kBeamWaves), lds, s, a);
+    return;
+  }
   // the commutative (set / bank) models get their own instantiation: their evaluation code would
   // otherwise double the register budget of the register-family kernel
   if (a.model_kind == TBC_MODEL_SET || a.model_kind == TBC_MODEL_BANK)
