@@ -166,6 +166,11 @@ def main():
     t_gen = time.time()
     seeds = shard.shard_indices(F * B * world, rank, world)      # history i of the job lives on rank i % world
     hists_all = [synth.register_ops_many(seeds[k * B:(k + 1) * B], n_ops=args.ops, n_procs=args.procs, busy=args.busy, info=args.info) for k in range(F)]
+    # every resident batch carries ONE history with a planted bad read (its last): a verdict mix-up cannot hide behind "all valid"
+    planted = B - 1
+    for k in range(F):
+        hists_all[k][planted] = columns.pair_events(synth.register_events(n_ops=args.ops, n_procs=args.procs, seed=int(seeds[k * B + planted]), busy=args.busy,
+                                                                          info=args.info, corrupt=0.5))
     hists = hists_all[0]
     t_gen = time.time() - t_gen
     model = core.make_model(N.MODEL_CAS_REGISTER, N.NIL)
@@ -230,6 +235,9 @@ def main():
         sharded_ms = {"median_ms": round(statistics.median(times[1:]), 3), "valid": r1[0]["valid"], "gpus": world}
 
     verdicts = batch.verdicts()
+    for b in batches:               # element-wise: the planted history is INVALID, every other one VALID, in every resident batch
+        v = b.verdicts()
+        assert int(v[planted]) == N.INVALID and bool((np.delete(v, planted) == N.VALID).all()), "a verdict is not where it belongs"
     all_counters = [b.counters() for b in batches]
     counters = {k: sum(c[k] for c in all_counters) // F for k in all_counters[0]}      # per launch: the mean over the resident batches
     n_valid = sum(int((b.verdicts() == N.VALID).sum()) for b in batches)            # over all resident batches (F x B histories per GPU)
@@ -337,7 +345,7 @@ def main():
         if world == 1 and not args.no_cpu:
             from concurrent.futures import ThreadPoolExecutor
             from oracle import wgl
-            S = min(args.cpu_sample, B)
+            S = min(args.cpu_sample, B - 1)          # (the planted history is checked by itself below, not timed in the sample)
             om = {"kind": 1, "init": N.NIL}
             dicts = [hists[i].as_dict() for i in range(S)]
             wgl.check(dicts[0], om, "window", want_witness=False)          # loads / builds the oracle
@@ -385,15 +393,21 @@ def main():
                                     "level_sweep_on_cpu": {"value": round(S1 / ts, 3), "unit": "histories/s", "cores": 1,
                                                            "sample": f"first {S1} histories, oracle/sweep_ref.c"},
                                     "host_cores_visible": cores_visible, "host_cpu_quota": cpu_quota}
-            assert okw == oks == ok1 == sum(int(v == N.VALID) for v in verdicts[:S1]), "GPU and oracles disagree on the sample"
-            assert sum(int(v == 1) for v in oka[:S]) == sum(int(v == N.VALID) for v in verdicts[:S]), "GPU and oracle disagree on the sample"
-            assert sum(int(v == 1) for v in okwa[:S]) == sum(int(v == N.VALID) for v in verdicts[:S]), "GPU and oracle (wide schedule, thread pool) disagree on the sample"
+            # element-wise, not sums: history i's verdict on the GPU is history i's verdict on the CPU, in every formulation
+            assert okw == oks == ok1 == S1 and all(int(v) == N.VALID for v in verdicts[:S1]), "GPU and oracles disagree on the sample"
+            assert [int(v) for v in oka[:S]] == [int(v) for v in verdicts[:S]], "GPU and oracle disagree on the sample"
+            assert [int(v) for v in okwa[:S]] == [int(v) for v in verdicts[:S]], "GPU and oracle (wide schedule, thread pool) disagree on the sample"
+            rp = wgl.check(hists[planted].as_dict(), om, "window", want_witness=False, max_steps=50_000_000)
+            assert rp["valid"] == 0 == int(verdicts[planted]), "GPU and oracle disagree on the planted history"
+            rgp = core.check_ops(hists[planted], model, o_sweep)
+            assert rgp["valid"] == 0 and rgp["fail_op"] == rp["fail_op"], "the planted history's failing op"
             line["extra"]["time_to_verdict_ms"]["vs_cpu_port_single_thread"] = round((tc / S1 * 1e3) / statistics.median(ttv), 2)
 
             if not args.no_tiers:
                 # crashed-op tiers x {as generated, one bad read}; one history each, GPU limit 3 s,
-                # CPU limit 2*10^7 steps.  With crashed calls the sweep has one segment (a crashed call stays open for ever)
-                # or hands over to the depth-first search; > 64 process slots always do.
+                # CPU limit 2*10^7 steps.  With crashed calls the library takes the COUNT FORM (crashed calls as counts per effect
+                # class, one mask word; a history the budgeted exact search leaves open is refuted relaxed, then its prefix is
+                # linearized): cpu_port_ms is the plain knossos.wgl restatement, cpu_same_algorithm_ms the count form's passes on one core.
                 tiers = []
                 for info in (0.0, 0.01, 0.05):
                     for corrupt in (0.0, 0.5):
@@ -404,11 +418,18 @@ def main():
                         t1 = time.perf_counter()
                         rc = wgl.check(hh.as_dict(), om, "window", want_witness=False, max_steps=20_000_000)
                         tcpu = (time.perf_counter() - t1) * 1e3
+                        # the count form's own passes on one CPU core (oracle/wgl_count.c): the algorithm is the CPU's too
+                        t1 = time.perf_counter()
+                        rp = wgl.check_count_pipeline(hh.as_dict(), om, width=max(rg["search_width"], 1)) if info else None
+                        tpipe = (time.perf_counter() - t1) * 1e3
+                        if rp is not None:
+                            assert rg["valid"] == rp[0] and (rp[0] == 1 or rg["fail_op"] == rp[1]), (info, corrupt, "count form")
                         if rg["valid"] != -1 and rc["valid"] != -1:
                             assert rg["valid"] == rc["valid"] and (rg["valid"] == 1 or rg["fail_op"] == rc["fail_op"]), (info, corrupt)
                         tiers.append({"info_rate": info, "history": "1 bad read" if corrupt else "as generated", "process_slots": int(hh.n_process),
                                       "gpu_ms": round(tg, 3), "gpu_verdict": rg["valid"], "gpu_analyzer": "linear" if rg["analyzer"] == N.ALG_LINEAR else "wgl",
-                                      "cpu_port_ms": round(tcpu, 3), "cpu_verdict": rc["valid"]})
+                                      "cpu_port_ms": round(tcpu, 3), "cpu_verdict": rc["valid"],
+                                      "cpu_same_algorithm_ms": None if rp is None else round(tpipe, 3), "cpu_same_algorithm_passes": None if rp is None else rp[4]})
                 line["extra"]["tiers"] = tiers
 
         if world == 1 and args.busy2 > 0:

@@ -38,7 +38,9 @@
 extern "C" {
 #endif
 
-#define TBC_ABI_VERSION 1u
+/* 2: tbc_opts grew to 64 bytes (lanes_per_history, reserved0), tbc_batch_sweep_finish gained merged_bytes, tbc_opts.dominance
+ * gained TBC_DOM_NO_COUNT_FORM.  A caller built against another version must refuse the library (tbc_version()). */
+#define TBC_ABI_VERSION 2u
 
 /* ------------------------------------------------------------------ status */
 typedef enum tbc_status {
@@ -339,8 +341,8 @@ tbc_status tbc_batch_last_timing(const tbc_batch* b, uint64_t ns[4]);
 /* SEVERAL BATCHES IN FLIGHT.  A batch owns its stream and its arenas, so different batches may be run at the
  * same time from different host threads (tbc_batch_run holds no process-wide lock; one batch is still one
  * thread's at a time) -- which is how jepsen.independent/checker drives a checker: one (bounded-)pmap thread
- * per key group (reference: src/tigerbeetle/checker.clj:60-78 hands each key's sub-history to the wrapped
- * checker).  Batches that run several histories per wavefront take the whole GPU for their search and the
+ * per key group (the reference wraps its per-key checkers in jepsen.independent/checker at
+ * src/tigerbeetle/workloads/set_full.clj:154-158).  Batches that run several histories per wavefront take the whole GPU for their search and the
  * library gives those searches the device one at a time, in launch order, through a device-side event; the
  * init and pack of the next batch run beside the search of the previous one (measured: 2 x 32,768 histories
  * in flight, 258k histories/s against 204k one batch after the other).  ns = how long the last run's search
@@ -352,7 +354,7 @@ uint64_t tbc_batch_device_bytes(const tbc_batch* b);
 /* the search_width this batch runs the depth-first search at (what tbc_opts.search_width = 0 resolved to; 1 when
  * several histories share a wavefront) */
 uint32_t tbc_batch_search_width(const tbc_batch* b);
-/* lanes per history of the depth-first search: 8 / 16 / 32 (several histories per wavefront) or 64 */
+/* lanes per history of the depth-first search: 4 / 8 / 16 / 32 (several histories per wavefront) or 64 */
 uint32_t tbc_batch_lanes_per_history(const tbc_batch* b);
 /* how the last run was answered when the level sweep (knossos.linear; jit_sweep.hip) is in play:
  * TBC_ALG_LINEAR always asks for it, TBC_ALG_COMPETITION on small batches that want no witness.

@@ -179,6 +179,7 @@ SYMBOLS = {
 }
 
 _LIB = None
+ABI_VERSION = 2          # include/tbcheck.h TBC_ABI_VERSION
 
 
 def build(force: bool = False) -> str:
@@ -208,6 +209,9 @@ def lib():
             fn = getattr(_LIB, name)
             fn.restype = res
             fn.argtypes = args
+        if _LIB.tbc_version() != ABI_VERSION:      # the structs above are this version's: another layout would be read past its end
+            v, _LIB = _LIB.tbc_version(), None
+            raise ImportError(f"{LIB_PATH} has ABI version {v}, this binding is written for {ABI_VERSION}: rebuild (__graft_entry__.build())")
     return _LIB
 
 

@@ -201,6 +201,11 @@ class Batch:
     def sweep_merge(self, gathered, world):
         """`gathered`: a torch CUDA uint8 tensor holding the `world` ranks' tables back to back (all_gather_into_tensor):
         OR-ed on the device, composed; the exchanged bytes never pass through the host."""
+        # the producer of `gathered` (an all_gather_into_tensor, a torch.cat) was only ENQUEUED on torch's current stream; the library
+        # reads the buffer on the batch's own non-blocking stream, which has no ordering against it: wait for the producer first
+        import torch
+        if gathered.is_cuda:
+            torch.cuda.current_stream(gathered.device).synchronize()
         st = N.lib().tbc_batch_sweep_merge(self._h, C.c_void_p(gathered.data_ptr()), C.c_uint64(gathered.numel() * gathered.element_size()),
                                            C.c_uint32(world), self._res)
         N.check_status(st)

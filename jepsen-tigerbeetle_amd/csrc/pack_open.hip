@@ -532,8 +532,8 @@ __global__ __launch_bounds__(256) void count_fronts_kernel(PackOpenArgs A) {
     const BeamHist* B = &A.bh[h];
     const uint32_t R = H->n_ret, nc = B->n_classes;
     if (!(H->flags & kHistCount) || H->status != 0 || B->status != 0 || R == 0 || nc == 0) continue;
-    const OpRec* cls = A.crashed + H->op_off;
     const uint64_t* cmem = A.cmem + B->cmem_off;
+    const OpRec* cls = reinterpret_cast<const OpRec*>(cmem);          // the class records head the history's block
     uint32_t* ncr = A.ncr + B->off_off;
     uint64_t* look = A.look ? A.look + look_off(H->op_off, h, A.mask_words) : nullptr;
     for (uint32_t F = tid; F < R; F += NT) {

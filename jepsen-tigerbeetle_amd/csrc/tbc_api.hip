@@ -335,6 +335,10 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
     return TBC_ERR_NO_DEVICE;
   }
   B->opts = *opts;
+  // several histories per wavefront expand one config per iteration: search_width 1 next to a named lanes_per_history means what
+  // 0 means (tbcheck.h says "leave search_width 0 or 1"), not the sequential knossos.wgl kernel
+  if (opts->lanes_per_history != 0 && opts->lanes_per_history != 64 && opts->search_width == 1) B->opts.search_width = 0;
+  opts = &B->opts;
   B->model = *model;
   B->device = (int)opts->device;
   if (B->device >= ndev || !device_is_gfx950(B->device)) {
@@ -1381,7 +1385,9 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results, int phase = 
       if (B->opts.want_witness) {
         r.witness = B->witness_host.data() + B->hist[h].op_off;
         if (by_sweep[h]) { r.witness = nullptr; r.n_witness = 0; }      // knossos.linear returns configs, not a linearization
-        else if ((B->rules & kRuleEager) && !is_seq[h] && d.depth) {
+        // (under branch lists the normalised root may pass every completion by itself -- a history of reads of nil / of the initial
+        // value: an empty chain, whose expansion is exactly those reads)
+        else if ((B->rules & kRuleEager) && !is_seq[h] && (d.depth || ((B->rules & kRuleBranch) && hist_back[h].n_ret != 0))) {
           tbc_status ws = expand_eager_witness(B, h, r.witness, &r.n_witness);
           if (ws != TBC_OK) return ws;
         }

@@ -294,7 +294,8 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
   const uint32_t* off = A.off + off_off;
   const uint32_t* ncr = A.ncr + off_off;
   const OpRec* lst = A.lst + ru64(B->lst_off);
-  const OpRec* crashed = A.crashed + op_off;
+  // (count form: the candidates past the live calls are the CLASSES of crashed calls, whose records head the history's block of cmem[])
+  const OpRec* crashed = CNT ? reinterpret_cast<const OpRec*>(A.cmem + ru64(B->cmem_off)) : A.crashed + op_off;
   const uint8_t* slot8 = A.slot8 + slot8_off(op_off, hidx);
   const uint32_t R = rfl(H->n_ret), status = rfl(H->status) | rfl(B->status);
   // K parents per iteration, G = 64 / K lanes (candidate slots) per parent per round.  A history that has

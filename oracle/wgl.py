@@ -385,3 +385,43 @@ def check_count(ops, model, width=4, max_probes=0, want_witness=True, round_pair
     if want_slots:
         out["slots"] = slots[:n].copy()
     return out
+
+
+def completion_rank(ops, op):
+    """rank of op's completion among the completions (crashed calls hold 0xFFFFFFFF: never below a completion)"""
+    ret = np.asarray(ops["ret_pos"]).astype(np.int64)
+    return int((ret < ret[op]).sum())
+
+
+def check_count_pipeline(ops, model, width=4, budget=None, want_witness=False):
+    """What the library does with a history in count form (tbc_api.hip, batch_run_impl), pass by pass over wgl_count.c: the exact
+    search under a budget of probes (the library: 32 per op of the batch's longest history); past it the RELAXED search (every
+    class an unlimited supply: a superset of the linearizations), whose INVALID verdict bounds the failing completion from above;
+    then the exact search of the PREFIX before that completion -- a linearization of it pins the failing op without exhausting
+    the exact config space.  Returns (valid, fail_op, result of the last pass, counters summed over the passes, which passes ran),
+    or None where the count form does not apply."""
+    n = len(ops["f"])
+    budget = 32 * n if budget is None else budget
+    tot = {"probes": 0, "visited": 0, "expanded": 0}
+
+    def add(r):
+        for k in tot:
+            tot[k] += r[k]
+        return r
+    g = check_count(ops, model, width=width, want_witness=want_witness, max_probes=budget)
+    if g is None:
+        return None
+    add(g)
+    if g["valid"] != -1:
+        return g["valid"], g["fail_op"], g, tot, "exact"
+    r = add(check_count(ops, model, width=width, want_witness=False, relaxed=True))
+    if r["valid"] == 1:
+        g = add(check_count(ops, model, width=width, want_witness=want_witness))
+        return g["valid"], g["fail_op"], g, tot, "exact, no budget"
+    t = completion_rank(ops, r["fail_op"])
+    if t == 0:
+        return 0, r["fail_op"], r, tot, "relaxed"
+    g = add(check_count(ops, model, width=width, want_witness=False, target=t))
+    if g["valid"] == 1:
+        return 0, r["fail_op"], g, tot, "prefix"
+    return g["valid"], g["fail_op"], g, tot, "prefix exhausted"

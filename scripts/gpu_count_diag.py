@@ -4,8 +4,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import jepsen_tigerbeetle_amd  # noqa
 from jepsen_tigerbeetle_amd import _native as N, columns, core, synth
 from oracle import wgl
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
-from test_count_form_gpu import oracle_pipeline
+def oracle_pipeline(w, ops, width):
+    return w.check_count_pipeline(ops, om, width=width)
 
 gm = core.make_model(N.MODEL_CAS_REGISTER, N.NIL)
 om = {"kind": 1, "init": N.NIL}

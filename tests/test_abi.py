@@ -30,7 +30,7 @@ def test_every_declared_symbol_is_exported_and_bound(native):
     for name in decl:
         assert hasattr(lib, name), f"{name} declared in include/ but not exported"
         assert name in native.SYMBOLS, f"{name} has no ctypes binding"
-    assert lib.tbc_version() == 1
+    assert lib.tbc_version() == 2
     assert lib.tbc_strerror(3).decode().startswith("no usable gfx950")
 
 

@@ -13,30 +13,9 @@ from oracle import brute
 CAS = {"kind": 1, "init": N.NIL}
 
 
-def completion_rank(ops, op):
-    ret = np.asarray(ops["ret_pos"]).astype(np.int64)
-    return int((ret < ret[op]).sum())          # crashed calls hold 0xFFFFFFFF: never below a completion
-
-
 def verdict_pipeline(oracle, ops, width, budget):
-    """What the library does with a history in count form: the exact search under a probe budget; past it the RELAXED
-    search (every class an unlimited supply: a superset of the linearizations), whose INVALID verdict bounds the failing
-    completion from above; then the exact search of the PREFIX before that completion -- a linearization of it pins the
-    failing op without exhausting the exact config space."""
-    g = oracle.check_count(ops, CAS, width=width, want_witness=False, max_probes=budget)
-    if g["valid"] != -1:
-        return g["valid"], g["fail_op"], "exact"
-    r = oracle.check_count(ops, CAS, width=width, want_witness=False, relaxed=True)
-    if r["valid"] == 1:
-        g = oracle.check_count(ops, CAS, width=width, want_witness=False)
-        return g["valid"], g["fail_op"], "exact, no budget"
-    t = completion_rank(ops, r["fail_op"])
-    if t == 0:
-        return 0, r["fail_op"], "relaxed"
-    g = oracle.check_count(ops, CAS, width=width, want_witness=False, target=t)
-    if g["valid"] == 1:
-        return 0, r["fail_op"], "prefix"
-    return g["valid"], g["fail_op"], "prefix exhausted"
+    v, fo, _, _, how = oracle.check_count_pipeline(ops, CAS, width=width, budget=budget)
+    return v, fo, how
 
 
 def crashy(seed, rng, small):

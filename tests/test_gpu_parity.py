@@ -627,3 +627,27 @@ def test_big_quiet_batches_take_the_narrow_kernel_by_default(native, oracle):
     assert all(r["valid"] == 1 and r["probes"] == res[j % 64]["probes"] for j, r in enumerate(res))      # every one of them, refilled groups included
     with core.Batch([base[i % 64] for i in range(4096)], gm(), opts) as b:
         assert (b.lanes_per_history(), b.search_width()) == (64, 2)
+
+
+def test_narrow_kernel_at_the_bench_configuration(native, oracle):
+    """bench.py's own configuration, bit for bit: 24,576 histories of 10k invocations / 64 processes at 10 % duty in ONE batch
+    (so the library takes the narrow kernel by itself: 8 histories per wavefront, compact 64 B front records, branch lists, first
+    visited sets of 4 entries per op that grow inside the kernel, more histories than group slots: the work queue refills) --
+    a sample of 64 valid histories and three with a planted bad read against the oracle's schedule for that kernel: verdict,
+    failing op and every counter (probes, new configs, configs expanded, deepest stack)."""
+    B = 24576
+    hists = synth.register_ops_many(range(7_000_000, 7_000_000 + B), n_ops=10000, n_procs=64, busy=0.1, info=0.0)
+    planted = [11, 4097, B - 5]
+    for i in planted:
+        hists[i] = columns.pair_events(synth.register_events(n_ops=10000, n_procs=64, seed=7_000_000 + i, busy=0.1, corrupt=0.5))
+    opts = core.make_opts(time_limit_ms=600000, want_witness=False, algorithm=N.ALG_COMPETITION, visited_per_op=4)      # bench.py's options
+    with core.Batch(hists, gm(), opts) as b:
+        assert (b.lanes_per_history(), b.search_width()) == (8, 1)
+        b.run()
+        verdicts = b.verdicts()
+        res = b.results()
+    sample = sorted(set(list(range(0, B, B // 61))[:61] + planted + [B - 1, B - 2, 1]))
+    for i in sample:
+        _assert_narrow(res[i], _narrow_expect(oracle, hists[i], 8, want_witness=False), i)
+    assert [int(verdicts[i]) for i in planted] == [0, 0, 0]
+    assert int((verdicts == 1).sum()) == B - len(planted)                      # element-wise: only the planted ones are invalid
