@@ -145,20 +145,39 @@ def main():
     import numpy as np
     import torch
     import torch.distributed as dist
-    if not torch.cuda.is_available():
+    # TBC_BENCH_BACKEND=gloo + TBC_BENCH_BATCH_CLASS=module:Class: the N > 1 plumbing of this file (barrier, max-over-ranks clock,
+    # verdict all-reduce, the one JSON line from rank 0) driven without a GPU by tests/test_distributed_gloo.py, which supplies a
+    # stand-in for core.Batch; nothing is measured in that mode and the line says so ("data": "stand-in")
+    backend = os.environ.get("TBC_BENCH_BACKEND", "nccl")
+    on_gpu = backend == "nccl"
+    if on_gpu and not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: libtbcheck has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    if on_gpu:
+        torch.cuda.set_device(local_rank)
+    else:
+        args.only_headline = args.no_cpu = args.no_tiers = args.no_set_full = True
+        args.busy2 = args.busy3 = 0.0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if on_gpu:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     import jepsen_tigerbeetle_amd  # noqa: F401
     from jepsen_tigerbeetle_amd import _native as N, columns, core, shard, synth
 
+    BatchCls = core.Batch
+    if not on_gpu:
+        import importlib
+        mod, cls = os.environ["TBC_BENCH_BATCH_CLASS"].split(":")
+        BatchCls = getattr(importlib.import_module(mod), cls)
+
     def barrier():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        if on_gpu:
+            torch.cuda.synchronize()
 
     # ---- synthetic input: B distinct seeded histories per rank
     B = args.batch
@@ -166,11 +185,19 @@ def main():
     t_gen = time.time()
     seeds = shard.shard_indices(F * B * world, rank, world)      # history i of the job lives on rank i % world
     hists_all = [synth.register_ops_many(seeds[k * B:(k + 1) * B], n_ops=args.ops, n_procs=args.procs, busy=args.busy, info=args.info) for k in range(F)]
-    # every resident batch carries ONE history with a planted bad read (its last): a verdict mix-up cannot hide behind "all valid"
+    # every resident batch carries ONE history with a planted bad read (its last): a verdict mix-up cannot hide behind "all valid".
+    # The read is planted 2 % into the history: an INVALID verdict means exhausting the configs up to the failing completion, and one
+    # in the middle of a 10k-op history costs 9x a valid history's search -- the slowest history of a batch is the batch's step
+    # (planted in the middle: 284 ms per step instead of 127, profiles/r04_bench_planted_in_the_middle.json.log)
+    # -- and it reads the value 4 in a history that only ever writes 0..3: impossible, and inside the batch's value domain (the
+    # generator's own planted value, 12, would widen every front record of the batch from 64 to 160 bytes: another kernel instantiation)
     planted = B - 1
     for k in range(F):
-        hists_all[k][planted] = columns.pair_events(synth.register_events(n_ops=args.ops, n_procs=args.procs, seed=int(seeds[k * B + planted]), busy=args.busy,
-                                                                          info=args.info, corrupt=0.5))
+        hp = columns.pair_events(synth.register_events(n_ops=args.ops, n_procs=args.procs, seed=int(seeds[k * B + planted]), busy=args.busy,
+                                                       info=args.info, corrupt=0.02, n_values=4))
+        assert int((hp.a == 4 + 7).sum()) == 1
+        hp.a[hp.a == 4 + 7] = 4
+        hists_all[k][planted] = hp
     hists = hists_all[0]
     t_gen = time.time() - t_gen
     model = core.make_model(N.MODEL_CAS_REGISTER, N.NIL)
@@ -178,7 +205,7 @@ def main():
                           algorithm=N.ALG_COMPETITION, search_width=args.width, visited_per_op=args.visited_per_op,
                           round_budget=args.round_budget, lanes_per_history=args.lanes)
     t_create = time.perf_counter()
-    batches = [core.Batch(h, model, opts) for h in hists_all]        # H2D happens here: inputs resident before timing
+    batches = [BatchCls(h, model, opts) for h in hists_all]        # H2D happens here: inputs resident before timing
     t_create = (time.perf_counter() - t_create) / F
     batch = batches[0]
     width = batch.search_width()                  # what --width 0 became for this batch
@@ -243,7 +270,7 @@ def main():
     n_valid = sum(int((b.verdicts() == N.VALID).sum()) for b in batches)            # over all resident batches (F x B histories per GPU)
     n_unknown = sum(int((b.verdicts() == N.UNKNOWN).sum()) for b in batches)
     if world > 1:
-        t = torch.tensor([n_valid, n_unknown], dtype=torch.int64, device="cuda")
+        t = torch.tensor([n_valid, n_unknown], dtype=torch.int64, device="cuda" if on_gpu else "cpu")
         dist.all_reduce(t)
         n_valid, n_unknown = int(t[0]), int(t[1])
 
@@ -270,7 +297,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u64", "data": "synthetic",
+            "dtype": "u64", "data": "synthetic" if on_gpu else "stand-in",
             "config": {"workload": workload_name(args.ops, args.procs, args.busy, args.info), "histories_per_gpu": B, "ops_after_pairing": int(batch.total_ops // B),
                        "processes": args.procs, "busy": args.busy, "info_rate": args.info,
                        "batches_in_flight": F,
@@ -323,25 +350,26 @@ def main():
                 "kernel_ms": round(tm4["search"] / 1e6, 3), "pack_ms": round(tm4["pack"] / 1e6, 3),
                 "probes_per_launch": c4["probes"], "new_configs_per_launch": c4["visited"], "algorithmic_bytes_per_launch": alg4,
                 "roofline_frac": round(alg4 / (tm4["search"] * 1e-9) / 1e9 / HBM_PEAK_GBS, 6)}
-        ttv, ttv_dfs, analyzers = [], [], []
-        o_sweep = core.make_opts(device=local_rank, want_witness=False, algorithm=N.ALG_COMPETITION)
-        o_dfs = core.make_opts(device=local_rank, want_witness=True, algorithm=N.ALG_COMPETITION, search_width=args.width)
-        core.check_ops(hists[0], model, o_sweep)                     # first call sizes the persistent context
-        for i in range(min(10, B)):
-            t1 = time.perf_counter(); r = core.check_ops(hists[i], model, o_sweep); ttv.append((time.perf_counter() - t1) * 1e3)
-            analyzers.append(r["analyzer"])
-            assert r["valid"] == verdicts[i]
-        core.check_ops(hists[0], model, o_dfs)
-        for i in range(min(5, B)):
-            t1 = time.perf_counter(); r = core.check_ops(hists[i], model, o_dfs); ttv_dfs.append((time.perf_counter() - t1) * 1e3)
-        bad = columns.pair_events(synth.register_events(n_ops=args.ops, n_procs=args.procs, seed=12345, busy=args.busy,
-                                                        info=args.info, corrupt=0.5))
-        t1 = time.perf_counter(); rb = core.check_ops(bad, model, o_sweep); tb_gpu = (time.perf_counter() - t1) * 1e3
-        line["extra"]["time_to_verdict_ms"] = {"valid_median": round(statistics.median(ttv), 3), "valid_min": round(min(ttv), 3),
-                                               "answered_by_sweep": sum(a == N.ALG_LINEAR for a in analyzers), "of": len(analyzers),
-                                               "depth_first_with_witness_median": round(statistics.median(ttv_dfs), 3),
-                                               "invalid_example": round(tb_gpu, 3),
-                                               "invalid_example_verdict": rb["valid"], "invalid_example_steps": rb["steps"]}
+        if on_gpu:      # (one history through tbc_check: needs the device)
+            ttv, ttv_dfs, analyzers = [], [], []
+            o_sweep = core.make_opts(device=local_rank, want_witness=False, algorithm=N.ALG_COMPETITION)
+            o_dfs = core.make_opts(device=local_rank, want_witness=True, algorithm=N.ALG_COMPETITION, search_width=args.width)
+            core.check_ops(hists[0], model, o_sweep)                     # first call sizes the persistent context
+            for i in range(min(10, B)):
+                t1 = time.perf_counter(); r = core.check_ops(hists[i], model, o_sweep); ttv.append((time.perf_counter() - t1) * 1e3)
+                analyzers.append(r["analyzer"])
+                assert r["valid"] == verdicts[i]
+            core.check_ops(hists[0], model, o_dfs)
+            for i in range(min(5, B)):
+                t1 = time.perf_counter(); r = core.check_ops(hists[i], model, o_dfs); ttv_dfs.append((time.perf_counter() - t1) * 1e3)
+            bad = columns.pair_events(synth.register_events(n_ops=args.ops, n_procs=args.procs, seed=12345, busy=args.busy,
+                                                            info=args.info, corrupt=0.5))
+            t1 = time.perf_counter(); rb = core.check_ops(bad, model, o_sweep); tb_gpu = (time.perf_counter() - t1) * 1e3
+            line["extra"]["time_to_verdict_ms"] = {"valid_median": round(statistics.median(ttv), 3), "valid_min": round(min(ttv), 3),
+                                                   "answered_by_sweep": sum(a == N.ALG_LINEAR for a in analyzers), "of": len(analyzers),
+                                                   "depth_first_with_witness_median": round(statistics.median(ttv_dfs), 3),
+                                                   "invalid_example": round(tb_gpu, 3),
+                                                   "invalid_example_verdict": rb["valid"], "invalid_example_steps": rb["steps"]}
         if world == 1 and not args.no_cpu:
             from concurrent.futures import ThreadPoolExecutor
             from oracle import wgl

@@ -179,3 +179,62 @@ def test_check_sharded_code_path_world_size_2(tmp_path, native, oracle):
         ops = columns.pair_events(synth.register_events(**c)).as_dict()
         ref = oracle.check_sweep(ops, {"kind": 1, "init": N.NIL}, seg_target=seg_target, n_dom=n_dom)
         assert row[0] == ref["valid"] and (row[2], row[3]) == (ref["probes"], ref["configs_total"])
+
+
+class StandInBatch:
+    """core.Batch's surface as bench.py uses it, without a device: every history VALID except the planted one (bench.py plants an
+    impossible read in the last history of every resident batch).  For the plumbing test below only."""
+
+    def __init__(self, histories, model, opts):
+        self.n_hist = len(histories)
+        self.total_ops = sum(len(h) for h in histories)
+        self._v = np.ones(self.n_hist, np.int32)
+        self._v[-1] = 0
+
+    def run(self):
+        return self
+
+    def verdicts(self):
+        return self._v
+
+    def timing_ns(self):
+        return {"init": 1000, "pack": 2000, "search": 3000, "retries": 0, "turn_wait": 0}
+
+    def counters(self):
+        return {"steps": 10 * self.n_hist, "visited": 8 * self.n_hist, "probes": 10 * self.n_hist, "backtracks": 0, "max_depth": 1,
+                "table_slots": 0, "ns_pack": 0, "ns_search": 0, "ns_total": 0}
+
+    def search_width(self):
+        return 1
+
+    def lanes_per_history(self):
+        return 8
+
+    def device_bytes(self):
+        return 0
+
+    def close(self):
+        pass
+
+
+def test_bench_n_gt_1_plumbing_over_gloo(native):
+    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one process per rank), over gloo with a stand-in for
+    the device batch: the sharding of the seeds, the barriers, the max-over-ranks clock, the verdict all-reduce and the ONE JSON
+    line from rank 0 are the code a multi-GPU node will run."""
+    import json
+    import subprocess
+    env = dict(os.environ, TBC_BENCH_BACKEND="gloo", TBC_BENCH_BATCH_CLASS="test_distributed_gloo:StandInBatch",
+               PYTHONPATH=os.pathsep.join([os.path.join(ROOT, "tests"), ROOT, os.environ.get("PYTHONPATH", "")]))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
+           "--batch", "6", "--ops", "300", "--procs", "8", "--in-flight", "2"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                   # rank 0 only
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 4 and line["warmup"] == 1 and line["scaling"] == "weak" and line["data"] == "stand-in"
+    assert line["config"]["histories_per_gpu"] == 6 and line["config"]["batches_in_flight"] == 2
+    # whole-job aggregate: 2 ranks x 6 histories per step; verdicts summed over the ranks' resident batches (one planted INVALID each)
+    assert abs(line["value"] - 2 * 6 * 4 / (line["ms_per_step"] * 4 / 1e3)) < 0.01 * line["value"]      # (ms_per_step is rounded to a microsecond)
+    assert line["extra"]["valid"] == 2 * 2 * 5 and line["extra"]["unknown"] == 0
