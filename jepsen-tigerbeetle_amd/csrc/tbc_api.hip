@@ -290,6 +290,10 @@ struct tbc_batch {
   bool count_form = false;
   DevBuf<uint64_t> d_cmem;
   std::vector<CountHist> count_hist;       // (kept for the result marshalling: which crashed calls a count vector stands for)
+  uint32_t epoch = 0;               // narrow kernel: the pass number its visited-set keys are tagged with (1..255; the arena is zeroed when it wraps)
+  bool any_crashed = true;          // some op of the batch never completes (else the crashed-call arena is never read: one element)
+  // u64 words per entry of the batch's own visited-set arena: the narrow kernel keeps no parent links when nobody wants a witness
+  uint32_t tab_stride() const { return entry_words() - ((lanes && !opts.want_witness) ? 1u : 0u); }
   uint32_t entry_words() const { return mask_words + 2u + (count_form ? kCountWords : 0u); }   // u64 words per wide-schedule entry
   DevBuf<unsigned long long> d_pool_cursor;
   // last run
@@ -375,6 +379,7 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
 
   const uint32_t nh = desc->n_hist;
   B->n_hist = nh;
+  TRACE("create: begin");
   B->total_ops = desc->op_off[nh];
   if (B->total_ops != desc->cols.n) { set_error("op_off[n_hist] (%llu) != cols.n (%u)", (unsigned long long)B->total_ops, desc->cols.n); return TBC_ERR_INVALID_ARG; }
   // the offsets index the op columns from here on (width heuristic, value scan, sweep sizing): check them first
@@ -520,6 +525,15 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
     if (B->lanes && (B->rules & kRuleEager)) B->rules |= kRuleBranch;
   }
   const uint32_t EW = B->entry_words();   // u64 words per wide-schedule entry
+  {
+    bool any = false;
+    const uint32_t* rp = desc->cols.ret_pos;
+    for (uint64_t i = 0; i < B->total_ops && !any; i++) any = rp[i] == TBC_POS_CRASHED;
+    B->any_crashed = any;
+  }
+  // the frames arena is the pack kernels' scratch (3 words per op) and the sequential kernel's stack (4 + 2 mask words per op): a
+  // wide-schedule batch only needs the former -- the rare history that falls back to the sequential kernel gets frames of its own then
+  if (beam) B->frame_words = 3;
   if (B->sweep) {
     // segments: enough wavefronts to fill the GPU several times over, none shorter than 32 completions; cuts need the
     // register family's value domain (nil + 0..vmax = vpad's range) to enumerate the configs possible at a front
@@ -558,6 +572,7 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
       list_caps[h] = (uint32_t)std::min<uint64_t>(0xFFFFFFF0ull, open_list_entries(desc->cols, desc->op_off[h], n, desc->n_events[h], std::max(1u, slots_of(h)), rank_scratch, branch));
     }
   }
+  TRACE("create: lists sized");
   for (uint32_t h = 0; h < nh; h++) {
     Hist& H = B->hist[h];
     std::memset(&H, 0, sizeof H);
@@ -597,6 +612,7 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
       Q.lst_off = blst_n; blst_n += Q.lst_cap;
       Q.stack_off = bstack_n; bstack_n += (1ull << blg);
       Q.tab_off = btab_n; btab_n += (1ull << blg);
+    (void)EW;
     }
   }
 
@@ -615,6 +631,7 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
     }
   }
   if (B->sweep) { bstack_n = 0; btab_n = 0; }     // the sweep has no visited set; its fallback takes scratch arenas
+  TRACE("create: layout done");
   tbc_status s;
   const uint64_t T = B->total_ops;
   if ((s = B->d_f.alloc(T)) || (s = B->d_a.alloc(T)) || (s = B->d_b.alloc(T)) || (s = B->d_proc.alloc(T)) ||
@@ -626,8 +643,8 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
     return s;
   if (beam) {
     if ((s = B->d_bh.alloc(nh)) || (s = B->d_off.alloc(boff_n)) || (s = B->d_ncr.alloc(boff_n)) ||
-        (s = B->d_lst.alloc(blst_n)) || (s = B->d_crashed.alloc(B->count_form ? 0 : T)) || (s = B->d_cmem.alloc(B->count_form ? bocc_n : 0)) ||
-        (s = B->d_slot8.alloc(slot8_bytes(T, nh))) || (s = B->d_stack.alloc(bstack_n)) || (s = B->d_btab.alloc(btab_n * EW)) ||
+        (s = B->d_lst.alloc(blst_n)) || (s = B->d_crashed.alloc((B->count_form || !B->any_crashed) ? 0 : T)) || (s = B->d_cmem.alloc(B->count_form ? bocc_n : 0)) ||
+        (s = B->d_slot8.alloc(slot8_bytes(T, nh))) || (s = B->d_stack.alloc(bstack_n)) || (s = B->d_btab.alloc(btab_n * B->tab_stride())) ||
         (s = B->d_pool_cursor.alloc(1)))
       return s;
     if (B->sweep && ((s = B->d_cuts.alloc((uint64_t)nh * B->max_segs)) || (s = B->d_sres.alloc((uint64_t)nh * B->max_segs * kSweepSlices)) || (s = B->d_seglist.alloc((uint64_t)nh * B->max_segs * kSweepSlices * 3)))) return s;
@@ -636,7 +653,10 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
     if (B->rules && ((s = B->d_twn.alloc(blst_n * B->mask_words)) || (s = B->d_rdm.alloc(B->lanes ? 1 : T * B->vpad * B->mask_words)))) return s;
     // several histories per wavefront: front records (tbc_internal.h) instead of plain rows, with or without the rules
     if (B->lanes) { B->d_rdm.release(); if ((s = B->d_rdm.alloc(T * B->front_words()))) return s; }
-    if (B->lookahead && ((s = B->d_look.alloc(look_words(T, nh, B->mask_words))) || (s = B->d_looktmp.alloc(T)) ||
+    // (d_looktmp: scratch of the walk with lane = process slot only -- launch_pack_open's choice, repeated here)
+    const char* walk_env = std::getenv("TBC_OPEN_WALK");
+    const bool by_front = B->mask_words == 1 && B->vpad <= 32 && !(walk_env && std::strcmp(walk_env, "slots") == 0);
+    if (B->lookahead && ((s = B->d_look.alloc(look_words(T, nh, B->mask_words))) || (s = B->d_looktmp.alloc(by_front ? 0 : T)) ||
                          (s = B->d_dstack.alloc(bstack_n)))) return s;
     // growth pool: 30 % of the visited-set arena -- 10 % for the big quiet batches that run several histories per wavefront, whose sets
     // rarely grow (a history that outgrows its table and finds the pool empty is run again from a scratch arena: at 32 calls in
@@ -644,7 +664,7 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
     {
       uint64_t biggest = 0;
       for (uint32_t h = 0; h < nh; h++) biggest = std::max<uint64_t>(biggest, 1ull << B->bh[h].tab_log2);
-      uint64_t words = std::max<uint64_t>(btab_n * EW * (B->lanes ? 1u : 3u) / 10, biggest * (4 + 16 + 4) * (EW + 1));
+      uint64_t words = std::max<uint64_t>(btab_n * B->tab_stride() * (B->lanes ? 1u : 3u) / 10, biggest * (4 + 16 + 4) * (EW + 1));
       words = std::min<uint64_t>(words, (32ull << 30) / 8);
       if (B->sweep) words = 1;
       if ((s = B->d_pool.alloc(words))) return s;
@@ -676,6 +696,7 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
     for (auto& e : B->ev) HIP_TRY(hipEventCreate(&e));
   }
 
+  TRACE("create: arenas allocated");
   // inputs become resident
   if (T) {
     HIP_TRY(hipMemcpyAsync(B->d_f.p, desc->cols.f, T, hipMemcpyHostToDevice, B->stream));
@@ -696,6 +717,7 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
   for (uint32_t h = 0; h < nh; h++) work[h] = h;
   HIP_TRY(hipMemcpyAsync(B->d_work.p, work.data(), nh * 4, hipMemcpyHostToDevice, B->stream));
   HIP_TRY(hipStreamSynchronize(B->stream));
+  TRACE("create: inputs resident");
   B->res_host.resize(nh);
   return TBC_OK;
 }
@@ -763,7 +785,7 @@ static BeamArgs make_beam_args(tbc_batch* B, uint64_t* tab, uint32_t* stack, uin
   a.model_aux = B->model.init; a.n_keys = B->model.n_keys;
   a.n_classes = B->model.n_classes; a.width = B->width;
   a.round_budget = B->opts.round_budget;
-  a.cmem = B->d_cmem.p; a.count_mode = kCountExact;
+  a.cmem = B->d_cmem.p; a.count_mode = kCountExact; a.tab_stride = B->entry_words(); a.epoch = 0;
   a.rules = B->rules; a.twn = B->d_twn.p; a.rdm = B->d_rdm.p; a.vpad = B->vpad; a.rk8 = B->d_rk8.p; a.front_words = B->front_words(); a.next_work = B->d_queue.p;
   a.max_steps = B->opts.max_steps;
   a.time_limit_ticks = B->opts.time_limit_ms * 100000ull;
@@ -805,9 +827,15 @@ static tbc_status scratch_pass(tbc_batch* B, const std::vector<uint32_t>& grp, c
     entries += 1ull << lg[i];
   }
   DevBuf<uint64_t> big;
-  DevBuf<uint32_t> bstack, bdstack;
+  DevBuf<uint32_t> bstack, bdstack, bframes;
   tbc_status st = big.alloc(entries * words_per_entry);
   if (st != TBC_OK) return st;
+  const uint32_t seq_fw = search_frame_words(B->mask_words);
+  if (!beam && B->frame_words < seq_fw) {          // the batch's frames arena is sized for the pack kernels only: the sequential kernel's stack is taken here
+    uint64_t fn = 0;
+    for (size_t i = 0; i < grp.size(); i++) { ph[i].frame_off = fn; fn += std::max<uint64_t>(ph[i].n_ops, 1) * seq_fw; }
+    if ((st = bframes.alloc(fn)) != TBC_OK) { big.release(); return st; }
+  }
   if (beam && (st = bstack.alloc(entries)) != TBC_OK) { big.release(); return st; }
   if (beam && B->lookahead && (st = bdstack.alloc(entries)) != TBC_OK) { big.release(); bstack.release(); return st; }
   hipError_t e = hipMemsetAsync(big.p, 0, entries * words_per_entry * 8, s);
@@ -824,7 +852,7 @@ static tbc_status scratch_pass(tbc_batch* B, const std::vector<uint32_t>& grp, c
       if (steps_override >= 0) ba.max_steps = (uint64_t)steps_override;
       // (a retry runs the schedule of the first pass: several histories per wavefront stay so)
       if (B->lanes && (!width_override || width_override == B->width)) launch_narrow(ba, B->mask_words, B->lanes, s); else launch_beam(ba, B->mask_words, search_blocks(nw), s); }
-    else { SearchArgs ra = make_search_args(B, big.p, nw); launch_search(ra, B->mask_words, search_blocks(nw), s); }
+    else { SearchArgs ra = make_search_args(B, big.p, nw); if (bframes.p) ra.frames = bframes.p; launch_search(ra, B->mask_words, search_blocks(nw), s); }
     e = hipGetLastError();
   }
   for (size_t i = 0; i < grp.size() && e == hipSuccess; i++)
@@ -836,7 +864,7 @@ static tbc_status scratch_pass(tbc_batch* B, const std::vector<uint32_t>& grp, c
     if (beam && e == hipSuccess) e = hipMemcpyAsync(B->d_bh.p + grp[i], &bh_back[grp[i]], sizeof(BeamHist), hipMemcpyHostToDevice, s);
   }
   if (e == hipSuccess) e = hipStreamSynchronize(s);
-  big.release(); bstack.release(); bdstack.release();
+  big.release(); bstack.release(); bdstack.release(); bframes.release();
   if (e != hipSuccess) { set_error("scratch pass failed: %s", hipGetErrorString(e)); return TBC_ERR_HIP; }
   return TBC_OK;
 }
@@ -1011,8 +1039,12 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results, int phase = 
   TRACE("run: begin");
   HIP_TRY(hipEventRecord(B->ev[0], s));
   HIP_TRY(hipMemsetAsync(B->d_bitmap.p, 0, B->d_bitmap.bytes(), s));
+  // several histories per wavefront: the visited sets are not zeroed before every pass -- the keys carry the pass number and
+  // another pass's entries read as empty (wgl_narrow_impl.h, entry_empty); the arena is zeroed when the number wraps (and first of all)
+  const bool use_epoch = beam && B->lanes != 0 && B->max_ops < 0xFFFFF0ull;
   if (beam) {
-    HIP_TRY(hipMemsetAsync(B->d_btab.p, 0, B->d_btab.bytes(), s));
+    if (use_epoch) B->epoch = B->epoch % 255u + 1u;
+    if (!use_epoch || B->epoch == 1u) HIP_TRY(hipMemsetAsync(B->d_btab.p, 0, B->d_btab.bytes(), s));
     HIP_TRY(hipMemsetAsync(B->d_pool.p, 0, B->d_pool.bytes(), s));
     HIP_TRY(hipMemsetAsync(B->d_pool_cursor.p, 0, sizeof(unsigned long long), s));
     HIP_TRY(hipMemsetAsync(B->d_off.p, 0, B->d_off.bytes(), s));
@@ -1063,6 +1095,7 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results, int phase = 
   } else if (beam) {
     BeamArgs ba = make_beam_args(B, B->d_btab.p, B->d_stack.p, B->d_dstack.p, nh);
     if (count_budget) ba.max_steps = count_budget;
+    if (B->lanes) { ba.tab_stride = B->tab_stride(); ba.epoch = use_epoch ? B->epoch : 0u; }
     if (B->lanes) {
       SearchTurn turn(B->device, s);        // one whole-GPU search at a time; another batch's pack runs beside it
       if (!B->ev_turn) HIP_TRY(hipEventCreate(&B->ev_turn));

@@ -315,7 +315,10 @@ struct BeamArgs {
   uint32_t front_words;              // u64 words per front record in rdm (narrow kernel only; kFrontCompactWords = the compact form)
   const uint64_t* cmem;              // count form: class members (tbc_internal.h, kRuleCount)
   uint32_t count_mode;               // kCountExact / kCountRelaxed
-  uint32_t pad4;
+  uint32_t tab_stride;               // narrow kernel: u64 words per entry of the batch's visited-set arena: mask_words + 2, or mask_words + 1
+                                     // when nobody wants a witness (no parent words: the kernel would not write them anyway)
+  uint32_t pad5;
+  uint32_t epoch;                    // narrow kernel: this pass's tag in the visited-set keys, 1..255 (wgl_narrow_impl.h, entry_empty); 0 = none
   uint32_t first_dynamic;            // narrow kernel: work items below this are dealt to the wavefronts at launch (wave w, group g: w * H + g) ...
   unsigned int* next_work;           // ... the others are taken from this counter (zeroed before the launch) as groups finish
 };

@@ -60,37 +60,12 @@ WV_DEV uint32_t key_hash32(uint64_t k0, const uint64_t* M, int mw) {      // as 
   return h;
 }
 
-// look at one bucket (four entries of KW u64): match | empty << 4
-template <int MW>
-WV_DEV uint32_t scan_bucket(const wv::gu64* bp, uint64_t k0, const uint64_t (&M)[MW]) {
-  constexpr uint32_t KW = MW + 1;
-  uint32_t match = 0, empty = 0;
-  if constexpr (MW == 1) {
-    wv::u32x4 e0, e1, e2, e3;
-    wv::ld_bucket16(bp, e0, e1, e2, e3);
-    const uint32_t k0l = (uint32_t)k0, k0h = (uint32_t)(k0 >> 32), ml = (uint32_t)M[0], mh = (uint32_t)(M[0] >> 32);
-    empty = (e0.x == 0u ? 1u : 0u) | (e1.x == 0u ? 2u : 0u) | (e2.x == 0u ? 4u : 0u) | (e3.x == 0u ? 8u : 0u);
-    match = ((e0.x == k0l && e0.y == k0h && e0.z == ml && e0.w == mh) ? 1u : 0u) |
-            ((e1.x == k0l && e1.y == k0h && e1.z == ml && e1.w == mh) ? 2u : 0u) |
-            ((e2.x == k0l && e2.y == k0h && e2.z == ml && e2.w == mh) ? 4u : 0u) |
-            ((e3.x == k0l && e3.y == k0h && e3.z == ml && e3.w == mh) ? 8u : 0u);
-  } else {
-    uint64_t kk[4];
-    WV_UNROLL
-    for (int t = 0; t < 4; t++) kk[t] = wv::ld64(bp + t * KW);
-    WV_UNROLL
-    for (int t = 0; t < 4; t++) {
-      if ((uint32_t)kk[t] == 0u) empty |= 1u << t;
-      else if (kk[t] == k0) {
-        bool same = true;
-        WV_UNROLL
-        for (int j = 0; j < MW; j++) same = same && wv::ld64(bp + t * KW + 1 + j) == M[j];
-        match |= same ? 1u << t : 0u;
-      }
-    }
-  }
-  return match | empty << 4;
-}
+// EPOCH TAGS.  A batch's visited sets used to be zeroed before every pass (28 GB of memset for the bench's batch, 2.6x the
+// algorithmic bytes of the search itself).  Instead the pass number (BeamArgs.epoch, 1..255) rides in bits 24..31 of every key's
+// low word (front + 1 < 2^24), and an entry whose tag is another pass's reads as EMPTY: the arena is zeroed once in 255 passes.
+// Zero stays empty too (the growth pool, scratch arenas), and epoch 0 is the untagged form: empty = zero.
+WV_DEV bool entry_empty(uint32_t x, uint32_t etag) { return x == 0u || (x & 0xFF000000u) != etag; }
+constexpr uint32_t kFrontMask = 0x00FFFFFFu;
 
 template <int MW>
 WV_DEV bool mask_bit(const uint64_t (&M)[MW], uint32_t p) {
@@ -124,7 +99,7 @@ WV_DEV int32_t reg_apply(int32_t st, uint32_t f, int32_t a, int32_t b) {
 // capacity, wave-uniform.  Slot numbers change: the caller empties the group's ring.
 template <int MW, class ColdArgs>
 WV_DEV bool grow_group(ColdArgs C, wv::gu64*& tab_u, wv::gu32*& stack_u, wv::gu32*& dstack_u, uint32_t& cap_log2_u,
-                       uint32_t sp, uint32_t dsp, uint32_t lane) {
+                       uint32_t sp, uint32_t dsp, uint32_t lane, uint32_t etag, bool links) {
   constexpr uint32_t KW = MW + 1, EW = MW + 2;
   const wv::gu64* tab = tab_u;
   const wv::gu32* stack = stack_u;
@@ -149,7 +124,7 @@ WV_DEV bool grow_group(ColdArgs C, wv::gu64*& tab_u, wv::gu32*& stack_u, wv::gu3
   for (uint64_t s = lane; s < old_cap; s += 64) {
     const wv::gu64* e = tab + s * KW;
     const uint64_t k0 = wv::ld64(e);
-    if ((uint32_t)k0 == 0u) continue;
+    if (entry_empty((uint32_t)k0, etag)) continue;
     uint64_t Mx[MW];
     WV_UNROLL
     for (int j = 0; j < MW; j++) Mx[j] = wv::ld64(e + 1 + j);
@@ -170,8 +145,8 @@ WV_DEV bool grow_group(ColdArgs C, wv::gu64*& tab_u, wv::gu32*& stack_u, wv::gu3
   wv::threadfence();
   wv::barrier();
   WV_NOUNROLL
-  for (uint64_t s = lane; s < old_cap; s += 64) {       // parent links -> new slot numbers
-    if ((uint32_t)wv::ld64(tab + s * KW) == 0u) continue;
+  for (uint64_t s = lane; links && s < old_cap; s += 64) {       // parent links -> new slot numbers (none are kept without a witness: the old table may have no room for them at all)
+    if (entry_empty((uint32_t)wv::ld64(tab + s * KW), etag)) continue;
     const uint64_t pw = wv::ld64(opar + s);
     const uint64_t npw = (uint32_t)pw != kNone ? ((uint64_t)wv::ld32(remap + (uint32_t)pw) | (pw & 0xFFFFFFFF00000000ull)) : pw;
     wv::st64(npar + wv::ld32(remap + s), npw);
@@ -217,6 +192,7 @@ WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* ld
 
   // ---- the group's history (a group takes a new one whenever it has finished one: A.next_work)
   const uint32_t rules = A.rules, vpad = A.vpad;
+  const uint32_t etag = A.epoch << 24;          // (see entry_empty)
   const bool look_avail = A.look != nullptr && A.dstack != nullptr;
   bool has = false;
   uint32_t hidx = 0, op_off = 0, R = 0, lst_off = 0, look_lo = 0, cap_log2 = 10;
@@ -234,7 +210,7 @@ WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* ld
     R = has ? Hd->n_ret : 0u;
     const uint32_t status = has ? (Hd->status | Bd->status) : 0u;
     lst_off = has ? (uint32_t)Bd->lst_off : 0u;
-    tab = (gu64*)A.tab + (has ? Bd->tab_off : 0ull) * (KW + 1);
+    tab = (gu64*)A.tab + (has ? Bd->tab_off : 0ull) * A.tab_stride;
     stack = (gu32*)A.stack + (has ? Bd->stack_off : 0ull);
     cap_log2 = has ? Bd->tab_log2 : 10u;
     look_lo = (uint32_t)look_off(op_off, hidx, MW);           // u64 units into A.look
@@ -270,7 +246,7 @@ WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* ld
       }
       if (f0 == R) verdict0 = TBC_VALID;            // (only reads the initial state allows: nothing to search)
       else {
-        const uint64_t k0 = (uint64_t)(f0 + 1u) | ((uint64_t)(uint32_t)A.init_state << 32);
+        const uint64_t k0 = (uint64_t)((f0 + 1u) | etag) | ((uint64_t)(uint32_t)A.init_state << 32);
         const uint32_t idx = (key_hash32(k0, M0, MW) & (uint32_t)((1ull << (cap_log2 - 2)) - 1ull)) * 4u;
         if (li == 0) {                              // root config: first entry of its bucket, on the stack
           gu64* e = tab + (uint64_t)idx * KW;
@@ -392,13 +368,13 @@ WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* ld
         for (uint64_t s0 = 0; s0 < ncap; s0 += 64) {
           const gu64* e = t_u + (s0 + lane) * KW;
           const uint64_t k0 = wv::ld64(e);
-          const bool hit = (uint32_t)k0 == mf_u + 1u;
+          const bool hit = (uint32_t)k0 == ((mf_u + 1u) | etag);
           const uint64_t hb = wv::ballot(hit);
           if (hit) {
             const uint32_t pos = n + (uint32_t)__builtin_popcountll(hb & ((1ull << lane) - 1ull));
             if (pos < kCfgCap) {
               uint64_t* o = cfg + (uint64_t)pos * (2 + MW);
-              o[0] = k0;
+              o[0] = k0 & ~(uint64_t)0xFF000000u;          // (without the epoch tag)
               WV_UNROLL
               for (int j = 0; j < MW; j++) o[1 + j] = wv::ld64(e + 1 + j);
               const uint64_t pw = links ? wv::ld64(par_u + s0 + lane) : (uint64_t)kNone;
@@ -460,7 +436,7 @@ WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* ld
         gu32* d_u = (gu32*)((uint64_t)GSg[G_DSTACK] | ((uint64_t)GSg[G_DSTACK + 1] << 32));
         uint32_t cap_u = wv::readlane(cap_log2, src);
         const uint32_t sp_u = wv::readlane(sp, src), dsp_u = wv::readlane(dsp, src);
-        const bool ok = grow_group<MW>(C, t_u, s_u, d_u, cap_u, sp_u, dsp_u, lane);
+        const bool ok = grow_group<MW>(C, t_u, s_u, d_u, cap_u, sp_u, dsp_u, lane, etag, links);
         if (g == gg) {
           if (ok) {
             tab = t_u; stack = s_u; cap_log2 = cap_u;
@@ -510,13 +486,13 @@ WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* ld
           k0 = wv::own_ld64(e);
           WV_UNROLL
           for (int j = 0; j < MW; j++) Mp[j] = wv::own_ld64(e + 1 + j);
-          const uint64_t* fr = A.rdm + ((uint64_t)op_off + ((uint32_t)k0 - 1u)) * FW + (CF ? 6u : FM);      // its front's record
+          const uint64_t* fr = A.rdm + ((uint64_t)op_off + (((uint32_t)k0 & kFrontMask) - 1u)) * FW + (CF ? 6u : FM);      // its front's record
           const uint64_t m0 = fr[0];
           pslot = idx; poff = (uint32_t)m0;
           if constexpr (CF) { nlive = (uint32_t)(m0 >> 32) & 0xFFu; cnt = (uint32_t)(m0 >> 40); p_ws0 = fr[1]; }
           else { nlive = (uint32_t)(m0 >> 32); cnt = (uint32_t)fr[1]; p_ws0 = fr[2]; p_ws1 = fr[3]; p_wk0 = fr[4]; p_wk1 = fr[5]; }
         }
-        p_fi = (uint32_t)k0 - 1u; p_st = (int32_t)(uint32_t)(k0 >> 32);
+        p_fi = ((uint32_t)k0 & kFrontMask) - 1u; p_st = (int32_t)(uint32_t)(k0 >> 32);
         if (visited + cnt > full_at) {
           flags |= F_NEED_GROW;                  // room for every pair of this parent?  If not it stays on the stack
         } else {
@@ -715,7 +691,7 @@ WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* ld
     }
 
     // ---- trip 2, issue: the child's bucket of the visited set ...
-    const uint64_t k0c = (uint64_t)(fi2 + 1u) | ((uint64_t)(uint32_t)st2 << 32);
+    const uint64_t k0c = (uint64_t)((fi2 + 1u) | etag) | ((uint64_t)(uint32_t)st2 << 32);
     uint32_t b = key_hash32(k0c, M2, MW) & bmask, idx = 0, full_buckets = 0;
     bool pending = go, fresh = false;
     wv::u32x4 ke[4];                 // MW = 1: the bucket's four 16 B entries
@@ -767,14 +743,14 @@ WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* ld
           const uint32_t k0l = (uint32_t)k0c, k0h = (uint32_t)(k0c >> 32), ml = (uint32_t)M2[0], mh = (uint32_t)(M2[0] >> 32);
           WV_UNROLL
           for (int t = 0; t < 4; t++) {
-            if (ke[t].x == 0u) empty |= 1u << t;
+            if (entry_empty(ke[t].x, etag)) empty |= 1u << t;
             else if (ke[t].x == k0l && ke[t].y == k0h && ke[t].z == ml && ke[t].w == mh) match |= 1u << t;
           }
         } else {
           const gu64* bp = tab + (uint64_t)b * (4 * KW);
           WV_UNROLL
           for (int t = 0; t < 4; t++) {
-            if ((uint32_t)kk[t] == 0u) empty |= 1u << t;
+            if (entry_empty((uint32_t)kk[t], etag)) empty |= 1u << t;
             else if (kk[t] == k0c) {
               bool same = true;
               WV_UNROLL

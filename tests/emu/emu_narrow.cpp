@@ -51,7 +51,7 @@ void emu_stats(uint64_t* out, int reset) { for (int i = 0; i < 64; i++) { out[i]
 int emu_narrow_run(uint32_t nh, const uint64_t* op_off, const uint32_t* n_process, const uint8_t* f, const int32_t* a, const int32_t* b,
                    const int32_t* process, const uint32_t* inv_pos, const uint32_t* ret_pos, uint32_t model_kind, int32_t init,
                    uint32_t L, uint32_t MW, uint32_t rules, uint32_t vpad, uint32_t lookahead, uint32_t entries_per_op, uint64_t max_steps,
-                   uint64_t pool_words, uint32_t want_witness, uint32_t max_waves, uint32_t want_compact, DevResult* results, uint32_t* witness, uint64_t* cfg_out) {
+                   uint64_t pool_words, uint32_t want_witness, uint32_t max_waves, uint32_t want_compact, uint32_t epochs, DevResult* results, uint32_t* witness, uint64_t* cfg_out) {
   Tables T;
   // the compact front records where libtbcheck would take them (tbc_api.hip front_words()): eager rule, one mask word, values <= 4
   uint32_t n_dom = 0;
@@ -73,15 +73,24 @@ int emu_narrow_run(uint32_t nh, const uint64_t* op_off, const uint32_t* n_proces
   A.look = lookahead ? T.look.data() : nullptr; A.slot8 = T.slot8.data(); A.ret_slot = T.ret_slot.data(); A.ret_op = T.ret_op.data();
   A.stack = stack.data(); A.dstack = lookahead ? dstack.data() : nullptr; A.tab = tab.data(); A.results = res.data();
   A.witness = want_witness ? wit.data() : nullptr; A.work = work.data(); A.table = nullptr; A.n_work = nh; A.model_kind = model_kind;
-  A.init_state = init; A.width = 1; A.max_steps = max_steps; A.time_limit_ticks = 0; A.dbg = nullptr;
+  A.init_state = init; A.width = 1; A.tab_stride = EW; A.max_steps = max_steps; A.time_limit_ticks = 0; A.dbg = nullptr;
   A.pool = pool_words ? pool.data() : nullptr; A.pool_cursor = &cursor; A.pool_words = pool_words; A.max_tab_log2 = 28;
   A.pool_vals = nullptr; A.cfg = cfg.data(); A.rules = rules; A.twn = (rules & kRuleTwin) ? T.twn.data() : nullptr;
   A.rdm = T.rdm.data(); A.vpad = vpad; A.rk8 = T.rk8.data(); A.front_words = compact ? kFrontCompactWords : front_stride(vpad, MW);
 #define RUN(MWV, LV) if (MW == MWV && L == LV) { run_all<MWV, LV>(A, max_waves); ran = true; }
   bool ran = false;
-  RUN(1, 4) RUN(1, 8) RUN(1, 16) RUN(1, 32) RUN(2, 8) RUN(2, 16) RUN(4, 8) RUN(4, 16)
+  // epochs > 0: that many passes over the SAME visited-set arena, never cleared in between, each under its own epoch tag
+  // (what libtbcheck does instead of zeroing the arena before every pass); the last pass's results are returned
+  for (uint32_t pass = 0; pass < (epochs ? epochs : 1u); pass++) {
+    A.epoch = epochs ? pass + 1u : 0u;
+    cursor = 0;
+    std::fill(pool.begin(), pool.end(), 0ull);            // (the growth pool IS zeroed per pass: a tenth of the arena)
+    memset(res.data(), 0xFF, nh * sizeof(DevResult));
+    ran = false;
+    RUN(1, 4) RUN(1, 8) RUN(1, 16) RUN(1, 32) RUN(2, 8) RUN(2, 16) RUN(4, 8) RUN(4, 16)
+    if (!ran) return 2;
+  }
 #undef RUN
-  if (!ran) return 2;
   memcpy(results, res.data(), nh * sizeof(DevResult));
   if (want_witness && witness) memcpy(witness, wit.data(), total * 4);
   if (cfg_out) memcpy(cfg_out, cfg.data(), (uint64_t)nh * kCfgCap * (2 + MW) * 8);

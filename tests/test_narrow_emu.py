@@ -186,3 +186,18 @@ def test_the_bench_configuration_at_full_size():
     bad = [columns.pair_events(synth.register_events(n_ops=10000, n_procs=64, seed=s, busy=0.1, corrupt=0.5)) for s in (12345, 12346)]
     got = compare(bad, CAS, 8, tag="bench-invalid", entries_per_op=4, pool_words=8_000_000, want_witness=False)
     assert all(g["valid"] == 0 for g in got)
+
+
+def test_epoch_tags_instead_of_zeroed_visited_sets():
+    """libtbcheck does not zero a batch's visited sets before every pass any more: keys carry the pass number (BeamArgs.epoch) and
+    another pass's entries read as empty.  Three passes over ONE arena that is never cleared, each under its own tag -- with the
+    invalid histories' crowded tables, growth into the (zeroed) pool, and both record forms -- give what one pass over a zeroed
+    arena gives, which is what the oracle gives."""
+    hists = [columns.pair_events(synth.register_events(n_ops=n, n_procs=p, seed=s, busy=busy, info=info, corrupt=corrupt))
+             for (n, p, info, corrupt, busy) in SHAPES[:9] for s in range(2)]
+    for kw in ({}, {"compact": False}, {"want_witness": False}):
+        compare(hists, CAS, 8, tag=f"epochs{kw}", pool_words=4_000_000, epochs=3, **kw)
+    grow = [columns.pair_events(synth.register_events(n_ops=2500, n_procs=16, seed=s, busy=0.25, info=0.0, corrupt=c)) for s in range(3) for c in (0.0, 0.4)]
+    compare(grow, CAS, 8, tag="epochs-grow", entries_per_op=1, pool_words=8_000_000, epochs=3)
+    wide = [columns.pair_events(synth.register_events(n_ops=600, n_procs=12, seed=s, busy=0.15, info=0.08)) for s in range(2)]
+    compare(wide, CAS, 8, tag="epochs-two-words", pool_words=4_000_000, epochs=2, max_steps=30000)
