@@ -193,6 +193,10 @@ WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* ld
   // ---- the group's history (a group takes a new one whenever it has finished one: A.next_work)
   const uint32_t rules = A.rules, vpad = A.vpad;
   const uint32_t etag = A.epoch << 24;          // (see entry_empty)
+  // parent links ({parent entry, op} per config, behind the keys) are what a witness is read from -- and nothing else is: a
+  // caller who wants no witness gets none written (an 8 B store to a line of its own per new config: 7 % of the launch), and the
+  // batch's arena then has no room for them at all (BeamArgs.tab_stride)
+  const bool links = A.witness != nullptr;
   const bool look_avail = A.look != nullptr && A.dstack != nullptr;
   bool has = false;
   uint32_t hidx = 0, op_off = 0, R = 0, lst_off = 0, look_lo = 0, cap_log2 = 10;
@@ -253,7 +257,7 @@ WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* ld
           wv::own_st64(e, k0);
           WV_UNROLL
           for (int j = 0; j < MW; j++) wv::own_st64(e + 1 + j, M0[j]);
-          wv::own_st64(tab + ((uint64_t)KW << cap_log2) + idx, (uint64_t)kNone | ((uint64_t)kNone << 32));
+          if (links) wv::own_st64(tab + ((uint64_t)KW << cap_log2) + idx, (uint64_t)kNone | ((uint64_t)kNone << 32));
           wv::own_st32(stack, idx);
         }
         sp = 1; visited = 1;
@@ -295,9 +299,6 @@ WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* ld
   uint64_t p_ws0 = 0, p_ws1 = 0, p_wk0 = ~0ull, p_wk1 = ~0ull;
   const uint32_t FW = A.front_words, FM = vpad * MW;          // u64 words per front record; where its list location starts
   const bool eager = (rules & kRuleEager) != 0u, twin = (rules & kRuleTwin) != 0u;
-  // parent links ({parent entry, op} per config, behind the keys) are what a witness is read from -- and nothing else is: a
-  // caller who wants no witness gets none written (an 8 B store to a line of its own per new config: 7 % of the launch)
-  const bool links = A.witness != nullptr;
   // Loads that are in flight across other work are issued UNCONDITIONALLY, from addresses clamped into the history's own
   // arenas, and what they bring is judged where it is used: a load under a divergent `if` with a default on the other path
   // makes the compiler merge the two right behind the load -- a full s_waitcnt there, the trip no longer overlaps anything.

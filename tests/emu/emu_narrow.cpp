@@ -61,8 +61,10 @@ int emu_narrow_run(uint32_t nh, const uint64_t* op_off, const uint32_t* n_proces
   const uint64_t total = op_off[nh];
   uint64_t entries = 0;
   for (uint32_t h = 0; h < nh; h++) entries += 1ull << T.bh[h].tab_log2;
-  const uint32_t EW = MW + 2;
-  std::vector<uint64_t> tab(entries * EW + 1, 0), pool(pool_words + 1, 0), cfg((uint64_t)nh * kCfgCap * (2 + MW) + 1, 0);
+  // words per entry of the arena: keys and parent links -- or, as in libtbcheck, keys only when nobody wants a witness (tbc_api.hip
+  // tab_stride()); guard words behind the arena catch a kernel that writes a link all the same
+  const uint32_t EW = want_witness ? MW + 2 : MW + 1;
+  std::vector<uint64_t> tab(entries * EW + 64, 0), pool(pool_words + 1, 0), cfg((uint64_t)nh * kCfgCap * (2 + MW) + 1, 0);
   std::vector<uint32_t> stack(entries + 1, 0), dstack(entries + 1, 0), work(nh), wit(total + 1, 0);
   unsigned long long cursor = 0;
   for (uint32_t h = 0; h < nh; h++) work[h] = h;
@@ -91,6 +93,7 @@ int emu_narrow_run(uint32_t nh, const uint64_t* op_off, const uint32_t* n_proces
     if (!ran) return 2;
   }
 #undef RUN
+  for (uint64_t i = entries * EW; i < entries * EW + 64; i++) if (tab[i] != 0) return 3;       // something was written past the arena
   memcpy(results, res.data(), nh * sizeof(DevResult));
   if (want_witness && witness) memcpy(witness, wit.data(), total * 4);
   if (cfg_out) memcpy(cfg_out, cfg.data(), (uint64_t)nh * kCfgCap * (2 + MW) * 8);
