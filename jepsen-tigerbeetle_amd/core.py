@@ -138,7 +138,10 @@ class Batch:
         d.cols = self._cols.struct()
         d.model_aux = _p(self._aux, C.c_int32) if self._aux is not None else None
         self._h = C.c_void_p()
+        import time
+        t0 = time.perf_counter()
         st = N.lib().tbc_batch_create(C.byref(d), C.byref(self._m), C.byref(self._o), C.byref(self._h))
+        self.create_s = time.perf_counter() - t0          # tbc_batch_create alone: arenas, H2D of the op columns, list sizing
         N.check_status(st)
         self._res = (N.Result * nh)()
 

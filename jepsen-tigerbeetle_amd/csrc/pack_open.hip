@@ -93,7 +93,7 @@ __global__ __launch_bounds__(1024) void open_counts_kernel(PackOpenArgs A) {
     BeamHist* B = &A.bh[h];
     const uint32_t n = H->n_ops, R = H->n_ret;
     if (H->status != 0 || R == 0) {
-      if (tid == 0) { B->status = 0; B->n_crashed = 0; }
+      if (tid == 0) { B->status = 0; B->n_crashed = 0; B->lst_need = 0; }
       continue;
     }
     // count form: crashed calls are not candidates one by one -- their classes (crashed[], cmem[]) are built by the host when the
@@ -206,6 +206,7 @@ __global__ __launch_bounds__(1024) void open_counts_kernel(PackOpenArgs A) {
       chunk_loads(ncr, lo, hi, [&](uint32_t i, uint32_t v) { run += v; ncr[i] = run; });
       __syncthreads();
     }
+    if (tid == 0) B->lst_need = total;
     if (total > B->lst_cap) {
       if (tid == 0) { B->status = 1; B->n_crashed = 0; }
       __syncthreads();
@@ -588,6 +589,11 @@ __global__ __launch_bounds__(256) void front_meta_kernel(PackOpenArgs A) {
   rec[0] = (uint64_t)o0 | ((uint64_t)(o1 - o0) << 32);
   rec[1] = (uint64_t)((o1 - o0) + nc);
   rec[2] = w[0]; rec[3] = w[1]; rec[4] = w[2]; rec[5] = w[3];
+}
+
+void launch_open_counts(const PackOpenArgs& a, void* stream) {
+  const uint32_t n_here = a.n_hist - a.h0;
+  hipLaunchKernelGGL(open_counts_kernel, dim3(n_here < 4096 ? n_here : 4096), dim3(n_here <= 64 ? 1024 : 256), 0, (hipStream_t)stream, a);
 }
 
 void launch_pack_open(const PackOpenArgs& a, void* stream) {

@@ -331,6 +331,9 @@ int32_t tbc_device_count(void) {
   return k;
 }
 
+static PackArgs make_pack_args(tbc_batch* B);
+static PackOpenArgs make_pack_open_args(tbc_batch* B);
+
 static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model* model,
                                     const tbc_opts* opts, tbc_batch* B) {
   int ndev = 0;
@@ -560,11 +563,13 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
   uint64_t boff_n = 0, bocc_n = 0, blst_n = 0, bstack_n = 0, btab_n = 0;
   std::vector<uint32_t> rank_scratch;
   uint64_t rec_n = 0, seg_n = 0, bm_n = 0, frame_n = 0, tab_n = 0;
-  // how many entries each history's per-front lists hold: a pass over the history's events each.  (On one thread: dealing the
-  // histories to 4 or 16 host threads made tbc_batch_create SLOWER, 2.3 -> 3.3-3.9 s for 32,768 histories --
-  // profiles/r03_create_threads_ab.log; the time is in the allocations and the copies, not here.)
+  // how many entries each history's per-front lists hold.  A few histories (tbc_check: latency matters): a pass over each
+  // history's events on the host.  A big batch: that pass was 1.5 of tbc_batch_create's 1.7 s for 32,768 histories
+  // (profiles/r04_cold_batch.log) -- the pack and counts kernels, which every run launches anyway, say the same numbers in 30 ms once the inputs are
+  // resident (device_sizing below), and the list arenas are allocated after that.
+  const bool device_sizing = beam && nh > 64;
   std::vector<uint32_t> list_caps;
-  if (beam) {
+  if (beam && !device_sizing) {
     list_caps.assign(nh, 0u);
     const bool branch = (B->rules & kRuleBranch) != 0;
     for (uint32_t h = 0; h < nh; h++) {
@@ -608,15 +613,17 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
         Q.cmem_off = bocc_n; bocc_n += ch.words.size();
         Q.n_classes = ch.n_classes; Q.top[0] = ch.top[0]; Q.top[1] = ch.top[1];
       }
-      Q.lst_cap = list_caps[h];
-      Q.lst_off = blst_n; blst_n += Q.lst_cap;
+      Q.lst_cap = device_sizing ? 0xFFFFFFF0u : list_caps[h];
+      Q.lst_off = blst_n; blst_n += device_sizing ? 0u : Q.lst_cap;
       Q.stack_off = bstack_n; bstack_n += (1ull << blg);
       Q.tab_off = btab_n; btab_n += (1ull << blg);
     (void)EW;
     }
   }
 
-  if (B->lanes && (blst_n >= (1ull << 32) || boff_n >= (1ull << 32))) {      // 32-bit element offsets (wgl_narrow_impl.h)
+  // the narrow kernel addresses lists and fronts with 32-bit element offsets (wgl_narrow_impl.h): a batch past that keeps a wavefront per history
+  const auto lists_too_long = [&]() -> bool { return B->lanes && (blst_n >= (1ull << 32) || boff_n >= (1ull << 32)); };
+  if (!device_sizing && lists_too_long()) {
     if (opts->lanes_per_history) { set_error("lanes_per_history: the batch's open-call lists exceed 2^32 entries; split the batch"); return TBC_ERR_UNSUPPORTED; }
     const bool had_branch = (B->rules & kRuleBranch) != 0;
     B->lanes = 0; B->rules &= ~kRuleBranch;
@@ -629,6 +636,10 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
         Q.lst_off = blst_n; blst_n += Q.lst_cap;
       }
     }
+  }
+  if (device_sizing && B->lanes && boff_n >= (1ull << 32)) {
+    if (opts->lanes_per_history) { set_error("lanes_per_history: the batch exceeds 2^32 fronts; split the batch"); return TBC_ERR_UNSUPPORTED; }
+    B->lanes = 0; B->rules &= ~kRuleBranch;
   }
   if (B->sweep) { bstack_n = 0; btab_n = 0; }     // the sweep has no visited set; its fallback takes scratch arenas
   TRACE("create: layout done");
@@ -643,14 +654,14 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
     return s;
   if (beam) {
     if ((s = B->d_bh.alloc(nh)) || (s = B->d_off.alloc(boff_n)) || (s = B->d_ncr.alloc(boff_n)) ||
-        (s = B->d_lst.alloc(blst_n)) || (s = B->d_crashed.alloc((B->count_form || !B->any_crashed) ? 0 : T)) || (s = B->d_cmem.alloc(B->count_form ? bocc_n : 0)) ||
+        (!device_sizing && (s = B->d_lst.alloc(blst_n))) || (s = B->d_crashed.alloc((B->count_form || !B->any_crashed) ? 0 : T)) || (s = B->d_cmem.alloc(B->count_form ? bocc_n : 0)) ||
         (s = B->d_slot8.alloc(slot8_bytes(T, nh))) || (s = B->d_stack.alloc(bstack_n)) || (s = B->d_btab.alloc(btab_n * B->tab_stride())) ||
         (s = B->d_pool_cursor.alloc(1)))
       return s;
     if (B->sweep && ((s = B->d_cuts.alloc((uint64_t)nh * B->max_segs)) || (s = B->d_sres.alloc((uint64_t)nh * B->max_segs * kSweepSlices)) || (s = B->d_seglist.alloc((uint64_t)nh * B->max_segs * kSweepSlices * 3)))) return s;
     if (B->sweep) B->seg_host.resize((size_t)nh * B->max_segs * kSweepSlices);
     if (B->lanes && (s = B->d_rk8.alloc(slot8_bytes(T, nh)))) return s;
-    if (B->rules && ((s = B->d_twn.alloc(blst_n * B->mask_words)) || (s = B->d_rdm.alloc(B->lanes ? 1 : T * B->vpad * B->mask_words)))) return s;
+    if (B->rules && ((!device_sizing && (s = B->d_twn.alloc(blst_n * B->mask_words))) || (s = B->d_rdm.alloc(B->lanes ? 1 : T * B->vpad * B->mask_words)))) return s;
     // several histories per wavefront: front records (tbc_internal.h) instead of plain rows, with or without the rules
     if (B->lanes) { B->d_rdm.release(); if ((s = B->d_rdm.alloc(T * B->front_words()))) return s; }
     // (d_looktmp: scratch of the walk with lane = process slot only -- launch_pack_open's choice, repeated here)
@@ -718,6 +729,45 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
   HIP_TRY(hipMemcpyAsync(B->d_work.p, work.data(), nh * 4, hipMemcpyHostToDevice, B->stream));
   HIP_TRY(hipStreamSynchronize(B->stream));
   TRACE("create: inputs resident");
+  if (device_sizing) {
+    // the pack and counts kernels over the resident inputs: BeamHist.lst_need = entries each history's per-front lists hold
+    hipStream_t st = B->stream;
+    for (int attempt = 0; attempt < 2; attempt++) {
+      HIP_TRY(hipMemsetAsync(B->d_bitmap.p, 0, B->d_bitmap.bytes(), st));
+      HIP_TRY(hipMemsetAsync(B->d_off.p, 0, B->d_off.bytes(), st));
+      HIP_TRY(hipMemsetAsync(B->d_ncr.p, 0, B->d_ncr.bytes(), st));
+      HIP_TRY(hipMemcpyAsync(B->d_bh.p, B->bh.data(), nh * sizeof(BeamHist), hipMemcpyHostToDevice, st));
+      HIP_TRY(hipMemcpyAsync(B->d_hist.p, B->hist.data(), nh * sizeof(Hist), hipMemcpyHostToDevice, st));
+      launch_pack(make_pack_args(B), st);
+      HIP_TRY(hipGetLastError());
+      launch_open_counts(make_pack_open_args(B), st);
+      HIP_TRY(hipGetLastError());
+      std::vector<BeamHist> back(nh);
+      HIP_TRY(hipMemcpyAsync(back.data(), B->d_bh.p, nh * sizeof(BeamHist), hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      blst_n = 0;
+      for (uint32_t h = 0; h < nh; h++) {
+        BeamHist& Q = B->bh[h];
+        Q.lst_cap = std::max(1u, back[h].lst_need);
+        Q.lst_off = blst_n; blst_n += Q.lst_cap;
+      }
+      if (!lists_too_long()) break;
+      if (opts->lanes_per_history) { set_error("lanes_per_history: the batch's open-call lists exceed 2^32 entries; split the batch"); return TBC_ERR_UNSUPPORTED; }
+      const bool had_branch = (B->rules & kRuleBranch) != 0;
+      B->lanes = 0; B->rules &= ~kRuleBranch;
+      if (!opts->want_witness) {                   // (a wavefront per history keeps parent links whatever the caller wants: the arena grows by them)
+        B->device_bytes -= B->d_btab.bytes();
+        B->d_btab.release();
+        if ((s = B->d_btab.alloc(btab_n * B->tab_stride()))) return s;
+        B->device_bytes += B->d_btab.bytes();
+      }
+      if (!had_branch) break;                      // (else the lists hold the reads again: counted once more)
+      for (uint32_t h = 0; h < nh; h++) { B->bh[h].lst_cap = 0xFFFFFFF0u; B->bh[h].lst_off = 0; }
+    }
+    if ((s = B->d_lst.alloc(blst_n)) || (B->rules && (s = B->d_twn.alloc(blst_n * B->mask_words)))) return s;
+    B->device_bytes += B->d_lst.bytes() + B->d_twn.bytes();
+    TRACE("create: lists sized on the device");
+  }
   B->res_host.resize(nh);
   return TBC_OK;
 }
@@ -767,6 +817,31 @@ static SearchArgs make_search_args(tbc_batch* B, uint64_t* tab, uint32_t n_work)
   a.pool_vals = B->d_pool_vals.p;
   a.cfg = B->d_cfg.p;
   return a;
+}
+
+static PackArgs make_pack_args(tbc_batch* B) {
+  PackArgs pa{};
+  pa.hist = B->d_hist.p; pa.f = B->d_f.p; pa.a = B->d_a.p; pa.b = B->d_b.p; pa.process = B->d_proc.p;
+  pa.inv_pos = B->d_inv.p; pa.ret_pos = B->d_ret.p; pa.rec = B->d_rec.p; pa.seg = B->d_seg.p;
+  pa.ret_slot = B->d_ret_slot.p; pa.ret_op = B->d_ret_op.p; pa.bitmap = B->d_bitmap.p; pa.wpre = B->d_wpre.p;
+  pa.scratch = B->d_frames.p; pa.frame_words = B->frame_words; pa.n_hist = B->n_hist;
+  pa.model_kind = B->model.kind; pa.n_classes = B->model.n_classes; pa.dbg = debug_words();
+  pa.pool_vals = B->d_pool_vals.p; pa.pool_len = B->pool_len; pa.n_keys = B->model.n_keys;
+  return pa;
+}
+
+static PackOpenArgs make_pack_open_args(tbc_batch* B) {
+  PackOpenArgs po{};
+  po.hist = B->d_hist.p; po.bh = B->d_bh.p; po.f = B->d_f.p; po.a = B->d_a.p; po.b = B->d_b.p; po.process = B->d_proc.p;
+  po.scratch = B->d_frames.p; po.off = B->d_off.p; po.ncr = B->d_ncr.p; po.lst = B->d_lst.p;
+  po.rec = B->d_rec.p; po.seg = B->d_seg.p; po.chunks_per_hist = (uint32_t)((B->max_ops + 63) / 64);
+  po.crashed = B->d_crashed.p; po.ret_slot = B->d_ret_slot.p; po.slot8 = B->d_slot8.p;
+  po.ret_op = B->d_ret_op.p; po.look = B->lookahead ? B->d_look.p : nullptr; po.tmp = B->d_looktmp.p; po.n_hist = B->n_hist; po.mask_words = B->mask_words;
+  po.branch_lists = (B->rules & kRuleBranch) ? 1u : 0u;
+  po.rk8 = B->lanes ? B->d_rk8.p : nullptr; po.front_words = B->front_words(); po.front_compact = B->front_words() == kFrontCompactWords ? 1u : 0u;
+  po.twn = B->rules ? B->d_twn.p : nullptr; po.rdm = (B->rules || B->lanes) ? B->d_rdm.p : nullptr; po.vpad = B->vpad;
+  po.cmem = B->count_form ? B->d_cmem.p : nullptr;
+  return po;
 }
 
 static uint32_t search_blocks(uint32_t n_work) {
@@ -1058,26 +1133,10 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results, int phase = 
   TRACE("run: memsets queued");
   SYNC_TRACE("memsets");
 
-  PackArgs pa{};
-  pa.hist = B->d_hist.p; pa.f = B->d_f.p; pa.a = B->d_a.p; pa.b = B->d_b.p; pa.process = B->d_proc.p;
-  pa.inv_pos = B->d_inv.p; pa.ret_pos = B->d_ret.p; pa.rec = B->d_rec.p; pa.seg = B->d_seg.p;
-  pa.ret_slot = B->d_ret_slot.p; pa.ret_op = B->d_ret_op.p; pa.bitmap = B->d_bitmap.p; pa.wpre = B->d_wpre.p;
-  pa.scratch = B->d_frames.p; pa.frame_words = B->frame_words; pa.n_hist = nh;
-  pa.model_kind = B->model.kind; pa.n_classes = B->model.n_classes; pa.dbg = debug_words();
-  pa.pool_vals = B->d_pool_vals.p; pa.pool_len = B->pool_len; pa.n_keys = B->model.n_keys;
-  launch_pack(pa, s);
+  launch_pack(make_pack_args(B), s);
   HIP_TRY(hipGetLastError());
   if (beam) {
-    PackOpenArgs po{};
-    po.hist = B->d_hist.p; po.bh = B->d_bh.p; po.f = B->d_f.p; po.a = B->d_a.p; po.b = B->d_b.p; po.process = B->d_proc.p;
-    po.scratch = B->d_frames.p; po.off = B->d_off.p; po.ncr = B->d_ncr.p; po.lst = B->d_lst.p;
-    po.rec = B->d_rec.p; po.seg = B->d_seg.p; po.chunks_per_hist = (uint32_t)((B->max_ops + 63) / 64);
-    po.crashed = B->d_crashed.p; po.ret_slot = B->d_ret_slot.p; po.slot8 = B->d_slot8.p;
-    po.ret_op = B->d_ret_op.p; po.look = B->lookahead ? B->d_look.p : nullptr; po.tmp = B->d_looktmp.p; po.n_hist = nh; po.mask_words = B->mask_words;
-    po.branch_lists = (B->rules & kRuleBranch) ? 1u : 0u;
-    po.rk8 = B->lanes ? B->d_rk8.p : nullptr; po.front_words = B->front_words(); po.front_compact = B->front_words() == kFrontCompactWords ? 1u : 0u;
-    po.twn = B->rules ? B->d_twn.p : nullptr; po.rdm = (B->rules || B->lanes) ? B->d_rdm.p : nullptr; po.vpad = B->vpad;
-    po.cmem = B->count_form ? B->d_cmem.p : nullptr;
+    PackOpenArgs po = make_pack_open_args(B);
     launch_pack_open(po, s);
     HIP_TRY(hipGetLastError());
   }

@@ -229,6 +229,8 @@ struct __attribute__((aligned(16))) BeamHist {
   uint32_t n_classes;   // count form: classes of crashed calls (OpRecs at crashed[])
   uint32_t target;      // count form: the search ends VALID when a config has passed this many completions (0 = all of them)
   uint64_t top[kCountWords];   // count form: the top bit of every class's field (field-wise compare of count vectors)
+  uint32_t lst_need;    // open_counts_kernel: entries the history's per-front lists hold (tbc_batch_create sizes the list arenas from it)
+  uint32_t pad2[3];
 };
 
 struct PackOpenArgs {
@@ -368,6 +370,8 @@ struct SweepArgs {
 bool launch_sweep(const SweepArgs& a, void* stream);
 
 void launch_pack_open(const PackOpenArgs& a, void* stream);
+// open_counts_kernel alone: how many entries each history's per-front lists hold (BeamHist.lst_need), before those arenas exist
+void launch_open_counts(const PackOpenArgs& a, void* stream);
 bool launch_beam(const BeamArgs& a, uint32_t mask_words, uint32_t n_blocks, void* stream);
 // several histories per wavefront (wgl_narrow.hip): `lanes` = 8 / 16 / 32 lanes per history, one config per iteration
 bool narrow_supported(uint32_t mask_words, uint32_t lanes);
