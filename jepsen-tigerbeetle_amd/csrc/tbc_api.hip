@@ -12,6 +12,7 @@
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <thread>
 #include <vector>
 #include "tbc_internal.h"
 
@@ -120,6 +121,43 @@ bool build_count_form(const tbc_ops& c, uint64_t o0, uint64_t n, uint32_t n_proc
   }
   if (out.words.size() & 1) out.words.push_back(~0ull);         // (the next history's class records stay 16 B aligned)
   return true;
+}
+
+// What the layout decisions ask of the op columns, in ONE pass over them (four passes of 3 GB each were 0.6 s of a 32,768-history
+// tbc_batch_create), dealt to a few host threads: do all register values fit the rule tables (>= 0), the greatest value, is any
+// call crashed, is any crashed call one with an effect (:write, or :cas [a b] with a != b).
+struct ColumnScan { bool nonneg = true, any_crashed = false, any_crashed_effect = false; int32_t vmax = -1; };
+ColumnScan scan_columns(const tbc_ops& c, uint64_t T) {
+  const unsigned nt = T > (1ull << 22) ? 8u : 1u;
+  std::vector<ColumnScan> part(nt);
+  const auto work = [&](unsigned t) {
+    ColumnScan r;
+    const uint64_t lo = T * t / nt, hi = T * (t + 1) / nt;
+    for (uint64_t i = lo; i < hi; i++) {
+      const int32_t a = c.a[i];
+      const uint32_t f = c.f[i];
+      if (a != TBC_NIL) { r.nonneg = r.nonneg && a >= 0; r.vmax = std::max(r.vmax, a); }
+      int32_t b = 0;
+      if (f == TBC_F_CAS) { b = c.b[i]; r.nonneg = r.nonneg && b >= 0; r.vmax = std::max(r.vmax, b); }
+      if (c.ret_pos[i] == TBC_POS_CRASHED) {
+        r.any_crashed = true;
+        r.any_crashed_effect = r.any_crashed_effect || f == TBC_F_WRITE || (f == TBC_F_CAS && a != b);
+      }
+    }
+    part[t] = r;
+  };
+  if (nt == 1) work(0);
+  else {
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; t++) th.emplace_back(work, t);
+    for (auto& x : th) x.join();
+  }
+  ColumnScan out;
+  for (const ColumnScan& r : part) {
+    out.nonneg = out.nonneg && r.nonneg; out.vmax = std::max(out.vmax, r.vmax);
+    out.any_crashed = out.any_crashed || r.any_crashed; out.any_crashed_effect = out.any_crashed_effect || r.any_crashed_effect;
+  }
+  return out;
 }
 
 bool device_is_gfx950(int dev) {
@@ -397,19 +435,16 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
   // default rules and knossos.competition (the published orders -- TBC_ALG_WGL, TBC_ALG_LINEAR -- keep a mask bit per crashed call).
   // The process column is re-numbered (re-used slots; a crashed call holds none) and the crashed calls become classes with counts.
   std::vector<int32_t> slot_col;
+  const ColumnScan scan = scan_columns(desc->cols, B->total_ops);
+  B->any_crashed = scan.any_crashed;
   {
     const bool regfam = model->kind == TBC_MODEL_REGISTER || model->kind == TBC_MODEL_CAS_REGISTER;
     const tbc_ops& c = desc->cols;
     bool want = regfam && opts->algorithm == TBC_ALG_COMPETITION && (opts->dominance & (TBC_DOM_NO_EAGER_READS | TBC_DOM_NO_TWIN_RULE | TBC_DOM_NO_COUNT_FORM)) == 0 &&
                 opts->search_width != 1 && (opts->lanes_per_history == 0 || opts->lanes_per_history == 64) && opts->lookahead != 1 &&
                 (model->init == TBC_NIL || (model->init >= 0 && model->init <= kMaxRuleValue));
-    bool any = false;
-    for (uint64_t i = 0; i < c.n && want; i++) {
-      const int32_t a = c.a[i];
-      if (a != TBC_NIL && (a < 0 || a > kMaxRuleValue)) want = false;
-      if (c.f[i] == TBC_F_CAS && (c.b[i] < 0 || c.b[i] > kMaxRuleValue)) want = false;
-      any = any || (c.ret_pos[i] == TBC_POS_CRASHED && (c.f[i] == TBC_F_WRITE || (c.f[i] == TBC_F_CAS && a != c.b[i])));
-    }
+    want = want && scan.nonneg && scan.vmax <= kMaxRuleValue;
+    const bool any = scan.any_crashed_effect;
     if (want && any) {
       slot_col.resize((size_t)B->total_ops + 1);
       B->count_hist.resize(nh);
@@ -467,14 +502,8 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
   const bool beam = width > 1;
   // dominance rules: same scope as the lookahead, and every register value must index the per-front read table
   if (B->lookahead || (width > 1 && width <= 16 && (model->kind == TBC_MODEL_REGISTER || model->kind == TBC_MODEL_CAS_REGISTER))) {
-    int32_t vmax = model->init == TBC_NIL ? -1 : model->init;
-    bool in_range = model->init == TBC_NIL || model->init >= 0;
-    const tbc_ops& c = desc->cols;
-    for (uint64_t i = 0; i < c.n && in_range; i++) {
-      const int32_t a = c.a[i];
-      if (a != TBC_NIL) { in_range = a >= 0; vmax = std::max(vmax, a); }
-      if (c.f[i] == TBC_F_CAS) { const int32_t b = c.b[i]; in_range = in_range && b >= 0; vmax = std::max(vmax, b); }
-    }
+    const int32_t vmax = std::max(model->init == TBC_NIL ? -1 : model->init, scan.vmax);
+    const bool in_range = (model->init == TBC_NIL || model->init >= 0) && scan.nonneg;
     if (in_range && vmax <= kMaxRuleValue) {
       B->n_dom = (uint32_t)(vmax + 2);                   // nil + 0..vmax: the states a register can be in
       B->rules = ((opts->dominance & TBC_DOM_NO_EAGER_READS) ? 0u : kRuleEager) | ((opts->dominance & TBC_DOM_NO_TWIN_RULE) ? 0u : kRuleTwin);
@@ -528,12 +557,6 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
     if (B->lanes && (B->rules & kRuleEager)) B->rules |= kRuleBranch;
   }
   const uint32_t EW = B->entry_words();   // u64 words per wide-schedule entry
-  {
-    bool any = false;
-    const uint32_t* rp = desc->cols.ret_pos;
-    for (uint64_t i = 0; i < B->total_ops && !any; i++) any = rp[i] == TBC_POS_CRASHED;
-    B->any_crashed = any;
-  }
   // the frames arena is the pack kernels' scratch (3 words per op) and the sequential kernel's stack (4 + 2 mask words per op): a
   // wide-schedule batch only needs the former -- the rare history that falls back to the sequential kernel gets frames of its own then
   if (beam) B->frame_words = 3;
