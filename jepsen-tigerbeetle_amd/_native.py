@@ -33,7 +33,7 @@ ALG_COMPETITION, ALG_WGL, ALG_LINEAR = 0, 1, 2
 # verdicts / causes
 VALID, INVALID, UNKNOWN = 1, 0, -1
 CAUSE_NONE, CAUSE_TIME_LIMIT, CAUSE_STEP_LIMIT, CAUSE_VISITED_FULL = 0, 1, 2, 3
-DOM_NO_EAGER_READS, DOM_NO_TWIN_RULE, DOM_NO_COUNT_FORM = 1, 2, 4
+DOM_NO_EAGER_READS, DOM_NO_TWIN_RULE, DOM_NO_COUNT_FORM, DOM_NO_LAZY_COMMUTING = 1, 2, 4, 8
 # status
 (OK_STATUS, ERR_INVALID_ARG, ERR_BAD_HISTORY, ERR_NO_DEVICE, ERR_OOM, ERR_WINDOW_TOO_WIDE,
  ERR_MODEL, ERR_HIP, ERR_UNSUPPORTED) = range(9)

@@ -34,7 +34,7 @@ DEFAULT_COUNT_FORM = True
 
 def make_opts(algorithm=N.ALG_WGL, device=0, time_limit_ms=0, max_steps=0, max_visited_bytes=0,
               want_witness=True, visited_per_op=0, search_width=0, round_budget=0, lookahead=True,
-              eager_reads=True, twin_rule=True, lanes_per_history=0, count_form=None):
+              eager_reads=True, twin_rule=True, lanes_per_history=0, count_form=None, lazy_commuting=True):
     o = N.Opts()
     o.algorithm = algorithm
     o.device = device
@@ -46,7 +46,7 @@ def make_opts(algorithm=N.ALG_WGL, device=0, time_limit_ms=0, max_steps=0, max_v
     o.search_width = int(search_width)
     o.round_budget = int(round_budget)
     o.lookahead = 0 if lookahead else 1     # C-ABI: 0 = on (default), 1 = off
-    o.dominance = (0 if eager_reads else N.DOM_NO_EAGER_READS) | (0 if twin_rule else N.DOM_NO_TWIN_RULE) | (0 if (DEFAULT_COUNT_FORM if count_form is None else count_form) else N.DOM_NO_COUNT_FORM)
+    o.dominance = (0 if eager_reads else N.DOM_NO_EAGER_READS) | (0 if twin_rule else N.DOM_NO_TWIN_RULE) | (0 if (DEFAULT_COUNT_FORM if count_form is None else count_form) else N.DOM_NO_COUNT_FORM) | (0 if lazy_commuting else N.DOM_NO_LAZY_COMMUTING)
     o.lanes_per_history = int(lanes_per_history)     # 8 / 16 / 32: several histories per wavefront; 64: one; 0: the library's choice
     o.reserved0 = 0
     return o

@@ -83,11 +83,32 @@ struct Model {
 template <int MW, bool COMM, bool REGF = false>
 __device__ __forceinline__ bool pair_viable(const Model& model, int32_t st, uint32_t fi, const uint64_t (&Mp)[MW],
                                             uint32_t poff, uint32_t nlive, uint32_t cnt, const OpRec* lst,
-                                            const OpRec* crashed, const OpRec& oi) {
+                                            const OpRec* crashed, const OpRec& oi, bool lazy = false) {
   const uint32_t f = oi.f_slot & 0xFFu;
   if constexpr (!COMM) {
     return model.template ok<REGF>(st, f, oi.a, oi.b);
   } else {
+  // the lazy rule (tbcheck.h, TBC_DOM_NO_LAZY_COMMUTING): a mutating call that does not complete at the front is a candidate only
+  // while an open, not yet linearized read could take it -- set: one whose value holds the element; bank: one with a value
+  if (lazy && (f == TBC_F_ADD || f == TBC_F_TRANSFER) && !(oi.f_slot & kAtFront)) {
+    bool wanted = false;
+    for (uint32_t cc = 0; !wanted && cc < nlive; cc++) {          // (reads are live calls: a crashed read has no value and is no candidate)
+      const OpRec ox = lst[poff + cc];
+      if ((ox.f_slot & 0xFFu) != TBC_F_READ || ox.a == TBC_NIL) continue;
+      const uint32_t px = (ox.f_slot >> 8) & kSlotMask;
+      bool lx = false;
+#pragma unroll
+      for (int j = 0; j < MW; j++) if ((px >> 6) == (uint32_t)j) lx = (Mp[j] >> (px & 63u)) & 1ull;
+      if (lx) continue;
+      if (f == TBC_F_TRANSFER) wanted = true;
+      else {
+        const int32_t* rp = model.pool + ox.a;
+        const uint32_t jx = (uint32_t)oi.a;
+        wanted = rp[0] >= 0 && ((((uint32_t)rp[2 + (jx >> 5)]) >> (jx & 31u)) & 1u);
+      }
+    }
+    if (!wanted) return false;
+  }
   if (model.kind == TBC_MODEL_SET) {
     // knossos.model/set, state-free: a read of R is consistent iff the adds completed before the
     // front plus the open adds already linearized are exactly R (pool layout: include/tbcheck.h)

@@ -328,6 +328,7 @@ struct tbc_batch {
   bool count_form = false;
   DevBuf<uint64_t> d_cmem;
   std::vector<CountHist> count_hist;       // (kept for the result marshalling: which crashed calls a count vector stands for)
+  uint32_t reg_rules() const { return rules & (kRuleEager | kRuleTwin); }     // the register family's rules (their tables: twn, rdm)
   uint32_t epoch = 0;               // narrow kernel: the pass number its visited-set keys are tagged with (1..255; the arena is zeroed when it wraps)
   bool any_crashed = true;          // some op of the batch never completes (else the crashed-call arena is never read: one element)
   // u64 words per entry of the batch's own visited-set arena: the narrow kernel keeps no parent links when nobody wants a witness
@@ -496,6 +497,7 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
     B->sweep = !never && (asked || forced) && !commutative && B->mask_words == 1 && width <= 16 && !B->count_form;   // (the sweep's segments cannot start from count vectors)
     if (B->sweep && width < 2) width = 4;                // the fallback's schedule; the per-front lists are the wide kernel's
   }
+  if (commutative && !(opts->dominance & TBC_DOM_NO_LAZY_COMMUTING)) B->rules |= kRuleLazyComm;
   B->width = width;
   B->lookahead = !B->sweep && width > 1 && width <= 16 && opts->lookahead != 1 &&
                  (model->kind == TBC_MODEL_REGISTER || model->kind == TBC_MODEL_CAS_REGISTER);
@@ -684,7 +686,7 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
     if (B->sweep && ((s = B->d_cuts.alloc((uint64_t)nh * B->max_segs)) || (s = B->d_sres.alloc((uint64_t)nh * B->max_segs * kSweepSlices)) || (s = B->d_seglist.alloc((uint64_t)nh * B->max_segs * kSweepSlices * 3)))) return s;
     if (B->sweep) B->seg_host.resize((size_t)nh * B->max_segs * kSweepSlices);
     if (B->lanes && (s = B->d_rk8.alloc(slot8_bytes(T, nh)))) return s;
-    if (B->rules && ((!device_sizing && (s = B->d_twn.alloc(blst_n * B->mask_words))) || (s = B->d_rdm.alloc(B->lanes ? 1 : T * B->vpad * B->mask_words)))) return s;
+    if (B->reg_rules() && ((!device_sizing && (s = B->d_twn.alloc(blst_n * B->mask_words))) || (s = B->d_rdm.alloc(B->lanes ? 1 : T * B->vpad * B->mask_words)))) return s;
     // several histories per wavefront: front records (tbc_internal.h) instead of plain rows, with or without the rules
     if (B->lanes) { B->d_rdm.release(); if ((s = B->d_rdm.alloc(T * B->front_words()))) return s; }
     // (d_looktmp: scratch of the walk with lane = process slot only -- launch_pack_open's choice, repeated here)
@@ -787,7 +789,7 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
       if (!had_branch) break;                      // (else the lists hold the reads again: counted once more)
       for (uint32_t h = 0; h < nh; h++) { B->bh[h].lst_cap = 0xFFFFFFF0u; B->bh[h].lst_off = 0; }
     }
-    if ((s = B->d_lst.alloc(blst_n)) || (B->rules && (s = B->d_twn.alloc(blst_n * B->mask_words)))) return s;
+    if ((s = B->d_lst.alloc(blst_n)) || (B->reg_rules() && (s = B->d_twn.alloc(blst_n * B->mask_words)))) return s;
     B->device_bytes += B->d_lst.bytes() + B->d_twn.bytes();
     TRACE("create: lists sized on the device");
   }
@@ -862,7 +864,7 @@ static PackOpenArgs make_pack_open_args(tbc_batch* B) {
   po.ret_op = B->d_ret_op.p; po.look = B->lookahead ? B->d_look.p : nullptr; po.tmp = B->d_looktmp.p; po.n_hist = B->n_hist; po.mask_words = B->mask_words;
   po.branch_lists = (B->rules & kRuleBranch) ? 1u : 0u;
   po.rk8 = B->lanes ? B->d_rk8.p : nullptr; po.front_words = B->front_words(); po.front_compact = B->front_words() == kFrontCompactWords ? 1u : 0u;
-  po.twn = B->rules ? B->d_twn.p : nullptr; po.rdm = (B->rules || B->lanes) ? B->d_rdm.p : nullptr; po.vpad = B->vpad;
+  po.twn = B->reg_rules() ? B->d_twn.p : nullptr; po.rdm = (B->reg_rules() || B->lanes) ? B->d_rdm.p : nullptr; po.vpad = B->vpad;
   po.cmem = B->count_form ? B->d_cmem.p : nullptr;
   return po;
 }
@@ -1124,7 +1126,7 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results, int phase = 
   SweepArgs swa{};
   if (B->sweep) {
     swa.hist = B->d_hist.p; swa.bh = B->d_bh.p; swa.off = B->d_off.p; swa.ncr = B->d_ncr.p; swa.lst = B->d_lst.p;
-    swa.crashed = B->d_crashed.p; swa.twn = B->rules ? B->d_twn.p : nullptr; swa.rdm = B->rules ? B->d_rdm.p : nullptr;
+    swa.crashed = B->d_crashed.p; swa.twn = B->reg_rules() ? B->d_twn.p : nullptr; swa.rdm = B->reg_rules() ? B->d_rdm.p : nullptr;
     swa.slot8 = B->d_slot8.p; swa.cuts = B->d_cuts.p; swa.seg = B->d_sres.p; swa.table = B->d_table.p;
     swa.pool_vals = B->d_pool_vals.p; swa.n_hist = nh; swa.max_segs = B->max_segs; swa.seg_target = B->seg_target;
     swa.cut_open = B->cut_open; swa.n_dom = B->n_dom; swa.vpad = B->vpad ? B->vpad : 1; swa.rules = B->rules;

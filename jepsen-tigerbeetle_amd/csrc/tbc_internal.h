@@ -191,6 +191,8 @@ constexpr uint32_t kRuleBranch = 4u;
 // Visited-set entries carry the count words behind the mask words; buckets are chosen by (k0, M) alone, so every config with
 // one key lies on one probe chain.
 constexpr uint32_t kRuleCount = 8u;
+// set / bank (wide schedule): the lazy rule of the commutative models (tbcheck.h, TBC_DOM_NO_LAZY_COMMUTING; oracle/wgl_beam.c)
+constexpr uint32_t kRuleLazyComm = 16u;
 constexpr uint32_t kHotBit = 0x40000000u;
 constexpr uint32_t kCountWords = 2;
 // BeamArgs.count_mode

@@ -568,7 +568,7 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
           }
         }
       }
-      bool viable = act && !lin && !dominated && !is_cls && pair_viable<MW, COMM, REGF>(model, st, fi, Mp, poff, nlive, cnt, lst, crashed, oi);
+      bool viable = act && !lin && !dominated && !is_cls && pair_viable<MW, COMM, REGF>(model, st, fi, Mp, poff, nlive, cnt, lst, crashed, oi, COMM && (A.rules & kRuleLazyComm) != 0u);
       if constexpr (CNT) {
         const uint32_t cf = oi.f_slot & 0xFFu;
         // a hot config only takes calls whose precondition is its state; a crashed :write is not one, and never writes the state it finds

@@ -160,7 +160,7 @@ def rules_apply(ops, model, round_pairs=64):
 
 
 def check_beam(ops, model, width=16, max_probes=0, want_witness=True, round_pairs=64, widen_after=0, lookahead=None, eager_reads=None, twin_rule=None,
-               twin_selfcheck=False, rules_at_any_round_size=False, branch_lists=False):
+               twin_selfcheck=False, rules_at_any_round_size=False, branch_lists=False, lazy_commuting=None):
     """The wide (K configs per iteration) schedule of the same search: wgl_beam.c.
 
     lookahead: None = what the library does by default (on for register / cas-register under the
@@ -185,6 +185,8 @@ def check_beam(ops, model, width=16, max_probes=0, want_witness=True, round_pair
         eager_reads = twin_rule = False
     lib().wgl_beam_set_eager_reads(C.c_uint32(1 if eager_reads else 0))
     lib().wgl_beam_set_twin_rule(C.c_uint32(1 if twin_rule else 0))
+    # lazy_commuting: the lazy rule of the commutative models (set, bank); None = what the library does by default (on)
+    lib().wgl_beam_set_lazy_commuting(C.c_uint32(1 if ((model["kind"] in (5, 6)) if lazy_commuting is None else lazy_commuting) else 0))
     # twin_selfcheck: evaluate every twin test of a crashed candidate also by the previous-crashed-twin shortcut
     # (wgl_beam.c) and report how many were compared / disagreed as twin_checked / twin_mismatch
     # branch_lists: candidate lists hold the live :write / :cas calls only and the root starts in normal form (the narrow
@@ -203,6 +205,7 @@ def check_beam(ops, model, width=16, max_probes=0, want_witness=True, round_pair
         lib().wgl_beam_set_twin_rule(C.c_uint32(0))
         lib().wgl_beam_set_twin_selfcheck(C.c_uint32(0))
         lib().wgl_beam_set_branch_lists(C.c_uint32(0))
+        lib().wgl_beam_set_lazy_commuting(C.c_uint32(0))
 
 
 def _check_beam(ops, model, width, max_probes, want_witness, round_pairs, widen_after, lookahead):

@@ -192,6 +192,14 @@ void wgl_beam_set_branch_lists(uint32_t on) { g_branch_lists = on; }
 void wgl_beam_set_twin_rule(uint32_t on) { g_twin_rule = on; }
 void wgl_beam_set_eager_reads(uint32_t on) { g_eager_reads = on; }
 uint64_t wgl_beam_absorbed(void) { return g_absorbed; }
+/* LAZY RULE for the commutative models (set, bank; tbc_opts.dominance, TBC_DOM_NO_LAZY_COMMUTING off = rule on).  An :add / :transfer
+ * changes nothing any call can see except a :read, and the calls of these models commute, so in any linearization a mutating call
+ * can be moved later -- up to its own completion, or (a crashed one: for ever) -- past everything but a read.  Without loss of
+ * generality it is therefore linearized only when it COMPLETES AT THE FRONT, or when an open, not yet linearized read could take it:
+ * set -- a read whose value contains the element (a crashed add no read ever contains is never linearized at all: knossos.model/set
+ * reads are exact); bank -- any read with a value.  Config space: no longer 2^(open or crashed mutating calls). */
+static uint32_t g_lazy_comm = 0;
+void wgl_beam_set_lazy_commuting(uint32_t on) { g_lazy_comm = on; }
 static uint32_t g_stall_rounds = 0, g_stall_width = 64, g_stall_mode = 0;
 void wgl_beam_set_stall(uint32_t rounds, uint32_t width, uint32_t mode) { g_stall_rounds = rounds; g_stall_width = width; g_stall_mode = mode; }
 static uint32_t* g_trace = NULL; static uint32_t g_trace_cap = 0, g_trace_n = 0;
@@ -444,6 +452,20 @@ int wgl_beam_check_rp(uint32_t n, const uint8_t* f, const int32_t* a, const int3
             uint32_t x = cc < nlive ? clst[coff[fi] + cc] : crashed[cc - nlive];
             uint32_t px = (uint32_t)process[x];
             open_ops[no] = x; open_lin[no] = (uint8_t)(pk[1 + (px >> 6)] >> (px & 63) & 1); no++;
+          }
+          if (g_lazy_comm && (f[op] == O_ADD || f[op] == O_TRANSFER) && ret_rank[op] != fi) {
+            int wanted = 0;
+            for (uint32_t cc = 0; cc < no && !wanted; cc++) {
+              const uint32_t x = open_ops[cc];
+              if (open_lin[cc] || f[x] != O_READ || a[x] == O_NIL) continue;
+              if (f[op] == O_TRANSFER) wanted = 1;
+              else {
+                const int32_t* rec = model->pool + a[x];
+                const uint32_t j = (uint32_t)a[op];
+                wanted = rec[0] >= 0 && ((((const uint32_t*)(rec + 2))[j >> 5] >> (j & 31)) & 1u);
+              }
+            }
+            if (!wanted) continue;
           }
           if (!oracle_cfg_step(model, fi, open_ops, open_lin, no, f, a, op)) continue;
           s2 = 0;
