@@ -69,7 +69,7 @@ def test_config4_multi_register_100k_ops_256_procs(native, oracle):
 
 
 def _bank_case(i):
-    h = bank_history(5000, 8, 500 + i, busy=0.25, info=0.0, corrupt=(i % 16 == 5))
+    h = bank_history(5000, 8, 500 + i, busy=0.5, info=0.0, corrupt=(i % 16 == 5))     # (8 client processes, each busy half of the time)
     e = _analysis.Encoded(M.bank(), h)
     return e.ops, e.native_model[0].kind
 
