@@ -120,6 +120,8 @@ def main():
     ap.add_argument("--batch2", type=int, default=2048, help="second workload: histories per GPU (a 2^21-entry visited set each: no retries)")
     ap.add_argument("--busy3", type=float, default=0.3, help="a point in between: ~19 calls in flight (0 = skip)")
     ap.add_argument("--batch3", type=int, default=8192, help="third workload: histories per GPU")
+    ap.add_argument("--info4", type=float, default=0.01, help="a batch of the headline workload with this share of crashed (:info) calls (0 = skip)")
+    ap.add_argument("--batch4", type=int, default=8192, help="crashed workload: histories per GPU")
     ap.add_argument("--no-tiers", action="store_true", help="skip the crashed-op tiers (extra.tiers)")
     ap.add_argument("--no-set-full", action="store_true", help="skip the checker/set-full scan (extra.set_full)")
     ap.add_argument("--no-cpu", action="store_true")
@@ -132,7 +134,7 @@ def main():
     args = ap.parse_args()
     if args.only_headline:
         args.no_cpu = args.no_tiers = args.no_set_full = True
-        args.busy2 = args.busy3 = 0.0
+        args.busy2 = args.busy3 = args.info4 = 0.0
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -156,7 +158,7 @@ def main():
         torch.cuda.set_device(local_rank)
     else:
         args.only_headline = args.no_cpu = args.no_tiers = args.no_set_full = True
-        args.busy2 = args.busy3 = 0.0
+        args.busy2 = args.busy3 = args.info4 = 0.0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if on_gpu:
@@ -471,8 +473,8 @@ def main():
             # A history at 32 in flight can need > 10^6 configs (the tail is heavy): 2^21-entry visited sets with their stacks = 67 MB
             # each, 2,048 of them (137 GB) a batch -- a quarter of the GPU's wavefront slots; smaller first sets cost retries that take
             # longer than the whole step (measured: 4,096 histories at 2^20 entries, 134 s of retries).
-            def second(busy, B2, vpo, seed0, cpu_n, cpu_cap, warm):
-                h2 = synth.register_ops_many(range(seed0, seed0 + B2), n_ops=args.ops, n_procs=args.procs, busy=busy, info=0.0)
+            def second(busy, B2, vpo, seed0, cpu_n, cpu_cap, warm, info=0.0):
+                h2 = synth.register_ops_many(range(seed0, seed0 + B2), n_ops=args.ops, n_procs=args.procs, busy=busy, info=info)
                 o2 = core.make_opts(device=local_rank, time_limit_ms=600000, want_witness=False, algorithm=N.ALG_COMPETITION,
                                     search_width=args.width, visited_per_op=vpo)
                 with core.Batch(h2, model, o2) as b2:
@@ -483,7 +485,7 @@ def main():
                     c2 = b2.counters(); tm2 = b2.timing_ns(); v2 = b2.verdicts()
                 alg2 = 16 * (c2["probes"] - c2["visited"]) + 32 * c2["visited"]
                 k2 = (tm2["search"] + tm2["retries"]) / 1e6
-                out = {"workload": workload_name(args.ops, args.procs, busy, 0.0), "histories_per_gpu": B2, "search_width": width2, "lanes_per_history": lanes2,
+                out = {"workload": workload_name(args.ops, args.procs, busy, info), "histories_per_gpu": B2, "search_width": width2, "lanes_per_history": lanes2,
                        "value": round(B2 / t2, 2), "unit": "histories/s", "ms_per_step": round(t2 * 1e3, 3),
                        "valid": int((v2 == N.VALID).sum()), "unknown": int((v2 == N.UNKNOWN).sum()),
                        "roofline": {"bound": "hbm", "achieved": round(alg2 / (k2 * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -491,7 +493,22 @@ def main():
                                     "kernel": "wgl_narrow_kernel" if lanes2 != 64 else "wgl_beam_kernel",
                                     "kernel_ms": round(k2, 3), "probes_per_launch": c2["probes"], "new_configs_per_launch": c2["visited"]},
                        "device_ms": {k: round(x / 1e6, 3) for k, x in tm2.items()}}
-                if not args.no_cpu:
+                if not args.no_cpu and info:
+                    # crashed calls: the library's count form; the CPU runs the same passes (oracle/wgl_count.c) on a thread pool
+                    from concurrent.futures import ThreadPoolExecutor
+                    from oracle import wgl
+                    cores, _, _ = usable_cores()
+                    dd = [h2[i].as_dict() for i in range(min(cpu_n, B2))]
+                    budget = 32 * max(len(h) for h in h2)
+                    tcp = time.perf_counter()
+                    with ThreadPoolExecutor(cores) as ex:
+                        rr = list(ex.map(lambda d: wgl.check_count_pipeline(d, {"kind": 1, "init": N.NIL}, width=width2, budget=budget), dd))
+                    tcp = time.perf_counter() - tcp
+                    assert all(r is not None and r[0] == int(v2[i]) for i, r in enumerate(rr)), "GPU and oracle disagree on the crashed workload's sample"
+                    out["cpu_baseline"] = {"value": round(len(dd) / tcp, 3), "unit": "histories/s", "cores": cores, "kind": "port",
+                                           "sample": f"first {len(dd)} histories, oracle/wgl_count.c (the count form's own passes, {width2} configs per round) from {cores} Python threads "
+                                                     f"(ctypes releases the GIL)"}
+                elif not args.no_cpu:
                     from oracle import wgl
                     cores, _, _ = usable_cores()
                     dd = [h2[i].as_dict() for i in range(min(cpu_n, B2))]
@@ -507,6 +524,10 @@ def main():
             line["extra"]["workload_2"] = second(args.busy2, args.batch2, 256, 10_000_000, 64, 60_000_000, False)      # (a step is ~25 s: one run, no warm-up)
             if args.busy3 > 0:
                 line["extra"]["workload_3"] = second(args.busy3, args.batch3, 32, 20_000_000, 128, 60_000_000, True)
+            if args.info4 > 0:
+                # the regime the reference produces (a nemesis makes clients time out: :info): the headline workload with 1 % of the
+                # calls crashed, a batch of them -- the count form, a wavefront per history
+                line["extra"]["workload_crashed"] = second(args.busy, args.batch4, 8, 30_000_000, 256, 0, True, info=args.info4)
         if world == 1 and not args.no_set_full:
             # checker/set-full (the checker the reference runs: set_full.clj:157): the reads x elements membership scan,
             # the one streaming kernel of the path.  Synthetic: 262,144 elements x 32,768 reads (1 GB of bits), an element
