@@ -89,6 +89,11 @@ def usable_cores():
     return n, (os.cpu_count() or 1), quota
 
 
+def leg(name):
+    """progress on stderr (the JSON line is the only thing on stdout): which leg a run was in if it does not end"""
+    print(f"[bench {time.strftime('%H:%M:%S')}] {name}", file=sys.stderr, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -206,6 +211,7 @@ def main():
     opts = core.make_opts(device=local_rank, time_limit_ms=600000, want_witness=False,
                           algorithm=N.ALG_COMPETITION, search_width=args.width, visited_per_op=args.visited_per_op,
                           round_budget=args.round_budget, lanes_per_history=args.lanes)
+    leg("inputs generated; creating the resident batches")
     t_create = time.perf_counter()
     batches = [BatchCls(h, model, opts) for h in hists_all]        # H2D happens here: inputs resident before timing
     t_create = (time.perf_counter() - t_create) / F
@@ -228,7 +234,9 @@ def main():
         th = [threading.Thread(target=passes, args=(k, len(range(k, total, F)), None if logs is None else logs[k])) for k in range(F)]
         for x in th: x.start()
         for x in th: x.join()
+    leg("warm-up")
     in_flight(max(args.warmup, F), None)                      # (every resident batch is run once before the clock starts)
+    leg("timed region")
     barrier()
     t0 = time.perf_counter()
     logs = [[] for _ in range(F)]
@@ -240,6 +248,7 @@ def main():
     assert len(tms) == args.steps
     search_ns, pack_ns, init_ns, retry_ns = ([tm[k] for tm in tms] for k in ("search", "pack", "init", "retries"))
     wait_ns = [tm["turn_wait"] for tm in tms]
+    leg("timed region done")
     # the same passes with nothing else in flight: one batch, one pass after the other (never `value` unless --in-flight 1)
     alone = None
     if F > 1 and not args.only_headline:
@@ -341,6 +350,7 @@ def main():
         # knossos.competition without a witness = the level sweep (jit_sweep.hip); with a witness = the depth-first search
         for b in batches:
             b.close()
+        leg("same batch, one history per wavefront")
         if world == 1 and narrow and args.lanes == 0 and not args.only_headline:
             # the same batch with ONE history per wavefront (round 2's kernel, wgl_beam_kernel at the width it chose then): what
             # several histories per wavefront buy, measured in the same run.  Never `value`.
@@ -355,6 +365,7 @@ def main():
                 "kernel_ms": round(tm4["search"] / 1e6, 3), "pack_ms": round(tm4["pack"] / 1e6, 3),
                 "probes_per_launch": c4["probes"], "new_configs_per_launch": c4["visited"], "algorithmic_bytes_per_launch": alg4,
                 "roofline_frac": round(alg4 / (tm4["search"] * 1e-9) / 1e9 / HBM_PEAK_GBS, 6)}
+        leg("time to verdict (one history through tbc_check)")
         if on_gpu:      # (one history through tbc_check: needs the device)
             ttv, ttv_dfs, analyzers = [], [], []
             o_sweep = core.make_opts(device=local_rank, want_witness=False, algorithm=N.ALG_COMPETITION)
@@ -375,6 +386,7 @@ def main():
                                                    "depth_first_with_witness_median": round(statistics.median(ttv_dfs), 3),
                                                    "invalid_example": round(tb_gpu, 3),
                                                    "invalid_example_verdict": rb["valid"], "invalid_example_steps": rb["steps"]}
+        leg("CPU baselines")
         if world == 1 and not args.no_cpu:
             from concurrent.futures import ThreadPoolExecutor
             from oracle import wgl
@@ -444,6 +456,7 @@ def main():
                 tiers = []
                 for info in (0.0, 0.01, 0.05):
                     for corrupt in (0.0, 0.5):
+                        leg(f"tier info {info} corrupt {corrupt}")
                         hh = columns.pair_events(synth.register_events(n_ops=args.ops, n_procs=args.procs, seed=4242, busy=args.busy, info=info, corrupt=corrupt))
                         t1 = time.perf_counter()
                         rg = core.check_ops(hh, model, core.make_opts(device=local_rank, want_witness=False, algorithm=N.ALG_COMPETITION, time_limit_ms=3000))
@@ -521,13 +534,17 @@ def main():
                                            "sample": f"first {len(dd)} histories, oracle/wgl_beam.c (the kernel's schedule, {width2} configs per round, lookahead + eager reads + "
                                                      f"twin rule) on {started} pthreads, at most {cpu_cap:.0e} probes each: {done} finished (the others are not counted)"}
                 return out
+            leg("workload 2")
             line["extra"]["workload_2"] = second(args.busy2, args.batch2, 256, 10_000_000, 64, 60_000_000, False)      # (a step is ~25 s: one run, no warm-up)
             if args.busy3 > 0:
+                leg("workload 3")
                 line["extra"]["workload_3"] = second(args.busy3, args.batch3, 32, 20_000_000, 128, 60_000_000, True)
             if args.info4 > 0:
                 # the regime the reference produces (a nemesis makes clients time out: :info): the headline workload with 1 % of the
                 # calls crashed, a batch of them -- the count form, a wavefront per history
+                leg("workload with crashed calls")
                 line["extra"]["workload_crashed"] = second(args.busy, args.batch4, 8, 30_000_000, 256, 0, True, info=args.info4)
+        leg("checker/set-full")
         if world == 1 and not args.no_set_full:
             # checker/set-full (the checker the reference runs: set_full.clj:157): the reads x elements membership scan,
             # the one streaming kernel of the path.  Synthetic: 262,144 elements x 32,768 reads (1 GB of bits), an element
