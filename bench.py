@@ -22,7 +22,7 @@
              duration, measured with HIP events on the pass's own stream (from the moment the search
              has the device to its end: with two batches in flight that is the search beside the other
              batch's pack); traffic = FETCH_SIZE + WRITE_SIZE of the committed rocprofv3 passes
-             (profiles/r03_traffic.json), copied only if kernel sources and configuration match
+             (profiles/r04_traffic.json), copied only if kernel sources and configuration match
   cpu_baseline : the CPU restatement of the same search (oracle/wgl_window.c, "port") on a bounded
              sample of the same histories: on all host cores (pthread pool, oracle/many.c) = `value`,
              and on one thread (`single_thread`)
@@ -131,7 +131,7 @@ def main():
     ap.add_argument("--no-set-full", action="store_true", help="skip the checker/set-full scan (extra.set_full)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--only-headline", action="store_true",
-                    help="the warm-up and the timed steps only (no extra legs): what scripts/gpu_profile_r03.sh runs under rocprofv3 --kernel-trace "
+                    help="the warm-up and the timed steps only (no extra legs): what scripts/gpu_profile_r04.sh runs under rocprofv3 --kernel-trace "
                          "--stats, so that the kernel's average duration there is the one of the timed region")
     ap.add_argument("--sharded-ttv", action="store_true",
                     help="N > 1 only: also time ONE history swept by all N GPUs (shard.check_sharded: wavefronts dealt to the ranks, "
@@ -296,7 +296,7 @@ def main():
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         traffic = None
         try:   # HBM bytes per launch from the committed rocprofv3 PMC passes: same config AND same kernel sources only
-            with open(os.path.join(ROOT, "profiles", "r03_traffic.json")) as fh:
+            with open(os.path.join(ROOT, "profiles", "r04_traffic.json")) as fh:
                 for e in json.load(fh)["entries"]:
                     key = (e["histories_per_gpu"], e["search_width"], e.get("lanes_per_history", 64), e["visited_per_op"], e["ops"], e["procs"], e["busy"], e["info"])
                     if e.get("kernel_sha") == kernel_sha() and key == (B, width, lanes, args.visited_per_op, args.ops, args.procs, args.busy, args.info):
