@@ -492,6 +492,24 @@ typedef struct tbc_setfull_out {   /* arrays caller-allocated, n_elements each; 
 typedef struct tbc_setfull tbc_setfull;
 /* inputs become resident in HBM (H2D here); run scans them; results copied into `out` */
 tbc_status tbc_setfull_create(const tbc_setfull_in* in, tbc_setfull** handle);
+
+/* The same with the reads in COMPACT form, the membership matrix built ON THE DEVICE (nothing of size reads x elements exists on
+ * the host or crosses PCIe).  A read of a grow-only set is, up to a few exceptions, a PREFIX of the elements in add-invocation
+ * order -- what had been added when it ran; so read r is given as top[r] (every element numbered below top[r] is in it) and a
+ * list of exceptions exc[exc_off[r] .. exc_off[r + 1]): element numbers, each at most once per read -- a listed element below
+ * top[r] is ABSENT from the read, one at or above it PRESENT.  (The reference's reads, workloads/set_full.clj:128-134, return the
+ * sorted set: the caller numbers the values by add invocation, takes top = greatest element read + 1 and lists the holes.) */
+typedef struct tbc_setfull_rows {
+  uint32_t n_elements, n_reads, device, reserved0;
+  const uint32_t* add_invoke;    /* as tbc_setfull_in */
+  const uint32_t* add_ok;
+  const uint32_t* read_invoke;
+  const uint32_t* read_ok;
+  const uint32_t* top;           /* [n_reads], <= n_elements */
+  const uint64_t* exc_off;       /* [n_reads + 1], ascending, exc_off[0] = 0 */
+  const uint32_t* exc;           /* [exc_off[n_reads]] element numbers < n_elements */
+} tbc_setfull_rows;
+tbc_status tbc_setfull_create_rows(const tbc_setfull_rows* in, tbc_setfull** handle);
 tbc_status tbc_setfull_run(tbc_setfull* handle, tbc_setfull_out* out);
 void tbc_setfull_destroy(tbc_setfull* handle);
 

@@ -127,6 +127,13 @@ class SetFullIn(C.Structure):
                 ("read_ok", C.POINTER(C.c_uint32)), ("present", C.POINTER(C.c_uint32))]
 
 
+class SetFullRows(C.Structure):
+    _fields_ = [("n_elements", C.c_uint32), ("n_reads", C.c_uint32), ("device", C.c_uint32), ("reserved0", C.c_uint32),
+                ("add_invoke", C.POINTER(C.c_uint32)), ("add_ok", C.POINTER(C.c_uint32)), ("read_invoke", C.POINTER(C.c_uint32)),
+                ("read_ok", C.POINTER(C.c_uint32)), ("top", C.POINTER(C.c_uint32)), ("exc_off", C.POINTER(C.c_uint64)),
+                ("exc", C.POINTER(C.c_uint32))]
+
+
 class SetFullOut(C.Structure):
     _fields_ = [("known", C.POINTER(C.c_uint32)), ("last_present", C.POINTER(C.c_uint32)), ("last_absent", C.POINTER(C.c_uint32)),
                 ("ns_scan", C.c_uint64), ("bytes_scanned", C.c_uint64), ("bytes_matrix", C.c_uint64)]
@@ -163,6 +170,7 @@ SYMBOLS = {
     "tbc_batch_sweep_finish": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(Result)]),
     "tbc_batch_sweep_merge": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(Result)]),
     "tbc_setfull_create": (C.c_int, [C.POINTER(SetFullIn), C.POINTER(C.c_void_p)]),
+    "tbc_setfull_create_rows": (C.c_int, [C.POINTER(SetFullRows), C.POINTER(C.c_void_p)]),
     "tbc_setfull_run": (C.c_int, [C.c_void_p, C.POINTER(SetFullOut)]),
     "tbc_setfull_destroy": (None, [C.c_void_p]),
     "tbc_batch_destroy": (None, [C.c_void_p]),

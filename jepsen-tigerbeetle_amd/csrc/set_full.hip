@@ -53,6 +53,25 @@ __device__ __forceinline__ uint32_t prefix_mask(uint32_t p, uint32_t w) {       
   return p >= 32u * w + 32u ? 0xFFFFFFFFu : (p <= 32u * w ? 0u : (1u << (p - 32u * w)) - 1u);
 }
 
+// ---- the membership matrix from the reads' compact form (tbc_setfull_create_rows): one workgroup per read writes its row --
+// ones below top[r], zeros above (a coalesced stream: the matrix is written once, at HBM's write rate) -- and then flips the
+// listed exceptions in it.  No row ever exists on the host.
+__global__ __launch_bounds__(256) void setfull_rows_kernel(const uint32_t* __restrict__ top, const unsigned long long* __restrict__ exc_off,
+                                                           const uint32_t* __restrict__ exc, uint32_t R, uint32_t WPR, uint32_t* __restrict__ M) {
+  for (uint32_t r = blockIdx.x; r < R; r += gridDim.x) {
+    uint32_t* row = M + (uint64_t)r * WPR;
+    const uint32_t t = top[r];
+    for (uint32_t w = threadIdx.x; w < WPR; w += 256u) row[w] = prefix_mask(t, w);
+    __syncthreads();
+    const unsigned long long e0 = exc_off[r], e1 = exc_off[r + 1];
+    for (unsigned long long i = e0 + threadIdx.x; i < e1; i += 256u) {
+      const uint32_t e = exc[i];
+      atomicXor(&row[e >> 5], 1u << (e & 31u));
+    }
+    __syncthreads();
+  }
+}
+
 // ---- pass 1: per (word column, chunk of rows) -- is any bit of the column present / absent in the chunk?  The streaming
 // pass: eight rows requested at a time (whether to go on depends on what was loaded), the chunk's row metadata in LDS,
 // two coalesced words written per thread, no atomics.
@@ -251,7 +270,7 @@ struct tbc_setfull {
   }
 };
 
-static tbc_status setfull_create_impl(const tbc_setfull_in* in, tbc_setfull* S) {
+static tbc_status setfull_create_impl(const tbc_setfull_in* in, tbc_setfull* S, const tbc_setfull_rows* rows = nullptr) {
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || (int)in->device >= ndev) {
     set_error("no usable HIP device; libtbcheck has no CPU fallback");
@@ -264,6 +283,14 @@ static tbc_status setfull_create_impl(const tbc_setfull_in* in, tbc_setfull* S) 
   }
   S->device = (int)in->device; S->E = in->n_elements; S->R = in->n_reads; S->WPR = in->words_per_row;
   if ((uint64_t)S->WPR * 32 < S->E) { set_error("tbc_setfull: words_per_row too small for n_elements"); return TBC_ERR_INVALID_ARG; }
+  if (rows) {          // the compact form: every offset and element number is checked here, the kernel trusts them
+    if (rows->exc_off[0] != 0) { set_error("tbc_setfull_create_rows: exc_off[0] must be 0"); return TBC_ERR_INVALID_ARG; }
+    for (uint32_t r = 0; r < S->R; r++) {
+      if (rows->top[r] > S->E || rows->exc_off[r + 1] < rows->exc_off[r]) { set_error("tbc_setfull_create_rows: read %u: bad top / exc_off", r); return TBC_ERR_INVALID_ARG; }
+    }
+    const uint64_t ne = rows->exc_off[S->R];
+    for (uint64_t i = 0; i < ne; i++) if (rows->exc[i] >= S->E) { set_error("tbc_setfull_create_rows: exception %llu names element %u of %u", (unsigned long long)i, rows->exc[i], S->E); return TBC_ERR_INVALID_ARG; }
+  }
   // the prefix search per row and "the latest row" both rest on the documented orders
   for (uint32_t e = 1; e < S->E; e++) if (in->add_invoke[e] <= in->add_invoke[e - 1]) { set_error("tbc_setfull: add_invoke must be strictly ascending (element %u)", e); return TBC_ERR_INVALID_ARG; }
   for (uint32_t r = 1; r < S->R; r++) if (in->read_invoke[r] <= in->read_invoke[r - 1]) { set_error("tbc_setfull: read_invoke must be strictly ascending (read %u)", r); return TBC_ERR_INVALID_ARG; }
@@ -291,7 +318,22 @@ static tbc_status setfull_create_impl(const tbc_setfull_in* in, tbc_setfull* S) 
   if (S->R) {
     SF_TRY(hipMemcpyAsync(S->d_read_invoke, in->read_invoke, (size_t)S->R * 4, hipMemcpyHostToDevice, S->stream));
     SF_TRY(hipMemcpyAsync(S->d_read_ok, in->read_ok, (size_t)S->R * 4, hipMemcpyHostToDevice, S->stream));
-    SF_TRY(hipMemcpyAsync(S->d_M, in->present, (size_t)S->R * S->WPR * 4, hipMemcpyHostToDevice, S->stream));
+    if (!rows) SF_TRY(hipMemcpyAsync(S->d_M, in->present, (size_t)S->R * S->WPR * 4, hipMemcpyHostToDevice, S->stream));
+  }
+  if (rows && S->R) {
+    const uint64_t ne = rows->exc_off[S->R];
+    uint32_t *d_top = nullptr, *d_exc = nullptr; unsigned long long* d_off = nullptr;
+    SF_TRY(hipMalloc((void**)&d_top, r4)); SF_TRY(hipMalloc((void**)&d_off, ((size_t)S->R + 1) * 8)); SF_TRY(hipMalloc((void**)&d_exc, std::max<size_t>(4, ne * 4)));
+    hipError_t e = hipMemcpyAsync(d_top, rows->top, (size_t)S->R * 4, hipMemcpyHostToDevice, S->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_off, rows->exc_off, ((size_t)S->R + 1) * 8, hipMemcpyHostToDevice, S->stream);
+    if (e == hipSuccess && ne) e = hipMemcpyAsync(d_exc, rows->exc, ne * 4, hipMemcpyHostToDevice, S->stream);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(setfull_rows_kernel, dim3(std::min<uint32_t>(S->R, 16384u)), dim3(256), 0, S->stream, d_top, d_off, d_exc, S->R, std::max(1u, S->WPR), S->d_M);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(S->stream);
+    (void)hipFree(d_top); (void)hipFree(d_off); (void)hipFree(d_exc);
+    if (e != hipSuccess) { set_error("tbc_setfull_create_rows: building the matrix failed: %s", hipGetErrorString(e)); return TBC_ERR_HIP; }
   }
   // p[r] (how many elements had been invoked when read r completed) and the chunks' maxima depend on the inputs only
   SF_TRY(hipMemsetAsync(S->d_pmax, 0, (size_t)S->chunks * 4, S->stream));
@@ -350,6 +392,23 @@ tbc_status tbc_setfull_run(tbc_setfull* S, tbc_setfull_out* out) {
   out->ns_scan = (uint64_t)(ms * 1e6);
   out->bytes_scanned = (uint64_t)words * 4;
   out->bytes_matrix = (uint64_t)S->R * S->WPR * 4;
+  return TBC_OK;
+}
+
+tbc_status tbc_setfull_create_rows(const tbc_setfull_rows* in, tbc_setfull** handle) {
+  if (!in || !handle || (in->n_elements && (!in->add_invoke || !in->add_ok)) ||
+      (in->n_reads && (!in->read_invoke || !in->read_ok || !in->top)) || !in->exc_off || (in->exc_off[in->n_reads] && !in->exc) || in->reserved0 != 0) {
+    set_error("tbc_setfull_create_rows: null argument");
+    return TBC_ERR_INVALID_ARG;
+  }
+  tbc_setfull_in dense{};
+  dense.n_elements = in->n_elements; dense.n_reads = in->n_reads; dense.words_per_row = std::max(1u, (in->n_elements + 31u) / 32u); dense.device = in->device;
+  dense.add_invoke = in->add_invoke; dense.add_ok = in->add_ok; dense.read_invoke = in->read_invoke; dense.read_ok = in->read_ok; dense.present = nullptr;
+  tbc_setfull* S = new (std::nothrow) tbc_setfull();
+  if (!S) return TBC_ERR_OOM;
+  const tbc_status st = setfull_create_impl(&dense, S, in);
+  if (st != TBC_OK) { delete S; return st; }
+  *handle = S;
   return TBC_OK;
 }
 

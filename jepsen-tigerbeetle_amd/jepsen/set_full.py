@@ -65,7 +65,13 @@ class Encoded:
         self.add_ok = np.array([add_ok.get(_freeze(v), NONE) for v in order], np.uint32)
         self.read_invoke = np.array([r[0] for r in reads], np.uint32)
         self.read_ok = np.array([r[1] for r in reads], np.uint32)
-        bits = np.zeros((max(R, 1), self.wpr * 32), bool)
+        # the reads in COMPACT form (tbc_setfull_rows): top[r] = every element numbered below it is in read r, except the listed
+        # exceptions -- a listed element below top is absent, one at or above it present.  A read of a grow-only set is a prefix of
+        # the elements in add-invocation order with a few holes, so top = greatest element read + 1 and the holes are the list.
+        self.top = np.zeros(max(R, 1), np.uint32)
+        self.exc_off = np.zeros(R + 1, np.uint64)
+        exc_parts = []
+        cols_of = []                                       # per read: the column numbers it contains (sorted, unique)
         ints = all(isinstance(v, int) and not isinstance(v, bool) for v in order)
         if ints and E:
             keys = np.array(order, np.int64)
@@ -83,19 +89,38 @@ class Encoded:
                         self.duplicated[x] = max(self.duplicated.get(x, 0), n)
                 pos = np.minimum(np.searchsorted(ks, arr), E - 1)
                 hit = ks[pos] == arr                       # values nobody added are not columns: jepsen ignores them here too
-                bits[r, srt[pos[hit]]] = True
+                cols_of.append((r, np.unique(srt[pos[hit]])))
             else:
                 seen = {}
                 for x in vals:
                     fx = _freeze(x)
                     seen[fx] = seen.get(fx, 0) + 1
-                    e = elems.get(fx)
-                    if e is not None:
-                        bits[r, e[0]] = True
+                cols_of.append((r, np.unique(np.array([elems[fx][0] for fx in seen if fx in elems], np.int64))))
                 for fx, n in seen.items():
                     if n > 1:
                         self.duplicated[fx] = max(self.duplicated.get(fx, 0), n)
-        self.present = np.ascontiguousarray(np.packbits(bits, axis=1, bitorder="little").view(np.uint32))
+        counts = np.zeros(R, np.int64)
+        for r, cols in cols_of:
+            if len(cols) == 0:
+                continue
+            t = int(cols[-1]) + 1
+            self.top[r] = t
+            holes = np.setdiff1d(np.arange(t, dtype=np.int64), cols, assume_unique=True)
+            counts[r] = len(holes)
+            if len(holes):
+                exc_parts.append(holes.astype(np.uint32))
+        self.exc_off[1:] = np.cumsum(counts)
+        self.exc = np.concatenate(exc_parts) if exc_parts else np.zeros(0, np.uint32)
+        self._cols_of = cols_of
+
+    @property
+    def present(self):
+        """The dense reads x elements bit matrix (tbc_setfull_in.present), built on demand: the checker itself hands the compact form
+        to the device, which builds the matrix there; tests and the dense entry point take this one."""
+        bits = np.zeros((max(self.R, 1), self.wpr * 32), bool)
+        for r, cols in self._cols_of:
+            bits[r, cols] = True
+        return np.ascontiguousarray(np.packbits(bits, axis=1, bitorder="little").view(np.uint32))
 
 
 def _freeze(v):
@@ -105,16 +130,34 @@ def _freeze(v):
 class Scan:
     """tbc_setfull_*: the matrix resident in HBM, `run()` scans it."""
 
-    def __init__(self, enc_or_arrays, device=0):
+    def __init__(self, enc_or_arrays, device=0, rows=None):
+        """rows: True = hand the reads over in compact form (top / exc_off / exc: tbc_setfull_create_rows, the matrix is built on
+        the device), False = the dense bit matrix (`present`); None = compact where the argument has it."""
         a = enc_or_arrays
         self._keep = a
+        if rows is None:
+            rows = hasattr(a, "top") and hasattr(a, "exc_off")
+        self.E = a.E
+        self._h = C.c_void_p()
+        if rows:
+            top = np.ascontiguousarray(a.top, np.uint32)
+            off = np.ascontiguousarray(a.exc_off, np.uint64)
+            exc = np.ascontiguousarray(a.exc if len(a.exc) else np.zeros(1, np.uint32), np.uint32)
+            self._keep = (a, top, off, exc)
+            s = N.SetFullRows()
+            s.n_elements, s.n_reads, s.device, s.reserved0 = a.E, a.R, device, 0
+            s.add_invoke, s.add_ok = _p(a.add_invoke, C.c_uint32), _p(a.add_ok, C.c_uint32)
+            s.read_invoke, s.read_ok = _p(a.read_invoke, C.c_uint32), _p(a.read_ok, C.c_uint32)
+            s.top, s.exc_off, s.exc = _p(top, C.c_uint32), _p(off, C.c_uint64), _p(exc, C.c_uint32)
+            N.check_status(N.lib().tbc_setfull_create_rows(C.byref(s), C.byref(self._h)))
+            return
+        present = a.present
+        self._keep = (a, present)
         s = N.SetFullIn()
         s.n_elements, s.n_reads, s.words_per_row, s.device = a.E, a.R, a.wpr, device
         s.add_invoke, s.add_ok = _p(a.add_invoke, C.c_uint32), _p(a.add_ok, C.c_uint32)
         s.read_invoke, s.read_ok = _p(a.read_invoke, C.c_uint32), _p(a.read_ok, C.c_uint32)
-        s.present = _p(a.present, C.c_uint32)
-        self.E = a.E
-        self._h = C.c_void_p()
+        s.present = _p(present, C.c_uint32)
         N.check_status(N.lib().tbc_setfull_create(C.byref(s), C.byref(self._h)))
 
     def run(self):

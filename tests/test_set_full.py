@@ -51,6 +51,33 @@ def test_encoder_builds_the_membership_matrix():
     assert e.present[:, 0].tolist() == [0b01, 0b11]          # 99 was never added: not a column
 
 
+def test_compact_rows_say_what_the_matrix_says():
+    """tbc_setfull_rows (top / exc_off / exc: what the checker hands to the device, which builds the matrix there) against the
+    dense matrix, read by read: ones below top, the listed exceptions flipped -- on histories with lost, stale and never-read
+    elements, re-adds, and reads that hold values nobody added."""
+    for seed in range(6):
+        hist = _lossy_set_history(seed, n_ops=600)[0]
+        first = next(o["value"] for o in hist if o["f"] == "add")
+        if seed % 2:
+            hist = hist + _h([("invoke", "add", first, 0), ("ok", "add", first, 0), ("invoke", "read", None, 1),
+                              ("ok", "read", [first, 10 ** 7], 1)])
+            for i, o in enumerate(hist):
+                o["index"] = i
+        enc = sf.Encoded(hist)
+        dense = enc.present
+        assert enc.exc_off[0] == 0 and len(enc.exc) == enc.exc_off[-1] and (np.diff(enc.exc_off.astype(np.int64)) >= 0).all()
+        n_exc = 0
+        for r in range(enc.R):
+            row = np.zeros(enc.wpr * 32, bool)
+            row[:enc.top[r]] = True
+            ex = enc.exc[int(enc.exc_off[r]):int(enc.exc_off[r + 1])]
+            assert len(np.unique(ex)) == len(ex) and (ex < enc.E).all()
+            row[ex] ^= True
+            assert np.array_equal(np.packbits(row, bitorder="little").view(np.uint32), dense[r]), (seed, r)
+            n_exc += len(ex)
+        assert n_exc > 0
+
+
 def _lossy_set_history(seed, n_ops=3000, lose=3, stale=4):
     """A grow-only-set history from the simulated store, then damaged: `lose` elements vanish from every read after some
     point (lost), `stale` elements are hidden from a few reads right after their add (stale), late adds stay unread."""
@@ -89,6 +116,23 @@ def test_scan_matches_the_restatement(native):
             assert [w["element"] for w in got["worst-stale"]][:3] == [w["element"] for w in want["worst-stale"]][:3]
         assert set(want["lost"]) == victims and got["valid?"] is False
         assert st["bytes_scanned"] <= 2 * st["bytes_matrix"] + 4096
+
+
+@pytest.mark.gpu
+def test_matrix_built_on_the_device_equals_the_matrix_from_the_host(native):
+    """tbc_setfull_create_rows (compact reads in, the matrix built by setfull_rows_kernel) against tbc_setfull_create (the dense
+    matrix over PCIe): the same three indices for every element; malformed compact inputs are refused before any device work."""
+    for seed in range(4):
+        enc = sf.Encoded(_lossy_set_history(10 + seed, n_ops=2500)[0])
+        with sf.Scan(enc, rows=True) as a, sf.Scan(enc, rows=False) as b:
+            ra, rb = a.run(), b.run()
+        for k in ("known", "last_present", "last_absent"):
+            assert np.array_equal(ra[k], rb[k]), (seed, k)
+        assert ra["bytes_scanned"] == rb["bytes_scanned"]
+    bad = sf.Encoded(_lossy_set_history(3, n_ops=300)[0])
+    bad.exc = bad.exc.copy(); bad.exc[0] = bad.E + 5
+    with pytest.raises(N.TbcError):
+        sf.Scan(bad, rows=True)
 
 
 @pytest.mark.gpu
