@@ -526,7 +526,8 @@ __global__ __launch_bounds__(1024) void open_dprod_kernel(PackOpenArgs A) {
 //   ncr[F]   = classes with a member invoked by front F (the classes are in order of their first invocation)
 //   look[t]  bit 48 of word 0: a crashed call that produces the value the call completing at t needs was invoked by then (the
 //            lookahead takes such a producer as available whatever the counts: conservative, a dead config is dead)
-__global__ __launch_bounds__(256) void count_fronts_kernel(PackOpenArgs A) {
+// phase 0 (before the front walk, whose front records hold the candidate counts): ncr[];  phase 1 (after it): the lookahead bit
+__global__ __launch_bounds__(256) void count_fronts_kernel(PackOpenArgs A, uint32_t phase) {
   const uint32_t NT = blockDim.x, tid = threadIdx.x, LW = 1u + A.mask_words;
   for (uint32_t h = A.h0 + blockIdx.x; h < A.n_hist; h += gridDim.x) {
     const Hist* H = &A.hist[h];
@@ -536,7 +537,8 @@ __global__ __launch_bounds__(256) void count_fronts_kernel(PackOpenArgs A) {
     const uint64_t* cmem = A.cmem + B->cmem_off;
     const OpRec* cls = reinterpret_cast<const OpRec*>(cmem);          // the class records head the history's block
     uint32_t* ncr = A.ncr + B->off_off;
-    uint64_t* look = A.look ? A.look + look_off(H->op_off, h, A.mask_words) : nullptr;
+    uint64_t* look = (A.look && phase == 1u) ? A.look + look_off(H->op_off, h, A.mask_words) : nullptr;
+    if (phase == 1u && !look) continue;
     for (uint32_t F = tid; F < R; F += NT) {
       const uint32_t need = look ? (uint32_t)(look[(uint64_t)F * LW] >> 16) & 0xFFu : kLookNone;
       uint32_t avail = 0; bool producer = false;
@@ -546,8 +548,8 @@ __global__ __launch_bounds__(256) void count_fronts_kernel(PackOpenArgs A) {
         avail++;
         producer = producer || look_prod(o.f_slot & 0xFFu, o.a, o.b) == need;
       }
-      ncr[F] = avail;
-      if (producer && need != kLookNone) look[(uint64_t)F * LW] |= 1ull << 48;
+      if (phase == 0u) ncr[F] = avail;
+      else if (producer && need != kLookNone) look[(uint64_t)F * LW] |= 1ull << 48;
     }
   }
 }
@@ -603,6 +605,7 @@ void launch_pack_open(const PackOpenArgs& a, void* stream) {
   // few histories: latency matters (tbc_check), give each the widest workgroup; many: occupancy matters
   const uint32_t nt = n_here <= 64 ? 1024 : 256;
   hipLaunchKernelGGL(open_counts_kernel, dim3(grid), dim3(nt), 0, s, a);
+  if (a.cmem) hipLaunchKernelGGL(count_fronts_kernel, dim3(grid), dim3(256), 0, s, a, 0u);
   const uint64_t waves = (uint64_t)n_here * a.chunks_per_hist;
   const uint32_t wgrid = (uint32_t)((waves + 3) / 4);
   // one mask word: the walk with lane = front (a fifth of the vector instructions); TBC_OPEN_WALK=slots keeps the walk with
@@ -620,7 +623,7 @@ void launch_pack_open(const PackOpenArgs& a, void* stream) {
   }
   // (the walk by front leaves the producer distances in the lookahead records and writes compact front records whole)
   if (a.look && !by_front) hipLaunchKernelGGL(open_dprod_kernel, dim3(grid), dim3(nt), 0, s, a);
-  if (a.cmem) hipLaunchKernelGGL(count_fronts_kernel, dim3(grid), dim3(256), 0, s, a);
+  if (a.cmem) hipLaunchKernelGGL(count_fronts_kernel, dim3(grid), dim3(256), 0, s, a, 1u);
   if (a.front_words && !(by_front && a.front_compact)) {
     const uint64_t fronts = (uint64_t)n_here * a.chunks_per_hist * 64u;
     hipLaunchKernelGGL(front_meta_kernel, dim3((uint32_t)((fronts + 255) / 256)), dim3(256), 0, s, a);

@@ -442,7 +442,7 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
     const bool regfam = model->kind == TBC_MODEL_REGISTER || model->kind == TBC_MODEL_CAS_REGISTER;
     const tbc_ops& c = desc->cols;
     bool want = regfam && opts->algorithm == TBC_ALG_COMPETITION && (opts->dominance & (TBC_DOM_NO_EAGER_READS | TBC_DOM_NO_TWIN_RULE | TBC_DOM_NO_COUNT_FORM)) == 0 &&
-                opts->search_width != 1 && (opts->lanes_per_history == 0 || opts->lanes_per_history == 64) && opts->lookahead != 1 &&
+                opts->search_width != 1 && opts->lanes_per_history != 4 && opts->lookahead != 1 &&      // (several histories per wavefront: 8 / 16 / 32 lanes in the count form)
                 (model->init == TBC_NIL || (model->init >= 0 && model->init <= kMaxRuleValue));
     want = want && scan.nonneg && scan.vmax <= kMaxRuleValue;
     const bool any = scan.any_crashed_effect;
@@ -543,20 +543,21 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
     if (opts->reserved0 != 0) { set_error("tbc_opts.reserved0 must be 0"); return TBC_ERR_INVALID_ARG; }
     const bool regfam3 = model->kind == TBC_MODEL_REGISTER || model->kind == TBC_MODEL_CAS_REGISTER || model->kind == TBC_MODEL_MUTEX;
     // the narrow kernel addresses a history's tables with 32-bit element offsets
-    const bool can = beam && !B->sweep && !B->count_form && regfam3 && narrow_supported(B->mask_words, 8) && opts->algorithm != TBC_ALG_WGL &&
+    const bool can = beam && !B->sweep && (!B->count_form || B->mask_words <= 2) && regfam3 && narrow_supported(B->mask_words, 8) && opts->algorithm != TBC_ALG_WGL &&
                      look_words(B->total_ops, nh, B->mask_words) < (1ull << 32);
     if (asked != 0 && asked != 64) {
       if (!can) { set_error("lanes_per_history %u: needs the depth-first search of a register / cas-register / mutex batch with at most 256 process slots (not TBC_ALG_WGL, not the level sweep)", asked); return TBC_ERR_UNSUPPORTED; }
       if (opts->search_width > 1) { set_error("lanes_per_history %u expands one config per iteration: leave search_width 0 or 1", asked); return TBC_ERR_INVALID_ARG; }
       B->lanes = asked;
-    } else if (asked == 0 && can && opts->search_width == 0 && B->width == 2 && nh >= 24576) {
+    } else if (asked == 0 && can && !B->count_form && opts->search_width == 0 && B->width == 2 && nh >= 24576) {      // (count form: by name only until measured)
       // measured (profiles/r03_narrow_batch_sizes.log): 8 lanes per history lose to a wavefront each at 4,096 and 8,192
       // histories (59 / 61 ms against 40 / 47: one round of the narrow kernel is ~10 us of dependent instructions and trips
       // whatever the load, so it needs three or four wavefronts per SIMD to hide it), tie at 16,384, win 97 against 160 ms at 32,768
       B->lanes = 8;
     }
     // under the eager rule the narrow kernel branches over :write / :cas only: lists without reads, root in normal form
-    if (B->lanes && (B->rules & kRuleEager)) B->rules |= kRuleBranch;
+    // (the count form's schedule, oracle/wgl_count.c, keeps the full lists and the root as given)
+    if (B->lanes && (B->rules & kRuleEager) && !B->count_form) B->rules |= kRuleBranch;
   }
   const uint32_t EW = B->entry_words();   // u64 words per wide-schedule entry
   // the frames arena is the pack kernels' scratch (3 words per op) and the sequential kernel's stack (4 + 2 mask words per op): a

@@ -17,13 +17,13 @@ constexpr uint32_t kNarrowWaves = 2;
 #define TBC_NARROW_MIN_WAVES 4
 #endif
 
-template <int MW, int L, bool CF>
-__global__ __launch_bounds__(64 * kNarrowWaves, TBC_NARROW_MIN_WAVES) void wgl_narrow_kernel(BeamArgs A) {
+template <int MW, int L, bool CF, bool CNT = false>
+__global__ __launch_bounds__(64 * kNarrowWaves, CNT ? 2 : TBC_NARROW_MIN_WAVES) void wgl_narrow_kernel(BeamArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wv_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const uint32_t w = blockIdx.x * kNarrowWaves + wv_;
-  narrow::narrow_wave<MW, L, CF>(A, w, lds + wv_ * narrow::narrow_lds_words(MW, L, CF), lane);
+  narrow::narrow_wave<MW, L, CF, CNT>(A, w, lds + wv_ * narrow::narrow_lds_words(MW, L, CF, CNT), lane);
 }
 
 // Wavefronts the GPU keeps resident at once: the launch is sized to that, not to the batch -- a wavefront's groups take more
@@ -40,10 +40,10 @@ uint32_t resident_waves(size_t lds_bytes_per_wave, uint32_t waves_per_simd) {
   return (uint32_t)cus * per_cu;
 }
 
-template <int MW, int L, bool CF>
+template <int MW, int L, bool CF, bool CNT = false>
 void launch_cf(const BeamArgs& a_in, hipStream_t s, uint32_t wps) {
   const uint32_t H = 64u / L;
-  const size_t lds_wave = (size_t)narrow::narrow_lds_words(MW, L, CF) * 4;
+  const size_t lds_wave = (size_t)narrow::narrow_lds_words(MW, L, CF, CNT) * 4;
   uint32_t waves = (a_in.n_work + H - 1) / H;
   const uint32_t fit = resident_waves(lds_wave, wps);
   if (waves > fit) waves = fit;
@@ -51,11 +51,18 @@ void launch_cf(const BeamArgs& a_in, hipStream_t s, uint32_t wps) {
   BeamArgs a = a_in;
   a.first_dynamic = blocks * kNarrowWaves * H;          // what the launch deals out; the queue hands out the rest
   (void)hipMemsetAsync(a.next_work, 0, sizeof(unsigned int), s);
-  hipLaunchKernelGGL((wgl_narrow_kernel<MW, L, CF>), dim3(blocks), dim3(64 * kNarrowWaves), lds_wave * kNarrowWaves, s, a);
+  hipLaunchKernelGGL((wgl_narrow_kernel<MW, L, CF, CNT>), dim3(blocks), dim3(64 * kNarrowWaves), lds_wave * kNarrowWaves, s, a);
 }
 
 template <int MW, int L>
 void launch_one(const BeamArgs& a, hipStream_t s, uint32_t wps) {
+  if constexpr (MW <= 2 && L >= 8) {
+    if (a.rules & kRuleCount) {          // the count form (crashed calls as counts per class): one or two mask words, 8 / 16 / 32 lanes per history
+      if constexpr (MW == 1) { if (a.front_words == kFrontCompactWords) { launch_cf<1, L, true, true>(a, s, wps); return; } }
+      launch_cf<MW, L, false, true>(a, s, wps);
+      return;
+    }
+  }
   if constexpr (MW == 1) {
     if (a.front_words == kFrontCompactWords) { launch_cf<1, L, true>(a, s, wps); return; }
   }

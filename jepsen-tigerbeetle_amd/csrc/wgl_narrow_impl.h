@@ -46,9 +46,10 @@ enum : uint32_t {
 };
 WV_HD constexpr uint32_t ring_size(uint32_t L) { return L <= 4u ? 8u : (L < 16u ? 16u : L); }      // (>= L: a round's pushes never clash)
 // ring entry: pos idx off nlive cnt (u32), k0 (u64), M[mw] (u64), the window word(s) of the config's front (u64: 4, or 1 compact)
-WV_HD constexpr uint32_t group_words(uint32_t mw, uint32_t L, bool cf = false) { return G_RING + ring_size(L) * (5u + 2u + 2u * mw + (cf ? 2u : 8u)); }
-// + the lookahead staging of a round (wave-wide): c_fi c_st c_lo (u32 x 64), c_M (u64 x 64 x mw)
-WV_HD constexpr uint32_t narrow_lds_words(uint32_t mw, uint32_t L, bool cf = false) { return (64u / L) * group_words(mw, L, cf) + 64u * 3u + 64u * 2u * mw; }
+// (count form: + the config's count vector, 2 x u64)
+WV_HD constexpr uint32_t group_words(uint32_t mw, uint32_t L, bool cf = false, bool cnt = false) { return G_RING + ring_size(L) * (5u + 2u + 2u * mw + (cf ? 2u : 8u) + (cnt ? 2u * kCountWords : 0u)); }
+// + the lookahead staging of a round (wave-wide): c_fi c_st c_lo (u32 x 64), c_M (u64 x 64 x mw); count form: + c_rt (u32 x 64: the prefix target)
+WV_HD constexpr uint32_t narrow_lds_words(uint32_t mw, uint32_t L, bool cf = false, bool cnt = false) { return (64u / L) * group_words(mw, L, cf, cnt) + 64u * 3u + 64u * 2u * mw + (cnt ? 64u : 0u); }
 
 WV_DEV uint32_t key_hash32(uint64_t k0, const uint64_t* M, int mw) {      // as wgl_beam.hip (a table a wide run grew is the same table)
   uint32_t h = (uint32_t)k0 * 0x9E3779B1u ^ (uint32_t)(k0 >> 32) * 0x85EBCA77u;
@@ -66,6 +67,16 @@ WV_DEV uint32_t key_hash32(uint64_t k0, const uint64_t* M, int mw) {      // as 
 // Zero stays empty too (the growth pool, scratch arenas), and epoch 0 is the untagged form: empty = zero.
 WV_DEV bool entry_empty(uint32_t x, uint32_t etag) { return x == 0u || (x & 0xFF000000u) != etag; }
 constexpr uint32_t kFrontMask = 0x00FFFFFFu;
+// count form: field-wise x >= y over packed count vectors, top = the top bit of every field (oracle/wgl_count.c, counts_ge)
+WV_DEV bool counts_ge(const uint64_t (&x)[kCountWords], const uint64_t (&y)[kCountWords], const uint64_t (&top)[kCountWords]) {
+  bool ge = true;
+  WV_UNROLL
+  for (uint32_t w = 0; w < kCountWords; w++) {
+    const uint64_t t = (x[w] | top[w]) - (y[w] & ~top[w]);
+    ge = ge && ((((x[w] & ~y[w]) | (~(x[w] ^ y[w]) & t)) & top[w]) == top[w]);
+  }
+  return ge;
+}
 
 template <int MW>
 WV_DEV bool mask_bit(const uint64_t (&M)[MW], uint32_t p) {
@@ -97,10 +108,11 @@ WV_DEV int32_t reg_apply(int32_t st, uint32_t f, int32_t a, int32_t b) {
 // ---- cold path: group `gsel`'s history moves to a 4x larger visited set (and stacks) from the batch's growth pool, done
 // by the whole wavefront (as wgl_beam.hip's grow_visited_set).  In / out: the group's table, stack, second stack and
 // capacity, wave-uniform.  Slot numbers change: the caller empties the group's ring.
-template <int MW, class ColdArgs>
+template <int MW, bool CNT, class ColdArgs>
 WV_DEV bool grow_group(ColdArgs C, wv::gu64*& tab_u, wv::gu32*& stack_u, wv::gu32*& dstack_u, uint32_t& cap_log2_u,
                        uint32_t sp, uint32_t dsp, uint32_t lane, uint32_t etag, bool links) {
-  constexpr uint32_t KW = MW + 1, EW = MW + 2;
+  constexpr uint32_t CWn = CNT ? kCountWords : 0u;        // count form: the count words ride behind the mask words (not hashed)
+  constexpr uint32_t KW = MW + 1 + CWn, EW = KW + 1;
   const wv::gu64* tab = tab_u;
   const wv::gu32* stack = stack_u;
   const wv::gu32* dstack = dstack_u;
@@ -125,9 +137,9 @@ WV_DEV bool grow_group(ColdArgs C, wv::gu64*& tab_u, wv::gu32*& stack_u, wv::gu3
     const wv::gu64* e = tab + s * KW;
     const uint64_t k0 = wv::ld64(e);
     if (entry_empty((uint32_t)k0, etag)) continue;
-    uint64_t Mx[MW];
+    uint64_t Mx[MW + CWn];
     WV_UNROLL
-    for (int j = 0; j < MW; j++) Mx[j] = wv::ld64(e + 1 + j);
+    for (int j = 0; j < MW + (int)CWn; j++) Mx[j] = wv::ld64(e + 1 + j);
     uint32_t b = key_hash32(k0, Mx, MW) & nbmask, idx = 0;
     for (bool placed = false; !placed; b = (b + 1u) & nbmask) {
       WV_NOUNROLL
@@ -135,7 +147,7 @@ WV_DEV bool grow_group(ColdArgs C, wv::gu64*& tab_u, wv::gu32*& stack_u, wv::gu3
         wv::gu64* ne = ntab + ((uint64_t)b * 4 + t) * KW;
         if (wv::cas64_from_zero(ne, k0) == 0ull) {
           WV_UNROLL
-          for (int j = 0; j < MW; j++) wv::st64(ne + 1 + j, Mx[j]);
+          for (int j = 0; j < MW + (int)CWn; j++) wv::st64(ne + 1 + j, Mx[j]);
           idx = b * 4 + t; placed = true;
         }
       }
@@ -163,13 +175,15 @@ WV_DEV bool grow_group(ColdArgs C, wv::gu64*& tab_u, wv::gu32*& stack_u, wv::gu3
 
 // One wavefront: H = 64 / L histories, work items wave_idx * H .. + H - 1 of A.work.
 // CF: the front records are the compact 64 B ones (tbc_internal.h; MW = 1)
-template <int MW, int L, bool CF = false>
+// CNT: the count form (tbc_internal.h, kRuleCount; the schedule is oracle/wgl_count.c's at one config per iteration and L pairs per round)
+template <int MW, int L, bool CF = false, bool CNT = false>
 WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* lds, const uint32_t lane) {
   static_assert(!CF || MW == 1, "compact front records have one mask word");
   constexpr uint32_t WN = CF ? 1u : 4u;          // window words per config
   using wv::gu32;
   using wv::gu64;
-  constexpr uint32_t H = 64u / L, RS = ring_size(L), KW = MW + 1, GW = group_words(MW, L, CF);
+  constexpr uint32_t CWn = CNT ? kCountWords : 0u;
+  constexpr uint32_t H = 64u / L, RS = ring_size(L), KW = MW + 1 + CWn, GW = group_words(MW, L, CF, CNT);
   static_assert(L == 4 || L == 8 || L == 16 || L == 32, "lanes per history");
   const uint32_t li = lane & (L - 1u), gbase = lane & ~(L - 1u), g = lane / L;
   const uint32_t below = (1u << li) - 1u;                       // the group's lower lanes, as group bits
@@ -185,10 +199,12 @@ WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* ld
   uint64_t* const r_k0 = reinterpret_cast<uint64_t*>(r_cnt + RS);
   uint64_t* const r_M = r_k0 + RS;
   uint64_t* const r_W = r_M + RS * MW;          // windows of completion slots / read kinds from the config's front on
+  uint64_t* const r_C = r_W + RS * WN;          // count form: the config's count vector
   uint32_t* const c_fi = lds + H * GW;          // this round's new configs for the lookahead, wave-wide
   uint32_t* const c_st = c_fi + 64;
   uint32_t* const c_lo = c_st + 64;
   uint64_t* const c_M = reinterpret_cast<uint64_t*>(c_lo + 64);
+  uint32_t* const c_rt = reinterpret_cast<uint32_t*>(c_M + 64 * MW);      // count form: the child's history's prefix target
 
   // ---- the group's history (a group takes a new one whenever it has finished one: A.next_work)
   const uint32_t rules = A.rules, vpad = A.vpad;
@@ -200,6 +216,11 @@ WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* ld
   const bool look_avail = A.look != nullptr && A.dstack != nullptr;
   bool has = false;
   uint32_t hidx = 0, op_off = 0, R = 0, lst_off = 0, look_lo = 0, cap_log2 = 10;
+  // count form: where the history's block of cmem[] starts (class records, then their members), the top bit of every count
+  // field, the completions a config must pass for the search to end VALID (all of them, or a prefix), exact / relaxed
+  uint32_t cmem_lo = 0, RT = 0;
+  uint64_t top[kCountWords] = {0ull, 0ull};
+  const bool relaxed = CNT && A.count_mode == kCountRelaxed;
   uint64_t slot8_lo = 0;
   gu64* tab = (gu64*)A.tab;
   gu32* stack = (gu32*)A.stack;
@@ -219,6 +240,13 @@ WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* ld
     cap_log2 = has ? Bd->tab_log2 : 10u;
     look_lo = (uint32_t)look_off(op_off, hidx, MW);           // u64 units into A.look
     slot8_lo = slot8_off(op_off, hidx);
+    RT = R;
+    if constexpr (CNT) {
+      cmem_lo = has ? (uint32_t)Bd->cmem_off : 0u;
+      top[0] = has ? Bd->top[0] : 0ull; top[1] = has ? Bd->top[1] : 0ull;
+      const uint32_t tg = has ? Bd->target : 0u;
+      if (tg != 0u && tg < R) RT = tg;
+    }
     flags = 0; sp = 0; dsp = 0; visited = 0;
     int32_t verdict0 = -2;
     uint32_t f0 = 0;                                // the root's front
@@ -257,6 +285,7 @@ WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* ld
           wv::own_st64(e, k0);
           WV_UNROLL
           for (int j = 0; j < MW; j++) wv::own_st64(e + 1 + j, M0[j]);
+          if constexpr (CNT) { wv::own_st64(e + 1 + MW, 0ull); wv::own_st64(e + 2 + MW, 0ull); }
           if (links) wv::own_st64(tab + ((uint64_t)KW << cap_log2) + idx, (uint64_t)kNone | ((uint64_t)kNone << 32));
           wv::own_st32(stack, idx);
         }
@@ -284,6 +313,8 @@ WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* ld
   // the parent config of the group (a copy in every lane of the group) and the round it is in
   uint32_t p_fi = 0, pslot = 0, poff = 0, nlive = 0, cnt = 0, base = 0;
   int32_t p_st = 0;
+  bool p_hot = false;                    // count form: the parent is hot (bit 30 of its state word)
+  uint64_t Cp[kCountWords] = {0ull, 0ull};
   uint64_t Mp[MW];
   WV_UNROLL
   for (int j = 0; j < MW; j++) Mp[j] = 0;
@@ -311,7 +342,9 @@ WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* ld
     const uint32_t c_ = have ? cnt_ - 1u - cd_ : 0u;
     const bool live_ = have ? c_ < nlive_ : true;
     const uint32_t po = have ? poff_ : 0u;
-    const OpRec* rp = live_ ? A.lst + ((uint64_t)lst_off + po + c_) : A.crashed + ((uint64_t)op_off + (c_ - nlive_));
+    // (count form: the candidates past the live calls are the CLASSES of crashed calls, whose records head the history's block of cmem[])
+    const OpRec* rp = live_ ? A.lst + ((uint64_t)lst_off + po + c_)
+                            : (CNT ? reinterpret_cast<const OpRec*>(A.cmem + cmem_lo) + (c_ - nlive_) : A.crashed + ((uint64_t)op_off + (c_ - nlive_)));
     c_oi = *rp;
     const uint64_t* tw = tw_base + ((twin && live_) ? ((uint64_t)lst_off + po + c_) * MW : 0ull);
     WV_UNROLL
@@ -437,7 +470,7 @@ WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* ld
         gu32* d_u = (gu32*)((uint64_t)GSg[G_DSTACK] | ((uint64_t)GSg[G_DSTACK + 1] << 32));
         uint32_t cap_u = wv::readlane(cap_log2, src);
         const uint32_t sp_u = wv::readlane(sp, src), dsp_u = wv::readlane(dsp, src);
-        const bool ok = grow_group<MW>(C, t_u, s_u, d_u, cap_u, sp_u, dsp_u, lane, etag, links);
+        const bool ok = grow_group<MW, CNT>(C, t_u, s_u, d_u, cap_u, sp_u, dsp_u, lane, etag, links);
         if (g == gg) {
           if (ok) {
             tab = t_u; stack = s_u; cap_log2 = cap_u;
@@ -481,12 +514,14 @@ WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* ld
           pslot = r_idx[rs]; poff = r_off[rs]; nlive = r_nlive[rs]; cnt = r_cnt[rs];
           p_ws0 = r_W[rs * WN];
           if constexpr (!CF) { p_ws1 = r_W[rs * 4 + 1]; p_wk0 = r_W[rs * 4 + 2]; p_wk1 = r_W[rs * 4 + 3]; }
+          if constexpr (CNT) { Cp[0] = r_C[rs * 2]; Cp[1] = r_C[rs * 2 + 1]; }
         } else {
           const uint32_t idx = wv::own_ld32(stack + pos);
           const gu64* e = tab + (uint64_t)idx * KW;
           k0 = wv::own_ld64(e);
           WV_UNROLL
           for (int j = 0; j < MW; j++) Mp[j] = wv::own_ld64(e + 1 + j);
+          if constexpr (CNT) { Cp[0] = wv::own_ld64(e + 1 + MW); Cp[1] = wv::own_ld64(e + 2 + MW); }
           const uint64_t* fr = A.rdm + ((uint64_t)op_off + (((uint32_t)k0 & kFrontMask) - 1u)) * FW + (CF ? 6u : FM);      // its front's record
           const uint64_t m0 = fr[0];
           pslot = idx; poff = (uint32_t)m0;
@@ -494,6 +529,7 @@ WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* ld
           else { nlive = (uint32_t)(m0 >> 32); cnt = (uint32_t)fr[1]; p_ws0 = fr[2]; p_ws1 = fr[3]; p_wk0 = fr[4]; p_wk1 = fr[5]; }
         }
         p_fi = ((uint32_t)k0 & kFrontMask) - 1u; p_st = (int32_t)(uint32_t)(k0 >> 32);
+        if constexpr (CNT) { p_hot = ((uint32_t)(k0 >> 32) & kHotBit) != 0u; p_st = (int32_t)((uint32_t)(k0 >> 32) & ~kHotBit); }
         if (visited + cnt > full_at) {
           flags |= F_NEED_GROW;                  // room for every pair of this parent?  If not it stays on the stack
         } else {
@@ -525,19 +561,36 @@ WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* ld
       WV_UNROLL
       for (int j = 0; j < MW; j++) dominated = dominated || (c_tw[j] & ~Mp[j]) != 0ull;
     }
-    const uint32_t op = oi.op;
-    const uint32_t f = oi.f_slot & 0xFFu, p = (oi.f_slot >> 8) & kSlotMask;
-    const bool lin = mask_bit<MW>(Mp, p);
+    // count form: a candidate past the live calls is a CLASS of crashed calls; its next member (the parent's count says which) must
+    // be invoked by the parent's front -- one dependent load here (inv_rank | op << 32; the sentinel behind the last member is all ones)
+    const bool is_cls = CNT && act && !live;
+    uint64_t mem = ~0ull;
+    if constexpr (CNT) {
+      const uint32_t sh = (oi.f_slot >> 8) & 0xFFu, wd = (oi.f_slot >> 16) & 0xFFu;
+      const uint32_t kc = (is_cls && !relaxed) ? (uint32_t)(((sh & 64u) ? Cp[1] : Cp[0]) >> (sh & 63u)) & ((1u << wd) - 1u) : 0u;
+      mem = A.cmem[(uint64_t)cmem_lo + (is_cls ? oi.op + kc : 0u)];
+      if (!is_cls) mem = ~0ull;
+    }
+    const uint32_t op = is_cls ? (uint32_t)(mem >> 32) : oi.op;
+    const uint32_t f = oi.f_slot & 0xFFu, p = is_cls ? 0u : (oi.f_slot >> 8) & kSlotMask;
+    const bool lin = !is_cls && mask_bit<MW>(Mp, p);
     // a crashed call has no per-front entry: its twins are every live open call with its effect (they all complete
     // earlier) and the crashed ones invoked before it -- walk the list (crash-heavy histories only)
-    if (twin && act && !lin && !live && (f == TBC_F_WRITE || f == TBC_F_CAS)) {
+    if (!CNT && twin && act && !lin && !live && (f == TBC_F_WRITE || f == TBC_F_CAS)) {
       for (uint32_t cc = 0; cc < c && !dominated; cc++) {
         const OpRec y = cc < nlive ? A.lst[(uint64_t)lst_off + poff + cc] : A.crashed[(uint64_t)op_off + (cc - nlive)];
         if ((y.f_slot & 0xFFu) != f || y.a != oi.a || (f == TBC_F_CAS && y.b != oi.b)) continue;
         dominated = !mask_bit<MW>(Mp, (y.f_slot >> 8) & kSlotMask);
       }
     }
-    const bool viable = act && !lin && !dominated && reg_ok(st, f, oi.a);
+    bool viable = act && !lin && !dominated && !is_cls && reg_ok(st, f, oi.a);
+    if constexpr (CNT) {
+      // a hot config only takes calls whose precondition is its state; a crashed :write is not one, and never writes the state it finds
+      if (p_hot) viable = viable && (f == TBC_F_READ || f == TBC_F_CAS) && oi.a == st;
+      if (is_cls) viable = (uint32_t)mem <= fi && (f == TBC_F_WRITE ? (!p_hot && oi.a != st) : oi.a == st);
+    }
+    bool observed = !is_cls;               // (a child reached by a crashed call is hot until a read of exactly its new state takes it)
+    uint64_t C2[kCountWords] = {Cp[0], Cp[1]};
     // the child: linearize; the front moves past every completion whose call is linearized -- or, under the eager rule,
     // is a read the child's state allows (value nil or the state: it is open, so the rule takes it).  Slots and read kinds
     // of the next ranks came with the candidate: no memory access here.  The reads the rule takes that are still open at
@@ -555,7 +608,13 @@ WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* ld
     };
     if (viable) {
       st2 = reg_apply(st, f, oi.a, oi.b);
-      mask_set<MW>(M2, p);
+      if (!is_cls) mask_set<MW>(M2, p);
+      if constexpr (CNT) {
+        if (is_cls && !relaxed) {            // the class's count goes up: no mask bit, the front stays where the reads let it
+          const uint32_t sh = (oi.f_slot >> 8) & 0xFFu;
+          if (sh & 64u) C2[1] += 1ull << (sh & 63u); else C2[0] += 1ull << (sh & 63u);
+        }
+      }
       const uint32_t vis = eager ? rdm_index(st2, vpad) : 0xFFFFu;
       for (;;) {
         uint32_t pp, rk;
@@ -571,6 +630,7 @@ WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* ld
         else {
           if (!eager) break;
           if (!(rk == 0u || rk == vis)) break;
+          if (CNT && rk != 0u) observed = true;        // a read of exactly the state completes here: it observes the crashed call
         }
         fi2++;
         if (fi2 == R) break;
@@ -578,7 +638,7 @@ WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* ld
     }
     if (inround && li == 0) wv::lds_add64(GS + G_ROUNDS, 1ull);
     // linearizable: the group's lowest pair wins, nothing of this round is inserted
-    const uint32_t gsucc = grp(wv::ballot(viable && fi2 == R));
+    const uint32_t gsucc = grp(wv::ballot(viable && fi2 >= RT));        // (RT = R unless the count form checks a prefix)
     if (gsucc) {
       if (li == (uint32_t)__builtin_ctz(gsucc)) {
         GS[G_WINPAR] = pslot; GS[G_WINOP] = op; GS[G_WINSTATE] = (uint32_t)st2; GS[G_VERDICT] = (uint32_t)TBC_VALID;
@@ -598,7 +658,7 @@ WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* ld
     const bool lkme = go && (flags & F_LOOK);
     const uint64_t lk = wv::ballot(lkme);
     const uint32_t ci = (uint32_t)__builtin_popcountll(lk & ((1ull << lane) - 1ull)), nn0 = (uint32_t)__builtin_popcountll(lk);
-    if (lkme) { c_fi[ci] = fi2; c_lo[ci] = look_lo; }
+    if (lkme) { c_fi[ci] = fi2; c_lo[ci] = look_lo; if constexpr (CNT) c_rt[ci] = RT; }
     wv::barrier();
     const uint32_t f3 = go ? fi2 : 0u;
     const uint64_t* const fr = A.rdm + ((uint64_t)op_off + f3) * FW;
@@ -627,6 +687,10 @@ WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* ld
       }
       WV_UNROLL
       for (int j = 0; j < MW; j++) { r0[j] = eager ? fr[j] : 0ull; rv[j] = eager ? fr[vi * MW + j] : 0ull; }
+      if constexpr (CNT) {
+        WV_UNROLL
+        for (int j = 0; j < MW; j++) observed = observed || (go && (rv[j] & ~M2[j]) != 0ull);
+      }
       WV_UNROLL
       for (int j = 0; j < MW; j++) M2[j] |= go ? (r0[j] | rv[j]) : 0ull;
       co0 = (uint32_t)m0;
@@ -646,7 +710,8 @@ WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* ld
     // their child's call un-linearizable (wgl_beam.hip states the rule)
     const auto look_batch = [&](uint32_t cb, uint64_t w_0, const uint64_t (&pm)[MW]) -> uint64_t {
       const uint32_t cc = cb + (lane >> 3), j = lane & 7u;
-      const bool val = cc < nn0;
+      bool val = cc < nn0;
+      if constexpr (CNT) val = val && c_fi[cc] + j < c_rt[cc];       // (completions past a prefix target constrain nothing)
       const int32_t cs = val ? (int32_t)c_st[cc] : 0;
       uint64_t Mc[MW];
       WV_UNROLL
@@ -667,7 +732,8 @@ WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* ld
       if (j >= 4u) acc |= x;
       uint32_t before = wv::row_shr0<1>(acc);
       if (j == 0u) before = 0u;
-      const bool ok = need == kLookNone || linz || (int32_t)need == cs || dprod < j || pmhit || ((before >> need) & 1u);
+      // (count form: bit 48 = a crashed call producing `need` is invoked by that rank: available whatever the counts)
+      const bool ok = need == kLookNone || linz || (int32_t)need == cs || dprod < j || pmhit || ((before >> need) & 1u) || (CNT && ((w_0 >> 48) & 1ull));
       return wv::ballot(val && !ok);
     };
     if (nn0) {
@@ -692,14 +758,14 @@ WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* ld
     }
 
     // ---- trip 2, issue: the child's bucket of the visited set ...
-    const uint64_t k0c = (uint64_t)((fi2 + 1u) | etag) | ((uint64_t)(uint32_t)st2 << 32);
+    const uint64_t k0c = (uint64_t)((fi2 + 1u) | etag) | ((uint64_t)((uint32_t)st2 | ((CNT && !observed) ? kHotBit : 0u)) << 32);
     uint32_t b = key_hash32(k0c, M2, MW) & bmask, idx = 0, full_buckets = 0;
     bool pending = go, fresh = false;
     wv::u32x4 ke[4];                 // MW = 1: the bucket's four 16 B entries
     uint64_t kk[4];                  // MW > 1: their first words
     const auto load_bucket = [&]() {
       const gu64* bp = tab + (uint64_t)b * (4 * KW);
-      if constexpr (MW == 1) {
+      if constexpr (MW == 1 && !CNT) {
         WV_UNROLL
         for (int t = 0; t < 4; t++) ke[t] = wv::own_ld128(bp + 2 * t);
       } else {
@@ -740,7 +806,7 @@ WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* ld
       bool want = false;
       if (pending) {
         uint32_t match = 0, empty = 0;
-        if constexpr (MW == 1) {
+        if constexpr (MW == 1 && !CNT) {
           const uint32_t k0l = (uint32_t)k0c, k0h = (uint32_t)(k0c >> 32), ml = (uint32_t)M2[0], mh = (uint32_t)(M2[0] >> 32);
           WV_UNROLL
           for (int t = 0; t < 4; t++) {
@@ -756,6 +822,14 @@ WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* ld
               bool same = true;
               WV_UNROLL
               for (int j = 0; j < MW; j++) same = same && wv::own_ld64(bp + t * KW + 1 + j) == M2[j];
+              if constexpr (CNT) {
+                // the Pareto rule: an entry with this key that has used no more of any class dominates the child ("match" = it is dropped);
+                // every config of one key lies on this chain, which ends at the first bucket with an empty entry
+                if (same) {
+                  const uint64_t theirs[kCountWords] = {wv::own_ld64(bp + t * KW + 1 + MW), wv::own_ld64(bp + t * KW + 2 + MW)};
+                  same = counts_ge(C2, theirs, top);
+                }
+              }
               match |= same ? 1u << t : 0u;
             }
           }
@@ -787,6 +861,7 @@ WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* ld
           wv::own_st64(e, k0c);
           WV_UNROLL
           for (int j = 0; j < MW; j++) wv::own_st64(e + 1 + j, M2[j]);
+          if constexpr (CNT) { wv::own_st64(e + 1 + MW, C2[0]); wv::own_st64(e + 2 + MW, C2[1]); }
           fresh = true; pending = false;
         }
       }
@@ -829,6 +904,7 @@ WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* ld
       r_off[rs] = co0; r_nlive[rs] = cnl; r_cnt[rs] = ccnt;
       WV_UNROLL
       for (uint32_t t = 0; t < WN; t++) r_W[rs * WN + t] = cw[t];
+      if constexpr (CNT) { r_C[rs * 2] = C2[0]; r_C[rs * 2 + 1] = C2[1]; }
     }
     sp += (uint32_t)__builtin_popcount(gnb);
     visited += (uint32_t)__builtin_popcount(grp(nb0));

@@ -369,6 +369,7 @@ def check_count(ops, model, width=4, max_probes=0, want_witness=True, round_pair
     slots = np.zeros(max(n, 1), np.uint32)
     L = lib()
     L.wgl_count_set_slots_out(_p(slots, C.c_uint32) if want_slots else None)
+    L.wgl_count_set_limit_per_round(C.c_uint32(1 if round_pairs != 64 else 0))      # (the narrow kernel looks at its step limit after every round)
     try:
         rc = L.wgl_count_check(C.c_uint32(n), _p(f, C.c_uint8), _p(a, C.c_int32), _p(b, C.c_int32),
                                _p(proc, C.c_int32), C.c_uint32(int(ops["n_process"])), _p(inv, C.c_uint32),
@@ -396,7 +397,7 @@ def completion_rank(ops, op):
     return int((ret < ret[op]).sum())
 
 
-def check_count_pipeline(ops, model, width=4, budget=None, want_witness=False):
+def check_count_pipeline(ops, model, width=4, budget=None, want_witness=False, round_pairs=64):
     """What the library does with a history in count form (tbc_api.hip, batch_run_impl), pass by pass over wgl_count.c: the exact
     search under a budget of probes (the library: 32 per op of the batch's longest history); past it the RELAXED search (every
     class an unlimited supply: a superset of the linearizations), whose INVALID verdict bounds the failing completion from above;
@@ -411,20 +412,20 @@ def check_count_pipeline(ops, model, width=4, budget=None, want_witness=False):
         for k in tot:
             tot[k] += r[k]
         return r
-    g = check_count(ops, model, width=width, want_witness=want_witness, max_probes=budget)
+    g = check_count(ops, model, width=width, want_witness=want_witness, max_probes=budget, round_pairs=round_pairs)
     if g is None:
         return None
     add(g)
     if g["valid"] != -1:
         return g["valid"], g["fail_op"], g, tot, "exact"
-    r = add(check_count(ops, model, width=width, want_witness=False, relaxed=True))
+    r = add(check_count(ops, model, width=width, want_witness=False, relaxed=True, round_pairs=round_pairs))
     if r["valid"] == 1:
-        g = add(check_count(ops, model, width=width, want_witness=want_witness))
+        g = add(check_count(ops, model, width=width, want_witness=want_witness, round_pairs=round_pairs))
         return g["valid"], g["fail_op"], g, tot, "exact, no budget"
     t = completion_rank(ops, r["fail_op"])
     if t == 0:
         return 0, r["fail_op"], r, tot, "relaxed"
-    g = add(check_count(ops, model, width=width, want_witness=False, target=t))
+    g = add(check_count(ops, model, width=width, want_witness=False, target=t, round_pairs=round_pairs))
     if g["valid"] == 1:
         return 0, r["fail_op"], g, tot, "prefix"
     return g["valid"], g["fail_op"], g, tot, "prefix exhausted"

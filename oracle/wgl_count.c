@@ -154,6 +154,11 @@ static uint32_t carena_add(carena* a, const uint64_t* k, const uint64_t* H, uint
 static _Thread_local uint32_t* g_slots_out = NULL;
 void wgl_count_set_slots_out(uint32_t* buf) { g_slots_out = buf; }
 
+/* where the step limit is looked at: between iterations (the wide kernel, wgl_beam.hip) or after every round (the narrow kernel,
+ * wgl_narrow_impl.h: "as after the round that exceeded it") */
+static uint32_t g_limit_per_round = 0;
+void wgl_count_set_limit_per_round(uint32_t on) { g_limit_per_round = on; }
+
 static uint32_t get_count(const uint64_t* C, const cclass* c) {
   return (uint32_t)((C[c->shift >> 6] >> (c->shift & 63u)) & ((1ull << c->width) - 1ull));
 }
@@ -448,9 +453,10 @@ int wgl_count_check(uint32_t n, const uint8_t* f, const int32_t* a, const int32_
         if (sp == scap) { scap *= 2; stack = (uint32_t*)realloc(stack, scap * 4); }
         stack[sp++] = id;
       }
+      if (g_limit_per_round && max_probes && st->probes > max_probes) { verdict = -1; break; }
     }
     if (sp > st->max_stack) st->max_stack = sp;
-    /* the step limit is looked at between iterations (as the kernel does) */
+    /* the step limit is looked at between iterations (as the wide kernel does) */
     if (verdict == -2 && max_probes && st->probes > max_probes) { verdict = -1; break; }
   }
 

@@ -112,7 +112,7 @@ def rules_for(hists, model_kind, init, nil=-(2 ** 31)):
     return 3, vpad
 
 
-def run(hists, model_kind, init, L, rules=None, lookahead=True, entries_per_op=8, max_steps=0, pool_words=0, want_witness=True, max_waves=0, branch_lists=True, compact=True, epochs=0):
+def run(hists, model_kind, init, L, rules=None, lookahead=True, entries_per_op=8, max_steps=0, pool_words=0, want_witness=True, max_waves=0, branch_lists=True, compact=True, epochs=0, count=False, relaxed=False, targets=None, mw=None):
     """hists: list of op-column dicts (f,a,b,process,inv_pos,ret_pos,n_process).  Returns one result dict per history."""
     ds = [h if isinstance(h, dict) else h.as_dict() for h in hists]
     nh = len(ds)
@@ -123,12 +123,13 @@ def run(hists, model_kind, init, L, rules=None, lookahead=True, entries_per_op=8
     f, a, b = cat("f", np.uint8), cat("a", np.int32), cat("b", np.int32)
     pr, inv, ret = cat("process", np.int32), cat("inv_pos", np.uint32), cat("ret_pos", np.uint32)
     npr = np.array([int(d["n_process"]) for d in ds], np.uint32)
-    mw = max(1, (int(npr.max()) + 63) // 64)
-    mw = 1 if mw <= 1 else 2 if mw <= 2 else 4
+    if mw is None:
+        mw = max(1, (int(npr.max()) + 63) // 64)
+        mw = 1 if mw <= 1 else 2 if mw <= 2 else 4
     r, vpad = rules_for(ds, model_kind, init)
     if rules is not None:
         r &= rules
-    if (r & 1) and branch_lists:
+    if (r & 1) and branch_lists and not count:
         r |= 4                 # kRuleBranch: what libtbcheck sets for the narrow kernel whenever the eager rule is on
     look = bool(lookahead) and model_kind in (0, 1)
     res = (DevResult * nh)()
@@ -138,7 +139,8 @@ def run(hists, model_kind, init, L, rules=None, lookahead=True, entries_per_op=8
     rc = lib().emu_narrow_run(C.c_uint32(nh), _p(op_off, C.c_uint64), _p(npr, C.c_uint32), _p(f, C.c_uint8), _p(a, C.c_int32), _p(b, C.c_int32),
                               _p(pr, C.c_int32), _p(inv, C.c_uint32), _p(ret, C.c_uint32), C.c_uint32(model_kind), C.c_int32(init),
                               C.c_uint32(L), C.c_uint32(mw), C.c_uint32(r), C.c_uint32(vpad), C.c_uint32(1 if look else 0),
-                              C.c_uint32(entries_per_op), C.c_uint64(max_steps), C.c_uint64(pool_words), C.c_uint32(1 if want_witness else 0), C.c_uint32(max_waves), C.c_uint32(1 if compact else 0), C.c_uint32(epochs),
+                              C.c_uint32(entries_per_op), C.c_uint64(max_steps), C.c_uint64(pool_words), C.c_uint32(1 if want_witness else 0), C.c_uint32(max_waves), C.c_uint32(1 if compact else 0), C.c_uint32(epochs), C.c_uint32(1 if count else 0), C.c_uint32(1 if relaxed else 0),
+                              _p(np.ascontiguousarray(targets, np.uint32), C.c_uint32) if targets is not None else None,
                               res, _p(wit, C.c_uint32), _p(cfg, C.c_uint64))
     if rc != 0:
         raise RuntimeError(f"emu_narrow_run rc={rc}")

@@ -23,6 +23,11 @@ void wave_entry(void* p, uint32_t lane) {
   auto* c = (WaveCall<MW, L>*)p;
   narrow::narrow_wave<MW, L, CF>(*c->A, c->wave, c->lds, lane);
 }
+template <int MW, int L, bool CF>
+void wave_entry_cnt(void* p, uint32_t lane) {
+  auto* c = (WaveCall<MW, L>*)p;
+  narrow::narrow_wave<MW, L, CF, true>(*c->A, c->wave, c->lds, lane);
+}
 template <int MW, int L>
 void run_all(BeamArgs& A, uint32_t max_waves) {
   const uint32_t H = 64 / L;
@@ -32,10 +37,18 @@ void run_all(BeamArgs& A, uint32_t max_waves) {
   next_work = 0;
   A.first_dynamic = waves * H; A.next_work = &next_work;
   const bool cf = MW == 1 && A.front_words == kFrontCompactWords;
-  std::vector<uint32_t> lds(narrow::narrow_lds_words(MW, L, cf) + 16);
+  const bool cnt = (A.rules & kRuleCount) != 0u;
+  std::vector<uint32_t> lds(narrow::narrow_lds_words(MW, L, cf, cnt) + 16);
   for (uint32_t w = 0; w < waves; w++) {
     std::fill(lds.begin(), lds.end(), 0xDEADBEEFu);          // LDS is not zeroed on the device either
     WaveCall<MW, L> c{&A, w, lds.data()};
+    if constexpr (MW <= 2 && L >= 8) {
+      if (cnt) {                                             // the count form's instantiations (wgl_narrow.hip launch_one)
+        if constexpr (MW == 1) { if (cf) { wv::run_wave(&wave_entry_cnt<MW, L, true>, &c); continue; } }
+        wv::run_wave(&wave_entry_cnt<MW, L, false>, &c);
+        continue;
+      }
+    }
     if constexpr (MW == 1) { if (cf) { wv::run_wave(&wave_entry<MW, L, true>, &c); continue; } }
     wv::run_wave(&wave_entry<MW, L, false>, &c);
   }
@@ -51,19 +64,21 @@ void emu_stats(uint64_t* out, int reset) { for (int i = 0; i < 64; i++) { out[i]
 int emu_narrow_run(uint32_t nh, const uint64_t* op_off, const uint32_t* n_process, const uint8_t* f, const int32_t* a, const int32_t* b,
                    const int32_t* process, const uint32_t* inv_pos, const uint32_t* ret_pos, uint32_t model_kind, int32_t init,
                    uint32_t L, uint32_t MW, uint32_t rules, uint32_t vpad, uint32_t lookahead, uint32_t entries_per_op, uint64_t max_steps,
-                   uint64_t pool_words, uint32_t want_witness, uint32_t max_waves, uint32_t want_compact, uint32_t epochs, DevResult* results, uint32_t* witness, uint64_t* cfg_out) {
+                   uint64_t pool_words, uint32_t want_witness, uint32_t max_waves, uint32_t want_compact, uint32_t epochs, uint32_t count, uint32_t relaxed, const uint32_t* targets,
+                   DevResult* results, uint32_t* witness, uint64_t* cfg_out) {
   Tables T;
   // the compact front records where libtbcheck would take them (tbc_api.hip front_words()): eager rule, one mask word, values <= 4
   uint32_t n_dom = 0;
   if (vpad) { int32_t vmax = init == TBC_NIL ? -1 : init; for (uint64_t i = 0; i < op_off[nh]; i++) { if (a[i] != TBC_NIL && a[i] > vmax) vmax = a[i]; if (f[i] == TBC_F_CAS && b[i] > vmax) vmax = b[i]; } n_dom = (uint32_t)(vmax + 2); }
   const bool compact = want_compact && (rules & kRuleEager) && front_compact_ok(n_dom, MW);
-  if (!build_tables(nh, op_off, n_process, f, a, b, process, inv_pos, ret_pos, MW, vpad, entries_per_op, (rules & kRuleBranch) != 0, compact, T)) return 1;
+  if (!build_tables(nh, op_off, n_process, f, a, b, process, inv_pos, ret_pos, MW, vpad, entries_per_op, (rules & kRuleBranch) != 0, compact, T, count != 0)) return 1;
+  if (count) { rules |= kRuleCount; for (uint32_t h = 0; h < nh && targets; h++) T.bh[h].target = targets[h]; }
   const uint64_t total = op_off[nh];
   uint64_t entries = 0;
   for (uint32_t h = 0; h < nh; h++) entries += 1ull << T.bh[h].tab_log2;
   // words per entry of the arena: keys and parent links -- or, as in libtbcheck, keys only when nobody wants a witness (tbc_api.hip
   // tab_stride()); guard words behind the arena catch a kernel that writes a link all the same
-  const uint32_t EW = want_witness ? MW + 2 : MW + 1;
+  const uint32_t EW = (want_witness ? MW + 2 : MW + 1) + (count ? kCountWords : 0u);
   std::vector<uint64_t> tab(entries * EW + 64, 0), pool(pool_words + 1, 0), cfg((uint64_t)nh * kCfgCap * (2 + MW) + 1, 0);
   std::vector<uint32_t> stack(entries + 1, 0), dstack(entries + 1, 0), work(nh), wit(total + 1, 0);
   unsigned long long cursor = 0;
@@ -75,7 +90,7 @@ int emu_narrow_run(uint32_t nh, const uint64_t* op_off, const uint32_t* n_proces
   A.look = lookahead ? T.look.data() : nullptr; A.slot8 = T.slot8.data(); A.ret_slot = T.ret_slot.data(); A.ret_op = T.ret_op.data();
   A.stack = stack.data(); A.dstack = lookahead ? dstack.data() : nullptr; A.tab = tab.data(); A.results = res.data();
   A.witness = want_witness ? wit.data() : nullptr; A.work = work.data(); A.table = nullptr; A.n_work = nh; A.model_kind = model_kind;
-  A.init_state = init; A.width = 1; A.tab_stride = EW; A.max_steps = max_steps; A.time_limit_ticks = 0; A.dbg = nullptr;
+  A.init_state = init; A.width = 1; A.tab_stride = EW; A.cmem = T.cmem.empty() ? nullptr : T.cmem.data(); A.count_mode = relaxed ? kCountRelaxed : kCountExact; A.max_steps = max_steps; A.time_limit_ticks = 0; A.dbg = nullptr;
   A.pool = pool_words ? pool.data() : nullptr; A.pool_cursor = &cursor; A.pool_words = pool_words; A.max_tab_log2 = 28;
   A.pool_vals = nullptr; A.cfg = cfg.data(); A.rules = rules; A.twn = (rules & kRuleTwin) ? T.twn.data() : nullptr;
   A.rdm = T.rdm.data(); A.vpad = vpad; A.rk8 = T.rk8.data(); A.front_words = compact ? kFrontCompactWords : front_stride(vpad, MW);

@@ -86,3 +86,33 @@ def test_the_crashed_tiers_at_full_size(native, oracle, info, corrupt):
     if not corrupt:
         w = core.check_ops(h, gm(), core.make_opts(time_limit_ms=60000, algorithm=N.ALG_COMPETITION, want_witness=True, count_form=True))
         assert brute.check_witness(CAS, op_tuples(h), [int(x) for x in w["witness"]]) == w["final_state"]
+
+
+@pytest.mark.parametrize("L", [8, 16])
+def test_count_form_several_histories_per_wavefront(native, oracle, L):
+    """The count form in the narrow kernel (lanes_per_history = L): one config per iteration, L pairs per round -- every pass of the
+    library's pipeline against oracle/wgl_count.c at that schedule, the crashed tiers at full size among the histories."""
+    hists = []
+    for n, p, busy, info, corrupt in SHAPES[:6] + [(10000, 64, 0.1, 0.01, 0.0), (10000, 64, 0.1, 0.05, 0.0), (10000, 64, 0.1, 0.01, 0.5)]:
+        for s in range(2):
+            h = columns.pair_events(synth.register_events(n_ops=n, n_procs=p, seed=2000 + s, busy=busy, info=info, corrupt=corrupt))
+            if oracle.check_count(h.as_dict(), CAS, width=1, max_probes=1) is not None:
+                hists.append(h)
+    budget = 32 * max(len(h) for h in hists)
+    with core.Batch(hists, gm(), core.make_opts(time_limit_ms=120000, algorithm=N.ALG_COMPETITION, lanes_per_history=L, count_form=True, want_witness=False)) as b:
+        assert (b.lanes_per_history(), b.search_width()) == (L, 1)
+        res = b.run().results()
+    how = {}
+    for i, (h, g) in enumerate(zip(hists, res)):
+        v, fo, last, tot, hw = oracle.check_count_pipeline(h.as_dict(), CAS, width=1, budget=budget, round_pairs=L)
+        how[hw] = how.get(hw, 0) + 1
+        assert g["valid"] == v, (i, hw)
+        assert (g["probes"], g["visited"], g["backtracks"]) == (tot["probes"], tot["visited"], tot["expanded"]), (i, hw)
+        if v == 0:
+            assert g["fail_op"] == fo, (i, hw)
+    assert how.get("exact", 0) >= 8 and how.get("prefix", 0) >= 3, how
+    # with a witness: the linearization replays legally (crashed calls included)
+    with core.Batch(hists[:6], gm(), core.make_opts(time_limit_ms=120000, algorithm=N.ALG_COMPETITION, lanes_per_history=L, count_form=True)) as b:
+        for h, g in zip(hists[:6], b.run().results()):
+            if g["valid"] == 1:
+                assert brute.check_witness(CAS, op_tuples(h), [int(x) for x in g["witness"]]) == g["final_state"]

@@ -201,3 +201,98 @@ def test_epoch_tags_instead_of_zeroed_visited_sets():
     compare(grow, CAS, 8, tag="epochs-grow", entries_per_op=1, pool_words=8_000_000, epochs=3)
     wide = [columns.pair_events(synth.register_events(n_ops=600, n_procs=12, seed=s, busy=0.15, info=0.08)) for s in range(2)]
     compare(wide, CAS, 8, tag="epochs-two-words", pool_words=4_000_000, epochs=2, max_steps=30000)
+
+
+def compare_count(hists, L, tag="", relaxed=False, targets=None, **kw):
+    """K5n in the COUNT FORM (crashed calls as counts per effect class) against oracle/wgl_count.c at one config per iteration and L pairs per round."""
+    ds = [h.as_dict() for h in hists]
+    got = emu.run(ds, 1, N.NIL, L, count=True, relaxed=relaxed, targets=targets, mw=kw.pop("mw", 1), **kw)
+    n_cls = 0
+    for i, (d, g) in enumerate(zip(ds, got)):
+        e = wgl.check_count(d, CAS, width=1, round_pairs=L, lookahead=kw.get("lookahead", True), relaxed=relaxed,
+                            target=int(targets[i]) if targets is not None else 0, max_probes=kw.get("max_steps", 0))
+        assert e is not None
+        t = (tag, i, L)
+        assert g["valid"] == e["valid"], (t, g["valid"], e["valid"], g["cause"])
+        for a_, b_ in (("probes", "probes"), ("visited", "visited"), ("backtracks", "expanded"), ("max_depth", "max_stack"), ("bucket_reads", "rounds")):
+            assert g[a_] == e[b_], (t, a_, g[a_], e[b_])
+        if e["valid"] == 0:
+            assert (g["fail_op"], g["prev_ok_op"]) == (e["fail_op"], e["prev_ok_op"]), t
+        if e["valid"] == 1 and len(d["f"]) and g["chain"] is not None and not relaxed and targets is None:
+            assert g["final_state"] == e["final_state"], t
+            # the chain of branching calls (crashed calls among them) replayed with the eager rule = the oracle's witness
+            assert expand_chain_count(d, g["chain"]) == [int(x) for x in e["witness"]], t
+        n_cls += e["class_steps"]
+    return got, n_cls
+
+
+def expand_chain_count(d, chain):
+    """as expand_chain, for a chain that may hold crashed calls (they set the state and hold no slot); lists in SLOT order (the count form's
+    re-used slots, from the oracle)"""
+    slots = wgl.check_count(d, CAS, width=1, want_slots=True)["slots"]
+    f, a, b = (np.asarray(d[k]) for k in ("f", "a", "b"))
+    inv, ret = np.asarray(d["inv_pos"], np.int64), np.asarray(d["ret_pos"], np.int64)
+    n = len(f)
+    live = [i for i in range(n) if ret[i] != 0xFFFFFFFF]
+    by_ret = sorted(live, key=lambda i: ret[i])
+    R = len(by_ret)
+    rets = np.sort(ret[live])
+    inv_rank = np.searchsorted(rets, inv, side="left").tolist()
+    ret_rank = {i: r for r, i in enumerate(by_ret)}
+    done, out = set(), []
+    front, state = 0, N.NIL
+
+    def advance():
+        nonlocal front
+        moved = False
+        while front < R and by_ret[front] in done:
+            front += 1
+            moved = True
+        return moved
+
+    for op in chain:
+        op = int(op)
+        state = int(a[op]) if f[op] == 1 else (int(b[op]) if f[op] == 2 else state)
+        done.add(op); out.append(op)
+        advance()
+        again = True
+        while again and front < R:
+            opens = sorted((i for i in live if i not in done and inv_rank[i] <= front <= ret_rank[i]), key=lambda i: slots[i])
+            for x in opens:
+                if f[x] == 0 and (a[x] == N.NIL or a[x] == state):
+                    done.add(x); out.append(x)
+            again = advance()
+    return out
+
+
+COUNT_SHAPES = [(40, 4, 0.3, 0.0, 0.5), (40, 4, 0.3, 0.5, 0.5), (300, 8, 0.05, 0.0, 0.3), (300, 8, 0.05, 0.5, 0.3), (1000, 16, 0.03, 0.0, 0.3),
+                (1000, 16, 0.03, 0.6, 0.3), (600, 4, 0.2, 0.0, 0.8), (2000, 64, 0.02, 0.0, 0.1)]
+
+
+@pytest.mark.parametrize("L", [8, 16, 32])
+def test_count_form_several_histories_per_wavefront(L):
+    """crashed calls as counts per effect class in the narrow kernel: classes as candidates, hot configs, the Pareto chain walk in the
+    probe, re-used slots -- every shape x 2 seeds in one launch; a step limit that stops the invalid histories' exhaustion where the
+    oracle's stops"""
+    hists = [columns.pair_events(synth.register_events(n_ops=n, n_procs=p, seed=40 + s, busy=busy, info=info, corrupt=corrupt))
+             for (n, p, info, corrupt, busy) in COUNT_SHAPES for s in range(2)]
+    hists = [h for h in hists if wgl.check_count(h.as_dict(), CAS, width=1, max_probes=1) is not None]
+    got, n_cls = compare_count(hists, L, tag="count", pool_words=8_000_000, max_steps=40000)
+    assert n_cls > 500 and sum(g["valid"] == 1 for g in got) >= 6
+
+
+def test_count_form_relaxed_prefix_growth_and_epochs():
+    hists = [columns.pair_events(synth.register_events(n_ops=400, n_procs=8, seed=60 + s, busy=0.3, info=0.06, corrupt=0.6)) for s in range(6)]
+    rel, _ = compare_count(hists, 8, tag="relaxed", relaxed=True, pool_words=4_000_000)
+    assert all(g["valid"] == 0 for g in rel)
+    # the prefix of each history before the completion the relaxed search could not pass: a linearization of it ends the search VALID
+    targets = np.array([g["max_front"] for g in rel], np.uint32)
+    assert (targets > 0).all()
+    pre, _ = compare_count(hists, 8, tag="prefix", targets=targets, pool_words=4_000_000, want_witness=False)
+    assert all(g["valid"] == 1 for g in pre)
+    # small first tables: growth with the count words carried along; several passes over one arena under epoch tags; two mask words
+    valid = [columns.pair_events(synth.register_events(n_ops=1500, n_procs=16, seed=70 + s, busy=0.25, info=0.03)) for s in range(4)]
+    compare_count(valid, 8, tag="grow", entries_per_op=1, pool_words=8_000_000)
+    compare_count(valid[:2], 16, tag="epochs", pool_words=4_000_000, epochs=3, want_witness=False)
+    wide = [columns.pair_events(synth.register_events(n_ops=500, n_procs=70, seed=80 + s, busy=0.5, info=0.05)) for s in range(2)]
+    compare_count(wide, 8, tag="two-words", pool_words=4_000_000, mw=2, max_steps=30000)
