@@ -101,6 +101,8 @@ int main(void){ printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu  %zu %zu %zu %zu
     assert offs == [56, 0, 4, 8, 12, 16, 24, 32, 40, 48, 48, 0, 8, 16, 24, 32, 40, 64, 56, 52]
     assert C.sizeof(native.SetFullIn) == 56 and C.sizeof(native.SetFullOut) == 48 and C.sizeof(native.Opts) == 64
     assert native.Opts.lanes_per_history.offset == 56
+    # tbc_setfull_rows (compact reads, ABI version 2): 72 bytes, pointers from offset 16
+    assert C.sizeof(native.SetFullRows) == 72 and native.SetFullRows.top.offset == 48 and native.SetFullRows.exc.offset == 64
 
 
 @pytest.mark.skipif(has_gpu(), reason="only meaningful on a box without a GPU")
