@@ -25,7 +25,11 @@ FS = {N.F_READ: "read", N.F_WRITE: "write", N.F_CAS: "cas"}
 SYNTH = [dict(n_ops=40, n_procs=4, seed=0, busy=0.5, info=0.05, corrupt=0.0), dict(n_ops=40, n_procs=4, seed=1, busy=0.5, info=0.0, corrupt=0.5),
          dict(n_ops=300, n_procs=8, seed=0, busy=0.4, info=0.02, corrupt=0.0), dict(n_ops=300, n_procs=8, seed=2, busy=0.3, info=0.0, corrupt=0.6),
          dict(n_ops=1000, n_procs=16, seed=0, busy=0.3, info=0.01, corrupt=0.0), dict(n_ops=1000, n_procs=16, seed=1, busy=0.2, info=0.0, corrupt=0.6),
-         dict(n_ops=2000, n_procs=64, seed=0, busy=0.1, info=0.0, corrupt=0.0), dict(n_ops=2000, n_procs=64, seed=3, busy=0.3, info=0.0, corrupt=0.0)]
+         dict(n_ops=2000, n_procs=64, seed=0, busy=0.1, info=0.0, corrupt=0.0), dict(n_ops=2000, n_procs=64, seed=3, busy=0.3, info=0.0, corrupt=0.0),
+         # crash-heavy (14 - 29 crashed calls: the library's count form; small enough for stock Knossos to finish the invalid ones)
+         dict(n_ops=200, n_procs=6, seed=11, busy=0.4, info=0.06, corrupt=0.0), dict(n_ops=200, n_procs=6, seed=12, busy=0.4, info=0.06, corrupt=0.6),
+         dict(n_ops=500, n_procs=8, seed=13, busy=0.3, info=0.03, corrupt=0.0), dict(n_ops=500, n_procs=8, seed=14, busy=0.3, info=0.03, corrupt=0.5),
+         dict(n_ops=300, n_procs=4, seed=15, busy=0.6, info=0.08, corrupt=0.0), dict(n_ops=300, n_procs=4, seed=16, busy=0.6, info=0.08, corrupt=0.4)]
 
 
 def event_maps(ev):

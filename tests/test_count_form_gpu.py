@@ -116,3 +116,24 @@ def test_count_form_several_histories_per_wavefront(native, oracle, L):
         for h, g in zip(hists[:6], b.run().results()):
             if g["valid"] == 1:
                 assert brute.check_witness(CAS, op_tuples(h), [int(x) for x in g["witness"]]) == g["final_state"]
+
+
+def test_crash_heavy_edn_goldens_in_the_count_form(native, monkeypatch):
+    """tests/golden/edn/synth_*_i0.0[368]*.edn (14 - 29 crashed calls each; what scripts/knossos_crosscheck.clj feeds to stock Knossos) through
+    the EDN reader and jepsen.checker/linearizable with the library's defaults -- the count form -- against the committed expectations."""
+    import json
+    import os
+    from helpers import GOLDEN, MODELS
+    from jepsen_tigerbeetle_amd.jepsen import checker as jc, edn
+    monkeypatch.setattr(core, "DEFAULT_COUNT_FORM", True)
+    cases = [c for c in json.load(open(os.path.join(GOLDEN, "edn", "expected.json")))["cases"] if "_i0.0" in c["file"] and "_i0.0_" not in c["file"]]
+    assert len(cases) >= 8
+    n_invalid = 0
+    for c in cases:
+        h = edn.read_history(os.path.join(GOLDEN, "edn", c["file"]))
+        a = jc.linearizable({"model": MODELS[c["model"]](), "algorithm": None}).check(None, h, None)
+        assert a["valid?"] is c["valid?"], c["file"]
+        if c["valid?"] is False:
+            assert a["op"]["index"] == c["op-index"], c["file"]
+            n_invalid += 1
+    assert n_invalid >= 3

@@ -15,7 +15,7 @@ CASES = json.load(open(os.path.join(EDN_DIR, "expected.json")))["cases"]
 
 
 def test_edn_goldens_are_committed_and_well_formed():
-    assert len(CASES) >= 28
+    assert len(CASES) >= 34
     for c in CASES:
         h = edn.read_history(os.path.join(EDN_DIR, c["file"]))
         assert all(op["index"] == i for i, op in enumerate(h)), c["file"]
