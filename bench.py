@@ -27,8 +27,15 @@
              sample of the same histories: on all host cores (pthread pool, oracle/many.c) = `value`,
              and on one thread (`single_thread`)
   extra    : time-to-verdict of ONE history through tbc_check (the level sweep, jit_sweep.hip), the
-             crashed-op tiers of BASELINE.md section 3, a second workload at 50 % duty ("64 concurrent
-             processes", ~32 calls in flight) with its own value / roofline, the H2D-inclusive rate
+             crashed-op tiers of BASELINE.md section 3 (the count form: crashed calls as counts per effect class;
+             beside each the plain CPU search AND the count form's own passes on one CPU core), a second workload at
+             50 % duty ("64 concurrent processes", ~32 calls in flight) and a third at 30 % with their own value /
+             roofline, a batch of the headline workload with 1 % crashed calls, the H2D-inclusive rate
+             (tbc_batch_create alone; the Python binding's concatenation of the columns is marshal_s), checker/set-full
+             (scan roofline; end to end from compact reads, the matrix built on the device)
+  checks   : every resident batch carries ONE history with a planted impossible read (2 % in, a value inside the
+             batch's domain): verdicts are compared element-wise -- that one INVALID, every other one VALID, the CPU
+             sample history by history, the planted one's failing op against the oracle's
 
 Usage: python bench.py --gpus N --steps K --warmup W   (N>1 via torch.distributed.run)
 """
