@@ -32,7 +32,9 @@
              50 % duty ("64 concurrent processes", ~32 calls in flight) and a third at 30 % with their own value /
              roofline, a batch of the headline workload with 1 % crashed calls, the H2D-inclusive rate
              (tbc_batch_create alone; the Python binding's concatenation of the columns is marshal_s), checker/set-full
-             (scan roofline; end to end from compact reads, the matrix built on the device)
+             (scan roofline; end to end from compact reads, the matrix built on the device).  The tiers, the three other
+             workloads and set-full each run in a process of their own (run_leg): a GPU fault in one of them costs that leg,
+             not the line
   checks   : every resident batch carries ONE history with a planted impossible read (2 % in, a value inside the
              batch's domain): verdicts are compared element-wise -- that one INVALID, every other one VALID, the CPU
              sample history by history, the planted one's failing op against the oracle's
@@ -101,6 +103,220 @@ def leg(name):
     print(f"[bench {time.strftime('%H:%M:%S')}] {name}", file=sys.stderr, flush=True)
 
 
+def _gpu_imports():
+    import numpy as np
+    import jepsen_tigerbeetle_amd  # noqa: F401
+    from jepsen_tigerbeetle_amd import _native as N, columns, core, synth
+    return np, N, columns, core, synth
+
+
+def leg_tiers(args, local_rank):
+    """extra.tiers (its own process, see run_leg)."""
+    np, N, columns, core, synth = _gpu_imports()
+    from oracle import wgl
+    model = core.make_model(N.MODEL_CAS_REGISTER, N.NIL)
+    om = {"kind": 1, "init": N.NIL}
+
+    # BASELINE.md section 3: crashed-op tiers x {as generated, one bad read}; one history each, GPU limit 3 s,
+    # CPU limit 2*10^7 steps.  With crashed calls the library takes the COUNT FORM (crashed calls as counts per effect
+    # class, one mask word; a history the budgeted exact search leaves open is refuted relaxed, then its prefix is
+    # linearized): cpu_port_ms is the plain knossos.wgl restatement, cpu_same_algorithm_ms the count form's passes on one core.
+    tiers = []
+    o_tier = core.make_opts(device=local_rank, want_witness=False, algorithm=N.ALG_COMPETITION, time_limit_ms=3000)
+    for seed in (1, 2):      # (this process's first calls: HIP context, code objects, the persistent context's arenas -- not a tier's time)
+        core.check_ops(columns.pair_events(synth.register_events(n_ops=args.ops, n_procs=args.procs, seed=seed, busy=args.busy, info=0.01 * (seed - 1))), model, o_tier)
+    for info in (0.0, 0.01, 0.05):
+        for corrupt in (0.0, 0.5):
+            leg(f"tier info {info} corrupt {corrupt}")
+            hh = columns.pair_events(synth.register_events(n_ops=args.ops, n_procs=args.procs, seed=4242, busy=args.busy, info=info, corrupt=corrupt))
+            t1 = time.perf_counter()
+            rg = core.check_ops(hh, model, o_tier)
+            tg = (time.perf_counter() - t1) * 1e3
+            t1 = time.perf_counter()
+            rc = wgl.check(hh.as_dict(), om, "window", want_witness=False, max_steps=20_000_000)
+            tcpu = (time.perf_counter() - t1) * 1e3
+            # the count form's own passes on one CPU core (oracle/wgl_count.c): the algorithm is the CPU's too
+            t1 = time.perf_counter()
+            rp = wgl.check_count_pipeline(hh.as_dict(), om, width=max(rg["search_width"], 1)) if info else None
+            tpipe = (time.perf_counter() - t1) * 1e3
+            if rp is not None:
+                assert rg["valid"] == rp[0] and (rp[0] == 1 or rg["fail_op"] == rp[1]), (info, corrupt, "count form")
+            if rg["valid"] != -1 and rc["valid"] != -1:
+                assert rg["valid"] == rc["valid"] and (rg["valid"] == 1 or rg["fail_op"] == rc["fail_op"]), (info, corrupt)
+            tiers.append({"info_rate": info, "history": "1 bad read" if corrupt else "as generated", "process_slots": int(hh.n_process),
+                          "gpu_ms": round(tg, 3), "gpu_verdict": rg["valid"], "gpu_analyzer": "linear" if rg["analyzer"] == N.ALG_LINEAR else "wgl",
+                          "cpu_port_ms": round(tcpu, 3), "cpu_verdict": rc["valid"],
+                          "cpu_same_algorithm_ms": None if rp is None else round(tpipe, 3), "cpu_same_algorithm_passes": None if rp is None else rp[4]})
+    return tiers
+
+
+
+def leg_workload(args, local_rank, which):
+    """extra.workload_2 / workload_3 / workload_crashed (each in its own process, see run_leg)."""
+    np, N, columns, core, synth = _gpu_imports()
+    model = core.make_model(N.MODEL_CAS_REGISTER, N.NIL)
+
+    # second workload: BASELINE.json's "64 concurrent processes" read literally is infeasible for every known
+    # algorithm (DESIGN.md section 6); busy 0.5 (~32 calls in flight) is the closest reading the dominance rules make
+    # checkable, busy 0.3 (~19 in flight) a point in between.  Each with its own value and roofline and the CPU restatement
+    # of the kernel's schedule on a sample beside it (thread pool, the CPUs this container may use); never mixed into `value`.
+    # A history at 32 in flight can need > 10^6 configs (the tail is heavy): 2^21-entry visited sets with their stacks = 67 MB
+    # each, 2,048 of them (137 GB) a batch -- a quarter of the GPU's wavefront slots; smaller first sets cost retries that take
+    # longer than the whole step (measured: 4,096 histories at 2^20 entries, 134 s of retries).
+    def second(busy, B2, vpo, seed0, cpu_n, cpu_cap, warm, info=0.0):
+        h2 = synth.register_ops_many(range(seed0, seed0 + B2), n_ops=args.ops, n_procs=args.procs, busy=busy, info=info)
+        o2 = core.make_opts(device=local_rank, time_limit_ms=600000, want_witness=False, algorithm=N.ALG_COMPETITION,
+                            search_width=args.width, visited_per_op=vpo)
+        with core.Batch(h2, model, o2) as b2:
+            width2, lanes2 = b2.search_width(), b2.lanes_per_history()
+            if warm:
+                b2.run()
+            t2 = time.perf_counter(); b2.run(); t2 = time.perf_counter() - t2
+            c2 = b2.counters(); tm2 = b2.timing_ns(); v2 = b2.verdicts()
+        alg2 = 16 * (c2["probes"] - c2["visited"]) + 32 * c2["visited"]
+        k2 = (tm2["search"] + tm2["retries"]) / 1e6
+        out = {"workload": workload_name(args.ops, args.procs, busy, info), "histories_per_gpu": B2, "search_width": width2, "lanes_per_history": lanes2,
+               "value": round(B2 / t2, 2), "unit": "histories/s", "ms_per_step": round(t2 * 1e3, 3),
+               "valid": int((v2 == N.VALID).sum()), "unknown": int((v2 == N.UNKNOWN).sum()),
+               "roofline": {"bound": "hbm", "achieved": round(alg2 / (k2 * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": round(alg2 / (k2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 6), "traffic": None,
+                            "kernel": "wgl_narrow_kernel" if lanes2 != 64 else "wgl_beam_kernel",
+                            "kernel_ms": round(k2, 3), "probes_per_launch": c2["probes"], "new_configs_per_launch": c2["visited"]},
+               "device_ms": {k: round(x / 1e6, 3) for k, x in tm2.items()}}
+        if not args.no_cpu and info:
+            # crashed calls: the library's count form; the CPU runs the same passes (oracle/wgl_count.c) on a thread pool
+            from concurrent.futures import ThreadPoolExecutor
+            from oracle import wgl
+            cores, _, _ = usable_cores()
+            dd = [h2[i].as_dict() for i in range(min(cpu_n, B2))]
+            budget = 32 * max(len(h) for h in h2)
+            tcp = time.perf_counter()
+            with ThreadPoolExecutor(cores) as ex:
+                rr = list(ex.map(lambda d: wgl.check_count_pipeline(d, {"kind": 1, "init": N.NIL}, width=width2, budget=budget), dd))
+            tcp = time.perf_counter() - tcp
+            assert all(r is not None and r[0] == int(v2[i]) for i, r in enumerate(rr)), "GPU and oracle disagree on the crashed workload's sample"
+            out["cpu_baseline"] = {"value": round(len(dd) / tcp, 3), "unit": "histories/s", "cores": cores, "kind": "port",
+                                   "sample": f"first {len(dd)} histories, oracle/wgl_count.c (the count form's own passes, {width2} configs per round) from {cores} Python threads "
+                                             f"(ctypes releases the GIL)"}
+        elif not args.no_cpu:
+            from oracle import wgl
+            cores, _, _ = usable_cores()
+            dd = [h2[i].as_dict() for i in range(min(cpu_n, B2))]
+            tcp = time.perf_counter()
+            vv, started = wgl.check_many(dd, {"kind": 1, "init": N.NIL}, cores, max_steps=cpu_cap, beam_width=width2 if width2 > 1 else 4)
+            tcp = time.perf_counter() - tcp
+            done = int((vv != -1).sum())
+            assert all(int(vv[i]) in (-1, int(v2[i])) for i in range(len(dd))), "GPU and oracle disagree on the second workload's sample"
+            out["cpu_baseline"] = {"value": round(done / tcp, 3), "unit": "histories/s", "cores": cores, "kind": "port",
+                                   "sample": f"first {len(dd)} histories, oracle/wgl_beam.c (the kernel's schedule, {width2} configs per round, lookahead + eager reads + "
+                                             f"twin rule) on {started} pthreads, at most {cpu_cap:.0e} probes each: {done} finished (the others are not counted)"}
+        return out
+    if which == "workload_2":
+        return second(args.busy2, args.batch2, 256, 10_000_000, 64, 60_000_000, False)      # (a step is ~25 s: one run, no warm-up)
+    if which == "workload_3":
+        return second(args.busy3, args.batch3, 32, 20_000_000, 128, 60_000_000, True)
+    # the regime the reference produces (a nemesis makes clients time out: :info): the headline workload with 1 % of the
+    # calls crashed, a batch of them -- the count form, a wavefront per history
+    assert which == "workload_crashed"
+    return second(args.busy, args.batch4, 8, 30_000_000, 256, 0, True, info=args.info4)
+
+
+def leg_set_full(args, local_rank):
+    """extra.set_full (its own process, see run_leg)."""
+    np, N, columns, core, synth = _gpu_imports()
+
+    # checker/set-full (the checker the reference runs: set_full.clj:157): the reads x elements membership scan,
+    # the one streaming kernel of the path.  Synthetic: 262,144 elements x 32,768 reads (1 GB of bits), an element
+    # is visible from about its acknowledgement on, 300 elements vanish in the last quarter (lost), sparse holes
+    # right after the add (stale reads).  roofline = matrix bytes the scan loaded / its time, against 8 TB/s.
+    from jepsen_tigerbeetle_amd.jepsen import set_full as sf
+    rng = np.random.default_rng(7)
+    E, R = 262144, 32768
+    add_invoke = (np.sort(rng.choice(4 * (E + R), E, replace=False)) * 2).astype(np.uint32)
+    read_invoke = (np.sort(rng.choice(4 * (E + R), R, replace=False)) * 2 + 1).astype(np.uint32)
+    read_ok = read_invoke + (rng.integers(1, 2000, R) * 2).astype(np.uint32)
+    add_ok = (add_invoke + 2001).astype(np.uint32)
+    p = np.searchsorted(add_ok, read_invoke).astype(np.int64)            # row r sees the elements acknowledged before it began
+    w = np.arange(E // 32, dtype=np.int64)
+    M = np.where(32 * (w + 1)[None, :] <= p[:, None], 0xFFFFFFFF,
+                 np.where(32 * w[None, :] >= p[:, None], 0, (1 << np.clip(p[:, None] - 32 * w[None, :], 0, 31)) - 1)).astype(np.uint32)
+    lost_e = rng.choice(E // 2, 300, replace=False)
+    for e in lost_e:
+        M[R * 3 // 4:, e // 32] &= np.uint32(~(1 << (e % 32)) & 0xFFFFFFFF)
+    holes_r = rng.integers(0, R, 200000); holes_e = np.clip(p[holes_r] - rng.integers(1, 2000, 200000), 0, E - 1)
+    np.bitwise_and.at(M, (holes_r, holes_e // 32), (~(np.uint32(1) << (holes_e % 32).astype(np.uint32))).astype(np.uint32))
+    # the same reads in COMPACT form (tbc_setfull_rows): a prefix of the elements and the holes in it -- what a caller that holds
+    # the reads as sorted id lists hands over; the matrix is then built on the device and nothing of its size crosses PCIe
+    late = np.arange(R * 3 // 4, R)
+    pr = np.concatenate([np.repeat(late, len(lost_e)), holes_r])
+    pe = np.concatenate([np.tile(lost_e, len(late)), holes_e])
+    keep = pe < p[pr]                                                   # (an element at or above the prefix is absent anyway)
+    pairs = np.unique(pr[keep].astype(np.int64) * E + pe[keep].astype(np.int64))
+    exc_rows, exc = pairs // E, (pairs % E).astype(np.uint32)
+    exc_off = np.zeros(R + 1, np.uint64)
+    exc_off[1:] = np.cumsum(np.bincount(exc_rows, minlength=R))
+
+    class A:
+        pass
+    a = A(); a.E, a.R, a.wpr = E, R, E // 32
+    a.add_invoke, a.add_ok, a.read_invoke, a.read_ok, a.present = add_invoke, add_ok, read_invoke, read_ok, np.ascontiguousarray(M)
+    with sf.Scan(a, device=local_rank, rows=False) as sc:
+        sc.run()
+        runs = [sc.run() for _ in range(5)]
+    a.top, a.exc_off, a.exc = p.astype(np.uint32), exc_off, exc
+    t_e2e = []
+    for _ in range(3):                   # end to end: compact reads on the host -> matrix built on the device -> scan -> three indices per element back
+        t1 = time.perf_counter()
+        with sf.Scan(a, device=local_rank, rows=True) as sc2:
+            r2 = sc2.run()
+        t_e2e.append((time.perf_counter() - t1) * 1e3)
+    for k in ("known", "last_present", "last_absent"):
+        assert np.array_equal(r2[k], runs[0][k]), f"set-full: the matrix built on the device gives another {k}" 
+    ms = statistics.mean(r["ns_scan"] for r in runs) / 1e6
+    lost = int(((runs[0]["last_present"].astype(np.int64) < runs[0]["last_absent"].astype(np.int64)) & (runs[0]["last_absent"] != N.NO_OP)).sum())
+    gbs = runs[0]["bytes_scanned"] / (ms * 1e-3) / 1e9
+    return {"elements": E, "reads": R, "matrix_GB": round(runs[0]["bytes_matrix"] / 1e9, 3),
+            "scan_ms": round(ms, 3), "bytes_scanned": int(runs[0]["bytes_scanned"]), "lost_elements_found": lost,
+            "end_to_end_ms": round(min(t_e2e), 3), "compact_input_MB": round((exc.nbytes + exc_off.nbytes + 4 * R) / 1e6, 2),
+            "end_to_end_note": "tbc_setfull_create_rows + tbc_setfull_run + destroy: allocation, H2D of the compact reads, the matrix built on the device, the scan, "
+                               "three indices per element back (best of 3); the dense form moves the 1 GB matrix over PCIe instead",
+            "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "setfull_any_kernel + setfull_resolve_kernel"}}
+
+
+LEGS = {"tiers": leg_tiers, "set_full": leg_set_full,
+        "workload_2": lambda a, d: leg_workload(a, d, "workload_2"), "workload_3": lambda a, d: leg_workload(a, d, "workload_3"),
+        "workload_crashed": lambda a, d: leg_workload(a, d, "workload_crashed")}
+
+
+def run_leg(name, args, local_rank):
+    """One of the extra legs in a process of its own (python bench.py <the same arguments> --leg NAME prints {"leg": ..., "result": ...}):
+    none of them feeds `value`, and a leg whose process is killed -- a GPU fault aborts the process it happens in; round 4 saw one
+    in five runs of this file, never reproduced -- must not take the measured line with it; the line then says so
+    (extra.<leg>.error).  A leg that fails an assertion fails the whole run, as before.  TBC_BENCH_INLINE_LEGS=1 runs them in this process instead."""
+    leg(name.replace("_", " "))
+    if os.environ.get("TBC_BENCH_INLINE_LEGS") == "1":
+        return LEGS[name](args, local_rank)
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + ["--leg", name]
+    try:
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, timeout=1500, env=dict(os.environ, LOCAL_RANK=str(local_rank)))   # (stderr: inherited, the leg markers)
+    except subprocess.TimeoutExpired:
+        return {"error": "the leg's process did not finish within 1500 s"}
+    for ln in reversed(r.stdout.decode(errors="replace").splitlines()):
+        if ln.startswith("{"):
+            try:
+                d = json.loads(ln)
+            except ValueError:
+                continue
+            if d.get("leg") == name and r.returncode == 0:
+                return d["result"]
+    if r.returncode > 0:      # a Python exception in the leg (an assertion: GPU and oracle disagree): as loud as it was in this process
+        raise SystemExit(f"bench.py --leg {name} failed with return code {r.returncode} (its traceback is on stderr)")
+    return {"error": f"the leg's process was killed by signal {-r.returncode} (a GPU fault aborts the process it happens in); no result"}
+
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -143,7 +359,16 @@ def main():
     ap.add_argument("--sharded-ttv", action="store_true",
                     help="N > 1 only: also time ONE history swept by all N GPUs (shard.check_sharded: wavefronts dealt to the ranks, "
                          "one RCCL all-gather of the relation tables); off by default -- it adds a collective to the run")
+    ap.add_argument("--leg", default=None, help="(internal) run this one extra leg and print its result: see run_leg")
     args = ap.parse_args()
+    if args.leg is not None:
+        import torch
+        lr = int(os.environ.get("LOCAL_RANK", "0"))
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: libtbcheck has no CPU fallback")
+        torch.cuda.set_device(lr)
+        print(json.dumps({"leg": args.leg, "result": LEGS[args.leg](args, lr)}), flush=True)
+        return
     if args.only_headline:
         args.no_cpu = args.no_tiers = args.no_set_full = True
         args.busy2 = args.busy3 = args.info4 = 0.0
@@ -456,160 +681,17 @@ def main():
             line["extra"]["time_to_verdict_ms"]["vs_cpu_port_single_thread"] = round((tc / S1 * 1e3) / statistics.median(ttv), 2)
 
             if not args.no_tiers:
-                # crashed-op tiers x {as generated, one bad read}; one history each, GPU limit 3 s,
-                # CPU limit 2*10^7 steps.  With crashed calls the library takes the COUNT FORM (crashed calls as counts per effect
-                # class, one mask word; a history the budgeted exact search leaves open is refuted relaxed, then its prefix is
-                # linearized): cpu_port_ms is the plain knossos.wgl restatement, cpu_same_algorithm_ms the count form's passes on one core.
-                tiers = []
-                for info in (0.0, 0.01, 0.05):
-                    for corrupt in (0.0, 0.5):
-                        leg(f"tier info {info} corrupt {corrupt}")
-                        hh = columns.pair_events(synth.register_events(n_ops=args.ops, n_procs=args.procs, seed=4242, busy=args.busy, info=info, corrupt=corrupt))
-                        t1 = time.perf_counter()
-                        rg = core.check_ops(hh, model, core.make_opts(device=local_rank, want_witness=False, algorithm=N.ALG_COMPETITION, time_limit_ms=3000))
-                        tg = (time.perf_counter() - t1) * 1e3
-                        t1 = time.perf_counter()
-                        rc = wgl.check(hh.as_dict(), om, "window", want_witness=False, max_steps=20_000_000)
-                        tcpu = (time.perf_counter() - t1) * 1e3
-                        # the count form's own passes on one CPU core (oracle/wgl_count.c): the algorithm is the CPU's too
-                        t1 = time.perf_counter()
-                        rp = wgl.check_count_pipeline(hh.as_dict(), om, width=max(rg["search_width"], 1)) if info else None
-                        tpipe = (time.perf_counter() - t1) * 1e3
-                        if rp is not None:
-                            assert rg["valid"] == rp[0] and (rp[0] == 1 or rg["fail_op"] == rp[1]), (info, corrupt, "count form")
-                        if rg["valid"] != -1 and rc["valid"] != -1:
-                            assert rg["valid"] == rc["valid"] and (rg["valid"] == 1 or rg["fail_op"] == rc["fail_op"]), (info, corrupt)
-                        tiers.append({"info_rate": info, "history": "1 bad read" if corrupt else "as generated", "process_slots": int(hh.n_process),
-                                      "gpu_ms": round(tg, 3), "gpu_verdict": rg["valid"], "gpu_analyzer": "linear" if rg["analyzer"] == N.ALG_LINEAR else "wgl",
-                                      "cpu_port_ms": round(tcpu, 3), "cpu_verdict": rc["valid"],
-                                      "cpu_same_algorithm_ms": None if rp is None else round(tpipe, 3), "cpu_same_algorithm_passes": None if rp is None else rp[4]})
-                line["extra"]["tiers"] = tiers
+                line["extra"]["tiers"] = run_leg("tiers", args, local_rank)
 
+        # the legs below run in processes of their own (run_leg): their inputs are their own, none feeds `value`
         if world == 1 and args.busy2 > 0:
-            # second workload: BASELINE.json's "64 concurrent processes" read literally is infeasible for every known
-            # algorithm; busy 0.5 (~32 calls in flight) is the closest reading the dominance rules make
-            # checkable, busy 0.3 (~19 in flight) a point in between.  Each with its own value and roofline and the CPU restatement
-            # of the kernel's schedule on a sample beside it (thread pool, the CPUs this container may use); never mixed into `value`.
-            # A history at 32 in flight can need > 10^6 configs (the tail is heavy): 2^21-entry visited sets with their stacks = 67 MB
-            # each, 2,048 of them (137 GB) a batch -- a quarter of the GPU's wavefront slots; smaller first sets cost retries that take
-            # longer than the whole step (measured: 4,096 histories at 2^20 entries, 134 s of retries).
-            def second(busy, B2, vpo, seed0, cpu_n, cpu_cap, warm, info=0.0):
-                h2 = synth.register_ops_many(range(seed0, seed0 + B2), n_ops=args.ops, n_procs=args.procs, busy=busy, info=info)
-                o2 = core.make_opts(device=local_rank, time_limit_ms=600000, want_witness=False, algorithm=N.ALG_COMPETITION,
-                                    search_width=args.width, visited_per_op=vpo)
-                with core.Batch(h2, model, o2) as b2:
-                    width2, lanes2 = b2.search_width(), b2.lanes_per_history()
-                    if warm:
-                        b2.run()
-                    t2 = time.perf_counter(); b2.run(); t2 = time.perf_counter() - t2
-                    c2 = b2.counters(); tm2 = b2.timing_ns(); v2 = b2.verdicts()
-                alg2 = 16 * (c2["probes"] - c2["visited"]) + 32 * c2["visited"]
-                k2 = (tm2["search"] + tm2["retries"]) / 1e6
-                out = {"workload": workload_name(args.ops, args.procs, busy, info), "histories_per_gpu": B2, "search_width": width2, "lanes_per_history": lanes2,
-                       "value": round(B2 / t2, 2), "unit": "histories/s", "ms_per_step": round(t2 * 1e3, 3),
-                       "valid": int((v2 == N.VALID).sum()), "unknown": int((v2 == N.UNKNOWN).sum()),
-                       "roofline": {"bound": "hbm", "achieved": round(alg2 / (k2 * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                    "frac": round(alg2 / (k2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 6), "traffic": None,
-                                    "kernel": "wgl_narrow_kernel" if lanes2 != 64 else "wgl_beam_kernel",
-                                    "kernel_ms": round(k2, 3), "probes_per_launch": c2["probes"], "new_configs_per_launch": c2["visited"]},
-                       "device_ms": {k: round(x / 1e6, 3) for k, x in tm2.items()}}
-                if not args.no_cpu and info:
-                    # crashed calls: the library's count form; the CPU runs the same passes (oracle/wgl_count.c) on a thread pool
-                    from concurrent.futures import ThreadPoolExecutor
-                    from oracle import wgl
-                    cores, _, _ = usable_cores()
-                    dd = [h2[i].as_dict() for i in range(min(cpu_n, B2))]
-                    budget = 32 * max(len(h) for h in h2)
-                    tcp = time.perf_counter()
-                    with ThreadPoolExecutor(cores) as ex:
-                        rr = list(ex.map(lambda d: wgl.check_count_pipeline(d, {"kind": 1, "init": N.NIL}, width=width2, budget=budget), dd))
-                    tcp = time.perf_counter() - tcp
-                    assert all(r is not None and r[0] == int(v2[i]) for i, r in enumerate(rr)), "GPU and oracle disagree on the crashed workload's sample"
-                    out["cpu_baseline"] = {"value": round(len(dd) / tcp, 3), "unit": "histories/s", "cores": cores, "kind": "port",
-                                           "sample": f"first {len(dd)} histories, oracle/wgl_count.c (the count form's own passes, {width2} configs per round) from {cores} Python threads "
-                                                     f"(ctypes releases the GIL)"}
-                elif not args.no_cpu:
-                    from oracle import wgl
-                    cores, _, _ = usable_cores()
-                    dd = [h2[i].as_dict() for i in range(min(cpu_n, B2))]
-                    tcp = time.perf_counter()
-                    vv, started = wgl.check_many(dd, {"kind": 1, "init": N.NIL}, cores, max_steps=cpu_cap, beam_width=width2 if width2 > 1 else 4)
-                    tcp = time.perf_counter() - tcp
-                    done = int((vv != -1).sum())
-                    assert all(int(vv[i]) in (-1, int(v2[i])) for i in range(len(dd))), "GPU and oracle disagree on the second workload's sample"
-                    out["cpu_baseline"] = {"value": round(done / tcp, 3), "unit": "histories/s", "cores": cores, "kind": "port",
-                                           "sample": f"first {len(dd)} histories, oracle/wgl_beam.c (the kernel's schedule, {width2} configs per round, lookahead + eager reads + "
-                                                     f"twin rule) on {started} pthreads, at most {cpu_cap:.0e} probes each: {done} finished (the others are not counted)"}
-                return out
-            leg("workload 2")
-            line["extra"]["workload_2"] = second(args.busy2, args.batch2, 256, 10_000_000, 64, 60_000_000, False)      # (a step is ~25 s: one run, no warm-up)
+            line["extra"]["workload_2"] = run_leg("workload_2", args, local_rank)
             if args.busy3 > 0:
-                leg("workload 3")
-                line["extra"]["workload_3"] = second(args.busy3, args.batch3, 32, 20_000_000, 128, 60_000_000, True)
+                line["extra"]["workload_3"] = run_leg("workload_3", args, local_rank)
             if args.info4 > 0:
-                # the regime the reference produces (a nemesis makes clients time out: :info): the headline workload with 1 % of the
-                # calls crashed, a batch of them -- the count form, a wavefront per history
-                leg("workload with crashed calls")
-                line["extra"]["workload_crashed"] = second(args.busy, args.batch4, 8, 30_000_000, 256, 0, True, info=args.info4)
-        leg("checker/set-full")
+                line["extra"]["workload_crashed"] = run_leg("workload_crashed", args, local_rank)
         if world == 1 and not args.no_set_full:
-            # checker/set-full (the checker the reference runs: set_full.clj:157): the reads x elements membership scan,
-            # the one streaming kernel of the path.  Synthetic: 262,144 elements x 32,768 reads (1 GB of bits), an element
-            # is visible from about its acknowledgement on, 300 elements vanish in the last quarter (lost), sparse holes
-            # right after the add (stale reads).  roofline = matrix bytes the scan loaded / its time, against 8 TB/s.
-            from jepsen_tigerbeetle_amd.jepsen import set_full as sf
-            rng = np.random.default_rng(7)
-            E, R = 262144, 32768
-            add_invoke = (np.sort(rng.choice(4 * (E + R), E, replace=False)) * 2).astype(np.uint32)
-            read_invoke = (np.sort(rng.choice(4 * (E + R), R, replace=False)) * 2 + 1).astype(np.uint32)
-            read_ok = read_invoke + (rng.integers(1, 2000, R) * 2).astype(np.uint32)
-            add_ok = (add_invoke + 2001).astype(np.uint32)
-            p = np.searchsorted(add_ok, read_invoke).astype(np.int64)            # row r sees the elements acknowledged before it began
-            w = np.arange(E // 32, dtype=np.int64)
-            M = np.where(32 * (w + 1)[None, :] <= p[:, None], 0xFFFFFFFF,
-                         np.where(32 * w[None, :] >= p[:, None], 0, (1 << np.clip(p[:, None] - 32 * w[None, :], 0, 31)) - 1)).astype(np.uint32)
-            lost_e = rng.choice(E // 2, 300, replace=False)
-            for e in lost_e:
-                M[R * 3 // 4:, e // 32] &= np.uint32(~(1 << (e % 32)) & 0xFFFFFFFF)
-            holes_r = rng.integers(0, R, 200000); holes_e = np.clip(p[holes_r] - rng.integers(1, 2000, 200000), 0, E - 1)
-            np.bitwise_and.at(M, (holes_r, holes_e // 32), (~(np.uint32(1) << (holes_e % 32).astype(np.uint32))).astype(np.uint32))
-            # the same reads in COMPACT form (tbc_setfull_rows): a prefix of the elements and the holes in it -- what a caller that holds
-            # the reads as sorted id lists hands over; the matrix is then built on the device and nothing of its size crosses PCIe
-            late = np.arange(R * 3 // 4, R)
-            pr = np.concatenate([np.repeat(late, len(lost_e)), holes_r])
-            pe = np.concatenate([np.tile(lost_e, len(late)), holes_e])
-            keep = pe < p[pr]                                                   # (an element at or above the prefix is absent anyway)
-            pairs = np.unique(pr[keep].astype(np.int64) * E + pe[keep].astype(np.int64))
-            exc_rows, exc = pairs // E, (pairs % E).astype(np.uint32)
-            exc_off = np.zeros(R + 1, np.uint64)
-            exc_off[1:] = np.cumsum(np.bincount(exc_rows, minlength=R))
-
-            class A:
-                pass
-            a = A(); a.E, a.R, a.wpr = E, R, E // 32
-            a.add_invoke, a.add_ok, a.read_invoke, a.read_ok, a.present = add_invoke, add_ok, read_invoke, read_ok, np.ascontiguousarray(M)
-            with sf.Scan(a, device=local_rank, rows=False) as sc:
-                sc.run()
-                runs = [sc.run() for _ in range(5)]
-            a.top, a.exc_off, a.exc = p.astype(np.uint32), exc_off, exc
-            t_e2e = []
-            for _ in range(3):                   # end to end: compact reads on the host -> matrix built on the device -> scan -> three indices per element back
-                t1 = time.perf_counter()
-                with sf.Scan(a, device=local_rank, rows=True) as sc2:
-                    r2 = sc2.run()
-                t_e2e.append((time.perf_counter() - t1) * 1e3)
-            for k in ("known", "last_present", "last_absent"):
-                assert np.array_equal(r2[k], runs[0][k]), f"set-full: the matrix built on the device gives another {k}" 
-            ms = statistics.mean(r["ns_scan"] for r in runs) / 1e6
-            lost = int(((runs[0]["last_present"].astype(np.int64) < runs[0]["last_absent"].astype(np.int64)) & (runs[0]["last_absent"] != N.NO_OP)).sum())
-            gbs = runs[0]["bytes_scanned"] / (ms * 1e-3) / 1e9
-            line["extra"]["set_full"] = {"elements": E, "reads": R, "matrix_GB": round(runs[0]["bytes_matrix"] / 1e9, 3),
-                                         "scan_ms": round(ms, 3), "bytes_scanned": int(runs[0]["bytes_scanned"]), "lost_elements_found": lost,
-                                         "end_to_end_ms": round(min(t_e2e), 3), "compact_input_MB": round((exc.nbytes + exc_off.nbytes + 4 * R) / 1e6, 2),
-                                         "end_to_end_note": "tbc_setfull_create_rows + tbc_setfull_run + destroy: allocation, H2D of the compact reads, the matrix built on the device, the scan, "
-                                                            "three indices per element back (best of 3); the dense form moves the 1 GB matrix over PCIe instead",
-                                         "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                                      "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "setfull_any_kernel + setfull_resolve_kernel"}}
+            line["extra"]["set_full"] = run_leg("set_full", args, local_rank)
         print(json.dumps(line), flush=True)
     for b in batches:
         b.close()

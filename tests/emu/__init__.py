@@ -12,7 +12,11 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(os.path.dirname(_HERE))
 _CSRC = os.path.join(_ROOT, "jepsen-tigerbeetle_amd", "csrc")
-_SO = os.path.join(_HERE, "_build", "libemu_narrow.so")
+# TBC_EMU_ASAN=1: the same library under AddressSanitizer (every table is a std::vector of exactly the device's size, so a read or a
+# write of the kernel body past any of them stops the test); run as  LD_PRELOAD=$(gcc -print-file-name=libasan.so)
+# ASAN_OPTIONS=detect_leaks=0 TBC_EMU_ASAN=1 python -m pytest tests/test_narrow_emu.py
+_ASAN = os.environ.get("TBC_EMU_ASAN") == "1"
+_SO = os.path.join(_HERE, "_build", "libemu_narrow_asan.so" if _ASAN else "libemu_narrow.so")
 _LIB = None
 
 
@@ -28,8 +32,9 @@ def build(force=False):
             os.path.join(_CSRC, "wgl_narrow_impl.h"), os.path.join(_CSRC, "tbc_internal.h"), os.path.join(_CSRC, "wave_env.h")]
     if force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs):
         os.makedirs(os.path.dirname(_SO), exist_ok=True)
-        subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas",
-                               "-I", _HERE, "-I", _CSRC, "-o", _SO, srcs[0]])
+        subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas"]
+                              + (["-fsanitize=address", "-fno-omit-frame-pointer"] if _ASAN else [])
+                              + ["-I", _HERE, "-I", _CSRC, "-o", _SO, srcs[0]])
     return _SO
 
 

@@ -238,3 +238,34 @@ def test_bench_n_gt_1_plumbing_over_gloo(native):
     # whole-job aggregate: 2 ranks x 6 histories per step; verdicts summed over the ranks' resident batches (one planted INVALID each)
     assert abs(line["value"] - 2 * 6 * 4 / (line["ms_per_step"] * 4 / 1e3)) < 0.01 * line["value"]      # (ms_per_step is rounded to a microsecond)
     assert line["extra"]["valid"] == 2 * 2 * 5 and line["extra"]["unknown"] == 0
+
+
+def test_bench_extra_legs_run_in_their_own_process(monkeypatch):
+    """bench.run_leg: a leg's result comes back from its process; a leg killed by a signal (what a GPU fault does to the process it
+    happens in) leaves an error in its place and the measured line lives; a leg that fails an assertion fails the run."""
+    import argparse
+    import json
+    import subprocess
+    import types
+    sys.path.insert(0, ROOT)
+    import bench
+    seen = []
+
+    def fake_run(rc, out):
+        def run(cmd, **kw):
+            seen.append(cmd)
+            return types.SimpleNamespace(returncode=rc, stdout=out)
+        return run
+    monkeypatch.delenv("TBC_BENCH_INLINE_LEGS", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--steps", "4"])
+    args = argparse.Namespace()
+    monkeypatch.setattr(subprocess, "run", fake_run(0, b"noise\n" + json.dumps({"leg": "set_full", "result": {"scan_ms": 1.5}}).encode() + b"\n"))
+    assert bench.run_leg("set_full", args, 0) == {"scan_ms": 1.5}
+    assert seen[-1][-4:] == ["--steps", "4", "--leg", "set_full"]          # the same arguments, and the leg's name
+    monkeypatch.setattr(subprocess, "run", fake_run(-6, b""))
+    r = bench.run_leg("workload_crashed", args, 0)
+    assert set(r) == {"error"} and "signal 6" in r["error"]
+    monkeypatch.setattr(subprocess, "run", fake_run(1, b""))
+    with pytest.raises(SystemExit):
+        bench.run_leg("tiers", args, 0)
+    assert set(bench.LEGS) == {"tiers", "set_full", "workload_2", "workload_3", "workload_crashed"}
