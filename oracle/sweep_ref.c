@@ -138,6 +138,14 @@ void sweep_set_segments(uint32_t seg_target, uint32_t max_cut_open) { g_seg_targ
  * histories shares one domain in the library (the greatest value of the whole batch). */
 static uint32_t g_n_dom = 0;
 void sweep_set_domain(uint32_t n_dom) { g_n_dom = n_dom; }
+/* ids per segment's origin space: 128 = the kernel's (4 wavefronts of 32 origins per segment, tbc_sweep_rel's four words per origin);
+ * up to 512 for design studies (cuts at fronts with more calls open: scripts/sweep_cut_study.py) -- no relation export then */
+#define SW_MAX_WORDS 16
+static uint32_t g_max_ids = 128;
+/* origins per wavefront ("slice"): 32 = the kernel's; fewer for design studies (no relation export then) */
+static uint32_t g_slice = 32;
+void sweep_set_slice(uint32_t g) { g_slice = (g == 0 || g > 32) ? 32 : g; }
+void sweep_set_max_ids(uint32_t n) { g_max_ids = n < 32 ? 32 : (n > 32 * SW_MAX_WORDS ? 32 * SW_MAX_WORDS : n); }
 /* Multi-GPU stand-in (tests/test_distributed_gloo.py): instead of composing, write the relation of every wavefront
  * with (segment * 4 + slice) % world == rank into rel[segment * 4 + slice] -- exactly what rank `rank` of `world`
  * GPUs leaves in its table after tbc_batch_sweep_partial -- and sweep nothing else.  rel = NULL switches it off. */
@@ -242,8 +250,8 @@ int sweep_ref_check(uint32_t n, const uint8_t* f, const int32_t* a, const int32_
   }
   const uint32_t nd = g_n_dom ? g_n_dom : (uint32_t)(vmax + 2);
   uint32_t m_open = 0;
-  int cut_ok = regfam && g_seg_target && nd <= 128;
-  if (cut_ok) while (m_open < g_max_cut_open && (nd << (m_open + 1)) <= 128) m_open++;
+  int cut_ok = regfam && g_seg_target && nd <= g_max_ids;
+  if (cut_ok) while (m_open < g_max_cut_open && (nd << (m_open + 1)) <= g_max_ids) m_open++;
   /* ---- cuts: in every window the front with the FEWEST open calls (the first of them), if that is <= m_open */
   uint32_t* cuts = (uint32_t*)malloc(4 * ((size_t)R + 2));
   uint32_t* cutk = (uint32_t*)malloc(4 * ((size_t)R + 2));     /* window number of each cut = the kernel's segment number */
@@ -271,7 +279,7 @@ int sweep_ref_check(uint32_t n, const uint8_t* f, const int32_t* a, const int32_
   uint32_t fail_level = 0;
   int32_t final_state = model->init;
   /* the composition's live set: ids of the current segment's origin space (<= 128), segment 0: id 0 = the initial config */
-  orgset live = 1;
+  uint32_t live[SW_MAX_WORDS] = {1}, next_live[SW_MAX_WORDS];
 
   for (uint32_t sg = 0; sg < S && verdict == 1; sg++) {
     const uint32_t F0 = cuts[sg], F1 = cuts[sg + 1];
@@ -279,11 +287,11 @@ int sweep_ref_check(uint32_t n, const uint8_t* f, const int32_t* a, const int32_
      * kernel gives every 32 consecutive ids a wavefront of their own ("slice"), and so does this restatement -- the
      * statistics count a config once per slice it is reachable in.  Ids that are not in normal form are nobody's config. */
     const uint32_t no0 = sg ? H.off[F0 + 1] - H.off[F0] : 0;
-    const uint32_t n_ids = sg ? nd << no0 : 1, n_slices = (n_ids + 31) / 32;
+    const uint32_t n_ids = sg ? nd << no0 : 1, n_slices = (n_ids + g_slice - 1) / g_slice;
     const uint32_t no1 = F1 < R ? H.off[F1 + 1] - H.off[F1] : 0;
     if (n_ids > st->max_origins) st->max_origins = n_ids;
     if (F1 - F0 > st->longest_segment) st->longest_segment = F1 - F0;
-    orgset next_live = 0;
+    memset(next_live, 0, sizeof next_live);
     uint32_t reached = F0;
     for (uint32_t sl = 0; sl < n_slices && verdict == 1; sl++) {
       if (g_rel && (cutk[sg] * 4 + sl) % g_rel_world != g_rel_rank) continue;      /* another rank's wavefront */
@@ -291,8 +299,8 @@ int sweep_ref_check(uint32_t n, const uint8_t* f, const int32_t* a, const int32_
       const uint64_t cfg_before = st->configs_total, sub_before = st->subrounds;
       uint32_t slice_max = 0;
       cs_clear(&cur);
-      for (uint32_t l = 0; l < 32; l++) {
-        const uint32_t id = 32 * sl + l;
+      for (uint32_t l = 0; l < g_slice; l++) {
+        const uint32_t id = g_slice * sl + l;
         if (id >= n_ids) break;
         memset(key, 0, KW * 8);
         if (sg == 0) key[0] = (uint64_t)(uint32_t)model->init << 32;
@@ -310,7 +318,7 @@ int sweep_ref_check(uint32_t n, const uint8_t* f, const int32_t* a, const int32_
       st->n_waves++;
       const uint64_t probes_before = st->probes;
       uint32_t last_level[32]; for (uint32_t q = 0; q < 32; q++) last_level[q] = F0;
-      uint32_t M[32][4]; memset(M, 0, sizeof M);
+      uint32_t M[32][SW_MAX_WORDS]; memset(M, 0, sizeof M);
 
       for (uint32_t F = F0; F < F1 && verdict == 1; F++) {
         const uint32_t x = H.ret_op[F], px = (uint32_t)process[x];
@@ -391,20 +399,23 @@ int sweep_ref_check(uint32_t n, const uint8_t* f, const int32_t* a, const int32_
         r->subrounds = (uint32_t)(st->subrounds - sub_before); r->n_end = (uint32_t)cur.n;
         r->end_state = cur.n ? (uint32_t)(cur.key[0] >> 32) : 0u;
         r->configs_total = st->configs_total - cfg_before; r->probes = st->probes - probes_before;
-        memcpy(r->M, M, sizeof M); memcpy(r->last_level, last_level, sizeof last_level);
+        if (g_max_ids > 128 || g_slice != 32) { verdict = -3; break; }                /* (the exported record holds four words per origin) */
+        for (uint32_t q = 0; q < 32; q++) memcpy(r->M[q], M[q], sizeof r->M[q]);
+        memcpy(r->last_level, last_level, sizeof last_level);
         continue;
       }
       /* composition over this slice's live origins */
-      for (uint32_t q = 0; q < 32; q++) if (live >> (32 * sl + q) & 1) {
-        for (uint32_t w = 0; w < 4; w++) next_live |= (orgset)M[q][w] << (32 * w);
+      for (uint32_t q = 0; q < g_slice; q++) if (live[(g_slice * sl + q) >> 5] >> ((g_slice * sl + q) & 31) & 1) {
+        for (uint32_t w = 0; w < SW_MAX_WORDS; w++) next_live[w] |= M[q][w];
         if (last_level[q] > reached) reached = last_level[q];
       }
     }
     if (verdict != 1) break;
     if (g_rel) continue;                                   /* relations only: the ranks compose after the exchange */
-    if (next_live == 0) { verdict = 0; fail_level = reached; break; }
-    if (F1 == R) { for (uint32_t q = 0; q < 32; q++) if (next_live >> q & 1) { final_state = regfam ? dom[q < nd ? q : 0] : model->init; break; } }
-    live = next_live;
+    { uint32_t any_live = 0; for (uint32_t w = 0; w < SW_MAX_WORDS; w++) any_live |= next_live[w];
+      if (any_live == 0) { verdict = 0; fail_level = reached; break; } }
+    if (F1 == R) { for (uint32_t q = 0; q < 32; q++) if (next_live[0] >> q & 1) { final_state = regfam ? dom[q < nd ? q : 0] : model->init; break; } }
+    memcpy(live, next_live, sizeof live);
   }
   if (verdict == 1 && !regfam) final_state = cur.n ? (int32_t)(uint32_t)(cur.key[0] >> 32) : model->init;
 
