@@ -86,6 +86,9 @@ typedef struct sweep_stats {
   uint64_t longest_segment; /* levels */
   uint64_t n_waves;         /* wavefronts the kernel uses: one per 32 origins of each segment */
   uint64_t max_segment_probes;
+  /* design study (sweep_set_model_lanes): lane-steps of the most expensive wavefront if a level's passes ran `lanes` pairs at a time:
+   * sum over its levels of ceil(configs / lanes) + sum over sub-rounds of ceil(pending configs * 2^ceil(log2 open calls) / lanes), and its levels */
+  uint64_t critical_steps, critical_levels, total_steps;
 } sweep_stats;
 
 /* ordered exact set of configs: entries (KW words key: [state+1 | 0][mask...]) + origin mask, insertion order kept */
@@ -143,7 +146,8 @@ void sweep_set_domain(uint32_t n_dom) { g_n_dom = n_dom; }
 #define SW_MAX_WORDS 16
 static uint32_t g_max_ids = 128;
 /* origins per wavefront ("slice"): 32 = the kernel's; fewer for design studies (no relation export then) */
-static uint32_t g_slice = 32;
+static uint32_t g_slice = 32, g_model_lanes = 64;
+void sweep_set_model_lanes(uint32_t l) { g_model_lanes = l ? l : 64; }
 void sweep_set_slice(uint32_t g) { g_slice = (g == 0 || g > 32) ? 32 : g; }
 void sweep_set_max_ids(uint32_t n) { g_max_ids = n < 32 ? 32 : (n > 32 * SW_MAX_WORDS ? 32 * SW_MAX_WORDS : n); }
 /* Multi-GPU stand-in (tests/test_distributed_gloo.py): instead of composing, write the relation of every wavefront
@@ -317,6 +321,7 @@ int sweep_ref_check(uint32_t n, const uint8_t* f, const int32_t* a, const int32_
       if (cur.n == 0) continue;                                       /* the kernel's wavefront has nothing to sweep */
       st->n_waves++;
       const uint64_t probes_before = st->probes;
+      uint64_t steps = 0, levels = 0;
       uint32_t last_level[32]; for (uint32_t q = 0; q < 32; q++) last_level[q] = F0;
       uint32_t M[32][SW_MAX_WORDS]; memset(M, 0, sizeof M);
 
@@ -329,9 +334,11 @@ int sweep_ref_check(uint32_t n, const uint8_t* f, const int32_t* a, const int32_
           else cs_add(&pa, c, cur.org[e]);
         }
         cset* P = &pa; cset* Q = &pb;
+        levels++; steps += (cur.n + g_model_lanes - 1) / g_model_lanes;
         const uint32_t nlive = H.off[F + 1] - H.off[F], tot = nlive + H.ncr[F];
         while (P->n) {
           st->subrounds++;
+          { uint32_t gs = 0; while ((1u << gs) < tot) gs++; steps += (((uint64_t)P->n << gs) + g_model_lanes - 1) / g_model_lanes; }
           if (P->n > st->max_pending) st->max_pending = P->n;
           cs_clear(Q);
           for (size_t e = 0; e < P->n; e++) {
@@ -377,6 +384,8 @@ int sweep_ref_check(uint32_t n, const uint8_t* f, const int32_t* a, const int32_
       }
       if (verdict != 1) break;
       if (st->probes - probes_before > st->max_segment_probes) st->max_segment_probes = st->probes - probes_before;
+      st->total_steps += steps;
+      if (steps > st->critical_steps) { st->critical_steps = steps; st->critical_levels = levels; }
       /* the relation this slice hands on: origin -> ids of the next segment's origin space (last segment: final states) */
       for (size_t e = 0; e < cur.n; e++) {
         const uint64_t* c = cur.key + e * KW;

@@ -259,7 +259,8 @@ class SweepStats(C.Structure):
     _fields_ = [("configs_total", C.c_uint64), ("max_level", C.c_uint64), ("probes", C.c_uint64),
                 ("subrounds", C.c_uint64), ("levels", C.c_uint64), ("n_segments", C.c_uint64),
                 ("max_origins", C.c_uint64), ("max_pending", C.c_uint64), ("longest_segment", C.c_uint64),
-                ("n_waves", C.c_uint64), ("max_segment_probes", C.c_uint64)]
+                ("n_waves", C.c_uint64), ("max_segment_probes", C.c_uint64),
+                ("critical_steps", C.c_uint64), ("critical_levels", C.c_uint64), ("total_steps", C.c_uint64)]
 
 
 def check_sweep(ops, model, eager_reads=True, twin_rule=True, seg_target=0, max_cut_open=4, max_level=0, want_levels=False, n_dom=0):

@@ -159,3 +159,41 @@ def run(hists, model_kind, init, L, rules=None, lookahead=True, entries_per_op=8
         d["rules"], d["vpad"], d["mw"] = r, vpad, mw
         out.append(d)
     return out
+
+
+# ---- K6w: the level sweep by workgroups (csrc/jit_sweep_wg_impl.h) under the workgroup emulator
+_SO_SWEEP = os.path.join(_HERE, "_build", "libemu_sweep_asan.so" if _ASAN else "libemu_sweep.so")
+_LIB_SWEEP = None
+
+
+def build_sweep(force=False):
+    srcs = [os.path.join(_HERE, "emu_sweep.cpp"), os.path.join(_HERE, "wave_env_emu.h"), os.path.join(_HERE, "wave_env_wg_emu.h"), os.path.join(_HERE, "host_tables.h"),
+            os.path.join(_CSRC, "jit_sweep_wg_impl.h"), os.path.join(_CSRC, "tbc_internal.h"), os.path.join(_CSRC, "wave_env.h"), os.path.join(_CSRC, "wave_env_wg.h")]
+    if force or not os.path.exists(_SO_SWEEP) or any(os.path.getmtime(s) > os.path.getmtime(_SO_SWEEP) for s in srcs):
+        os.makedirs(os.path.dirname(_SO_SWEEP), exist_ok=True)
+        subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas"]
+                              + (["-fsanitize=address", "-fno-omit-frame-pointer"] if _ASAN else [])
+                              + ["-I", _HERE, "-I", _CSRC, "-I", os.path.join(_ROOT, "include"), "-o", _SO_SWEEP, srcs[0]])
+    return _SO_SWEEP
+
+
+def sweep_wg(ops, model_kind, init, seg_target, n_dom, max_segs, waves=8, cap=1024, rules=None, seed=1, rel_bytes=688):
+    """ONE history through K6w: max_segs * 4 tbc_sweep_rel records as a uint8 array (as oracle.wgl.sweep_relations returns them)."""
+    global _LIB_SWEEP
+    if _LIB_SWEEP is None:
+        _LIB_SWEEP = C.CDLL(build_sweep())
+        _LIB_SWEEP.emu_sweep_wg_run.restype = C.c_int
+    d = ops if isinstance(ops, dict) else ops.as_dict()
+    f, a, b = (np.ascontiguousarray(d[k], t) for k, t in (("f", np.uint8), ("a", np.int32), ("b", np.int32)))
+    pr, inv, ret = (np.ascontiguousarray(d[k], t) for k, t in (("process", np.int32), ("inv_pos", np.uint32), ("ret_pos", np.uint32)))
+    r, vpad = rules_for([d], model_kind, init)
+    if rules is not None:
+        r &= rules
+    buf = np.zeros(max_segs * 4 * rel_bytes, np.uint8)
+    rc = _LIB_SWEEP.emu_sweep_wg_run(C.c_uint32(len(f)), C.c_uint32(int(d["n_process"])), _p(f, C.c_uint8), _p(a, C.c_int32), _p(b, C.c_int32), _p(pr, C.c_int32),
+                                     _p(inv, C.c_uint32), _p(ret, C.c_uint32), C.c_uint32(model_kind), C.c_int32(init), C.c_uint32(vpad), C.c_uint32(r),
+                                     C.c_uint32(n_dom), C.c_uint32(seg_target), C.c_uint32(max_segs), C.c_uint32(waves), C.c_uint32(cap), C.c_uint64(seed),
+                                     buf.ctypes.data_as(C.c_void_p))
+    if rc != 0:
+        raise RuntimeError(f"emu_sweep_wg_run rc={rc}")
+    return buf

@@ -78,6 +78,7 @@ struct EmuWave {
   int cur = 0;
   uint64_t rendezvous = 0;
   uint64_t clock = 0;
+  int wave_index = 0;     // within its workgroup (wave_env_wg_emu.h)
 };
 inline EmuWave*& W() { static thread_local EmuWave* w = nullptr; return w; }
 

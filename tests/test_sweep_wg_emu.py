@@ -1,0 +1,115 @@
+"""K6w -- the level sweep with a WORKGROUP per segment (jepsen-tigerbeetle_amd/csrc/jit_sweep_wg_impl.h) -- run on the CPU under the
+workgroup emulator (tests/emu/wave_env_wg_emu.h: NW x 64 fibers, wavefronts interleaved in seeded orders) against oracle/sweep_ref.c:
+every record a workgroup leaves (status, levels, level sizes, sub-rounds, probes, the relation, the origins' last levels) is the
+record the oracle writes for that (segment, slice), and the library's own composition of them gives the oracle's verdict."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import jepsen_tigerbeetle_amd  # noqa: F401
+from jepsen_tigerbeetle_amd import _native as N, columns, synth
+from oracle import wgl
+
+import emu
+
+CAS = {"kind": 1, "init": N.NIL}
+
+
+def _records(buf):
+    return np.frombuffer(buf, dtype=np.uint8).reshape(-1, C.sizeof(N.SweepRel))
+
+
+def _compare(ops, seg_target, n_dom, waves, cap=1024, rules=None, seed=1, expect_overflow=False):
+    d = ops.as_dict()
+    R = int((np.asarray(d["ret_pos"]) != 0xFFFFFFFF).sum())
+    max_segs = max(1, min(512, (R + seg_target - 1) // seg_target)) if seg_target else 1
+    eager = twin = True if rules is None else bool(rules)
+    L = wgl.lib()
+    buf = np.zeros(max_segs * 4 * C.sizeof(N.SweepRel), np.uint8)
+    L.sweep_set_export(buf.ctypes.data_as(C.c_void_p), C.c_uint32(max_segs), C.c_uint32(0), C.c_uint32(1))
+    try:
+        wgl.check_sweep(d, CAS, eager_reads=eager, twin_rule=twin, seg_target=seg_target, n_dom=n_dom)
+    finally:
+        L.sweep_set_export(None, C.c_uint32(0), C.c_uint32(0), C.c_uint32(1))
+    got = emu.sweep_wg(d, 1, N.NIL, seg_target, n_dom, max_segs, waves=waves, cap=cap, rules=None if rules is None else (3 if rules else 0), seed=seed)
+    want = [N.SweepRel.from_buffer_copy(r.tobytes()) for r in _records(buf)]
+    have = [N.SweepRel.from_buffer_copy(r.tobytes()) for r in _records(got)]
+    n_swept = overflowed = 0
+    for i, (w, g) in enumerate(zip(want, have)):
+        if g.status == 2:
+            overflowed += 1
+            continue
+        assert g.status == w.status, (i, g.status, w.status)
+        if w.status == 0:
+            continue
+        n_swept += 1
+        for k in ("F0", "F1", "max_level", "subrounds", "n_end", "configs_total", "probes"):
+            assert getattr(g, k) == getattr(w, k), (i, k, getattr(g, k), getattr(w, k))
+        assert [list(r) for r in g.M] == [list(r) for r in w.M], (i, "relation")
+        assert list(g.last_level) == list(w.last_level), (i, "last levels")
+    assert (overflowed > 0) == expect_overflow
+    if not overflowed:      # the library's own composition (host code, no device) of K6w's records = the oracle's verdict
+        ref = wgl.check_sweep(d, CAS, eager_reads=eager, twin_rule=twin, seg_target=seg_target, n_dom=n_dom)
+        v = N.SweepVerdict()
+        recs = (N.SweepRel * len(have))(*have)
+        assert N.lib().tbc_sweep_compose(recs, C.c_uint32(max_segs), C.c_uint32(R), C.byref(v)) == 0
+        assert v.valid == ref["valid"]
+        if ref["valid"] == 0:
+            order = np.argsort(np.asarray(d["ret_pos"], np.int64) + (np.asarray(d["ret_pos"]) == 0xFFFFFFFF) * (1 << 40), kind="stable")
+            assert int(order[v.fail_level]) == ref["fail_op"]
+        else:
+            assert v.probes == ref["probes"] and v.configs_total == ref["configs_total"]
+    return n_swept
+
+
+@pytest.mark.parametrize("waves", [2, 4, 8])
+def test_small_histories_every_record(waves):
+    n = 0
+    for seed in range(6):
+        for corrupt in (0.0, 0.4):
+            h = columns.pair_events(synth.register_events(n_ops=300, n_procs=8, seed=100 + seed, busy=0.5, info=0.0, corrupt=corrupt))
+            n += _compare(h, 32, 6, waves, seed=seed)
+    assert n > 20
+
+
+def test_rules_off_and_one_segment():
+    for seed in range(3):
+        h = columns.pair_events(synth.register_events(n_ops=120, n_procs=5, seed=200 + seed, busy=0.6, info=0.0, corrupt=0.0))
+        _compare(h, 32, 6, 4, rules=False)
+        _compare(h, 0, 6, 4)
+
+
+def test_wavefront_interleavings_do_not_matter():
+    """the same history under eight schedules of the wavefronts (a read of LDS another wavefront writes with no barrier between
+    them would differ somewhere)"""
+    h = columns.pair_events(synth.register_events(n_ops=600, n_procs=16, seed=7, busy=0.5, info=0.0, corrupt=0.0))
+    for seed in range(8):
+        _compare(h, 32, 6, 8, seed=1000 + 17 * seed)
+
+
+def test_a_bench_history_with_its_bursts():
+    """one 10k-invocation / 64-process history of the bench: ~340 workgroups, among them the burst segment (a level of hundreds of
+    configs, sub-rounds of thousands of pairs) that the workgroup form exists for"""
+    h = synth.register_ops_many([3], n_ops=10000, n_procs=64, busy=0.1, info=0.0)[0]
+    assert _compare(h, 32, 6, 8) > 250
+
+
+def test_histories_with_crashed_calls():
+    """crashed calls stay candidates for ever (K6's list behind the live calls, their twins computed from the level's records) and
+    end the cutting at the first of them; a level or a sub-round set past the capacity ends the segment with status 2"""
+    for seed in (49, 54, 58, 59):
+        h = columns.pair_events(synth.register_events(n_ops=300, n_procs=8, seed=seed, busy=0.4, info=0.015, corrupt=0.0))
+        assert int((np.asarray(h.as_dict()["ret_pos"]) == 0xFFFFFFFF).sum()) >= 5
+        _compare(h, 32, 6, 4)
+    h = columns.pair_events(synth.register_events(n_ops=400, n_procs=8, seed=31, busy=0.5, info=0.03, corrupt=0.0))     # levels of 11,520 configs
+    _compare(h, 32, 6, 4, expect_overflow=True)
+
+
+def test_overflow_is_reported_not_mis_swept():
+    """sets of 512 configs against a burst that needs more: the segment ends with status 2 (the host then sweeps it again with
+    K6's big sets), every other record is still the oracle's"""
+    h = synth.register_ops_many([4], n_ops=10000, n_procs=64, busy=0.1, info=0.0)[0]
+    ref = wgl.check_sweep(h.as_dict(), CAS, seg_target=32, n_dom=6)
+    if ref["max_level"] > 512:
+        _compare(h, 32, 6, 4, cap=512, expect_overflow=True)
