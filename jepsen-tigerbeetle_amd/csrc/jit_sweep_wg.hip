@@ -1,0 +1,43 @@
+// jit_sweep_wg.hip -- K6w: the level sweep with a WORKGROUP of wavefronts per (history, segment, 32 origins) (gfx950); the body
+// is jit_sweep_wg_impl.h.  Same inputs, same records as jit_sweep_kernel (jit_sweep.hip), which keeps the dump pass and every
+// model outside the register family.
+#include <hip/hip_runtime.h>
+#include "tbc_internal.h"
+#include "jit_sweep_wg_impl.h"
+
+namespace tbc {
+
+namespace {
+
+template <uint32_t CAP, uint32_t NW>
+__global__ __launch_bounds__(64 * NW) void jit_sweep_wg_kernel(SweepArgs A) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  sweepwg::segment<CAP, NW>(A, lds);
+}
+
+template <uint32_t CAP, uint32_t NW>
+bool launch_one(const SweepArgs& a, hipStream_t s) {
+  constexpr uint32_t bytes = sweepwg::lds_words<CAP, NW>() * 4;
+  static bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&jit_sweep_wg_kernel<CAP, NW>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
+  if (!ok) return false;
+  const uint32_t groups = a.seg_list ? a.n_list : a.n_hist * a.max_segs * kSweepSlices;
+  hipLaunchKernelGGL((jit_sweep_wg_kernel<CAP, NW>), dim3(groups), dim3(64 * NW), bytes, s, a);
+  return true;
+}
+
+}  // namespace
+
+// the first pass of the sweep (cuts are in place): `waves` wavefronts per workgroup, sets of kSweepCapMid configs (78 KB of LDS
+// with 8 wavefronts: two workgroups per CU); the second pass (a.seg_list: the segments that overflowed those): sets of
+// kSweepCapBig configs, 8 wavefronts (148 KB: one workgroup per CU)
+bool launch_sweep_wg(const SweepArgs& a, uint32_t waves, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (!(a.model_kind == TBC_MODEL_REGISTER || a.model_kind == TBC_MODEL_CAS_REGISTER) || a.dump_cfg) return false;
+  if (a.seg_list) return launch_one<kSweepCapBig, 8>(a, s);
+  if (waves == 4) return launch_one<kSweepCapMid, 4>(a, s);
+  if (waves == 8) return launch_one<kSweepCapMid, 8>(a, s);
+  return false;
+}
+
+}  // namespace tbc

@@ -16,7 +16,7 @@
 //     wavefront (K6: lane order) -- a set is a set;
 //   * everything a decision hangs on (set sizes, generations, status, the level's numbers) is kept by every thread and
 //     derived from LDS words all of them read after a barrier: control flow is uniform across the workgroup by construction.
-// Register family only (the models K6 cuts into segments); the dump pass and the second pass over overflowed segments stay K6's.
+// Register family only (the models K6 cuts into segments); the dump pass stays K6's.
 //
 // Written against wave_env.h / wave_env_wg.h: tests/emu runs this very file on NW x 64 host fibers with the wavefronts
 // interleaved in seeded orders and compares every record with oracle/sweep_ref.c (tests/test_sweep_wg_emu.py).
@@ -181,8 +181,10 @@ WV_DEV void segment(const SweepArgs& A, uint32_t* lds) {
   X.tid = wv::wg_thread(); X.lane = X.tid & 63u; X.wave = X.tid >> 6; X.parity = 0;
   const uint32_t tid = X.tid, lane = X.lane;
   const uint32_t w = wv::wg_index();
-  const uint32_t per = A.max_segs * kSweepSlices;
-  const uint32_t h = w / per, r_ = w - h * per, k = r_ / kSweepSlices, sl = r_ % kSweepSlices;
+  // second pass (A.seg_list): the listed (history, segment, slice) triples only -- the ones that overflowed the first pass's sets
+  uint32_t h, k, sl;
+  if (A.seg_list) { h = A.seg_list[3 * w]; k = A.seg_list[3 * w + 1]; sl = A.seg_list[3 * w + 2]; }
+  else { const uint32_t per = A.max_segs * kSweepSlices; h = w / per; const uint32_t r_ = w - h * per; k = r_ / kSweepSlices; sl = r_ % kSweepSlices; }
   if (h >= A.n_hist) return;
   if (A.shard_world > 1u && (k * kSweepSlices + sl) % A.shard_world != A.shard_rank) return;   // another rank's (its record stays zero)
   const uint32_t* cuts = A.cuts + (uint64_t)h * A.max_segs;

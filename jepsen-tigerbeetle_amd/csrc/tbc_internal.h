@@ -370,6 +370,8 @@ struct SweepArgs {
   uint32_t* dump_count;      // number of configs at that level (may exceed kCfgCap)
 };
 bool launch_sweep(const SweepArgs& a, void* stream);
+// K6w (jit_sweep_wg.hip): the first pass with `waves` (4 / 8) wavefronts per segment; false = not for this batch (the caller takes K6)
+bool launch_sweep_wg(const SweepArgs& a, uint32_t waves, void* stream);
 
 void launch_pack_open(const PackOpenArgs& a, void* stream);
 // open_counts_kernel alone: how many entries each history's per-front lists hold (BeamHist.lst_need), before those arenas exist

@@ -33,10 +33,12 @@ void run_all(const SweepArgs& A, uint32_t n_wg, uint64_t seed) {
 
 extern "C" {
 
-// ONE history; out: max_segs * 4 tbc_sweep_rel records (zeroed here first)
+// ONE history; out: max_segs * 4 tbc_sweep_rel records (zeroed here first) -- or, with seg_list (n_list (0, segment, slice) triples: the
+// second pass over segments that overflowed), the first pass's records, of which only the listed ones are swept again
 int emu_sweep_wg_run(uint32_t n, uint32_t n_process, const uint8_t* f, const int32_t* a, const int32_t* b, const int32_t* process,
                      const uint32_t* inv_pos, const uint32_t* ret_pos, uint32_t model_kind, int32_t init, uint32_t vpad, uint32_t rules,
-                     uint32_t n_dom, uint32_t seg_target, uint32_t max_segs, uint32_t NW, uint32_t CAP, uint64_t seed, SegResult* out) {
+                     uint32_t n_dom, uint32_t seg_target, uint32_t max_segs, uint32_t NW, uint32_t CAP, uint64_t seed, const uint32_t* seg_list, uint32_t n_list,
+                     SegResult* out) {
   Tables T;
   const uint64_t op_off[2] = {0, n};
   if (!build_tables(1, op_off, &n_process, f, a, b, process, inv_pos, ret_pos, 1, vpad, 1, false, false, T)) return 1;
@@ -63,14 +65,14 @@ int emu_sweep_wg_run(uint32_t n, uint32_t n_process, const uint8_t* f, const int
     }
     cuts[k] = cut;
   }
-  memset(out, 0, sizeof(SegResult) * (size_t)max_segs * kSweepSlices);
+  if (!seg_list) memset(out, 0, sizeof(SegResult) * (size_t)max_segs * kSweepSlices);
   SweepArgs A{};
   A.hist = T.hist.data(); A.bh = T.bh.data(); A.off = T.off.data(); A.ncr = T.ncr.data(); A.lst = T.lst.data(); A.crashed = T.crashed.data();
   A.twn = (rules & kRuleTwin) ? T.twn.data() : nullptr; A.rdm = (rules & kRuleEager) ? rows.data() : nullptr; A.slot8 = T.slot8.data();
   A.cuts = cuts.data(); A.seg = out; A.table = nullptr; A.pool_vals = nullptr; A.n_hist = 1; A.max_segs = max_segs; A.seg_target = seg_target;
   A.cut_open = cut_open; A.n_dom = n_dom; A.vpad = vpad ? vpad : 1; A.rules = rules; A.model_kind = model_kind; A.init_state = init;
-  A.shard_rank = 0; A.shard_world = 1; A.seg_list = nullptr; A.dump_cfg = nullptr; A.dump_count = nullptr;
-  const uint32_t n_wg = max_segs * kSweepSlices;
+  A.shard_rank = 0; A.shard_world = 1; A.seg_list = seg_list; A.n_list = n_list; A.dump_cfg = nullptr; A.dump_count = nullptr;
+  const uint32_t n_wg = seg_list ? n_list : max_segs * kSweepSlices;
 #define RUN(C_, W_) if (CAP == C_ && NW == W_) { run_all<C_, W_>(A, n_wg, seed); return 0; }
   RUN(1024, 2) RUN(1024, 4) RUN(1024, 8) RUN(512, 4) RUN(2048, 8)
 #undef RUN
