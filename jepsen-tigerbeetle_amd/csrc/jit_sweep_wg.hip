@@ -2,6 +2,7 @@
 // is jit_sweep_wg_impl.h.  Same inputs, same records as jit_sweep_kernel (jit_sweep.hip), which keeps the dump pass and every
 // model outside the register family.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "tbc_internal.h"
 #include "jit_sweep_wg_impl.h"
 
@@ -13,6 +14,12 @@ template <uint32_t CAP, uint32_t NW>
 __global__ __launch_bounds__(64 * NW) void jit_sweep_wg_kernel(SweepArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   sweepwg::segment<CAP, NW>(A, lds);
+}
+// the experimental ring form (jit_sweep_wg_impl.h, QUEUE): a kernel of its own so that the one above stays exactly what was measured
+template <uint32_t CAP, uint32_t NW>
+__global__ __launch_bounds__(64 * NW) void jit_sweep_wg_ring_kernel(SweepArgs A) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  sweepwg::segment<CAP, NW, true>(A, lds);
 }
 
 template <uint32_t CAP, uint32_t NW>
@@ -26,6 +33,16 @@ bool launch_one(const SweepArgs& a, hipStream_t s) {
   return true;
 }
 
+template <uint32_t CAP, uint32_t NW>
+bool launch_ring(const SweepArgs& a, hipStream_t s) {
+  constexpr uint32_t bytes = sweepwg::lds_words<CAP, NW, true>() * 4;
+  static bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&jit_sweep_wg_ring_kernel<CAP, NW>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
+  if (!ok) return false;
+  hipLaunchKernelGGL((jit_sweep_wg_ring_kernel<CAP, NW>), dim3(a.n_hist * a.max_segs * kSweepSlices), dim3(64 * NW), bytes, s, a);
+  return true;
+}
+
 }  // namespace
 
 // the first pass of the sweep (cuts are in place): `waves` wavefronts per workgroup, sets of kSweepCapMid configs (78 KB of LDS
@@ -35,6 +52,10 @@ bool launch_sweep_wg(const SweepArgs& a, uint32_t waves, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (!(a.model_kind == TBC_MODEL_REGISTER || a.model_kind == TBC_MODEL_CAS_REGISTER) || a.dump_cfg) return false;
   if (a.seg_list) return launch_one<kSweepCapBig, 8>(a, s);
+  // TBC_SWEEP_WG_RING=1: the first pass in the ring form (89 KB of LDS: one workgroup per CU).  Verified under the emulator only
+  // (tests/test_sweep_wg_emu.py); nothing takes it unless asked
+  static const bool ring = [] { const char* e = std::getenv("TBC_SWEEP_WG_RING"); return e && e[0] == '1'; }();
+  if (ring && waves == 8) return launch_ring<kSweepCapMid, 8>(a, s);
   if (waves == 4) return launch_one<kSweepCapMid, 4>(a, s);
   if (waves == 8) return launch_one<kSweepCapMid, 8>(a, s);
   return false;

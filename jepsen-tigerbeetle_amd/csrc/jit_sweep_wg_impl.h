@@ -59,9 +59,11 @@ struct Scratch {
   static constexpr uint32_t kWords = 8 * NW + 8;
 };
 
-template <uint32_t CAP, uint32_t NW>
+// QUEUE (experimental, see segment): + a ring of 2 x 64 x NW children (16 B each) and their target sets (a byte each)
+template <uint32_t CAP, uint32_t NW, bool QUEUE = false>
 constexpr uint32_t lds_words() {
-  return 3 * CAP * 4 + 2 * (2 * CAP) + 64 * NW * 4 + kCand * 4 + kCand * 2 + 2 * 32 * 2 + CAP / 2 + 128 + Scratch<NW>::kWords;
+  return 3 * CAP * 4 + 2 * (2 * CAP) + 64 * NW * 4 + kCand * 4 + kCand * 2 + 2 * 32 * 2 + CAP / 2 + 128 + Scratch<NW>::kWords +
+         (QUEUE ? 2 * 64 * NW * 4 + 2 * 64 * NW / 4 : 0u);
 }
 
 WV_DEV uint64_t mask_of(const Ent& e) { return (uint64_t)e.mlo | ((uint64_t)e.mhi << 32); }
@@ -169,8 +171,72 @@ WV_DEV bool insert2(Build& A, Build& B, uint32_t sel, uint32_t mlo, uint32_t mhi
   return fits;
 }
 
-// One workgroup: segment k of history h, origins 32 * sl .. 32 * sl + 31 (as one wavefront of K6).
+// QUEUE: insert `cnt` (<= 64 * NW, the same in every thread) children from the ring, starting at qh: they are staged where they lie
+// (one barrier makes them visible), a claim carries the RING position.
 template <uint32_t CAP, uint32_t NW>
+WV_DEV bool insert_q(Build& A, Build& B, Ent* wq, const uint8_t* wq_sel, uint32_t qh, uint32_t cnt, Ctx<NW>& X) {
+  using S = Scratch<NW>;
+  constexpr uint32_t HS = 2 * CAP, QM = 2 * 64 * NW - 1;
+  wv::wg_barrier();                                           // the children the passes wrote into the ring are visible
+  const uint32_t at = (qh + X.tid) & QM;
+  const Ent c = wq[at];
+  const uint32_t sel = X.tid < cnt ? (uint32_t)wq_sel[at] : 0u;
+  const uint32_t mlo = c.mlo, mhi = c.mhi, st = c.st, org = c.org;
+  uint32_t* const tab = sel == 2u ? B.tab : A.tab;
+  Ent* const ent = sel == 2u ? B.e : A.e;
+  const uint32_t gen = sel == 2u ? B.gen : A.gen, gtag = gen << kGenShift;
+  uint32_t h = key_slot<HS>(mlo, mhi, st), mine = 0;
+  bool pend = sel != 0u, won = false;
+  while (wv::ballot(pend)) {
+    if (pend) {
+      uint32_t s = wv::lds_ld32(&tab[h]);
+      if ((s >> kGenShift) != gen) {
+        const uint32_t old = wv::lds_cas32(&tab[h], s, gtag | kProv | at);
+        if (old == s) { won = true; mine = h; pend = false; }
+        else s = old;
+      }
+      if (pend) {
+        const Ent* kp = (s & kProv) ? &wq[s & QM] : &ent[s & 0xFFFFu];
+        if (kp->mlo == mlo && kp->mhi == mhi && kp->st == st) {
+          wv::lds_or32(const_cast<uint32_t*>(&kp->org), org);
+          pend = false;
+        } else {
+          h = (h + 1u) & (HS - 1u);
+        }
+      }
+    }
+  }
+  const uint64_t wa = wv::ballot(won && sel == 1u), wb = wv::ballot(won && sel == 2u);
+  if (X.lane == 0) {
+    X.ws[S::kTot + 2 * X.wave] = (uint32_t)__builtin_popcountll(wa);
+    X.ws[S::kTot + 2 * X.wave + 1] = (uint32_t)__builtin_popcountll(wb);
+  }
+  wv::wg_barrier();                                           // every claim and every OR is done; the winner counts are visible
+  uint32_t offa = A.n, offb = B.n, ta = A.n, tb = B.n;
+  WV_UNROLL
+  for (uint32_t w = 0; w < NW; w++) {
+    const uint32_t ca = X.ws[S::kTot + 2 * w], cb = X.ws[S::kTot + 2 * w + 1];
+    if (w < X.wave) { offa += ca; offb += cb; }
+    ta += ca; tb += cb;
+  }
+  const bool fits = ta <= CAP && tb <= CAP;
+  if (won && fits) {
+    const uint64_t below = (1ull << X.lane) - 1ull;
+    const uint32_t idx = sel == 2u ? offb + (uint32_t)__builtin_popcountll(wb & below) : offa + (uint32_t)__builtin_popcountll(wa & below);
+    ent[idx] = Ent{mlo, mhi, st, wq[at].org};
+    tab[mine] = gtag | idx;
+  }
+  if (fits) { A.n = ta; B.n = tb; }
+  wv::wg_barrier();                                           // entries committed; the ring positions are free, the counts may be written again
+  return fits;
+}
+
+// One workgroup: segment k of history h, origins 32 * sl .. 32 * sl + 31 (as one wavefront of K6).
+// QUEUE (experimental, off in every launch of round 4: verified under the emulator only, not yet measured): a sub-round's passes
+// put their children into a ring in LDS (one barrier per pass of 64 * NW pairs) and the insertion -- the expensive half, three
+// barriers in the plain form -- runs only when 64 * NW children are waiting: about a third of the pairs of a burst yield a child,
+// so a third as many insertions, each with every lane busy.  Costs 17 KB of LDS at NW = 8 (one workgroup per CU instead of two).
+template <uint32_t CAP, uint32_t NW, bool QUEUE = false>
 WV_DEV void segment(const SweepArgs& A, uint32_t* lds) {
   static_assert(64 * NW >= kCand, "a level's open calls are parked one per thread");
   static_assert(64 * NW <= 1024 && CAP <= 0x8000u, "thread numbers and entry numbers share a table word");
@@ -220,6 +286,9 @@ WV_DEV void segment(const SweepArgs& A, uint32_t* lds) {
   uint16_t* expl = reinterpret_cast<uint16_t*>(row_b + 32);   // entries of `cur` that still need X
   uint32_t* Mrel = reinterpret_cast<uint32_t*>(expl + CAP);   // 32 x 4 words: origin -> origin ids of the next segment
   X.ws = Mrel + 128;
+  Ent* wq = nullptr;
+  uint8_t* wq_sel = nullptr;
+  if constexpr (QUEUE) { wq = reinterpret_cast<Ent*>(X.ws + S::kWords); wq_sel = reinterpret_cast<uint8_t*>(wq + 2 * T); }
   for (uint32_t i = tid; i < 2 * HS; i += T) tab_nxt[i] = 0u;
   for (uint32_t i = tid; i < 128u; i += T) Mrel[i] = 0u;
   for (uint32_t i = tid; i < S::kWords; i += T) X.ws[i] = 0u;
@@ -363,24 +432,87 @@ WV_DEV void segment(const SweepArgs& A, uint32_t* lds) {
       subrounds++;
       build_begin<HS, NW>(q, dst_e, tab_q, gen_q, X);
       const uint32_t total = n_src << gshift;
-      for (uint32_t base = 0; base < total && status == kSegOk; base += T) {
-        const uint32_t r = base + tid, ci = r >> gshift, kc = r & ((1u << gshift) - 1u);
-        const bool val = r < total && kc < C;
-        const Ent e = val ? src[via_list ? (uint32_t)expl[ci] : ci] : Ent{0, 0, 0, 0};
-        const OpRec y = val ? cand[kc] : OpRec{0, kFNone, 0, 0};
-        const uint64_t tw = val ? cand_tw[kc] : 0ull;
-        const uint64_t m = mask_of(e);
-        const uint32_t yf = y.f_slot & 0xFFu, ys = (y.f_slot >> 8) & 63u;
-        const int32_t st = (int32_t)e.st;
-        const bool viable = val && !((m >> ys) & 1ull) && !(eager && yf == TBC_F_READ) && (tw & ~m) == 0ull && reg_ok(st, yf, y.a);
-        probes += (uint64_t)__builtin_popcountll(wv::ballot(viable));
-        const int32_t st2 = viable ? reg_apply(st, yf, y.a, y.b) : st;
-        uint64_t m2 = m | (1ull << ys);
-        if (eager) m2 |= row_a[0] | row_a[rdm_index(st2, V)];
-        const bool has = viable && (m2 & xbit) != 0ull;
-        if (has) { m2 &= ~xbit; if (eager) m2 |= row_b[0] | row_b[rdm_index(st2, V)]; }
-        const uint32_t sel = viable ? (has ? 1u : 2u) : 0u;
-        if (!insert2<CAP, NW>(nxt, q, sel, (uint32_t)m2, (uint32_t)(m2 >> 32), (uint32_t)st2, e.org, false, so_, st_, X)) status = kSegOverflow;
+      if constexpr (!QUEUE) {
+        for (uint32_t base = 0; base < total && status == kSegOk; base += T) {
+          const uint32_t r = base + tid, ci = r >> gshift, kc = r & ((1u << gshift) - 1u);
+          const bool val = r < total && kc < C;
+          const Ent e = val ? src[via_list ? (uint32_t)expl[ci] : ci] : Ent{0, 0, 0, 0};
+          const OpRec y = val ? cand[kc] : OpRec{0, kFNone, 0, 0};
+          const uint64_t tw = val ? cand_tw[kc] : 0ull;
+          const uint64_t m = mask_of(e);
+          const uint32_t yf = y.f_slot & 0xFFu, ys = (y.f_slot >> 8) & 63u;
+          const int32_t st = (int32_t)e.st;
+          const bool viable = val && !((m >> ys) & 1ull) && !(eager && yf == TBC_F_READ) && (tw & ~m) == 0ull && reg_ok(st, yf, y.a);
+          probes += (uint64_t)__builtin_popcountll(wv::ballot(viable));
+          const int32_t st2 = viable ? reg_apply(st, yf, y.a, y.b) : st;
+          uint64_t m2 = m | (1ull << ys);
+          if (eager) m2 |= row_a[0] | row_a[rdm_index(st2, V)];
+          const bool has = viable && (m2 & xbit) != 0ull;
+          if (has) { m2 &= ~xbit; if (eager) m2 |= row_b[0] | row_b[rdm_index(st2, V)]; }
+          const uint32_t sel = viable ? (has ? 1u : 2u) : 0u;
+          if (!insert2<CAP, NW>(nxt, q, sel, (uint32_t)m2, (uint32_t)(m2 >> 32), (uint32_t)st2, e.org, false, so_, st_, X)) status = kSegOverflow;
+        }
+      } else if (total <= T) {                         // (one pass: nothing to gather -- the plain form, as above)
+        for (uint32_t base = 0; base < total && status == kSegOk; base += T) {
+          const uint32_t r = base + tid, ci = r >> gshift, kc = r & ((1u << gshift) - 1u);
+          const bool val = r < total && kc < C;
+          const Ent e = val ? src[via_list ? (uint32_t)expl[ci] : ci] : Ent{0, 0, 0, 0};
+          const OpRec y = val ? cand[kc] : OpRec{0, kFNone, 0, 0};
+          const uint64_t tw = val ? cand_tw[kc] : 0ull;
+          const uint64_t m = mask_of(e);
+          const uint32_t yf = y.f_slot & 0xFFu, ys = (y.f_slot >> 8) & 63u;
+          const int32_t st = (int32_t)e.st;
+          const bool viable = val && !((m >> ys) & 1ull) && !(eager && yf == TBC_F_READ) && (tw & ~m) == 0ull && reg_ok(st, yf, y.a);
+          probes += (uint64_t)__builtin_popcountll(wv::ballot(viable));
+          const int32_t st2 = viable ? reg_apply(st, yf, y.a, y.b) : st;
+          uint64_t m2 = m | (1ull << ys);
+          if (eager) m2 |= row_a[0] | row_a[rdm_index(st2, V)];
+          const bool has = viable && (m2 & xbit) != 0ull;
+          if (has) { m2 &= ~xbit; if (eager) m2 |= row_b[0] | row_b[rdm_index(st2, V)]; }
+          const uint32_t sel = viable ? (has ? 1u : 2u) : 0u;
+          if (!insert2<CAP, NW>(nxt, q, sel, (uint32_t)m2, (uint32_t)(m2 >> 32), (uint32_t)st2, e.org, false, so_, st_, X)) status = kSegOverflow;
+        }
+      } else {
+        uint32_t qh = 0, qn = 0, pass_no = 0;          // ring head and count (the same in every thread), passes so far
+        for (uint32_t base = 0; base < total && status == kSegOk; base += T) {
+          const uint32_t r = base + tid, ci = r >> gshift, kc = r & ((1u << gshift) - 1u);
+          const bool val = r < total && kc < C;
+          const Ent e = val ? src[via_list ? (uint32_t)expl[ci] : ci] : Ent{0, 0, 0, 0};
+          const OpRec y = val ? cand[kc] : OpRec{0, kFNone, 0, 0};
+          const uint64_t tw = val ? cand_tw[kc] : 0ull;
+          const uint64_t m = mask_of(e);
+          const uint32_t yf = y.f_slot & 0xFFu, ys = (y.f_slot >> 8) & 63u;
+          const int32_t st = (int32_t)e.st;
+          const bool viable = val && !((m >> ys) & 1ull) && !(eager && yf == TBC_F_READ) && (tw & ~m) == 0ull && reg_ok(st, yf, y.a);
+          const uint64_t vb = wv::ballot(viable);
+          probes += (uint64_t)__builtin_popcountll(vb);
+          const int32_t st2 = viable ? reg_apply(st, yf, y.a, y.b) : st;
+          uint64_t m2 = m | (1ull << ys);
+          if (eager) m2 |= row_a[0] | row_a[rdm_index(st2, V)];
+          const bool has = viable && (m2 & xbit) != 0ull;
+          if (has) { m2 &= ~xbit; if (eager) m2 |= row_b[0] | row_b[rdm_index(st2, V)]; }
+          // ring positions: the wavefronts' child counts through LDS (by pass parity), one barrier; the children are written after
+          // it and read only behind insert_q's own barrier
+          const uint32_t pp = (pass_no++ & 1u) * NW;
+          if (lane == 0) X.ws[S::kSide + pp + X.wave] = (uint32_t)__builtin_popcountll(vb);
+          wv::wg_barrier();
+          uint32_t before = 0, all = 0;
+          WV_UNROLL
+          for (uint32_t w2 = 0; w2 < NW; w2++) { const uint32_t c2 = X.ws[S::kSide + pp + w2]; if (w2 < X.wave) before += c2; all += c2; }
+          if (viable) {
+            const uint32_t pos = (qh + qn + before + (uint32_t)__builtin_popcountll(vb & ((1ull << lane) - 1ull))) & (2 * T - 1u);
+            wq[pos] = Ent{(uint32_t)m2, (uint32_t)(m2 >> 32), (uint32_t)st2, e.org};
+            wq_sel[pos] = has ? (uint8_t)1 : (uint8_t)2;
+          }
+          qn += all;
+          while (qn >= T && status == kSegOk) {
+            if (!insert_q<CAP, NW>(nxt, q, wq, wq_sel, qh, T, X)) status = kSegOverflow;
+            qh = (qh + T) & (2 * T - 1u); qn -= T;
+          }
+        }
+        if (qn != 0 && status == kSegOk) {                     // what is left in the ring
+          if (!insert_q<CAP, NW>(nxt, q, wq, wq_sel, qh, qn, X)) status = kSegOverflow;
+        }
       }
       src = q.e; n_src = q.n; via_list = false;
       { Ent* t = dst_e; dst_e = dst_other; dst_other = t; }

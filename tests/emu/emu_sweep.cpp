@@ -14,18 +14,18 @@ using namespace tbc;
 namespace {
 
 struct Call { const SweepArgs* A; uint32_t* lds; };
-template <uint32_t CAP, uint32_t NW>
+template <uint32_t CAP, uint32_t NW, bool QUEUE>
 void entry(void* p, uint32_t) {
   auto* c = (Call*)p;
-  sweepwg::segment<CAP, NW>(*c->A, c->lds);
+  sweepwg::segment<CAP, NW, QUEUE>(*c->A, c->lds);
 }
-template <uint32_t CAP, uint32_t NW>
+template <uint32_t CAP, uint32_t NW, bool QUEUE = false>
 void run_all(const SweepArgs& A, uint32_t n_wg, uint64_t seed) {
-  std::vector<uint32_t> lds(sweepwg::lds_words<CAP, NW>() + 16);
+  std::vector<uint32_t> lds(sweepwg::lds_words<CAP, NW, QUEUE>() + 16);
   for (uint32_t w = 0; w < n_wg; w++) {
     std::fill(lds.begin(), lds.end(), 0xDEADBEEFu);          // LDS is not zeroed on the device either
     Call c{&A, lds.data()};
-    wv::run_workgroup(&entry<CAP, NW>, &c, (int)NW, w, seed + w);
+    wv::run_workgroup(&entry<CAP, NW, QUEUE>, &c, (int)NW, w, seed + w);
   }
 }
 
@@ -33,11 +33,13 @@ void run_all(const SweepArgs& A, uint32_t n_wg, uint64_t seed) {
 
 extern "C" {
 
+void emu_sweep_stats(uint64_t* out, int reset) { for (int i = 0; i < 64; i++) { out[i] = wv::stats()[i]; if (reset) wv::stats()[i] = 0; } }
+
 // ONE history; out: max_segs * 4 tbc_sweep_rel records (zeroed here first) -- or, with seg_list (n_list (0, segment, slice) triples: the
 // second pass over segments that overflowed), the first pass's records, of which only the listed ones are swept again
 int emu_sweep_wg_run(uint32_t n, uint32_t n_process, const uint8_t* f, const int32_t* a, const int32_t* b, const int32_t* process,
                      const uint32_t* inv_pos, const uint32_t* ret_pos, uint32_t model_kind, int32_t init, uint32_t vpad, uint32_t rules,
-                     uint32_t n_dom, uint32_t seg_target, uint32_t max_segs, uint32_t NW, uint32_t CAP, uint64_t seed, const uint32_t* seg_list, uint32_t n_list,
+                     uint32_t n_dom, uint32_t seg_target, uint32_t max_segs, uint32_t NW, uint32_t CAP, uint32_t queue, uint64_t seed, const uint32_t* seg_list, uint32_t n_list,
                      SegResult* out) {
   Tables T;
   const uint64_t op_off[2] = {0, n};
@@ -73,9 +75,12 @@ int emu_sweep_wg_run(uint32_t n, uint32_t n_process, const uint8_t* f, const int
   A.cut_open = cut_open; A.n_dom = n_dom; A.vpad = vpad ? vpad : 1; A.rules = rules; A.model_kind = model_kind; A.init_state = init;
   A.shard_rank = 0; A.shard_world = 1; A.seg_list = seg_list; A.n_list = n_list; A.dump_cfg = nullptr; A.dump_count = nullptr;
   const uint32_t n_wg = seg_list ? n_list : max_segs * kSweepSlices;
-#define RUN(C_, W_) if (CAP == C_ && NW == W_) { run_all<C_, W_>(A, n_wg, seed); return 0; }
+#define RUN(C_, W_) if (CAP == C_ && NW == W_ && !queue) { run_all<C_, W_>(A, n_wg, seed); return 0; }
   RUN(1024, 2) RUN(1024, 4) RUN(1024, 8) RUN(512, 4) RUN(2048, 8)
 #undef RUN
+#define RUNQ(C_, W_) if (CAP == C_ && NW == W_ && queue) { run_all<C_, W_, true>(A, n_wg, seed); return 0; }
+  RUNQ(1024, 2) RUNQ(1024, 4) RUNQ(1024, 8) RUNQ(512, 4) RUNQ(2048, 8)
+#undef RUNQ
   return 2;
 }
 

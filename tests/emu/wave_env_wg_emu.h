@@ -20,6 +20,7 @@ inline uint32_t wg_index() { return WG()->index; }
 inline uint32_t lds_ld32(const uint32_t* p) { return *p; }
 inline uint32_t lds_cas32(uint32_t* p, uint32_t expected, uint32_t desired) { const uint32_t old = *p; if (old == expected) *p = desired; return old; }
 inline void lds_or32(uint32_t* p, uint32_t v) { *p |= v; }
+inline uint32_t lds_fetch_add32(uint32_t* p, uint32_t v) { const uint32_t old = *p; *p += v; return old; }
 inline uint32_t wave_or32_at(uint32_t v, int site) {
   const uint64_t* s = gather(v, site);
   uint32_t r = 0;
@@ -51,6 +52,7 @@ inline void run_workgroup(void (*fn)(void*, uint32_t), void* arg, int nw, uint32
     g.wave[w] = e;
   }
   bool blocked[32] = {}, finished[32] = {};
+  uint64_t n_barriers = 0;                 // workgroup barriers passed (stats 40: the most of any workgroup so far, 41: their sum)
   int bsite[32] = {};
   uint64_t rng = seed * 0x9E3779B97F4A7C15ull + 0x1234567ull;
   for (;;) {
@@ -113,10 +115,13 @@ inline void run_workgroup(void (*fn)(void*, uint32_t), void* arg, int nw, uint32
       if (!any) break;
       for (int w = 0; w < nw; w++) blocked[w] = false;
       progressed = true;
+      n_barriers++;
     }
     if (!progressed) { fprintf(stderr, "emu: workgroup made no progress\n"); abort(); }
   }
   for (int w = 0; w < nw; w++) { free(g.wave[w]->stacks); delete g.wave[w]; }
+  if (n_barriers > stats()[40]) stats()[40] = n_barriers;
+  stats()[41] += n_barriers;
   W() = nullptr;
   WG() = nullptr;
 }

@@ -20,7 +20,7 @@ def _records(buf):
     return np.frombuffer(buf, dtype=np.uint8).reshape(-1, C.sizeof(N.SweepRel))
 
 
-def _compare(ops, seg_target, n_dom, waves, cap=1024, rules=None, seed=1, expect_overflow=False, second_pass=False):
+def _compare(ops, seg_target, n_dom, waves, cap=1024, rules=None, seed=1, expect_overflow=False, second_pass=False, queue=False):
     d = ops.as_dict()
     R = int((np.asarray(d["ret_pos"]) != 0xFFFFFFFF).sum())
     max_segs = max(1, min(512, (R + seg_target - 1) // seg_target)) if seg_target else 1
@@ -32,7 +32,7 @@ def _compare(ops, seg_target, n_dom, waves, cap=1024, rules=None, seed=1, expect
         wgl.check_sweep(d, CAS, eager_reads=eager, twin_rule=twin, seg_target=seg_target, n_dom=n_dom)
     finally:
         L.sweep_set_export(None, C.c_uint32(0), C.c_uint32(0), C.c_uint32(1))
-    got = emu.sweep_wg(d, 1, N.NIL, seg_target, n_dom, max_segs, waves=waves, cap=cap, rules=None if rules is None else (3 if rules else 0), seed=seed)
+    got = emu.sweep_wg(d, 1, N.NIL, seg_target, n_dom, max_segs, waves=waves, cap=cap, rules=None if rules is None else (3 if rules else 0), seed=seed, queue=queue)
     want = [N.SweepRel.from_buffer_copy(r.tobytes()) for r in _records(buf)]
     have = [N.SweepRel.from_buffer_copy(r.tobytes()) for r in _records(got)]
     if second_pass:      # the segments that overflowed, once more with sets of 2,048 configs and eight wavefronts (what launch_sweep does)
@@ -120,3 +120,27 @@ def test_overflow_is_reported_not_mis_swept():
     assert max(ref["max_level"], ref["max_pending"]) > 512
     _compare(h, 32, 6, 4, cap=512, expect_overflow=True)
     _compare(h, 32, 6, 4, cap=512, expect_overflow=True, second_pass=True)        # ... and the second pass makes every record the oracle's
+
+
+@pytest.mark.parametrize("waves", [2, 8])
+def test_the_ring_variant_every_record(waves):
+    """QUEUE (jit_sweep_wg_impl.h; experimental, no launch of round 4 takes it): a sub-round's children wait in a ring and are inserted a
+    full workgroup at a time -- the same records"""
+    n = 0
+    for seed in range(4):
+        for corrupt in (0.0, 0.4):
+            h = columns.pair_events(synth.register_events(n_ops=300, n_procs=8, seed=100 + seed, busy=0.5, info=0.0, corrupt=corrupt))
+            n += _compare(h, 32, 6, waves, seed=seed, queue=True)
+    assert n > 12
+    h = columns.pair_events(synth.register_events(n_ops=300, n_procs=8, seed=58, busy=0.4, info=0.015, corrupt=0.0))      # crashed calls
+    _compare(h, 32, 6, waves, queue=True)
+
+
+def test_the_ring_variant_on_a_bench_history_under_several_interleavings():
+    h = synth.register_ops_many([3], n_ops=10000, n_procs=64, busy=0.1, info=0.0)[0]
+    assert _compare(h, 32, 6, 8, queue=True) > 250
+    h = columns.pair_events(synth.register_events(n_ops=600, n_procs=16, seed=7, busy=0.5, info=0.0, corrupt=0.0))
+    for seed in range(6):
+        _compare(h, 32, 6, 8, seed=2000 + 13 * seed, queue=True)
+    h4 = synth.register_ops_many([4], n_ops=10000, n_procs=64, busy=0.1, info=0.0)[0]
+    _compare(h4, 32, 6, 4, cap=512, expect_overflow=True, queue=True)
