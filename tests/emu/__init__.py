@@ -38,7 +38,7 @@ def build(force=False):
     return _SO
 
 
-_SO_WALK = os.path.join(_HERE, "_build", "libemu_walk.so")
+_SO_WALK = os.path.join(_HERE, "_build", "libemu_walk_asan.so" if _ASAN else "libemu_walk.so")
 _LIB_WALK = None
 
 
@@ -47,8 +47,9 @@ def build_walk(force=False):
             os.path.join(_CSRC, "open_walk_impl.h"), os.path.join(_CSRC, "tbc_internal.h"), os.path.join(_CSRC, "wave_env.h")]
     if force or not os.path.exists(_SO_WALK) or any(os.path.getmtime(s) > os.path.getmtime(_SO_WALK) for s in srcs):
         os.makedirs(os.path.dirname(_SO_WALK), exist_ok=True)
-        subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas",
-                               "-I", _HERE, "-I", _CSRC, "-o", _SO_WALK, srcs[0]])
+        subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas"]
+                              + (["-fsanitize=address", "-fno-omit-frame-pointer"] if _ASAN else [])
+                              + ["-I", _HERE, "-I", _CSRC, "-o", _SO_WALK, srcs[0]])
     return _SO_WALK
 
 
