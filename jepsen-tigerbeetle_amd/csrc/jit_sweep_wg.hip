@@ -16,10 +16,16 @@ __global__ __launch_bounds__(64 * NW) void jit_sweep_wg_kernel(SweepArgs A) {
   sweepwg::segment<CAP, NW>(A, lds);
 }
 // the experimental ring form (jit_sweep_wg_impl.h, QUEUE): a kernel of its own so that the one above stays exactly what was measured
-template <uint32_t CAP, uint32_t NW>
+template <uint32_t CAP, uint32_t NW, bool FP = false>
 __global__ __launch_bounds__(64 * NW) void jit_sweep_wg_ring_kernel(SweepArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-  sweepwg::segment<CAP, NW, true>(A, lds);
+  sweepwg::segment<CAP, NW, true, FP>(A, lds);
+}
+// ... and the fingerprint form of the plain sweep (FP)
+template <uint32_t CAP, uint32_t NW>
+__global__ __launch_bounds__(64 * NW) void jit_sweep_wg_fp_kernel(SweepArgs A) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  sweepwg::segment<CAP, NW, false, true>(A, lds);
 }
 
 template <uint32_t CAP, uint32_t NW>
@@ -33,13 +39,22 @@ bool launch_one(const SweepArgs& a, hipStream_t s) {
   return true;
 }
 
-template <uint32_t CAP, uint32_t NW>
+template <uint32_t CAP, uint32_t NW, bool FP>
 bool launch_ring(const SweepArgs& a, hipStream_t s) {
   constexpr uint32_t bytes = sweepwg::lds_words<CAP, NW, true>() * 4;
-  static bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&jit_sweep_wg_ring_kernel<CAP, NW>),
+  static bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&jit_sweep_wg_ring_kernel<CAP, NW, FP>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
   if (!ok) return false;
-  hipLaunchKernelGGL((jit_sweep_wg_ring_kernel<CAP, NW>), dim3(a.n_hist * a.max_segs * kSweepSlices), dim3(64 * NW), bytes, s, a);
+  hipLaunchKernelGGL((jit_sweep_wg_ring_kernel<CAP, NW, FP>), dim3(a.n_hist * a.max_segs * kSweepSlices), dim3(64 * NW), bytes, s, a);
+  return true;
+}
+template <uint32_t CAP, uint32_t NW>
+bool launch_fp(const SweepArgs& a, hipStream_t s) {
+  constexpr uint32_t bytes = sweepwg::lds_words<CAP, NW>() * 4;
+  static bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&jit_sweep_wg_fp_kernel<CAP, NW>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
+  if (!ok) return false;
+  hipLaunchKernelGGL((jit_sweep_wg_fp_kernel<CAP, NW>), dim3(a.n_hist * a.max_segs * kSweepSlices), dim3(64 * NW), bytes, s, a);
   return true;
 }
 
@@ -54,8 +69,11 @@ bool launch_sweep_wg(const SweepArgs& a, uint32_t waves, void* stream) {
   if (a.seg_list) return launch_one<kSweepCapBig, 8>(a, s);
   // TBC_SWEEP_WG_RING=1: the first pass in the ring form (89 KB of LDS: one workgroup per CU).  Verified under the emulator only
   // (tests/test_sweep_wg_emu.py); nothing takes it unless asked
+  // TBC_SWEEP_WG_FP=1: a fingerprint of the key in the table word (with or without the ring).  The same standing.
   static const bool ring = [] { const char* e = std::getenv("TBC_SWEEP_WG_RING"); return e && e[0] == '1'; }();
-  if (ring && waves == 8) return launch_ring<kSweepCapMid, 8>(a, s);
+  static const bool fpr = [] { const char* e = std::getenv("TBC_SWEEP_WG_FP"); return e && e[0] == '1'; }();
+  if (ring && waves == 8) return fpr ? launch_ring<kSweepCapMid, 8, true>(a, s) : launch_ring<kSweepCapMid, 8, false>(a, s);
+  if (fpr && waves == 8) return launch_fp<kSweepCapMid, 8>(a, s);
   if (waves == 4) return launch_one<kSweepCapMid, 4>(a, s);
   if (waves == 8) return launch_one<kSweepCapMid, 8>(a, s);
   return false;

@@ -30,6 +30,9 @@ namespace sweepwg {
 constexpr uint32_t kCand = kSweepCandMax;
 constexpr uint32_t kProv = 1u << 16;          // slot holds a thread number (this pass's claimant), not an entry
 constexpr uint32_t kGenShift = 17;
+// FP (experimental, see segment): the table word also carries 8 bits of the key's hash -- [generation 7][fingerprint 8][provisional 1][entry 16]
+constexpr uint32_t kGenShiftFp = 25, kFpShift = 17;
+template <bool FP> constexpr uint32_t gen_shift() { return FP ? kGenShiftFp : kGenShift; }
 
 struct __attribute__((aligned(16))) Ent { uint32_t mlo, mhi, st, org; };
 
@@ -38,6 +41,12 @@ WV_DEV uint32_t key_slot(uint32_t mlo, uint32_t mhi, uint32_t st) {
   uint32_t h = mlo * 0x9E3779B1u ^ mhi * 0x85EBCA77u ^ st * 0xC2B2AE3Du;
   h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 13;
   return h & (HS - 1u);
+}
+// FP: the same hash whole -- the slot from its low bits, the fingerprint from its top eight
+WV_DEV uint32_t key_hash(uint32_t mlo, uint32_t mhi, uint32_t st) {
+  uint32_t h = mlo * 0x9E3779B1u ^ mhi * 0x85EBCA77u ^ st * 0xC2B2AE3Du;
+  h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 13;
+  return h;
 }
 
 struct Build {
@@ -82,10 +91,10 @@ struct Ctx {
 };
 
 // Start a new set in table `tab`: a new generation makes every old slot read as empty.
-template <uint32_t HS, uint32_t NW>
+template <uint32_t HS, uint32_t NW, bool FP = false>
 WV_DEV void build_begin(Build& b, Ent* e, uint32_t* tab, uint32_t& gen_counter, const Ctx<NW>& X) {
   gen_counter++;
-  if (gen_counter >= (1u << (32 - kGenShift))) {       // generation wrapped: really clear
+  if (gen_counter >= (1u << (32 - gen_shift<FP>()))) {       // generation wrapped: really clear
     for (uint32_t i = X.tid; i < HS; i += 64 * NW) tab[i] = 0u;
     gen_counter = 1;
     wv::wg_barrier();
@@ -96,7 +105,7 @@ WV_DEV void build_begin(Build& b, Ent* e, uint32_t* tab, uint32_t& gen_counter, 
 // Insert up to 64 * NW configs, one per thread, each into set A (sel 1) or set B (sel 2), OR-ing the origin sets of equal
 // keys.  `side`: a flag per thread the callers want numbered in the same breath (sub-round 0's "still needs X" list):
 // side_off = how many threads before this one have it set, side_total = how many in all.  Returns false if a set outgrew CAP.
-template <uint32_t CAP, uint32_t NW>
+template <uint32_t CAP, uint32_t NW, bool FP = false>
 WV_DEV bool insert2(Build& A, Build& B, uint32_t sel, uint32_t mlo, uint32_t mhi, uint32_t st, uint32_t org,
                     bool side, uint32_t& side_off, uint32_t& side_total, Ctx<NW>& X) {
   using S = Scratch<NW>;
@@ -124,16 +133,21 @@ WV_DEV bool insert2(Build& A, Build& B, uint32_t sel, uint32_t mlo, uint32_t mhi
   if (!any) return true;                                      // (the same in every thread: nobody has passed another barrier)
   uint32_t* const tab = sel == 2u ? B.tab : A.tab;
   Ent* const ent = sel == 2u ? B.e : A.e;
-  const uint32_t gen = sel == 2u ? B.gen : A.gen, gtag = gen << kGenShift;
-  uint32_t h = key_slot<HS>(mlo, mhi, st), mine = 0;
+  const uint32_t gen = sel == 2u ? B.gen : A.gen;
+  uint32_t gtag = gen << gen_shift<FP>();
+  uint32_t h = key_slot<HS>(mlo, mhi, st), mine = 0, fp = 0;
+  if constexpr (FP) { const uint32_t hh = key_hash(mlo, mhi, st); fp = hh >> 24; gtag |= fp << kFpShift; }
   bool pend = sel != 0u, won = false;
   while (wv::ballot(pend)) {
     if (pend) {
       uint32_t s = wv::lds_ld32(&tab[h]);
-      if ((s >> kGenShift) != gen) {                      // empty: claim it with the thread number
+      if ((s >> gen_shift<FP>()) != gen) {                      // empty: claim it with the thread number
         const uint32_t old = wv::lds_cas32(&tab[h], s, gtag | kProv | X.tid);
         if (old == s) { won = true; mine = h; pend = false; }
         else s = old;                                     // claimed in this very pass by another thread
+      }
+      if constexpr (FP) {                                 // another key's fingerprint: no need to look at the key
+        if (pend && ((s >> kFpShift) & 0xFFu) != fp) { h = (h + 1u) & (HS - 1u); continue; }
       }
       if (pend) {
         const Ent* kp = (s & kProv) ? &X.stage[s & 0x3FFu] : &ent[s & 0xFFFFu];
@@ -173,7 +187,7 @@ WV_DEV bool insert2(Build& A, Build& B, uint32_t sel, uint32_t mlo, uint32_t mhi
 
 // QUEUE: insert `cnt` (<= 64 * NW, the same in every thread) children from the ring, starting at qh: they are staged where they lie
 // (one barrier makes them visible), a claim carries the RING position.
-template <uint32_t CAP, uint32_t NW>
+template <uint32_t CAP, uint32_t NW, bool FP = false>
 WV_DEV bool insert_q(Build& A, Build& B, Ent* wq, const uint8_t* wq_sel, uint32_t qh, uint32_t cnt, Ctx<NW>& X) {
   using S = Scratch<NW>;
   constexpr uint32_t HS = 2 * CAP, QM = 2 * 64 * NW - 1;
@@ -184,16 +198,21 @@ WV_DEV bool insert_q(Build& A, Build& B, Ent* wq, const uint8_t* wq_sel, uint32_
   const uint32_t mlo = c.mlo, mhi = c.mhi, st = c.st, org = c.org;
   uint32_t* const tab = sel == 2u ? B.tab : A.tab;
   Ent* const ent = sel == 2u ? B.e : A.e;
-  const uint32_t gen = sel == 2u ? B.gen : A.gen, gtag = gen << kGenShift;
-  uint32_t h = key_slot<HS>(mlo, mhi, st), mine = 0;
+  const uint32_t gen = sel == 2u ? B.gen : A.gen;
+  uint32_t gtag = gen << gen_shift<FP>();
+  uint32_t h = key_slot<HS>(mlo, mhi, st), mine = 0, fp = 0;
+  if constexpr (FP) { const uint32_t hh = key_hash(mlo, mhi, st); fp = hh >> 24; gtag |= fp << kFpShift; }
   bool pend = sel != 0u, won = false;
   while (wv::ballot(pend)) {
     if (pend) {
       uint32_t s = wv::lds_ld32(&tab[h]);
-      if ((s >> kGenShift) != gen) {
+      if ((s >> gen_shift<FP>()) != gen) {
         const uint32_t old = wv::lds_cas32(&tab[h], s, gtag | kProv | at);
         if (old == s) { won = true; mine = h; pend = false; }
         else s = old;
+      }
+      if constexpr (FP) {
+        if (pend && ((s >> kFpShift) & 0xFFu) != fp) { h = (h + 1u) & (HS - 1u); continue; }
       }
       if (pend) {
         const Ent* kp = (s & kProv) ? &wq[s & QM] : &ent[s & 0xFFFFu];
@@ -236,7 +255,10 @@ WV_DEV bool insert_q(Build& A, Build& B, Ent* wq, const uint8_t* wq_sel, uint32_
 // put their children into a ring in LDS (one barrier per pass of 64 * NW pairs) and the insertion -- the expensive half, three
 // barriers in the plain form -- runs only when 64 * NW children are waiting: about a third of the pairs of a burst yield a child,
 // so a third as many insertions, each with every lane busy.  Costs 17 KB of LDS at NW = 8 (one workgroup per CU instead of two).
-template <uint32_t CAP, uint32_t NW, bool QUEUE = false>
+// FP (experimental, likewise): 8 bits of the key's hash in the table word.  A probe that meets another key's slot then costs one LDS
+// word instead of the word and the 16 B key behind it; the barrier after the probe loop waits for the LONGEST chain among the
+// workgroup's 512 lanes, so the cost of a chain link is what a pass costs.  Generations wrap every 127 sets instead of 32,767.
+template <uint32_t CAP, uint32_t NW, bool QUEUE = false, bool FP = false>
 WV_DEV void segment(const SweepArgs& A, uint32_t* lds) {
   static_assert(64 * NW >= kCand, "a level's open calls are parked one per thread");
   static_assert(64 * NW <= 1024 && CAP <= 0x8000u, "thread numbers and entry numbers share a table word");
@@ -353,7 +375,7 @@ WV_DEV void segment(const SweepArgs& A, uint32_t* lds) {
   nxt = none; q = none;
   uint32_t n_org = 0, so_ = 0, st_ = 0;
   {
-    build_begin<HS, NW>(cur, cur_e, tab_q, gen_q, X);
+    build_begin<HS, NW, FP>(cur, cur_e, tab_q, gen_q, X);
     load_row(row_a, F0);
     uint32_t nlive = 0, C = 0;
     const bool okc = load_cands(F0, nlive, C);              // (its barrier also publishes row_a)
@@ -373,7 +395,7 @@ WV_DEV void segment(const SweepArgs& A, uint32_t* lds) {
       if (eager) act = act && ((row_a[0] | row_a[rdm_index((int32_t)st, V)]) & ~m) == 0ull;     // in normal form already?
     }
     Build unused = none;
-    if (status == kSegOk && !insert2<CAP, NW>(cur, unused, act ? 1u : 0u, (uint32_t)m, (uint32_t)(m >> 32), st, 1u << (tid & 31u), false, so_, st_, X)) status = kSegOverflow;
+    if (status == kSegOk && !insert2<CAP, NW, FP>(cur, unused, act ? 1u : 0u, (uint32_t)m, (uint32_t)(m >> 32), st, 1u << (tid & 31u), false, so_, st_, X)) status = kSegOverflow;
   }
   n_org = cur.n;
   if (n_org == 0 && status == kSegOk) { if (tid == 0) out->status = kSegNone; return; }   // none of these ids is a config
@@ -401,7 +423,7 @@ WV_DEV void segment(const SweepArgs& A, uint32_t* lds) {
       if (tid < 32 && eager && tid < V && F + 2u < R) p_row = rdm[(uint64_t)(F + 2u) * V + tid];
     }
     const uint64_t xbit = 1ull << (px & 63u);
-    build_begin<HS, NW>(nxt, nxt_e, tab_nxt, gen_nxt, X);
+    build_begin<HS, NW, FP>(nxt, nxt_e, tab_nxt, gen_nxt, X);
     // sub-round 0: a config that has X linearized passes the completion -- X's bit is cleared and the reads open at
     // the next front are absorbed; the others are listed for expansion
     uint32_t n_exp = 0;
@@ -415,7 +437,7 @@ WV_DEV void segment(const SweepArgs& A, uint32_t* lds) {
       if (eager) m2 |= row_b[0] | row_b[rdm_index((int32_t)e.st, V)];
       Build unused = none;
       uint32_t soff = 0, stot = 0;
-      if (!insert2<CAP, NW>(nxt, unused, has ? 1u : 0u, (uint32_t)m2, (uint32_t)(m2 >> 32), e.st, e.org, val && !has, soff, stot, X)) status = kSegOverflow;
+      if (!insert2<CAP, NW, FP>(nxt, unused, has ? 1u : 0u, (uint32_t)m2, (uint32_t)(m2 >> 32), e.st, e.org, val && !has, soff, stot, X)) status = kSegOverflow;
       if (val && !has) expl[n_exp + soff] = (uint16_t)i;
       n_exp += stot;
     }
@@ -430,7 +452,7 @@ WV_DEV void segment(const SweepArgs& A, uint32_t* lds) {
     Ent* dst_e = q_e; Ent* dst_other = cur_e;       // `cur` is dead once its own expansion is done
     while (n_src != 0 && status == kSegOk) {
       subrounds++;
-      build_begin<HS, NW>(q, dst_e, tab_q, gen_q, X);
+      build_begin<HS, NW, FP>(q, dst_e, tab_q, gen_q, X);
       const uint32_t total = n_src << gshift;
       if constexpr (!QUEUE) {
         for (uint32_t base = 0; base < total && status == kSegOk; base += T) {
@@ -450,7 +472,7 @@ WV_DEV void segment(const SweepArgs& A, uint32_t* lds) {
           const bool has = viable && (m2 & xbit) != 0ull;
           if (has) { m2 &= ~xbit; if (eager) m2 |= row_b[0] | row_b[rdm_index(st2, V)]; }
           const uint32_t sel = viable ? (has ? 1u : 2u) : 0u;
-          if (!insert2<CAP, NW>(nxt, q, sel, (uint32_t)m2, (uint32_t)(m2 >> 32), (uint32_t)st2, e.org, false, so_, st_, X)) status = kSegOverflow;
+          if (!insert2<CAP, NW, FP>(nxt, q, sel, (uint32_t)m2, (uint32_t)(m2 >> 32), (uint32_t)st2, e.org, false, so_, st_, X)) status = kSegOverflow;
         }
       } else if (total <= T) {                         // (one pass: nothing to gather -- the plain form, as above)
         for (uint32_t base = 0; base < total && status == kSegOk; base += T) {
@@ -470,7 +492,7 @@ WV_DEV void segment(const SweepArgs& A, uint32_t* lds) {
           const bool has = viable && (m2 & xbit) != 0ull;
           if (has) { m2 &= ~xbit; if (eager) m2 |= row_b[0] | row_b[rdm_index(st2, V)]; }
           const uint32_t sel = viable ? (has ? 1u : 2u) : 0u;
-          if (!insert2<CAP, NW>(nxt, q, sel, (uint32_t)m2, (uint32_t)(m2 >> 32), (uint32_t)st2, e.org, false, so_, st_, X)) status = kSegOverflow;
+          if (!insert2<CAP, NW, FP>(nxt, q, sel, (uint32_t)m2, (uint32_t)(m2 >> 32), (uint32_t)st2, e.org, false, so_, st_, X)) status = kSegOverflow;
         }
       } else {
         uint32_t qh = 0, qn = 0, pass_no = 0;          // ring head and count (the same in every thread), passes so far
@@ -506,12 +528,12 @@ WV_DEV void segment(const SweepArgs& A, uint32_t* lds) {
           }
           qn += all;
           while (qn >= T && status == kSegOk) {
-            if (!insert_q<CAP, NW>(nxt, q, wq, wq_sel, qh, T, X)) status = kSegOverflow;
+            if (!insert_q<CAP, NW, FP>(nxt, q, wq, wq_sel, qh, T, X)) status = kSegOverflow;
             qh = (qh + T) & (2 * T - 1u); qn -= T;
           }
         }
         if (qn != 0 && status == kSegOk) {                     // what is left in the ring
-          if (!insert_q<CAP, NW>(nxt, q, wq, wq_sel, qh, qn, X)) status = kSegOverflow;
+          if (!insert_q<CAP, NW, FP>(nxt, q, wq, wq_sel, qh, qn, X)) status = kSegOverflow;
         }
       }
       src = q.e; n_src = q.n; via_list = false;

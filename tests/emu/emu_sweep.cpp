@@ -14,18 +14,18 @@ using namespace tbc;
 namespace {
 
 struct Call { const SweepArgs* A; uint32_t* lds; };
-template <uint32_t CAP, uint32_t NW, bool QUEUE>
+template <uint32_t CAP, uint32_t NW, bool QUEUE, bool FP>
 void entry(void* p, uint32_t) {
   auto* c = (Call*)p;
-  sweepwg::segment<CAP, NW, QUEUE>(*c->A, c->lds);
+  sweepwg::segment<CAP, NW, QUEUE, FP>(*c->A, c->lds);
 }
-template <uint32_t CAP, uint32_t NW, bool QUEUE = false>
+template <uint32_t CAP, uint32_t NW, bool QUEUE = false, bool FP = false>
 void run_all(const SweepArgs& A, uint32_t n_wg, uint64_t seed) {
   std::vector<uint32_t> lds(sweepwg::lds_words<CAP, NW, QUEUE>() + 16);
   for (uint32_t w = 0; w < n_wg; w++) {
     std::fill(lds.begin(), lds.end(), 0xDEADBEEFu);          // LDS is not zeroed on the device either
     Call c{&A, lds.data()};
-    wv::run_workgroup(&entry<CAP, NW, QUEUE>, &c, (int)NW, w, seed + w);
+    wv::run_workgroup(&entry<CAP, NW, QUEUE, FP>, &c, (int)NW, w, seed + w);
   }
 }
 
@@ -78,9 +78,14 @@ int emu_sweep_wg_run(uint32_t n, uint32_t n_process, const uint8_t* f, const int
 #define RUN(C_, W_) if (CAP == C_ && NW == W_ && !queue) { run_all<C_, W_>(A, n_wg, seed); return 0; }
   RUN(1024, 2) RUN(1024, 4) RUN(1024, 8) RUN(512, 4) RUN(2048, 8)
 #undef RUN
-#define RUNQ(C_, W_) if (CAP == C_ && NW == W_ && queue) { run_all<C_, W_, true>(A, n_wg, seed); return 0; }
+#define RUNQ(C_, W_) if (CAP == C_ && NW == W_ && queue == 1) { run_all<C_, W_, true>(A, n_wg, seed); return 0; }
   RUNQ(1024, 2) RUNQ(1024, 4) RUNQ(1024, 8) RUNQ(512, 4) RUNQ(2048, 8)
 #undef RUNQ
+  // variant bit 1: the fingerprint form (FP), with or without the ring
+#define RUNF(C_, W_) if (CAP == C_ && NW == W_ && queue == 2) { run_all<C_, W_, false, true>(A, n_wg, seed); return 0; } \
+                     if (CAP == C_ && NW == W_ && queue == 3) { run_all<C_, W_, true, true>(A, n_wg, seed); return 0; }
+  RUNF(1024, 2) RUNF(1024, 8) RUNF(512, 4)
+#undef RUNF
   return 2;
 }
 

@@ -20,7 +20,7 @@ def _records(buf):
     return np.frombuffer(buf, dtype=np.uint8).reshape(-1, C.sizeof(N.SweepRel))
 
 
-def _compare(ops, seg_target, n_dom, waves, cap=1024, rules=None, seed=1, expect_overflow=False, second_pass=False, queue=False):
+def _compare(ops, seg_target, n_dom, waves, cap=1024, rules=None, seed=1, expect_overflow=False, second_pass=False, queue=False, fp=False):
     d = ops.as_dict()
     R = int((np.asarray(d["ret_pos"]) != 0xFFFFFFFF).sum())
     max_segs = max(1, min(512, (R + seg_target - 1) // seg_target)) if seg_target else 1
@@ -32,7 +32,7 @@ def _compare(ops, seg_target, n_dom, waves, cap=1024, rules=None, seed=1, expect
         wgl.check_sweep(d, CAS, eager_reads=eager, twin_rule=twin, seg_target=seg_target, n_dom=n_dom)
     finally:
         L.sweep_set_export(None, C.c_uint32(0), C.c_uint32(0), C.c_uint32(1))
-    got = emu.sweep_wg(d, 1, N.NIL, seg_target, n_dom, max_segs, waves=waves, cap=cap, rules=None if rules is None else (3 if rules else 0), seed=seed, queue=queue)
+    got = emu.sweep_wg(d, 1, N.NIL, seg_target, n_dom, max_segs, waves=waves, cap=cap, rules=None if rules is None else (3 if rules else 0), seed=seed, queue=queue, fp=fp)
     want = [N.SweepRel.from_buffer_copy(r.tobytes()) for r in _records(buf)]
     have = [N.SweepRel.from_buffer_copy(r.tobytes()) for r in _records(got)]
     if second_pass:      # the segments that overflowed, once more with sets of 2,048 configs and eight wavefronts (what launch_sweep does)
@@ -144,3 +144,21 @@ def test_the_ring_variant_on_a_bench_history_under_several_interleavings():
         _compare(h, 32, 6, 8, seed=2000 + 13 * seed, queue=True)
     h4 = synth.register_ops_many([4], n_ops=10000, n_procs=64, busy=0.1, info=0.0)[0]
     _compare(h4, 32, 6, 4, cap=512, expect_overflow=True, queue=True)
+
+
+@pytest.mark.parametrize("queue", [False, True])
+def test_the_fingerprint_variant_every_record(queue):
+    """FP (experimental, no launch of round 4 takes it): 8 bits of the key's hash in the table word, generations wrapping every 127
+    sets -- the same records, with and without the ring"""
+    n = 0
+    for seed in range(4):
+        for corrupt in (0.0, 0.4):
+            h = columns.pair_events(synth.register_events(n_ops=300, n_procs=8, seed=100 + seed, busy=0.5, info=0.0, corrupt=corrupt))
+            n += _compare(h, 32, 6, 2 if seed % 2 else 8, seed=seed, queue=queue, fp=True)
+    assert n > 12
+    h = columns.pair_events(synth.register_events(n_ops=300, n_procs=8, seed=58, busy=0.4, info=0.015, corrupt=0.0))      # crashed calls, one long segment: generations wrap
+    _compare(h, 32, 6, 8, queue=queue, fp=True)
+    h = synth.register_ops_many([3], n_ops=10000, n_procs=64, busy=0.1, info=0.0)[0]
+    assert _compare(h, 32, 6, 8, queue=queue, fp=True) > 250
+    h4 = synth.register_ops_many([4], n_ops=10000, n_procs=64, busy=0.1, info=0.0)[0]
+    _compare(h4, 32, 6, 4, cap=512, expect_overflow=True, queue=queue, fp=True)
