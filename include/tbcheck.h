@@ -530,6 +530,7 @@ int tbc_debug_peek(uint32_t* out, uint32_t n);
  *   TBC_SWEEP_WG=0|4|8            wavefronts per segment of a sweep of at most 4,096 wavefronts (default 8: a workgroup per segment,
  *                                 jit_sweep_wg.hip; 0 = one wavefront per segment always)
  *   TBC_SWEEP_WG_RING=1           (experimental) the workgroup sweep gathers a sub-round's children in a ring before inserting them
+ *   TBC_SWEEP_WG_FP=1             (experimental) ... keeps 8 bits of a key's hash in its table word (a probe past another key reads no key)
  *   TBC_DEBUG=1, TBC_SYNC_EACH=1  progress words (above), a traced synchronisation after every launch */
 
 #ifdef __cplusplus
