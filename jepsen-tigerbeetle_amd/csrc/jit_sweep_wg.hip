@@ -76,6 +76,9 @@ bool launch_sweep_wg(const SweepArgs& a, uint32_t waves, void* stream) {
   if (fpr && waves == 8) return launch_fp<kSweepCapMid, 8>(a, s);
   if (waves == 4) return launch_one<kSweepCapMid, 4>(a, s);
   if (waves == 8) return launch_one<kSweepCapMid, 8>(a, s);
+  // TBC_SWEEP_WG=16 (experimental, emulator-verified only): sixteen wavefronts on the big sets from the start -- no second pass,
+  // 154 KB of LDS, one workgroup per CU
+  if (waves == 16) return launch_one<kSweepCapBig, 16>(a, s);
   return false;
 }
 

@@ -11,6 +11,7 @@ run TBC_SWEEP_WG=8 TBC_SWEEP_WG_RING=1
 run TBC_SWEEP_WG=8 TBC_SWEEP_WG_FP=1
 run TBC_SWEEP_WG=8 TBC_SWEEP_WG_RING=1 TBC_SWEEP_WG_FP=1
 run TBC_SWEEP_WG=8 TBC_SWEEP_WG_FP=1 TBC_SWEEP_SEG=16
+run TBC_SWEEP_WG=16
 cat $OUT
 for v in "TBC_SWEEP_WG_RING=1" "TBC_SWEEP_WG_FP=1" "TBC_SWEEP_WG_RING=1 TBC_SWEEP_WG_FP=1"; do
   echo "== tests/test_sweep.py under $v" | tee -a $OUT

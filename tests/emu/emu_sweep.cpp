@@ -76,7 +76,7 @@ int emu_sweep_wg_run(uint32_t n, uint32_t n_process, const uint8_t* f, const int
   A.shard_rank = 0; A.shard_world = 1; A.seg_list = seg_list; A.n_list = n_list; A.dump_cfg = nullptr; A.dump_count = nullptr;
   const uint32_t n_wg = seg_list ? n_list : max_segs * kSweepSlices;
 #define RUN(C_, W_) if (CAP == C_ && NW == W_ && !queue) { run_all<C_, W_>(A, n_wg, seed); return 0; }
-  RUN(1024, 2) RUN(1024, 4) RUN(1024, 8) RUN(512, 4) RUN(2048, 8)
+  RUN(1024, 2) RUN(1024, 4) RUN(1024, 8) RUN(512, 4) RUN(2048, 8) RUN(2048, 16)
 #undef RUN
 #define RUNQ(C_, W_) if (CAP == C_ && NW == W_ && queue == 1) { run_all<C_, W_, true>(A, n_wg, seed); return 0; }
   RUNQ(1024, 2) RUNQ(1024, 4) RUNQ(1024, 8) RUNQ(512, 4) RUNQ(2048, 8)

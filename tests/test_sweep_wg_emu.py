@@ -162,3 +162,12 @@ def test_the_fingerprint_variant_every_record(queue):
     assert _compare(h, 32, 6, 8, queue=queue, fp=True) > 250
     h4 = synth.register_ops_many([4], n_ops=10000, n_procs=64, busy=0.1, info=0.0)[0]
     _compare(h4, 32, 6, 4, cap=512, expect_overflow=True, queue=queue, fp=True)
+
+
+def test_sixteen_wavefronts_on_the_big_sets():
+    """TBC_SWEEP_WG=16 (experimental): 1,024 threads per segment, sets of 2,048 configs from the start"""
+    for seed in range(3):
+        h = columns.pair_events(synth.register_events(n_ops=300, n_procs=8, seed=100 + seed, busy=0.5, info=0.0, corrupt=0.4 * (seed % 2)))
+        _compare(h, 32, 6, 16, cap=2048, seed=seed)
+    h4 = synth.register_ops_many([4], n_ops=10000, n_procs=64, busy=0.1, info=0.0)[0]      # the history whose burst overflows 1,024 configs: no overflow here
+    assert _compare(h4, 32, 6, 16, cap=2048) > 250
