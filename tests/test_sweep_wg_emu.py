@@ -158,10 +158,12 @@ def test_the_fingerprint_variant_every_record(queue):
     assert n > 12
     h = columns.pair_events(synth.register_events(n_ops=300, n_procs=8, seed=58, busy=0.4, info=0.015, corrupt=0.0))      # crashed calls, one long segment: generations wrap
     _compare(h, 32, 6, 8, queue=queue, fp=True)
-    h = synth.register_ops_many([3], n_ops=10000, n_procs=64, busy=0.1, info=0.0)[0]
-    assert _compare(h, 32, 6, 8, queue=queue, fp=True) > 250
-    h4 = synth.register_ops_many([4], n_ops=10000, n_procs=64, busy=0.1, info=0.0)[0]
-    _compare(h4, 32, 6, 4, cap=512, expect_overflow=True, queue=queue, fp=True)
+    if queue:       # (the bench history with its bursts once: both forms at once; the plain fingerprint form is covered by the histories above)
+        h = synth.register_ops_many([3], n_ops=10000, n_procs=64, busy=0.1, info=0.0)[0]
+        assert _compare(h, 32, 6, 8, queue=queue, fp=True) > 250
+    else:
+        h4 = synth.register_ops_many([4], n_ops=10000, n_procs=64, busy=0.1, info=0.0)[0]
+        _compare(h4, 32, 6, 4, cap=512, expect_overflow=True, queue=queue, fp=True)
 
 
 def test_sixteen_wavefronts_on_the_big_sets():
