@@ -284,7 +284,81 @@ def leg_set_full(args, local_rank):
                          "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "setfull_any_kernel + setfull_resolve_kernel"}}
 
 
-LEGS = {"tiers": leg_tiers, "set_full": leg_set_full,
+# ---- extra.single_history_forms: ONE history through tbc_check under every form of the single-history path that exists in the
+# library behind an environment switch (include/tbcheck.h lists them).  The switches are read once per process, so every form
+# runs in a process of its own; the forms other than the default were verified under the wavefront emulator (tests/emu) and had
+# not all been timed on the device when they were committed -- this leg is their measurement, and it can never cost the line:
+# a form that faults, times out or disagrees leaves {"error": ...} / "counters_match": false in its own entry.
+FORMS = [("K6 (one wavefront per segment)", {"TBC_SWEEP_WG": "0"}),
+         ("K6w, 8 wavefronts per segment (the default)", {}),
+         ("K6w + ring", {"TBC_SWEEP_WG_RING": "1"}),
+         ("K6w + fingerprint", {"TBC_SWEEP_WG_FP": "1"}),
+         ("K6w + ring + fingerprint", {"TBC_SWEEP_WG_RING": "1", "TBC_SWEEP_WG_FP": "1"}),
+         ("K6w + fingerprint, 16 completions per segment", {"TBC_SWEEP_WG_FP": "1", "TBC_SWEEP_SEG": "16"}),
+         ("K6w, 16 wavefronts on the big sets", {"TBC_SWEEP_WG": "16"}),
+         ("pack by a workgroup's sixteen wavefronts", {"TBC_PACK_ONE": "1"}),
+         ("pack by sixteen wavefronts + K6w ring + fingerprint", {"TBC_PACK_ONE": "1", "TBC_SWEEP_WG_RING": "1", "TBC_SWEEP_WG_FP": "1"})]
+
+
+def leg_one_form(args, local_rank):
+    """One form (this process's environment): best-of-3 time to verdict of 10 valid histories and one invalid one, and the
+    counters every form must agree on."""
+    np, N, columns, core, synth = _gpu_imports()
+    model = core.make_model(N.MODEL_CAS_REGISTER, N.NIL)
+    o = core.make_opts(device=local_rank, want_witness=False, algorithm=N.ALG_COMPETITION)
+    hs = synth.register_ops_many(range(10), n_ops=args.ops, n_procs=args.procs, busy=args.busy, info=0.0)
+    bad = columns.pair_events(synth.register_events(n_ops=args.ops, n_procs=args.procs, seed=12345, busy=args.busy, info=0.0, corrupt=0.5))
+    core.check_ops(hs[0], model, o); core.check_ops(hs[0], model, o)
+    tt, sig = [], []
+    for h in hs:
+        best = 1e9
+        for _ in range(3):
+            t = time.perf_counter(); r = core.check_ops(h, model, o); best = min(best, (time.perf_counter() - t) * 1e3)
+        tt.append(best); sig.append([int(r["valid"]), int(r["analyzer"]), int(r["steps"]), int(r["visited"]), int(r["probes"])])
+    t = time.perf_counter(); rb = core.check_ops(bad, model, o); tb = (time.perf_counter() - t) * 1e3
+    sig.append([int(rb["valid"]), int(rb["analyzer"]), int(rb["fail_op"])])
+    return {"valid_median_ms": round(statistics.median(tt), 3), "valid_min_ms": round(min(tt), 3), "valid_max_ms": round(max(tt), 3),
+            "invalid_example_ms": round(tb, 3), "signature": sig}
+
+
+def leg_single_history_forms(args, local_rank):
+    import subprocess
+    out, base = [], None
+    for name, env in FORMS:
+        leg("form: " + name)
+        entry = {"form": name, "env": env}
+        try:
+            cmd = [sys.executable, os.path.abspath(__file__)] + [a for a in sys.argv[1:] if a not in ("--leg", "single_history_forms")] + ["--leg", "one_form"]
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, timeout=180, env=dict(os.environ, LOCAL_RANK=str(local_rank), **env))
+            res = None
+            for ln in reversed(r.stdout.decode(errors="replace").splitlines()):
+                if ln.startswith("{"):
+                    try:
+                        d = json.loads(ln)
+                    except ValueError:
+                        continue
+                    if d.get("leg") == "one_form":
+                        res = d["result"]
+                        break
+            if res is None or r.returncode != 0:
+                entry["error"] = f"return code {r.returncode}, no result"
+            else:
+                sig = res.pop("signature")
+                if not env:
+                    base = sig
+                entry.update(res)
+                entry["_sig"] = sig
+        except subprocess.TimeoutExpired:
+            entry["error"] = "did not finish within 180 s"
+        out.append(entry)
+    for e in out:          # the same verdicts, analyzer, failing op and sweep counters as the default form (which the GPU tests pin to the oracle)
+        sig = e.pop("_sig", None)
+        if sig is not None:
+            e["counters_match"] = base is not None and sig == base
+    return out
+
+
+LEGS = {"tiers": leg_tiers, "one_form": leg_one_form, "single_history_forms": leg_single_history_forms, "set_full": leg_set_full,
         "workload_2": lambda a, d: leg_workload(a, d, "workload_2"), "workload_3": lambda a, d: leg_workload(a, d, "workload_3"),
         "workload_crashed": lambda a, d: leg_workload(a, d, "workload_crashed")}
 
@@ -352,6 +426,7 @@ def main():
     ap.add_argument("--batch4", type=int, default=8192, help="crashed workload: histories per GPU")
     ap.add_argument("--no-tiers", action="store_true", help="skip the crashed-op tiers (extra.tiers)")
     ap.add_argument("--no-set-full", action="store_true", help="skip the checker/set-full scan (extra.set_full)")
+    ap.add_argument("--no-forms", action="store_true", help="skip extra.single_history_forms (one history under every form of the single-history path)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--only-headline", action="store_true",
                     help="the warm-up and the timed steps only (no extra legs): what scripts/gpu_profile_r04.sh runs under rocprofv3 --kernel-trace "
@@ -692,6 +767,11 @@ def main():
                 line["extra"]["workload_crashed"] = run_leg("workload_crashed", args, local_rank)
         if world == 1 and not args.no_set_full:
             line["extra"]["set_full"] = run_leg("set_full", args, local_rank)
+        if world == 1 and on_gpu and not args.only_headline and not args.no_forms:
+            try:
+                line["extra"]["single_history_forms"] = run_leg("single_history_forms", args, local_rank)
+            except SystemExit as e:      # (this leg measures forms not yet timed on the device: it reports, it never fails the run)
+                line["extra"]["single_history_forms"] = {"error": str(e)}
         print(json.dumps(line), flush=True)
     for b in batches:
         b.close()

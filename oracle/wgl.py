@@ -160,7 +160,7 @@ def rules_apply(ops, model, round_pairs=64):
 
 
 def check_beam(ops, model, width=16, max_probes=0, want_witness=True, round_pairs=64, widen_after=0, lookahead=None, eager_reads=None, twin_rule=None,
-               twin_selfcheck=False, rules_at_any_round_size=False, branch_lists=False, lazy_commuting=None):
+               twin_selfcheck=False, rules_at_any_round_size=False, branch_lists=False, lazy_commuting=None, eager_txns=False):
     """The wide (K configs per iteration) schedule of the same search: wgl_beam.c.
 
     lookahead: None = what the library does by default (on for register / cas-register under the
@@ -193,6 +193,9 @@ def check_beam(ops, model, width=16, max_probes=0, want_witness=True, round_pair
     # kernel's lists under the eager rule); without eager reads the switch does nothing
     lib().wgl_beam_set_branch_lists(C.c_uint32(1 if (branch_lists and eager_reads) else 0))
     lib().wgl_beam_set_twin_selfcheck(C.c_uint32(1 if twin_selfcheck else 0))
+    # eager_txns: DESIGN STUDY (no kernel counterpart): the eager rule for multi-register -- an open txn of micro-reads only that the
+    # state allows is linearized at once (wgl_beam.c, g_eager_txns); what it buys is measured in DESIGN.md section 8
+    lib().wgl_beam_set_eager_txns(C.c_uint32(1 if (eager_txns and model["kind"] == 4) else 0))
     try:
         r = _check_beam(ops, model, width, max_probes, want_witness, round_pairs, widen_after, bool(lookahead))
         if twin_selfcheck:
@@ -206,6 +209,7 @@ def check_beam(ops, model, width=16, max_probes=0, want_witness=True, round_pair
         lib().wgl_beam_set_twin_selfcheck(C.c_uint32(0))
         lib().wgl_beam_set_branch_lists(C.c_uint32(0))
         lib().wgl_beam_set_lazy_commuting(C.c_uint32(0))
+        lib().wgl_beam_set_eager_txns(C.c_uint32(0))
 
 
 def _check_beam(ops, model, width, max_probes, want_witness, round_pairs, widen_after, lookahead):

@@ -191,6 +191,13 @@ static uint32_t g_branch_lists = 0;
 void wgl_beam_set_branch_lists(uint32_t on) { g_branch_lists = on; }
 void wgl_beam_set_twin_rule(uint32_t on) { g_twin_rule = on; }
 void wgl_beam_set_eager_reads(uint32_t on) { g_eager_reads = on; }
+/* eager_txns (multi-register; tbc_opts.dominance, TBC_DOM_NO_EAGER_TXNS = off): the eager rule for knossos.model/multi-register.
+ * An open :txn made of micro-READS only, each of nil or of its key's current value, changes nothing and can be linearized now
+ * without loss of generality -- the argument of the eager reads word for word: everything that must
+ * precede it is linearized, the state stays, every later schedule stays possible.  A txn that writes is never absorbed, not
+ * even one that writes the values already there (it may be needed later, to put them back). */
+static uint32_t g_eager_txns = 0;
+void wgl_beam_set_eager_txns(uint32_t on) { g_eager_txns = on; }
 uint64_t wgl_beam_absorbed(void) { return g_absorbed; }
 /* LAZY RULE for the commutative models (set, bank; tbc_opts.dominance, TBC_DOM_NO_LAZY_COMMUTING off = rule on).  An :add / :transfer
  * changes nothing any call can see except a :read, and the calls of these models commute, so in any linearization a mutating call
@@ -229,6 +236,44 @@ static uint32_t absorb_reads(uint64_t* c2, uint32_t fi2, int32_t s, uint32_t R, 
       if (wit) wit[(*nw)++] = x;
     }
     /* the front moves past every completion now linearized; new calls open up: look again */
+    uint32_t pp = (uint32_t)process[ret_op[fi2]];
+    while (c2[1 + (pp >> 6)] >> (pp & 63) & 1) {
+      c2[1 + (pp >> 6)] &= ~(1ull << (pp & 63));
+      fi2++; again = 1;
+      if (fi2 == R) break;
+      pp = (uint32_t)process[ret_op[fi2]];
+    }
+  }
+  return fi2;
+}
+
+/* multi-register: is op x a :txn of micro-reads only, each consistent with state s? */
+static int pure_read_txn_ok(const oracle_model* model, int32_t s, uint8_t f, int32_t a, int32_t b) {
+  if (f != O_TXN) return 0;
+  for (int32_t i = 0; i < b; i++) {
+    const int32_t mf = model->pool[a + 3 * i], k = model->pool[a + 3 * i + 1], v = model->pool[a + 3 * i + 2];
+    if (mf != 0) return 0;
+    if (!(v == O_NIL || (((uint32_t)s >> (4 * k)) & 15u) == (uint32_t)(v + 1))) return 0;
+  }
+  return 1;
+}
+
+/* eager_txns: absorb_reads for multi-register -- the config takes every open pure-read txn its state allows, the front moves
+ * past the completions that linearizes, the calls open at the new front are looked at again */
+static uint32_t absorb_txns(const oracle_model* model, uint64_t* c2, uint32_t fi2, int32_t s, uint32_t R, const uint32_t* off, const uint32_t* lst,
+                            const int32_t* process, const uint32_t* ret_op, const uint8_t* f, const int32_t* a, const int32_t* b,
+                            uint32_t* wit, uint32_t* nw) {
+  int again = 1;
+  while (again && fi2 < R) {
+    again = 0;
+    const uint32_t nl = off[fi2 + 1] - off[fi2];
+    for (uint32_t cc = 0; cc < nl; cc++) {
+      const uint32_t x = lst[off[fi2] + cc], px = (uint32_t)process[x];
+      if (c2[1 + (px >> 6)] >> (px & 63) & 1) continue;
+      if (!pure_read_txn_ok(model, s, f[x], a[x], b[x])) continue;
+      c2[1 + (px >> 6)] |= 1ull << (px & 63); g_absorbed++;
+      if (wit) wit[(*nw)++] = x;
+    }
     uint32_t pp = (uint32_t)process[ret_op[fi2]];
     while (c2[1 + (pp >> 6)] >> (pp & 63) & 1) {
       c2[1 + (pp >> 6)] &= ~(1ull << (pp & 63));
@@ -486,6 +531,8 @@ int wgl_beam_check_rp(uint32_t n, const uint8_t* f, const int32_t* a, const int3
         }
         if (g_eager_reads && !cfgm && (model->kind == O_REGISTER || model->kind == O_CAS_REGISTER))
           fi2 = absorb_reads(c2, fi2, s2, R, off, lst, process, ret_op, f, a, NULL, NULL);
+        if (g_eager_txns && model->kind == O_MULTI_REGISTER)
+          fi2 = absorb_txns(model, c2, fi2, s2, R, off, lst, process, ret_op, f, a, b, NULL, NULL);
         c2[0] = (uint64_t)(fi2 + 1) | ((uint64_t)(uint32_t)s2 << 32);
         cviable[l] = 1; cfront[l] = fi2; cstate[l] = s2;
         if (fi2 == R && success < 0) success = (int)l;
@@ -560,7 +607,10 @@ int wgl_beam_check_rp(uint32_t n, const uint8_t* f, const int32_t* a, const int3
     if (witness) {
       uint32_t w = len ? len - 1 : 0; id = win_parent;
       if (!root_wins) { witness[w] = win_op; while (ar.parent[id]) { witness[--w] = ar.op[id]; id = ar.parent[id]; } }
-      if (g_eager_reads && !cfgm && (model->kind == O_REGISTER || model->kind == O_CAS_REGISTER)) {
+      const int etx = g_eager_txns && model->kind == O_MULTI_REGISTER;
+#define ABSORB(c2_, fr_, s_) (etx ? absorb_txns(model, c2_, fr_, s_, R, off, lst, process, ret_op, f, a, b, witness, &nw) \
+                                  : absorb_reads(c2_, fr_, s_, R, off, lst, process, ret_op, f, a, witness, &nw))
+      if (etx || (g_eager_reads && !cfgm && (model->kind == O_REGISTER || model->kind == O_CAS_REGISTER))) {
         /* the chain holds the branching ops only: replay it from the root, absorbing reads as the search did */
         uint32_t* chain = (uint32_t*)malloc(4 * (size_t)len);
         memcpy(chain, witness, 4 * (size_t)len);
@@ -582,8 +632,9 @@ int wgl_beam_check_rp(uint32_t n, const uint8_t* f, const int32_t* a, const int3
               if (!(c2[1 + (pp >> 6)] >> (pp & 63) & 1)) break;
             }
           }
-          fr = absorb_reads(c2, fr, s, R, off, lst, process, ret_op, f, a, witness, &nw);
+          fr = ABSORB(c2, fr, s);
         }
+#undef ABSORB
         out->n_witness = nw;
         free(chain); free(c2);
       }

@@ -40,6 +40,32 @@ def test_small_histories_against_brute_force(native, oracle):
     assert n_bad > 15
 
 
+def test_eager_pure_read_txns_change_no_answer(native, oracle):
+    """The eager rule for multi-register as a design study of the oracle (oracle/wgl_beam.c, g_eager_txns; no kernel speaks it):
+    an open txn of micro-reads only that the state allows is linearized at once.  Same verdict and failing op as brute force and
+    as the plain search on small crash-heavy histories, fewer probes on larger ones."""
+    n_bad = fewer = 0
+    for seed in range(240):
+        hist = multi_register_history(8, 3, 1000 + seed, n_keys=2, n_values=2, busy=0.8, info=0.15, corrupt=seed % 2 == 1)
+        enc, om = encode(hist)
+        bad = brute.first_bad_completion(om, op_tuples(enc.ops))
+        n_bad += bad is not None
+        for width in (1, 4):
+            r = oracle.check_beam(enc.ops.as_dict(), om, width, eager_txns=True)
+            assert r["valid"] == (1 if bad is None else 0) and (bad is None or r["fail_op"] == bad), (seed, width)
+            if bad is None:          # the witness (absorbed txns included) replayed by the independent checker
+                assert brute.check_witness(om, op_tuples(enc.ops), [int(x) for x in r["witness"]]) == r["final_state"]
+    assert n_bad > 25
+    for seed in range(6):
+        hist = multi_register_history(3000, 32, seed, n_keys=8, n_values=5, busy=0.12, info=0.0, corrupt=seed % 3 == 2)
+        enc, om = encode(hist)
+        plain = oracle.check_beam(enc.ops.as_dict(), om, 8, want_witness=False)
+        eager = oracle.check_beam(enc.ops.as_dict(), om, 8, want_witness=False, eager_txns=True)
+        assert (plain["valid"], plain["fail_op"] if plain["valid"] == 0 else None) == (eager["valid"], eager["fail_op"] if eager["valid"] == 0 else None)
+        fewer += eager["probes"] < plain["probes"]
+    assert fewer >= 5
+
+
 def test_memo_fallback_when_too_many_keys(native):
     hist = [{"type": "invoke", "f": "txn", "value": [["w", k, 1] for k in range(10)], "process": 0},
             {"type": "ok", "f": "txn", "value": [["w", k, 1] for k in range(10)], "process": 0}]
