@@ -1159,7 +1159,16 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results, int phase = 
   TRACE("run: memsets queued");
   SYNC_TRACE("memsets");
 
-  launch_pack(make_pack_args(B), s);
+  // TBC_PACK_ONE=1 (experimental; pack_one.hip): a handful of histories are packed by a workgroup's sixteen wavefronts each -- the
+  // single-history call's 0.28 ms pack is one wavefront's chain in pack_kernel.  Verified under the emulator only; nothing takes it unless asked
+  static const bool pack_one = [] { const char* e = std::getenv("TBC_PACK_ONE"); return e && e[0] == '1'; }();
+  bool packed = false;
+  if (pack_one && nh <= 8) {
+    bool fits = true;
+    for (uint32_t h = 0; h < nh; h++) fits = fits && pack_one_fits(B->model.kind, B->hist[h].n_ops, B->hist[h].n_events, B->hist[h].n_slots);
+    if (fits) packed = launch_pack_one(make_pack_args(B), s);
+  }
+  if (!packed) launch_pack(make_pack_args(B), s);
   HIP_TRY(hipGetLastError());
   if (beam) {
     PackOpenArgs po = make_pack_open_args(B);

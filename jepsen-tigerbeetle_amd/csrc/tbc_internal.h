@@ -384,6 +384,9 @@ bool launch_narrow(const BeamArgs& a, uint32_t mask_words, uint32_t lanes, void*
 
 // kernel launchers (defined in the .hip files)
 void launch_pack(const PackArgs& a, void* stream);
+// K1 for one history or a handful (pack_one.hip): does the body take such a history; launch it for [a.h0, a.n_hist) (false = not launched)
+bool pack_one_fits(uint32_t model_kind, uint32_t n_ops, uint32_t n_events, uint32_t n_slots);
+bool launch_pack_one(const PackArgs& a, void* stream);
 // returns false if mw is unsupported
 bool launch_search(const SearchArgs& a, uint32_t mask_words, uint32_t n_blocks, void* stream);
 uint32_t search_frame_words(uint32_t mask_words);

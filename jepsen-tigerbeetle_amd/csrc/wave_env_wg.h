@@ -23,6 +23,7 @@ WV_DEV uint32_t lds_cas32(uint32_t* p, uint32_t expected, uint32_t desired) {   
 }
 WV_DEV void lds_or32(uint32_t* p, uint32_t v) { (void)__hip_atomic_fetch_or((WV_LDS uint32_t*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 WV_DEV uint32_t lds_fetch_add32(uint32_t* p, uint32_t v) { return __hip_atomic_fetch_add((WV_LDS uint32_t*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+WV_DEV void lds_add32_wg(uint32_t* p, uint32_t v) { (void)__hip_atomic_fetch_add((WV_LDS uint32_t*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }   // (ds_add, no return)
 
 // OR over the wavefront's lanes (every lane gets it)
 WV_DEV uint32_t wave_or32(uint32_t v) {

@@ -200,3 +200,57 @@ def sweep_wg(ops, model_kind, init, seg_target, n_dom, max_segs, waves=8, cap=10
     if rc != 0:
         raise RuntimeError(f"emu_sweep_wg_run rc={rc}")
     return buf
+
+
+# ---- K1 for one history: pack by a workgroup's sixteen wavefronts (csrc/pack_one_impl.h) under the workgroup emulator
+_SO_PACK = os.path.join(_HERE, "_build", "libemu_pack_asan.so" if _ASAN else "libemu_pack.so")
+_LIB_PACK = None
+
+
+def build_pack(force=False):
+    srcs = [os.path.join(_HERE, "emu_pack.cpp"), os.path.join(_HERE, "wave_env_emu.h"), os.path.join(_HERE, "wave_env_wg_emu.h"),
+            os.path.join(_CSRC, "pack_one_impl.h"), os.path.join(_CSRC, "tbc_internal.h"), os.path.join(_CSRC, "wave_env.h"), os.path.join(_CSRC, "wave_env_wg.h")]
+    if force or not os.path.exists(_SO_PACK) or any(os.path.getmtime(s) > os.path.getmtime(_SO_PACK) for s in srcs):
+        os.makedirs(os.path.dirname(_SO_PACK), exist_ok=True)
+        subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas"]
+                              + (["-fsanitize=address", "-fno-omit-frame-pointer"] if _ASAN else [])
+                              + ["-I", _HERE, "-I", _CSRC, "-I", os.path.join(_ROOT, "include"), "-o", _SO_PACK, srcs[0]])
+    return _SO_PACK
+
+
+def pack_one_check(hists, model_kind=1, n_classes=0, count=False, per_launch=0, seed=1, n_events=None):
+    """Run pack_one (csrc/pack_one_impl.h) under the workgroup emulator on these histories (op-column dicts or OpColumns), one
+    workgroup of sixteen wavefronts each, and compare every word it leaves -- records, list starts, completion tables, the scratch
+    arena, n_ret, status -- with the host restatement in emu_pack.cpp.  n_events: rows of each history (default: last position + 1).
+    Returns None when all agree, else (what, history, index, got, want)."""
+    global _LIB_PACK
+    if _LIB_PACK is None:
+        _LIB_PACK = C.CDLL(build_pack())
+        _LIB_PACK.emu_pack_one_check.restype = C.c_int
+    ds = [h if isinstance(h, dict) else h.as_dict() for h in hists]
+    nh = len(ds)
+    op_off = np.zeros(nh + 1, np.uint64)
+    for i, d in enumerate(ds):
+        op_off[i + 1] = op_off[i] + len(d["f"])
+    cat = lambda k, dt: np.ascontiguousarray(np.concatenate([np.asarray(d[k], dt) for d in ds]), dt)
+    f, a, b = cat("f", np.uint8), cat("a", np.int32), cat("b", np.int32)
+    pr, inv, ret = cat("process", np.int32), cat("inv_pos", np.uint32), cat("ret_pos", np.uint32)
+    npr = np.array([int(d["n_process"]) for d in ds], np.uint32)
+    if n_events is None:
+        n_events = []
+        for h, d in zip(hists, ds):
+            if getattr(h, "n_events", None) is not None:
+                n_events.append(int(h.n_events))
+                continue
+            r = np.asarray(d["ret_pos"], np.uint64); i = np.asarray(d["inv_pos"], np.uint64)
+            live = r[r != 0xFFFFFFFF]
+            n_events.append(int(max(int(i.max()) if len(i) else 0, int(live.max()) if len(live) else 0)) + 1)
+    ne = np.ascontiguousarray(n_events, np.uint32)
+    diag = np.zeros(8, np.uint64)
+    rc = _LIB_PACK.emu_pack_one_check(C.c_uint32(nh), _p(op_off, C.c_uint64), _p(npr, C.c_uint32), _p(ne, C.c_uint32), _p(f, C.c_uint8), _p(a, C.c_int32),
+                                      _p(b, C.c_int32), _p(pr, C.c_int32), _p(inv, C.c_uint32), _p(ret, C.c_uint32), C.c_uint32(model_kind),
+                                      C.c_uint32(n_classes), C.c_uint32(1 if count else 0), C.c_uint32(per_launch), C.c_uint64(seed), _p(diag, C.c_uint64))
+    if rc == 0:
+        return None
+    what = {1: "status", 2: "n_ret", 3: "seg", 4: "ret_slot", 5: "ret_op", 6: "scratch", 7: "rec word", 90: "does not fit"}.get(rc, str(rc))
+    return (what, int(diag[0]), int(diag[1]), int(diag[2]), int(diag[3]))

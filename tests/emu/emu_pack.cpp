@@ -1,0 +1,174 @@
+// TEST INFRASTRUCTURE -- NOT PRODUCT CODE.  emu_pack.cpp: runs K1 for one history, pack by a workgroup's sixteen wavefronts
+// (jepsen-tigerbeetle_amd/csrc/pack_one_impl.h, the very file hipcc compiles into libtbcheck.so), on the CPU under the workgroup
+// emulator of wave_env_wg_emu.h and compares EVERY WORD it leaves behind -- records and sentinels, list starts, completion tables,
+// the ranks and places in the scratch arena, n_ret, status -- with a restatement of what pack.hip's header defines, written here
+// from those definitions (sorting, no bitmap, no counting sort).  tests/test_pack_one_emu.py drives it.
+#define TBC_EMU 1
+#define __HIPCC__ 1
+#include "wave_env_emu.h"
+#include "../../jepsen-tigerbeetle_amd/csrc/pack_one_impl.h"
+
+#include <algorithm>
+#include <vector>
+
+using namespace tbc;
+
+namespace {
+
+struct Call { const PackArgs* A; uint32_t* lds; };
+void entry(void* p, uint32_t) {
+  auto* c = (Call*)p;
+  packone::history(*c->A, c->lds);
+}
+
+struct Want {
+  uint32_t status = 0, n_ret = 0;
+  bool tables = false;                     // records, list starts, completion tables and scratch are defined (status 0, or the one-open-op check failed)
+  std::vector<Rec> rec; std::vector<uint32_t> seg, ret_slot, ret_op, scratch;
+};
+
+bool op_ok_host(uint32_t kind, uint32_t f, int32_t a, uint32_t n_classes) {
+  switch (kind) {
+    case TBC_MODEL_REGISTER: return f == TBC_F_READ || f == TBC_F_WRITE;
+    case TBC_MODEL_CAS_REGISTER: return f == TBC_F_READ || f == TBC_F_WRITE || f == TBC_F_CAS;
+    case TBC_MODEL_MUTEX: return f == TBC_F_ACQUIRE || f == TBC_F_RELEASE;
+    case TBC_MODEL_TABLE: return f == TBC_F_CLASS && (uint32_t)a < n_classes;
+    default: return false;
+  }
+}
+
+// pack.hip's header, restated: what a history's pack leaves behind
+void want_for(uint32_t n, uint32_t W, uint32_t E, bool cf, const uint8_t* f, const int32_t* a, const int32_t* b, const int32_t* proc,
+              const uint32_t* inv, const uint32_t* ret, uint32_t kind, uint32_t n_classes, Want& w) {
+  bool bad = false, model_bad = false;
+  for (uint32_t i = 0; i < n; i++) {
+    const bool slotless = cf && ret[i] == TBC_POS_CRASHED;
+    bool rb = inv[i] >= E || (!slotless && (proc[i] < 0 || (uint32_t)proc[i] >= W)) || (i > 0 && inv[i - 1] >= inv[i]);
+    if (ret[i] != TBC_POS_CRASHED) rb = rb || ret[i] <= inv[i] || ret[i] >= E;
+    if (rb) { bad = true; continue; }
+    if (!op_ok_host(kind, f[i], a[i], n_classes)) model_bad = true;
+  }
+  if (bad || model_bad) { w.status = model_bad ? (uint32_t)TBC_ERR_MODEL : (uint32_t)TBC_ERR_BAD_HISTORY; w.n_ret = 0; return; }
+  std::vector<std::pair<uint32_t, uint32_t>> rets;
+  for (uint32_t i = 0; i < n; i++) if (ret[i] != TBC_POS_CRASHED) rets.push_back({ret[i], i});
+  std::sort(rets.begin(), rets.end());
+  for (size_t r = 1; r < rets.size(); r++) if (rets[r].first == rets[r - 1].first) { w.status = (uint32_t)TBC_ERR_BAD_HISTORY; w.n_ret = 0; return; }
+  const uint32_t R = (uint32_t)rets.size();
+  w.n_ret = R; w.tables = true;
+  std::vector<uint32_t> ret_rank(n, kInf), inv_rank(n, 0);
+  w.ret_slot.assign(R, 0); w.ret_op.assign(R, 0);
+  for (uint32_t r = 0; r < R; r++) { ret_rank[rets[r].second] = r; w.ret_op[r] = rets[r].second; w.ret_slot[r] = (uint32_t)proc[rets[r].second]; }
+  for (uint32_t i = 0; i < n; i++) {
+    uint32_t c = 0;
+    c = (uint32_t)(std::lower_bound(rets.begin(), rets.end(), std::make_pair(inv[i], 0u)) - rets.begin());
+    inv_rank[i] = c;
+  }
+  std::vector<std::vector<uint32_t>> lists(W);
+  for (uint32_t i = 0; i < n; i++) if (!(cf && ret[i] == TBC_POS_CRASHED)) lists[(uint32_t)proc[i]].push_back(i);
+  w.seg.assign(W + 1, 0);
+  for (uint32_t p = 0; p < W; p++) w.seg[p + 1] = w.seg[p] + (uint32_t)lists[p].size() + 2;
+  w.rec.assign(w.seg[W], Rec{});
+  w.scratch.assign(3 * (size_t)n, 0);
+  for (uint32_t i = 0; i < n; i++) { w.scratch[i] = inv_rank[i]; w.scratch[n + i] = ret_rank[i]; w.scratch[2 * (size_t)n + i] = kInf; }
+  bool overlap = false;
+  for (uint32_t p = 0; p < W; p++) {
+    Rec hd{}; hd.inv_rank = 0; hd.ret_rank = 0; hd.opidx = kInf; hd.f = kFNone; hd.a = 0; hd.b = 0; hd.cls = 0; hd.prod = kLookNone;
+    Rec tl = hd; tl.inv_rank = kInf; tl.ret_rank = kInf;
+    w.rec[w.seg[p]] = hd; w.rec[w.seg[p + 1] - 1] = tl;
+    for (size_t k = 0; k < lists[p].size(); k++) {
+      const uint32_t i = lists[p][k];
+      Rec r{}; r.inv_rank = inv_rank[i]; r.ret_rank = ret_rank[i]; r.opidx = i; r.f = f[i]; r.a = a[i]; r.b = b[i];
+      r.cls = rec_cls(f[i], a[i], ret_rank[i] == kInf); r.prod = look_prod(f[i], a[i], b[i]);
+      w.rec[w.seg[p] + 1 + k] = r;
+      w.scratch[2 * (size_t)n + i] = w.seg[p] + 1 + (uint32_t)k;
+      if (k > 0 && !(ret_rank[lists[p][k - 1]] < inv_rank[i])) overlap = true;      // (a crashed predecessor: kInf < x is false)
+    }
+  }
+  w.status = overlap ? (uint32_t)TBC_ERR_BAD_HISTORY : 0u;
+}
+
+}  // namespace
+
+extern "C" {
+
+void emu_pack_stats(uint64_t* out, int reset) { for (int i = 0; i < 64; i++) { out[i] = wv::stats()[i]; if (reset) wv::stats()[i] = 0; } }
+
+// nh histories (ops at op_off[h] .. op_off[h + 1]), one workgroup each, launched `per_launch` histories at a time (h0 moves).
+// count != 0: the count form's inputs -- live calls on re-used slots, a crashed call slotless (the host's re-numbering, restated as
+// in host_tables.h).  Returns 0 when every word agrees, else a code; diag = {history, index, got, want}.
+int emu_pack_one_check(uint32_t nh, const uint64_t* op_off, const uint32_t* n_process, const uint32_t* n_events, const uint8_t* f, const int32_t* a,
+                       const int32_t* b, const int32_t* process, const uint32_t* inv_pos, const uint32_t* ret_pos, uint32_t model_kind,
+                       uint32_t n_classes, uint32_t count, uint32_t per_launch, uint64_t seed, uint64_t* diag) {
+  const uint64_t total = op_off[nh];
+  std::vector<int32_t> slot(process, process + total);
+  std::vector<Hist> hist(nh);
+  uint64_t rec_n = 0, seg_n = 0;
+  for (uint32_t h = 0; h < nh; h++) {
+    const uint64_t o = op_off[h];
+    const uint32_t n = (uint32_t)(op_off[h + 1] - o);
+    uint32_t W = n_process[h];
+    if (count) {
+      std::vector<int32_t> slot_of(n_process[h] + 1, -1);
+      std::vector<uint8_t> used(n_process[h] + 2, 0);
+      W = 1;
+      for (uint32_t i = 0; i < n; i++) {
+        const int32_t p = process[o + i];
+        if (p < 0 || (uint32_t)p >= n_process[h]) continue;                 // (a bad row: left for the kernel to refuse)
+        if (ret_pos[o + i] == TBC_POS_CRASHED) { if (slot_of[p] >= 0) { used[slot_of[p]] = 0; slot_of[p] = -1; } slot[o + i] = 0; continue; }
+        if (slot_of[p] < 0) { uint32_t sl = 0; while (used[sl]) sl++; used[sl] = 1; slot_of[p] = (int32_t)sl; W = std::max(W, sl + 1); }
+        slot[o + i] = slot_of[p];
+      }
+    }
+    Hist& H = hist[h];
+    H = Hist{};
+    H.op_off = o; H.rec_off = rec_n; H.seg_off = seg_n; H.ret_off = o; H.bm_off = 0; H.frame_off = 3 * o;
+    H.n_ops = n; H.n_events = n_events[h]; H.n_slots = W; H.n_ret = 0xABABABABu; H.status = 0xCDCDCDCDu; H.flags = count ? kHistCount : 0u;
+    rec_n += (uint64_t)n + 2ull * W; seg_n += W + 1;
+    if (!packone::fits(model_kind, n, H.n_events, W)) return 90;
+  }
+  std::vector<Rec> rec(rec_n);
+  memset(rec.data(), 0xEE, rec.size() * sizeof(Rec));
+  std::vector<uint32_t> seg(seg_n, 0xEEEEEEEEu), ret_slot(total, 0xEEEEEEEEu), ret_op(total, 0xEEEEEEEEu), scratch(3 * total, 0xEEEEEEEEu);
+  PackArgs A{};
+  A.hist = hist.data(); A.f = f; A.a = a; A.b = b; A.process = slot.data(); A.inv_pos = inv_pos; A.ret_pos = ret_pos;
+  A.rec = rec.data(); A.seg = seg.data(); A.ret_slot = ret_slot.data(); A.ret_op = ret_op.data();
+  A.bitmap = nullptr; A.wpre = nullptr;                    // the LDS tables replace them
+  A.scratch = scratch.data(); A.frame_words = 3; A.n_hist = nh; A.model_kind = model_kind; A.n_classes = n_classes; A.dbg = nullptr;
+  A.pool_vals = nullptr; A.pool_len = 0; A.n_keys = 0;
+  std::vector<uint32_t> lds(packone::lds_words());
+  if (per_launch == 0) per_launch = nh;
+  for (uint32_t h0 = 0; h0 < nh; h0 += per_launch) {
+    PackArgs L = A; L.h0 = h0; L.n_hist = std::min(nh, h0 + per_launch);
+    for (uint32_t g = 0; g < L.n_hist - h0; g++) {
+      std::fill(lds.begin(), lds.end(), 0xDEADBEEFu);        // LDS is not zeroed on the device either
+      Call c{&L, lds.data()};
+      wv::run_workgroup(&entry, &c, (int)packone::kNW, g, seed + h0 + g);
+    }
+  }
+  for (uint32_t h = 0; h < nh; h++) {
+    const Hist& H = hist[h];
+    const uint64_t o = H.op_off;
+    const uint32_t n = H.n_ops, W = H.n_slots;
+    Want w;
+    want_for(n, W, H.n_events, count != 0, f + o, a + o, b + o, slot.data() + o, inv_pos + o, ret_pos + o, model_kind, n_classes, w);
+#define MISMATCH(code, idx, got, want) do { diag[0] = h; diag[1] = (idx); diag[2] = (got); diag[3] = (want); return (code); } while (0)
+    if (H.status != w.status) MISMATCH(1, 0, H.status, w.status);
+    if (H.n_ret != w.n_ret) MISMATCH(2, 0, H.n_ret, w.n_ret);
+    if (!w.tables) continue;
+    for (uint32_t p = 0; p <= W; p++) if (seg[H.seg_off + p] != w.seg[p]) MISMATCH(3, p, seg[H.seg_off + p], w.seg[p]);
+    for (uint32_t r = 0; r < w.n_ret; r++) {
+      if (ret_slot[o + r] != w.ret_slot[r]) MISMATCH(4, r, ret_slot[o + r], w.ret_slot[r]);
+      if (ret_op[o + r] != w.ret_op[r]) MISMATCH(5, r, ret_op[o + r], w.ret_op[r]);
+    }
+    for (uint32_t x = 0; x < 3 * n; x++) if (scratch[3 * o + x] != w.scratch[x]) MISMATCH(6, x, scratch[3 * o + x], w.scratch[x]);
+    for (uint32_t x = 0; x < w.seg[W]; x++) {
+      const uint32_t* g = reinterpret_cast<const uint32_t*>(&rec[H.rec_off + x]);
+      const uint32_t* e = reinterpret_cast<const uint32_t*>(&w.rec[x]);
+      for (uint32_t k = 0; k < 8; k++) if (g[k] != e[k]) MISMATCH(7, x * 8 + k, g[k], e[k]);
+    }
+#undef MISMATCH
+  }
+  return 0;
+}
+
+}  // extern "C"

@@ -21,6 +21,7 @@ inline uint32_t lds_ld32(const uint32_t* p) { return *p; }
 inline uint32_t lds_cas32(uint32_t* p, uint32_t expected, uint32_t desired) { const uint32_t old = *p; if (old == expected) *p = desired; return old; }
 inline void lds_or32(uint32_t* p, uint32_t v) { *p |= v; }
 inline uint32_t lds_fetch_add32(uint32_t* p, uint32_t v) { const uint32_t old = *p; *p += v; return old; }
+inline void lds_add32_wg(uint32_t* p, uint32_t v) { *p += v; }
 inline uint32_t wave_or32_at(uint32_t v, int site) {
   const uint64_t* s = gather(v, site);
   uint32_t r = 0;
