@@ -309,16 +309,24 @@ def leg_one_form(args, local_rank):
     hs = synth.register_ops_many(range(10), n_ops=args.ops, n_procs=args.procs, busy=args.busy, info=0.0)
     bad = columns.pair_events(synth.register_events(n_ops=args.ops, n_procs=args.procs, seed=12345, busy=args.busy, info=0.0, corrupt=0.5))
     core.check_ops(hs[0], model, o); core.check_ops(hs[0], model, o)
-    tt, sig = [], []
+    tt, sig, parts = [], [], []
     for h in hs:
-        best = 1e9
+        best, bp = 1e9, None
         for _ in range(3):
-            t = time.perf_counter(); r = core.check_ops(h, model, o); best = min(best, (time.perf_counter() - t) * 1e3)
-        tt.append(best); sig.append([int(r["valid"]), int(r["analyzer"]), int(r["steps"]), int(r["visited"]), int(r["probes"])])
+            t = time.perf_counter(); r = core.check_ops(h, model, o); dt = (time.perf_counter() - t) * 1e3
+            if dt < best:
+                best, bp = dt, (r["ns_pack"] / 1e3, r["ns_search"] / 1e3, r["ns_total"] / 1e3)
+        tt.append(best); parts.append(bp); sig.append([int(r["valid"]), int(r["analyzer"]), int(r["steps"]), int(r["visited"]), int(r["probes"])])
     t = time.perf_counter(); rb = core.check_ops(bad, model, o); tb = (time.perf_counter() - t) * 1e3
-    sig.append([int(rb["valid"]), int(rb["analyzer"]), int(rb["fail_op"])])
+    sig.append([int(rb["valid"]), int(rb["analyzer"]), -1 if rb["fail_op"] is None else int(rb["fail_op"])])
+    med = lambda k: round(statistics.median(p[k] for p in parts), 1)
     return {"valid_median_ms": round(statistics.median(tt), 3), "valid_min_ms": round(min(tt), 3), "valid_max_ms": round(max(tt), 3),
-            "invalid_example_ms": round(tb, 3), "signature": sig}
+            "invalid_example_ms": round(tb, 3),
+            # where a call's time goes (medians over the histories' best runs): HIP events around the pack kernels and around the
+            # search (the sweep and what follows it), wall time inside tbc_check, and what the ctypes binding adds around it
+            "breakdown_us": {"device_pack": med(0), "device_search": med(1), "inside_tbc_check": med(2),
+                             "binding_around_it": round(statistics.median(tt) * 1e3 - med(2), 1)},
+            "signature": sig}
 
 
 def leg_single_history_forms(args, local_rank):

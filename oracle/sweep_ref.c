@@ -158,6 +158,20 @@ void sweep_set_export(void* rel, uint32_t max_segs, uint32_t rank, uint32_t worl
   g_rel = (tbc_sweep_rel*)rel; g_rel_segs = max_segs; g_rel_rank = rank; g_rel_world = world ? world : 1;
 }
 
+/* lookahead (the wide search's rule, wgl_beam.c, applied to the sweep; 0 = off, else the completions looked at = 8 in the kernels):
+ * a config at front F is DEAD when the call completing at one of the next `depth` ranks can never be linearized from it -- it is not
+ * linearized yet and needs a register value (0..31) that is neither the state nor produced (:write v / :cas [_ v]) by any OTHER call
+ * that can still be linearized before that completion: a call open somewhere in [F, t] (crashed ones invoked before t included) that is
+ * not open-at-F-and-linearized.  No linearization goes through a dead config, so the sweep drops it where it would enter a set: an
+ * origin, a pending child (at its level's front), a config entering the next level (at that front).  A verdict VALID is therefore
+ * unchanged; a set may run EMPTY EARLIER than without the rule (the configs were doomed, not yet refuted), so an INVALID verdict under
+ * the rule names a completion at or before the failing one -- the library sweeps such a history once more without the rule for
+ * its failing op and :configs.  Counters (levels' sizes, probes, sub-rounds) are the rule's own. */
+static uint32_t g_look = 0;
+void sweep_set_lookahead(uint32_t depth) { g_look = depth; }
+static _Thread_local uint64_t g_look_dropped = 0;
+uint64_t sweep_look_dropped(void) { return g_look_dropped; }
+
 typedef struct {
   uint32_t n, R, W, MW, KW;
   const uint8_t* f; const int32_t* a; const int32_t* b; const int32_t* process;
@@ -179,11 +193,37 @@ static void normalise(const hist_t* H, uint64_t* key, uint32_t F) {
   }
 }
 
+static int is_dead(const hist_t* H, const uint64_t* key, uint32_t F) {
+  if (!g_look || F >= H->R) return 0;
+  const int32_t s = (int32_t)(uint32_t)(key[0] >> 32);
+  for (uint32_t j = 0; j < g_look && F + j < H->R; j++) {
+    const uint32_t t = F + j, fop = H->ret_op[t], pf = (uint32_t)H->process[fop];
+    if (!((H->f[fop] == O_READ && H->a[fop] != O_NIL) || H->f[fop] == O_CAS)) continue;
+    const int32_t v = H->a[fop];
+    if (v < 0 || v >= 32) continue;
+    if (H->inv_rank[fop] <= F && bit(key + 1, pf)) continue;                 /* already linearized */
+    if (v == s) continue;
+    int ok = 0;
+    for (uint32_t F2 = F; F2 <= t && !ok; F2++) {                             /* calls open somewhere in [F, t] */
+      const uint32_t nl = H->off[F2 + 1] - H->off[F2], tot = nl + (F2 == t ? H->ncr[F2] : 0);
+      for (uint32_t cc = 0; cc < tot && !ok; cc++) {
+        const uint32_t x = cc < nl ? H->lst[H->off[F2] + cc] : H->crashed[cc - nl];
+        if (x == fop) continue;
+        if (H->inv_rank[x] <= F && bit(key + 1, (uint32_t)H->process[x])) continue;   /* open at F, linearized */
+        if ((H->f[x] == O_WRITE && H->a[x] == v) || (H->f[x] == O_CAS && H->b[x] == v)) ok = 1;
+      }
+    }
+    if (!ok) { g_look_dropped++; return 1; }
+  }
+  return 0;
+}
+
 /* a config that has X (slot px) linearized passes completion F: into level F+1 (front F+1 < R) or the end set */
 static void pass_level(const hist_t* H, cset* nxt, const uint64_t* key, orgset org, uint32_t px, uint32_t F, uint64_t* tmp) {
   memcpy(tmp, key, H->KW * 8);
   clrb(tmp + 1, px);
   if (F + 1 < H->R) normalise(H, tmp, F + 1);
+  if (is_dead(H, tmp, F + 1)) return;
   cs_add(nxt, tmp, org);
 }
 
@@ -316,6 +356,7 @@ int sweep_ref_check(uint32_t n, const uint8_t* f, const int32_t* a, const int32_
         normalise(&H, tmp, F0);
         if (sg == 0) memcpy(key, tmp, KW * 8);                       /* the initial config is taken in normal form */
         else if (memcmp(tmp, key, KW * 8) != 0) continue;             /* not in normal form: no config has this id */
+        if (is_dead(&H, key, F0)) continue;
         cs_add(&cur, key, (orgset)1 << l);
       }
       if (cur.n == 0) continue;                                       /* the kernel's wavefront has nothing to sweep */
@@ -366,7 +407,7 @@ int sweep_ref_check(uint32_t n, const uint8_t* f, const int32_t* a, const int32_
               key[0] = (uint64_t)(uint32_t)s2 << 32;
               normalise(&H, key, F);
               if (bit(key + 1, px)) pass_level(&H, &nxt, key, org, px, F, tmp);
-              else cs_add(Q, key, org);
+              else if (!is_dead(&H, key, F)) cs_add(Q, key, org);
             }
           }
           { cset* t = P; P = Q; Q = t; }
