@@ -366,7 +366,76 @@ def leg_single_history_forms(args, local_rank):
     return out
 
 
-LEGS = {"tiers": leg_tiers, "one_form": leg_one_form, "single_history_forms": leg_single_history_forms, "set_full": leg_set_full,
+# ---- extra.batch_forms: ONE resident batch of the headline workload (a quarter of its size) under the switchable forms of the batch
+# path, each in a process of its own (the switches are read once per process), never fatal -- as extra.single_history_forms.
+BATCH_FORMS = [("pack_kernel + open_counts_kernel (the default)", {}),
+               ("pack + open counts by four wavefronts per history, tables in LDS", {"TBC_PACK_WG": "2"})]
+
+
+def leg_one_batch_form(args, local_rank):
+    """One form (this process's environment): a batch of 8,192 headline histories with one planted invalid one, by the narrow kernel named
+    outright (8 lanes per history: what the library takes by itself from 24,576 histories), three passes; the device-time
+    breakdown of the best, and the counters every form must agree on."""
+    np, N, columns, core, synth = _gpu_imports()
+    model = core.make_model(N.MODEL_CAS_REGISTER, N.NIL)
+    B = 8192
+    hs = synth.register_ops_many(range(5_000_000, 5_000_000 + B), n_ops=args.ops, n_procs=args.procs, busy=args.busy, info=0.0)
+    hs[77] = columns.pair_events(synth.register_events(n_ops=args.ops, n_procs=args.procs, seed=5_000_077, busy=args.busy, info=0.0, corrupt=0.02))
+    o = core.make_opts(device=local_rank, time_limit_ms=600000, want_witness=False, algorithm=N.ALG_COMPETITION, visited_per_op=args.visited_per_op,
+                       lanes_per_history=8)
+    best = None
+    with core.Batch(hs, model, o) as b:
+        lanes = b.lanes_per_history()
+        for _ in range(4):
+            t = time.perf_counter(); b.run(); dt = (time.perf_counter() - t) * 1e3
+            tm = b.timing_ns()
+            if best is None or dt < best[0]:
+                best = (dt, tm)
+        c = b.counters(); v = b.verdicts()
+    return {"histories": B, "lanes_per_history": lanes, "ms_per_pass": round(best[0], 3),
+            "device_ms": {k: round(x / 1e6, 3) for k, x in best[1].items()},
+            "signature": [int((v == N.VALID).sum()), int((v == N.INVALID).sum()), int(np.flatnonzero(v == N.INVALID)[0]) if (v == N.INVALID).any() else -1,
+                          int(c["probes"]), int(c["visited"])]}
+
+
+def leg_batch_forms(args, local_rank):
+    import subprocess
+    out, base = [], None
+    for name, env in BATCH_FORMS:
+        leg("batch form: " + name)
+        entry = {"form": name, "env": env}
+        try:
+            cmd = [sys.executable, os.path.abspath(__file__)] + [a for a in sys.argv[1:] if a not in ("--leg", "batch_forms")] + ["--leg", "one_batch_form"]
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, timeout=240, env=dict(os.environ, LOCAL_RANK=str(local_rank), **env))
+            res = None
+            for ln in reversed(r.stdout.decode(errors="replace").splitlines()):
+                if ln.startswith("{"):
+                    try:
+                        d = json.loads(ln)
+                    except ValueError:
+                        continue
+                    if d.get("leg") == "one_batch_form":
+                        res = d["result"]
+                        break
+            if res is None or r.returncode != 0:
+                entry["error"] = f"return code {r.returncode}, no result"
+            else:
+                sig = res.pop("signature")
+                if not env:
+                    base = sig
+                entry.update(res)
+                entry["_sig"] = sig
+        except subprocess.TimeoutExpired:
+            entry["error"] = "did not finish within 240 s"
+        out.append(entry)
+    for e in out:          # the same verdicts, the same planted history found, the same probes and new configs as the default form
+        sig = e.pop("_sig", None)
+        if sig is not None:
+            e["counters_match"] = base is not None and sig == base
+    return out
+
+
+LEGS = {"tiers": leg_tiers, "one_batch_form": leg_one_batch_form, "batch_forms": leg_batch_forms, "one_form": leg_one_form, "single_history_forms": leg_single_history_forms, "set_full": leg_set_full,
         "workload_2": lambda a, d: leg_workload(a, d, "workload_2"), "workload_3": lambda a, d: leg_workload(a, d, "workload_3"),
         "workload_crashed": lambda a, d: leg_workload(a, d, "workload_crashed")}
 
@@ -780,6 +849,10 @@ def main():
                 line["extra"]["single_history_forms"] = run_leg("single_history_forms", args, local_rank)
             except SystemExit as e:      # (this leg measures forms not yet timed on the device: it reports, it never fails the run)
                 line["extra"]["single_history_forms"] = {"error": str(e)}
+            try:
+                line["extra"]["batch_forms"] = run_leg("batch_forms", args, local_rank)
+            except SystemExit as e:
+                line["extra"]["batch_forms"] = {"error": str(e)}
         print(json.dumps(line), flush=True)
     for b in batches:
         b.close()

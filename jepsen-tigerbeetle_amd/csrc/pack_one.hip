@@ -1,7 +1,10 @@
-// pack_one.hip -- K1 for one history (or a handful): pack by a workgroup's sixteen wavefronts (gfx950); the body is pack_one_impl.h.
-// Same inputs, same bytes left behind as pack_kernel (pack.hip), which keeps the batches and the models this body does not take.
-// STANDING: the body is verified under the workgroup emulator (tests/test_pack_one_emu.py) and had not run on the device when it was
-// committed; tbc_api.hip takes it only under TBC_PACK_ONE=1 (bench.py's extra.single_history_forms measures it).
+// pack_one.hip -- K1 by a workgroup's wavefronts with its tables in LDS (gfx950); the body is pack_one_impl.h.  Two forms:
+//   pack_one_kernel  one history (or a handful): sixteen wavefronts, same inputs and same bytes left behind as pack_kernel (pack.hip);
+//   pack_wg_kernel   a batch: four wavefronts per history, pack_kernel's AND open_counts_kernel's (pack_open.hip) bytes in one pass --
+//                    the ranks never leave the registers between the two.
+// pack_kernel + open_counts_kernel keep the models and the histories these bodies do not take.
+// STANDING: both bodies are verified under the workgroup emulator (tests/test_pack_one_emu.py) and had not run on the device when
+// they were committed; tbc_api.hip takes them only under TBC_PACK_ONE=1 / TBC_PACK_WG=1 (bench.py's extra legs measure them).
 #include <hip/hip_runtime.h>
 #include "tbc_internal.h"
 #include "pack_one_impl.h"
@@ -9,9 +12,14 @@
 namespace tbc {
 
 namespace {
-__global__ __launch_bounds__(64 * packone::kNW) void pack_one_kernel(PackArgs A) {
+__global__ __launch_bounds__(64 * packone::OneGeo::kNW) void pack_one_kernel(PackArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-  packone::history(A, lds);
+  const PackOpenArgs none{};
+  packone::history<packone::OneGeo>(A, none, lds);
+}
+__global__ __launch_bounds__(64 * packone::BatchGeo::kNW) void pack_wg_kernel(PackArgs A, PackOpenArgs O) {
+  __shared__ __attribute__((aligned(16))) uint32_t lds[packone::BatchGeo::lds_words()];
+  packone::history<packone::BatchGeo>(A, O, lds);
 }
 }  // namespace
 
@@ -25,6 +33,19 @@ bool launch_pack_one(const PackArgs& a, void* stream) {
   static bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&pack_one_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
   if (!ok || a.n_hist <= a.h0) return false;
   hipLaunchKernelGGL(pack_one_kernel, dim3(a.n_hist - a.h0), dim3(64 * packone::kNW), bytes, (hipStream_t)stream, a);
+  return true;
+}
+
+bool pack_wg_fits(uint32_t model_kind, uint32_t n_ops, uint32_t n_events, uint32_t n_slots) {
+  return packone::BatchGeo::fits(model_kind, n_ops, n_events, n_slots);
+}
+
+// histories [a.h0, a.n_hist), one workgroup of four wavefronts each (31 KB of LDS, static): pack + open counts.  The caller has
+// asked pack_wg_fits() of every history, o is what launch_pack_open() would hand open_counts_kernel (same h0 / n_hist), and the
+// walk that follows is launched with skip_counts.  false = not launched.
+bool launch_pack_wg(const PackArgs& a, const PackOpenArgs& o, void* stream) {
+  if (a.n_hist <= a.h0 || o.h0 != a.h0 || o.n_hist != a.n_hist || !o.bh || !o.off || !o.ncr || !o.slot8 || (o.branch_lists && !o.rk8)) return false;
+  hipLaunchKernelGGL(pack_wg_kernel, dim3(a.n_hist - a.h0), dim3(64 * packone::BatchGeo::kNW), 0, (hipStream_t)stream, a, o);
   return true;
 }
 

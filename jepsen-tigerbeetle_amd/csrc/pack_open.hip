@@ -598,13 +598,13 @@ void launch_open_counts(const PackOpenArgs& a, void* stream) {
   hipLaunchKernelGGL(open_counts_kernel, dim3(n_here < 4096 ? n_here : 4096), dim3(n_here <= 64 ? 1024 : 256), 0, (hipStream_t)stream, a);
 }
 
-void launch_pack_open(const PackOpenArgs& a, void* stream) {
+void launch_pack_open(const PackOpenArgs& a, void* stream, bool skip_counts) {
   hipStream_t s = (hipStream_t)stream;
   const uint32_t n_here = a.n_hist - a.h0;
   const uint32_t grid = n_here < 4096 ? n_here : 4096;
   // few histories: latency matters (tbc_check), give each the widest workgroup; many: occupancy matters
   const uint32_t nt = n_here <= 64 ? 1024 : 256;
-  hipLaunchKernelGGL(open_counts_kernel, dim3(grid), dim3(nt), 0, s, a);
+  if (!skip_counts) hipLaunchKernelGGL(open_counts_kernel, dim3(grid), dim3(nt), 0, s, a);
   if (a.cmem) hipLaunchKernelGGL(count_fronts_kernel, dim3(grid), dim3(256), 0, s, a, 0u);
   const uint64_t waves = (uint64_t)n_here * a.chunks_per_hist;
   const uint32_t wgrid = (uint32_t)((waves + 3) / 4);

@@ -1168,11 +1168,24 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results, int phase = 
     for (uint32_t h = 0; h < nh; h++) fits = fits && pack_one_fits(B->model.kind, B->hist[h].n_ops, B->hist[h].n_events, B->hist[h].n_slots);
     if (fits) packed = launch_pack_one(make_pack_args(B), s);
   }
+  // TBC_PACK_WG=1 (experimental; pack_one.hip, pack_wg_kernel): a batch of the wide schedule is packed by four wavefronts per history
+  // with the tables in LDS, and the same pass leaves what open_counts_kernel would (the ranks never leave the registers between the
+  // two).  Verified under the emulator only (tests/test_pack_one_emu.py); nothing takes it unless asked
+  // (TBC_PACK_WG=2: a batch of the wide schedule that cannot take it is an error instead of pack_kernel's -- the measurements' and the
+  // GPU tests' guarantee that they ran what they name)
+  static const int pack_wg = [] { const char* e = std::getenv("TBC_PACK_WG"); return (e && (e[0] == '1' || e[0] == '2')) ? e[0] - '0' : 0; }();
+  bool counted = false;
+  if (!packed && pack_wg && beam) {
+    bool fits = true;
+    for (uint32_t h = 0; h < nh && fits; h++) fits = pack_wg_fits(B->model.kind, B->hist[h].n_ops, B->hist[h].n_events, B->hist[h].n_slots);
+    if (fits) packed = counted = launch_pack_wg(make_pack_args(B), make_pack_open_args(B), s);
+    if (!counted && pack_wg == 2) { set_error("TBC_PACK_WG=2: this batch does not fit the workgroup pack (model, rows, slots or ops per history)"); return TBC_ERR_UNSUPPORTED; }
+  }
   if (!packed) launch_pack(make_pack_args(B), s);
   HIP_TRY(hipGetLastError());
   if (beam) {
     PackOpenArgs po = make_pack_open_args(B);
-    launch_pack_open(po, s);
+    launch_pack_open(po, s, counted);
     HIP_TRY(hipGetLastError());
   }
   TRACE("run: pack launched");

@@ -373,7 +373,8 @@ bool launch_sweep(const SweepArgs& a, void* stream);
 // K6w (jit_sweep_wg.hip): the first pass with `waves` (4 / 8) wavefronts per segment; false = not for this batch (the caller takes K6)
 bool launch_sweep_wg(const SweepArgs& a, uint32_t waves, void* stream);
 
-void launch_pack_open(const PackOpenArgs& a, void* stream);
+// skip_counts: open_counts_kernel's tables are already there (launch_pack_wg built them with the pack)
+void launch_pack_open(const PackOpenArgs& a, void* stream, bool skip_counts = false);
 // open_counts_kernel alone: how many entries each history's per-front lists hold (BeamHist.lst_need), before those arenas exist
 void launch_open_counts(const PackOpenArgs& a, void* stream);
 bool launch_beam(const BeamArgs& a, uint32_t mask_words, uint32_t n_blocks, void* stream);
@@ -387,6 +388,10 @@ void launch_pack(const PackArgs& a, void* stream);
 // K1 for one history or a handful (pack_one.hip): does the body take such a history; launch it for [a.h0, a.n_hist) (false = not launched)
 bool pack_one_fits(uint32_t model_kind, uint32_t n_ops, uint32_t n_events, uint32_t n_slots);
 bool launch_pack_one(const PackArgs& a, void* stream);
+// K1 + open counts for a batch (pack_one.hip, pack_wg_kernel): four wavefronts per history, tables in LDS; o = what launch_pack_open()
+// would give open_counts_kernel.  false = not launched (the caller takes pack_kernel, and launch_pack_open() without skip_counts)
+bool pack_wg_fits(uint32_t model_kind, uint32_t n_ops, uint32_t n_events, uint32_t n_slots);
+bool launch_pack_wg(const PackArgs& a, const PackOpenArgs& o, void* stream);
 // returns false if mw is unsupported
 bool launch_search(const SearchArgs& a, uint32_t mask_words, uint32_t n_blocks, void* stream);
 uint32_t search_frame_words(uint32_t mask_words);

@@ -208,7 +208,7 @@ _LIB_PACK = None
 
 
 def build_pack(force=False):
-    srcs = [os.path.join(_HERE, "emu_pack.cpp"), os.path.join(_HERE, "wave_env_emu.h"), os.path.join(_HERE, "wave_env_wg_emu.h"),
+    srcs = [os.path.join(_HERE, "emu_pack.cpp"), os.path.join(_HERE, "wave_env_emu.h"), os.path.join(_HERE, "wave_env_wg_emu.h"), os.path.join(_HERE, "host_tables.h"),
             os.path.join(_CSRC, "pack_one_impl.h"), os.path.join(_CSRC, "tbc_internal.h"), os.path.join(_CSRC, "wave_env.h"), os.path.join(_CSRC, "wave_env_wg.h")]
     if force or not os.path.exists(_SO_PACK) or any(os.path.getmtime(s) > os.path.getmtime(_SO_PACK) for s in srcs):
         os.makedirs(os.path.dirname(_SO_PACK), exist_ok=True)
@@ -253,4 +253,45 @@ def pack_one_check(hists, model_kind=1, n_classes=0, count=False, per_launch=0, 
     if rc == 0:
         return None
     what = {1: "status", 2: "n_ret", 3: "seg", 4: "ret_slot", 5: "ret_op", 6: "scratch", 7: "rec word", 90: "does not fit"}.get(rc, str(rc))
+    return (what, int(diag[0]), int(diag[1]), int(diag[2]), int(diag[3]))
+
+
+def pack_wg_check(hists, model_kind=1, n_classes=0, vpad=8, count=False, branch=False, look=True, rk8=True, lst_cap=0, per_launch=0, seed=1, n_events=None):
+    """The batch form (csrc/pack_one_impl.h, BatchGeo: four wavefronts per history, pack + open counts in one pass) under the workgroup
+    emulator: every word pack_kernel AND open_counts_kernel would leave -- as pack_one_check, plus off[], ncr[], slot8, rk8, the
+    crashed-call list, the lookahead records past the last rank, BeamHist.status / n_crashed / lst_need -- against the restatements in
+    emu_pack.cpp and host_tables.h.  Returns None when all agree, else (what, history, index, got, want)."""
+    global _LIB_PACK
+    if _LIB_PACK is None:
+        _LIB_PACK = C.CDLL(build_pack())
+        _LIB_PACK.emu_pack_one_check.restype = C.c_int
+    _LIB_PACK.emu_pack_wg_check.restype = C.c_int
+    ds = [h if isinstance(h, dict) else h.as_dict() for h in hists]
+    nh = len(ds)
+    op_off = np.zeros(nh + 1, np.uint64)
+    for i, d in enumerate(ds):
+        op_off[i + 1] = op_off[i] + len(d["f"])
+    cat = lambda k, dt: np.ascontiguousarray(np.concatenate([np.asarray(d[k], dt) for d in ds]), dt)
+    f, a, b = cat("f", np.uint8), cat("a", np.int32), cat("b", np.int32)
+    pr, inv, ret = cat("process", np.int32), cat("inv_pos", np.uint32), cat("ret_pos", np.uint32)
+    npr = np.array([int(d["n_process"]) for d in ds], np.uint32)
+    if n_events is None:
+        n_events = []
+        for h, d in zip(hists, ds):
+            if getattr(h, "n_events", None) is not None:
+                n_events.append(int(h.n_events))
+                continue
+            r = np.asarray(d["ret_pos"], np.uint64); i = np.asarray(d["inv_pos"], np.uint64)
+            live = r[r != 0xFFFFFFFF]
+            n_events.append(int(max(int(i.max()) if len(i) else 0, int(live.max()) if len(live) else 0)) + 1)
+    ne = np.ascontiguousarray(n_events, np.uint32)
+    diag = np.zeros(8, np.uint64)
+    flags = (1 if count else 0) | (2 if branch else 0) | (4 if look else 0) | (8 if rk8 else 0)
+    rc = _LIB_PACK.emu_pack_wg_check(C.c_uint32(nh), _p(op_off, C.c_uint64), _p(npr, C.c_uint32), _p(ne, C.c_uint32), _p(f, C.c_uint8), _p(a, C.c_int32),
+                                     _p(b, C.c_int32), _p(pr, C.c_int32), _p(inv, C.c_uint32), _p(ret, C.c_uint32), C.c_uint32(model_kind),
+                                     C.c_uint32(n_classes), C.c_uint32(vpad), C.c_uint32(flags), C.c_uint32(lst_cap), C.c_uint32(per_launch), C.c_uint64(seed), _p(diag, C.c_uint64))
+    if rc == 0:
+        return None
+    what = {1: "status", 2: "n_ret", 3: "seg", 4: "ret_slot", 5: "ret_op", 6: "scratch", 7: "rec word", 10: "off", 11: "ncr", 12: "slot8", 13: "rk8", 14: "crashed",
+            15: "BeamHist.status", 16: "n_crashed", 17: "lst_need", 18: "look", 90: "does not fit", 91: "host tables"}.get(rc, str(rc))
     return (what, int(diag[0]), int(diag[1]), int(diag[2]), int(diag[3]))

@@ -109,3 +109,67 @@ def test_histories_pack_refuses():
     ne = int(max(d["inv_pos"].max(), d["ret_pos"][d["ret_pos"] != 0xFFFFFFFF].max())) + 1
     assert emu.pack_one_check([d], n_events=[ne - 1]) is None
     assert emu.pack_one_check([d], n_events=[ne + 1000]) is None          # rows after the last op (nemesis lines): fine
+
+
+# ---- the batch form: four wavefronts per history, pack + open counts in one pass (BatchGeo; TBC_PACK_WG=1)
+@pytest.mark.parametrize("seed", [1, 2])
+@pytest.mark.parametrize("branch", [False, True])
+def test_batch_form_every_word_of_pack_and_open_counts(seed, branch):
+    """all shapes, with the full lists and with branch lists (live reads left out, the reads' completions subtracted), crashed calls in
+    the mask form (ncr[], the crashed-call list) -- every word pack_kernel and open_counts_kernel would leave"""
+    assert emu.pack_wg_check(_hists(), branch=branch, seed=seed) is None
+    assert emu.pack_wg_check(_hists(seeds=(3,)), branch=branch, look=False, rk8=False, vpad=32, seed=seed + 10) is None
+
+
+def test_batch_form_count_form_and_crash_heavy():
+    h = [columns.pair_events(synth.register_events(n_ops=n, n_procs=p, seed=s, busy=busy, info=info))
+         for (n, p, busy, info) in [(600, 16, 0.5, 0.1), (900, 64, 0.2, 0.3), (130, 4, 1.0, 0.5), (64, 8, 0.5, 1.0)] for s in (1, 2)]
+    assert emu.pack_wg_check(h, count=True, seed=3) is None                 # count form: no ncr[], no crashed list from this kernel
+    assert emu.pack_wg_check(h, count=True, branch=True, seed=4) is None
+    small = [x for x in h if x.n_process <= 256]
+    assert len(small) >= 4
+    assert emu.pack_wg_check(small, count=False, seed=5) is None            # the same in the mask form: a slot per crashed call
+    assert emu.pack_wg_check(small, count=False, branch=True, per_launch=3, seed=6) is None
+
+
+def test_batch_form_full_size_histories():
+    """BASELINE.json configs[1] (10k invocations / 64 processes: 7,3xx completions of the 8,192 the LDS histogram holds) at 10 % and
+    50 % duty, with crashed calls in both forms"""
+    h = synth.register_ops_many(range(7000, 7002), n_ops=10000, n_procs=64, busy=0.1, info=0.0)
+    busy = synth.register_ops_many(range(7100, 7101), n_ops=10000, n_procs=64, busy=0.5, info=0.0)
+    crashed = synth.register_ops_many(range(7200, 7201), n_ops=10000, n_procs=64, busy=0.1, info=0.01)
+    assert emu.pack_wg_check(h + busy, branch=True, seed=11) is None
+    assert emu.pack_wg_check(h[:1] + crashed, branch=False, seed=12) is None
+    assert emu.pack_wg_check(crashed, count=True, branch=True, seed=13) is None
+
+
+def test_batch_form_lists_that_do_not_fit_and_histories_pack_refuses():
+    """a list arena too small: BeamHist.status 1, lst_need says how much; a refused history: no lists, as open_counts_kernel leaves it"""
+    hs = _hists(seeds=(4,), shapes=[(400, 12, 0.6, 0.02), (300, 16, 0.3, 0.0)])
+    assert emu.pack_wg_check(hs, lst_cap=50, seed=1) is None
+    good = hs[0]
+    d = _d(good); d["inv_pos"][100], d["inv_pos"][101] = d["inv_pos"][101], d["inv_pos"][100]
+    e = _d(good); e["f"][33] = 77
+    g = _d(good)
+    p0 = np.flatnonzero(g["process"] == g["process"][0])
+    g["ret_pos"][p0[0]] = g["inv_pos"][p0[1]] + 1              # two calls of one process open at once: found by the last phase
+    assert emu.pack_wg_check([good, d, e, g, good], branch=True, seed=2) is None
+    one = columns.pair_events(synth.register_events(n_ops=1, n_procs=1, seed=1, busy=0.5, info=1.0))      # no completion at all
+    assert emu.pack_wg_check([one, good], seed=3) is None
+
+
+def test_batch_form_crashed_calls_invoked_after_the_last_completion():
+    """crashed calls invoked when nothing completes any more: in the crashed-call list, in no front's count (their rank is R)"""
+    good = _hists(seeds=(6,), shapes=[(300, 8, 0.5, 0.05)])[0]
+    d = _d(good)
+    last = int(max(d["inv_pos"].max(), d["ret_pos"][d["ret_pos"] != 0xFFFFFFFF].max()))
+    k = 4
+    d["f"] = np.concatenate([d["f"], np.full(k, N.F_WRITE, np.uint8)])
+    d["a"] = np.concatenate([d["a"], np.arange(k, dtype=np.int32)])
+    d["b"] = np.concatenate([d["b"], np.zeros(k, np.int32)])
+    d["process"] = np.concatenate([d["process"], np.arange(k, dtype=np.int32) + int(d["n_process"])])
+    d["inv_pos"] = np.concatenate([d["inv_pos"], (last + 1 + np.arange(k)).astype(np.uint32)])
+    d["ret_pos"] = np.concatenate([d["ret_pos"], np.full(k, 0xFFFFFFFF, np.uint32)])
+    d["n_process"] = int(d["n_process"]) + k
+    for branch in (False, True):
+        assert emu.pack_wg_check([d, good], branch=branch, seed=1) is None

@@ -1,5 +1,6 @@
 """The single-history path under each of its experimental forms, ON THE DEVICE: the level sweep's ring / fingerprint / sixteen-wavefront
-forms (jit_sweep_wg.hip) and pack by a workgroup's sixteen wavefronts (pack_one.hip).  Each form is selected by an environment switch
+forms (jit_sweep_wg.hip) and pack by a workgroup's sixteen wavefronts (pack_one.hip) -- and the batch form of that pack (four
+wavefronts per history, pack + open counts in one pass; TBC_PACK_WG=1) under the batch parity tests.  Each form is selected by an environment switch
 the library reads once per process, so each runs the sweep's own GPU tests (tests/test_sweep.py: every record against
 oracle/sweep_ref.c) -- and, for the pack, the histories pack must refuse -- in a process of its own.
 
@@ -19,7 +20,8 @@ pytestmark = pytest.mark.gpu
 
 # (the ring and the fingerprint forms one by one: bench.py's extra.single_history_forms compares their counters with the default's)
 FORMS = [("ring+fingerprint", {"TBC_SWEEP_WG_RING": "1", "TBC_SWEEP_WG_FP": "1"}), ("sixteen-wavefronts", {"TBC_SWEEP_WG": "16"}),
-         ("pack-one", {"TBC_PACK_ONE": "1"}), ("pack-one+ring+fingerprint", {"TBC_PACK_ONE": "1", "TBC_SWEEP_WG_RING": "1", "TBC_SWEEP_WG_FP": "1"})]
+         ("pack-one", {"TBC_PACK_ONE": "1"}), ("pack-one+ring+fingerprint", {"TBC_PACK_ONE": "1", "TBC_SWEEP_WG_RING": "1", "TBC_SWEEP_WG_FP": "1"}),
+         ("pack-wg", {"TBC_PACK_WG": "1"}), ("pack-wg-or-error", {"TBC_PACK_WG": "2"})]
 
 
 @pytest.mark.xfail(strict=False, reason="experimental form: emulator-verified, not yet run on the device when committed")
@@ -29,6 +31,15 @@ def test_form_passes_the_sweeps_own_gpu_tests(native, name, env):
     if "TBC_PACK_ONE" in env:        # what pack refuses, and one history through every engine
         targets += ["tests/test_gpu_parity.py::test_rejects_malformed_ops", "tests/test_gpu_parity.py::test_mutex_and_table_models",
                     "tests/test_gpu_parity.py::test_single_history_matches_oracle", "tests/test_gpu_parity.py::test_kat_through_knossos_surface"]
+    if "TBC_PACK_WG" in env:         # the batch form of the pack (four wavefronts per history, pack + open counts): the batches of the wide and the
+        # narrow schedule against their oracles (every counter depends on every list and count the pack leaves), what pack refuses
+        targets = ["tests/test_gpu_parity.py::test_narrow_kernel_matches_its_oracle", "tests/test_gpu_parity.py::test_narrow_kernel_rules_lookahead_growth_and_limits",
+                   "tests/test_gpu_parity.py::test_batch_matches_oracle_and_single", "tests/test_gpu_parity.py::test_rejects_malformed_ops",
+                   "tests/test_gpu_parity.py::test_lookahead_value_range_crashed_writers_and_plain_register", "tests/test_gpu_parity.py::test_wide_window_many_crashed_processes",
+                   "tests/test_gpu_parity.py::test_front_walk_by_front_and_by_slot_build_the_same_tables", "tests/test_gpu_parity.py::test_narrow_kernel_at_the_bench_configuration",
+                   "tests/test_count_form_gpu.py::test_count_form_several_histories_per_wavefront", "tests/test_count_form_gpu.py::test_count_form_agrees_with_the_mask_form"]
+    if env.get("TBC_PACK_WG") == "2":        # (2: a batch that does not take the workgroup pack is an error -- these all fit, so they ran it)
+        targets = ["tests/test_gpu_parity.py::test_narrow_kernel_matches_its_oracle", "tests/test_gpu_parity.py::test_big_quiet_batches_take_the_narrow_kernel_by_default"]
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"] + targets,
                        cwd=ROOT, env=dict(os.environ, **env), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
     tail = r.stdout.decode(errors="replace")[-1500:]
