@@ -1,10 +1,11 @@
 // pack_one.hip -- K1 by a workgroup's wavefronts with its tables in LDS (gfx950); the body is pack_one_impl.h.  Two forms:
 //   pack_one_kernel  one history (or a handful): sixteen wavefronts, same inputs and same bytes left behind as pack_kernel (pack.hip);
+//   pack_one_counts_kernel  ... and open_counts_kernel's bytes in the same pass (TBC_PACK_ONE=2: one launch fewer per tbc_check);
 //   pack_wg_kernel   a batch: four wavefronts per history, pack_kernel's AND open_counts_kernel's (pack_open.hip) bytes in one pass --
 //                    the ranks never leave the registers between the two.
 // pack_kernel + open_counts_kernel keep the models and the histories these bodies do not take.
 // STANDING: both bodies are verified under the workgroup emulator (tests/test_pack_one_emu.py) and had not run on the device when
-// they were committed; tbc_api.hip takes them only under TBC_PACK_ONE=1 / TBC_PACK_WG=1 (bench.py's extra legs measure them).
+// they were committed; tbc_api.hip takes them only under TBC_PACK_ONE=1|2 / TBC_PACK_WG=1|2 (bench.py's extra legs measure them).
 #include <hip/hip_runtime.h>
 #include "tbc_internal.h"
 #include "pack_one_impl.h"
@@ -16,6 +17,10 @@ __global__ __launch_bounds__(64 * packone::OneGeo::kNW) void pack_one_kernel(Pac
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   const PackOpenArgs none{};
   packone::history<packone::OneGeo>(A, none, lds);
+}
+__global__ __launch_bounds__(64 * packone::OneCountsGeo::kNW) void pack_one_counts_kernel(PackArgs A, PackOpenArgs O) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  packone::history<packone::OneCountsGeo>(A, O, lds);
 }
 __global__ __launch_bounds__(64 * packone::BatchGeo::kNW) void pack_wg_kernel(PackArgs A, PackOpenArgs O) {
   __shared__ __attribute__((aligned(16))) uint32_t lds[packone::BatchGeo::lds_words()];
@@ -33,6 +38,18 @@ bool launch_pack_one(const PackArgs& a, void* stream) {
   static bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&pack_one_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
   if (!ok || a.n_hist <= a.h0) return false;
   hipLaunchKernelGGL(pack_one_kernel, dim3(a.n_hist - a.h0), dim3(64 * packone::kNW), bytes, (hipStream_t)stream, a);
+  return true;
+}
+
+// the same with open_counts_kernel's tables left behind too (138 KB of LDS); o and the walk that follows as for launch_pack_wg below
+bool pack_one_counts_fits(uint32_t model_kind, uint32_t n_ops, uint32_t n_events, uint32_t n_slots) {
+  return packone::OneCountsGeo::fits(model_kind, n_ops, n_events, n_slots);
+}
+bool launch_pack_one_counts(const PackArgs& a, const PackOpenArgs& o, void* stream) {
+  constexpr uint32_t bytes = packone::OneCountsGeo::lds_words() * 4;
+  static bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&pack_one_counts_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
+  if (!ok || a.n_hist <= a.h0 || o.h0 != a.h0 || o.n_hist != a.n_hist || !o.bh || !o.off || !o.ncr || !o.slot8 || (o.branch_lists && !o.rk8)) return false;
+  hipLaunchKernelGGL(pack_one_counts_kernel, dim3(a.n_hist - a.h0), dim3(64 * packone::OneCountsGeo::kNW), bytes, (hipStream_t)stream, a, o);
   return true;
 }
 

@@ -59,6 +59,7 @@ struct Geo {
   }
 };
 using OneGeo = Geo<16, 131072, kMaxSlots, 0>;        // one history or a handful through tbc_check: sixteen wavefronts, 103 KB
+using OneCountsGeo = Geo<16, 131072, kMaxSlots, 16384>;   // ... and open_counts_kernel's work in the same pass (one launch fewer per call): 138 KB
 using BatchGeo = Geo<4, 32768, 256, 8192>;           // a batch: four wavefronts, pack + open counts, 31 KB
 
 constexpr uint32_t kNW = OneGeo::kNW;                // (the one-history form's, for its launcher and the emulator harness)

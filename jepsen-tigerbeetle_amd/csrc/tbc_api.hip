@@ -1161,12 +1161,17 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results, int phase = 
 
   // TBC_PACK_ONE=1 (experimental; pack_one.hip): a handful of histories are packed by a workgroup's sixteen wavefronts each -- the
   // single-history call's 0.28 ms pack is one wavefront's chain in pack_kernel.  Verified under the emulator only; nothing takes it unless asked
-  static const bool pack_one = [] { const char* e = std::getenv("TBC_PACK_ONE"); return e && e[0] == '1'; }();
-  bool packed = false;
+  // (TBC_PACK_ONE=2: open_counts_kernel's tables in the same pass -- pack_one_counts_kernel, one launch fewer per call)
+  static const int pack_one = [] { const char* e = std::getenv("TBC_PACK_ONE"); return (e && (e[0] == '1' || e[0] == '2')) ? e[0] - '0' : 0; }();
+  bool packed = false, counted = false;
   if (pack_one && nh <= 8) {
-    bool fits = true;
-    for (uint32_t h = 0; h < nh; h++) fits = fits && pack_one_fits(B->model.kind, B->hist[h].n_ops, B->hist[h].n_events, B->hist[h].n_slots);
-    if (fits) packed = launch_pack_one(make_pack_args(B), s);
+    bool fits = true, fits2 = pack_one == 2 && beam;
+    for (uint32_t h = 0; h < nh; h++) {
+      fits = fits && pack_one_fits(B->model.kind, B->hist[h].n_ops, B->hist[h].n_events, B->hist[h].n_slots);
+      fits2 = fits2 && pack_one_counts_fits(B->model.kind, B->hist[h].n_ops, B->hist[h].n_events, B->hist[h].n_slots);
+    }
+    if (fits2) packed = counted = launch_pack_one_counts(make_pack_args(B), make_pack_open_args(B), s);
+    if (!packed && fits) packed = launch_pack_one(make_pack_args(B), s);
   }
   // TBC_PACK_WG=1 (experimental; pack_one.hip, pack_wg_kernel): a batch of the wide schedule is packed by four wavefronts per history
   // with the tables in LDS, and the same pass leaves what open_counts_kernel would (the ranks never leave the registers between the
@@ -1174,7 +1179,6 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results, int phase = 
   // (TBC_PACK_WG=2: a batch of the wide schedule that cannot take it is an error instead of pack_kernel's -- the measurements' and the
   // GPU tests' guarantee that they ran what they name)
   static const int pack_wg = [] { const char* e = std::getenv("TBC_PACK_WG"); return (e && (e[0] == '1' || e[0] == '2')) ? e[0] - '0' : 0; }();
-  bool counted = false;
   if (!packed && pack_wg && beam) {
     bool fits = true;
     for (uint32_t h = 0; h < nh && fits; h++) fits = pack_wg_fits(B->model.kind, B->hist[h].n_ops, B->hist[h].n_events, B->hist[h].n_slots);

@@ -390,6 +390,8 @@ bool pack_one_fits(uint32_t model_kind, uint32_t n_ops, uint32_t n_events, uint3
 bool launch_pack_one(const PackArgs& a, void* stream);
 // K1 + open counts for a batch (pack_one.hip, pack_wg_kernel): four wavefronts per history, tables in LDS; o = what launch_pack_open()
 // would give open_counts_kernel.  false = not launched (the caller takes pack_kernel, and launch_pack_open() without skip_counts)
+bool pack_one_counts_fits(uint32_t model_kind, uint32_t n_ops, uint32_t n_events, uint32_t n_slots);
+bool launch_pack_one_counts(const PackArgs& a, const PackOpenArgs& o, void* stream);      // (pack_one_kernel + open counts, one history or a handful)
 bool pack_wg_fits(uint32_t model_kind, uint32_t n_ops, uint32_t n_events, uint32_t n_slots);
 bool launch_pack_wg(const PackArgs& a, const PackOpenArgs& o, void* stream);
 // returns false if mw is unsupported

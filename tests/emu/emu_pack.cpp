@@ -23,9 +23,10 @@ void entry(void* p, uint32_t) {
   const PackOpenArgs none{};
   packone::history<packone::OneGeo>(*c->A, none, c->lds);
 }
-void entry_wg(void* p, uint32_t) {
+template <class G>
+void entry_counts(void* p, uint32_t) {
   auto* c = (Call*)p;
-  packone::history<packone::BatchGeo>(*c->A, *c->O, c->lds);
+  packone::history<G>(*c->A, *c->O, c->lds);
 }
 
 struct Want {
@@ -184,10 +185,12 @@ int emu_pack_one_check(uint32_t nh, const uint64_t* op_off, const uint32_t* n_pr
 // pack refuses, against open_counts_kernel's "no lists".  flags: 1 = count form, 2 = branch lists, 4 = lookahead records asked for,
 // 8 = rk8 asked for.  lst_cap: the room of every history's list arena (0 = plenty).  Codes 1-7 as above, 10 off, 11 ncr, 12 slot8,
 // 13 rk8, 14 crashed, 15 BeamHist.status, 16 n_crashed, 17 lst_need, 18 look.
-int emu_pack_wg_check(uint32_t nh, const uint64_t* op_off, const uint32_t* n_process, const uint32_t* n_events, const uint8_t* f, const int32_t* a,
+}  // extern "C"
+
+template <class G>
+static int pack_counts_check(uint32_t nh, const uint64_t* op_off, const uint32_t* n_process, const uint32_t* n_events, const uint8_t* f, const int32_t* a,
                       const int32_t* b, const int32_t* process, const uint32_t* inv_pos, const uint32_t* ret_pos, uint32_t model_kind,
                       uint32_t n_classes, uint32_t vpad, uint32_t flags, uint32_t lst_cap, uint32_t per_launch, uint64_t seed, uint64_t* diag) {
-  using G = packone::BatchGeo;
   const bool count = flags & 1u, branch = flags & 2u, want_look = flags & 4u, want_rk8 = (flags & 8u) || branch;
   const uint64_t total = op_off[nh];
   std::vector<int32_t> slot(process, process + total);
@@ -246,7 +249,7 @@ int emu_pack_wg_check(uint32_t nh, const uint64_t* op_off, const uint32_t* n_pro
     for (uint32_t g = 0; g < L.n_hist - h0; g++) {
       std::fill(lds.begin(), lds.end(), 0xDEADBEEFu);
       Call c{&L, lds.data(), &LO};
-      wv::run_workgroup(&entry_wg, &c, (int)G::kNW, g, seed + h0 + g);
+      wv::run_workgroup(&entry_counts<G>, &c, (int)G::kNW, g, seed + h0 + g);
     }
   }
 #define MISMATCH(code, idx, got, want) do { diag[0] = h; diag[1] = (idx); diag[2] = (got); diag[3] = (want); return (code); } while (0)
@@ -283,7 +286,7 @@ int emu_pack_wg_check(uint32_t nh, const uint64_t* op_off, const uint32_t* n_pro
     Tables T;
     const uint64_t oo[2] = {0, n};
     const uint32_t np1[1] = {n_process[h]};
-    if (!build_tables(1, oo, np1, f + o, a + o, b + o, process + o, inv_pos + o, ret_pos + o, 4, vpad, 1, branch, false, T, count)) return 91;
+    if (!build_tables(1, oo, np1, f + o, a + o, b + o, process + o, inv_pos + o, ret_pos + o, G::kMaxW > 256 ? 16 : 4, vpad, 1, branch, false, T, count)) return 91;
     const uint32_t R = w.n_ret;
     const uint32_t need = T.off[R];
     if (B.lst_need != need) MISMATCH(17, 0, B.lst_need, need);
@@ -325,6 +328,16 @@ int emu_pack_wg_check(uint32_t nh, const uint64_t* op_off, const uint32_t* n_pro
   }
 #undef MISMATCH
   return 0;
+}
+
+extern "C" {
+
+// flags bit 16: the one-history geometry with counts (OneCountsGeo, sixteen wavefronts) instead of the batch geometry
+int emu_pack_wg_check(uint32_t nh, const uint64_t* op_off, const uint32_t* n_process, const uint32_t* n_events, const uint8_t* f, const int32_t* a,
+                      const int32_t* b, const int32_t* process, const uint32_t* inv_pos, const uint32_t* ret_pos, uint32_t model_kind,
+                      uint32_t n_classes, uint32_t vpad, uint32_t flags, uint32_t lst_cap, uint32_t per_launch, uint64_t seed, uint64_t* diag) {
+  if (flags & 16u) return pack_counts_check<packone::OneCountsGeo>(nh, op_off, n_process, n_events, f, a, b, process, inv_pos, ret_pos, model_kind, n_classes, vpad, flags, lst_cap, per_launch, seed, diag);
+  return pack_counts_check<packone::BatchGeo>(nh, op_off, n_process, n_events, f, a, b, process, inv_pos, ret_pos, model_kind, n_classes, vpad, flags, lst_cap, per_launch, seed, diag);
 }
 
 }  // extern "C"

@@ -173,3 +173,18 @@ def test_batch_form_crashed_calls_invoked_after_the_last_completion():
     d["n_process"] = int(d["n_process"]) + k
     for branch in (False, True):
         assert emu.pack_wg_check([d, good], branch=branch, seed=1) is None
+
+
+# ---- the one-history form with open counts (OneCountsGeo: sixteen wavefronts; TBC_PACK_ONE=2)
+def test_one_history_form_with_open_counts():
+    """every word of pack and open counts by sixteen wavefronts: all shapes, both list forms, both crashed-call forms, many slots,
+    a full-size history"""
+    assert emu.pack_wg_check(_hists(), branch=True, one=True, seed=1) is None
+    assert emu.pack_wg_check(_hists(seeds=(2,)), branch=False, one=True, seed=2) is None
+    crash = [columns.pair_events(synth.register_events(n_ops=n, n_procs=p, seed=1, busy=busy, info=info))
+             for (n, p, busy, info) in [(600, 16, 0.5, 0.1), (900, 64, 0.2, 0.3), (3000, 64, 0.5, 0.2)]]
+    assert max(x.n_process for x in crash) > 300                                # (mask form: hundreds of slots)
+    assert emu.pack_wg_check(crash, one=True, seed=3) is None
+    assert emu.pack_wg_check(crash, count=True, branch=True, one=True, seed=4) is None
+    full = synth.register_ops_many(range(7000, 7001), n_ops=10000, n_procs=64, busy=0.1, info=0.0)
+    assert emu.pack_wg_check(full, branch=True, one=True, seed=5) is None
