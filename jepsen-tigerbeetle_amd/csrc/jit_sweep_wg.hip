@@ -28,6 +28,13 @@ __global__ __launch_bounds__(64 * NW) void jit_sweep_wg_fp_kernel(SweepArgs A) {
   sweepwg::segment<CAP, NW, false, true>(A, lds);
 }
 
+// ... and the compact walk (COMPACT), with or without the fingerprint
+template <uint32_t CAP, uint32_t NW, bool FP = false>
+__global__ __launch_bounds__(64 * NW) void jit_sweep_wg_compact_kernel(SweepArgs A) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  sweepwg::segment<CAP, NW, false, FP, true>(A, lds);
+}
+
 template <uint32_t CAP, uint32_t NW>
 bool launch_one(const SweepArgs& a, hipStream_t s) {
   constexpr uint32_t bytes = sweepwg::lds_words<CAP, NW>() * 4;
@@ -58,6 +65,16 @@ bool launch_fp(const SweepArgs& a, hipStream_t s) {
   return true;
 }
 
+template <uint32_t CAP, uint32_t NW, bool FP>
+bool launch_compact(const SweepArgs& a, hipStream_t s) {
+  constexpr uint32_t bytes = sweepwg::lds_words<CAP, NW, false, true>() * 4;
+  static bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&jit_sweep_wg_compact_kernel<CAP, NW, FP>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
+  if (!ok) return false;
+  hipLaunchKernelGGL((jit_sweep_wg_compact_kernel<CAP, NW, FP>), dim3(a.n_hist * a.max_segs * kSweepSlices), dim3(64 * NW), bytes, s, a);
+  return true;
+}
+
 }  // namespace
 
 // the first pass of the sweep (cuts are in place): `waves` wavefronts per workgroup, sets of kSweepCapMid configs (78 KB of LDS
@@ -72,6 +89,10 @@ bool launch_sweep_wg(const SweepArgs& a, uint32_t waves, void* stream) {
   // TBC_SWEEP_WG_FP=1: a fingerprint of the key in the table word (with or without the ring).  The same standing.
   static const bool ring = [] { const char* e = std::getenv("TBC_SWEEP_WG_RING"); return e && e[0] == '1'; }();
   static const bool fpr = [] { const char* e = std::getenv("TBC_SWEEP_WG_FP"); return e && e[0] == '1'; }();
+  // TBC_SWEEP_WG_COMPACT=1: a sub-round of more than two passes takes 512 CHILDREN a pass, not 512 (config, call) slots (81 KB of LDS: still
+  // two workgroups per CU; with or without the fingerprint; not with the ring).  The same standing.
+  static const bool compact = [] { const char* e = std::getenv("TBC_SWEEP_WG_COMPACT"); return e && e[0] == '1'; }();
+  if (compact && !ring && waves == 8) return fpr ? launch_compact<kSweepCapMid, 8, true>(a, s) : launch_compact<kSweepCapMid, 8, false>(a, s);
   if (ring && waves == 8) return fpr ? launch_ring<kSweepCapMid, 8, true>(a, s) : launch_ring<kSweepCapMid, 8, false>(a, s);
   if (fpr && waves == 8) return launch_fp<kSweepCapMid, 8>(a, s);
   if (waves == 4) return launch_one<kSweepCapMid, 4>(a, s);

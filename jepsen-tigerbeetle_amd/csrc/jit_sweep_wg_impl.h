@@ -69,10 +69,31 @@ struct Scratch {
 };
 
 // QUEUE (experimental, see segment): + a ring of 2 x 64 x NW children (16 B each) and their target sets (a byte each)
-template <uint32_t CAP, uint32_t NW, bool QUEUE = false>
+// COMPACT (experimental, see segment): + a block's child offsets (16 bits a config, 64 x NW of them) and 2 x NW scan words
+template <uint32_t CAP, uint32_t NW, bool QUEUE = false, bool COMPACT = false>
 constexpr uint32_t lds_words() {
   return 3 * CAP * 4 + 2 * (2 * CAP) + 64 * NW * 4 + kCand * 4 + kCand * 2 + 2 * 32 * 2 + CAP / 2 + 128 + Scratch<NW>::kWords +
-         (QUEUE ? 2 * 64 * NW * 4 + 2 * 64 * NW / 4 : 0u);
+         (QUEUE ? 2 * 64 * NW * 4 + 2 * 64 * NW / 4 : 0u) + (COMPACT ? 64 * NW / 2 + 2 * NW : 0u);
+}
+
+// exclusive prefix sum of x over the workgroup's threads (thread order), *total = the sum; every thread calls it.  Inside a
+// wavefront: rows of 16 by row shifts, the four row sums by lane reads; across wavefronts: NW totals in LDS (sw: 2 x NW words, used
+// alternately by consecutive calls -- `flip` -- so that one workgroup barrier per call is enough)
+template <uint32_t NW>
+WV_DEV uint32_t wg_scan_excl(uint32_t x, uint32_t& total, uint32_t* sw, uint32_t flip, uint32_t lane, uint32_t wave) {
+  uint32_t y = x;
+  y += wv::row_shr0<1>(y); y += wv::row_shr0<2>(y); y += wv::row_shr0<4>(y); y += wv::row_shr0<8>(y);
+  const uint32_t t0 = wv::readlane(y, 15u), t1 = wv::readlane(y, 31u), t2 = wv::readlane(y, 47u), t3 = wv::readlane(y, 63u);
+  const uint32_t row = lane >> 4;
+  y += (row > 0u ? t0 : 0u) + (row > 1u ? t1 : 0u) + (row > 2u ? t2 : 0u);
+  uint32_t* tt = sw + (flip & 1u) * NW;
+  if (lane == 0u) tt[wave] = t0 + t1 + t2 + t3;
+  wv::wg_barrier();
+  uint32_t base = 0u, all = 0u;
+  WV_UNROLL
+  for (uint32_t w = 0; w < NW; w++) { const uint32_t v = wv::lds_ld32(&tt[w]); base += w < wave ? v : 0u; all += v; }
+  total = all;
+  return base + y - x;
 }
 
 WV_DEV uint64_t mask_of(const Ent& e) { return (uint64_t)e.mlo | ((uint64_t)e.mhi << 32); }
@@ -250,6 +271,9 @@ WV_DEV bool insert_q(Build& A, Build& B, Ent* wq, const uint8_t* wq_sel, uint32_
   return fits;
 }
 
+template <bool COMPACT> struct CompactState {};
+template <> struct CompactState<true> { uint16_t* blk; uint32_t* scanw; uint32_t flip; };
+
 // One workgroup: segment k of history h, origins 32 * sl .. 32 * sl + 31 (as one wavefront of K6).
 // QUEUE (experimental, off in every launch of round 4: verified under the emulator only, not yet measured): a sub-round's passes
 // put their children into a ring in LDS (one barrier per pass of 64 * NW pairs) and the insertion -- the expensive half, three
@@ -258,8 +282,17 @@ WV_DEV bool insert_q(Build& A, Build& B, Ent* wq, const uint8_t* wq_sel, uint32_
 // FP (experimental, likewise): 8 bits of the key's hash in the table word.  A probe that meets another key's slot then costs one LDS
 // word instead of the word and the 16 B key behind it; the barrier after the probe loop waits for the LONGEST chain among the
 // workgroup's 512 lanes, so the cost of a chain link is what a pass costs.  Generations wrap every 127 sets instead of 32,767.
-template <uint32_t CAP, uint32_t NW, bool QUEUE = false, bool FP = false>
+// COMPACT (experimental, likewise; TBC_SWEEP_WG_COMPACT=1): a sub-round no longer walks all 2^gshift (config, open call) slots of
+// every config -- of which a burst makes a child of one in three to five -- but, per block of 64 x NW configs: every thread counts
+// ITS config's viable calls (a loop over the level's <= 64 open calls in LDS, no barrier), one workgroup scan numbers the children,
+// and the insertion passes then take 64 x NW CHILDREN each: thread r finds its config by binary search over the block's 16-bit
+// offsets and its call as the j-th viable one.  The children are the same and come in the same (config, call) order, so sets,
+// statistics and records are those of the plain form; the barriers of a burst's sub-round drop from 3 per 64 x NW SLOTS to 2 per
+// block + 3 per 64 x NW CHILDREN.  1 KB more LDS at NW = 8 (still two workgroups per CU).  Levels with more than 64 open calls keep
+// the plain walk.
+template <uint32_t CAP, uint32_t NW, bool QUEUE = false, bool FP = false, bool COMPACT = false>
 WV_DEV void segment(const SweepArgs& A, uint32_t* lds) {
+  static_assert(!(QUEUE && COMPACT), "the ring gathers what the compact walk never produces");
   static_assert(64 * NW >= kCand, "a level's open calls are parked one per thread");
   static_assert(64 * NW <= 1024 && CAP <= 0x8000u, "thread numbers and entry numbers share a table word");
   static_assert(64 * NW < CAP, "a pass's provisional claims on top of a full set must leave the table (2 x CAP slots) an empty slot");
@@ -311,6 +344,8 @@ WV_DEV void segment(const SweepArgs& A, uint32_t* lds) {
   Ent* wq = nullptr;
   uint8_t* wq_sel = nullptr;
   if constexpr (QUEUE) { wq = reinterpret_cast<Ent*>(X.ws + S::kWords); wq_sel = reinterpret_cast<uint8_t*>(wq + 2 * T); }
+  CompactState<COMPACT> cs;         // COMPACT: where each config of the block's children start, the scan's words (else: nothing at all)
+  if constexpr (COMPACT) { cs.blk = reinterpret_cast<uint16_t*>(X.ws + S::kWords); cs.scanw = reinterpret_cast<uint32_t*>(cs.blk + T); cs.flip = 0; }
   for (uint32_t i = tid; i < 2 * HS; i += T) tab_nxt[i] = 0u;
   for (uint32_t i = tid; i < 128u; i += T) Mrel[i] = 0u;
   for (uint32_t i = tid; i < S::kWords; i += T) X.ws[i] = 0u;
@@ -455,6 +490,52 @@ WV_DEV void segment(const SweepArgs& A, uint32_t* lds) {
       build_begin<HS, NW, FP>(q, dst_e, tab_q, gen_q, X);
       const uint32_t total = n_src << gshift;
       if constexpr (!QUEUE) {
+       if constexpr (COMPACT) {
+        if (C <= 64u && total > 2u * T) {        // (a sub-round of one or two plain passes keeps them: the block's two barriers would not pay)
+          // is open call kc a viable step from config (m, st)?  (the same test as the plain walk's)
+          const auto viable_at = [&](uint64_t m, int32_t st, uint32_t kc) -> bool {
+            const OpRec y = cand[kc];
+            const uint32_t yf = y.f_slot & 0xFFu, ys = (y.f_slot >> 8) & 63u;
+            return !((m >> ys) & 1ull) && !(eager && yf == TBC_F_READ) && (cand_tw[kc] & ~m) == 0ull && reg_ok(st, yf, y.a);
+          };
+          for (uint32_t cb = 0; cb < n_src && status == kSegOk; cb += T) {
+            const uint32_t nb = n_src - cb < T ? n_src - cb : T;          // configs of this block
+            // every thread counts its config's children
+            uint32_t cnt = 0;
+            if (tid < nb) {
+              const Ent e = src[via_list ? (uint32_t)expl[cb + tid] : cb + tid];
+              const uint64_t m = mask_of(e);
+              for (uint32_t kc = 0; kc < C; kc++) cnt += viable_at(m, (int32_t)e.st, kc) ? 1u : 0u;
+            }
+            WV_UNROLL
+            for (uint32_t bit = 0; bit < 7u; bit++) probes += (uint64_t)__builtin_popcountll(wv::ballot(((cnt >> bit) & 1u) != 0u)) << bit;
+            uint32_t tot = 0;
+            const uint32_t my_off = wg_scan_excl<NW>(cnt, tot, cs.scanw, cs.flip++, lane, X.wave);
+            cs.blk[tid] = (uint16_t)my_off;                                 // (<= 64 x 512: fits; threads past the block: = tot)
+            wv::wg_barrier();                                             // the offsets are visible
+            for (uint32_t pb = 0; pb < tot && status == kSegOk; pb += T) {
+              const uint32_t r = pb + tid;
+              const bool val = r < tot;
+              uint32_t lo_ = 0, hi_ = T;                                  // the last config whose children start at or before r
+              while (hi_ - lo_ > 1u) { const uint32_t mid = (lo_ + hi_) >> 1; if ((uint32_t)cs.blk[mid] <= r) lo_ = mid; else hi_ = mid; }
+              const uint32_t ci = val ? lo_ : 0u;
+              const Ent e = val ? src[via_list ? (uint32_t)expl[cb + ci] : cb + ci] : Ent{0, 0, 0, 0};
+              const uint64_t m = mask_of(e);
+              const int32_t st = (int32_t)e.st;
+              uint32_t j = val ? r - (uint32_t)cs.blk[ci] : 0u, kc = 0;
+              if (val) for (;; kc++) { if (viable_at(m, st, kc)) { if (j == 0u) break; j--; } }
+              const OpRec y = val ? cand[kc] : OpRec{0, kFNone, 0, 0};
+              const uint32_t yf = y.f_slot & 0xFFu, ys = (y.f_slot >> 8) & 63u;
+              const int32_t st2 = val ? reg_apply(st, yf, y.a, y.b) : st;
+              uint64_t m2 = m | (1ull << ys);
+              if (eager) m2 |= row_a[0] | row_a[rdm_index(st2, V)];
+              const bool has = val && (m2 & xbit) != 0ull;
+              if (has) { m2 &= ~xbit; if (eager) m2 |= row_b[0] | row_b[rdm_index(st2, V)]; }
+              const uint32_t sel = val ? (has ? 1u : 2u) : 0u;
+              if (!insert2<CAP, NW, FP>(nxt, q, sel, (uint32_t)m2, (uint32_t)(m2 >> 32), (uint32_t)st2, e.org, false, so_, st_, X)) status = kSegOverflow;
+            }
+          }
+        } else {
         for (uint32_t base = 0; base < total && status == kSegOk; base += T) {
           const uint32_t r = base + tid, ci = r >> gshift, kc = r & ((1u << gshift) - 1u);
           const bool val = r < total && kc < C;
@@ -474,6 +555,28 @@ WV_DEV void segment(const SweepArgs& A, uint32_t* lds) {
           const uint32_t sel = viable ? (has ? 1u : 2u) : 0u;
           if (!insert2<CAP, NW, FP>(nxt, q, sel, (uint32_t)m2, (uint32_t)(m2 >> 32), (uint32_t)st2, e.org, false, so_, st_, X)) status = kSegOverflow;
         }
+        }
+       } else {
+        for (uint32_t base = 0; base < total && status == kSegOk; base += T) {
+          const uint32_t r = base + tid, ci = r >> gshift, kc = r & ((1u << gshift) - 1u);
+          const bool val = r < total && kc < C;
+          const Ent e = val ? src[via_list ? (uint32_t)expl[ci] : ci] : Ent{0, 0, 0, 0};
+          const OpRec y = val ? cand[kc] : OpRec{0, kFNone, 0, 0};
+          const uint64_t tw = val ? cand_tw[kc] : 0ull;
+          const uint64_t m = mask_of(e);
+          const uint32_t yf = y.f_slot & 0xFFu, ys = (y.f_slot >> 8) & 63u;
+          const int32_t st = (int32_t)e.st;
+          const bool viable = val && !((m >> ys) & 1ull) && !(eager && yf == TBC_F_READ) && (tw & ~m) == 0ull && reg_ok(st, yf, y.a);
+          probes += (uint64_t)__builtin_popcountll(wv::ballot(viable));
+          const int32_t st2 = viable ? reg_apply(st, yf, y.a, y.b) : st;
+          uint64_t m2 = m | (1ull << ys);
+          if (eager) m2 |= row_a[0] | row_a[rdm_index(st2, V)];
+          const bool has = viable && (m2 & xbit) != 0ull;
+          if (has) { m2 &= ~xbit; if (eager) m2 |= row_b[0] | row_b[rdm_index(st2, V)]; }
+          const uint32_t sel = viable ? (has ? 1u : 2u) : 0u;
+          if (!insert2<CAP, NW, FP>(nxt, q, sel, (uint32_t)m2, (uint32_t)(m2 >> 32), (uint32_t)st2, e.org, false, so_, st_, X)) status = kSegOverflow;
+        }
+       }
       } else if (total <= T) {                         // (one pass: nothing to gather -- the plain form, as above)
         for (uint32_t base = 0; base < total && status == kSegOk; base += T) {
           const uint32_t r = base + tid, ci = r >> gshift, kc = r & ((1u << gshift) - 1u);

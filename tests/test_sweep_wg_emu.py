@@ -20,7 +20,7 @@ def _records(buf):
     return np.frombuffer(buf, dtype=np.uint8).reshape(-1, C.sizeof(N.SweepRel))
 
 
-def _compare(ops, seg_target, n_dom, waves, cap=1024, rules=None, seed=1, expect_overflow=False, second_pass=False, queue=False, fp=False):
+def _compare(ops, seg_target, n_dom, waves, cap=1024, rules=None, seed=1, expect_overflow=False, second_pass=False, queue=False, fp=False, compact=False):
     d = ops.as_dict()
     R = int((np.asarray(d["ret_pos"]) != 0xFFFFFFFF).sum())
     max_segs = max(1, min(512, (R + seg_target - 1) // seg_target)) if seg_target else 1
@@ -32,7 +32,7 @@ def _compare(ops, seg_target, n_dom, waves, cap=1024, rules=None, seed=1, expect
         wgl.check_sweep(d, CAS, eager_reads=eager, twin_rule=twin, seg_target=seg_target, n_dom=n_dom)
     finally:
         L.sweep_set_export(None, C.c_uint32(0), C.c_uint32(0), C.c_uint32(1))
-    got = emu.sweep_wg(d, 1, N.NIL, seg_target, n_dom, max_segs, waves=waves, cap=cap, rules=None if rules is None else (3 if rules else 0), seed=seed, queue=queue, fp=fp)
+    got = emu.sweep_wg(d, 1, N.NIL, seg_target, n_dom, max_segs, waves=waves, cap=cap, rules=None if rules is None else (3 if rules else 0), seed=seed, queue=queue, fp=fp, compact=compact)
     want = [N.SweepRel.from_buffer_copy(r.tobytes()) for r in _records(buf)]
     have = [N.SweepRel.from_buffer_copy(r.tobytes()) for r in _records(got)]
     if second_pass:      # the segments that overflowed, once more with sets of 2,048 configs and eight wavefronts (what launch_sweep does)
@@ -173,3 +173,35 @@ def test_sixteen_wavefronts_on_the_big_sets():
         _compare(h, 32, 6, 16, cap=2048, seed=seed)
     h4 = synth.register_ops_many([4], n_ops=10000, n_procs=64, busy=0.1, info=0.0)[0]      # the history whose burst overflows 1,024 configs: no overflow here
     assert _compare(h4, 32, 6, 16, cap=2048) > 250
+
+
+# ---- the compact walk (COMPACT, TBC_SWEEP_WG_COMPACT=1): a sub-round's passes take 64 x NW CHILDREN, not 64 x NW (config, call) slots
+@pytest.mark.parametrize("fp", [False, True])
+def test_the_compact_walk_every_record(fp):
+    """the same records as the plain form: small histories valid and invalid, rules off (reads are candidates: more children per
+    config), crashed calls (one long segment, classes of candidates past the live calls), fewer and more wavefronts"""
+    n = 0
+    for seed in range(4):
+        for corrupt in (0.0, 0.4):
+            h = columns.pair_events(synth.register_events(n_ops=300, n_procs=8, seed=100 + seed, busy=0.5, info=0.0, corrupt=corrupt))
+            n += _compare(h, 32, 6, (2, 4, 8, 8)[seed], seed=seed, compact=True, fp=fp)
+    assert n > 12
+    h = columns.pair_events(synth.register_events(n_ops=400, n_procs=8, seed=5, busy=0.6, info=0.0, corrupt=0.0))
+    _compare(h, 32, 6, 8, rules=False, seed=3, compact=True, fp=fp)
+    h = columns.pair_events(synth.register_events(n_ops=400, n_procs=16, seed=5, busy=0.8, info=0.0, corrupt=0.0))      # levels past 1,024 configs without the rules
+    _compare(h, 32, 6, 8, rules=False, seed=3, compact=True, fp=fp, expect_overflow=True)
+    h = columns.pair_events(synth.register_events(n_ops=300, n_procs=8, seed=58, busy=0.4, info=0.015, corrupt=0.0))
+    _compare(h, 32, 6, 8, seed=4, compact=True, fp=fp)
+    _compare(h, 0, 6, 4, seed=5, compact=True, fp=fp)                    # one segment
+
+
+def test_the_compact_walk_on_a_bench_history_its_bursts_and_overflow():
+    """a 10k-op bench history (349 workgroups; its bursts are the sub-rounds of more than two plain passes the compact walk takes:
+    blocks of 512 configs, several insertion passes a block); the history whose burst overflows the small sets: reported"""
+    h = synth.register_ops_many([3], n_ops=10000, n_procs=64, busy=0.1, info=0.0)[0]
+    assert _compare(h, 32, 6, 8, compact=True) > 250
+    h = columns.pair_events(synth.register_events(n_ops=600, n_procs=16, seed=7, busy=0.5, info=0.0, corrupt=0.0))
+    for seed in range(2):
+        _compare(h, 32, 6, 2, cap=512, seed=3000 + 17 * seed, compact=True)       # (two wavefronts: 128 children a pass -- many blocks, many passes)
+    h4 = synth.register_ops_many([4], n_ops=10000, n_procs=64, busy=0.1, info=0.0)[0]
+    _compare(h4, 32, 6, 4, cap=512, expect_overflow=True, compact=True)
