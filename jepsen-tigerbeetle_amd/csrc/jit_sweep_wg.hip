@@ -29,10 +29,10 @@ __global__ __launch_bounds__(64 * NW) void jit_sweep_wg_fp_kernel(SweepArgs A) {
 }
 
 // ... and the compact walk (COMPACT), with or without the fingerprint
-template <uint32_t CAP, uint32_t NW, bool FP = false>
+template <uint32_t CAP, uint32_t NW, bool FP = false, bool SOLO = false>
 __global__ __launch_bounds__(64 * NW) void jit_sweep_wg_compact_kernel(SweepArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-  sweepwg::segment<CAP, NW, false, FP, true>(A, lds);
+  sweepwg::segment<CAP, NW, false, FP, true, SOLO>(A, lds);
 }
 
 template <uint32_t CAP, uint32_t NW>
@@ -65,13 +65,13 @@ bool launch_fp(const SweepArgs& a, hipStream_t s) {
   return true;
 }
 
-template <uint32_t CAP, uint32_t NW, bool FP>
+template <uint32_t CAP, uint32_t NW, bool FP, bool SOLO>
 bool launch_compact(const SweepArgs& a, hipStream_t s) {
   constexpr uint32_t bytes = sweepwg::lds_words<CAP, NW, false, true>() * 4;
-  static bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&jit_sweep_wg_compact_kernel<CAP, NW, FP>),
+  static bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&jit_sweep_wg_compact_kernel<CAP, NW, FP, SOLO>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
   if (!ok) return false;
-  hipLaunchKernelGGL((jit_sweep_wg_compact_kernel<CAP, NW, FP>), dim3(a.n_hist * a.max_segs * kSweepSlices), dim3(64 * NW), bytes, s, a);
+  hipLaunchKernelGGL((jit_sweep_wg_compact_kernel<CAP, NW, FP, SOLO>), dim3(a.n_hist * a.max_segs * kSweepSlices), dim3(64 * NW), bytes, s, a);
   return true;
 }
 
@@ -91,8 +91,10 @@ bool launch_sweep_wg(const SweepArgs& a, uint32_t waves, void* stream) {
   static const bool fpr = [] { const char* e = std::getenv("TBC_SWEEP_WG_FP"); return e && e[0] == '1'; }();
   // TBC_SWEEP_WG_COMPACT=1: a sub-round of more than two passes takes 512 CHILDREN a pass, not 512 (config, call) slots (81 KB of LDS: still
   // two workgroups per CU; with or without the fingerprint; not with the ring).  The same standing.
-  static const bool compact = [] { const char* e = std::getenv("TBC_SWEEP_WG_COMPACT"); return e && e[0] == '1'; }();
-  if (compact && !ring && waves == 8) return fpr ? launch_compact<kSweepCapMid, 8, true>(a, s) : launch_compact<kSweepCapMid, 8, false>(a, s);
+  // TBC_SWEEP_WG_COMPACT=2: ... and a pass that fits one wavefront is run by wavefront 0 alone (one workgroup barrier instead of three)
+  static const int compact = [] { const char* e = std::getenv("TBC_SWEEP_WG_COMPACT"); return (e && (e[0] == '1' || e[0] == '2')) ? e[0] - '0' : 0; }();
+  if (compact == 1 && !ring && waves == 8) return fpr ? launch_compact<kSweepCapMid, 8, true, false>(a, s) : launch_compact<kSweepCapMid, 8, false, false>(a, s);
+  if (compact == 2 && !ring && waves == 8) return fpr ? launch_compact<kSweepCapMid, 8, true, true>(a, s) : launch_compact<kSweepCapMid, 8, false, true>(a, s);
   if (ring && waves == 8) return fpr ? launch_ring<kSweepCapMid, 8, true>(a, s) : launch_ring<kSweepCapMid, 8, false>(a, s);
   if (fpr && waves == 8) return launch_fp<kSweepCapMid, 8>(a, s);
   if (waves == 4) return launch_one<kSweepCapMid, 4>(a, s);

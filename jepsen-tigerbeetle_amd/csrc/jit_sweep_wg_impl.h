@@ -206,6 +206,75 @@ WV_DEV bool insert2(Build& A, Build& B, uint32_t sel, uint32_t mlo, uint32_t mhi
   return fits;
 }
 
+// SOLO: insert2 for a pass that fits ONE wavefront, run by wavefront 0 alone (its 64 threads call it, nobody else): the three workgroup
+// barriers become wavefront barriers -- the other wavefronts wait at the ONE workgroup barrier behind which the caller publishes the
+// new set sizes (solo_publish / solo_collect below).  Same claims, same ORs, same entries: a set is a set.
+template <uint32_t CAP, uint32_t NW, bool FP = false>
+WV_DEV bool insert2_solo(Build& A, Build& B, uint32_t sel, uint32_t mlo, uint32_t mhi, uint32_t st, uint32_t org,
+                         bool side, uint32_t& side_off, uint32_t& side_total, Ctx<NW>& X) {
+  constexpr uint32_t HS = 2 * CAP;
+  X.stage[X.tid] = Ent{mlo, mhi, st, sel ? org : 0u};
+  const uint64_t sb = wv::ballot(side);
+  const uint64_t anyb = wv::ballot(sel != 0u);
+  wv::barrier();                                              // staged keys visible to the wavefront
+  side_off = (uint32_t)__builtin_popcountll(sb & ((1ull << X.lane) - 1ull));
+  side_total = (uint32_t)__builtin_popcountll(sb);
+  if (!anyb) return true;
+  uint32_t* const tab = sel == 2u ? B.tab : A.tab;
+  Ent* const ent = sel == 2u ? B.e : A.e;
+  const uint32_t gen = sel == 2u ? B.gen : A.gen;
+  uint32_t gtag = gen << gen_shift<FP>();
+  uint32_t h = key_slot<HS>(mlo, mhi, st), mine = 0, fp = 0;
+  if constexpr (FP) { const uint32_t hh = key_hash(mlo, mhi, st); fp = hh >> 24; gtag |= fp << kFpShift; }
+  bool pend = sel != 0u, won = false;
+  while (wv::ballot(pend)) {
+    if (pend) {
+      uint32_t s = wv::lds_ld32(&tab[h]);
+      if ((s >> gen_shift<FP>()) != gen) {
+        const uint32_t old = wv::lds_cas32(&tab[h], s, gtag | kProv | X.tid);
+        if (old == s) { won = true; mine = h; pend = false; }
+        else s = old;
+      }
+      if constexpr (FP) {
+        if (pend && ((s >> kFpShift) & 0xFFu) != fp) { h = (h + 1u) & (HS - 1u); continue; }
+      }
+      if (pend) {
+        const Ent* kp = (s & kProv) ? &X.stage[s & 0x3FFu] : &ent[s & 0xFFFFu];
+        if (kp->mlo == mlo && kp->mhi == mhi && kp->st == st) {
+          wv::lds_or32(const_cast<uint32_t*>(&kp->org), org);
+          pend = false;
+        } else {
+          h = (h + 1u) & (HS - 1u);
+        }
+      }
+    }
+  }
+  const uint64_t wa = wv::ballot(won && sel == 1u), wb = wv::ballot(won && sel == 2u);
+  wv::barrier();                                              // every claim and every OR of the wavefront is done
+  const uint32_t ta = A.n + (uint32_t)__builtin_popcountll(wa), tb = B.n + (uint32_t)__builtin_popcountll(wb);
+  const bool fits = ta <= CAP && tb <= CAP;
+  if (won && fits) {
+    const uint64_t below = (1ull << X.lane) - 1ull;
+    const uint32_t idx = sel == 2u ? B.n + (uint32_t)__builtin_popcountll(wb & below) : A.n + (uint32_t)__builtin_popcountll(wa & below);
+    ent[idx] = Ent{mlo, mhi, st, X.stage[X.tid].org};
+    tab[mine] = gtag | idx;
+  }
+  if (fits) { A.n = ta; B.n = tb; }
+  wv::barrier();
+  return fits;
+}
+// what wavefront 0 did alone, told to the workgroup: two words by pass parity (the spare words of Scratch), one workgroup barrier
+template <uint32_t NW>
+WV_DEV void solo_exchange(Build& A, Build& B, bool& fits, uint32_t& side_total, Ctx<NW>& X) {
+  using S = Scratch<NW>;
+  uint32_t* pub = X.ws + S::kBad + 1u + 2u * (X.parity & 1u);
+  X.parity++;
+  if (X.tid == 0u) { pub[0] = A.n | (B.n << 16); pub[1] = (fits ? 1u : 0u) | (side_total << 1); }
+  wv::wg_barrier();
+  const uint32_t w0 = pub[0], w1 = pub[1];
+  A.n = w0 & 0xFFFFu; B.n = w0 >> 16; fits = (w1 & 1u) != 0u; side_total = w1 >> 1;
+}
+
 // QUEUE: insert `cnt` (<= 64 * NW, the same in every thread) children from the ring, starting at qh: they are staged where they lie
 // (one barrier makes them visible), a claim carries the RING position.
 template <uint32_t CAP, uint32_t NW, bool FP = false>
@@ -290,9 +359,15 @@ template <> struct CompactState<true> { uint16_t* blk; uint32_t* scanw; uint32_t
 // statistics and records are those of the plain form; the barriers of a burst's sub-round drop from 3 per 64 x NW SLOTS to 2 per
 // block + 3 per 64 x NW CHILDREN.  1 KB more LDS at NW = 8 (still two workgroups per CU).  Levels with more than 64 open calls keep
 // the plain walk.
-template <uint32_t CAP, uint32_t NW, bool QUEUE = false, bool FP = false, bool COMPACT = false>
+// SOLO (experimental, likewise; with COMPACT: TBC_SWEEP_WG_COMPACT=2): a pass that fits one wavefront -- a level of at most 64
+// configs, a sub-round of at most 64 (config, call) slots: 100 of the 187 steps of that critical workgroup, and nearly every step of
+// the other 340 -- is run by wavefront 0 alone with wavefront barriers, the others waiting at ONE workgroup barrier for the new set
+// sizes (insert2_solo, solo_exchange): one workgroup barrier instead of three, and a probe loop that waits for the longest chain
+// of 64 lanes, not 512.
+template <uint32_t CAP, uint32_t NW, bool QUEUE = false, bool FP = false, bool COMPACT = false, bool SOLO = false>
 WV_DEV void segment(const SweepArgs& A, uint32_t* lds) {
   static_assert(!(QUEUE && COMPACT), "the ring gathers what the compact walk never produces");
+  static_assert(!SOLO || (COMPACT && CAP < 0x10000u && Scratch<NW>::kBad + 5u <= Scratch<NW>::kWords), "solo passes: with the compact walk; two set sizes share a word");
   static_assert(64 * NW >= kCand, "a level's open calls are parked one per thread");
   static_assert(64 * NW <= 1024 && CAP <= 0x8000u, "thread numbers and entry numbers share a table word");
   static_assert(64 * NW < CAP, "a pass's provisional claims on top of a full set must leave the table (2 x CAP slots) an empty slot");
@@ -462,6 +537,28 @@ WV_DEV void segment(const SweepArgs& A, uint32_t* lds) {
     // sub-round 0: a config that has X linearized passes the completion -- X's bit is cleared and the reads open at
     // the next front are absorbed; the others are listed for expansion
     uint32_t n_exp = 0;
+    bool solo0 = false;
+    if constexpr (SOLO) solo0 = cur.n <= 64u;
+    if (solo0) {                       // the whole level is one wavefront's: wavefront 0 passes it alone
+      Build unused = none;
+      bool fits = true;
+      uint32_t stot = 0;
+      if (X.wave == 0u) {
+        const uint32_t i = tid;
+        const bool val = i < cur.n;
+        const Ent e = val ? cur.e[i] : Ent{0, 0, 0, 0};
+        const uint64_t m = mask_of(e);
+        const bool has = val && (m & xbit) != 0ull;
+        uint64_t m2 = m & ~xbit;
+        if (eager) m2 |= row_b[0] | row_b[rdm_index((int32_t)e.st, V)];
+        uint32_t soff = 0;
+        fits = insert2_solo<CAP, NW, FP>(nxt, unused, has ? 1u : 0u, (uint32_t)m2, (uint32_t)(m2 >> 32), e.st, e.org, val && !has, soff, stot, X);
+        if (val && !has) expl[soff] = (uint16_t)i;
+      }
+      solo_exchange<NW>(nxt, unused, fits, stot, X);           // (its barrier: the list is complete, too)
+      if (!fits) status = kSegOverflow;
+      n_exp = stot;
+    } else {
     for (uint32_t base = 0; base < cur.n && status == kSegOk; base += T) {
       const uint32_t i = base + tid;
       const bool val = i < cur.n;
@@ -477,6 +574,7 @@ WV_DEV void segment(const SweepArgs& A, uint32_t* lds) {
       n_exp += stot;
     }
     wv::wg_barrier();                                          // the list is complete
+    }
     // sub-rounds: expand what still needs X, one (config, open call) pair per thread, 2^gshift pairs per config.  Children
     // that have X go to level F+1, the others to the next sub-round's set -- one probe loop for both.
     uint32_t gshift = 0;
@@ -535,6 +633,30 @@ WV_DEV void segment(const SweepArgs& A, uint32_t* lds) {
               if (!insert2<CAP, NW, FP>(nxt, q, sel, (uint32_t)m2, (uint32_t)(m2 >> 32), (uint32_t)st2, e.org, false, so_, st_, X)) status = kSegOverflow;
             }
           }
+        } else if (SOLO && total <= 64u) {          // the sub-round is one wavefront's: wavefront 0 walks and inserts it alone
+          bool fits = true;
+          uint32_t unused_total = 0;
+          if (X.wave == 0u) {
+            const uint32_t r = tid, ci = r >> gshift, kc = r & ((1u << gshift) - 1u);
+            const bool val = r < total && kc < C;
+            const Ent e = val ? src[via_list ? (uint32_t)expl[ci] : ci] : Ent{0, 0, 0, 0};
+            const OpRec y = val ? cand[kc] : OpRec{0, kFNone, 0, 0};
+            const uint64_t tw = val ? cand_tw[kc] : 0ull;
+            const uint64_t m = mask_of(e);
+            const uint32_t yf = y.f_slot & 0xFFu, ys = (y.f_slot >> 8) & 63u;
+            const int32_t st = (int32_t)e.st;
+            const bool viable = val && !((m >> ys) & 1ull) && !(eager && yf == TBC_F_READ) && (tw & ~m) == 0ull && reg_ok(st, yf, y.a);
+            probes += (uint64_t)__builtin_popcountll(wv::ballot(viable));
+            const int32_t st2 = viable ? reg_apply(st, yf, y.a, y.b) : st;
+            uint64_t m2 = m | (1ull << ys);
+            if (eager) m2 |= row_a[0] | row_a[rdm_index(st2, V)];
+            const bool has = viable && (m2 & xbit) != 0ull;
+            if (has) { m2 &= ~xbit; if (eager) m2 |= row_b[0] | row_b[rdm_index(st2, V)]; }
+            const uint32_t sel = viable ? (has ? 1u : 2u) : 0u;
+            fits = insert2_solo<CAP, NW, FP>(nxt, q, sel, (uint32_t)m2, (uint32_t)(m2 >> 32), (uint32_t)st2, e.org, false, so_, st_, X);
+          }
+          solo_exchange<NW>(nxt, q, fits, unused_total, X);
+          if (!fits) status = kSegOverflow;
         } else {
         for (uint32_t base = 0; base < total && status == kSegOk; base += T) {
           const uint32_t r = base + tid, ci = r >> gshift, kc = r & ((1u << gshift) - 1u);

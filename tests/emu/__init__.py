@@ -195,7 +195,7 @@ def sweep_wg(ops, model_kind, init, seg_target, n_dom, max_segs, waves=8, cap=10
     sl = None if again is None else np.ascontiguousarray([x for (k, j) in again for x in (0, k, j)], np.uint32)
     rc = _LIB_SWEEP.emu_sweep_wg_run(C.c_uint32(len(f)), C.c_uint32(int(d["n_process"])), _p(f, C.c_uint8), _p(a, C.c_int32), _p(b, C.c_int32), _p(pr, C.c_int32),
                                      _p(inv, C.c_uint32), _p(ret, C.c_uint32), C.c_uint32(model_kind), C.c_int32(init), C.c_uint32(vpad), C.c_uint32(r),
-                                     C.c_uint32(n_dom), C.c_uint32(seg_target), C.c_uint32(max_segs), C.c_uint32(waves), C.c_uint32(cap), C.c_uint32((1 if queue else 0) | (2 if fp else 0) | (4 if compact else 0)), C.c_uint64(seed),
+                                     C.c_uint32(n_dom), C.c_uint32(seg_target), C.c_uint32(max_segs), C.c_uint32(waves), C.c_uint32(cap), C.c_uint32((1 if queue else 0) | (2 if fp else 0) | (4 if compact else 0) | (8 if compact == 2 else 0)), C.c_uint64(seed),      # compact=2: + solo passes
                                      None if sl is None else _p(sl, C.c_uint32), C.c_uint32(0 if again is None else len(again)), buf.ctypes.data_as(C.c_void_p))
     if rc != 0:
         raise RuntimeError(f"emu_sweep_wg_run rc={rc}")

@@ -205,3 +205,31 @@ def test_the_compact_walk_on_a_bench_history_its_bursts_and_overflow():
         _compare(h, 32, 6, 2, cap=512, seed=3000 + 17 * seed, compact=True)       # (two wavefronts: 128 children a pass -- many blocks, many passes)
     h4 = synth.register_ops_many([4], n_ops=10000, n_procs=64, busy=0.1, info=0.0)[0]
     _compare(h4, 32, 6, 4, cap=512, expect_overflow=True, compact=True)
+
+
+# ---- narrow passes by wavefront 0 alone (SOLO, with the compact walk: TBC_SWEEP_WG_COMPACT=2)
+@pytest.mark.parametrize("fp", [False, True])
+def test_solo_passes_every_record(fp):
+    """a level of at most 64 configs / a sub-round of at most 64 slots is wavefront 0's alone (one workgroup barrier instead of three):
+    the same records -- small histories (nearly every pass is narrow), rules off, crashed calls, one segment, several interleavings"""
+    n = 0
+    for seed in range(4):
+        for corrupt in (0.0, 0.4):
+            h = columns.pair_events(synth.register_events(n_ops=300, n_procs=8, seed=100 + seed, busy=0.5, info=0.0, corrupt=corrupt))
+            n += _compare(h, 32, 6, (2, 4, 8, 8)[seed], seed=seed, compact=2, fp=fp)
+    assert n > 12
+    h = columns.pair_events(synth.register_events(n_ops=400, n_procs=8, seed=5, busy=0.6, info=0.0, corrupt=0.0))
+    _compare(h, 32, 6, 8, rules=False, seed=3, compact=2, fp=fp)
+    h = columns.pair_events(synth.register_events(n_ops=300, n_procs=8, seed=58, busy=0.4, info=0.015, corrupt=0.0))
+    _compare(h, 32, 6, 8, seed=4, compact=2, fp=fp)
+    _compare(h, 0, 6, 4, seed=5, compact=2, fp=fp)
+    h = columns.pair_events(synth.register_events(n_ops=600, n_procs=16, seed=7, busy=0.5, info=0.0, corrupt=0.0))
+    for seed in range(3):
+        _compare(h, 32, 6, 8, seed=4000 + 19 * seed, compact=2, fp=fp)
+
+
+def test_solo_passes_on_a_bench_history_and_overflow():
+    h = synth.register_ops_many([3], n_ops=10000, n_procs=64, busy=0.1, info=0.0)[0]
+    assert _compare(h, 32, 6, 8, compact=2) > 250
+    h4 = synth.register_ops_many([4], n_ops=10000, n_procs=64, busy=0.1, info=0.0)[0]
+    _compare(h4, 32, 6, 4, cap=512, expect_overflow=True, compact=2)

@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 # (the ring and the fingerprint forms one by one: bench.py's extra.single_history_forms compares their counters with the default's)
-FORMS = [("ring+fingerprint", {"TBC_SWEEP_WG_RING": "1", "TBC_SWEEP_WG_FP": "1"}), ("compact+fingerprint", {"TBC_SWEEP_WG_COMPACT": "1", "TBC_SWEEP_WG_FP": "1"}), ("sixteen-wavefronts", {"TBC_SWEEP_WG": "16"}),
+FORMS = [("ring+fingerprint", {"TBC_SWEEP_WG_RING": "1", "TBC_SWEEP_WG_FP": "1"}), ("compact", {"TBC_SWEEP_WG_COMPACT": "1"}), ("compact+solo+fingerprint", {"TBC_SWEEP_WG_COMPACT": "2", "TBC_SWEEP_WG_FP": "1"}), ("sixteen-wavefronts", {"TBC_SWEEP_WG": "16"}),
          ("pack-one", {"TBC_PACK_ONE": "1"}), ("pack-one+counts+ring+fingerprint", {"TBC_PACK_ONE": "2", "TBC_SWEEP_WG_RING": "1", "TBC_SWEEP_WG_FP": "1"}),
          ("pack-wg", {"TBC_PACK_WG": "1"}), ("pack-wg-or-error", {"TBC_PACK_WG": "2"})]
 
