@@ -294,14 +294,12 @@ FORMS = [("K6 (one wavefront per segment)", {"TBC_SWEEP_WG": "0"}),
          ("K6w + ring", {"TBC_SWEEP_WG_RING": "1"}),
          ("K6w + fingerprint", {"TBC_SWEEP_WG_FP": "1"}),
          ("K6w + ring + fingerprint", {"TBC_SWEEP_WG_RING": "1", "TBC_SWEEP_WG_FP": "1"}),
-         ("K6w + fingerprint, 16 completions per segment", {"TBC_SWEEP_WG_FP": "1", "TBC_SWEEP_SEG": "16"}),
          ("K6w + compact walk", {"TBC_SWEEP_WG_COMPACT": "1"}),
          ("K6w + compact walk + narrow passes by one wavefront", {"TBC_SWEEP_WG_COMPACT": "2"}),
          ("K6w + compact walk + narrow passes by one wavefront + fingerprint", {"TBC_SWEEP_WG_COMPACT": "2", "TBC_SWEEP_WG_FP": "1"}),
          ("K6w, 16 wavefronts on the big sets", {"TBC_SWEEP_WG": "16"}),
          ("pack by a workgroup's sixteen wavefronts", {"TBC_PACK_ONE": "1"}),
          ("pack + open counts by sixteen wavefronts, one launch", {"TBC_PACK_ONE": "2"}),
-         ("pack + open counts by sixteen wavefronts + K6w ring + fingerprint", {"TBC_PACK_ONE": "2", "TBC_SWEEP_WG_RING": "1", "TBC_SWEEP_WG_FP": "1"}),
          ("pack + open counts by sixteen wavefronts + K6w compact + narrow + fingerprint", {"TBC_PACK_ONE": "2", "TBC_SWEEP_WG_COMPACT": "2", "TBC_SWEEP_WG_FP": "1"})]
 
 
