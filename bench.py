@@ -340,7 +340,7 @@ def leg_single_history_forms(args, local_rank):
         entry = {"form": name, "env": env}
         try:
             cmd = [sys.executable, os.path.abspath(__file__)] + [a for a in sys.argv[1:] if a not in ("--leg", "single_history_forms")] + ["--leg", "one_form"]
-            r = subprocess.run(cmd, stdout=subprocess.PIPE, timeout=180, env=dict(os.environ, LOCAL_RANK=str(local_rank), **env))
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, timeout=120, env=dict(os.environ, LOCAL_RANK=str(local_rank), **env))
             res = None
             for ln in reversed(r.stdout.decode(errors="replace").splitlines()):
                 if ln.startswith("{"):
@@ -360,7 +360,7 @@ def leg_single_history_forms(args, local_rank):
                 entry.update(res)
                 entry["_sig"] = sig
         except subprocess.TimeoutExpired:
-            entry["error"] = "did not finish within 180 s"
+            entry["error"] = "did not finish within 120 s"
         out.append(entry)
     for e in out:          # the same verdicts, analyzer, failing op and sweep counters as the default form (which the GPU tests pin to the oracle)
         sig = e.pop("_sig", None)
