@@ -372,7 +372,9 @@ def leg_single_history_forms(args, local_rank):
 # ---- extra.batch_forms: ONE resident batch of the headline workload (a quarter of its size) under the switchable forms of the batch
 # path, each in a process of its own (the switches are read once per process), never fatal -- as extra.single_history_forms.
 BATCH_FORMS = [("pack_kernel + open_counts_kernel (the default)", {}),
-               ("pack + open counts by four wavefronts per history, tables in LDS", {"TBC_PACK_WG": "2"})]
+               ("pack + open counts by four wavefronts per history, tables in LDS", {"TBC_PACK_WG": "2"}),
+               ("lean tables: list entries {call, twin mask}, 8 B lookahead records", {"TBC_NARROW_LEAN": "1"}),
+               ("lean tables + pack by four wavefronts", {"TBC_NARROW_LEAN": "1", "TBC_PACK_WG": "2"})]
 
 
 def leg_one_batch_form(args, local_rank):
@@ -383,7 +385,9 @@ def leg_one_batch_form(args, local_rank):
     model = core.make_model(N.MODEL_CAS_REGISTER, N.NIL)
     B = 8192
     hs = synth.register_ops_many(range(5_000_000, 5_000_000 + B), n_ops=args.ops, n_procs=args.procs, busy=args.busy, info=0.0)
-    hs[77] = columns.pair_events(synth.register_events(n_ops=args.ops, n_procs=args.procs, seed=5_000_077, busy=args.busy, info=0.0, corrupt=0.02))
+    hp = columns.pair_events(synth.register_events(n_ops=args.ops, n_procs=args.procs, seed=5_000_077, busy=args.busy, info=0.0, corrupt=0.02, n_values=4))
+    hp.a[hp.a == 4 + 7] = 4          # (the planted read's value inside the batch's domain: compact front records, as the headline's batches)
+    hs[77] = hp
     o = core.make_opts(device=local_rank, time_limit_ms=600000, want_witness=False, algorithm=N.ALG_COMPETITION, visited_per_op=args.visited_per_op,
                        lanes_per_history=8)
     best = None
@@ -435,6 +439,11 @@ def leg_batch_forms(args, local_rank):
         sig = e.pop("_sig", None)
         if sig is not None:
             e["counters_match"] = base is not None and sig == base
+            # (the lean lookahead record reads three or more open producers as "one is still to come": its schedule is the oracle's
+            # look_two, a handful of probes away from the default's on such histories -- verdicts and the planted history must agree)
+            e["verdicts_match"] = base is not None and sig[:3] == base[:3]
+            if base is not None and sig != base:
+                e["probes_vs_default"] = [sig[3] - base[3], sig[4] - base[4]]
     return out
 
 

@@ -533,6 +533,8 @@ int tbc_debug_peek(uint32_t* out, uint32_t n);
  *   TBC_SWEEP_WG_FP=1             (experimental) ... keeps 8 bits of a key's hash in its table word (a probe past another key reads no key)
  *   TBC_SWEEP_WG_COMPACT=1|2      (experimental) ... a wide sub-round numbers its children first and inserts 512 CHILDREN a pass (not with the ring);
  *                                 2 = and a pass that fits one wavefront is run by wavefront 0 alone
+ *   TBC_NARROW_LEAN=1             (experimental) several histories per wavefront over lean tables: a list entry {call, twin mask} in one array,
+ *                                 an 8 B lookahead record (two producer slots; three or more read as "one is still to be linearized")
  *   TBC_PACK_ONE=1|2              (experimental) a handful of histories are packed by sixteen wavefronts each, tables in LDS (pack_one.hip);
  *                                 2 = and the per-front counts in the same launch
  *   TBC_PACK_WG=1                 (experimental) a batch of the wide schedule is packed by four wavefronts per history, tables in LDS,

@@ -258,7 +258,10 @@ __global__ __launch_bounds__(1024) void open_counts_kernel(PackOpenArgs A) {
       __syncthreads();
     }
     // lookahead records past the last rank: nothing is needed there
-    if (A.look) {
+    if (A.look && (A.lean & kLeanLook)) {          // (the lean format: one word a rank)
+      uint64_t* look = A.look + look_off(H->op_off, h, 0);
+      for (uint32_t t = R + tid; t < R + kLookPad; t += NT) look[t] = lean_look(0u, kLookNone, kLookNone, 255u, 255u, 0ull);
+    } else if (A.look) {
       const uint32_t LW = 1 + MW;
       uint64_t* look = A.look + look_off(H->op_off, h, MW);
       for (uint32_t t = R + tid; t < R + kLookPad; t += NT) {

@@ -299,6 +299,17 @@ struct tbc_batch {
   // u64 words per front record (0 = plain rdm rows): the compact 64 B form where one mask word and six row entries do
   uint32_t front_words() const { return !lanes ? 0u : ((rules & kRuleEager) && front_compact_ok(n_dom, mask_words)) ? kFrontCompactWords : front_stride(vpad, mask_words); }
   uint32_t lanes = 0;               // 8 / 16 / 32: several histories per wavefront (wgl_narrow.hip), one config per iteration; 0 = one per wavefront
+  // TBC_NARROW_LEAN=1 (experimental; tbc_internal.h, kLeanCands | kLeanLook): the per-front lists and the lookahead records of a batch
+  // that runs several histories per wavefront in the lean formats -- where nothing else reads those tables: compact front records
+  // (the walk with lane = front writes them), both rules and the lookahead on, no count form, no level sweep beside it, no round
+  // budget (whose stragglers the wide kernel would take over).  Verified under the emulators only; nothing takes it unless asked
+  uint32_t lean() const {
+    static const bool asked = [] { const char* e = std::getenv("TBC_NARROW_LEAN"); return e && e[0] == '1'; }();
+    static const bool by_slots = [] { const char* e = std::getenv("TBC_OPEN_WALK"); return e && std::strcmp(e, "slots") == 0; }();
+    const bool ok = asked && !by_slots && lanes >= 8 && mask_words == 1 && front_words() == kFrontCompactWords &&
+                    (rules & (kRuleEager | kRuleTwin | kRuleCount)) == (kRuleEager | kRuleTwin) && lookahead && !sweep && opts.round_budget == 0;
+    return ok ? (kLeanCands | kLeanLook) : 0u;
+  }
   std::vector<BeamHist> bh;
   DevBuf<BeamHist> d_bh;
   DevBuf<uint32_t> d_off, d_ncr, d_stack;
@@ -867,6 +878,8 @@ static PackOpenArgs make_pack_open_args(tbc_batch* B) {
   po.rk8 = B->lanes ? B->d_rk8.p : nullptr; po.front_words = B->front_words(); po.front_compact = B->front_words() == kFrontCompactWords ? 1u : 0u;
   po.twn = B->reg_rules() ? B->d_twn.p : nullptr; po.rdm = (B->reg_rules() || B->lanes) ? B->d_rdm.p : nullptr; po.vpad = B->vpad;
   po.cmem = B->count_form ? B->d_cmem.p : nullptr;
+  po.lean = B->lean();
+  if (po.lean & kLeanCands) po.twn = nullptr;          // (the twin masks ride in the list entries)
   return po;
 }
 
@@ -887,6 +900,7 @@ static BeamArgs make_beam_args(tbc_batch* B, uint64_t* tab, uint32_t* stack, uin
   a.n_classes = B->model.n_classes; a.width = B->width;
   a.round_budget = B->opts.round_budget;
   a.cmem = B->d_cmem.p; a.count_mode = kCountExact; a.tab_stride = B->entry_words(); a.epoch = 0;
+  a.lean = B->lean();
   a.rules = B->rules; a.twn = B->d_twn.p; a.rdm = B->d_rdm.p; a.vpad = B->vpad; a.rk8 = B->d_rk8.p; a.front_words = B->front_words(); a.next_work = B->d_queue.p;
   a.max_steps = B->opts.max_steps;
   a.time_limit_ticks = B->opts.time_limit_ms * 100000ull;

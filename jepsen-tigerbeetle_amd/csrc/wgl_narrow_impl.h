@@ -176,9 +176,12 @@ WV_DEV bool grow_group(ColdArgs C, wv::gu64*& tab_u, wv::gu32*& stack_u, wv::gu3
 // One wavefront: H = 64 / L histories, work items wave_idx * H .. + H - 1 of A.work.
 // CF: the front records are the compact 64 B ones (tbc_internal.h; MW = 1)
 // CNT: the count form (tbc_internal.h, kRuleCount; the schedule is oracle/wgl_count.c's at one config per iteration and L pairs per round)
-template <int MW, int L, bool CF = false, bool CNT = false>
+// LEAN: kLeanCands | kLeanLook -- the tables are in the lean formats (tbc_internal.h; compact front records, exact counts only)
+template <int MW, int L, bool CF = false, bool CNT = false, int LEAN = 0>
 WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* lds, const uint32_t lane) {
   static_assert(!CF || MW == 1, "compact front records have one mask word");
+  static_assert(LEAN == 0 || (CF && !CNT), "the lean formats: compact front records, no count form");
+  constexpr bool LC = (LEAN & (int)kLeanCands) != 0, LK = (LEAN & (int)kLeanLook) != 0;
   constexpr uint32_t WN = CF ? 1u : 4u;          // window words per config
   using wv::gu32;
   using wv::gu64;
@@ -238,7 +241,7 @@ WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* ld
     tab = (gu64*)A.tab + (has ? Bd->tab_off : 0ull) * A.tab_stride;
     stack = (gu32*)A.stack + (has ? Bd->stack_off : 0ull);
     cap_log2 = has ? Bd->tab_log2 : 10u;
-    look_lo = (uint32_t)look_off(op_off, hidx, MW);           // u64 units into A.look
+    look_lo = (uint32_t)look_off(op_off, hidx, LK ? 0u : (uint32_t)MW);           // u64 units into A.look (lean: one word a rank)
     slot8_lo = slot8_off(op_off, hidx);
     RT = R;
     if constexpr (CNT) {
@@ -346,9 +349,21 @@ WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* ld
     const OpRec* rp = live_ ? A.lst + ((uint64_t)lst_off + po + c_)
                             : (CNT ? reinterpret_cast<const OpRec*>(A.cmem + cmem_lo) + (c_ - nlive_) : A.crashed + ((uint64_t)op_off + (c_ - nlive_)));
     c_oi = *rp;
+    if constexpr (LC) {
+      // lean list entry {call, twin mask}: 16 B of ONE array -- the record is unpacked, the mask came with it
+      const uint64_t call = (uint64_t)c_oi.op | ((uint64_t)c_oi.f_slot << 32), tw64 = (uint64_t)(uint32_t)c_oi.a | ((uint64_t)(uint32_t)c_oi.b << 32);
+      if (live_) {
+        const uint32_t a6 = (uint32_t)(call >> 34) & 63u, b6 = (uint32_t)(call >> 40) & 63u;
+        c_oi.op = (uint32_t)call & 0xFFFFFFu;
+        c_oi.f_slot = ((uint32_t)(call >> 24) & 7u) | (((uint32_t)(call >> 28) & 63u) << 8) | (((call >> 27) & 1ull) ? kAtFront : 0u);
+        c_oi.a = a6 ? (int32_t)a6 - 1 : TBC_NIL; c_oi.b = b6 ? (int32_t)b6 - 1 : TBC_NIL;
+      }
+      c_tw[0] = (twin && live_ && have) ? tw64 : 0ull;
+    } else {
     const uint64_t* tw = tw_base + ((twin && live_) ? ((uint64_t)lst_off + po + c_) * MW : 0ull);
     WV_UNROLL
     for (int j = 0; j < MW; j++) c_tw[j] = tw[j];
+    }
   };
   // ---- results of the groups that have just finished (sel: mine has).  The witness (only when asked for: the parent chain
   // is thousands of dependent loads) is walked by all of them at once, each lane following its own group's chain; the configs
@@ -578,7 +593,15 @@ WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* ld
     // earlier) and the crashed ones invoked before it -- walk the list (crash-heavy histories only)
     if (!CNT && twin && act && !lin && !live && (f == TBC_F_WRITE || f == TBC_F_CAS)) {
       for (uint32_t cc = 0; cc < c && !dominated; cc++) {
-        const OpRec y = cc < nlive ? A.lst[(uint64_t)lst_off + poff + cc] : A.crashed[(uint64_t)op_off + (cc - nlive)];
+        OpRec y = cc < nlive ? A.lst[(uint64_t)lst_off + poff + cc] : A.crashed[(uint64_t)op_off + (cc - nlive)];
+        if constexpr (LC) {
+          if (cc < nlive) {               // (a lean list entry: unpack what the comparison below reads)
+            const uint64_t call = (uint64_t)y.op | ((uint64_t)y.f_slot << 32);
+            const uint32_t a6 = (uint32_t)(call >> 34) & 63u, b6 = (uint32_t)(call >> 40) & 63u;
+            y.f_slot = ((uint32_t)(call >> 24) & 7u) | (((uint32_t)(call >> 28) & 63u) << 8);
+            y.a = a6 ? (int32_t)a6 - 1 : TBC_NIL; y.b = b6 ? (int32_t)b6 - 1 : TBC_NIL;
+          }
+        }
         if ((y.f_slot & 0xFFu) != f || y.a != oi.a || (f == TBC_F_CAS && y.b != oi.b)) continue;
         dominated = !mask_bit<MW>(Mp, (y.f_slot >> 8) & kSlotMask);
       }
@@ -673,10 +696,10 @@ WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* ld
         const uint32_t cc = 8u * bt + (lane >> 3), jr = lane & 7u;
         const bool val = cc < nn0;
         const uint32_t lo_ = val ? c_lo[cc] : (look_avail ? look_lo : 0u), fr_ = val ? c_fi[cc] + jr : 0u;
-        const uint64_t* rec = lk_base + (uint64_t)lo_ + (uint64_t)fr_ * (MW + 1);
+        const uint64_t* rec = lk_base + (uint64_t)lo_ + (uint64_t)fr_ * (LK ? 1 : MW + 1);
         lw0[bt] = rec[0];
         WV_UNROLL
-        for (int w = 0; w < MW; w++) lpm[bt][w] = rec[1 + w];
+        for (int w = 0; w < MW; w++) lpm[bt][w] = LK ? 0ull : rec[1 + w];
       }
       uint64_t m0, m1 = 0;
       if constexpr (CF) { m0 = fr[6]; cw[0] = fr[7]; }
@@ -716,11 +739,22 @@ WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* ld
       uint64_t Mc[MW];
       WV_UNROLL
       for (int w = 0; w < MW; w++) Mc[w] = val ? c_M[cc * MW + w] : 0ull;
-      const uint32_t slot = (uint32_t)w_0 & 0xFFFFu, need = (uint32_t)(w_0 >> 16) & 0xFFu, prod = (uint32_t)(w_0 >> 24) & 0xFFu;
-      const uint32_t dinv = (uint32_t)(w_0 >> 32) & 0xFFu, dprod = (uint32_t)(w_0 >> 40) & 0xFFu;
+      uint32_t slot, need, prod, dinv, dprod;
       bool pmhit = false;
+      if constexpr (LK) {
+        // the 8 B record: two producer slots instead of a mask, `many` = three or more (read as: one of them is still to be linearized)
+        slot = (uint32_t)w_0 & 63u;
+        const uint32_t n5 = (uint32_t)(w_0 >> 6) & 31u, p5 = (uint32_t)(w_0 >> 11) & 31u;
+        need = n5 == kLean5None ? kLookNone : n5; prod = p5 == kLean5None ? kLookNone : p5;
+        dinv = (uint32_t)(w_0 >> 16) & 0xFFu; dprod = (uint32_t)(w_0 >> 24) & 0xFFu;
+        const uint32_t p1 = (uint32_t)(w_0 >> 33) & 127u, p2 = (uint32_t)(w_0 >> 40) & 127u;
+        pmhit = ((w_0 >> 47) & 1ull) != 0ull || (p1 != 0u && !mask_bit<MW>(Mc, p1 - 1u)) || (p2 != 0u && !mask_bit<MW>(Mc, p2 - 1u));
+      } else {
+      slot = (uint32_t)w_0 & 0xFFFFu; need = (uint32_t)(w_0 >> 16) & 0xFFu; prod = (uint32_t)(w_0 >> 24) & 0xFFu;
+      dinv = (uint32_t)(w_0 >> 32) & 0xFFu; dprod = (uint32_t)(w_0 >> 40) & 0xFFu;
       WV_UNROLL
       for (int w = 0; w < MW; w++) pmhit = pmhit || (pm[w] & ~Mc[w]) != 0ull;
+      }
       const bool linz = dinv >= j && mask_bit<MW>(Mc, slot);     // open at the config's front and linearized
       // values the calls completing at the ranks before this one can still provide (prefix-OR over the 8 lanes)
       uint32_t acc = (prod != kLookNone && !linz) ? 1u << prod : 0u;
@@ -747,11 +781,11 @@ WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* ld
         const uint32_t cc = cb + (lane >> 3), jr = lane & 7u;
         const bool val = cc < nn0;
         const uint32_t lo_ = val ? c_lo[cc] : (look_avail ? look_lo : 0u), fr_ = val ? c_fi[cc] + jr : 0u;
-        const uint64_t* rec = lk_base + (uint64_t)lo_ + (uint64_t)fr_ * (MW + 1);
+        const uint64_t* rec = lk_base + (uint64_t)lo_ + (uint64_t)fr_ * (LK ? 1 : MW + 1);
         uint64_t xpm[MW];
         const uint64_t xw0 = rec[0];
         WV_UNROLL
-        for (int w = 0; w < MW; w++) xpm[w] = rec[1 + w];
+        for (int w = 0; w < MW; w++) xpm[w] = LK ? 0ull : rec[1 + w];
         const uint64_t badx = look_batch(cb, xw0, xpm);
         if (lkme && ci >= cb && ci < cb + 8u) dead = ((badx >> (8u * (ci - cb))) & 0xFFull) != 0ull;
       }

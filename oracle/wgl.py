@@ -160,7 +160,7 @@ def rules_apply(ops, model, round_pairs=64):
 
 
 def check_beam(ops, model, width=16, max_probes=0, want_witness=True, round_pairs=64, widen_after=0, lookahead=None, eager_reads=None, twin_rule=None,
-               twin_selfcheck=False, rules_at_any_round_size=False, branch_lists=False, lazy_commuting=None, eager_txns=False):
+               twin_selfcheck=False, rules_at_any_round_size=False, branch_lists=False, lazy_commuting=None, eager_txns=False, look_two=False):
     """The wide (K configs per iteration) schedule of the same search: wgl_beam.c.
 
     lookahead: None = what the library does by default (on for register / cas-register under the
@@ -196,6 +196,8 @@ def check_beam(ops, model, width=16, max_probes=0, want_witness=True, round_pair
     # eager_txns: DESIGN STUDY (no kernel counterpart): the eager rule for multi-register -- an open txn of micro-reads only that the
     # state allows is linearized at once (wgl_beam.c, g_eager_txns); what it buys is measured in DESIGN.md section 8
     lib().wgl_beam_set_eager_txns(C.c_uint32(1 if (eager_txns and model["kind"] == 4) else 0))
+    # look_two: the lean lookahead record's reading of three or more open producers (wgl_beam.c, g_look_two; csrc kLeanLook)
+    lib().wgl_beam_set_look_two(C.c_uint32(1 if look_two else 0))
     try:
         r = _check_beam(ops, model, width, max_probes, want_witness, round_pairs, widen_after, bool(lookahead))
         if twin_selfcheck:
@@ -210,6 +212,7 @@ def check_beam(ops, model, width=16, max_probes=0, want_witness=True, round_pair
         lib().wgl_beam_set_branch_lists(C.c_uint32(0))
         lib().wgl_beam_set_lazy_commuting(C.c_uint32(0))
         lib().wgl_beam_set_eager_txns(C.c_uint32(0))
+        lib().wgl_beam_set_look_two(C.c_uint32(0))
 
 
 def _check_beam(ops, model, width, max_probes, want_witness, round_pairs, widen_after, lookahead):

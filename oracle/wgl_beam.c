@@ -173,6 +173,11 @@ uint64_t wgl_beam_twin_mismatch(void) { return g_twin_mismatch; }
  * lookahead_depth: completions looked at (the kernel's is 8).
  * trace:       greatest front and stack depth sampled every 256 rounds. */
 void wgl_beam_set_lookahead_depth(uint32_t d) { g_lookahead_depth = d; }
+/* look_two (the lean lookahead record of the narrow kernel, csrc/tbc_internal.h kLeanLook): the record of a rank names at most TWO of the
+ * other calls open at that rank's front that produce the needed value; three or more are read as "one of them is still to be
+ * linearized" -- the rule then lets the config live without looking further.  Never a config declared dead that is not. */
+static uint32_t g_look_two = 0;
+void wgl_beam_set_look_two(uint32_t on) { g_look_two = on; }
 static uint32_t g_list_order = 0;
 void wgl_beam_set_list_order(uint32_t o) { g_list_order = o; }
 /* eager reads (experiment for the next round, register family): a read that is viable NOW can be linearized
@@ -569,6 +574,15 @@ int wgl_beam_check_rp(uint32_t n, const uint8_t* f, const int32_t* a, const int3
             if (inv_rank[fop] <= F && (c2[1 + (pf >> 6)] >> (pf & 63) & 1)) continue;   /* already linearized */
             if (v == s2) continue;
             int ok = 0;
+            if (g_look_two) {              /* three or more producers open at front t: the lean record says no more than that */
+              const uint32_t nl = coff[t + 1] - coff[t], tot = nl + ncr[t];
+              uint32_t np = 0;
+              for (uint32_t cc = 0; cc < tot; cc++) {
+                const uint32_t x = cc < nl ? clst[coff[t] + cc] : crashed[cc - nl];
+                if (x != fop && ((f[x] == O_WRITE && a[x] == v) || (f[x] == O_CAS && b[x] == v))) np++;
+              }
+              if (np >= 3) ok = 1;
+            }
             for (uint32_t F2 = F; F2 <= t && !ok; F2++) {                /* calls open somewhere in [F, t] */
               const uint32_t nl = coff[F2 + 1] - coff[F2], tot = nl + (F2 == t ? ncr[F2] : 0);
               for (uint32_t cc = 0; cc < tot && !ok; cc++) {

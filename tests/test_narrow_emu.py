@@ -67,7 +67,7 @@ def compare(hists, model, L, kind=1, tag="", **kw):
     for i, (d, g) in enumerate(zip(ds, got)):
         e = wgl.check_beam(d, model, 1, round_pairs=L, rules_at_any_round_size=True, lookahead=kw.get("lookahead", True),
                            eager_reads=bool(g["rules"] & 1), twin_rule=bool(g["rules"] & 2), max_probes=kw.get("max_steps", 0),
-                           branch_lists=bool(g["rules"] & 4))
+                           branch_lists=bool(g["rules"] & 4), look_two=bool(kw.get("lean", False)))
         t = (tag, i, L)
         assert g["valid"] == e["valid"], (t, g["valid"], e["valid"], g["cause"])
         for a_, b_ in (("probes", "probes"), ("visited", "visited"), ("backtracks", "expanded"), ("max_depth", "max_stack"), ("bucket_reads", "rounds")):
@@ -296,3 +296,51 @@ def test_count_form_relaxed_prefix_growth_and_epochs():
     compare_count(valid[:2], 16, tag="epochs", pool_words=4_000_000, epochs=3, want_witness=False)
     wide = [columns.pair_events(synth.register_events(n_ops=500, n_procs=70, seed=80 + s, busy=0.5, info=0.05)) for s in range(2)]
     compare_count(wide, 8, tag="two-words", pool_words=4_000_000, mw=2, max_steps=30000)
+
+
+# ---- the lean tables (csrc/tbc_internal.h kLeanCands | kLeanLook; TBC_NARROW_LEAN=1): list entries {call, twin mask}, 8 B lookahead records
+def _in_domain(n, p, s, busy, info, corrupt):
+    """a history whose planted bad read (if any) stays inside the value domain 0..4: the compact front records the lean tables need"""
+    h = columns.pair_events(synth.register_events(n_ops=n, n_procs=p, seed=s, busy=busy, info=info, corrupt=corrupt, n_values=4 if corrupt else 5))
+    h.a[h.a == 4 + 7] = 4
+    return h
+
+
+LEAN_SHAPES = [(8, 3, 0.0, 0.0, 0.8), (40, 4, 0.0, 0.5, 0.5), (200, 8, 0.0, 0.0, 0.5), (200, 8, 0.0, 0.6, 0.3), (1000, 16, 0.0, 0.0, 0.5),
+               (1000, 16, 0.01, 0.0, 0.3), (1000, 16, 0.0, 0.6, 0.2), (2000, 64, 0.0, 0.0, 0.1), (600, 24, 0.03, 0.0, 0.6)]
+
+
+@pytest.mark.parametrize("L", [8, 16, 32])
+def test_lean_tables_every_counter(L):
+    """the narrow kernel over the lean tables against the oracle's schedule with the lean lookahead's reading of three or more open
+    producers (look_two): verdict, failing op, witness, every counter -- valid, invalid, crashed calls in the mask form"""
+    hists = [_in_domain(n, p, s, busy, info, corrupt) for (n, p, info, corrupt, busy) in LEAN_SHAPES for s in range(3)]
+    hists = [h for h in hists if h.n_process <= 64]
+    assert sum(1 for h in hists if (h.a == 4).any()) >= 6
+    assert len(hists) >= 24
+    compare(hists, CAS, L, tag="lean", pool_words=4_000_000, lean=True)
+
+
+def test_lean_tables_where_the_many_bit_matters_and_growth_epochs_queue():
+    """two values and every process busy: completions with three or more open producers, where the lean record says less than the mask
+    (the oracle's look_two and the plain oracle disagree on these histories' counters -- the kernel follows look_two); then growth
+    inside the kernel, epoch tags and the work queue over the lean tables"""
+    h = [columns.pair_events(synth.register_events(n_ops=300, n_procs=24, seed=s, busy=1.0, n_values=2)) for s in range(6)]
+    compare(h, CAS, 8, tag="many", pool_words=8_000_000, lean=True)
+    differs = 0
+    for x in h:
+        d = x.as_dict()
+        a = wgl.check_beam(d, CAS, 1, round_pairs=8, rules_at_any_round_size=True, branch_lists=True, look_two=True, want_witness=False)
+        b = wgl.check_beam(d, CAS, 1, round_pairs=8, rules_at_any_round_size=True, branch_lists=True, look_two=False, want_witness=False)
+        assert (a["valid"], a["fail_op"] if a["valid"] == 0 else None) == (b["valid"], b["fail_op"] if b["valid"] == 0 else None)
+        differs += a["probes"] != b["probes"]
+    assert differs >= 1
+    hists = [_in_domain(1500, 16, s, 0.4, 0.0, 0.5 * (s % 2)) for s in range(12)]
+    compare(hists, CAS, 8, tag="lean growth", entries_per_op=1, pool_words=6_000_000, lean=True, want_witness=False)
+    compare(hists, CAS, 8, tag="lean epochs", epochs=3, pool_words=6_000_000, lean=True)
+    compare(hists, CAS, 8, tag="lean queue", max_waves=1, pool_words=6_000_000, lean=True)
+
+
+def test_lean_tables_at_the_bench_configuration():
+    hists = synth.register_ops_many(range(7000, 7008), n_ops=10000, n_procs=64, busy=0.1, info=0.0)
+    compare(hists, CAS, 8, tag="lean bench", entries_per_op=4, pool_words=1 << 24, want_witness=False, lean=True)

@@ -57,3 +57,19 @@ def test_full_size_histories():
     assert emu.walk_check(h, 8, branch=True, front="compact") is None
     assert emu.walk_check(h + busy, 8, branch=False, front="plain") is None
     assert emu.walk_check(busy, 8, branch=True, front="wide") is None
+
+
+# ---- the lean formats (csrc/tbc_internal.h, kLeanCands | kLeanLook; TBC_NARROW_LEAN=1): a list entry {call, twin mask}, an 8 B lookahead record
+@pytest.mark.parametrize("branch", [True, False])
+def test_lean_formats_every_word(branch):
+    assert emu.walk_check(_hists(), 8, branch=branch, front="compact", lean=True) is None
+
+
+def test_lean_formats_many_twins_and_many_producers():
+    """two values, every process busy: most writes have twins, and a completion often has three or more open producers of the value
+    it needs (the lean record's `many` bit)"""
+    h = [columns.pair_events(synth.register_events(n_ops=400, n_procs=40, seed=s, busy=1.0, n_values=2)) for s in range(3)]
+    assert emu.walk_check(h, 8, branch=True, front="compact", lean=True) is None
+    full = synth.register_ops_many(range(7000, 7003), n_ops=10000, n_procs=64, busy=0.1, info=0.0)
+    busy = synth.register_ops_many(range(7100, 7101), n_ops=10000, n_procs=64, busy=0.5, info=0.0)
+    assert emu.walk_check(full + busy, 8, branch=True, front="compact", lean=True) is None
