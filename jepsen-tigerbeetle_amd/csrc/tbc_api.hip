@@ -801,7 +801,8 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
       if (!had_branch) break;                      // (else the lists hold the reads again: counted once more)
       for (uint32_t h = 0; h < nh; h++) { B->bh[h].lst_cap = 0xFFFFFFF0u; B->bh[h].lst_off = 0; }
     }
-    if ((s = B->d_lst.alloc(blst_n)) || (B->reg_rules() && (s = B->d_twn.alloc(blst_n * B->mask_words)))) return s;
+    // (the lean tables carry the twin masks inside the list entries: no twn[] arena at all -- 8.5 GB of the bench's batch)
+    if ((s = B->d_lst.alloc(blst_n)) || (B->reg_rules() && !(B->lean() & kLeanCands) && (s = B->d_twn.alloc(blst_n * B->mask_words)))) return s;
     B->device_bytes += B->d_lst.bytes() + B->d_twn.bytes();
     TRACE("create: lists sized on the device");
   }
