@@ -768,6 +768,15 @@ WV_DEV void segment(const SweepArgs& A, uint32_t* lds) {
     // level F+1 is complete
     configs_total += nxt.n;
     max_level = max_level > nxt.n ? max_level : nxt.n;
+    // SOLO: the prefetched level is parked in LDS here already -- nobody reads this level's records or rows any more (every pass of
+    // it is behind a workgroup barrier) -- so that the barrier of the origins' word below publishes it too: one barrier a level fewer
+    if constexpr (SOLO) {
+      if (pre && p_C <= kCand) {
+        if (tid < p_C) { cand[tid] = p_rec; cand_tw[tid] = p_tw; }
+        { uint64_t* t = row_a; row_a = row_b; row_b = t; }
+        if (tid < 32) row_b[tid] = p_row;
+      }
+    }
     {   // which origins are still alive
       const uint32_t lp = (F & 1u);
       uint32_t any = 0;
@@ -787,10 +796,12 @@ WV_DEV void segment(const SweepArgs& A, uint32_t* lds) {
     // ---- park the prefetched level in LDS
     if (pre) {
       if (p_C > kCand) { status = kSegOverflow; break; }
+      if constexpr (!SOLO) {          // (SOLO: parked above, published by the barrier of the origins' word)
       if (tid < p_C) { cand[tid] = p_rec; cand_tw[tid] = p_tw; }
       { uint64_t* t = row_a; row_a = row_b; row_b = t; }
       if (tid < 32) row_b[tid] = p_row;
       wv::wg_barrier();
+      }
       crashed_twins(p_nlive, p_C);
     }
   }
