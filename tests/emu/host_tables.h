@@ -52,6 +52,7 @@ bool build_tables(uint32_t nh, const uint64_t* op_off, const uint32_t* n_process
       uint32_t W = 1;
       for (uint32_t i = 0; i < n; i++) {
         const uint32_t p = (uint32_t)process[o + i];
+        if (p >= n_process[h]) return false;            // (libtbcheck's build_count_form refuses such a history too: it never reaches the kernels in the count form)
         if (ret_pos[o + i] == TBC_POS_CRASHED) { if (slot_of[p] >= 0) { used[slot_of[p]] = 0; slot_of[p] = -1; } slot[i] = 0; continue; }
         if (slot_of[p] < 0) { uint32_t sl = 0; while (used[sl]) sl++; used[sl] = 1; slot_of[p] = (int32_t)sl; W = std::max(W, sl + 1); }
         slot[i] = (uint32_t)slot_of[p];
