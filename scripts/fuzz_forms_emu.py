@@ -1,0 +1,50 @@
+"""The experimental forms of the level sweep (compact walk, narrow passes by one wavefront, fingerprint, ring) and the lean tables of
+the narrow search under the emulators on random small histories -- sizes, concurrency, planted bad reads (inside the value domain),
+crashed calls, wavefronts per workgroup, set sizes, segment lengths, interleaving seeds -- every record / counter against the oracle.
+usage: fuzz_forms_emu.py [rounds] [seed]      Round 4: 150 rounds, no mismatch."""
+import os, random, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import jepsen_tigerbeetle_amd  # noqa: F401
+from jepsen_tigerbeetle_amd import _native as N, columns, synth
+import test_sweep_wg_emu as TS
+import test_narrow_emu as TN
+
+rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 5)
+bad = 0
+for it in range(rounds):
+    n = rng.choice([20, 60, 150, 300, 500]); p = rng.choice([2, 4, 8, 16, 24]); busy = rng.choice([0.2, 0.5, 0.8, 1.0])
+    corrupt = rng.choice([0.0, 0.0, 0.3, 0.7]); info = rng.choice([0.0, 0.0, 0.0, 0.02])
+    seed = rng.randrange(10 ** 6)
+    h = TN._in_domain(n, p, seed, busy, info, corrupt)
+    # ---- the sweep's forms
+    form = rng.choice([{"compact": True}, {"compact": 2}, {"compact": 2, "fp": True}, {"compact": True, "fp": True}, {"queue": True, "fp": True}])
+    waves, cap = rng.choice([(2, 512), (2, 1024), (4, 1024), (8, 1024), (8, 2048)])
+    if form.get("queue") and (waves, cap) not in ((2, 1024), (4, 1024), (8, 1024)):
+        waves, cap = 8, 1024
+    if form.get("fp") and not form.get("compact") and (waves, cap) not in ((2, 1024), (8, 1024)):
+        waves, cap = 8, 1024
+    seg = rng.choice([0, 16, 32, 32])
+    try:
+        try:
+            TS._compare(h, seg, 6, waves, cap=cap, seed=rng.randrange(1000), **form)
+        except AssertionError as e:
+            if e.args:
+                raise
+            TS._compare(h, seg, 6, waves, cap=cap, seed=rng.randrange(1000), expect_overflow=True, **form)      # (the bare assert: a level outgrew the sets)
+    except Exception as e:
+        bad += 1; print("SWEEP MISMATCH", it, (n, p, busy, corrupt, info, seed), form, waves, cap, seg, repr(e)[:300], flush=True)
+    # ---- the lean tables
+    if h.n_process <= 64:
+        try:
+            TN.compare([h], TN.CAS, rng.choice([8, 16, 32]), tag="fuzz", pool_words=8_000_000, lean=True, entries_per_op=rng.choice([1, 4, 8]),
+                       want_witness=bool(it & 1), epochs=rng.choice([0, 0, 2]))
+        except Exception as e:
+            a = e.args[0] if e.args else None
+            if isinstance(a, tuple) and len(a) == 4 and a[1] == -1 and a[3] == 3:
+                continue                                  # (the emulator's growth pool ran out under an exhaustive search: a limit, not a mismatch)
+            bad += 1; print("LEAN MISMATCH", it, (n, p, busy, corrupt, info, seed), repr(e)[:300], flush=True)
+print("rounds", rounds, "mismatches", bad)
+sys.exit(1 if bad else 0)
