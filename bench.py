@@ -691,14 +691,19 @@ def main():
         k_ms = statistics.mean(search_ns) / 1e6
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         traffic = None
-        try:   # HBM bytes per launch from the committed rocprofv3 PMC passes: same config AND same kernel sources only
-            with open(os.path.join(ROOT, "profiles", "r04_traffic.json")) as fh:
-                for e in json.load(fh)["entries"]:
-                    key = (e["histories_per_gpu"], e["search_width"], e.get("lanes_per_history", 64), e["visited_per_op"], e["ops"], e["procs"], e["busy"], e["info"])
-                    if e.get("kernel_sha") == kernel_sha() and key == (B, width, lanes, args.visited_per_op, args.ops, args.procs, args.busy, args.info):
-                        traffic = e["traffic_bytes"]
-        except (OSError, KeyError, ValueError):
-            pass
+        # HBM bytes per launch from the committed rocprofv3 PMC passes (the newest round's file that has one): same config AND same kernel sources only
+        import glob
+        for tf in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
+            try:
+                with open(tf) as fh:
+                    for e in json.load(fh)["entries"]:
+                        key = (e["histories_per_gpu"], e["search_width"], e.get("lanes_per_history", 64), e["visited_per_op"], e["ops"], e["procs"], e["busy"], e["info"])
+                        if e.get("kernel_sha") == kernel_sha() and key == (B, width, lanes, args.visited_per_op, args.ops, args.procs, args.busy, args.info):
+                            traffic = e["traffic_bytes"]
+            except (OSError, KeyError, ValueError):
+                continue
+            if traffic is not None:
+                break
         line = {
             "metric": "histories/sec, 10k-op/64-proc cas-register histories (time-to-verdict ms in extra)",
             "value": round(value, 2), "unit": "histories/s",

@@ -20,7 +20,7 @@ for line in open(os.path.join(d, "pmc_summary.txt")):
         ms = float(m.group(3))
 run = [l for l in open(os.path.join(d, "trace.log")) if " run" in l and "probes=" in l][-1]
 probes, visited = int(re.search(r"probes=(\d+)", run).group(1)), int(re.search(r"visited=(\d+)", run).group(1))
-path = os.path.join(ROOT, "profiles", "r04_traffic.json")
+path = os.path.join(ROOT, "profiles", os.environ.get("TBC_TRAFFIC_FILE", "r04_traffic.json"))       # (a later round: TBC_TRAFFIC_FILE=r05_traffic.json)
 doc = {"_comment": "HBM bytes per batch launch of the dominant kernel from rocprofv3 PMC passes: FETCH_SIZE and WRITE_SIZE in separate --pmc runs, "
                    "values in KB (x1024), used as counted: calibrated for this access pattern in round 2 (scripts/hbm_calib.hip, "
                    "profiles/r02_hbm_counter_calibration.txt: random 64 B bucket reads are counted 1.16x, a 16 B or 8 B store costs a 32 B sector; the 2x "
