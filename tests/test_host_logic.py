@@ -94,3 +94,23 @@ def test_merge_valid_and_independent_split():
     assert independent.history_keys(h) == [1, 2]
     s1 = independent.subhistory(1, h)
     assert [o["value"] for o in s1 if o["process"] != "nemesis"] == [9, 9] and len(s1) == 3
+
+
+def test_the_committed_traffic_figure_is_keyed_to_this_tree():
+    """bench.py quotes roofline.traffic only for the kernel sources it was measured on (profiles/r*_traffic.json carries their hash).
+    An edit of a hashed file that leaves the measured kernels' instructions alone must re-key the entry WITH its evidence
+    (scripts/isa_same.py; the entry's `rekeyed` note) -- this test is the reminder; an edit that changes those kernels makes the
+    figure stale, and then the entry goes (bench.py reports traffic: null) until it is measured again."""
+    import glob
+    import importlib.util
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_for_sha", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    files = sorted(glob.glob(os.path.join(root, "profiles", "r*_traffic.json")), reverse=True)
+    assert files
+    entries = json.load(open(files[0]))["entries"]
+    assert entries and all(e["kernel_sha"] == bench.kernel_sha() for e in entries), \
+        "profiles/%s: kernel_sha is not this tree's -- re-key it with scripts/isa_same.py's evidence, or drop the stale entry" % os.path.basename(files[0])
