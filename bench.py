@@ -374,7 +374,8 @@ def leg_single_history_forms(args, local_rank):
 BATCH_FORMS = [("pack_kernel + open_counts_kernel (the default)", {}),
                ("pack + open counts by four wavefronts per history, tables in LDS", {"TBC_PACK_WG": "2"}),
                ("lean tables: list entries {call, twin mask}, 8 B lookahead records", {"TBC_NARROW_LEAN": "1"}),
-               ("lean tables + pack by four wavefronts", {"TBC_NARROW_LEAN": "1", "TBC_PACK_WG": "2"})]
+               ("lists in order of completion", {"TBC_NARROW_ORDER": "1"}),
+               ("lean tables + lists in order of completion + pack by four wavefronts", {"TBC_NARROW_LEAN": "1", "TBC_NARROW_ORDER": "1", "TBC_PACK_WG": "2"})]
 
 
 def leg_one_batch_form(args, local_rank):
@@ -440,7 +441,8 @@ def leg_batch_forms(args, local_rank):
         if sig is not None:
             e["counters_match"] = base is not None and sig == base
             # (the lean lookahead record reads three or more open producers as "one is still to come": its schedule is the oracle's
-            # look_two, a handful of probes away from the default's on such histories -- verdicts and the planted history must agree)
+            # look_two, a handful of probes away from the default's on such histories; lists in order of completion are another
+            # schedule altogether (fewer rounds) -- verdicts and the planted history must agree)
             e["verdicts_match"] = base is not None and sig[:3] == base[:3]
             if base is not None and sig != base:
                 e["probes_vs_default"] = [sig[3] - base[3], sig[4] - base[4]]

@@ -158,6 +158,28 @@ WV_DEV void walk_wave(const PackOpenArgs& A, uint32_t wid, uint32_t* lds, uint32
   }
   wv::barrier();
 
+  // ---- A2. list_order 1: the loop below takes the candidates in order of completion (then every front's list comes out in that
+  // order: a front's entries are appended as the loop meets its members).  Candidate i's place = the candidates that complete before it
+  // (ties -- crashed calls, ret = kInf, which are in no list -- by table position); the places as 16-bit words over the scan's scratch.
+  const bool by_ret = A.list_order == 1u;
+  uint16_t* const perm = reinterpret_cast<uint16_t*>(aux);
+  if (by_ret) {
+    WV_UNROLL
+    for (int s = 0; s < 3; s++) {
+      const uint32_t idx = lane + 64u * (uint32_t)s;
+      if (idx < NC) {
+        const uint32_t my = cand[idx * kCandWords + 1u];
+        uint32_t place = 0u;
+        for (uint32_t j = 0; j < NC; j++) {
+          const uint32_t rj = cand[j * kCandWords + 1u];
+          place += (rj < my || (rj == my && j < idx)) ? 1u : 0u;
+        }
+        perm[place] = (uint16_t)idx;
+      }
+    }
+    wv::barrier();
+  }
+
   // ---- B. the candidates once more, one per lane (three sets): what the static twin test asks of them
   uint32_t c_key[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, c_ret[3] = {0u, 0u, 0u};
   if (want_tw) {
@@ -197,7 +219,7 @@ WV_DEV void walk_wave(const PackOpenArgs& A, uint32_t wid, uint32_t* lds, uint32
 
   WV_NOUNROLL
   for (uint32_t t = 0; t < NC; t++) {
-    const uint32_t* e = cand + t * kCandWords;
+    const uint32_t* e = cand + (by_ret ? (uint32_t)perm[t] : t) * kCandWords;
     const uint32_t inv = e[0], ret = e[1];
     const uint32_t fl = wv::readfirstlane(e[6]);
     const uint32_t slot = (fl >> 12) & 63u;
@@ -252,6 +274,7 @@ WV_DEV void walk_wave(const PackOpenArgs& A, uint32_t wid, uint32_t* lds, uint32
   // ---- D. the rest of each front's record / row
   uint64_t w6 = 0ull, w7 = 0ull;
   if (compact) {           // list location and the window of the next seven ranks (tbc_internal.h), through LDS: codes of the chunk + 6 after
+    if (by_ret) wv::barrier();                                      // (the places above lived in these words: every lane is past the loop)
     aux[lane] = active ? rank_code(px, xf, xa, V) : (7u << 6);
     if (lane < kFrontCompactRanks - 1u) {
       const uint32_t G = F_lo + 64u + lane;

@@ -1,4 +1,4 @@
-"""The lean tables ON THE DEVICE (csrc/tbc_internal.h kLeanCands | kLeanLook; TBC_NARROW_LEAN=1, read once per process: this file
+"""The lean tables and / or the lists in order of completion ON THE DEVICE (csrc/tbc_internal.h kLeanCands | kLeanLook; TBC_NARROW_LEAN=1, read once per process: this file
 runs only in a process started with it -- tests/test_zy_forms_gpu.py does that): the narrow kernel over list entries {call, twin mask}
 and 8 B lookahead records against the oracle's schedule with the lean record's reading of three or more open producers (look_two):
 verdict, failing op, every counter.  That the lean formats were really in effect is part of the comparison: on the two-valued busy
@@ -10,7 +10,9 @@ import pytest
 
 from jepsen_tigerbeetle_amd import _native as N, columns, core, synth
 
-pytestmark = [pytest.mark.gpu, pytest.mark.skipif(os.environ.get("TBC_NARROW_LEAN") != "1", reason="a process started with TBC_NARROW_LEAN=1 only")]
+LEAN = os.environ.get("TBC_NARROW_LEAN") == "1"
+ORDER = os.environ.get("TBC_NARROW_ORDER") == "1"      # the fronts' lists in order of completion (PackOpenArgs.list_order): only without a witness
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not (LEAN or ORDER), reason="a process started with TBC_NARROW_LEAN=1 and / or TBC_NARROW_ORDER=1 only")]
 
 CAS = {"kind": 1, "init": N.NIL}
 SHAPES = [(8, 3, 0.0, 0.0, 0.8), (40, 4, 0.0, 0.5, 0.5), (200, 8, 0.0, 0.0, 0.5), (200, 8, 0.0, 0.6, 0.3), (1000, 16, 0.0, 0.0, 0.5),
@@ -23,8 +25,9 @@ def _in_domain(n, p, s, busy, info, corrupt, n_values=5):
     return h
 
 
-def _expect(oracle, h, L, look_two=True):
-    return oracle.check_beam(h.as_dict(), CAS, 1, round_pairs=L, rules_at_any_round_size=True, branch_lists=True, look_two=look_two)
+def _expect(oracle, h, L, look_two=None, list_order=None, **kw):
+    return oracle.check_beam(h.as_dict(), CAS, 1, round_pairs=L, rules_at_any_round_size=True, branch_lists=True,
+                             look_two=LEAN if look_two is None else look_two, list_order=(1 if ORDER else 0) if list_order is None else list_order, **kw)
 
 
 @pytest.mark.parametrize("L", [8, 16])
@@ -33,13 +36,19 @@ def test_lean_tables_match_the_oracles_look_two_schedule(native, oracle, L):
     hists += [columns.pair_events(synth.register_events(n_ops=300, n_procs=24, seed=s, busy=1.0, n_values=2)) for s in range(6)]
     hists = [h for h in hists if h.n_process <= 64]
     model = core.make_model(N.MODEL_CAS_REGISTER, N.NIL)
-    with core.Batch(hists, model, core.make_opts(time_limit_ms=60000, algorithm=N.ALG_COMPETITION, lanes_per_history=L)) as b:
+    # (enough histories that the library does not add the level sweep beside the search; no witness under ORDER: the library takes the
+    # completion order only then)
+    n1 = len(hists)
+    hists = hists * 10
+    with core.Batch(hists, model, core.make_opts(time_limit_ms=60000, algorithm=N.ALG_COMPETITION, lanes_per_history=L, want_witness=not ORDER)) as b:
         assert b.lanes_per_history() == L
         res = b.run().results()
         again = b.run().results()
     differs = 0
     for i, (h, got) in enumerate(zip(hists, res)):
-        exp = _expect(oracle, h, L)
+        if i >= n1 and i % 7:
+            continue
+        exp = _expect(oracle, h, L, want_witness=not ORDER)
         assert got["valid"] == exp["valid"], (i, got["valid"], exp["valid"], got["cause"])
         assert (got["probes"], got["visited"], got["backtracks"], got["max_depth"]) == (exp["probes"], exp["visited"], exp["expanded"], exp["max_stack"]), i
         if exp["valid"] == 0:
@@ -47,8 +56,9 @@ def test_lean_tables_match_the_oracles_look_two_schedule(native, oracle, L):
         elif got["witness"] is not None:
             assert np.array_equal(got["witness"], exp["witness"]), i
         assert (again[i]["valid"], again[i]["probes"]) == (got["valid"], got["probes"])
-        differs += _expect(oracle, h, L, look_two=False)["probes"] != exp["probes"]
-    assert differs >= 1          # (else this run could not tell the lean tables from the default ones)
+        plain = _expect(oracle, h, L, look_two=False, list_order=0, want_witness=False)
+        differs += (plain["probes"], plain["rounds"]) != (exp["probes"], exp["rounds"])
+    assert differs >= 1          # (else this run could not tell these tables from the default ones)
 
 
 def test_lean_tables_in_a_big_batch_with_the_queue(native, oracle):
@@ -58,7 +68,7 @@ def test_lean_tables_in_a_big_batch_with_the_queue(native, oracle):
     with core.Batch([base[i % 64] for i in range(4096)], model, core.make_opts(time_limit_ms=60000, want_witness=False, algorithm=N.ALG_COMPETITION, lanes_per_history=8, visited_per_op=1)) as b:
         res = b.run().results()
     for i in range(64):
-        exp = oracle.check_beam(base[i].as_dict(), CAS, 1, round_pairs=8, rules_at_any_round_size=True, branch_lists=True, look_two=True, want_witness=False)
+        exp = _expect(oracle, base[i], 8, want_witness=False)
         for k in (i, i + 64 * 17, i + 64 * 63):
             got = res[k]
             assert (got["valid"], got["probes"], got["visited"]) == (exp["valid"], exp["probes"], exp["visited"]), (i, k)

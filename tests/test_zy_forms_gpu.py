@@ -22,7 +22,8 @@ pytestmark = pytest.mark.gpu
 FORMS = [("ring+fingerprint", {"TBC_SWEEP_WG_RING": "1", "TBC_SWEEP_WG_FP": "1"}), ("compact", {"TBC_SWEEP_WG_COMPACT": "1"}),
          ("compact+solo+fingerprint", {"TBC_SWEEP_WG_COMPACT": "2", "TBC_SWEEP_WG_FP": "1"}), ("sixteen-wavefronts", {"TBC_SWEEP_WG": "16"}),
          ("pack-one", {"TBC_PACK_ONE": "1"}), ("pack-one+counts+compact+solo+fingerprint", {"TBC_PACK_ONE": "2", "TBC_SWEEP_WG_COMPACT": "2", "TBC_SWEEP_WG_FP": "1"}),
-         ("pack-wg", {"TBC_PACK_WG": "1"}), ("pack-wg-or-error", {"TBC_PACK_WG": "2"}), ("lean-tables", {"TBC_NARROW_LEAN": "1"})]
+         ("pack-wg", {"TBC_PACK_WG": "1"}), ("pack-wg-or-error", {"TBC_PACK_WG": "2"}), ("lean-tables", {"TBC_NARROW_LEAN": "1"}),
+         ("lists-by-completion+lean", {"TBC_NARROW_ORDER": "1", "TBC_NARROW_LEAN": "1"})]
 
 
 @pytest.mark.xfail(strict=False, reason="experimental form: emulator-verified, not yet run on the device when committed")
@@ -39,7 +40,7 @@ def test_form_passes_the_sweeps_own_gpu_tests(native, name, env):
                    "tests/test_gpu_parity.py::test_lookahead_value_range_crashed_writers_and_plain_register", "tests/test_gpu_parity.py::test_wide_window_many_crashed_processes",
                    "tests/test_gpu_parity.py::test_front_walk_by_front_and_by_slot_build_the_same_tables",      # (the bench's own shape: bench.py extra.batch_forms)
                    "tests/test_count_form_gpu.py::test_count_form_several_histories_per_wavefront", "tests/test_count_form_gpu.py::test_count_form_agrees_with_the_mask_form"]
-    if "TBC_NARROW_LEAN" in env:     # the lean formats of the per-front lists and the lookahead records under the narrow kernel: its own file
+    if "TBC_NARROW_LEAN" in env or "TBC_NARROW_ORDER" in env:     # the lean formats of the per-front lists and the lookahead records under the narrow kernel: its own file
         targets = ["tests/test_lean_gpu.py"]         # (the schedule is the oracle's look_two, not the default's: the other files would compare with the wrong one)
     if env.get("TBC_PACK_WG") == "2":        # (2: a batch that does not take the workgroup pack is an error -- these all fit, so they ran it)
         targets = ["tests/test_gpu_parity.py::test_narrow_kernel_matches_its_oracle", "tests/test_gpu_parity.py::test_big_quiet_batches_take_the_narrow_kernel_by_default"]
