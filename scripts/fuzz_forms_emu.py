@@ -1,5 +1,5 @@
-"""The experimental forms of the level sweep (compact walk, narrow passes by one wavefront, fingerprint, ring) and the lean tables of
-the narrow search under the emulators on random small histories -- sizes, concurrency, planted bad reads (inside the value domain),
+"""The experimental forms of the level sweep (compact walk, narrow passes by one wavefront, fingerprint, ring) and the lean tables / the lists in order
+of completion of the narrow search under the emulators on random small histories -- sizes, concurrency, planted bad reads (inside the value domain),
 crashed calls, wavefronts per workgroup, set sizes, segment lengths, interleaving seeds -- every record / counter against the oracle.
 usage: fuzz_forms_emu.py [rounds] [seed]      Round 4: 150 rounds, no mismatch."""
 import os, random, sys
@@ -39,8 +39,9 @@ for it in range(rounds):
     # ---- the lean tables
     if h.n_process <= 64:
         try:
-            TN.compare([h], TN.CAS, rng.choice([8, 16, 32]), tag="fuzz", pool_words=8_000_000, lean=True, entries_per_op=rng.choice([1, 4, 8]),
-                       want_witness=bool(it & 1), epochs=rng.choice([0, 0, 2]))
+            by_ret = bool(it & 2)                       # the fronts' lists in order of completion (only without a witness)
+            TN.compare([h], TN.CAS, rng.choice([8, 16, 32]), tag="fuzz", pool_words=8_000_000, lean=bool(it & 4) or not by_ret, entries_per_op=rng.choice([1, 4, 8]),
+                       want_witness=bool(it & 1) and not by_ret, epochs=rng.choice([0, 0, 2]), by_ret=by_ret)
         except Exception as e:
             a = e.args[0] if e.args else None
             if isinstance(a, tuple) and len(a) == 4 and a[1] == -1 and a[3] == 3:
