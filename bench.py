@@ -375,7 +375,10 @@ BATCH_FORMS = [("pack_kernel + open_counts_kernel (the default)", {}),
                ("pack + open counts by four wavefronts per history, tables in LDS", {"TBC_PACK_WG": "2"}),
                ("lean tables: list entries {call, twin mask}, 8 B lookahead records", {"TBC_NARROW_LEAN": "1"}),
                ("lists in order of completion", {"TBC_NARROW_ORDER": "1"}),
-               ("lean tables + lists in order of completion + pack by four wavefronts", {"TBC_NARROW_LEAN": "1", "TBC_NARROW_ORDER": "1", "TBC_PACK_WG": "2"})]
+               ("lean tables + lists in order of completion + pack by four wavefronts", {"TBC_NARROW_LEAN": "1", "TBC_NARROW_ORDER": "1", "TBC_PACK_WG": "2"}),
+               # (a wavefront per history at 19 calls in flight -- workload 3's kernel -- in both list orders; compared with each other only)
+               ("19 calls in flight, a wavefront per history", {"TBC_BENCH_FORM_BUSY": "0.3"}),
+               ("19 calls in flight, a wavefront per history, lists in order of completion", {"TBC_BENCH_FORM_BUSY": "0.3", "TBC_NARROW_ORDER": "1"})]
 
 
 def leg_one_batch_form(args, local_rank):
@@ -384,6 +387,23 @@ def leg_one_batch_form(args, local_rank):
     breakdown of the best, and the counters every form must agree on."""
     np, N, columns, core, synth = _gpu_imports()
     model = core.make_model(N.MODEL_CAS_REGISTER, N.NIL)
+    busy_form = os.environ.get("TBC_BENCH_FORM_BUSY")
+    if busy_form:        # another workload: more calls in flight, a wavefront per history (what the library takes there), a smaller batch
+        B = 2048
+        hs = synth.register_ops_many(range(6_000_000, 6_000_000 + B), n_ops=args.ops, n_procs=args.procs, busy=float(busy_form), info=0.0)
+        o = core.make_opts(device=local_rank, time_limit_ms=600000, want_witness=False, algorithm=N.ALG_COMPETITION, search_width=args.width, visited_per_op=32)
+        best = None
+        with core.Batch(hs, model, o) as b:
+            lanes = b.lanes_per_history()
+            for _ in range(2):
+                t = time.perf_counter(); b.run(); dt = (time.perf_counter() - t) * 1e3
+                tm = b.timing_ns()
+                if best is None or dt < best[0]:
+                    best = (dt, tm)
+            c = b.counters(); v = b.verdicts()
+        return {"histories": B, "busy": float(busy_form), "lanes_per_history": lanes, "ms_per_pass": round(best[0], 3),
+                "device_ms": {k: round(x / 1e6, 3) for k, x in best[1].items()}, "probes": int(c["probes"]), "new_configs": int(c["visited"]),
+                "signature": [int((v == N.VALID).sum()), int((v == N.INVALID).sum()), -1, int(c["probes"]), int(c["visited"])]}
     B = 8192
     hs = synth.register_ops_many(range(5_000_000, 5_000_000 + B), n_ops=args.ops, n_procs=args.procs, busy=args.busy, info=0.0)
     hp = columns.pair_events(synth.register_events(n_ops=args.ops, n_procs=args.procs, seed=5_000_077, busy=args.busy, info=0.0, corrupt=0.02, n_values=4))
@@ -429,8 +449,10 @@ def leg_batch_forms(args, local_rank):
                 entry["error"] = f"return code {r.returncode}, no result"
             else:
                 sig = res.pop("signature")
-                if not env:
-                    base = sig
+                grp = env.get("TBC_BENCH_FORM_BUSY", "")          # (a form is compared with the first of its own workload)
+                if not isinstance(base, dict):
+                    base = {}
+                base.setdefault(grp, sig)
                 entry.update(res)
                 entry["_sig"] = sig
         except subprocess.TimeoutExpired:
@@ -439,13 +461,14 @@ def leg_batch_forms(args, local_rank):
     for e in out:          # the same verdicts, the same planted history found, the same probes and new configs as the default form
         sig = e.pop("_sig", None)
         if sig is not None:
-            e["counters_match"] = base is not None and sig == base
+            b0 = (base or {}).get(e["env"].get("TBC_BENCH_FORM_BUSY", "")) if isinstance(base, dict) else None
+            e["counters_match"] = b0 is not None and sig == b0
             # (the lean lookahead record reads three or more open producers as "one is still to come": its schedule is the oracle's
             # look_two, a handful of probes away from the default's on such histories; lists in order of completion are another
             # schedule altogether (fewer rounds) -- verdicts and the planted history must agree)
-            e["verdicts_match"] = base is not None and sig[:3] == base[:3]
-            if base is not None and sig != base:
-                e["probes_vs_default"] = [sig[3] - base[3], sig[4] - base[4]]
+            e["verdicts_match"] = b0 is not None and sig[:3] == b0[:3]
+            if b0 is not None and sig != b0:
+                e["probes_vs_default"] = [sig[3] - b0[3], sig[4] - b0[4]]
     return out
 
 

@@ -310,16 +310,17 @@ struct tbc_batch {
                     (rules & (kRuleEager | kRuleTwin | kRuleCount)) == (kRuleEager | kRuleTwin) && lookahead && !sweep && opts.round_budget == 0;
     return ok ? (kLeanCands | kLeanLook) : 0u;
   }
-  // TBC_NARROW_ORDER=1 (experimental; tbc_internal.h PackOpenArgs.list_order): the per-front lists of a batch that runs several histories
-  // per wavefront in order of COMPLETION instead of process slot -- the search then tries the call that completes soonest first: on
+  // TBC_NARROW_ORDER=1 (experimental; tbc_internal.h PackOpenArgs.list_order): the per-front lists of a batch of the wide schedule (several histories
+  // per wavefront, or one) in order of COMPLETION instead of process slot -- the search then tries the call that completes soonest first: on
   // the bench workload 18 % fewer rounds for the same probes, the longest history 31 % fewer (oracle counts).  Where
   // nothing depends on slot order: the walk with lane = front, no witness (its absorbed reads are replayed in slot order), no level
   // sweep beside it (origins are numbered by list position), no count form, no round budget.  Emulator-verified only; off unless asked
   uint32_t list_order() const {
     static const bool asked = [] { const char* e = std::getenv("TBC_NARROW_ORDER"); return e && e[0] == '1'; }();
     static const bool by_slots = [] { const char* e = std::getenv("TBC_OPEN_WALK"); return e && std::strcmp(e, "slots") == 0; }();
-    return (asked && !by_slots && lanes >= 8 && mask_words == 1 && vpad <= 32 && !(rules & kRuleCount) && !sweep && !opts.want_witness &&
-            opts.round_budget == 0) ? 1u : 0u;
+    // (a wavefront per history too -- the wide kernel takes its pairs from the same lists: at 19 calls in flight 28 % fewer probes, 41 % fewer rounds)
+    return (asked && !by_slots && width > 1 && mask_words == 1 && vpad <= 32 && !(rules & kRuleCount) && !sweep && !opts.want_witness &&
+            opts.round_budget == 0 && (model.kind == TBC_MODEL_REGISTER || model.kind == TBC_MODEL_CAS_REGISTER)) ? 1u : 0u;
   }
   std::vector<BeamHist> bh;
   DevBuf<BeamHist> d_bh;

@@ -72,3 +72,30 @@ def test_lean_tables_in_a_big_batch_with_the_queue(native, oracle):
         for k in (i, i + 64 * 17, i + 64 * 63):
             got = res[k]
             assert (got["valid"], got["probes"], got["visited"]) == (exp["valid"], exp["probes"], exp["visited"]), (i, k)
+
+
+@pytest.mark.skipif(not ORDER, reason="TBC_NARROW_ORDER=1 only")
+@pytest.mark.parametrize("width", [2, 4])
+def test_wide_schedule_over_lists_in_order_of_completion(native, oracle, width):
+    """a wavefront per history (the kernel of workloads 2 / 3) takes its pairs from the same lists: against the oracle's wide schedule
+    with list_order = 1 -- verdict, failing op, every counter -- at 6, 19 and 32 calls in flight; and it needs fewer probes there"""
+    cases = [(200, 8, 0.0, 0.0, 0.5), (200, 8, 0.0, 0.6, 0.3), (1000, 16, 0.0, 0.0, 0.5), (1000, 16, 0.0, 0.6, 0.2), (2000, 64, 0.0, 0.0, 0.1),
+             (2000, 64, 0.0, 0.0, 0.3), (2000, 64, 0.0, 0.0, 0.5), (1500, 64, 0.0, 0.5, 0.3)]
+    hists = [_in_domain(n, p, s, busy, info, corrupt) for (n, p, info, corrupt, busy) in cases for s in range(3)]
+    n1 = len(hists)
+    model = core.make_model(N.MODEL_CAS_REGISTER, N.NIL)
+    with core.Batch(hists * 11, model, core.make_opts(time_limit_ms=60000, search_width=width, algorithm=N.ALG_COMPETITION, want_witness=False)) as b:
+        assert b.lanes_per_history() == 64
+        res = b.run().results()
+    fewer = 0
+    for i, h in enumerate(hists):
+        exp = oracle.check_beam(h.as_dict(), CAS, width, max_probes=20_000_000, want_witness=False, list_order=1)
+        plain = oracle.check_beam(h.as_dict(), CAS, width, max_probes=20_000_000, want_witness=False)
+        for k in (i, i + 5 * n1):
+            got = res[k]
+            assert got["valid"] == exp["valid"], (i, k)
+            if exp["valid"] == 0:
+                assert got["fail_op"] == exp["fail_op"], (i, k)
+            assert (got["probes"], got["visited"], got["backtracks"], got["max_depth"]) == (exp["probes"], exp["visited"], exp["expanded"], exp["max_stack"]), (i, k)
+        fewer += exp["probes"] < plain["probes"]
+    assert fewer >= n1 // 2
