@@ -759,6 +759,13 @@ WV_DEV void segment(const SweepArgs& A, uint32_t* lds) {
         }
         if (qn != 0 && status == kSegOk) {                     // what is left in the ring
           if (!insert_q<CAP, NW, FP>(nxt, q, wq, wq_sel, qh, qn, X)) status = kSegOverflow;
+        } else {
+          // A sub-round whose last pass left the ring empty ends without a barrier behind that pass's count words -- and the next
+          // sub-round starts its pass parity at 0 again, or is a small one whose insert2 uses the same words by ITS parity: a fast
+          // wavefront then overwrites a count a slow one has not read, the two disagree on how full the ring is and meet at
+          // different barriers (found by scripts/fuzz_forms_emu.py on a crash-heavy history, one long segment; the emulator stops at
+          // "wavefronts at different workgroup barriers", a GPU would hang).  One barrier here closes it.
+          wv::wg_barrier();
         }
       }
       src = q.e; n_src = q.n; via_list = false;

@@ -27,6 +27,8 @@ for it in range(rounds):
     if form.get("fp") and not form.get("compact") and (waves, cap) not in ((2, 1024), (8, 1024)):
         waves, cap = 8, 1024
     seg = rng.choice([0, 16, 32, 32])
+    if os.environ.get("TBC_FUZZ_TRACE"):        # (an emulator abort -- a divergent barrier -- ends the process: name the case first)
+        print("case", it, (n, p, busy, corrupt, info, seed), form, waves, cap, seg, flush=True)
     try:
         try:
             TS._compare(h, seg, 6, waves, cap=cap, seed=rng.randrange(1000), **form)
