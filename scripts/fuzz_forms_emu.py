@@ -20,12 +20,17 @@ for it in range(rounds):
     seed = rng.randrange(10 ** 6)
     h = TN._in_domain(n, p, seed, busy, info, corrupt)
     # ---- the sweep's forms
-    form = rng.choice([{"compact": True}, {"compact": 2}, {"compact": 2, "fp": True}, {"compact": True, "fp": True}, {"queue": True, "fp": True}])
-    waves, cap = rng.choice([(2, 512), (2, 1024), (4, 1024), (8, 1024), (8, 2048)])
-    if form.get("queue") and (waves, cap) not in ((2, 1024), (4, 1024), (8, 1024)):
-        waves, cap = 8, 1024
-    if form.get("fp") and not form.get("compact") and (waves, cap) not in ((2, 1024), (8, 1024)):
-        waves, cap = 8, 1024
+    form = rng.choice([{"compact": True}, {"compact": 2}, {"compact": 2, "fp": True}, {"compact": True, "fp": True}, {"queue": True, "fp": True},
+                       {"queue": True}, {"fp": True}, {}])
+    # (the geometries tests/emu/emu_sweep.cpp instantiates for each form)
+    if form.get("compact"):
+        waves, cap = rng.choice([(2, 512), (2, 1024), (4, 1024), (8, 1024), (8, 2048), (16, 2048)])
+    elif form.get("fp"):
+        waves, cap = rng.choice([(2, 1024), (8, 1024), (4, 512)])
+    elif form.get("queue"):
+        waves, cap = rng.choice([(2, 1024), (4, 1024), (8, 1024), (4, 512), (8, 2048)])
+    else:
+        waves, cap = rng.choice([(2, 1024), (4, 1024), (8, 1024), (4, 512), (8, 2048), (16, 2048)])
     seg = rng.choice([0, 16, 32, 32])
     if os.environ.get("TBC_FUZZ_TRACE"):        # (an emulator abort -- a divergent barrier -- ends the process: name the case first)
         print("case", it, (n, p, busy, corrupt, info, seed), form, waves, cap, seg, flush=True)
