@@ -378,7 +378,10 @@ BATCH_FORMS = [("pack_kernel + open_counts_kernel (the default)", {}),
                ("lean tables + lists in order of completion + pack by four wavefronts", {"TBC_NARROW_LEAN": "1", "TBC_NARROW_ORDER": "1", "TBC_PACK_WG": "2"}),
                # (a wavefront per history at 19 calls in flight -- workload 3's kernel -- in both list orders; compared with each other only)
                ("19 calls in flight, a wavefront per history", {"TBC_BENCH_FORM_BUSY": "0.3"}),
-               ("19 calls in flight, a wavefront per history, lists in order of completion", {"TBC_BENCH_FORM_BUSY": "0.3", "TBC_NARROW_ORDER": "1"})]
+               ("19 calls in flight, a wavefront per history, lists in order of completion", {"TBC_BENCH_FORM_BUSY": "0.3", "TBC_NARROW_ORDER": "1"}),
+               # (32 in flight: a pass is its slowest history -- on oracle samples of 16-32 histories the order moves the tail by 0.7x .. 7x either way)
+               ("32 calls in flight, a wavefront per history", {"TBC_BENCH_FORM_BUSY": "0.5"}),
+               ("32 calls in flight, a wavefront per history, lists in order of completion", {"TBC_BENCH_FORM_BUSY": "0.5", "TBC_NARROW_ORDER": "1"})]
 
 
 def leg_one_batch_form(args, local_rank):
@@ -389,13 +392,15 @@ def leg_one_batch_form(args, local_rank):
     model = core.make_model(N.MODEL_CAS_REGISTER, N.NIL)
     busy_form = os.environ.get("TBC_BENCH_FORM_BUSY")
     if busy_form:        # another workload: more calls in flight, a wavefront per history (what the library takes there), a smaller batch
-        B = 2048
+        heavy = float(busy_form) > 0.4          # (32 in flight: 2^21-entry first sets as workload 2's, fewer histories, one pass)
+        B = 1024 if heavy else 2048
         hs = synth.register_ops_many(range(6_000_000, 6_000_000 + B), n_ops=args.ops, n_procs=args.procs, busy=float(busy_form), info=0.0)
-        o = core.make_opts(device=local_rank, time_limit_ms=600000, want_witness=False, algorithm=N.ALG_COMPETITION, search_width=args.width, visited_per_op=32)
+        o = core.make_opts(device=local_rank, time_limit_ms=600000, want_witness=False, algorithm=N.ALG_COMPETITION, search_width=args.width,
+                           visited_per_op=256 if heavy else 32)
         best = None
         with core.Batch(hs, model, o) as b:
             lanes = b.lanes_per_history()
-            for _ in range(2):
+            for _ in range(1 if heavy else 2):
                 t = time.perf_counter(); b.run(); dt = (time.perf_counter() - t) * 1e3
                 tm = b.timing_ns()
                 if best is None or dt < best[0]:
