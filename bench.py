@@ -375,6 +375,10 @@ BATCH_FORMS = [("pack_kernel + open_counts_kernel (the default)", {}),
                ("pack + open counts by four wavefronts per history, tables in LDS", {"TBC_PACK_WG": "2"}),
                ("lean tables: list entries {call, twin mask}, 8 B lookahead records", {"TBC_NARROW_LEAN": "1"}),
                ("lists in order of completion", {"TBC_NARROW_ORDER": "1"}),
+               # (4 lanes per history = 16 histories a wavefront: the oracle counts 30 % more rounds a history in completion order, 39 % in slot
+               # order, for the same probes -- and half the wavefront iterations a history-round; emulator-tested, never run on the device)
+               ("4 lanes per history", {"TBC_BENCH_FORM_LANES": "4"}),
+               ("4 lanes per history, lists in order of completion", {"TBC_BENCH_FORM_LANES": "4", "TBC_NARROW_ORDER": "1"}),
                ("lean tables + lists in order of completion + pack by four wavefronts", {"TBC_NARROW_LEAN": "1", "TBC_NARROW_ORDER": "1", "TBC_PACK_WG": "2"}),
                # (a wavefront per history at 19 calls in flight -- workload 3's kernel -- in both list orders; compared with each other only)
                ("19 calls in flight, a wavefront per history", {"TBC_BENCH_FORM_BUSY": "0.3"}),
@@ -415,7 +419,7 @@ def leg_one_batch_form(args, local_rank):
     hp.a[hp.a == 4 + 7] = 4          # (the planted read's value inside the batch's domain: compact front records, as the headline's batches)
     hs[77] = hp
     o = core.make_opts(device=local_rank, time_limit_ms=600000, want_witness=False, algorithm=N.ALG_COMPETITION, visited_per_op=args.visited_per_op,
-                       lanes_per_history=8)
+                       lanes_per_history=int(os.environ.get("TBC_BENCH_FORM_LANES", "8")))
     best = None
     with core.Batch(hs, model, o) as b:
         lanes = b.lanes_per_history()
