@@ -379,6 +379,7 @@ BATCH_FORMS = [("pack_kernel + open_counts_kernel (the default)", {}),
                # order, for the same probes -- and half the wavefront iterations a history-round; emulator-tested, never run on the device)
                ("4 lanes per history", {"TBC_BENCH_FORM_LANES": "4"}),
                ("4 lanes per history, lists in order of completion", {"TBC_BENCH_FORM_LANES": "4", "TBC_NARROW_ORDER": "1"}),
+               ("4 lanes per history, lists in order of completion, lean tables", {"TBC_BENCH_FORM_LANES": "4", "TBC_NARROW_ORDER": "1", "TBC_NARROW_LEAN": "1"}),
                ("lean tables + lists in order of completion + pack by four wavefronts", {"TBC_NARROW_LEAN": "1", "TBC_NARROW_ORDER": "1", "TBC_PACK_WG": "2"}),
                # (a wavefront per history at 19 calls in flight -- workload 3's kernel -- in both list orders; compared with each other only)
                ("19 calls in flight, a wavefront per history", {"TBC_BENCH_FORM_BUSY": "0.3"}),

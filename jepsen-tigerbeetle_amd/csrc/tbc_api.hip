@@ -306,7 +306,7 @@ struct tbc_batch {
   uint32_t lean() const {
     static const bool asked = [] { const char* e = std::getenv("TBC_NARROW_LEAN"); return e && e[0] == '1'; }();
     static const bool by_slots = [] { const char* e = std::getenv("TBC_OPEN_WALK"); return e && std::strcmp(e, "slots") == 0; }();
-    const bool ok = asked && !by_slots && lanes >= 8 && mask_words == 1 && front_words() == kFrontCompactWords &&
+    const bool ok = asked && !by_slots && lanes >= 4 && lanes < 64 && mask_words == 1 && front_words() == kFrontCompactWords &&
                     (rules & (kRuleEager | kRuleTwin | kRuleCount)) == (kRuleEager | kRuleTwin) && lookahead && !sweep && opts.round_budget == 0;
     return ok ? (kLeanCands | kLeanLook) : 0u;
   }

@@ -80,7 +80,7 @@ void launch_lean(const BeamArgs& a_in, hipStream_t s, uint32_t wps) {
 
 template <int MW, int L>
 void launch_one(const BeamArgs& a, hipStream_t s, uint32_t wps) {
-  if constexpr (MW == 1 && L >= 8) {
+  if constexpr (MW == 1) {
     if (a.lean == (kLeanCands | kLeanLook) && a.front_words == kFrontCompactWords && !(a.rules & kRuleCount)) { launch_lean<L>(a, s, wps); return; }
   }
   if constexpr (MW <= 2 && L >= 8) {

@@ -355,8 +355,7 @@ def test_lists_in_order_of_completion_every_counter(lean):
     # (no witness: the chain's absorbed reads come out in list order, and libtbcheck takes this order only when nobody wants a witness)
     compare(hists, CAS, 8, tag="by ret", pool_words=4_000_000, by_ret=True, lean=lean, want_witness=False)
     compare(hists[:10], CAS, 16, tag="by ret 16", pool_words=4_000_000, by_ret=True, lean=lean, want_witness=False)
-    if not lean:          # (4 lanes per history: 16 histories a wavefront; the lean kernel is built for 8 lanes and more)
-        compare(hists, CAS, 4, tag="by ret 4", pool_words=4_000_000, by_ret=True, want_witness=False)
+    compare(hists, CAS, 4, tag="by ret 4", pool_words=4_000_000, by_ret=True, lean=lean, want_witness=False)      # (16 histories a wavefront)
 
 
 def test_lists_in_order_of_completion_need_fewer_rounds():
