@@ -289,18 +289,19 @@ def leg_set_full(args, local_rank):
 # runs in a process of its own; the forms other than the default were verified under the wavefront emulator (tests/emu) and had
 # not all been timed on the device when they were committed -- this leg is their measurement, and it can never cost the line:
 # a form that faults, times out or disagrees leaves {"error": ...} / "counters_match": false in its own entry.
-FORMS = [("K6 (one wavefront per segment)", {"TBC_SWEEP_WG": "0"}),
-         ("K6w, 8 wavefronts per segment (the default)", {}),
-         ("K6w + ring", {"TBC_SWEEP_WG_RING": "1"}),
-         ("K6w + fingerprint", {"TBC_SWEEP_WG_FP": "1"}),
-         ("K6w + ring + fingerprint", {"TBC_SWEEP_WG_RING": "1", "TBC_SWEEP_WG_FP": "1"}),
-         ("K6w + compact walk", {"TBC_SWEEP_WG_COMPACT": "1"}),
-         ("K6w + compact walk + narrow passes by one wavefront", {"TBC_SWEEP_WG_COMPACT": "2"}),
+# (in order of what is wanted most: a leg has a time budget -- TBC_BENCH_FORMS_BUDGET_S, default 100 s -- and the forms it does not get to say so)
+FORMS = [("K6w, 8 wavefronts per segment (the default)", {}),
          ("K6w + compact walk + narrow passes by one wavefront + fingerprint", {"TBC_SWEEP_WG_COMPACT": "2", "TBC_SWEEP_WG_FP": "1"}),
-         ("K6w, 16 wavefronts on the big sets", {"TBC_SWEEP_WG": "16"}),
-         ("pack by a workgroup's sixteen wavefronts", {"TBC_PACK_ONE": "1"}),
+         ("pack + open counts by sixteen wavefronts + K6w compact + narrow + fingerprint", {"TBC_PACK_ONE": "2", "TBC_SWEEP_WG_COMPACT": "2", "TBC_SWEEP_WG_FP": "1"}),
+         ("K6w + compact walk + narrow passes by one wavefront", {"TBC_SWEEP_WG_COMPACT": "2"}),
          ("pack + open counts by sixteen wavefronts, one launch", {"TBC_PACK_ONE": "2"}),
-         ("pack + open counts by sixteen wavefronts + K6w compact + narrow + fingerprint", {"TBC_PACK_ONE": "2", "TBC_SWEEP_WG_COMPACT": "2", "TBC_SWEEP_WG_FP": "1"})]
+         ("K6w + compact walk", {"TBC_SWEEP_WG_COMPACT": "1"}),
+         ("K6w + fingerprint", {"TBC_SWEEP_WG_FP": "1"}),
+         ("pack by a workgroup's sixteen wavefronts", {"TBC_PACK_ONE": "1"}),
+         ("K6w + ring + fingerprint", {"TBC_SWEEP_WG_RING": "1", "TBC_SWEEP_WG_FP": "1"}),
+         ("K6 (one wavefront per segment)", {"TBC_SWEEP_WG": "0"}),
+         ("K6w + ring", {"TBC_SWEEP_WG_RING": "1"}),
+         ("K6w, 16 wavefronts on the big sets", {"TBC_SWEEP_WG": "16"})]
 
 
 def leg_one_form(args, local_rank):
@@ -335,9 +336,15 @@ def leg_one_form(args, local_rank):
 def leg_single_history_forms(args, local_rank):
     import subprocess
     out, base = [], None
+    t_leg = time.time()
+    budget = float(os.environ.get("TBC_BENCH_FORMS_BUDGET_S", "100"))
     for name, env in FORMS:
-        leg("form: " + name)
         entry = {"form": name, "env": env}
+        if time.time() - t_leg > budget:
+            entry["skipped"] = f"the leg's {budget:.0f} s were spent (TBC_BENCH_FORMS_BUDGET_S)"
+            out.append(entry)
+            continue
+        leg("form: " + name)
         try:
             cmd = [sys.executable, os.path.abspath(__file__)] + [a for a in sys.argv[1:] if a not in ("--leg", "single_history_forms")] + ["--leg", "one_form"]
             r = subprocess.run(cmd, stdout=subprocess.PIPE, timeout=120, env=dict(os.environ, LOCAL_RANK=str(local_rank), **env))
@@ -372,18 +379,18 @@ def leg_single_history_forms(args, local_rank):
 # ---- extra.batch_forms: ONE resident batch of the headline workload (a quarter of its size) under the switchable forms of the batch
 # path, each in a process of its own (the switches are read once per process), never fatal -- as extra.single_history_forms.
 BATCH_FORMS = [("pack_kernel + open_counts_kernel (the default)", {}),
-               ("pack + open counts by four wavefronts per history, tables in LDS", {"TBC_PACK_WG": "2"}),
-               ("lean tables: list entries {call, twin mask}, 8 B lookahead records", {"TBC_NARROW_LEAN": "1"}),
                ("lists in order of completion", {"TBC_NARROW_ORDER": "1"}),
+               ("lean tables: list entries {call, twin mask}, 8 B lookahead records", {"TBC_NARROW_LEAN": "1"}),
+               ("lean tables + lists in order of completion + pack by four wavefronts", {"TBC_NARROW_LEAN": "1", "TBC_NARROW_ORDER": "1", "TBC_PACK_WG": "2"}),
+               ("pack + open counts by four wavefronts per history, tables in LDS", {"TBC_PACK_WG": "2"}),
                # (4 lanes per history = 16 histories a wavefront: the oracle counts 30 % more rounds a history in completion order, 39 % in slot
                # order, for the same probes -- and half the wavefront iterations a history-round; emulator-tested, never run on the device)
-               ("4 lanes per history", {"TBC_BENCH_FORM_LANES": "4"}),
                ("4 lanes per history, lists in order of completion", {"TBC_BENCH_FORM_LANES": "4", "TBC_NARROW_ORDER": "1"}),
                ("4 lanes per history, lists in order of completion, lean tables", {"TBC_BENCH_FORM_LANES": "4", "TBC_NARROW_ORDER": "1", "TBC_NARROW_LEAN": "1"}),
-               ("lean tables + lists in order of completion + pack by four wavefronts", {"TBC_NARROW_LEAN": "1", "TBC_NARROW_ORDER": "1", "TBC_PACK_WG": "2"}),
                # (a wavefront per history at 19 calls in flight -- workload 3's kernel -- in both list orders; compared with each other only)
                ("19 calls in flight, a wavefront per history", {"TBC_BENCH_FORM_BUSY": "0.3"}),
                ("19 calls in flight, a wavefront per history, lists in order of completion", {"TBC_BENCH_FORM_BUSY": "0.3", "TBC_NARROW_ORDER": "1"}),
+               ("4 lanes per history", {"TBC_BENCH_FORM_LANES": "4"}),
                # (32 in flight: a pass is its slowest history -- on oracle samples of 16-32 histories the order moves the tail by 0.7x .. 7x either way)
                ("32 calls in flight, a wavefront per history", {"TBC_BENCH_FORM_BUSY": "0.5"}),
                ("32 calls in flight, a wavefront per history, lists in order of completion", {"TBC_BENCH_FORM_BUSY": "0.5", "TBC_NARROW_ORDER": "1"})]
@@ -439,9 +446,15 @@ def leg_one_batch_form(args, local_rank):
 def leg_batch_forms(args, local_rank):
     import subprocess
     out, base = [], None
+    t_leg = time.time()
+    budget = float(os.environ.get("TBC_BENCH_FORMS_BUDGET_S", "100")) * 1.3        # (the forms it does not get to say so)
     for name, env in BATCH_FORMS:
-        leg("batch form: " + name)
         entry = {"form": name, "env": env}
+        if time.time() - t_leg > budget:
+            entry["skipped"] = f"the leg's {budget:.0f} s were spent (TBC_BENCH_FORMS_BUDGET_S x 1.3)"
+            out.append(entry)
+            continue
+        leg("batch form: " + name)
         try:
             cmd = [sys.executable, os.path.abspath(__file__)] + [a for a in sys.argv[1:] if a not in ("--leg", "batch_forms")] + ["--leg", "one_batch_form"]
             r = subprocess.run(cmd, stdout=subprocess.PIPE, timeout=240, env=dict(os.environ, LOCAL_RANK=str(local_rank), **env))
@@ -516,6 +529,7 @@ def run_leg(name, args, local_rank):
 
 
 def main():
+    t_bench0 = time.time()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=32, help="timed passes (each over one batch); with two batches in flight the first pack and the last search are not overlapped, so few steps under-report the steady rate (16 steps: -3 %%)")
@@ -897,14 +911,16 @@ def main():
         if world == 1 and not args.no_set_full:
             line["extra"]["set_full"] = run_leg("set_full", args, local_rank)
         if world == 1 and on_gpu and not args.only_headline and not args.no_forms:
-            try:
-                line["extra"]["single_history_forms"] = run_leg("single_history_forms", args, local_rank)
-            except SystemExit as e:      # (this leg measures forms not yet timed on the device: it reports, it never fails the run)
-                line["extra"]["single_history_forms"] = {"error": str(e)}
-            try:
-                line["extra"]["batch_forms"] = run_leg("batch_forms", args, local_rank)
-            except SystemExit as e:
-                line["extra"]["batch_forms"] = {"error": str(e)}
+            # the two form legs measure what has not been timed on the device yet: they report, they never fail the run, and they never make
+            # it long -- each has a budget of its own (TBC_BENCH_FORMS_BUDGET_S), and a run that is past five minutes skips what is left
+            for name in ("single_history_forms", "batch_forms"):
+                if time.time() - t_bench0 > 300:
+                    line["extra"][name] = {"skipped": "the run was past 300 s when this leg's turn came"}
+                    continue
+                try:
+                    line["extra"][name] = run_leg(name, args, local_rank)
+                except SystemExit as e:
+                    line["extra"][name] = {"error": str(e)}
         print(json.dumps(line), flush=True)
     for b in batches:
         b.close()
