@@ -289,7 +289,7 @@ def leg_set_full(args, local_rank):
 # runs in a process of its own; the forms other than the default were verified under the wavefront emulator (tests/emu) and had
 # not all been timed on the device when they were committed -- this leg is their measurement, and it can never cost the line:
 # a form that faults, times out or disagrees leaves {"error": ...} / "counters_match": false in its own entry.
-# (in order of what is wanted most: a leg has a time budget -- TBC_BENCH_FORMS_BUDGET_S, default 100 s -- and the forms it does not get to say so)
+# (in order of what is wanted most: a leg has a time budget -- TBC_BENCH_FORMS_BUDGET_S, default 80 s -- and the forms it does not get to say so)
 FORMS = [("K6w, 8 wavefronts per segment (the default)", {}),
          ("K6w + compact walk + narrow passes by one wavefront + fingerprint", {"TBC_SWEEP_WG_COMPACT": "2", "TBC_SWEEP_WG_FP": "1"}),
          ("pack + open counts by sixteen wavefronts + K6w compact + narrow + fingerprint", {"TBC_PACK_ONE": "2", "TBC_SWEEP_WG_COMPACT": "2", "TBC_SWEEP_WG_FP": "1"}),
@@ -337,7 +337,7 @@ def leg_single_history_forms(args, local_rank):
     import subprocess
     out, base = [], None
     t_leg = time.time()
-    budget = float(os.environ.get("TBC_BENCH_FORMS_BUDGET_S", "100"))
+    budget = float(os.environ.get("TBC_BENCH_FORMS_BUDGET_S", "80"))
     for name, env in FORMS:
         entry = {"form": name, "env": env}
         if time.time() - t_leg > budget:
@@ -447,7 +447,7 @@ def leg_batch_forms(args, local_rank):
     import subprocess
     out, base = [], None
     t_leg = time.time()
-    budget = float(os.environ.get("TBC_BENCH_FORMS_BUDGET_S", "100")) * 1.3        # (the forms it does not get to say so)
+    budget = float(os.environ.get("TBC_BENCH_FORMS_BUDGET_S", "80")) * 1.3        # (the forms it does not get to say so)
     for name, env in BATCH_FORMS:
         entry = {"form": name, "env": env}
         if time.time() - t_leg > budget:
