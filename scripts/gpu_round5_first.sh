@@ -1,5 +1,5 @@
 #!/bin/bash
-# The next round's FIRST gpurun call (one box, ~12 minutes): everything round 4 prepared under the emulators and could not measure.
+# The next round's FIRST gpurun call (one box, ~20 minutes): everything round 4 prepared under the emulators and could not measure.
 #   1. the GPU tests (the experimental forms are tests/test_zy_forms_gpu.py: XPASS = the form is right on the device)
 #   2. bench.py's two form legs alone: one history under every form of the single-history path, a batch under both packs
 #   3. rocprofv3 kernel stats of a batch pass under pack_kernel + open_counts_kernel, under pack_wg_kernel (TBC_PACK_WG=2) and over the
@@ -10,7 +10,7 @@ mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
 timeout -k 5 900 python -m pytest tests -q -m gpu -rxX 2>&1 | tail -40 > $OUT/gpu_tests.txt
 for leg in single_history_forms batch_forms; do
-  timeout -k 5 600 python bench.py --leg $leg 2> $OUT/$leg.stderr | tail -1 > $OUT/$leg.json
+  TBC_BENCH_FORMS_BUDGET_S=900 timeout -k 5 1200 python bench.py --leg $leg 2> $OUT/$leg.stderr | tail -1 > $OUT/$leg.json     # (every form: the driver's run has 80 s a leg)
 done
 cd /tmp && export TMPDIR=/tmp
 for form in default wg lean; do
