@@ -230,3 +230,31 @@ def test_narrow_round_schedules_keep_verdict_and_failing_op(oracle):
                         assert (r["probes"], r["visited"]) == (ref["probes"], ref["visited"]) and r["rounds"] >= ref["rounds"]
                     n_checked += 1
     assert n_checked > 60
+
+
+def test_list_order_and_the_lean_lookahead_never_change_a_verdict(native, oracle):
+    """The schedules behind TBC_NARROW_ORDER (a front's candidates in order of completion, wgl_beam_set_list_order(1)) and
+    TBC_NARROW_LEAN (three or more open producers read as "one is still to be linearized", look_two) are schedules of the SAME
+    search: verdict and failing op are the sequential restatement's on random histories, valid and invalid, with crashed calls --
+    at one config a round over 8 pairs (the narrow kernel's), at 2 and 4 configs a round (the wide kernel's)."""
+    import random
+    rng = random.Random(1)
+    cas = {"kind": 1, "init": N.NIL}
+    n_invalid = n = 0
+    for it in range(140):
+        shape = dict(n_ops=rng.choice([10, 30, 80, 200]), n_procs=rng.choice([2, 4, 8, 16]), busy=rng.choice([0.3, 0.7, 1.0]),
+                     info=rng.choice([0, 0, 0.05]), corrupt=rng.choice([0, 0.3, 0.7]), n_values=rng.choice([2, 5]))
+        d = columns.pair_events(synth.register_events(seed=rng.randrange(10 ** 6), **shape)).as_dict()
+        ref = oracle.check(d, cas, "window", max_steps=5_000_000, want_witness=False)
+        if ref["valid"] == -1:
+            continue
+        n += 1
+        n_invalid += ref["valid"] == 0
+        for width, kw in ((1, dict(round_pairs=8, rules_at_any_round_size=True, branch_lists=True, look_two=True)), (4, {}), (2, dict(look_two=True))):
+            r = oracle.check_beam(d, cas, width, want_witness=False, list_order=1, max_probes=20_000_000, **kw)
+            if r["valid"] == -1:
+                continue
+            assert r["valid"] == ref["valid"], (it, width, shape)
+            if ref["valid"] == 0:
+                assert r["fail_op"] == ref["fail_op"], (it, width, shape)
+    assert n > 100 and n_invalid > 40
