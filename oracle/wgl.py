@@ -160,7 +160,7 @@ def rules_apply(ops, model, round_pairs=64):
 
 
 def check_beam(ops, model, width=16, max_probes=0, want_witness=True, round_pairs=64, widen_after=0, lookahead=None, eager_reads=None, twin_rule=None,
-               twin_selfcheck=False, rules_at_any_round_size=False, branch_lists=False, lazy_commuting=None, eager_txns=False, look_two=False, list_order=0):
+               twin_selfcheck=False, rules_at_any_round_size=False, branch_lists=False, lazy_commuting=None, eager_txns=False, look_two=False, list_order=0, lazy_look=False):
     """The wide (K configs per iteration) schedule of the same search: wgl_beam.c.
 
     lookahead: None = what the library does by default (on for register / cas-register under the
@@ -200,6 +200,8 @@ def check_beam(ops, model, width=16, max_probes=0, want_witness=True, round_pair
     lib().wgl_beam_set_look_two(C.c_uint32(1 if look_two else 0))
     # list_order: 0 = a front's open calls in process-slot order, 1 = in order of completion (csrc PackOpenArgs.list_order)
     lib().wgl_beam_set_list_order(C.c_uint32(list_order))
+    # lazy_look: DESIGN STUDY (no kernel counterpart): the lookahead at once only for the config that will be popped next (wgl_beam.c)
+    lib().wgl_beam_set_lazy_look(C.c_uint32(1 if lazy_look else 0))
     try:
         r = _check_beam(ops, model, width, max_probes, want_witness, round_pairs, widen_after, bool(lookahead))
         if twin_selfcheck:
@@ -216,6 +218,7 @@ def check_beam(ops, model, width=16, max_probes=0, want_witness=True, round_pair
         lib().wgl_beam_set_eager_txns(C.c_uint32(0))
         lib().wgl_beam_set_look_two(C.c_uint32(0))
         lib().wgl_beam_set_list_order(C.c_uint32(0))
+        lib().wgl_beam_set_lazy_look(C.c_uint32(0))
 
 
 def _check_beam(ops, model, width, max_probes, want_witness, round_pairs, widen_after, lookahead):

@@ -178,6 +178,14 @@ void wgl_beam_set_lookahead_depth(uint32_t d) { g_lookahead_depth = d; }
  * linearized" -- the rule then lets the config live without looking further.  Never a config declared dead that is not. */
 static uint32_t g_look_two = 0;
 void wgl_beam_set_look_two(uint32_t on) { g_look_two = on; }
+/* lazy_look (DESIGN STUDY, no kernel counterpart yet; one config per iteration only): the lookahead is run at once only for the new
+ * config of a round that will be popped next (the last one pushed); its siblings are pushed UNCHECKED and looked at if they are ever
+ * popped -- a dead one is set aside then.  Same verdicts, and in a nearly greedy search about half the lookahead runs.
+ * wgl_beam_look_runs(): lookahead evaluations of the last run. */
+static uint32_t g_lazy_look = 0;
+static _Thread_local uint64_t g_look_runs = 0;
+void wgl_beam_set_lazy_look(uint32_t on) { g_lazy_look = on; }
+uint64_t wgl_beam_look_runs(void) { return g_look_runs; }
 static uint32_t g_list_order = 0;
 void wgl_beam_set_list_order(uint32_t o) { g_list_order = o; }
 /* eager reads (experiment for the next round, register family): a read that is viable NOW can be linearized
@@ -407,6 +415,43 @@ int wgl_beam_check_rp(uint32_t n, const uint8_t* f, const int32_t* a, const int3
   stack[sp++] = arena_add(&ar, key, 0, 0xFFFFFFFFu);
   st->visited = 1; st->max_stack = 1;
 
+  uint8_t* unchecked = NULL; size_t unchecked_cap = 0;          /* lazy_look: configs pushed without their lookahead run, by arena id */
+  g_look_runs = 0;
+  /* the lookahead's verdict on a config (key words c2, front F, state s2): 1 = dead (GCC nested function: it reads the search's tables) */
+  int look_dead(const uint64_t* c2, uint32_t F, int32_t s2) {
+    int dead = 0;
+    g_look_runs++;
+    for (uint32_t j = 0; j < g_lookahead_depth && F + j < R && !dead; j++) {
+      const uint32_t t = F + j, fop = ret_op[t], pf = (uint32_t)process[fop];
+      if (!((f[fop] == O_READ && a[fop] != O_NIL) || f[fop] == O_CAS)) continue;
+      const int32_t v = a[fop];
+      if (v < 0 || v >= 32) continue;
+      if (inv_rank[fop] <= F && (c2[1 + (pf >> 6)] >> (pf & 63) & 1)) continue;   /* already linearized */
+      if (v == s2) continue;
+      int ok = 0;
+      if (g_look_two) {              /* three or more producers open at front t: the lean record says no more than that */
+        const uint32_t nl = coff[t + 1] - coff[t], tot = nl + ncr[t];
+        uint32_t np = 0;
+        for (uint32_t cc = 0; cc < tot; cc++) {
+          const uint32_t x = cc < nl ? clst[coff[t] + cc] : crashed[cc - nl];
+          if (x != fop && ((f[x] == O_WRITE && a[x] == v) || (f[x] == O_CAS && b[x] == v))) np++;
+        }
+        if (np >= 3) ok = 1;
+      }
+      for (uint32_t F2 = F; F2 <= t && !ok; F2++) {                /* calls open somewhere in [F, t] */
+        const uint32_t nl = coff[F2 + 1] - coff[F2], tot = nl + (F2 == t ? ncr[F2] : 0);
+        for (uint32_t cc = 0; cc < tot && !ok; cc++) {
+          const uint32_t x = cc < nl ? clst[coff[F2] + cc] : crashed[cc - nl];
+          const uint32_t px = (uint32_t)process[x];
+          if (x == fop) continue;
+          if (inv_rank[x] <= F && (c2[1 + (px >> 6)] >> (px & 63) & 1)) continue;   /* open at F, linearized */
+          if ((f[x] == O_WRITE && a[x] == v) || (f[x] == O_CAS && b[x] == v)) ok = 1;
+        }
+      }
+      if (!ok) dead = 1;
+    }
+    return dead;
+  }
   uint32_t par[64], pcnt[64], pstart[65];
   /* per-round scratch */
   uint64_t* ck = (uint64_t*)malloc((size_t)RP * KW * 8);
@@ -446,6 +491,17 @@ int wgl_beam_check_rp(uint32_t n, const uint8_t* f, const int32_t* a, const int3
     uint32_t np = sp < Kc ? (uint32_t)sp : Kc;
     for (uint32_t q = 0; q < np; q++) par[q] = stack[sp - np + q];      /* q = 0 is the bottom-most popped */
     sp -= np;
+    if (g_lazy_look && K == 1 && np == 1 && look_on && par[0] < unchecked_cap && unchecked[par[0]]) {
+      /* lazy_look: a sibling that was pushed unchecked is looked at now that it is wanted; dead -> set aside, the next one is popped */
+      unchecked[par[0]] = 0;
+      const uint64_t* pk0 = ar.keys + (size_t)par[0] * KW;
+      if (look_dead(pk0, (uint32_t)pk0[0] - 1, (int32_t)(pk0[0] >> 32))) {
+        g_pruned++;
+        if (dsp == dcap) { dcap *= 2; dstack = (uint32_t*)realloc(dstack, dcap * 4); }
+        dstack[dsp++] = par[0];
+        continue;
+      }
+    }
     st->iterations++; st->expanded += np;
     uint32_t T = 0;
     for (uint32_t q = 0; q < np; q++) {
@@ -563,38 +619,10 @@ int wgl_beam_check_rp(uint32_t n, const uint8_t* f, const int32_t* a, const int3
            * linearized before that completion: a call invoked after this front and before the completion,
            * or a call open at this front (crashed ones included) and not linearized.  No linearization goes
            * through a dead config, so it is set aside instead of pushed (see the top of the loop). */
-          const uint64_t* c2 = ck + (size_t)l * KW;
-          const uint32_t F = cfront[l]; const int32_t s2 = cstate[l];
-          int dead = 0;
-          for (uint32_t j = 0; j < g_lookahead_depth && F + j < R && !dead; j++) {
-            const uint32_t t = F + j, fop = ret_op[t], pf = (uint32_t)process[fop];
-            if (!((f[fop] == O_READ && a[fop] != O_NIL) || f[fop] == O_CAS)) continue;
-            const int32_t v = a[fop];
-            if (v < 0 || v >= 32) continue;
-            if (inv_rank[fop] <= F && (c2[1 + (pf >> 6)] >> (pf & 63) & 1)) continue;   /* already linearized */
-            if (v == s2) continue;
-            int ok = 0;
-            if (g_look_two) {              /* three or more producers open at front t: the lean record says no more than that */
-              const uint32_t nl = coff[t + 1] - coff[t], tot = nl + ncr[t];
-              uint32_t np = 0;
-              for (uint32_t cc = 0; cc < tot; cc++) {
-                const uint32_t x = cc < nl ? clst[coff[t] + cc] : crashed[cc - nl];
-                if (x != fop && ((f[x] == O_WRITE && a[x] == v) || (f[x] == O_CAS && b[x] == v))) np++;
-              }
-              if (np >= 3) ok = 1;
-            }
-            for (uint32_t F2 = F; F2 <= t && !ok; F2++) {                /* calls open somewhere in [F, t] */
-              const uint32_t nl = coff[F2 + 1] - coff[F2], tot = nl + (F2 == t ? ncr[F2] : 0);
-              for (uint32_t cc = 0; cc < tot && !ok; cc++) {
-                const uint32_t x = cc < nl ? clst[coff[F2] + cc] : crashed[cc - nl];
-                const uint32_t px = (uint32_t)process[x];
-                if (x == fop) continue;
-                if (inv_rank[x] <= F && (c2[1 + (px >> 6)] >> (px & 63) & 1)) continue;   /* open at F, linearized */
-                if ((f[x] == O_WRITE && a[x] == v) || (f[x] == O_CAS && b[x] == v)) ok = 1;
-              }
-            }
-            if (!ok) dead = 1;
-          }
+          const int last_new = !g_lazy_look || K != 1 || l + 1 == m || ({ int later = 0; for (uint32_t l2 = l + 1; l2 < m; l2++) later |= cviable[l2]; !later; });
+          if (!last_new) { if (id >= unchecked_cap) { const size_t nc = ((size_t)id + 1) * 2; unchecked = (uint8_t*)realloc(unchecked, nc); memset(unchecked + unchecked_cap, 0, nc - unchecked_cap); unchecked_cap = nc; }
+                           unchecked[id] = 1; if (sp == scap) { scap *= 2; stack = (uint32_t*)realloc(stack, scap * 4); } stack[sp++] = id; continue; }
+          const int dead = look_dead(ck + (size_t)l * KW, cfront[l], cstate[l]);
           if (dead) {
             g_pruned++;
             if (dsp == dcap) { dcap *= 2; dstack = (uint32_t*)realloc(dstack, dcap * 4); }
@@ -666,6 +694,6 @@ int wgl_beam_check_rp(uint32_t n, const uint8_t* f, const int32_t* a, const int3
   if (branch) { free(coff); free(clst); }
   free(rets); free(ret_rank); free(inv_rank); free(ret_op); free(off); free(ncr); free(lst); free(fill); free(crashed); free(prev_twin);
   free(open_ops); free(open_lin);
-  free(ar.keys); free(ar.parent); free(ar.op); free(ar.slots); free(stack); free(dstack); free(key); free(ck);
+  free(ar.keys); free(ar.parent); free(ar.op); free(ar.slots); free(stack); free(dstack); free(unchecked); free(key); free(ck);
   return 0;
 }

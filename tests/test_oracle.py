@@ -258,3 +258,35 @@ def test_list_order_and_the_lean_lookahead_never_change_a_verdict(native, oracle
             if ref["valid"] == 0:
                 assert r["fail_op"] == ref["fail_op"], (it, width, shape)
     assert n > 100 and n_invalid > 40
+
+
+def test_lazy_lookahead_is_the_same_schedule_with_half_the_lookahead_runs(native, oracle):
+    """DESIGN STUDY (oracle/wgl_beam.c, g_lazy_look; no kernel yet): the lookahead run at once only for the new config that will be popped
+    next, its siblings checked if they are ever popped.  Same verdicts and failing ops as the sequential restatement; on a bench-shaped
+    history the same probes, new configs and rounds as the eager lookahead, and about half as many lookahead runs in completion order."""
+    import ctypes as C
+    import random
+    cas = {"kind": 1, "init": N.NIL}
+    L = oracle.lib()
+    L.wgl_beam_look_runs.restype = C.c_uint64
+    kw = dict(round_pairs=8, rules_at_any_round_size=True, branch_lists=True, want_witness=False)
+    for h in synth.register_ops_many(range(500, 503), n_ops=10000, n_procs=64, busy=0.1, info=0.0):
+        d = h.as_dict()
+        eager = oracle.check_beam(d, cas, 1, list_order=1, **kw)
+        runs_eager = L.wgl_beam_look_runs()
+        lazy = oracle.check_beam(d, cas, 1, list_order=1, lazy_look=True, **kw)
+        runs_lazy = L.wgl_beam_look_runs()
+        assert (lazy["valid"], lazy["probes"], lazy["visited"], lazy["rounds"]) == (eager["valid"], eager["probes"], eager["visited"], eager["rounds"])
+        assert runs_lazy < 0.6 * runs_eager
+    rng = random.Random(2)
+    n_invalid = 0
+    for it in range(120):
+        d = columns.pair_events(synth.register_events(n_ops=rng.choice([10, 40, 120]), n_procs=rng.choice([2, 4, 8, 16]), seed=rng.randrange(10 ** 6),
+                                                      busy=rng.choice([0.3, 0.7, 1.0]), info=rng.choice([0, 0, 0.05]), corrupt=rng.choice([0, 0.3, 0.7]))).as_dict()
+        ref = oracle.check(d, cas, "window", max_steps=5_000_000, want_witness=False)
+        if ref["valid"] == -1:
+            continue
+        n_invalid += ref["valid"] == 0
+        r = oracle.check_beam(d, cas, 1, list_order=it & 1, lazy_look=True, **kw)
+        assert r["valid"] == ref["valid"] and (ref["valid"] == 1 or r["fail_op"] == ref["fail_op"]), it
+    assert n_invalid > 30
