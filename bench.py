@@ -381,7 +381,8 @@ def leg_single_history_forms(args, local_rank):
 BATCH_FORMS = [("pack_kernel + open_counts_kernel (the default)", {}),
                ("lists in order of completion", {"TBC_NARROW_ORDER": "1"}),
                ("lean tables: list entries {call, twin mask}, 8 B lookahead records", {"TBC_NARROW_LEAN": "1"}),
-               ("lean tables + lists in order of completion + pack by four wavefronts", {"TBC_NARROW_LEAN": "1", "TBC_NARROW_ORDER": "1", "TBC_PACK_WG": "2"}),
+               ("lean tables + lazy lookahead + lists in order of completion + pack by four wavefronts", {"TBC_NARROW_LEAN": "2", "TBC_NARROW_ORDER": "1", "TBC_PACK_WG": "2"}),
+               ("lean tables + lazy lookahead", {"TBC_NARROW_LEAN": "2"}),
                ("pack + open counts by four wavefronts per history, tables in LDS", {"TBC_PACK_WG": "2"}),
                # (4 lanes per history = 16 histories a wavefront: the oracle counts 30 % more rounds a history in completion order, 39 % in slot
                # order, for the same probes -- and half the wavefront iterations a history-round; emulator-tested, never run on the device)

@@ -533,7 +533,7 @@ int tbc_debug_peek(uint32_t* out, uint32_t n);
  *   TBC_SWEEP_WG_FP=1             (experimental) ... keeps 8 bits of a key's hash in its table word (a probe past another key reads no key)
  *   TBC_SWEEP_WG_COMPACT=1|2      (experimental) ... a wide sub-round numbers its children first and inserts 512 CHILDREN a pass (not with the ring);
  *                                 2 = and a pass that fits one wavefront is run by wavefront 0 alone
- *   TBC_NARROW_LEAN=1             (experimental) several histories per wavefront over lean tables: a list entry {call, twin mask} in one array,
+ *   TBC_NARROW_LEAN=1|2           (experimental; 2 = and the lookahead at once only for the config that is popped next) several histories per wavefront over lean tables: a list entry {call, twin mask} in one array,
  *                                 an 8 B lookahead record (two producer slots; three or more read as "one is still to be linearized")
  *   TBC_NARROW_ORDER=1            (experimental) ... with every front's list in order of completion: the call that completes soonest is tried
  *                                 first (fewer rounds for the same probes); only without a witness

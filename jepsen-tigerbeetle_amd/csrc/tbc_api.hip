@@ -304,11 +304,11 @@ struct tbc_batch {
   // (the walk with lane = front writes them), both rules and the lookahead on, no count form, no level sweep beside it, no round
   // budget (whose stragglers the wide kernel would take over).  Verified under the emulators only; nothing takes it unless asked
   uint32_t lean() const {
-    static const bool asked = [] { const char* e = std::getenv("TBC_NARROW_LEAN"); return e && e[0] == '1'; }();
+    static const int asked = [] { const char* e = std::getenv("TBC_NARROW_LEAN"); return (e && (e[0] == '1' || e[0] == '2')) ? e[0] - '0' : 0; }();      // 2: + kLeanLazy
     static const bool by_slots = [] { const char* e = std::getenv("TBC_OPEN_WALK"); return e && std::strcmp(e, "slots") == 0; }();
-    const bool ok = asked && !by_slots && lanes >= 4 && lanes < 64 && mask_words == 1 && front_words() == kFrontCompactWords &&
+    const bool ok = asked != 0 && !by_slots && lanes >= 4 && lanes < 64 && mask_words == 1 && front_words() == kFrontCompactWords &&
                     (rules & (kRuleEager | kRuleTwin | kRuleCount)) == (kRuleEager | kRuleTwin) && lookahead && !sweep && opts.round_budget == 0;
-    return ok ? (kLeanCands | kLeanLook) : 0u;
+    return ok ? (kLeanCands | kLeanLook | (asked == 2 ? kLeanLazy : 0u)) : 0u;
   }
   // TBC_NARROW_ORDER=1 (experimental; tbc_internal.h PackOpenArgs.list_order): the per-front lists of a batch of the wide schedule (several histories
   // per wavefront, or one) in order of COMPLETION instead of process slot -- the search then tries the call that completes soonest first: on
@@ -891,7 +891,7 @@ static PackOpenArgs make_pack_open_args(tbc_batch* B) {
   po.rk8 = B->lanes ? B->d_rk8.p : nullptr; po.front_words = B->front_words(); po.front_compact = B->front_words() == kFrontCompactWords ? 1u : 0u;
   po.twn = B->reg_rules() ? B->d_twn.p : nullptr; po.rdm = (B->reg_rules() || B->lanes) ? B->d_rdm.p : nullptr; po.vpad = B->vpad;
   po.cmem = B->count_form ? B->d_cmem.p : nullptr;
-  po.lean = B->lean();
+  po.lean = B->lean() & (kLeanCands | kLeanLook);          // (the formats; kLeanLazy is the search's alone)
   po.list_order = B->list_order();
   if (po.lean & kLeanCands) po.twn = nullptr;          // (the twin masks ride in the list entries)
   return po;

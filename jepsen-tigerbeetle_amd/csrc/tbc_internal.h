@@ -225,7 +225,12 @@ __host__ __device__ inline bool front_compact_ok(uint32_t n_dom, uint32_t mask_w
 //               such calls set `many`, which the rule reads as "one of them is still to be linearized" -- never a config declared dead
 //               that is not (a dead config is set aside, not dropped, so even that would cost time and no verdict); oracle/wgl_beam.c
 //               states the same reading (wgl_beam_set_look_two)
-constexpr uint32_t kLeanCands = 1u, kLeanLook = 2u;
+//   kLeanLazy   (a schedule detail, not a format; with the two above) the lookahead is run at once only for the new config of a round that
+//               will be popped next (the highest viable pair); its siblings go onto the stack UNCHECKED (bit 31 of their stack word)
+//               and are looked at if they are ever popped -- a dead one is set aside then.  The same probes, configs and rounds; half
+//               the lookahead runs of a nearly greedy search (oracle/wgl_beam.c, wgl_beam_set_lazy_look)
+constexpr uint32_t kLeanCands = 1u, kLeanLook = 2u, kLeanLazy = 4u;
+constexpr uint32_t kUnchecked = 0x80000000u;
 constexpr uint32_t kLean5None = 31u;
 __host__ __device__ inline uint64_t lean_call(uint32_t op, uint32_t f, bool at_front, uint32_t slot, int32_t a, int32_t b) {
   const uint64_t a6 = a == TBC_NIL ? 0ull : (uint64_t)((uint32_t)a + 1u) & 63ull, b6 = b == TBC_NIL ? 0ull : (uint64_t)((uint32_t)b + 1u) & 63ull;

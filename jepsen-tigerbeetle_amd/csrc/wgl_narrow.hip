@@ -27,13 +27,13 @@ __global__ __launch_bounds__(64 * kNarrowWaves, CNT ? 2 : TBC_NARROW_MIN_WAVES) 
 }
 // the lean tables (tbc_internal.h, kLeanCands | kLeanLook; experimental, TBC_NARROW_LEAN=1): a kernel of its own, so that the one above
 // stays instruction for instruction what was measured
-template <int L>
+template <int L, int LEAN = (int)(kLeanCands | kLeanLook)>
 __global__ __launch_bounds__(64 * kNarrowWaves, TBC_NARROW_MIN_WAVES) void wgl_narrow_lean_kernel(BeamArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wv_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const uint32_t w = blockIdx.x * kNarrowWaves + wv_;
-  narrow::narrow_wave<1, L, true, false, (int)(kLeanCands | kLeanLook)>(A, w, lds + wv_ * narrow::narrow_lds_words(1, L, true, false), lane);
+  narrow::narrow_wave<1, L, true, false, LEAN>(A, w, lds + wv_ * narrow::narrow_lds_words(1, L, true, false), lane);
 }
 
 // Wavefronts the GPU keeps resident at once: the launch is sized to that, not to the batch -- a wavefront's groups take more
@@ -75,13 +75,15 @@ void launch_lean(const BeamArgs& a_in, hipStream_t s, uint32_t wps) {
   BeamArgs a = a_in;
   a.first_dynamic = blocks * kNarrowWaves * H;
   (void)hipMemsetAsync(a.next_work, 0, sizeof(unsigned int), s);
-  hipLaunchKernelGGL((wgl_narrow_lean_kernel<L>), dim3(blocks), dim3(64 * kNarrowWaves), lds_wave * kNarrowWaves, s, a);
+  // (kLeanLazy: the lookahead at once only for the config popped next -- TBC_NARROW_LEAN=2)
+  if (a.lean & kLeanLazy) hipLaunchKernelGGL((wgl_narrow_lean_kernel<L, (int)(kLeanCands | kLeanLook | kLeanLazy)>), dim3(blocks), dim3(64 * kNarrowWaves), lds_wave * kNarrowWaves, s, a);
+  else hipLaunchKernelGGL((wgl_narrow_lean_kernel<L>), dim3(blocks), dim3(64 * kNarrowWaves), lds_wave * kNarrowWaves, s, a);
 }
 
 template <int MW, int L>
 void launch_one(const BeamArgs& a, hipStream_t s, uint32_t wps) {
   if constexpr (MW == 1) {
-    if (a.lean == (kLeanCands | kLeanLook) && a.front_words == kFrontCompactWords && !(a.rules & kRuleCount)) { launch_lean<L>(a, s, wps); return; }
+    if ((a.lean & (kLeanCands | kLeanLook)) == (kLeanCands | kLeanLook) && a.front_words == kFrontCompactWords && !(a.rules & kRuleCount)) { launch_lean<L>(a, s, wps); return; }
   }
   if constexpr (MW <= 2 && L >= 8) {
     if (a.rules & kRuleCount) {          // the count form (crashed calls as counts per class): one or two mask words, 8 / 16 / 32 lanes per history

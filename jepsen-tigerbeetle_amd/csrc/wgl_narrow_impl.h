@@ -32,7 +32,7 @@ namespace narrow {
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 
 // group flags
-enum : uint32_t { F_ACTIVE = 1u, F_NEED_POP = 2u, F_LOOK = 4u, F_NEED_GROW = 8u, F_CAND = 16u };
+enum : uint32_t { F_ACTIVE = 1u, F_NEED_POP = 2u, F_LOOK = 4u, F_NEED_GROW = 8u, F_CAND = 16u, F_CHECK = 32u };      // F_CHECK: the parent was pushed unchecked (kLeanLazy)
 
 // LDS words of a group: counters and results, then the ring of the most recent pushes
 enum : uint32_t {
@@ -108,7 +108,7 @@ WV_DEV int32_t reg_apply(int32_t st, uint32_t f, int32_t a, int32_t b) {
 // ---- cold path: group `gsel`'s history moves to a 4x larger visited set (and stacks) from the batch's growth pool, done
 // by the whole wavefront (as wgl_beam.hip's grow_visited_set).  In / out: the group's table, stack, second stack and
 // capacity, wave-uniform.  Slot numbers change: the caller empties the group's ring.
-template <int MW, bool CNT, class ColdArgs>
+template <int MW, bool CNT, class ColdArgs, bool LZ = false>
 WV_DEV bool grow_group(ColdArgs C, wv::gu64*& tab_u, wv::gu32*& stack_u, wv::gu32*& dstack_u, uint32_t& cap_log2_u,
                        uint32_t sp, uint32_t dsp, uint32_t lane, uint32_t etag, bool links) {
   constexpr uint32_t CWn = CNT ? kCountWords : 0u;        // count form: the count words ride behind the mask words (not hashed)
@@ -164,7 +164,11 @@ WV_DEV bool grow_group(ColdArgs C, wv::gu64*& tab_u, wv::gu32*& stack_u, wv::gu3
     wv::st64(npar + wv::ld32(remap + s), npw);
   }
   WV_NOUNROLL
-  for (uint32_t i = lane; i < sp; i += 64) wv::st32(nstack + i, wv::ld32(remap + wv::ld32(stack + i)));
+  for (uint32_t i = lane; i < sp; i += 64) {
+    const uint32_t x = wv::ld32(stack + i);
+    if constexpr (LZ) wv::st32(nstack + i, wv::ld32(remap + (x & ~kUnchecked)) | (x & kUnchecked));      // (an unchecked sibling keeps its mark)
+    else wv::st32(nstack + i, wv::ld32(remap + x));
+  }
   WV_NOUNROLL
   for (uint32_t i = lane; i < dsp; i += 64) wv::st32(ndstack + i, wv::ld32(remap + wv::ld32(dstack + i)));
   wv::threadfence();
@@ -181,7 +185,7 @@ template <int MW, int L, bool CF = false, bool CNT = false, int LEAN = 0>
 WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* lds, const uint32_t lane) {
   static_assert(!CF || MW == 1, "compact front records have one mask word");
   static_assert(LEAN == 0 || (CF && !CNT), "the lean formats: compact front records, no count form");
-  constexpr bool LC = (LEAN & (int)kLeanCands) != 0, LK = (LEAN & (int)kLeanLook) != 0;
+  constexpr bool LC = (LEAN & (int)kLeanCands) != 0, LK = (LEAN & (int)kLeanLook) != 0, LZ = (LEAN & (int)kLeanLazy) != 0;
   constexpr uint32_t WN = CF ? 1u : 4u;          // window words per config
   using wv::gu32;
   using wv::gu64;
@@ -485,7 +489,7 @@ WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* ld
         gu32* d_u = (gu32*)((uint64_t)GSg[G_DSTACK] | ((uint64_t)GSg[G_DSTACK + 1] << 32));
         uint32_t cap_u = wv::readlane(cap_log2, src);
         const uint32_t sp_u = wv::readlane(sp, src), dsp_u = wv::readlane(dsp, src);
-        const bool ok = grow_group<MW, CNT>(C, t_u, s_u, d_u, cap_u, sp_u, dsp_u, lane, etag, links);
+        const bool ok = grow_group<MW, CNT, decltype(C), LZ>(C, t_u, s_u, d_u, cap_u, sp_u, dsp_u, lane, etag, links);
         if (g == gg) {
           if (ok) {
             tab = t_u; stack = s_u; cap_log2 = cap_u;
@@ -522,16 +526,19 @@ WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* ld
       } else {
         const uint32_t pos = sp - 1u, rs = pos & (RS - 1u);
         uint64_t k0;
+        uint32_t raw_idx;
         if (r_pos[rs] == pos) {                  // pushed recently: config (and its front's list) still in the ring
           k0 = r_k0[rs];
           WV_UNROLL
           for (int j = 0; j < MW; j++) Mp[j] = r_M[rs * MW + j];
-          pslot = r_idx[rs]; poff = r_off[rs]; nlive = r_nlive[rs]; cnt = r_cnt[rs];
+          raw_idx = r_idx[rs];
+          pslot = LZ ? (raw_idx & ~kUnchecked) : raw_idx; poff = r_off[rs]; nlive = r_nlive[rs]; cnt = r_cnt[rs];
           p_ws0 = r_W[rs * WN];
           if constexpr (!CF) { p_ws1 = r_W[rs * 4 + 1]; p_wk0 = r_W[rs * 4 + 2]; p_wk1 = r_W[rs * 4 + 3]; }
           if constexpr (CNT) { Cp[0] = r_C[rs * 2]; Cp[1] = r_C[rs * 2 + 1]; }
         } else {
-          const uint32_t idx = wv::own_ld32(stack + pos);
+          raw_idx = wv::own_ld32(stack + pos);
+          const uint32_t idx = LZ ? (raw_idx & ~kUnchecked) : raw_idx;
           const gu64* e = tab + (uint64_t)idx * KW;
           k0 = wv::own_ld64(e);
           WV_UNROLL
@@ -550,15 +557,20 @@ WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* ld
         } else {
           sp = pos; base = 0u;
           if (cnt != 0u) flags &= ~F_NEED_POP;       // (only the root can have no candidate at all: the others are not pushed)
-          if (li == 0) wv::lds_add64(GS + G_EXPANDED, 1ull);
+          // kLeanLazy: a sibling pushed unchecked is looked at first -- this iteration runs its lookahead (and fetches its candidates) instead
+          // of a round; it counts as expanded only once it is known to live
+          const bool unchecked = LZ && (raw_idx & kUnchecked) != 0u && (flags & F_LOOK) != 0u;
+          if (unchecked) flags |= F_CHECK;
+          else if (li == 0) wv::lds_add64(GS + G_EXPANDED, 1ull);
         }
       }
     }
 
     // ---- a group whose candidates were not fetched ahead sits this round out and fetches them with the others' (below)
     const bool wants = (flags & (F_ACTIVE | F_NEED_POP | F_NEED_GROW)) == F_ACTIVE;
-    const bool inround = wants && (flags & F_CAND);
-    const bool fetch_now = wants && !(flags & F_CAND);
+    const bool chk = LZ && wants && (flags & F_CHECK) != 0u;           // its lookahead first: no round, its candidates fetched beside it
+    const bool inround = wants && (flags & F_CAND) && !chk;
+    const bool fetch_now = wants && (!(flags & F_CAND) || chk);
     if (fetch_now && li == 0) wv::stat(22, 1);
 
     // ---- the round: lane li takes pair base + li of the parent = its open call number cnt - 1 - (base + li)
@@ -678,10 +690,12 @@ WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* ld
     // ---- trip 1: the child's front's record -- the reads the eager rule takes there, where its open-call list is, and the
     // windows its own children will advance over: one line -- and, in the same trip, the lookahead records of every viable
     // child (8 lanes per child, one rank each, staged wave-wide: the fronts now, states and masks when the rows are in)
-    const bool lkme = go && (flags & F_LOOK);
+    // (kLeanLazy: only the child that will be popped next -- the group's highest viable pair -- and a parent under check, on the group's first lane)
+    const bool chk_lane = chk && li == 0u;
+    const bool lkme = (go && (flags & F_LOOK) && (!LZ || li == 31u - (uint32_t)__builtin_clz(gv | 1u))) || chk_lane;
     const uint64_t lk = wv::ballot(lkme);
     const uint32_t ci = (uint32_t)__builtin_popcountll(lk & ((1ull << lane) - 1ull)), nn0 = (uint32_t)__builtin_popcountll(lk);
-    if (lkme) { c_fi[ci] = fi2; c_lo[ci] = look_lo; if constexpr (CNT) c_rt[ci] = RT; }
+    if (lkme) { c_fi[ci] = chk_lane ? p_fi : fi2; c_lo[ci] = look_lo; if constexpr (CNT) c_rt[ci] = RT; }
     wv::barrier();
     const uint32_t f3 = go ? fi2 : 0u;
     const uint64_t* const fr = A.rdm + ((uint64_t)op_off + f3) * FW;
@@ -724,9 +738,9 @@ WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* ld
     // the candidates fetched below follow the highest child that is ALIVE
     bool dead = false;
     if (lkme) {
-      c_st[ci] = (uint32_t)st2;
+      c_st[ci] = (uint32_t)(chk_lane ? p_st : st2);
       WV_UNROLL
-      for (int j = 0; j < MW; j++) c_M[ci * MW + j] = M2[j];
+      for (int j = 0; j < MW; j++) c_M[ci * MW + j] = chk_lane ? Mp[j] : M2[j];
     }
     wv::barrier();
     // one batch of 8 children: lane (child cb + lane / 8, rank lane % 8) decides its rank; returns the lanes that found
@@ -788,6 +802,25 @@ WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* ld
         for (int w = 0; w < MW; w++) xpm[w] = LK ? 0ull : rec[1 + w];
         const uint64_t badx = look_batch(cb, xw0, xpm);
         if (lkme && ci >= cb && ci < cb + 8u) dead = ((badx >> (8u * (ci - cb))) & 0xFFull) != 0ull;
+      }
+    }
+
+    // kLeanLazy: a parent under check.  Dead: it is set aside (as a dead new config would have been) and the next entry is popped; alive: it
+    // counts as expanded now and runs its first round in the next iteration, over the candidates this iteration fetches.
+    bool chk_dead = false;
+    if constexpr (LZ) {
+      chk_dead = grp(wv::ballot(chk_lane && dead)) != 0u;
+      if (chk) {
+        if (chk_dead) {
+          if (li == 0u) {
+            gu32* const ds = (gu32*)((uint64_t)GS[G_DSTACK] | ((uint64_t)GS[G_DSTACK + 1] << 32));
+            wv::own_st32(ds + dsp, pslot);
+          }
+          dsp += 1u;
+          flags |= F_NEED_POP;
+        } else if (li == 0u) wv::lds_add64(GS + G_EXPANDED, 1ull);
+        flags &= ~F_CHECK;
+        dead = false;
       }
     }
 
@@ -930,9 +963,11 @@ WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* ld
     const uint32_t gnb = grp(wv::ballot(keep));
     if (keep) {
       const uint32_t pos = sp + (uint32_t)__builtin_popcount(gnb & below);
-      wv::own_st32(stack + pos, idx);
+      // (kLeanLazy: every kept config but the round's highest viable pair goes on unchecked -- its lookahead was not run)
+      const uint32_t word = (LZ && (flags & F_LOOK) && li != 31u - (uint32_t)__builtin_clz(gv | 1u)) ? (idx | kUnchecked) : idx;
+      wv::own_st32(stack + pos, word);
       const uint32_t rs = pos & (RS - 1u);          // at most L <= RS pushes a round: no clash
-      r_pos[rs] = pos; r_idx[rs] = idx; r_k0[rs] = k0c;
+      r_pos[rs] = pos; r_idx[rs] = word; r_k0[rs] = k0c;
       WV_UNROLL
       for (int j = 0; j < MW; j++) r_M[rs * MW + j] = M2[j];
       r_off[rs] = co0; r_nlive[rs] = cnl; r_cnt[rs] = ccnt;
@@ -947,7 +982,7 @@ WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* ld
       // were the candidates fetched above the next round's?  (the highest viable child is the next parent iff it was kept;
       // a group that sat out fetched the round it wanted; anybody else has none)
       // (to_below: every viable child was dead or barren -- none is pushed onto the stack -- unless a dead one... dead ones go aside)
-      const bool right = inround ? (cand_next && (more || (to_below && gnb == 0u) || (to_child && ((gnb >> hv) & 1u)))) : fetch_now;
+      const bool right = inround ? (cand_next && (more || (to_below && gnb == 0u) || (to_child && ((gnb >> hv) & 1u)))) : (fetch_now && !chk_dead);
       flags = right ? (flags | F_CAND) : (flags & ~F_CAND);
       if (inround && li == 0) {
         wv::stat(right ? 23 : 24, 1);

@@ -48,7 +48,8 @@ for it in range(rounds):
     if h.n_process <= 64:
         try:
             by_ret = bool(it & 2)                       # the fronts' lists in order of completion (only without a witness)
-            TN.compare([h], TN.CAS, rng.choice([8, 16, 32]), tag="fuzz", pool_words=8_000_000, lean=bool(it & 4) or not by_ret, entries_per_op=rng.choice([1, 4, 8]),
+            lean = (2 if it & 8 else 1) if (it & 4 or not by_ret) else False          # 2: + the lazy lookahead
+            TN.compare([h], TN.CAS, rng.choice([8, 16, 32]), tag="fuzz", pool_words=8_000_000, lean=lean, entries_per_op=rng.choice([1, 4, 8]),
                        want_witness=bool(it & 1) and not by_ret, epochs=rng.choice([0, 0, 2]), by_ret=by_ret)
         except Exception as e:
             a = e.args[0] if e.args else None

@@ -145,7 +145,7 @@ def run(hists, model_kind, init, L, rules=None, lookahead=True, entries_per_op=8
     rc = lib().emu_narrow_run(C.c_uint32(nh), _p(op_off, C.c_uint64), _p(npr, C.c_uint32), _p(f, C.c_uint8), _p(a, C.c_int32), _p(b, C.c_int32),
                               _p(pr, C.c_int32), _p(inv, C.c_uint32), _p(ret, C.c_uint32), C.c_uint32(model_kind), C.c_int32(init),
                               C.c_uint32(L), C.c_uint32(mw), C.c_uint32(r), C.c_uint32(vpad), C.c_uint32(1 if look else 0),
-                              C.c_uint32(entries_per_op), C.c_uint64(max_steps), C.c_uint64(pool_words), C.c_uint32(1 if want_witness else 0), C.c_uint32(max_waves), C.c_uint32((1 if compact else 0) | (2 if lean else 0) | (4 if by_ret else 0)), C.c_uint32(epochs), C.c_uint32(1 if count else 0), C.c_uint32(1 if relaxed else 0),
+                              C.c_uint32(entries_per_op), C.c_uint64(max_steps), C.c_uint64(pool_words), C.c_uint32(1 if want_witness else 0), C.c_uint32(max_waves), C.c_uint32((1 if compact else 0) | (2 if lean else 0) | (4 if by_ret else 0) | (8 if lean == 2 else 0)), C.c_uint32(epochs), C.c_uint32(1 if count else 0), C.c_uint32(1 if relaxed else 0),
                               _p(np.ascontiguousarray(targets, np.uint32), C.c_uint32) if targets is not None else None,
                               res, _p(wit, C.c_uint32), _p(cfg, C.c_uint64))
     if rc != 0:

@@ -31,7 +31,10 @@ void wave_entry_cnt(void* p, uint32_t lane) {
 template <int MW, int L>
 void wave_entry_lean(void* p, uint32_t lane) {
   auto* c = (WaveCall<MW, L>*)p;
-  if constexpr (MW == 1) narrow::narrow_wave<1, L, true, false, (int)(kLeanCands | kLeanLook)>(*c->A, c->wave, c->lds, lane);
+  if constexpr (MW == 1) {
+    if (c->A->lean & kLeanLazy) narrow::narrow_wave<1, L, true, false, (int)(kLeanCands | kLeanLook | kLeanLazy)>(*c->A, c->wave, c->lds, lane);
+    else narrow::narrow_wave<1, L, true, false, (int)(kLeanCands | kLeanLook)>(*c->A, c->wave, c->lds, lane);
+  }
 }
 template <int MW, int L>
 void run_all(BeamArgs& A, uint32_t max_waves) {
@@ -104,7 +107,7 @@ int emu_narrow_run(uint32_t nh, const uint64_t* op_off, const uint32_t* n_proces
   A.pool = pool_words ? pool.data() : nullptr; A.pool_cursor = &cursor; A.pool_words = pool_words; A.max_tab_log2 = 28;
   A.pool_vals = nullptr; A.cfg = cfg.data(); A.rules = rules; A.twn = (rules & kRuleTwin) ? T.twn.data() : nullptr;
   A.rdm = T.rdm.data(); A.vpad = vpad; A.rk8 = T.rk8.data(); A.front_words = compact ? kFrontCompactWords : front_stride(vpad, MW);
-  A.lean = lean;
+  A.lean = lean | ((lean && (want_compact & 8u)) ? kLeanLazy : 0u);          // want_compact bit 3: the lazy lookahead (TBC_NARROW_LEAN=2)
   if (lean) A.twn = nullptr;                    // (the twin masks ride in the list entries: the array does not exist)
 #define RUN(MWV, LV) if (MW == MWV && L == LV) { run_all<MWV, LV>(A, max_waves); ran = true; }
   bool ran = false;

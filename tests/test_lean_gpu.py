@@ -10,9 +10,10 @@ import pytest
 
 from jepsen_tigerbeetle_amd import _native as N, columns, core, synth
 
-LEAN = os.environ.get("TBC_NARROW_LEAN") == "1"
+LEAN = os.environ.get("TBC_NARROW_LEAN") in ("1", "2")
+LAZY = os.environ.get("TBC_NARROW_LEAN") == "2"        # + the lookahead at once only for the config popped next (the oracle's lazy_look)
 ORDER = os.environ.get("TBC_NARROW_ORDER") == "1"      # the fronts' lists in order of completion (PackOpenArgs.list_order): only without a witness
-pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not (LEAN or ORDER), reason="a process started with TBC_NARROW_LEAN=1 and / or TBC_NARROW_ORDER=1 only")]
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not (LEAN or ORDER), reason="a process started with TBC_NARROW_LEAN=1|2 and / or TBC_NARROW_ORDER=1 only")]
 
 CAS = {"kind": 1, "init": N.NIL}
 SHAPES = [(8, 3, 0.0, 0.0, 0.8), (40, 4, 0.0, 0.5, 0.5), (200, 8, 0.0, 0.0, 0.5), (200, 8, 0.0, 0.6, 0.3), (1000, 16, 0.0, 0.0, 0.5),
@@ -27,7 +28,8 @@ def _in_domain(n, p, s, busy, info, corrupt, n_values=5):
 
 def _expect(oracle, h, L, look_two=None, list_order=None, **kw):
     return oracle.check_beam(h.as_dict(), CAS, 1, round_pairs=L, rules_at_any_round_size=True, branch_lists=True,
-                             look_two=LEAN if look_two is None else look_two, list_order=(1 if ORDER else 0) if list_order is None else list_order, **kw)
+                             look_two=LEAN if look_two is None else look_two, list_order=(1 if ORDER else 0) if list_order is None else list_order,
+                             lazy_look=LAZY and look_two is None, **kw)
 
 
 @pytest.mark.parametrize("L", [8, 16])

@@ -67,7 +67,7 @@ def compare(hists, model, L, kind=1, tag="", **kw):
     for i, (d, g) in enumerate(zip(ds, got)):
         e = wgl.check_beam(d, model, 1, round_pairs=L, rules_at_any_round_size=True, lookahead=kw.get("lookahead", True),
                            eager_reads=bool(g["rules"] & 1), twin_rule=bool(g["rules"] & 2), max_probes=kw.get("max_steps", 0),
-                           branch_lists=bool(g["rules"] & 4), look_two=bool(kw.get("lean", False)), list_order=1 if kw.get("by_ret") else 0)
+                           branch_lists=bool(g["rules"] & 4), look_two=bool(kw.get("lean", False)), list_order=1 if kw.get("by_ret") else 0, lazy_look=kw.get("lean") == 2)
         t = (tag, i, L)
         assert g["valid"] == e["valid"], (t, g["valid"], e["valid"], g["cause"])
         for a_, b_ in (("probes", "probes"), ("visited", "visited"), ("backtracks", "expanded"), ("max_depth", "max_stack"), ("bucket_reads", "rounds")):
@@ -364,3 +364,24 @@ def test_lists_in_order_of_completion_need_fewer_rounds():
     got = compare(hists, CAS, 8, tag="by ret bench", entries_per_op=4, pool_words=1 << 24, want_witness=False, by_ret=True, lean=True)
     plain = [wgl.check_beam(h.as_dict(), CAS, 1, round_pairs=8, rules_at_any_round_size=True, branch_lists=True, want_witness=False) for h in hists]
     assert sum(g["bucket_reads"] for g in got) < 0.9 * sum(p["rounds"] for p in plain)
+
+
+# ---- the lazy lookahead (csrc kLeanLazy; TBC_NARROW_LEAN=2): the lookahead at once only for the config that will be popped next, its siblings
+# pushed unchecked and looked at if they are ever popped -- the oracle's lazy_look schedule, deepest stack included
+@pytest.mark.parametrize("L", [8, 16])
+def test_lazy_lookahead_every_counter(L):
+    hists = [_in_domain(n, p, s, busy, info, corrupt) for (n, p, info, corrupt, busy) in LEAN_SHAPES for s in range(3)]
+    hists = [h for h in hists if h.n_process <= 64]
+    compare(hists, CAS, L, tag="lazy", pool_words=4_000_000, lean=2)
+    compare(hists, CAS, L, tag="lazy by ret", pool_words=4_000_000, lean=2, by_ret=True, want_witness=False)
+
+
+def test_lazy_lookahead_growth_epochs_queue_and_the_bench_configuration():
+    hists = [_in_domain(1500, 16, s, 0.4, 0.0, 0.5 * (s % 2)) for s in range(12)]
+    compare(hists, CAS, 8, tag="lazy growth", entries_per_op=1, pool_words=6_000_000, lean=2, want_witness=False)
+    compare(hists, CAS, 8, tag="lazy epochs", epochs=3, pool_words=6_000_000, lean=2)
+    compare(hists, CAS, 8, tag="lazy queue", max_waves=1, pool_words=6_000_000, lean=2, by_ret=True, want_witness=False)
+    h = [columns.pair_events(synth.register_events(n_ops=300, n_procs=24, seed=s, busy=1.0, n_values=2)) for s in range(6)]      # many backtracks: unchecked siblings popped
+    compare(h, CAS, 8, tag="lazy busy", pool_words=8_000_000, lean=2)
+    bench = synth.register_ops_many(range(7000, 7006), n_ops=10000, n_procs=64, busy=0.1, info=0.0)
+    compare(bench, CAS, 8, tag="lazy bench", entries_per_op=4, pool_words=1 << 24, want_witness=False, lean=2, by_ret=True)
