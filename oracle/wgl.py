@@ -160,7 +160,7 @@ def rules_apply(ops, model, round_pairs=64):
 
 
 def check_beam(ops, model, width=16, max_probes=0, want_witness=True, round_pairs=64, widen_after=0, lookahead=None, eager_reads=None, twin_rule=None,
-               twin_selfcheck=False, rules_at_any_round_size=False, branch_lists=False, lazy_commuting=None, eager_txns=False, look_two=False, list_order=0, lazy_look=False):
+               twin_selfcheck=False, rules_at_any_round_size=False, branch_lists=False, lazy_commuting=None, eager_txns=False, look_two=False, list_order=0, lazy_look=False, defer=False):
     """The wide (K configs per iteration) schedule of the same search: wgl_beam.c.
 
     lookahead: None = what the library does by default (on for register / cas-register under the
@@ -202,6 +202,8 @@ def check_beam(ops, model, width=16, max_probes=0, want_witness=True, round_pair
     lib().wgl_beam_set_list_order(C.c_uint32(list_order))
     # lazy_look: DESIGN STUDY (no kernel counterpart): the lookahead at once only for the config that will be popped next (wgl_beam.c)
     lib().wgl_beam_set_lazy_look(C.c_uint32(1 if lazy_look else 0))
+    # defer: DESIGN STUDY: one child at a time -- a round's other viable pairs wait on the stack as (parent, pair) markers (wgl_beam.c)
+    lib().wgl_beam_set_defer(C.c_uint32(1 if defer else 0))
     try:
         r = _check_beam(ops, model, width, max_probes, want_witness, round_pairs, widen_after, bool(lookahead))
         if twin_selfcheck:
@@ -219,6 +221,7 @@ def check_beam(ops, model, width=16, max_probes=0, want_witness=True, round_pair
         lib().wgl_beam_set_look_two(C.c_uint32(0))
         lib().wgl_beam_set_list_order(C.c_uint32(0))
         lib().wgl_beam_set_lazy_look(C.c_uint32(0))
+        lib().wgl_beam_set_defer(C.c_uint32(0))
 
 
 def _check_beam(ops, model, width, max_probes, want_witness, round_pairs, widen_after, lookahead):

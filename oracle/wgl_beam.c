@@ -185,6 +185,13 @@ void wgl_beam_set_look_two(uint32_t on) { g_look_two = on; }
 static uint32_t g_lazy_look = 0;
 static _Thread_local uint64_t g_look_runs = 0;
 void wgl_beam_set_lazy_look(uint32_t on) { g_lazy_look = on; }
+/* defer (DESIGN STUDY, no kernel counterpart; one config per iteration only): ONE CHILD AT A TIME.  Of a round's viable pairs only the
+ * last one -- the child that is popped next -- is probed, inserted and pushed; the others go onto the stack as MARKERS (parent, pair)
+ * and become configs only if the search ever pops them (a one-pair round then).  The order of exploration is the eager schedule's;
+ * a sibling nobody comes back to costs no probe, no entry, no front record.  Success is still seen at once (a child is computed
+ * without memory). */
+static uint32_t g_defer = 0;
+void wgl_beam_set_defer(uint32_t on) { g_defer = on; }
 uint64_t wgl_beam_look_runs(void) { return g_look_runs; }
 static uint32_t g_list_order = 0;
 void wgl_beam_set_list_order(uint32_t o) { g_list_order = o; }
@@ -396,6 +403,9 @@ int wgl_beam_check_rp(uint32_t n, const uint8_t* f, const int32_t* a, const int3
   ar.slots = (uint32_t*)calloc(ar.nslots, 4);
   size_t scap = 1 << 16, sp = 0;
   uint32_t* stack = (uint32_t*)malloc(scap * 4);
+  uint16_t* spair = (uint16_t*)malloc(scap * 2);          /* defer: 0xFFFF = a config; else the stack word is a PARENT and this its pair number */
+  size_t spcap = scap;
+#define SPAIR_ROOM() do { if (spcap < scap) { spair = (uint16_t*)realloc(spair, scap * 2); spcap = scap; } } while (0)
   /* configs the lookahead found dead: set aside, expanded only if the search would otherwise end INVALID */
   size_t dcap = 1 << 12, dsp = 0;
   uint32_t* dstack = (uint32_t*)malloc(dcap * 4);
@@ -412,6 +422,7 @@ int wgl_beam_check_rp(uint32_t n, const uint8_t* f, const int32_t* a, const int3
     maxf = f0 < R ? f0 : R - 1;
     if (f0 == R) { root_wins = 1; verdict = 1; win_state = model->init; }
   }
+  spair[sp] = 0xFFFFu;
   stack[sp++] = arena_add(&ar, key, 0, 0xFFFFFFFFu);
   st->visited = 1; st->max_stack = 1;
 
@@ -455,7 +466,7 @@ int wgl_beam_check_rp(uint32_t n, const uint8_t* f, const int32_t* a, const int3
   uint32_t par[64], pcnt[64], pstart[65];
   /* per-round scratch */
   uint64_t* ck = (uint64_t*)malloc((size_t)RP * KW * 8);
-  uint32_t cop[1024], cpar[1024]; int cviable[1024]; uint32_t cfront[1024]; int32_t cstate[1024];
+  uint32_t cop[1024], cpar[1024]; int cviable[1024]; uint32_t cfront[1024]; int32_t cstate[1024]; uint16_t cpair[1024];
 
   uint64_t last_progress = 0; uint32_t seen_maxf = 0, stall_w = g_stall_width;
   while (verdict == -2) {
@@ -466,6 +477,8 @@ int wgl_beam_check_rp(uint32_t n, const uint8_t* f, const int32_t* a, const int3
        * exactly once overall -- failing op, configs, visited / probes / expanded are the plain search's */
       { uint32_t* t = stack; stack = dstack; dstack = t; size_t c = scap; scap = dcap; dcap = c; }
       sp = dsp; dsp = 0; look_on = 0;
+      SPAIR_ROOM();
+      for (size_t i = 0; i < sp; i++) spair[i] = 0xFFFFu;
     }
     if (g_stall_rounds && g_stall_mode < 2) {
       if (maxf > seen_maxf) { seen_maxf = maxf; last_progress = st->rounds; stall_w = g_stall_width; }
@@ -490,6 +503,8 @@ int wgl_beam_check_rp(uint32_t n, const uint8_t* f, const int32_t* a, const int3
     const uint32_t Kc = (g_widen_after && st->rounds > g_widen_after && Ks < 16) ? 16 : Ks;
     uint32_t np = sp < Kc ? (uint32_t)sp : Kc;
     for (uint32_t q = 0; q < np; q++) par[q] = stack[sp - np + q];      /* q = 0 is the bottom-most popped */
+    const int single = g_defer && K == 1 && np == 1 && spair[sp - 1] != 0xFFFFu;      /* a marker: its parent, one pair */
+    const uint32_t single_c = single ? spair[sp - 1] : 0;
     sp -= np;
     if (g_lazy_look && K == 1 && np == 1 && look_on && par[0] < unchecked_cap && unchecked[par[0]]) {
       /* lazy_look: a sibling that was pushed unchecked is looked at now that it is wanted; dead -> set aside, the next one is popped */
@@ -502,7 +517,7 @@ int wgl_beam_check_rp(uint32_t n, const uint8_t* f, const int32_t* a, const int3
         continue;
       }
     }
-    st->iterations++; st->expanded += np;
+    st->iterations++; if (!single) st->expanded += np;
     uint32_t T = 0;
     for (uint32_t q = 0; q < np; q++) {
       uint32_t fi = (uint32_t)ar.keys[(size_t)par[q] * KW] - 1;
@@ -510,6 +525,7 @@ int wgl_beam_check_rp(uint32_t n, const uint8_t* f, const int32_t* a, const int3
       pstart[q] = T; T += pcnt[q];
     }
     pstart[np] = T;
+    if (single) T = 1;                   /* (pcnt stays the parent's: the twin rule looks at all of its open calls) */
     for (uint32_t base = 0; base < T && verdict == -2; base += RP) {
       uint32_t m = T - base < RP ? T - base : RP;
       int success = -1;
@@ -519,7 +535,8 @@ int wgl_beam_check_rp(uint32_t n, const uint8_t* f, const int32_t* a, const int3
         const uint64_t* pk = ar.keys + (size_t)par[q] * KW;
         uint32_t fi = (uint32_t)pk[0] - 1; int32_t s = (int32_t)(pk[0] >> 32);
         uint32_t nlive = coff[fi + 1] - coff[fi];
-        uint32_t c = pcnt[q] - 1 - (r - pstart[q]);
+        uint32_t c = single ? single_c : pcnt[q] - 1 - (r - pstart[q]);
+        cpair[l] = (uint16_t)c;
         uint32_t op = c < nlive ? clst[coff[fi] + c] : crashed[c - nlive];
         uint32_t p = (uint32_t)process[op];
         cviable[l] = 0; cop[l] = op; cpar[l] = par[q];
@@ -604,6 +621,16 @@ int wgl_beam_check_rp(uint32_t n, const uint8_t* f, const int32_t* a, const int3
       if (success >= 0) { verdict = 1; win_parent = cpar[success]; win_op = cop[success]; win_state = cstate[success]; break; }
       for (uint32_t l = 0; l < m; l++) {
         if (!cviable[l]) continue;
+        if (g_defer && K == 1 && !single) {          /* all but the last viable pair of the round: a marker, nothing else */
+          int later = 0;
+          for (uint32_t l2 = l + 1; l2 < m; l2++) later |= cviable[l2];
+          if (later) {
+            if (sp == scap) { scap *= 2; stack = (uint32_t*)realloc(stack, scap * 4); }
+            SPAIR_ROOM();
+            spair[sp] = cpair[l]; stack[sp++] = cpar[l];
+            continue;
+          }
+        }
         st->probes++;
         uint32_t id = arena_add(&ar, ck + (size_t)l * KW, cpar[l], cop[l]);
         if (!id) continue;
@@ -621,7 +648,7 @@ int wgl_beam_check_rp(uint32_t n, const uint8_t* f, const int32_t* a, const int3
            * through a dead config, so it is set aside instead of pushed (see the top of the loop). */
           const int last_new = !g_lazy_look || K != 1 || l + 1 == m || ({ int later = 0; for (uint32_t l2 = l + 1; l2 < m; l2++) later |= cviable[l2]; !later; });
           if (!last_new) { if (id >= unchecked_cap) { const size_t nc = ((size_t)id + 1) * 2; unchecked = (uint8_t*)realloc(unchecked, nc); memset(unchecked + unchecked_cap, 0, nc - unchecked_cap); unchecked_cap = nc; }
-                           unchecked[id] = 1; if (sp == scap) { scap *= 2; stack = (uint32_t*)realloc(stack, scap * 4); } stack[sp++] = id; continue; }
+                           unchecked[id] = 1; if (sp == scap) { scap *= 2; stack = (uint32_t*)realloc(stack, scap * 4); } SPAIR_ROOM(); spair[sp] = 0xFFFFu; stack[sp++] = id; continue; }
           const int dead = look_dead(ck + (size_t)l * KW, cfront[l], cstate[l]);
           if (dead) {
             g_pruned++;
@@ -631,6 +658,8 @@ int wgl_beam_check_rp(uint32_t n, const uint8_t* f, const int32_t* a, const int3
           }
         }
         if (sp == scap) { scap *= 2; stack = (uint32_t*)realloc(stack, scap * 4); }
+        SPAIR_ROOM();
+        spair[sp] = 0xFFFFu;
         stack[sp++] = id;
       }
       if (max_probes && st->probes > max_probes) { verdict = -1; break; }
@@ -694,6 +723,6 @@ int wgl_beam_check_rp(uint32_t n, const uint8_t* f, const int32_t* a, const int3
   if (branch) { free(coff); free(clst); }
   free(rets); free(ret_rank); free(inv_rank); free(ret_op); free(off); free(ncr); free(lst); free(fill); free(crashed); free(prev_twin);
   free(open_ops); free(open_lin);
-  free(ar.keys); free(ar.parent); free(ar.op); free(ar.slots); free(stack); free(dstack); free(unchecked); free(key); free(ck);
+  free(ar.keys); free(ar.parent); free(ar.op); free(ar.slots); free(stack); free(dstack); free(unchecked); free(spair); free(key); free(ck);
   return 0;
 }

@@ -289,4 +289,6 @@ def test_lazy_lookahead_is_the_same_schedule_with_half_the_lookahead_runs(native
         n_invalid += ref["valid"] == 0
         r = oracle.check_beam(d, cas, 1, list_order=it & 1, lazy_look=True, **kw)
         assert r["valid"] == ref["valid"] and (ref["valid"] == 1 or r["fail_op"] == ref["fail_op"]), it
+        r = oracle.check_beam(d, cas, 1, list_order=it & 1, defer=True, **kw)          # (one child at a time: another study knob, measured and not built)
+        assert r["valid"] == ref["valid"] and (ref["valid"] == 1 or r["fail_op"] == ref["fail_op"]), it
     assert n_invalid > 30
