@@ -391,6 +391,9 @@ BATCH_FORMS = [("pack_kernel + open_counts_kernel (the default)", {}),
                # (a wavefront per history at 19 calls in flight -- workload 3's kernel -- in both list orders; compared with each other only)
                ("19 calls in flight, a wavefront per history", {"TBC_BENCH_FORM_BUSY": "0.3"}),
                ("19 calls in flight, a wavefront per history, lists in order of completion", {"TBC_BENCH_FORM_BUSY": "0.3", "TBC_NARROW_ORDER": "1"}),
+               # (round 4 measured 16 lanes per history LOSING to a wavefront per history there, 4.06 s against 1.83 s per 8,192; in completion order
+               # the oracle counts 27.9k rounds a history for it, four histories a wavefront, against the wide schedule's 16.9k for one)
+               ("19 calls in flight, 16 lanes per history, lists in order of completion", {"TBC_BENCH_FORM_BUSY": "0.3", "TBC_BENCH_FORM_LANES": "16", "TBC_NARROW_ORDER": "1"}),
                ("4 lanes per history", {"TBC_BENCH_FORM_LANES": "4"}),
                # (32 in flight: a pass is its slowest history -- on oracle samples of 16-32 histories the order moves the tail by 0.7x .. 7x either way)
                ("32 calls in flight, a wavefront per history", {"TBC_BENCH_FORM_BUSY": "0.5"}),
@@ -409,7 +412,7 @@ def leg_one_batch_form(args, local_rank):
         B = 1024 if heavy else 2048
         hs = synth.register_ops_many(range(6_000_000, 6_000_000 + B), n_ops=args.ops, n_procs=args.procs, busy=float(busy_form), info=0.0)
         o = core.make_opts(device=local_rank, time_limit_ms=600000, want_witness=False, algorithm=N.ALG_COMPETITION, search_width=args.width,
-                           visited_per_op=256 if heavy else 32)
+                           visited_per_op=256 if heavy else 32, lanes_per_history=int(os.environ.get("TBC_BENCH_FORM_LANES", "0")))
         best = None
         with core.Batch(hs, model, o) as b:
             lanes = b.lanes_per_history()
