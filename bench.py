@@ -379,14 +379,13 @@ def leg_single_history_forms(args, local_rank):
 # ---- extra.batch_forms: ONE resident batch of the headline workload (a quarter of its size) under the switchable forms of the batch
 # path, each in a process of its own (the switches are read once per process), never fatal -- as extra.single_history_forms.
 BATCH_FORMS = [("pack_kernel + open_counts_kernel (the default)", {}),
-               ("lists in order of completion", {"TBC_NARROW_ORDER": "1"}),
-               ("lean tables: list entries {call, twin mask}, 8 B lookahead records", {"TBC_NARROW_LEAN": "1"}),
                ("lean tables + lazy lookahead + lists in order of completion + pack by four wavefronts", {"TBC_NARROW_LEAN": "2", "TBC_NARROW_ORDER": "1", "TBC_PACK_WG": "2"}),
+               ("lists in order of completion", {"TBC_NARROW_ORDER": "1"}),
                ("lean tables + lazy lookahead", {"TBC_NARROW_LEAN": "2"}),
                ("pack + open counts by four wavefronts per history, tables in LDS", {"TBC_PACK_WG": "2"}),
+               ("lean tables: list entries {call, twin mask}, 8 B lookahead records", {"TBC_NARROW_LEAN": "1"}),
                # (4 lanes per history = 16 histories a wavefront: the oracle counts 30 % more rounds a history in completion order, 39 % in slot
                # order, for the same probes -- and half the wavefront iterations a history-round; emulator-tested, never run on the device)
-               ("4 lanes per history, lists in order of completion", {"TBC_BENCH_FORM_LANES": "4", "TBC_NARROW_ORDER": "1"}),
                ("4 lanes per history, lists in order of completion, lean tables", {"TBC_BENCH_FORM_LANES": "4", "TBC_NARROW_ORDER": "1", "TBC_NARROW_LEAN": "1"}),
                # (a wavefront per history at 19 calls in flight -- workload 3's kernel -- in both list orders; compared with each other only)
                ("19 calls in flight, a wavefront per history", {"TBC_BENCH_FORM_BUSY": "0.3"}),
@@ -394,6 +393,7 @@ BATCH_FORMS = [("pack_kernel + open_counts_kernel (the default)", {}),
                # (round 4 measured 16 lanes per history LOSING to a wavefront per history there, 4.06 s against 1.83 s per 8,192; in completion order
                # the oracle counts 27.9k rounds a history for it, four histories a wavefront, against the wide schedule's 16.9k for one)
                ("19 calls in flight, 16 lanes per history, lists in order of completion", {"TBC_BENCH_FORM_BUSY": "0.3", "TBC_BENCH_FORM_LANES": "16", "TBC_NARROW_ORDER": "1"}),
+               ("4 lanes per history, lists in order of completion", {"TBC_BENCH_FORM_LANES": "4", "TBC_NARROW_ORDER": "1"}),
                ("4 lanes per history", {"TBC_BENCH_FORM_LANES": "4"}),
                # (32 in flight: a pass is its slowest history -- on oracle samples of 16-32 histories the order moves the tail by 0.7x .. 7x either way)
                ("32 calls in flight, a wavefront per history", {"TBC_BENCH_FORM_BUSY": "0.5"}),
