@@ -15,6 +15,7 @@
 #include <thread>
 #include <vector>
 #include "tbc_internal.h"
+#include "witness_expand.h"
 
 using namespace tbc;
 
@@ -313,13 +314,13 @@ struct tbc_batch {
   // TBC_NARROW_ORDER=1 (experimental; tbc_internal.h PackOpenArgs.list_order): the per-front lists of a batch of the wide schedule (several histories
   // per wavefront, or one) in order of COMPLETION instead of process slot -- the search then tries the call that completes soonest first: on
   // the bench workload 18 % fewer rounds for the same probes, the longest history 31 % fewer (oracle counts).  Where
-  // nothing depends on slot order: the walk with lane = front, no witness (its absorbed reads are replayed in slot order), no level
+  // nothing depends on slot order: the walk with lane = front (a witness's absorbed reads are replayed in the same order: expand_eager_witness), no level
   // sweep beside it (origins are numbered by list position), no count form, no round budget.  Emulator-verified only; off unless asked
   uint32_t list_order() const {
     static const bool asked = [] { const char* e = std::getenv("TBC_NARROW_ORDER"); return e && e[0] == '1'; }();
     static const bool by_slots = [] { const char* e = std::getenv("TBC_OPEN_WALK"); return e && std::strcmp(e, "slots") == 0; }();
     // (a wavefront per history too -- the wide kernel takes its pairs from the same lists: at 19 calls in flight 28 % fewer probes, 41 % fewer rounds)
-    return (asked && !by_slots && width > 1 && mask_words == 1 && vpad <= 32 && !(rules & kRuleCount) && !sweep && !opts.want_witness &&
+    return (asked && !by_slots && width > 1 && mask_words == 1 && vpad <= 32 && !(rules & kRuleCount) && !sweep &&
             opts.round_budget == 0 && (model.kind == TBC_MODEL_REGISTER || model.kind == TBC_MODEL_CAS_REGISTER)) ? 1u : 0u;
   }
   std::vector<BeamHist> bh;
@@ -1064,49 +1065,13 @@ static tbc_status expand_eager_witness(tbc_batch* B, uint32_t h, uint32_t* wit, 
   HIP_TRY(hipMemcpy(proc.data(), B->d_proc.p + H.op_off, (size_t)n * 4, hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(inv.data(), B->d_inv.p + H.op_off, (size_t)n * 4, hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(ret.data(), B->d_ret.p + H.op_off, (size_t)n * 4, hipMemcpyDeviceToHost));
-  std::vector<uint32_t> by_ret;                      // completed calls in completion order
-  for (uint32_t i = 0; i < n; i++) if (ret[i] != TBC_POS_CRASHED) by_ret.push_back(i);
-  std::sort(by_ret.begin(), by_ret.end(), [&](uint32_t x, uint32_t y) { return ret[x] < ret[y]; });
-  const uint32_t R = (uint32_t)by_ret.size();
-  std::vector<uint32_t> opens_at(n);                 // number of completions before the call's invocation
-  { uint32_t r = 0; for (uint32_t i = 0; i < n; i++) { while (r < R && ret[by_ret[r]] < inv[i]) r++; opens_at[i] = r; } }
-  std::vector<uint8_t> done(n, 0);
-  std::vector<int64_t> open_by_slot(std::max(1u, H.n_slots), -1);   // live call open on each process slot at the front
-  std::vector<uint32_t> chain(wit, wit + *len), out;
-  out.reserve(n);
-  uint32_t front = 0, next_inv = 0;
-  int32_t state = B->model.init;
-  auto open_calls = [&]() {
-    while (next_inv < n && opens_at[next_inv] <= front) {
-      if (ret[next_inv] != TBC_POS_CRASHED) open_by_slot[(uint32_t)proc[next_inv]] = next_inv;
-      next_inv++;
-    }
-  };
-  auto advance = [&]() -> bool {
-    bool moved = false;
-    while (front < R && done[by_ret[front]]) { open_by_slot[(uint32_t)proc[by_ret[front]]] = -1; front++; moved = true; open_calls(); }
-    return moved;
-  };
-  open_calls();
-  if (B->rules & kRuleBranch) {      // the root itself starts in normal form: its reads come first
-    for (bool again = true; again && front < R;) {
-      for (int64_t x : open_by_slot)
-        if (x >= 0 && !done[x] && f[x] == TBC_F_READ && (a[x] == TBC_NIL || a[x] == state)) { done[x] = 1; out.push_back((uint32_t)x); }
-      again = advance();
-    }
+  // (the replay itself is plain host code: witness_expand.h -- tests/test_narrow_emu.py runs the same function on the emulator's chains)
+  std::vector<uint32_t> out;
+  if (!expand_eager_chain(n, f.data(), a.data(), b.data(), proc.data(), inv.data(), ret.data(), H.n_slots, B->model.init,
+                          (B->rules & kRuleBranch) != 0u, B->list_order() != 0u, wit, *len, out)) {
+    set_error("history %u: malformed witness chain", h);
+    return TBC_ERR_HIP;
   }
-  for (uint32_t op : chain) {
-    if (op >= n || done[op]) { set_error("history %u: malformed witness chain", h); return TBC_ERR_HIP; }
-    state = f[op] == TBC_F_WRITE ? a[op] : (f[op] == TBC_F_CAS ? b[op] : state);
-    done[op] = 1; out.push_back(op);
-    advance();
-    for (bool again = true; again && front < R;) {
-      for (int64_t x : open_by_slot)
-        if (x >= 0 && !done[x] && f[x] == TBC_F_READ && (a[x] == TBC_NIL || a[x] == state)) { done[x] = 1; out.push_back((uint32_t)x); }
-      again = advance();
-    }
-  }
-  if (out.size() > n) { set_error("history %u: witness longer than the history", h); return TBC_ERR_HIP; }
   std::copy(out.begin(), out.end(), wit);
   *len = (uint32_t)out.size();
   return TBC_OK;

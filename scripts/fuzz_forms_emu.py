@@ -47,10 +47,10 @@ for it in range(rounds):
     # ---- the lean tables
     if h.n_process <= 64:
         try:
-            by_ret = bool(it & 2)                       # the fronts' lists in order of completion (only without a witness)
+            by_ret = bool(it & 2)                       # the fronts' lists in order of completion (a witness's absorbed reads in that order too)
             lean = (2 if it & 8 else 1) if (it & 4 or not by_ret) else False          # 2: + the lazy lookahead
             TN.compare([h], TN.CAS, rng.choice([8, 16, 32]), tag="fuzz", pool_words=8_000_000, lean=lean, entries_per_op=rng.choice([1, 4, 8]),
-                       want_witness=bool(it & 1) and not by_ret, epochs=rng.choice([0, 0, 2]), by_ret=by_ret)
+                       want_witness=bool(it & 1), epochs=rng.choice([0, 0, 2]), by_ret=by_ret)
         except Exception as e:
             a = e.args[0] if e.args else None
             if isinstance(a, tuple) and len(a) == 4 and a[1] == -1 and a[3] == 3:

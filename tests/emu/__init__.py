@@ -29,7 +29,8 @@ class DevResult(C.Structure):
 
 def build(force=False):
     srcs = [os.path.join(_HERE, "emu_narrow.cpp"), os.path.join(_HERE, "wave_env_emu.h"), os.path.join(_HERE, "host_tables.h"),
-            os.path.join(_CSRC, "wgl_narrow_impl.h"), os.path.join(_CSRC, "tbc_internal.h"), os.path.join(_CSRC, "wave_env.h")]
+            os.path.join(_CSRC, "wgl_narrow_impl.h"), os.path.join(_CSRC, "tbc_internal.h"), os.path.join(_CSRC, "wave_env.h"),
+            os.path.join(_CSRC, "witness_expand.h")]
     if force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs):
         os.makedirs(os.path.dirname(_SO), exist_ok=True)
         subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas"]
@@ -87,6 +88,21 @@ def lib():
         _LIB = C.CDLL(build())
         _LIB.emu_narrow_run.restype = C.c_int
     return _LIB
+
+
+def expand_witness(d, chain, init, branch, by_completion=False):
+    """The product's host-side replay of a chain of branching calls into the whole witness (csrc/witness_expand.h)."""
+    f = np.ascontiguousarray(d["f"], np.uint8); a = np.ascontiguousarray(d["a"], np.int32); b = np.ascontiguousarray(d["b"], np.int32)
+    proc = np.ascontiguousarray(d["process"], np.int32)
+    inv = np.ascontiguousarray(d["inv_pos"], np.uint32); ret = np.ascontiguousarray(d["ret_pos"], np.uint32)
+    ch = np.ascontiguousarray(chain, np.uint32)
+    out = np.zeros(len(f) + 1, np.uint32)
+    fn = lib().emu_expand_witness
+    fn.restype = C.c_int64
+    n = fn(C.c_uint32(len(f)), _p(f, C.c_uint8), _p(a, C.c_int32), _p(b, C.c_int32), _p(proc, C.c_int32), _p(inv, C.c_uint32), _p(ret, C.c_uint32),
+           C.c_uint32(int(proc.max()) + 1 if len(proc) else 1), C.c_int32(init), C.c_uint32(bool(branch)), C.c_uint32(bool(by_completion)),
+           _p(ch, C.c_uint32), C.c_uint32(len(ch)), _p(out, C.c_uint32))
+    return None if n < 0 else [int(x) for x in out[:n]]
 
 
 def _p(a, ct):

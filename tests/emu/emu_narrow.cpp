@@ -9,6 +9,7 @@
 #define __HIPCC__ 1          // tbc_internal.h's look_val / look_need / look_prod / rec_cls helpers
 #include "wave_env_emu.h"
 #include "../../jepsen-tigerbeetle_amd/csrc/wgl_narrow_impl.h"
+#include "../../jepsen-tigerbeetle_amd/csrc/witness_expand.h"
 
 using namespace tbc;
 
@@ -66,6 +67,17 @@ void run_all(BeamArgs& A, uint32_t max_waves) {
 }  // namespace
 
 extern "C" {
+
+// the product's own replay of a chain of branching calls into the whole witness (csrc/witness_expand.h, what tbc_api.hip's
+// expand_eager_witness runs on the columns it copies back); returns the witness's length, -1 for a chain it refuses
+int64_t emu_expand_witness(uint32_t n, const uint8_t* f, const int32_t* a, const int32_t* b, const int32_t* slot, const uint32_t* inv_pos,
+                           const uint32_t* ret_pos, uint32_t n_slots, int32_t init, uint32_t branch, uint32_t by_completion,
+                           const uint32_t* chain, uint32_t chain_len, uint32_t* out) {
+  std::vector<uint32_t> w;
+  if (!tbc::expand_eager_chain(n, f, a, b, slot, inv_pos, ret_pos, n_slots, init, branch != 0, by_completion != 0, chain, chain_len, w)) return -1;
+  std::copy(w.begin(), w.end(), out);
+  return (int64_t)w.size();
+}
 
 void emu_stats(uint64_t* out, int reset) { for (int i = 0; i < 64; i++) { out[i] = wv::stats()[i]; if (reset) wv::stats()[i] = 0; } }
 

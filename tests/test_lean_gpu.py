@@ -12,7 +12,7 @@ from jepsen_tigerbeetle_amd import _native as N, columns, core, synth
 
 LEAN = os.environ.get("TBC_NARROW_LEAN") in ("1", "2")
 LAZY = os.environ.get("TBC_NARROW_LEAN") == "2"        # + the lookahead at once only for the config popped next (the oracle's lazy_look)
-ORDER = os.environ.get("TBC_NARROW_ORDER") == "1"      # the fronts' lists in order of completion (PackOpenArgs.list_order): only without a witness
+ORDER = os.environ.get("TBC_NARROW_ORDER") == "1"      # the fronts' lists in order of completion (PackOpenArgs.list_order); a witness replays its absorbed reads in that order
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not (LEAN or ORDER), reason="a process started with TBC_NARROW_LEAN=1|2 and / or TBC_NARROW_ORDER=1 only")]
 
 CAS = {"kind": 1, "init": N.NIL}
@@ -38,11 +38,11 @@ def test_lean_tables_match_the_oracles_look_two_schedule(native, oracle, L):
     hists += [columns.pair_events(synth.register_events(n_ops=300, n_procs=24, seed=s, busy=1.0, n_values=2)) for s in range(6)]
     hists = [h for h in hists if h.n_process <= 64]
     model = core.make_model(N.MODEL_CAS_REGISTER, N.NIL)
-    # (enough histories that the library does not add the level sweep beside the search; no witness under ORDER: the library takes the
-    # completion order only then)
+    # (enough histories that the library does not add the level sweep beside the search; a witness every time: under ORDER the library
+    # replays the absorbed reads in completion order, as the oracle's list_order does)
     n1 = len(hists)
     hists = hists * 10
-    with core.Batch(hists, model, core.make_opts(time_limit_ms=60000, algorithm=N.ALG_COMPETITION, lanes_per_history=L, want_witness=not ORDER)) as b:
+    with core.Batch(hists, model, core.make_opts(time_limit_ms=60000, algorithm=N.ALG_COMPETITION, lanes_per_history=L, want_witness=True)) as b:
         assert b.lanes_per_history() == L
         res = b.run().results()
         again = b.run().results()
@@ -50,7 +50,7 @@ def test_lean_tables_match_the_oracles_look_two_schedule(native, oracle, L):
     for i, (h, got) in enumerate(zip(hists, res)):
         if i >= n1 and i % 7:
             continue
-        exp = _expect(oracle, h, L, want_witness=not ORDER)
+        exp = _expect(oracle, h, L, want_witness=True)
         assert got["valid"] == exp["valid"], (i, got["valid"], exp["valid"], got["cause"])
         assert (got["probes"], got["visited"], got["backtracks"], got["max_depth"]) == (exp["probes"], exp["visited"], exp["expanded"], exp["max_stack"]), i
         if exp["valid"] == 0:

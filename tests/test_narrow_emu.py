@@ -16,10 +16,10 @@ from oracle import wgl
 CAS = {"kind": 1, "init": N.NIL}
 
 
-def expand_chain(d, chain, model, eager, branch=False):
+def expand_chain(d, chain, model, eager, branch=False, completion_order=False):
     """The chain of branching calls replayed from the initial state, absorbing reads as the search does (a third
     formulation, besides oracle/wgl_beam.c's and tbc_api.hip's expand_eager_witness).  branch: the root starts in normal
-    form (its own reads come first)."""
+    form (its own reads come first).  completion_order: the lists are in order of completion (TBC_NARROW_ORDER), not by slot."""
     if not eager:
         return [int(x) for x in chain]
     f, a, b, proc = (np.asarray(d[k]) for k in ("f", "a", "b", "process"))
@@ -53,7 +53,7 @@ def expand_chain(d, chain, model, eager, branch=False):
             advance()
         again = True
         while again and front < R:
-            opens = sorted((i for i in live if i not in done and inv_rank[i] <= front <= ret_rank[i]), key=lambda i: proc[i])
+            opens = sorted((i for i in live if i not in done and inv_rank[i] <= front <= ret_rank[i]), key=(lambda i: ret_rank[i]) if completion_order else (lambda i: proc[i]))
             for x in opens:
                 if f[x] == 0 and (a[x] == N.NIL or a[x] == state):
                     done.add(x); out.append(x)
@@ -77,7 +77,9 @@ def compare(hists, model, L, kind=1, tag="", **kw):
         if e["valid"] == 1 and len(d["f"]):
             assert g["final_state"] == e["final_state"], t
             if g["chain"] is not None:
-                    assert expand_chain(d, g["chain"], model, bool(g["rules"] & 1), bool(g["rules"] & 4)) == [int(x) for x in e["witness"]], t
+                    assert expand_chain(d, g["chain"], model, bool(g["rules"] & 1), bool(g["rules"] & 4), bool(kw.get("by_ret"))) == [int(x) for x in e["witness"]], t
+                    if g["rules"] & 1:        # ... and the product's own replay (csrc/witness_expand.h: what tbc_api.hip runs on the device's chain)
+                        assert emu.expand_witness(d, g["chain"], model["init"], bool(g["rules"] & 4), bool(kw.get("by_ret"))) == [int(x) for x in e["witness"]], t
     return got
 
 
@@ -352,8 +354,8 @@ def test_lean_tables_at_the_bench_configuration():
 def test_lists_in_order_of_completion_every_counter(lean):
     hists = [_in_domain(n, p, s, busy, info, corrupt) for (n, p, info, corrupt, busy) in LEAN_SHAPES for s in range(2)]
     hists = [h for h in hists if h.n_process <= 64]
-    # (no witness: the chain's absorbed reads come out in list order, and libtbcheck takes this order only when nobody wants a witness)
-    compare(hists, CAS, 8, tag="by ret", pool_words=4_000_000, by_ret=True, lean=lean, want_witness=False)
+    # (the chain's absorbed reads come out in list order: the third formulation above, expand_chain, replays them in that order too)
+    compare(hists, CAS, 8, tag="by ret", pool_words=4_000_000, by_ret=True, lean=lean)
     compare(hists[:10], CAS, 16, tag="by ret 16", pool_words=4_000_000, by_ret=True, lean=lean, want_witness=False)
     compare(hists, CAS, 4, tag="by ret 4", pool_words=4_000_000, by_ret=True, lean=lean, want_witness=False)      # (16 histories a wavefront)
 
