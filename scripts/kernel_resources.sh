@@ -19,7 +19,7 @@ name = sys.argv[1]
 for blk in re.split(r"\n  - \.agpr_count:", txt)[1:]:
     g = lambda k: (re.search(r"\." + k + r":\s*(\S+)", blk) or [None, "?"])[1]
     kn = g("name")
-    print("%-16s %-64s vgpr %3s sgpr %3s vgpr_spill %3s sgpr_spill %3s lds %6s scratch %5s" % (name, kn[:64], g("vgpr_count"), g("sgpr_count"), g("vgpr_spill_count"), g("sgpr_spill_count"), g("group_segment_fixed_size"), g("private_segment_fixed_size")))
+    print("%-16s %-80s vgpr %3s sgpr %3s vgpr_spill %3s sgpr_spill %3s lds %6s scratch %5s" % (name, kn[:80], g("vgpr_count"), g("sgpr_count"), g("vgpr_spill_count"), g("sgpr_spill_count"), g("group_segment_fixed_size"), g("private_segment_fixed_size")))
 ' "$(basename "$o")"
   rm -f "$tmp"/x.o*
 done
