@@ -461,7 +461,7 @@ def leg_batch_forms(args, local_rank):
         leg("batch form: " + name)
         try:
             cmd = [sys.executable, os.path.abspath(__file__)] + [a for a in sys.argv[1:] if a not in ("--leg", "batch_forms")] + ["--leg", "one_batch_form"]
-            r = subprocess.run(cmd, stdout=subprocess.PIPE, timeout=240, env=dict(os.environ, LOCAL_RANK=str(local_rank), **env))
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, timeout=150, env=dict(os.environ, LOCAL_RANK=str(local_rank), **env))
             res = None
             for ln in reversed(r.stdout.decode(errors="replace").splitlines()):
                 if ln.startswith("{"):
@@ -483,7 +483,7 @@ def leg_batch_forms(args, local_rank):
                 entry.update(res)
                 entry["_sig"] = sig
         except subprocess.TimeoutExpired:
-            entry["error"] = "did not finish within 240 s"
+            entry["error"] = "did not finish within 150 s"
         out.append(entry)
     for e in out:          # the same verdicts, the same planted history found, the same probes and new configs as the default form
         sig = e.pop("_sig", None)

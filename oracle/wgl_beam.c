@@ -361,7 +361,8 @@ int wgl_beam_check_rp(uint32_t n, const uint8_t* f, const int32_t* a, const int3
       for (uint32_t fr = inv_rank[i]; fr <= ret_rank[i]; fr++) lst[fill[fr]++] = i;
     }
 #define LIST_KEY(o) (g_list_order == 0 ? (uint32_t)process[o] : g_list_order == 1 ? ret_rank[o] : \
-                     g_list_order == 2 ? inv_rank[o] * 1024u + (uint32_t)process[o] : 0xFFFFFFFEu - ret_rank[o])
+                     g_list_order == 2 ? inv_rank[o] * 1024u + (uint32_t)process[o] : g_list_order == 3 ? 0xFFFFFFFEu - ret_rank[o] : \
+                     g_list_order == 4 ? (ret_rank[o] | (f[o] == O_WRITE ? 0x40000000u : 0u)) : (ret_rank[o] | (f[o] == O_CAS ? 0x40000000u : 0u)))
     for (uint32_t fr = 0; fr < R; fr++)          /* each front's live list in the chosen order */
       for (uint32_t x = off[fr] + 1; x < off[fr + 1]; x++) {
         uint32_t v = lst[x], y = x;
