@@ -161,17 +161,22 @@ WV_DEV void walk_wave(const PackOpenArgs& A, uint32_t wid, uint32_t* lds, uint32
   // ---- A2. list_order 1: the loop below takes the candidates in order of completion (then every front's list comes out in that
   // order: a front's entries are appended as the loop meets its members).  Candidate i's place = the candidates that complete before it
   // (ties -- crashed calls, ret = kInf, which are in no list -- by table position); the places as 16-bit words over the scan's scratch.
-  const bool by_ret = A.list_order == 1u;
+  // list_order 2: in order of completion with the :write calls after everything else -- the search takes a config's candidates last to
+  // first and pops the last child first, so a :cas the state allows NOW is tried before a :write, which the state always allows
+  // (oracle/wgl_beam.c list order 4: at 19 calls in flight a quarter fewer rounds again than plain completion order).  The key: the
+  // completion rank with bit 30 set for a :write (ranks are below 2^30; kInf keeps its place at the end).
+  const bool by_ret = A.list_order != 0u;
+  const uint32_t wr_last = A.list_order == 2u ? 0x40000000u : 0u;
   uint16_t* const perm = reinterpret_cast<uint16_t*>(aux);
   if (by_ret) {
     WV_UNROLL
     for (int s = 0; s < 3; s++) {
       const uint32_t idx = lane + 64u * (uint32_t)s;
       if (idx < NC) {
-        const uint32_t my = cand[idx * kCandWords + 1u];
+        const uint32_t my = cand[idx * kCandWords + 1u] | ((cand[idx * kCandWords + 3u] & 0xFFu) == TBC_F_WRITE ? wr_last : 0u);
         uint32_t place = 0u;
         for (uint32_t j = 0; j < NC; j++) {
-          const uint32_t rj = cand[j * kCandWords + 1u];
+          const uint32_t rj = cand[j * kCandWords + 1u] | ((cand[j * kCandWords + 3u] & 0xFFu) == TBC_F_WRITE ? wr_last : 0u);
           place += (rj < my || (rj == my && j < idx)) ? 1u : 0u;
         }
         perm[place] = (uint16_t)idx;

@@ -303,6 +303,7 @@ struct PackOpenArgs {
                              // TBC_NARROW_ORDER=1): the search takes a config's candidates last to first and pops the last child first, so the call
                              // that completes soonest is tried first -- on the bench workload 18 % fewer rounds for the same probes, the longest
                              // history 31 % fewer (oracle/wgl_beam.c, wgl_beam_set_list_order(1))
+                             // 2 = in order of completion, the :write calls after everything else (TBC_NARROW_ORDER=2; the oracle's list order 4)
 };
 
 // byte offset of history h's slot8[] (n_ret entries + 16 of padding), 8-byte aligned

@@ -159,6 +159,9 @@ def rules_apply(ops, model, round_pairs=64):
     return bool(len(v) == 0 or (v.min() >= 0 and v.max() <= 30))
 
 
+ORACLE_LIST_ORDER = {0: 0, 1: 1, 2: 4}       # csrc PackOpenArgs.list_order (TBC_NARROW_ORDER) -> wgl_beam_set_list_order
+
+
 def check_beam(ops, model, width=16, max_probes=0, want_witness=True, round_pairs=64, widen_after=0, lookahead=None, eager_reads=None, twin_rule=None,
                twin_selfcheck=False, rules_at_any_round_size=False, branch_lists=False, lazy_commuting=None, eager_txns=False, look_two=False, list_order=0, lazy_look=False, defer=False):
     """The wide (K configs per iteration) schedule of the same search: wgl_beam.c.
@@ -198,7 +201,9 @@ def check_beam(ops, model, width=16, max_probes=0, want_witness=True, round_pair
     lib().wgl_beam_set_eager_txns(C.c_uint32(1 if (eager_txns and model["kind"] == 4) else 0))
     # look_two: the lean lookahead record's reading of three or more open producers (wgl_beam.c, g_look_two; csrc kLeanLook)
     lib().wgl_beam_set_look_two(C.c_uint32(1 if look_two else 0))
-    # list_order: 0 = a front's open calls in process-slot order, 1 = in order of completion (csrc PackOpenArgs.list_order)
+    # list_order: 0 = a front's open calls in process-slot order, 1 = in order of completion (csrc PackOpenArgs.list_order); study knobs of
+    # wgl_beam.c beyond those: 2 = in order of invocation, 3 = latest completion first, 4 = in order of completion with the :write calls
+    # last (PackOpenArgs.list_order = 2: ORACLE_LIST_ORDER maps the library's numbers to these), 5 = ... with the :cas calls last
     lib().wgl_beam_set_list_order(C.c_uint32(list_order))
     # lazy_look: DESIGN STUDY (no kernel counterpart): the lookahead at once only for the config that will be popped next (wgl_beam.c)
     lib().wgl_beam_set_lazy_look(C.c_uint32(1 if lazy_look else 0))

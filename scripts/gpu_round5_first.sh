@@ -13,8 +13,8 @@ for leg in single_history_forms batch_forms; do
   TBC_BENCH_FORMS_BUDGET_S=900 timeout -k 5 1200 python bench.py --leg $leg 2> $OUT/$leg.stderr | tail -1 > $OUT/$leg.json     # (every form: the driver's run has 80 s a leg)
 done
 cd /tmp && export TMPDIR=/tmp
-for form in default wg lean all; do
-  case $form in wg) E="TBC_PACK_WG=2";; lean) E="TBC_NARROW_LEAN=1";; all) E="TBC_NARROW_LEAN=2 TBC_NARROW_ORDER=1 TBC_PACK_WG=2";; *) E="TBC_PACK_WG=0";; esac
+for form in default wg lean all all2; do
+  case $form in wg) E="TBC_PACK_WG=2";; lean) E="TBC_NARROW_LEAN=1";; all) E="TBC_NARROW_LEAN=2 TBC_NARROW_ORDER=1 TBC_PACK_WG=2";; all2) E="TBC_NARROW_LEAN=2 TBC_NARROW_ORDER=2 TBC_PACK_WG=2";; *) E="TBC_PACK_WG=0";; esac
   env $E timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$form -o p -- \
     python $GRAFT_REPO_ROOT/scripts/gpu_narrow_ab.py 16384 0.1 8 4 3 > $OUT/trace_$form.log 2>&1 < /dev/null
   f=$(ls $OUT/trace_$form/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && head -12 "$f" > $OUT/kernel_stats_$form.csv
@@ -31,4 +31,4 @@ except Exception as ex:
     print("no result:", ex)
 PY
 done
-for form in default wg lean all; do echo "== kernel stats, form $form"; cut -c1-160 $OUT/kernel_stats_$form.csv 2>/dev/null; done
+for form in default wg lean all all2; do echo "== kernel stats, form $form"; cut -c1-160 $OUT/kernel_stats_$form.csv 2>/dev/null; done

@@ -34,7 +34,7 @@ int emu_walk_check(uint32_t nh, const uint64_t* op_off, const uint32_t* n_proces
   const bool want_twn = flags & 1u, want_look = flags & 2u, branch = flags & 4u, records = flags & 8u, compact = (flags & 16u) && records;
   const uint32_t lean = (flags & 32u) ? (kLeanCands | kLeanLook) : 0u;          // the lean formats (with twin masks and compact records only)
   if (lean && !(want_twn && compact)) return 9;
-  const bool by_ret = (flags & 64u) != 0u;          // a front's list in order of completion (PackOpenArgs.list_order = 1)
+  const uint32_t by_ret = (flags & 128u) ? 2u : (flags & 64u) ? 1u : 0u;          // a front's list in order of completion (PackOpenArgs.list_order = 1; 2: the writes last)
   Tables T;
   if (!build_tables(nh, op_off, n_process, f, a, b, process, inv_pos, ret_pos, 1, vpad, 1, branch, compact, T, false, lean, by_ret)) return 9;
   const uint64_t total = op_off[nh];
@@ -76,7 +76,7 @@ int emu_walk_check(uint32_t nh, const uint64_t* op_off, const uint32_t* n_proces
   A.off = T.off.data(); A.ncr = T.ncr.data(); A.lst = lst.data(); A.crashed = nullptr; A.ret_slot = T.ret_slot.data(); A.ret_op = T.ret_op.data();
   A.look = want_look ? look.data() : nullptr; A.tmp = want_look ? tmp.data() : nullptr; A.slot8 = nullptr;
   A.front_words = records ? FS : 0u; A.front_compact = compact ? 1u : 0u; A.rk8 = nullptr; A.n_hist = nh; A.mask_words = 1;
-  A.twn = (want_twn && !lean) ? twn.data() : nullptr; A.rdm = vpad ? rdm.data() : nullptr; A.vpad = vpad; A.h0 = 0; A.lean = lean; A.list_order = by_ret ? 1u : 0u;
+  A.twn = (want_twn && !lean) ? twn.data() : nullptr; A.rdm = vpad ? rdm.data() : nullptr; A.vpad = vpad; A.h0 = 0; A.lean = lean; A.list_order = by_ret;
   std::vector<uint32_t> lds(walk::walk_lds_words() + 16);
   for (uint32_t w = 0; w < nh * A.chunks_per_hist; w++) {
     std::fill(lds.begin(), lds.end(), 0xDEADBEEFu);

@@ -22,8 +22,9 @@ struct Tables {
 // the per-front tables of every history of the batch, from the definitions
 bool build_tables(uint32_t nh, const uint64_t* op_off, const uint32_t* n_process, const uint8_t* f, const int32_t* a, const int32_t* b,
                   const int32_t* process, const uint32_t* inv_pos, const uint32_t* ret_pos, uint32_t MW, uint32_t vpad_in,
-                  uint32_t tab_log2_per_op, bool branch, bool compact, Tables& T, bool count = false, uint32_t lean = 0, bool list_by_ret = false) {
-  // list_by_ret: a front's list in order of completion instead of process-slot order (csrc PackOpenArgs.list_order = 1)
+                  uint32_t tab_log2_per_op, bool branch, bool compact, Tables& T, bool count = false, uint32_t lean = 0, uint32_t list_by_ret = 0) {
+  // list_by_ret: a front's list in order of completion instead of process-slot order (csrc PackOpenArgs.list_order = 1); 2 = in order
+  // of completion with the :write calls after everything else (list_order = 2)
   // lean = kLeanCands | kLeanLook (csrc/tbc_internal.h): the same tables with the list entries as {call, twin mask} and the lookahead
   // records as 8 B words -- converted at the end from the plain ones, field by field (one mask word only)
   // count = the COUNT FORM, from its definition (oracle/wgl_count.c states it a third time): live calls on re-used slots (the
@@ -121,7 +122,10 @@ bool build_tables(uint32_t nh, const uint64_t* op_off, const uint32_t* n_process
     uint32_t run = 0;
     for (uint32_t F = 0; F < R; F++) {
       off[F] = run;
-      if (list_by_ret) std::sort(open[F].begin(), open[F].end(), [&](uint32_t x, uint32_t y) { return ret_rank[x] < ret_rank[y]; });
+      if (list_by_ret == 2u) std::sort(open[F].begin(), open[F].end(), [&](uint32_t x, uint32_t y) {
+        const bool wx = f[o + x] == TBC_F_WRITE, wy = f[o + y] == TBC_F_WRITE;
+        return wx != wy ? wy : ret_rank[x] < ret_rank[y]; });
+      else if (list_by_ret) std::sort(open[F].begin(), open[F].end(), [&](uint32_t x, uint32_t y) { return ret_rank[x] < ret_rank[y]; });
       else std::sort(open[F].begin(), open[F].end(), [&](uint32_t x, uint32_t y) { return slot[x] < slot[y]; });
       run += (uint32_t)open[F].size();
     }

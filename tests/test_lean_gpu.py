@@ -12,8 +12,8 @@ from jepsen_tigerbeetle_amd import _native as N, columns, core, synth
 
 LEAN = os.environ.get("TBC_NARROW_LEAN") in ("1", "2")
 LAZY = os.environ.get("TBC_NARROW_LEAN") == "2"        # + the lookahead at once only for the config popped next (the oracle's lazy_look)
-ORDER = os.environ.get("TBC_NARROW_ORDER") == "1"      # the fronts' lists in order of completion (PackOpenArgs.list_order); a witness replays its absorbed reads in that order
-pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not (LEAN or ORDER), reason="a process started with TBC_NARROW_LEAN=1|2 and / or TBC_NARROW_ORDER=1 only")]
+ORDER = int(os.environ.get("TBC_NARROW_ORDER", "0")) if os.environ.get("TBC_NARROW_ORDER") in ("1", "2") else 0      # (2: ... with the :write calls last) the fronts' lists in order of completion (PackOpenArgs.list_order); a witness replays its absorbed reads in that order
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not (LEAN or ORDER), reason="a process started with TBC_NARROW_LEAN=1|2 and / or TBC_NARROW_ORDER=1|2 only")]
 
 CAS = {"kind": 1, "init": N.NIL}
 SHAPES = [(8, 3, 0.0, 0.0, 0.8), (40, 4, 0.0, 0.5, 0.5), (200, 8, 0.0, 0.0, 0.5), (200, 8, 0.0, 0.6, 0.3), (1000, 16, 0.0, 0.0, 0.5),
@@ -28,7 +28,7 @@ def _in_domain(n, p, s, busy, info, corrupt, n_values=5):
 
 def _expect(oracle, h, L, look_two=None, list_order=None, **kw):
     return oracle.check_beam(h.as_dict(), CAS, 1, round_pairs=L, rules_at_any_round_size=True, branch_lists=True,
-                             look_two=LEAN if look_two is None else look_two, list_order=(1 if ORDER else 0) if list_order is None else list_order,
+                             look_two=LEAN if look_two is None else look_two, list_order=oracle.ORACLE_LIST_ORDER[ORDER] if list_order is None else list_order,
                              lazy_look=LAZY and look_two is None, **kw)
 
 
@@ -76,7 +76,7 @@ def test_lean_tables_in_a_big_batch_with_the_queue(native, oracle):
             assert (got["valid"], got["probes"], got["visited"]) == (exp["valid"], exp["probes"], exp["visited"]), (i, k)
 
 
-@pytest.mark.skipif(not ORDER, reason="TBC_NARROW_ORDER=1 only")
+@pytest.mark.skipif(not ORDER, reason="TBC_NARROW_ORDER=1|2 only")
 @pytest.mark.parametrize("width", [2, 4])
 def test_wide_schedule_over_lists_in_order_of_completion(native, oracle, width):
     """a wavefront per history (the kernel of workloads 2 / 3) takes its pairs from the same lists: against the oracle's wide schedule
@@ -91,7 +91,7 @@ def test_wide_schedule_over_lists_in_order_of_completion(native, oracle, width):
         res = b.run().results()
     fewer = 0
     for i, h in enumerate(hists):
-        exp = oracle.check_beam(h.as_dict(), CAS, width, max_probes=20_000_000, want_witness=False, list_order=1)
+        exp = oracle.check_beam(h.as_dict(), CAS, width, max_probes=20_000_000, want_witness=False, list_order=oracle.ORACLE_LIST_ORDER[ORDER])
         plain = oracle.check_beam(h.as_dict(), CAS, width, max_probes=20_000_000, want_witness=False)
         for k in (i, i + 5 * n1):
             got = res[k]

@@ -67,7 +67,7 @@ def compare(hists, model, L, kind=1, tag="", **kw):
     for i, (d, g) in enumerate(zip(ds, got)):
         e = wgl.check_beam(d, model, 1, round_pairs=L, rules_at_any_round_size=True, lookahead=kw.get("lookahead", True),
                            eager_reads=bool(g["rules"] & 1), twin_rule=bool(g["rules"] & 2), max_probes=kw.get("max_steps", 0),
-                           branch_lists=bool(g["rules"] & 4), look_two=bool(kw.get("lean", False)), list_order=1 if kw.get("by_ret") else 0, lazy_look=kw.get("lean") == 2)
+                           branch_lists=bool(g["rules"] & 4), look_two=bool(kw.get("lean", False)), list_order=wgl.ORACLE_LIST_ORDER[int(kw.get("by_ret", 0))], lazy_look=kw.get("lean") == 2)
         t = (tag, i, L)
         assert g["valid"] == e["valid"], (t, g["valid"], e["valid"], g["cause"])
         for a_, b_ in (("probes", "probes"), ("visited", "visited"), ("backtracks", "expanded"), ("max_depth", "max_stack"), ("bucket_reads", "rounds")):
@@ -366,6 +366,28 @@ def test_lists_in_order_of_completion_need_fewer_rounds():
     got = compare(hists, CAS, 8, tag="by ret bench", entries_per_op=4, pool_words=1 << 24, want_witness=False, by_ret=True, lean=True)
     plain = [wgl.check_beam(h.as_dict(), CAS, 1, round_pairs=8, rules_at_any_round_size=True, branch_lists=True, want_witness=False) for h in hists]
     assert sum(g["bucket_reads"] for g in got) < 0.9 * sum(p["rounds"] for p in plain)
+
+
+# ---- ... with the :write calls after everything else (PackOpenArgs.list_order = 2; TBC_NARROW_ORDER=2; the oracle's list order 4): a :cas the
+# state allows now is tried before a :write, which it always allows
+@pytest.mark.parametrize("lean", [False, 2])
+def test_lists_in_order_of_completion_writes_last_every_counter(lean):
+    hists = [_in_domain(n, p, s, busy, info, corrupt) for (n, p, info, corrupt, busy) in LEAN_SHAPES for s in range(2)]
+    hists = [h for h in hists if h.n_process <= 64]
+    compare(hists, CAS, 8, tag="writes last", pool_words=4_000_000, by_ret=2, lean=lean)         # (witnesses: absorbed reads in order of completion, as under 1)
+    compare(hists[:10], CAS, 16, tag="writes last 16", pool_words=4_000_000, by_ret=2, lean=lean, want_witness=False)
+    compare(hists, CAS, 4, tag="writes last 4", pool_words=4_000_000, by_ret=2, lean=lean, want_witness=False)
+    h = [columns.pair_events(synth.register_events(n_ops=300, n_procs=24, seed=s, busy=1.0, n_values=2)) for s in range(4)]      # many backtracks
+    compare(h, CAS, 8, tag="writes last busy", pool_words=8_000_000, by_ret=2, lean=lean, want_witness=False)
+
+
+def test_writes_last_needs_fewer_rounds_than_plain_completion_order():
+    """what it buys (oracle counts, the kernel following them): a few per cent on the bench workload, about a quarter at 19 calls in flight"""
+    hists = synth.register_ops_many(range(7000, 7004), n_ops=10000, n_procs=64, busy=0.1, info=0.0) + \
+            synth.register_ops_many(range(7200, 7202), n_ops=10000, n_procs=64, busy=0.3, info=0.0)
+    got = compare(hists, CAS, 8, tag="writes last bench", entries_per_op=4, pool_words=1 << 25, want_witness=False, by_ret=2, lean=2)
+    plain = [wgl.check_beam(h.as_dict(), CAS, 1, round_pairs=8, rules_at_any_round_size=True, branch_lists=True, want_witness=False, list_order=1) for h in hists]
+    assert sum(g["bucket_reads"] for g in got) < 0.97 * sum(p["rounds"] for p in plain)
 
 
 # ---- the lazy lookahead (csrc kLeanLazy; TBC_NARROW_LEAN=2): the lookahead at once only for the config that will be popped next, its siblings

@@ -251,12 +251,13 @@ def test_list_order_and_the_lean_lookahead_never_change_a_verdict(native, oracle
         n += 1
         n_invalid += ref["valid"] == 0
         for width, kw in ((1, dict(round_pairs=8, rules_at_any_round_size=True, branch_lists=True, look_two=True)), (4, {}), (2, dict(look_two=True))):
-            r = oracle.check_beam(d, cas, width, want_witness=False, list_order=1, max_probes=20_000_000, **kw)
-            if r["valid"] == -1:
-                continue
-            assert r["valid"] == ref["valid"], (it, width, shape)
-            if ref["valid"] == 0:
-                assert r["fail_op"] == ref["fail_op"], (it, width, shape)
+            for order in (1, oracle.ORACLE_LIST_ORDER[2]):          # (TBC_NARROW_ORDER=2: ... with the :write calls last)
+                r = oracle.check_beam(d, cas, width, want_witness=False, list_order=order, max_probes=20_000_000, **kw)
+                if r["valid"] == -1:
+                    continue
+                assert r["valid"] == ref["valid"], (it, width, order, shape)
+                if ref["valid"] == 0:
+                    assert r["fail_op"] == ref["fail_op"], (it, width, order, shape)
     assert n > 100 and n_invalid > 40
 
 
