@@ -385,7 +385,8 @@ BATCH_FORMS = [("pack_kernel + open_counts_kernel (the default)", {}),
                # (order 2: in order of completion with the :write calls last -- a :cas the state allows now before a :write; oracle: 5 % fewer rounds
                # than order 1 here, a quarter fewer at 19 calls in flight)
                ("lists in order of completion, writes last", {"TBC_NARROW_ORDER": "2"}),
-               ("lean tables + lazy lookahead + lists in order of completion, writes last", {"TBC_NARROW_LEAN": "2", "TBC_NARROW_ORDER": "2"}),
+               # (order 16 + W: a :write as if it completed W ranks later, the soft form; W = 24: the best of the oracle's scan at 6, 19 and 32 in flight)
+               ("lean tables + lazy lookahead + lists in order of completion, a write 24 ranks later", {"TBC_NARROW_LEAN": "2", "TBC_NARROW_ORDER": "40"}),
                ("pack + open counts by four wavefronts per history, tables in LDS", {"TBC_PACK_WG": "2"}),
                ("lean tables: list entries {call, twin mask}, 8 B lookahead records", {"TBC_NARROW_LEAN": "1"}),
                # (4 lanes per history = 16 histories a wavefront: the oracle counts 30 % more rounds a history in completion order, 39 % in slot
@@ -394,6 +395,7 @@ BATCH_FORMS = [("pack_kernel + open_counts_kernel (the default)", {}),
                # (a wavefront per history at 19 calls in flight -- workload 3's kernel -- in both list orders; compared with each other only)
                ("19 calls in flight, a wavefront per history", {"TBC_BENCH_FORM_BUSY": "0.3"}),
                ("19 calls in flight, a wavefront per history, lists in order of completion", {"TBC_BENCH_FORM_BUSY": "0.3", "TBC_NARROW_ORDER": "1"}),
+               ("19 calls in flight, a wavefront per history, lists in order of completion, a write 24 ranks later", {"TBC_BENCH_FORM_BUSY": "0.3", "TBC_NARROW_ORDER": "40"}),
                ("19 calls in flight, a wavefront per history, lists in order of completion, writes last", {"TBC_BENCH_FORM_BUSY": "0.3", "TBC_NARROW_ORDER": "2"}),
                # (round 4 measured 16 lanes per history LOSING to a wavefront per history there, 4.06 s against 1.83 s per 8,192; in completion order
                # the oracle counts 27.9k rounds a history for it, four histories a wavefront, against the wide schedule's 16.9k for one)
@@ -402,6 +404,7 @@ BATCH_FORMS = [("pack_kernel + open_counts_kernel (the default)", {}),
                ("4 lanes per history", {"TBC_BENCH_FORM_LANES": "4"}),
                # (32 in flight: a pass is its slowest history -- on oracle samples of 16-32 histories the order moves the tail by 0.7x .. 7x either way)
                ("32 calls in flight, a wavefront per history", {"TBC_BENCH_FORM_BUSY": "0.5"}),
+               ("32 calls in flight, a wavefront per history, lists in order of completion, a write 24 ranks later", {"TBC_BENCH_FORM_BUSY": "0.5", "TBC_NARROW_ORDER": "40"}),
                ("32 calls in flight, a wavefront per history, lists in order of completion", {"TBC_BENCH_FORM_BUSY": "0.5", "TBC_NARROW_ORDER": "1"})]
 
 

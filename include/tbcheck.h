@@ -535,9 +535,10 @@ int tbc_debug_peek(uint32_t* out, uint32_t n);
  *                                 2 = and a pass that fits one wavefront is run by wavefront 0 alone
  *   TBC_NARROW_LEAN=1|2           (experimental; 2 = and the lookahead at once only for the config that is popped next) several histories per wavefront over lean tables: a list entry {call, twin mask} in one array,
  *                                 an 8 B lookahead record (two producer slots; three or more read as "one is still to be linearized")
- *   TBC_NARROW_ORDER=1|2          (experimental) ... with every front's list in order of completion: the call that completes soonest is tried
+ *   TBC_NARROW_ORDER=1|2|16+W     (experimental) ... with every front's list in order of completion: the call that completes soonest is tried
  *                                 first (fewer rounds for the same probes); a witness's absorbed reads follow the same order;
- *                                 2 = and the :write calls after everything else (a :cas the state allows now before a :write)
+ *                                 2 = and the :write calls after everything else (a :cas the state allows now before a :write);
+ *                                 16 + W = and a :write as if it completed W ranks later (the soft form of 2; W = 16 .. 24)
  *   TBC_PACK_ONE=1|2              (experimental) a handful of histories are packed by sixteen wavefronts each, tables in LDS (pack_one.hip);
  *                                 2 = and the per-front counts in the same launch
  *   TBC_PACK_WG=1                 (experimental) a batch of the wide schedule is packed by four wavefronts per history, tables in LDS,

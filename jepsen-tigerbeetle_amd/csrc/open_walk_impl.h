@@ -164,19 +164,24 @@ WV_DEV void walk_wave(const PackOpenArgs& A, uint32_t wid, uint32_t* lds, uint32
   // list_order 2: in order of completion with the :write calls after everything else -- the search takes a config's candidates last to
   // first and pops the last child first, so a :cas the state allows NOW is tried before a :write, which the state always allows
   // (oracle/wgl_beam.c list order 4: at 19 calls in flight a quarter fewer rounds again than plain completion order).  The key: the
-  // completion rank with bit 30 set for a :write (ranks are below 2^30; kInf keeps its place at the end).
+  // completion rank plus 2^30 for a :write (ranks are below 2^30).
+  // list_order 16 + W: a :write takes the place of a call completing W ranks later (the soft form of the same preference; keys are doubled
+  // ranks, a :write's odd: after the call it ties with) -- W = 16 .. 24 is the best of the scan at 6, 19 and 32 calls in flight (oracle list
+  // order 16 + W: at 19 in flight 19 - 22k rounds a history against 28k writes last, 59k plain completion order).  Any key gives a
+  // permutation: a place is the count of smaller keys, ties by table position.
   const bool by_ret = A.list_order != 0u;
-  const uint32_t wr_last = A.list_order == 2u ? 0x40000000u : 0u;
+  const uint32_t wr_last = A.list_order == 2u ? 0x40000000u : A.list_order >= 16u ? 2u * (A.list_order - 16u) + 1u : 0u;
+  const uint32_t rk_mul = A.list_order >= 16u ? 2u : 1u;
   uint16_t* const perm = reinterpret_cast<uint16_t*>(aux);
   if (by_ret) {
     WV_UNROLL
     for (int s = 0; s < 3; s++) {
       const uint32_t idx = lane + 64u * (uint32_t)s;
       if (idx < NC) {
-        const uint32_t my = cand[idx * kCandWords + 1u] | ((cand[idx * kCandWords + 3u] & 0xFFu) == TBC_F_WRITE ? wr_last : 0u);
+        const uint32_t my = cand[idx * kCandWords + 1u] * rk_mul + ((cand[idx * kCandWords + 3u] & 0xFFu) == TBC_F_WRITE ? wr_last : 0u);
         uint32_t place = 0u;
         for (uint32_t j = 0; j < NC; j++) {
-          const uint32_t rj = cand[j * kCandWords + 1u] | ((cand[j * kCandWords + 3u] & 0xFFu) == TBC_F_WRITE ? wr_last : 0u);
+          const uint32_t rj = cand[j * kCandWords + 1u] * rk_mul + ((cand[j * kCandWords + 3u] & 0xFFu) == TBC_F_WRITE ? wr_last : 0u);
           place += (rj < my || (rj == my && j < idx)) ? 1u : 0u;
         }
         perm[place] = (uint16_t)idx;

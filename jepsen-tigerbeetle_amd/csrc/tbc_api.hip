@@ -320,7 +320,9 @@ struct tbc_batch {
     // (2: in order of completion with the :write calls last -- a :cas the state allows now goes before a :write, which it always allows;
     // oracle list order 4: another quarter fewer rounds at 19 calls in flight, 5 % on the bench workload.  A witness's absorbed reads are
     // reads: their order among themselves is the order of completion either way)
-    static const uint32_t asked = [] { const char* e = std::getenv("TBC_NARROW_ORDER"); return (e && (e[0] == '1' || e[0] == '2')) ? (uint32_t)(e[0] - '0') : 0u; }();
+    // (16 + W: a :write takes the place of a call completing W ranks later -- the soft form; W = 16 .. 24 the best of the oracle's scan)
+    static const uint32_t asked = [] { const char* e = std::getenv("TBC_NARROW_ORDER"); const long v = e ? std::strtol(e, nullptr, 10) : 0;
+                                       return (v == 1 || v == 2 || (v >= 16 && v <= 16 + 4096)) ? (uint32_t)v : 0u; }();
     static const bool by_slots = [] { const char* e = std::getenv("TBC_OPEN_WALK"); return e && std::strcmp(e, "slots") == 0; }();
     // (a wavefront per history too -- the wide kernel takes its pairs from the same lists: at 19 calls in flight 28 % fewer probes, 41 % fewer rounds)
     return (asked && !by_slots && width > 1 && mask_words == 1 && vpad <= 32 && !(rules & kRuleCount) && !sweep &&

@@ -304,6 +304,7 @@ struct PackOpenArgs {
                              // that completes soonest is tried first -- on the bench workload 18 % fewer rounds for the same probes, the longest
                              // history 31 % fewer (oracle/wgl_beam.c, wgl_beam_set_list_order(1))
                              // 2 = in order of completion, the :write calls after everything else (TBC_NARROW_ORDER=2; the oracle's list order 4)
+                             // 16 + W = in order of completion, a :write as if it completed W ranks later (the oracle's list order 16 + W)
 };
 
 // byte offset of history h's slot8[] (n_ret entries + 16 of padding), 8-byte aligned

@@ -159,7 +159,14 @@ def rules_apply(ops, model, round_pairs=64):
     return bool(len(v) == 0 or (v.min() >= 0 and v.max() <= 30))
 
 
-ORACLE_LIST_ORDER = {0: 0, 1: 1, 2: 4}       # csrc PackOpenArgs.list_order (TBC_NARROW_ORDER) -> wgl_beam_set_list_order
+class _ListOrders(dict):       # csrc PackOpenArgs.list_order (TBC_NARROW_ORDER) -> wgl_beam_set_list_order; 16 + W is 16 + W on both sides
+    def __missing__(self, k):
+        if k >= 16:
+            return k
+        raise KeyError(k)
+
+
+ORACLE_LIST_ORDER = _ListOrders({0: 0, 1: 1, 2: 4})
 
 
 def check_beam(ops, model, width=16, max_probes=0, want_witness=True, round_pairs=64, widen_after=0, lookahead=None, eager_reads=None, twin_rule=None,
@@ -203,7 +210,8 @@ def check_beam(ops, model, width=16, max_probes=0, want_witness=True, round_pair
     lib().wgl_beam_set_look_two(C.c_uint32(1 if look_two else 0))
     # list_order: 0 = a front's open calls in process-slot order, 1 = in order of completion (csrc PackOpenArgs.list_order); study knobs of
     # wgl_beam.c beyond those: 2 = in order of invocation, 3 = latest completion first, 4 = in order of completion with the :write calls
-    # last (PackOpenArgs.list_order = 2: ORACLE_LIST_ORDER maps the library's numbers to these), 5 = ... with the :cas calls last
+    # last (PackOpenArgs.list_order = 2: ORACLE_LIST_ORDER maps the library's numbers to these), 5 = ... with the :cas calls last, 6 / 7 = writes last by latest completion / by invocation (both worse), 16 + W = in order of completion with a
+    # :write as if it completed W ranks later (PackOpenArgs.list_order = 16 + W)
     lib().wgl_beam_set_list_order(C.c_uint32(list_order))
     # lazy_look: DESIGN STUDY (no kernel counterpart): the lookahead at once only for the config that will be popped next (wgl_beam.c)
     lib().wgl_beam_set_lazy_look(C.c_uint32(1 if lazy_look else 0))

@@ -362,7 +362,11 @@ int wgl_beam_check_rp(uint32_t n, const uint8_t* f, const int32_t* a, const int3
     }
 #define LIST_KEY(o) (g_list_order == 0 ? (uint32_t)process[o] : g_list_order == 1 ? ret_rank[o] : \
                      g_list_order == 2 ? inv_rank[o] * 1024u + (uint32_t)process[o] : g_list_order == 3 ? 0xFFFFFFFEu - ret_rank[o] : \
-                     g_list_order == 4 ? (ret_rank[o] | (f[o] == O_WRITE ? 0x40000000u : 0u)) : (ret_rank[o] | (f[o] == O_CAS ? 0x40000000u : 0u)))
+                     g_list_order == 4 ? (ret_rank[o] | (f[o] == O_WRITE ? 0x40000000u : 0u)) : \
+                     g_list_order == 5 ? (ret_rank[o] | (f[o] == O_CAS ? 0x40000000u : 0u)) : \
+                     g_list_order == 6 ? (f[o] == O_WRITE ? 0x7FFFFFFFu - ret_rank[o] : ret_rank[o]) : \
+                     g_list_order == 7 ? (f[o] == O_WRITE ? 0x40000000u + inv_rank[o] : ret_rank[o]) : \
+                     (ret_rank[o] * 2u + (f[o] == O_WRITE ? 2u * (g_list_order - 16u) + 1u : 0u)))      /* >= 16: a :write as if it completed (order - 16) ranks later */
     for (uint32_t fr = 0; fr < R; fr++)          /* each front's live list in the chosen order */
       for (uint32_t x = off[fr] + 1; x < off[fr + 1]; x++) {
         uint32_t v = lst[x], y = x;

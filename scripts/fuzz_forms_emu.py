@@ -47,7 +47,7 @@ for it in range(rounds):
     # ---- the lean tables
     if h.n_process <= 64:
         try:
-            by_ret = (2 if it & 16 else 1) if it & 2 else 0        # (2: ... with the :write calls last, TBC_NARROW_ORDER=2) the fronts' lists in order of completion (a witness's absorbed reads in that order too)
+            by_ret = ((16 + rng.choice([1, 4, 16, 24, 200]) if it & 32 else 2) if it & 16 else 1) if it & 2 else 0        # (2: ... with the :write calls last, TBC_NARROW_ORDER=2) the fronts' lists in order of completion (a witness's absorbed reads in that order too)
             lean = (2 if it & 8 else 1) if (it & 4 or not by_ret) else False          # 2: + the lazy lookahead
             TN.compare([h], TN.CAS, rng.choice([8, 16, 32]), tag="fuzz", pool_words=8_000_000, lean=lean, entries_per_op=rng.choice([1, 4, 8]),
                        want_witness=bool(it & 1), epochs=rng.choice([0, 0, 2]), by_ret=by_ret)

@@ -14,7 +14,7 @@ for leg in single_history_forms batch_forms; do
 done
 cd /tmp && export TMPDIR=/tmp
 for form in default wg lean all all2; do
-  case $form in wg) E="TBC_PACK_WG=2";; lean) E="TBC_NARROW_LEAN=1";; all) E="TBC_NARROW_LEAN=2 TBC_NARROW_ORDER=1 TBC_PACK_WG=2";; all2) E="TBC_NARROW_LEAN=2 TBC_NARROW_ORDER=2 TBC_PACK_WG=2";; *) E="TBC_PACK_WG=0";; esac
+  case $form in wg) E="TBC_PACK_WG=2";; lean) E="TBC_NARROW_LEAN=1";; all) E="TBC_NARROW_LEAN=2 TBC_NARROW_ORDER=1 TBC_PACK_WG=2";; all2) E="TBC_NARROW_LEAN=2 TBC_NARROW_ORDER=40 TBC_PACK_WG=2";; *) E="TBC_PACK_WG=0";; esac
   env $E timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$form -o p -- \
     python $GRAFT_REPO_ROOT/scripts/gpu_narrow_ab.py 16384 0.1 8 4 3 > $OUT/trace_$form.log 2>&1 < /dev/null
   f=$(ls $OUT/trace_$form/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && head -12 "$f" > $OUT/kernel_stats_$form.csv

@@ -72,7 +72,7 @@ def walk_check(hists, vpad, twin=True, look=True, branch=False, front="plain", l
     pr, inv, ret = cat("process", np.int32), cat("inv_pos", np.uint32), cat("ret_pos", np.uint32)
     npr = np.array([int(d["n_process"]) for d in ds], np.uint32)
     assert int(npr.max()) <= 64
-    flags = (1 if twin else 0) | (2 if look else 0) | (4 if branch else 0) | {"plain": 0, "wide": 8, "compact": 24}[front] | (32 if lean else 0) | (128 if by_ret == 2 else 64 if by_ret else 0)      # lean: csrc kLeanCands | kLeanLook; by_ret: list_order 1
+    flags = (1 if twin else 0) | (2 if look else 0) | (4 if branch else 0) | {"plain": 0, "wide": 8, "compact": 24}[front] | (32 if lean else 0) | ((int(by_ret) << 16) if int(by_ret) >= 16 else 128 if by_ret == 2 else 64 if by_ret else 0)      # lean: csrc kLeanCands | kLeanLook; by_ret: list_order 1
     diag = np.zeros(8, np.uint64)
     rc = _LIB_WALK.emu_walk_check(C.c_uint32(nh), _p(op_off, C.c_uint64), _p(npr, C.c_uint32), _p(f, C.c_uint8), _p(a, C.c_int32), _p(b, C.c_int32),
                                   _p(pr, C.c_int32), _p(inv, C.c_uint32), _p(ret, C.c_uint32), C.c_uint32(vpad), C.c_uint32(flags), _p(diag, C.c_uint64))
@@ -161,7 +161,7 @@ def run(hists, model_kind, init, L, rules=None, lookahead=True, entries_per_op=8
     rc = lib().emu_narrow_run(C.c_uint32(nh), _p(op_off, C.c_uint64), _p(npr, C.c_uint32), _p(f, C.c_uint8), _p(a, C.c_int32), _p(b, C.c_int32),
                               _p(pr, C.c_int32), _p(inv, C.c_uint32), _p(ret, C.c_uint32), C.c_uint32(model_kind), C.c_int32(init),
                               C.c_uint32(L), C.c_uint32(mw), C.c_uint32(r), C.c_uint32(vpad), C.c_uint32(1 if look else 0),
-                              C.c_uint32(entries_per_op), C.c_uint64(max_steps), C.c_uint64(pool_words), C.c_uint32(1 if want_witness else 0), C.c_uint32(max_waves), C.c_uint32((1 if compact else 0) | (2 if lean else 0) | (16 if by_ret == 2 else 4 if by_ret else 0) | (8 if lean == 2 else 0)), C.c_uint32(epochs), C.c_uint32(1 if count else 0), C.c_uint32(1 if relaxed else 0),
+                              C.c_uint32(entries_per_op), C.c_uint64(max_steps), C.c_uint64(pool_words), C.c_uint32(1 if want_witness else 0), C.c_uint32(max_waves), C.c_uint32((1 if compact else 0) | (2 if lean else 0) | ((int(by_ret) << 16) if int(by_ret) >= 16 else 16 if by_ret == 2 else 4 if by_ret else 0) | (8 if lean == 2 else 0)), C.c_uint32(epochs), C.c_uint32(1 if count else 0), C.c_uint32(1 if relaxed else 0),
                               _p(np.ascontiguousarray(targets, np.uint32), C.c_uint32) if targets is not None else None,
                               res, _p(wit, C.c_uint32), _p(cfg, C.c_uint64))
     if rc != 0:

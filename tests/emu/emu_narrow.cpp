@@ -96,7 +96,7 @@ int emu_narrow_run(uint32_t nh, const uint64_t* op_off, const uint32_t* n_proces
   const uint32_t lean = ((want_compact & 2u) && compact && MW == 1 && !count && lookahead && (rules & (kRuleEager | kRuleTwin)) == (kRuleEager | kRuleTwin)) ? (kLeanCands | kLeanLook) : 0u;
   if ((want_compact & 2u) && !lean) return 4;
   // want_compact bit 2: the fronts' lists in order of completion (libtbcheck: TBC_NARROW_ORDER=1; the kernel reads what it is given)
-  if (!build_tables(nh, op_off, n_process, f, a, b, process, inv_pos, ret_pos, MW, vpad, entries_per_op, (rules & kRuleBranch) != 0, compact, T, count != 0, lean, (want_compact & 16u) ? 2u : (want_compact & 4u) ? 1u : 0u)) return 1;      // (16: in order of completion with the writes last, list_order 2)
+  if (!build_tables(nh, op_off, n_process, f, a, b, process, inv_pos, ret_pos, MW, vpad, entries_per_op, (rules & kRuleBranch) != 0, compact, T, count != 0, lean, (want_compact >> 16) ? (want_compact >> 16) : (want_compact & 16u) ? 2u : (want_compact & 4u) ? 1u : 0u)) return 1;      // (16: in order of completion with the writes last, list_order 2)
   if (count) { rules |= kRuleCount; for (uint32_t h = 0; h < nh && targets; h++) T.bh[h].target = targets[h]; }
   const uint64_t total = op_off[nh];
   uint64_t entries = 0;

@@ -34,7 +34,7 @@ int emu_walk_check(uint32_t nh, const uint64_t* op_off, const uint32_t* n_proces
   const bool want_twn = flags & 1u, want_look = flags & 2u, branch = flags & 4u, records = flags & 8u, compact = (flags & 16u) && records;
   const uint32_t lean = (flags & 32u) ? (kLeanCands | kLeanLook) : 0u;          // the lean formats (with twin masks and compact records only)
   if (lean && !(want_twn && compact)) return 9;
-  const uint32_t by_ret = (flags & 128u) ? 2u : (flags & 64u) ? 1u : 0u;          // a front's list in order of completion (PackOpenArgs.list_order = 1; 2: the writes last)
+  const uint32_t by_ret = (flags >> 16) ? (flags >> 16) : (flags & 128u) ? 2u : (flags & 64u) ? 1u : 0u;      // (bits 16 up: list_order 16 + W)          // a front's list in order of completion (PackOpenArgs.list_order = 1; 2: the writes last)
   Tables T;
   if (!build_tables(nh, op_off, n_process, f, a, b, process, inv_pos, ret_pos, 1, vpad, 1, branch, compact, T, false, lean, by_ret)) return 9;
   const uint64_t total = op_off[nh];

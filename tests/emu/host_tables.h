@@ -122,7 +122,11 @@ bool build_tables(uint32_t nh, const uint64_t* op_off, const uint32_t* n_process
     uint32_t run = 0;
     for (uint32_t F = 0; F < R; F++) {
       off[F] = run;
-      if (list_by_ret == 2u) std::sort(open[F].begin(), open[F].end(), [&](uint32_t x, uint32_t y) {
+      if (list_by_ret >= 16u) std::sort(open[F].begin(), open[F].end(), [&](uint32_t x, uint32_t y) {      // 16 + W: a :write W ranks later, after its tie
+        const uint64_t kx = 2ull * ret_rank[x] + (f[o + x] == TBC_F_WRITE ? 2ull * (list_by_ret - 16u) + 1ull : 0ull);
+        const uint64_t ky = 2ull * ret_rank[y] + (f[o + y] == TBC_F_WRITE ? 2ull * (list_by_ret - 16u) + 1ull : 0ull);
+        return kx < ky; });
+      else if (list_by_ret == 2u) std::sort(open[F].begin(), open[F].end(), [&](uint32_t x, uint32_t y) {
         const bool wx = f[o + x] == TBC_F_WRITE, wy = f[o + y] == TBC_F_WRITE;
         return wx != wy ? wy : ret_rank[x] < ret_rank[y]; });
       else if (list_by_ret) std::sort(open[F].begin(), open[F].end(), [&](uint32_t x, uint32_t y) { return ret_rank[x] < ret_rank[y]; });

@@ -12,7 +12,7 @@ from jepsen_tigerbeetle_amd import _native as N, columns, core, synth
 
 LEAN = os.environ.get("TBC_NARROW_LEAN") in ("1", "2")
 LAZY = os.environ.get("TBC_NARROW_LEAN") == "2"        # + the lookahead at once only for the config popped next (the oracle's lazy_look)
-ORDER = int(os.environ.get("TBC_NARROW_ORDER", "0")) if os.environ.get("TBC_NARROW_ORDER") in ("1", "2") else 0      # (2: ... with the :write calls last) the fronts' lists in order of completion (PackOpenArgs.list_order); a witness replays its absorbed reads in that order
+ORDER = int(os.environ.get("TBC_NARROW_ORDER", "0")) if os.environ.get("TBC_NARROW_ORDER", "").isdigit() and (int(os.environ["TBC_NARROW_ORDER"]) in (1, 2) or 16 <= int(os.environ["TBC_NARROW_ORDER"]) <= 16 + 4096) else 0      # (2: ... with the :write calls last) the fronts' lists in order of completion (PackOpenArgs.list_order); a witness replays its absorbed reads in that order
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not (LEAN or ORDER), reason="a process started with TBC_NARROW_LEAN=1|2 and / or TBC_NARROW_ORDER=1|2 only")]
 
 CAS = {"kind": 1, "init": N.NIL}

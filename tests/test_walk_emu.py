@@ -86,13 +86,14 @@ def test_lists_in_order_of_completion_every_word(lean):
     assert emu.walk_check(h + full + busy, 8, branch=True, front="compact", lean=lean, by_ret=True) is None
 
 
+@pytest.mark.parametrize("by_ret", [2, 16 + 24, 16 + 3])
 @pytest.mark.parametrize("lean", [False, True])
-def test_lists_in_order_of_completion_writes_last_every_word(lean):
+def test_lists_in_order_of_completion_writes_last_every_word(lean, by_ret):
     """PackOpenArgs.list_order = 2 (TBC_NARROW_ORDER=2): every front's list by completion rank with the :write calls after everything else
-    (full lists -- reads, then cas, then writes apart -- and branch lists)"""
-    assert emu.walk_check(_hists(), 8, branch=True, front="compact", lean=lean, by_ret=2) is None
-    assert emu.walk_check(_hists(seeds=(3,)), 8, branch=False, front="compact", lean=lean, by_ret=2) is None
+    (full lists -- reads, then cas, then writes apart -- and branch lists); 16 + W: a :write as if it completed W ranks later"""
+    assert emu.walk_check(_hists(), 8, branch=True, front="compact", lean=lean, by_ret=by_ret) is None
+    assert emu.walk_check(_hists(seeds=(3,)), 8, branch=False, front="compact", lean=lean, by_ret=by_ret) is None
     h = [columns.pair_events(synth.register_events(n_ops=400, n_procs=40, seed=s, busy=1.0, n_values=2)) for s in range(2)]
     full = synth.register_ops_many(range(7000, 7002), n_ops=10000, n_procs=64, busy=0.1, info=0.0)
     busy = synth.register_ops_many(range(7100, 7101), n_ops=10000, n_procs=64, busy=0.5, info=0.0)
-    assert emu.walk_check(h + full + busy, 8, branch=True, front="compact", lean=lean, by_ret=2) is None
+    assert emu.walk_check(h + full + busy, 8, branch=True, front="compact", lean=lean, by_ret=by_ret) is None

@@ -24,7 +24,7 @@ FORMS = [("compact+solo+fingerprint", {"TBC_SWEEP_WG_COMPACT": "2", "TBC_SWEEP_W
          ("pack-one+counts+compact+solo+fingerprint", {"TBC_PACK_ONE": "2", "TBC_SWEEP_WG_COMPACT": "2", "TBC_SWEEP_WG_FP": "1"}),
          ("pack-wg", {"TBC_PACK_WG": "1"}), ("pack-wg-or-error", {"TBC_PACK_WG": "2"}), ("lean-tables", {"TBC_NARROW_LEAN": "1"}),
          ("lists-by-completion+lean+lazy-lookahead", {"TBC_NARROW_ORDER": "1", "TBC_NARROW_LEAN": "2"}),
-         ("lists-by-completion-writes-last", {"TBC_NARROW_ORDER": "2"})]
+         ("lists-by-completion-a-write-24-ranks-later", {"TBC_NARROW_ORDER": "40"})]       # (16 + W; 2 = writes last: the same code path)
 # (the ring, the fingerprint alone, the compact walk alone, sixteen wavefronts, pack-one alone: timed and compared counter by counter by
 # bench.py's extra.single_history_forms, not run through the test files here -- the GPU tier's minutes are the driver's)
 
