@@ -190,7 +190,8 @@ static uint32_t cabsorb(uint64_t* M2, uint32_t fi2, int32_t s, uint32_t R, const
   return fi2;
 }
 
-/* list order (csrc PackOpenArgs.list_order; oracle/wgl_beam.c has the same switch): 0 = a front's live calls in slot order, 1 = in order of completion */
+/* list order (csrc PackOpenArgs.list_order; oracle/wgl_beam.c has the same switch): 0 = a front's live calls in slot order, 1 = in order of completion,
+   16 + W = in order of completion with a :write as if it completed W ranks later (a study knob here) */
 static uint32_t g_count_list_order = 0;
 void wgl_count_set_list_order(uint32_t o) { g_count_list_order = o; }
 
@@ -313,7 +314,9 @@ int wgl_count_check(uint32_t n, const uint8_t* f, const int32_t* a, const int32_
     for (uint32_t fr = 0; fr < R; fr++)
       for (uint32_t x = off[fr] + 1; x < off[fr + 1]; x++) {
         uint32_t v = lst[x], y = x;
-        while (y > off[fr] && (g_count_list_order == 1 ? ret_rank[lst[y - 1]] > ret_rank[v] : slot[lst[y - 1]] > slot[v])) { lst[y] = lst[y - 1]; y--; }
+#define COUNT_KEY(o) (g_count_list_order == 1 ? ret_rank[o] : g_count_list_order >= 16 ? \
+                      2u * ret_rank[o] + (f[o] == O_WRITE ? 2u * (g_count_list_order - 16u) + 1u : 0u) : (uint32_t)slot[o])      /* 16 + W: as wgl_beam.c */
+        while (y > off[fr] && COUNT_KEY(lst[y - 1]) > COUNT_KEY(v)) { lst[y] = lst[y - 1]; y--; }
         lst[y] = v;
       } }
 
