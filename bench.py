@@ -387,15 +387,15 @@ BATCH_FORMS = [("pack_kernel + open_counts_kernel (the default)", {}),
                ("lists in order of completion, writes last", {"TBC_NARROW_ORDER": "2"}),
                # (order 16 + W: a :write as if it completed W ranks later, the soft form; W = 24: the best of the oracle's scan at 6, 19 and 32 in flight)
                ("lean tables + lazy lookahead + lists in order of completion, a write 24 ranks later", {"TBC_NARROW_LEAN": "2", "TBC_NARROW_ORDER": "40"}),
+               # (a wavefront per history at 19 calls in flight -- workload 3's kernel -- in both list orders; compared with each other only)
+               ("19 calls in flight, a wavefront per history", {"TBC_BENCH_FORM_BUSY": "0.3"}),
+               ("19 calls in flight, a wavefront per history, lists in order of completion", {"TBC_BENCH_FORM_BUSY": "0.3", "TBC_NARROW_ORDER": "1"}),
+               ("19 calls in flight, a wavefront per history, lists in order of completion, a write 24 ranks later", {"TBC_BENCH_FORM_BUSY": "0.3", "TBC_NARROW_ORDER": "40"}),
                ("pack + open counts by four wavefronts per history, tables in LDS", {"TBC_PACK_WG": "2"}),
                ("lean tables: list entries {call, twin mask}, 8 B lookahead records", {"TBC_NARROW_LEAN": "1"}),
                # (4 lanes per history = 16 histories a wavefront: the oracle counts 30 % more rounds a history in completion order, 39 % in slot
                # order, for the same probes -- and half the wavefront iterations a history-round; emulator-tested, never run on the device)
                ("4 lanes per history, lists in order of completion, lean tables", {"TBC_BENCH_FORM_LANES": "4", "TBC_NARROW_ORDER": "1", "TBC_NARROW_LEAN": "1"}),
-               # (a wavefront per history at 19 calls in flight -- workload 3's kernel -- in both list orders; compared with each other only)
-               ("19 calls in flight, a wavefront per history", {"TBC_BENCH_FORM_BUSY": "0.3"}),
-               ("19 calls in flight, a wavefront per history, lists in order of completion", {"TBC_BENCH_FORM_BUSY": "0.3", "TBC_NARROW_ORDER": "1"}),
-               ("19 calls in flight, a wavefront per history, lists in order of completion, a write 24 ranks later", {"TBC_BENCH_FORM_BUSY": "0.3", "TBC_NARROW_ORDER": "40"}),
                ("19 calls in flight, a wavefront per history, lists in order of completion, writes last", {"TBC_BENCH_FORM_BUSY": "0.3", "TBC_NARROW_ORDER": "2"}),
                # (round 4 measured 16 lanes per history LOSING to a wavefront per history there, 4.06 s against 1.83 s per 8,192; in completion order
                # the oracle counts 27.9k rounds a history for it, four histories a wavefront, against the wide schedule's 16.9k for one)
