@@ -507,6 +507,81 @@ def leg_batch_forms(args, local_rank):
     return out
 
 
+def _pick(d, *keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+
+
+def compact_line(line):
+    """The ONE line the driver parses (last line of stdout): every field the bench contract names, `roofline`, `cpu_baseline`
+    and a small `extra` -- at most 4 KB whatever the legs returned (the driver keeps a 13.7 KB tail of stdout; round 4's line
+    outgrew it and the round went unmeasured).  Everything else is in the full object: gpurun_out/bench_full.json and, one
+    line, on stderr.  tests/test_bench_line.py builds this from a worst-case payload and checks the size and the keys."""
+    out = _pick(line, "metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data")
+    out["config"] = _pick(line.get("config", {}), "workload", "histories_per_gpu", "ops_after_pairing", "processes", "busy", "info_rate",
+                          "batches_in_flight", "search_width", "lanes_per_history", "list_order", "parallelism")
+    out["roofline"] = _pick(line.get("roofline", {}), "bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms",
+                            "probes_per_launch", "new_configs_per_launch", "algorithmic_bytes_per_launch")
+    cb = line.get("cpu_baseline")
+    if cb is not None:
+        c = _pick(cb, "value", "unit", "cores", "kind")
+        c["sample"] = str(cb.get("sample", ""))[:120]
+        if "single_thread" in cb:
+            c["single_thread"] = _pick(cb["single_thread"], "value", "ms_per_history")
+        ss = cb.get("same_schedule_as_kernel")
+        if ss:
+            c["same_schedule"] = {"single_thread": ss.get("value"), "all_cores": (ss.get("all_cores") or {}).get("value")}
+        out["cpu_baseline"] = c
+    ex, e = line.get("extra", {}), {}
+    e.update(_pick(ex, "valid", "unknown", "device_GB_per_batch", "h2d_inclusive_hist_per_s"))
+    if "device_ms" in ex:
+        e["device_ms"] = _pick(ex["device_ms"], "init_memsets", "pack", "search", "retries", "search_waiting_for_its_turn")
+    if "one_batch_at_a_time" in ex:
+        a = ex["one_batch_at_a_time"]
+        e["one_batch_at_a_time"] = {"value": a.get("value"), "search_ms": (a.get("device_ms") or {}).get("search"), "pack_ms": (a.get("device_ms") or {}).get("pack"),
+                                    "roofline_frac": a.get("roofline_frac")}
+    if "time_to_verdict_ms" in ex:
+        e["time_to_verdict_ms"] = _pick(ex["time_to_verdict_ms"], "valid_median", "valid_min", "answered_by_sweep", "of", "invalid_example",
+                                        "depth_first_with_witness_median", "vs_cpu_port_single_thread", "vs_cpu_same_schedule_single_thread", "split_us")
+    if isinstance(ex.get("tiers"), list):       # six short rows: [crashed-op rate, bad read planted, GPU ms, verdict, plain CPU port ms, the same passes on one CPU core ms]
+        e["tiers"] = {"cols": ["info", "bad_read", "gpu_ms", "verdict", "cpu_port_ms", "cpu_same_alg_ms"],
+                      "rows": [[t.get("info_rate"), int(t.get("history") != "as generated"), t.get("gpu_ms"), t.get("gpu_verdict"), t.get("cpu_port_ms"),
+                                t.get("cpu_same_algorithm_ms")] for t in ex["tiers"][:6]]}
+    elif "tiers" in ex:
+        e["tiers"] = ex["tiers"]
+    for w in ("workload_2", "workload_3", "workload_crashed"):
+        d = ex.get(w)
+        if isinstance(d, dict):
+            e[w] = {"error": str(d["error"])[:100]} if "error" in d else {
+                "value": d.get("value"), "histories": d.get("histories_per_gpu"), "unknown": d.get("unknown"), "frac": (d.get("roofline") or {}).get("frac"),
+                "traffic": (d.get("roofline") or {}).get("traffic"), "kernel_ms": (d.get("roofline") or {}).get("kernel_ms"), "cpu": (d.get("cpu_baseline") or {}).get("value")}
+    d = ex.get("set_full")
+    if isinstance(d, dict):
+        e["set_full"] = {"error": str(d["error"])[:100]} if "error" in d else {"scan_ms": d.get("scan_ms"), "end_to_end_ms": d.get("end_to_end_ms"),
+                                                                              "frac": (d.get("roofline") or {}).get("frac")}
+    if "one_history_over_all_gpus" in ex:
+        e["one_history_over_all_gpus"] = ex["one_history_over_all_gpus"]
+    e["full"] = "gpurun_out/bench_full.json"
+    out["extra"] = e
+    return out
+
+
+def emit(line):
+    """Full object -> gpurun_out/bench_full.json + stderr; the compact line -> stdout, last."""
+    full = json.dumps(line)
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "bench_full.json"), "w") as fh:
+            fh.write(full + "\n")
+    except OSError:
+        pass
+    print("[bench full] " + full, file=sys.stderr, flush=True)
+    small = json.dumps(compact_line(line), separators=(",", ":"))
+    assert len(small) < 8192, len(small)
+    sys.stdout.flush()
+    print(small, flush=True)
+
+
 LEGS = {"tiers": leg_tiers, "one_batch_form": leg_one_batch_form, "batch_forms": leg_batch_forms, "one_form": leg_one_form, "single_history_forms": leg_single_history_forms, "set_full": leg_set_full,
         "workload_2": lambda a, d: leg_workload(a, d, "workload_2"), "workload_3": lambda a, d: leg_workload(a, d, "workload_3"),
         "workload_crashed": lambda a, d: leg_workload(a, d, "workload_crashed")}
@@ -576,7 +651,8 @@ def main():
     ap.add_argument("--batch4", type=int, default=8192, help="crashed workload: histories per GPU")
     ap.add_argument("--no-tiers", action="store_true", help="skip the crashed-op tiers (extra.tiers)")
     ap.add_argument("--no-set-full", action="store_true", help="skip the checker/set-full scan (extra.set_full)")
-    ap.add_argument("--no-forms", action="store_true", help="skip extra.single_history_forms (one history under every form of the single-history path)")
+    ap.add_argument("--forms", action="store_true", help="also run the two form legs (one history / a batch under every switched-off form of the library): never part "
+                                                        "of the default run; their results go to gpurun_out/bench_full.json, not into the line")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--only-headline", action="store_true",
                     help="the warm-up and the timed steps only (no extra legs): what scripts/gpu_profile_r04.sh runs under rocprofv3 --kernel-trace "
@@ -909,6 +985,8 @@ def main():
             rgp = core.check_ops(hists[planted], model, o_sweep)
             assert rgp["valid"] == 0 and rgp["fail_op"] == rp["fail_op"], "the planted history's failing op"
             line["extra"]["time_to_verdict_ms"]["vs_cpu_port_single_thread"] = round((tc / S1 * 1e3) / statistics.median(ttv), 2)
+            # ... and against the best single-thread CPU formulation of this repo (the kernel's own schedule with the dominance rules)
+            line["extra"]["time_to_verdict_ms"]["vs_cpu_same_schedule_single_thread"] = round((tw / S1 * 1e3) / statistics.median(ttv), 2)
 
             if not args.no_tiers:
                 line["extra"]["tiers"] = run_leg("tiers", args, local_rank)
@@ -922,7 +1000,7 @@ def main():
                 line["extra"]["workload_crashed"] = run_leg("workload_crashed", args, local_rank)
         if world == 1 and not args.no_set_full:
             line["extra"]["set_full"] = run_leg("set_full", args, local_rank)
-        if world == 1 and on_gpu and not args.only_headline and not args.no_forms:
+        if world == 1 and on_gpu and not args.only_headline and args.forms:
             # the two form legs measure what has not been timed on the device yet: they report, they never fail the run, and they never make
             # it long -- each has a budget of its own (TBC_BENCH_FORMS_BUDGET_S), and a run that is past five minutes skips what is left
             for name in ("single_history_forms", "batch_forms"):
@@ -933,7 +1011,7 @@ def main():
                     line["extra"][name] = run_leg(name, args, local_rank)
                 except SystemExit as e:
                     line["extra"][name] = {"error": str(e)}
-        print(json.dumps(line), flush=True)
+        emit(line)
     for b in batches:
         b.close()
     if world > 1:
