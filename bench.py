@@ -22,7 +22,7 @@
              duration, measured with HIP events on the pass's own stream (from the moment the search
              has the device to its end: with two batches in flight that is the search beside the other
              batch's pack); traffic = FETCH_SIZE + WRITE_SIZE of the committed rocprofv3 passes
-             (profiles/r04_traffic.json), copied only if kernel sources and configuration match
+             (profiles/r05_traffic.json), copied only if kernel sources and configuration match
   cpu_baseline : the CPU restatement of the same search (oracle/wgl_window.c, "port") on a bounded
              sample of the same histories: on all host cores (pthread pool, oracle/many.c) = `value`,
              and on one thread (`single_thread`)
@@ -168,14 +168,14 @@ def leg_workload(args, local_rank, which):
         o2 = core.make_opts(device=local_rank, time_limit_ms=600000, want_witness=False, algorithm=N.ALG_COMPETITION,
                             search_width=args.width, visited_per_op=vpo)
         with core.Batch(h2, model, o2) as b2:
-            width2, lanes2 = b2.search_width(), b2.lanes_per_history()
+            width2, lanes2, order2 = b2.search_width(), b2.lanes_per_history(), b2.list_order()
             if warm:
                 b2.run()
             t2 = time.perf_counter(); b2.run(); t2 = time.perf_counter() - t2
             c2 = b2.counters(); tm2 = b2.timing_ns(); v2 = b2.verdicts()
         alg2 = 16 * (c2["probes"] - c2["visited"]) + 32 * c2["visited"]
         k2 = (tm2["search"] + tm2["retries"]) / 1e6
-        out = {"workload": workload_name(args.ops, args.procs, busy, info), "histories_per_gpu": B2, "search_width": width2, "lanes_per_history": lanes2,
+        out = {"workload": workload_name(args.ops, args.procs, busy, info), "histories_per_gpu": B2, "search_width": width2, "lanes_per_history": lanes2, "list_order": order2,
                "value": round(B2 / t2, 2), "unit": "histories/s", "ms_per_step": round(t2 * 1e3, 3),
                "valid": int((v2 == N.VALID).sum()), "unknown": int((v2 == N.UNKNOWN).sum()),
                "roofline": {"bound": "hbm", "achieved": round(alg2 / (k2 * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -203,7 +203,8 @@ def leg_workload(args, local_rank, which):
             cores, _, _ = usable_cores()
             dd = [h2[i].as_dict() for i in range(min(cpu_n, B2))]
             tcp = time.perf_counter()
-            vv, started = wgl.check_many(dd, {"kind": 1, "init": N.NIL}, cores, max_steps=cpu_cap, beam_width=width2 if width2 > 1 else 4)
+            vv, started = wgl.check_many(dd, {"kind": 1, "init": N.NIL}, cores, max_steps=cpu_cap, beam_width=width2 if width2 > 1 else 4,
+                                         list_order=order2 if order2 >= 16 else wgl.ORACLE_LIST_ORDER[order2 - 1])          # (the kernel's own list order)
             tcp = time.perf_counter() - tcp
             done = int((vv != -1).sum())
             assert all(int(vv[i]) in (-1, int(v2[i])) for i in range(len(dd))), "GPU and oracle disagree on the second workload's sample"
@@ -284,229 +285,6 @@ def leg_set_full(args, local_rank):
                          "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "setfull_any_kernel + setfull_resolve_kernel"}}
 
 
-# ---- extra.single_history_forms: ONE history through tbc_check under every form of the single-history path that exists in the
-# library behind an environment switch (include/tbcheck.h lists them).  The switches are read once per process, so every form
-# runs in a process of its own; the forms other than the default were verified under the wavefront emulator (tests/emu) and had
-# not all been timed on the device when they were committed -- this leg is their measurement, and it can never cost the line:
-# a form that faults, times out or disagrees leaves {"error": ...} / "counters_match": false in its own entry.
-# (in order of what is wanted most: a leg has a time budget -- TBC_BENCH_FORMS_BUDGET_S, default 80 s -- and the forms it does not get to say so)
-FORMS = [("K6w, 8 wavefronts per segment (the default)", {}),
-         ("K6w + compact walk + narrow passes by one wavefront + fingerprint", {"TBC_SWEEP_WG_COMPACT": "2", "TBC_SWEEP_WG_FP": "1"}),
-         ("pack + open counts by sixteen wavefronts + K6w compact + narrow + fingerprint", {"TBC_PACK_ONE": "2", "TBC_SWEEP_WG_COMPACT": "2", "TBC_SWEEP_WG_FP": "1"}),
-         ("K6w + compact walk + narrow passes by one wavefront", {"TBC_SWEEP_WG_COMPACT": "2"}),
-         ("pack + open counts by sixteen wavefronts, one launch", {"TBC_PACK_ONE": "2"}),
-         ("K6w + compact walk", {"TBC_SWEEP_WG_COMPACT": "1"}),
-         ("K6w + fingerprint", {"TBC_SWEEP_WG_FP": "1"}),
-         ("pack by a workgroup's sixteen wavefronts", {"TBC_PACK_ONE": "1"}),
-         ("K6w + ring + fingerprint", {"TBC_SWEEP_WG_RING": "1", "TBC_SWEEP_WG_FP": "1"}),
-         ("K6 (one wavefront per segment)", {"TBC_SWEEP_WG": "0"}),
-         ("K6w + ring", {"TBC_SWEEP_WG_RING": "1"}),
-         ("K6w, 16 wavefronts on the big sets", {"TBC_SWEEP_WG": "16"})]
-
-
-def leg_one_form(args, local_rank):
-    """One form (this process's environment): best-of-3 time to verdict of 10 valid histories and one invalid one, and the
-    counters every form must agree on."""
-    np, N, columns, core, synth = _gpu_imports()
-    model = core.make_model(N.MODEL_CAS_REGISTER, N.NIL)
-    o = core.make_opts(device=local_rank, want_witness=False, algorithm=N.ALG_COMPETITION)
-    hs = synth.register_ops_many(range(10), n_ops=args.ops, n_procs=args.procs, busy=args.busy, info=0.0)
-    bad = columns.pair_events(synth.register_events(n_ops=args.ops, n_procs=args.procs, seed=12345, busy=args.busy, info=0.0, corrupt=0.5))
-    core.check_ops(hs[0], model, o); core.check_ops(hs[0], model, o)
-    tt, sig, parts = [], [], []
-    for h in hs:
-        best, bp = 1e9, None
-        for _ in range(3):
-            t = time.perf_counter(); r = core.check_ops(h, model, o); dt = (time.perf_counter() - t) * 1e3
-            if dt < best:
-                best, bp = dt, (r["ns_pack"] / 1e3, r["ns_search"] / 1e3, r["ns_total"] / 1e3)
-        tt.append(best); parts.append(bp); sig.append([int(r["valid"]), int(r["analyzer"]), int(r["steps"]), int(r["visited"]), int(r["probes"])])
-    t = time.perf_counter(); rb = core.check_ops(bad, model, o); tb = (time.perf_counter() - t) * 1e3
-    sig.append([int(rb["valid"]), int(rb["analyzer"]), -1 if rb["fail_op"] is None else int(rb["fail_op"])])
-    med = lambda k: round(statistics.median(p[k] for p in parts), 1)
-    return {"valid_median_ms": round(statistics.median(tt), 3), "valid_min_ms": round(min(tt), 3), "valid_max_ms": round(max(tt), 3),
-            "invalid_example_ms": round(tb, 3),
-            # where a call's time goes (medians over the histories' best runs): HIP events around the pack kernels and around the
-            # search (the sweep and what follows it), wall time inside tbc_check, and what the ctypes binding adds around it
-            "breakdown_us": {"device_pack": med(0), "device_search": med(1), "inside_tbc_check": med(2),
-                             "binding_around_it": round(statistics.median(tt) * 1e3 - med(2), 1)},
-            "signature": sig}
-
-
-def leg_single_history_forms(args, local_rank):
-    import subprocess
-    out, base = [], None
-    t_leg = time.time()
-    budget = float(os.environ.get("TBC_BENCH_FORMS_BUDGET_S", "80"))
-    for name, env in FORMS:
-        entry = {"form": name, "env": env}
-        if time.time() - t_leg > budget:
-            entry["skipped"] = f"the leg's {budget:.0f} s were spent (TBC_BENCH_FORMS_BUDGET_S)"
-            out.append(entry)
-            continue
-        leg("form: " + name)
-        try:
-            cmd = [sys.executable, os.path.abspath(__file__)] + [a for a in sys.argv[1:] if a not in ("--leg", "single_history_forms")] + ["--leg", "one_form"]
-            r = subprocess.run(cmd, stdout=subprocess.PIPE, timeout=120, env=dict(os.environ, LOCAL_RANK=str(local_rank), **env))
-            res = None
-            for ln in reversed(r.stdout.decode(errors="replace").splitlines()):
-                if ln.startswith("{"):
-                    try:
-                        d = json.loads(ln)
-                    except ValueError:
-                        continue
-                    if d.get("leg") == "one_form":
-                        res = d["result"]
-                        break
-            if res is None or r.returncode != 0:
-                entry["error"] = f"return code {r.returncode}, no result"
-            else:
-                sig = res.pop("signature")
-                if not env:
-                    base = sig
-                entry.update(res)
-                entry["_sig"] = sig
-        except subprocess.TimeoutExpired:
-            entry["error"] = "did not finish within 120 s"
-        out.append(entry)
-    for e in out:          # the same verdicts, analyzer, failing op and sweep counters as the default form (which the GPU tests pin to the oracle)
-        sig = e.pop("_sig", None)
-        if sig is not None:
-            e["counters_match"] = base is not None and sig == base
-    return out
-
-
-# ---- extra.batch_forms: ONE resident batch of the headline workload (a quarter of its size) under the switchable forms of the batch
-# path, each in a process of its own (the switches are read once per process), never fatal -- as extra.single_history_forms.
-BATCH_FORMS = [("pack_kernel + open_counts_kernel (the default)", {}),
-               ("lean tables + lazy lookahead + lists in order of completion + pack by four wavefronts", {"TBC_NARROW_LEAN": "2", "TBC_NARROW_ORDER": "1", "TBC_PACK_WG": "2"}),
-               ("lists in order of completion", {"TBC_NARROW_ORDER": "1"}),
-               ("lean tables + lazy lookahead", {"TBC_NARROW_LEAN": "2"}),
-               # (order 2: in order of completion with the :write calls last -- a :cas the state allows now before a :write; oracle: 5 % fewer rounds
-               # than order 1 here, a quarter fewer at 19 calls in flight)
-               ("lists in order of completion, writes last", {"TBC_NARROW_ORDER": "2"}),
-               # (order 16 + W: a :write as if it completed W ranks later, the soft form; W = 24: the best of the oracle's scan at 6, 19 and 32 in flight)
-               ("lean tables + lazy lookahead + lists in order of completion, a write 24 ranks later", {"TBC_NARROW_LEAN": "2", "TBC_NARROW_ORDER": "40"}),
-               # (a wavefront per history at 19 calls in flight -- workload 3's kernel -- in both list orders; compared with each other only)
-               ("19 calls in flight, a wavefront per history", {"TBC_BENCH_FORM_BUSY": "0.3"}),
-               ("19 calls in flight, a wavefront per history, lists in order of completion", {"TBC_BENCH_FORM_BUSY": "0.3", "TBC_NARROW_ORDER": "1"}),
-               ("19 calls in flight, a wavefront per history, lists in order of completion, a write 24 ranks later", {"TBC_BENCH_FORM_BUSY": "0.3", "TBC_NARROW_ORDER": "40"}),
-               ("pack + open counts by four wavefronts per history, tables in LDS", {"TBC_PACK_WG": "2"}),
-               ("lean tables: list entries {call, twin mask}, 8 B lookahead records", {"TBC_NARROW_LEAN": "1"}),
-               # (4 lanes per history = 16 histories a wavefront: the oracle counts 30 % more rounds a history in completion order, 39 % in slot
-               # order, for the same probes -- and half the wavefront iterations a history-round; emulator-tested, never run on the device)
-               ("4 lanes per history, lists in order of completion, lean tables", {"TBC_BENCH_FORM_LANES": "4", "TBC_NARROW_ORDER": "1", "TBC_NARROW_LEAN": "1"}),
-               ("19 calls in flight, a wavefront per history, lists in order of completion, writes last", {"TBC_BENCH_FORM_BUSY": "0.3", "TBC_NARROW_ORDER": "2"}),
-               # (round 4 measured 16 lanes per history LOSING to a wavefront per history there, 4.06 s against 1.83 s per 8,192; in completion order
-               # the oracle counts 27.9k rounds a history for it, four histories a wavefront, against the wide schedule's 16.9k for one)
-               ("19 calls in flight, 16 lanes per history, lists in order of completion", {"TBC_BENCH_FORM_BUSY": "0.3", "TBC_BENCH_FORM_LANES": "16", "TBC_NARROW_ORDER": "1"}),
-               ("4 lanes per history, lists in order of completion", {"TBC_BENCH_FORM_LANES": "4", "TBC_NARROW_ORDER": "1"}),
-               ("4 lanes per history", {"TBC_BENCH_FORM_LANES": "4"}),
-               # (32 in flight: a pass is its slowest history -- on oracle samples of 16-32 histories the order moves the tail by 0.7x .. 7x either way)
-               ("32 calls in flight, a wavefront per history", {"TBC_BENCH_FORM_BUSY": "0.5"}),
-               ("32 calls in flight, a wavefront per history, lists in order of completion, a write 24 ranks later", {"TBC_BENCH_FORM_BUSY": "0.5", "TBC_NARROW_ORDER": "40"}),
-               ("32 calls in flight, a wavefront per history, lists in order of completion", {"TBC_BENCH_FORM_BUSY": "0.5", "TBC_NARROW_ORDER": "1"})]
-
-
-def leg_one_batch_form(args, local_rank):
-    """One form (this process's environment): a batch of 8,192 headline histories with one planted invalid one, by the narrow kernel named
-    outright (8 lanes per history: what the library takes by itself from 24,576 histories), three passes; the device-time
-    breakdown of the best, and the counters every form must agree on."""
-    np, N, columns, core, synth = _gpu_imports()
-    model = core.make_model(N.MODEL_CAS_REGISTER, N.NIL)
-    busy_form = os.environ.get("TBC_BENCH_FORM_BUSY")
-    if busy_form:        # another workload: more calls in flight, a wavefront per history (what the library takes there), a smaller batch
-        heavy = float(busy_form) > 0.4          # (32 in flight: 2^21-entry first sets as workload 2's, fewer histories, one pass)
-        B = 1024 if heavy else 2048
-        hs = synth.register_ops_many(range(6_000_000, 6_000_000 + B), n_ops=args.ops, n_procs=args.procs, busy=float(busy_form), info=0.0)
-        o = core.make_opts(device=local_rank, time_limit_ms=600000, want_witness=False, algorithm=N.ALG_COMPETITION, search_width=args.width,
-                           visited_per_op=256 if heavy else 32, lanes_per_history=int(os.environ.get("TBC_BENCH_FORM_LANES", "0")))
-        best = None
-        with core.Batch(hs, model, o) as b:
-            lanes = b.lanes_per_history()
-            for _ in range(1 if heavy else 2):
-                t = time.perf_counter(); b.run(); dt = (time.perf_counter() - t) * 1e3
-                tm = b.timing_ns()
-                if best is None or dt < best[0]:
-                    best = (dt, tm)
-            c = b.counters(); v = b.verdicts()
-        return {"histories": B, "busy": float(busy_form), "lanes_per_history": lanes, "ms_per_pass": round(best[0], 3),
-                "device_ms": {k: round(x / 1e6, 3) for k, x in best[1].items()}, "probes": int(c["probes"]), "new_configs": int(c["visited"]),
-                "signature": [int((v == N.VALID).sum()), int((v == N.INVALID).sum()), -1, int(c["probes"]), int(c["visited"])]}
-    B = 8192
-    hs = synth.register_ops_many(range(5_000_000, 5_000_000 + B), n_ops=args.ops, n_procs=args.procs, busy=args.busy, info=0.0)
-    hp = columns.pair_events(synth.register_events(n_ops=args.ops, n_procs=args.procs, seed=5_000_077, busy=args.busy, info=0.0, corrupt=0.02, n_values=4))
-    hp.a[hp.a == 4 + 7] = 4          # (the planted read's value inside the batch's domain: compact front records, as the headline's batches)
-    hs[77] = hp
-    o = core.make_opts(device=local_rank, time_limit_ms=600000, want_witness=False, algorithm=N.ALG_COMPETITION, visited_per_op=args.visited_per_op,
-                       lanes_per_history=int(os.environ.get("TBC_BENCH_FORM_LANES", "8")))
-    best = None
-    with core.Batch(hs, model, o) as b:
-        lanes = b.lanes_per_history()
-        for _ in range(4):
-            t = time.perf_counter(); b.run(); dt = (time.perf_counter() - t) * 1e3
-            tm = b.timing_ns()
-            if best is None or dt < best[0]:
-                best = (dt, tm)
-        c = b.counters(); v = b.verdicts()
-    return {"histories": B, "lanes_per_history": lanes, "ms_per_pass": round(best[0], 3),
-            "device_ms": {k: round(x / 1e6, 3) for k, x in best[1].items()},
-            "signature": [int((v == N.VALID).sum()), int((v == N.INVALID).sum()), int(np.flatnonzero(v == N.INVALID)[0]) if (v == N.INVALID).any() else -1,
-                          int(c["probes"]), int(c["visited"])]}
-
-
-def leg_batch_forms(args, local_rank):
-    import subprocess
-    out, base = [], None
-    t_leg = time.time()
-    budget = float(os.environ.get("TBC_BENCH_FORMS_BUDGET_S", "80")) * 1.3        # (the forms it does not get to say so)
-    for name, env in BATCH_FORMS:
-        entry = {"form": name, "env": env}
-        if time.time() - t_leg > budget:
-            entry["skipped"] = f"the leg's {budget:.0f} s were spent (TBC_BENCH_FORMS_BUDGET_S x 1.3)"
-            out.append(entry)
-            continue
-        leg("batch form: " + name)
-        try:
-            cmd = [sys.executable, os.path.abspath(__file__)] + [a for a in sys.argv[1:] if a not in ("--leg", "batch_forms")] + ["--leg", "one_batch_form"]
-            r = subprocess.run(cmd, stdout=subprocess.PIPE, timeout=150, env=dict(os.environ, LOCAL_RANK=str(local_rank), **env))
-            res = None
-            for ln in reversed(r.stdout.decode(errors="replace").splitlines()):
-                if ln.startswith("{"):
-                    try:
-                        d = json.loads(ln)
-                    except ValueError:
-                        continue
-                    if d.get("leg") == "one_batch_form":
-                        res = d["result"]
-                        break
-            if res is None or r.returncode != 0:
-                entry["error"] = f"return code {r.returncode}, no result"
-            else:
-                sig = res.pop("signature")
-                grp = env.get("TBC_BENCH_FORM_BUSY", "")          # (a form is compared with the first of its own workload)
-                if not isinstance(base, dict):
-                    base = {}
-                base.setdefault(grp, sig)
-                entry.update(res)
-                entry["_sig"] = sig
-        except subprocess.TimeoutExpired:
-            entry["error"] = "did not finish within 150 s"
-        out.append(entry)
-    for e in out:          # the same verdicts, the same planted history found, the same probes and new configs as the default form
-        sig = e.pop("_sig", None)
-        if sig is not None:
-            b0 = (base or {}).get(e["env"].get("TBC_BENCH_FORM_BUSY", "")) if isinstance(base, dict) else None
-            e["counters_match"] = b0 is not None and sig == b0
-            # (the lean lookahead record reads three or more open producers as "one is still to come": its schedule is the oracle's
-            # look_two, a handful of probes away from the default's on such histories; lists in order of completion are another
-            # schedule altogether (fewer rounds) -- verdicts and the planted history must agree)
-            e["verdicts_match"] = b0 is not None and sig[:3] == b0[:3]
-            if b0 is not None and sig != b0:
-                e["probes_vs_default"] = [sig[3] - b0[3], sig[4] - b0[4]]
-    return out
-
-
 def _pick(d, *keys):
     return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
 
@@ -582,7 +360,7 @@ def emit(line):
     print(small, flush=True)
 
 
-LEGS = {"tiers": leg_tiers, "one_batch_form": leg_one_batch_form, "batch_forms": leg_batch_forms, "one_form": leg_one_form, "single_history_forms": leg_single_history_forms, "set_full": leg_set_full,
+LEGS = {"tiers": leg_tiers, "set_full": leg_set_full,
         "workload_2": lambda a, d: leg_workload(a, d, "workload_2"), "workload_3": lambda a, d: leg_workload(a, d, "workload_3"),
         "workload_crashed": lambda a, d: leg_workload(a, d, "workload_crashed")}
 
@@ -651,11 +429,9 @@ def main():
     ap.add_argument("--batch4", type=int, default=8192, help="crashed workload: histories per GPU")
     ap.add_argument("--no-tiers", action="store_true", help="skip the crashed-op tiers (extra.tiers)")
     ap.add_argument("--no-set-full", action="store_true", help="skip the checker/set-full scan (extra.set_full)")
-    ap.add_argument("--forms", action="store_true", help="also run the two form legs (one history / a batch under every switched-off form of the library): never part "
-                                                        "of the default run; their results go to gpurun_out/bench_full.json, not into the line")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--only-headline", action="store_true",
-                    help="the warm-up and the timed steps only (no extra legs): what scripts/gpu_profile_r04.sh runs under rocprofv3 --kernel-trace "
+                    help="the warm-up and the timed steps only (no extra legs): what scripts/gpu_profile_r05.sh runs under rocprofv3 --kernel-trace "
                          "--stats, so that the kernel's average duration there is the one of the timed region")
     ap.add_argument("--sharded-ttv", action="store_true",
                     help="N > 1 only: also time ONE history swept by all N GPUs (shard.check_sharded: wavefronts dealt to the ranks, "
@@ -754,6 +530,7 @@ def main():
     lanes = batch.lanes_per_history()             # 8 / 16 / 32: several histories per wavefront (one config per iteration); 64: one
     narrow = lanes != 64
     kname = "wgl_narrow_kernel" if narrow else ("wgl_search_kernel" if width == 1 else "wgl_beam_kernel")
+    batch_list_order = batch.list_order() if hasattr(batch, "list_order") else None      # TBC_ORDER_*: what tbc_opts.list_order = 0 became (16 + 24 for the headline batch)
 
     # a step = one pass (init + pack + search + verdicts back) over one resident batch.  Step i goes to batch i % F; each batch
     # has its own host thread and stream, so up to F passes are in flight (tbc_batch_run is a blocking C call that releases the GIL)
@@ -852,6 +629,7 @@ def main():
                        "processes": args.procs, "busy": args.busy, "info_rate": args.info,
                        "batches_in_flight": F,
                        "search_width": width, "search_width_asked": args.width, "lanes_per_history": lanes, "histories_per_wavefront": 64 // lanes,
+                       "list_order": batch_list_order,
                        "round_budget": args.round_budget,
                        "parallelism": f"independent histories sharded over {world} GPU(s), no collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -909,10 +687,17 @@ def main():
             o_sweep = core.make_opts(device=local_rank, want_witness=False, algorithm=N.ALG_COMPETITION)
             o_dfs = core.make_opts(device=local_rank, want_witness=True, algorithm=N.ALG_COMPETITION, search_width=args.width)
             core.check_ops(hists[0], model, o_sweep)                     # first call sizes the persistent context
+            parts = []
             for i in range(min(10, B)):
-                t1 = time.perf_counter(); r = core.check_ops(hists[i], model, o_sweep); ttv.append((time.perf_counter() - t1) * 1e3)
+                best, bp = 1e9, None
+                for _ in range(3):          # (best of 3 per history, the median over the histories: what round 4's form legs reported)
+                    t1 = time.perf_counter(); r = core.check_ops(hists[i], model, o_sweep); dt = (time.perf_counter() - t1) * 1e3
+                    if dt < best:
+                        best, bp = dt, (r["ns_pack"] / 1e3, r["ns_search"] / 1e3, r["ns_total"] / 1e3)
+                ttv.append(best); parts.append(bp)
                 analyzers.append(r["analyzer"])
                 assert r["valid"] == verdicts[i]
+            med = lambda k: round(statistics.median(p[k] for p in parts), 1)
             core.check_ops(hists[0], model, o_dfs)
             for i in range(min(5, B)):
                 t1 = time.perf_counter(); r = core.check_ops(hists[i], model, o_dfs); ttv_dfs.append((time.perf_counter() - t1) * 1e3)
@@ -923,7 +708,12 @@ def main():
                                                    "answered_by_sweep": sum(a == N.ALG_LINEAR for a in analyzers), "of": len(analyzers),
                                                    "depth_first_with_witness_median": round(statistics.median(ttv_dfs), 3),
                                                    "invalid_example": round(tb_gpu, 3),
-                                                   "invalid_example_verdict": rb["valid"], "invalid_example_steps": rb["steps"]}
+                                                   "invalid_example_verdict": rb["valid"], "invalid_example_steps": rb["steps"],
+                                                   # where a call's time goes (medians over the histories' best runs): HIP events around the pack and around the
+                                                   # sweep (+ what follows it), the rest of the wall time inside tbc_check (H2D, memsets, launches, D2H, the host's
+                                                   # composition of the segments' relations), and what the ctypes binding adds around the call
+                                                   "split_us": {"device_pack": med(0), "device_sweep": med(1), "rest_inside_tbc_check": round(med(2) - med(0) - med(1), 1),
+                                                                "binding": round(statistics.median(ttv) * 1e3 - med(2), 1)}}
         leg("CPU baselines")
         if world == 1 and not args.no_cpu:
             from concurrent.futures import ThreadPoolExecutor
@@ -950,13 +740,14 @@ def main():
             tb = time.perf_counter() - tb
             # the SAME schedule the kernel runs (wide, K configs per iteration, lookahead, eager reads, twin rule) on one
             # host thread: how much of the speed-up is the algorithm and how much the GPU
-            sk = dict(width=1, round_pairs=lanes, rules_at_any_round_size=True) if narrow else dict(width=width if width > 1 else 4)
+            lo = batch_list_order if batch_list_order is not None and batch_list_order >= 16 else wgl.ORACLE_LIST_ORDER[(batch_list_order or 1) - 1]      # TBC_ORDER_* -> the oracle's
+            sk = dict(width=1, round_pairs=lanes, rules_at_any_round_size=True, branch_lists=True, list_order=lo) if narrow else dict(width=width if width > 1 else 4, list_order=lo)
             tw = time.perf_counter()
             okw = sum(wgl.check_beam(d, om, want_witness=False, **sk)["valid"] == 1 for d in dicts[:S1])
             tw = time.perf_counter() - tw
             # ... and on every CPU this container may use (oracle/many.c runs wgl_beam.c on the same thread pool)
             twa = time.perf_counter()
-            okwa, _ = wgl.check_many(work, om, cores, beam_width=sk["width"], round_pairs=lanes if narrow else 64)
+            okwa, _ = wgl.check_many(work, om, cores, beam_width=sk["width"], round_pairs=lanes if narrow else 64, list_order=lo, branch_lists=narrow)
             twa = time.perf_counter() - twa
             ts = time.perf_counter()
             oks = sum(wgl.check_sweep(d, om)["valid"] == 1 for d in dicts[:S1])
@@ -1000,17 +791,6 @@ def main():
                 line["extra"]["workload_crashed"] = run_leg("workload_crashed", args, local_rank)
         if world == 1 and not args.no_set_full:
             line["extra"]["set_full"] = run_leg("set_full", args, local_rank)
-        if world == 1 and on_gpu and not args.only_headline and args.forms:
-            # the two form legs measure what has not been timed on the device yet: they report, they never fail the run, and they never make
-            # it long -- each has a budget of its own (TBC_BENCH_FORMS_BUDGET_S), and a run that is past five minutes skips what is left
-            for name in ("single_history_forms", "batch_forms"):
-                if time.time() - t_bench0 > 300:
-                    line["extra"][name] = {"skipped": "the run was past 300 s when this leg's turn came"}
-                    continue
-                try:
-                    line["extra"][name] = run_leg(name, args, local_rank)
-                except SystemExit as e:
-                    line["extra"][name] = {"error": str(e)}
         emit(line)
     for b in batches:
         b.close()

@@ -31,7 +31,7 @@
    :model        {:size 32  :kind 0 :init 4 :table 8 :n_states 16 :n_classes 20 :n_keys 24 :flags 28}
    :opts         {:size 64  :algorithm 0 :device 4 :time_limit_ms 8 :max_steps 16 :max_visited_bytes 24
                   :want_witness 32 :visited_per_op 36 :search_width 40 :round_budget 44 :lookahead 48
-                  :dominance 52 :lanes_per_history 56 :reserved0 60}
+                  :dominance 52 :lanes_per_history 56 :list_order 60}
    :config       {:size 84  :state 0 :last_op 4 :n_pending 8 :n_linearized 12 :pending 16 :linearized_mask 80}
    :result       {:size 960 :valid 0 :cause 4 :analyzer 8 :fail_op 12 :prev_ok_op 16 :final_state 20
                   :n_witness 24 :search_width 28 :witness 32 :n_configs 40 :configs 44}

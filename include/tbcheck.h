@@ -39,7 +39,8 @@ extern "C" {
 #endif
 
 /* 2: tbc_opts grew to 64 bytes (lanes_per_history, reserved0), tbc_batch_sweep_finish gained merged_bytes, tbc_opts.dominance
- * gained TBC_DOM_NO_COUNT_FORM.  A caller built against another version must refuse the library (tbc_version()). */
+ * gained TBC_DOM_NO_COUNT_FORM.  A caller built against another version must refuse the library (tbc_version()).
+ * Still 2, additive: the word that was reserved0 (must be 0) is tbc_opts.list_order, 0 = the library's choice; tbc_batch_list_order(). */
 #define TBC_ABI_VERSION 2u
 
 /* ------------------------------------------------------------------ status */
@@ -226,8 +227,23 @@ typedef struct tbc_opts {
                              /* histories under both dominance rules with at most 10     */
                              /* calls in flight, if search_width is 0 too; else 64.      */
                              /* tbc_batch_lanes_per_history() says what was chosen.      */
-  uint32_t reserved0;        /* must be 0                                                */
+  uint32_t list_order;       /* depth-first search, register / cas-register: the order   */
+                             /* in which a config's open calls are tried (TBC_ORDER_*).   */
+                             /* Verdict, failing op and :previous-ok do not depend on it; */
+                             /* counters, witness and :configs are the chosen schedule's. */
+                             /* 0 = the library chooses: in order of completion with a    */
+                             /* :write as if it completed 24 ranks later (16 + 24) where  */
+                             /* it applies (one mask word, no level sweep beside the      */
+                             /* search, no count form, no round budget), else slot order. */
+                             /* tbc_batch_list_order() says what a batch runs.            */
 } tbc_opts;
+
+/* tbc_opts.list_order.  The search takes a config's candidates last to first and pops the last child first, so the order of a
+ * front's list of open calls decides which linearization is tried first.  SLOT: by process slot (rounds 1-4; what oracle/wgl_beam.c
+ * runs unless told otherwise).  COMPLETION: the call that completes soonest first.  WRITES_LAST: ... and every :write after everything
+ * else (a :cas the state allows now before a :write, which every state allows).  16 + W: in order of completion, a :write placed as
+ * if it completed W ranks later (W <= 4096) -- the soft form; W = 24 halves the rounds at 19 calls in flight. */
+enum { TBC_ORDER_DEFAULT = 0u, TBC_ORDER_SLOT = 1u, TBC_ORDER_COMPLETION = 2u, TBC_ORDER_WRITES_LAST = 3u, TBC_ORDER_WRITE_DELAY = 16u };
 
 /* tbc_opts.dominance bits (set = rule OFF).  Eager reads: an open read whose value is nil or
  * the current state is linearized at once (it changes nothing, so every later schedule stays
@@ -362,6 +378,9 @@ uint64_t tbc_batch_device_bytes(const tbc_batch* b);
 uint32_t tbc_batch_search_width(const tbc_batch* b);
 /* lanes per history of the depth-first search: 4 / 8 / 16 / 32 (several histories per wavefront) or 64 */
 uint32_t tbc_batch_lanes_per_history(const tbc_batch* b);
+/* the order of the fronts' lists this batch's depth-first search runs over: TBC_ORDER_SLOT / _COMPLETION / _WRITES_LAST or 16 + W
+ * (what tbc_opts.list_order = 0 resolved to; SLOT wherever another order does not apply) */
+uint32_t tbc_batch_list_order(const tbc_batch* b);
 /* how the last run was answered when the level sweep (knossos.linear; jit_sweep.hip) is in play:
  * TBC_ALG_LINEAR always asks for it, TBC_ALG_COMPETITION on small batches that want no witness.
  * The sweep cuts a history into segments of about seg_target completions at fronts with at most

@@ -34,6 +34,8 @@ ALG_COMPETITION, ALG_WGL, ALG_LINEAR = 0, 1, 2
 VALID, INVALID, UNKNOWN = 1, 0, -1
 CAUSE_NONE, CAUSE_TIME_LIMIT, CAUSE_STEP_LIMIT, CAUSE_VISITED_FULL = 0, 1, 2, 3
 DOM_NO_EAGER_READS, DOM_NO_TWIN_RULE, DOM_NO_COUNT_FORM, DOM_NO_LAZY_COMMUTING = 1, 2, 4, 8
+# tbc_opts.list_order (16 + W: completion order, a :write as if it completed W ranks later; the default where it applies is 16 + 24)
+ORDER_DEFAULT, ORDER_SLOT, ORDER_COMPLETION, ORDER_WRITES_LAST, ORDER_WRITE_DELAY = 0, 1, 2, 3, 16
 # status
 (OK_STATUS, ERR_INVALID_ARG, ERR_BAD_HISTORY, ERR_NO_DEVICE, ERR_OOM, ERR_WINDOW_TOO_WIDE,
  ERR_MODEL, ERR_HIP, ERR_UNSUPPORTED) = range(9)
@@ -73,7 +75,7 @@ class Opts(C.Structure):
                 ("max_steps", C.c_uint64), ("max_visited_bytes", C.c_uint64),
                 ("want_witness", C.c_uint32), ("visited_per_op", C.c_uint32),
                 ("search_width", C.c_uint32), ("round_budget", C.c_uint32),
-                ("lookahead", C.c_uint32), ("dominance", C.c_uint32), ("lanes_per_history", C.c_uint32), ("reserved0", C.c_uint32)]
+                ("lookahead", C.c_uint32), ("dominance", C.c_uint32), ("lanes_per_history", C.c_uint32), ("list_order", C.c_uint32)]
 
 
 class Config(C.Structure):
@@ -162,6 +164,7 @@ SYMBOLS = {
     "tbc_batch_device_bytes": (C.c_uint64, [C.c_void_p]),
     "tbc_batch_search_width": (C.c_uint32, [C.c_void_p]),
     "tbc_batch_lanes_per_history": (C.c_uint32, [C.c_void_p]),
+    "tbc_batch_list_order": (C.c_uint32, [C.c_void_p]),
     "tbc_batch_sweep_info": (C.c_int, [C.c_void_p, C.POINTER(SweepInfo)]),
     "tbc_sweep_compose": (C.c_int, [C.POINTER(SweepRel), C.c_uint32, C.c_uint32, C.POINTER(SweepVerdict)]),
     "tbc_batch_set_shard": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),

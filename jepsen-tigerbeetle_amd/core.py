@@ -30,11 +30,13 @@ def make_model(kind, init=N.NIL, table=None, n_keys=0):
 # tbc_opts.dominance, TBC_DOM_NO_COUNT_FORM: the library's default is the count form (crashed calls as counts per effect class)
 # wherever it applies; tests that pin the mask-form schedules against their oracles switch this off (tests/conftest.py)
 DEFAULT_COUNT_FORM = True
+# tbc_opts.list_order when make_opts() is not told: 0 = the library's choice (tests/conftest.py pins slot order for the tests that compare with the slot-order oracle)
+DEFAULT_LIST_ORDER = 0
 
 
 def make_opts(algorithm=N.ALG_WGL, device=0, time_limit_ms=0, max_steps=0, max_visited_bytes=0,
               want_witness=True, visited_per_op=0, search_width=0, round_budget=0, lookahead=True,
-              eager_reads=True, twin_rule=True, lanes_per_history=0, count_form=None, lazy_commuting=True):
+              eager_reads=True, twin_rule=True, lanes_per_history=0, count_form=None, lazy_commuting=True, list_order=None):
     o = N.Opts()
     o.algorithm = algorithm
     o.device = device
@@ -48,7 +50,7 @@ def make_opts(algorithm=N.ALG_WGL, device=0, time_limit_ms=0, max_steps=0, max_v
     o.lookahead = 0 if lookahead else 1     # C-ABI: 0 = on (default), 1 = off
     o.dominance = (0 if eager_reads else N.DOM_NO_EAGER_READS) | (0 if twin_rule else N.DOM_NO_TWIN_RULE) | (0 if (DEFAULT_COUNT_FORM if count_form is None else count_form) else N.DOM_NO_COUNT_FORM) | (0 if lazy_commuting else N.DOM_NO_LAZY_COMMUTING)
     o.lanes_per_history = int(lanes_per_history)     # 8 / 16 / 32: several histories per wavefront; 64: one; 0: the library's choice
-    o.reserved0 = 0
+    o.list_order = int(DEFAULT_LIST_ORDER if list_order is None else list_order)      # N.ORDER_*: 0 = the library's choice (completion order, a :write 24 ranks later, where it applies)
     return o
 
 
@@ -234,6 +236,10 @@ class Batch:
     def lanes_per_history(self):
         """8 / 16 / 32 when several histories share a wavefront (one config per iteration), else 64."""
         return int(N.lib().tbc_batch_lanes_per_history(self._h))
+
+    def list_order(self):
+        """N.ORDER_SLOT / _COMPLETION / _WRITES_LAST or 16 + W: the order of the fronts' lists this batch's search runs over."""
+        return int(N.lib().tbc_batch_list_order(self._h))
 
     def close(self):
         if self._h:

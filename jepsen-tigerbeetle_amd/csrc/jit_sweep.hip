@@ -516,12 +516,11 @@ bool launch_sweep(const SweepArgs& a, void* stream) {
     else hipLaunchKernelGGL(jit_sweep_kernel<kSmall>, dim3(1), dim3(64), sweep_lds_words<kSmall>() * 4, s, a);
     return true;
   }
-  // TBC_SWEEP_WG = 4 / 8: a workgroup of that many wavefronts per segment (K6w, jit_sweep_wg.hip) where latency is what counts --
-  // a burst of concurrency is one segment whatever the cuts, and only more lanes on its levels shorten it (round 4, one 10k-op
-  // history through tbc_check: 2.48 -> 1.56 ms median, profiles/r04_sweep_wg_first_measurement.log).  Default 8; 0 = K6 only.
-  static const uint32_t wg = [] { const char* e = std::getenv("TBC_SWEEP_WG"); return e ? (uint32_t)std::strtoul(e, nullptr, 10) : 8u; }();
+  // a workgroup of eight wavefronts per segment (K6w, jit_sweep_wg.hip) where latency is what counts -- a burst of concurrency is
+  // one segment whatever the cuts, and only more lanes on its levels shorten it (round 4, one 10k-op history through tbc_check:
+  // 2.48 -> 1.56 ms median, profiles/r04_sweep_wg_first_measurement.log)
   if (a.seg_list) {        // second pass over the segments that overflowed the small sets
-    if (wg && a.n_list <= 4096u && launch_sweep_wg(a, wg, s)) return true;
+    if (a.n_list <= 4096u && launch_sweep_wg(a, s)) return true;
     if (!big_ok) return false;
     hipLaunchKernelGGL(jit_sweep_kernel<kBig>, dim3(a.n_list), dim3(64), sweep_lds_words<kBig>() * 4, s, a);
     return true;
@@ -529,7 +528,7 @@ bool launch_sweep(const SweepArgs& a, void* stream) {
   hipLaunchKernelGGL(sweep_cuts_kernel, dim3(a.n_hist), dim3(256), 0, s, a);
   const uint32_t waves = a.n_hist * a.max_segs * kSweepSlices;
   // few wavefronts (a history or a handful through tbc_check): a workgroup per segment
-  if (wg && waves <= 4096u && launch_sweep_wg(a, wg, s)) return true;
+  if (waves <= 4096u && launch_sweep_wg(a, s)) return true;
   // a few histories: latency is what counts and the CUs are not full -- take the larger sets, so that a burst of
   // concurrency does not cost a second pass; many: four wavefronts per CU
   if (mid_ok && waves <= 4096u) hipLaunchKernelGGL(jit_sweep_kernel<kMid>, dim3(waves), dim3(64), sweep_lds_words<kMid>() * 4, s, a);

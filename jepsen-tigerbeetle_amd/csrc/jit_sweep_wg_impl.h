@@ -30,9 +30,6 @@ namespace sweepwg {
 constexpr uint32_t kCand = kSweepCandMax;
 constexpr uint32_t kProv = 1u << 16;          // slot holds a thread number (this pass's claimant), not an entry
 constexpr uint32_t kGenShift = 17;
-// FP (experimental, see segment): the table word also carries 8 bits of the key's hash -- [generation 7][fingerprint 8][provisional 1][entry 16]
-constexpr uint32_t kGenShiftFp = 25, kFpShift = 17;
-template <bool FP> constexpr uint32_t gen_shift() { return FP ? kGenShiftFp : kGenShift; }
 
 struct __attribute__((aligned(16))) Ent { uint32_t mlo, mhi, st, org; };
 
@@ -42,13 +39,6 @@ WV_DEV uint32_t key_slot(uint32_t mlo, uint32_t mhi, uint32_t st) {
   h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 13;
   return h & (HS - 1u);
 }
-// FP: the same hash whole -- the slot from its low bits, the fingerprint from its top eight
-WV_DEV uint32_t key_hash(uint32_t mlo, uint32_t mhi, uint32_t st) {
-  uint32_t h = mlo * 0x9E3779B1u ^ mhi * 0x85EBCA77u ^ st * 0xC2B2AE3Du;
-  h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 13;
-  return h;
-}
-
 struct Build {
   Ent* e;
   uint32_t* tab;
@@ -68,12 +58,11 @@ struct Scratch {
   static constexpr uint32_t kWords = 8 * NW + 8;
 };
 
-// QUEUE (experimental, see segment): + a ring of 2 x 64 x NW children (16 B each) and their target sets (a byte each)
-// COMPACT (experimental, see segment): + a block's child offsets (16 bits a config, 64 x NW of them) and 2 x NW scan words
-template <uint32_t CAP, uint32_t NW, bool QUEUE = false, bool COMPACT = false>
+// COMPACT (see segment): + a block's child offsets (16 bits a config, 64 x NW of them) and 2 x NW scan words
+template <uint32_t CAP, uint32_t NW, bool COMPACT = false>
 constexpr uint32_t lds_words() {
   return 3 * CAP * 4 + 2 * (2 * CAP) + 64 * NW * 4 + kCand * 4 + kCand * 2 + 2 * 32 * 2 + CAP / 2 + 128 + Scratch<NW>::kWords +
-         (QUEUE ? 2 * 64 * NW * 4 + 2 * 64 * NW / 4 : 0u) + (COMPACT ? 64 * NW / 2 + 2 * NW : 0u);
+         (COMPACT ? 64 * NW / 2 + 2 * NW : 0u);
 }
 
 // exclusive prefix sum of x over the workgroup's threads (thread order), *total = the sum; every thread calls it.  Inside a
@@ -112,10 +101,10 @@ struct Ctx {
 };
 
 // Start a new set in table `tab`: a new generation makes every old slot read as empty.
-template <uint32_t HS, uint32_t NW, bool FP = false>
+template <uint32_t HS, uint32_t NW>
 WV_DEV void build_begin(Build& b, Ent* e, uint32_t* tab, uint32_t& gen_counter, const Ctx<NW>& X) {
   gen_counter++;
-  if (gen_counter >= (1u << (32 - gen_shift<FP>()))) {       // generation wrapped: really clear
+  if (gen_counter >= (1u << (32 - kGenShift))) {       // generation wrapped: really clear
     for (uint32_t i = X.tid; i < HS; i += 64 * NW) tab[i] = 0u;
     gen_counter = 1;
     wv::wg_barrier();
@@ -126,7 +115,7 @@ WV_DEV void build_begin(Build& b, Ent* e, uint32_t* tab, uint32_t& gen_counter, 
 // Insert up to 64 * NW configs, one per thread, each into set A (sel 1) or set B (sel 2), OR-ing the origin sets of equal
 // keys.  `side`: a flag per thread the callers want numbered in the same breath (sub-round 0's "still needs X" list):
 // side_off = how many threads before this one have it set, side_total = how many in all.  Returns false if a set outgrew CAP.
-template <uint32_t CAP, uint32_t NW, bool FP = false>
+template <uint32_t CAP, uint32_t NW>
 WV_DEV bool insert2(Build& A, Build& B, uint32_t sel, uint32_t mlo, uint32_t mhi, uint32_t st, uint32_t org,
                     bool side, uint32_t& side_off, uint32_t& side_total, Ctx<NW>& X) {
   using S = Scratch<NW>;
@@ -155,20 +144,16 @@ WV_DEV bool insert2(Build& A, Build& B, uint32_t sel, uint32_t mlo, uint32_t mhi
   uint32_t* const tab = sel == 2u ? B.tab : A.tab;
   Ent* const ent = sel == 2u ? B.e : A.e;
   const uint32_t gen = sel == 2u ? B.gen : A.gen;
-  uint32_t gtag = gen << gen_shift<FP>();
-  uint32_t h = key_slot<HS>(mlo, mhi, st), mine = 0, fp = 0;
-  if constexpr (FP) { const uint32_t hh = key_hash(mlo, mhi, st); fp = hh >> 24; gtag |= fp << kFpShift; }
+  const uint32_t gtag = gen << kGenShift;
+  uint32_t h = key_slot<HS>(mlo, mhi, st), mine = 0;
   bool pend = sel != 0u, won = false;
   while (wv::ballot(pend)) {
     if (pend) {
       uint32_t s = wv::lds_ld32(&tab[h]);
-      if ((s >> gen_shift<FP>()) != gen) {                      // empty: claim it with the thread number
+      if ((s >> kGenShift) != gen) {                      // empty: claim it with the thread number
         const uint32_t old = wv::lds_cas32(&tab[h], s, gtag | kProv | X.tid);
         if (old == s) { won = true; mine = h; pend = false; }
         else s = old;                                     // claimed in this very pass by another thread
-      }
-      if constexpr (FP) {                                 // another key's fingerprint: no need to look at the key
-        if (pend && ((s >> kFpShift) & 0xFFu) != fp) { h = (h + 1u) & (HS - 1u); continue; }
       }
       if (pend) {
         const Ent* kp = (s & kProv) ? &X.stage[s & 0x3FFu] : &ent[s & 0xFFFFu];
@@ -209,7 +194,7 @@ WV_DEV bool insert2(Build& A, Build& B, uint32_t sel, uint32_t mlo, uint32_t mhi
 // SOLO: insert2 for a pass that fits ONE wavefront, run by wavefront 0 alone (its 64 threads call it, nobody else): the three workgroup
 // barriers become wavefront barriers -- the other wavefronts wait at the ONE workgroup barrier behind which the caller publishes the
 // new set sizes (solo_publish / solo_collect below).  Same claims, same ORs, same entries: a set is a set.
-template <uint32_t CAP, uint32_t NW, bool FP = false>
+template <uint32_t CAP, uint32_t NW>
 WV_DEV bool insert2_solo(Build& A, Build& B, uint32_t sel, uint32_t mlo, uint32_t mhi, uint32_t st, uint32_t org,
                          bool side, uint32_t& side_off, uint32_t& side_total, Ctx<NW>& X) {
   constexpr uint32_t HS = 2 * CAP;
@@ -223,20 +208,16 @@ WV_DEV bool insert2_solo(Build& A, Build& B, uint32_t sel, uint32_t mlo, uint32_
   uint32_t* const tab = sel == 2u ? B.tab : A.tab;
   Ent* const ent = sel == 2u ? B.e : A.e;
   const uint32_t gen = sel == 2u ? B.gen : A.gen;
-  uint32_t gtag = gen << gen_shift<FP>();
-  uint32_t h = key_slot<HS>(mlo, mhi, st), mine = 0, fp = 0;
-  if constexpr (FP) { const uint32_t hh = key_hash(mlo, mhi, st); fp = hh >> 24; gtag |= fp << kFpShift; }
+  const uint32_t gtag = gen << kGenShift;
+  uint32_t h = key_slot<HS>(mlo, mhi, st), mine = 0;
   bool pend = sel != 0u, won = false;
   while (wv::ballot(pend)) {
     if (pend) {
       uint32_t s = wv::lds_ld32(&tab[h]);
-      if ((s >> gen_shift<FP>()) != gen) {
+      if ((s >> kGenShift) != gen) {
         const uint32_t old = wv::lds_cas32(&tab[h], s, gtag | kProv | X.tid);
         if (old == s) { won = true; mine = h; pend = false; }
         else s = old;
-      }
-      if constexpr (FP) {
-        if (pend && ((s >> kFpShift) & 0xFFu) != fp) { h = (h + 1u) & (HS - 1u); continue; }
       }
       if (pend) {
         const Ent* kp = (s & kProv) ? &X.stage[s & 0x3FFu] : &ent[s & 0xFFFFu];
@@ -275,83 +256,11 @@ WV_DEV void solo_exchange(Build& A, Build& B, bool& fits, uint32_t& side_total, 
   A.n = w0 & 0xFFFFu; B.n = w0 >> 16; fits = (w1 & 1u) != 0u; side_total = w1 >> 1;
 }
 
-// QUEUE: insert `cnt` (<= 64 * NW, the same in every thread) children from the ring, starting at qh: they are staged where they lie
-// (one barrier makes them visible), a claim carries the RING position.
-template <uint32_t CAP, uint32_t NW, bool FP = false>
-WV_DEV bool insert_q(Build& A, Build& B, Ent* wq, const uint8_t* wq_sel, uint32_t qh, uint32_t cnt, Ctx<NW>& X) {
-  using S = Scratch<NW>;
-  constexpr uint32_t HS = 2 * CAP, QM = 2 * 64 * NW - 1;
-  wv::wg_barrier();                                           // the children the passes wrote into the ring are visible
-  const uint32_t at = (qh + X.tid) & QM;
-  const Ent c = wq[at];
-  const uint32_t sel = X.tid < cnt ? (uint32_t)wq_sel[at] : 0u;
-  const uint32_t mlo = c.mlo, mhi = c.mhi, st = c.st, org = c.org;
-  uint32_t* const tab = sel == 2u ? B.tab : A.tab;
-  Ent* const ent = sel == 2u ? B.e : A.e;
-  const uint32_t gen = sel == 2u ? B.gen : A.gen;
-  uint32_t gtag = gen << gen_shift<FP>();
-  uint32_t h = key_slot<HS>(mlo, mhi, st), mine = 0, fp = 0;
-  if constexpr (FP) { const uint32_t hh = key_hash(mlo, mhi, st); fp = hh >> 24; gtag |= fp << kFpShift; }
-  bool pend = sel != 0u, won = false;
-  while (wv::ballot(pend)) {
-    if (pend) {
-      uint32_t s = wv::lds_ld32(&tab[h]);
-      if ((s >> gen_shift<FP>()) != gen) {
-        const uint32_t old = wv::lds_cas32(&tab[h], s, gtag | kProv | at);
-        if (old == s) { won = true; mine = h; pend = false; }
-        else s = old;
-      }
-      if constexpr (FP) {
-        if (pend && ((s >> kFpShift) & 0xFFu) != fp) { h = (h + 1u) & (HS - 1u); continue; }
-      }
-      if (pend) {
-        const Ent* kp = (s & kProv) ? &wq[s & QM] : &ent[s & 0xFFFFu];
-        if (kp->mlo == mlo && kp->mhi == mhi && kp->st == st) {
-          wv::lds_or32(const_cast<uint32_t*>(&kp->org), org);
-          pend = false;
-        } else {
-          h = (h + 1u) & (HS - 1u);
-        }
-      }
-    }
-  }
-  const uint64_t wa = wv::ballot(won && sel == 1u), wb = wv::ballot(won && sel == 2u);
-  if (X.lane == 0) {
-    X.ws[S::kTot + 2 * X.wave] = (uint32_t)__builtin_popcountll(wa);
-    X.ws[S::kTot + 2 * X.wave + 1] = (uint32_t)__builtin_popcountll(wb);
-  }
-  wv::wg_barrier();                                           // every claim and every OR is done; the winner counts are visible
-  uint32_t offa = A.n, offb = B.n, ta = A.n, tb = B.n;
-  WV_UNROLL
-  for (uint32_t w = 0; w < NW; w++) {
-    const uint32_t ca = X.ws[S::kTot + 2 * w], cb = X.ws[S::kTot + 2 * w + 1];
-    if (w < X.wave) { offa += ca; offb += cb; }
-    ta += ca; tb += cb;
-  }
-  const bool fits = ta <= CAP && tb <= CAP;
-  if (won && fits) {
-    const uint64_t below = (1ull << X.lane) - 1ull;
-    const uint32_t idx = sel == 2u ? offb + (uint32_t)__builtin_popcountll(wb & below) : offa + (uint32_t)__builtin_popcountll(wa & below);
-    ent[idx] = Ent{mlo, mhi, st, wq[at].org};
-    tab[mine] = gtag | idx;
-  }
-  if (fits) { A.n = ta; B.n = tb; }
-  wv::wg_barrier();                                           // entries committed; the ring positions are free, the counts may be written again
-  return fits;
-}
-
 template <bool COMPACT> struct CompactState {};
 template <> struct CompactState<true> { uint16_t* blk; uint32_t* scanw; uint32_t flip; };
 
 // One workgroup: segment k of history h, origins 32 * sl .. 32 * sl + 31 (as one wavefront of K6).
-// QUEUE (experimental, off in every launch of round 4: verified under the emulator only, not yet measured): a sub-round's passes
-// put their children into a ring in LDS (one barrier per pass of 64 * NW pairs) and the insertion -- the expensive half, three
-// barriers in the plain form -- runs only when 64 * NW children are waiting: about a third of the pairs of a burst yield a child,
-// so a third as many insertions, each with every lane busy.  Costs 17 KB of LDS at NW = 8 (one workgroup per CU instead of two).
-// FP (experimental, likewise): 8 bits of the key's hash in the table word.  A probe that meets another key's slot then costs one LDS
-// word instead of the word and the 16 B key behind it; the barrier after the probe loop waits for the LONGEST chain among the
-// workgroup's 512 lanes, so the cost of a chain link is what a pass costs.  Generations wrap every 127 sets instead of 32,767.
-// COMPACT (experimental, likewise; TBC_SWEEP_WG_COMPACT=1): a sub-round no longer walks all 2^gshift (config, open call) slots of
+// COMPACT (round 5: the first pass's form; 93 us of a 10k-op history's 928, profiles/r05_single_history_forms_first_device_run.json): a sub-round no longer walks all 2^gshift (config, open call) slots of
 // every config -- of which a burst makes a child of one in three to five -- but, per block of 64 x NW configs: every thread counts
 // ITS config's viable calls (a loop over the level's <= 64 open calls in LDS, no barrier), one workgroup scan numbers the children,
 // and the insertion passes then take 64 x NW CHILDREN each: thread r finds its config by binary search over the block's 16-bit
@@ -359,14 +268,13 @@ template <> struct CompactState<true> { uint16_t* blk; uint32_t* scanw; uint32_t
 // statistics and records are those of the plain form; the barriers of a burst's sub-round drop from 3 per 64 x NW SLOTS to 2 per
 // block + 3 per 64 x NW CHILDREN.  1 KB more LDS at NW = 8 (still two workgroups per CU).  Levels with more than 64 open calls keep
 // the plain walk.
-// SOLO (experimental, likewise; with COMPACT: TBC_SWEEP_WG_COMPACT=2): a pass that fits one wavefront -- a level of at most 64
+// SOLO (with COMPACT; likewise the first pass's form): a pass that fits one wavefront -- a level of at most 64
 // configs, a sub-round of at most 64 (config, call) slots: 100 of the 187 steps of that critical workgroup, and nearly every step of
 // the other 340 -- is run by wavefront 0 alone with wavefront barriers, the others waiting at ONE workgroup barrier for the new set
 // sizes (insert2_solo, solo_exchange): one workgroup barrier instead of three, and a probe loop that waits for the longest chain
 // of 64 lanes, not 512.
-template <uint32_t CAP, uint32_t NW, bool QUEUE = false, bool FP = false, bool COMPACT = false, bool SOLO = false>
+template <uint32_t CAP, uint32_t NW, bool COMPACT = false, bool SOLO = false>
 WV_DEV void segment(const SweepArgs& A, uint32_t* lds) {
-  static_assert(!(QUEUE && COMPACT), "the ring gathers what the compact walk never produces");
   static_assert(!SOLO || (COMPACT && CAP < 0x10000u && Scratch<NW>::kBad + 5u <= Scratch<NW>::kWords), "solo passes: with the compact walk; two set sizes share a word");
   static_assert(64 * NW >= kCand, "a level's open calls are parked one per thread");
   static_assert(64 * NW <= 1024 && CAP <= 0x8000u, "thread numbers and entry numbers share a table word");
@@ -416,9 +324,6 @@ WV_DEV void segment(const SweepArgs& A, uint32_t* lds) {
   uint16_t* expl = reinterpret_cast<uint16_t*>(row_b + 32);   // entries of `cur` that still need X
   uint32_t* Mrel = reinterpret_cast<uint32_t*>(expl + CAP);   // 32 x 4 words: origin -> origin ids of the next segment
   X.ws = Mrel + 128;
-  Ent* wq = nullptr;
-  uint8_t* wq_sel = nullptr;
-  if constexpr (QUEUE) { wq = reinterpret_cast<Ent*>(X.ws + S::kWords); wq_sel = reinterpret_cast<uint8_t*>(wq + 2 * T); }
   CompactState<COMPACT> cs;         // COMPACT: where each config of the block's children start, the scan's words (else: nothing at all)
   if constexpr (COMPACT) { cs.blk = reinterpret_cast<uint16_t*>(X.ws + S::kWords); cs.scanw = reinterpret_cast<uint32_t*>(cs.blk + T); cs.flip = 0; }
   for (uint32_t i = tid; i < 2 * HS; i += T) tab_nxt[i] = 0u;
@@ -485,7 +390,7 @@ WV_DEV void segment(const SweepArgs& A, uint32_t* lds) {
   nxt = none; q = none;
   uint32_t n_org = 0, so_ = 0, st_ = 0;
   {
-    build_begin<HS, NW, FP>(cur, cur_e, tab_q, gen_q, X);
+    build_begin<HS, NW>(cur, cur_e, tab_q, gen_q, X);
     load_row(row_a, F0);
     uint32_t nlive = 0, C = 0;
     const bool okc = load_cands(F0, nlive, C);              // (its barrier also publishes row_a)
@@ -505,7 +410,7 @@ WV_DEV void segment(const SweepArgs& A, uint32_t* lds) {
       if (eager) act = act && ((row_a[0] | row_a[rdm_index((int32_t)st, V)]) & ~m) == 0ull;     // in normal form already?
     }
     Build unused = none;
-    if (status == kSegOk && !insert2<CAP, NW, FP>(cur, unused, act ? 1u : 0u, (uint32_t)m, (uint32_t)(m >> 32), st, 1u << (tid & 31u), false, so_, st_, X)) status = kSegOverflow;
+    if (status == kSegOk && !insert2<CAP, NW>(cur, unused, act ? 1u : 0u, (uint32_t)m, (uint32_t)(m >> 32), st, 1u << (tid & 31u), false, so_, st_, X)) status = kSegOverflow;
   }
   n_org = cur.n;
   if (n_org == 0 && status == kSegOk) { if (tid == 0) out->status = kSegNone; return; }   // none of these ids is a config
@@ -533,7 +438,7 @@ WV_DEV void segment(const SweepArgs& A, uint32_t* lds) {
       if (tid < 32 && eager && tid < V && F + 2u < R) p_row = rdm[(uint64_t)(F + 2u) * V + tid];
     }
     const uint64_t xbit = 1ull << (px & 63u);
-    build_begin<HS, NW, FP>(nxt, nxt_e, tab_nxt, gen_nxt, X);
+    build_begin<HS, NW>(nxt, nxt_e, tab_nxt, gen_nxt, X);
     // sub-round 0: a config that has X linearized passes the completion -- X's bit is cleared and the reads open at
     // the next front are absorbed; the others are listed for expansion
     uint32_t n_exp = 0;
@@ -552,7 +457,7 @@ WV_DEV void segment(const SweepArgs& A, uint32_t* lds) {
         uint64_t m2 = m & ~xbit;
         if (eager) m2 |= row_b[0] | row_b[rdm_index((int32_t)e.st, V)];
         uint32_t soff = 0;
-        fits = insert2_solo<CAP, NW, FP>(nxt, unused, has ? 1u : 0u, (uint32_t)m2, (uint32_t)(m2 >> 32), e.st, e.org, val && !has, soff, stot, X);
+        fits = insert2_solo<CAP, NW>(nxt, unused, has ? 1u : 0u, (uint32_t)m2, (uint32_t)(m2 >> 32), e.st, e.org, val && !has, soff, stot, X);
         if (val && !has) expl[soff] = (uint16_t)i;
       }
       solo_exchange<NW>(nxt, unused, fits, stot, X);           // (its barrier: the list is complete, too)
@@ -569,7 +474,7 @@ WV_DEV void segment(const SweepArgs& A, uint32_t* lds) {
       if (eager) m2 |= row_b[0] | row_b[rdm_index((int32_t)e.st, V)];
       Build unused = none;
       uint32_t soff = 0, stot = 0;
-      if (!insert2<CAP, NW, FP>(nxt, unused, has ? 1u : 0u, (uint32_t)m2, (uint32_t)(m2 >> 32), e.st, e.org, val && !has, soff, stot, X)) status = kSegOverflow;
+      if (!insert2<CAP, NW>(nxt, unused, has ? 1u : 0u, (uint32_t)m2, (uint32_t)(m2 >> 32), e.st, e.org, val && !has, soff, stot, X)) status = kSegOverflow;
       if (val && !has) expl[n_exp + soff] = (uint16_t)i;
       n_exp += stot;
     }
@@ -585,9 +490,9 @@ WV_DEV void segment(const SweepArgs& A, uint32_t* lds) {
     Ent* dst_e = q_e; Ent* dst_other = cur_e;       // `cur` is dead once its own expansion is done
     while (n_src != 0 && status == kSegOk) {
       subrounds++;
-      build_begin<HS, NW, FP>(q, dst_e, tab_q, gen_q, X);
+      build_begin<HS, NW>(q, dst_e, tab_q, gen_q, X);
       const uint32_t total = n_src << gshift;
-      if constexpr (!QUEUE) {
+      {
        if constexpr (COMPACT) {
         if (C <= 64u && total > 2u * T) {        // (a sub-round of one or two plain passes keeps them: the block's two barriers would not pay)
           // is open call kc a viable step from config (m, st)?  (the same test as the plain walk's)
@@ -630,7 +535,7 @@ WV_DEV void segment(const SweepArgs& A, uint32_t* lds) {
               const bool has = val && (m2 & xbit) != 0ull;
               if (has) { m2 &= ~xbit; if (eager) m2 |= row_b[0] | row_b[rdm_index(st2, V)]; }
               const uint32_t sel = val ? (has ? 1u : 2u) : 0u;
-              if (!insert2<CAP, NW, FP>(nxt, q, sel, (uint32_t)m2, (uint32_t)(m2 >> 32), (uint32_t)st2, e.org, false, so_, st_, X)) status = kSegOverflow;
+              if (!insert2<CAP, NW>(nxt, q, sel, (uint32_t)m2, (uint32_t)(m2 >> 32), (uint32_t)st2, e.org, false, so_, st_, X)) status = kSegOverflow;
             }
           }
         } else if (SOLO && total <= 64u) {          // the sub-round is one wavefront's: wavefront 0 walks and inserts it alone
@@ -653,7 +558,7 @@ WV_DEV void segment(const SweepArgs& A, uint32_t* lds) {
             const bool has = viable && (m2 & xbit) != 0ull;
             if (has) { m2 &= ~xbit; if (eager) m2 |= row_b[0] | row_b[rdm_index(st2, V)]; }
             const uint32_t sel = viable ? (has ? 1u : 2u) : 0u;
-            fits = insert2_solo<CAP, NW, FP>(nxt, q, sel, (uint32_t)m2, (uint32_t)(m2 >> 32), (uint32_t)st2, e.org, false, so_, st_, X);
+            fits = insert2_solo<CAP, NW>(nxt, q, sel, (uint32_t)m2, (uint32_t)(m2 >> 32), (uint32_t)st2, e.org, false, so_, st_, X);
           }
           solo_exchange<NW>(nxt, q, fits, unused_total, X);
           if (!fits) status = kSegOverflow;
@@ -675,7 +580,7 @@ WV_DEV void segment(const SweepArgs& A, uint32_t* lds) {
           const bool has = viable && (m2 & xbit) != 0ull;
           if (has) { m2 &= ~xbit; if (eager) m2 |= row_b[0] | row_b[rdm_index(st2, V)]; }
           const uint32_t sel = viable ? (has ? 1u : 2u) : 0u;
-          if (!insert2<CAP, NW, FP>(nxt, q, sel, (uint32_t)m2, (uint32_t)(m2 >> 32), (uint32_t)st2, e.org, false, so_, st_, X)) status = kSegOverflow;
+          if (!insert2<CAP, NW>(nxt, q, sel, (uint32_t)m2, (uint32_t)(m2 >> 32), (uint32_t)st2, e.org, false, so_, st_, X)) status = kSegOverflow;
         }
         }
        } else {
@@ -696,77 +601,9 @@ WV_DEV void segment(const SweepArgs& A, uint32_t* lds) {
           const bool has = viable && (m2 & xbit) != 0ull;
           if (has) { m2 &= ~xbit; if (eager) m2 |= row_b[0] | row_b[rdm_index(st2, V)]; }
           const uint32_t sel = viable ? (has ? 1u : 2u) : 0u;
-          if (!insert2<CAP, NW, FP>(nxt, q, sel, (uint32_t)m2, (uint32_t)(m2 >> 32), (uint32_t)st2, e.org, false, so_, st_, X)) status = kSegOverflow;
+          if (!insert2<CAP, NW>(nxt, q, sel, (uint32_t)m2, (uint32_t)(m2 >> 32), (uint32_t)st2, e.org, false, so_, st_, X)) status = kSegOverflow;
         }
        }
-      } else if (total <= T) {                         // (one pass: nothing to gather -- the plain form, as above)
-        for (uint32_t base = 0; base < total && status == kSegOk; base += T) {
-          const uint32_t r = base + tid, ci = r >> gshift, kc = r & ((1u << gshift) - 1u);
-          const bool val = r < total && kc < C;
-          const Ent e = val ? src[via_list ? (uint32_t)expl[ci] : ci] : Ent{0, 0, 0, 0};
-          const OpRec y = val ? cand[kc] : OpRec{0, kFNone, 0, 0};
-          const uint64_t tw = val ? cand_tw[kc] : 0ull;
-          const uint64_t m = mask_of(e);
-          const uint32_t yf = y.f_slot & 0xFFu, ys = (y.f_slot >> 8) & 63u;
-          const int32_t st = (int32_t)e.st;
-          const bool viable = val && !((m >> ys) & 1ull) && !(eager && yf == TBC_F_READ) && (tw & ~m) == 0ull && reg_ok(st, yf, y.a);
-          probes += (uint64_t)__builtin_popcountll(wv::ballot(viable));
-          const int32_t st2 = viable ? reg_apply(st, yf, y.a, y.b) : st;
-          uint64_t m2 = m | (1ull << ys);
-          if (eager) m2 |= row_a[0] | row_a[rdm_index(st2, V)];
-          const bool has = viable && (m2 & xbit) != 0ull;
-          if (has) { m2 &= ~xbit; if (eager) m2 |= row_b[0] | row_b[rdm_index(st2, V)]; }
-          const uint32_t sel = viable ? (has ? 1u : 2u) : 0u;
-          if (!insert2<CAP, NW, FP>(nxt, q, sel, (uint32_t)m2, (uint32_t)(m2 >> 32), (uint32_t)st2, e.org, false, so_, st_, X)) status = kSegOverflow;
-        }
-      } else {
-        uint32_t qh = 0, qn = 0, pass_no = 0;          // ring head and count (the same in every thread), passes so far
-        for (uint32_t base = 0; base < total && status == kSegOk; base += T) {
-          const uint32_t r = base + tid, ci = r >> gshift, kc = r & ((1u << gshift) - 1u);
-          const bool val = r < total && kc < C;
-          const Ent e = val ? src[via_list ? (uint32_t)expl[ci] : ci] : Ent{0, 0, 0, 0};
-          const OpRec y = val ? cand[kc] : OpRec{0, kFNone, 0, 0};
-          const uint64_t tw = val ? cand_tw[kc] : 0ull;
-          const uint64_t m = mask_of(e);
-          const uint32_t yf = y.f_slot & 0xFFu, ys = (y.f_slot >> 8) & 63u;
-          const int32_t st = (int32_t)e.st;
-          const bool viable = val && !((m >> ys) & 1ull) && !(eager && yf == TBC_F_READ) && (tw & ~m) == 0ull && reg_ok(st, yf, y.a);
-          const uint64_t vb = wv::ballot(viable);
-          probes += (uint64_t)__builtin_popcountll(vb);
-          const int32_t st2 = viable ? reg_apply(st, yf, y.a, y.b) : st;
-          uint64_t m2 = m | (1ull << ys);
-          if (eager) m2 |= row_a[0] | row_a[rdm_index(st2, V)];
-          const bool has = viable && (m2 & xbit) != 0ull;
-          if (has) { m2 &= ~xbit; if (eager) m2 |= row_b[0] | row_b[rdm_index(st2, V)]; }
-          // ring positions: the wavefronts' child counts through LDS (by pass parity), one barrier; the children are written after
-          // it and read only behind insert_q's own barrier
-          const uint32_t pp = (pass_no++ & 1u) * NW;
-          if (lane == 0) X.ws[S::kSide + pp + X.wave] = (uint32_t)__builtin_popcountll(vb);
-          wv::wg_barrier();
-          uint32_t before = 0, all = 0;
-          WV_UNROLL
-          for (uint32_t w2 = 0; w2 < NW; w2++) { const uint32_t c2 = X.ws[S::kSide + pp + w2]; if (w2 < X.wave) before += c2; all += c2; }
-          if (viable) {
-            const uint32_t pos = (qh + qn + before + (uint32_t)__builtin_popcountll(vb & ((1ull << lane) - 1ull))) & (2 * T - 1u);
-            wq[pos] = Ent{(uint32_t)m2, (uint32_t)(m2 >> 32), (uint32_t)st2, e.org};
-            wq_sel[pos] = has ? (uint8_t)1 : (uint8_t)2;
-          }
-          qn += all;
-          while (qn >= T && status == kSegOk) {
-            if (!insert_q<CAP, NW, FP>(nxt, q, wq, wq_sel, qh, T, X)) status = kSegOverflow;
-            qh = (qh + T) & (2 * T - 1u); qn -= T;
-          }
-        }
-        if (qn != 0 && status == kSegOk) {                     // what is left in the ring
-          if (!insert_q<CAP, NW, FP>(nxt, q, wq, wq_sel, qh, qn, X)) status = kSegOverflow;
-        } else {
-          // A sub-round whose last pass left the ring empty ends without a barrier behind that pass's count words -- and the next
-          // sub-round starts its pass parity at 0 again, or is a small one whose insert2 uses the same words by ITS parity: a fast
-          // wavefront then overwrites a count a slow one has not read, the two disagree on how full the ring is and meet at
-          // different barriers (found by scripts/fuzz_forms_emu.py on a crash-heavy history, one long segment; the emulator stops at
-          // "wavefronts at different workgroup barriers", a GPU would hang).  One barrier here closes it.
-          wv::wg_barrier();
-        }
       }
       src = q.e; n_src = q.n; via_list = false;
       { Ent* t = dst_e; dst_e = dst_other; dst_other = t; }

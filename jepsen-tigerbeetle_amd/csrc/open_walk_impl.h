@@ -92,10 +92,8 @@ WV_DEV void walk_wave(const PackOpenArgs& A, uint32_t wid, uint32_t* lds, uint32
   const uint32_t FW = A.front_words ? A.front_words : V;             // u64 words per front: a plain row, or a front record
   const bool compact = A.front_compact != 0u;                        // the 64 B record, written whole (masks, list location, windows)
   uint64_t* rdm = (A.rdm && (V || compact)) ? A.rdm + H->op_off * FW : nullptr;
-  // the lean formats (tbc_internal.h): a list entry {call, twin mask} in lst[] alone (no twn[]), an 8 B lookahead record
-  const bool lc = (A.lean & kLeanCands) != 0u, lk8 = (A.lean & kLeanLook) != 0u;
-  const bool want_tw = twn != nullptr || lc;
-  uint64_t* look = A.look ? A.look + look_off(H->op_off, h, lk8 ? 0u : 1u) : nullptr;
+  const bool want_tw = twn != nullptr;
+  uint64_t* look = A.look ? A.look + look_off(H->op_off, h, 1u) : nullptr;
   uint32_t* cand = lds;
   uint32_t* aux = lds + kCandCap * kCandWords;
 
@@ -255,10 +253,6 @@ WV_DEV void walk_wave(const PackOpenArgs& A, uint32_t wid, uint32_t* lds, uint32
       }
       if (member) {
         OpRec o; o.op = e[2]; o.f_slot = e[3] | (ret == F ? kAtFront : 0u); o.a = (int32_t)e[4]; o.b = (int32_t)e[5];
-        if (lc) {                       // {call, twin mask}: one 16 B entry
-          const uint64_t call = lean_call(e[2], e[3] & 0xFFu, ret == F, slot, (int32_t)e[4], (int32_t)e[5]);
-          o.op = (uint32_t)call; o.f_slot = (uint32_t)(call >> 32); o.a = (int32_t)tw_lo; o.b = (int32_t)tw_hi;
-        }
         lst[pos] = o;
         if (twn) twn[pos] = (uint64_t)tw_lo | ((uint64_t)tw_hi << 32);
         pos++;
@@ -313,11 +307,8 @@ WV_DEV void walk_wave(const PackOpenArgs& A, uint32_t wid, uint32_t* lds, uint32
     uint64_t pm = (uint64_t)pm_lo | ((uint64_t)pm_hi << 32);
     pm &= ~(1ull << (px & 63u));                                    // one call per slot is open at a front: this is the completing call itself
     const uint64_t w0 = (uint64_t)(px & 0xFFFFu) | (uint64_t)need << 16 | (uint64_t)xprod << 24 | (uint64_t)di << 32 | ((uint64_t)dmin << 40);
-    if (lk8) look[(uint64_t)F] = lean_look(px, need, xprod, di, dmin, pm);
-    else {
     look[(uint64_t)F * 2u] = w0;
     look[(uint64_t)F * 2u + 1u] = pm;
-    }
   }
 }
 

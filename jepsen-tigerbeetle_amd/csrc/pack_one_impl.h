@@ -366,10 +366,7 @@ WV_DEV void history(const PackArgs& A, const PackOpenArgs& O, uint32_t* lds) {
       }
       if (tid == 0u) { Bh->status = 0u; Bh->n_crashed = all; }
     }
-    if (O.look && (O.lean & kLeanLook)) {          // (the lean format: one word a rank)
-      uint64_t* look = O.look + look_off(H->op_off, h, 0);
-      for (uint32_t t = R + tid; t < R + kLookPad; t += kT) look[t] = lean_look(0u, kLookNone, kLookNone, 255u, 255u, 0ull);
-    } else if (O.look) {                 // lookahead records past the last rank: nothing is needed there
+    if (O.look) {                 // lookahead records past the last rank: nothing is needed there
       const uint32_t MW = O.mask_words, LW = 1u + MW;
       uint64_t* look = O.look + look_off(H->op_off, h, MW);
       for (uint32_t t = R + tid; t < R + kLookPad; t += kT) {

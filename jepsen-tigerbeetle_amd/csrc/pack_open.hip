@@ -258,10 +258,7 @@ __global__ __launch_bounds__(1024) void open_counts_kernel(PackOpenArgs A) {
       __syncthreads();
     }
     // lookahead records past the last rank: nothing is needed there
-    if (A.look && (A.lean & kLeanLook)) {          // (the lean format: one word a rank)
-      uint64_t* look = A.look + look_off(H->op_off, h, 0);
-      for (uint32_t t = R + tid; t < R + kLookPad; t += NT) look[t] = lean_look(0u, kLookNone, kLookNone, 255u, 255u, 0ull);
-    } else if (A.look) {
+    if (A.look) {
       const uint32_t LW = 1 + MW;
       uint64_t* look = A.look + look_off(H->op_off, h, MW);
       for (uint32_t t = R + tid; t < R + kLookPad; t += NT) {
@@ -611,16 +608,13 @@ void launch_pack_open(const PackOpenArgs& a, void* stream, bool skip_counts) {
   if (a.cmem) hipLaunchKernelGGL(count_fronts_kernel, dim3(grid), dim3(256), 0, s, a, 0u);
   const uint64_t waves = (uint64_t)n_here * a.chunks_per_hist;
   const uint32_t wgrid = (uint32_t)((waves + 3) / 4);
-  // one mask word: the walk with lane = front (a fifth of the vector instructions); TBC_OPEN_WALK=slots keeps the walk with
-  // lane = process slot for it too (the A/B in tests/test_gpu_parity.py), which wider masks always take
-  const char* which = std::getenv("TBC_OPEN_WALK");
-  const bool by_front = a.mask_words == 1 && a.vpad <= 32 && !(which && std::strcmp(which, "slots") == 0);
+  // one mask word: the walk with lane = front (a fifth of the vector instructions); wider masks take the walk with lane = process slot
+  const bool by_front = a.mask_words == 1 && a.vpad <= 32;
   const size_t walk_lds_bytes = 4u * walk::walk_lds_words() * sizeof(uint32_t);
   if (by_front) {
     if (a.vpad <= 8) hipLaunchKernelGGL(open_walk_fronts_kernel<8>, dim3(wgrid), dim3(256), walk_lds_bytes, s, a);
     else hipLaunchKernelGGL(open_walk_fronts_kernel<32>, dim3(wgrid), dim3(256), walk_lds_bytes, s, a);
   } else switch (a.mask_words) {
-    case 1: hipLaunchKernelGGL(open_walk_kernel<1>, dim3(wgrid), dim3(256), 0, s, a); break;
     case 2: hipLaunchKernelGGL(open_walk_kernel<2>, dim3(wgrid), dim3(256), 0, s, a); break;
     default: hipLaunchKernelGGL(open_walk_kernel<4>, dim3(wgrid), dim3(256), 0, s, a); break;
   }

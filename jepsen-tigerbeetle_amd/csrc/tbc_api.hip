@@ -300,33 +300,24 @@ struct tbc_batch {
   // u64 words per front record (0 = plain rdm rows): the compact 64 B form where one mask word and six row entries do
   uint32_t front_words() const { return !lanes ? 0u : ((rules & kRuleEager) && front_compact_ok(n_dom, mask_words)) ? kFrontCompactWords : front_stride(vpad, mask_words); }
   uint32_t lanes = 0;               // 8 / 16 / 32: several histories per wavefront (wgl_narrow.hip), one config per iteration; 0 = one per wavefront
-  // TBC_NARROW_LEAN=1 (experimental; tbc_internal.h, kLeanCands | kLeanLook): the per-front lists and the lookahead records of a batch
-  // that runs several histories per wavefront in the lean formats -- where nothing else reads those tables: compact front records
-  // (the walk with lane = front writes them), both rules and the lookahead on, no count form, no level sweep beside it, no round
-  // budget (whose stragglers the wide kernel would take over).  Verified under the emulators only; nothing takes it unless asked
-  uint32_t lean() const {
-    static const int asked = [] { const char* e = std::getenv("TBC_NARROW_LEAN"); return (e && (e[0] == '1' || e[0] == '2')) ? e[0] - '0' : 0; }();      // 2: + kLeanLazy
-    static const bool by_slots = [] { const char* e = std::getenv("TBC_OPEN_WALK"); return e && std::strcmp(e, "slots") == 0; }();
-    const bool ok = asked != 0 && !by_slots && lanes >= 4 && lanes < 64 && mask_words == 1 && front_words() == kFrontCompactWords &&
-                    (rules & (kRuleEager | kRuleTwin | kRuleCount)) == (kRuleEager | kRuleTwin) && lookahead && !sweep && opts.round_budget == 0;
-    return ok ? (kLeanCands | kLeanLook | (asked == 2 ? kLeanLazy : 0u)) : 0u;
+  // The order of a front's list of open calls (tbc_opts.list_order; PackOpenArgs.list_order).  The search takes a config's candidates last to
+  // first and pops the last child first; in order of COMPLETION, a :write placed as if it completed 24 ranks later (16 + 24), the call
+  // that completes soonest is tried first and a :cas the state allows now goes before a :write that completes soon after it: on the bench
+  // workload 4,513 rounds a history instead of 5,580 in process-slot order, at 19 calls in flight half the rounds of the wide kernel, at 32 a
+  // third (oracle counts; measured round 5: search 70.9 -> 43.1 ms per 8,192 x 8 histories).  It is the library's
+  // choice wherever nothing depends on slot order: the walk with lane = front (one mask word), the register family under the
+  // rules' value range, no level sweep beside the search (its origins are numbered by list position), no count form (its oracle
+  // counts say slot order), no round budget.  A witness's absorbed reads are replayed in the same order (witness_expand.h).
+  static constexpr uint32_t kDefaultListOrder = 16u + 24u;
+  bool list_order_applies() const {
+    return width > 1 && mask_words == 1 && vpad <= 32 && !(rules & kRuleCount) && !sweep && opts.round_budget == 0 &&
+           (model.kind == TBC_MODEL_REGISTER || model.kind == TBC_MODEL_CAS_REGISTER);
   }
-  // TBC_NARROW_ORDER=1 (experimental; tbc_internal.h PackOpenArgs.list_order): the per-front lists of a batch of the wide schedule (several histories
-  // per wavefront, or one) in order of COMPLETION instead of process slot -- the search then tries the call that completes soonest first: on
-  // the bench workload 18 % fewer rounds for the same probes, the longest history 31 % fewer (oracle counts).  Where
-  // nothing depends on slot order: the walk with lane = front (a witness's absorbed reads are replayed in the same order: expand_eager_witness), no level
-  // sweep beside it (origins are numbered by list position), no count form, no round budget.  Emulator-verified only; off unless asked
+  // PackOpenArgs.list_order: 0 = slot order, 1 = completion, 2 = completion with the :write calls last, 16 + W
   uint32_t list_order() const {
-    // (2: in order of completion with the :write calls last -- a :cas the state allows now goes before a :write, which it always allows;
-    // oracle list order 4: another quarter fewer rounds at 19 calls in flight, 5 % on the bench workload.  A witness's absorbed reads are
-    // reads: their order among themselves is the order of completion either way)
-    // (16 + W: a :write takes the place of a call completing W ranks later -- the soft form; W = 16 .. 24 the best of the oracle's scan)
-    static const uint32_t asked = [] { const char* e = std::getenv("TBC_NARROW_ORDER"); const long v = e ? std::strtol(e, nullptr, 10) : 0;
-                                       return (v == 1 || v == 2 || (v >= 16 && v <= 16 + 4096)) ? (uint32_t)v : 0u; }();
-    static const bool by_slots = [] { const char* e = std::getenv("TBC_OPEN_WALK"); return e && std::strcmp(e, "slots") == 0; }();
-    // (a wavefront per history too -- the wide kernel takes its pairs from the same lists: at 19 calls in flight 28 % fewer probes, 41 % fewer rounds)
-    return (asked && !by_slots && width > 1 && mask_words == 1 && vpad <= 32 && !(rules & kRuleCount) && !sweep &&
-            opts.round_budget == 0 && (model.kind == TBC_MODEL_REGISTER || model.kind == TBC_MODEL_CAS_REGISTER)) ? asked : 0u;
+    if (!list_order_applies() || opts.list_order == TBC_ORDER_SLOT) return 0u;
+    if (opts.list_order == TBC_ORDER_DEFAULT) return kDefaultListOrder;
+    return opts.list_order >= 16u ? opts.list_order : opts.list_order - 1u;        // TBC_ORDER_COMPLETION = 2 -> 1, TBC_ORDER_WRITES_LAST = 3 -> 2
   }
   std::vector<BeamHist> bh;
   DevBuf<BeamHist> d_bh;
@@ -569,13 +560,17 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
   {
     const uint32_t asked = opts->lanes_per_history;
     if (asked != 0 && asked != 4 && asked != 8 && asked != 16 && asked != 32 && asked != 64) { set_error("lanes_per_history must be 0, 4, 8, 16, 32 or 64"); return TBC_ERR_INVALID_ARG; }
-    if (opts->reserved0 != 0) { set_error("tbc_opts.reserved0 must be 0"); return TBC_ERR_INVALID_ARG; }
+    if (opts->list_order > 3 && (opts->list_order < 16 || opts->list_order > 16 + 4096)) { set_error("tbc_opts.list_order must be TBC_ORDER_* or 16 + W, W <= 4096"); return TBC_ERR_INVALID_ARG; }
     const bool regfam3 = model->kind == TBC_MODEL_REGISTER || model->kind == TBC_MODEL_CAS_REGISTER || model->kind == TBC_MODEL_MUTEX;
-    // the narrow kernel addresses a history's tables with 32-bit element offsets
-    const bool can = beam && !B->sweep && (!B->count_form || B->mask_words <= 2) && regfam3 && narrow_supported(B->mask_words, 8) && opts->algorithm != TBC_ALG_WGL &&
+    // the narrow kernel addresses a history's tables with 32-bit element offsets, and its visited-set keys hold front + 1 in 24 bits
+    // (bits 24-31 of the low word are the pass's epoch tag, wgl_narrow_impl.h kFrontMask / entry_empty): a history of 2^24 completions
+    // or more would have its fronts truncated -- such a batch keeps a wavefront per history
+    uint64_t longest = 0;
+    for (uint32_t h = 0; h < nh; h++) longest = std::max<uint64_t>(longest, desc->op_off[h + 1] - desc->op_off[h]);
+    const bool can = beam && !B->sweep && longest < kNarrowMaxOps && (!B->count_form || B->mask_words <= 2) && regfam3 && narrow_supported(B->mask_words, 8) && opts->algorithm != TBC_ALG_WGL &&
                      look_words(B->total_ops, nh, B->mask_words) < (1ull << 32);
     if (asked != 0 && asked != 64) {
-      if (!can) { set_error("lanes_per_history %u: needs the depth-first search of a register / cas-register / mutex batch with at most 256 process slots (not TBC_ALG_WGL, not the level sweep)", asked); return TBC_ERR_UNSUPPORTED; }
+      if (!can) { set_error("lanes_per_history %u: needs the depth-first search of a register / cas-register / mutex batch with at most 256 process slots and fewer than 2^24 - 16 ops per history (not TBC_ALG_WGL, not the level sweep)", asked); return TBC_ERR_UNSUPPORTED; }
       if (opts->search_width > 1) { set_error("lanes_per_history %u expands one config per iteration: leave search_width 0 or 1", asked); return TBC_ERR_INVALID_ARG; }
       B->lanes = asked;
     } else if (asked == 0 && can && !B->count_form && opts->search_width == 0 && B->width == 2 && nh >= 24576) {      // (count form: by name only until measured)
@@ -720,8 +715,7 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
     // several histories per wavefront: front records (tbc_internal.h) instead of plain rows, with or without the rules
     if (B->lanes) { B->d_rdm.release(); if ((s = B->d_rdm.alloc(T * B->front_words()))) return s; }
     // (d_looktmp: scratch of the walk with lane = process slot only -- launch_pack_open's choice, repeated here)
-    const char* walk_env = std::getenv("TBC_OPEN_WALK");
-    const bool by_front = B->mask_words == 1 && B->vpad <= 32 && !(walk_env && std::strcmp(walk_env, "slots") == 0);
+    const bool by_front = B->mask_words == 1 && B->vpad <= 32;
     if (B->lookahead && ((s = B->d_look.alloc(look_words(T, nh, B->mask_words))) || (s = B->d_looktmp.alloc(by_front ? 0 : T)) ||
                          (s = B->d_dstack.alloc(bstack_n)))) return s;
     // growth pool: 30 % of the visited-set arena -- 10 % for the big quiet batches that run several histories per wavefront, whose sets
@@ -819,8 +813,7 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
       if (!had_branch) break;                      // (else the lists hold the reads again: counted once more)
       for (uint32_t h = 0; h < nh; h++) { B->bh[h].lst_cap = 0xFFFFFFF0u; B->bh[h].lst_off = 0; }
     }
-    // (the lean tables carry the twin masks inside the list entries: no twn[] arena at all -- 8.5 GB of the bench's batch)
-    if ((s = B->d_lst.alloc(blst_n)) || (B->reg_rules() && !(B->lean() & kLeanCands) && (s = B->d_twn.alloc(blst_n * B->mask_words)))) return s;
+    if ((s = B->d_lst.alloc(blst_n)) || (B->reg_rules() && (s = B->d_twn.alloc(blst_n * B->mask_words)))) return s;
     B->device_bytes += B->d_lst.bytes() + B->d_twn.bytes();
     TRACE("create: lists sized on the device");
   }
@@ -897,9 +890,7 @@ static PackOpenArgs make_pack_open_args(tbc_batch* B) {
   po.rk8 = B->lanes ? B->d_rk8.p : nullptr; po.front_words = B->front_words(); po.front_compact = B->front_words() == kFrontCompactWords ? 1u : 0u;
   po.twn = B->reg_rules() ? B->d_twn.p : nullptr; po.rdm = (B->reg_rules() || B->lanes) ? B->d_rdm.p : nullptr; po.vpad = B->vpad;
   po.cmem = B->count_form ? B->d_cmem.p : nullptr;
-  po.lean = B->lean() & (kLeanCands | kLeanLook);          // (the formats; kLeanLazy is the search's alone)
   po.list_order = B->list_order();
-  if (po.lean & kLeanCands) po.twn = nullptr;          // (the twin masks ride in the list entries)
   return po;
 }
 
@@ -920,7 +911,6 @@ static BeamArgs make_beam_args(tbc_batch* B, uint64_t* tab, uint32_t* stack, uin
   a.n_classes = B->model.n_classes; a.width = B->width;
   a.round_budget = B->opts.round_budget;
   a.cmem = B->d_cmem.p; a.count_mode = kCountExact; a.tab_stride = B->entry_words(); a.epoch = 0;
-  a.lean = B->lean();
   a.rules = B->rules; a.twn = B->d_twn.p; a.rdm = B->d_rdm.p; a.vpad = B->vpad; a.rk8 = B->d_rk8.p; a.front_words = B->front_words(); a.next_work = B->d_queue.p;
   a.max_steps = B->opts.max_steps;
   a.time_limit_ticks = B->opts.time_limit_ms * 100000ull;
@@ -1140,7 +1130,7 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results, int phase = 
   HIP_TRY(hipMemsetAsync(B->d_bitmap.p, 0, B->d_bitmap.bytes(), s));
   // several histories per wavefront: the visited sets are not zeroed before every pass -- the keys carry the pass number and
   // another pass's entries read as empty (wgl_narrow_impl.h, entry_empty); the arena is zeroed when the number wraps (and first of all)
-  const bool use_epoch = beam && B->lanes != 0 && B->max_ops < 0xFFFFF0ull;
+  const bool use_epoch = beam && B->lanes != 0;          // (a batch with lanes has every history below kNarrowMaxOps: batch_create_impl)
   if (beam) {
     if (use_epoch) B->epoch = B->epoch % 255u + 1u;
     if (!use_epoch || B->epoch == 1u) HIP_TRY(hipMemsetAsync(B->d_btab.p, 0, B->d_btab.bytes(), s));
@@ -1157,13 +1147,12 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results, int phase = 
   TRACE("run: memsets queued");
   SYNC_TRACE("memsets");
 
-  // TBC_PACK_ONE=1 (experimental; pack_one.hip): a handful of histories are packed by a workgroup's sixteen wavefronts each -- the
-  // single-history call's 0.28 ms pack is one wavefront's chain in pack_kernel.  Verified under the emulator only; nothing takes it unless asked
-  // (TBC_PACK_ONE=2: open_counts_kernel's tables in the same pass -- pack_one_counts_kernel, one launch fewer per call)
-  static const int pack_one = [] { const char* e = std::getenv("TBC_PACK_ONE"); return (e && (e[0] == '1' || e[0] == '2')) ? e[0] - '0' : 0; }();
+  // a handful of histories are packed by a workgroup's sixteen wavefronts each (pack_one.hip) -- the single-history call's 0.36 ms pack
+  // was one wavefront's chain in pack_kernel -- with open_counts_kernel's tables in the same pass where they fit (pack_one_counts_kernel,
+  // one launch fewer per call): 0.36 -> 0.10 ms, measured round 5 (profiles/r05_single_history_forms_first_device_run.json)
   bool packed = false, counted = false;
-  if (pack_one && nh <= 8) {
-    bool fits = true, fits2 = pack_one == 2 && beam;
+  if (nh <= 8) {
+    bool fits = true, fits2 = beam;
     for (uint32_t h = 0; h < nh; h++) {
       fits = fits && pack_one_fits(B->model.kind, B->hist[h].n_ops, B->hist[h].n_events, B->hist[h].n_slots);
       fits2 = fits2 && pack_one_counts_fits(B->model.kind, B->hist[h].n_ops, B->hist[h].n_events, B->hist[h].n_slots);
@@ -1171,17 +1160,14 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results, int phase = 
     if (fits2) packed = counted = launch_pack_one_counts(make_pack_args(B), make_pack_open_args(B), s);
     if (!packed && fits) packed = launch_pack_one(make_pack_args(B), s);
   }
-  // TBC_PACK_WG=1 (experimental; pack_one.hip, pack_wg_kernel): a batch of the wide schedule is packed by four wavefronts per history
-  // with the tables in LDS, and the same pass leaves what open_counts_kernel would (the ranks never leave the registers between the
-  // two).  Verified under the emulator only (tests/test_pack_one_emu.py); nothing takes it unless asked
-  // (TBC_PACK_WG=2: a batch of the wide schedule that cannot take it is an error instead of pack_kernel's -- the measurements' and the
-  // GPU tests' guarantee that they ran what they name)
-  static const int pack_wg = [] { const char* e = std::getenv("TBC_PACK_WG"); return (e && (e[0] == '1' || e[0] == '2')) ? e[0] - '0' : 0; }();
-  if (!packed && pack_wg && beam) {
+  // a batch of the wide schedule whose histories all fit is packed by four wavefronts per history with the tables in LDS (pack_one.hip,
+  // pack_wg_kernel), and the same pass leaves what open_counts_kernel would -- the ranks never leave the registers between the two
+  // (round 5, first device run: 14.4 against 16.1 ms per 8,192 bench histories; every batch parity test green under it); the others keep
+  // pack_kernel + open_counts_kernel
+  if (!packed && beam) {
     bool fits = true;
     for (uint32_t h = 0; h < nh && fits; h++) fits = pack_wg_fits(B->model.kind, B->hist[h].n_ops, B->hist[h].n_events, B->hist[h].n_slots);
     if (fits) packed = counted = launch_pack_wg(make_pack_args(B), make_pack_open_args(B), s);
-    if (!counted && pack_wg == 2) { set_error("TBC_PACK_WG=2: this batch does not fit the workgroup pack (model, rows, slots or ops per history)"); return TBC_ERR_UNSUPPORTED; }
   }
   if (!packed) launch_pack(make_pack_args(B), s);
   HIP_TRY(hipGetLastError());
@@ -1650,6 +1636,11 @@ tbc_status tbc_batch_last_counters(const tbc_batch* b, tbc_counters* out) {
 uint64_t tbc_batch_device_bytes(const tbc_batch* b) { return b ? b->device_bytes : 0; }
 uint32_t tbc_batch_search_width(const tbc_batch* b) { return b ? (b->lanes ? 1u : b->width) : 0; }
 uint32_t tbc_batch_lanes_per_history(const tbc_batch* b) { return b ? (b->lanes ? b->lanes : 64u) : 0; }
+uint32_t tbc_batch_list_order(const tbc_batch* b) {
+  if (!b) return 0;
+  const uint32_t lo = b->list_order();          // PackOpenArgs' numbering -> TBC_ORDER_*
+  return lo >= 16u ? lo : lo + 1u;
+}
 
 tbc_status tbc_batch_sweep_info(const tbc_batch* b, tbc_sweep_info* out) {
   if (!b || !out) return TBC_ERR_INVALID_ARG;

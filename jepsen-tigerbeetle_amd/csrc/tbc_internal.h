@@ -213,38 +213,7 @@ __host__ __device__ inline uint32_t front_stride(uint32_t vpad, uint32_t mask_wo
 //   7   ranks F .. F + 6, nine bits each: process slot (6) | read kind (3: the rdm index of the value read, 7 = not a read)
 constexpr uint32_t kFrontCompactWords = 8, kFrontCompactRanks = 7;
 __host__ __device__ inline bool front_compact_ok(uint32_t n_dom, uint32_t mask_words) { return mask_words == 1 && n_dom >= 2 && n_dom <= 6; }
-// LEAN TABLES (narrow kernel over compact front records; experimental, TBC_NARROW_LEAN): the same information in fewer memory lines --
-// a round of the search fetches ~12 lines of 64 B, 42 % of them the lookahead's, 11 % the twin masks' (DESIGN.md section 8).
-//   kLeanCands  a list entry is 16 B {call, twin mask} in ONE array (lst[], read as u64 pairs; no twn[] array):
-//               call = op (24) | f (3) << 24 | at-front (1) << 27 | slot (6) << 28 | a + 1 (6) << 34 | b + 1 (6) << 40   (NIL = 0;
-//               values 0 .. kMaxRuleValue, as everything under the dominance rules)
-//   kLeanLook   a lookahead record is 8 B, so the eight ranks a new config is checked against are ONE 64 B run:
-//               slot (6) | need (5) << 6 | prod (5) << 11 | dinv (8) << 16 | dprod (8) << 24 | crashed producer (1) << 32 |
-//               p1 (7) << 33 | p2 (7) << 40 | many (1) << 47          (need / prod: 31 = none)
-//               p1, p2 = slot + 1 of the (at most two) other calls open at that rank's front that produce `need`, 0 = none; three or more
-//               such calls set `many`, which the rule reads as "one of them is still to be linearized" -- never a config declared dead
-//               that is not (a dead config is set aside, not dropped, so even that would cost time and no verdict); oracle/wgl_beam.c
-//               states the same reading (wgl_beam_set_look_two)
-//   kLeanLazy   (a schedule detail, not a format; with the two above) the lookahead is run at once only for the new config of a round that
-//               will be popped next (the highest viable pair); its siblings go onto the stack UNCHECKED (bit 31 of their stack word)
-//               and are looked at if they are ever popped -- a dead one is set aside then.  The same probes, configs and rounds; half
-//               the lookahead runs of a nearly greedy search (oracle/wgl_beam.c, wgl_beam_set_lazy_look)
-constexpr uint32_t kLeanCands = 1u, kLeanLook = 2u, kLeanLazy = 4u;
-constexpr uint32_t kUnchecked = 0x80000000u;
-constexpr uint32_t kLean5None = 31u;
-__host__ __device__ inline uint64_t lean_call(uint32_t op, uint32_t f, bool at_front, uint32_t slot, int32_t a, int32_t b) {
-  const uint64_t a6 = a == TBC_NIL ? 0ull : (uint64_t)((uint32_t)a + 1u) & 63ull, b6 = b == TBC_NIL ? 0ull : (uint64_t)((uint32_t)b + 1u) & 63ull;
-  return (uint64_t)(op & 0xFFFFFFu) | (uint64_t)(f & 7u) << 24 | (uint64_t)(at_front ? 1u : 0u) << 27 | (uint64_t)(slot & 63u) << 28 | a6 << 34 | b6 << 40;
-}
-__host__ __device__ inline uint64_t lean_look(uint32_t slot, uint32_t need, uint32_t prod, uint32_t dinv, uint32_t dprod, uint64_t pm) {
-  const uint32_t n = (uint32_t)__builtin_popcountll(pm);
-  const uint64_t pm2 = pm & (pm - 1ull);
-  const uint32_t p1 = n ? (uint32_t)__builtin_ctzll(pm) + 1u : 0u, p2 = n >= 2u ? (uint32_t)__builtin_ctzll(pm2) + 1u : 0u, many = n >= 3u ? 1u : 0u;
-  const uint32_t n5 = need == 0xFFu ? kLean5None : (need & 31u), p5 = prod == 0xFFu ? kLean5None : (prod & 31u);
-  return (uint64_t)(slot & 63u) | (uint64_t)n5 << 6 | (uint64_t)p5 << 11 | (uint64_t)(dinv & 0xFFu) << 16 | (uint64_t)(dprod & 0xFFu) << 24 |
-         (uint64_t)p1 << 33 | (uint64_t)p2 << 40 | (uint64_t)many << 47;
-}
-constexpr uint64_t kLeanLookCrashedBit = 1ull << 32;
+constexpr uint64_t kNarrowMaxOps = 0xFFFFF0ull;          // several histories per wavefront: front + 1 must fit 24 bits of a visited-set key
 constexpr int32_t kMaxRuleValue = 30;       // register values 0..30 (vpad <= 32); anything else switches the rules off
 __host__ __device__ inline uint32_t rdm_index(int32_t v, uint32_t vpad) {   // row entry of state / read value v
   return (v == TBC_NIL || (uint32_t)(v + 1) >= vpad) ? 0u : (uint32_t)(v + 1);
@@ -298,7 +267,6 @@ struct PackOpenArgs {
   uint32_t vpad;
   uint32_t h0;               // histories [h0, n_hist) are worked on by this launch
   const uint64_t* cmem;      // count form: class members (inv_rank | op << 32), or null
-  uint32_t lean;             // kLeanCands | kLeanLook: the lean formats of lst[] / look[] (the walk with lane = front, compact front records)
   uint32_t list_order;       // 0 = a front's list in process-slot order; 1 = in order of completion (the walk with lane = front only; experimental,
                              // TBC_NARROW_ORDER=1): the search takes a config's candidates last to first and pops the last child first, so the call
                              // that completes soonest is tried first -- on the bench workload 18 % fewer rounds for the same probes, the longest
@@ -364,8 +332,6 @@ struct BeamArgs {
   uint32_t epoch;                    // narrow kernel: this pass's tag in the visited-set keys, 1..255 (wgl_narrow_impl.h, entry_empty); 0 = none
   uint32_t first_dynamic;            // narrow kernel: work items below this are dealt to the wavefronts at launch (wave w, group g: w * H + g) ...
   unsigned int* next_work;           // ... the others are taken from this counter (zeroed before the launch) as groups finish
-  uint32_t lean;                     // narrow kernel: kLeanCands | kLeanLook (the tables are in the lean formats; a kernel instance of its own)
-  uint32_t pad_lean;
 };
 
 // ---- level sweep (jit_sweep.hip): knossos.linear as segments swept by one wavefront each
@@ -412,7 +378,7 @@ struct SweepArgs {
 };
 bool launch_sweep(const SweepArgs& a, void* stream);
 // K6w (jit_sweep_wg.hip): the first pass with `waves` (4 / 8) wavefronts per segment; false = not for this batch (the caller takes K6)
-bool launch_sweep_wg(const SweepArgs& a, uint32_t waves, void* stream);
+bool launch_sweep_wg(const SweepArgs& a, void* stream);
 
 // skip_counts: open_counts_kernel's tables are already there (launch_pack_wg built them with the pack)
 void launch_pack_open(const PackOpenArgs& a, void* stream, bool skip_counts = false);

@@ -25,17 +25,6 @@ __global__ __launch_bounds__(64 * kNarrowWaves, CNT ? 2 : TBC_NARROW_MIN_WAVES) 
   const uint32_t w = blockIdx.x * kNarrowWaves + wv_;
   narrow::narrow_wave<MW, L, CF, CNT>(A, w, lds + wv_ * narrow::narrow_lds_words(MW, L, CF, CNT), lane);
 }
-// the lean tables (tbc_internal.h, kLeanCands | kLeanLook; experimental, TBC_NARROW_LEAN=1): a kernel of its own, so that the one above
-// stays instruction for instruction what was measured
-template <int L, int LEAN = (int)(kLeanCands | kLeanLook)>
-__global__ __launch_bounds__(64 * kNarrowWaves, TBC_NARROW_MIN_WAVES) void wgl_narrow_lean_kernel(BeamArgs A) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-  const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t wv_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const uint32_t w = blockIdx.x * kNarrowWaves + wv_;
-  narrow::narrow_wave<1, L, true, false, LEAN>(A, w, lds + wv_ * narrow::narrow_lds_words(1, L, true, false), lane);
-}
-
 // Wavefronts the GPU keeps resident at once: the launch is sized to that, not to the batch -- a wavefront's groups take more
 // histories off the queue as they finish (BeamArgs.next_work), so no wavefront starts late into a half-empty machine and a
 // group whose history was short does not idle until its seven neighbours are done.
@@ -64,27 +53,8 @@ void launch_cf(const BeamArgs& a_in, hipStream_t s, uint32_t wps) {
   hipLaunchKernelGGL((wgl_narrow_kernel<MW, L, CF, CNT>), dim3(blocks), dim3(64 * kNarrowWaves), lds_wave * kNarrowWaves, s, a);
 }
 
-template <int L>
-void launch_lean(const BeamArgs& a_in, hipStream_t s, uint32_t wps) {
-  const uint32_t H = 64u / L;
-  const size_t lds_wave = (size_t)narrow::narrow_lds_words(1, L, true, false) * 4;
-  uint32_t waves = (a_in.n_work + H - 1) / H;
-  const uint32_t fit = resident_waves(lds_wave, wps);
-  if (waves > fit) waves = fit;
-  const uint32_t blocks = (waves + kNarrowWaves - 1) / kNarrowWaves;
-  BeamArgs a = a_in;
-  a.first_dynamic = blocks * kNarrowWaves * H;
-  (void)hipMemsetAsync(a.next_work, 0, sizeof(unsigned int), s);
-  // (kLeanLazy: the lookahead at once only for the config popped next -- TBC_NARROW_LEAN=2)
-  if (a.lean & kLeanLazy) hipLaunchKernelGGL((wgl_narrow_lean_kernel<L, (int)(kLeanCands | kLeanLook | kLeanLazy)>), dim3(blocks), dim3(64 * kNarrowWaves), lds_wave * kNarrowWaves, s, a);
-  else hipLaunchKernelGGL((wgl_narrow_lean_kernel<L>), dim3(blocks), dim3(64 * kNarrowWaves), lds_wave * kNarrowWaves, s, a);
-}
-
 template <int MW, int L>
 void launch_one(const BeamArgs& a, hipStream_t s, uint32_t wps) {
-  if constexpr (MW == 1) {
-    if ((a.lean & (kLeanCands | kLeanLook)) == (kLeanCands | kLeanLook) && a.front_words == kFrontCompactWords && !(a.rules & kRuleCount)) { launch_lean<L>(a, s, wps); return; }
-  }
   if constexpr (MW <= 2 && L >= 8) {
     if (a.rules & kRuleCount) {          // the count form (crashed calls as counts per class): one or two mask words, 8 / 16 / 32 lanes per history
       if constexpr (MW == 1) { if (a.front_words == kFrontCompactWords) { launch_cf<1, L, true, true>(a, s, wps); return; } }

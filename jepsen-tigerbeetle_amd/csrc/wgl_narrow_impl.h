@@ -32,7 +32,7 @@ namespace narrow {
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 
 // group flags
-enum : uint32_t { F_ACTIVE = 1u, F_NEED_POP = 2u, F_LOOK = 4u, F_NEED_GROW = 8u, F_CAND = 16u, F_CHECK = 32u };      // F_CHECK: the parent was pushed unchecked (kLeanLazy)
+enum : uint32_t { F_ACTIVE = 1u, F_NEED_POP = 2u, F_LOOK = 4u, F_NEED_GROW = 8u, F_CAND = 16u };
 
 // LDS words of a group: counters and results, then the ring of the most recent pushes
 enum : uint32_t {
@@ -67,6 +67,7 @@ WV_DEV uint32_t key_hash32(uint64_t k0, const uint64_t* M, int mw) {      // as 
 // Zero stays empty too (the growth pool, scratch arenas), and epoch 0 is the untagged form: empty = zero.
 WV_DEV bool entry_empty(uint32_t x, uint32_t etag) { return x == 0u || (x & 0xFF000000u) != etag; }
 constexpr uint32_t kFrontMask = 0x00FFFFFFu;
+static_assert(kNarrowMaxOps + 1 <= kFrontMask, "a history the narrow kernel takes has front + 1 inside the key's 24 bits (tbc_api.hip refuses longer ones)");
 // count form: field-wise x >= y over packed count vectors, top = the top bit of every field (oracle/wgl_count.c, counts_ge)
 WV_DEV bool counts_ge(const uint64_t (&x)[kCountWords], const uint64_t (&y)[kCountWords], const uint64_t (&top)[kCountWords]) {
   bool ge = true;
@@ -108,7 +109,7 @@ WV_DEV int32_t reg_apply(int32_t st, uint32_t f, int32_t a, int32_t b) {
 // ---- cold path: group `gsel`'s history moves to a 4x larger visited set (and stacks) from the batch's growth pool, done
 // by the whole wavefront (as wgl_beam.hip's grow_visited_set).  In / out: the group's table, stack, second stack and
 // capacity, wave-uniform.  Slot numbers change: the caller empties the group's ring.
-template <int MW, bool CNT, class ColdArgs, bool LZ = false>
+template <int MW, bool CNT, class ColdArgs>
 WV_DEV bool grow_group(ColdArgs C, wv::gu64*& tab_u, wv::gu32*& stack_u, wv::gu32*& dstack_u, uint32_t& cap_log2_u,
                        uint32_t sp, uint32_t dsp, uint32_t lane, uint32_t etag, bool links) {
   constexpr uint32_t CWn = CNT ? kCountWords : 0u;        // count form: the count words ride behind the mask words (not hashed)
@@ -166,8 +167,7 @@ WV_DEV bool grow_group(ColdArgs C, wv::gu64*& tab_u, wv::gu32*& stack_u, wv::gu3
   WV_NOUNROLL
   for (uint32_t i = lane; i < sp; i += 64) {
     const uint32_t x = wv::ld32(stack + i);
-    if constexpr (LZ) wv::st32(nstack + i, wv::ld32(remap + (x & ~kUnchecked)) | (x & kUnchecked));      // (an unchecked sibling keeps its mark)
-    else wv::st32(nstack + i, wv::ld32(remap + x));
+    wv::st32(nstack + i, wv::ld32(remap + x));
   }
   WV_NOUNROLL
   for (uint32_t i = lane; i < dsp; i += 64) wv::st32(ndstack + i, wv::ld32(remap + wv::ld32(dstack + i)));
@@ -180,12 +180,9 @@ WV_DEV bool grow_group(ColdArgs C, wv::gu64*& tab_u, wv::gu32*& stack_u, wv::gu3
 // One wavefront: H = 64 / L histories, work items wave_idx * H .. + H - 1 of A.work.
 // CF: the front records are the compact 64 B ones (tbc_internal.h; MW = 1)
 // CNT: the count form (tbc_internal.h, kRuleCount; the schedule is oracle/wgl_count.c's at one config per iteration and L pairs per round)
-// LEAN: kLeanCands | kLeanLook -- the tables are in the lean formats (tbc_internal.h; compact front records, exact counts only)
-template <int MW, int L, bool CF = false, bool CNT = false, int LEAN = 0>
+template <int MW, int L, bool CF = false, bool CNT = false>
 WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* lds, const uint32_t lane) {
   static_assert(!CF || MW == 1, "compact front records have one mask word");
-  static_assert(LEAN == 0 || (CF && !CNT), "the lean formats: compact front records, no count form");
-  constexpr bool LC = (LEAN & (int)kLeanCands) != 0, LK = (LEAN & (int)kLeanLook) != 0, LZ = (LEAN & (int)kLeanLazy) != 0;
   constexpr uint32_t WN = CF ? 1u : 4u;          // window words per config
   using wv::gu32;
   using wv::gu64;
@@ -245,7 +242,7 @@ WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* ld
     tab = (gu64*)A.tab + (has ? Bd->tab_off : 0ull) * A.tab_stride;
     stack = (gu32*)A.stack + (has ? Bd->stack_off : 0ull);
     cap_log2 = has ? Bd->tab_log2 : 10u;
-    look_lo = (uint32_t)look_off(op_off, hidx, LK ? 0u : (uint32_t)MW);           // u64 units into A.look (lean: one word a rank)
+    look_lo = (uint32_t)look_off(op_off, hidx, (uint32_t)MW);           // u64 units into A.look
     slot8_lo = slot8_off(op_off, hidx);
     RT = R;
     if constexpr (CNT) {
@@ -353,21 +350,9 @@ WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* ld
     const OpRec* rp = live_ ? A.lst + ((uint64_t)lst_off + po + c_)
                             : (CNT ? reinterpret_cast<const OpRec*>(A.cmem + cmem_lo) + (c_ - nlive_) : A.crashed + ((uint64_t)op_off + (c_ - nlive_)));
     c_oi = *rp;
-    if constexpr (LC) {
-      // lean list entry {call, twin mask}: 16 B of ONE array -- the record is unpacked, the mask came with it
-      const uint64_t call = (uint64_t)c_oi.op | ((uint64_t)c_oi.f_slot << 32), tw64 = (uint64_t)(uint32_t)c_oi.a | ((uint64_t)(uint32_t)c_oi.b << 32);
-      if (live_) {
-        const uint32_t a6 = (uint32_t)(call >> 34) & 63u, b6 = (uint32_t)(call >> 40) & 63u;
-        c_oi.op = (uint32_t)call & 0xFFFFFFu;
-        c_oi.f_slot = ((uint32_t)(call >> 24) & 7u) | (((uint32_t)(call >> 28) & 63u) << 8) | (((call >> 27) & 1ull) ? kAtFront : 0u);
-        c_oi.a = a6 ? (int32_t)a6 - 1 : TBC_NIL; c_oi.b = b6 ? (int32_t)b6 - 1 : TBC_NIL;
-      }
-      c_tw[0] = (twin && live_ && have) ? tw64 : 0ull;
-    } else {
     const uint64_t* tw = tw_base + ((twin && live_) ? ((uint64_t)lst_off + po + c_) * MW : 0ull);
     WV_UNROLL
     for (int j = 0; j < MW; j++) c_tw[j] = tw[j];
-    }
   };
   // ---- results of the groups that have just finished (sel: mine has).  The witness (only when asked for: the parent chain
   // is thousands of dependent loads) is walked by all of them at once, each lane following its own group's chain; the configs
@@ -489,7 +474,7 @@ WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* ld
         gu32* d_u = (gu32*)((uint64_t)GSg[G_DSTACK] | ((uint64_t)GSg[G_DSTACK + 1] << 32));
         uint32_t cap_u = wv::readlane(cap_log2, src);
         const uint32_t sp_u = wv::readlane(sp, src), dsp_u = wv::readlane(dsp, src);
-        const bool ok = grow_group<MW, CNT, decltype(C), LZ>(C, t_u, s_u, d_u, cap_u, sp_u, dsp_u, lane, etag, links);
+        const bool ok = grow_group<MW, CNT, decltype(C)>(C, t_u, s_u, d_u, cap_u, sp_u, dsp_u, lane, etag, links);
         if (g == gg) {
           if (ok) {
             tab = t_u; stack = s_u; cap_log2 = cap_u;
@@ -532,13 +517,13 @@ WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* ld
           WV_UNROLL
           for (int j = 0; j < MW; j++) Mp[j] = r_M[rs * MW + j];
           raw_idx = r_idx[rs];
-          pslot = LZ ? (raw_idx & ~kUnchecked) : raw_idx; poff = r_off[rs]; nlive = r_nlive[rs]; cnt = r_cnt[rs];
+          pslot = raw_idx; poff = r_off[rs]; nlive = r_nlive[rs]; cnt = r_cnt[rs];
           p_ws0 = r_W[rs * WN];
           if constexpr (!CF) { p_ws1 = r_W[rs * 4 + 1]; p_wk0 = r_W[rs * 4 + 2]; p_wk1 = r_W[rs * 4 + 3]; }
           if constexpr (CNT) { Cp[0] = r_C[rs * 2]; Cp[1] = r_C[rs * 2 + 1]; }
         } else {
           raw_idx = wv::own_ld32(stack + pos);
-          const uint32_t idx = LZ ? (raw_idx & ~kUnchecked) : raw_idx;
+          const uint32_t idx = raw_idx;
           const gu64* e = tab + (uint64_t)idx * KW;
           k0 = wv::own_ld64(e);
           WV_UNROLL
@@ -557,20 +542,15 @@ WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* ld
         } else {
           sp = pos; base = 0u;
           if (cnt != 0u) flags &= ~F_NEED_POP;       // (only the root can have no candidate at all: the others are not pushed)
-          // kLeanLazy: a sibling pushed unchecked is looked at first -- this iteration runs its lookahead (and fetches its candidates) instead
-          // of a round; it counts as expanded only once it is known to live
-          const bool unchecked = LZ && (raw_idx & kUnchecked) != 0u && (flags & F_LOOK) != 0u;
-          if (unchecked) flags |= F_CHECK;
-          else if (li == 0) wv::lds_add64(GS + G_EXPANDED, 1ull);
+          if (li == 0) wv::lds_add64(GS + G_EXPANDED, 1ull);
         }
       }
     }
 
     // ---- a group whose candidates were not fetched ahead sits this round out and fetches them with the others' (below)
     const bool wants = (flags & (F_ACTIVE | F_NEED_POP | F_NEED_GROW)) == F_ACTIVE;
-    const bool chk = LZ && wants && (flags & F_CHECK) != 0u;           // its lookahead first: no round, its candidates fetched beside it
-    const bool inround = wants && (flags & F_CAND) && !chk;
-    const bool fetch_now = wants && (!(flags & F_CAND) || chk);
+    const bool inround = wants && (flags & F_CAND);
+    const bool fetch_now = wants && !(flags & F_CAND);
     if (fetch_now && li == 0) wv::stat(22, 1);
 
     // ---- the round: lane li takes pair base + li of the parent = its open call number cnt - 1 - (base + li)
@@ -606,14 +586,6 @@ WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* ld
     if (!CNT && twin && act && !lin && !live && (f == TBC_F_WRITE || f == TBC_F_CAS)) {
       for (uint32_t cc = 0; cc < c && !dominated; cc++) {
         OpRec y = cc < nlive ? A.lst[(uint64_t)lst_off + poff + cc] : A.crashed[(uint64_t)op_off + (cc - nlive)];
-        if constexpr (LC) {
-          if (cc < nlive) {               // (a lean list entry: unpack what the comparison below reads)
-            const uint64_t call = (uint64_t)y.op | ((uint64_t)y.f_slot << 32);
-            const uint32_t a6 = (uint32_t)(call >> 34) & 63u, b6 = (uint32_t)(call >> 40) & 63u;
-            y.f_slot = ((uint32_t)(call >> 24) & 7u) | (((uint32_t)(call >> 28) & 63u) << 8);
-            y.a = a6 ? (int32_t)a6 - 1 : TBC_NIL; y.b = b6 ? (int32_t)b6 - 1 : TBC_NIL;
-          }
-        }
         if ((y.f_slot & 0xFFu) != f || y.a != oi.a || (f == TBC_F_CAS && y.b != oi.b)) continue;
         dominated = !mask_bit<MW>(Mp, (y.f_slot >> 8) & kSlotMask);
       }
@@ -690,12 +662,10 @@ WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* ld
     // ---- trip 1: the child's front's record -- the reads the eager rule takes there, where its open-call list is, and the
     // windows its own children will advance over: one line -- and, in the same trip, the lookahead records of every viable
     // child (8 lanes per child, one rank each, staged wave-wide: the fronts now, states and masks when the rows are in)
-    // (kLeanLazy: only the child that will be popped next -- the group's highest viable pair -- and a parent under check, on the group's first lane)
-    const bool chk_lane = chk && li == 0u;
-    const bool lkme = (go && (flags & F_LOOK) && (!LZ || li == 31u - (uint32_t)__builtin_clz(gv | 1u))) || chk_lane;
+    const bool lkme = go && (flags & F_LOOK);
     const uint64_t lk = wv::ballot(lkme);
     const uint32_t ci = (uint32_t)__builtin_popcountll(lk & ((1ull << lane) - 1ull)), nn0 = (uint32_t)__builtin_popcountll(lk);
-    if (lkme) { c_fi[ci] = chk_lane ? p_fi : fi2; c_lo[ci] = look_lo; if constexpr (CNT) c_rt[ci] = RT; }
+    if (lkme) { c_fi[ci] = fi2; c_lo[ci] = look_lo; if constexpr (CNT) c_rt[ci] = RT; }
     wv::barrier();
     const uint32_t f3 = go ? fi2 : 0u;
     const uint64_t* const fr = A.rdm + ((uint64_t)op_off + f3) * FW;
@@ -710,10 +680,10 @@ WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* ld
         const uint32_t cc = 8u * bt + (lane >> 3), jr = lane & 7u;
         const bool val = cc < nn0;
         const uint32_t lo_ = val ? c_lo[cc] : (look_avail ? look_lo : 0u), fr_ = val ? c_fi[cc] + jr : 0u;
-        const uint64_t* rec = lk_base + (uint64_t)lo_ + (uint64_t)fr_ * (LK ? 1 : MW + 1);
+        const uint64_t* rec = lk_base + (uint64_t)lo_ + (uint64_t)fr_ * (MW + 1);
         lw0[bt] = rec[0];
         WV_UNROLL
-        for (int w = 0; w < MW; w++) lpm[bt][w] = LK ? 0ull : rec[1 + w];
+        for (int w = 0; w < MW; w++) lpm[bt][w] = rec[1 + w];
       }
       uint64_t m0, m1 = 0;
       if constexpr (CF) { m0 = fr[6]; cw[0] = fr[7]; }
@@ -738,9 +708,9 @@ WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* ld
     // the candidates fetched below follow the highest child that is ALIVE
     bool dead = false;
     if (lkme) {
-      c_st[ci] = (uint32_t)(chk_lane ? p_st : st2);
+      c_st[ci] = (uint32_t)st2;
       WV_UNROLL
-      for (int j = 0; j < MW; j++) c_M[ci * MW + j] = chk_lane ? Mp[j] : M2[j];
+      for (int j = 0; j < MW; j++) c_M[ci * MW + j] = M2[j];
     }
     wv::barrier();
     // one batch of 8 children: lane (child cb + lane / 8, rank lane % 8) decides its rank; returns the lanes that found
@@ -755,20 +725,10 @@ WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* ld
       for (int w = 0; w < MW; w++) Mc[w] = val ? c_M[cc * MW + w] : 0ull;
       uint32_t slot, need, prod, dinv, dprod;
       bool pmhit = false;
-      if constexpr (LK) {
-        // the 8 B record: two producer slots instead of a mask, `many` = three or more (read as: one of them is still to be linearized)
-        slot = (uint32_t)w_0 & 63u;
-        const uint32_t n5 = (uint32_t)(w_0 >> 6) & 31u, p5 = (uint32_t)(w_0 >> 11) & 31u;
-        need = n5 == kLean5None ? kLookNone : n5; prod = p5 == kLean5None ? kLookNone : p5;
-        dinv = (uint32_t)(w_0 >> 16) & 0xFFu; dprod = (uint32_t)(w_0 >> 24) & 0xFFu;
-        const uint32_t p1 = (uint32_t)(w_0 >> 33) & 127u, p2 = (uint32_t)(w_0 >> 40) & 127u;
-        pmhit = ((w_0 >> 47) & 1ull) != 0ull || (p1 != 0u && !mask_bit<MW>(Mc, p1 - 1u)) || (p2 != 0u && !mask_bit<MW>(Mc, p2 - 1u));
-      } else {
       slot = (uint32_t)w_0 & 0xFFFFu; need = (uint32_t)(w_0 >> 16) & 0xFFu; prod = (uint32_t)(w_0 >> 24) & 0xFFu;
       dinv = (uint32_t)(w_0 >> 32) & 0xFFu; dprod = (uint32_t)(w_0 >> 40) & 0xFFu;
       WV_UNROLL
       for (int w = 0; w < MW; w++) pmhit = pmhit || (pm[w] & ~Mc[w]) != 0ull;
-      }
       const bool linz = dinv >= j && mask_bit<MW>(Mc, slot);     // open at the config's front and linearized
       // values the calls completing at the ranks before this one can still provide (prefix-OR over the 8 lanes)
       uint32_t acc = (prod != kLookNone && !linz) ? 1u << prod : 0u;
@@ -795,32 +755,13 @@ WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* ld
         const uint32_t cc = cb + (lane >> 3), jr = lane & 7u;
         const bool val = cc < nn0;
         const uint32_t lo_ = val ? c_lo[cc] : (look_avail ? look_lo : 0u), fr_ = val ? c_fi[cc] + jr : 0u;
-        const uint64_t* rec = lk_base + (uint64_t)lo_ + (uint64_t)fr_ * (LK ? 1 : MW + 1);
+        const uint64_t* rec = lk_base + (uint64_t)lo_ + (uint64_t)fr_ * (MW + 1);
         uint64_t xpm[MW];
         const uint64_t xw0 = rec[0];
         WV_UNROLL
-        for (int w = 0; w < MW; w++) xpm[w] = LK ? 0ull : rec[1 + w];
+        for (int w = 0; w < MW; w++) xpm[w] = rec[1 + w];
         const uint64_t badx = look_batch(cb, xw0, xpm);
         if (lkme && ci >= cb && ci < cb + 8u) dead = ((badx >> (8u * (ci - cb))) & 0xFFull) != 0ull;
-      }
-    }
-
-    // kLeanLazy: a parent under check.  Dead: it is set aside (as a dead new config would have been) and the next entry is popped; alive: it
-    // counts as expanded now and runs its first round in the next iteration, over the candidates this iteration fetches.
-    bool chk_dead = false;
-    if constexpr (LZ) {
-      chk_dead = grp(wv::ballot(chk_lane && dead)) != 0u;
-      if (chk) {
-        if (chk_dead) {
-          if (li == 0u) {
-            gu32* const ds = (gu32*)((uint64_t)GS[G_DSTACK] | ((uint64_t)GS[G_DSTACK + 1] << 32));
-            wv::own_st32(ds + dsp, pslot);
-          }
-          dsp += 1u;
-          flags |= F_NEED_POP;
-        } else if (li == 0u) wv::lds_add64(GS + G_EXPANDED, 1ull);
-        flags &= ~F_CHECK;
-        dead = false;
       }
     }
 
@@ -963,8 +904,7 @@ WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* ld
     const uint32_t gnb = grp(wv::ballot(keep));
     if (keep) {
       const uint32_t pos = sp + (uint32_t)__builtin_popcount(gnb & below);
-      // (kLeanLazy: every kept config but the round's highest viable pair goes on unchecked -- its lookahead was not run)
-      const uint32_t word = (LZ && (flags & F_LOOK) && li != 31u - (uint32_t)__builtin_clz(gv | 1u)) ? (idx | kUnchecked) : idx;
+      const uint32_t word = idx;
       wv::own_st32(stack + pos, word);
       const uint32_t rs = pos & (RS - 1u);          // at most L <= RS pushes a round: no clash
       r_pos[rs] = pos; r_idx[rs] = word; r_k0[rs] = k0c;
@@ -982,7 +922,7 @@ WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* ld
       // were the candidates fetched above the next round's?  (the highest viable child is the next parent iff it was kept;
       // a group that sat out fetched the round it wanted; anybody else has none)
       // (to_below: every viable child was dead or barren -- none is pushed onto the stack -- unless a dead one... dead ones go aside)
-      const bool right = inround ? (cand_next && (more || (to_below && gnb == 0u) || (to_child && ((gnb >> hv) & 1u)))) : (fetch_now && !chk_dead);
+      const bool right = inround ? (cand_next && (more || (to_below && gnb == 0u) || (to_child && ((gnb >> hv) & 1u)))) : fetch_now;
       flags = right ? (flags | F_CAND) : (flags & ~F_CAND);
       if (inround && li == 0) {
         wv::stat(right ? 23 : 24, 1);

@@ -323,7 +323,7 @@ def check_sweep(ops, model, eager_reads=True, twin_rule=True, seg_target=0, max_
     return out
 
 
-def check_many(ops_list, model, n_threads, max_steps=0, beam_width=0, round_pairs=64):
+def check_many(ops_list, model, n_threads, max_steps=0, beam_width=0, round_pairs=64, list_order=0, branch_lists=False):
     """Many histories on a pthread pool (many.c): verdicts as an int32 array.  beam_width = 0: wgl_window_check (the
     sequential knossos.wgl restatement); > 0: wgl_beam.c at that many configs per round with the library's default
     rules (lookahead, eager reads, twin rule where they apply to the FIRST history's model and values); round_pairs = 8 / 16 / 32 with
@@ -351,6 +351,8 @@ def check_many(ops_list, model, n_threads, max_steps=0, beam_width=0, round_pair
         lib().wgl_beam_set_lookahead(C.c_uint32(1 if model["kind"] in (0, 1) else 0))
         lib().wgl_beam_set_eager_reads(C.c_uint32(1 if rules else 0))
         lib().wgl_beam_set_twin_rule(C.c_uint32(1 if rules else 0))
+        lib().wgl_beam_set_list_order(C.c_uint32(list_order))          # (as check_beam's: the order of a front's list of open calls)
+        lib().wgl_beam_set_branch_lists(C.c_uint32(1 if (branch_lists and rules) else 0))
     try:
         started = fn(C.c_uint32(nh), _p(n, C.c_uint32), _p(npr, C.c_uint32), f, a, b, pr, inv, ret, C.byref(m),
                      C.c_uint64(max_steps), C.c_uint32(n_threads), C.c_uint32(beam_width), C.c_uint32(round_pairs), _p(valid, C.c_int32))
@@ -358,6 +360,8 @@ def check_many(ops_list, model, n_threads, max_steps=0, beam_width=0, round_pair
         if beam_width:
             lib().wgl_beam_set_eager_reads(C.c_uint32(0))
             lib().wgl_beam_set_twin_rule(C.c_uint32(0))
+            lib().wgl_beam_set_list_order(C.c_uint32(0))
+            lib().wgl_beam_set_branch_lists(C.c_uint32(0))
     del keep, keep_m
     return valid, started
 

@@ -1,5 +1,5 @@
-"""The experimental forms of the level sweep (compact walk, narrow passes by one wavefront, fingerprint, ring) and the lean tables / the lists in order
-of completion of the narrow search under the emulators on random small histories -- sizes, concurrency, planted bad reads (inside the value domain),
+"""The forms of the level sweep (plain walk, compact walk, narrow passes by one wavefront) and the lists in every order
+of the narrow search under the emulators on random small histories -- sizes, concurrency, planted bad reads (inside the value domain),
 crashed calls, wavefronts per workgroup, set sizes, segment lengths, interleaving seeds -- every record / counter against the oracle.
 usage: fuzz_forms_emu.py [rounds] [seed]      Round 4: 650 rounds over five seeds; one find -- the ring form's missing barrier (wavefronts at
 different workgroup barriers: a hang on the device), fixed -- and no mismatch since."""
@@ -21,15 +21,10 @@ for it in range(rounds):
     seed = rng.randrange(10 ** 6)
     h = TN._in_domain(n, p, seed, busy, info, corrupt)
     # ---- the sweep's forms
-    form = rng.choice([{"compact": True}, {"compact": 2}, {"compact": 2, "fp": True}, {"compact": True, "fp": True}, {"queue": True, "fp": True},
-                       {"queue": True}, {"fp": True}, {}])
+    form = rng.choice([{"compact": True}, {"compact": 2}, {"compact": 2}, {}])
     # (the geometries tests/emu/emu_sweep.cpp instantiates for each form)
     if form.get("compact"):
         waves, cap = rng.choice([(2, 512), (2, 1024), (4, 1024), (8, 1024), (8, 2048), (16, 2048)])
-    elif form.get("fp"):
-        waves, cap = rng.choice([(2, 1024), (8, 1024), (4, 512)])
-    elif form.get("queue"):
-        waves, cap = rng.choice([(2, 1024), (4, 1024), (8, 1024), (4, 512), (8, 2048)])
     else:
         waves, cap = rng.choice([(2, 1024), (4, 1024), (8, 1024), (4, 512), (8, 2048), (16, 2048)])
     seg = rng.choice([0, 16, 32, 32])
@@ -44,17 +39,16 @@ for it in range(rounds):
             TS._compare(h, seg, 6, waves, cap=cap, seed=rng.randrange(1000), expect_overflow=True, **form)      # (the bare assert: a level outgrew the sets)
     except Exception as e:
         bad += 1; print("SWEEP MISMATCH", it, (n, p, busy, corrupt, info, seed), form, waves, cap, seg, repr(e)[:300], flush=True)
-    # ---- the lean tables
+    # ---- the narrow kernel over the fronts' lists in every order
     if h.n_process <= 64:
         try:
             by_ret = ((16 + rng.choice([1, 4, 16, 24, 200]) if it & 32 else 2) if it & 16 else 1) if it & 2 else 0        # (2: ... with the :write calls last, TBC_NARROW_ORDER=2) the fronts' lists in order of completion (a witness's absorbed reads in that order too)
-            lean = (2 if it & 8 else 1) if (it & 4 or not by_ret) else False          # 2: + the lazy lookahead
-            TN.compare([h], TN.CAS, rng.choice([8, 16, 32]), tag="fuzz", pool_words=8_000_000, lean=lean, entries_per_op=rng.choice([1, 4, 8]),
+            TN.compare([h], TN.CAS, rng.choice([8, 16, 32]), tag="fuzz", pool_words=8_000_000, entries_per_op=rng.choice([1, 4, 8]),
                        want_witness=bool(it & 1), epochs=rng.choice([0, 0, 2]), by_ret=by_ret)
         except Exception as e:
             a = e.args[0] if e.args else None
             if isinstance(a, tuple) and len(a) == 4 and a[1] == -1 and a[3] == 3:
                 continue                                  # (the emulator's growth pool ran out under an exhaustive search: a limit, not a mismatch)
-            bad += 1; print("LEAN MISMATCH", it, (n, p, busy, corrupt, info, seed), repr(e)[:300], flush=True)
+            bad += 1; print("ORDER MISMATCH", it, (n, p, busy, corrupt, info, seed), repr(e)[:300], flush=True)
 print("rounds", rounds, "mismatches", bad)
 sys.exit(1 if bad else 0)

@@ -39,7 +39,7 @@ for it in range(rounds):
     if not hs:
         continue
     cap = rng.choice([0, 0, 0, 40, 400])
-    for kw in ({"branch": bool(it & 1), "lst_cap": cap}, {"count": True, "branch": bool(it & 2), "lean": bool(it & 4)}, {"one": True, "branch": True, "lst_cap": cap}):
+    for kw in ({"branch": bool(it & 1), "lst_cap": cap}, {"count": True, "branch": bool(it & 2)}, {"one": True, "branch": True, "lst_cap": cap}):
         r = emu.pack_wg_check(hs, seed=it, per_launch=rng.choice([0, 1, 4]), **kw)
         if r is not None:
             bad += 1

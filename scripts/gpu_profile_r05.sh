@@ -4,7 +4,7 @@
 # (8 / 16 / 32, or 64 = one history per wavefront), $3 = tag of the output directory, $5 = visited-set entries per op (default 4, the bench's).
 B=${1:-32768}
 L=${2:-8}
-TAG=${3:-r03_l$L}
+TAG=${3:-r05_l$L}
 VPO=${5:-4}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
@@ -26,7 +26,7 @@ fi
 python $GRAFT_REPO_ROOT/scripts/summarize_pmc_csv.py $OUT/pmc1 $OUT/pmc2 $OUT/pmc3 $OUT/pmc4 > $OUT/pmc_summary.txt 2>&1
 if [ "$4" = traffic ]; then
   mkdir -p $GRAFT_REPO_ROOT/gpurun_out/profiles
-  (cd $GRAFT_REPO_ROOT && python scripts/update_traffic.py $OUT $B $L $VPO && cp profiles/r03_traffic.json gpurun_out/profiles/) 2>&1 | tail -2
+  (cd $GRAFT_REPO_ROOT && TBC_TRAFFIC_FILE=r05_traffic.json python scripts/update_traffic.py $OUT $B $L $VPO && cp profiles/r05_traffic.json gpurun_out/profiles/) 2>&1 | tail -2
 fi
 f=$(ls $OUT/trace/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && head -14 "$f" > $OUT/kernel_stats_head.csv
 rm -rf $OUT/trace/*kernel_trace.csv $OUT/pmc*/*.csv 2>/dev/null

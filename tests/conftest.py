@@ -17,11 +17,16 @@ def _mask_form_unless_asked():
     """The tests written before the count form pin the MASK-form schedules (one mask bit per crashed call) against their oracles
     (wgl_beam.c, wgl_window.c, sweep_ref.c): for them core.make_opts() leaves the count form off.  tests/test_count_form*.py ask for
     it by name (count_form=True), which is also what the library does by default."""
-    from jepsen_tigerbeetle_amd import core
-    old = core.DEFAULT_COUNT_FORM
+    from jepsen_tigerbeetle_amd import _native as N, core
+    old = core.DEFAULT_COUNT_FORM, core.DEFAULT_LIST_ORDER
     core.DEFAULT_COUNT_FORM = False
+    # Likewise the order of the fronts' lists (tbc_opts.list_order): the tests written before round 5 compare counters and witnesses with
+    # oracle/wgl_beam.c in PROCESS-SLOT order, and the oracle cannot know where the library's own choice (completion order, a :write 24
+    # ranks later) applies -- so for them make_opts() asks for slot order.  The shipped default is pinned by name where it is the point:
+    # tests/test_list_order_gpu.py (every order, both kernels), test_narrow_kernel_at_the_bench_configuration, the smoke test, bench.py.
+    core.DEFAULT_LIST_ORDER = N.ORDER_SLOT
     yield
-    core.DEFAULT_COUNT_FORM = old
+    core.DEFAULT_COUNT_FORM, core.DEFAULT_LIST_ORDER = old
 
 
 @pytest.fixture(scope="session")

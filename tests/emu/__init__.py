@@ -54,7 +54,7 @@ def build_walk(force=False):
     return _SO_WALK
 
 
-def walk_check(hists, vpad, twin=True, look=True, branch=False, front="plain", lean=False, by_ret=False):
+def walk_check(hists, vpad, twin=True, look=True, branch=False, front="plain", by_ret=False):
     """Run the front walk with lane = front (csrc/open_walk_impl.h) under the emulator on these histories (at most 64 process
     slots each) and compare every word it writes with the host-built tables.  front: "plain" rows, "wide" or "compact" front
     records.  Returns None when all agree, else (what, history, front, index, got, want)."""
@@ -72,7 +72,7 @@ def walk_check(hists, vpad, twin=True, look=True, branch=False, front="plain", l
     pr, inv, ret = cat("process", np.int32), cat("inv_pos", np.uint32), cat("ret_pos", np.uint32)
     npr = np.array([int(d["n_process"]) for d in ds], np.uint32)
     assert int(npr.max()) <= 64
-    flags = (1 if twin else 0) | (2 if look else 0) | (4 if branch else 0) | {"plain": 0, "wide": 8, "compact": 24}[front] | (32 if lean else 0) | ((int(by_ret) << 16) if int(by_ret) >= 16 else 128 if by_ret == 2 else 64 if by_ret else 0)      # lean: csrc kLeanCands | kLeanLook; by_ret: list_order 1
+    flags = (1 if twin else 0) | (2 if look else 0) | (4 if branch else 0) | {"plain": 0, "wide": 8, "compact": 24}[front] | ((int(by_ret) << 16) if int(by_ret) >= 16 else 128 if by_ret == 2 else 64 if by_ret else 0)      # lean: csrc kLeanCands | kLeanLook; by_ret: list_order 1
     diag = np.zeros(8, np.uint64)
     rc = _LIB_WALK.emu_walk_check(C.c_uint32(nh), _p(op_off, C.c_uint64), _p(npr, C.c_uint32), _p(f, C.c_uint8), _p(a, C.c_int32), _p(b, C.c_int32),
                                   _p(pr, C.c_int32), _p(inv, C.c_uint32), _p(ret, C.c_uint32), C.c_uint32(vpad), C.c_uint32(flags), _p(diag, C.c_uint64))
@@ -134,7 +134,7 @@ def rules_for(hists, model_kind, init, nil=-(2 ** 31)):
     return 3, vpad
 
 
-def run(hists, model_kind, init, L, rules=None, lookahead=True, entries_per_op=8, max_steps=0, pool_words=0, want_witness=True, max_waves=0, branch_lists=True, compact=True, epochs=0, count=False, relaxed=False, targets=None, mw=None, lean=False, by_ret=False):
+def run(hists, model_kind, init, L, rules=None, lookahead=True, entries_per_op=8, max_steps=0, pool_words=0, want_witness=True, max_waves=0, branch_lists=True, compact=True, epochs=0, count=False, relaxed=False, targets=None, mw=None, by_ret=False):
     """hists: list of op-column dicts (f,a,b,process,inv_pos,ret_pos,n_process).  Returns one result dict per history."""
     ds = [h if isinstance(h, dict) else h.as_dict() for h in hists]
     nh = len(ds)
@@ -161,7 +161,7 @@ def run(hists, model_kind, init, L, rules=None, lookahead=True, entries_per_op=8
     rc = lib().emu_narrow_run(C.c_uint32(nh), _p(op_off, C.c_uint64), _p(npr, C.c_uint32), _p(f, C.c_uint8), _p(a, C.c_int32), _p(b, C.c_int32),
                               _p(pr, C.c_int32), _p(inv, C.c_uint32), _p(ret, C.c_uint32), C.c_uint32(model_kind), C.c_int32(init),
                               C.c_uint32(L), C.c_uint32(mw), C.c_uint32(r), C.c_uint32(vpad), C.c_uint32(1 if look else 0),
-                              C.c_uint32(entries_per_op), C.c_uint64(max_steps), C.c_uint64(pool_words), C.c_uint32(1 if want_witness else 0), C.c_uint32(max_waves), C.c_uint32((1 if compact else 0) | (2 if lean else 0) | ((int(by_ret) << 16) if int(by_ret) >= 16 else 16 if by_ret == 2 else 4 if by_ret else 0) | (8 if lean == 2 else 0)), C.c_uint32(epochs), C.c_uint32(1 if count else 0), C.c_uint32(1 if relaxed else 0),
+                              C.c_uint32(entries_per_op), C.c_uint64(max_steps), C.c_uint64(pool_words), C.c_uint32(1 if want_witness else 0), C.c_uint32(max_waves), C.c_uint32((1 if compact else 0) | ((int(by_ret) << 16) if int(by_ret) >= 16 else 16 if by_ret == 2 else 4 if by_ret else 0)), C.c_uint32(epochs), C.c_uint32(1 if count else 0), C.c_uint32(1 if relaxed else 0),
                               _p(np.ascontiguousarray(targets, np.uint32), C.c_uint32) if targets is not None else None,
                               res, _p(wit, C.c_uint32), _p(cfg, C.c_uint64))
     if rc != 0:
@@ -194,7 +194,7 @@ def build_sweep(force=False):
     return _SO_SWEEP
 
 
-def sweep_wg(ops, model_kind, init, seg_target, n_dom, max_segs, waves=8, cap=1024, rules=None, seed=1, rel_bytes=688, again=None, first=None, queue=False, fp=False, compact=False):
+def sweep_wg(ops, model_kind, init, seg_target, n_dom, max_segs, waves=8, cap=1024, rules=None, seed=1, rel_bytes=688, again=None, first=None, compact=False):
     """ONE history through K6w: max_segs * 4 tbc_sweep_rel records as a uint8 array (as oracle.wgl.sweep_relations returns them).
     again = [(segment, slice), ...] with first = the first pass's records: the second pass over those segments only."""
     global _LIB_SWEEP
@@ -211,7 +211,7 @@ def sweep_wg(ops, model_kind, init, seg_target, n_dom, max_segs, waves=8, cap=10
     sl = None if again is None else np.ascontiguousarray([x for (k, j) in again for x in (0, k, j)], np.uint32)
     rc = _LIB_SWEEP.emu_sweep_wg_run(C.c_uint32(len(f)), C.c_uint32(int(d["n_process"])), _p(f, C.c_uint8), _p(a, C.c_int32), _p(b, C.c_int32), _p(pr, C.c_int32),
                                      _p(inv, C.c_uint32), _p(ret, C.c_uint32), C.c_uint32(model_kind), C.c_int32(init), C.c_uint32(vpad), C.c_uint32(r),
-                                     C.c_uint32(n_dom), C.c_uint32(seg_target), C.c_uint32(max_segs), C.c_uint32(waves), C.c_uint32(cap), C.c_uint32((1 if queue else 0) | (2 if fp else 0) | (4 if compact else 0) | (8 if compact == 2 else 0)), C.c_uint64(seed),      # compact=2: + solo passes
+                                     C.c_uint32(n_dom), C.c_uint32(seg_target), C.c_uint32(max_segs), C.c_uint32(waves), C.c_uint32(cap), C.c_uint32((4 if compact else 0) | (8 if compact == 2 else 0)), C.c_uint64(seed),      # compact=2: + solo passes
                                      None if sl is None else _p(sl, C.c_uint32), C.c_uint32(0 if again is None else len(again)), buf.ctypes.data_as(C.c_void_p))
     if rc != 0:
         raise RuntimeError(f"emu_sweep_wg_run rc={rc}")
@@ -272,7 +272,7 @@ def pack_one_check(hists, model_kind=1, n_classes=0, count=False, per_launch=0, 
     return (what, int(diag[0]), int(diag[1]), int(diag[2]), int(diag[3]))
 
 
-def pack_wg_check(hists, model_kind=1, n_classes=0, vpad=8, count=False, branch=False, look=True, rk8=True, lst_cap=0, per_launch=0, seed=1, n_events=None, one=False, lean=False):
+def pack_wg_check(hists, model_kind=1, n_classes=0, vpad=8, count=False, branch=False, look=True, rk8=True, lst_cap=0, per_launch=0, seed=1, n_events=None, one=False):
     """The batch form (csrc/pack_one_impl.h, BatchGeo: four wavefronts per history, pack + open counts in one pass) under the workgroup
     emulator: every word pack_kernel AND open_counts_kernel would leave -- as pack_one_check, plus off[], ncr[], slot8, rk8, the
     crashed-call list, the lookahead records past the last rank, BeamHist.status / n_crashed / lst_need -- against the restatements in
@@ -302,7 +302,7 @@ def pack_wg_check(hists, model_kind=1, n_classes=0, vpad=8, count=False, branch=
             n_events.append(int(max(int(i.max()) if len(i) else 0, int(live.max()) if len(live) else 0)) + 1)
     ne = np.ascontiguousarray(n_events, np.uint32)
     diag = np.zeros(8, np.uint64)
-    flags = (1 if count else 0) | (2 if branch else 0) | (4 if look else 0) | (8 if rk8 else 0) | (16 if one else 0) | (32 if lean else 0)      # one: sixteen wavefronts (OneCountsGeo, TBC_PACK_ONE=2); lean: 8 B lookahead records (the pads)
+    flags = (1 if count else 0) | (2 if branch else 0) | (4 if look else 0) | (8 if rk8 else 0) | (16 if one else 0)      # one: sixteen wavefronts (OneCountsGeo, TBC_PACK_ONE=2); lean: 8 B lookahead records (the pads)
     rc = _LIB_PACK.emu_pack_wg_check(C.c_uint32(nh), _p(op_off, C.c_uint64), _p(npr, C.c_uint32), _p(ne, C.c_uint32), _p(f, C.c_uint8), _p(a, C.c_int32),
                                      _p(b, C.c_int32), _p(pr, C.c_int32), _p(inv, C.c_uint32), _p(ret, C.c_uint32), C.c_uint32(model_kind),
                                      C.c_uint32(n_classes), C.c_uint32(vpad), C.c_uint32(flags), C.c_uint32(lst_cap), C.c_uint32(per_launch), C.c_uint64(seed), _p(diag, C.c_uint64))

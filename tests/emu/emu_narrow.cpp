@@ -30,14 +30,6 @@ void wave_entry_cnt(void* p, uint32_t lane) {
   narrow::narrow_wave<MW, L, CF, true>(*c->A, c->wave, c->lds, lane);
 }
 template <int MW, int L>
-void wave_entry_lean(void* p, uint32_t lane) {
-  auto* c = (WaveCall<MW, L>*)p;
-  if constexpr (MW == 1) {
-    if (c->A->lean & kLeanLazy) narrow::narrow_wave<1, L, true, false, (int)(kLeanCands | kLeanLook | kLeanLazy)>(*c->A, c->wave, c->lds, lane);
-    else narrow::narrow_wave<1, L, true, false, (int)(kLeanCands | kLeanLook)>(*c->A, c->wave, c->lds, lane);
-  }
-}
-template <int MW, int L>
 void run_all(BeamArgs& A, uint32_t max_waves) {
   const uint32_t H = 64 / L;
   uint32_t waves = (A.n_work + H - 1) / H;
@@ -58,7 +50,6 @@ void run_all(BeamArgs& A, uint32_t max_waves) {
         continue;
       }
     }
-    if constexpr (MW == 1) { if (cf && A.lean) { wv::run_wave(&wave_entry_lean<MW, L>, &c); continue; } }
     if constexpr (MW == 1) { if (cf) { wv::run_wave(&wave_entry<MW, L, true>, &c); continue; } }
     wv::run_wave(&wave_entry<MW, L, false>, &c);
   }
@@ -92,11 +83,9 @@ int emu_narrow_run(uint32_t nh, const uint64_t* op_off, const uint32_t* n_proces
   uint32_t n_dom = 0;
   if (vpad) { int32_t vmax = init == TBC_NIL ? -1 : init; for (uint64_t i = 0; i < op_off[nh]; i++) { if (a[i] != TBC_NIL && a[i] > vmax) vmax = a[i]; if (f[i] == TBC_F_CAS && b[i] > vmax) vmax = b[i]; } n_dom = (uint32_t)(vmax + 2); }
   const bool compact = (want_compact & 1u) && (rules & kRuleEager) && front_compact_ok(n_dom, MW);
-  // want_compact bit 1: the lean formats of the list entries and the lookahead records (libtbcheck: TBC_NARROW_LEAN=1, tbc_api.hip lean())
-  const uint32_t lean = ((want_compact & 2u) && compact && MW == 1 && !count && lookahead && (rules & (kRuleEager | kRuleTwin)) == (kRuleEager | kRuleTwin)) ? (kLeanCands | kLeanLook) : 0u;
-  if ((want_compact & 2u) && !lean) return 4;
-  // want_compact bit 2: the fronts' lists in order of completion (libtbcheck: TBC_NARROW_ORDER=1; the kernel reads what it is given)
-  if (!build_tables(nh, op_off, n_process, f, a, b, process, inv_pos, ret_pos, MW, vpad, entries_per_op, (rules & kRuleBranch) != 0, compact, T, count != 0, lean, (want_compact >> 16) ? (want_compact >> 16) : (want_compact & 16u) ? 2u : (want_compact & 4u) ? 1u : 0u)) return 1;      // (16: in order of completion with the writes last, list_order 2)
+  if (want_compact & (2u | 8u)) return 4;          // (bits 1 and 3 were the lean tables and the lazy lookahead: measured slower on the device in round 5, deleted)
+  // want_compact bit 2: the fronts' lists in order of completion (tbc_opts.list_order; the kernel reads what it is given)
+  if (!build_tables(nh, op_off, n_process, f, a, b, process, inv_pos, ret_pos, MW, vpad, entries_per_op, (rules & kRuleBranch) != 0, compact, T, count != 0, (want_compact >> 16) ? (want_compact >> 16) : (want_compact & 16u) ? 2u : (want_compact & 4u) ? 1u : 0u)) return 1;      // (16: in order of completion with the writes last, list_order 2)
   if (count) { rules |= kRuleCount; for (uint32_t h = 0; h < nh && targets; h++) T.bh[h].target = targets[h]; }
   const uint64_t total = op_off[nh];
   uint64_t entries = 0;
@@ -119,8 +108,6 @@ int emu_narrow_run(uint32_t nh, const uint64_t* op_off, const uint32_t* n_proces
   A.pool = pool_words ? pool.data() : nullptr; A.pool_cursor = &cursor; A.pool_words = pool_words; A.max_tab_log2 = 28;
   A.pool_vals = nullptr; A.cfg = cfg.data(); A.rules = rules; A.twn = (rules & kRuleTwin) ? T.twn.data() : nullptr;
   A.rdm = T.rdm.data(); A.vpad = vpad; A.rk8 = T.rk8.data(); A.front_words = compact ? kFrontCompactWords : front_stride(vpad, MW);
-  A.lean = lean | ((lean && (want_compact & 8u)) ? kLeanLazy : 0u);          // want_compact bit 3: the lazy lookahead (TBC_NARROW_LEAN=2)
-  if (lean) A.twn = nullptr;                    // (the twin masks ride in the list entries: the array does not exist)
 #define RUN(MWV, LV) if (MW == MWV && L == LV) { run_all<MWV, LV>(A, max_waves); ran = true; }
   bool ran = false;
   // epochs > 0: that many passes over the SAME visited-set arena, never cleared in between, each under its own epoch tag

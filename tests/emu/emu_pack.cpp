@@ -192,7 +192,7 @@ static int pack_counts_check(uint32_t nh, const uint64_t* op_off, const uint32_t
                       const int32_t* b, const int32_t* process, const uint32_t* inv_pos, const uint32_t* ret_pos, uint32_t model_kind,
                       uint32_t n_classes, uint32_t vpad, uint32_t flags, uint32_t lst_cap, uint32_t per_launch, uint64_t seed, uint64_t* diag) {
   const bool count = flags & 1u, branch = flags & 2u, want_look = flags & 4u, want_rk8 = (flags & 8u) || branch;
-  const bool lean_look8 = (flags & 32u) != 0u;                 // the lean lookahead records (csrc kLeanLook): one word a rank, the pads too
+  if (flags & 32u) return 9;          // (was: the lean lookahead records -- deleted in round 5)
   const uint64_t total = op_off[nh];
   std::vector<int32_t> slot(process, process + total);
   std::vector<Hist> hist(nh);
@@ -241,7 +241,7 @@ static int pack_counts_check(uint32_t nh, const uint64_t* op_off, const uint32_t
   PackOpenArgs O{};
   O.hist = hist.data(); O.bh = bh.data(); O.f = f; O.a = a; O.b = b; O.process = slot.data(); O.scratch = scratch.data(); O.rec = rec.data(); O.seg = seg.data();
   O.branch_lists = branch ? 1u : 0u; O.off = off.data(); O.ncr = ncr.data(); O.crashed = crashed.data(); O.ret_slot = ret_slot.data(); O.ret_op = ret_op.data();
-  O.look = want_look ? look.data() : nullptr; O.slot8 = slot8.data(); O.rk8 = want_rk8 ? rk8.data() : nullptr; O.n_hist = nh; O.mask_words = 1; O.vpad = vpad; O.lean = lean_look8 ? kLeanLook : 0u;
+  O.look = want_look ? look.data() : nullptr; O.slot8 = slot8.data(); O.rk8 = want_rk8 ? rk8.data() : nullptr; O.n_hist = nh; O.mask_words = 1; O.vpad = vpad;
   std::vector<uint32_t> lds(G::lds_words());
   if (per_launch == 0) per_launch = nh;
   for (uint32_t h0 = 0; h0 < nh; h0 += per_launch) {
@@ -318,11 +318,7 @@ static int pack_counts_check(uint32_t nh, const uint64_t* op_off, const uint32_t
       const uint32_t* e = reinterpret_cast<const uint32_t*>(&T.crashed[k]);
       for (uint32_t q = 0; q < 4; q++) if (g[q] != e[q]) MISMATCH(14, k * 4 + q, g[q], e[q]);
     }
-    if (want_look && lean_look8) {
-      const uint64_t* lk = look.data() + look_off(o, h, 0);
-      const uint64_t w0 = lean_look(0u, kLookNone, kLookNone, 255u, 255u, 0ull);
-      for (uint32_t t = R; t < R + kLookPad; t++) if (lk[t] != w0) MISMATCH(18, t, lk[t], w0);
-    } else if (want_look) {
+    if (want_look) {
       const uint64_t* lk = look.data() + look_off(o, h, 1);
       for (uint32_t t = R; t < R + kLookPad; t++) {
         const uint64_t w0 = (uint64_t)(kLookNone << 16 | kLookNone << 24) | (255ull << 32) | (255ull << 40);

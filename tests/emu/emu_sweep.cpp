@@ -14,18 +14,18 @@ using namespace tbc;
 namespace {
 
 struct Call { const SweepArgs* A; uint32_t* lds; };
-template <uint32_t CAP, uint32_t NW, bool QUEUE, bool FP, bool COMPACT, bool SOLO>
+template <uint32_t CAP, uint32_t NW, bool COMPACT, bool SOLO>
 void entry(void* p, uint32_t) {
   auto* c = (Call*)p;
-  sweepwg::segment<CAP, NW, QUEUE, FP, COMPACT, SOLO>(*c->A, c->lds);
+  sweepwg::segment<CAP, NW, COMPACT, SOLO>(*c->A, c->lds);
 }
-template <uint32_t CAP, uint32_t NW, bool QUEUE = false, bool FP = false, bool COMPACT = false, bool SOLO = false>
+template <uint32_t CAP, uint32_t NW, bool COMPACT = false, bool SOLO = false>
 void run_all(const SweepArgs& A, uint32_t n_wg, uint64_t seed) {
-  std::vector<uint32_t> lds(sweepwg::lds_words<CAP, NW, QUEUE, COMPACT>() + 16);
+  std::vector<uint32_t> lds(sweepwg::lds_words<CAP, NW, COMPACT>() + 16);
   for (uint32_t w = 0; w < n_wg; w++) {
     std::fill(lds.begin(), lds.end(), 0xDEADBEEFu);          // LDS is not zeroed on the device either
     Call c{&A, lds.data()};
-    wv::run_workgroup(&entry<CAP, NW, QUEUE, FP, COMPACT, SOLO>, &c, (int)NW, w, seed + w);
+    wv::run_workgroup(&entry<CAP, NW, COMPACT, SOLO>, &c, (int)NW, w, seed + w);
   }
 }
 
@@ -78,19 +78,10 @@ int emu_sweep_wg_run(uint32_t n, uint32_t n_process, const uint8_t* f, const int
 #define RUN(C_, W_) if (CAP == C_ && NW == W_ && !queue) { run_all<C_, W_>(A, n_wg, seed); return 0; }
   RUN(1024, 2) RUN(1024, 4) RUN(1024, 8) RUN(512, 4) RUN(2048, 8) RUN(2048, 16)
 #undef RUN
-#define RUNQ(C_, W_) if (CAP == C_ && NW == W_ && queue == 1) { run_all<C_, W_, true>(A, n_wg, seed); return 0; }
-  RUNQ(1024, 2) RUNQ(1024, 4) RUNQ(1024, 8) RUNQ(512, 4) RUNQ(2048, 8)
-#undef RUNQ
-  // variant bit 1: the fingerprint form (FP), with or without the ring
-#define RUNF(C_, W_) if (CAP == C_ && NW == W_ && queue == 2) { run_all<C_, W_, false, true>(A, n_wg, seed); return 0; } \
-                     if (CAP == C_ && NW == W_ && queue == 3) { run_all<C_, W_, true, true>(A, n_wg, seed); return 0; }
-  RUNF(1024, 2) RUNF(1024, 8) RUNF(512, 4)
-#undef RUNF
-  // variant bit 2: the compact walk (COMPACT), with or without the fingerprint; bit 3: + narrow passes by wavefront 0 alone (SOLO)
-#define RUNC(C_, W_) if (CAP == C_ && NW == W_ && queue == 4) { run_all<C_, W_, false, false, true>(A, n_wg, seed); return 0; } \
-                     if (CAP == C_ && NW == W_ && queue == 6) { run_all<C_, W_, false, true, true>(A, n_wg, seed); return 0; } \
-                     if (CAP == C_ && NW == W_ && queue == 12) { run_all<C_, W_, false, false, true, true>(A, n_wg, seed); return 0; } \
-                     if (CAP == C_ && NW == W_ && queue == 14) { run_all<C_, W_, false, true, true, true>(A, n_wg, seed); return 0; }
+  // variant bit 2: the compact walk (COMPACT); bit 3: + narrow passes by wavefront 0 alone (SOLO) -- the library's first pass since round 5
+  // (bits 0 and 1 were the ring and the fingerprint forms: measured slower on the device, deleted)
+#define RUNC(C_, W_) if (CAP == C_ && NW == W_ && queue == 4) { run_all<C_, W_, true>(A, n_wg, seed); return 0; } \
+                     if (CAP == C_ && NW == W_ && queue == 12) { run_all<C_, W_, true, true>(A, n_wg, seed); return 0; }
   RUNC(1024, 2) RUNC(1024, 4) RUNC(1024, 8) RUNC(512, 2) RUNC(512, 4) RUNC(2048, 8) RUNC(2048, 16)
 #undef RUNC
   return 2;

@@ -32,11 +32,10 @@ extern "C" {
 int emu_walk_check(uint32_t nh, const uint64_t* op_off, const uint32_t* n_process, const uint8_t* f, const int32_t* a, const int32_t* b,
                    const int32_t* process, const uint32_t* inv_pos, const uint32_t* ret_pos, uint32_t vpad, uint32_t flags, uint64_t* diag) {
   const bool want_twn = flags & 1u, want_look = flags & 2u, branch = flags & 4u, records = flags & 8u, compact = (flags & 16u) && records;
-  const uint32_t lean = (flags & 32u) ? (kLeanCands | kLeanLook) : 0u;          // the lean formats (with twin masks and compact records only)
-  if (lean && !(want_twn && compact)) return 9;
+  if (flags & 32u) return 9;          // (was: the lean formats -- deleted in round 5)
   const uint32_t by_ret = (flags >> 16) ? (flags >> 16) : (flags & 128u) ? 2u : (flags & 64u) ? 1u : 0u;      // (bits 16 up: list_order 16 + W)          // a front's list in order of completion (PackOpenArgs.list_order = 1; 2: the writes last)
   Tables T;
-  if (!build_tables(nh, op_off, n_process, f, a, b, process, inv_pos, ret_pos, 1, vpad, 1, branch, compact, T, false, lean, by_ret)) return 9;
+  if (!build_tables(nh, op_off, n_process, f, a, b, process, inv_pos, ret_pos, 1, vpad, 1, branch, compact, T, false, by_ret)) return 9;
   const uint64_t total = op_off[nh];
   const uint32_t FS = compact ? kFrontCompactWords : front_stride(vpad, 1);      // the reference's rows (always front records)
   const uint32_t FW = records ? FS : vpad;                                       // the walk's
@@ -76,7 +75,7 @@ int emu_walk_check(uint32_t nh, const uint64_t* op_off, const uint32_t* n_proces
   A.off = T.off.data(); A.ncr = T.ncr.data(); A.lst = lst.data(); A.crashed = nullptr; A.ret_slot = T.ret_slot.data(); A.ret_op = T.ret_op.data();
   A.look = want_look ? look.data() : nullptr; A.tmp = want_look ? tmp.data() : nullptr; A.slot8 = nullptr;
   A.front_words = records ? FS : 0u; A.front_compact = compact ? 1u : 0u; A.rk8 = nullptr; A.n_hist = nh; A.mask_words = 1;
-  A.twn = (want_twn && !lean) ? twn.data() : nullptr; A.rdm = vpad ? rdm.data() : nullptr; A.vpad = vpad; A.h0 = 0; A.lean = lean; A.list_order = by_ret;
+  A.twn = want_twn ? twn.data() : nullptr; A.rdm = vpad ? rdm.data() : nullptr; A.vpad = vpad; A.h0 = 0; A.list_order = by_ret;
   std::vector<uint32_t> lds(walk::walk_lds_words() + 16);
   for (uint32_t w = 0; w < nh * A.chunks_per_hist; w++) {
     std::fill(lds.begin(), lds.end(), 0xDEADBEEFu);
@@ -95,16 +94,13 @@ int emu_walk_check(uint32_t nh, const uint64_t* op_off, const uint32_t* n_proces
         if (g.op != w.op) return fail(1, h, F, i - off[F], g.op, w.op);
         if (g.f_slot != w.f_slot) return fail(1, h, F, i - off[F], g.f_slot, w.f_slot);
         if (g.a != w.a || g.b != w.b) return fail(1, h, F, i - off[F], (uint32_t)g.a, (uint32_t)w.a);
-        if (want_twn && !lean && twn[l0 + i] != T.twn[l0 + i]) return fail(2, h, F, i - off[F], twn[l0 + i], T.twn[l0 + i]);
+        if (want_twn && twn[l0 + i] != T.twn[l0 + i]) return fail(2, h, F, i - off[F], twn[l0 + i], T.twn[l0 + i]);
       }
       for (uint32_t v = 0; v < vpad; v++) {
         const uint64_t want = T.rdm[(o + F) * FS + v];      // (a compact record whole: words 6, 7 are the list location and the window of the next ranks)
         if (rdm[(o + F) * FW + v] != want) return fail(3, h, F, v, rdm[(o + F) * FW + v], want);
       }
-      if (want_look && lean) {
-        const uint64_t lo = look_off(o, h, 0);
-        if (look[lo + F] != T.look[lo + F]) return fail(4, h, F, 0, look[lo + F], T.look[lo + F]);
-      } else if (want_look) {
+      if (want_look) {
         const uint64_t lo = look_off(o, h, 1);
         const uint64_t w0 = T.look[lo + (uint64_t)F * 2];                                  // (with the producer distance)
         if (look[lo + (uint64_t)F * 2] != w0) return fail(4, h, F, 0, look[lo + (uint64_t)F * 2], w0);

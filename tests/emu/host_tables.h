@@ -22,11 +22,9 @@ struct Tables {
 // the per-front tables of every history of the batch, from the definitions
 bool build_tables(uint32_t nh, const uint64_t* op_off, const uint32_t* n_process, const uint8_t* f, const int32_t* a, const int32_t* b,
                   const int32_t* process, const uint32_t* inv_pos, const uint32_t* ret_pos, uint32_t MW, uint32_t vpad_in,
-                  uint32_t tab_log2_per_op, bool branch, bool compact, Tables& T, bool count = false, uint32_t lean = 0, uint32_t list_by_ret = 0) {
+                  uint32_t tab_log2_per_op, bool branch, bool compact, Tables& T, bool count = false, uint32_t list_by_ret = 0) {
   // list_by_ret: a front's list in order of completion instead of process-slot order (csrc PackOpenArgs.list_order = 1); 2 = in order
   // of completion with the :write calls after everything else (list_order = 2)
-  // lean = kLeanCands | kLeanLook (csrc/tbc_internal.h): the same tables with the list entries as {call, twin mask} and the lookahead
-  // records as 8 B words -- converted at the end from the plain ones, field by field (one mask word only)
   // count = the COUNT FORM, from its definition (oracle/wgl_count.c states it a third time): live calls on re-used slots (the
   // lowest free one when the process first invokes; a process that crashes hands its slot back), crashed calls with an effect
   // grouped into classes by effect in order of first invocation, a count field of bit_length(n) bits each (never across a word)
@@ -213,24 +211,6 @@ bool build_tables(uint32_t nh, const uint64_t* op_off, const uint32_t* n_process
     off_n += n + 2; lst_n += run;
   }
   T.lst.resize(lst_n + 1); T.twn.resize((lst_n + 1) * MW);
-  if (lean && MW != 1) return false;
-  if (lean & kLeanCands)
-    for (uint64_t i = 0; i < lst_n; i++) {
-      const OpRec o = T.lst[i];
-      const uint64_t call = lean_call(o.op, o.f_slot & 0xFFu, (o.f_slot & kAtFront) != 0u, (o.f_slot >> 8) & kSlotMask, o.a, o.b), tw = T.twn[i];
-      T.lst[i] = OpRec{(uint32_t)call, (uint32_t)(call >> 32), (int32_t)(uint32_t)tw, (int32_t)(uint32_t)(tw >> 32)};
-    }
-  if (lean & kLeanLook) {
-    std::vector<uint64_t> lk(look_words(total, nh, 0), 0);
-    for (uint32_t h = 0; h < nh; h++) {
-      const uint64_t o = op_off[h], lo2 = look_off(o, h, 1), lo1 = look_off(o, h, 0);
-      for (uint32_t t = 0; t < T.hist[h].n_ret + kLookPad; t++) {
-        const uint64_t w0 = T.look[lo2 + 2ull * t], pm = T.look[lo2 + 2ull * t + 1];
-        lk[lo1 + t] = lean_look((uint32_t)w0 & 0xFFFFu, (uint32_t)(w0 >> 16) & 0xFFu, (uint32_t)(w0 >> 24) & 0xFFu, (uint32_t)(w0 >> 32) & 0xFFu, (uint32_t)(w0 >> 40) & 0xFFu, pm);
-      }
-    }
-    T.look.swap(lk);
-  }
   return true;
 }
 

@@ -268,4 +268,4 @@ def test_bench_extra_legs_run_in_their_own_process(monkeypatch):
     monkeypatch.setattr(subprocess, "run", fake_run(1, b""))
     with pytest.raises(SystemExit):
         bench.run_leg("tiers", args, 0)
-    assert set(bench.LEGS) >= {"tiers", "set_full", "workload_2", "workload_3", "workload_crashed", "single_history_forms"}
+    assert set(bench.LEGS) >= {"tiers", "set_full", "workload_2", "workload_3", "workload_crashed"}

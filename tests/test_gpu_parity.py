@@ -540,36 +540,6 @@ def test_narrow_kernel_wide_masks_and_other_models(native, oracle):
         core.Batch(reg, core.make_model(N.MODEL_REGISTER, N.NIL), core.make_opts(algorithm=N.ALG_COMPETITION, lanes_per_history=8, search_width=4))
 
 
-def test_front_walk_by_front_and_by_slot_build_the_same_tables(native, monkeypatch):
-    """pack_open.hip builds the per-front tables of a batch with at most 64 process slots with lane = front (open_walk_impl.h;
-    tests/test_walk_emu.py checks its every word on the CPU); TBC_OPEN_WALK=slots keeps the walk with lane = process slot.  Every
-    search that reads the tables -- several histories per wavefront, one per wavefront at width 2 and 4, the level sweep, with
-    and without a witness -- must not be able to tell: same verdicts, counters, witnesses, failing ops."""
-    hists = [columns.pair_events(synth.register_events(n_ops=n, n_procs=p, seed=s, busy=busy, info=info, corrupt=corrupt))
-             for (n, p, busy, info, corrupt) in [(400, 16, 0.3, 0.0, 0.0), (900, 64, 0.1, 0.0, 0.0), (300, 40, 0.25, 0.0, 0.3), (500, 24, 0.4, 0.02, 0.0),
-                                                 (700, 8, 1.0, 0.0, 0.5), (65, 64, 0.15, 0.0, 0.0)] for s in (11, 12, 13)]      # (at most ~10 calls in flight: every search ends by itself)
-    hists = [h for h in hists if h.n_process <= 64]
-    assert len(hists) >= 15
-    configs = [dict(algorithm=N.ALG_COMPETITION, lanes_per_history=8, want_witness=True), dict(algorithm=N.ALG_COMPETITION, lanes_per_history=16, want_witness=False),
-               dict(algorithm=N.ALG_COMPETITION, lanes_per_history=64, search_width=2), dict(algorithm=N.ALG_COMPETITION, lanes_per_history=64, search_width=4, eager_reads=False),
-               dict(algorithm=N.ALG_COMPETITION, lanes_per_history=64, search_width=2, lookahead=False), dict(algorithm=N.ALG_LINEAR, want_witness=False)]
-    def run_all():
-        out = []
-        for kw in configs:
-            with core.Batch(hists, gm(), core.make_opts(time_limit_ms=60000, max_steps=3_000_000, **kw)) as b:
-                res = b.run().results()
-            out.append([(r["valid"], r["probes"], r["visited"], r["backtracks"], r["max_depth"], r["fail_op"], r["final_state"],
-                         None if r["witness"] is None else r["witness"].tolist()) for r in res])
-        return out
-    by_front = run_all()
-    monkeypatch.setenv("TBC_OPEN_WALK", "slots")
-    by_slot = run_all()
-    monkeypatch.delenv("TBC_OPEN_WALK")
-    for kw, x, y in zip(configs, by_front, by_slot):
-        assert x == y, kw
-    assert any(v[0] == 0 for v in by_front[0]) and any(v[0] == 1 for v in by_front[0])
-
-
 def test_batches_in_flight_from_several_threads(native, oracle):
     """tbcheck.h, "several batches in flight": three resident batches, each run four times from its own host thread at the same
     time (their searches take the device in turn, everything else floats) -- every pass of every batch gives what the batch
@@ -640,14 +610,14 @@ def test_narrow_kernel_at_the_bench_configuration(native, oracle):
     planted = [11, 4097, B - 5]
     for i in planted:
         hists[i] = columns.pair_events(synth.register_events(n_ops=10000, n_procs=64, seed=7_000_000 + i, busy=0.1, corrupt=0.5))
-    opts = core.make_opts(time_limit_ms=600000, want_witness=False, algorithm=N.ALG_COMPETITION, visited_per_op=4)      # bench.py's options
+    opts = core.make_opts(time_limit_ms=600000, want_witness=False, algorithm=N.ALG_COMPETITION, visited_per_op=4, list_order=N.ORDER_DEFAULT)      # bench.py's options
     with core.Batch(hists, gm(), opts) as b:
-        assert (b.lanes_per_history(), b.search_width()) == (8, 1)
+        assert (b.lanes_per_history(), b.search_width(), b.list_order()) == (8, 1, 16 + 24)      # the shipped default: in order of completion, a :write 24 ranks later
         b.run()
         verdicts = b.verdicts()
         res = b.results()
     sample = sorted(set(list(range(0, B, B // 61))[:61] + planted + [B - 1, B - 2, 1]))
     for i in sample:
-        _assert_narrow(res[i], _narrow_expect(oracle, hists[i], 8, want_witness=False), i)
+        _assert_narrow(res[i], _narrow_expect(oracle, hists[i], 8, want_witness=False, list_order=16 + 24), i)
     assert [int(verdicts[i]) for i in planted] == [0, 0, 0]
     assert int((verdicts == 1).sum()) == B - len(planted)                      # element-wise: only the planted ones are invalid

@@ -67,7 +67,7 @@ def compare(hists, model, L, kind=1, tag="", **kw):
     for i, (d, g) in enumerate(zip(ds, got)):
         e = wgl.check_beam(d, model, 1, round_pairs=L, rules_at_any_round_size=True, lookahead=kw.get("lookahead", True),
                            eager_reads=bool(g["rules"] & 1), twin_rule=bool(g["rules"] & 2), max_probes=kw.get("max_steps", 0),
-                           branch_lists=bool(g["rules"] & 4), look_two=bool(kw.get("lean", False)), list_order=wgl.ORACLE_LIST_ORDER[int(kw.get("by_ret", 0))], lazy_look=kw.get("lean") == 2)
+                           branch_lists=bool(g["rules"] & 4), list_order=wgl.ORACLE_LIST_ORDER[int(kw.get("by_ret", 0))])
         t = (tag, i, L)
         assert g["valid"] == e["valid"], (t, g["valid"], e["valid"], g["cause"])
         for a_, b_ in (("probes", "probes"), ("visited", "visited"), ("backtracks", "expanded"), ("max_depth", "max_stack"), ("bucket_reads", "rounds")):
@@ -300,114 +300,46 @@ def test_count_form_relaxed_prefix_growth_and_epochs():
     compare_count(wide, 8, tag="two-words", pool_words=4_000_000, mw=2, max_steps=30000)
 
 
-# ---- the lean tables (csrc/tbc_internal.h kLeanCands | kLeanLook; TBC_NARROW_LEAN=1): list entries {call, twin mask}, 8 B lookahead records
+# ---- the fronts' lists in order of completion (tbc_opts.list_order; csrc PackOpenArgs.list_order): the kernel reads what it is given, the
+# schedule is the oracle's with that list order -- the call that completes soonest is tried first.  16 + 24 is the library's default
+# wherever the order applies (round 5); 1 / 2 are the plain forms of the same walk.
 def _in_domain(n, p, s, busy, info, corrupt):
-    """a history whose planted bad read (if any) stays inside the value domain 0..4: the compact front records the lean tables need"""
+    """a history whose planted bad read (if any) stays inside the value domain 0..4 (compact front records)"""
     h = columns.pair_events(synth.register_events(n_ops=n, n_procs=p, seed=s, busy=busy, info=info, corrupt=corrupt, n_values=4 if corrupt else 5))
     h.a[h.a == 4 + 7] = 4
     return h
 
 
-LEAN_SHAPES = [(8, 3, 0.0, 0.0, 0.8), (40, 4, 0.0, 0.5, 0.5), (200, 8, 0.0, 0.0, 0.5), (200, 8, 0.0, 0.6, 0.3), (1000, 16, 0.0, 0.0, 0.5),
-               (1000, 16, 0.01, 0.0, 0.3), (1000, 16, 0.0, 0.6, 0.2), (2000, 64, 0.0, 0.0, 0.1), (600, 24, 0.03, 0.0, 0.6)]
+ORDER_SHAPES = [(8, 3, 0.0, 0.0, 0.8), (40, 4, 0.0, 0.5, 0.5), (200, 8, 0.0, 0.0, 0.5), (200, 8, 0.0, 0.6, 0.3), (1000, 16, 0.0, 0.0, 0.5),
+                (1000, 16, 0.01, 0.0, 0.3), (1000, 16, 0.0, 0.6, 0.2), (2000, 64, 0.0, 0.0, 0.1), (600, 24, 0.03, 0.0, 0.6)]
 
 
-@pytest.mark.parametrize("L", [8, 16, 32])
-def test_lean_tables_every_counter(L):
-    """the narrow kernel over the lean tables against the oracle's schedule with the lean lookahead's reading of three or more open
-    producers (look_two): verdict, failing op, witness, every counter -- valid, invalid, crashed calls in the mask form"""
-    hists = [_in_domain(n, p, s, busy, info, corrupt) for (n, p, info, corrupt, busy) in LEAN_SHAPES for s in range(3)]
-    hists = [h for h in hists if h.n_process <= 64]
-    assert sum(1 for h in hists if (h.a == 4).any()) >= 6
-    assert len(hists) >= 24
-    compare(hists, CAS, L, tag="lean", pool_words=4_000_000, lean=True)
-
-
-def test_lean_tables_where_the_many_bit_matters_and_growth_epochs_queue():
-    """two values and every process busy: completions with three or more open producers, where the lean record says less than the mask
-    (the oracle's look_two and the plain oracle disagree on these histories' counters -- the kernel follows look_two); then growth
-    inside the kernel, epoch tags and the work queue over the lean tables"""
-    h = [columns.pair_events(synth.register_events(n_ops=300, n_procs=24, seed=s, busy=1.0, n_values=2)) for s in range(6)]
-    compare(h, CAS, 8, tag="many", pool_words=8_000_000, lean=True)
-    differs = 0
-    for x in h:
-        d = x.as_dict()
-        a = wgl.check_beam(d, CAS, 1, round_pairs=8, rules_at_any_round_size=True, branch_lists=True, look_two=True, want_witness=False)
-        b = wgl.check_beam(d, CAS, 1, round_pairs=8, rules_at_any_round_size=True, branch_lists=True, look_two=False, want_witness=False)
-        assert (a["valid"], a["fail_op"] if a["valid"] == 0 else None) == (b["valid"], b["fail_op"] if b["valid"] == 0 else None)
-        differs += a["probes"] != b["probes"]
-    assert differs >= 1
-    hists = [_in_domain(1500, 16, s, 0.4, 0.0, 0.5 * (s % 2)) for s in range(12)]
-    compare(hists, CAS, 8, tag="lean growth", entries_per_op=1, pool_words=6_000_000, lean=True, want_witness=False)
-    compare(hists, CAS, 8, tag="lean epochs", epochs=3, pool_words=6_000_000, lean=True)
-    compare(hists, CAS, 8, tag="lean queue", max_waves=1, pool_words=6_000_000, lean=True)
-
-
-def test_lean_tables_at_the_bench_configuration():
-    hists = synth.register_ops_many(range(7000, 7008), n_ops=10000, n_procs=64, busy=0.1, info=0.0)
-    compare(hists, CAS, 8, tag="lean bench", entries_per_op=4, pool_words=1 << 24, want_witness=False, lean=True)
-
-
-# ---- the fronts' lists in order of completion (csrc PackOpenArgs.list_order = 1; TBC_NARROW_ORDER=1): the kernel reads what it is given,
-# the schedule is the oracle's with list_order = 1 -- the call that completes soonest is tried first
-@pytest.mark.parametrize("lean", [False, True])
-def test_lists_in_order_of_completion_every_counter(lean):
-    hists = [_in_domain(n, p, s, busy, info, corrupt) for (n, p, info, corrupt, busy) in LEAN_SHAPES for s in range(2)]
+@pytest.mark.parametrize("by_ret", [1, 2, 16 + 24, 16 + 5])
+def test_lists_in_order_of_completion_every_counter(by_ret):
+    hists = [_in_domain(n, p, s, busy, info, corrupt) for (n, p, info, corrupt, busy) in ORDER_SHAPES for s in range(2)]
     hists = [h for h in hists if h.n_process <= 64]
     # (the chain's absorbed reads come out in list order: the third formulation above, expand_chain, replays them in that order too)
-    compare(hists, CAS, 8, tag="by ret", pool_words=4_000_000, by_ret=True, lean=lean)
-    compare(hists[:10], CAS, 16, tag="by ret 16", pool_words=4_000_000, by_ret=True, lean=lean, want_witness=False)
-    compare(hists, CAS, 4, tag="by ret 4", pool_words=4_000_000, by_ret=True, lean=lean, want_witness=False)      # (16 histories a wavefront)
-
-
-def test_lists_in_order_of_completion_need_fewer_rounds():
-    """what the order buys on the bench workload (oracle counts): about a sixth fewer rounds for the same probes"""
-    hists = synth.register_ops_many(range(7000, 7006), n_ops=10000, n_procs=64, busy=0.1, info=0.0)
-    got = compare(hists, CAS, 8, tag="by ret bench", entries_per_op=4, pool_words=1 << 24, want_witness=False, by_ret=True, lean=True)
-    plain = [wgl.check_beam(h.as_dict(), CAS, 1, round_pairs=8, rules_at_any_round_size=True, branch_lists=True, want_witness=False) for h in hists]
-    assert sum(g["bucket_reads"] for g in got) < 0.9 * sum(p["rounds"] for p in plain)
-
-
-# ---- ... with the :write calls after everything else (PackOpenArgs.list_order = 2; TBC_NARROW_ORDER=2; the oracle's list order 4): a :cas the
-# state allows now is tried before a :write, which it always allows
-@pytest.mark.parametrize("lean,by_ret", [(False, 2), (2, 2), (False, 16 + 24), (2, 16 + 24), (True, 16 + 5)])
-def test_lists_in_order_of_completion_writes_last_every_counter(lean, by_ret):
-    hists = [_in_domain(n, p, s, busy, info, corrupt) for (n, p, info, corrupt, busy) in LEAN_SHAPES for s in range(2)]
-    hists = [h for h in hists if h.n_process <= 64]
-    compare(hists, CAS, 8, tag="writes last", pool_words=4_000_000, by_ret=by_ret, lean=lean)         # (witnesses: absorbed reads in order of completion, as under 1)
-    compare(hists[:10], CAS, 16, tag="writes last 16", pool_words=4_000_000, by_ret=by_ret, lean=lean, want_witness=False)
-    compare(hists, CAS, 4, tag="writes last 4", pool_words=4_000_000, by_ret=by_ret, lean=lean, want_witness=False)
+    compare(hists, CAS, 8, tag="by ret", pool_words=4_000_000, by_ret=by_ret)
+    compare(hists[:10], CAS, 16, tag="by ret 16", pool_words=4_000_000, by_ret=by_ret, want_witness=False)
+    compare(hists, CAS, 4, tag="by ret 4", pool_words=4_000_000, by_ret=by_ret, want_witness=False)      # (16 histories a wavefront)
     h = [columns.pair_events(synth.register_events(n_ops=300, n_procs=24, seed=s, busy=1.0, n_values=2)) for s in range(4)]      # many backtracks
-    compare(h, CAS, 8, tag="writes last busy", pool_words=8_000_000, by_ret=by_ret, lean=lean, want_witness=False)
+    compare(h, CAS, 8, tag="by ret busy", pool_words=8_000_000, by_ret=by_ret, want_witness=False)
 
 
-def test_writes_last_needs_fewer_rounds_than_plain_completion_order():
-    """what it buys (oracle counts, the kernel following them): a few per cent on the bench workload, about a quarter at 19 calls in flight"""
+def test_default_list_order_growth_epochs_queue():
+    hists = [_in_domain(1500, 16, s, 0.4, 0.0, 0.5 * (s % 2)) for s in range(12)]
+    compare(hists, CAS, 8, tag="order growth", entries_per_op=1, pool_words=6_000_000, by_ret=16 + 24, want_witness=False)
+    compare(hists, CAS, 8, tag="order epochs", epochs=3, pool_words=6_000_000, by_ret=16 + 24)
+    compare(hists, CAS, 8, tag="order queue", max_waves=1, pool_words=6_000_000, by_ret=16 + 24, want_witness=False)
+
+
+def test_the_default_list_order_needs_fewer_rounds_at_the_bench_configuration():
+    """what the order buys (oracle counts, the kernel following them): on the bench workload about a fifth fewer rounds than slot order,
+    and the write delay a few per cent over plain completion order; at 19 calls in flight much more"""
     hists = synth.register_ops_many(range(7000, 7004), n_ops=10000, n_procs=64, busy=0.1, info=0.0) + \
             synth.register_ops_many(range(7200, 7202), n_ops=10000, n_procs=64, busy=0.3, info=0.0)
-    got = compare(hists, CAS, 8, tag="writes last bench", entries_per_op=4, pool_words=1 << 25, want_witness=False, by_ret=2, lean=2)
-    soft = compare(hists, CAS, 8, tag="writes 24 ranks later bench", entries_per_op=4, pool_words=1 << 25, want_witness=False, by_ret=16 + 24, lean=2)
+    soft = compare(hists, CAS, 8, tag="a write 24 ranks later, bench", entries_per_op=4, pool_words=1 << 25, want_witness=False, by_ret=16 + 24)
+    slot = [wgl.check_beam(h.as_dict(), CAS, 1, round_pairs=8, rules_at_any_round_size=True, branch_lists=True, want_witness=False) for h in hists]
     plain = [wgl.check_beam(h.as_dict(), CAS, 1, round_pairs=8, rules_at_any_round_size=True, branch_lists=True, want_witness=False, list_order=1) for h in hists]
-    assert sum(g["bucket_reads"] for g in got) < 0.97 * sum(p["rounds"] for p in plain)
     assert sum(g["bucket_reads"] for g in soft) < 0.97 * sum(p["rounds"] for p in plain)
-
-
-# ---- the lazy lookahead (csrc kLeanLazy; TBC_NARROW_LEAN=2): the lookahead at once only for the config that will be popped next, its siblings
-# pushed unchecked and looked at if they are ever popped -- the oracle's lazy_look schedule, deepest stack included
-@pytest.mark.parametrize("L", [8, 16])
-def test_lazy_lookahead_every_counter(L):
-    hists = [_in_domain(n, p, s, busy, info, corrupt) for (n, p, info, corrupt, busy) in LEAN_SHAPES for s in range(3)]
-    hists = [h for h in hists if h.n_process <= 64]
-    compare(hists, CAS, L, tag="lazy", pool_words=4_000_000, lean=2)
-    compare(hists, CAS, L, tag="lazy by ret", pool_words=4_000_000, lean=2, by_ret=True, want_witness=False)
-
-
-def test_lazy_lookahead_growth_epochs_queue_and_the_bench_configuration():
-    hists = [_in_domain(1500, 16, s, 0.4, 0.0, 0.5 * (s % 2)) for s in range(12)]
-    compare(hists, CAS, 8, tag="lazy growth", entries_per_op=1, pool_words=6_000_000, lean=2, want_witness=False)
-    compare(hists, CAS, 8, tag="lazy epochs", epochs=3, pool_words=6_000_000, lean=2)
-    compare(hists, CAS, 8, tag="lazy queue", max_waves=1, pool_words=6_000_000, lean=2, by_ret=True, want_witness=False)
-    h = [columns.pair_events(synth.register_events(n_ops=300, n_procs=24, seed=s, busy=1.0, n_values=2)) for s in range(6)]      # many backtracks: unchecked siblings popped
-    compare(h, CAS, 8, tag="lazy busy", pool_words=8_000_000, lean=2)
-    bench = synth.register_ops_many(range(7000, 7006), n_ops=10000, n_procs=64, busy=0.1, info=0.0)
-    compare(bench, CAS, 8, tag="lazy bench", entries_per_op=4, pool_words=1 << 24, want_witness=False, lean=2, by_ret=True)
+    assert sum(g["bucket_reads"] for g in soft[:4]) < 0.9 * sum(p["rounds"] for p in slot[:4])

@@ -232,11 +232,11 @@ def test_narrow_round_schedules_keep_verdict_and_failing_op(oracle):
     assert n_checked > 60
 
 
-def test_list_order_and_the_lean_lookahead_never_change_a_verdict(native, oracle):
-    """The schedules behind TBC_NARROW_ORDER (a front's candidates in order of completion, wgl_beam_set_list_order(1)) and
-    TBC_NARROW_LEAN (three or more open producers read as "one is still to be linearized", look_two) are schedules of the SAME
-    search: verdict and failing op are the sequential restatement's on random histories, valid and invalid, with crashed calls --
-    at one config a round over 8 pairs (the narrow kernel's), at 2 and 4 configs a round (the wide kernel's)."""
+def test_list_order_never_changes_a_verdict(native, oracle):
+    """The schedules behind tbc_opts.list_order (a front's candidates in order of completion, with the :write calls last, with a :write
+    24 ranks later -- the library's default; wgl_beam_set_list_order) are schedules of the SAME search: verdict and failing op are
+    the sequential restatement's on random histories, valid and invalid, with crashed calls -- at one config a round over 8 pairs
+    (the narrow kernel's), at 2 and 4 configs a round (the wide kernel's)."""
     import random
     rng = random.Random(1)
     cas = {"kind": 1, "init": N.NIL}
@@ -250,8 +250,8 @@ def test_list_order_and_the_lean_lookahead_never_change_a_verdict(native, oracle
             continue
         n += 1
         n_invalid += ref["valid"] == 0
-        for width, kw in ((1, dict(round_pairs=8, rules_at_any_round_size=True, branch_lists=True, look_two=True)), (4, {}), (2, dict(look_two=True))):
-            for order in (1, oracle.ORACLE_LIST_ORDER[2]):          # (TBC_NARROW_ORDER=2: ... with the :write calls last)
+        for width, kw in ((1, dict(round_pairs=8, rules_at_any_round_size=True, branch_lists=True)), (4, {}), (2, {})):
+            for order in (1, oracle.ORACLE_LIST_ORDER[2], oracle.ORACLE_LIST_ORDER[16 + 24]):          # (PackOpenArgs.list_order 1, 2, 16 + 24)
                 r = oracle.check_beam(d, cas, width, want_witness=False, list_order=order, max_probes=20_000_000, **kw)
                 if r["valid"] == -1:
                     continue
@@ -259,37 +259,3 @@ def test_list_order_and_the_lean_lookahead_never_change_a_verdict(native, oracle
                 if ref["valid"] == 0:
                     assert r["fail_op"] == ref["fail_op"], (it, width, order, shape)
     assert n > 100 and n_invalid > 40
-
-
-def test_lazy_lookahead_is_the_same_schedule_with_half_the_lookahead_runs(native, oracle):
-    """DESIGN STUDY (oracle/wgl_beam.c, g_lazy_look; no kernel yet): the lookahead run at once only for the new config that will be popped
-    next, its siblings checked if they are ever popped.  Same verdicts and failing ops as the sequential restatement; on a bench-shaped
-    history the same probes, new configs and rounds as the eager lookahead, and about half as many lookahead runs in completion order."""
-    import ctypes as C
-    import random
-    cas = {"kind": 1, "init": N.NIL}
-    L = oracle.lib()
-    L.wgl_beam_look_runs.restype = C.c_uint64
-    kw = dict(round_pairs=8, rules_at_any_round_size=True, branch_lists=True, want_witness=False)
-    for h in synth.register_ops_many(range(500, 503), n_ops=10000, n_procs=64, busy=0.1, info=0.0):
-        d = h.as_dict()
-        eager = oracle.check_beam(d, cas, 1, list_order=1, **kw)
-        runs_eager = L.wgl_beam_look_runs()
-        lazy = oracle.check_beam(d, cas, 1, list_order=1, lazy_look=True, **kw)
-        runs_lazy = L.wgl_beam_look_runs()
-        assert (lazy["valid"], lazy["probes"], lazy["visited"], lazy["rounds"]) == (eager["valid"], eager["probes"], eager["visited"], eager["rounds"])
-        assert runs_lazy < 0.6 * runs_eager
-    rng = random.Random(2)
-    n_invalid = 0
-    for it in range(120):
-        d = columns.pair_events(synth.register_events(n_ops=rng.choice([10, 40, 120]), n_procs=rng.choice([2, 4, 8, 16]), seed=rng.randrange(10 ** 6),
-                                                      busy=rng.choice([0.3, 0.7, 1.0]), info=rng.choice([0, 0, 0.05]), corrupt=rng.choice([0, 0.3, 0.7]))).as_dict()
-        ref = oracle.check(d, cas, "window", max_steps=5_000_000, want_witness=False)
-        if ref["valid"] == -1:
-            continue
-        n_invalid += ref["valid"] == 0
-        r = oracle.check_beam(d, cas, 1, list_order=it & 1, lazy_look=True, **kw)
-        assert r["valid"] == ref["valid"] and (ref["valid"] == 1 or r["fail_op"] == ref["fail_op"]), it
-        r = oracle.check_beam(d, cas, 1, list_order=it & 1, defer=True, **kw)          # (one child at a time: another study knob, measured and not built)
-        assert r["valid"] == ref["valid"] and (ref["valid"] == 1 or r["fail_op"] == ref["fail_op"]), it
-    assert n_invalid > 30

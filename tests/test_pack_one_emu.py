@@ -188,8 +188,3 @@ def test_one_history_form_with_open_counts():
     assert emu.pack_wg_check(crash, count=True, branch=True, one=True, seed=4) is None
     full = synth.register_ops_many(range(7000, 7001), n_ops=10000, n_procs=64, busy=0.1, info=0.0)
     assert emu.pack_wg_check(full, branch=True, one=True, seed=5) is None
-
-
-def test_batch_form_leaves_the_lean_lookahead_pads():
-    """TBC_PACK_WG with TBC_NARROW_LEAN: the records past the last rank in the 8 B format"""
-    assert emu.pack_wg_check(_hists(seeds=(1,)), branch=True, lean=True, seed=1) is None

@@ -20,7 +20,7 @@ def _records(buf):
     return np.frombuffer(buf, dtype=np.uint8).reshape(-1, C.sizeof(N.SweepRel))
 
 
-def _compare(ops, seg_target, n_dom, waves, cap=1024, rules=None, seed=1, expect_overflow=False, second_pass=False, queue=False, fp=False, compact=False):
+def _compare(ops, seg_target, n_dom, waves, cap=1024, rules=None, seed=1, expect_overflow=False, second_pass=False, compact=False):
     d = ops.as_dict()
     R = int((np.asarray(d["ret_pos"]) != 0xFFFFFFFF).sum())
     max_segs = max(1, min(512, (R + seg_target - 1) // seg_target)) if seg_target else 1
@@ -32,7 +32,7 @@ def _compare(ops, seg_target, n_dom, waves, cap=1024, rules=None, seed=1, expect
         wgl.check_sweep(d, CAS, eager_reads=eager, twin_rule=twin, seg_target=seg_target, n_dom=n_dom)
     finally:
         L.sweep_set_export(None, C.c_uint32(0), C.c_uint32(0), C.c_uint32(1))
-    got = emu.sweep_wg(d, 1, N.NIL, seg_target, n_dom, max_segs, waves=waves, cap=cap, rules=None if rules is None else (3 if rules else 0), seed=seed, queue=queue, fp=fp, compact=compact)
+    got = emu.sweep_wg(d, 1, N.NIL, seg_target, n_dom, max_segs, waves=waves, cap=cap, rules=None if rules is None else (3 if rules else 0), seed=seed, compact=compact)
     want = [N.SweepRel.from_buffer_copy(r.tobytes()) for r in _records(buf)]
     have = [N.SweepRel.from_buffer_copy(r.tobytes()) for r in _records(got)]
     if second_pass:      # the segments that overflowed, once more with sets of 2,048 configs and eight wavefronts (what launch_sweep does)
@@ -153,77 +153,23 @@ def test_overflow_is_reported_not_mis_swept():
     _compare(h, 32, 6, 4, cap=512, expect_overflow=True, second_pass=True)        # ... and the second pass makes every record the oracle's
 
 
-@pytest.mark.parametrize("waves", [2, 8])
-def test_the_ring_variant_every_record(waves):
-    """QUEUE (jit_sweep_wg_impl.h; experimental, no launch of round 4 takes it): a sub-round's children wait in a ring and are inserted a
-    full workgroup at a time -- the same records"""
-    n = 0
-    for seed in range(4):
-        for corrupt in (0.0, 0.4):
-            h = columns.pair_events(synth.register_events(n_ops=300, n_procs=8, seed=100 + seed, busy=0.5, info=0.0, corrupt=corrupt))
-            n += _compare(h, 32, 6, waves, seed=seed, queue=True)
-    assert n > 12
-    h = columns.pair_events(synth.register_events(n_ops=300, n_procs=8, seed=58, busy=0.4, info=0.015, corrupt=0.0))      # crashed calls
-    _compare(h, 32, 6, waves, queue=True)
-
-
-def test_the_ring_variant_on_a_bench_history_under_several_interleavings():
-    h = synth.register_ops_many([3], n_ops=10000, n_procs=64, busy=0.1, info=0.0)[0]
-    assert _compare_sample(h, 32, 6, 8, queue=True) > 40
-    h = columns.pair_events(synth.register_events(n_ops=600, n_procs=16, seed=7, busy=0.5, info=0.0, corrupt=0.0))
-    for seed in range(6):
-        _compare(h, 32, 6, 8, seed=2000 + 13 * seed, queue=True)
-    h4 = synth.register_ops_many([4], n_ops=10000, n_procs=64, busy=0.1, info=0.0)[0]
-    _compare(h4, 32, 6, 4, cap=512, expect_overflow=True, queue=True)
-
-
-@pytest.mark.parametrize("queue", [False, True])
-def test_the_fingerprint_variant_every_record(queue):
-    """FP (experimental, no launch of round 4 takes it): 8 bits of the key's hash in the table word, generations wrapping every 127
-    sets -- the same records, with and without the ring"""
-    n = 0
-    for seed in range(4):
-        for corrupt in (0.0, 0.4):
-            h = columns.pair_events(synth.register_events(n_ops=300, n_procs=8, seed=100 + seed, busy=0.5, info=0.0, corrupt=corrupt))
-            n += _compare(h, 32, 6, 2 if seed % 2 else 8, seed=seed, queue=queue, fp=True)
-    assert n > 12
-    h = columns.pair_events(synth.register_events(n_ops=300, n_procs=8, seed=58, busy=0.4, info=0.015, corrupt=0.0))      # crashed calls, one long segment: generations wrap
-    _compare(h, 32, 6, 8, queue=queue, fp=True)
-    if queue:       # (the bench history with its bursts once: both forms at once; the plain fingerprint form is covered by the histories above)
-        h = synth.register_ops_many([3], n_ops=10000, n_procs=64, busy=0.1, info=0.0)[0]
-        assert _compare(h, 32, 6, 8, queue=queue, fp=True) > 250
-    else:
-        h4 = synth.register_ops_many([4], n_ops=10000, n_procs=64, busy=0.1, info=0.0)[0]
-        _compare(h4, 32, 6, 4, cap=512, expect_overflow=True, queue=queue, fp=True)
-
-
-def test_sixteen_wavefronts_on_the_big_sets():
-    """TBC_SWEEP_WG=16 (experimental): 1,024 threads per segment, sets of 2,048 configs from the start"""
-    for seed in range(3):
-        h = columns.pair_events(synth.register_events(n_ops=300, n_procs=8, seed=100 + seed, busy=0.5, info=0.0, corrupt=0.4 * (seed % 2)))
-        _compare(h, 32, 6, 16, cap=2048, seed=seed)
-    h4 = synth.register_ops_many([4], n_ops=10000, n_procs=64, busy=0.1, info=0.0)[0]      # the history whose burst overflows 1,024 configs: no overflow here
-    assert _compare_sample(h4, 32, 6, 16, cap=2048) > 40          # (a sample of its workgroups, the bursts among them: _compare_sample)
-
-
-# ---- the compact walk (COMPACT, TBC_SWEEP_WG_COMPACT=1): a sub-round's passes take 64 x NW CHILDREN, not 64 x NW (config, call) slots
-@pytest.mark.parametrize("fp", [False, True])
-def test_the_compact_walk_every_record(fp):
+# ---- the compact walk (COMPACT): a sub-round's passes take 64 x NW CHILDREN, not 64 x NW (config, call) slots
+def test_the_compact_walk_every_record():
     """the same records as the plain form: small histories valid and invalid, rules off (reads are candidates: more children per
     config), crashed calls (one long segment, classes of candidates past the live calls), fewer and more wavefronts"""
     n = 0
     for seed in range(4):
         for corrupt in (0.0, 0.4):
             h = columns.pair_events(synth.register_events(n_ops=300, n_procs=8, seed=100 + seed, busy=0.5, info=0.0, corrupt=corrupt))
-            n += _compare(h, 32, 6, (2, 4, 8, 8)[seed], seed=seed, compact=True, fp=fp)
+            n += _compare(h, 32, 6, (2, 4, 8, 8)[seed], seed=seed, compact=True)
     assert n > 12
     h = columns.pair_events(synth.register_events(n_ops=400, n_procs=8, seed=5, busy=0.6, info=0.0, corrupt=0.0))
-    _compare(h, 32, 6, 8, rules=False, seed=3, compact=True, fp=fp)
+    _compare(h, 32, 6, 8, rules=False, seed=3, compact=True)
     h = columns.pair_events(synth.register_events(n_ops=400, n_procs=16, seed=5, busy=0.8, info=0.0, corrupt=0.0))      # levels past 1,024 configs without the rules
-    _compare(h, 32, 6, 8, rules=False, seed=3, compact=True, fp=fp, expect_overflow=True)
+    _compare(h, 32, 6, 8, rules=False, seed=3, compact=True, expect_overflow=True)
     h = columns.pair_events(synth.register_events(n_ops=300, n_procs=8, seed=58, busy=0.4, info=0.015, corrupt=0.0))
-    _compare(h, 32, 6, 8, seed=4, compact=True, fp=fp)
-    _compare(h, 0, 6, 4, seed=5, compact=True, fp=fp)                    # one segment
+    _compare(h, 32, 6, 8, seed=4, compact=True)
+    _compare(h, 0, 6, 4, seed=5, compact=True)                    # one segment
 
 
 def test_the_compact_walk_on_a_bench_history_its_bursts_and_overflow():
@@ -238,25 +184,24 @@ def test_the_compact_walk_on_a_bench_history_its_bursts_and_overflow():
     _compare(h4, 32, 6, 4, cap=512, expect_overflow=True, compact=True)
 
 
-# ---- narrow passes by wavefront 0 alone (SOLO, with the compact walk: TBC_SWEEP_WG_COMPACT=2)
-@pytest.mark.parametrize("fp", [False, True])
-def test_solo_passes_every_record(fp):
+# ---- narrow passes by wavefront 0 alone (SOLO, with the compact walk): the library's first pass since round 5
+def test_solo_passes_every_record():
     """a level of at most 64 configs / a sub-round of at most 64 slots is wavefront 0's alone (one workgroup barrier instead of three):
     the same records -- small histories (nearly every pass is narrow), rules off, crashed calls, one segment, several interleavings"""
     n = 0
     for seed in range(4):
         for corrupt in (0.0, 0.4):
             h = columns.pair_events(synth.register_events(n_ops=300, n_procs=8, seed=100 + seed, busy=0.5, info=0.0, corrupt=corrupt))
-            n += _compare(h, 32, 6, (2, 4, 8, 8)[seed], seed=seed, compact=2, fp=fp)
+            n += _compare(h, 32, 6, (2, 4, 8, 8)[seed], seed=seed, compact=2)
     assert n > 12
     h = columns.pair_events(synth.register_events(n_ops=400, n_procs=8, seed=5, busy=0.6, info=0.0, corrupt=0.0))
-    _compare(h, 32, 6, 8, rules=False, seed=3, compact=2, fp=fp)
+    _compare(h, 32, 6, 8, rules=False, seed=3, compact=2)
     h = columns.pair_events(synth.register_events(n_ops=300, n_procs=8, seed=58, busy=0.4, info=0.015, corrupt=0.0))
-    _compare(h, 32, 6, 8, seed=4, compact=2, fp=fp)
-    _compare(h, 0, 6, 4, seed=5, compact=2, fp=fp)
+    _compare(h, 32, 6, 8, seed=4, compact=2)
+    _compare(h, 0, 6, 4, seed=5, compact=2)
     h = columns.pair_events(synth.register_events(n_ops=600, n_procs=16, seed=7, busy=0.5, info=0.0, corrupt=0.0))
     for seed in range(3):
-        _compare(h, 32, 6, 8, seed=4000 + 19 * seed, compact=2, fp=fp)
+        _compare(h, 32, 6, 8, seed=4000 + 19 * seed, compact=2)
 
 
 def test_solo_passes_on_a_bench_history_and_overflow():

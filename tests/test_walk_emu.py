@@ -59,41 +59,15 @@ def test_full_size_histories():
     assert emu.walk_check(busy, 8, branch=True, front="wide") is None
 
 
-# ---- the lean formats (csrc/tbc_internal.h, kLeanCands | kLeanLook; TBC_NARROW_LEAN=1): a list entry {call, twin mask}, an 8 B lookahead record
-@pytest.mark.parametrize("branch", [True, False])
-def test_lean_formats_every_word(branch):
-    assert emu.walk_check(_hists(), 8, branch=branch, front="compact", lean=True) is None
-
-
-def test_lean_formats_many_twins_and_many_producers():
-    """two values, every process busy: most writes have twins, and a completion often has three or more open producers of the value
-    it needs (the lean record's `many` bit)"""
-    h = [columns.pair_events(synth.register_events(n_ops=400, n_procs=40, seed=s, busy=1.0, n_values=2)) for s in range(3)]
-    assert emu.walk_check(h, 8, branch=True, front="compact", lean=True) is None
-    full = synth.register_ops_many(range(7000, 7003), n_ops=10000, n_procs=64, busy=0.1, info=0.0)
-    busy = synth.register_ops_many(range(7100, 7101), n_ops=10000, n_procs=64, busy=0.5, info=0.0)
-    assert emu.walk_check(full + busy, 8, branch=True, front="compact", lean=True) is None
-
-
-@pytest.mark.parametrize("lean", [False, True])
-def test_lists_in_order_of_completion_every_word(lean):
-    """PackOpenArgs.list_order = 1 (TBC_NARROW_ORDER=1): the same tables with every front's list sorted by completion rank"""
-    assert emu.walk_check(_hists(), 8, branch=True, front="compact", lean=lean, by_ret=True) is None
-    assert emu.walk_check(_hists(seeds=(3,)), 8, branch=False, front="compact", lean=lean, by_ret=True) is None
+# ---- the fronts' lists in order of completion (tbc_opts.list_order; PackOpenArgs.list_order 1, 2, 16 + W -- 16 + 24 is the library's default)
+@pytest.mark.parametrize("by_ret", [1, 2, 16 + 24, 16 + 3])
+def test_lists_in_order_of_completion_every_word(by_ret):
+    """the same tables with every front's list sorted by completion rank; 2: the :write calls after everything else (full lists -- reads,
+    then cas, then writes apart -- and branch lists); 16 + W: a :write as if it completed W ranks later"""
+    assert emu.walk_check(_hists(), 8, branch=True, front="compact", by_ret=by_ret) is None
+    assert emu.walk_check(_hists(seeds=(3,)), 8, branch=False, front="compact", by_ret=by_ret) is None
     h = [columns.pair_events(synth.register_events(n_ops=400, n_procs=40, seed=s, busy=1.0, n_values=2)) for s in range(2)]
     full = synth.register_ops_many(range(7000, 7002), n_ops=10000, n_procs=64, busy=0.1, info=0.0)
     busy = synth.register_ops_many(range(7100, 7101), n_ops=10000, n_procs=64, busy=0.5, info=0.0)
-    assert emu.walk_check(h + full + busy, 8, branch=True, front="compact", lean=lean, by_ret=True) is None
-
-
-@pytest.mark.parametrize("by_ret", [2, 16 + 24, 16 + 3])
-@pytest.mark.parametrize("lean", [False, True])
-def test_lists_in_order_of_completion_writes_last_every_word(lean, by_ret):
-    """PackOpenArgs.list_order = 2 (TBC_NARROW_ORDER=2): every front's list by completion rank with the :write calls after everything else
-    (full lists -- reads, then cas, then writes apart -- and branch lists); 16 + W: a :write as if it completed W ranks later"""
-    assert emu.walk_check(_hists(), 8, branch=True, front="compact", lean=lean, by_ret=by_ret) is None
-    assert emu.walk_check(_hists(seeds=(3,)), 8, branch=False, front="compact", lean=lean, by_ret=by_ret) is None
-    h = [columns.pair_events(synth.register_events(n_ops=400, n_procs=40, seed=s, busy=1.0, n_values=2)) for s in range(2)]
-    full = synth.register_ops_many(range(7000, 7002), n_ops=10000, n_procs=64, busy=0.1, info=0.0)
-    busy = synth.register_ops_many(range(7100, 7101), n_ops=10000, n_procs=64, busy=0.5, info=0.0)
-    assert emu.walk_check(h + full + busy, 8, branch=True, front="compact", lean=lean, by_ret=by_ret) is None
+    assert emu.walk_check(h + full + busy, 8, branch=True, front="compact", by_ret=by_ret) is None
+    assert emu.walk_check(full[:1] + busy, 8, branch=False, front="plain", by_ret=by_ret) is None          # (the wide kernel's tables: plain rows, full lists)
