@@ -65,7 +65,7 @@ def test_default_list_order_in_a_big_batch_with_the_queue(native, oracle):
     """4,096 bench-shaped histories (1,000 ops each) by 8 lanes per history: wavefronts refill from the queue, sets grow inside the kernel"""
     base = [_in_domain(1000, 64, 9000 + s, 0.1, 0.0, 0.5 * (s % 8 == 0)) for s in range(64)]
     model = core.make_model(N.MODEL_CAS_REGISTER, N.NIL)
-    with core.Batch([base[i % 64] for i in range(4096)], model, core.make_opts(time_limit_ms=60000, want_witness=False, algorithm=N.ALG_COMPETITION, lanes_per_history=8, visited_per_op=1)) as b:
+    with core.Batch([base[i % 64] for i in range(4096)], model, core.make_opts(time_limit_ms=60000, want_witness=False, algorithm=N.ALG_COMPETITION, lanes_per_history=8, visited_per_op=1, list_order=N.ORDER_DEFAULT)) as b:
         assert b.list_order() == 16 + 24
         res = b.run().results()
     for i in range(64):
@@ -106,13 +106,13 @@ def test_list_order_where_it_does_not_apply_is_slot_order(native):
     """the count form, the level sweep beside the search, two mask words: the lists stay in slot order whatever is asked, and the batch says so"""
     model = core.make_model(N.MODEL_CAS_REGISTER, N.NIL)
     crashed = [columns.pair_events(synth.register_events(n_ops=400, n_procs=8, seed=s, busy=0.5, info=0.05)) for s in range(4)]
-    with core.Batch(crashed, model, core.make_opts(algorithm=N.ALG_COMPETITION, search_width=4, want_witness=False, list_order=16 + 24)) as b:      # count form
+    with core.Batch(crashed, model, core.make_opts(algorithm=N.ALG_COMPETITION, search_width=4, want_witness=False, list_order=16 + 24, count_form=True)) as b:      # count form
         assert b.list_order() == N.ORDER_SLOT
     few = [columns.pair_events(synth.register_events(n_ops=400, n_procs=8, seed=s, busy=0.5)) for s in range(4)]
-    with core.Batch(few, model, core.make_opts(algorithm=N.ALG_COMPETITION, want_witness=False)) as b:      # the level sweep takes a handful of histories
+    with core.Batch(few, model, core.make_opts(algorithm=N.ALG_COMPETITION, want_witness=False, list_order=N.ORDER_DEFAULT)) as b:      # the level sweep takes a handful of histories
         assert b.sweep_info()["enabled"] == 1 and b.list_order() == N.ORDER_SLOT
     wide = [columns.pair_events(synth.register_events(n_ops=600, n_procs=100, seed=s, busy=0.05)) for s in range(4)]
-    with core.Batch(wide, model, core.make_opts(algorithm=N.ALG_COMPETITION, search_width=4, want_witness=False)) as b:
+    with core.Batch(wide, model, core.make_opts(algorithm=N.ALG_COMPETITION, search_width=4, want_witness=False, list_order=N.ORDER_DEFAULT)) as b:
         assert b.list_order() == N.ORDER_SLOT
     with pytest.raises(N.TbcError):
         core.Batch(few, model, core.make_opts(algorithm=N.ALG_COMPETITION, list_order=7))
