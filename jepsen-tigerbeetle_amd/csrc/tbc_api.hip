@@ -177,6 +177,11 @@ struct Ctx {
   int device = 0;
   char* slab = nullptr;
   size_t cap = 0, used = 0, wanted = 0;
+  // ... and one PINNED host region (round 5): what a call copies to and from the device -- the op columns staged as one block, the
+  // sweep's relation table, the descriptors read back -- goes through it, so a copy is one DMA instead of a staged blit per 64 KB
+  // of pageable memory, and nothing waits for a copy before the kernels are queued (tbc_check: 77 + 50 us of its 1.07 ms)
+  char* pin = nullptr;
+  size_t pin_cap = 0, pin_used = 0, pin_wanted = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev[6] = {};
 };
@@ -205,6 +210,34 @@ struct DevBuf {
   size_t bytes() const { return (n ? n : 1) * sizeof(T); }
 };
 
+// host memory a stream copies into or out of: carved from the calling thread's persistent context's pinned region when there is
+// one (tbc_check), a plain vector otherwise (a resident batch reads its results back into pageable memory as before)
+template <typename T>
+struct HostBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  std::vector<T> own;
+  void resize(size_t count) {
+    n = count;
+    const size_t bytes = (std::max<size_t>(count, 1) * sizeof(T) + 255) & ~(size_t)255;
+    if (t_ctx) {
+      t_ctx->pin_wanted += bytes;
+      if (t_ctx->pin_used + bytes <= t_ctx->pin_cap) { p = (T*)(t_ctx->pin + t_ctx->pin_used); t_ctx->pin_used += bytes; own.clear(); return; }
+    }
+    own.resize(count);
+    p = own.data();
+  }
+  T* data() { return p; }
+  const T* data() const { return p; }
+  size_t size() const { return n; }
+  T& operator[](size_t i) { return p[i]; }
+  const T& operator[](size_t i) const { return p[i]; }
+  T* begin() { return p; }
+  T* end() { return p + n; }
+  const T* begin() const { return p; }
+  const T* end() const { return p + n; }
+};
+
 Ctx* ctx_acquire(int device) {
   {
     std::lock_guard<std::mutex> lk(g_ctx_mu);
@@ -228,6 +261,15 @@ void ctx_release(Ctx* c) {
     if (hipMalloc((void**)&c->slab, want) == hipSuccess) c->cap = want;
   }
   c->used = 0; c->wanted = 0;
+  if (c->pin_wanted > c->pin_cap && c->pin_wanted < (1ull << 30)) {
+    if (c->pin) (void)hipHostFree(c->pin);
+    c->pin = nullptr; c->pin_cap = 0;
+    const size_t want = c->pin_wanted + c->pin_wanted / 4;
+    // (non-coherent = cached on the host: the composition reads the 0.6 MB relation table right after the copy -- through a coherent,
+    // uncached mapping that took 75 us instead of 25; the stream synchronize before it makes the copy visible)
+    if (hipHostMalloc((void**)&c->pin, want, hipHostMallocNonCoherent) == hipSuccess) c->pin_cap = want;
+  }
+  c->pin_used = 0; c->pin_wanted = 0;
   std::lock_guard<std::mutex> lk(g_ctx_mu);
   g_ctx_free.push_back(c);
 }
@@ -334,12 +376,14 @@ struct tbc_batch {
   uint32_t max_segs = 1, seg_target = 0, cut_open = 0, n_dom = 1;
   DevBuf<uint32_t> d_cuts, d_seglist;
   DevBuf<SegResult> d_sres;
-  std::vector<SegResult> seg_host;
+  HostBuf<SegResult> seg_host;
   uint32_t last_segments = 0, last_fallback = 0;
   uint32_t shard_rank = 0, shard_world = 1;      // tbc_batch_set_shard: this rank's share of the sweep's wavefronts
   bool partial_done = false;                     // a tbc_batch_sweep_partial is waiting for its tbc_batch_sweep_finish
-  std::vector<Hist> hist_back_m;                 // descriptors as the pack kernels left them (kept between
-  std::vector<BeamHist> bh_back_m;               //   tbc_batch_sweep_partial and tbc_batch_sweep_finish)
+  HostBuf<Hist> hist_back_m;                     // descriptors as the pack kernels left them (kept between
+  HostBuf<BeamHist> bh_back_m;                   //   tbc_batch_sweep_partial and tbc_batch_sweep_finish)
+  HostBuf<char> upload_stage;       // tbc_check: the block create uploads (pinned, the context's)
+  bool inputs_fresh = false;        // tbc_check: create has just uploaded hist / bh / work with the columns -- the first run does not again
   uint32_t rules = 0;               // kRuleEager | kRuleTwin: wide single-wave schedule, register family, values 0..kMaxRuleValue
   uint32_t vpad = 0;                // entries per rdm row (nil + values), power of two
   DevBuf<uint64_t> d_twn, d_rdm;    // dominance tables (tbc_internal.h)
@@ -624,7 +668,11 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
     const bool branch = (B->rules & kRuleBranch) != 0;
     for (uint32_t h = 0; h < nh; h++) {
       const uint64_t n = desc->op_off[h + 1] - desc->op_off[h];
-      list_caps[h] = (uint32_t)std::min<uint64_t>(0xFFFFFFF0ull, open_list_entries(desc->cols, desc->op_off[h], n, desc->n_events[h], std::max(1u, slots_of(h)), rank_scratch, branch));
+      // (tbc_check: the arenas are pieces of a slab that is there already -- where the worst case, every slot at every front, is a few MB,
+      // take it and skip the pass over the history's events: 20 us of a 1 ms call)
+      const uint64_t worst = std::max<uint64_t>(n, 1) * std::max(1u, slots_of(h));
+      if (t_ctx && worst * (sizeof(OpRec) + 8 * B->mask_words) <= (24ull << 20)) list_caps[h] = (uint32_t)worst;
+      else list_caps[h] = (uint32_t)std::min<uint64_t>(0xFFFFFFF0ull, open_list_entries(desc->cols, desc->op_off[h], n, desc->n_events[h], std::max(1u, slots_of(h)), rank_scratch, branch));
     }
   }
   TRACE("create: lists sized");
@@ -695,18 +743,20 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
   TRACE("create: layout done");
   tbc_status s;
   const uint64_t T = B->total_ops;
+  // (the order matters to tbc_check, whose arenas are consecutive pieces of its context's slab: what is uploaded -- the six columns,
+  // the descriptors, the work list -- first, as one block (upload_block below); then what every run zeroes, as one memset (zero_block))
   if ((s = B->d_f.alloc(T)) || (s = B->d_a.alloc(T)) || (s = B->d_b.alloc(T)) || (s = B->d_proc.alloc(T)) ||
-      (s = B->d_inv.alloc(T)) || (s = B->d_ret.alloc(T)) || (s = B->d_hist.alloc(nh)) || (s = B->d_rec.alloc(rec_n)) ||
+      (s = B->d_inv.alloc(T)) || (s = B->d_ret.alloc(T)) || (s = B->d_hist.alloc(nh)) || (s = B->d_bh.alloc(beam ? nh : 0)) || (s = B->d_work.alloc(nh)) ||
+      (s = B->d_bitmap.alloc(bm_n)) || (s = B->d_off.alloc(beam ? boff_n : 0)) || (s = B->d_ncr.alloc(beam ? boff_n : 0)) || (s = B->d_pool_cursor.alloc(1)) ||
+      (s = B->d_rec.alloc(rec_n)) ||
       (s = B->d_seg.alloc(seg_n)) || (s = B->d_ret_slot.alloc(T)) || (s = B->d_ret_op.alloc(T)) ||
-      (s = B->d_bitmap.alloc(bm_n)) || (s = B->d_wpre.alloc(bm_n)) || (s = B->d_frames.alloc(frame_n)) ||
-      (s = B->d_tab.alloc(tab_n)) || (s = B->d_results.alloc(nh)) || (s = B->d_work.alloc(nh)) ||
+      (s = B->d_wpre.alloc(bm_n)) || (s = B->d_frames.alloc(frame_n)) ||
+      (s = B->d_tab.alloc(tab_n)) || (s = B->d_results.alloc(nh)) ||
       (s = B->d_queue.alloc(4)) || (s = B->d_witness.alloc(opts->want_witness ? T : 0)))
     return s;
   if (beam) {
-    if ((s = B->d_bh.alloc(nh)) || (s = B->d_off.alloc(boff_n)) || (s = B->d_ncr.alloc(boff_n)) ||
-        (!device_sizing && (s = B->d_lst.alloc(blst_n))) || (s = B->d_crashed.alloc((B->count_form || !B->any_crashed) ? 0 : T)) || (s = B->d_cmem.alloc(B->count_form ? bocc_n : 0)) ||
-        (s = B->d_slot8.alloc(slot8_bytes(T, nh))) || (s = B->d_stack.alloc(bstack_n)) || (s = B->d_btab.alloc(btab_n * B->tab_stride())) ||
-        (s = B->d_pool_cursor.alloc(1)))
+    if ((!device_sizing && (s = B->d_lst.alloc(blst_n))) || (s = B->d_crashed.alloc((B->count_form || !B->any_crashed) ? 0 : T)) || (s = B->d_cmem.alloc(B->count_form ? bocc_n : 0)) ||
+        (s = B->d_slot8.alloc(slot8_bytes(T, nh))) || (s = B->d_stack.alloc(bstack_n)) || (s = B->d_btab.alloc(btab_n * B->tab_stride())))
       return s;
     if (B->sweep && ((s = B->d_cuts.alloc((uint64_t)nh * B->max_segs)) || (s = B->d_sres.alloc((uint64_t)nh * B->max_segs * kSweepSlices)) || (s = B->d_seglist.alloc((uint64_t)nh * B->max_segs * kSweepSlices * 3)))) return s;
     if (B->sweep) B->seg_host.resize((size_t)nh * B->max_segs * kSweepSlices);
@@ -758,6 +808,42 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
 
   TRACE("create: arenas allocated");
   // inputs become resident
+  std::vector<uint32_t> work(nh);
+  for (uint32_t h = 0; h < nh; h++) work[h] = h;
+  // tbc_check: columns, descriptors and work list are consecutive pieces of the context's slab -- staged in the context's pinned
+  // region and uploaded as ONE copy that nobody waits for (the run's kernels follow it in stream order; the region lives until the
+  // call ends).  Eight staged copies of pageable memory and a synchronize were 77 us of a 1.07 ms call.
+  bool uploaded = false;
+  if (t_ctx && T && !(B->count_form && bocc_n) && !device_sizing) {
+    char* const base = (char*)B->d_f.p;
+    const auto at = [&](const void* p) { return (size_t)((const char*)p - base); };
+    const auto a256 = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const bool consecutive = !B->d_f.owned && !B->d_a.owned && !B->d_b.owned && !B->d_proc.owned && !B->d_inv.owned && !B->d_ret.owned && !B->d_hist.owned &&
+                             !B->d_bh.owned && !B->d_work.owned && at(B->d_a.p) == a256(T) && at(B->d_b.p) == at(B->d_a.p) + a256(T * 4) &&
+                             at(B->d_proc.p) == at(B->d_b.p) + a256(T * 4) && at(B->d_inv.p) == at(B->d_proc.p) + a256(T * 4) && at(B->d_ret.p) == at(B->d_inv.p) + a256(T * 4) &&
+                             at(B->d_hist.p) == at(B->d_ret.p) + a256(T * 4) && at(B->d_bh.p) == at(B->d_hist.p) + a256(nh * sizeof(Hist)) &&
+                             at(B->d_work.p) == at(B->d_bh.p) + a256(std::max<size_t>(beam ? nh : 0, 1) * sizeof(BeamHist));
+    if (consecutive) {
+      const size_t total = at(B->d_work.p) + a256((size_t)nh * 4);
+      B->upload_stage.resize(total);
+      if (B->upload_stage.own.empty()) {          // (pinned: else the plain copies below)
+        char* st = B->upload_stage.data();
+        std::memcpy(st, desc->cols.f, T);
+        std::memcpy(st + at(B->d_a.p), desc->cols.a, T * 4);
+        std::memcpy(st + at(B->d_b.p), desc->cols.b, T * 4);
+        std::memcpy(st + at(B->d_proc.p), B->count_form ? slot_col.data() : desc->cols.process, T * 4);
+        std::memcpy(st + at(B->d_inv.p), desc->cols.inv_pos, T * 4);
+        std::memcpy(st + at(B->d_ret.p), desc->cols.ret_pos, T * 4);
+        std::memcpy(st + at(B->d_hist.p), B->hist.data(), nh * sizeof(Hist));
+        if (beam) std::memcpy(st + at(B->d_bh.p), B->bh.data(), nh * sizeof(BeamHist));
+        std::memcpy(st + at(B->d_work.p), work.data(), (size_t)nh * 4);
+        HIP_TRY(hipMemcpyAsync(base, st, total, hipMemcpyHostToDevice, B->stream));
+        uploaded = true;
+        B->inputs_fresh = true;
+      }
+    }
+  }
+  if (uploaded) { B->res_host.resize(nh); TRACE("create: inputs queued as one block"); return TBC_OK; }
   if (T) {
     HIP_TRY(hipMemcpyAsync(B->d_f.p, desc->cols.f, T, hipMemcpyHostToDevice, B->stream));
     HIP_TRY(hipMemcpyAsync(B->d_a.p, desc->cols.a, T * 4, hipMemcpyHostToDevice, B->stream));
@@ -773,8 +859,6 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
     HIP_TRY(hipMemcpyAsync(B->d_cmem.p, cmem_host.data(), cmem_host.size() * 8, hipMemcpyHostToDevice, B->stream));
   }
   HIP_TRY(hipMemcpyAsync(B->d_hist.p, B->hist.data(), nh * sizeof(Hist), hipMemcpyHostToDevice, B->stream));
-  std::vector<uint32_t> work(nh);
-  for (uint32_t h = 0; h < nh; h++) work[h] = h;
   HIP_TRY(hipMemcpyAsync(B->d_work.p, work.data(), nh * 4, hipMemcpyHostToDevice, B->stream));
   HIP_TRY(hipStreamSynchronize(B->stream));
   TRACE("create: inputs resident");
@@ -931,7 +1015,7 @@ static BeamArgs make_beam_args(tbc_batch* B, uint64_t* tab, uint32_t* stack, uin
 // scratch arena (overflow retries, and wide-schedule histories that fall back to the sequential kernel).
 // count form: `count_mode` (exact / relaxed), per-history prefix targets and a step limit of the pass's own (steps_override >= 0).
 static tbc_status scratch_pass(tbc_batch* B, const std::vector<uint32_t>& grp, const std::vector<uint32_t>& lg,
-                               bool beam, const std::vector<Hist>& hist_back, const std::vector<BeamHist>& bh_back,
+                               bool beam, const HostBuf<Hist>& hist_back, const HostBuf<BeamHist>& bh_back,
                                uint32_t width_override = 0, uint32_t count_mode = kCountExact, const std::vector<uint32_t>* targets = nullptr,
                                int64_t steps_override = -1) {
   hipStream_t s = B->stream;
@@ -1107,8 +1191,8 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results, int phase = 
   hipStream_t s = B->stream;
   const bool beam = B->width > 1;
   const uint32_t KW = 1 + B->mask_words, EW = B->entry_words();
-  std::vector<Hist>& hist_back = B->hist_back_m;
-  std::vector<BeamHist>& bh_back = B->bh_back_m;
+  HostBuf<Hist>& hist_back = B->hist_back_m;
+  HostBuf<BeamHist>& bh_back = B->bh_back_m;
   // count form: the exact search runs under a budget of probes; what it does not finish goes through the relaxed refutation and
   // the prefix search below (a caller who names max_steps gets one exact pass under that limit instead)
   const uint64_t count_budget = (B->count_form && B->opts.max_steps == 0) ? 32ull * B->max_ops : 0ull;
@@ -1127,22 +1211,35 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results, int phase = 
 
   TRACE("run: begin");
   HIP_TRY(hipEventRecord(B->ev[0], s));
-  HIP_TRY(hipMemsetAsync(B->d_bitmap.p, 0, B->d_bitmap.bytes(), s));
+  // (tbc_check: the arenas a run zeroes -- position bitmap, list offsets, crashed-call counts, the pool cursor -- are consecutive
+  // pieces of the context's slab: one memset; the descriptors came up with the columns: not again.  Six memsets and two copies were 34 us)
+  const bool zero_block = B->borrowed && !B->d_bitmap.owned && !B->d_off.owned && !B->d_ncr.owned && !B->d_pool_cursor.owned &&
+                          (char*)B->d_bitmap.p < (char*)B->d_pool_cursor.p && (size_t)((char*)B->d_pool_cursor.p - (char*)B->d_bitmap.p) < (64u << 20) &&
+                          (char*)B->d_off.p > (char*)B->d_bitmap.p && (char*)B->d_off.p < (char*)B->d_pool_cursor.p &&
+                          (char*)B->d_ncr.p > (char*)B->d_bitmap.p && (char*)B->d_ncr.p < (char*)B->d_pool_cursor.p;
+  const bool fresh = B->inputs_fresh;
+  B->inputs_fresh = false;
+  if (zero_block) HIP_TRY(hipMemsetAsync(B->d_bitmap.p, 0, (size_t)((char*)B->d_pool_cursor.p - (char*)B->d_bitmap.p) + sizeof(unsigned long long), s));
+  else HIP_TRY(hipMemsetAsync(B->d_bitmap.p, 0, B->d_bitmap.bytes(), s));
   // several histories per wavefront: the visited sets are not zeroed before every pass -- the keys carry the pass number and
   // another pass's entries read as empty (wgl_narrow_impl.h, entry_empty); the arena is zeroed when the number wraps (and first of all)
   const bool use_epoch = beam && B->lanes != 0;          // (a batch with lanes has every history below kNarrowMaxOps: batch_create_impl)
   if (beam) {
     if (use_epoch) B->epoch = B->epoch % 255u + 1u;
-    if (!use_epoch || B->epoch == 1u) HIP_TRY(hipMemsetAsync(B->d_btab.p, 0, B->d_btab.bytes(), s));
-    HIP_TRY(hipMemsetAsync(B->d_pool.p, 0, B->d_pool.bytes(), s));
-    HIP_TRY(hipMemsetAsync(B->d_pool_cursor.p, 0, sizeof(unsigned long long), s));
-    HIP_TRY(hipMemsetAsync(B->d_off.p, 0, B->d_off.bytes(), s));
-    HIP_TRY(hipMemsetAsync(B->d_ncr.p, 0, B->d_ncr.bytes(), s));
-    HIP_TRY(hipMemcpyAsync(B->d_bh.p, B->bh.data(), nh * sizeof(BeamHist), hipMemcpyHostToDevice, s));
+    // (a sweep batch has no visited sets and no growth pool of its own -- one-element stand-ins nobody reads: what the sweep hands
+    // to the depth-first search runs in scratch arenas, scratch_pass)
+    if (!B->sweep && (!use_epoch || B->epoch == 1u)) HIP_TRY(hipMemsetAsync(B->d_btab.p, 0, B->d_btab.bytes(), s));
+    if (!B->sweep) HIP_TRY(hipMemsetAsync(B->d_pool.p, 0, B->d_pool.bytes(), s));
+    if (!zero_block) {
+      HIP_TRY(hipMemsetAsync(B->d_pool_cursor.p, 0, sizeof(unsigned long long), s));
+      HIP_TRY(hipMemsetAsync(B->d_off.p, 0, B->d_off.bytes(), s));
+      HIP_TRY(hipMemsetAsync(B->d_ncr.p, 0, B->d_ncr.bytes(), s));
+    }
+    if (!fresh) HIP_TRY(hipMemcpyAsync(B->d_bh.p, B->bh.data(), nh * sizeof(BeamHist), hipMemcpyHostToDevice, s));
   } else {
     HIP_TRY(hipMemsetAsync(B->d_tab.p, 0, B->d_tab.bytes(), s));
   }
-  HIP_TRY(hipMemcpyAsync(B->d_hist.p, B->hist.data(), nh * sizeof(Hist), hipMemcpyHostToDevice, s));
+  if (!fresh) HIP_TRY(hipMemcpyAsync(B->d_hist.p, B->hist.data(), nh * sizeof(Hist), hipMemcpyHostToDevice, s));
   HIP_TRY(hipEventRecord(B->ev[1], s));
   TRACE("run: memsets queued");
   SYNC_TRACE("memsets");

@@ -169,6 +169,23 @@ void sweep_set_export(void* rel, uint32_t max_segs, uint32_t rank, uint32_t worl
  * its failing op and :configs.  Counters (levels' sizes, probes, sub-rounds) are the rule's own. */
 static uint32_t g_look = 0;
 void sweep_set_lookahead(uint32_t depth) { g_look = depth; }
+
+/* RELAXED sweep of a history with crashed (:info) calls (round 5; the refutation pass of the count form, DESIGN.md section 2.4, as a
+ * level sweep): every CLASS of crashed calls with the same effect -- (:write v), (:cas [a b]) with a != b on a cas-register -- is an
+ * unlimited supply from the moment its first member is invoked: it may take effect any number of times, at any later point.  That is a
+ * SUPERSET of the linearizations (each real crashed call takes effect at most once), so INVALID at completion t proves the history
+ * invalid with its first bad completion at t or earlier; VALID proves nothing.  In this reading a crashed call holds no process slot
+ * and no mask bit (live calls take re-used slots exactly as the count form numbers them: the lowest slot free when the process first
+ * invokes, a process that crashes hands its slot back), so a config is (mask over live slots, state) as in a crash-free history, every
+ * front with few open calls is a cut, and the history is swept by hundreds of wavefronts at once.  A class step changes the state and
+ * nothing else: with reach_F[s] = the states reachable from s through one or more steps of the classes available at front F (a
+ * transitive closure over at most 32 states), every set the sweep builds is CLOSED once, when it is complete, over the members it
+ * has then: for each member (mask, s) and each s' in reach_F[s] the sibling (mask + the open reads of s', s') joins -- the next level
+ * if it has the completing call linearized (a read of s' that the step made possible), the same set otherwise.  Closing once is
+ * enough because reach is transitive.  Sets closed: a slice's origins (front C_i), every sub-round set P_j (front F), every level
+ * F + 1 < R when it is complete (front F + 1).  Each sibling tried counts as a probe; level sizes are the closed sets'. */
+static uint32_t g_relaxed = 0;
+void sweep_set_relaxed(uint32_t on) { g_relaxed = on; }
 static _Thread_local uint64_t g_look_dropped = 0;
 uint64_t sweep_look_dropped(void) { return g_look_dropped; }
 
@@ -227,6 +244,26 @@ static void pass_level(const hist_t* H, cset* nxt, const uint64_t* key, orgset o
   cs_add(nxt, tmp, org);
 }
 
+/* RELAXED: close set S over its first n0 members at front F (see sweep_set_relaxed): reach[si] = the state indices reachable from
+ * state index si; a sibling that has the completing call px linearized passes into nxt when route_x is set */
+static void close_set(const hist_t* H, cset* S, size_t n0, cset* nxt, uint32_t F, int route_x, uint32_t px, const uint32_t* reach,
+                      uint32_t nd, const int32_t* dom, uint64_t* key, uint64_t* tmp, sweep_stats* st) {
+  for (size_t e = 0; e < n0; e++) {
+    const int32_t s = (int32_t)(uint32_t)(S->key[e * H->KW] >> 32);
+    const uint32_t si = s == O_NIL ? 0u : (uint32_t)(s + 1);
+    if (si >= nd) continue;
+    const orgset org = S->org[e];
+    for (uint32_t t = 0; t < nd; t++) if (t != si && (reach[si] >> t & 1u)) {
+      memcpy(key, S->key + e * H->KW, H->KW * 8);
+      key[0] = (uint64_t)(uint32_t)dom[t] << 32;
+      normalise(H, key, F);
+      st->probes++;
+      if (route_x && bit(key + 1, px)) pass_level(H, nxt, key, org, px, F, tmp);
+      else cs_add(S, key, org);
+    }
+  }
+}
+
 int sweep_ref_check(uint32_t n, const uint8_t* f, const int32_t* a, const int32_t* b,
                     const int32_t* process, uint32_t n_process,
                     const uint32_t* inv_pos, const uint32_t* ret_pos,
@@ -247,7 +284,6 @@ int sweep_ref_check(uint32_t n, const uint8_t* f, const int32_t* a, const int32_
   if (R == 0) { out->valid = 1; out->final_state = model->init; return 0; }
   hist_t H; H.n = n; H.R = R; H.W = n_process; H.MW = (n_process + 63) / 64; H.KW = 1 + H.MW;
   H.f = f; H.a = a; H.b = b; H.process = process; H.model = model;
-  const uint32_t KW = H.KW;
   posop* rets = (posop*)malloc(sizeof(posop) * R);
   H.ret_rank = (uint32_t*)malloc(4 * (size_t)n); H.inv_rank = (uint32_t*)malloc(4 * (size_t)n); H.ret_op = (uint32_t*)malloc(4 * (size_t)R);
   uint32_t k = 0;
@@ -257,11 +293,43 @@ int sweep_ref_check(uint32_t n, const uint8_t* f, const int32_t* a, const int32_
   { uint32_t r = 0;
     for (uint32_t i = 0; i < n; i++) { while (r < R && rets[r].pos < inv_pos[i]) r++; H.inv_rank[i] = r; } }
   for (uint32_t i = 0; i < n; i++) if (ret_pos[i] == O_CRASHED) H.ret_rank[i] = 0xFFFFFFFFu;
+  /* ---- RELAXED: re-used process slots for the live calls, the crashed calls as classes of effects (see sweep_set_relaxed) */
+  const int relaxed = g_relaxed && regfam;
+  int32_t* slot_arr = NULL;
+  uint32_t ncls = 0;
+  uint32_t *cls_f = NULL, *cls_from = NULL; int32_t *cls_a = NULL, *cls_b = NULL;
+  if (relaxed) {
+    slot_arr = (int32_t*)calloc((size_t)n + 1, 4);
+    int32_t* slot_of = (int32_t*)malloc(4 * ((size_t)n_process + 1));
+    uint8_t* used = (uint8_t*)calloc((size_t)n_process + 2, 1);
+    uint32_t W = 1;
+    for (uint32_t p = 0; p < n_process; p++) slot_of[p] = -1;
+    cls_f = (uint32_t*)malloc(4 * ((size_t)n + 1)); cls_from = (uint32_t*)malloc(4 * ((size_t)n + 1));
+    cls_a = (int32_t*)malloc(4 * ((size_t)n + 1)); cls_b = (int32_t*)malloc(4 * ((size_t)n + 1));
+    for (uint32_t i = 0; i < n; i++) {
+      const uint32_t p = (uint32_t)process[i];
+      if (ret_pos[i] == O_CRASHED) {
+        if (slot_of[p] >= 0) { used[slot_of[p]] = 0; slot_of[p] = -1; }
+        if (!(f[i] == O_WRITE || (f[i] == O_CAS && model->kind == O_CAS_REGISTER && a[i] != b[i]))) continue;
+        uint32_t c = 0;
+        while (c < ncls && !(cls_f[c] == f[i] && cls_a[c] == a[i] && (f[i] != O_CAS || cls_b[c] == b[i]))) c++;
+        if (c == ncls) { cls_f[c] = f[i]; cls_a[c] = a[i]; cls_b[c] = f[i] == O_CAS ? b[i] : 0; cls_from[c] = H.inv_rank[i]; ncls++; }
+        continue;
+      }
+      if (slot_of[p] < 0) { uint32_t s = 0; while (used[s]) s++; used[s] = 1; slot_of[p] = (int32_t)s; if (s + 1 > W) W = s + 1; }
+      slot_arr[i] = slot_of[p];
+    }
+    free(slot_of); free(used);
+    process = slot_arr; n_process = W;
+    H.process = process; H.W = W; H.MW = (W + 63) / 64; H.KW = 1 + H.MW;
+  }
+  const uint32_t KW = H.KW;
   H.off = (uint32_t*)calloc((size_t)R + 1, 4); H.ncr = (uint32_t*)calloc((size_t)R + 1, 4);
   uint32_t n_crashed = 0;
   const int eager_on = g_eager && regfam;
   for (uint32_t i = 0; i < n; i++) {
     if (H.ret_rank[i] == 0xFFFFFFFFu) {
+      if (relaxed) continue;                                          /* no slot, no list entry: a class */
       if (regfam && f[i] == O_READ && a[i] == O_NIL) continue;       /* crashed read: no effect, no constraint */
       n_crashed++; if (H.inv_rank[i] < R) H.ncr[H.inv_rank[i]]++; continue;
     }
@@ -275,7 +343,7 @@ int sweep_ref_check(uint32_t n, const uint8_t* f, const int32_t* a, const int32_
   H.crashed = (uint32_t*)malloc(4 * ((size_t)n_crashed + 1));
   { uint32_t c = 0;
     for (uint32_t i = 0; i < n; i++) {
-      if (H.ret_rank[i] == 0xFFFFFFFFu) { if (!(regfam && f[i] == O_READ && a[i] == O_NIL)) H.crashed[c++] = i; continue; }
+      if (H.ret_rank[i] == 0xFFFFFFFFu) { if (!relaxed && !(regfam && f[i] == O_READ && a[i] == O_NIL)) H.crashed[c++] = i; continue; }
       for (uint32_t fr = H.inv_rank[i]; fr <= H.ret_rank[i]; fr++) H.lst[fill[fr]++] = i;
     }
     for (uint32_t fr = 0; fr < R; fr++)          /* slot order */
@@ -316,6 +384,18 @@ int sweep_ref_check(uint32_t n, const uint8_t* f, const int32_t* a, const int32_
   dom[0] = O_NIL;
   for (uint32_t q = 1; q < nd; q++) dom[q] = (int32_t)q - 1;
 
+  /* RELAXED: reach[si] at a front = closure over the classes whose first member is invoked by then (they are in that order) */
+  uint32_t reach[32]; uint32_t reach_n = 0xFFFFFFFFu;
+  memset(reach, 0, sizeof reach);
+#define REACH_AT(F_) do { if (relaxed) { uint32_t na_ = 0; while (na_ < ncls && cls_from[na_] <= (F_)) na_++; \
+    if (na_ != reach_n) { reach_n = na_; memset(reach, 0, sizeof reach); \
+      for (int again_ = 1; again_; ) { again_ = 0; \
+        for (uint32_t si_ = 0; si_ < nd && si_ < 32; si_++) for (uint32_t c_ = 0; c_ < na_; c_++) { \
+          if (cls_f[c_] == O_CAS && dom[si_] != cls_a[c_]) continue; \
+          const int32_t tv_ = cls_f[c_] == O_WRITE ? cls_a[c_] : cls_b[c_]; \
+          const uint32_t ti_ = (uint32_t)(tv_ + 1); if (ti_ >= nd || ti_ >= 32) continue; \
+          const uint32_t add_ = (1u << ti_) | reach[ti_]; \
+          if ((reach[si_] | add_) != reach[si_]) { reach[si_] |= add_; again_ = 1; } } } } } } while (0)
   cset cur, nxt, pa, pb;
   cs_init(&cur, KW); cs_init(&nxt, KW); cs_init(&pa, KW); cs_init(&pb, KW);
   uint64_t* key = (uint64_t*)calloc(KW, 8); uint64_t* tmp = (uint64_t*)calloc(KW, 8);
@@ -362,6 +442,7 @@ int sweep_ref_check(uint32_t n, const uint8_t* f, const int32_t* a, const int32_
       if (cur.n == 0) continue;                                       /* the kernel's wavefront has nothing to sweep */
       st->n_waves++;
       const uint64_t probes_before = st->probes;
+      if (relaxed) { REACH_AT(F0); close_set(&H, &cur, cur.n, NULL, F0, 0, 0, reach, nd, dom, key, tmp, st); }
       uint64_t steps = 0, levels = 0;
       uint32_t last_level[32]; for (uint32_t q = 0; q < 32; q++) last_level[q] = F0;
       uint32_t M[32][SW_MAX_WORDS]; memset(M, 0, sizeof M);
@@ -410,8 +491,10 @@ int sweep_ref_check(uint32_t n, const uint8_t* f, const int32_t* a, const int32_
               else if (!is_dead(&H, key, F)) cs_add(Q, key, org);
             }
           }
+          if (relaxed) { REACH_AT(F); close_set(&H, Q, Q->n, &nxt, F, 1, px, reach, nd, dom, key, tmp, st); }
           { cset* t = P; P = Q; Q = t; }
         }
+        if (relaxed && F + 1 < R) { REACH_AT(F + 1); close_set(&H, &nxt, nxt.n, NULL, F + 1, 0, 0, reach, nd, dom, key, tmp, st); }
         st->levels++;
         st->configs_total += nxt.n;
         if (nxt.n > st->max_level) st->max_level = nxt.n;
@@ -481,5 +564,7 @@ int sweep_ref_check(uint32_t n, const uint8_t* f, const int32_t* a, const int32_
   cs_free(&cur); cs_free(&nxt); cs_free(&pa); cs_free(&pb);
   free(key); free(tmp); free(dom); free(cuts); free(cutk); free(rets); free(fill);
   free(H.ret_rank); free(H.inv_rank); free(H.ret_op); free(H.off); free(H.ncr); free(H.lst); free(H.crashed);
+  free(slot_arr); free(cls_f); free(cls_from); free(cls_a); free(cls_b);
+#undef REACH_AT
   return verdict == -2 ? 4 : verdict == -3 ? 5 : 0;
 }

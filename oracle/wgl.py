@@ -292,7 +292,7 @@ class SweepStats(C.Structure):
                 ("critical_steps", C.c_uint64), ("critical_levels", C.c_uint64), ("total_steps", C.c_uint64)]
 
 
-def check_sweep(ops, model, eager_reads=True, twin_rule=True, seg_target=0, max_cut_open=4, max_level=0, want_levels=False, n_dom=0):
+def check_sweep(ops, model, eager_reads=True, twin_rule=True, seg_target=0, max_cut_open=4, max_level=0, want_levels=False, n_dom=0, relaxed=False):
     """The segmented level sweep (sweep_ref.c): knossos.linear's just-in-time linearization with the
     dominance rules, cut into independently swept segments that are composed afterwards."""
     n = len(ops["f"])
@@ -309,10 +309,24 @@ def check_sweep(ops, model, eager_reads=True, twin_rule=True, seg_target=0, max_
     L.sweep_set_rules(C.c_uint32(1 if eager_reads else 0), C.c_uint32(1 if twin_rule else 0))
     L.sweep_set_segments(C.c_uint32(seg_target), C.c_uint32(max_cut_open))
     L.sweep_set_domain(C.c_uint32(n_dom))
-    rc = L.sweep_ref_check(C.c_uint32(n), _p(f, C.c_uint8), _p(a, C.c_int32), _p(b, C.c_int32),
+    # relaxed: crashed calls as classes of effects in unlimited supply (sweep_ref.c, sweep_set_relaxed): INVALID proves invalid at or before
+    # the completion it names, VALID proves nothing -- the refutation pass of the count form as a level sweep
+    L.sweep_set_relaxed(C.c_uint32(1 if relaxed else 0))
+    try:
+        rc = _sweep_call(L, n, f, a, b, proc, ops, inv, ret, m, max_level, lv, want_levels, res, st)
+    finally:
+        L.sweep_set_relaxed(C.c_uint32(0))
+    return _sweep_out(rc, res, st, lv, want_levels)
+
+
+def _sweep_call(L, n, f, a, b, proc, ops, inv, ret, m, max_level, lv, want_levels, res, st):
+    return L.sweep_ref_check(C.c_uint32(n), _p(f, C.c_uint8), _p(a, C.c_int32), _p(b, C.c_int32),
                            _p(proc, C.c_int32), C.c_uint32(int(ops["n_process"])), _p(inv, C.c_uint32),
                            _p(ret, C.c_uint32), C.byref(m), C.c_uint64(max_level),
                            _p(lv, C.c_uint32) if want_levels else None, C.byref(res), C.byref(st))
+
+
+def _sweep_out(rc, res, st, lv, want_levels):
     if rc != 0:
         raise ValueError(f"oracle rejected history (rc={rc})")
     out = {k: getattr(res, k) for k, _ in OracleResult._fields_}
