@@ -521,6 +521,7 @@ bool launch_sweep(const SweepArgs& a, void* stream) {
   // 2.48 -> 1.56 ms median, profiles/r04_sweep_wg_first_measurement.log)
   if (a.seg_list) {        // second pass over the segments that overflowed the small sets
     if (a.n_list <= 4096u && launch_sweep_wg(a, s)) return true;
+    if (a.reach_hdr) return false;          // (the relaxed sweep exists in the workgroup kernel only)
     if (!big_ok) return false;
     hipLaunchKernelGGL(jit_sweep_kernel<kBig>, dim3(a.n_list), dim3(64), sweep_lds_words<kBig>() * 4, s, a);
     return true;
@@ -529,6 +530,7 @@ bool launch_sweep(const SweepArgs& a, void* stream) {
   const uint32_t waves = a.n_hist * a.max_segs * kSweepSlices;
   // few wavefronts (a history or a handful through tbc_check): a workgroup per segment
   if (waves <= 4096u && launch_sweep_wg(a, s)) return true;
+  if (a.reach_hdr) return false;
   // a few histories: latency is what counts and the CUs are not full -- take the larger sets, so that a burst of
   // concurrency does not cost a second pass; many: four wavefronts per CU
   if (mid_ok && waves <= 4096u) hipLaunchKernelGGL(jit_sweep_kernel<kMid>, dim3(waves), dim3(64), sweep_lds_words<kMid>() * 4, s, a);

@@ -22,6 +22,24 @@ __global__ __launch_bounds__(64 * NW) void jit_sweep_wg_compact_kernel(SweepArgs
   sweepwg::segment<CAP, NW, true, true>(A, lds);
 }
 
+// the RELAXED sweep of a count-form history (jit_sweep_wg_impl.h, RLX): the plain walk over compound steps
+template <uint32_t CAP, uint32_t NW>
+__global__ __launch_bounds__(64 * NW) void jit_sweep_wg_relaxed_kernel(SweepArgs A) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  sweepwg::segment<CAP, NW, false, false, true>(A, lds);
+}
+
+template <uint32_t CAP, uint32_t NW>
+bool launch_relaxed(const SweepArgs& a, hipStream_t s) {
+  constexpr uint32_t bytes = sweepwg::lds_words<CAP, NW>() * 4;
+  static bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&jit_sweep_wg_relaxed_kernel<CAP, NW>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
+  if (!ok) return false;
+  const uint32_t groups = a.seg_list ? a.n_list : a.n_hist * a.max_segs * kSweepSlices;
+  hipLaunchKernelGGL((jit_sweep_wg_relaxed_kernel<CAP, NW>), dim3(groups), dim3(64 * NW), bytes, s, a);
+  return true;
+}
+
 template <uint32_t CAP, uint32_t NW>
 bool launch_one(const SweepArgs& a, hipStream_t s) {
   constexpr uint32_t bytes = sweepwg::lds_words<CAP, NW>() * 4;
@@ -53,6 +71,7 @@ bool launch_compact(const SweepArgs& a, hipStream_t s) {
 bool launch_sweep_wg(const SweepArgs& a, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (!(a.model_kind == TBC_MODEL_REGISTER || a.model_kind == TBC_MODEL_CAS_REGISTER) || a.dump_cfg) return false;
+  if (a.reach_hdr) return a.seg_list ? launch_relaxed<kSweepCapBig, 8>(a, s) : launch_relaxed<kSweepCapMid, 8>(a, s);
   if (a.seg_list) return launch_one<kSweepCapBig, 8>(a, s);
   return launch_compact<kSweepCapMid, 8>(a, s);
 }

@@ -273,9 +273,12 @@ template <> struct CompactState<true> { uint16_t* blk; uint32_t* scanw; uint32_t
 // the other 340 -- is run by wavefront 0 alone with wavefront barriers, the others waiting at ONE workgroup barrier for the new set
 // sizes (insert2_solo, solo_exchange): one workgroup barrier instead of three, and a probe loop that waits for the longest chain
 // of 64 lanes, not 512.
-template <uint32_t CAP, uint32_t NW, bool COMPACT = false, bool SOLO = false>
+// RLX (round 5): the RELAXED sweep of a history with crashed calls (reach_table.h; oracle/sweep_ref.c, sweep_set_relaxed): a sub-round's
+// pairs are COMPOUND steps -- a hop to a state the available classes reach, its open reads absorbed, then an open call (or nothing more)
+template <uint32_t CAP, uint32_t NW, bool COMPACT = false, bool SOLO = false, bool RLX = false>
 WV_DEV void segment(const SweepArgs& A, uint32_t* lds) {
   static_assert(!SOLO || (COMPACT && CAP < 0x10000u && Scratch<NW>::kBad + 5u <= Scratch<NW>::kWords), "solo passes: with the compact walk; two set sizes share a word");
+  static_assert(!RLX || (!COMPACT && !SOLO), "the relaxed sweep: the plain walk");
   static_assert(64 * NW >= kCand, "a level's open calls are parked one per thread");
   static_assert(64 * NW <= 1024 && CAP <= 0x8000u, "thread numbers and entry numbers share a table word");
   static_assert(64 * NW < CAP, "a pass's provisional claims on top of a full set must leave the table (2 x CAP slots) an empty slot");
@@ -334,6 +337,10 @@ WV_DEV void segment(const SweepArgs& A, uint32_t* lds) {
 
   uint32_t status = kSegOk;
   uint64_t configs_total = 0, probes = 0;                     // probes: this wavefront's (summed at the end)
+  // RLX: this history's reach table and the epoch of the current front
+  const uint32_t* rch = nullptr;
+  uint32_t n_ep = 0, ep = 0;
+  if constexpr (RLX) { const uint32_t* hd = A.reach_hdr + 2u * h; rch = A.reach + hd[0]; n_ep = hd[1]; }
   uint32_t subrounds = 0, max_level = 0, last_level = F0;     // last_level: thread o < 32 keeps origin o's
 
   // ---- per-front scalars, 64 fronts at a time: lane l of EVERY wavefront holds those of front wbase + l
@@ -482,8 +489,10 @@ WV_DEV void segment(const SweepArgs& A, uint32_t* lds) {
     }
     // sub-rounds: expand what still needs X, one (config, open call) pair per thread, 2^gshift pairs per config.  Children
     // that have X go to level F+1, the others to the next sub-round's set -- one probe loop for both.
-    uint32_t gshift = 0;
-    while ((1u << gshift) < C) gshift++;
+    uint32_t gshift = 0, ntm = 0;
+    if constexpr (RLX) { while (ep + 1u < n_ep && rch[ep + 1u] <= F) ep++; ntm = rch[n_ep + ep]; }
+    const uint32_t pairs = RLX ? (1u + ntm) * (C + 1u) : C;         // RLX: (no hop or the t-th reachable state) x (an open call or nothing more)
+    while ((1u << gshift) < pairs) gshift++;
     const Ent* src = cur.e;
     uint32_t n_src = n_exp;
     bool via_list = true;
@@ -586,17 +595,37 @@ WV_DEV void segment(const SweepArgs& A, uint32_t* lds) {
        } else {
         for (uint32_t base = 0; base < total && status == kSegOk; base += T) {
           const uint32_t r = base + tid, ci = r >> gshift, kc = r & ((1u << gshift) - 1u);
-          const bool val = r < total && kc < C;
+          bool val = r < total && kc < pairs;
           const Ent e = val ? src[via_list ? (uint32_t)expl[ci] : ci] : Ent{0, 0, 0, 0};
-          const OpRec y = val ? cand[kc] : OpRec{0, kFNone, 0, 0};
-          const uint64_t tw = val ? cand_tw[kc] : 0ull;
-          const uint64_t m = mask_of(e);
+          uint64_t m = mask_of(e);
+          int32_t st = (int32_t)e.st;
+          uint32_t yc = kc;
+          bool alone = false, hop = false;             // RLX: the hop with nothing behind it; a real hop
+          if constexpr (RLX) {
+            const uint32_t ti = kc / (C + 1u);
+            yc = kc - ti * (C + 1u);
+            alone = yc == C;
+            hop = ti != 0u;
+            if (ti != 0u) {                            // the ti-th state this one reaches
+              const uint32_t si = rdm_index(st, V);
+              uint32_t rr = val ? (rch[2u * n_ep + 32u * ep + si] & ~(1u << si)) : 0u;
+              val = val && (uint32_t)__builtin_popcount(rr) >= ti;
+              for (uint32_t q2 = 1; q2 < ti; q2++) rr &= rr - 1u;
+              const uint32_t t = rr ? (uint32_t)__builtin_ctz(rr) : 0u;
+              st = t == 0u ? TBC_NIL : (int32_t)t - 1;
+              const uint64_t m1 = eager ? (m | row_a[0] | row_a[t < V ? t : 0u]) : m;
+              if (alone) val = val && m1 != m;         // (alone it must have absorbed a read: every child has more calls linearized)
+              m = m1;
+            } else if (alone) val = false;
+          }
+          const OpRec y = (val && !alone) ? cand[yc] : OpRec{0, kFNone, 0, 0};
+          const uint64_t tw = (val && !alone) ? cand_tw[yc] : 0ull;
           const uint32_t yf = y.f_slot & 0xFFu, ys = (y.f_slot >> 8) & 63u;
-          const int32_t st = (int32_t)e.st;
-          const bool viable = val && !((m >> ys) & 1ull) && !(eager && yf == TBC_F_READ) && (tw & ~m) == 0ull && reg_ok(st, yf, y.a);
+          // (after a real hop only a :cas expecting the new state: the lazy rule -- a crashed call is worth a step only for a call that observes it)
+          const bool viable = alone ? val : (val && !((m >> ys) & 1ull) && !(eager && yf == TBC_F_READ) && !(hop && yf != TBC_F_CAS) && (tw & ~m) == 0ull && reg_ok(st, yf, y.a));
           probes += (uint64_t)__builtin_popcountll(wv::ballot(viable));
-          const int32_t st2 = viable ? reg_apply(st, yf, y.a, y.b) : st;
-          uint64_t m2 = m | (1ull << ys);
+          const int32_t st2 = (viable && !alone) ? reg_apply(st, yf, y.a, y.b) : st;
+          uint64_t m2 = alone ? m : (m | (1ull << ys));
           if (eager) m2 |= row_a[0] | row_a[rdm_index(st2, V)];
           const bool has = viable && (m2 & xbit) != 0ull;
           if (has) { m2 &= ~xbit; if (eager) m2 |= row_b[0] | row_b[rdm_index(st2, V)]; }

@@ -375,6 +375,11 @@ struct SweepArgs {
   uint32_t n_list, pad4;
   uint64_t* dump_cfg;        // records {front + 1 | state << 32, mask, TBC_NO_OP} as SearchArgs.cfg, kCfgCap at most
   uint32_t* dump_count;      // number of configs at that level (may exceed kCfgCap)
+  // the RELAXED sweep of a count-form history (reach_table.h; K6w only): crashed calls as classes in unlimited supply.  reach_hdr: two
+  // words per history {where its table starts in reach[], epochs}; null = the plain sweep.  (ncr must then be all zero: no crashed call
+  // is a candidate of its own.)
+  const uint32_t* reach;
+  const uint32_t* reach_hdr;
 };
 bool launch_sweep(const SweepArgs& a, void* stream);
 // K6w (jit_sweep_wg.hip): the first pass with `waves` (4 / 8) wavefronts per segment; false = not for this batch (the caller takes K6)

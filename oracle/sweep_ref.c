@@ -144,6 +144,7 @@ void sweep_set_domain(uint32_t n_dom) { g_n_dom = n_dom; }
 /* ids per segment's origin space: 128 = the kernel's (4 wavefronts of 32 origins per segment, tbc_sweep_rel's four words per origin);
  * up to 512 for design studies (cuts at fronts with more calls open: scripts/sweep_cut_study.py) -- no relation export then */
 #define SW_MAX_WORDS 16
+#define SW_MAX_KW 20          /* key words of a config: 1 + mask words (<= 1,216 process slots) */
 static uint32_t g_max_ids = 128;
 /* origins per wavefront ("slice"): 32 = the kernel's; fewer for design studies (no relation export then) */
 static uint32_t g_slice = 32, g_model_lanes = 64;
@@ -177,13 +178,16 @@ void sweep_set_lookahead(uint32_t depth) { g_look = depth; }
  * invalid with its first bad completion at t or earlier; VALID proves nothing.  In this reading a crashed call holds no process slot
  * and no mask bit (live calls take re-used slots exactly as the count form numbers them: the lowest slot free when the process first
  * invokes, a process that crashes hands its slot back), so a config is (mask over live slots, state) as in a crash-free history, every
- * front with few open calls is a cut, and the history is swept by hundreds of wavefronts at once.  A class step changes the state and
- * nothing else: with reach_F[s] = the states reachable from s through one or more steps of the classes available at front F (a
- * transitive closure over at most 32 states), every set the sweep builds is CLOSED once, when it is complete, over the members it
- * has then: for each member (mask, s) and each s' in reach_F[s] the sibling (mask + the open reads of s', s') joins -- the next level
- * if it has the completing call linearized (a read of s' that the step made possible), the same set otherwise.  Closing once is
- * enough because reach is transitive.  Sets closed: a slice's origins (front C_i), every sub-round set P_j (front F), every level
- * F + 1 < R when it is complete (front F + 1).  Each sibling tried counts as a probe; level sizes are the closed sets'. */
+ * front with few open calls is a cut, and the history is swept by hundreds of wavefronts at once.
+ * A class step changes the state and nothing else.  With reach_F[s] = the states reachable from s through one or more steps of the
+ * classes available at front F (a transitive closure over at most 32 states), the expansion of a config (mask, s) in a sub-round is over
+ * COMPOUND steps: a hop to a state s' in {s} + reach_F[s] (no hop, or class steps), the open reads of s' absorbed (eager rule), and then
+ * either an open live call y the state s' allows -- child = normal form of (mask + reads(s') + y, step(s', y)); after a real hop only
+ * a :cas expecting s' (the LAZY rule of the count form: a crashed call is worth linearizing only for a call that observes its value --
+ * one whose value is overwritten unobserved can be deleted from any linearization) -- or, after a real hop that absorbed at least
+ * one read, nothing more -- child = (mask + reads(s'), s').  Every child has strictly more calls linearized
+ * than its parent, so the sub-rounds end as they do without crashed calls, and no closure of whole sets is needed: class steps that
+ * nothing follows before a completion can be moved behind it.  A compound step whose parts are all allowed counts as one probe. */
 static uint32_t g_relaxed = 0;
 void sweep_set_relaxed(uint32_t on) { g_relaxed = on; }
 static _Thread_local uint64_t g_look_dropped = 0;
@@ -244,26 +248,6 @@ static void pass_level(const hist_t* H, cset* nxt, const uint64_t* key, orgset o
   cs_add(nxt, tmp, org);
 }
 
-/* RELAXED: close set S over its first n0 members at front F (see sweep_set_relaxed): reach[si] = the state indices reachable from
- * state index si; a sibling that has the completing call px linearized passes into nxt when route_x is set */
-static void close_set(const hist_t* H, cset* S, size_t n0, cset* nxt, uint32_t F, int route_x, uint32_t px, const uint32_t* reach,
-                      uint32_t nd, const int32_t* dom, uint64_t* key, uint64_t* tmp, sweep_stats* st) {
-  for (size_t e = 0; e < n0; e++) {
-    const int32_t s = (int32_t)(uint32_t)(S->key[e * H->KW] >> 32);
-    const uint32_t si = s == O_NIL ? 0u : (uint32_t)(s + 1);
-    if (si >= nd) continue;
-    const orgset org = S->org[e];
-    for (uint32_t t = 0; t < nd; t++) if (t != si && (reach[si] >> t & 1u)) {
-      memcpy(key, S->key + e * H->KW, H->KW * 8);
-      key[0] = (uint64_t)(uint32_t)dom[t] << 32;
-      normalise(H, key, F);
-      st->probes++;
-      if (route_x && bit(key + 1, px)) pass_level(H, nxt, key, org, px, F, tmp);
-      else cs_add(S, key, org);
-    }
-  }
-}
-
 int sweep_ref_check(uint32_t n, const uint8_t* f, const int32_t* a, const int32_t* b,
                     const int32_t* process, uint32_t n_process,
                     const uint32_t* inv_pos, const uint32_t* ret_pos,
@@ -322,6 +306,7 @@ int sweep_ref_check(uint32_t n, const uint8_t* f, const int32_t* a, const int32_
     free(slot_of); free(used);
     process = slot_arr; n_process = W;
     H.process = process; H.W = W; H.MW = (W + 63) / 64; H.KW = 1 + H.MW;
+    if (H.KW > SW_MAX_KW) { free(slot_arr); free(cls_f); free(cls_from); free(cls_a); free(cls_b); free(rets); free(H.ret_rank); free(H.inv_rank); free(H.ret_op); return 3; }
   }
   const uint32_t KW = H.KW;
   H.off = (uint32_t*)calloc((size_t)R + 1, 4); H.ncr = (uint32_t*)calloc((size_t)R + 1, 4);
@@ -442,7 +427,6 @@ int sweep_ref_check(uint32_t n, const uint8_t* f, const int32_t* a, const int32_
       if (cur.n == 0) continue;                                       /* the kernel's wavefront has nothing to sweep */
       st->n_waves++;
       const uint64_t probes_before = st->probes;
-      if (relaxed) { REACH_AT(F0); close_set(&H, &cur, cur.n, NULL, F0, 0, 0, reach, nd, dom, key, tmp, st); }
       uint64_t steps = 0, levels = 0;
       uint32_t last_level[32]; for (uint32_t q = 0; q < 32; q++) last_level[q] = F0;
       uint32_t M[32][SW_MAX_WORDS]; memset(M, 0, sizeof M);
@@ -463,7 +447,51 @@ int sweep_ref_check(uint32_t n, const uint8_t* f, const int32_t* a, const int32_
           { uint32_t gs = 0; while ((1u << gs) < tot) gs++; steps += (((uint64_t)P->n << gs) + g_model_lanes - 1) / g_model_lanes; }
           if (P->n > st->max_pending) st->max_pending = P->n;
           cs_clear(Q);
-          for (size_t e = 0; e < P->n; e++) {
+          if (relaxed) REACH_AT(F);
+          for (size_t e = 0; relaxed && e < P->n; e++) {             /* RELAXED: compound steps (see sweep_set_relaxed) */
+            const uint64_t* c = P->key + e * KW; const orgset org = P->org[e];
+            const int32_t s0 = (int32_t)(uint32_t)(c[0] >> 32);
+            const uint32_t si = s0 == O_NIL ? 0u : (uint32_t)(s0 + 1);
+            for (uint32_t t = 0; t < nd && t < 32; t++) {
+              const int hop = t != si;
+              if (hop && !(si < 32 && (reach[si] >> t & 1u))) continue;
+              const int32_t s1 = dom[t];
+              memcpy(key, c, KW * 8); key[0] = (uint64_t)(uint32_t)s1 << 32;
+              normalise(&H, key, F);                                  /* the open reads of s1 */
+              uint64_t base[SW_MAX_KW]; memcpy(base, key, KW * 8);
+              if (hop && memcmp(base + 1, c + 1, (KW - 1) * 8) != 0) {      /* the hop alone, if it absorbed a read */
+                st->probes++;
+                if (bit(base + 1, px)) pass_level(&H, &nxt, base, org, px, F, tmp);
+                else cs_add(Q, base, org);
+              }
+              for (uint32_t cc = 0; cc < nlive; cc++) {
+                const uint32_t y = H.lst[H.off[F] + cc], py = (uint32_t)process[y];
+                if (bit(base + 1, py)) continue;
+                if (eager_on && f[y] == O_READ) continue;
+                if (hop && f[y] != O_CAS) continue;                  /* the lazy rule: a hop is worth taking only for a call that observes s1 */
+                if (g_twin && (f[y] == O_WRITE || f[y] == O_CAS)) {
+                  int dominated = 0;
+                  for (uint32_t dd = 0; dd < nlive && !dominated; dd++) {
+                    const uint32_t z = H.lst[H.off[F] + dd];
+                    if (z == y || f[z] != f[y] || a[z] != a[y] || (f[y] == O_CAS && b[z] != b[y])) continue;
+                    if (bit(base + 1, (uint32_t)process[z])) continue;
+                    if (H.ret_rank[z] < H.ret_rank[y] || (H.ret_rank[z] == H.ret_rank[y] && z < y)) dominated = 1;
+                  }
+                  if (dominated) continue;
+                }
+                int32_t s2;
+                if (!oracle_step(model, s1, f[y], a[y], b[y], &s2)) continue;
+                st->probes++;
+                memcpy(key, base, KW * 8);
+                setb(key + 1, py);
+                key[0] = (uint64_t)(uint32_t)s2 << 32;
+                normalise(&H, key, F);
+                if (bit(key + 1, px)) pass_level(&H, &nxt, key, org, px, F, tmp);
+                else cs_add(Q, key, org);
+              }
+            }
+          }
+          for (size_t e = 0; !relaxed && e < P->n; e++) {
             const uint64_t* c = P->key + e * KW; const orgset org = P->org[e];
             const int32_t s0 = (int32_t)(uint32_t)(c[0] >> 32);
             for (uint32_t cc = 0; cc < tot; cc++) {
@@ -491,10 +519,8 @@ int sweep_ref_check(uint32_t n, const uint8_t* f, const int32_t* a, const int32_
               else if (!is_dead(&H, key, F)) cs_add(Q, key, org);
             }
           }
-          if (relaxed) { REACH_AT(F); close_set(&H, Q, Q->n, &nxt, F, 1, px, reach, nd, dom, key, tmp, st); }
           { cset* t = P; P = Q; Q = t; }
         }
-        if (relaxed && F + 1 < R) { REACH_AT(F + 1); close_set(&H, &nxt, nxt.n, NULL, F + 1, 0, 0, reach, nd, dom, key, tmp, st); }
         st->levels++;
         st->configs_total += nxt.n;
         if (nxt.n > st->max_level) st->max_level = nxt.n;

@@ -185,7 +185,8 @@ _LIB_SWEEP = None
 
 def build_sweep(force=False):
     srcs = [os.path.join(_HERE, "emu_sweep.cpp"), os.path.join(_HERE, "wave_env_emu.h"), os.path.join(_HERE, "wave_env_wg_emu.h"), os.path.join(_HERE, "host_tables.h"),
-            os.path.join(_CSRC, "jit_sweep_wg_impl.h"), os.path.join(_CSRC, "tbc_internal.h"), os.path.join(_CSRC, "wave_env.h"), os.path.join(_CSRC, "wave_env_wg.h")]
+            os.path.join(_CSRC, "jit_sweep_wg_impl.h"), os.path.join(_CSRC, "tbc_internal.h"), os.path.join(_CSRC, "wave_env.h"), os.path.join(_CSRC, "wave_env_wg.h"),
+            os.path.join(_CSRC, "reach_table.h")]
     if force or not os.path.exists(_SO_SWEEP) or any(os.path.getmtime(s) > os.path.getmtime(_SO_SWEEP) for s in srcs):
         os.makedirs(os.path.dirname(_SO_SWEEP), exist_ok=True)
         subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas"]
@@ -194,7 +195,7 @@ def build_sweep(force=False):
     return _SO_SWEEP
 
 
-def sweep_wg(ops, model_kind, init, seg_target, n_dom, max_segs, waves=8, cap=1024, rules=None, seed=1, rel_bytes=688, again=None, first=None, compact=False):
+def sweep_wg(ops, model_kind, init, seg_target, n_dom, max_segs, waves=8, cap=1024, rules=None, seed=1, rel_bytes=688, again=None, first=None, compact=False, relaxed=False):
     """ONE history through K6w: max_segs * 4 tbc_sweep_rel records as a uint8 array (as oracle.wgl.sweep_relations returns them).
     again = [(segment, slice), ...] with first = the first pass's records: the second pass over those segments only."""
     global _LIB_SWEEP
@@ -211,7 +212,7 @@ def sweep_wg(ops, model_kind, init, seg_target, n_dom, max_segs, waves=8, cap=10
     sl = None if again is None else np.ascontiguousarray([x for (k, j) in again for x in (0, k, j)], np.uint32)
     rc = _LIB_SWEEP.emu_sweep_wg_run(C.c_uint32(len(f)), C.c_uint32(int(d["n_process"])), _p(f, C.c_uint8), _p(a, C.c_int32), _p(b, C.c_int32), _p(pr, C.c_int32),
                                      _p(inv, C.c_uint32), _p(ret, C.c_uint32), C.c_uint32(model_kind), C.c_int32(init), C.c_uint32(vpad), C.c_uint32(r),
-                                     C.c_uint32(n_dom), C.c_uint32(seg_target), C.c_uint32(max_segs), C.c_uint32(waves), C.c_uint32(cap), C.c_uint32((4 if compact else 0) | (8 if compact == 2 else 0)), C.c_uint64(seed),      # compact=2: + solo passes
+                                     C.c_uint32(n_dom), C.c_uint32(seg_target), C.c_uint32(max_segs), C.c_uint32(waves), C.c_uint32(cap), C.c_uint32((4 if compact else 0) | (8 if compact == 2 else 0) | (16 if relaxed else 0)), C.c_uint64(seed),      # compact=2: + solo passes
                                      None if sl is None else _p(sl, C.c_uint32), C.c_uint32(0 if again is None else len(again)), buf.ctypes.data_as(C.c_void_p))
     if rc != 0:
         raise RuntimeError(f"emu_sweep_wg_run rc={rc}")

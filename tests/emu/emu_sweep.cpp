@@ -10,22 +10,23 @@
 using namespace tbc;
 
 #include "host_tables.h"
+#include "reach_table.h"
 
 namespace {
 
 struct Call { const SweepArgs* A; uint32_t* lds; };
-template <uint32_t CAP, uint32_t NW, bool COMPACT, bool SOLO>
+template <uint32_t CAP, uint32_t NW, bool COMPACT, bool SOLO, bool RLX>
 void entry(void* p, uint32_t) {
   auto* c = (Call*)p;
-  sweepwg::segment<CAP, NW, COMPACT, SOLO>(*c->A, c->lds);
+  sweepwg::segment<CAP, NW, COMPACT, SOLO, RLX>(*c->A, c->lds);
 }
-template <uint32_t CAP, uint32_t NW, bool COMPACT = false, bool SOLO = false>
+template <uint32_t CAP, uint32_t NW, bool COMPACT = false, bool SOLO = false, bool RLX = false>
 void run_all(const SweepArgs& A, uint32_t n_wg, uint64_t seed) {
   std::vector<uint32_t> lds(sweepwg::lds_words<CAP, NW, COMPACT>() + 16);
   for (uint32_t w = 0; w < n_wg; w++) {
     std::fill(lds.begin(), lds.end(), 0xDEADBEEFu);          // LDS is not zeroed on the device either
     Call c{&A, lds.data()};
-    wv::run_workgroup(&entry<CAP, NW, COMPACT, SOLO>, &c, (int)NW, w, seed + w);
+    wv::run_workgroup(&entry<CAP, NW, COMPACT, SOLO, RLX>, &c, (int)NW, w, seed + w);
   }
 }
 
@@ -43,7 +44,16 @@ int emu_sweep_wg_run(uint32_t n, uint32_t n_process, const uint8_t* f, const int
                      SegResult* out) {
   Tables T;
   const uint64_t op_off[2] = {0, n};
-  if (!build_tables(1, op_off, &n_process, f, a, b, process, inv_pos, ret_pos, 1, vpad, 1, false, false, T)) return 1;
+  // variant bit 4: the RELAXED sweep of a history with crashed calls -- the count form's tables (re-used slots, the crashed calls as classes),
+  // no crashed call a candidate of its own (ncr all zero), the reach table from the classes (csrc/reach_table.h, the library's own builder)
+  const bool relaxed = (queue & 16u) != 0u;
+  if (!build_tables(1, op_off, &n_process, f, a, b, process, inv_pos, ret_pos, 1, vpad, 1, false, false, T, relaxed)) return 1;
+  std::vector<uint32_t> reach, reach_hdr{0u, 0u};
+  if (relaxed) {
+    reach_hdr[1] = build_reach_table(T.cmem.data() + T.bh[0].cmem_off, T.bh[0].n_classes, reach);
+    std::fill(T.ncr.begin(), T.ncr.end(), 0u);
+  }
+  queue &= ~16u;
   const uint32_t R = T.hist[0].n_ret;
   // plain read-mask rows (what K5 / K6 read): vpad words per front
   const uint32_t FS = front_stride(vpad, 1);
@@ -75,6 +85,13 @@ int emu_sweep_wg_run(uint32_t n, uint32_t n_process, const uint8_t* f, const int
   A.cut_open = cut_open; A.n_dom = n_dom; A.vpad = vpad ? vpad : 1; A.rules = rules; A.model_kind = model_kind; A.init_state = init;
   A.shard_rank = 0; A.shard_world = 1; A.seg_list = seg_list; A.n_list = n_list; A.dump_cfg = nullptr; A.dump_count = nullptr;
   const uint32_t n_wg = seg_list ? n_list : max_segs * kSweepSlices;
+  if (relaxed) {
+    A.reach = reach.data(); A.reach_hdr = reach_hdr.data(); A.crashed = nullptr;
+#define RUNR(C_, W_) if (CAP == C_ && NW == W_ && !queue) { run_all<C_, W_, false, false, true>(A, n_wg, seed); return 0; }
+    RUNR(1024, 2) RUNR(1024, 8) RUNR(512, 4) RUNR(2048, 8)
+#undef RUNR
+    return 2;
+  }
 #define RUN(C_, W_) if (CAP == C_ && NW == W_ && !queue) { run_all<C_, W_>(A, n_wg, seed); return 0; }
   RUN(1024, 2) RUN(1024, 4) RUN(1024, 8) RUN(512, 4) RUN(2048, 8) RUN(2048, 16)
 #undef RUN

@@ -20,7 +20,7 @@ def _records(buf):
     return np.frombuffer(buf, dtype=np.uint8).reshape(-1, C.sizeof(N.SweepRel))
 
 
-def _compare(ops, seg_target, n_dom, waves, cap=1024, rules=None, seed=1, expect_overflow=False, second_pass=False, compact=False):
+def _compare(ops, seg_target, n_dom, waves, cap=1024, rules=None, seed=1, expect_overflow=False, second_pass=False, compact=False, relaxed=False):
     d = ops.as_dict()
     R = int((np.asarray(d["ret_pos"]) != 0xFFFFFFFF).sum())
     max_segs = max(1, min(512, (R + seg_target - 1) // seg_target)) if seg_target else 1
@@ -29,10 +29,10 @@ def _compare(ops, seg_target, n_dom, waves, cap=1024, rules=None, seed=1, expect
     buf = np.zeros(max_segs * 4 * C.sizeof(N.SweepRel), np.uint8)
     L.sweep_set_export(buf.ctypes.data_as(C.c_void_p), C.c_uint32(max_segs), C.c_uint32(0), C.c_uint32(1))
     try:
-        wgl.check_sweep(d, CAS, eager_reads=eager, twin_rule=twin, seg_target=seg_target, n_dom=n_dom)
+        wgl.check_sweep(d, CAS, eager_reads=eager, twin_rule=twin, seg_target=seg_target, n_dom=n_dom, relaxed=relaxed)
     finally:
         L.sweep_set_export(None, C.c_uint32(0), C.c_uint32(0), C.c_uint32(1))
-    got = emu.sweep_wg(d, 1, N.NIL, seg_target, n_dom, max_segs, waves=waves, cap=cap, rules=None if rules is None else (3 if rules else 0), seed=seed, compact=compact)
+    got = emu.sweep_wg(d, 1, N.NIL, seg_target, n_dom, max_segs, waves=waves, cap=cap, rules=None if rules is None else (3 if rules else 0), seed=seed, compact=compact, relaxed=relaxed)
     want = [N.SweepRel.from_buffer_copy(r.tobytes()) for r in _records(buf)]
     have = [N.SweepRel.from_buffer_copy(r.tobytes()) for r in _records(got)]
     if second_pass:      # the segments that overflowed, once more with sets of 2,048 configs and eight wavefronts (what launch_sweep does)
@@ -56,7 +56,7 @@ def _compare(ops, seg_target, n_dom, waves, cap=1024, rules=None, seed=1, expect
         assert list(g.last_level) == list(w.last_level), (i, "last levels")
     assert (overflowed > 0) == expect_overflow
     if not overflowed:      # the library's own composition (host code, no device) of K6w's records = the oracle's verdict
-        ref = wgl.check_sweep(d, CAS, eager_reads=eager, twin_rule=twin, seg_target=seg_target, n_dom=n_dom)
+        ref = wgl.check_sweep(d, CAS, eager_reads=eager, twin_rule=twin, seg_target=seg_target, n_dom=n_dom, relaxed=relaxed)
         v = N.SweepVerdict()
         recs = (N.SweepRel * len(have))(*have)
         assert N.lib().tbc_sweep_compose(recs, C.c_uint32(max_segs), C.c_uint32(R), C.byref(v)) == 0
@@ -90,7 +90,7 @@ def _compare_sample(ops, seg_target, n_dom, waves, cap=1024, seed=1, heavy=24, e
     buf = np.zeros(max_segs * 4 * C.sizeof(N.SweepRel), np.uint8)
     L.sweep_set_export(buf.ctypes.data_as(C.c_void_p), C.c_uint32(max_segs), C.c_uint32(0), C.c_uint32(1))
     try:
-        wgl.check_sweep(d, CAS, seg_target=seg_target, n_dom=n_dom)
+        wgl.check_sweep(d, CAS, seg_target=seg_target, n_dom=n_dom, relaxed=bool(form.get("relaxed")))
     finally:
         L.sweep_set_export(None, C.c_uint32(0), C.c_uint32(0), C.c_uint32(1))
     want = [N.SweepRel.from_buffer_copy(r.tobytes()) for r in _records(buf)]
@@ -100,14 +100,18 @@ def _compare_sample(ops, seg_target, n_dom, waves, cap=1024, seed=1, heavy=24, e
     got = emu.sweep_wg(d, 1, N.NIL, seg_target, n_dom, max_segs, waves=waves, cap=cap, seed=seed, again=[(i // 4, i % 4) for i in pick],
                        first=np.zeros_like(buf), **form)
     have = [N.SweepRel.from_buffer_copy(r.tobytes()) for r in _records(got)]
+    compared = 0
     for i in pick:
         w, g = want[i], have[i]
+        if g.status == 2 and form.get("relaxed"):          # (a relaxed burst that outgrows the sets: reported, the library's depth-first passes take the history)
+            continue
         assert g.status == w.status, (i, g.status, w.status)
         for k in ("F0", "F1", "max_level", "subrounds", "n_end", "configs_total", "probes"):
             assert getattr(g, k) == getattr(w, k), (i, k, getattr(g, k), getattr(w, k))
         assert [list(r) for r in g.M] == [list(r) for r in w.M], (i, "relation")
         assert list(g.last_level) == list(w.last_level), (i, "last levels")
-    return len(pick)
+        compared += 1
+    return compared
 
 
 def test_rules_off_and_one_segment():
@@ -209,3 +213,29 @@ def test_solo_passes_on_a_bench_history_and_overflow():
     assert _compare_sample(h, 32, 6, 8, compact=2) > 40
     h4 = synth.register_ops_many([4], n_ops=10000, n_procs=64, busy=0.1, info=0.0)[0]
     _compare(h4, 32, 6, 4, cap=512, expect_overflow=True, compact=2)
+
+
+# ---- the RELAXED sweep of a history with crashed calls (RLX; csrc/reach_table.h; oracle/sweep_ref.c sweep_set_relaxed): the crashed calls
+# as classes in unlimited supply, a sub-round's pairs compound steps -- every record of every workgroup against the oracle's
+def test_the_relaxed_sweep_every_record():
+    n = 0
+    for seed in range(6):
+        for corrupt in (0.0, 0.4):
+            for info in (0.05, 0.2):
+                h = columns.pair_events(synth.register_events(n_ops=300, n_procs=8, seed=300 + seed, busy=0.5, info=info, corrupt=corrupt))
+                n += _compare(h, 32, 6, (2, 8, 8)[seed % 3], seed=seed, relaxed=True)
+    assert n > 40
+    # two values, busy processes, many crashed writes: hops that absorb reads, chains of class steps
+    for seed in range(4):
+        h = columns.pair_events(synth.register_events(n_ops=200, n_procs=12, seed=400 + seed, busy=0.9, info=0.3, n_values=2, corrupt=0.3 * (seed % 2)))
+        _compare(h, 16, 4, 8, seed=seed, relaxed=True)
+    h = columns.pair_events(synth.register_events(n_ops=400, n_procs=8, seed=5, busy=0.6, info=0.1))
+    _compare(h, 0, 6, 8, seed=5, relaxed=True)                    # one segment
+    _compare(h, 32, 6, 4, cap=512, seed=6, relaxed=True)
+
+
+def test_the_relaxed_sweep_on_bench_tiers_and_the_second_pass():
+    """the bench's crashed-op tiers (10k ops, 1 % and 5 % crashed, one bad read planted): a sample of the workgroups, the bursts among them"""
+    for info, seed in ((0.01, 4242), (0.05, 4242)):
+        h = columns.pair_events(synth.register_events(n_ops=10000, n_procs=64, seed=seed, busy=0.1, info=info, corrupt=0.5))
+        assert _compare_sample(h, 32, 6, 8, cap=2048, relaxed=True) > 30
