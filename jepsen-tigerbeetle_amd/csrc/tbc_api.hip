@@ -15,6 +15,7 @@
 #include <thread>
 #include <vector>
 #include "tbc_internal.h"
+#include "reach_table.h"
 #include "witness_expand.h"
 
 using namespace tbc;
@@ -184,6 +185,8 @@ struct Ctx {
   size_t pin_cap = 0, pin_used = 0, pin_wanted = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev[6] = {};
+  hipStream_t stream2 = nullptr;      // the relaxed sweep beside the exact search (tbc_batch::rsweep), created when first wanted
+  hipEvent_t ev2[2] = {};
 };
 thread_local Ctx* t_ctx = nullptr;      // the context the calling thread's DevBufs draw from (tbc_check only)
 std::mutex g_ctx_mu;
@@ -262,12 +265,15 @@ void ctx_release(Ctx* c) {
   }
   c->used = 0; c->wanted = 0;
   if (c->pin_wanted > c->pin_cap && c->pin_wanted < (1ull << 30)) {
-    if (c->pin) (void)hipHostFree(c->pin);
+    if (c->pin) { (void)hipHostUnregister(c->pin); std::free(c->pin); }
     c->pin = nullptr; c->pin_cap = 0;
-    const size_t want = c->pin_wanted + c->pin_wanted / 4;
-    // (non-coherent = cached on the host: the composition reads the 0.6 MB relation table right after the copy -- through a coherent,
-    // uncached mapping that took 75 us instead of 25; the stream synchronize before it makes the copy visible)
-    if (hipHostMalloc((void**)&c->pin, want, hipHostMallocNonCoherent) == hipSuccess) c->pin_cap = want;
+    const size_t want = (c->pin_wanted + c->pin_wanted / 4 + 4095) & ~(size_t)4095;
+    // (ordinary cached memory, registered: the composition reads the 0.6 MB relation table right after the copy, and through
+    // hipHostMalloc's mapping -- coherent or "non-coherent" alike -- that took 78 us instead of 27; the stream synchronize before it
+    // makes the copy visible)
+    void* mem = std::aligned_alloc(4096, want);
+    if (mem && hipHostRegister(mem, want, hipHostRegisterDefault) == hipSuccess) { c->pin = (char*)mem; c->pin_cap = want; }
+    else std::free(mem);
   }
   c->pin_used = 0; c->pin_wanted = 0;
   std::lock_guard<std::mutex> lk(g_ctx_mu);
@@ -377,6 +383,14 @@ struct tbc_batch {
   DevBuf<uint32_t> d_cuts, d_seglist;
   DevBuf<SegResult> d_sres;
   HostBuf<SegResult> seg_host;
+  // the RELAXED sweep in front of a count-form search (round 5; oracle/sweep_ref.c sweep_set_relaxed, jit_sweep_wg_impl.h RLX): a handful
+  // of histories with crashed calls, nobody asking for a witness or a schedule -- every class of crashed calls an unlimited supply, so
+  // the sweep's cuts apply and an INVALID history is refuted by hundreds of wavefronts in milliseconds instead of by one wavefront's
+  // exhaustion of the relaxed config space (0.7 / 2.0 s on the bench's tiers); the prefix search then pins the failing completion as before
+  bool rsweep = false;
+  DevBuf<uint32_t> d_zncr, d_reach, d_reach_hdr, d_abort;
+  hipStream_t stream2 = nullptr;    // ... on a stream of its own, beside the exact search (the context's when borrowed)
+  hipEvent_t ev2[2] = {};
   uint32_t last_segments = 0, last_fallback = 0;
   uint32_t shard_rank = 0, shard_world = 1;      // tbc_batch_set_shard: this rank's share of the sweep's wavefronts
   bool partial_done = false;                     // a tbc_batch_sweep_partial is waiting for its tbc_batch_sweep_finish
@@ -415,6 +429,8 @@ struct tbc_batch {
     d_bitmap.release(); d_wpre.release(); d_frames.release(); d_witness.release(); d_work.release();
     d_queue.release(); d_tab.release(); d_results.release(); d_table.release(); d_pool_vals.release(); d_cfg.release();
     d_bh.release(); d_off.release(); d_ncr.release(); d_lst.release(); d_crashed.release(); d_stack.release();
+    d_zncr.release(); d_reach.release(); d_reach_hdr.release(); d_abort.release();
+    if (!borrowed) { for (auto& e : ev2) if (e) (void)hipEventDestroy(e); if (stream2) (void)hipStreamDestroy(stream2); }
     d_cmem.release(); d_occ.release(); d_btab.release(); d_slot8.release(); d_rk8.release(); d_look.release(); d_looktmp.release(); d_twn.release(); d_rdm.release(); d_cuts.release(); d_seglist.release(); d_sres.release(); d_dstack.release(); d_pool.release(); d_pool_cursor.release();
     if (ev_turn) (void)hipEventDestroy(ev_turn);
     if (!borrowed) {
@@ -563,6 +579,9 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
   }
   if (commutative && !(opts->dominance & TBC_DOM_NO_LAZY_COMMUTING)) B->rules |= kRuleLazyComm;
   B->width = width;
+  B->rsweep = B->count_form && !B->sweep && opts->algorithm == TBC_ALG_COMPETITION && !opts->want_witness && opts->search_width == 0 &&
+              opts->max_steps == 0 && nh <= 8 && (opts->lanes_per_history == 0 || opts->lanes_per_history == 64) && B->mask_words == 1 &&
+              width > 1 && width <= 16 && (model->kind == TBC_MODEL_REGISTER || model->kind == TBC_MODEL_CAS_REGISTER);
   B->lookahead = !B->sweep && width > 1 && width <= 16 && opts->lookahead != 1 &&
                  (model->kind == TBC_MODEL_REGISTER || model->kind == TBC_MODEL_CAS_REGISTER);
   const bool beam = width > 1;
@@ -631,7 +650,7 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
   // the frames arena is the pack kernels' scratch (3 words per op) and the sequential kernel's stack (4 + 2 mask words per op): a
   // wide-schedule batch only needs the former -- the rare history that falls back to the sequential kernel gets frames of its own then
   if (beam) B->frame_words = 3;
-  if (B->sweep) {
+  if (B->sweep || B->rsweep) {
     // segments: enough wavefronts to fill the GPU several times over, none shorter than 32 completions; cuts need the
     // register family's value domain (nil + 0..vmax = vpad's range) to enumerate the configs possible at a front
     uint64_t max_n = 1;
@@ -758,8 +777,20 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
     if ((!device_sizing && (s = B->d_lst.alloc(blst_n))) || (s = B->d_crashed.alloc((B->count_form || !B->any_crashed) ? 0 : T)) || (s = B->d_cmem.alloc(B->count_form ? bocc_n : 0)) ||
         (s = B->d_slot8.alloc(slot8_bytes(T, nh))) || (s = B->d_stack.alloc(bstack_n)) || (s = B->d_btab.alloc(btab_n * B->tab_stride())))
       return s;
-    if (B->sweep && ((s = B->d_cuts.alloc((uint64_t)nh * B->max_segs)) || (s = B->d_sres.alloc((uint64_t)nh * B->max_segs * kSweepSlices)) || (s = B->d_seglist.alloc((uint64_t)nh * B->max_segs * kSweepSlices * 3)))) return s;
-    if (B->sweep) B->seg_host.resize((size_t)nh * B->max_segs * kSweepSlices);
+    if ((B->sweep || B->rsweep) && ((s = B->d_cuts.alloc((uint64_t)nh * B->max_segs)) || (s = B->d_sres.alloc((uint64_t)nh * B->max_segs * kSweepSlices)) || (s = B->d_seglist.alloc((uint64_t)nh * B->max_segs * kSweepSlices * 3)))) return s;
+    if (B->sweep || B->rsweep) B->seg_host.resize((size_t)nh * B->max_segs * kSweepSlices);
+    if (B->rsweep) {          // no crashed call is a candidate of its own (a zero ncr[]); the classes' reach tables (reach_table.h)
+      std::vector<uint32_t> reach, hdr;
+      for (uint32_t h = 0; h < nh; h++) {
+        const CountHist& ch = B->count_hist[h];
+        hdr.push_back((uint32_t)reach.size());
+        hdr.push_back(build_reach_table(ch.words.data(), ch.n_classes, reach));
+      }
+      if ((s = B->d_zncr.alloc(boff_n)) || (s = B->d_reach.alloc(reach.size())) || (s = B->d_reach_hdr.alloc(hdr.size())) || (s = B->d_abort.alloc(nh))) return s;
+      HIP_TRY(hipMemset(B->d_zncr.p, 0, B->d_zncr.bytes()));
+      HIP_TRY(hipMemcpy(B->d_reach.p, reach.data(), reach.size() * 4, hipMemcpyHostToDevice));
+      HIP_TRY(hipMemcpy(B->d_reach_hdr.p, hdr.data(), hdr.size() * 4, hipMemcpyHostToDevice));
+    }
     if (B->lanes && (s = B->d_rk8.alloc(slot8_bytes(T, nh)))) return s;
     if (B->reg_rules() && ((!device_sizing && (s = B->d_twn.alloc(blst_n * B->mask_words))) || (s = B->d_rdm.alloc(B->lanes ? 1 : T * B->vpad * B->mask_words)))) return s;
     // several histories per wavefront: front records (tbc_internal.h) instead of plain rows, with or without the rules
@@ -801,9 +832,20 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
   if (t_ctx) {
     B->borrowed = true; B->stream = t_ctx->stream;
     for (int i = 0; i < 6; i++) B->ev[i] = t_ctx->ev[i];
+    if (B->rsweep) {
+      if (!t_ctx->stream2) {
+        HIP_TRY(hipStreamCreateWithFlags(&t_ctx->stream2, hipStreamNonBlocking));
+        for (auto& e : t_ctx->ev2) HIP_TRY(hipEventCreate(&e));
+      }
+      B->stream2 = t_ctx->stream2; B->ev2[0] = t_ctx->ev2[0]; B->ev2[1] = t_ctx->ev2[1];
+    }
   } else {
     HIP_TRY(hipStreamCreateWithFlags(&B->stream, hipStreamNonBlocking));
     for (auto& e : B->ev) HIP_TRY(hipEventCreate(&e));
+    if (B->rsweep) {
+      HIP_TRY(hipStreamCreateWithFlags(&B->stream2, hipStreamNonBlocking));
+      for (auto& e : B->ev2) HIP_TRY(hipEventCreate(&e));
+    }
   }
 
   TRACE("create: arenas allocated");
@@ -1197,7 +1239,7 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results, int phase = 
   // the prefix search below (a caller who names max_steps gets one exact pass under that limit instead)
   const uint64_t count_budget = (B->count_form && B->opts.max_steps == 0) ? 32ull * B->max_ops : 0ull;
   SweepArgs swa{};
-  if (B->sweep) {
+  if (B->sweep || B->rsweep) {
     swa.hist = B->d_hist.p; swa.bh = B->d_bh.p; swa.off = B->d_off.p; swa.ncr = B->d_ncr.p; swa.lst = B->d_lst.p;
     swa.crashed = B->d_crashed.p; swa.twn = B->reg_rules() ? B->d_twn.p : nullptr; swa.rdm = B->reg_rules() ? B->d_rdm.p : nullptr;
     swa.slot8 = B->d_slot8.p; swa.cuts = B->d_cuts.p; swa.seg = B->d_sres.p; swa.table = B->d_table.p;
@@ -1207,6 +1249,9 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results, int phase = 
     swa.n_classes = B->model.n_classes; swa.n_keys = B->model.n_keys;
     swa.shard_rank = 0; swa.shard_world = 1;
   }
+  // the relaxed sweep's verdicts: the completion rank at which history h is refuted (kInf: not refuted -- or not swept at all)
+  std::vector<uint32_t> rs_level(nh, kInf);
+  std::vector<uint8_t> rs_valid(nh, 0);          // ... and the histories it could not refute (VALID under the relaxation: the exact search just needs its time)
   if (phase != 2) {
 
   TRACE("run: begin");
@@ -1277,6 +1322,25 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results, int phase = 
   SYNC_TRACE("pack");
   HIP_TRY(hipEventRecord(B->ev[2], s));
 
+  // ---- the RELAXED sweep (see tbc_batch::rsweep) on a stream of its own, BESIDE the exact search: INVALID at completion t = invalid, first bad
+  // completion at t or earlier -- the history's exact search is told to stop (BeamArgs.abort) and the prefix search below pins the completion;
+  // VALID (or a burst that outgrows the sets) proves nothing and the exact search runs on as it always did, the sweep's 17 ms hidden behind it
+  const bool rs_on = B->rsweep && phase == 0 && beam && !B->lanes;
+  SweepArgs ra = swa;
+  if (rs_on) {
+    ra.ncr = B->d_zncr.p; ra.crashed = nullptr; ra.reach = B->d_reach.p; ra.reach_hdr = B->d_reach_hdr.p;
+    ra.rules = B->rules & (kRuleEager | kRuleTwin);
+    HIP_TRY(hipMemsetAsync(B->d_abort.p, 0, B->d_abort.bytes(), s));
+    HIP_TRY(hipEventRecord(B->ev2[0], s));                      // the pack's tables are complete, the abort words zero
+    HIP_TRY(hipStreamWaitEvent(B->stream2, B->ev2[0], 0));
+    hist_back.resize(nh);
+    if (launch_sweep(ra, B->stream2)) {
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipMemcpyAsync(B->seg_host.data(), B->d_sres.p, B->seg_host.size() * sizeof(SegResult), hipMemcpyDeviceToHost, B->stream2));
+      HIP_TRY(hipMemcpyAsync(hist_back.data(), B->d_hist.p, nh * sizeof(Hist), hipMemcpyDeviceToHost, B->stream2));
+    }
+  }
+
   if (B->sweep) {
     SweepArgs mine = swa;
     if (phase == 1 && B->shard_world > 1) {     // another rank's records must read as zero in the exchanged table
@@ -1287,6 +1351,7 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results, int phase = 
   } else if (beam) {
     BeamArgs ba = make_beam_args(B, B->d_btab.p, B->d_stack.p, B->d_dstack.p, nh);
     if (count_budget) ba.max_steps = count_budget;
+    if (rs_on) ba.abort = B->d_abort.p;
     if (B->lanes) { ba.tab_stride = B->tab_stride(); ba.epoch = use_epoch ? B->epoch : 0u; }
     if (B->lanes) {
       SearchTurn turn(B->device, s);        // one whole-GPU search at a time; another batch's pack runs beside it
@@ -1301,6 +1366,37 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results, int phase = 
   HIP_TRY(hipGetLastError());
   TRACE("run: search launched");
   SYNC_TRACE("search");
+  if (rs_on) {
+    // (the exact search is running; the sweep's relations arrive on the other stream)
+    HIP_TRY(hipStreamSynchronize(B->stream2));
+    const uint32_t SL = kSweepSlices;
+    std::vector<uint32_t> again;
+    for (uint32_t h = 0; h < nh; h++) if (hist_back[h].status == 0)
+      for (uint32_t k = 0; k < B->max_segs; k++) for (uint32_t j = 0; j < SL; j++)
+        if (B->seg_host[((size_t)h * B->max_segs + k) * SL + j].status == kSegOverflow) { again.push_back(h); again.push_back(k); again.push_back(j); }
+    if (!again.empty()) {          // the bursts that outgrew the first pass's sets: once more with the big ones
+      HIP_TRY(hipMemcpyAsync(B->d_seglist.p, again.data(), again.size() * 4, hipMemcpyHostToDevice, B->stream2));
+      SweepArgs r2 = ra;
+      r2.seg_list = B->d_seglist.p; r2.n_list = (uint32_t)(again.size() / 3);
+      if (launch_sweep(r2, B->stream2)) {
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(B->seg_host.data(), B->d_sres.p, B->seg_host.size() * sizeof(SegResult), hipMemcpyDeviceToHost, B->stream2));
+      }
+      HIP_TRY(hipStreamSynchronize(B->stream2));
+    }
+    static const uint32_t kOne = 1u;
+    for (uint32_t h = 0; h < nh; h++) {
+      if (hist_back[h].status != 0 || hist_back[h].n_ret == 0) continue;
+      tbc_sweep_verdict v{};
+      (void)tbc_sweep_compose(&B->seg_host[(size_t)h * B->max_segs * SL], B->max_segs, hist_back[h].n_ret, &v);
+      if (v.valid == TBC_INVALID) {
+        rs_level[h] = v.fail_level;
+        HIP_TRY(hipMemcpyAsync(B->d_abort.p + h, &kOne, 4, hipMemcpyHostToDevice, B->stream2));      // its exact search may stop
+      }
+      rs_valid[h] = v.valid == TBC_VALID;
+    }
+    TRACE("run: relaxed sweep composed");
+  }
   HIP_TRY(hipEventRecord(B->ev[3], s));
   if (!B->sweep) HIP_TRY(hipMemcpyAsync(B->res_host.data(), B->d_results.p, nh * sizeof(DevResult), hipMemcpyDeviceToHost, s));
   else HIP_TRY(hipMemcpyAsync(B->seg_host.data(), B->d_sres.p, B->seg_host.size() * sizeof(SegResult), hipMemcpyDeviceToHost, s));
@@ -1310,6 +1406,12 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results, int phase = 
   if (beam) HIP_TRY(hipMemcpyAsync(bh_back.data(), B->d_bh.p, nh * sizeof(BeamHist), hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   TRACE("run: first pass synced");
+  for (uint32_t h = 0; h < nh; h++) if (rs_level[h] != kInf) {      // refuted by the relaxed sweep: whatever its exact search got to before it was told to stop is dropped (the passes below, and their counters, are then the same run after run)
+    DevResult& d = B->res_host[h];
+    std::memset(&d, 0, sizeof d);
+    d.valid = TBC_UNKNOWN; d.cause = TBC_CAUSE_STEP_LIMIT; d.fail_op = TBC_NO_OP; d.prev_ok_op = TBC_NO_OP; d.final_state = B->model.init;
+    d.tab_log2 = B->bh[h].tab_log2;
+  }
   }   // phase != 2
   B->partial_done = phase == 1;
   if (phase == 1) return TBC_OK;
@@ -1516,9 +1618,23 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results, int phase = 
         return TBC_OK;
       };
       bank(pend);
-      tbc_status st = run_pass(pend, kCountRelaxed, nullptr);
+      // (what the relaxed SWEEP already decided is not searched again: refuted at a completion -> the prefix pass; valid under the
+      // relaxation -> the exact search without a budget; only the others -- no sweep, or a burst that outgrew its sets -- take the relaxed search)
+      std::vector<uint32_t> pend_dfs;
+      for (uint32_t h : pend) if (rs_level[h] == kInf && !rs_valid[h]) pend_dfs.push_back(h);
+      tbc_status st = pend_dfs.empty() ? TBC_OK : run_pass(pend_dfs, kCountRelaxed, nullptr);
       if (st != TBC_OK) return st;
-      bank(pend);
+      bank(pend_dfs);
+      for (uint32_t h : pend) {
+        DevResult& r = B->res_host[h];
+        if (rs_valid[h]) { r.valid = TBC_VALID; r.cause = TBC_CAUSE_NONE; }
+        if (rs_level[h] == kInf) continue;
+        const uint32_t t = rs_level[h], first = t ? t - 1 : 0;
+        uint32_t two[2] = {TBC_NO_OP, TBC_NO_OP};
+        HIP_TRY(hipMemcpy(two, B->d_ret_op.p + hist_back[h].ret_off + first, (t ? 2 : 1) * 4, hipMemcpyDeviceToHost));
+        r.valid = TBC_INVALID; r.cause = TBC_CAUSE_NONE; r.max_front = t; r.n_configs = 0;
+        r.fail_op = t ? two[1] : two[0]; r.prev_ok_op = t ? two[0] : TBC_NO_OP;
+      }
       std::vector<uint32_t> longer, prefix, targets;
       std::vector<DevResult> relaxed(nh);
       for (uint32_t h : pend) {

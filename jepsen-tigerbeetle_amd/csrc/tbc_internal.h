@@ -306,6 +306,9 @@ struct BeamArgs {
   uint64_t max_steps;
   uint64_t time_limit_ticks;
   uint32_t* dbg;
+  const uint32_t* abort;     // wide kernel, optional: one word per history that another stream may set while the search runs -- a history whose
+                             // word is set ends UNKNOWN / STEP_LIMIT at its next look at the clock (every 64th round): the relaxed sweep, running
+                             // beside the exact search of a count-form history, has refuted it and the prefix search takes over (tbc_api.hip)
   // growth pool: zeroed scratch a wavefront takes a 4x larger visited set + stack from when its own fills up
   uint64_t* pool;
   unsigned long long* pool_cursor;   // words handed out so far (zeroed before the launch)

@@ -847,6 +847,11 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
       if (verdict == -2 && limit && probes <= probe_room && (uint64_t)wall_clock64() - sld64(S, S_T0) > limit) {
         verdict = TBC_UNKNOWN; cause = TBC_CAUSE_TIME_LIMIT;
       }
+      // (BeamArgs.abort: somebody else has decided this history meanwhile -- read past the caches, it is written while the kernel runs)
+      const uint32_t* const ab = C->abort;
+      if (ab && verdict == -2 && __hip_atomic_load(ab + hidx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) {
+        verdict = TBC_UNKNOWN; cause = TBC_CAUSE_STEP_LIMIT;
+      }
     }
   }
   if (need_park && verdict == -2) {       // left to look at the totals: over the step limit?

@@ -445,7 +445,7 @@ def completion_rank(ops, op):
     return int((ret < ret[op]).sum())
 
 
-def check_count_pipeline(ops, model, width=4, budget=None, want_witness=False, round_pairs=64):
+def check_count_pipeline(ops, model, width=4, budget=None, want_witness=False, round_pairs=64, relaxed_sweep=False):
     """What the library does with a history in count form (tbc_api.hip, batch_run_impl), pass by pass over wgl_count.c: the exact
     search under a budget of probes (the library: 32 per op of the batch's longest history); past it the RELAXED search (every
     class an unlimited supply: a superset of the linearizations), whose INVALID verdict bounds the failing completion from above;
@@ -460,12 +460,33 @@ def check_count_pipeline(ops, model, width=4, budget=None, want_witness=False, r
         for k in tot:
             tot[k] += r[k]
         return r
+    # relaxed_sweep (the library for a handful of histories, nobody asking for a witness or a schedule: tbc_batch::rsweep): the RELAXED
+    # LEVEL SWEEP in front -- a refuted history goes straight to the prefix search (it is never searched exactly under a budget, nor
+    # relaxed depth-first), one it finds valid under the relaxation skips the relaxed depth-first search; the sweep's own probes are not
+    # in the sums (the library reports the depth-first passes' counters)
+    swept_valid = False
+    if relaxed_sweep:
+        if check_count(ops, model, width=width, want_witness=False, max_probes=1, round_pairs=round_pairs) is None:
+            return None
+        sw = check_sweep(ops, model, relaxed=True, seg_target=32)
+        if sw["valid"] == 0:
+            t = completion_rank(ops, sw["fail_op"])
+            if t == 0:
+                return 0, sw["fail_op"], sw, tot, "relaxed sweep"
+            g = add(check_count(ops, model, width=width, want_witness=False, target=t, round_pairs=round_pairs))
+            if g["valid"] == 1:
+                return 0, sw["fail_op"], g, tot, "relaxed sweep, prefix"
+            return g["valid"], g["fail_op"], g, tot, "relaxed sweep, prefix exhausted"
+        swept_valid = sw["valid"] == 1
     g = check_count(ops, model, width=width, want_witness=want_witness, max_probes=budget, round_pairs=round_pairs)
     if g is None:
         return None
     add(g)
     if g["valid"] != -1:
         return g["valid"], g["fail_op"], g, tot, "exact"
+    if swept_valid:
+        g = add(check_count(ops, model, width=width, want_witness=want_witness, round_pairs=round_pairs))
+        return g["valid"], g["fail_op"], g, tot, "exact, no budget"
     r = add(check_count(ops, model, width=width, want_witness=False, relaxed=True, round_pairs=round_pairs))
     if r["valid"] == 1:
         g = add(check_count(ops, model, width=width, want_witness=want_witness, round_pairs=round_pairs))

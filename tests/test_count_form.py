@@ -102,3 +102,31 @@ def test_the_bench_tiers_get_verdicts(native, oracle):
             assert how == ("prefix" if corrupt else "exact")
             if corrupt:
                 assert hh["a"][fo] == 12          # the planted value (n_values + 7)
+
+
+def test_the_pipeline_with_the_relaxed_sweep_in_front(native, oracle):
+    """check_count_pipeline(relaxed_sweep=True) -- the library's passes for a handful of histories -- gives the verdict and the failing op of
+    the pipeline without it and of the sequential restatement; the relaxed level sweep and the relaxed depth-first search are the same
+    relaxation (same verdict, same completion)."""
+    import random
+    rng = random.Random(7)
+    n = refuted = 0
+    for it in range(250):
+        d = columns.pair_events(synth.register_events(n_ops=rng.choice([10, 30, 60, 120]), n_procs=rng.choice([2, 4, 8]), seed=rng.randrange(10 ** 6),
+                                                      busy=rng.choice([0.3, 0.7, 1.0]), info=rng.choice([0.05, 0.15, 0.3, 0.5]), corrupt=rng.choice([0, 0.3, 0.7]),
+                                                      n_values=rng.choice([2, 5]))).as_dict()
+        a = oracle.check_count_pipeline(d, CAS, width=4, budget=rng.choice([1, 10, 100, None]), relaxed_sweep=True)
+        b = oracle.check_count_pipeline(d, CAS, width=4)
+        if a is None or b is None:
+            assert a is None and b is None
+            continue
+        ref = oracle.check(d, CAS, "window", max_steps=3_000_000, want_witness=False)
+        if ref["valid"] == -1:
+            continue
+        n += 1
+        assert (a[0], a[1] if a[0] == 0 else None) == (b[0], b[1] if b[0] == 0 else None) == (ref["valid"], ref["fail_op"] if ref["valid"] == 0 else None), (it, a[4], b[4])
+        refuted += a[4].startswith("relaxed sweep")
+        sw = oracle.check_sweep(d, CAS, relaxed=True, seg_target=rng.choice([0, 8, 32]))
+        rl = oracle.check_count(d, CAS, width=4, relaxed=True, want_witness=False)
+        assert (sw["valid"], sw["fail_op"] if sw["valid"] == 0 else None) == (rl["valid"], rl["fail_op"] if rl["valid"] == 0 else None), it
+    assert n > 150 and refuted > 50

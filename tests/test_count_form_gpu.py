@@ -71,13 +71,13 @@ def test_count_form_agrees_with_the_mask_form(native, oracle):
 @pytest.mark.parametrize("info,corrupt", [(0.01, 0.0), (0.01, 0.5), (0.05, 0.0), (0.05, 0.5)])
 def test_the_crashed_tiers_at_full_size(native, oracle, info, corrupt):
     """BASELINE.md section 3's crashed tiers, 10k ops / 64 processes: the library's default path (knossos.competition, no
-    witness) through tbc_check -- the budgeted exact search, then for the planted bad read the relaxed refutation and the
-    prefix search -- pass by pass against the oracle."""
+    witness) through tbc_check -- the relaxed level sweep, then the budgeted exact search or, for the planted bad read the sweep
+    refutes, the prefix search -- pass by pass against the oracle."""
     h = columns.pair_events(synth.register_events(n_ops=10000, n_procs=64, seed=4242, busy=0.1, info=info, corrupt=corrupt))
     g = core.check_ops(h, gm(), core.make_opts(time_limit_ms=60000, algorithm=N.ALG_COMPETITION, want_witness=False, count_form=True))
     width = g["search_width"]
-    v, fo, last, tot, how = oracle_pipeline(oracle, h.as_dict(), width)
-    assert how == ("prefix" if corrupt else "exact")
+    v, fo, last, tot, how = oracle.check_count_pipeline(h.as_dict(), CAS, width=width, relaxed_sweep=True)
+    assert how == ("relaxed sweep, prefix" if corrupt else "exact")
     assert g["valid"] == v == (0 if corrupt else 1)
     if corrupt:
         assert g["fail_op"] == fo and h.a[fo] == 12
@@ -137,3 +137,47 @@ def test_crash_heavy_edn_goldens_in_the_count_form(native, monkeypatch):
             assert a["op"]["index"] == c["op-index"], c["file"]
             n_invalid += 1
     assert n_invalid >= 3
+
+
+def test_relaxed_sweep_in_front_of_the_count_form_search(native, oracle):
+    """tbc_check / a handful of histories with crashed calls, knossos.competition, no witness, no schedule named: the RELAXED LEVEL SWEEP
+    runs first (tbc_batch::rsweep).  A history it refutes goes to the prefix search alone, one it finds valid under the relaxation
+    never takes the relaxed depth-first search: verdict, failing op and the depth-first passes' counters against the oracle's statement
+    of the same pipeline -- crash-heavy small histories one by one and eight to a batch, valid and with a planted bad read."""
+    hists = []
+    for n, p, busy, info, corrupt in [(300, 8, 0.3, 0.05, 0.0), (300, 8, 0.3, 0.05, 0.5), (1000, 16, 0.3, 0.03, 0.0), (1000, 16, 0.3, 0.03, 0.6), (2000, 64, 0.1, 0.02, 0.5),
+                                      (600, 4, 0.8, 0.2, 0.0), (600, 4, 0.8, 0.2, 0.7), (1500, 24, 0.25, 0.01, 0.3), (200, 12, 0.9, 0.3, 0.4)]:
+        for s in range(3):
+            h = columns.pair_events(synth.register_events(n_ops=n, n_procs=p, seed=5000 + s, busy=busy, info=info, corrupt=corrupt, n_values=2 if p == 12 else 5))
+            if h.n_process and oracle.check_count(h.as_dict(), CAS, width=4, max_probes=1) is not None:
+                hists.append(h)
+    assert len(hists) >= 24
+    opts = core.make_opts(time_limit_ms=60000, algorithm=N.ALG_COMPETITION, want_witness=False, count_form=True)
+    n_refuted = 0
+    for i, h in enumerate(hists):
+        g = core.check_ops(h, gm(), opts)
+        exp = oracle.check_count_pipeline(h.as_dict(), CAS, width=g["search_width"], relaxed_sweep=True)
+        if exp is None:
+            continue
+        v, fo, last, tot, how = exp
+        assert g["valid"] == v, (i, how)
+        if v == 0:
+            assert g["fail_op"] == fo, (i, how)
+        assert (g["probes"], g["visited"], g["backtracks"]) == (tot["probes"], tot["visited"], tot["expanded"]), (i, how)
+        n_refuted += how.startswith("relaxed sweep")
+        ref = oracle.check(h.as_dict(), CAS, "window", max_steps=5_000_000, want_witness=False)      # ... and the sequential restatement, whatever the passes
+        if ref["valid"] != -1:
+            assert (g["valid"], g["fail_op"] if v == 0 else None) == (ref["valid"], ref["fail_op"] if ref["valid"] == 0 else None), i
+    assert n_refuted >= 6
+    for lo in range(0, len(hists) - 7, 8):
+        group = hists[lo:lo + 8]
+        with core.Batch(group, gm(), opts) as b:
+            res = b.run().results()
+            again = b.run().results()
+        for h, g, g2 in zip(group, res, again):
+            exp = oracle.check_count_pipeline(h.as_dict(), CAS, width=g["search_width"], budget=32 * max(len(x) for x in group), relaxed_sweep=True)
+            if exp is None:
+                continue
+            assert (g["valid"], g["fail_op"] if exp[0] == 0 else None) == (exp[0], exp[1] if exp[0] == 0 else None), lo
+            assert (g["probes"], g["visited"]) == (exp[3]["probes"], exp[3]["visited"]), (lo, exp[4])
+            assert (g2["valid"], g2["probes"]) == (g["valid"], g["probes"])
