@@ -511,15 +511,17 @@ def main():
     seeds = shard.shard_indices(F * B * world, rank, world)      # history i of the job lives on rank i % world
     hists_all = [synth.register_ops_many(seeds[k * B:(k + 1) * B], n_ops=args.ops, n_procs=args.procs, busy=args.busy, info=args.info) for k in range(F)]
     # every resident batch carries ONE history with a planted bad read (its last): a verdict mix-up cannot hide behind "all valid".
-    # The read is planted 2 % into the history: an INVALID verdict means exhausting the configs up to the failing completion, and one
-    # in the middle of a 10k-op history costs 9x a valid history's search -- the slowest history of a batch is the batch's step
-    # (planted in the middle: 284 ms per step instead of 127, profiles/r04_bench_planted_in_the_middle.json.log)
-    # -- and it reads the value 4 in a history that only ever writes 0..3: impossible, and inside the batch's value domain (the
-    # generator's own planted value, 12, would widen every front record of the batch from 64 to 160 bytes: another kernel instantiation)
+    # The read is planted ANYWHERE in the history (round 5; rounds 3-4 planted it 2 % in: an INVALID verdict means exhausting the configs up
+    # to the failing completion, nine times a valid history's search from the middle of a 10k-op history, and the slowest history of a
+    # batch is the batch's step -- 284 ms instead of 127, profiles/r04_bench_planted_in_the_middle.json.log).  The library now stops a
+    # history that no longer passes completions and hands it to the level sweep (tbc_opts.dominance, TBC_DOM_NO_STALL_HANDOVER = off).
+    # It reads the value 4 in a history that only ever writes 0..3: impossible, and inside the batch's value domain (the generator's
+    # own planted value, 12, would widen every front record of the batch from 64 to 160 bytes: another kernel instantiation)
     planted = B - 1
     for k in range(F):
+        where = 0.1 + 0.8 * ((int(seeds[k * B + planted]) * 2654435761) % 1000) / 1000.0          # anywhere between 10 % and 90 % of the history, by the seed
         hp = columns.pair_events(synth.register_events(n_ops=args.ops, n_procs=args.procs, seed=int(seeds[k * B + planted]), busy=args.busy,
-                                                       info=args.info, corrupt=0.02, n_values=4))
+                                                       info=args.info, corrupt=where, n_values=4))
         assert int((hp.a == 4 + 7).sum()) == 1
         hp.a[hp.a == 4 + 7] = 4
         hists_all[k][planted] = hp

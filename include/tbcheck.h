@@ -265,7 +265,14 @@ enum { TBC_DOM_NO_EAGER_READS = 1u, TBC_DOM_NO_TWIN_RULE = 2u,
         * not yet linearized read could take it (set: a read whose value contains the element -- a crashed add no read ever contains
         * is never linearized; bank: a read with a value).  The config space is then no longer 2^(open or crashed mutating calls):
         * a 10k-op set history with 98 crashed adds needs 1.9 * 10^4 probes where the plain search gives up past 2 * 10^7.  Set = off. */
-       TBC_DOM_NO_LAZY_COMMUTING = 8u };
+       TBC_DOM_NO_LAZY_COMMUTING = 8u,
+       /* STALL HANDOVER (a big quiet batch of register / cas-register histories, several to a wavefront, nobody asking for a witness or
+        * naming a step limit): a history whose search has not passed a completion for 512 rounds -- it is not linearizable, or in a
+        * burst of concurrency -- is stopped and checked again by the level sweep in a small batch of its own (milliseconds instead of
+        * holding the whole pass for nine times a valid history's search).  Verdict and failing op are the same either way; the counters
+        * of such a history are the stopped search's plus the sweep's, tbc_result.analyzer says who answered.  Set = every history is
+        * searched to its end by the schedule the batch runs (what the oracle's schedule counts). */
+       TBC_DOM_NO_STALL_HANDOVER = 16u };
 
 /* ------------------------------------------------------------------ result */
 enum { TBC_VALID = 1, TBC_INVALID = 0, TBC_UNKNOWN = -1 };

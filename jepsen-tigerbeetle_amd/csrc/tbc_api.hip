@@ -1226,6 +1226,76 @@ uint32_t narrow_waves_per_simd() {
 }
 }  // namespace
 
+// Histories of a narrow-kernel batch that stopped because they no longer passed completions (BeamArgs.stall_checks) are checked again as
+// a small batch of their own -- knossos.competition without a witness, i.e. the level sweep (what it cannot finish: the wide search) --
+// from their op columns as they lie in HBM.  A history stalls when it is NOT linearizable (the search is exhausting the configs in front
+// of the completion nobody can pass: nine times a valid history's search for a bad read in the middle of a 10k-op history, and a pass is
+// as long as its slowest history) or, rarely, in a burst of concurrency; the sweep decides either in milliseconds.
+// How long is "no longer"?  A VALID history stalls too, in a burst of concurrency: of 24 bench histories under the emulator 3 stop at 8 looks at
+// the clock (512 rounds), 2 at 16, none at 32 -- and a valid history that is stopped has lost its search.  48 looks (3,072 rounds, ~40 ms,
+// two thirds of a whole valid search) is past every burst seen; a bad read in the middle of a history then holds its pass for 40 ms
+// instead of 450.
+static const uint32_t kStallChecks = 48;
+static tbc_status hand_over_stalled(tbc_batch* B, const std::vector<uint32_t>& list, std::vector<tbc_result>& out) {
+  Ctx* const saved = t_ctx;
+  t_ctx = nullptr;                               // (the inner batch owns its arenas, stream and events)
+  tbc_status st = TBC_OK;
+  const size_t chunk = list.size() <= 8 ? 1 : 256;          // (a few: one at a time through tbc_check's persistent contexts -- no allocation, ~2 ms each)
+  for (size_t lo = 0; lo < list.size() && st == TBC_OK; lo += chunk) {
+    const size_t hi = std::min(list.size(), lo + chunk);
+    const uint32_t k = (uint32_t)(hi - lo);
+    std::vector<uint64_t> off(k + 1, 0);
+    std::vector<uint32_t> nev(k), npr(k);
+    std::vector<int32_t> aux(k);
+    for (uint32_t i = 0; i < k; i++) {
+      const Hist& H = B->hist[list[lo + i]];
+      off[i + 1] = off[i] + H.n_ops; nev[i] = H.n_events; npr[i] = H.n_slots; aux[i] = H.aux;
+    }
+    const uint64_t T = off[k];
+    std::vector<uint8_t> f(T + 1);
+    std::vector<int32_t> a(T + 1), b(T + 1), pr(T + 1);
+    std::vector<uint32_t> inv(T + 1), ret(T + 1);
+    for (uint32_t i = 0; i < k; i++) {
+      const Hist& H = B->hist[list[lo + i]];
+      const uint64_t n = H.n_ops, o = off[i], s0 = H.op_off;
+      if (!n) continue;
+      HIP_TRY(hipMemcpy(f.data() + o, B->d_f.p + s0, n, hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpy(a.data() + o, B->d_a.p + s0, n * 4, hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpy(b.data() + o, B->d_b.p + s0, n * 4, hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpy(pr.data() + o, B->d_proc.p + s0, n * 4, hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpy(inv.data() + o, B->d_inv.p + s0, n * 4, hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpy(ret.data() + o, B->d_ret.p + s0, n * 4, hipMemcpyDeviceToHost));
+    }
+    tbc_batch_desc d{};
+    d.n_hist = k; d.op_off = off.data(); d.n_events = nev.data(); d.n_process = npr.data(); d.model_aux = aux.data();
+    d.cols.n = (uint32_t)T; d.cols.f = f.data(); d.cols.a = a.data(); d.cols.b = b.data(); d.cols.process = pr.data();
+    d.cols.inv_pos = inv.data(); d.cols.ret_pos = ret.data();
+    tbc_opts o = B->opts;
+    o.algorithm = TBC_ALG_COMPETITION; o.want_witness = 0; o.search_width = 0; o.lanes_per_history = 0; o.round_budget = 0; o.max_steps = 0;
+    o.visited_per_op = 0; o.list_order = TBC_ORDER_DEFAULT;
+    if (chunk == 1) {
+      tbc_ops one = d.cols;
+      one.n = (uint32_t)T; one.n_events = nev[0]; one.n_process = npr[0];
+      tbc_model m1 = B->model;
+      m1.init = aux[0];
+      tbc_result r1;
+      st = tbc_check(&one, &m1, &o, &r1);
+      if (st == TBC_OK) { out[list[lo]] = r1; out[list[lo]].witness = nullptr; tbc_result_free(&r1); }
+      continue;
+    }
+    tbc_batch* I = nullptr;
+    st = tbc_batch_create(&d, &B->model, &o, &I);
+    if (st == TBC_OK) {
+      std::vector<tbc_result> res(k);
+      st = tbc_batch_run(I, res.data());
+      for (uint32_t i = 0; i < k && st == TBC_OK; i++) { out[list[lo + i]] = res[i]; out[list[lo + i]].witness = nullptr; }
+      tbc_batch_destroy(I);
+    }
+  }
+  t_ctx = saved;
+  return st;
+}
+
 static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results, int phase = 0) {
   HIP_TRY(hipSetDevice(B->device));
   const uint64_t t_start = now_ns();
@@ -1249,6 +1319,12 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results, int phase = 
     swa.n_classes = B->model.n_classes; swa.n_keys = B->model.n_keys;
     swa.shard_rank = 0; swa.shard_world = 1;
   }
+  // a big quiet batch (several histories per wavefront): a history that stops passing completions is handed to the level sweep
+  // (hand_over_stalled) -- where that can answer: register / cas-register, one mask word, nobody asking for a witness or naming a step limit
+  const bool stall_on = B->lanes != 0 && !(B->opts.dominance & TBC_DOM_NO_STALL_HANDOVER) && !B->count_form && B->mask_words == 1 && !B->opts.want_witness && B->opts.max_steps == 0 && phase == 0 &&
+                        (B->model.kind == TBC_MODEL_REGISTER || B->model.kind == TBC_MODEL_CAS_REGISTER) && B->vpad != 0;
+  std::vector<tbc_result> handed;
+  std::vector<uint8_t> was_handed(nh, 0);
   // the relaxed sweep's verdicts: the completion rank at which history h is refuted (kInf: not refuted -- or not swept at all)
   std::vector<uint32_t> rs_level(nh, kInf);
   std::vector<uint8_t> rs_valid(nh, 0);          // ... and the histories it could not refute (VALID under the relaxation: the exact search just needs its time)
@@ -1353,6 +1429,7 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results, int phase = 
     if (count_budget) ba.max_steps = count_budget;
     if (rs_on) ba.abort = B->d_abort.p;
     if (B->lanes) { ba.tab_stride = B->tab_stride(); ba.epoch = use_epoch ? B->epoch : 0u; }
+    if (stall_on) ba.stall_checks = kStallChecks;
     if (B->lanes) {
       SearchTurn turn(B->device, s);        // one whole-GPU search at a time; another batch's pack runs beside it
       if (!B->ev_turn) HIP_TRY(hipEventCreate(&B->ev_turn));
@@ -1566,6 +1643,18 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results, int phase = 
       }
     }
   }
+  if (stall_on) {
+    std::vector<uint32_t> stalled;
+    for (uint32_t h = 0; h < nh; h++)
+      if (!is_seq[h] && hist_back[h].status == 0 && B->res_host[h].valid == TBC_UNKNOWN && B->res_host[h].cause == TBC_CAUSE_STEP_LIMIT) stalled.push_back(h);
+    if (!stalled.empty()) {
+      handed.resize(nh);
+      tbc_status st = hand_over_stalled(B, stalled, handed);
+      if (st != TBC_OK) return st;
+      for (uint32_t h : stalled) was_handed[h] = 1;
+      HIP_TRY(hipSetDevice(B->device));
+    }
+  }
   // ---- count form: the histories the budgeted exact search left undecided (oracle/wgl_count.c; tests/test_count_form.py states the
   // same pipeline over the oracle).  (1) The RELAXED search -- every class of crashed calls an unlimited supply, counts ignored: a
   // superset of the linearizations over a config space no larger than a crash-free history's -- either finds a linearization (then
@@ -1708,6 +1797,18 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results, int phase = 
     if (hist_back[h].status != 0 && worst == TBC_OK) {
       worst = (tbc_status)hist_back[h].status;
       set_error("history %u rejected by the pack kernel: %s", h, tbc_strerror((int)hist_back[h].status));
+    }
+    if (was_handed[h]) {          // answered by the small batch it was handed to: its result, the first pass's counters added
+      const tbc_result& g = handed[h];
+      B->sum.steps += g.counters.steps; B->sum.visited += g.counters.visited; B->sum.probes += g.counters.probes; B->sum.backtracks += g.counters.backtracks;
+      if (results) {
+        tbc_result& r = results[h];
+        r = g;
+        r.counters.steps += d.steps; r.counters.visited += d.visited; r.counters.probes += d.probes; r.counters.backtracks += d.backtracks;
+        r.counters.max_depth = std::max<uint64_t>(r.counters.max_depth, d.max_depth);
+        r.counters.ns_pack = B->timing_ns[1]; r.counters.ns_search = B->timing_ns[2] + B->timing_ns[3]; r.counters.ns_total = t_end - t_start;
+      }
+      continue;
     }
     if (!results) continue;
     tbc_result& r = results[h];

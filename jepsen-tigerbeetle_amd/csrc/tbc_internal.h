@@ -306,6 +306,10 @@ struct BeamArgs {
   uint64_t max_steps;
   uint64_t time_limit_ticks;
   uint32_t* dbg;
+  uint32_t stall_checks;     // narrow kernel, 0 = off: a history whose greatest front has not moved over this many looks at the clock (one every 64
+  uint32_t pad_stall;        // rounds) ends UNKNOWN / STEP_LIMIT -- a valid history at this concurrency passes a completion nearly every round, one that
+                             // stalls is exhausting the configs in front of a completion nobody can pass: the library hands it to the level
+                             // sweep (tbc_api.hip, hand_over_stalled), which refutes it in milliseconds instead of holding the pass for ten passes' time
   const uint32_t* abort;     // wide kernel, optional: one word per history that another stream may set while the search runs -- a history whose
                              // word is set ends UNKNOWN / STEP_LIMIT at its next look at the clock (every 64th round): the relaxed sweep, running
                              // beside the exact search of a count-form history, has refuted it and the prefix search takes over (tbc_api.hip)

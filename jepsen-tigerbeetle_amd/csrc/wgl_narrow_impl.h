@@ -38,6 +38,8 @@ enum : uint32_t { F_ACTIVE = 1u, F_NEED_POP = 2u, F_LOOK = 4u, F_NEED_GROW = 8u,
 enum : uint32_t {
   G_DSTACK = 0, G_PROBES = 2, G_EXPANDED = 4, G_ROUNDS = 6, G_VERDICT = 8, G_CAUSE = 9, G_MAXF = 10, G_MAXSP = 11,
   G_WINPAR = 12, G_WINOP = 13, G_WINSTATE = 14,
+  G_STALLF = 15,    // BeamArgs.stall_checks: the greatest front at the last look at the clock ...
+  G_STALLN = 55,    // ... and for how many looks it has not moved
   G_T0 = 52,        // 2 words: when the history was taken up (time limit)
   G_NEXT = 54,      // the work item a finished group takes next
   G_PF = 16,        // 4 words: front, list offset, live and all open calls of the child whose candidates are fetched ahead
@@ -309,6 +311,7 @@ WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* ld
         GS[G_VERDICT] = (uint32_t)verdict0; GS[G_CAUSE] = (uint32_t)TBC_CAUSE_NONE; GS[G_MAXF] = f0 < R ? f0 : 0u; GS[G_MAXSP] = sp;
         GS[G_WINPAR] = kNone; GS[G_WINOP] = kNone; GS[G_WINSTATE] = (uint32_t)A.init_state;
         GS[G_T0] = (uint32_t)t0; GS[G_T0 + 1] = (uint32_t)(t0 >> 32);
+        GS[G_STALLF] = f0 < R ? f0 : 0u; GS[G_STALLN] = 0u;
       }
     }
     for (uint32_t i = li; i < RS; i += L) r_pos[i] = kNone;
@@ -949,6 +952,17 @@ WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* ld
       if (limit && (flags & F_ACTIVE) && wv::clock100mhz() - ((uint64_t)GS[G_T0] | ((uint64_t)GS[G_T0 + 1] << 32)) > limit) {
         flags &= ~F_ACTIVE;
         if (li == 0) { GS[G_VERDICT] = (uint32_t)TBC_UNKNOWN; GS[G_CAUSE] = (uint32_t)TBC_CAUSE_TIME_LIMIT; }
+      }
+      const uint32_t stall = C->stall_checks;
+      if (stall) {                                     // a history that no longer passes completions (BeamArgs.stall_checks)
+        const uint32_t mf = GS[G_MAXF];
+        const uint32_t sn = GS[G_STALLF] == mf ? GS[G_STALLN] + 1u : 0u;
+        wv::barrier();                                 // (every lane of the group has read the two words)
+        if (li == 0) { GS[G_STALLF] = mf; GS[G_STALLN] = sn; }
+        if (sn >= stall && (flags & F_ACTIVE)) {
+          flags &= ~F_ACTIVE;
+          if (li == 0) { GS[G_VERDICT] = (uint32_t)TBC_UNKNOWN; GS[G_CAUSE] = (uint32_t)TBC_CAUSE_STEP_LIMIT; }
+        }
       }
     }
   }

@@ -134,7 +134,7 @@ def rules_for(hists, model_kind, init, nil=-(2 ** 31)):
     return 3, vpad
 
 
-def run(hists, model_kind, init, L, rules=None, lookahead=True, entries_per_op=8, max_steps=0, pool_words=0, want_witness=True, max_waves=0, branch_lists=True, compact=True, epochs=0, count=False, relaxed=False, targets=None, mw=None, by_ret=False):
+def run(hists, model_kind, init, L, rules=None, lookahead=True, entries_per_op=8, max_steps=0, pool_words=0, want_witness=True, max_waves=0, branch_lists=True, compact=True, epochs=0, count=False, relaxed=False, targets=None, mw=None, by_ret=False, stall=0):
     """hists: list of op-column dicts (f,a,b,process,inv_pos,ret_pos,n_process).  Returns one result dict per history."""
     ds = [h if isinstance(h, dict) else h.as_dict() for h in hists]
     nh = len(ds)
@@ -161,7 +161,7 @@ def run(hists, model_kind, init, L, rules=None, lookahead=True, entries_per_op=8
     rc = lib().emu_narrow_run(C.c_uint32(nh), _p(op_off, C.c_uint64), _p(npr, C.c_uint32), _p(f, C.c_uint8), _p(a, C.c_int32), _p(b, C.c_int32),
                               _p(pr, C.c_int32), _p(inv, C.c_uint32), _p(ret, C.c_uint32), C.c_uint32(model_kind), C.c_int32(init),
                               C.c_uint32(L), C.c_uint32(mw), C.c_uint32(r), C.c_uint32(vpad), C.c_uint32(1 if look else 0),
-                              C.c_uint32(entries_per_op), C.c_uint64(max_steps), C.c_uint64(pool_words), C.c_uint32(1 if want_witness else 0), C.c_uint32(max_waves), C.c_uint32((1 if compact else 0) | ((int(by_ret) << 16) if int(by_ret) >= 16 else 16 if by_ret == 2 else 4 if by_ret else 0)), C.c_uint32(epochs), C.c_uint32(1 if count else 0), C.c_uint32(1 if relaxed else 0),
+                              C.c_uint32(entries_per_op), C.c_uint64(max_steps), C.c_uint64(pool_words), C.c_uint32(1 if want_witness else 0), C.c_uint32(max_waves), C.c_uint32((1 if compact else 0) | (int(stall) << 8) | ((int(by_ret) << 16) if int(by_ret) >= 16 else 16 if by_ret == 2 else 4 if by_ret else 0)), C.c_uint32(epochs), C.c_uint32(1 if count else 0), C.c_uint32(1 if relaxed else 0),
                               _p(np.ascontiguousarray(targets, np.uint32), C.c_uint32) if targets is not None else None,
                               res, _p(wit, C.c_uint32), _p(cfg, C.c_uint64))
     if rc != 0:

@@ -107,6 +107,7 @@ int emu_narrow_run(uint32_t nh, const uint64_t* op_off, const uint32_t* n_proces
   A.init_state = init; A.width = 1; A.tab_stride = EW; A.cmem = T.cmem.empty() ? nullptr : T.cmem.data(); A.count_mode = relaxed ? kCountRelaxed : kCountExact; A.max_steps = max_steps; A.time_limit_ticks = 0; A.dbg = nullptr;
   A.pool = pool_words ? pool.data() : nullptr; A.pool_cursor = &cursor; A.pool_words = pool_words; A.max_tab_log2 = 28;
   A.pool_vals = nullptr; A.cfg = cfg.data(); A.rules = rules; A.twn = (rules & kRuleTwin) ? T.twn.data() : nullptr;
+  A.stall_checks = (want_compact >> 8) & 0xFFu;          // want_compact bits 8..15: BeamArgs.stall_checks (a history that stops passing completions is stopped)
   A.rdm = T.rdm.data(); A.vpad = vpad; A.rk8 = T.rk8.data(); A.front_words = compact ? kFrontCompactWords : front_stride(vpad, MW);
 #define RUN(MWV, LV) if (MW == MWV && L == LV) { run_all<MWV, LV>(A, max_waves); ran = true; }
   bool ran = false;
