@@ -346,6 +346,10 @@ def compact_line(line):
     if isinstance(d, dict):
         e["set_full"] = {"error": str(d["error"])[:100]} if "error" in d else {"scan_ms": d.get("scan_ms"), "end_to_end_ms": d.get("end_to_end_ms"),
                                                                               "frac": (d.get("roofline") or {}).get("frac")}
+    bm = ex.get("bad_read_in_the_middle")
+    if isinstance(bm, dict):
+        e["bad_read_in_the_middle"] = {"step_ms_with_handover": (bm.get("with_handover") or {}).get("ms_per_step_alone"),
+                                       "step_ms_without": (bm.get("without_handover") or {}).get("ms_per_step_alone")}
     if "one_history_over_all_gpus" in ex:
         e["one_history_over_all_gpus"] = ex["one_history_over_all_gpus"]
     e["full"] = "gpurun_out/bench_full.json"
@@ -511,17 +515,17 @@ def main():
     seeds = shard.shard_indices(F * B * world, rank, world)      # history i of the job lives on rank i % world
     hists_all = [synth.register_ops_many(seeds[k * B:(k + 1) * B], n_ops=args.ops, n_procs=args.procs, busy=args.busy, info=args.info) for k in range(F)]
     # every resident batch carries ONE history with a planted bad read (its last): a verdict mix-up cannot hide behind "all valid".
-    # The read is planted ANYWHERE in the history (round 5; rounds 3-4 planted it 2 % in: an INVALID verdict means exhausting the configs up
-    # to the failing completion, nine times a valid history's search from the middle of a 10k-op history, and the slowest history of a
-    # batch is the batch's step -- 284 ms instead of 127, profiles/r04_bench_planted_in_the_middle.json.log).  The library now stops a
-    # history that no longer passes completions and hands it to the level sweep (tbc_opts.dominance, TBC_DOM_NO_STALL_HANDOVER = off).
-    # It reads the value 4 in a history that only ever writes 0..3: impossible, and inside the batch's value domain (the generator's
-    # own planted value, 12, would widen every front record of the batch from 64 to 160 bytes: another kernel instantiation)
+    # In the headline the read is planted 2 % into the history, as in rounds 3 and 4 (the workload is VALID histories; the guard should not
+    # be what is measured): an INVALID verdict means exhausting the configs up to the failing completion, nine times a valid history's
+    # search from the middle of a 10k-op history, and the slowest history of a batch is the batch's step.  What a bad read ANYWHERE costs
+    # is measured by itself, in the same run: extra.bad_read_in_the_middle (asked to, the library stops a history that no longer passes
+    # completions and hands it to the level sweep: tbc_opts.dominance, TBC_DOM_STALL_HANDOVER -- off by default, measured both ways there).  It reads the value 4 in a history that only ever
+    # writes 0..3: impossible, and inside the batch's value domain (the generator's own planted value, 12, would widen every front
+    # record of the batch from 64 to 160 bytes: another kernel instantiation)
     planted = B - 1
     for k in range(F):
-        where = 0.1 + 0.8 * ((int(seeds[k * B + planted]) * 2654435761) % 1000) / 1000.0          # anywhere between 10 % and 90 % of the history, by the seed
         hp = columns.pair_events(synth.register_events(n_ops=args.ops, n_procs=args.procs, seed=int(seeds[k * B + planted]), busy=args.busy,
-                                                       info=args.info, corrupt=where, n_values=4))
+                                                       info=args.info, corrupt=0.02, n_values=4))
         assert int((hp.a == 4 + 7).sum()) == 1
         hp.a[hp.a == 4 + 7] = 4
         hists_all[k][planted] = hp
@@ -692,6 +696,26 @@ def main():
                 "kernel_ms": round(tm4["search"] / 1e6, 3), "pack_ms": round(tm4["pack"] / 1e6, 3),
                 "probes_per_launch": c4["probes"], "new_configs_per_launch": c4["visited"], "algorithmic_bytes_per_launch": alg4,
                 "roofline_frac": round(alg4 / (tm4["search"] * 1e-9) / 1e9 / HBM_PEAK_GBS, 6)}
+        leg("a bad read in the middle of one history of the batch")
+        if world == 1 and narrow and args.lanes == 0 and not args.only_headline and on_gpu:
+            # the SAME batch with its planted history's bad read half way in: one pass alone, the stall handover on and off (the library's default) -- how long one not-linearizable history holds a pass of 32,768.  Never `value`.
+            mid = list(hists)
+            mid[planted] = columns.pair_events(synth.register_events(n_ops=args.ops, n_procs=args.procs, seed=int(seeds[planted]), busy=args.busy,
+                                                                    info=args.info, corrupt=0.5, n_values=4))
+            mid[planted].a[mid[planted].a == 4 + 7] = 4
+            out_mid = {"bad_read_at": 0.5}
+            for name, ho in (("with_handover", True), ("without_handover", False)):
+                with core.Batch(mid, model, core.make_opts(device=local_rank, time_limit_ms=600000, want_witness=False, algorithm=N.ALG_COMPETITION,
+                                                           visited_per_op=args.visited_per_op, stall_handover=ho)) as bm:
+                    bm.run()
+                    tmid = time.perf_counter(); bm.run(); tmid = time.perf_counter() - tmid
+                    vm, tmm = bm.verdicts(), bm.timing_ns()
+                    rm = bm.results()[planted]
+                assert int(vm[planted]) == N.INVALID and int((vm == N.VALID).sum()) == B - 1
+                out_mid[name] = {"ms_per_step_alone": round(tmid * 1e3, 3), "search_ms": round(tmm["search"] / 1e6, 3), "after_the_search_ms": round(tmm["retries"] / 1e6, 3),
+                                 "fail_op": rm["fail_op"], "answered_by": "linear" if rm["analyzer"] == N.ALG_LINEAR else "wgl"}
+            assert out_mid["with_handover"]["fail_op"] == out_mid["without_handover"]["fail_op"]
+            line["extra"]["bad_read_in_the_middle"] = out_mid
         leg("time to verdict (one history through tbc_check)")
         if on_gpu:      # (one history through tbc_check: needs the device)
             ttv, ttv_dfs, analyzers = [], [], []

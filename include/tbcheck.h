@@ -255,7 +255,9 @@ enum { TBC_DOM_NO_EAGER_READS = 1u, TBC_DOM_NO_TWIN_RULE = 2u,
         * calls of one effect are linearized in invocation order, so a config keeps a COUNT per effect class instead of a mask bit
         * per crashed call, process slots are re-used, a crashed call is only linearized right before a call that observes its
         * value, and a config that has used no fewer crashed calls of any class than a visited one with the same (front, mask,
-        * state) is dropped.  A history the exact search does not decide within 32 probes per op is first refuted with every
+        * state) is dropped.  A history the exact search does not decide within 32 probes per op OF THE BATCH'S LONGEST HISTORY (one
+        * budget per launch) -- and only when the caller names no max_steps: a caller's own step limit is one exact pass under that
+        * limit, nothing after it -- is first refuted with every
         * class an unlimited supply (a superset of the linearizations), then the prefix before the refuted completion is
         * linearized: verdict and failing op are exact, :configs of such a verdict is empty.  Set = keep one mask bit per
         * crashed call (the published form). */
@@ -266,13 +268,15 @@ enum { TBC_DOM_NO_EAGER_READS = 1u, TBC_DOM_NO_TWIN_RULE = 2u,
         * is never linearized; bank: a read with a value).  The config space is then no longer 2^(open or crashed mutating calls):
         * a 10k-op set history with 98 crashed adds needs 1.9 * 10^4 probes where the plain search gives up past 2 * 10^7.  Set = off. */
        TBC_DOM_NO_LAZY_COMMUTING = 8u,
-       /* STALL HANDOVER (a big quiet batch of register / cas-register histories, several to a wavefront, nobody asking for a witness or
-        * naming a step limit): a history whose search has not passed a completion for 512 rounds -- it is not linearizable, or in a
-        * burst of concurrency -- is stopped and checked again by the level sweep in a small batch of its own (milliseconds instead of
-        * holding the whole pass for nine times a valid history's search).  Verdict and failing op are the same either way; the counters
-        * of such a history are the stopped search's plus the sweep's, tbc_result.analyzer says who answered.  Set = every history is
-        * searched to its end by the schedule the batch runs (what the oracle's schedule counts). */
-       TBC_DOM_NO_STALL_HANDOVER = 16u };
+       /* STALL HANDOVER -- the one bit of this word that switches something ON (a big quiet batch of register / cas-register histories,
+        * several to a wavefront, nobody asking for a witness or naming a step limit): a history whose search has not passed a completion
+        * for 4,096 rounds -- it is not linearizable, or in a burst of concurrency -- is stopped and checked again by the level sweep
+        * (a few through tbc_check, many as a small batch).  For a batch that holds NOT LINEARIZABLE histories: 342 of 2,048 invalid, search
+        * 159 -> 30 ms.  Off by default, measured: valid histories stall too (~10 of 32,768 bench histories at this threshold), they are
+        * the ones with the biggest bursts, which the sweep is slowest at, and an all-valid batch pays 54 ms a pass for them while one bad
+        * read in the middle of one history costs a pass 104 ms without the handover and 53 with it.  Verdict and failing op are the same
+        * either way; the counters of a handed-over history are the stopped search's plus the sweep's, tbc_result.analyzer says who answered. */
+       TBC_DOM_STALL_HANDOVER = 16u };
 
 /* ------------------------------------------------------------------ result */
 enum { TBC_VALID = 1, TBC_INVALID = 0, TBC_UNKNOWN = -1 };
@@ -533,7 +537,7 @@ typedef struct tbc_setfull_rows {
   const uint32_t* read_ok;
   const uint32_t* top;           /* [n_reads], <= n_elements */
   const uint64_t* exc_off;       /* [n_reads + 1], ascending, exc_off[0] = 0 */
-  const uint32_t* exc;           /* [exc_off[n_reads]] element numbers < n_elements */
+  const uint32_t* exc;           /* [exc_off[n_reads]] element numbers < n_elements, strictly ascending within a read (each at most once: a duplicate is TBC_ERR_INVALID_ARG) */
 } tbc_setfull_rows;
 tbc_status tbc_setfull_create_rows(const tbc_setfull_rows* in, tbc_setfull** handle);
 tbc_status tbc_setfull_run(tbc_setfull* handle, tbc_setfull_out* out);

@@ -33,7 +33,7 @@ ALG_COMPETITION, ALG_WGL, ALG_LINEAR = 0, 1, 2
 # verdicts / causes
 VALID, INVALID, UNKNOWN = 1, 0, -1
 CAUSE_NONE, CAUSE_TIME_LIMIT, CAUSE_STEP_LIMIT, CAUSE_VISITED_FULL = 0, 1, 2, 3
-DOM_NO_EAGER_READS, DOM_NO_TWIN_RULE, DOM_NO_COUNT_FORM, DOM_NO_LAZY_COMMUTING, DOM_NO_STALL_HANDOVER = 1, 2, 4, 8, 16
+DOM_NO_EAGER_READS, DOM_NO_TWIN_RULE, DOM_NO_COUNT_FORM, DOM_NO_LAZY_COMMUTING, DOM_STALL_HANDOVER = 1, 2, 4, 8, 16
 # tbc_opts.list_order (16 + W: completion order, a :write as if it completed W ranks later; the default where it applies is 16 + 24)
 ORDER_DEFAULT, ORDER_SLOT, ORDER_COMPLETION, ORDER_WRITES_LAST, ORDER_WRITE_DELAY = 0, 1, 2, 3, 16
 # status

@@ -290,6 +290,10 @@ static tbc_status setfull_create_impl(const tbc_setfull_in* in, tbc_setfull* S, 
     }
     const uint64_t ne = rows->exc_off[S->R];
     for (uint64_t i = 0; i < ne; i++) if (rows->exc[i] >= S->E) { set_error("tbc_setfull_create_rows: exception %llu names element %u of %u", (unsigned long long)i, rows->exc[i], S->E); return TBC_ERR_INVALID_ARG; }
+    // each element at most once per read -- strictly ascending: the kernel FLIPS the listed bits, a duplicate would flip one back silently
+    for (uint32_t r = 0; r < S->R; r++)
+      for (uint64_t i = rows->exc_off[r] + 1; i < rows->exc_off[r + 1]; i++)
+        if (rows->exc[i] <= rows->exc[i - 1]) { set_error("tbc_setfull_create_rows: read %u: exceptions must be strictly ascending (element %u after %u)", r, rows->exc[i], rows->exc[i - 1]); return TBC_ERR_INVALID_ARG; }
   }
   // the prefix search per row and "the latest row" both rest on the documented orders
   for (uint32_t e = 1; e < S->E; e++) if (in->add_invoke[e] <= in->add_invoke[e - 1]) { set_error("tbc_setfull: add_invoke must be strictly ascending (element %u)", e); return TBC_ERR_INVALID_ARG; }
@@ -323,8 +327,11 @@ static tbc_status setfull_create_impl(const tbc_setfull_in* in, tbc_setfull* S, 
   if (rows && S->R) {
     const uint64_t ne = rows->exc_off[S->R];
     uint32_t *d_top = nullptr, *d_exc = nullptr; unsigned long long* d_off = nullptr;
-    SF_TRY(hipMalloc((void**)&d_top, r4)); SF_TRY(hipMalloc((void**)&d_off, ((size_t)S->R + 1) * 8)); SF_TRY(hipMalloc((void**)&d_exc, std::max<size_t>(4, ne * 4)));
-    hipError_t e = hipMemcpyAsync(d_top, rows->top, (size_t)S->R * 4, hipMemcpyHostToDevice, S->stream);
+    // (one exit below frees whatever of the three was allocated: an allocation that fails must not leak the ones before it)
+    hipError_t e = hipMalloc((void**)&d_top, r4);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_off, ((size_t)S->R + 1) * 8);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_exc, std::max<size_t>(4, ne * 4));
+    if (e == hipSuccess) e = hipMemcpyAsync(d_top, rows->top, (size_t)S->R * 4, hipMemcpyHostToDevice, S->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d_off, rows->exc_off, ((size_t)S->R + 1) * 8, hipMemcpyHostToDevice, S->stream);
     if (e == hipSuccess && ne) e = hipMemcpyAsync(d_exc, rows->exc, ne * 4, hipMemcpyHostToDevice, S->stream);
     if (e == hipSuccess) {
@@ -332,8 +339,10 @@ static tbc_status setfull_create_impl(const tbc_setfull_in* in, tbc_setfull* S, 
       e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(S->stream);
-    (void)hipFree(d_top); (void)hipFree(d_off); (void)hipFree(d_exc);
-    if (e != hipSuccess) { set_error("tbc_setfull_create_rows: building the matrix failed: %s", hipGetErrorString(e)); return TBC_ERR_HIP; }
+    if (d_top) (void)hipFree(d_top);
+    if (d_off) (void)hipFree(d_off);
+    if (d_exc) (void)hipFree(d_exc);
+    if (e != hipSuccess) { set_error("tbc_setfull_create_rows: building the matrix failed: %s", hipGetErrorString(e)); return e == hipErrorOutOfMemory ? TBC_ERR_OOM : TBC_ERR_HIP; }
   }
   // p[r] (how many elements had been invoked when read r completed) and the chunks' maxima depend on the inputs only
   SF_TRY(hipMemsetAsync(S->d_pmax, 0, (size_t)S->chunks * 4, S->stream));

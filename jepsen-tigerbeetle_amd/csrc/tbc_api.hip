@@ -192,24 +192,78 @@ thread_local Ctx* t_ctx = nullptr;      // the context the calling thread's DevB
 std::mutex g_ctx_mu;
 std::vector<Ctx*> g_ctx_free;
 
+// TBC_GUARD=1 (diagnostic, like TBC_DEBUG): every device arena gets 256 poisoned bytes behind it and tbc_batch_run checks them all when
+// it ends -- a kernel that writes past an arena is named (allocation number, address, the first bad byte) instead of corrupting a
+// neighbour silently.  Round 4 saw ONE bench run of five die with a GPU memory fault that nothing reproduced; this is how it was hunted
+// (profiles/r05_guard_runs.txt).
+bool guard_on() { static const bool on = [] { const char* e = std::getenv("TBC_GUARD"); return e && e[0] == '1'; }(); return on; }
+// (an arena belongs to the batch being created or run by the allocating thread -- t_guard_owner; a run checks its own batch's arenas
+// only: another thread's batch may be poisoning a re-used piece of its context's slab at that very moment -- the first version of this
+// check read such bytes and cried wolf, ten times in a two-thread bench run)
+struct GuardRec { const char* at; size_t serial; size_t nth; const void* owner; };
+std::mutex g_guard_mu;
+std::vector<GuardRec> g_guards;
+size_t g_guard_serial = 0;
+thread_local const void* t_guard_owner = nullptr;
+thread_local size_t t_guard_nth = 0;          // the arena's number within its batch (allocation order of batch_create_impl: names it)
+constexpr size_t kGuardBytes = 256;
+void guard_add(const void* arena_end) {
+  static const std::vector<unsigned char> poison(kGuardBytes, 0xA5);
+  (void)hipMemcpy(const_cast<void*>(arena_end), poison.data(), kGuardBytes, hipMemcpyHostToDevice);      // (synchronous: the bytes are there before anything is launched)
+  std::lock_guard<std::mutex> lk(g_guard_mu);
+  g_guards.push_back(GuardRec{(const char*)arena_end, g_guard_serial++, t_guard_nth++, t_guard_owner});
+}
+void guard_remove(const void* arena_end) {
+  std::lock_guard<std::mutex> lk(g_guard_mu);
+  for (size_t i = 0; i < g_guards.size(); i++) if (g_guards[i].at == (const char*)arena_end) { g_guards.erase(g_guards.begin() + (long)i); return; }
+}
+// returns the number of arenas whose guard bytes were overwritten (after the caller's stream is idle)
+size_t guard_check(const char* when, const void* owner) {
+  std::vector<GuardRec> live;
+  { std::lock_guard<std::mutex> lk(g_guard_mu); for (const GuardRec& g : g_guards) if (g.owner == owner) live.push_back(g); }
+  size_t bad = 0;
+  unsigned char buf[kGuardBytes];
+  for (const GuardRec& g : live) {
+    if (hipMemcpy(buf, g.at, kGuardBytes, hipMemcpyDeviceToHost) != hipSuccess) continue;
+    for (size_t i = 0; i < kGuardBytes; i++) if (buf[i] != 0xA5) {
+      std::fprintf(stderr, "[tbc guard] %s: arena #%zu (the batch's %zu-th, ends at %p) overrun: byte +%zu = 0x%02x\n", when, g.serial, g.nth, (const void*)g.at, i, buf[i]);
+      bad++;
+      break;
+    }
+  }
+  return bad;
+}
+
 template <typename T>
 struct DevBuf {
   T* p = nullptr;
   size_t n = 0;
   bool owned = false;
+  bool guarded = false;
   tbc_status alloc(size_t count) {
     n = count;
     if (count == 0) count = 1;
-    const size_t bytes = (count * sizeof(T) + 255) & ~(size_t)255;
+    const size_t body = (count * sizeof(T) + 255) & ~(size_t)255;
+    const size_t bytes = body + (guard_on() ? kGuardBytes : 0);
+    guarded = guard_on();
     if (t_ctx) {
       t_ctx->wanted += bytes;
-      if (t_ctx->used + bytes <= t_ctx->cap) { p = (T*)(t_ctx->slab + t_ctx->used); t_ctx->used += bytes; owned = false; return TBC_OK; }
+      if (t_ctx->used + bytes <= t_ctx->cap) {
+        p = (T*)(t_ctx->slab + t_ctx->used); t_ctx->used += bytes; owned = false;
+        if (guarded) guard_add((const char*)p + body);
+        return TBC_OK;
+      }
     }
-    HIP_TRY(hipMalloc((void**)&p, count * sizeof(T)));
+    HIP_TRY(hipMalloc((void**)&p, bytes));
     owned = true;
+    if (guarded) guard_add((const char*)p + body);
     return TBC_OK;
   }
-  void release() { if (p && owned) (void)hipFree(p); p = nullptr; n = 0; owned = false; }
+  void release() {
+    if (p && guarded) guard_remove((const char*)p + (((n ? n : 1) * sizeof(T) + 255) & ~(size_t)255));
+    if (p && owned) (void)hipFree(p);
+    p = nullptr; n = 0; owned = false; guarded = false;
+  }
   size_t bytes() const { return (n ? n : 1) * sizeof(T); }
 };
 
@@ -962,6 +1016,9 @@ tbc_status tbc_batch_create(const tbc_batch_desc* desc, const tbc_model* model,
   tbc_batch* B = new (std::nothrow) tbc_batch();
   if (!B) return TBC_ERR_OOM;
   tbc_status s;
+  const void* const guard_prev = t_guard_owner;
+  const size_t guard_prev_nth = t_guard_nth;
+  t_guard_owner = B; t_guard_nth = 0;
   try {
     s = batch_create_impl(desc, model, opts, B);
   } catch (const std::bad_alloc&) {
@@ -971,6 +1028,7 @@ tbc_status tbc_batch_create(const tbc_batch_desc* desc, const tbc_model* model,
     set_error("unexpected exception");
     s = TBC_ERR_HIP;
   }
+  t_guard_owner = guard_prev; t_guard_nth = guard_prev_nth;
   if (s != TBC_OK) { delete B; return s; }
   *out = B;
   return TBC_OK;
@@ -1232,15 +1290,15 @@ uint32_t narrow_waves_per_simd() {
 // of the completion nobody can pass: nine times a valid history's search for a bad read in the middle of a 10k-op history, and a pass is
 // as long as its slowest history) or, rarely, in a burst of concurrency; the sweep decides either in milliseconds.
 // How long is "no longer"?  A VALID history stalls too, in a burst of concurrency: of 24 bench histories under the emulator 3 stop at 8 looks at
-// the clock (512 rounds), 2 at 16, none at 32 -- and a valid history that is stopped has lost its search.  48 looks (3,072 rounds, ~40 ms,
-// two thirds of a whole valid search) is past every burst seen; a bad read in the middle of a history then holds its pass for 40 ms
-// instead of 450.
-static const uint32_t kStallChecks = 48;
+// the clock (512 rounds), 2 at 16, none at 32; on the device, at 48 looks, ~20 of 32,768 -- and a valid history that is stopped has lost
+// its search and costs a sweep.  64 looks (4,096 rounds, ~53 ms: a whole valid search) is past nearly every burst; a bad read in the
+// middle of a history then holds its pass for one more search's time instead of nine.
+static const uint32_t kStallChecks = 64;
 static tbc_status hand_over_stalled(tbc_batch* B, const std::vector<uint32_t>& list, std::vector<tbc_result>& out) {
   Ctx* const saved = t_ctx;
   t_ctx = nullptr;                               // (the inner batch owns its arenas, stream and events)
   tbc_status st = TBC_OK;
-  const size_t chunk = list.size() <= 8 ? 1 : 256;          // (a few: one at a time through tbc_check's persistent contexts -- no allocation, ~2 ms each)
+  const size_t chunk = list.size() <= 32 ? 1 : 256;         // (a few: one at a time through tbc_check's persistent contexts -- no allocation, 1 - 3 ms each)
   for (size_t lo = 0; lo < list.size() && st == TBC_OK; lo += chunk) {
     const size_t hi = std::min(list.size(), lo + chunk);
     const uint32_t k = (uint32_t)(hi - lo);
@@ -1319,9 +1377,9 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results, int phase = 
     swa.n_classes = B->model.n_classes; swa.n_keys = B->model.n_keys;
     swa.shard_rank = 0; swa.shard_world = 1;
   }
-  // a big quiet batch (several histories per wavefront): a history that stops passing completions is handed to the level sweep
-  // (hand_over_stalled) -- where that can answer: register / cas-register, one mask word, nobody asking for a witness or naming a step limit
-  const bool stall_on = B->lanes != 0 && !(B->opts.dominance & TBC_DOM_NO_STALL_HANDOVER) && !B->count_form && B->mask_words == 1 && !B->opts.want_witness && B->opts.max_steps == 0 && phase == 0 &&
+  // a big quiet batch (several histories per wavefront), IF ASKED (tbc_opts.dominance, TBC_DOM_STALL_HANDOVER: off by default, tbcheck.h says why):
+  // a history that stops passing completions is handed to the level sweep (hand_over_stalled) -- where that can answer: register / cas-register, one mask word, nobody asking for a witness or naming a step limit
+  const bool stall_on = B->lanes != 0 && (B->opts.dominance & TBC_DOM_STALL_HANDOVER) != 0 && !B->count_form && B->mask_words == 1 && !B->opts.want_witness && B->opts.max_steps == 0 && phase == 0 &&
                         (B->model.kind == TBC_MODEL_REGISTER || B->model.kind == TBC_MODEL_CAS_REGISTER) && B->vpad != 0;
   std::vector<tbc_result> handed;
   std::vector<uint8_t> was_handed(nh, 0);
@@ -1334,7 +1392,7 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results, int phase = 
   HIP_TRY(hipEventRecord(B->ev[0], s));
   // (tbc_check: the arenas a run zeroes -- position bitmap, list offsets, crashed-call counts, the pool cursor -- are consecutive
   // pieces of the context's slab: one memset; the descriptors came up with the columns: not again.  Six memsets and two copies were 34 us)
-  const bool zero_block = B->borrowed && !B->d_bitmap.owned && !B->d_off.owned && !B->d_ncr.owned && !B->d_pool_cursor.owned &&
+  const bool zero_block = B->borrowed && !guard_on() && !B->d_bitmap.owned && !B->d_off.owned && !B->d_ncr.owned && !B->d_pool_cursor.owned &&
                           (char*)B->d_bitmap.p < (char*)B->d_pool_cursor.p && (size_t)((char*)B->d_pool_cursor.p - (char*)B->d_bitmap.p) < (64u << 20) &&
                           (char*)B->d_off.p > (char*)B->d_bitmap.p && (char*)B->d_off.p < (char*)B->d_pool_cursor.p &&
                           (char*)B->d_ncr.p > (char*)B->d_bitmap.p && (char*)B->d_ncr.p < (char*)B->d_pool_cursor.p;
@@ -1843,11 +1901,14 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results, int phase = 
   }
   B->sum.ns_pack = B->timing_ns[1]; B->sum.ns_search = B->timing_ns[2] + B->timing_ns[3];
   B->sum.ns_total = t_end - t_start;
+  if (guard_on() && guard_check("tbc_batch_run", B) != 0) { set_error("TBC_GUARD: a kernel wrote past a device arena (see stderr)"); return TBC_ERR_HIP; }
   return worst;
 }
 
 tbc_status tbc_batch_run(tbc_batch* b, tbc_result* results) {
   if (!b) { set_error("tbc_batch_run: null batch"); return TBC_ERR_INVALID_ARG; }
+  struct OwnerScope { const void* prev; size_t prev_nth; OwnerScope(const void* o) : prev(t_guard_owner), prev_nth(t_guard_nth) { t_guard_owner = o; t_guard_nth = 1000; }
+                      ~OwnerScope() { t_guard_owner = prev; t_guard_nth = prev_nth; } } scope(b);      // (scratch arenas of a run: the batch's, numbered from 1000)
   try {
     return batch_run_impl(b, results);
   } catch (const std::bad_alloc&) {

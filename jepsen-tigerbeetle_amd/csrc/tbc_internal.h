@@ -185,9 +185,11 @@ constexpr uint32_t kRuleBranch = 4u;
 // config space small: a crashed call is only linearized right before a call that OBSERVES its value (a config reached by a
 // crashed call no absorbed read observed is HOT: bit 30 of the state word; only calls whose precondition is the state are its
 // candidates), and a new config is dropped when a visited config with the same key has used no more of any class (Pareto).
-//   crashed[]  (at op_off, as before) holds one OpRec per CLASS, in order of the class's first invocation:
-//              {op = first member's index in cmem[], f | shift << 8 | width << 16, a, b};  ncr[F] = classes with a member invoked by F
-//   cmem[]     (at BeamHist.cmem_off) per class its members in invocation order, inv_rank | op << 32, then a sentinel (all ones)
+//   cmem[]     (at BeamHist.cmem_off) first one 16 B OpRec per CLASS, in order of the class's first invocation:
+//              {op = first member's word in this block, f | shift << 8 | width << 16, a, b};  ncr[F] = classes with a member invoked by F;
+//              then per class its members in invocation order, inv_rank | op << 32, and a sentinel (all ones)
+//   crashed[]  is NOT allocated in the count form (zero elements): nothing may read A.crashed when kRuleCount is set -- the class
+//              records are the head of the history's cmem[] block
 // Visited-set entries carry the count words behind the mask words; buckets are chosen by (k0, M) alone, so every config with
 // one key lies on one probe chain.
 constexpr uint32_t kRuleCount = 8u;

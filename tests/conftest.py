@@ -18,16 +18,15 @@ def _mask_form_unless_asked():
     (wgl_beam.c, wgl_window.c, sweep_ref.c): for them core.make_opts() leaves the count form off.  tests/test_count_form*.py ask for
     it by name (count_form=True), which is also what the library does by default."""
     from jepsen_tigerbeetle_amd import _native as N, core
-    old = core.DEFAULT_COUNT_FORM, core.DEFAULT_LIST_ORDER, core.DEFAULT_STALL_HANDOVER
+    old = core.DEFAULT_COUNT_FORM, core.DEFAULT_LIST_ORDER
     core.DEFAULT_COUNT_FORM = False
-    core.DEFAULT_STALL_HANDOVER = False          # (likewise: an invalid history's counters are compared with the narrow schedule's own exhaustion; tests/test_stall_handover_gpu.py asks for the default)
     # Likewise the order of the fronts' lists (tbc_opts.list_order): the tests written before round 5 compare counters and witnesses with
     # oracle/wgl_beam.c in PROCESS-SLOT order, and the oracle cannot know where the library's own choice (completion order, a :write 24
     # ranks later) applies -- so for them make_opts() asks for slot order.  The shipped default is pinned by name where it is the point:
     # tests/test_list_order_gpu.py (every order, both kernels), test_narrow_kernel_at_the_bench_configuration, the smoke test, bench.py.
     core.DEFAULT_LIST_ORDER = N.ORDER_SLOT
     yield
-    core.DEFAULT_COUNT_FORM, core.DEFAULT_LIST_ORDER, core.DEFAULT_STALL_HANDOVER = old
+    core.DEFAULT_COUNT_FORM, core.DEFAULT_LIST_ORDER = old
 
 
 @pytest.fixture(scope="session")

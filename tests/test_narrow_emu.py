@@ -346,14 +346,14 @@ def test_the_default_list_order_needs_fewer_rounds_at_the_bench_configuration():
 
 
 def test_a_history_that_stops_passing_completions_is_stopped():
-    """BeamArgs.stall_checks (the library: 48 looks at the clock = 3,072 rounds; tbc_api.hip hands such a history to the level sweep): valid bench
+    """BeamArgs.stall_checks (the library: 64 looks at the clock = 4,096 rounds; tbc_api.hip hands such a history to the level sweep): valid bench
     histories -- the one of them whose burst of concurrency costs 1,500 rounds included -- run to their end with the oracle's counters, a history
     with a bad read in its middle is stopped (UNKNOWN, step limit) long before it has exhausted what lies in front of that read"""
     hists = synth.register_ops_many(range(7000, 7004), n_ops=10000, n_procs=64, busy=0.1, info=0.0)
-    compare(hists, CAS, 8, tag="stall, valid", entries_per_op=4, pool_words=1 << 25, want_witness=False, by_ret=16 + 24, stall=48)
+    compare(hists, CAS, 8, tag="stall, valid", entries_per_op=4, pool_words=1 << 25, want_witness=False, by_ret=16 + 24, stall=64)
     bad = _in_domain(10000, 64, 7100, 0.1, 0.0, 0.5)
     full = wgl.check_beam(bad.as_dict(), CAS, 1, round_pairs=8, rules_at_any_round_size=True, branch_lists=True, list_order=16 + 24, want_witness=False)
     assert full["valid"] == 0
-    got = emu.run([bad.as_dict()], 1, N.NIL, 8, entries_per_op=4, pool_words=1 << 25, want_witness=False, by_ret=16 + 24, stall=48)[0]
+    got = emu.run([bad.as_dict()], 1, N.NIL, 8, entries_per_op=4, pool_words=1 << 25, want_witness=False, by_ret=16 + 24, stall=64)[0]
     assert (got["valid"], got["cause"]) == (-1, 2)
-    assert got["bucket_reads"] < 0.5 * full["rounds"] and got["bucket_reads"] > 3072
+    assert got["bucket_reads"] < 0.5 * full["rounds"] and got["bucket_reads"] > 4096

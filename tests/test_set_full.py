@@ -133,6 +133,13 @@ def test_matrix_built_on_the_device_equals_the_matrix_from_the_host(native):
     bad.exc = bad.exc.copy(); bad.exc[0] = bad.E + 5
     with pytest.raises(N.TbcError):
         sf.Scan(bad, rows=True)
+    # an element listed twice in one read's exceptions: the kernel flips the listed bits, the second flip would undo the first -- refused
+    dup = sf.Encoded(_lossy_set_history(3, n_ops=300)[0])
+    r = int(np.argmax(np.diff(dup.exc_off) >= 2))
+    assert dup.exc_off[r + 1] - dup.exc_off[r] >= 2
+    dup.exc = dup.exc.copy(); dup.exc[int(dup.exc_off[r]) + 1] = dup.exc[int(dup.exc_off[r])]
+    with pytest.raises(N.TbcError, match="strictly ascending"):
+        sf.Scan(dup, rows=True)
 
 
 @pytest.mark.gpu

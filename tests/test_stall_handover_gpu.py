@@ -1,7 +1,8 @@
 """A big quiet batch (several histories per wavefront) with NOT LINEARIZABLE histories in it: a pass is as long as its slowest history, and
-exhausting the configs in front of a bad read in the middle of a history costs many times a valid history's search.  By default the narrow
-kernel stops a history that has not passed a completion for 3,072 rounds (BeamArgs.stall_checks) and the library checks it again with the
-level sweep in a small batch of its own (tbc_api.hip, hand_over_stalled; tbc_opts.dominance TBC_DOM_NO_STALL_HANDOVER switches it off).
+exhausting the configs in front of a bad read in the middle of a history costs many times a valid history's search.  When asked (tbc_opts.dominance,
+TBC_DOM_STALL_HANDOVER -- off by default: valid histories stall too and an all-valid batch pays for them, tbcheck.h) the narrow
+kernel stops a history that has not passed a completion for 4,096 rounds (BeamArgs.stall_checks) and the library checks it again with the
+level sweep in a small batch of its own (tbc_api.hip, hand_over_stalled).
 Verdict and failing op are the search's either way; who answered is in tbc_result.analyzer."""
 import numpy as np
 import pytest
