@@ -46,7 +46,7 @@ enum : uint32_t {
   G_CLAIM = 20,     // 32 words: who takes the empty entry of a bucket (by bucket number mod 32) this round
   G_RING = 56
 };
-WV_HD constexpr uint32_t ring_size(uint32_t L) { return L <= 4u ? 8u : (L < 16u ? 16u : L); }      // (>= L: a round's pushes never clash)
+WV_HD constexpr uint32_t ring_size(uint32_t L) { return L <= 8u ? 8u : L; }      // (>= L: a round's pushes never clash.  Round 5: 8 entries for 8 lanes, not 16: 5.9 KB of LDS a wavefront instead of 8.7 -- the same rate on the device, alone and beside another batch's pack: profiles/r05_ring8_ab.txt)
 // ring entry: pos idx off nlive cnt (u32), k0 (u64), M[mw] (u64), the window word(s) of the config's front (u64: 4, or 1 compact)
 // (count form: + the config's count vector, 2 x u64)
 WV_HD constexpr uint32_t group_words(uint32_t mw, uint32_t L, bool cf = false, bool cnt = false) { return G_RING + ring_size(L) * (5u + 2u + 2u * mw + (cf ? 2u : 8u) + (cnt ? 2u * kCountWords : 0u)); }
