@@ -711,6 +711,10 @@ static tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model*
     for (uint32_t h = 0; h < nh; h++) max_n = std::max<uint64_t>(max_n, desc->op_off[h + 1] - desc->op_off[h]);
     const char* env = std::getenv("TBC_SWEEP_SEG");
     uint64_t T = env ? std::strtoull(env, nullptr, 10) : std::max<uint64_t>(32, (max_n * nh + 4095) / 4096);
+    // one history or a handful -- the workgroup kernel's case (at most 4,096 workgroups): windows of 48 completions.  Measured round 5 with
+    // the compact walk (profiles/r05_sweep_segment_length.txt): one 10k-op history 1.07 ms at 32, 0.97 - 1.02 at 40, 0.97 - 0.99 at 48,
+    // 1.11 at 56, 1.20 at 64 (fewer workgroups, shorter table to bring back and compose; past 48 the longest segment costs more than that saves)
+    if (!env && T < 48 && (uint64_t)nh * ((max_n + 47) / 48) * kSweepSlices <= 4096) T = 48;
     const bool regfam = model->kind == TBC_MODEL_REGISTER || model->kind == TBC_MODEL_CAS_REGISTER;
     if (!regfam || B->vpad == 0 || T == 0 || T >= max_n) { B->seg_target = 0; B->max_segs = 1; }
     else {
@@ -1539,6 +1543,14 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results, int phase = 
   bh_back.resize(beam ? nh : 0);
   HIP_TRY(hipMemcpyAsync(hist_back.data(), B->d_hist.p, nh * sizeof(Hist), hipMemcpyDeviceToHost, s));
   if (beam) HIP_TRY(hipMemcpyAsync(bh_back.data(), B->d_bh.p, nh * sizeof(BeamHist), hipMemcpyDeviceToHost, s));
+  if (B->borrowed && B->sweep) {
+    // tbc_check through the level sweep: the whole device side of the call is ~1 ms -- waiting for it by asking the stream (a few
+    // thousand queries) instead of sleeping until the driver wakes the thread saves the wake-up; anything longer sleeps as before
+    const uint64_t t_spin = now_ns();
+    hipError_t q;
+    while ((q = hipStreamQuery(s)) == hipErrorNotReady && now_ns() - t_spin < 3000000ull) {}
+    if (q != hipSuccess && q != hipErrorNotReady) HIP_TRY(q);
+  }
   HIP_TRY(hipStreamSynchronize(s));
   TRACE("run: first pass synced");
   for (uint32_t h = 0; h < nh; h++) if (rs_level[h] != kInf) {      // refuted by the relaxed sweep: whatever its exact search got to before it was told to stop is dropped (the passes below, and their counters, are then the same run after run)
