@@ -167,23 +167,45 @@ WV_DEV void walk_wave(const PackOpenArgs& A, uint32_t wid, uint32_t* lds, uint32
   // ranks, a :write's odd: after the call it ties with) -- W = 16 .. 24 is the best of the scan at 6, 19 and 32 calls in flight (oracle list
   // order 16 + W: at 19 in flight 19 - 22k rounds a history against 28k writes last, 59k plain completion order).  Any key gives a
   // permutation: a place is the count of smaller keys, ties by table position.
+  // The keys are made UNIQUE so that a place is one compare per pair: completion ranks are (live calls), and so are ranks + 2^30 for
+  // the writes and doubled ranks with the writes' odd; the only ties of the definition are among crashed calls (ret = kInf), which are in
+  // no list -- and what the loop does for an unlisted candidate (a bit of a read row, of the lookahead mask, the producer distance)
+  // does not depend on when it meets it: they take keys above every live one, by table position.  The keys stay in registers, one
+  // candidate per lane (three sets); candidate j's key reaches the lanes by a lane read (j is uniform), and every lane counts the
+  // smaller keys for each of its candidates: 1 + 2 vector instructions per set instead of a dozen with two LDS reads.
   const bool by_ret = A.list_order != 0u;
   const uint32_t wr_last = A.list_order == 2u ? 0x40000000u : A.list_order >= 16u ? 2u * (A.list_order - 16u) + 1u : 0u;
   const uint32_t rk_mul = A.list_order >= 16u ? 2u : 1u;
   uint16_t* const perm = reinterpret_cast<uint16_t*>(aux);
   if (by_ret) {
+    uint32_t my[3], place[3] = {0u, 0u, 0u};
     WV_UNROLL
     for (int s = 0; s < 3; s++) {
       const uint32_t idx = lane + 64u * (uint32_t)s;
-      if (idx < NC) {
-        const uint32_t my = cand[idx * kCandWords + 1u] * rk_mul + ((cand[idx * kCandWords + 3u] & 0xFFu) == TBC_F_WRITE ? wr_last : 0u);
-        uint32_t place = 0u;
-        for (uint32_t j = 0; j < NC; j++) {
-          const uint32_t rj = cand[j * kCandWords + 1u] * rk_mul + ((cand[j * kCandWords + 3u] & 0xFFu) == TBC_F_WRITE ? wr_last : 0u);
-          place += (rj < my || (rj == my && j < idx)) ? 1u : 0u;
+      const uint32_t* e = cand + (idx < NC ? idx : 0u) * kCandWords;
+      const uint32_t rt = e[1];
+      my[s] = idx >= NC ? 0xFFFFFFFFu : rt == kInf ? (0xFFFFFF00u | idx) : rt * rk_mul + ((e[3] & 0xFFu) == TBC_F_WRITE ? wr_last : 0u);
+    }
+    const uint32_t n0 = NC < 64u ? NC : 64u, n1 = NC <= 64u ? 0u : (NC < 128u ? NC - 64u : 64u), n2 = NC <= 128u ? 0u : NC - 128u;
+    if (NC <= 64u) {
+      for (uint32_t j = 0; j < n0; j++) place[0] += wv::readlane(my[0], j) < my[0] ? 1u : 0u;
+    } else if (NC <= 128u) {
+      for (uint32_t j = 0; j < n0; j++) { const uint32_t kj = wv::readlane(my[0], j); place[0] += kj < my[0] ? 1u : 0u; place[1] += kj < my[1] ? 1u : 0u; }
+      for (uint32_t j = 0; j < n1; j++) { const uint32_t kj = wv::readlane(my[1], j); place[0] += kj < my[0] ? 1u : 0u; place[1] += kj < my[1] ? 1u : 0u; }
+    } else {
+      WV_UNROLL
+      for (int s2 = 0; s2 < 3; s2++) {
+        const uint32_t cnt = s2 == 0 ? n0 : s2 == 1 ? n1 : n2;
+        for (uint32_t j = 0; j < cnt; j++) {
+          const uint32_t kj = wv::readlane(my[s2], j);
+          place[0] += kj < my[0] ? 1u : 0u; place[1] += kj < my[1] ? 1u : 0u; place[2] += kj < my[2] ? 1u : 0u;
         }
-        perm[place] = (uint16_t)idx;
       }
+    }
+    WV_UNROLL
+    for (int s = 0; s < 3; s++) {
+      const uint32_t idx = lane + 64u * (uint32_t)s;
+      if (idx < NC) perm[place[s]] = (uint16_t)idx;
     }
     wv::barrier();
   }

@@ -1,11 +1,12 @@
 // pack_one.hip -- K1 by a workgroup's wavefronts with its tables in LDS (gfx950); the body is pack_one_impl.h.  Two forms:
 //   pack_one_kernel  one history (or a handful): sixteen wavefronts, same inputs and same bytes left behind as pack_kernel (pack.hip);
-//   pack_one_counts_kernel  ... and open_counts_kernel's bytes in the same pass (TBC_PACK_ONE=2: one launch fewer per tbc_check);
+//   pack_one_counts_kernel  ... and open_counts_kernel's bytes in the same pass (one launch fewer per tbc_check);
 //   pack_wg_kernel   a batch: four wavefronts per history, pack_kernel's AND open_counts_kernel's (pack_open.hip) bytes in one pass --
 //                    the ranks never leave the registers between the two.
 // pack_kernel + open_counts_kernel keep the models and the histories these bodies do not take.
-// STANDING: both bodies are verified under the workgroup emulator (tests/test_pack_one_emu.py) and had not run on the device when
-// they were committed; tbc_api.hip takes them only under TBC_PACK_ONE=1|2 / TBC_PACK_WG=1|2 (bench.py's extra legs measure them).
+//   pack_wg64_kernel the same for histories of at most 64 process slots: 19 KB of LDS instead of 31, eight workgroups per CU.
+// Verified word for word under the workgroup emulator (tests/test_pack_one_emu.py) and on the device through every GPU parity test:
+// tbc_api.hip takes pack_one_counts_kernel for one history and pack_wg(64)_kernel for a batch whenever the histories fit.
 #include <hip/hip_runtime.h>
 #include "tbc_internal.h"
 #include "pack_one_impl.h"
@@ -25,6 +26,10 @@ __global__ __launch_bounds__(64 * packone::OneCountsGeo::kNW) void pack_one_coun
 __global__ __launch_bounds__(64 * packone::BatchGeo::kNW) void pack_wg_kernel(PackArgs A, PackOpenArgs O) {
   __shared__ __attribute__((aligned(16))) uint32_t lds[packone::BatchGeo::lds_words()];
   packone::history<packone::BatchGeo>(A, O, lds);
+}
+__global__ __launch_bounds__(64 * packone::Batch64Geo::kNW) void pack_wg64_kernel(PackArgs A, PackOpenArgs O) {
+  __shared__ __attribute__((aligned(16))) uint32_t lds[packone::Batch64Geo::lds_words()];
+  packone::history<packone::Batch64Geo>(A, O, lds);
 }
 }  // namespace
 
@@ -56,13 +61,17 @@ bool launch_pack_one_counts(const PackArgs& a, const PackOpenArgs& o, void* stre
 bool pack_wg_fits(uint32_t model_kind, uint32_t n_ops, uint32_t n_events, uint32_t n_slots) {
   return packone::BatchGeo::fits(model_kind, n_ops, n_events, n_slots);
 }
+bool pack_wg64_fits(uint32_t model_kind, uint32_t n_ops, uint32_t n_events, uint32_t n_slots) {
+  return packone::Batch64Geo::fits(model_kind, n_ops, n_events, n_slots);
+}
 
 // histories [a.h0, a.n_hist), one workgroup of four wavefronts each (31 KB of LDS, static): pack + open counts.  The caller has
 // asked pack_wg_fits() of every history, o is what launch_pack_open() would hand open_counts_kernel (same h0 / n_hist), and the
-// walk that follows is launched with skip_counts.  false = not launched.
-bool launch_pack_wg(const PackArgs& a, const PackOpenArgs& o, void* stream) {
+// walk that follows is launched with skip_counts.  slots64: every history also passed pack_wg64_fits() (19 KB of LDS).  false = not launched.
+bool launch_pack_wg(const PackArgs& a, const PackOpenArgs& o, void* stream, bool slots64) {
   if (a.n_hist <= a.h0 || o.h0 != a.h0 || o.n_hist != a.n_hist || !o.bh || !o.off || !o.ncr || !o.slot8 || (o.branch_lists && !o.rk8)) return false;
-  hipLaunchKernelGGL(pack_wg_kernel, dim3(a.n_hist - a.h0), dim3(64 * packone::BatchGeo::kNW), 0, (hipStream_t)stream, a, o);
+  if (slots64) hipLaunchKernelGGL(pack_wg64_kernel, dim3(a.n_hist - a.h0), dim3(64 * packone::Batch64Geo::kNW), 0, (hipStream_t)stream, a, o);
+  else hipLaunchKernelGGL(pack_wg_kernel, dim3(a.n_hist - a.h0), dim3(64 * packone::BatchGeo::kNW), 0, (hipStream_t)stream, a, o);
   return true;
 }
 

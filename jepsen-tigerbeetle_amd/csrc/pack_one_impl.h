@@ -19,7 +19,7 @@
 // Register, cas-register, mutex and table models (what one history through tbc_check is, and what the level sweep takes); set, bank
 // and multi-register keep pack_kernel, and so does a history too long for the LDS tables (tbc_api.hip decides, pack_one_fits()).
 //
-// THE BATCH FORM (geometry BatchGeo; pack_one.hip's pack_wg_kernel, TBC_PACK_WG=1).  In a batch the same walk is what a pass pays for
+// THE BATCH FORM (geometry BatchGeo; pack_one.hip's pack_wg_kernel).  In a batch the same walk is what a pass pays for
 // three times over: pack_kernel (one wavefront of four walking, the bitmap and its prefix in global memory), then open_counts_kernel
 // (pack_open.hip), which reads the ranks back from the scratch arena, builds the histogram of invocation ranks with global atomics
 // and scans it in global memory three times -- 28 ms of a 60 ms pack per 32,768 histories, at 6 % vector use and 50-70 % of the wave
@@ -28,9 +28,13 @@
 // invocation ranks in LDS (16 bits a rank), its scans in LDS, off[] written once; the crashed-call arrays (mask form only) as
 // open_counts_kernel builds them.  Four wavefronts and 31 KB of LDS per history: five workgroups per CU.
 //
+// Batch64Geo is the same body for histories of at most 64 process slots (what the narrow search kernel takes): the (block, process)
+// counts shrink with the slots and a histogram entry to a byte -- 19 KB, eight workgroups per CU instead of five; the kernel waits on
+// memory for half of its wave cycles (profiles/r05_pmc_final.txt), so residency is what it is short of.
+//
 // Written against wave_env_wg.h like jit_sweep_wg_impl.h: the same file compiles for the workgroup emulator (tests/emu).
-// STANDING: verified under the emulator only (TBC_PACK_ONE=1 / TBC_PACK_WG=1 select the two forms; the measured default is pack_kernel
-// + open_counts_kernel).
+// Both forms are the library's defaults since round 5 (tbc_api.hip: one history -> pack_one_counts_kernel, a batch -> pack_wg_kernel;
+// pack_kernel + open_counts_kernel keep what these bodies do not take).
 #pragma once
 #include "tbc_internal.h"
 #include "wave_env_wg.h"
@@ -39,16 +43,19 @@ namespace tbc {
 namespace packone {
 
 // A geometry: wavefronts per workgroup, the history rows the LDS bitmap holds, process slots, and (COUNTS) completions
-template <uint32_t NW_, uint32_t MAXEV_, uint32_t MAXW_, uint32_t MAXR_>
+// HBITS_: bits of a rank's entry in the histogram of the listed calls' invocation ranks (at most one call per process slot is invoked
+// between two completions: an entry holds MAXW_)
+template <uint32_t NW_, uint32_t MAXEV_, uint32_t MAXW_, uint32_t MAXR_, uint32_t HBITS_ = 16>
 struct Geo {
-  static constexpr uint32_t kNW = NW_, kT = 64 * NW_, kMaxEvents = MAXEV_, kMaxW = MAXW_, kMaxR = MAXR_;
+  static constexpr uint32_t kNW = NW_, kT = 64 * NW_, kMaxEvents = MAXEV_, kMaxW = MAXW_, kMaxR = MAXR_, kHBits = HBITS_, kHPer = 32 / HBITS_;
+  static_assert((HBITS_ == 8 || HBITS_ == 16) && MAXW_ < (1u << HBITS_), "a histogram entry counts up to one call per slot");
   static constexpr bool kCounts = MAXR_ != 0;
   static constexpr uint32_t kBmWords = MAXEV_ / 32 + 32;      // (+ the word E / 32 itself and padding)
   // LDS words: bitmap | prefix | (block, process) counts | list starts | per-wavefront scan totals | flags | (COUNTS) histogram of
-  // invocation ranks, two ranks a word | (COUNTS) the ranks at which a read completes, one bit each
+  // invocation ranks, two (or four) ranks a word | (COUNTS) the ranks at which a read completes, one bit each
   static constexpr uint32_t kOffBm = 0, kOffPre = kBmWords, kOffCnt = 2 * kBmWords, kOffSeg = kOffCnt + NW_ * MAXW_,
                             kOffTot = kOffSeg + MAXW_ + 8, kOffFlag = kOffTot + 2 * NW_, kOffHist = kOffFlag + 8,
-                            kHistWords = kCounts ? MAXR_ / 2 + 4 : 0, kOffRdb = kOffHist + kHistWords,
+                            kHistWords = kCounts ? MAXR_ / kHPer + 4 : 0, kOffRdb = kOffHist + kHistWords,
                             kRdbWords = kCounts ? MAXR_ / 32 + 2 : 0, kLdsWords = kOffRdb + kRdbWords;
   WV_HD static constexpr uint32_t lds_words() { return kLdsWords; }
   // what the body handles (tbc_api.hip asks before it launches it; everything else goes to pack_kernel)
@@ -60,7 +67,8 @@ struct Geo {
 };
 using OneGeo = Geo<16, 131072, kMaxSlots, 0>;        // one history or a handful through tbc_check: sixteen wavefronts, 103 KB
 using OneCountsGeo = Geo<16, 131072, kMaxSlots, 16384>;   // ... and open_counts_kernel's work in the same pass (one launch fewer per call): 138 KB
-using BatchGeo = Geo<4, 32768, 256, 8192>;           // a batch: four wavefronts, pack + open counts, 31 KB
+using BatchGeo = Geo<4, 32768, 256, 8192>;           // a batch: four wavefronts, pack + open counts, 31 KB: five workgroups per CU
+using Batch64Geo = Geo<4, 32768, 64, 8192, 8>;       // ... of histories with at most 64 process slots (one mask word: the narrow kernel's batches): 19 KB, eight per CU
 
 constexpr uint32_t kNW = OneGeo::kNW;                // (the one-history form's, for its launcher and the emulator harness)
 WV_HD constexpr uint32_t lds_words() { return OneGeo::lds_words(); }
@@ -119,7 +127,7 @@ WV_DEV void history(const PackArgs& A, const PackOpenArgs& O, uint32_t* lds) {
   uint32_t* seg = lds + G::kOffSeg;        // first record of each process's list (W + 1 entries)
   uint32_t* tot = lds + G::kOffTot;
   uint32_t* flag = lds + G::kOffFlag;      // 0 = error bits, 1 = completions seen, 2 = (COUNTS) crashed calls that are candidates
-  uint32_t* hist = lds + G::kOffHist;      // COUNTS: listed calls invoked at each rank, 16 bits a rank (at most W <= 1,024 of them)
+  uint32_t* hist = lds + G::kOffHist;      // COUNTS: listed calls invoked at each rank, G::kHBits bits a rank (at most W of them)
   uint32_t* rdb = lds + G::kOffRdb;        // COUNTS, branch lists: a read completes at this rank
   const uint32_t nw = E / 32u + 1u;
   const uint32_t chunks = (n + 63u) / 64u;
@@ -273,7 +281,7 @@ WV_DEV void history(const PackArgs& A, const PackOpenArgs& O, uint32_t* lds) {
             slot8[rr] = (uint8_t)pp;
             if (rk8) rk8[rr] = isread ? (uint8_t)rdm_index(aa, O.vpad) : (uint8_t)0xFF;
             if (branch && isread) wv::lds_or32(&rdb[rr >> 5], 1u << (rr & 31u));
-            else wv::lds_add32_wg(&hist[ir >> 1], 1u << (16u * (ir & 1u)));
+            else wv::lds_add32_wg(&hist[ir / G::kHPer], 1u << (G::kHBits * (ir % G::kHPer)));
           } else if (!cf && !(isread && aa == TBC_NIL)) {
             crashed_cands++;
             if (ir < R) atomicAdd(&ncr[ir], 1u);
@@ -298,14 +306,24 @@ WV_DEV void history(const PackArgs& A, const PackOpenArgs& O, uint32_t* lds) {
   {
     const uint32_t c0 = wave * cpw, c1 = c0 + cpw < chunks ? c0 + cpw : chunks;
     uint32_t err = 0u;
-    for (uint32_t c = c0; c < c1; c++) {
-      const uint32_t i = c * 64u + lane;
-      if (i >= n) continue;
-      uint32_t d = sc_dst[i];                                 // (this thread's own store)
-      if (d == kInf) continue;                                // slotless: no record, no predecessor
-      const wv::gu32* prev = (const wv::gu32*)(const void*)&rec[d - 1u];
-      const uint32_t prev_ret = wv::ld32(prev + 1), prev_f = wv::ld32(prev + 3);
-      if (prev_f != kFNone && !(prev_ret < sc_inv[i])) err = (uint32_t)TBC_ERR_BAD_HISTORY;
+    for (uint32_t c = c0; c < c1; c += 4u) {                  // four chunks' places first, then their eight words of records: two round trips for four chunks
+      uint32_t d[4], iv[4], pr[4], pf[4];
+      WV_UNROLL
+      for (uint32_t k = 0; k < 4u; k++) {
+        const uint32_t i = (c + k) * 64u + lane;
+        const bool in = c + k < c1 && i < n;
+        d[k] = in ? sc_dst[i] : kInf;                         // (this thread's own store; kInf = slotless: no record, no predecessor)
+        iv[k] = in ? sc_inv[i] : 0u;
+      }
+      WV_UNROLL
+      for (uint32_t k = 0; k < 4u; k++) {
+        const wv::gu32* prev = (const wv::gu32*)(const void*)&rec[d[k] != kInf ? d[k] - 1u : 0u];
+        pr[k] = d[k] != kInf ? wv::ld32(prev + 1) : 0u;
+        pf[k] = d[k] != kInf ? wv::ld32(prev + 3) : kFNone;
+      }
+      WV_UNROLL
+      for (uint32_t k = 0; k < 4u; k++)
+        if (d[k] != kInf && pf[k] != kFNone && !(pr[k] < iv[k])) err = (uint32_t)TBC_ERR_BAD_HISTORY;
     }
     if (err) wv::lds_or32(&flag[0], err);
   }
@@ -322,7 +340,7 @@ WV_DEV void history(const PackArgs& A, const PackOpenArgs& O, uint32_t* lds) {
     if (tid < 16u) { slot8[R + tid] = (uint8_t)0; if (rk8) rk8[R + tid] = (uint8_t)0xFF; }
     const uint32_t per = (R + kT - 1u) / kT;
     const uint32_t lo = tid * per < R ? tid * per : R, hi = lo + per < R ? lo + per : R;
-    const auto h16 = [&](uint32_t i) -> uint32_t { return (hist[i >> 1] >> (16u * (i & 1u))) & 0xFFFFu; };
+    const auto h16 = [&](uint32_t i) -> uint32_t { return (hist[i / G::kHPer] >> (G::kHBits * (i % G::kHPer))) & ((1u << G::kHBits) - 1u); };
     const auto rd_at = [&](uint32_t i) -> uint32_t { return branch ? (rdb[i >> 5] >> (i & 31u)) & 1u : 0u; };
     uint32_t nrd = 0u, sum = 0u;
     for (uint32_t i = lo; i < hi; i++) { nrd += rd_at(i); sum += h16(i); }

@@ -13,9 +13,9 @@
 //
 // Layout: rows = reads in invocation order, words_per_row 32-bit words each; a wavefront's 64 lanes take 64
 // consecutive words of a row (256 B coalesced).  Two passes, no atomics:
-//   setfull_any_kernel      grid = word columns x chunks of rows: a thread ORs "present" and "absent" over ONE word
-//                           column (32 elements) of ONE chunk, eight rows in flight, and stops when both words are
-//                           saturated -- the streaming pass, two coalesced words written per thread;
+//   setfull_any_kernel      grid = word columns x chunks of rows: a thread ORs "present" and "absent" over FOUR word
+//                           columns (128 elements, 16 B loads) of ONE chunk, four rows in flight -- the streaming
+//                           pass, coalesced words written per thread (one column, eight rows when a row is not a multiple of 16 B);
 //   setfull_resolve_kernel  one thread per word column: the chunk summaries say WHICH chunk holds each element's last
 //                           present / last absent / first present read; only those chunks are walked again, bit-parallel
 //                           (a 32-bit "still wanted" mask per direction), and the thread writes its own 32 results.
@@ -73,38 +73,65 @@ __global__ __launch_bounds__(256) void setfull_rows_kernel(const uint32_t* __res
 }
 
 // ---- pass 1: per (word column, chunk of rows) -- is any bit of the column present / absent in the chunk?  The streaming
-// pass: eight rows requested at a time (whether to go on depends on what was loaded), the chunk's row metadata in LDS,
-// two coalesced words written per thread, no atomics.
+// pass.  VEC = 4: a lane takes FOUR consecutive word columns (16 B loads, a wavefront 1 KB of a row; rows of a multiple of four
+// words), four rows requested before the first is used; VEC = 1: one column, eight rows.  Nothing a load returns decides whether
+// the next is issued (a chunk is at most 2,048 rows: stopping at a saturated column saved nothing on set-full's matrices, where an
+// element is absent before its add and present after, and cost a round trip every eight rows); the chunk's row metadata in LDS,
+// coalesced words written per thread, no atomics.
+template <int VEC>
 __global__ __launch_bounds__(256) void setfull_any_kernel(const uint32_t* __restrict__ M, const uint32_t* __restrict__ P,
                                                           const uint32_t* __restrict__ pmax, uint32_t E, uint32_t R, uint32_t WPR,
                                                           uint32_t rows_per_chunk, uint32_t* __restrict__ any_p, uint32_t* __restrict__ any_a,
                                                           unsigned long long* words_loaded) {
-  const uint32_t w = blockIdx.x * 256u + threadIdx.x, c = blockIdx.y;
+  constexpr uint32_t U = VEC == 1 ? 8u : 4u;            // rows in flight
+  const uint32_t w0 = (blockIdx.x * 256u + threadIdx.x) * (uint32_t)VEC, c = blockIdx.y;
   uint32_t loaded = 0;
   __shared__ uint32_t s_P[kSetFullRows];
   const uint32_t r0 = min(c * rows_per_chunk, R), r1 = min(r0 + rows_per_chunk, R);     // (a trailing chunk may be empty)
   for (uint32_t i = threadIdx.x; i < r1 - r0; i += 256u) s_P[i] = P[r0 + i];
   __syncthreads();
-  if (w < WPR) {
-    uint32_t pa = 0, aa = 0;
-    if (pmax[c] > 32u * w) {
-      const uint32_t full = E - 32u * w >= 32u ? 0xFFFFFFFFu : (1u << (E - 32u * w)) - 1u;
-      for (uint32_t hi = r1; hi > r0 && (pa & aa) != full;) {
-        const uint32_t lo8 = hi - r0 >= 8u ? hi - 8u : r0;
-        uint32_t wd[8], vm[8];
+  if (w0 < WPR) {
+    uint32_t pa[VEC], aa[VEC], full[VEC];
 #pragma unroll
-        for (uint32_t q = 0; q < 8; q++) {
+    for (int v = 0; v < VEC; v++) {
+      pa[v] = 0u; aa[v] = 0u;
+      const uint32_t lo = 32u * (w0 + (uint32_t)v);
+      full[v] = lo >= E ? 0u : (E - lo >= 32u ? 0xFFFFFFFFu : (1u << (E - lo)) - 1u);
+    }
+    if (pmax[c] > 32u * w0) {
+      for (uint32_t hi = r1; hi > r0;) {
+        const uint32_t lo8 = hi - r0 >= U ? hi - U : r0;
+        uint32_t wd[U][VEC], pr[U];
+#pragma unroll
+        for (uint32_t q = 0; q < U; q++) {
           const uint32_t r = hi - 1u - q;
-          vm[q] = hi - lo8 > q ? prefix_mask(s_P[r - r0], w) & full : 0u;
-          wd[q] = vm[q] ? M[(uint64_t)r * WPR + w] : 0u;
+          pr[q] = hi - lo8 > q ? s_P[r - r0] : 0u;                      // (0: no element of the row counts)
+          const bool need = pr[q] > 32u * w0 && full[0] != 0u;
+          if constexpr (VEC == 4) {
+            const uint4 x = need ? *reinterpret_cast<const uint4*>(M + (uint64_t)r * WPR + w0) : make_uint4(0u, 0u, 0u, 0u);
+            wd[q][0] = x.x; wd[q][1] = x.y; wd[q][2] = x.z; wd[q][3] = x.w;
+          } else {
+            wd[q][0] = need ? M[(uint64_t)r * WPR + w0] : 0u;
+          }
         }
 #pragma unroll
-        for (uint32_t q = 0; q < 8; q++) { pa |= wd[q] & vm[q]; aa |= ~wd[q] & vm[q]; loaded += vm[q] ? 1u : 0u; }
+        for (uint32_t q = 0; q < U; q++) {
+#pragma unroll
+          for (int v = 0; v < VEC; v++) {
+            const uint32_t vm = prefix_mask(pr[q], w0 + (uint32_t)v) & full[v];
+            pa[v] |= wd[q][v] & vm; aa[v] |= ~wd[q][v] & vm; loaded += vm ? 1u : 0u;
+          }
+        }
         hi = lo8;
       }
     }
-    any_p[(uint64_t)c * WPR + w] = pa;
-    any_a[(uint64_t)c * WPR + w] = aa;
+    if constexpr (VEC == 4) {        // (WPR is a multiple of four: all four columns exist)
+      *reinterpret_cast<uint4*>(any_p + (uint64_t)c * WPR + w0) = make_uint4(pa[0], pa[1], pa[2], pa[3]);
+      *reinterpret_cast<uint4*>(any_a + (uint64_t)c * WPR + w0) = make_uint4(aa[0], aa[1], aa[2], aa[3]);
+    } else {
+      any_p[(uint64_t)c * WPR + w0] = pa[0];
+      any_a[(uint64_t)c * WPR + w0] = aa[0];
+    }
   }
   unsigned long long tot = loaded;
   for (int d = 32; d >= 1; d >>= 1) tot += __shfl_xor(tot, d);
@@ -165,6 +192,18 @@ __global__ __launch_bounds__(256) void setfull_resolve_kernel(const uint32_t* __
     const uint32_t full = E - 32u * w >= 32u ? 0xFFFFFFFFu : (1u << (E - 32u * w)) - 1u;
     // the chunk summaries, 64 chunks (one per lane) at a time; any number of chunks
     const uint32_t G = (chunks + 63u) / 64u;
+    // up to 256 chunks (what tbc_setfull_create makes of up to 524,288 reads): the column's summaries are fetched ONCE, all eight
+    // loads in flight together, instead of group after group in each of the three passes below
+    const bool pre = G <= 4u;
+    uint32_t sp[4], sa[4];
+#pragma unroll
+    for (uint32_t k = 0; k < 4u; k++) {
+      const uint32_t cl = lane + 64u * k;
+      const bool in = pre && cl < chunks;
+      sp[k] = in ? any_p[(uint64_t)cl * WPR + w] : 0u;
+      sa[k] = in ? any_a[(uint64_t)cl * WPR + w] : 0u;
+    }
+    const auto pick = [](const uint32_t (&r)[4], uint32_t gi) -> uint32_t { return gi == 0u ? r[0] : gi == 1u ? r[1] : gi == 2u ? r[2] : r[3]; };
     // last present / last absent: the latest chunk that has the bit decides; inside it, the latest row
 #pragma unroll
     for (int pass = 0; pass < 2; pass++) {
@@ -172,7 +211,7 @@ __global__ __launch_bounds__(256) void setfull_resolve_kernel(const uint32_t* __
       uint32_t need = full;
       for (uint32_t gi = G; gi-- > 0 && need;) {
         const uint32_t cl = lane + 64u * gi;
-        const uint32_t mine = cl < chunks ? any[(uint64_t)cl * WPR + w] : 0u;
+        const uint32_t mine = pre ? pick(pass == 0 ? sp : sa, gi) : (cl < chunks ? any[(uint64_t)cl * WPR + w] : 0u);
         uint64_t cand = __ballot((mine & need) != 0u);
         while (cand && need) {
           const uint32_t l = 63u - (uint32_t)__builtin_clzll(cand);
@@ -192,7 +231,7 @@ __global__ __launch_bounds__(256) void setfull_resolve_kernel(const uint32_t* __
     uint32_t ever = 0, first_c = chunks;
     for (uint32_t gi = 0; gi < G; gi++) {
       const uint32_t cl = lane + 64u * gi;
-      uint32_t o = cl < chunks ? any_p[(uint64_t)cl * WPR + w] & full : 0u;
+      uint32_t o = (pre ? pick(sp, gi) : (cl < chunks ? any_p[(uint64_t)cl * WPR + w] : 0u)) & full;
       const uint64_t bl = __ballot(o != 0u);
       if (bl && first_c == chunks) first_c = (uint32_t)__builtin_ctzll(bl) + 64u * gi;
 #pragma unroll
@@ -380,8 +419,12 @@ tbc_status tbc_setfull_run(tbc_setfull* S, tbc_setfull_out* out) {
   SF_TRY(hipMemsetAsync(S->d_words, 0, 8, s));
   SF_TRY(hipEventRecord(S->ev0, s));
   if (S->R && S->E) {
-    hipLaunchKernelGGL(setfull_any_kernel, dim3((S->WPR + 255) / 256, S->chunks), dim3(256), 0, s, S->d_M, S->d_P, S->d_pmax, S->E, S->R, S->WPR,
-                       S->rows_per_chunk, S->d_anyp, S->d_anya, S->d_words);
+    if (S->WPR % 4u == 0u)      // (hipMalloc'ed arrays, rows of a multiple of four words: every 16 B load and store is aligned)
+      hipLaunchKernelGGL(setfull_any_kernel<4>, dim3((S->WPR / 4u + 255) / 256, S->chunks), dim3(256), 0, s, S->d_M, S->d_P, S->d_pmax, S->E, S->R, S->WPR,
+                         S->rows_per_chunk, S->d_anyp, S->d_anya, S->d_words);
+    else
+      hipLaunchKernelGGL(setfull_any_kernel<1>, dim3((S->WPR + 255) / 256, S->chunks), dim3(256), 0, s, S->d_M, S->d_P, S->d_pmax, S->E, S->R, S->WPR,
+                         S->rows_per_chunk, S->d_anyp, S->d_anya, S->d_words);
     hipLaunchKernelGGL(setfull_resolve_kernel, dim3((S->WPR + 3) / 4), dim3(256), 0, s, S->d_M, S->d_P, S->d_read_invoke, S->d_read_ok, S->d_anyp,
                        S->d_anya, S->E, S->R, S->WPR, S->rows_per_chunk, S->chunks, S->d_lp, S->d_la, S->d_known, S->d_words);
   }

@@ -1445,9 +1445,12 @@ static tbc_status batch_run_impl(tbc_batch* B, tbc_result* results, int phase = 
   // (round 5, first device run: 14.4 against 16.1 ms per 8,192 bench histories; every batch parity test green under it); the others keep
   // pack_kernel + open_counts_kernel
   if (!packed && beam) {
-    bool fits = true;
-    for (uint32_t h = 0; h < nh && fits; h++) fits = pack_wg_fits(B->model.kind, B->hist[h].n_ops, B->hist[h].n_events, B->hist[h].n_slots);
-    if (fits) packed = counted = launch_pack_wg(make_pack_args(B), make_pack_open_args(B), s);
+    bool fits = true, slots64 = true;          // (at most 64 slots everywhere: 19 KB of LDS a history instead of 31, eight workgroups per CU)
+    for (uint32_t h = 0; h < nh && fits; h++) {
+      fits = pack_wg_fits(B->model.kind, B->hist[h].n_ops, B->hist[h].n_events, B->hist[h].n_slots);
+      slots64 = slots64 && pack_wg64_fits(B->model.kind, B->hist[h].n_ops, B->hist[h].n_events, B->hist[h].n_slots);
+    }
+    if (fits) packed = counted = launch_pack_wg(make_pack_args(B), make_pack_open_args(B), s, slots64);
   }
   if (!packed) launch_pack(make_pack_args(B), s);
   HIP_TRY(hipGetLastError());

@@ -414,7 +414,8 @@ bool launch_pack_one(const PackArgs& a, void* stream);
 bool pack_one_counts_fits(uint32_t model_kind, uint32_t n_ops, uint32_t n_events, uint32_t n_slots);
 bool launch_pack_one_counts(const PackArgs& a, const PackOpenArgs& o, void* stream);      // (pack_one_kernel + open counts, one history or a handful)
 bool pack_wg_fits(uint32_t model_kind, uint32_t n_ops, uint32_t n_events, uint32_t n_slots);
-bool launch_pack_wg(const PackArgs& a, const PackOpenArgs& o, void* stream);
+bool pack_wg64_fits(uint32_t model_kind, uint32_t n_ops, uint32_t n_events, uint32_t n_slots);      // ... and has at most 64 process slots: the 19 KB geometry
+bool launch_pack_wg(const PackArgs& a, const PackOpenArgs& o, void* stream, bool slots64);
 // returns false if mw is unsupported
 bool launch_search(const SearchArgs& a, uint32_t mask_words, uint32_t n_blocks, void* stream);
 uint32_t search_frame_words(uint32_t mask_words);

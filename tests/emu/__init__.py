@@ -273,7 +273,7 @@ def pack_one_check(hists, model_kind=1, n_classes=0, count=False, per_launch=0, 
     return (what, int(diag[0]), int(diag[1]), int(diag[2]), int(diag[3]))
 
 
-def pack_wg_check(hists, model_kind=1, n_classes=0, vpad=8, count=False, branch=False, look=True, rk8=True, lst_cap=0, per_launch=0, seed=1, n_events=None, one=False):
+def pack_wg_check(hists, model_kind=1, n_classes=0, vpad=8, count=False, branch=False, look=True, rk8=True, lst_cap=0, per_launch=0, seed=1, n_events=None, one=False, slots64=False):
     """The batch form (csrc/pack_one_impl.h, BatchGeo: four wavefronts per history, pack + open counts in one pass) under the workgroup
     emulator: every word pack_kernel AND open_counts_kernel would leave -- as pack_one_check, plus off[], ncr[], slot8, rk8, the
     crashed-call list, the lookahead records past the last rank, BeamHist.status / n_crashed / lst_need -- against the restatements in
@@ -303,7 +303,7 @@ def pack_wg_check(hists, model_kind=1, n_classes=0, vpad=8, count=False, branch=
             n_events.append(int(max(int(i.max()) if len(i) else 0, int(live.max()) if len(live) else 0)) + 1)
     ne = np.ascontiguousarray(n_events, np.uint32)
     diag = np.zeros(8, np.uint64)
-    flags = (1 if count else 0) | (2 if branch else 0) | (4 if look else 0) | (8 if rk8 else 0) | (16 if one else 0)      # one: sixteen wavefronts (OneCountsGeo, TBC_PACK_ONE=2); lean: 8 B lookahead records (the pads)
+    flags = (1 if count else 0) | (2 if branch else 0) | (4 if look else 0) | (8 if rk8 else 0) | (16 if one else 0) | (64 if slots64 else 0)      # one: sixteen wavefronts (OneCountsGeo); slots64: Batch64Geo (at most 64 process slots, 19 KB)
     rc = _LIB_PACK.emu_pack_wg_check(C.c_uint32(nh), _p(op_off, C.c_uint64), _p(npr, C.c_uint32), _p(ne, C.c_uint32), _p(f, C.c_uint8), _p(a, C.c_int32),
                                      _p(b, C.c_int32), _p(pr, C.c_int32), _p(inv, C.c_uint32), _p(ret, C.c_uint32), C.c_uint32(model_kind),
                                      C.c_uint32(n_classes), C.c_uint32(vpad), C.c_uint32(flags), C.c_uint32(lst_cap), C.c_uint32(per_launch), C.c_uint64(seed), _p(diag, C.c_uint64))

@@ -333,10 +333,12 @@ static int pack_counts_check(uint32_t nh, const uint64_t* op_off, const uint32_t
 
 extern "C" {
 
-// flags bit 16: the one-history geometry with counts (OneCountsGeo, sixteen wavefronts) instead of the batch geometry
+// flags bit 16: the one-history geometry with counts (OneCountsGeo, sixteen wavefronts) instead of the batch geometry; bit 64: the batch
+// geometry for at most 64 process slots (Batch64Geo: a byte per histogram entry)
 int emu_pack_wg_check(uint32_t nh, const uint64_t* op_off, const uint32_t* n_process, const uint32_t* n_events, const uint8_t* f, const int32_t* a,
                       const int32_t* b, const int32_t* process, const uint32_t* inv_pos, const uint32_t* ret_pos, uint32_t model_kind,
                       uint32_t n_classes, uint32_t vpad, uint32_t flags, uint32_t lst_cap, uint32_t per_launch, uint64_t seed, uint64_t* diag) {
+  if (flags & 64u) return pack_counts_check<packone::Batch64Geo>(nh, op_off, n_process, n_events, f, a, b, process, inv_pos, ret_pos, model_kind, n_classes, vpad, flags, lst_cap, per_launch, seed, diag);
   if (flags & 16u) return pack_counts_check<packone::OneCountsGeo>(nh, op_off, n_process, n_events, f, a, b, process, inv_pos, ret_pos, model_kind, n_classes, vpad, flags, lst_cap, per_launch, seed, diag);
   return pack_counts_check<packone::BatchGeo>(nh, op_off, n_process, n_events, f, a, b, process, inv_pos, ret_pos, model_kind, n_classes, vpad, flags, lst_cap, per_launch, seed, diag);
 }

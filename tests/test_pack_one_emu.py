@@ -111,7 +111,7 @@ def test_histories_pack_refuses():
     assert emu.pack_one_check([d], n_events=[ne + 1000]) is None          # rows after the last op (nemesis lines): fine
 
 
-# ---- the batch form: four wavefronts per history, pack + open counts in one pass (BatchGeo; TBC_PACK_WG=1)
+# ---- the batch form: four wavefronts per history, pack + open counts in one pass (BatchGeo / Batch64Geo)
 @pytest.mark.parametrize("seed", [1, 2])
 @pytest.mark.parametrize("branch", [False, True])
 def test_batch_form_every_word_of_pack_and_open_counts(seed, branch):
@@ -141,6 +141,31 @@ def test_batch_form_full_size_histories():
     assert emu.pack_wg_check(h + busy, branch=True, seed=11) is None
     assert emu.pack_wg_check(h[:1] + crashed, branch=False, seed=12) is None
     assert emu.pack_wg_check(crashed, count=True, branch=True, seed=13) is None
+
+
+def test_batch_form_for_at_most_64_slots():
+    """Batch64Geo (what a batch of the narrow kernel's histories is packed by: a byte per histogram entry, 19 KB of LDS): all shapes with at
+    most 64 slots in both list forms, the bench histories, all 64 slots invoked between two completions (an entry of 64), crashed calls
+    in both forms, refused histories and a list arena too small"""
+    hs = [h for h in _hists() if h.n_process <= 64]
+    assert len(hs) >= 8
+    for branch in (False, True):
+        assert emu.pack_wg_check(hs, branch=branch, slots64=True, seed=1 + branch) is None
+    h = synth.register_ops_many(range(7000, 7002), n_ops=10000, n_procs=64, busy=0.1, info=0.0)
+    busy = synth.register_ops_many(range(7100, 7101), n_ops=10000, n_procs=64, busy=1.0, info=0.0)      # every process always in a call
+    crashed = synth.register_ops_many(range(7200, 7201), n_ops=10000, n_procs=56, busy=0.1, info=0.001)
+    assert all(x.n_process <= 64 for x in h + busy + crashed)
+    assert emu.pack_wg_check(h + busy, branch=True, slots64=True, seed=3) is None
+    assert emu.pack_wg_check(crashed + h[:1], branch=False, slots64=True, seed=4) is None
+    assert emu.pack_wg_check(crashed, count=True, branch=True, slots64=True, seed=5) is None
+    small = _hists(seeds=(4,), shapes=[(400, 12, 0.6, 0.02), (300, 16, 0.3, 0.0)])
+    assert emu.pack_wg_check(small, lst_cap=50, slots64=True, seed=6) is None
+    good = small[0]
+    e = _d(good); e["f"][33] = 77
+    assert emu.pack_wg_check([good, e, good], branch=True, slots64=True, seed=7) is None
+    wide = [x for x in _hists() if x.n_process > 64]
+    if wide:
+        assert emu.pack_wg_check(wide[:1], slots64=True) == ("does not fit", 0, 0, 0, 0) or emu.pack_wg_check(wide[:1], slots64=True)[0] == "does not fit"
 
 
 def test_batch_form_lists_that_do_not_fit_and_histories_pack_refuses():
@@ -175,7 +200,7 @@ def test_batch_form_crashed_calls_invoked_after_the_last_completion():
         assert emu.pack_wg_check([d, good], branch=branch, seed=1) is None
 
 
-# ---- the one-history form with open counts (OneCountsGeo: sixteen wavefronts; TBC_PACK_ONE=2)
+# ---- the one-history form with open counts (OneCountsGeo: sixteen wavefronts)
 def test_one_history_form_with_open_counts():
     """every word of pack and open counts by sixteen wavefronts: all shapes, both list forms, both crashed-call forms, many slots,
     a full-size history"""

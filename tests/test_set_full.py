@@ -196,6 +196,45 @@ def test_large_matrix_against_numpy(native):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("E,R", [(1000, 700), (4096 + 77, 3000), (130, 5000)])
+def test_rows_of_a_multiple_of_16_bytes_and_rows_that_are_not(native, E, R):
+    """the streaming pass takes four word columns a lane (16 B loads) when a row is a multiple of four words and one otherwise: the
+    same matrix at words_per_row = ceil(E / 32) rounded up to four, + 1, + 2 and + 3 -- the same three indices as numpy's, the
+    same bytes counted"""
+    rng = np.random.default_rng(E + R)
+    add_invoke = np.sort(rng.choice(4 * (E + R), E, replace=False)).astype(np.uint32) * 2
+    read_invoke = (np.sort(rng.choice(4 * (E + R), R, replace=False)).astype(np.uint32) * 2 + 1)
+    read_ok = read_invoke + rng.integers(1, 300, R).astype(np.uint32) * 2
+    add_ok = np.where(rng.random(E) < 0.05, N.NO_OP, add_invoke + rng.integers(1, 400, E).astype(np.uint32) * 2 + 1).astype(np.uint32)
+    vis = np.where(add_ok == N.NO_OP, add_invoke + 100, add_ok)
+    present = read_invoke[:, None] > vis[None, :]
+    present[R * 2 // 3:, rng.choice(E, max(1, E // 50), replace=False)] = False          # lost
+    present &= ~(rng.random((R, E)) < 0.002)                                               # holes anywhere
+    valid = read_ok[:, None] > add_invoke[None, :]
+    inv = read_invoke.astype(np.int64)[:, None]
+    lp = np.where(present & valid, inv, -1).max(axis=0)
+    la = np.where(~present & valid, inv, -1).max(axis=0)
+    kn = np.where(present & valid, read_ok.astype(np.int64)[:, None], 2 ** 40).min(axis=0)
+    kn = np.minimum(kn, np.where(add_ok == N.NO_OP, 2 ** 40, add_ok.astype(np.int64)))
+    w4 = (((E + 31) // 32) + 3) // 4 * 4
+    scanned = set()
+    for wpr in (w4, w4 + 1, w4 + 2, w4 + 3):
+        bits = np.zeros((R, wpr * 32), bool); bits[:, :E] = present
+        class A:
+            pass
+        a = A(); a.E, a.R, a.wpr = E, R, wpr
+        a.add_invoke, a.add_ok, a.read_invoke, a.read_ok = add_invoke, add_ok, read_invoke, read_ok
+        a.present = np.ascontiguousarray(np.packbits(bits, axis=1, bitorder="little").view(np.uint32))
+        with sf.Scan(a) as s:
+            st = s.run()
+        assert np.array_equal(np.where(st["last_present"] == N.NO_OP, -1, st["last_present"].astype(np.int64)), lp), wpr
+        assert np.array_equal(np.where(st["last_absent"] == N.NO_OP, -1, st["last_absent"].astype(np.int64)), la), wpr
+        assert np.array_equal(np.where(st["known"] == N.NO_OP, 2 ** 40, st["known"].astype(np.int64)), kn), wpr
+        scanned.add(int(st["bytes_scanned"]))
+    assert len(scanned) == 1, scanned
+
+
+@pytest.mark.gpu
 def test_more_than_256_chunks_of_reads(native):
     """n_reads > 256 * 2048: the resolve pass must consult every chunk's summary, not the first 256 (round 2 held four
     summaries per lane).  600,000 reads of 64 elements; the deciding rows lie in the LAST chunks: every element is

@@ -71,3 +71,9 @@ def test_lists_in_order_of_completion_every_word(by_ret):
     busy = synth.register_ops_many(range(7100, 7101), n_ops=10000, n_procs=64, busy=0.5, info=0.0)
     assert emu.walk_check(h + full + busy, 8, branch=True, front="compact", by_ret=by_ret) is None
     assert emu.walk_check(full[:1] + busy, 8, branch=False, front="plain", by_ret=by_ret) is None          # (the wide kernel's tables: plain rows, full lists)
+    # more than 128 candidates in a chunk (58 - 62 slots all busy + the 71 completions of the window), crashed calls among them: the
+    # three register sets of the keys, and crashed calls' keys above every live one
+    crowd = [columns.pair_events(synth.register_events(n_ops=400, n_procs=58, seed=s, busy=1.0, info=0.01)) for s in range(3)]
+    assert all(58 <= h.n_process <= 64 for h in crowd), [h.n_process for h in crowd]
+    assert emu.walk_check(crowd, 8, branch=True, front="compact", by_ret=by_ret) is None
+    assert emu.walk_check(crowd, 8, branch=False, front="plain", by_ret=by_ret) is None
