@@ -37,6 +37,8 @@ namespace {
 
 constexpr uint32_t kNoneU = 0xFFFFFFFFu;
 constexpr uint32_t kSetFullRows = 2048;      // rows per chunk at most (their metadata is staged in LDS)
+constexpr uint32_t kWordCounters = 256;      // the words-loaded statistic: a wavefront adds to counter (its workgroup mod 256), 128 B apart -- thousands of
+                                             // atomics on ONE address queue up in one L2 channel; the host adds the counters up
 
 __global__ __launch_bounds__(256) void setfull_prefix_kernel(const uint32_t* add_invoke, const uint32_t* read_ok, uint32_t E, uint32_t R,
                                                              uint32_t rows_per_chunk, uint32_t* P, uint32_t* pmax) {
@@ -74,16 +76,17 @@ __global__ __launch_bounds__(256) void setfull_rows_kernel(const uint32_t* __res
 
 // ---- pass 1: per (word column, chunk of rows) -- is any bit of the column present / absent in the chunk?  The streaming
 // pass.  VEC = 4: a lane takes FOUR consecutive word columns (16 B loads, a wavefront 1 KB of a row; rows of a multiple of four
-// words), four rows requested before the first is used; VEC = 1: one column, eight rows.  Nothing a load returns decides whether
+// words), VEC = 1: one column; four rows are requested while the four before them are used.  Nothing a load returns decides whether
 // the next is issued (a chunk is at most 2,048 rows: stopping at a saturated column saved nothing on set-full's matrices, where an
 // element is absent before its add and present after, and cost a round trip every eight rows); the chunk's row metadata in LDS,
-// coalesced words written per thread, no atomics.
+// no atomics.
+// (115 registers: four wavefronts a SIMD.  Asking for five -- all ~4,400 wavefronts above the diagonal resident at once -- spills 19 of them: 0.21 ms against 0.16)
 template <int VEC>
 __global__ __launch_bounds__(256) void setfull_any_kernel(const uint32_t* __restrict__ M, const uint32_t* __restrict__ P,
                                                           const uint32_t* __restrict__ pmax, uint32_t E, uint32_t R, uint32_t WPR,
-                                                          uint32_t rows_per_chunk, uint32_t* __restrict__ any_p, uint32_t* __restrict__ any_a,
-                                                          unsigned long long* words_loaded) {
-  constexpr uint32_t U = VEC == 1 ? 8u : 4u;            // rows in flight
+                                                          uint32_t rows_per_chunk, uint32_t CHP, uint32_t* __restrict__ any_p,
+                                                          uint32_t* __restrict__ any_a, unsigned long long* words_loaded) {
+  constexpr uint32_t U = 4u;                            // rows a set of registers holds (two sets: 4 .. 8 rows in flight, 16 B each at VEC = 4)
   const uint32_t w0 = (blockIdx.x * 256u + threadIdx.x) * (uint32_t)VEC, c = blockIdx.y;
   uint32_t loaded = 0;
   __shared__ uint32_t s_P[kSetFullRows];
@@ -99,21 +102,31 @@ __global__ __launch_bounds__(256) void setfull_any_kernel(const uint32_t* __rest
       full[v] = lo >= E ? 0u : (E - lo >= 32u ? 0xFFFFFFFFu : (1u << (E - lo)) - 1u);
     }
     if (pmax[c] > 32u * w0) {
-      for (uint32_t hi = r1; hi > r0;) {
-        const uint32_t lo8 = hi - r0 >= U ? hi - U : r0;
-        uint32_t wd[U][VEC], pr[U];
+      // rows [hi - U, hi) of the chunk (latest first; fewer at its start): requested ...
+      const auto fetch = [&](uint32_t hi, uint32_t (&wd)[U][VEC], uint32_t (&pr)[U]) {
+        const uint32_t lo = hi - r0 >= U ? hi - U : r0;
 #pragma unroll
         for (uint32_t q = 0; q < U; q++) {
           const uint32_t r = hi - 1u - q;
-          pr[q] = hi - lo8 > q ? s_P[r - r0] : 0u;                      // (0: no element of the row counts)
+          const bool in = hi - lo > q;
+          const uint32_t pv = s_P[in ? r - r0 : 0u];                    // (read either way: no branch between the loads)
+          pr[q] = in ? pv : 0u;                                         // (0: no element of the row counts)
           const bool need = pr[q] > 32u * w0 && full[0] != 0u;
+          // a row that does not count is not fetched -- but by an ADDRESS, not a branch: such a lane reads row 0's words (one hot line
+          // for the whole grid; the fold masks them out, vm = 0).  A branch around every load hides from the compiler how many loads
+          // are outstanding, and it then waits for ALL of them (s_waitcnt vmcnt(0)) before the fold: the rows requested ahead would
+          // be waited for at once, i.e. nothing would be ahead
+          const uint32_t* src = M + (need ? (uint64_t)r * WPR : 0ull) + w0;
           if constexpr (VEC == 4) {
-            const uint4 x = need ? *reinterpret_cast<const uint4*>(M + (uint64_t)r * WPR + w0) : make_uint4(0u, 0u, 0u, 0u);
+            const uint4 x = *reinterpret_cast<const uint4*>(src);
             wd[q][0] = x.x; wd[q][1] = x.y; wd[q][2] = x.z; wd[q][3] = x.w;
           } else {
-            wd[q][0] = need ? M[(uint64_t)r * WPR + w0] : 0u;
+            wd[q][0] = *src;
           }
         }
+      };
+      // ... and folded into the column's two words
+      const auto fold = [&](const uint32_t (&wd)[U][VEC], const uint32_t (&pr)[U]) {
 #pragma unroll
         for (uint32_t q = 0; q < U; q++) {
 #pragma unroll
@@ -122,26 +135,42 @@ __global__ __launch_bounds__(256) void setfull_any_kernel(const uint32_t* __rest
             pa[v] |= wd[q][v] & vm; aa[v] |= ~wd[q][v] & vm; loaded += vm ? 1u : 0u;
           }
         }
-        hi = lo8;
+      };
+      // two sets of registers: the next U rows are on their way while these are folded
+      uint32_t wa[U][VEC], pra[U], wb[U][VEC], prb[U];
+      uint32_t hi = r1;
+      if (hi > r0) {
+        fetch(hi, wa, pra);
+        hi = hi - r0 >= U ? hi - U : r0;
+        for (;;) {          // (a fold right behind ITS fetch on one straight path: the compiler then knows that U younger loads may stay out)
+          if (hi <= r0) { fold(wa, pra); break; }
+          fetch(hi, wb, prb); hi = hi - r0 >= U ? hi - U : r0;
+          fold(wa, pra);
+          if (hi <= r0) { fold(wb, prb); break; }
+          fetch(hi, wa, pra); hi = hi - r0 >= U ? hi - U : r0;
+          fold(wb, prb);
+        }
       }
     }
-    if constexpr (VEC == 4) {        // (WPR is a multiple of four: all four columns exist)
-      *reinterpret_cast<uint4*>(any_p + (uint64_t)c * WPR + w0) = make_uint4(pa[0], pa[1], pa[2], pa[3]);
-      *reinterpret_cast<uint4*>(any_a + (uint64_t)c * WPR + w0) = make_uint4(aa[0], aa[1], aa[2], aa[3]);
-    } else {
-      any_p[(uint64_t)c * WPR + w0] = pa[0];
-      any_a[(uint64_t)c * WPR + w0] = aa[0];
+    // the summaries lie COLUMN-major ([word column][chunk], CHP chunks a column): pass 2 reads a column's chunks, 64 at a time, as one
+    // 256 B line -- chunk-major (what this pass would write coalesced) cost it 64 sectors for 64 words, half of its traffic; here
+    // it is 4 B stores 4 * CHP apart, 16 MB of them against the 550 MB this pass reads
+#pragma unroll
+    for (int v = 0; v < VEC; v++) {        // (VEC = 4: WPR is a multiple of four, all four columns exist)
+      any_p[(uint64_t)(w0 + (uint32_t)v) * CHP + c] = pa[v];
+      any_a[(uint64_t)(w0 + (uint32_t)v) * CHP + c] = aa[v];
     }
   }
   unsigned long long tot = loaded;
   for (int d = 32; d >= 1; d >>= 1) tot += __shfl_xor(tot, d);
-  if ((threadIdx.x & 63u) == 0 && tot) atomicAdd(words_loaded, tot);
+  if ((threadIdx.x & 63u) == 0 && tot) atomicAdd(words_loaded + 16u * ((blockIdx.x + blockIdx.y * gridDim.x) % kWordCounters), tot);
 }
 
 // ---- pass 2: one WAVEFRONT per word column resolves its 32 elements.  The chunk summaries say WHICH chunk holds an
 // element's last present / last absent / first present read: lanes hold the summaries of 64 chunks each, a ballot finds
 // the deciding chunk, and that chunk is walked again with lane = row (64 rows loaded at once, one ballot per wanted bit
-// finds the row).  No atomics, no serial chain of loads.  lp1 / la1 hold invocation index + 1 (0 = none).
+// finds the row).  No atomics, no serial chain of loads.  Lane b < 32 keeps element b's three results in registers and writes
+// them once, in their final form (no index: TBC_NO_OP; known: the earlier of the add's ack and the first read that held it).
 __device__ __forceinline__ uint32_t wave_min_u32_all(uint32_t v) {
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, d));
@@ -149,18 +178,18 @@ __device__ __forceinline__ uint32_t wave_min_u32_all(uint32_t v) {
 }
 
 // walk chunk c from its latest row down, lane = row: for every bit of `want` find the latest row where the bit is present
-// (present = true) or absent; store read_invoke + 1 there; returns the bits found
+// (present = true) or absent; lane b keeps read_invoke + 1 of bit b's row in `res`; returns the bits found
 __device__ __forceinline__ uint32_t setfull_last_in_chunk(const uint32_t* __restrict__ M, const uint32_t* __restrict__ P,
                                                           const uint32_t* __restrict__ read_invoke, uint32_t WPR, uint32_t w, uint32_t full,
-                                                          uint32_t r0, uint32_t r1, uint32_t want, bool present, uint32_t* out1, uint32_t lane,
+                                                          uint32_t r0, uint32_t r1, uint32_t want, bool present, uint32_t& res, uint32_t lane,
                                                           uint32_t& loaded) {
   uint32_t found = 0;
   for (uint32_t hi = r1; hi > r0 && (want & ~found); hi = hi - r0 > 64u ? hi - 64u : r0) {
     const uint32_t base = hi - r0 > 64u ? hi - 64u : r0;       // rows [base, hi), lane l = row base + l
     const uint32_t r = base + lane;
     const bool in = r < hi;
+    const uint32_t word = in ? M[(uint64_t)r * WPR + w] : 0u;          // (not waiting for P[r] to say whether the row counts: one round trip a step, not two)
     const uint32_t valid = in ? prefix_mask(P[r], w) & full : 0u;
-    const uint32_t word = valid ? M[(uint64_t)r * WPR + w] : 0u;
     const uint32_t inv1 = in ? read_invoke[r] + 1u : 0u;
     loaded += valid ? 1u : 0u;
     const uint32_t x = (present ? word : ~word) & valid;
@@ -172,7 +201,7 @@ __device__ __forceinline__ uint32_t setfull_last_in_chunk(const uint32_t* __rest
       if (bal) {
         const uint32_t l = 63u - (uint32_t)__builtin_clzll(bal);
         const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)inv1, l);
-        if (lane == 0) out1[32u * w + b] = v;
+        if (lane == b) res = v;
         found |= 1u << b;
       }
     }
@@ -183,8 +212,9 @@ __device__ __forceinline__ uint32_t setfull_last_in_chunk(const uint32_t* __rest
 __global__ __launch_bounds__(256) void setfull_resolve_kernel(const uint32_t* __restrict__ M, const uint32_t* __restrict__ P,
                                                               const uint32_t* __restrict__ read_invoke, const uint32_t* __restrict__ read_ok,
                                                               const uint32_t* __restrict__ any_p, const uint32_t* __restrict__ any_a,
-                                                              uint32_t E, uint32_t R, uint32_t WPR, uint32_t rows_per_chunk, uint32_t chunks,
-                                                              uint32_t* lp1, uint32_t* la1, uint32_t* known, unsigned long long* words_loaded) {
+                                                              uint32_t E, uint32_t R, uint32_t WPR, uint32_t rows_per_chunk, uint32_t chunks, uint32_t CHP,
+                                                              const uint32_t* __restrict__ add_ok, uint32_t* lp, uint32_t* la, uint32_t* known,
+                                                              unsigned long long* words_loaded) {
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t w = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
   uint32_t loaded = 0;
@@ -200,25 +230,27 @@ __global__ __launch_bounds__(256) void setfull_resolve_kernel(const uint32_t* __
     for (uint32_t k = 0; k < 4u; k++) {
       const uint32_t cl = lane + 64u * k;
       const bool in = pre && cl < chunks;
-      sp[k] = in ? any_p[(uint64_t)cl * WPR + w] : 0u;
-      sa[k] = in ? any_a[(uint64_t)cl * WPR + w] : 0u;
+      sp[k] = in ? any_p[(uint64_t)w * CHP + cl] : 0u;
+      sa[k] = in ? any_a[(uint64_t)w * CHP + cl] : 0u;
     }
     const auto pick = [](const uint32_t (&r)[4], uint32_t gi) -> uint32_t { return gi == 0u ? r[0] : gi == 1u ? r[1] : gi == 2u ? r[2] : r[3]; };
     // last present / last absent: the latest chunk that has the bit decides; inside it, the latest row
+    uint32_t res_p = 0u, res_a = 0u;          // read_invoke + 1 of the element's last present / last absent read, 0 = none
 #pragma unroll
     for (int pass = 0; pass < 2; pass++) {
       const uint32_t* __restrict__ any = pass == 0 ? any_p : any_a;
+      uint32_t& res = pass == 0 ? res_p : res_a;
       uint32_t need = full;
       for (uint32_t gi = G; gi-- > 0 && need;) {
         const uint32_t cl = lane + 64u * gi;
-        const uint32_t mine = pre ? pick(pass == 0 ? sp : sa, gi) : (cl < chunks ? any[(uint64_t)cl * WPR + w] : 0u);
+        const uint32_t mine = pre ? pick(pass == 0 ? sp : sa, gi) : (cl < chunks ? any[(uint64_t)w * CHP + cl] : 0u);
         uint64_t cand = __ballot((mine & need) != 0u);
         while (cand && need) {
           const uint32_t l = 63u - (uint32_t)__builtin_clzll(cand);
           const uint32_t c = l + 64u * gi;
           const uint32_t mc = (uint32_t)__builtin_amdgcn_readlane((int)mine, l) & need;
           const uint32_t r0 = min(c * rows_per_chunk, R), r1 = min(r0 + rows_per_chunk, R);
-          (void)setfull_last_in_chunk(M, P, read_invoke, WPR, w, full, r0, r1, mc, pass == 0, pass == 0 ? lp1 : la1, lane, loaded);
+          (void)setfull_last_in_chunk(M, P, read_invoke, WPR, w, full, r0, r1, mc, pass == 0, res, lane, loaded);
           need &= ~mc;
           cand = __ballot((mine & need) != 0u) & ((1ull << l) - 1ull);
         }
@@ -231,24 +263,24 @@ __global__ __launch_bounds__(256) void setfull_resolve_kernel(const uint32_t* __
     uint32_t ever = 0, first_c = chunks;
     for (uint32_t gi = 0; gi < G; gi++) {
       const uint32_t cl = lane + 64u * gi;
-      uint32_t o = (pre ? pick(sp, gi) : (cl < chunks ? any_p[(uint64_t)cl * WPR + w] : 0u)) & full;
+      uint32_t o = (pre ? pick(sp, gi) : (cl < chunks ? any_p[(uint64_t)w * CHP + cl] : 0u)) & full;
       const uint64_t bl = __ballot(o != 0u);
       if (bl && first_c == chunks) first_c = (uint32_t)__builtin_ctzll(bl) + 64u * gi;
 #pragma unroll
       for (int d = 32; d >= 1; d >>= 1) o |= (uint32_t)__shfl_xor((int)o, d);
       ever |= o;
     }
+    uint32_t best = 0xFFFFFFFFu;                                // lane b < 32 keeps element b's minimum
     if (ever) {
       uint32_t seen = 0, until = 0;
-      uint32_t best = 0xFFFFFFFFu;                              // lane b < 32 keeps element b's minimum
       for (uint32_t base = first_c * rows_per_chunk; base < R; base += 64u) {
         const uint32_t r = base + lane;
         const bool in = r < R;
         const uint32_t inv = in ? read_invoke[r] : 0xFFFFFFFFu;
         const uint32_t inv_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)inv);
         if (seen == ever && inv_first > until) break;
+        const uint32_t word = in ? M[(uint64_t)r * WPR + w] : 0u;
         const uint32_t valid = in ? prefix_mask(P[r], w) & full : 0u;
-        const uint32_t word = valid ? M[(uint64_t)r * WPR + w] : 0u;
         const uint32_t ok = in ? read_ok[r] : 0xFFFFFFFFu;
         loaded += valid ? 1u : 0u;
         const uint32_t hits = word & valid;
@@ -265,12 +297,17 @@ __global__ __launch_bounds__(256) void setfull_resolve_kernel(const uint32_t* __
         }
         seen |= any_hits;
       }
-      if (lane < 32u && ((ever >> lane) & 1u)) known[32u * w + lane] = min(known[32u * w + lane], best);
+    }
+    if (lane < 32u) {                                           // (the arrays are padded to whole word columns)
+      const uint32_t e = 32u * w + lane;
+      lp[e] = res_p ? res_p - 1u : kNoneU;
+      la[e] = res_a ? res_a - 1u : kNoneU;
+      known[e] = min(best, e < E ? add_ok[e] : kNoneU);
     }
   }
   unsigned long long tot = loaded;
   for (int d = 32; d >= 1; d >>= 1) tot += __shfl_xor(tot, d);
-  if ((threadIdx.x & 63u) == 0 && tot) atomicAdd(words_loaded, tot);
+  if ((threadIdx.x & 63u) == 0 && tot) atomicAdd(words_loaded + 16u * (blockIdx.x % kWordCounters), tot);
 }
 
 __global__ __launch_bounds__(256) void setfull_finish_kernel(uint32_t* lp1, uint32_t* la1, uint32_t* known, const uint32_t* add_ok, uint32_t E) {
@@ -294,10 +331,11 @@ __global__ __launch_bounds__(256) void setfull_finish_kernel(uint32_t* lp1, uint
 
 struct tbc_setfull {
   int device = 0;
-  uint32_t E = 0, R = 0, WPR = 0, chunks = 1, rows_per_chunk = 1;
+  uint32_t E = 0, R = 0, WPR = 0, chunks = 1, rows_per_chunk = 1, chp = 64;      // chp: chunks rounded up to 64 (a column of the summaries)
   uint32_t *d_add_invoke = nullptr, *d_add_ok = nullptr, *d_read_invoke = nullptr, *d_read_ok = nullptr, *d_M = nullptr;
   uint32_t *d_P = nullptr, *d_pmax = nullptr, *d_lp = nullptr, *d_la = nullptr, *d_known = nullptr, *d_anyp = nullptr, *d_anya = nullptr;
   unsigned long long* d_words = nullptr;
+  unsigned long long h_words[kWordCounters * 16] = {};
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   ~tbc_setfull() {
@@ -350,8 +388,10 @@ static tbc_status setfull_create_impl(const tbc_setfull_in* in, tbc_setfull* S, 
   SF_TRY(hipMalloc((void**)&S->d_M, m4)); SF_TRY(hipMalloc((void**)&S->d_P, r4)); SF_TRY(hipMalloc((void**)&S->d_pmax, (size_t)S->chunks * 4));
   const size_t ew = (size_t)std::max(1u, S->WPR) * 32 * 4;       // per-element outputs padded to whole words
   SF_TRY(hipMalloc((void**)&S->d_lp, ew)); SF_TRY(hipMalloc((void**)&S->d_la, ew)); SF_TRY(hipMalloc((void**)&S->d_known, ew));
-  SF_TRY(hipMalloc((void**)&S->d_words, 8));
-  SF_TRY(hipMalloc((void**)&S->d_anyp, (size_t)S->chunks * std::max(1u, S->WPR) * 4)); SF_TRY(hipMalloc((void**)&S->d_anya, (size_t)S->chunks * std::max(1u, S->WPR) * 4));
+  SF_TRY(hipMalloc((void**)&S->d_words, (size_t)kWordCounters * 128));
+  S->chp = (S->chunks + 63u) / 64u * 64u;
+  const size_t any4 = (size_t)S->chp * std::max(1u, S->WPR) * 4;
+  SF_TRY(hipMalloc((void**)&S->d_anyp, any4)); SF_TRY(hipMalloc((void**)&S->d_anya, any4));
   SF_TRY(hipStreamCreateWithFlags(&S->stream, hipStreamNonBlocking));
   SF_TRY(hipEventCreate(&S->ev0)); SF_TRY(hipEventCreate(&S->ev1));
   if (S->E) {
@@ -385,6 +425,7 @@ static tbc_status setfull_create_impl(const tbc_setfull_in* in, tbc_setfull* S, 
   }
   // p[r] (how many elements had been invoked when read r completed) and the chunks' maxima depend on the inputs only
   SF_TRY(hipMemsetAsync(S->d_pmax, 0, (size_t)S->chunks * 4, S->stream));
+  SF_TRY(hipMemsetAsync(S->d_anyp, 0, any4, S->stream)); SF_TRY(hipMemsetAsync(S->d_anya, 0, any4, S->stream));      // (the padding of a column is never written)
   if (S->R && S->E)
     hipLaunchKernelGGL(setfull_prefix_kernel, dim3((S->R + 255) / 256), dim3(256), 0, S->stream, S->d_add_invoke, S->d_read_ok, S->E, S->R,
                        S->rows_per_chunk, S->d_P, S->d_pmax);
@@ -416,19 +457,20 @@ tbc_status tbc_setfull_run(tbc_setfull* S, tbc_setfull_out* out) {
   const size_t ew = (size_t)std::max(1u, S->WPR) * 32 * 4;
   SF_TRY(hipMemsetAsync(S->d_lp, 0, ew, s)); SF_TRY(hipMemsetAsync(S->d_la, 0, ew, s));
   SF_TRY(hipMemsetAsync(S->d_known, 0xFF, ew, s));
-  SF_TRY(hipMemsetAsync(S->d_words, 0, 8, s));
+  SF_TRY(hipMemsetAsync(S->d_words, 0, (size_t)kWordCounters * 128, s));
   SF_TRY(hipEventRecord(S->ev0, s));
   if (S->R && S->E) {
     if (S->WPR % 4u == 0u)      // (hipMalloc'ed arrays, rows of a multiple of four words: every 16 B load and store is aligned)
       hipLaunchKernelGGL(setfull_any_kernel<4>, dim3((S->WPR / 4u + 255) / 256, S->chunks), dim3(256), 0, s, S->d_M, S->d_P, S->d_pmax, S->E, S->R, S->WPR,
-                         S->rows_per_chunk, S->d_anyp, S->d_anya, S->d_words);
+                         S->rows_per_chunk, S->chp, S->d_anyp, S->d_anya, S->d_words);
     else
       hipLaunchKernelGGL(setfull_any_kernel<1>, dim3((S->WPR + 255) / 256, S->chunks), dim3(256), 0, s, S->d_M, S->d_P, S->d_pmax, S->E, S->R, S->WPR,
-                         S->rows_per_chunk, S->d_anyp, S->d_anya, S->d_words);
+                         S->rows_per_chunk, S->chp, S->d_anyp, S->d_anya, S->d_words);
     hipLaunchKernelGGL(setfull_resolve_kernel, dim3((S->WPR + 3) / 4), dim3(256), 0, s, S->d_M, S->d_P, S->d_read_invoke, S->d_read_ok, S->d_anyp,
-                       S->d_anya, S->E, S->R, S->WPR, S->rows_per_chunk, S->chunks, S->d_lp, S->d_la, S->d_known, S->d_words);
+                       S->d_anya, S->E, S->R, S->WPR, S->rows_per_chunk, S->chunks, S->chp, S->d_add_ok, S->d_lp, S->d_la, S->d_known, S->d_words);
+  } else if (S->E) {        // no read at all: nothing was seen, known = the add's ack
+    hipLaunchKernelGGL(setfull_finish_kernel, dim3((S->E + 255) / 256), dim3(256), 0, s, S->d_lp, S->d_la, S->d_known, S->d_add_ok, S->E);
   }
-  if (S->E) hipLaunchKernelGGL(setfull_finish_kernel, dim3((S->E + 255) / 256), dim3(256), 0, s, S->d_lp, S->d_la, S->d_known, S->d_add_ok, S->E);
   SF_TRY(hipGetLastError());
   SF_TRY(hipEventRecord(S->ev1, s));
   unsigned long long words = 0;
@@ -437,11 +479,13 @@ tbc_status tbc_setfull_run(tbc_setfull* S, tbc_setfull_out* out) {
     SF_TRY(hipMemcpyAsync(out->last_present, S->d_lp, (size_t)S->E * 4, hipMemcpyDeviceToHost, s));
     SF_TRY(hipMemcpyAsync(out->last_absent, S->d_la, (size_t)S->E * 4, hipMemcpyDeviceToHost, s));
   }
-  SF_TRY(hipMemcpyAsync(&words, S->d_words, 8, hipMemcpyDeviceToHost, s));
+  unsigned long long* counters = S->h_words;
+  SF_TRY(hipMemcpyAsync(counters, S->d_words, (size_t)kWordCounters * 128, hipMemcpyDeviceToHost, s));
   SF_TRY(hipStreamSynchronize(s));
   float ms = 0;
   SF_TRY(hipEventElapsedTime(&ms, S->ev0, S->ev1));
   out->ns_scan = (uint64_t)(ms * 1e6);
+  for (uint32_t k = 0; k < kWordCounters; k++) words += counters[16u * k];
   out->bytes_scanned = (uint64_t)words * 4;
   out->bytes_matrix = (uint64_t)S->R * S->WPR * 4;
   return TBC_OK;
