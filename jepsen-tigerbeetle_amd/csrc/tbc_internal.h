@@ -269,12 +269,12 @@ struct PackOpenArgs {
   uint32_t vpad;
   uint32_t h0;               // histories [h0, n_hist) are worked on by this launch
   const uint64_t* cmem;      // count form: class members (inv_rank | op << 32), or null
-  uint32_t list_order;       // 0 = a front's list in process-slot order; 1 = in order of completion (the walk with lane = front only; experimental,
-                             // TBC_NARROW_ORDER=1): the search takes a config's candidates last to first and pops the last child first, so the call
+  uint32_t list_order;       // 0 = a front's list in process-slot order; 1 = in order of completion (the walk with lane = front only;
+                             // tbc_opts.list_order TBC_ORDER_COMPLETION): the search takes a config's candidates last to first and pops the last child first, so the call
                              // that completes soonest is tried first -- on the bench workload 18 % fewer rounds for the same probes, the longest
                              // history 31 % fewer (oracle/wgl_beam.c, wgl_beam_set_list_order(1))
-                             // 2 = in order of completion, the :write calls after everything else (TBC_NARROW_ORDER=2; the oracle's list order 4)
-                             // 16 + W = in order of completion, a :write as if it completed W ranks later (the oracle's list order 16 + W)
+                             // 2 = in order of completion, the :write calls after everything else (TBC_ORDER_WRITES_LAST; the oracle's list order 4)
+                             // 16 + W = in order of completion, a :write as if it completed W ranks later (the oracle's list order 16 + W); 16 + 24 is the library's default
 };
 
 // byte offset of history h's slot8[] (n_ret entries + 16 of padding), 8-byte aligned

@@ -19,7 +19,7 @@ CAS = {"kind": 1, "init": N.NIL}
 def expand_chain(d, chain, model, eager, branch=False, completion_order=False):
     """The chain of branching calls replayed from the initial state, absorbing reads as the search does (a third
     formulation, besides oracle/wgl_beam.c's and tbc_api.hip's expand_eager_witness).  branch: the root starts in normal
-    form (its own reads come first).  completion_order: the lists are in order of completion (TBC_NARROW_ORDER), not by slot."""
+    form (its own reads come first).  completion_order: the lists are in order of completion (tbc_opts.list_order), not by slot."""
     if not eager:
         return [int(x) for x in chain]
     f, a, b, proc = (np.asarray(d[k]) for k in ("f", "a", "b", "process"))

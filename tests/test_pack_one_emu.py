@@ -1,5 +1,5 @@
 """K1 for one history -- pack by a workgroup's sixteen wavefronts (csrc/pack_one_impl.h, the file hipcc compiles into libtbcheck.so;
-TBC_PACK_ONE=1 selects it for tbc_check) -- on the CPU under the workgroup emulator of tests/emu, against a restatement of what
+what tbc_check packs one history with) -- on the CPU under the workgroup emulator of tests/emu, against a restatement of what
 pack.hip's header defines (tests/emu/emu_pack.cpp): every record and sentinel, list start, completion table entry, rank and place in
 the scratch arena, n_ret and status, word for word, under several seeded interleavings of the wavefronts.  Test infrastructure
 only: the product has no CPU path."""
