@@ -2,7 +2,8 @@
 small batches -- sizes around the chunk and wavefront boundaries, crashed calls in both forms, a broken row in one history of five
 (invocations out of order, a live call of an unknown process, an op the model does not know, two completions on one row), list
 arenas too small -- every word against the restatements (tests/emu/emu_pack.cpp, host_tables.h).  usage: fuzz_pack_emu.py [rounds] [seed]
-Round 4: 400 rounds x 3 forms, no mismatch (the one it found was the harness's own: host_tables.h indexed by an unknown process)."""
+Round 4: 400 rounds x 3 forms, no mismatch (the one it found was the harness's own: host_tables.h indexed by an unknown process).
+Round 5: + the 64-slot batch geometry (Batch64Geo) in the mask and the count form."""
 import os, random, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -39,8 +40,12 @@ for it in range(rounds):
     if not hs:
         continue
     cap = rng.choice([0, 0, 0, 40, 400])
-    for kw in ({"branch": bool(it & 1), "lst_cap": cap}, {"count": True, "branch": bool(it & 2)}, {"one": True, "branch": True, "lst_cap": cap}):
-        r = emu.pack_wg_check(hs, seed=it, per_launch=rng.choice([0, 1, 4]), **kw)
+    hs64 = [d for d in hs if d["n_process"] <= 64]              # Batch64Geo: at most 64 process slots (a crashed call of the mask form takes one)
+    for kw in ({"branch": bool(it & 1), "lst_cap": cap}, {"count": True, "branch": bool(it & 2)}, {"one": True, "branch": True, "lst_cap": cap},
+               {"slots64": True, "branch": bool(it & 1), "lst_cap": cap}, {"slots64": True, "count": True, "branch": bool(it & 2)}):
+        if kw.get("slots64") and not hs64:
+            continue
+        r = emu.pack_wg_check(hs64 if kw.get("slots64") else hs, seed=it, per_launch=rng.choice([0, 1, 4]), **kw)
         if r is not None:
             bad += 1
             print("MISMATCH", it, kw, r, flush=True)
