@@ -321,6 +321,12 @@ def compact_line(line):
         out["cpu_baseline"] = c
     ex, e = line.get("extra", {}), {}
     e.update(_pick(ex, "valid", "unknown", "device_GB_per_batch", "h2d_inclusive_hist_per_s"))
+    fi = ex.get("fresh_input")
+    if isinstance(fi, dict):          # every step consumes histories the device has never seen (PCIe copy + unpack + pack + search): first-class beside `value`
+        e["fresh_input"] = _pick(fi, "histories_per_s", "steps", "ms_per_step", "pcie_GB_per_input", "pcie_GB_s_over_the_timed_region", "pcie_GB_s_while_copying", "pcie_peak_GB_s")
+        ru = fi.get("re_uploaded")
+        if isinstance(ru, dict):
+            e["fresh_input"]["re_uploaded"] = _pick(ru, "histories_per_s", "steps", "pcie_GB_s_over_the_timed_region")
     if "device_ms" in ex:
         e["device_ms"] = _pick(ex["device_ms"], "init_memsets", "pack", "search", "retries", "search_waiting_for_its_turn")
     if "one_batch_at_a_time" in ex:
@@ -440,6 +446,10 @@ def main():
     ap.add_argument("--batch3", type=int, default=8192, help="third workload: histories per GPU")
     ap.add_argument("--info4", type=float, default=0.01, help="a batch of the headline workload with this share of crashed (:info) calls (0 = skip)")
     ap.add_argument("--batch4", type=int, default=8192, help="crashed workload: histories per GPU")
+    ap.add_argument("--fresh-batches", type=int, default=int(os.environ.get("TBC_BENCH_FRESH", "4")),
+                    help="extra.fresh_input: this many MORE batches of --batch histories each are generated on the host and written, in wire format, "
+                         "into the resident batches' pinned slots; every step of that leg copies its input over PCIe, unpacks, packs and searches it "
+                         "(tbc_batch_submit_input + tbc_batch_run) -- the rate a caller who checks every history once gets.  0 = skip")
     ap.add_argument("--no-tiers", action="store_true", help="skip the crashed-op tiers (extra.tiers)")
     ap.add_argument("--no-set-full", action="store_true", help="skip the checker/set-full scan (extra.set_full)")
     ap.add_argument("--no-cpu", action="store_true")
@@ -462,6 +472,7 @@ def main():
     if args.only_headline:
         args.no_cpu = args.no_tiers = args.no_set_full = True
         args.busy2 = args.busy3 = args.info4 = 0.0
+        args.fresh_batches = 0
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -486,6 +497,7 @@ def main():
     else:
         args.only_headline = args.no_cpu = args.no_tiers = args.no_set_full = True
         args.busy2 = args.busy3 = args.info4 = 0.0
+        args.fresh_batches = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if on_gpu:
@@ -585,6 +597,98 @@ def main():
         barrier()
         alone = (shard.max_over_ranks((time.perf_counter() - ta0) / 3, world, dist), tma)
 
+    # ---- FRESH INPUTS (include/tbcheck.h "streaming"; csrc/batch_stream.hip): what a caller who checks every history ONCE gets -- the
+    # reference's call pattern (checker/compose over the test's one history, core.clj:139-146; independent/checker per key,
+    # set_full.clj:155-158).  The resident batches keep their arenas; G more batches of histories the device has never seen are generated
+    # on the host and written in wire format (12 B an op) into the batches' pinned slots BEFORE the clock starts (the host's encoding
+    # of its histories is the caller's work, as marshal_s is for the resident line); every timed step then submits one slot (PCIe copy on
+    # the batch's copy stream, under the other passes) and runs it: unpack, pack, search, verdicts back.  Each batch object has its own
+    # host thread, as in the headline.  `never_seen`: each of the G inputs consumed exactly once.  `re_uploaded`: the same G host batches
+    # taken round-robin for 3 G more steps -- every step still copies, unpacks and packs its input from scratch (nothing of an earlier
+    # pass is reused on the device: the tables are rebuilt, the visited sets are another epoch's).  Never `value`.
+    fresh = None
+    G = (args.fresh_batches // F) * F
+    if G > 0 and on_gpu and narrow:
+        per = G // F
+        fresh_verdicts = {}
+        fresh_infos = []
+        def fresh_passes(k, order, keep):
+            b = batches[k]
+            b.map_input(order[0])                       # (waits for the slot's previous copy; the slot is not re-written)
+            b.submit_input(order[0], B)
+            for i, sl in enumerate(order):
+                if i + 1 < len(order):
+                    b.map_input(order[i + 1])
+                    b.submit_input(order[i + 1], B)
+                b.run()
+                fresh_infos.append(b.input_info())
+                if keep:
+                    fresh_verdicts[(k, sl)] = b.verdicts()
+        def fresh_round(orders, keep):
+            th = [threading.Thread(target=fresh_passes, args=(k, orders[k], keep)) for k in range(F)]
+            for x in th: x.start()
+            for x in th: x.join()
+        # warm-up: every batch object's OWN resident histories through the wire (slot 0) -- the arenas' one-time growth and the first
+        # unpack are not in the clock, and a reloaded resident batch must answer as it did
+        leg("fresh inputs: warm-up (the resident histories through the wire)")
+        t_enc = time.perf_counter()
+        for k in range(F):
+            batches[k]._cols = None                     # (the binding's concatenated columns: the library copied them at create)
+            batches[k].fill_input(0, hists_all[k])
+        t_enc = (time.perf_counter() - t_enc) / F
+        fresh_round([[0] for _ in range(F)], True)
+        for k in range(F):
+            v = fresh_verdicts[(k, 0)]
+            assert int(v[planted]) == N.INVALID and bool((np.delete(v, planted) == N.VALID).all()), "a reloaded resident batch answers differently"
+        leg("fresh inputs: generating and encoding %d more batches" % G)
+        t_fgen = time.perf_counter()
+        fseeds = shard.shard_indices(G * B * world, rank, world) + F * B * world          # seeds past the resident batches'
+        fresh_sample = None
+        for g in range(G):
+            hs = synth.register_ops_many(fseeds[g * B:(g + 1) * B], n_ops=args.ops, n_procs=args.procs, busy=args.busy, info=args.info)
+            hp = columns.pair_events(synth.register_events(n_ops=args.ops, n_procs=args.procs, seed=int(fseeds[g * B + planted]), busy=args.busy,
+                                                           info=args.info, corrupt=0.02, n_values=4))
+            hp.a[hp.a == 4 + 7] = 4
+            hs[planted] = hp
+            batches[g // per].fill_input(g % per, hs)          # (in wire format, in place in the pinned slot; the set itself is dropped)
+            if g == 0:
+                fresh_sample = hs[:8]
+            del hs
+        t_fgen = time.perf_counter() - t_fgen
+        fresh_infos.clear()
+        leg("fresh inputs: timed (never seen)")
+        barrier()
+        tf0 = time.perf_counter()
+        fresh_round([list(range(per)) for _ in range(F)], True)
+        barrier()
+        t_never = shard.max_over_ranks(time.perf_counter() - tf0, world, dist)
+        infos_never = list(fresh_infos)
+        for k in range(F):
+            for j in range(per):
+                v = fresh_verdicts[(k, j)]
+                assert int(v[planted]) == N.INVALID and bool((np.delete(v, planted) == N.VALID).all()), "a fresh input's verdict is not where it belongs"
+        leg("fresh inputs: timed (re-uploaded round-robin)")
+        fresh_infos.clear()
+        barrier()
+        tf0 = time.perf_counter()
+        fresh_round([[j % per for j in range(3 * per)] for _ in range(F)], False)
+        barrier()
+        t_again = shard.max_over_ranks(time.perf_counter() - tf0, world, dist)
+        infos_again = list(fresh_infos)
+        gb = lambda infos: sum(i["bytes_copied"] for i in infos) / 1e9
+        copy_rate = lambda infos: round(statistics.mean(i["bytes_copied"] / max(1, i["ns_copy"]) for i in infos), 2)
+        fresh = {"histories_per_s": round(G * B * world / t_never, 2), "unit": "histories/s", "steps": G, "ms_per_step": round(t_never / G * 1e3, 3),
+                 "what": f"{G} batches of {B} histories the device had never seen, each consumed once: PCIe copy of the wire columns (12 B an op) + unpack + pack + search + verdicts; "
+                         f"{F} batch objects on {F} host threads, each input's copy queued before the previous input's run",
+                 "pcie_GB_per_input": round(gb(infos_never) / max(1, len(infos_never)), 3),
+                 "pcie_GB_s_over_the_timed_region": round(gb(infos_never) * world / t_never, 2),
+                 "pcie_GB_s_while_copying": copy_rate(infos_never), "pcie_peak_GB_s": 63.0,
+                 "re_uploaded": {"histories_per_s": round(3 * G * B * world / t_again, 2), "steps": 3 * G, "ms_per_step": round(t_again / (3 * G) * 1e3, 3),
+                                 "pcie_GB_s_over_the_timed_region": round(gb(infos_again) * world / t_again, 2), "pcie_GB_s_while_copying": copy_rate(infos_again),
+                                 "what": "the same host batches round-robin: every step copies, unpacks and packs its input again (nothing of an earlier pass is reused on the device)"},
+                 "lists_regrown": max(i["lists_regrown"] for i in infos_never + infos_again),
+                 "host_gen_and_encode_s": round(t_fgen, 2), "host_encode_s_per_batch": round(t_enc, 2), "device_GB_per_batch_after": round(batch.device_bytes() / 1e9, 3)}
+
     sharded_ms = None
     if world > 1 and args.sharded_ttv:
         o_lin = core.make_opts(device=local_rank, want_witness=False, algorithm=N.ALG_LINEAR)
@@ -675,6 +779,8 @@ def main():
                 "device_ms": {k2: round(statistics.mean(tm[k1] for tm in tma) / 1e6, 3) for k1, k2 in (("init", "init_memsets"), ("pack", "pack"), ("search", "search"), ("retries", "retries"))},
                 "roofline_frac": round(alg_bytes / (statistics.mean(tm["search"] for tm in tma) * 1e-9) / 1e9 / HBM_PEAK_GBS, 6),
                 "note": "the resident batch 0 alone, 3 passes back to back right after the timed region"}
+        if fresh is not None:
+            line["extra"]["fresh_input"] = fresh
         if sharded_ms is not None:
             line["extra"]["one_history_over_all_gpus"] = sharded_ms
         # time-to-verdict for ONE history through tbc_check (host columns in -> verdict out: H2D + kernels + D2H), rank 0.
@@ -806,6 +912,9 @@ def main():
             assert okw == oks == ok1 == S1 and all(int(v) == N.VALID for v in verdicts[:S1]), "GPU and oracles disagree on the sample"
             assert [int(v) for v in oka[:S]] == [int(v) for v in verdicts[:S]], "GPU and oracle disagree on the sample"
             assert [int(v) for v in okwa[:S]] == [int(v) for v in verdicts[:S]], "GPU and oracle (wide schedule, thread pool) disagree on the sample"
+            if fresh is not None:          # the first eight histories of the first never-seen input, history by history
+                for i, h in enumerate(fresh_sample):
+                    assert wgl.check(h.as_dict(), om, "window", want_witness=False)["valid"] == int(fresh_verdicts[(0, 0)][i]), "a fresh input: GPU and oracle disagree"
             rp = wgl.check(hists[planted].as_dict(), om, "window", want_witness=False, max_steps=50_000_000)
             assert rp["valid"] == 0 == int(verdicts[planted]), "GPU and oracle disagree on the planted history"
             rgp = core.check_ops(hists[planted], model, o_sweep)

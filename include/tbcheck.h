@@ -468,6 +468,70 @@ tbc_status tbc_batch_sweep_finish(tbc_batch* b, const void* merged, uint64_t mer
 tbc_status tbc_batch_sweep_merge(tbc_batch* b, const void* gathered_device, uint64_t gathered_bytes, uint32_t world, tbc_result* results);
 void tbc_batch_destroy(tbc_batch* b);
 
+/* ------------------------------------------------ streaming: the same batch, fresh histories
+ *
+ * The reference calls a checker ONCE per history: checker/compose over the test's one history
+ * (/root/reference/src/tigerbeetle/core.clj:139-146), jepsen.independent/checker once per key
+ * (/root/reference/src/tigerbeetle/workloads/set_full.clj:155-158).  A caller that checks many histories
+ * never checks one twice, and creating a batch per input pays for 85 GB of allocation, the op columns
+ * over PCIe from pageable memory and a sizing pass every time (round 5: 12-22k histories/s against 321k
+ * resident).  These entry points keep a batch -- arenas, streams, the decisions tbc_batch_create made --
+ * and change its histories:
+ *
+ *   tbc_batch_map_input     a slot of library-owned PINNED host memory for the caller to fill IN PLACE (a JNA
+ *                           Memory / direct ByteBuffer / numpy view over it): no copy inside the library
+ *   tbc_batch_submit_input  queues the slot's copy to the device on the batch's copy stream and returns; it runs
+ *                           under whatever the batch (or another batch) is computing.  Up to two inputs may wait.
+ *   tbc_batch_run           consumes the oldest waiting input, if any (else the resident input once more): waits
+ *                           for its copy, unpacks it on the device, packs, searches.  results: n_hist of THAT input.
+ *   tbc_batch_reload        convenience: the six columns of a tbc_batch_desc -> wire format -> slot 0 / 1 -> submitted
+ *
+ * WIRE FORMAT, 12 B an op (21 B in tbc_ops): word = f | a << 4 | b << 12 | process << 20 (f 4 bits; a, b 8 bits:
+ * 0..254 or TBC_WIRE_NIL; process 12 bits), inv_pos, ret_pos as in tbc_ops.  Register / cas-register / mutex.
+ *
+ * What a fresh input must share with the input the batch was created from (else TBC_ERR_UNSUPPORTED from the call
+ * that finds out -- tbc_batch_submit_input or the tbc_batch_run that consumes it -- and the caller destroys and
+ * creates): at most the first input's number of histories and an eighth more than its ops; process slots within the
+ * batch's mask words; register values within the batch's value domain (the greatest value of the first input,
+ * when the dominance rules are on); no crashed call if the first input had none.  Batches of the level sweep, of
+ * the count form, of set / bank / multi-register / table models and the sequential schedule take no fresh inputs.
+ * Verdict, failing op and every counter of a consumed input equal those of a batch created from the same histories
+ * (tests/test_stream_gpu.py).
+ */
+#define TBC_WIRE_NIL 0xFFu
+#define TBC_WIRE_WORD(f, a8, b8, process) ((uint32_t)(f) | ((uint32_t)(a8) << 4) | ((uint32_t)(b8) << 12) | ((uint32_t)(process) << 20))
+
+typedef struct tbc_batch_input {   /* pointers into one pinned slot; valid until the batch is destroyed */
+  uint32_t n_hist_cap;            /* histories the slot holds at most                              */
+  uint32_t reserved0;
+  uint64_t ops_cap;               /* ops the slot holds at most                                    */
+  uint64_t* op_off;               /* [n_hist_cap + 1] as tbc_batch_desc.op_off                     */
+  uint32_t* n_events;             /* [n_hist_cap]                                                  */
+  uint32_t* n_process;            /* [n_hist_cap]                                                  */
+  uint32_t* word;                 /* [ops_cap] TBC_WIRE_WORD(f, a, b, process)                     */
+  uint32_t* inv_pos;              /* [ops_cap]                                                     */
+  uint32_t* ret_pos;              /* [ops_cap] TBC_POS_CRASHED = never completed                   */
+} tbc_batch_input;
+
+/* slot < 16; allocated when first mapped.  Waits until the slot's previous input has left for the device. */
+tbc_status tbc_batch_map_input(tbc_batch* b, uint32_t slot, tbc_batch_input* out);
+/* the slot holds n_hist histories (op_off[0..n_hist], n_events, n_process, the wire columns): copy them, asynchronously */
+tbc_status tbc_batch_submit_input(tbc_batch* b, uint32_t slot, uint32_t n_hist);
+tbc_status tbc_batch_reload(tbc_batch* b, const tbc_batch_desc* desc);
+
+typedef struct tbc_input_info {
+  uint32_t n_hist;                /* histories of the resident input (what tbc_batch_run's results hold) */
+  uint32_t pending;               /* submitted inputs not yet consumed                                  */
+  uint64_t total_ops;             /* ops of the resident input                                          */
+  uint64_t bytes_copied;          /* last consumed input: bytes that crossed PCIe ...                   */
+  uint64_t ns_copy;               /* ... and how long the copy took (HIP events on the copy stream)     */
+  uint64_t inputs_consumed;
+  uint32_t lists_regrown;         /* times an input's per-front lists outgrew their arena               */
+  uint32_t n_hist_cap;
+  uint64_t ops_cap;
+} tbc_input_info;
+tbc_status tbc_batch_input_info(const tbc_batch* b, tbc_input_info* out);
+
 /* ----------------------------------------------------------------- memo
  *
  * knossos.model.memo/memo for a caller-defined model: given the closure

@@ -141,6 +141,22 @@ class SetFullOut(C.Structure):
                 ("ns_scan", C.c_uint64), ("bytes_scanned", C.c_uint64), ("bytes_matrix", C.c_uint64)]
 
 
+class BatchInput(C.Structure):
+    """tbc_batch_input: pointers into one pinned slot of a batch (tbc_batch_map_input)."""
+    _fields_ = [("n_hist_cap", C.c_uint32), ("reserved0", C.c_uint32), ("ops_cap", C.c_uint64),
+                ("op_off", C.POINTER(C.c_uint64)), ("n_events", C.POINTER(C.c_uint32)), ("n_process", C.POINTER(C.c_uint32)),
+                ("word", C.POINTER(C.c_uint32)), ("inv_pos", C.POINTER(C.c_uint32)), ("ret_pos", C.POINTER(C.c_uint32))]
+
+
+class InputInfo(C.Structure):
+    _fields_ = [("n_hist", C.c_uint32), ("pending", C.c_uint32), ("total_ops", C.c_uint64), ("bytes_copied", C.c_uint64),
+                ("ns_copy", C.c_uint64), ("inputs_consumed", C.c_uint64), ("lists_regrown", C.c_uint32), ("n_hist_cap", C.c_uint32),
+                ("ops_cap", C.c_uint64)]
+
+
+WIRE_NIL = 0xFF
+
+
 class SynthParams(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("n_ops", C.c_uint32), ("n_procs", C.c_uint32), ("n_values", C.c_uint32),
                 ("busy_permille", C.c_uint32), ("info_permille", C.c_uint32), ("read_permille", C.c_uint32),
@@ -177,6 +193,10 @@ SYMBOLS = {
     "tbc_setfull_run": (C.c_int, [C.c_void_p, C.POINTER(SetFullOut)]),
     "tbc_setfull_destroy": (None, [C.c_void_p]),
     "tbc_batch_destroy": (None, [C.c_void_p]),
+    "tbc_batch_map_input": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(BatchInput)]),
+    "tbc_batch_submit_input": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),
+    "tbc_batch_reload": (C.c_int, [C.c_void_p, C.POINTER(BatchDesc)]),
+    "tbc_batch_input_info": (C.c_int, [C.c_void_p, C.POINTER(InputInfo)]),
     "tbc_memo_build": (C.c_int, [C.c_int64, C.c_uint32, STEP_FN, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint16),
                                  C.POINTER(C.c_int64), C.POINTER(C.c_uint32)]),
     "tbc_version": (C.c_uint32, []),

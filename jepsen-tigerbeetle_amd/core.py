@@ -158,11 +158,93 @@ class Batch:
 
     def run(self, want_results=True, tolerate_bad_histories=False):
         """tolerate_bad_histories: a history the device-side validation rejects (TBC_ERR_BAD_HISTORY / TBC_ERR_MODEL)
-        comes back as :unknown with cause 0 instead of failing the whole batch."""
+        comes back as :unknown with cause 0 instead of failing the whole batch.
+        A submitted input that is waiting (submit_input / reload) is consumed by this run: the results are ITS histories'."""
+        pend = getattr(self, "_pending_n", None)
+        if pend:
+            self.n_hist = pend.pop(0)
         st = N.lib().tbc_batch_run(self._h, self._res if want_results else None)
         if not (tolerate_bad_histories and st in (N.ERR_BAD_HISTORY, N.ERR_MODEL)):
             N.check_status(st)
         return self
+
+    # ---- fresh inputs: the same batch, new histories (include/tbcheck.h "streaming"; csrc/batch_stream.hip)
+    def map_input(self, slot):
+        """Slot `slot` of the batch's pinned host memory as numpy views the caller fills IN PLACE:
+        {"op_off" u64[n_hist_cap + 1], "n_events", "n_process" u32[n_hist_cap], "word", "inv_pos", "ret_pos" u32[ops_cap]}.
+        Waits until the slot's previous input has left for the device."""
+        i = N.BatchInput()
+        N.check_status(N.lib().tbc_batch_map_input(self._h, slot, C.byref(i)))
+        nh, no = int(i.n_hist_cap), int(i.ops_cap)
+        view = lambda p, n: np.ctypeslib.as_array(p, shape=(n,))
+        return {"n_hist_cap": nh, "ops_cap": no, "op_off": view(i.op_off, nh + 1), "n_events": view(i.n_events, nh), "n_process": view(i.n_process, nh),
+                "word": view(i.word, no), "inv_pos": view(i.inv_pos, no), "ret_pos": view(i.ret_pos, no)}
+
+    @staticmethod
+    def wire_words(f, a, b, process):
+        """TBC_WIRE_WORD over columns: f | a << 4 | b << 12 | process << 20 (nil = 0xFF); values must be 0..254, processes 0..4095."""
+        a8 = np.where(a == N.NIL, N.WIRE_NIL, a).astype(np.uint32)
+        b8 = np.where(b == N.NIL, N.WIRE_NIL, np.where(f == N.F_CAS, b, 0)).astype(np.uint32)
+        if len(a8) and (int(a8.max()) > 255 or int(b8.max()) > 255 or int(process.max()) > 4095 or int(process.min()) < 0):
+            raise ValueError("the wire format holds values 0..254 (or nil) and processes 0..4095")
+        return f.astype(np.uint32) | (a8 << np.uint32(4)) | (b8 << np.uint32(12)) | (process.astype(np.uint32) << np.uint32(20))
+
+    def fill_input(self, slot, histories: Sequence[OpColumns]):
+        """Write `histories` into slot `slot` in wire format (what a caller's own encoder would do in place).  -> n_hist"""
+        m = self.map_input(slot)
+        nh = len(histories)
+        if nh > m["n_hist_cap"]:
+            raise ValueError(f"{nh} histories, the batch's slots hold {m['n_hist_cap']}")
+        lens = np.fromiter((len(h) for h in histories), np.uint64, nh)
+        T = int(lens.sum())
+        if T > m["ops_cap"]:
+            raise ValueError(f"{T} ops, the batch's slots hold {m['ops_cap']}")
+        m["op_off"][0] = 0
+        np.cumsum(lens, out=m["op_off"][1:nh + 1])
+        m["n_events"][:nh] = np.fromiter((h.n_events for h in histories), np.uint32, nh)
+        m["n_process"][:nh] = np.fromiter((h.n_process for h in histories), np.uint32, nh)
+        cat = lambda name: np.concatenate([getattr(h, name) for h in histories]) if nh else np.zeros(0, np.int32)
+        m["word"][:T] = self.wire_words(cat("f"), cat("a"), cat("b"), cat("process"))
+        m["inv_pos"][:T] = cat("inv_pos")
+        m["ret_pos"][:T] = cat("ret_pos")
+        return nh
+
+    def submit_input(self, slot, n_hist):
+        """Queue the slot's copy to the device (asynchronous); the next run() that finds it waiting consumes it."""
+        N.check_status(N.lib().tbc_batch_submit_input(self._h, slot, n_hist))
+        if not hasattr(self, "_pending_n"):
+            self._pending_n = []
+        self._pending_n.append(int(n_hist))
+        return self
+
+    def reload(self, histories: Sequence[OpColumns]):
+        """tbc_batch_reload: the histories' six columns -> wire format in the batch's next slot -> submitted."""
+        nh = len(histories)
+        op_off = np.zeros(nh + 1, np.uint64)
+        for i, h in enumerate(histories):
+            op_off[i + 1] = op_off[i] + len(h)
+        n_events = np.array([h.n_events for h in histories], np.uint32)
+        n_process = np.array([h.n_process for h in histories], np.uint32)
+        spec = (("f", np.uint8), ("a", np.int32), ("b", np.int32), ("process", np.int32), ("inv_pos", np.uint32), ("ret_pos", np.uint32))
+        cols = OpColumns(*[np.ascontiguousarray(np.concatenate([getattr(h, name) for h in histories]).astype(dt, copy=False)) for name, dt in spec],
+                         n_events=0, n_process=0)
+        d = N.BatchDesc()
+        d.n_hist = nh
+        d.op_off = _p(op_off, C.c_uint64)
+        d.n_events = _p(n_events, C.c_uint32)
+        d.n_process = _p(n_process, C.c_uint32)
+        d.cols = cols.struct()
+        d.model_aux = None
+        N.check_status(N.lib().tbc_batch_reload(self._h, C.byref(d)))
+        if not hasattr(self, "_pending_n"):
+            self._pending_n = []
+        self._pending_n.append(nh)
+        return self
+
+    def input_info(self):
+        i = N.InputInfo()
+        N.check_status(N.lib().tbc_batch_input_info(self._h, C.byref(i)))
+        return {k: getattr(i, k) for k, _ in N.InputInfo._fields_}
 
     def results(self, copy_witness=True):
         return [_result_dict(self._res[i], copy_witness) for i in range(self.n_hist)]

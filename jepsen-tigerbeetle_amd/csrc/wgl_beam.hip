@@ -633,6 +633,21 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
       if (succ) {   // linearizable: lowest pair wins, nothing of this round is inserted
         const uint32_t wl = (uint32_t)__builtin_ctzll(succ);
         if (lane == 0) { sst(S, S_WINPAR, rl(pslot, wl)); sst(S, S_WINOP, rl(op, wl)); sst(S, S_WINSTATE, rl((uint32_t)st2, wl)); }
+        if constexpr (CNT) {
+          // a PREFIX search (count-form pipeline, tbc_api: the relaxed pass refuted completion RT) that ends VALID: the config it ended in
+          // stands in front of the completion nobody passes -- record 0 of the history's :configs arena (round 6; the verdict's :configs
+          // used to be empty)
+          if (RT < R && lane == wl) {
+            const cold_args_ptr Cw = cold_args();
+            if (Cw->cfg) {
+              uint64_t* o = Cw->cfg + (uint64_t)hidx * kCfgCap * (2 + MW);
+              o[0] = (uint64_t)(fi2 + 1u) | ((uint64_t)(uint32_t)st2 << 32);
+#pragma unroll
+              for (int j = 0; j < MW; j++) o[1 + j] = M2[j];
+              o[1 + MW] = (uint64_t)op;
+            }
+          }
+        }
         verdict = TBC_VALID;
         break;
       }
@@ -933,6 +948,7 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
       n_cfg += (uint32_t)__popcll(hb);
     }
   }
+  if (CNT && verdict == TBC_VALID && RT < Rc && C->cfg) n_cfg = 1;          // (the prefix search's end config, written where the search ended)
   uint32_t wlen = 0;
   if (verdict == TBC_VALID && Rc != 0 && C->witness) {
     // witness = ops along the parent chain of the winning config, then the winning op.  Only when it is wanted: the

@@ -31,6 +31,11 @@ def worst_case_line():
                          "level_sweep_on_cpu": {"value": 66.7, "sample": LONG}},
         "extra": {"valid": 65534, "unknown": 0, "device_ms": {"init_memsets": 3.697, "pack": 66.201, "search": 117.456, "retries": 0.2, "search_waiting_for_its_turn": 9.506, "note": LONG},
                   "device_GB": 169.734, "device_GB_per_batch": 84.891, "h2d_inclusive_hist_per_s": 88330.93,
+                  "fresh_input": {"histories_per_s": 287654.32, "unit": "histories/s", "steps": 4, "ms_per_step": 113.912, "what": LONG, "pcie_GB_per_input": 2.883,
+                                  "pcie_GB_s_over_the_timed_region": 25.31, "pcie_GB_s_while_copying": 52.77, "pcie_peak_GB_s": 63.0,
+                                  "re_uploaded": {"histories_per_s": 291234.56, "steps": 12, "ms_per_step": 112.5, "pcie_GB_s_over_the_timed_region": 25.6,
+                                                  "pcie_GB_s_while_copying": 52.9, "what": LONG},
+                                  "lists_regrown": 0, "host_gen_and_encode_s": 40.12, "host_encode_s_per_batch": 1.23, "device_GB_per_batch_after": 96.5},
                   "one_batch_at_a_time": {"value": 204793.11, "device_ms": {"init_memsets": 0.7, "pack": 59.23, "search": 98.417}, "roofline_frac": 0.013736, "note": LONG},
                   "same_batch_one_history_per_wavefront": dict(wl),
                   "time_to_verdict_ms": {"valid_median": 2.499, "valid_min": 2.023, "answered_by_sweep": 10, "of": 10, "depth_first_with_witness_median": 22.96,
@@ -57,6 +62,7 @@ def test_compact_line_is_small_and_complete():
     assert len(small["extra"]["tiers"]["rows"]) == 6 and "batch_forms" not in small["extra"] and "single_history_forms" not in small["extra"]
     assert small["extra"]["time_to_verdict_ms"]["vs_cpu_same_schedule_single_thread"] == 2.8
     assert small["extra"]["workload_2"]["value"] == 123456.78
+    assert small["extra"]["fresh_input"]["histories_per_s"] == 287654.32 and small["extra"]["fresh_input"]["re_uploaded"]["steps"] == 12
 
 
 def test_emit_prints_the_compact_line_last(monkeypatch, tmp_path, capsys):
