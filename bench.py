@@ -606,6 +606,8 @@ def main():
     # host thread, as in the headline.  `never_seen`: each of the G inputs consumed exactly once.  `re_uploaded`: the same G host batches
     # taken round-robin for 3 G more steps -- every step still copies, unpacks and packs its input from scratch (nothing of an earlier
     # pass is reused on the device: the tables are rebuilt, the visited sets are another epoch's).  Never `value`.
+    device_bytes_resident = batch.device_bytes()          # (before the fresh inputs' stages and headroom)
+    device_bytes_all_resident = sum(b.device_bytes() for b in batches)
     fresh = None
     G = (args.fresh_batches // F) * F
     if G > 0 and on_gpu and narrow:
@@ -693,14 +695,19 @@ def main():
     if world > 1 and args.sharded_ttv:
         o_lin = core.make_opts(device=local_rank, want_witness=False, algorithm=N.ALG_LINEAR)
         one = synth.register_ops_many([424242], n_ops=args.ops, n_procs=args.procs, busy=args.busy, info=0.0)   # the same history on every rank
+        # the exchange runs INSIDE the library (csrc/tbc_comm.hip: its own RCCL communicator, ncclAllGather of the relation tables out of
+        # HBM) -- what a Clojure host would call; torch.distributed only carries the 128-byte id from rank 0 to the others
+        ident = [shard.Comm.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ident, src=0)
         times = []
-        for _ in range(4):
-            with core.Batch(one, model, o_lin) as b1:
-                barrier()
-                t1 = time.perf_counter()
-                r1 = shard.check_sharded(b1, rank, world, dist)
-                times.append(shard.max_over_ranks(time.perf_counter() - t1, world, dist) * 1e3)
-        sharded_ms = {"median_ms": round(statistics.median(times[1:]), 3), "valid": r1[0]["valid"], "gpus": world}
+        with shard.Comm.rccl(rank, world, ident[0], local_rank) as comm:
+            for _ in range(4):
+                with core.Batch(one, model, o_lin) as b1:
+                    barrier()
+                    t1 = time.perf_counter()
+                    r1 = comm.check(b1)
+                    times.append(shard.max_over_ranks(time.perf_counter() - t1, world, dist) * 1e3)
+        sharded_ms = {"median_ms": round(statistics.median(times[1:]), 3), "valid": r1[0]["valid"], "gpus": world, "exchange": "tbc_batch_sweep_allgather (RCCL inside libtbcheck)"}
 
     verdicts = batch.verdicts()
     for b in batches:               # element-wise: the planted history is INVALID, every other one VALID, in every resident batch
@@ -764,7 +771,7 @@ def main():
                                     "note": "per pass, HIP events on the pass's own stream; with several batches in flight a pass's init and pack "
                                             "share the GPU with another pass's search, so the four do not add up to ms_per_step"},
                       "steps_per_history": counters["steps"] / B,
-                      "device_GB": round(sum(b.device_bytes() for b in batches) / 1e9, 3), "device_GB_per_batch": round(batch.device_bytes() / 1e9, 3), "gen_s": round(t_gen, 2),
+                      "device_GB": round(device_bytes_all_resident / 1e9, 3), "device_GB_per_batch": round(device_bytes_resident / 1e9, 3), "gen_s": round(t_gen, 2),
                       # the same batch with its inputs NOT resident: tbc_batch_create (allocation + H2D of the op
                       # columns over PCIe) + one run; never `value`
                       # (create_h2d_s = tbc_batch_create: host SoA columns in, resident batch out; marshal_s = what the Python binding spends

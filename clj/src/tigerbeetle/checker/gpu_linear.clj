@@ -221,6 +221,18 @@
         (.setInt  b (* 4 i) (int (if (nil? vb) NIL vb)))))
     {:ops ops :n n :type typ :process prc :f fc :a a :b b :pool (some-> enc :pool)}))
 
+;; JNA LIFETIMES.  Memory.setPointer writes the pointee's ADDRESS into a struct and keeps no reference to the pointee; a Memory that is
+;; only reachable as "the thing whose address I wrote somewhere" is garbage, and its finalizer frees the native block -- while libtbcheck
+;; is reading it.  Clojure makes it worse: locals are cleared after their last use, so even a let-bound buffer may die before the
+;; native call returns.  Every native call below therefore runs inside (keeping [everything whose address it passes, directly or inside
+;; a struct] ...): the vector is held on the stack and fenced in a finally.  (ADVICE.md round 5: check-batch, set-full-indices, analysis.)
+(defmacro ^:private keeping
+  "Evaluates body with every object in the vector `xs` strongly reachable until body has returned."
+  [xs & body]
+  `(let [holder# ~xs]
+     (try ~@body
+          (finally (java.lang.ref.Reference/reachabilityFence holder#)))))
+
 (defn- events-struct ^Memory [{:keys [n type process f a b]}]
   (doto (struct :events)
     (.setInt (o :events :n) n) (.setPointer (o :events :type) type) (.setPointer (o :events :process) process)
@@ -234,8 +246,9 @@
         of    (Memory. cap) oa (Memory. (* 4 cap)) ob (Memory. (* 4 cap)) op* (Memory. (* 4 cap))
         inv   (Memory. (* 4 cap)) ret (Memory. (* 4 cap))
         n-ops (IntByReference.) n-proc (IntByReference.)
-        st    (.invokeInt (f "tbc_pair_events")
-                          (to-array [(events-struct cols) of oa ob op* inv ret n-ops n-proc]))]
+        es    (events-struct cols)
+        st    (keeping [cols es of oa ob op* inv ret n-ops n-proc]
+                (.invokeInt (f "tbc_pair_events") (to-array [es of oa ob op* inv ret n-ops n-proc])))]
     (when (zero? st)
       (assoc cols :of of :oa oa :ob ob :oproc op* :inv inv :ret ret
                   :n-ops (.getValue n-ops) :n-process (.getValue n-proc)
@@ -320,18 +333,23 @@
   [m hist opts]
   (when-let [[kind init n-keys] (and @lib (model->native m))]
     (when-let [{:keys [ops inv ret] :as p} (paired (columns hist m))]
-      (let [res (doto (Memory. (o :result :size)) (.clear))
-            st  (.invokeInt (f "tbc_check") (to-array [(ops-struct p) (model-struct kind init n-keys) (opts-struct opts) res]))]
-        (try
-          (when (zero? st)
-            (result-map res 0 m ops inv ret))
-          (finally (.invoke (f "tbc_result_free") Void/TYPE (to-array [res]))))))))
+      (let [res  (doto (Memory. (o :result :size)) (.clear))
+            os   (ops-struct p)                                    ; holds the ADDRESSES of p's columns, not the columns
+            ms   (model-struct kind init n-keys)
+            opt  (opts-struct opts)]
+        (keeping [p os ms opt res]
+          (let [st (.invokeInt (f "tbc_check") (to-array [os ms opt res]))]
+            (try
+              (when (zero? st)
+                (result-map res 0 m ops inv ret))
+              (finally (.invoke (f "tbc_result_free") Void/TYPE (to-array [res]))))))))))
 
 (defn linearizable
   "Drop-in for (checker/linearizable {:model m :algorithm a}): same options, same result map
    ({:valid? :op :previous-ok :configs :final-paths :analyzer}).  Extra, additive keys: :device, :time-limit (ms).
    With crashed (:info) calls and :algorithm nil the library searches in the count form (DESIGN.md 2.4): :valid?, :op
-   and :previous-ok are exact, :configs of an invalid verdict reached through the relaxed refutation is empty."
+   and :previous-ok are exact, :configs of an invalid verdict reached through the relaxed refutation holds the ONE config the
+   prefix's linearization ended in (not every config stuck at the failing completion)."
   [{:keys [model] :as opts}]
   (let [stock (checker/linearizable opts)]
     (reify checker/Checker
@@ -360,20 +378,25 @@
               n-ev   (int-pool (map :n enc))
               n-pr   (int-pool (map :n-process enc))
               C      (o :batch_desc :cols)
+              c-f    (cat :of 1) c-a (cat :oa 4) c-b (cat :ob 4) c-p (cat :oproc 4) c-inv (cat :inv 4) c-ret (cat :ret 4)
               desc   (doto (struct :batch_desc)
                        (.setInt (o :batch_desc :n_hist) nh) (.setPointer (o :batch_desc :op_off) op-off)
                        (.setPointer (o :batch_desc :n_events) n-ev) (.setPointer (o :batch_desc :n_process) n-pr)
                        (.setInt (+ C (o :ops :n)) (last offs))
-                       (.setPointer (+ C (o :ops :f)) (cat :of 1)) (.setPointer (+ C (o :ops :a)) (cat :oa 4))
-                       (.setPointer (+ C (o :ops :b)) (cat :ob 4)) (.setPointer (+ C (o :ops :process)) (cat :oproc 4))
-                       (.setPointer (+ C (o :ops :inv_pos)) (cat :inv 4)) (.setPointer (+ C (o :ops :ret_pos)) (cat :ret 4)))
+                       (.setPointer (+ C (o :ops :f)) c-f) (.setPointer (+ C (o :ops :a)) c-a)
+                       (.setPointer (+ C (o :ops :b)) c-b) (.setPointer (+ C (o :ops :process)) c-p)
+                       (.setPointer (+ C (o :ops :inv_pos)) c-inv) (.setPointer (+ C (o :ops :ret_pos)) c-ret))
+              ms     (model-struct kind init n-keys)
+              opt    (opts-struct opts)
               hnd    (PointerByReference.)
               res    (doto (Memory. (* (o :result :size) (max 1 nh))) (.clear))]
-          (when (zero? (.invokeInt (f "tbc_batch_create") (to-array [desc (model-struct kind init n-keys) (opts-struct opts) hnd])))
-            (try
-              (when (zero? (.invokeInt (f "tbc_batch_run") (to-array [(.getValue hnd) res])))
-                (vec (map-indexed (fn [i {:keys [ops inv ret]}] (result-map res (* i (o :result :size)) m ops inv ret)) enc)))
-              (finally (.invoke (f "tbc_batch_destroy") Void/TYPE (to-array [(.getValue hnd)]))))))))))
+          ;; (the library copies the columns during tbc_batch_create; the results and the per-key columns result-map reads live to the end)
+          (keeping [enc op-off n-ev n-pr c-f c-a c-b c-p c-inv c-ret desc ms opt hnd res]
+            (when (zero? (.invokeInt (f "tbc_batch_create") (to-array [desc ms opt hnd])))
+              (try
+                (when (zero? (.invokeInt (f "tbc_batch_run") (to-array [(.getValue hnd) res])))
+                  (vec (map-indexed (fn [i {:keys [ops inv ret]}] (result-map res (* i (o :result :size)) m ops inv ret)) enc)))
+                (finally (.invoke (f "tbc_batch_destroy") Void/TYPE (to-array [(.getValue hnd)])))))))))))
 
 (defn memo-table
   "knossos.model.memo/memo through tbc_memo_build: the dense transition table of an arbitrary model over the op
@@ -419,22 +442,27 @@
     (doseq [[r [_ _ v]] (map-indexed vector reads), x (distinct v) :let [e (elem-no x)] :when e]
       (let [off (* 4 (+ (* r wpr) (quot e 32)))]
         (.setInt present off (unchecked-int (bit-or (.getInt present off) (bit-shift-left 1 (rem e 32)))))))
-    (let [in  (doto (struct :setfull_in)
+    (let [a-inv (int-pool (map adds elements))
+          a-ok  (int-pool (map #(get add-ok % NO-OP) elements))
+          r-inv (int-pool (map first reads))
+          r-ok  (int-pool (map second reads))
+          in  (doto (struct :setfull_in)
                 (.setInt (o :setfull_in :n_elements) E) (.setInt (o :setfull_in :n_reads) R)
                 (.setInt (o :setfull_in :words_per_row) wpr) (.setInt (o :setfull_in :device) device)
-                (.setPointer (o :setfull_in :add_invoke) (int-pool (map adds elements)))
-                (.setPointer (o :setfull_in :add_ok) (int-pool (map #(get add-ok % NO-OP) elements)))
-                (.setPointer (o :setfull_in :read_invoke) (int-pool (map first reads)))
-                (.setPointer (o :setfull_in :read_ok) (int-pool (map second reads)))
+                (.setPointer (o :setfull_in :add_invoke) a-inv)
+                (.setPointer (o :setfull_in :add_ok) a-ok)
+                (.setPointer (o :setfull_in :read_invoke) r-inv)
+                (.setPointer (o :setfull_in :read_ok) r-ok)
                 (.setPointer (o :setfull_in :present) present))
           hnd (PointerByReference.)
           k   (Memory. (max 4 (* 4 E))) lp (Memory. (max 4 (* 4 E))) la (Memory. (max 4 (* 4 E)))
           out (doto (struct :setfull_out)
                 (.setPointer (o :setfull_out :known) k) (.setPointer (o :setfull_out :last_present) lp)
                 (.setPointer (o :setfull_out :last_absent) la))]
-      (when (zero? (.invokeInt (f "tbc_setfull_create") (to-array [in hnd])))       ; TBC_ERR_INVALID_ARG if the orders above are violated
-        (try
-          (when (zero? (.invokeInt (f "tbc_setfull_run") (to-array [(.getValue hnd) out])))
-            {:elements elements :known (vec (.getIntArray k 0 E)) :last-present (vec (.getIntArray lp 0 E))
-             :last-absent (vec (.getIntArray la 0 E))})
-          (finally (.invoke (f "tbc_setfull_destroy") Void/TYPE (to-array [(.getValue hnd)]))))))))
+      (keeping [a-inv a-ok r-inv r-ok present in hnd k lp la out]
+        (when (zero? (.invokeInt (f "tbc_setfull_create") (to-array [in hnd])))       ; TBC_ERR_INVALID_ARG if the orders above are violated
+          (try
+            (when (zero? (.invokeInt (f "tbc_setfull_run") (to-array [(.getValue hnd) out])))
+              {:elements elements :known (vec (.getIntArray k 0 E)) :last-present (vec (.getIntArray lp 0 E))
+               :last-absent (vec (.getIntArray la 0 E))})
+            (finally (.invoke (f "tbc_setfull_destroy") Void/TYPE (to-array [(.getValue hnd)])))))))))

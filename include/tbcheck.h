@@ -40,7 +40,9 @@ extern "C" {
 
 /* 2: tbc_opts grew to 64 bytes (lanes_per_history, reserved0), tbc_batch_sweep_finish gained merged_bytes, tbc_opts.dominance
  * gained TBC_DOM_NO_COUNT_FORM.  A caller built against another version must refuse the library (tbc_version()).
- * Still 2, additive: the word that was reserved0 (must be 0) is tbc_opts.list_order, 0 = the library's choice; tbc_batch_list_order(). */
+ * Still 2, additive: the word that was reserved0 (must be 0) is tbc_opts.list_order, 0 = the library's choice; tbc_batch_list_order().
+ * Still 2, additive (round 6): tbc_batch_map_input / _submit_input / _reload / _input_info (fresh histories into a batch's arenas),
+ * tbc_comm_* (the sharded sweep's exchange behind the C-ABI); tbc_setfull_create_rows takes its exception lists in any order again. */
 #define TBC_ABI_VERSION 2u
 
 /* ------------------------------------------------------------------ status */
@@ -259,8 +261,9 @@ enum { TBC_DOM_NO_EAGER_READS = 1u, TBC_DOM_NO_TWIN_RULE = 2u,
         * budget per launch) -- and only when the caller names no max_steps: a caller's own step limit is one exact pass under that
         * limit, nothing after it -- is first refuted with every
         * class an unlimited supply (a superset of the linearizations), then the prefix before the refuted completion is
-        * linearized: verdict and failing op are exact, :configs of such a verdict is empty.  Set = keep one mask bit per
-        * crashed call (the published form). */
+        * linearized: verdict and failing op are exact, :configs of such a verdict holds the ONE config the prefix's linearization
+        * ended in (the exact search's own exhaustion, when it names an earlier completion, reports its stuck configs as ever).
+        * Set = keep one mask bit per crashed call (the published form). */
        TBC_DOM_NO_COUNT_FORM = 4u,
        /* LAZY RULE of the commutative models (set, bank): an :add / :transfer changes nothing a call other than a :read can see and
         * commutes with its kind, so without loss of generality it is linearized only when it completes at the front or when an open,
@@ -466,6 +469,27 @@ tbc_status tbc_batch_sweep_finish(tbc_batch* b, const void* merged, uint64_t mer
 /* the same from the ranks' tables still in DEVICE memory, `world` of them back to back (what an all-gather over RCCL leaves):
  * they are OR-ed on the device into this batch's table, then composed -- the exchanged bytes never pass through the host */
 tbc_status tbc_batch_sweep_merge(tbc_batch* b, const void* gathered_device, uint64_t gathered_bytes, uint32_t world, tbc_result* results);
+/* ---- the exchange behind the C-ABI (round 6; csrc/tbc_comm.hip).  The host the reference is -- a Clojure process binding this library
+ * through JNA (/root/reference/project.clj:6-8) -- has no torch.distributed; with these a rank of ANY host language runs its share
+ * of a sharded check:
+ *   tbc_comm_unique_id         rank 0: 128 bytes that reach the other ranks however the host likes (they are an ncclUniqueId)
+ *   tbc_comm_init              an RCCL communicator over xGMI for this rank (librccl.so is loaded here, at the first call)
+ *   tbc_comm_init_host         ... or a transport of the caller's: an all-gather over HOST memory (MPI, a socket, a test's gloo)
+ *   tbc_batch_sweep_allgather  tbc_batch_set_shard + tbc_batch_sweep_partial + ONE all-gather of the relation tables (RCCL: straight
+ *                              out of HBM, OR-merged on the device; host transport: through tbc_batch_sweep_finish) + composition.
+ *                              Every rank calls it with a batch created from the same histories and options; every rank gets the results.
+ */
+typedef struct tbc_comm tbc_comm;
+#define TBC_COMM_ID_BYTES 128
+/* gather `bytes` from every rank: recv holds world * bytes, rank r's contribution at r * bytes.  0 = done. */
+typedef int (*tbc_allgather_fn)(void* user, const void* send, void* recv, uint64_t bytes);
+tbc_status tbc_comm_unique_id(void* id /* TBC_COMM_ID_BYTES */);
+tbc_status tbc_comm_init(uint32_t rank, uint32_t world, const void* id, uint32_t device, tbc_comm** out);
+tbc_status tbc_comm_init_host(uint32_t rank, uint32_t world, tbc_allgather_fn fn, void* user, tbc_comm** out);
+uint32_t tbc_comm_rank(const tbc_comm* c);
+uint32_t tbc_comm_world(const tbc_comm* c);
+void tbc_comm_destroy(tbc_comm* c);
+tbc_status tbc_batch_sweep_allgather(tbc_batch* b, tbc_comm* c, tbc_result* results);
 void tbc_batch_destroy(tbc_batch* b);
 
 /* ------------------------------------------------ streaming: the same batch, fresh histories
@@ -601,7 +625,7 @@ typedef struct tbc_setfull_rows {
   const uint32_t* read_ok;
   const uint32_t* top;           /* [n_reads], <= n_elements */
   const uint64_t* exc_off;       /* [n_reads + 1], ascending, exc_off[0] = 0 */
-  const uint32_t* exc;           /* [exc_off[n_reads]] element numbers < n_elements, strictly ascending within a read (each at most once: a duplicate is TBC_ERR_INVALID_ARG) */
+  const uint32_t* exc;           /* [exc_off[n_reads]] element numbers < n_elements, each at most once per read, in any order (a duplicate is TBC_ERR_INVALID_ARG) */
 } tbc_setfull_rows;
 tbc_status tbc_setfull_create_rows(const tbc_setfull_rows* in, tbc_setfull** handle);
 tbc_status tbc_setfull_run(tbc_setfull* handle, tbc_setfull_out* out);

@@ -164,6 +164,8 @@ class SynthParams(C.Structure):
 
 
 STEP_FN = C.CFUNCTYPE(C.c_int64, C.c_int64, C.c_uint32, C.c_void_p)
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64)      # tbc_allgather_fn(user, send, recv, bytes)
+COMM_ID_BYTES = 128
 
 # every symbol the headers declare: (name, restype, argtypes)
 SYMBOLS = {
@@ -193,6 +195,13 @@ SYMBOLS = {
     "tbc_setfull_run": (C.c_int, [C.c_void_p, C.POINTER(SetFullOut)]),
     "tbc_setfull_destroy": (None, [C.c_void_p]),
     "tbc_batch_destroy": (None, [C.c_void_p]),
+    "tbc_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "tbc_comm_init": (C.c_int, [C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]),
+    "tbc_comm_init_host": (C.c_int, [C.c_uint32, C.c_uint32, ALLGATHER_FN, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "tbc_comm_rank": (C.c_uint32, [C.c_void_p]),
+    "tbc_comm_world": (C.c_uint32, [C.c_void_p]),
+    "tbc_comm_destroy": (None, [C.c_void_p]),
+    "tbc_batch_sweep_allgather": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Result)]),
     "tbc_batch_map_input": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(BatchInput)]),
     "tbc_batch_submit_input": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),
     "tbc_batch_reload": (C.c_int, [C.c_void_p, C.POINTER(BatchDesc)]),

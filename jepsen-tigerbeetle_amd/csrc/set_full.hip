@@ -26,6 +26,8 @@
 // offering later rows' read_ok while they were invoked before the latest first-completion seen -- a window bounded by
 // the number of concurrent readers.
 #include <hip/hip_runtime.h>
+#include <vector>
+#include <algorithm>
 #include <cstdint>
 #include <cstring>
 #include <new>
@@ -367,10 +369,20 @@ static tbc_status setfull_create_impl(const tbc_setfull_in* in, tbc_setfull* S, 
     }
     const uint64_t ne = rows->exc_off[S->R];
     for (uint64_t i = 0; i < ne; i++) if (rows->exc[i] >= S->E) { set_error("tbc_setfull_create_rows: exception %llu names element %u of %u", (unsigned long long)i, rows->exc[i], S->E); return TBC_ERR_INVALID_ARG; }
-    // each element at most once per read -- strictly ascending: the kernel FLIPS the listed bits, a duplicate would flip one back silently
-    for (uint32_t r = 0; r < S->R; r++)
-      for (uint64_t i = rows->exc_off[r] + 1; i < rows->exc_off[r + 1]; i++)
-        if (rows->exc[i] <= rows->exc[i - 1]) { set_error("tbc_setfull_create_rows: read %u: exceptions must be strictly ascending (element %u after %u)", r, rows->exc[i], rows->exc[i - 1]); return TBC_ERR_INVALID_ARG; }
+    // each element at most once per read: the kernel FLIPS the listed bits, a duplicate would flip one back silently.  A strictly ascending
+    // list (what the in-repo encoders write) is seen to be duplicate-free in one pass; a list in any other order is sorted aside and looked
+    // at again -- round 5 refused every list that was not ascending, which a caller of the earlier header (any order, no duplicates) had
+    // no way to know at the same TBC_ABI_VERSION
+    std::vector<uint32_t> tmp;
+    for (uint32_t r = 0; r < S->R; r++) {
+      bool ascending = true;
+      for (uint64_t i = rows->exc_off[r] + 1; i < rows->exc_off[r + 1] && ascending; i++) ascending = rows->exc[i] > rows->exc[i - 1];
+      if (ascending) continue;
+      tmp.assign(rows->exc + rows->exc_off[r], rows->exc + rows->exc_off[r + 1]);
+      std::sort(tmp.begin(), tmp.end());
+      for (size_t i = 1; i < tmp.size(); i++)
+        if (tmp[i] == tmp[i - 1]) { set_error("tbc_setfull_create_rows: read %u lists element %u twice (each element at most once per read)", r, tmp[i]); return TBC_ERR_INVALID_ARG; }
+    }
   }
   // the prefix search per row and "the latest row" both rest on the documented orders
   for (uint32_t e = 1; e < S->E; e++) if (in->add_invoke[e] <= in->add_invoke[e - 1]) { set_error("tbc_setfull: add_invoke must be strictly ascending (element %u)", e); return TBC_ERR_INVALID_ARG; }

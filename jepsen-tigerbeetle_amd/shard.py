@@ -97,3 +97,66 @@ def check_sharded(batch, rank: int, world: int, dist=None):
         dist.all_gather_into_tensor(gathered, local)
     batch.sweep_merge(gathered, world)
     return batch.results()
+
+
+class Comm:
+    """tbc_comm_*: the sharded sweep's exchange BEHIND the C-ABI (csrc/tbc_comm.hip) -- what a Clojure host would call through JNA.
+    `Comm.rccl(rank, world, ident, device)`: an RCCL communicator inside the library (ident = Comm.unique_id() of rank 0, carried to
+    the other ranks by the caller).  `Comm.host(rank, world, allgather)`: the caller's own transport over host memory --
+    allgather(send: np.uint8[n]) -> np.uint8[world * n] (the tests hand in one over gloo)."""
+
+    def __init__(self, handle, keep=None):
+        self._h, self._keep = handle, keep
+
+    @staticmethod
+    def unique_id() -> bytes:
+        import ctypes as C
+        from . import _native as N
+        buf = (C.c_uint8 * N.COMM_ID_BYTES)()
+        N.check_status(N.lib().tbc_comm_unique_id(buf))
+        return bytes(buf)
+
+    @classmethod
+    def rccl(cls, rank, world, ident: bytes, device=0):
+        import ctypes as C
+        from . import _native as N
+        buf = (C.c_uint8 * N.COMM_ID_BYTES).from_buffer_copy(ident)
+        h = C.c_void_p()
+        N.check_status(N.lib().tbc_comm_init(rank, world, buf, device, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def host(cls, rank, world, allgather):
+        import ctypes as C
+        from . import _native as N
+
+        def thunk(user, send, recv, nbytes):
+            try:
+                src = np.ctypeslib.as_array(C.cast(send, C.POINTER(C.c_uint8)), shape=(nbytes,))
+                dst = np.ctypeslib.as_array(C.cast(recv, C.POINTER(C.c_uint8)), shape=(nbytes * world,))
+                dst[:] = np.asarray(allgather(src), np.uint8).reshape(-1)
+                return 0
+            except Exception:          # noqa: BLE001 -- an exception must not cross the C boundary; the library reports the code
+                return 1
+        fn = N.ALLGATHER_FN(thunk)
+        h = C.c_void_p()
+        N.check_status(N.lib().tbc_comm_init_host(rank, world, fn, None, C.byref(h)))
+        return cls(h, keep=fn)
+
+    def check(self, batch):
+        """tbc_batch_sweep_allgather: this rank's share of one sharded check; every rank gets the results."""
+        from . import _native as N
+        N.check_status(N.lib().tbc_batch_sweep_allgather(batch._h, self._h, batch._res))
+        return batch.results()
+
+    def close(self):
+        if self._h:
+            from . import _native as N
+            N.lib().tbc_comm_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()

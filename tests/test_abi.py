@@ -39,9 +39,10 @@ def test_struct_layouts_match_header(native):
 #include <stdio.h>
 #include "tbcheck.h"
 #include "tbsynth.h"
-int main(void){ printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(tbc_events), sizeof(tbc_ops),
+int main(void){ printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(tbc_events), sizeof(tbc_ops),
   sizeof(tbc_model), sizeof(tbc_opts), sizeof(tbc_config), sizeof(tbc_counters), sizeof(tbc_result),
-  sizeof(tbc_batch_desc), sizeof(tbs_params), offsetof(tbc_result, counters)); return 0; }
+  sizeof(tbc_batch_desc), sizeof(tbs_params), offsetof(tbc_result, counters),
+  sizeof(tbc_batch_input), offsetof(tbc_batch_input, word), sizeof(tbc_input_info), offsetof(tbc_input_info, ops_cap)); return 0; }
 '''
     with tempfile.TemporaryDirectory() as d:
         src = os.path.join(d, "s.c")
@@ -52,8 +53,11 @@ int main(void){ printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(tbc_e
     N = native
     mine = [C.sizeof(N.Events), C.sizeof(N.Ops), C.sizeof(N.Model), C.sizeof(N.Opts), C.sizeof(N.Config),
             C.sizeof(N.Counters), C.sizeof(N.Result), C.sizeof(N.BatchDesc), C.sizeof(N.SynthParams),
-            N.Result.counters.offset]
+            N.Result.counters.offset,
+            C.sizeof(N.BatchInput), N.BatchInput.word.offset, C.sizeof(N.InputInfo), N.InputInfo.ops_cap.offset]
     assert mine == sizes
+    # the wire word of the streaming inputs, as the header's macro packs it
+    assert N.WIRE_NIL == 0xFF and N.COMM_ID_BYTES == 128
 
 
 def test_result_offsets_the_jna_shim_reads(native):
@@ -124,3 +128,26 @@ def test_product_never_imports_the_oracle():
                 txt = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, re.M), f
                 assert "liboracle" not in txt and "oracle.wgl" not in txt, f   # comments may cite oracle/*.c
+
+
+def test_comm_objects_need_no_device(native):
+    """tbc_comm_init_host only records the caller's transport: it can be made, asked and destroyed on a machine without a GPU;
+    bad ranks are refused; the RCCL transport says why it is not there instead of crashing when librccl or the device is missing."""
+    lib = native.lib()
+    calls = []
+
+    @native.ALLGATHER_FN
+    def gather(user, send, recv, nbytes):
+        calls.append(nbytes)
+        return 0
+
+    h = C.c_void_p()
+    assert lib.tbc_comm_init_host(1, 2, gather, None, C.byref(h)) == 0
+    assert (lib.tbc_comm_rank(h), lib.tbc_comm_world(h)) == (1, 2)
+    lib.tbc_comm_destroy(h)
+    assert lib.tbc_comm_init_host(2, 2, gather, None, C.byref(h)) == native.ERR_INVALID_ARG
+    assert lib.tbc_batch_sweep_allgather(None, None, None) == native.ERR_INVALID_ARG
+    if not has_gpu():
+        ident = (C.c_uint8 * 128)()
+        st = lib.tbc_comm_init(0, 1, ident, 0, C.byref(h))
+        assert st in (native.ERR_NO_DEVICE, native.ERR_UNSUPPORTED), st

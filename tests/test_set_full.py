@@ -138,8 +138,28 @@ def test_matrix_built_on_the_device_equals_the_matrix_from_the_host(native):
     r = int(np.argmax(np.diff(dup.exc_off) >= 2))
     assert dup.exc_off[r + 1] - dup.exc_off[r] >= 2
     dup.exc = dup.exc.copy(); dup.exc[int(dup.exc_off[r]) + 1] = dup.exc[int(dup.exc_off[r])]
-    with pytest.raises(N.TbcError, match="strictly ascending"):
+    with pytest.raises(N.TbcError, match="twice"):
         sf.Scan(dup, rows=True)
+    # ... in whatever order it is listed; and an UNSORTED list without duplicates is what it always was: the same scan
+    enc = sf.Encoded(_lossy_set_history(12, n_ops=2500)[0])
+    with sf.Scan(enc, rows=True) as a:
+        ra = a.run()
+    rev = sf.Encoded(_lossy_set_history(12, n_ops=2500)[0])
+    rev.exc = rev.exc.copy()
+    for r in range(len(rev.exc_off) - 1):
+        lo, hi = int(rev.exc_off[r]), int(rev.exc_off[r + 1])
+        rev.exc[lo:hi] = rev.exc[lo:hi][::-1]
+    assert not np.array_equal(rev.exc, enc.exc)
+    with sf.Scan(rev, rows=True) as b:
+        rb = b.run()
+    for k in ("known", "last_present", "last_absent"):
+        assert np.array_equal(ra[k], rb[k]), k
+    dup2 = sf.Encoded(_lossy_set_history(3, n_ops=300)[0])
+    lo = int(dup2.exc_off[r_dup := int(np.argmax(np.diff(dup2.exc_off) >= 3))])
+    if dup2.exc_off[r_dup + 1] - lo >= 3:
+        dup2.exc = dup2.exc.copy(); dup2.exc[lo + 2] = dup2.exc[lo]; dup2.exc[lo], dup2.exc[lo + 1] = dup2.exc[lo + 1], dup2.exc[lo]
+        with pytest.raises(N.TbcError, match="twice"):
+            sf.Scan(dup2, rows=True)
 
 
 @pytest.mark.gpu
