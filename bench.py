@@ -182,11 +182,14 @@ def leg_workload(args, local_rank, which):
                 b2.run()
             t2 = time.perf_counter(); b2.run(); t2 = time.perf_counter() - t2
             c2 = b2.counters(); tm2 = b2.timing_ns(); v2 = b2.verdicts()
+            raced2 = b2.last_raced() if hasattr(b2, "last_raced") else 0
         alg2 = 16 * (c2["probes"] - c2["visited"]) + 32 * c2["visited"]
         k2 = (tm2["search"] + tm2["retries"]) / 1e6
         out = {"workload": workload_name(args.ops, args.procs, busy, info), "histories_per_gpu": B2, "search_width": width2, "lanes_per_history": lanes2, "list_order": order2,
                "value": round(B2 / t2, 2), "unit": "histories/s", "ms_per_step": round(t2 * 1e3, 3),
                "valid": int((v2 == N.VALID).sum()), "unknown": int((v2 == N.UNKNOWN).sum()),
+               # histories whose first pass ended at its budget (32 probes per op) and that were then searched in six list orders at once (tbcheck.h, TBC_DOM_NO_ORDER_RESTARTS)
+               "raced_in_six_orders": raced2,
                "roofline": {"bound": "hbm", "achieved": round(alg2 / (k2 * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": round(alg2 / (k2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 6), "traffic": None,
                             "kernel": "wgl_narrow_kernel" if lanes2 != 64 else "wgl_beam_kernel",

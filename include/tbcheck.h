@@ -279,7 +279,20 @@ enum { TBC_DOM_NO_EAGER_READS = 1u, TBC_DOM_NO_TWIN_RULE = 2u,
         * the ones with the biggest bursts, which the sweep is slowest at, and an all-valid batch pays 54 ms a pass for them while one bad
         * read in the middle of one history costs a pass 104 ms without the handover and 53 with it.  Verdict and failing op are the same
         * either way; the counters of a handed-over history are the stopped search's plus the sweep's, tbc_result.analyzer says who answered. */
-       TBC_DOM_STALL_HANDOVER = 16u };
+       TBC_DOM_STALL_HANDOVER = 16u,
+       /* ORDER RESTARTS (round 6; on by default where they apply: the wide depth-first search of a register / cas-register batch, one
+        * history per wavefront, the library's own list order, no step limit named).  At high concurrency the cost of a depth-first
+        * search is heavy-tailed in the ORDER its candidates are tried and nearly independent between orders (oracle counts, 24 histories
+        * at ~32 calls in flight, seven orders: the default order's slowest > 2 * 10^6 probes, its median 192k; the best order per
+        * history: slowest 341k, median 91k) -- and a pass over a batch is as long as its slowest history.  So the first pass runs under a
+        * budget of 32 probes per op of the batch's longest history; a history that has not ended by then is searched AGAIN FROM SCRATCH
+        * in other list orders (16 + 48, writes last, completion, 16 + 8, slot).  Nobody asking for a witness: in all six orders AT THE SAME
+        * TIME, as small batches of their own on streams of their own -- the first search to decide a history stops the others' searches
+        * of it (a race: knossos.competition's idea, between orders instead of algorithms); verdict and failing op are the search's in
+        * any order, which order answers and hence the counters can differ from run to run.  With a witness: one order after the other
+        * under the same budget, then the default order without one -- deterministic, the counters the sums over the passes, which
+        * oracle/wgl.py check_restart_pipeline states pass by pass.  Set = one pass, no budget. */
+       TBC_DOM_NO_ORDER_RESTARTS = 32u };
 
 /* ------------------------------------------------------------------ result */
 enum { TBC_VALID = 1, TBC_INVALID = 0, TBC_UNKNOWN = -1 };
@@ -395,6 +408,9 @@ uint32_t tbc_batch_lanes_per_history(const tbc_batch* b);
 /* the order of the fronts' lists this batch's depth-first search runs over: TBC_ORDER_SLOT / _COMPLETION / _WRITES_LAST or 16 + W
  * (what tbc_opts.list_order = 0 resolved to; SLOT wherever another order does not apply) */
 uint32_t tbc_batch_list_order(const tbc_batch* b);
+/* histories of the last run whose first pass ended at its budget and that were then searched in several list orders at once
+ * (tbc_opts.dominance, TBC_DOM_NO_ORDER_RESTARTS) */
+uint32_t tbc_batch_last_raced(const tbc_batch* b);
 /* how the last run was answered when the level sweep (knossos.linear; jit_sweep.hip) is in play:
  * TBC_ALG_LINEAR always asks for it, TBC_ALG_COMPETITION on small batches that want no witness.
  * The sweep cuts a history into segments of about seg_target completions at fronts with at most

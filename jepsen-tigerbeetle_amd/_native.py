@@ -33,7 +33,7 @@ ALG_COMPETITION, ALG_WGL, ALG_LINEAR = 0, 1, 2
 # verdicts / causes
 VALID, INVALID, UNKNOWN = 1, 0, -1
 CAUSE_NONE, CAUSE_TIME_LIMIT, CAUSE_STEP_LIMIT, CAUSE_VISITED_FULL = 0, 1, 2, 3
-DOM_NO_EAGER_READS, DOM_NO_TWIN_RULE, DOM_NO_COUNT_FORM, DOM_NO_LAZY_COMMUTING, DOM_STALL_HANDOVER = 1, 2, 4, 8, 16
+DOM_NO_EAGER_READS, DOM_NO_TWIN_RULE, DOM_NO_COUNT_FORM, DOM_NO_LAZY_COMMUTING, DOM_STALL_HANDOVER, DOM_NO_ORDER_RESTARTS = 1, 2, 4, 8, 16, 32
 # tbc_opts.list_order (16 + W: completion order, a :write as if it completed W ranks later; the default where it applies is 16 + 24)
 ORDER_DEFAULT, ORDER_SLOT, ORDER_COMPLETION, ORDER_WRITES_LAST, ORDER_WRITE_DELAY = 0, 1, 2, 3, 16
 # status
@@ -183,6 +183,7 @@ SYMBOLS = {
     "tbc_batch_search_width": (C.c_uint32, [C.c_void_p]),
     "tbc_batch_lanes_per_history": (C.c_uint32, [C.c_void_p]),
     "tbc_batch_list_order": (C.c_uint32, [C.c_void_p]),
+    "tbc_batch_last_raced": (C.c_uint32, [C.c_void_p]),
     "tbc_batch_sweep_info": (C.c_int, [C.c_void_p, C.POINTER(SweepInfo)]),
     "tbc_sweep_compose": (C.c_int, [C.POINTER(SweepRel), C.c_uint32, C.c_uint32, C.POINTER(SweepVerdict)]),
     "tbc_batch_set_shard": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),

@@ -464,7 +464,7 @@ tbc_batch::~tbc_batch() {
   d_bitmap.release(); d_wpre.release(); d_frames.release(); d_witness.release(); d_work.release();
   d_queue.release(); d_tab.release(); d_results.release(); d_table.release(); d_pool_vals.release(); d_cfg.release();
   d_bh.release(); d_off.release(); d_ncr.release(); d_lst.release(); d_crashed.release(); d_stack.release();
-  d_zncr.release(); d_reach.release(); d_reach_hdr.release(); d_abort.release();
+  d_zncr.release(); d_reach.release(); d_reach_hdr.release(); d_abort.release(); d_order.release(); d_park.release();
   if (abort_one) (void)hipHostFree(abort_one);
   if (!borrowed) { for (auto& e : ev2) if (e) (void)hipEventDestroy(e); if (stream2) (void)hipStreamDestroy(stream2); }
   d_cmem.release(); d_occ.release(); d_btab.release(); d_slot8.release(); d_rk8.release(); d_look.release(); d_looktmp.release(); d_twn.release(); d_rdm.release(); d_cuts.release(); d_seglist.release(); d_sres.release(); d_dstack.release(); d_pool.release(); d_pool_cursor.release();
@@ -541,6 +541,7 @@ tbc_status alloc_arenas(CreatePlan& P) {
     }
   }
   if ((s = B->d_cfg.alloc((uint64_t)nh * kCfgCap * (2 + B->mask_words)))) return s;
+  if (beam && (s = B->d_park.alloc((uint64_t)nh * kParkWords))) return s;
   B->pool_len = P.desc->cols.pool ? P.desc->cols.pool_len : 0;
   if ((s = B->d_pool_vals.alloc(B->pool_len))) return s;
   if (B->pool_len) HIP_TRY(hipMemcpy(B->d_pool_vals.p, P.desc->cols.pool, (size_t)B->pool_len * 4, hipMemcpyHostToDevice));

@@ -57,6 +57,7 @@ PackOpenArgs make_pack_open_args(tbc_batch* B) {
   po.twn = B->reg_rules() ? B->d_twn.p : nullptr; po.rdm = (B->reg_rules() || B->lanes) ? B->d_rdm.p : nullptr; po.vpad = B->vpad;
   po.cmem = B->count_form ? B->d_cmem.p : nullptr;
   po.list_order = B->list_order();
+  po.order_of = (!B->hist_order.empty() && B->d_order.p) ? B->d_order.p : nullptr;
   return po;
 }
 
@@ -84,6 +85,8 @@ static BeamArgs make_beam_args(tbc_batch* B, uint64_t* tab, uint32_t* stack, uin
   a.pool_vals = B->d_pool_vals.p;
   a.cfg = B->d_cfg.p;
   a.pool = B->d_pool.p; a.pool_cursor = B->d_pool_cursor.p; a.pool_words = B->d_pool.n;
+  a.abort = B->ext_abort; a.abort_set = B->ext_abort_set; a.abort_map = B->ext_abort_map;
+  a.park = B->d_park.p; a.resume = 0;
   {
     const uint64_t max_bytes = B->opts.max_visited_bytes ? B->opts.max_visited_bytes : (1ull << 30);
     uint32_t lg = 10;
@@ -242,8 +245,9 @@ static tbc_status expand_eager_witness(tbc_batch* B, uint32_t h, uint32_t* wit, 
   HIP_TRY(hipMemcpy(ret.data(), B->d_ret.p + H.op_off, (size_t)n * 4, hipMemcpyDeviceToHost));
   // (the replay itself is plain host code: witness_expand.h -- tests/test_narrow_emu.py runs the same function on the emulator's chains)
   std::vector<uint32_t> out;
+  const uint32_t order = h < B->order_of_hist.size() ? B->order_of_hist[h] : B->list_order();      // (an order restart's pass answers in its own order)
   if (!expand_eager_chain(n, f.data(), a.data(), b.data(), proc.data(), inv.data(), ret.data(), H.n_slots, B->model.init,
-                          (B->rules & kRuleBranch) != 0u, B->list_order() != 0u, wit, *len, out)) {
+                          (B->rules & kRuleBranch) != 0u, order != 0u, wit, *len, out)) {
     set_error("history %u: malformed witness chain", h);
     return TBC_ERR_HIP;
   }
@@ -288,6 +292,38 @@ uint32_t narrow_waves_per_simd() {
 // its search and costs a sweep.  64 looks (4,096 rounds, ~53 ms: a whole valid search) is past nearly every burst; a bad read in the
 // middle of a history then holds its pass for one more search's time instead of nine.
 static const uint32_t kStallChecks = 64;
+
+// The op columns of the histories in `list`, as they lie in HBM, gathered into ONE pinned host block (six columns back to back, the
+// histories in list order): a copy into pinned memory is a DMA that is merely queued, one into a std::vector is staged and waited
+// for -- ~1.5 ms each, 618 of them were 0.93 s of a 1.2 s pass (round 6, the race of list orders on bench workload_3).
+struct FetchedColumns {
+  char* pin = nullptr;
+  uint64_t T = 0;
+  std::vector<uint64_t> off;          // list.size() + 1
+  uint8_t* f = nullptr; int32_t* a = nullptr; int32_t* b = nullptr; int32_t* proc = nullptr; uint32_t* inv = nullptr; uint32_t* ret = nullptr;
+  ~FetchedColumns() { if (pin) (void)hipHostFree(pin); }
+};
+static tbc_status fetch_columns(tbc_batch* B, const uint32_t* list, size_t n_list, FetchedColumns& out) {
+  out.off.assign(n_list + 1, 0);
+  for (size_t i = 0; i < n_list; i++) out.off[i + 1] = out.off[i] + B->hist[list[i]].n_ops;
+  const uint64_t T = out.T = out.off[n_list], T4 = (T + 3) & ~3ull;
+  HIP_TRY(hipHostMalloc((void**)&out.pin, (size_t)(T4 * 21 + 64), hipHostMallocDefault));
+  out.a = (int32_t*)out.pin; out.b = out.a + T4; out.proc = out.b + T4; out.inv = (uint32_t*)(out.proc + T4); out.ret = out.inv + T4; out.f = (uint8_t*)(out.ret + T4);
+  for (size_t i = 0; i < n_list; i++) {
+    const Hist& H = B->hist[list[i]];
+    const uint64_t n = H.n_ops, o = out.off[i], s0 = H.op_off;
+    if (!n) continue;
+    HIP_TRY(hipMemcpyAsync(out.f + o, B->d_f.p + s0, n, hipMemcpyDeviceToHost, B->stream));
+    HIP_TRY(hipMemcpyAsync(out.a + o, B->d_a.p + s0, n * 4, hipMemcpyDeviceToHost, B->stream));
+    HIP_TRY(hipMemcpyAsync(out.b + o, B->d_b.p + s0, n * 4, hipMemcpyDeviceToHost, B->stream));
+    HIP_TRY(hipMemcpyAsync(out.proc + o, B->d_proc.p + s0, n * 4, hipMemcpyDeviceToHost, B->stream));
+    HIP_TRY(hipMemcpyAsync(out.inv + o, B->d_inv.p + s0, n * 4, hipMemcpyDeviceToHost, B->stream));
+    HIP_TRY(hipMemcpyAsync(out.ret + o, B->d_ret.p + s0, n * 4, hipMemcpyDeviceToHost, B->stream));
+  }
+  HIP_TRY(hipStreamSynchronize(B->stream));
+  return TBC_OK;
+}
+
 static tbc_status hand_over_stalled(tbc_batch* B, const std::vector<uint32_t>& list, std::vector<tbc_result>& out) {
   CtxSuspend own_arenas;                         // (the inner batch owns its arenas, stream and events; the caller's context comes back however this returns)
   tbc_status st = TBC_OK;
@@ -302,27 +338,14 @@ static tbc_status hand_over_stalled(tbc_batch* B, const std::vector<uint32_t>& l
       const Hist& H = B->hist[list[lo + i]];
       off[i + 1] = off[i] + H.n_ops; nev[i] = H.n_events; npr[i] = H.n_slots; aux[i] = H.aux;
     }
-    const uint64_t T = off[k];
-    std::vector<uint8_t> f(T + 1);
-    std::vector<int32_t> a(T + 1), b(T + 1), pr(T + 1);
-    std::vector<uint32_t> inv(T + 1), ret(T + 1);
-    // (the chunk's copies are queued on the batch's stream and waited for once: six blocking copies a history were 1,536 round trips a chunk)
-    for (uint32_t i = 0; i < k; i++) {
-      const Hist& H = B->hist[list[lo + i]];
-      const uint64_t n = H.n_ops, o = off[i], s0 = H.op_off;
-      if (!n) continue;
-      HIP_TRY(hipMemcpyAsync(f.data() + o, B->d_f.p + s0, n, hipMemcpyDeviceToHost, B->stream));
-      HIP_TRY(hipMemcpyAsync(a.data() + o, B->d_a.p + s0, n * 4, hipMemcpyDeviceToHost, B->stream));
-      HIP_TRY(hipMemcpyAsync(b.data() + o, B->d_b.p + s0, n * 4, hipMemcpyDeviceToHost, B->stream));
-      HIP_TRY(hipMemcpyAsync(pr.data() + o, B->d_proc.p + s0, n * 4, hipMemcpyDeviceToHost, B->stream));
-      HIP_TRY(hipMemcpyAsync(inv.data() + o, B->d_inv.p + s0, n * 4, hipMemcpyDeviceToHost, B->stream));
-      HIP_TRY(hipMemcpyAsync(ret.data() + o, B->d_ret.p + s0, n * 4, hipMemcpyDeviceToHost, B->stream));
-    }
-    HIP_TRY(hipStreamSynchronize(B->stream));
+    FetchedColumns fc;
+    if ((st = fetch_columns(B, list.data() + lo, k, fc)) != TBC_OK) break;
+    const uint64_t T = fc.T;
+    uint8_t* const f = fc.f; int32_t* const a = fc.a; int32_t* const b = fc.b; int32_t* const pr = fc.proc; uint32_t* const inv = fc.inv; uint32_t* const ret = fc.ret;
     tbc_batch_desc d{};
     d.n_hist = k; d.op_off = off.data(); d.n_events = nev.data(); d.n_process = npr.data(); d.model_aux = aux.data();
-    d.cols.n = (uint32_t)T; d.cols.f = f.data(); d.cols.a = a.data(); d.cols.b = b.data(); d.cols.process = pr.data();
-    d.cols.inv_pos = inv.data(); d.cols.ret_pos = ret.data();
+    d.cols.n = (uint32_t)T; d.cols.f = f; d.cols.a = a; d.cols.b = b; d.cols.process = pr;
+    d.cols.inv_pos = inv; d.cols.ret_pos = ret;
     tbc_opts o = B->opts;
     o.algorithm = TBC_ALG_COMPETITION; o.want_witness = 0; o.search_width = 0; o.lanes_per_history = 0; o.round_budget = 0; o.max_steps = 0;
     o.visited_per_op = 0; o.list_order = TBC_ORDER_DEFAULT;
@@ -365,6 +388,10 @@ struct RunState {
   // count form: the exact search runs under a budget of probes; what it does not finish goes through the relaxed refutation and
   // the prefix search (a caller who names max_steps gets one exact pass under that limit instead)
   const uint64_t count_budget;
+  // order restarts (tbcheck.h, TBC_DOM_NO_ORDER_RESTARTS): the first pass of a wide depth-first batch runs under the same kind of budget;
+  // what it leaves undecided is searched again in the next list order (order_restarts)
+  const uint64_t restart_budget;
+  uint64_t first_budget() const { return count_budget ? count_budget : restart_budget; }
   SweepArgs swa{};
   // a big quiet batch (several histories per wavefront), IF ASKED (tbc_opts.dominance, TBC_DOM_STALL_HANDOVER: off by default, tbcheck.h says why):
   // a history that stops passing completions is handed to the level sweep (hand_over_stalled) -- where that can answer: register / cas-register, one mask word, nobody asking for a witness or naming a step limit
@@ -379,6 +406,7 @@ struct RunState {
   std::vector<uint8_t> is_seq;            // which kernel owns the history's result
   std::vector<uint8_t> by_sweep;          // answered by the level sweep (analyzer :linear)
   std::vector<uint32_t> width_of;
+  std::vector<uint8_t> scratched;         // the history's last search ran in a scratch arena (freed since: its parked state points nowhere)
   bool touched_work = false;
   static constexpr uint64_t arena_budget = 32ull << 30;
 
@@ -386,6 +414,7 @@ struct RunState {
       : B(b), results(res), phase(ph), t_start(now_ns()), nh(b->n_hist), s(b->stream), beam(b->width > 1), KW(1 + b->mask_words), EW(b->entry_words()),
         hist_back(b->hist_back_m), bh_back(b->bh_back_m),
         count_budget((b->count_form && b->opts.max_steps == 0) ? 32ull * b->max_ops : 0ull),
+        restart_budget((ph == 0 && !b->sweep && b->order_restarts_apply()) ? 32ull * b->max_ops : 0ull),
         stall_on(b->lanes != 0 && (b->opts.dominance & TBC_DOM_STALL_HANDOVER) != 0 && !b->count_form && b->mask_words == 1 && !b->opts.want_witness && b->opts.max_steps == 0 && ph == 0 &&
                  (b->model.kind == TBC_MODEL_REGISTER || b->model.kind == TBC_MODEL_CAS_REGISTER) && b->vpad != 0),
         was_handed(b->n_hist, 0), rs_level(b->n_hist, kInf), rs_valid(b->n_hist, 0),
@@ -487,6 +516,10 @@ tbc_status first_pass(RunState& R) {
   TRACE("run: memsets queued");
   SYNC_TRACE("memsets");
 
+  if (!B->hist_order.empty()) {          // (a race's batch: every history's own list order goes up before the walk)
+    if (B->d_order.n < nh) { B->d_order.release(); const tbc_status os = B->d_order.alloc(nh); if (os != TBC_OK) return os; }
+    HIP_TRY(hipMemcpyAsync(B->d_order.p, B->hist_order.data(), (size_t)nh * 4, hipMemcpyHostToDevice, s));
+  }
   tbc_status ps = queue_pack(R);
   if (ps != TBC_OK) return ps;
   TRACE("run: pack launched");
@@ -523,7 +556,7 @@ tbc_status first_pass(RunState& R) {
     if (!launch_sweep(mine, s)) { set_error("level sweep launch failed"); return TBC_ERR_HIP; }
   } else if (beam) {
     BeamArgs ba = make_beam_args(B, B->d_btab.p, B->d_stack.p, B->d_dstack.p, nh);
-    if (R.count_budget) ba.max_steps = R.count_budget;
+    if (R.first_budget()) ba.max_steps = R.first_budget();
     if (rs_on) ba.abort = B->d_abort.p;
     if (B->lanes) { ba.tab_stride = B->tab_stride(); ba.epoch = use_epoch ? B->epoch : 0u; }
     if (R.stall_on) ba.stall_checks = kStallChecks;
@@ -738,10 +771,11 @@ tbc_status overflow_retries(RunState& R) {
           const uint64_t need = (1ull << lgs[pos]) * wpe * 8;
           if (!grp.empty() && (bytes + need > R.arena_budget || (pass == 1 && R.width_of[pend[pos]] != R.width_of[grp[0]]))) break;
           grp.push_back(pend[pos]); glg.push_back(lgs[pos]); R.final_log2[pend[pos]] = lgs[pos];
+          R.scratched[pend[pos]] = 1;
           bytes += need; pos++;
         }
         tbc_status st = scratch_pass(B, grp, glg, pass == 1, R.hist_back, R.bh_back, pass == 1 ? R.width_of[grp[0]] : 0, kCountExact, nullptr,
-                                     (pass == 1 && R.count_budget) ? (int64_t)R.count_budget : -1);
+                                     (pass == 1 && R.first_budget()) ? (int64_t)R.first_budget() : -1);
         if (st != TBC_OK) return st;
         R.touched_work = true;
       }
@@ -765,6 +799,270 @@ tbc_status stall_handover(RunState& R) {
   return TBC_OK;
 }
 
+// One budgeted pass of the wide / narrow depth-first search over `grp` in a scratch arena (count_mode, per-history prefix targets, `steps`
+// probes at most, 0 = no limit); a history whose visited set fills up is taken again with a 16x larger one.
+tbc_status budgeted_pass(RunState& R, const std::vector<uint32_t>& grp, uint32_t mode, const std::vector<uint32_t>* targets, int64_t steps) {
+  tbc_batch* B = R.B; const uint32_t EW = R.EW;
+  std::vector<uint32_t> todo = grp, tg, lgs;
+  if (targets) tg = *targets;
+  for (uint32_t h : todo) {
+    uint32_t lg = std::max(R.final_log2[h], ceil_log2(64ull * std::max<uint64_t>(B->hist[h].n_ops, 1)));
+    while (lg > 10 && ((1ull << lg) * EW * 8 > R.max_bytes || lg > kBeamMaxTabLog2)) lg--;
+    lgs.push_back(lg);
+  }
+  while (!todo.empty()) {
+    size_t pos = 0;
+    while (pos < todo.size()) {
+      std::vector<uint32_t> g, glg, gtg;
+      uint64_t bytes = 0;
+      while (pos < todo.size()) {
+        const uint64_t need = (1ull << lgs[pos]) * ((uint64_t)EW + 2) * 8;
+        if (!g.empty() && bytes + need > R.arena_budget) break;
+        g.push_back(todo[pos]); glg.push_back(lgs[pos]); if (targets) gtg.push_back(tg[pos]);
+        R.final_log2[todo[pos]] = lgs[pos]; bytes += need; pos++;
+      }
+      tbc_status st = scratch_pass(B, g, glg, true, R.hist_back, R.bh_back, 0, mode, targets ? &gtg : nullptr, steps);
+      if (st != TBC_OK) return st;
+    }
+    std::vector<uint32_t> again, alg, atg;
+    for (size_t i = 0; i < todo.size(); i++) {
+      const DevResult& d = B->res_host[todo[i]];
+      if (d.valid != TBC_UNKNOWN || d.cause != TBC_CAUSE_VISITED_FULL) continue;
+      uint32_t lg = lgs[i] + 4;
+      while (lg > lgs[i] && ((1ull << lg) * EW * 8 > R.max_bytes || lg > kBeamMaxTabLog2)) lg--;
+      if (lg > lgs[i]) { again.push_back(todo[i]); alg.push_back(lg); if (targets) atg.push_back(tg[i]); }
+    }
+    todo.swap(again); lgs.swap(alg); tg.swap(atg);
+  }
+  return TBC_OK;
+}
+
+// ---- ORDER RESTARTS (tbcheck.h, TBC_DOM_NO_ORDER_RESTARTS; oracle/wgl.py check_restart_pipeline states the same passes).  A pass over a
+// batch is as long as its slowest history, and at high concurrency the slowest history is slow because of the ORDER its candidates are
+// tried in -- another order ends it in a fraction of the probes (the costs are heavy-tailed and nearly independent between orders).  What
+// the budgeted first pass left undecided is searched again from scratch, order by order: the fronts' lists are walked again in the
+// pass's order (the walk with lane = front has no state to reset: streaming writes over the same places), the undecided histories run in
+// a scratch arena under the same budget; whoever no order ended runs in the default order without one.  The counters of a history are
+// the sums over its passes.
+static const uint32_t kRestartOrders[] = {16u + 48u, 2u, 1u, 16u + 8u, 0u};      // PackOpenArgs.list_order numbers (oracle/wgl.py RESTART_ORDERS)
+
+// ---- THE RACE (the form the library takes when nobody wants a witness).  One order after the other costs a budget per order before the
+// lucky one is reached, and a history no order is lucky for pays all of them and then its whole search (measured, bench workload_3:
+// 7.5k -> 2.9k histories/s).  Run AT THE SAME TIME the orders cost what the luckiest costs -- and the default order need not start again:
+// its search is RESUMED where the budget stopped it (BeamArgs.park / resume) while one small batch holds a replica of every undecided
+// history per other order (PackOpenArgs.order_of: each replica's lists walked in its own order), on a stream of its own.  All searches of
+// a history share one word: the first to decide it sets the word (BeamArgs.abort_set), the others stop at their next look at the clock
+// (BeamArgs.abort).  Six wavefronts a straggler, which is what a GPU whose pass is waiting for its slowest history has idle; a history
+// that is simply hard in every order costs what it cost before (its default-order search never stopped), plus the replicas' wavefronts.
+// Verdict and failing op are the search's in any order; WHICH order answers (and so the counters) can differ from run to run -- as
+// knossos.competition's :analyzer does.
+static const uint32_t kRaceOrders[] = {16u + 48u, 2u, 1u, 16u + 8u, 0u};      // PackOpenArgs.list_order numbers: the orders that race the default one
+tbc_status race_orders(RunState& R, const std::vector<uint32_t>& pend_all) {
+  tbc_batch* B = R.B; const uint32_t nh = R.nh; hipStream_t s = R.s;
+  constexpr uint32_t K = sizeof(kRaceOrders) / sizeof(kRaceOrders[0]);
+  const uint32_t default_order = B->list_order();
+  R.handed.resize(nh);
+  B->last_raced = (uint32_t)pend_all.size();
+  CtxSuspend own_arenas;                         // (the inner batch owns its arenas, stream and events)
+  // groups of histories whose replicas fit three quarters of the device memory that is free now (a replica: a first visited set of
+  // 64 entries an op -- a straggler's search needs 10^5 configs and more: a smaller set grows or, worse, fills up and starts again --
+  // with its stacks and growth pool, and the per-front tables: ~4 KB an op at 32 calls in flight)
+  size_t mem_free = 0, mem_total = 0;
+  if (hipMemGetInfo(&mem_free, &mem_total) != hipSuccess) mem_free = 32ull << 30;
+  const uint64_t mem_cap = std::max<uint64_t>(8ull << 30, (uint64_t)mem_free / 4 * 3);
+  std::vector<DevResult> outer_res(nh);
+  size_t lo = 0;
+  while (lo < pend_all.size()) {
+    uint64_t ops = 0;
+    size_t hi = lo;
+    while (hi < pend_all.size() && (hi == lo || (ops + B->hist[pend_all[hi]].n_ops) * 4000ull * (K + 1) <= mem_cap)) { ops += B->hist[pend_all[hi]].n_ops; hi++; }
+    const uint32_t k = (uint32_t)(hi - lo);
+    // ---- the default order goes on where its budgeted pass stopped (BeamArgs.resume: stacks, visited set, counters as they were left),
+    // in the batch's own arenas, on the batch's own stream -- launched first, so that nothing of what follows delays it.  (A history
+    // whose pass ended in a scratch arena -- its visited set had filled up -- has nothing left to go on from: the default order is one
+    // of its replicas below.)
+    std::vector<uint32_t> res_list, outer_map(nh, 0u);
+    for (uint32_t i = 0; i < k; i++) {
+      const uint32_t h = pend_all[lo + i];
+      outer_map[h] = i;
+      if (!R.scratched[h] && B->d_park.p) res_list.push_back(h);
+    }
+    DevBuf<uint32_t> decided, d_outer_map, d_inner_map;
+    tbc_status st;
+    if ((st = decided.alloc(k)) || (st = d_outer_map.alloc(nh))) return st;
+    HIP_TRY(hipMemsetAsync(decided.p, 0, (size_t)k * 4, s));
+    HIP_TRY(hipMemcpyAsync(d_outer_map.p, outer_map.data(), (size_t)nh * 4, hipMemcpyHostToDevice, s));
+    // the replicas' columns come from HBM first (the batch's stream is still idle)
+    std::vector<uint32_t> rep_hist, rep_order;          // replica -> (index in the group, its list order)
+    for (uint32_t i = 0; i < k; i++) {
+      for (uint32_t o : kRaceOrders) if (o != default_order) { rep_hist.push_back(i); rep_order.push_back(o); }
+      if (R.scratched[pend_all[lo + i]] || !B->d_park.p) { rep_hist.push_back(i); rep_order.push_back(default_order); }
+    }
+    const uint32_t nr = (uint32_t)rep_hist.size();
+    FetchedColumns fc;
+    if ((st = fetch_columns(B, pend_all.data() + lo, k, fc)) != TBC_OK) return st;
+    const std::vector<uint64_t>& goff = fc.off;
+    const uint8_t* const gf = fc.f; const int32_t* const ga = fc.a; const int32_t* const gb = fc.b; const int32_t* const gp = fc.proc;
+    const uint32_t* const gi = fc.inv; const uint32_t* const gr = fc.ret;
+    const uint32_t n_res = (uint32_t)res_list.size();
+    if (n_res) {
+      HIP_TRY(hipMemcpyAsync(B->d_work.p, res_list.data(), (size_t)n_res * 4, hipMemcpyHostToDevice, s));
+      BeamArgs ba = make_beam_args(B, B->d_btab.p, B->d_stack.p, B->d_dstack.p, n_res);
+      ba.resume = 1; ba.max_steps = 0; ba.abort = decided.p; ba.abort_set = decided.p; ba.abort_map = d_outer_map.p;
+      if (!launch_beam(ba, B->mask_words, search_blocks(n_res), s)) { set_error("unsupported mask width"); return TBC_ERR_UNSUPPORTED; }
+      HIP_TRY(hipGetLastError());
+      // (its results are read back AFTER the replicas have run: a copy into pageable memory queued here would hold this thread until the
+      // resumed searches end -- the first version did exactly that, and the race began when it was over: 21.6 s of a 24 s pass)
+      R.touched_work = true;
+    }
+    // ---- the other orders: ONE batch of replicas (a history once per order, each replica walked in its own order: PackOpenArgs.order_of),
+    // on a stream of its own beside the resumed default order; every replica of history i and the resumed search share word i
+    std::vector<uint64_t> off(nr + 1, 0);
+    std::vector<uint32_t> nev(nr), npr(nr), imap(nr);
+    for (uint32_t r = 0; r < nr; r++) {
+      const Hist& H = B->hist[pend_all[lo + rep_hist[r]]];
+      off[r + 1] = off[r] + H.n_ops; nev[r] = H.n_events; npr[r] = H.n_slots; imap[r] = rep_hist[r];
+    }
+    const uint64_t T = off[nr];
+    if (T > 0xFFFFFFFFull) { set_error("the race's replicas exceed 2^32 ops"); return TBC_ERR_OOM; }
+    std::vector<uint8_t> f(T + 1);
+    std::vector<int32_t> a(T + 1), b(T + 1), pr(T + 1);
+    std::vector<uint32_t> inv(T + 1), ret(T + 1);
+    for (uint32_t r = 0; r < nr; r++) {
+      const uint64_t n = off[r + 1] - off[r], o = off[r], g0 = goff[rep_hist[r]];
+      std::memcpy(f.data() + o, gf + g0, n);
+      std::memcpy(a.data() + o, ga + g0, n * 4); std::memcpy(b.data() + o, gb + g0, n * 4); std::memcpy(pr.data() + o, gp + g0, n * 4);
+      std::memcpy(inv.data() + o, gi + g0, n * 4); std::memcpy(ret.data() + o, gr + g0, n * 4);
+    }
+    tbc_batch_desc d{};
+    d.n_hist = nr; d.op_off = off.data(); d.n_events = nev.data(); d.n_process = npr.data();
+    d.cols.n = (uint32_t)T; d.cols.f = f.data(); d.cols.a = a.data(); d.cols.b = b.data(); d.cols.process = pr.data();
+    d.cols.inv_pos = inv.data(); d.cols.ret_pos = ret.data();
+    tbc_opts o = B->opts;
+    o.algorithm = TBC_ALG_COMPETITION; o.want_witness = 0; o.search_width = B->width; o.lanes_per_history = 64; o.round_budget = 0; o.max_steps = 0;
+    o.visited_per_op = 64; o.list_order = TBC_ORDER_SLOT; o.dominance = (B->opts.dominance | TBC_DOM_NO_ORDER_RESTARTS) & ~TBC_DOM_STALL_HANDOVER;
+    std::vector<tbc_result> res(nr);
+    tbc_batch* inner = nullptr;
+    TRACE("race: the replicas' batch is being made");
+    st = nr ? tbc_batch_create(&d, &B->model, &o, &inner) : TBC_OK;
+    if (st == TBC_OK && nr) {
+      st = d_inner_map.alloc(nr);
+      if (st == TBC_OK && hipMemcpy(d_inner_map.p, imap.data(), (size_t)nr * 4, hipMemcpyHostToDevice) != hipSuccess) st = TBC_ERR_HIP;
+      if (st == TBC_OK) {
+        inner->ext_abort = decided.p; inner->ext_abort_set = decided.p; inner->ext_abort_map = d_inner_map.p;
+        inner->hist_order = rep_order;
+        TRACE("race: the replicas run");
+        st = tbc_batch_run(inner, res.data());
+        TRACE("race: the replicas are done");
+      }
+    }
+    if (inner) tbc_batch_destroy(inner);
+    HIP_TRY(hipSetDevice(B->device));
+    const bool inner_ok = nr != 0 && (st == TBC_OK || st == TBC_ERR_BAD_HISTORY || st == TBC_ERR_MODEL);
+    if (!inner_ok && n_res == 0) { decided.release(); d_outer_map.release(); d_inner_map.release(); return st == TBC_OK ? TBC_ERR_HIP : st; }
+    if (n_res) HIP_TRY(hipMemcpyAsync(outer_res.data(), B->d_results.p, (size_t)nh * sizeof(DevResult), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));          // the resumed default order: decided, or told to stop by a replica that was
+    TRACE("race: the resumed default order is done");
+    decided.release(); d_outer_map.release(); d_inner_map.release();
+    // ---- who answered: the default order if it decided (its counters are then the whole single search's -- nothing was done twice);
+    // else the first replica, in the orders' sequence, that did.  What the others did before they stopped is work done: it is counted.
+    std::vector<uint32_t> first_rep(k, 0xFFFFFFFFu);
+    for (uint32_t r = nr; r-- > 0;) first_rep[rep_hist[r]] = r;
+    for (uint32_t i = 0; i < k; i++) {
+      const uint32_t h = pend_all[lo + i];
+      const bool resumed = !R.scratched[h] && B->d_park.p != nullptr && n_res != 0;
+      if (resumed) B->res_host[h] = outer_res[h];
+      const bool outer_decided = resumed && (outer_res[h].valid == TBC_VALID || outer_res[h].valid == TBC_INVALID);
+      tbc_counters extra{};
+      int win = -1;
+      if (inner_ok) for (uint32_t r = first_rep[i]; r < nr && rep_hist[r] == i; r++) {
+        if (win < 0 && (res[r].valid == TBC_VALID || res[r].valid == TBC_INVALID)) win = (int)r;
+        const tbc_counters& c = res[r].counters;
+        extra.steps += c.steps; extra.visited += c.visited; extra.probes += c.probes; extra.backtracks += c.backtracks;
+        extra.max_depth = std::max(extra.max_depth, c.max_depth);
+      }
+      if (outer_decided) {
+        // (the normal marshalling answers from res_host; the replicas' work is added to its counters)
+        DevResult& dr = B->res_host[h];
+        dr.steps += extra.steps; dr.visited += extra.visited; dr.probes += extra.probes; dr.backtracks += extra.backtracks;
+        dr.max_depth = std::max<uint64_t>(dr.max_depth, extra.max_depth);
+        continue;
+      }
+      if (win < 0) {          // nobody decided (a limit): the default order's answer stands, or the first replica's if there is no other
+        if (resumed || !inner_ok) continue;
+        win = (int)first_rep[i];
+      }
+      tbc_result r = res[(size_t)win];
+      r.witness = nullptr; r.n_witness = 0;
+      r.counters.steps = extra.steps; r.counters.visited = extra.visited; r.counters.probes = extra.probes; r.counters.backtracks = extra.backtracks;
+      r.counters.max_depth = extra.max_depth;
+      R.handed[h] = r;
+      R.was_handed[h] = 1;
+      B->order_of_hist[h] = rep_order[(size_t)win];
+    }
+    lo = hi;
+  }
+  return TBC_OK;
+}
+
+tbc_status order_restarts(RunState& R) {
+  tbc_batch* B = R.B; const uint32_t nh = R.nh; hipStream_t s = R.s;
+  std::vector<uint32_t> pend;
+  for (uint32_t h = 0; h < nh; h++)
+    if (!R.is_seq[h] && R.hist_back[h].status == 0 && B->res_host[h].valid == TBC_UNKNOWN && B->res_host[h].cause == TBC_CAUSE_STEP_LIMIT) pend.push_back(h);
+  if (pend.empty()) return TBC_OK;
+  // nobody wants a witness: the orders run at the same time (race_orders); with a witness (whose ops live in the answering batch's
+  // memory) one after the other, deterministically, as oracle/wgl.py check_restart_pipeline states
+  if (!B->opts.want_witness) {
+    const tbc_status rs = race_orders(R, pend);
+    if (rs != TBC_ERR_OOM) return rs;
+    // (no memory for the race beside this batch: what the budget cut short runs on in the default order, as it did before round 6)
+    std::vector<uint32_t> left;
+    for (uint32_t h : pend) if (!R.was_handed[h] && B->res_host[h].valid == TBC_UNKNOWN && B->res_host[h].cause == TBC_CAUSE_STEP_LIMIT) left.push_back(h);
+    B->last_raced = 0;
+    const tbc_status fs = left.empty() ? TBC_OK : budgeted_pass(R, left, kCountExact, nullptr, 0);
+    R.touched_work = true;
+    return fs;
+  }
+  struct Acc { uint64_t steps, visited, probes, backtracks, max_depth; };
+  std::vector<Acc> acc(nh, Acc{0, 0, 0, 0, 0});
+  const auto bank = [&](const std::vector<uint32_t>& grp) {
+    for (uint32_t h : grp) { const DevResult& d = B->res_host[h]; Acc& a = acc[h]; a.steps += d.steps; a.visited += d.visited; a.probes += d.probes; a.backtracks += d.backtracks; a.max_depth = std::max(a.max_depth, d.max_depth); }
+  };
+  const std::vector<uint32_t> all = pend;
+  const uint32_t default_order = B->list_order();
+  tbc_status st = TBC_OK;
+  const auto pass = [&](uint32_t order, int64_t steps) -> tbc_status {
+    bank(pend);                                            // what the pass before left behind
+    B->order_override = order;
+    launch_pack_open(make_pack_open_args(B), s, true);      // the lists again, in this pass's order (counts and places stay)
+    HIP_TRY(hipGetLastError());
+    tbc_status ps = budgeted_pass(R, pend, kCountExact, nullptr, steps);
+    if (ps != TBC_OK) return ps;
+    std::vector<uint32_t> left;
+    for (uint32_t h : pend) {
+      const DevResult& d = B->res_host[h];
+      if (d.valid == TBC_UNKNOWN && d.cause == TBC_CAUSE_STEP_LIMIT) left.push_back(h);
+      else B->order_of_hist[h] = order;
+    }
+    pend.swap(left);
+    return TBC_OK;
+  };
+  for (uint32_t order : kRestartOrders) {
+    if (pend.empty()) break;
+    if ((st = pass(order, (int64_t)R.restart_budget)) != TBC_OK) break;
+  }
+  if (st == TBC_OK && !pend.empty()) st = pass(default_order, 0);
+  B->order_override = tbc_batch::kNoOrderOverride;
+  if (st != TBC_OK) return st;
+  for (uint32_t h : all) {          // counters: the sum over the passes a history went through (its last pass's are in res_host)
+    DevResult& d = B->res_host[h]; const Acc& a = acc[h];
+    d.steps += a.steps; d.visited += a.visited; d.probes += a.probes; d.backtracks += a.backtracks; d.max_depth = std::max(d.max_depth, a.max_depth);
+  }
+  R.touched_work = true;
+  return TBC_OK;
+}
+
 // ---- count form: the histories the budgeted exact search left undecided (oracle/wgl_count.c; tests/test_count_form.py states the
 // same pipeline over the oracle).  (1) The RELAXED search -- every class of crashed calls an unlimited supply, counts ignored: a
 // superset of the linearizations over a config space no larger than a crash-free history's -- either finds a linearization (then
@@ -775,8 +1073,8 @@ tbc_status stall_handover(RunState& R) {
 // it was stuck with (as any exact search); when the prefix of t completions is linearizable -- the t-th completion is what nobody can
 // pass -- the ONE config its linearization ended in (the others would take the exhaustion this pipeline exists to avoid).
 tbc_status count_form_pipeline(RunState& R) {
-  tbc_batch* B = R.B; const uint32_t nh = R.nh; const uint32_t EW = R.EW;
-  HostBuf<Hist>& hist_back = R.hist_back; HostBuf<BeamHist>& bh_back = R.bh_back;
+  tbc_batch* B = R.B; const uint32_t nh = R.nh;
+  HostBuf<Hist>& hist_back = R.hist_back;
   std::vector<uint32_t> pend;
   for (uint32_t h = 0; h < nh; h++)
     if (!R.is_seq[h] && B->res_host[h].valid == TBC_UNKNOWN && B->res_host[h].cause == TBC_CAUSE_STEP_LIMIT) pend.push_back(h);
@@ -786,41 +1084,7 @@ tbc_status count_form_pipeline(RunState& R) {
   const auto bank = [&](const std::vector<uint32_t>& grp) {
     for (uint32_t h : grp) { const DevResult& d = B->res_host[h]; Acc& a = acc[h]; a.steps += d.steps; a.visited += d.visited; a.probes += d.probes; a.backtracks += d.backtracks; a.max_depth = std::max(a.max_depth, d.max_depth); }
   };
-  // one pass over `grp` in a scratch arena; a history whose visited set fills up is taken again with a 16x larger one
-  const auto run_pass = [&](const std::vector<uint32_t>& grp, uint32_t mode, const std::vector<uint32_t>* targets) -> tbc_status {
-    std::vector<uint32_t> todo = grp, tg, lgs;
-    if (targets) tg = *targets;
-    for (uint32_t h : todo) {
-      uint32_t lg = std::max(R.final_log2[h], ceil_log2(64ull * std::max<uint64_t>(B->hist[h].n_ops, 1)));
-      while (lg > 10 && ((1ull << lg) * EW * 8 > R.max_bytes || lg > kBeamMaxTabLog2)) lg--;
-      lgs.push_back(lg);
-    }
-    while (!todo.empty()) {
-      size_t pos = 0;
-      while (pos < todo.size()) {
-        std::vector<uint32_t> g, glg, gtg;
-        uint64_t bytes = 0;
-        while (pos < todo.size()) {
-          const uint64_t need = (1ull << lgs[pos]) * ((uint64_t)EW + 2) * 8;
-          if (!g.empty() && bytes + need > R.arena_budget) break;
-          g.push_back(todo[pos]); glg.push_back(lgs[pos]); if (targets) gtg.push_back(tg[pos]);
-          R.final_log2[todo[pos]] = lgs[pos]; bytes += need; pos++;
-        }
-        tbc_status st = scratch_pass(B, g, glg, true, hist_back, bh_back, 0, mode, targets ? &gtg : nullptr, 0);
-        if (st != TBC_OK) return st;
-      }
-      std::vector<uint32_t> again, alg, atg;
-      for (size_t i = 0; i < todo.size(); i++) {
-        const DevResult& d = B->res_host[todo[i]];
-        if (d.valid != TBC_UNKNOWN || d.cause != TBC_CAUSE_VISITED_FULL) continue;
-        uint32_t lg = lgs[i] + 4;
-        while (lg > lgs[i] && ((1ull << lg) * EW * 8 > R.max_bytes || lg > kBeamMaxTabLog2)) lg--;
-        if (lg > lgs[i]) { again.push_back(todo[i]); alg.push_back(lg); if (targets) atg.push_back(tg[i]); }
-      }
-      todo.swap(again); lgs.swap(alg); tg.swap(atg);
-    }
-    return TBC_OK;
-  };
+  const auto run_pass = [&](const std::vector<uint32_t>& grp, uint32_t mode, const std::vector<uint32_t>* targets) -> tbc_status { return budgeted_pass(R, grp, mode, targets, 0); };
   bank(pend);
   // (what the relaxed SWEEP already decided is not searched again: refuted at a completion -> the prefix pass; valid under the
   // relaxation -> the exact search without a budget; only the others -- no sweep, or a burst that outgrew its sets -- take the relaxed search)
@@ -986,6 +1250,7 @@ tbc_status batch_run_impl(tbc_batch* B, tbc_result* results, int phase) {
   if (B->inputs_stale) { set_error("the last submitted input was refused: there is nothing resident to run (submit another, or destroy and create)"); return TBC_ERR_INVALID_ARG; }
   RunState R(B, results, phase);
   const uint32_t nh = R.nh;
+  B->last_raced = 0;
   if (phase != 2 && (st = first_pass(R)) != TBC_OK) return st;
   B->partial_done = phase == 1;
   if (phase == 1) return TBC_OK;
@@ -1002,8 +1267,11 @@ tbc_status batch_run_impl(tbc_batch* B, tbc_result* results, int phase) {
   if (B->sweep && (st = sweep_verdicts(R)) != TBC_OK) return st;
   if (R.beam && (st = list_overflow_fallback(R)) != TBC_OK) return st;
   R.width_of.assign(nh, B->width);
+  R.scratched.assign(nh, 0);
   if ((st = overflow_retries(R)) != TBC_OK) return st;
   if (R.stall_on && (st = stall_handover(R)) != TBC_OK) return st;
+  B->order_of_hist.assign(nh, B->list_order());
+  if (R.restart_budget && (st = order_restarts(R)) != TBC_OK) { B->order_override = tbc_batch::kNoOrderOverride; return st; }
   if (R.count_budget && (st = count_form_pipeline(R)) != TBC_OK) return st;
   st = finish(R);
   if (phase == 0 && B->assign_lists) {          // a fresh input's lists that did not fit their arena: room for the next one

@@ -173,9 +173,10 @@ WV_DEV void walk_wave(const PackOpenArgs& A, uint32_t wid, uint32_t* lds, uint32
   // does not depend on when it meets it: they take keys above every live one, by table position.  The keys stay in registers, one
   // candidate per lane (three sets); candidate j's key reaches the lanes by a lane read (j is uniform), and every lane counts the
   // smaller keys for each of its candidates: 1 + 2 vector instructions per set instead of a dozen with two LDS reads.
-  const bool by_ret = A.list_order != 0u;
-  const uint32_t wr_last = A.list_order == 2u ? 0x40000000u : A.list_order >= 16u ? 2u * (A.list_order - 16u) + 1u : 0u;
-  const uint32_t rk_mul = A.list_order >= 16u ? 2u : 1u;
+  const uint32_t list_order = A.order_of ? A.order_of[h] : A.list_order;          // (the history's own order, if the batch says one)
+  const bool by_ret = list_order != 0u;
+  const uint32_t wr_last = list_order == 2u ? 0x40000000u : list_order >= 16u ? 2u * (list_order - 16u) + 1u : 0u;
+  const uint32_t rk_mul = list_order >= 16u ? 2u : 1u;
   uint16_t* const perm = reinterpret_cast<uint16_t*>(aux);
   if (by_ret) {
     uint32_t my[3], place[3] = {0u, 0u, 0u};

@@ -38,6 +38,7 @@ tbc_status tbc_batch_last_counters(const tbc_batch* b, tbc_counters* out) {
 uint64_t tbc_batch_device_bytes(const tbc_batch* b) { return b ? b->device_bytes : 0; }
 uint32_t tbc_batch_search_width(const tbc_batch* b) { return b ? (b->lanes ? 1u : b->width) : 0; }
 uint32_t tbc_batch_lanes_per_history(const tbc_batch* b) { return b ? (b->lanes ? b->lanes : 64u) : 0; }
+uint32_t tbc_batch_last_raced(const tbc_batch* b) { return b ? b->last_raced : 0; }
 uint32_t tbc_batch_list_order(const tbc_batch* b) {
   if (!b) return 0;
   const uint32_t lo = b->list_order();          // PackOpenArgs' numbering -> TBC_ORDER_*

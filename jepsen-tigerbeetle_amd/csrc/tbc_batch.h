@@ -229,9 +229,28 @@ struct tbc_batch {
   }
   // PackOpenArgs.list_order: 0 = slot order, 1 = completion, 2 = completion with the :write calls last, 16 + W
   uint32_t list_order() const {
+    if (order_override != kNoOrderOverride) return order_override;          // a pass of the order restarts (batch_run.hip): its own order
     if (!list_order_applies() || opts.list_order == TBC_ORDER_SLOT) return 0u;
     if (opts.list_order == TBC_ORDER_DEFAULT) return kDefaultListOrder;
     return opts.list_order >= 16u ? opts.list_order : opts.list_order - 1u;        // TBC_ORDER_COMPLETION = 2 -> 1, TBC_ORDER_WRITES_LAST = 3 -> 2
+  }
+  // ORDER RESTARTS (batch_run.hip, order_restarts): a history of the wide depth-first search that has not ended within a budget of probes
+  // is searched again from scratch in the next list order.  While such a pass runs the fronts' lists are walked again in ITS order.
+  static constexpr uint32_t kNoOrderOverride = 0xFFFFFFFFu;
+  uint32_t order_override = kNoOrderOverride;
+  std::vector<uint32_t> order_of_hist;      // last run: the list order (PackOpenArgs numbering) each history was answered in
+  // a RACE of list orders (batch_run.hip, race_orders): this batch is one of several that search the same histories, each in its own order;
+  // a history one of them decides sets its word, and the others' searches of it stop when they see it (BeamArgs.abort / abort_set)
+  const uint32_t* ext_abort = nullptr;
+  uint32_t* ext_abort_set = nullptr;
+  const uint32_t* ext_abort_map = nullptr;  // which word is history h's (several orders' replicas of one history share a word)
+  std::vector<uint32_t> hist_order;         // per history its own list order (PackOpenArgs numbering), or empty: the batch's for all
+  tbc::DevBuf<uint32_t> d_order;
+  tbc::DevBuf<uint32_t> d_park;             // wide kernel: the search state of every history as the last launch left it (BeamArgs.park)
+  uint32_t last_raced = 0;                  // last run: histories that went into a race of orders
+  bool order_restarts_apply() const {
+    return width > 1 && !lanes && !count_form && list_order_applies() && opts.list_order == TBC_ORDER_DEFAULT && opts.max_steps == 0 &&
+           !(opts.dominance & TBC_DOM_NO_ORDER_RESTARTS);
   }
   std::vector<tbc::BeamHist> bh;
   tbc::DevBuf<tbc::BeamHist> d_bh;

@@ -269,6 +269,7 @@ struct PackOpenArgs {
   uint32_t vpad;
   uint32_t h0;               // histories [h0, n_hist) are worked on by this launch
   const uint64_t* cmem;      // count form: class members (inv_rank | op << 32), or null
+  const uint32_t* order_of;  // per history: its own list_order (a race of orders keeps several orders' replicas of a history in one batch), or null
   uint32_t list_order;       // 0 = a front's list in process-slot order; 1 = in order of completion (the walk with lane = front only;
                              // tbc_opts.list_order TBC_ORDER_COMPLETION): the search takes a config's candidates last to first and pops the last child first, so the call
                              // that completes soonest is tried first -- on the bench workload 18 % fewer rounds for the same probes, the longest
@@ -341,7 +342,14 @@ struct BeamArgs {
   uint32_t epoch;                    // narrow kernel: this pass's tag in the visited-set keys, 1..255 (wgl_narrow_impl.h, entry_empty); 0 = none
   uint32_t first_dynamic;            // narrow kernel: work items below this are dealt to the wavefronts at launch (wave w, group g: w * H + g) ...
   unsigned int* next_work;           // ... the others are taken from this counter (zeroed before the launch) as groups finish
+  uint32_t* abort_set;               // wide kernel, optional: a history that ends VALID or INVALID sets its word here -- the same history searched in
+                                     // ANOTHER list order by another batch on another stream (whose BeamArgs.abort this is) may stop (batch_run.hip, race_orders)
+  const uint32_t* abort_map;         // ... which word of abort / abort_set is history hidx's (null: word hidx)
+  uint32_t* park;                    // wide kernel, optional: kParkWords words per history -- the search state as the kernel leaves it ...
+  uint32_t resume;                   // ... and, 1: the search is taken up from there (the visited set, the stacks and the growth pool as they were left) instead of from the root
+  uint32_t pad6;
 };
+constexpr uint32_t kParkWords = 32;
 
 // ---- level sweep (jit_sweep.hip): knossos.linear as segments swept by one wavefront each
 constexpr uint32_t kSweepCap = 512;        // configs per LDS set when many wavefronts must share a CU (38 KB, four per CU) ...

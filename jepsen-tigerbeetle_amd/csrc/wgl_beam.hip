@@ -356,9 +356,10 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
     const uint32_t cap0 = rfl(B->tab_log2);
     int32_t verdict0 = -2;
     uint32_t sp0 = 0;
+    const bool resuming = A.resume != 0u && A.park != nullptr && status == 0 && R != 0;
     if (status != 0) verdict0 = TBC_UNKNOWN;
     else if (R == 0) verdict0 = TBC_VALID;
-    else {
+    else if (!resuming) {
       // root config: first entry of its bucket
       const uint64_t k0 = 1ull | ((uint64_t)(uint32_t)A.init_state << 32);
       uint64_t zero[MW];
@@ -375,6 +376,16 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
       }
       sp0 = 1;
     }
+    if (resuming) {
+      // taken up where a budgeted pass left it: every word of the parked state, the verdict open again, the clock started again
+      if (lane < S_WORDS) S[lane] = A.park[(uint64_t)hidx * kParkWords + lane];
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (lane == 0) {
+        sst(S, S_VERDICT, (uint32_t)-2); sst(S, S_CAUSE, (uint32_t)TBC_CAUSE_NONE);
+        sst64(S, S_T0, A.time_limit_ticks ? (uint64_t)wall_clock64() : 0ull);
+      }
+    } else
     if (lane == 0) {
       sst64(S, S_TAB, (uint64_t)tab0); sst64(S, S_STACK, (uint64_t)stack0);
       sst64(S, S_DSTACK, (look && A.dstack) ? (uint64_t)((gu32*)A.dstack + ru64(B->stack_off)) : 0ull);
@@ -421,7 +432,8 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
   bool need_grow = false, need_switch = false;
 
   while (verdict == -2) {
-    // step limit (as after the iteration that exceeded it), or 2^31 probes to fold into the 64-bit totals
+    // step limit (as after the ITERATION that exceeded it: every popped config is expanded completely, so the parked state is one the
+    // search can be taken up from -- BeamArgs.resume; oracle/wgl_beam.c counts the same way for K > 1), or 2^31 probes to fold into the 64-bit totals
     if (__builtin_expect(probes > probe_room, 0)) { need_park = true; break; }
     if (sp == 0) {
       // no linearization through the live configs.  Those the lookahead set aside become the stack and the
@@ -864,7 +876,8 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
       }
       // (BeamArgs.abort: somebody else has decided this history meanwhile -- read past the caches, it is written while the kernel runs)
       const uint32_t* const ab = C->abort;
-      if (ab && verdict == -2 && __hip_atomic_load(ab + hidx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) {
+      const uint32_t* const abm = C->abort_map;
+      if (ab && verdict == -2 && __hip_atomic_load(ab + (abm ? abm[hidx] : hidx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) {
         verdict = TBC_UNKNOWN; cause = TBC_CAUSE_STEP_LIMIT;
       }
     }
@@ -987,6 +1000,16 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
     }
     out->steps = probes; out->visited = visited; out->probes = probes; out->backtracks = expanded;
     out->max_depth = max_sp; out->bucket_reads = rounds; out->tab_log2 = cap_log2;
+    // (a race of list orders: this history is decided -- whoever searches it in another order may stop)
+    uint32_t* const done = C->abort_set;
+    const uint32_t* const dmap = C->abort_map;
+    if (done && (verdict == TBC_VALID || verdict == TBC_INVALID)) __hip_atomic_store(done + (dmap ? dmap[hidx] : hidx), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  // the search state as it is left (batch_run.hip, race_orders: a history whose budgeted pass ended at the budget is taken up from here
+  // while other list orders race it -- the work done so far is not done again)
+  {
+    uint32_t* const park = C->park;
+    if (park && lane < S_WORDS) park[(uint64_t)hidx * kParkWords + lane] = S[lane];
   }
   uint32_t* const dbg = C->dbg;
   if (dbg && lane == 0) {

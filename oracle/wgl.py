@@ -445,6 +445,38 @@ def completion_rank(ops, op):
     return int((ret < ret[op]).sum())
 
 
+# the list orders the library's ORDER RESTARTS go through after the default one, as PackOpenArgs.list_order numbers (csrc/batch_run.hip kRestartOrders)
+RESTART_ORDERS = (16 + 48, 2, 1, 16 + 8, 0)
+DEFAULT_ORDER = 16 + 24
+
+
+def check_restart_pipeline(ops, model, width=4, budget=None, want_witness=False):
+    """What the library does with a hard history of the wide depth-first search (csrc/batch_run.hip, order_restarts), pass by pass over
+    wgl_beam.c: the search in the library's default list order (16 + 24) under a budget of probes (the library: 32 per op of the batch's
+    longest history); a history that has not ended by then is searched AGAIN FROM SCRATCH in the next list order under the same budget
+    -- at high concurrency the cost of a depth-first search is heavy-tailed in the order its candidates are tried and nearly independent
+    between orders, so the first order that is lucky ends it -- and when no order ended it, in the default order without a budget.
+    Returns (valid, fail_op, result of the last pass, counters summed over the passes, which pass answered)."""
+    n = len(ops["f"])
+    budget = 32 * n if budget is None else budget
+    tot = {"probes": 0, "visited": 0, "expanded": 0, "max_stack": 0}
+
+    def add(r):
+        for k in ("probes", "visited", "expanded"):
+            tot[k] += r[k]
+        tot["max_stack"] = max(tot["max_stack"], r["max_stack"])
+        return r
+    seq = [(DEFAULT_ORDER, budget)]
+    for o in RESTART_ORDERS:          # PackOpenArgs numbers -> the oracle's (0 slot, 1 completion, 2 writes last = the oracle's 4)
+        seq.append(((4 if o == 2 else o), budget))
+    seq.append((DEFAULT_ORDER, 0))
+    for k, (order, cap) in enumerate(seq):
+        r = add(check_beam(ops, model, width, want_witness=want_witness, list_order=order, max_probes=cap))
+        if r["valid"] != -1:
+            return r["valid"], r["fail_op"], r, tot, f"pass {k} (order {order}, budget {cap})"
+    return -1, r["fail_op"], r, tot, "no pass ended"
+
+
 def check_count_pipeline(ops, model, width=4, budget=None, want_witness=False, round_pairs=64, relaxed_sweep=False):
     """What the library does with a history in count form (tbc_api.hip, batch_run_impl), pass by pass over wgl_count.c: the exact
     search under a budget of probes (the library: 32 per op of the batch's longest history); past it the RELAXED search (every

@@ -667,8 +667,12 @@ int wgl_beam_check_rp(uint32_t n, const uint8_t* f, const int32_t* a, const int3
         spair[sp] = 0xFFFFu;
         stack[sp++] = id;
       }
-      if (max_probes && st->probes > max_probes) { verdict = -1; break; }
+      /* the step limit: one config per iteration (the narrow kernel's schedule) ends with the ROUND that exceeded it; K configs per
+       * iteration (the wide kernel's) with the ITERATION -- every popped config is then expanded completely, so the state the search
+       * is left in (stacks, visited set) is one it can be taken up from (csrc/wgl_beam.hip BeamArgs.resume: the race of list orders) */
+      if (K == 1 && max_probes && st->probes > max_probes) { verdict = -1; break; }
     }
+    if (K > 1 && verdict == -2 && max_probes && st->probes > max_probes) verdict = -1;
     if (sp > st->max_stack) st->max_stack = sp;
   }
 

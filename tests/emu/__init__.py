@@ -16,7 +16,10 @@ _CSRC = os.path.join(_ROOT, "jepsen-tigerbeetle_amd", "csrc")
 # write of the kernel body past any of them stops the test); run as  LD_PRELOAD=$(gcc -print-file-name=libasan.so)
 # ASAN_OPTIONS=detect_leaks=0 TBC_EMU_ASAN=1 python -m pytest tests/test_narrow_emu.py
 _ASAN = os.environ.get("TBC_EMU_ASAN") == "1"
-_SO = os.path.join(_HERE, "_build", "libemu_narrow_asan.so" if _ASAN else "libemu_narrow.so")
+# TBC_EMU_DEFS="-DTBC_NARROW_EB=1 ...": the kernel body's build-time forms (wgl_narrow_impl.h) under the emulator, in a library of their own
+_DEFS = os.environ.get("TBC_EMU_DEFS", "").split()
+_TAG = "".join(c if c.isalnum() else "_" for c in "".join(_DEFS))
+_SO = os.path.join(_HERE, "_build", ("libemu_narrow_asan" if _ASAN else "libemu_narrow") + (("_" + _TAG) if _TAG else "") + ".so")
 _LIB = None
 
 
@@ -35,7 +38,7 @@ def build(force=False):
         os.makedirs(os.path.dirname(_SO), exist_ok=True)
         subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function", "-Wno-unknown-pragmas"]
                               + (["-fsanitize=address", "-fno-omit-frame-pointer"] if _ASAN else [])
-                              + ["-I", _HERE, "-I", _CSRC, "-o", _SO, srcs[0]])
+                              + _DEFS + ["-I", _HERE, "-I", _CSRC, "-o", _SO, srcs[0]])
     return _SO
 
 
