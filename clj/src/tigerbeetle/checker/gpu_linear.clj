@@ -42,6 +42,11 @@
                   :bytes_matrix 40}
    :setfull_rows {:size 72  :n_elements 0 :n_reads 4 :device 8 :reserved0 12 :add_invoke 16 :add_ok 24
                   :read_invoke 32 :read_ok 40 :top 48 :exc_off 56 :exc 64}
+   ;; streaming (round 6): pointers into one pinned slot of a batch; what the last consumed input cost
+   :batch_input  {:size 64  :n_hist_cap 0 :reserved0 4 :ops_cap 8 :op_off 16 :n_events 24 :n_process 32 :word 40
+                  :inv_pos 48 :ret_pos 56}
+   :input_info   {:size 56  :n_hist 0 :pending 4 :total_ops 8 :bytes_copied 16 :ns_copy 24 :inputs_consumed 32
+                  :lists_regrown 40 :n_hist_cap 44 :ops_cap 48}
    :enums        {:type     {:invoke 0 :ok 1 :fail 2 :info 3}
                   :f        {:read 0 :write 1 :cas 2 :acquire 3 :release 4 :add 5 :txn 6 :transfer 7 :class 8}
                   :model    {:register 0 :cas-register 1 :mutex 2 :table 3 :multi-register 4 :set 5 :bank 6}
@@ -49,7 +54,9 @@
                   :valid    {:valid 1 :invalid 0 :unknown -1}
                   :cause    {:none 0 :time-limit 1 :step-limit 2 :memory 3}
                   :max-final-configs 10
-                  :config-pending 16}})
+                  :config-pending 16
+                  :wire-nil 255                  ; TBC_WIRE_NIL
+                  :comm-id-bytes 128}})          ; TBC_COMM_ID_BYTES
 
 (defn- o
   "Byte offset of field k of struct s (or its :size)."
@@ -393,10 +400,120 @@
           ;; (the library copies the columns during tbc_batch_create; the results and the per-key columns result-map reads live to the end)
           (keeping [enc op-off n-ev n-pr c-f c-a c-b c-p c-inv c-ret desc ms opt hnd res]
             (when (zero? (.invokeInt (f "tbc_batch_create") (to-array [desc ms opt hnd])))
-              (try
-                (when (zero? (.invokeInt (f "tbc_batch_run") (to-array [(.getValue hnd) res])))
-                  (vec (map-indexed (fn [i {:keys [ops inv ret]}] (result-map res (* i (o :result :size)) m ops inv ret)) enc)))
-                (finally (.invoke (f "tbc_batch_destroy") Void/TYPE (to-array [(.getValue hnd)])))))))))))
+              (let [keep? (::keep-open opts)          ; open-stream: the batch stays for check-next!
+                    out   (try
+                            (when (zero? (.invokeInt (f "tbc_batch_run") (to-array [(.getValue hnd) res])))
+                              (vec (map-indexed (fn [i {:keys [ops inv ret]}] (result-map res (* i (o :result :size)) m ops inv ret)) enc)))
+                            (finally (when-not keep? (.invoke (f "tbc_batch_destroy") Void/TYPE (to-array [(.getValue hnd)])))))]
+                (if keep?
+                  (if out
+                    {:handle (.getValue hnd) :model m :n-hist-cap nh :results out}
+                    (do (.invoke (f "tbc_batch_destroy") Void/TYPE (to-array [(.getValue hnd)])) nil))
+                  out)))))))))
+
+;; ---------------------------------------------------------------------------------------------------------
+;; streaming: ONE batch kept across many inputs (include/tbcheck.h "streaming"; csrc/batch_stream.hip).  The reference checks every
+;; history once (core.clj:139-146; workloads/set_full.clj:155-158): a run that checks many groups of keys opens a stream with the first
+;; group and hands every later group to the same batch -- its arenas, streams and kernel choices stay, the op columns cross PCIe in
+;; the 12-byte wire format, straight out of the slot this code writes them into.
+;; ---------------------------------------------------------------------------------------------------------
+(defn- wire-word
+  "TBC_WIRE_WORD: f | a << 4 | b << 12 | process << 20 (a / b: 0..254 or nil = 255)."
+  ^long [^long f a b ^long process]
+  (let [nil8 (long (get-in abi [:enums :wire-nil]))
+        v8   (fn [v] (cond (= v NIL) nil8 (<= 0 v 254) (long v) :else (throw (ex-info "value beyond the wire format" {:value v}))))]
+    (when-not (<= 0 process 4095) (throw (ex-info "process beyond the wire format" {:process process})))
+    (bit-or f (bit-shift-left (v8 a) 4) (bit-shift-left (if (= f (f-code :cas)) (v8 b) 0) 12) (bit-shift-left process 20))))
+
+(defn open-stream
+  "A batch created from the first group of histories (as check-batch) that stays open: returns {:handle :model :n-hist-cap :results}
+   or nil.  Check further groups with check-next!, free it with close-stream!."
+  [m histories opts]
+  (when-let [first-results (check-batch m histories (assoc opts ::keep-open true))]
+    first-results))
+
+(defn check-next!
+  "The next group of histories through an open stream (tbc_batch_map_input -> the wire columns written in place ->
+   tbc_batch_submit_input -> tbc_batch_run).  `slot` 0 / 1 alternately lets the copy of one group run under the search of the
+   previous one when two threads feed the stream.  Returns one result map per history, or nil (the caller then creates a batch)."
+  [{:keys [handle model]} histories slot]
+  (let [enc (mapv #(paired (columns % model)) histories)]
+    (when (every? some? enc)
+      (let [in  (struct :batch_input)
+            nh  (count enc)
+            res (doto (Memory. (* (o :result :size) (max 1 nh))) (.clear))]
+        (keeping [enc in res]
+          (when (and (zero? (.invokeInt (f "tbc_batch_map_input") (to-array [handle (int slot) in])))
+                     (<= nh (.getInt in (o :batch_input :n_hist_cap)))
+                     (<= (reduce + (map :n-ops enc)) (.getLong in (o :batch_input :ops_cap))))
+            (let [op-off (.getPointer in (o :batch_input :op_off)) n-ev (.getPointer in (o :batch_input :n_events))
+                  n-pr   (.getPointer in (o :batch_input :n_process)) word (.getPointer in (o :batch_input :word))
+                  inv    (.getPointer in (o :batch_input :inv_pos))  ret  (.getPointer in (o :batch_input :ret_pos))]
+              (.setLong op-off 0 0)
+              (loop [es enc i 0 off 0]
+                (when-let [{:keys [n n-ops n-process of oa ob oproc] :as e} (first es)]
+                  (dotimes [j n-ops]
+                    (let [at (* 4 (+ off j))]
+                      (.setInt word at (unchecked-int (wire-word (.getByte ^Memory of j) (.getInt ^Memory oa (* 4 j)) (.getInt ^Memory ob (* 4 j))
+                                                                 (.getInt ^Memory oproc (* 4 j)))))
+                      (.setInt inv at (.getInt ^Memory (:inv e) (* 4 j)))
+                      (.setInt ret at (.getInt ^Memory (:ret e) (* 4 j)))))
+                  (.setInt n-ev (* 4 i) (int n)) (.setInt n-pr (* 4 i) (int n-process))
+                  (.setLong op-off (* 8 (inc i)) (+ off n-ops))
+                  (recur (rest es) (inc i) (+ off n-ops))))
+              (when (and (zero? (.invokeInt (f "tbc_batch_submit_input") (to-array [handle (int slot) (int nh)])))
+                         (zero? (.invokeInt (f "tbc_batch_run") (to-array [handle res]))))
+                (vec (map-indexed (fn [i {:keys [ops inv ret]}] (result-map res (* i (o :result :size)) model ops inv ret)) enc))))))))))
+
+(defn close-stream! [{:keys [handle]}]
+  (when handle (.invoke (f "tbc_batch_destroy") Void/TYPE (to-array [handle]))))
+
+;; ---------------------------------------------------------------------------------------------------------
+;; one history over several GPUs, one JVM per GPU (include/tbcheck.h tbc_comm_*; csrc/tbc_comm.hip): rank 0 makes the id, the
+;; ranks exchange its 128 bytes however they talk to each other (the control node's own channel), every rank calls sharded-analysis
+;; with the SAME history and gets the same result map.
+;; ---------------------------------------------------------------------------------------------------------
+(defn comm-unique-id
+  "128 bytes for rank 0 to hand to the other ranks."
+  ^bytes []
+  (let [n (int (get-in abi [:enums :comm-id-bytes])) id (Memory. n)]
+    (when (zero? (.invokeInt (f "tbc_comm_unique_id") (to-array [id])))
+      (.getByteArray id 0 n))))
+
+(defn comm-init
+  "This rank's RCCL communicator (tbc_comm_init): a Pointer to keep and to free with comm-destroy!, or nil."
+  [rank world ^bytes id device]
+  (let [n (int (get-in abi [:enums :comm-id-bytes])) mem (doto (Memory. n) (.write 0 id 0 n)) out (PointerByReference.)]
+    (keeping [mem out]
+      (when (zero? (.invokeInt (f "tbc_comm_init") (to-array [(int rank) (int world) mem (int device) out])))
+        (.getValue out)))))
+
+(defn comm-destroy! [comm] (when comm (.invoke (f "tbc_comm_destroy") Void/TYPE (to-array [comm]))))
+
+(defn sharded-analysis
+  "(knossos.linear/analysis model history) with this rank's share of the level sweep's wavefronts and ONE all-gather of the
+   relation tables inside the library (tbc_batch_sweep_allgather).  Every rank of `comm` calls it with the same history."
+  [comm m hist opts]
+  (when-let [[kind init n-keys] (and @lib comm (model->native m))]
+    (when-let [{:keys [ops inv ret n-ops n n-process] :as p} (paired (columns hist m))]
+      (let [os     (ops-struct p)
+            op-off (let [mem (Memory. (* 8 2))] (dorun (map-indexed (fn [i x] (.setLong mem (* 8 i) x)) [0 n-ops])) mem)   ; op_off[0 .. 1] of the one history
+            n-ev   (int-pool [n]) n-pr (int-pool [n-process])
+            C      (o :batch_desc :cols)
+            desc   (doto (struct :batch_desc)
+                     (.setInt (o :batch_desc :n_hist) 1) (.setPointer (o :batch_desc :op_off) op-off)
+                     (.setPointer (o :batch_desc :n_events) n-ev) (.setPointer (o :batch_desc :n_process) n-pr))
+            _      (.write desc (long C) (.getByteArray os 0 (o :ops :size)) 0 (int (o :ops :size)))      ; tbc_batch_desc.cols = the tbc_ops
+            ms     (model-struct kind init n-keys)
+            opt    (opts-struct (assoc opts :algorithm :linear))
+            hnd    (PointerByReference.)
+            res    (doto (Memory. (o :result :size)) (.clear))]
+        (keeping [p os op-off n-ev n-pr desc ms opt hnd res]
+          (when (zero? (.invokeInt (f "tbc_batch_create") (to-array [desc ms opt hnd])))
+            (try
+              (when (zero? (.invokeInt (f "tbc_batch_sweep_allgather") (to-array [(.getValue hnd) comm res])))
+                (result-map res 0 m ops inv ret))
+              (finally (.invoke (f "tbc_batch_destroy") Void/TYPE (to-array [(.getValue hnd)]))))))))))
 
 (defn memo-table
   "knossos.model.memo/memo through tbc_memo_build: the dense transition table of an arbitrary model over the op

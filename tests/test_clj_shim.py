@@ -77,7 +77,8 @@ def test_the_shim_reads_as_clojure_forms(shim):
     src, forms = shim
     assert forms[0].startswith("(ns tigerbeetle.checker.gpu-linear")
     names = set(re.findall(r"^\((?:defn-?|def|defrecord)\s+(?:\^\S+\s+)?([^\s\]\[()]+)", src, re.M))
-    assert {"abi", "analysis", "linearizable", "check-batch", "memo-table", "set-full-indices", "bank-model", "Bank"} <= names, names
+    assert {"abi", "analysis", "linearizable", "check-batch", "memo-table", "set-full-indices", "bank-model", "Bank",
+            "open-stream", "check-next!", "close-stream!", "comm-unique-id", "comm-init", "sharded-analysis"} <= names, names
     for clj in ("scripts/knossos_crosscheck.clj",):
         top_level_forms(open(os.path.join(ROOT, clj)).read())
 
@@ -92,7 +93,8 @@ def test_brackets_checker_catches_imbalance():
 def test_abi_table_equals_the_ctypes_binding(native, abi):
     N = native
     structs = {"events": N.Events, "ops": N.Ops, "model": N.Model, "opts": N.Opts, "config": N.Config, "result": N.Result,
-               "batch_desc": N.BatchDesc, "setfull_in": N.SetFullIn, "setfull_out": N.SetFullOut, "setfull_rows": N.SetFullRows}
+               "batch_desc": N.BatchDesc, "setfull_in": N.SetFullIn, "setfull_out": N.SetFullOut, "setfull_rows": N.SetFullRows,
+               "batch_input": N.BatchInput, "input_info": N.InputInfo}
     assert abi["version"] == N.lib().tbc_version() == 2
     assert set(abi) == set(structs) | {"version", "enums"}
     for name, cls in structs.items():
@@ -114,6 +116,7 @@ def test_abi_table_equals_the_ctypes_binding(native, abi):
     assert e["valid"] == {"valid": N.VALID, "invalid": N.INVALID, "unknown": N.UNKNOWN}
     assert e["cause"] == {"none": N.CAUSE_NONE, "time-limit": N.CAUSE_TIME_LIMIT, "step-limit": N.CAUSE_STEP_LIMIT, "memory": N.CAUSE_VISITED_FULL}
     assert e["max-final-configs"] == len(N.Result().configs) and e["config-pending"] == len(N.Config().pending)
+    assert e["wire-nil"] == N.WIRE_NIL and e["comm-id-bytes"] == N.COMM_ID_BYTES
     # ... and against the header itself, for the enum spellings the binding takes on trust
     hdr = open(os.path.join(ROOT, "include", "tbcheck.h")).read()
     for k, v in e["f"].items():
@@ -142,7 +145,8 @@ def test_entry_points_the_shim_invokes_are_exported(native, shim):
     src, _ = shim
     called = set(re.findall(r'\(f "(tbc_[a-z_]+)"\)', src)) | set(re.findall(r'getFunction l "(tbc_[a-z_]+)"', src))
     assert {"tbc_version", "tbc_pair_events", "tbc_check", "tbc_result_free", "tbc_batch_create", "tbc_batch_run", "tbc_batch_destroy",
-            "tbc_memo_build", "tbc_setfull_create", "tbc_setfull_run", "tbc_setfull_destroy"} <= called
+            "tbc_memo_build", "tbc_setfull_create", "tbc_setfull_run", "tbc_setfull_destroy",
+            "tbc_batch_map_input", "tbc_batch_submit_input", "tbc_comm_unique_id", "tbc_comm_init", "tbc_comm_destroy", "tbc_batch_sweep_allgather"} <= called
     for name in called:
         assert hasattr(native.lib(), name), name
 
