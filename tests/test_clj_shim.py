@@ -169,3 +169,29 @@ def test_call_site_patches_apply_to_the_reference(tmp_path):
         top_level_forms(open(work / rel).read())          # still balanced after the patch
     assert "gpu-linear/linearizable" in open(work / "src/tigerbeetle/workloads/set_full.clj").read()
     assert "net.java.dev.jna/jna" in open(work / "project.clj").read()
+
+
+def test_the_crosscheck_recipe_still_covers_every_golden_file():
+    """`make -C clj crosscheck` is the only route to "parity pinned" (DESIGN.md): stock Knossos / jepsen.checker over tests/golden/edn*/.
+    Nobody here can run it, so what can rot silently is checked: the script reads as Clojure, takes its cases from expected.json, knows every
+    model and checker those cases name, the Makefile runs it over both directories and hands the output to the comparer -- and every
+    .edn file on disk IS a case (a golden file nobody lists would never be cross-checked)."""
+    import json
+    script = open(os.path.join(ROOT, "scripts", "knossos_crosscheck.clj")).read()
+    top_level_forms(script)
+    assert '"expected.json"' in script and "(:cases expected)" in script
+    known_models = set(re.findall(r'"([a-z-]+)"\s+#\(model/', script))
+    mk = open(os.path.join(ROOT, "clj", "Makefile")).read()
+    for d in ("edn", "edn_checkers"):
+        gold = os.path.join(ROOT, "tests", "golden", d)
+        cases = json.load(open(os.path.join(gold, "expected.json")))["cases"]
+        listed = {c["file"] for c in cases}
+        on_disk = {f for f in os.listdir(gold) if f.endswith(".edn")}
+        assert listed == on_disk, (d, sorted(listed ^ on_disk))
+        for c in cases:
+            if "model" in c and c["model"] != "bank":          # (Knossos ships no bank model: those files pin this repository's own)
+                assert c["model"] in known_models, c
+            if "checker" in c:
+                assert c["checker"] in ("set-full", "linearizable"), c
+        assert f"tests/golden/{d} > tests/golden/{d}/expected_knossos.json" in mk
+    assert "scripts/compare_crosscheck.py" in mk and os.path.exists(os.path.join(ROOT, "scripts", "compare_crosscheck.py"))

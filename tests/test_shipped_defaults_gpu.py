@@ -82,3 +82,40 @@ def test_a_big_quiet_batch_under_the_defaults(native, oracle):
     for k in range(NB):
         ref = refs[k % 64]
         assert res[k]["valid"] == ref["valid"] and (ref["valid"] == 1 or res[k]["fail_op"] == ref["fail_op"]), k
+
+
+def test_the_other_models_and_the_narrow_shapes_under_the_defaults(native, oracle):
+    """The parity files pinned by tests/conftest.py (mask form, slot order), a second time with NOTHING pinned, at verdict / failing-op level:
+    set and bank (the lazy rule), multi-register, the narrow kernel's shapes as one batch of >= 24,576 histories (the library then takes
+    eight to a wavefront, the default list order and -- for what the wide kernel gets -- the race of list orders on its own)."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from helpers import bank_history, multi_register_history, set_history
+    from test_commutative_models import enc_bank, enc_set
+    from test_multi_register import encode as enc_mr
+    o = core.make_opts(time_limit_ms=60000, algorithm=N.ALG_COMPETITION, want_witness=False)
+    for which, n_ops, procs, info, corrupt in [("set", 800, 8, 0.02, None), ("set", 800, 8, 0.0, "phantom"), ("set", 3000, 5, 0.02, "lost"),
+                                                ("bank", 800, 8, 0.02, False), ("bank", 800, 8, 0.0, True), ("mr", 600, 8, 0.02, False), ("mr", 600, 8, 0.0, True)]:
+        for seed in range(2):
+            if which == "set":
+                e, om = enc_set(set_history(n_ops, procs, seed, busy=0.2, info=info, corrupt=corrupt))
+            elif which == "bank":
+                e, om = enc_bank(bank_history(n_ops, procs, seed, busy=0.2, info=info, corrupt=corrupt))
+            else:
+                e, om = enc_mr(multi_register_history(n_ops, procs, seed, n_keys=8, n_values=5, busy=0.25, info=info, corrupt=corrupt))
+            exp = oracle.check_beam(e.ops.as_dict(), om, 8)
+            got = core.check_ops(e.ops, e.native_model, o)
+            assert got["valid"] == exp["valid"] == (0 if corrupt else 1), (which, seed)
+            if exp["valid"] == 0:
+                assert got["fail_op"] == exp["fail_op"], (which, seed)
+    shapes = [(40, 4, 0.0, 0.0, 0.5), (200, 8, 0.0, 0.6, 0.3), (1000, 16, 0.0, 0.0, 0.5), (1000, 16, 0.0, 0.6, 0.2), (3000, 64, 0.0, 0.0, 0.1), (3000, 64, 0.0, 0.6, 0.05)]
+    base = [columns.pair_events(synth.register_events(n_ops=n, n_procs=p, seed=7700 + s, busy=busy, info=info, corrupt=corrupt))
+            for (n, p, info, corrupt, busy) in shapes for s in range(4)]
+    refs = [oracle.check(h.as_dict(), CAS, "window", max_steps=20_000_000, want_witness=False) for h in base]
+    NB = 24576 + len(base)
+    with core.Batch([base[i % len(base)] for i in range(NB)], core.make_model(N.MODEL_CAS_REGISTER, N.NIL), o) as b:
+        res = b.run().results()
+    for k in range(NB):
+        ref = refs[k % len(base)]
+        if ref["valid"] != -1:
+            assert res[k]["valid"] == ref["valid"] and (ref["valid"] == 1 or res[k]["fail_op"] == ref["fail_op"]), k
