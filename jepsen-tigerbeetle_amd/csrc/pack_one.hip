@@ -29,6 +29,11 @@ __global__ __launch_bounds__(64 * packone::BatchGeo::kNW) void pack_wg_kernel(Pa
 }
 __global__ __launch_bounds__(64 * packone::Batch64Geo::kNW) void pack_wg64_kernel(PackArgs A, PackOpenArgs O) {
   __shared__ __attribute__((aligned(16))) uint32_t lds[packone::Batch64Geo::lds_words()];
+#ifdef TBC_PACK_LDS_PAD          // (a profiling build: fewer workgroups a CU -- does a workgroup get faster when fewer share the memory system?)
+  __shared__ uint32_t lds_pad[TBC_PACK_LDS_PAD];
+  if (A.n_hist == 0xFFFFFFFFu) lds_pad[threadIdx.x] = 1u;
+  if (A.n_hist == 0xFFFFFFFEu) lds[0] = lds_pad[threadIdx.x ^ 1u];
+#endif
   packone::history<packone::Batch64Geo>(A, O, lds);
 }
 }  // namespace
@@ -68,7 +73,21 @@ bool pack_wg64_fits(uint32_t model_kind, uint32_t n_ops, uint32_t n_events, uint
 // histories [a.h0, a.n_hist), one workgroup of four wavefronts each (31 KB of LDS, static): pack + open counts.  The caller has
 // asked pack_wg_fits() of every history, o is what launch_pack_open() would hand open_counts_kernel (same h0 / n_hist), and the
 // walk that follows is launched with skip_counts.  slots64: every history also passed pack_wg64_fits() (19 KB of LDS).  false = not launched.
-bool launch_pack_wg(const PackArgs& a, const PackOpenArgs& o, void* stream, bool slots64) {
+#ifdef TBC_PACK_PROF
+// (a profiling build only, scripts/build_variant.sh: the per-phase ticks go to 64 words of DEVICE memory -- atomics on the host-mapped debug
+// words clogged the very thing that was being measured -- and tbc_pack_prof_read brings them back)
+static uint32_t* g_pack_prof = nullptr;
+extern "C" int tbc_pack_prof_read(uint32_t* out) {
+  if (!g_pack_prof) return 0;
+  return hipMemcpy(out, g_pack_prof, 64 * 4, hipMemcpyDeviceToHost) == hipSuccess ? 1 : 0;
+}
+#endif
+bool launch_pack_wg(const PackArgs& a_in, const PackOpenArgs& o, void* stream, bool slots64) {
+  PackArgs a = a_in;
+#ifdef TBC_PACK_PROF
+  if (!g_pack_prof && hipMalloc((void**)&g_pack_prof, 64 * 4) == hipSuccess) (void)hipMemset(g_pack_prof, 0, 64 * 4);
+  a.dbg = g_pack_prof;
+#endif
   if (a.n_hist <= a.h0 || o.h0 != a.h0 || o.n_hist != a.n_hist || !o.bh || !o.off || !o.ncr || !o.slot8 || (o.branch_lists && !o.rk8)) return false;
   if (slots64) hipLaunchKernelGGL(pack_wg64_kernel, dim3(a.n_hist - a.h0), dim3(64 * packone::Batch64Geo::kNW), 0, (hipStream_t)stream, a, o);
   else hipLaunchKernelGGL(pack_wg_kernel, dim3(a.n_hist - a.h0), dim3(64 * packone::BatchGeo::kNW), 0, (hipStream_t)stream, a, o);

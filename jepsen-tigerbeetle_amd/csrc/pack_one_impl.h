@@ -141,6 +141,17 @@ WV_DEV void history(const PackArgs& A, const PackOpenArgs& O, uint32_t* lds) {
   // a history pack refuses (or one without a completion) leaves no lists: what open_counts_kernel says of it
   const auto no_lists = [&]() { if (G::kCounts && tid == 0u) { Bh->status = 0u; Bh->n_crashed = 0u; Bh->lst_need = 0u; } };
 
+  // TBC_PACK_PROF (a build of its own, scripts/build_variant.sh): where a workgroup's time goes -- its first thread adds the 100 MHz clock's
+  // ticks per phase to the debug words 32.. (TBC_DEBUG=1), tbc_debug_peek reads them
+#if defined(TBC_PACK_PROF) && !defined(TBC_EMU)
+  uint64_t prof_t = wall_clock64();
+  uint32_t prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  // (the ticks are kept in registers and added to the profile words once, when the workgroup ends)
+#define TBC_PROF_PHASE(ph_) do { if (tid == 0u) { const uint64_t t_ = wall_clock64(); prof_acc[ph_] += (uint32_t)(t_ - prof_t); prof_t = t_; \
+    if ((ph_) == 7 && A.dbg) { for (int q_ = 1; q_ < 8; q_++) atomicAdd(&A.dbg[32 + q_], prof_acc[q_]); } } } while (0)
+#else
+#define TBC_PROF_PHASE(ph_) do {} while (0)
+#endif
   // ---- phase 0: LDS tables to zero
   for (uint32_t w = tid; w < nw; w += kT) bm[w] = 0u;
   for (uint32_t x = tid; x < G::kNW * W; x += kT) cnt[x] = 0u;
@@ -184,6 +195,7 @@ WV_DEV void history(const PackArgs& A, const PackOpenArgs& O, uint32_t* lds) {
     if (done) wv::lds_add32_wg(&flag[1], done);
   }
   wv::wg_barrier();
+  TBC_PROF_PHASE(1);
   const uint32_t err1 = wv::lds_ld32(&flag[0]), n_done = wv::lds_ld32(&flag[1]);
   if (err1) {
     if (tid == 0u) { H->n_ret = 0u; H->status = (err1 & 0x100u) ? (uint32_t)TBC_ERR_MODEL : (uint32_t)TBC_ERR_BAD_HISTORY; }
@@ -202,6 +214,7 @@ WV_DEV void history(const PackArgs& A, const PackOpenArgs& O, uint32_t* lds) {
     TBC_PACK_ONE_SCAN(run, R, sum, 0);
     for (uint32_t w = lo; w < hi; w++) { pre[w] = run; run += (uint32_t)__builtin_popcount(bm[w]); }
   }
+  TBC_PROF_PHASE(2);
   if (R != n_done) {      // two completions on one history row
     if (tid == 0u) { H->n_ret = 0u; H->status = (uint32_t)TBC_ERR_BAD_HISTORY; }
     no_lists();
@@ -223,6 +236,7 @@ WV_DEV void history(const PackArgs& A, const PackOpenArgs& O, uint32_t* lds) {
     // (W can be as many as the threads: the scan's total is the last entry either way)
   }
   wv::wg_barrier();
+  TBC_PROF_PHASE(3);
 
   // ---- phase 4: every wavefront walks its block, 64 ops at a time.  An op's place in its process's list = the list's first
   // record + 1 + the ops of the process placed by earlier blocks and earlier chunks of this block (cnt) + the lower lanes of this
@@ -291,6 +305,7 @@ WV_DEV void history(const PackArgs& A, const PackOpenArgs& O, uint32_t* lds) {
     }
     if (G::kCounts && crashed_cands) wv::lds_add32_wg(&flag[2], crashed_cands);
   }
+  TBC_PROF_PHASE(4);
   // the sentinels
   for (uint32_t p = tid; p < W; p += kT) {
     Rec hd; hd.inv_rank = 0; hd.ret_rank = 0; hd.opidx = kInf; hd.f = kFNone; hd.a = 0; hd.b = 0; hd.cls = 0; hd.prod = kLookNone;
@@ -298,8 +313,9 @@ WV_DEV void history(const PackArgs& A, const PackOpenArgs& O, uint32_t* lds) {
     rec[seg[p]] = hd;
     rec[seg[p + 1u] - 1u] = tl;
   }
-  wv::threadfence();
+  wv::wg_fence();          // (the records are read back below by other wavefronts of THIS workgroup, through L2: no wider fence -- wave_env.h)
   wv::wg_barrier();
+  TBC_PROF_PHASE(5);
 
   // ---- phase 5: one open op per process: the previous op of the same process must have completed before this one was invoked
   // (the previous record of the list; another wavefront may have written it: agent-scope loads, as pack_kernel's)
@@ -328,6 +344,7 @@ WV_DEV void history(const PackArgs& A, const PackOpenArgs& O, uint32_t* lds) {
     if (err) wv::lds_or32(&flag[0], err);
   }
   wv::wg_barrier();
+  TBC_PROF_PHASE(6);
   const uint32_t err5 = wv::lds_ld32(&flag[0]);
   if (tid == 0u) { H->n_ret = R; H->status = err5 ? (uint32_t)TBC_ERR_BAD_HISTORY : 0u; }
 
@@ -384,6 +401,7 @@ WV_DEV void history(const PackArgs& A, const PackOpenArgs& O, uint32_t* lds) {
       }
       if (tid == 0u) { Bh->status = 0u; Bh->n_crashed = all; }
     }
+    TBC_PROF_PHASE(7);
     if (O.look) {                 // lookahead records past the last rank: nothing is needed there
       const uint32_t MW = O.mask_words, LW = 1u + MW;
       uint64_t* look = O.look + look_off(H->op_off, h, MW);

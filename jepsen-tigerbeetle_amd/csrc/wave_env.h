@@ -45,6 +45,13 @@ WV_DEV void barrier() {
   __builtin_amdgcn_wave_barrier();
 }
 WV_DEV void threadfence() { __threadfence(); }
+// Stores of this wavefront (or of the workgroup's other wavefronts, behind a workgroup barrier) are in L2 before what follows reads them
+// back through L2 (sc1 loads) -- a WORKGROUP-scope fence: s_waitcnt, nothing else.  __threadfence() is an AGENT-scope fence, and on a
+// chip of eight XCDs whose L2s are not coherent with each other that means `buffer_wbl2 sc1` + `buffer_inv sc1`: the XCD's whole L2
+// written back and its lines dropped -- for every other wavefront on the XCD too.  Round 6 found one of those in every workgroup of
+// pack_wg64_kernel and one per finished history in wgl_narrow_kernel (32,768 a launch); nothing in these kernels is read by another
+// compute unit before the kernel ends.
+WV_DEV void wg_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); }
 // the lane number, opaque to the optimiser: what an iteration derives from it is recomputed instead of kept live
 WV_DEV uint32_t opaque(uint32_t v) { asm volatile("" : "+v"(v)); return v; }
 

@@ -258,7 +258,7 @@ __device__ __forceinline__ bool grow_visited_set(state_ptr S, uint32_t* r_pos, u
     }
     st32(remap + s, idx);
   }
-  __threadfence();
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");      // (one wavefront owns the history: its stores are in L2 before it reads them back; an agent-scope fence would write back and drop the XCD's whole L2 -- wave_env.h wg_fence)
 #pragma unroll 1
   for (uint64_t s = lane; s < old_cap; s += 64) {       // parent links -> new slot numbers
     if ((uint32_t)ld64(tab + s * KW) == 0u) continue;
@@ -273,7 +273,7 @@ __device__ __forceinline__ bool grow_visited_set(state_ptr S, uint32_t* r_pos, u
   for (uint32_t i = lane; i < dsp; i += 64)
     st32(ndstack + i, ld32(remap + ld32(dstack + i)));
   if (lane < kRing) r_pos[lane] = kNone;       // the ring held old slot numbers
-  __threadfence();
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");      // (one wavefront owns the history: its stores are in L2 before it reads them back; an agent-scope fence would write back and drop the XCD's whole L2 -- wave_env.h wg_fence)
   if (lane == 0) {
     sst64(S, S_TAB, (uint64_t)ntab); sst64(S, S_STACK, (uint64_t)nstack); sst64(S, S_DSTACK, (uint64_t)ndstack);
     sst(S, S_CAP, cap_log2 + 2u);

@@ -157,7 +157,7 @@ WV_DEV bool grow_group(ColdArgs C, wv::gu64*& tab_u, wv::gu32*& stack_u, wv::gu3
     }
     wv::st32(remap + s, idx);
   }
-  wv::threadfence();
+  wv::wg_fence();
   wv::barrier();
   WV_NOUNROLL
   for (uint64_t s = lane; links && s < old_cap; s += 64) {       // parent links -> new slot numbers (none are kept without a witness: the old table may have no room for them at all)
@@ -173,7 +173,7 @@ WV_DEV bool grow_group(ColdArgs C, wv::gu64*& tab_u, wv::gu32*& stack_u, wv::gu3
   }
   WV_NOUNROLL
   for (uint32_t i = lane; i < dsp; i += 64) wv::st32(ndstack + i, wv::ld32(remap + wv::ld32(dstack + i)));
-  wv::threadfence();
+  wv::wg_fence();
   wv::barrier();
   tab_u = ntab; stack_u = nstack; dstack_u = ndstack; cap_log2_u = cap_log2 + 2u;
   return true;
@@ -362,7 +362,7 @@ WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* ld
   // of an invalid verdict are collected for one group at a time by the whole wavefront.
   const auto report = [&](bool sel) {
     wv::wait_stores();
-    wv::threadfence();
+    wv::wg_fence();
     wv::barrier();
     const auto C = wv::cold(A);
     const int32_t verdict = (int32_t)GS[G_VERDICT];
@@ -467,7 +467,7 @@ WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* ld
     if (gb) {
       const auto C = wv::cold(A);
       wv::wait_stores();                           // the plain stores of the rounds so far are in L2 before the table is re-read
-      wv::threadfence();
+      wv::wg_fence();
       for (uint32_t gg = 0; gg < H; gg++) {
         if (!((gb >> (gg * L)) & 1ull)) continue;
         const uint32_t src = gg * L;

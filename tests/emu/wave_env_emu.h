@@ -120,6 +120,7 @@ template <int N>
 inline uint32_t row_shr0_emu(uint32_t v) { return row_shr0_at<N>(v, 100000 + N); }
 inline void barrier_at(int site) { (void)gather(0, site); }
 inline void threadfence() {}
+inline void wg_fence() {}
 inline uint32_t opaque(uint32_t v) { return v; }
 
 inline uint64_t ld64(const gu64* p) { return *p; }
