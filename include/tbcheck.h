@@ -292,7 +292,16 @@ enum { TBC_DOM_NO_EAGER_READS = 1u, TBC_DOM_NO_TWIN_RULE = 2u,
         * any order, which order answers and hence the counters can differ from run to run.  With a witness: one order after the other
         * under the same budget, then the default order without one -- deterministic, the counters the sums over the passes, which
         * oracle/wgl.py check_restart_pipeline states pass by pass.  Set = one pass, no budget. */
-       TBC_DOM_NO_ORDER_RESTARTS = 32u };
+       TBC_DOM_NO_ORDER_RESTARTS = 32u,
+       /* multi-register (knossos.model/multi-register) under the wide schedule (search_width > 1), round 6; both on by default:
+        * EAGER TXNS -- an open :txn of micro-reads only, each nil or what the state holds for its key, is linearized at once (it changes
+        * nothing, so every later schedule stays possible; such calls are in the witness, not in the search's chain of branching calls).
+        * TXN INDEPENDENCE -- txns conflict when one writes a key the other reads or writes, and txns that do not conflict commute.  At a
+        * config whose front is the completion of call X, the candidates are the closure of {X} under "conflicts with" among the open calls
+        * not yet linearized (persistent-set reduction: in any valid continuation the first member of that closure can be moved to the
+        * front).  Same verdicts and failing ops; fewer configs (oracle/wgl_beam.c: 20k-op histories of 256 processes at 7.7 calls in
+        * flight, > 3 * 10^7 probes plain, 4 - 7 * 10^6 under both). */
+       TBC_DOM_NO_EAGER_TXNS = 64u, TBC_DOM_NO_TXN_INDEPENDENCE = 128u };
 
 /* ------------------------------------------------------------------ result */
 enum { TBC_VALID = 1, TBC_INVALID = 0, TBC_UNKNOWN = -1 };

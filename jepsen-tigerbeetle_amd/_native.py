@@ -34,6 +34,7 @@ ALG_COMPETITION, ALG_WGL, ALG_LINEAR = 0, 1, 2
 VALID, INVALID, UNKNOWN = 1, 0, -1
 CAUSE_NONE, CAUSE_TIME_LIMIT, CAUSE_STEP_LIMIT, CAUSE_VISITED_FULL = 0, 1, 2, 3
 DOM_NO_EAGER_READS, DOM_NO_TWIN_RULE, DOM_NO_COUNT_FORM, DOM_NO_LAZY_COMMUTING, DOM_STALL_HANDOVER, DOM_NO_ORDER_RESTARTS = 1, 2, 4, 8, 16, 32
+DOM_NO_EAGER_TXNS, DOM_NO_TXN_INDEPENDENCE = 64, 128
 # tbc_opts.list_order (16 + W: completion order, a :write as if it completed W ranks later; the default where it applies is 16 + 24)
 ORDER_DEFAULT, ORDER_SLOT, ORDER_COMPLETION, ORDER_WRITES_LAST, ORDER_WRITE_DELAY = 0, 1, 2, 3, 16
 # status

@@ -36,7 +36,7 @@ DEFAULT_LIST_ORDER = 0
 
 def make_opts(algorithm=N.ALG_WGL, device=0, time_limit_ms=0, max_steps=0, max_visited_bytes=0,
               want_witness=True, visited_per_op=0, search_width=0, round_budget=0, lookahead=True,
-              eager_reads=True, twin_rule=True, lanes_per_history=0, count_form=None, lazy_commuting=True, list_order=None, stall_handover=False, order_restarts=True):
+              eager_reads=True, twin_rule=True, lanes_per_history=0, count_form=None, lazy_commuting=True, list_order=None, stall_handover=False, order_restarts=True, eager_txns=True, txn_independence=True):
     o = N.Opts()
     o.algorithm = algorithm
     o.device = device
@@ -48,7 +48,7 @@ def make_opts(algorithm=N.ALG_WGL, device=0, time_limit_ms=0, max_steps=0, max_v
     o.search_width = int(search_width)
     o.round_budget = int(round_budget)
     o.lookahead = 0 if lookahead else 1     # C-ABI: 0 = on (default), 1 = off
-    o.dominance = (0 if eager_reads else N.DOM_NO_EAGER_READS) | (0 if twin_rule else N.DOM_NO_TWIN_RULE) | (0 if (DEFAULT_COUNT_FORM if count_form is None else count_form) else N.DOM_NO_COUNT_FORM) | (0 if lazy_commuting else N.DOM_NO_LAZY_COMMUTING) | (N.DOM_STALL_HANDOVER if stall_handover else 0) | (0 if order_restarts else N.DOM_NO_ORDER_RESTARTS)      # (stall_handover: the one opt-in bit, tbcheck.h)
+    o.dominance = (0 if eager_reads else N.DOM_NO_EAGER_READS) | (0 if twin_rule else N.DOM_NO_TWIN_RULE) | (0 if (DEFAULT_COUNT_FORM if count_form is None else count_form) else N.DOM_NO_COUNT_FORM) | (0 if lazy_commuting else N.DOM_NO_LAZY_COMMUTING) | (N.DOM_STALL_HANDOVER if stall_handover else 0) | (0 if order_restarts else N.DOM_NO_ORDER_RESTARTS) | (0 if eager_txns else N.DOM_NO_EAGER_TXNS) | (0 if txn_independence else N.DOM_NO_TXN_INDEPENDENCE)      # (stall_handover: the one opt-in bit, tbcheck.h)
     o.lanes_per_history = int(lanes_per_history)     # 8 / 16 / 32: several histories per wavefront; 64: one; 0: the library's choice
     o.list_order = int(DEFAULT_LIST_ORDER if list_order is None else list_order)      # N.ORDER_*: 0 = the library's choice (completion order, a :write 24 ranks later, where it applies)
     return o

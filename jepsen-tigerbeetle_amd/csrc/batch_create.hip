@@ -293,6 +293,9 @@ tbc_status plan_engines(CreatePlan& P) {
       B->vpad = 2; while (B->vpad < (uint32_t)(vmax + 2)) B->vpad <<= 1;
     }
   }
+  // multi-register under the wide schedule: eager pure-read txns, txn independence (tbc_internal.h kRuleTxnEager / kRuleTxnIndep)
+  if (beam && !B->sweep && model->kind == TBC_MODEL_MULTI_REGISTER)
+    B->rules |= ((opts->dominance & TBC_DOM_NO_EAGER_TXNS) ? 0u : kRuleTxnEager) | ((opts->dominance & TBC_DOM_NO_TXN_INDEPENDENCE) ? 0u : kRuleTxnIndep);
   // Nobody named a width: 4 configs per round, or 2 where that is measured faster -- a register / cas-register batch
   // under both dominance rules at low concurrency, where the depth-first order rarely backtracks and the third and
   // fourth config of a round are mostly expanded in vain (32,768 histories at 6.4 calls in flight: 5.6*10^8 probes and

@@ -246,6 +246,18 @@ static tbc_status expand_eager_witness(tbc_batch* B, uint32_t h, uint32_t* wit, 
   // (the replay itself is plain host code: witness_expand.h -- tests/test_narrow_emu.py runs the same function on the emulator's chains)
   std::vector<uint32_t> out;
   const uint32_t order = h < B->order_of_hist.size() ? B->order_of_hist[h] : B->list_order();      // (an order restart's pass answers in its own order)
+  if (B->rules & kRuleTxnEager) {          // multi-register: the calls the rule absorbed are pure-read txns; the micro-ops are in the value pool
+    std::vector<int32_t> pool(B->pool_len);
+    if (B->pool_len) HIP_TRY(hipMemcpy(pool.data(), B->d_pool_vals.p, (size_t)B->pool_len * 4, hipMemcpyDeviceToHost));
+    if (!expand_eager_txn_chain(n, f.data(), a.data(), b.data(), proc.data(), inv.data(), ret.data(), H.n_slots, B->model.init, order != 0u,
+                                pool.data(), wit, *len, out)) {
+      set_error("history %u: malformed witness chain", h);
+      return TBC_ERR_HIP;
+    }
+    std::copy(out.begin(), out.end(), wit);
+    *len = (uint32_t)out.size();
+    return TBC_OK;
+  }
   if (!expand_eager_chain(n, f.data(), a.data(), b.data(), proc.data(), inv.data(), ret.data(), H.n_slots, B->model.init,
                           (B->rules & kRuleBranch) != 0u, order != 0u, wit, *len, out)) {
     set_error("history %u: malformed witness chain", h);
@@ -1215,7 +1227,7 @@ tbc_status finish(RunState& R) {
         if (R.by_sweep[h]) { r.witness = nullptr; r.n_witness = 0; }      // knossos.linear returns configs, not a linearization
         // (under branch lists the normalised root may pass every completion by itself -- a history of reads of nil / of the initial
         // value: an empty chain, whose expansion is exactly those reads)
-        else if ((B->rules & kRuleEager) && !R.is_seq[h] && (d.depth || ((B->rules & kRuleBranch) && hist_back[h].n_ret != 0))) {
+        else if ((B->rules & (kRuleEager | kRuleTxnEager)) && !R.is_seq[h] && (d.depth || ((B->rules & kRuleBranch) && hist_back[h].n_ret != 0))) {
           tbc_status ws = expand_eager_witness(B, h, r.witness, &r.n_witness);
           if (ws != TBC_OK) return ws;
         }

@@ -53,6 +53,23 @@ struct Model {
     *out = (int32_t)s;
     return ok;
   }
+  // the keys a txn reads / writes, as bit sets (kRuleTxnIndep)
+  __device__ __forceinline__ void txn_keys(int32_t a, int32_t b, uint32_t& r, uint32_t& w) const {
+    r = 0u; w = 0u;
+    for (int32_t i = 0; i < b; i++) {
+      const int32_t mf = pool[a + 3 * i], k = pool[a + 3 * i + 1];
+      if (mf == 0) r |= 1u << k; else w |= 1u << k;
+    }
+  }
+  // a txn of micro-reads only, each nil or what the state holds for its key (kRuleTxnEager)
+  __device__ __forceinline__ bool pure_read_ok(int32_t st, uint32_t f, int32_t a, int32_t b) const {
+    bool ok = f == TBC_F_TXN;
+    for (int32_t i = 0; ok && i < b; i++) {
+      const int32_t mf = pool[a + 3 * i], k = pool[a + 3 * i + 1], v = pool[a + 3 * i + 2];
+      ok = mf == 0 && (v == TBC_NIL || (((uint32_t)st >> (4 * k)) & 15u) == (uint32_t)(v + 1));
+    }
+    return ok;
+  }
   // knossos.model/step: may op (f,a,b) be applied in state st?  REGF = the caller's kernel is the register-family
   // instantiation (register, cas-register, mutex): the table / multi-register paths are compiled out of it.
   // One formula serves register, cas-register and mutex: pack lets a history carry only its model's own ops

@@ -195,6 +195,13 @@ constexpr uint32_t kRuleBranch = 4u;
 constexpr uint32_t kRuleCount = 8u;
 // set / bank (wide schedule): the lazy rule of the commutative models (tbcheck.h, TBC_DOM_NO_LAZY_COMMUTING; oracle/wgl_beam.c)
 constexpr uint32_t kRuleLazyComm = 16u;
+// multi-register (wide schedule, wgl_beam.hip; specified in oracle/wgl_beam.c g_eager_txns / g_txn_por; tbcheck.h TBC_DOM_NO_EAGER_TXNS,
+// TBC_DOM_NO_TXN_INDEPENDENCE).  eager txns: an open :txn of micro-reads only, each nil or the state's value of its key, is linearized at
+// once (the eager reads' argument word for word: it changes nothing).  txn independence: two txns conflict when one writes a key the other
+// reads or writes; at a config whose front is the completion of X only the closure of {X} under "conflicts with" among the open calls
+// not yet linearized are candidates -- in any valid continuation the first member of the closure can be moved to the very front (the
+// calls before it conflict with no member and overlap all of them in real time).
+constexpr uint32_t kRuleTxnEager = 32u, kRuleTxnIndep = 64u;
 constexpr uint32_t kHotBit = 0x40000000u;
 constexpr uint32_t kCountWords = 2;
 // BeamArgs.count_mode

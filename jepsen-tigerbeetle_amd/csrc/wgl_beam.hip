@@ -580,6 +580,33 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
           }
         }
       }
+      if constexpr (!COMM && !REGF) {
+        // txn independence (multi-register, tbc_internal.h kRuleTxnIndep): the candidates are the closure of the call completing at the
+        // front under "conflicts with"; the closure is a fixed point over two key sets (what its members read / write)
+        if ((rules & kRuleTxnIndep) && act && !lin && !(oi.f_slot & kAtFront)) {
+          uint32_t cr = 0u, cw = 0u, yr, yw;
+          for (uint32_t cc = 0; cc < nlive; cc++) {
+            const OpRec y = lst[poff + cc];
+            if (y.f_slot & kAtFront) { model.txn_keys(y.a, y.b, cr, cw); break; }
+          }
+          for (bool grew = true; grew;) {
+            grew = false;
+            for (uint32_t cc = 0; cc < cnt; cc++) {
+              const OpRec y = cc < nlive ? lst[poff + cc] : crashed[cc - nlive];
+              const uint32_t py = (y.f_slot >> 8) & kSlotMask;
+              bool ly = false;
+#pragma unroll
+              for (int j = 0; j < MW; j++) if ((py >> 6) == (uint32_t)j) ly = (Mp[j] >> (py & 63u)) & 1ull;
+              if (ly) continue;
+              model.txn_keys(y.a, y.b, yr, yw);
+              if (!((yw & (cr | cw)) | (yr & cw))) continue;
+              if ((yr & ~cr) | (yw & ~cw)) { cr |= yr; cw |= yw; grew = true; }
+            }
+          }
+          model.txn_keys(oi.a, oi.b, yr, yw);
+          dominated = !((yw & (cr | cw)) | (yr & cw));
+        }
+      }
       bool viable = act && !lin && !dominated && !is_cls && pair_viable<MW, COMM, REGF>(model, st, fi, Mp, poff, nlive, cnt, lst, crashed, oi, COMM && (A.rules & kRuleLazyComm) != 0u);
       if constexpr (CNT) {
         const uint32_t cf = oi.f_slot & 0xFFu;
@@ -636,6 +663,37 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
               for (int j = 0; j < MW; j++) if ((pp >> 6) == (uint32_t)j) bit = (M2[j] >> (pp & 63u)) & 1ull;
             } while (bit);
             if (fi2 == R) break;
+          }
+        }
+      }
+      if constexpr (!COMM && !REGF) {
+        // eager txns (multi-register, kRuleTxnEager): the child takes every open pure-read txn its state allows, the front moves past the
+        // completions that linearizes, and the calls open at the new front are looked at again
+        if ((rules & kRuleTxnEager) && viable && fi2 < R) {
+          for (bool again = true; again && fi2 < R;) {
+            again = false;
+            const uint32_t e1 = off[fi2 + 1u];
+            for (uint32_t e = off[fi2]; e < e1; e++) {
+              const OpRec y = lst[e];
+              const uint32_t py = (y.f_slot >> 8) & kSlotMask;
+              bool ly = false;
+#pragma unroll
+              for (int j = 0; j < MW; j++) if ((py >> 6) == (uint32_t)j) ly = (M2[j] >> (py & 63u)) & 1ull;
+              if (ly || !model.pure_read_ok(st2, y.f_slot & 0xFFu, y.a, y.b)) continue;
+#pragma unroll
+              for (int j = 0; j < MW; j++) if ((py >> 6) == (uint32_t)j) M2[j] |= 1ull << (py & 63u);
+            }
+            for (;;) {
+              const uint32_t pp = slot_at(fi2);
+              bool bit = false;
+#pragma unroll
+              for (int j = 0; j < MW; j++) if ((pp >> 6) == (uint32_t)j) bit = (M2[j] >> (pp & 63u)) & 1ull;
+              if (!bit) break;
+#pragma unroll
+              for (int j = 0; j < MW; j++) if ((pp >> 6) == (uint32_t)j) M2[j] &= ~(1ull << (pp & 63u));
+              fi2++; again = true;
+              if (fi2 == R) break;
+            }
           }
         }
       }

@@ -65,4 +65,63 @@ inline bool expand_eager_chain(uint32_t n, const uint8_t* f, const int32_t* a, c
   return out.size() <= n;
 }
 
+// The same replay for multi-register under the eager-txn rule (tbc_internal.h kRuleTxnEager; oracle/wgl_beam.c absorb_txns): the state is
+// 4 bits per key (0 = nil, v + 1), a call's value its micro-ops {f, key, value} at pool[a .. a + 3 b); what a pass absorbs are the open
+// live txns of micro-reads only that the state allows.  The root is not normalised (the kernel's is not either).
+inline bool expand_eager_txn_chain(uint32_t n, const uint8_t* f, const int32_t* a, const int32_t* b, const int32_t* proc, const uint32_t* inv,
+                                   const uint32_t* ret, uint32_t n_slots, int32_t init, bool by_completion, const int32_t* pool,
+                                   const uint32_t* chain, uint32_t chain_len, std::vector<uint32_t>& out) {
+  std::vector<uint32_t> by_ret;
+  for (uint32_t i = 0; i < n; i++) if (ret[i] != TBC_POS_CRASHED) by_ret.push_back(i);
+  std::sort(by_ret.begin(), by_ret.end(), [&](uint32_t x, uint32_t y) { return ret[x] < ret[y]; });
+  const uint32_t R = (uint32_t)by_ret.size();
+  std::vector<uint32_t> opens_at(n);
+  { uint32_t r = 0; for (uint32_t i = 0; i < n; i++) { while (r < R && ret[by_ret[r]] < inv[i]) r++; opens_at[i] = r; } }
+  std::vector<uint8_t> done(n, 0);
+  std::vector<int64_t> open_by_slot(std::max(1u, n_slots), -1);
+  out.clear();
+  out.reserve(n);
+  uint32_t front = 0, next_inv = 0;
+  uint32_t state = (uint32_t)init;
+  auto open_calls = [&]() {
+    while (next_inv < n && opens_at[next_inv] <= front) {
+      if (ret[next_inv] != TBC_POS_CRASHED) open_by_slot[(uint32_t)proc[next_inv]] = next_inv;
+      next_inv++;
+    }
+  };
+  auto advance = [&]() -> bool {
+    bool moved = false;
+    while (front < R && done[by_ret[front]]) { open_by_slot[(uint32_t)proc[by_ret[front]]] = -1; front++; moved = true; open_calls(); }
+    return moved;
+  };
+  auto pure_read_ok = [&](uint32_t x) {
+    if (f[x] != TBC_F_TXN) return false;
+    for (int32_t i = 0; i < b[x]; i++) {
+      const int32_t mf = pool[a[x] + 3 * i], k = pool[a[x] + 3 * i + 1], v = pool[a[x] + 3 * i + 2];
+      if (mf != 0 || !(v == TBC_NIL || ((state >> (4 * k)) & 15u) == (uint32_t)(v + 1))) return false;
+    }
+    return true;
+  };
+  std::vector<uint32_t> take;
+  open_calls();
+  for (uint32_t k = 0; k < chain_len; k++) {
+    const uint32_t op = chain[k];
+    if (op >= n || done[op] || f[op] != TBC_F_TXN) return false;
+    for (int32_t i = 0; i < b[op]; i++) {
+      const int32_t mf = pool[a[op] + 3 * i], key = pool[a[op] + 3 * i + 1], v = pool[a[op] + 3 * i + 2];
+      if (mf != 0) state = (state & ~(15u << (4 * key))) | ((uint32_t)(v + 1) << (4 * key));
+    }
+    done[op] = 1; out.push_back(op);
+    advance();
+    for (bool again = true; again && front < R;) {
+      take.clear();
+      for (int64_t x : open_by_slot) if (x >= 0 && !done[x] && pure_read_ok((uint32_t)x)) take.push_back((uint32_t)x);
+      if (by_completion) std::sort(take.begin(), take.end(), [&](uint32_t x, uint32_t y) { return ret[x] < ret[y]; });
+      for (uint32_t x : take) { done[x] = 1; out.push_back(x); }
+      again = advance();
+    }
+  }
+  return out.size() <= n;
+}
+
 }  // namespace tbc

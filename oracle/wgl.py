@@ -170,7 +170,7 @@ ORACLE_LIST_ORDER = _ListOrders({0: 0, 1: 1, 2: 4})
 
 
 def check_beam(ops, model, width=16, max_probes=0, want_witness=True, round_pairs=64, widen_after=0, lookahead=None, eager_reads=None, twin_rule=None,
-               twin_selfcheck=False, rules_at_any_round_size=False, branch_lists=False, lazy_commuting=None, eager_txns=False, look_two=False, list_order=0, lazy_look=False, defer=False):
+               twin_selfcheck=False, rules_at_any_round_size=False, branch_lists=False, lazy_commuting=None, eager_txns=None, txn_independence=None, look_two=False, list_order=0, lazy_look=False, defer=False):
     """The wide (K configs per iteration) schedule of the same search: wgl_beam.c.
 
     lookahead: None = what the library does by default (on for register / cas-register under the
@@ -203,9 +203,13 @@ def check_beam(ops, model, width=16, max_probes=0, want_witness=True, round_pair
     # kernel's lists under the eager rule); without eager reads the switch does nothing
     lib().wgl_beam_set_branch_lists(C.c_uint32(1 if (branch_lists and eager_reads) else 0))
     lib().wgl_beam_set_twin_selfcheck(C.c_uint32(1 if twin_selfcheck else 0))
-    # eager_txns: DESIGN STUDY (no kernel counterpart): the eager rule for multi-register -- an open txn of micro-reads only that the
-    # state allows is linearized at once (wgl_beam.c, g_eager_txns); what it buys is measured in DESIGN.md section 8
+    # eager_txns / txn_independence (multi-register; csrc kRuleTxnEager / kRuleTxnIndep, tbcheck.h TBC_DOM_NO_EAGER_TXNS / _NO_TXN_INDEPENDENCE):
+    # an open txn of micro-reads only that the state allows is linearized at once; the candidates of a config are the closure of the call
+    # completing at its front under "conflicts with" (wgl_beam.c).  None = what the library does by default under its wide schedule: on
+    eager_txns = (width > 1) if eager_txns is None else eager_txns
+    txn_independence = (width > 1) if txn_independence is None else txn_independence
     lib().wgl_beam_set_eager_txns(C.c_uint32(1 if (eager_txns and model["kind"] == 4) else 0))
+    lib().wgl_beam_set_txn_independence(C.c_uint32(1 if (txn_independence and model["kind"] == 4) else 0))
     # look_two: the lean lookahead record's reading of three or more open producers (wgl_beam.c, g_look_two; csrc kLeanLook)
     lib().wgl_beam_set_look_two(C.c_uint32(1 if look_two else 0))
     # list_order: 0 = a front's open calls in process-slot order, 1 = in order of completion (csrc PackOpenArgs.list_order); study knobs of
@@ -231,6 +235,7 @@ def check_beam(ops, model, width=16, max_probes=0, want_witness=True, round_pair
         lib().wgl_beam_set_branch_lists(C.c_uint32(0))
         lib().wgl_beam_set_lazy_commuting(C.c_uint32(0))
         lib().wgl_beam_set_eager_txns(C.c_uint32(0))
+        lib().wgl_beam_set_txn_independence(C.c_uint32(0))
         lib().wgl_beam_set_look_two(C.c_uint32(0))
         lib().wgl_beam_set_list_order(C.c_uint32(0))
         lib().wgl_beam_set_lazy_look(C.c_uint32(0))

@@ -267,6 +267,25 @@ static uint32_t absorb_reads(uint64_t* c2, uint32_t fi2, int32_t s, uint32_t R, 
   return fi2;
 }
 
+/* txn_independence (multi-register; tbc_opts.dominance, TBC_DOM_NO_TXN_INDEPENDENCE = off): the persistent-set rule.  Two txns CONFLICT
+ * when one writes a key the other reads or writes; txns that do not conflict commute (same states, same viability, either order).  At a
+ * config whose front is the completion of call X, every linearization of what is left takes X before the front can move, and everything
+ * it takes before X is open at the front (a call invoked later is preceded by X in real time), hence concurrent with X and with each other.
+ * Let P = the closure of {X} under "conflicts with" among the open calls not yet linearized (viable now or not).  In any valid
+ * continuation the first member of P can be moved to the very front: everything before it is outside P, so it conflicts with no member of
+ * P, and all of them overlap in real time.  So the config needs only the candidates in P.  With keys as bit sets the closure is a fixed
+ * point over two words: CR / CW = the keys the members read / write; Y joins when Y.w & (CR | CW) or Y.r & CW. */
+static uint32_t g_txn_por = 0; static _Thread_local uint64_t g_por_skipped = 0;
+void wgl_beam_set_txn_independence(uint32_t on) { g_txn_por = on; }
+static void txn_keys(const oracle_model* model, uint8_t f, int32_t a, int32_t b, uint32_t* r, uint32_t* w) {
+  *r = *w = 0;
+  if (f != O_TXN) return;
+  for (int32_t i = 0; i < b; i++) {
+    const int32_t mf = model->pool[a + 3 * i], k = model->pool[a + 3 * i + 1];
+    if (mf == 0) *r |= 1u << k; else *w |= 1u << k;
+  }
+}
+
 /* multi-register: is op x a :txn of micro-reads only, each consistent with state s? */
 static int pure_read_txn_ok(const oracle_model* model, int32_t s, uint8_t f, int32_t a, int32_t b) {
   if (f != O_TXN) return 0;
@@ -546,6 +565,23 @@ int wgl_beam_check_rp(uint32_t n, const uint8_t* f, const int32_t* a, const int3
         uint32_t p = (uint32_t)process[op];
         cviable[l] = 0; cop[l] = op; cpar[l] = par[q];
         if (pk[1 + (p >> 6)] >> (p & 63) & 1) continue;
+        if (g_txn_por && model->kind == O_MULTI_REGISTER && op != ret_op[fi]) {
+          uint32_t cr, cw, yr, yw;
+          txn_keys(model, f[ret_op[fi]], a[ret_op[fi]], b[ret_op[fi]], &cr, &cw);
+          for (int grew = 1; grew;) {
+            grew = 0;
+            for (uint32_t cc = 0; cc < pcnt[q]; cc++) {
+              const uint32_t y = cc < nlive ? clst[coff[fi] + cc] : crashed[cc - nlive];
+              const uint32_t py = (uint32_t)process[y];
+              if (pk[1 + (py >> 6)] >> (py & 63) & 1) continue;
+              txn_keys(model, f[y], a[y], b[y], &yr, &yw);
+              if (!((yw & (cr | cw)) | (yr & cw))) continue;
+              if ((yr & ~cr) | (yw & ~cw)) { cr |= yr; cw |= yw; grew = 1; }
+            }
+          }
+          txn_keys(model, f[op], a[op], b[op], &yr, &yw);
+          if (!((yw & (cr | cw)) | (yr & cw))) { g_por_skipped++; continue; }
+        }
         if (g_twin_rule && !cfgm && (f[op] == O_WRITE || f[op] == O_CAS)) {
           int dominated = 0;
           for (uint32_t cc = 0; cc < pcnt[q] && !dominated; cc++) {

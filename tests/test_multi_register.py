@@ -40,30 +40,36 @@ def test_small_histories_against_brute_force(native, oracle):
     assert n_bad > 15
 
 
-def test_eager_pure_read_txns_change_no_answer(native, oracle):
-    """The eager rule for multi-register as a design study of the oracle (oracle/wgl_beam.c, g_eager_txns; no kernel speaks it):
-    an open txn of micro-reads only that the state allows is linearized at once.  Same verdict and failing op as brute force and
-    as the plain search on small crash-heavy histories, fewer probes on larger ones."""
-    n_bad = fewer = 0
-    for seed in range(240):
-        hist = multi_register_history(8, 3, 1000 + seed, n_keys=2, n_values=2, busy=0.8, info=0.15, corrupt=seed % 2 == 1)
+def test_the_multi_register_rules_change_no_answer(native, oracle):
+    """The two rules the wide kernel applies to multi-register (csrc kRuleTxnEager / kRuleTxnIndep; specified in oracle/wgl_beam.c):
+    eager txns -- an open txn of micro-reads only that the state allows is linearized at once --, and txn independence -- the candidates
+    of a config are the closure of the call completing at its front under "one writes a key the other reads or writes".  Each alone and
+    both together: same verdict and failing op as brute force on small crash-heavy histories (2 - 4 keys: closures that do and do not
+    cover the open calls), the witness replayed by the independent checker, fewer probes on larger ones."""
+    n_bad = 0
+    for seed in range(300):
+        hist = multi_register_history(8, 3, 1000 + seed, n_keys=2 + seed % 3, n_values=2, busy=0.8, info=0.15, corrupt=seed % 2 == 1)
         enc, om = encode(hist)
         bad = brute.first_bad_completion(om, op_tuples(enc.ops))
         n_bad += bad is not None
         for width in (1, 4):
-            r = oracle.check_beam(enc.ops.as_dict(), om, width, eager_txns=True)
-            assert r["valid"] == (1 if bad is None else 0) and (bad is None or r["fail_op"] == bad), (seed, width)
-            if bad is None:          # the witness (absorbed txns included) replayed by the independent checker
-                assert brute.check_witness(om, op_tuples(enc.ops), [int(x) for x in r["witness"]]) == r["final_state"]
-    assert n_bad > 25
+            for eager, indep in ((True, False), (False, True), (True, True)):
+                r = oracle.check_beam(enc.ops.as_dict(), om, width, eager_txns=eager, txn_independence=indep)
+                assert r["valid"] == (1 if bad is None else 0) and (bad is None or r["fail_op"] == bad), (seed, width, eager, indep)
+                if bad is None:          # the witness (absorbed txns included) replayed by the independent checker
+                    assert brute.check_witness(om, op_tuples(enc.ops), [int(x) for x in r["witness"]]) == r["final_state"]
+    assert n_bad > 30
+    fewer = [0, 0, 0]
     for seed in range(6):
         hist = multi_register_history(3000, 32, seed, n_keys=8, n_values=5, busy=0.12, info=0.0, corrupt=seed % 3 == 2)
         enc, om = encode(hist)
-        plain = oracle.check_beam(enc.ops.as_dict(), om, 8, want_witness=False)
-        eager = oracle.check_beam(enc.ops.as_dict(), om, 8, want_witness=False, eager_txns=True)
-        assert (plain["valid"], plain["fail_op"] if plain["valid"] == 0 else None) == (eager["valid"], eager["fail_op"] if eager["valid"] == 0 else None)
-        fewer += eager["probes"] < plain["probes"]
-    assert fewer >= 5
+        plain = oracle.check_beam(enc.ops.as_dict(), om, 8, want_witness=False, eager_txns=False, txn_independence=False)
+        answer = (plain["valid"], plain["fail_op"] if plain["valid"] == 0 else None)
+        for i, (eager, indep) in enumerate(((True, False), (False, True), (True, True))):
+            r = oracle.check_beam(enc.ops.as_dict(), om, 8, want_witness=False, eager_txns=eager, txn_independence=indep)
+            assert (r["valid"], r["fail_op"] if r["valid"] == 0 else None) == answer
+            fewer[i] += r["probes"] < plain["probes"]
+    assert min(fewer) >= 5
 
 
 def test_memo_fallback_when_too_many_keys(native):
@@ -90,17 +96,42 @@ def test_gpu_matches_oracle(native, oracle, n_ops, procs, info, corrupt):
             assert np.array_equal(got["witness"], exp["witness"]) and got["final_state"] == exp["final_state"]
         else:
             assert got["fail_op"] == exp["fail_op"]
-        expb = oracle.check_beam(enc.ops.as_dict(), om, 8)
-        gotb = core.check_ops(enc.ops, enc.native_model, core.make_opts(time_limit_ms=60000, algorithm=N.ALG_COMPETITION, search_width=8))
-        assert gotb["valid"] == expb["valid"] == exp["valid"]
-        assert (gotb["probes"], gotb["visited"]) == (expb["probes"], expb["visited"])
-        if exp["valid"] == 1:
-            assert np.array_equal(gotb["witness"], expb["witness"])
-        else:
-            assert gotb["fail_op"] == exp["fail_op"]
+        # the wide kernel: under both rules (the default), under each alone, under none -- every counter and the witness the oracle's
+        for eager, indep in ((True, True), (True, False), (False, True), (False, False)):
+            expb = oracle.check_beam(enc.ops.as_dict(), om, 8, eager_txns=eager, txn_independence=indep)
+            gotb = core.check_ops(enc.ops, enc.native_model, core.make_opts(time_limit_ms=60000, algorithm=N.ALG_COMPETITION, search_width=8,
+                                                                            eager_txns=eager, txn_independence=indep))
+            assert gotb["valid"] == expb["valid"] == exp["valid"], (eager, indep)
+            assert (gotb["probes"], gotb["visited"], gotb["backtracks"]) == (expb["probes"], expb["visited"], expb["backtracks"]), (eager, indep)
+            if exp["valid"] == 1:
+                assert np.array_equal(gotb["witness"], expb["witness"]), (eager, indep)
+                assert brute.check_witness(om, op_tuples(enc.ops), [int(x) for x in gotb["witness"]]) == gotb["final_state"]
+            else:
+                assert gotb["fail_op"] == exp["fail_op"]
         # and through the knossos surface (result map carries the decoded model)
         a = kwgl.analysis(M.multi_register({}), hist)
         assert a["valid?"] is (exp["valid"] == 1)
         if exp["valid"] == 1:
             assert isinstance(a["configs"][0]["model"], M.MultiRegister)
         assert linear.analysis(M.multi_register({}), hist)["valid?"] is (exp["valid"] == 1)
+
+
+@pytest.mark.gpu
+def test_the_rules_at_256_processes_and_with_crashed_txns(native, oracle):
+    """Four mask words (up to 256 process slots, crashed processes included: wider windows go to the sequential kernel), crashed txns among the candidates (they join a closure like any open call, the eager rule
+    never takes them), widths 2 .. 16, a planted bad read: verdict, failing op, witness and counters equal the oracle's under the rules."""
+    cases = [(4000, 256, 0.02, 0.0, False, 8), (4000, 200, 0.025, 0.01, False, 4), (3000, 200, 0.03, 0.0, True, 16), (1500, 70, 0.06, 0.02, False, 2),
+             (1500, 130, 0.03, 0.015, True, 8)]
+    for i, (n_ops, procs, busy, info, corrupt, width) in enumerate(cases):
+        hist = multi_register_history(n_ops, procs, 44 if i == 4 else 40 + i, n_keys=8, n_values=5, busy=busy, info=info, corrupt=corrupt)
+        enc, om = encode(hist)
+        exp = oracle.check_beam(enc.ops.as_dict(), om, width, max_probes=20_000_000)
+        assert exp["valid"] == (0 if corrupt else 1), i
+        got = core.check_ops(enc.ops, enc.native_model, core.make_opts(time_limit_ms=120000, algorithm=N.ALG_COMPETITION, search_width=width))
+        assert got["valid"] == exp["valid"], i
+        assert (got["probes"], got["visited"], got["backtracks"], got["max_depth"]) == (exp["probes"], exp["visited"], exp["backtracks"], exp["max_depth"]), i
+        if corrupt:
+            assert got["fail_op"] == exp["fail_op"]
+        else:
+            assert np.array_equal(got["witness"], exp["witness"]) and got["final_state"] == exp["final_state"]
+            assert brute.check_witness(om, op_tuples(enc.ops), [int(x) for x in got["witness"]]) == got["final_state"]
