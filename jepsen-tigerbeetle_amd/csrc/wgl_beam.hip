@@ -74,6 +74,7 @@ __device__ __forceinline__ uint64_t cas64_from_zero(gu64* p, uint64_t desired) {
 }
 
 constexpr uint32_t kRing = 64;     // most recent pushes mirrored in LDS
+constexpr uint32_t kCloByLane = 0xFFFFFFFFu;   // txn independence: no closure worked out for this parent (its key sets are 8 bits each)
 
 // The lane number, opaque to the optimiser.  What an iteration derives from it (LDS addresses, lane
 // masks, shuffle indices) is then recomputed per iteration instead of being hoisted out of the search
@@ -499,6 +500,49 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
     if (__builtin_expect(visited + (grouped ? np * G : T) > full_at, 0)) { sp += np; need_grow = true; break; }
     const uint32_t lr = opaque_lane(lane);
     iterations++; expanded += np;
+    if constexpr (!COMM && !REGF) {
+      // txn independence (multi-register, tbc_internal.h kRuleTxnIndep): a parent's closure -- the keys read / written by the calls that
+      // conflict, directly or through others, with the call completing at its front -- is worked out ONCE per parent, by the whole
+      // wavefront: lane = open call (one trip for the records, one for the micro-ops), the fixed point over two key sets by ballots.
+      // (The words are the lookahead's, which the register family alone uses.)
+      if (rules & kRuleTxnIndep) {
+        for (uint32_t qq = 0; qq < np; qq++) {
+          const uint32_t cq = p_cnt[qq], nlq = p_nlive[qq], poq = p_off[qq];
+          uint32_t clo = kCloByLane;                        // more than 64 open calls: every lane walks the list itself (below)
+          if (cq <= 64u) {
+            uint32_t yr = 0u, yw = 0u;
+            bool open = false, atf = false;
+            if (lane < cq) {
+              const OpRec y = lane < nlq ? lst[poq + lane] : crashed[lane - nlq];
+              const uint32_t py = (y.f_slot >> 8) & kSlotMask;
+              bool ly = false;
+#pragma unroll
+              for (int j = 0; j < MW; j++) if ((py >> 6) == (uint32_t)j) ly = (p_M[qq * MW + j] >> (py & 63u)) & 1ull;
+              open = !ly; atf = lane < nlq && (y.f_slot & kAtFront) != 0u;
+              model.txn_keys(y.a, y.b, yr, yw);
+            }
+            uint32_t cr = 0u, cw = 0u;
+            const uint64_t bx = __ballot(atf);               // the call completing at the front starts the closure
+            if (bx) { const uint32_t xl = (uint32_t)__builtin_ctzll(bx); cr = rl(yr, xl); cw = rl(yw, xl); }
+            for (bool more = true; more;) {
+              const bool hit = open && (((yw & (cr | cw)) | (yr & cw)) != 0u);
+              uint32_t nr = 0u, nw = 0u;
+#pragma unroll
+              for (uint32_t kb = 0; kb < 8u; kb++) {
+                if (__ballot(hit && ((yr >> kb) & 1u))) nr |= 1u << kb;
+                if (__ballot(hit && ((yw >> kb) & 1u))) nw |= 1u << kb;
+              }
+              more = ((nr & ~cr) | (nw & ~cw)) != 0u;
+              cr |= nr; cw |= nw;
+            }
+            clo = cr | (cw << 16);
+          }
+          if (lane == 0) c_fi[qq] = clo;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
     SEG(0);
 
     for (uint32_t base = 0; base < T && verdict == -2; base += 64) {
@@ -581,26 +625,29 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
         }
       }
       if constexpr (!COMM && !REGF) {
-        // txn independence (multi-register, tbc_internal.h kRuleTxnIndep): the candidates are the closure of the call completing at the
-        // front under "conflicts with"; the closure is a fixed point over two key sets (what its members read / write)
+        // txn independence: a candidate outside its parent's closure (worked out above, once per parent) is not tried
         if ((rules & kRuleTxnIndep) && act && !lin && !(oi.f_slot & kAtFront)) {
-          uint32_t cr = 0u, cw = 0u, yr, yw;
-          for (uint32_t cc = 0; cc < nlive; cc++) {
-            const OpRec y = lst[poff + cc];
-            if (y.f_slot & kAtFront) { model.txn_keys(y.a, y.b, cr, cw); break; }
-          }
-          for (bool grew = true; grew;) {
-            grew = false;
-            for (uint32_t cc = 0; cc < cnt; cc++) {
-              const OpRec y = cc < nlive ? lst[poff + cc] : crashed[cc - nlive];
-              const uint32_t py = (y.f_slot >> 8) & kSlotMask;
-              bool ly = false;
+          const uint32_t clo = c_fi[q];
+          uint32_t cr = clo & 0xFFFFu, cw = clo >> 16, yr, yw;
+          if (clo == kCloByLane) {
+            cr = 0u; cw = 0u;
+            for (uint32_t cc = 0; cc < nlive; cc++) {
+              const OpRec y = lst[poff + cc];
+              if (y.f_slot & kAtFront) { model.txn_keys(y.a, y.b, cr, cw); break; }
+            }
+            for (bool grew = true; grew;) {
+              grew = false;
+              for (uint32_t cc = 0; cc < cnt; cc++) {
+                const OpRec y = cc < nlive ? lst[poff + cc] : crashed[cc - nlive];
+                const uint32_t py = (y.f_slot >> 8) & kSlotMask;
+                bool ly = false;
 #pragma unroll
-              for (int j = 0; j < MW; j++) if ((py >> 6) == (uint32_t)j) ly = (Mp[j] >> (py & 63u)) & 1ull;
-              if (ly) continue;
-              model.txn_keys(y.a, y.b, yr, yw);
-              if (!((yw & (cr | cw)) | (yr & cw))) continue;
-              if ((yr & ~cr) | (yw & ~cw)) { cr |= yr; cw |= yw; grew = true; }
+                for (int j = 0; j < MW; j++) if ((py >> 6) == (uint32_t)j) ly = (Mp[j] >> (py & 63u)) & 1ull;
+                if (ly) continue;
+                model.txn_keys(y.a, y.b, yr, yw);
+                if (!((yw & (cr | cw)) | (yr & cw))) continue;
+                if ((yr & ~cr) | (yw & ~cw)) { cr |= yr; cw |= yw; grew = true; }
+              }
             }
           }
           model.txn_keys(oi.a, oi.b, yr, yw);
@@ -1096,7 +1143,8 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
 #endif
 constexpr uint32_t kBeamWaves = TBC_BEAM_WAVES;
 template <int MW, bool COMM, bool REGF, bool CNT = false>
-__global__ __launch_bounds__(64 * kBeamWaves, (COMM || CNT) ? 1 : TBC_BEAM_MIN_WAVES) void wgl_beam_kernel(BeamArgs A) {
+// (the table / multi-register instance takes the registers it needs: under the register family's bound it spilled 108 scalar registers)
+__global__ __launch_bounds__(64 * kBeamWaves, (COMM || CNT || !REGF) ? 1 : TBC_BEAM_MIN_WAVES) void wgl_beam_kernel(BeamArgs A) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
   const uint32_t lane = threadIdx.x & 63u, wv = rfl(threadIdx.x >> 6);
   const uint32_t w = blockIdx.x * kBeamWaves + wv;
