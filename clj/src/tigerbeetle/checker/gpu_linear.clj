@@ -47,6 +47,8 @@
                   :inv_pos 48 :ret_pos 56}
    :input_info   {:size 56  :n_hist 0 :pending 4 :total_ops 8 :bytes_copied 16 :ns_copy 24 :inputs_consumed 32
                   :lists_regrown 40 :n_hist_cap 44 :ops_cap 48}
+   ;; a run that is out, seen from another thread (tbc_batch_progress)
+   :progress     {:size 24  :n_histories 0 :n_decided 4 :phase 8 :running 12 :elapsed_ns 16}
    :enums        {:type     {:invoke 0 :ok 1 :fail 2 :info 3}
                   :f        {:read 0 :write 1 :cas 2 :acquire 3 :release 4 :add 5 :txn 6 :transfer 7 :class 8}
                   :model    {:register 0 :cas-register 1 :mutex 2 :table 3 :multi-register 4 :set 5 :bank 6}
@@ -464,6 +466,19 @@
               (when (and (zero? (.invokeInt (f "tbc_batch_submit_input") (to-array [handle (int slot) (int nh)])))
                          (zero? (.invokeInt (f "tbc_batch_run") (to-array [handle res]))))
                 (vec (map-indexed (fn [i {:keys [ops inv ret]}] (result-map res (* i (o :result :size)) model ops inv ret)) enc))))))))))
+
+(defn progress
+  "How far the run that is out on an open stream has come -- the one call another thread may make on a handle while check-next! is in
+   flight (tbc_batch_progress; knossos.search's reporter logs the same kind of line while a search runs):
+   {:histories n :decided n :running? bool :elapsed-ms t}, or nil."
+  [{:keys [handle]}]
+  (let [p (struct :progress)]
+    (keeping [p]
+      (when (zero? (.invokeInt (f "tbc_batch_progress") (to-array [handle p])))
+        {:histories  (.getInt p (o :progress :n_histories))
+         :decided    (.getInt p (o :progress :n_decided))
+         :running?   (not (zero? (.getInt p (o :progress :running))))
+         :elapsed-ms (/ (.getLong p (o :progress :elapsed_ns)) 1e6)}))))
 
 (defn close-stream! [{:keys [handle]}]
   (when handle (.invoke (f "tbc_batch_destroy") Void/TYPE (to-array [handle]))))

@@ -420,6 +420,18 @@ uint32_t tbc_batch_list_order(const tbc_batch* b);
 /* histories of the last run whose first pass ended at its budget and that were then searched in several list orders at once
  * (tbc_opts.dominance, TBC_DOM_NO_ORDER_RESTARTS) */
 uint32_t tbc_batch_last_raced(const tbc_batch* b);
+/* PROGRESS of a run that is out (reference: knossos.search reports on a search while it runs -- knossos/src/knossos/search.clj, the
+ * reporter its `run` starts; jepsen.checker/linearizable logs it).  Callable from ANOTHER thread while tbc_batch_run is in flight on
+ * the batch (the one entry point that is; nothing else may touch a batch that is running): how many of the batch's histories have a
+ * verdict so far -- the search kernels count them into host memory as they store their results --, the phase, the time since the
+ * run began.  After the run: what it handed back (n_decided = the histories whose verdict is not TBC_UNKNOWN), running = 0. */
+enum { TBC_PHASE_IDLE = 0, TBC_PHASE_PACK = 1 /* packing and the first search pass (queued together) */, TBC_PHASE_RETRIES = 2 /* verdicts
+       composed; histories that overflowed, stalled or hit a budget are searched again */ };
+typedef struct tbc_progress {
+  uint32_t n_histories, n_decided, phase, running;
+  uint64_t elapsed_ns;
+} tbc_progress;
+tbc_status tbc_batch_progress(const tbc_batch* b, tbc_progress* out);
 /* how the last run was answered when the level sweep (knossos.linear; jit_sweep.hip) is in play:
  * TBC_ALG_LINEAR always asks for it, TBC_ALG_COMPETITION on small batches that want no witness.
  * The sweep cuts a history into segments of about seg_target completions at fronts with at most

@@ -149,6 +149,14 @@ class BatchInput(C.Structure):
                 ("word", C.POINTER(C.c_uint32)), ("inv_pos", C.POINTER(C.c_uint32)), ("ret_pos", C.POINTER(C.c_uint32))]
 
 
+class Progress(C.Structure):
+    """tbc_progress: a run that is out, seen from another thread (include/tbcheck.h tbc_batch_progress)."""
+    _fields_ = [("n_histories", C.c_uint32), ("n_decided", C.c_uint32), ("phase", C.c_uint32), ("running", C.c_uint32), ("elapsed_ns", C.c_uint64)]
+
+
+PHASE_IDLE, PHASE_PACK, PHASE_RETRIES = 0, 1, 2
+
+
 class InputInfo(C.Structure):
     _fields_ = [("n_hist", C.c_uint32), ("pending", C.c_uint32), ("total_ops", C.c_uint64), ("bytes_copied", C.c_uint64),
                 ("ns_copy", C.c_uint64), ("inputs_consumed", C.c_uint64), ("lists_regrown", C.c_uint32), ("n_hist_cap", C.c_uint32),
@@ -208,6 +216,7 @@ SYMBOLS = {
     "tbc_batch_submit_input": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),
     "tbc_batch_reload": (C.c_int, [C.c_void_p, C.POINTER(BatchDesc)]),
     "tbc_batch_input_info": (C.c_int, [C.c_void_p, C.POINTER(InputInfo)]),
+    "tbc_batch_progress": (C.c_int, [C.c_void_p, C.POINTER(Progress)]),
     "tbc_memo_build": (C.c_int, [C.c_int64, C.c_uint32, STEP_FN, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint16),
                                  C.POINTER(C.c_int64), C.POINTER(C.c_uint32)]),
     "tbc_version": (C.c_uint32, []),

@@ -259,6 +259,12 @@ class Batch:
         N.check_status(N.lib().tbc_batch_last_turn_wait(self._h, C.byref(w)))
         return {"init": t[0], "pack": t[1], "search": t[2], "retries": t[3], "turn_wait": w.value}
 
+    def progress(self):
+        """How far a run that is out has come (tbc_batch_progress): the one call another thread may make while run() is in flight."""
+        p = N.Progress()
+        N.check_status(N.lib().tbc_batch_progress(self._h, C.byref(p)))
+        return {k: getattr(p, k) for k, _ in N.Progress._fields_}
+
     def counters(self):
         c = N.Counters()
         N.check_status(N.lib().tbc_batch_last_counters(self._h, C.byref(c)))

@@ -469,6 +469,8 @@ tbc_batch::~tbc_batch() {
   d_bh.release(); d_off.release(); d_ncr.release(); d_lst.release(); d_crashed.release(); d_stack.release();
   d_zncr.release(); d_reach.release(); d_reach_hdr.release(); d_abort.release(); d_order.release(); d_park.release();
   if (abort_one) (void)hipHostFree(abort_one);
+  if (progress) (void)hipHostFree(progress);
+  d_progress.release();
   if (!borrowed) { for (auto& e : ev2) if (e) (void)hipEventDestroy(e); if (stream2) (void)hipStreamDestroy(stream2); }
   d_cmem.release(); d_occ.release(); d_btab.release(); d_slot8.release(); d_rk8.release(); d_look.release(); d_looktmp.release(); d_twn.release(); d_rdm.release(); d_cuts.release(); d_seglist.release(); d_sres.release(); d_dstack.release(); d_pool.release(); d_pool_cursor.release();
   if (ev_turn) (void)hipEventDestroy(ev_turn);
@@ -493,6 +495,13 @@ tbc_status alloc_arenas(CreatePlan& P) {
   const uint32_t EW = B->entry_words();
   tbc_status s;
   const uint64_t T = B->total_ops;
+  // (progress words: host memory the kernels write and another host thread reads, coherent like the debug words of batch_common.hip.
+  // tbc_check's one-shot batches, which borrow a context and hand out no handle, have none: nobody could ask)
+  if (!t_ctx) {
+    HIP_TRY(hipHostMalloc((void**)&B->progress, 16 * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent));
+    std::memset(B->progress, 0, 16 * sizeof(uint32_t));
+    if ((s = B->d_progress.alloc(1))) return s;
+  }
   if ((s = B->d_f.alloc(T)) || (s = B->d_a.alloc(T)) || (s = B->d_b.alloc(T)) || (s = B->d_proc.alloc(T)) ||
       (s = B->d_inv.alloc(T)) || (s = B->d_ret.alloc(T)) || (s = B->d_hist.alloc(nh)) || (s = B->d_bh.alloc(beam ? nh : 0)) || (s = B->d_work.alloc(nh)) ||
       (s = B->d_bitmap.alloc(t.bm_n)) || (s = B->d_off.alloc(beam ? t.boff_n : 0)) || (s = B->d_ncr.alloc(beam ? t.boff_n : 0)) || (s = B->d_pool_cursor.alloc(1)) ||

@@ -31,6 +31,7 @@ static SearchArgs make_search_args(tbc_batch* B, uint64_t* tab, uint32_t n_work)
   a.dbg = debug_words();
   a.pool_vals = B->d_pool_vals.p;
   a.cfg = B->d_cfg.p;
+  a.progress = B->progress; a.progress_dev = B->d_progress.p;
   return a;
 }
 
@@ -87,6 +88,7 @@ static BeamArgs make_beam_args(tbc_batch* B, uint64_t* tab, uint32_t* stack, uin
   a.pool = B->d_pool.p; a.pool_cursor = B->d_pool_cursor.p; a.pool_words = B->d_pool.n;
   a.abort = B->ext_abort; a.abort_set = B->ext_abort_set; a.abort_map = B->ext_abort_map;
   a.park = B->d_park.p; a.resume = 0;
+  a.progress = B->progress; a.progress_dev = B->d_progress.p;
   {
     const uint64_t max_bytes = B->opts.max_visited_bytes ? B->opts.max_visited_bytes : (1ull << 30);
     uint32_t lg = 10;
@@ -495,6 +497,7 @@ tbc_status first_pass(RunState& R) {
   HostBuf<Hist>& hist_back = R.hist_back; HostBuf<BeamHist>& bh_back = R.bh_back;
   TRACE("run: begin");
   HIP_TRY(hipEventRecord(B->ev[0], s));
+  if (B->d_progress.p) HIP_TRY(hipMemsetAsync(B->d_progress.p, 0, sizeof(uint32_t), s));
   // (tbc_check: the arenas a run zeroes -- position bitmap, list offsets, crashed-call counts, the pool cursor -- are consecutive
   // pieces of the context's slab: one memset; the descriptors came up with the columns: not again.  Six memsets and two copies were 34 us)
   const bool zero_block = B->borrowed && !guard_on() && !B->d_bitmap.owned && !B->d_off.owned && !B->d_ncr.owned && !B->d_pool_cursor.owned &&
@@ -1249,9 +1252,25 @@ tbc_status finish(RunState& R) {
 
 // phase 0: the whole run.  phase 1 (tbc_batch_sweep_partial): pack + this rank's share of the sweep, stop before the
 // verdicts.  phase 2 (tbc_batch_sweep_finish): verdicts from the merged relation table already placed in seg_host.
+namespace {
+// tbc_batch_progress: the run says it is out and which phase it is in; the search kernels count into word 0 themselves
+struct RunningMark {
+  tbc_batch* B;
+  explicit RunningMark(tbc_batch* b) : B(b) {
+    if (B->progress) { ((volatile uint32_t*)B->progress)[0] = 0u; ((volatile uint32_t*)B->progress)[1] = TBC_PHASE_PACK; }
+    B->progress_seen.store(0u, std::memory_order_relaxed);
+    B->run_t0.store(now_ns(), std::memory_order_relaxed);
+    B->running.store(1u, std::memory_order_release);
+  }
+  void phase(uint32_t p) const { if (B->progress) ((volatile uint32_t*)B->progress)[1] = p; }
+  ~RunningMark() { phase(TBC_PHASE_IDLE); B->running.store(0u, std::memory_order_release); }
+};
+}  // namespace
+
 tbc_status batch_run_impl(tbc_batch* B, tbc_result* results, int phase) {
   HIP_TRY(hipSetDevice(B->device));
   tbc_status st;
+  RunningMark mark(B);
   if (phase == 0) {          // a fresh input waiting (batch_stream.hip)?  It becomes the batch's resident input now
     bool consumed = false;
     if ((st = stream_consume(B, &consumed)) != TBC_OK) return st;
@@ -1276,6 +1295,7 @@ tbc_status batch_run_impl(tbc_batch* B, tbc_result* results, int phase) {
   R.by_sweep.assign(nh, 0);
   for (uint32_t h = 0; h < nh; h++) R.final_log2[h] = R.beam ? B->bh[h].tab_log2 : B->hist[h].tab_log2;
   HIP_TRY(hipEventRecord(B->ev[4], R.s));
+  mark.phase(TBC_PHASE_RETRIES);
   if (B->sweep && (st = sweep_verdicts(R)) != TBC_OK) return st;
   if (R.beam && (st = list_overflow_fallback(R)) != TBC_OK) return st;
   R.width_of.assign(nh, B->width);
@@ -1286,6 +1306,11 @@ tbc_status batch_run_impl(tbc_batch* B, tbc_result* results, int phase) {
   if (R.restart_budget && (st = order_restarts(R)) != TBC_OK) { B->order_override = tbc_batch::kNoOrderOverride; return st; }
   if (R.count_budget && (st = count_form_pipeline(R)) != TBC_OK) return st;
   st = finish(R);
+  if (B->progress && results) {          // what the run hands back, whoever decided it (a sweep, a replica of a race, a retry from a scratch arena)
+    uint32_t decided = 0;
+    for (uint32_t h = 0; h < nh; h++) decided += results[h].valid != TBC_UNKNOWN ? 1u : 0u;
+    ((volatile uint32_t*)B->progress)[0] = decided;
+  }
   if (phase == 0 && B->assign_lists) {          // a fresh input's lists that did not fit their arena: room for the next one
     const tbc_status gs = stream_after_run(B, R.bh_back);
     if (gs != TBC_OK && st == TBC_OK) st = gs;

@@ -39,6 +39,20 @@ uint64_t tbc_batch_device_bytes(const tbc_batch* b) { return b ? b->device_bytes
 uint32_t tbc_batch_search_width(const tbc_batch* b) { return b ? (b->lanes ? 1u : b->width) : 0; }
 uint32_t tbc_batch_lanes_per_history(const tbc_batch* b) { return b ? (b->lanes ? b->lanes : 64u) : 0; }
 uint32_t tbc_batch_last_raced(const tbc_batch* b) { return b ? b->last_raced : 0; }
+tbc_status tbc_batch_progress(const tbc_batch* b, tbc_progress* out) {
+  if (!b || !out) { set_error("tbc_batch_progress: null argument"); return TBC_ERR_INVALID_ARG; }
+  const volatile uint32_t* w = b->progress;
+  out->n_histories = b->n_hist;
+  out->running = b->running.load(std::memory_order_acquire);
+  uint32_t d = w ? w[0] : 0u, seen = b->progress_seen.load(std::memory_order_relaxed);
+  while (d > seen && !b->progress_seen.compare_exchange_weak(seen, d, std::memory_order_relaxed)) {}
+  if (out->running && d < seen) d = seen;
+  out->n_decided = d < b->n_hist ? d : b->n_hist;       // (a history searched twice -- a retry, a race -- may have been counted twice while the run is out)
+  out->phase = w ? w[1] : (uint32_t)TBC_PHASE_IDLE;
+  const uint64_t t0 = b->run_t0.load(std::memory_order_relaxed);
+  out->elapsed_ns = (out->running && t0) ? now_ns() - t0 : 0ull;
+  return TBC_OK;
+}
 uint32_t tbc_batch_list_order(const tbc_batch* b) {
   if (!b) return 0;
   const uint32_t lo = b->list_order();          // PackOpenArgs' numbering -> TBC_ORDER_*

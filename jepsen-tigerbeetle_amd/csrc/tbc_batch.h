@@ -10,6 +10,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -248,6 +249,13 @@ struct tbc_batch {
   tbc::DevBuf<uint32_t> d_order;
   tbc::DevBuf<uint32_t> d_park;             // wide kernel: the search state of every history as the last launch left it (BeamArgs.park)
   uint32_t last_raced = 0;                  // last run: histories that went into a race of orders
+  // progress (tbc_batch_progress; the reference's knossos.search reports while it runs): words in HOST memory the search kernels count
+  // decided histories into (word 0) and the run writes its phase to (word 1); read by another thread while tbc_batch_run is out
+  uint32_t* progress = nullptr;
+  tbc::DevBuf<uint32_t> d_progress;         // the count itself, in HBM (wave_env.h count_decided)
+  mutable std::atomic<uint32_t> progress_seen{0};     // (two publishers can land out of order: a reader never reports less than it has seen)
+  std::atomic<uint64_t> run_t0{0};
+  std::atomic<uint32_t> running{0};
   bool order_restarts_apply() const {
     return width > 1 && !lanes && !count_form && list_order_applies() && opts.list_order == TBC_ORDER_DEFAULT && opts.max_steps == 0 &&
            !(opts.dominance & TBC_DOM_NO_ORDER_RESTARTS);

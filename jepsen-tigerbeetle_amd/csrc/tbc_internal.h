@@ -114,6 +114,8 @@ struct SearchArgs {
   uint32_t* dbg;              // optional host-mapped progress words (TBC_DEBUG=1), else null
   const int32_t* pool_vals;   // wide op values (multi-register micro-ops)
   uint64_t* cfg;              // kCfgCap records of (2 + mask_words) u64 per history: k0, M[], last op
+  uint32_t* progress;         // optional, HOST memory: word 0 = histories decided so far, as last published (tbc_batch_progress) ...
+  uint32_t* progress_dev;     // ... from this count in HBM
 };
 
 // ---- wide ("beam") schedule of the search: extra per-history layout built by pack_open_kernel
@@ -355,6 +357,8 @@ struct BeamArgs {
   uint32_t* park;                    // wide kernel, optional: kParkWords words per history -- the search state as the kernel leaves it ...
   uint32_t resume;                   // ... and, 1: the search is taken up from there (the visited set, the stacks and the growth pool as they were left) instead of from the root
   uint32_t pad6;
+  uint32_t* progress;                // optional, HOST memory: word 0 = histories decided so far, as last published (tbc_batch_progress) ...
+  uint32_t* progress_dev;            // ... from this count in HBM (wave_env.h count_decided)
 };
 constexpr uint32_t kParkWords = 32;
 

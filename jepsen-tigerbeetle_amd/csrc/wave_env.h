@@ -52,6 +52,13 @@ WV_DEV void threadfence() { __threadfence(); }
 // pack_wg64_kernel and one per finished history in wgl_narrow_kernel (32,768 a launch); nothing in these kernels is read by another
 // compute unit before the kernel ends.
 WV_DEV void wg_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); }
+// tbc_batch_progress: one more history decided.  The count lives in HBM (an atomic per history straight into HOST memory was measured:
+// 32,768 of them on one address serialize at the host bridge, ~0.6 us each, and a wavefront's later loads wait behind its own -- the
+// headline search went 57 -> 77 ms); every `every_mask + 1`-th count is published to the host word by a plain store.
+WV_DEV void count_decided(uint32_t* dev, uint32_t* host, uint32_t every_mask) {
+  const uint32_t n = atomicAdd(dev, 1u) + 1u;
+  if ((n & every_mask) == 0u) __hip_atomic_store(host, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 // the lane number, opaque to the optimiser: what an iteration derives from it is recomputed instead of kept live
 WV_DEV uint32_t opaque(uint32_t v) { asm volatile("" : "+v"(v)); return v; }
 

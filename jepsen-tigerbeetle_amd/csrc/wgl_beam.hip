@@ -1105,6 +1105,10 @@ __device__ void beam_one(const BeamArgs& A, const uint32_t hidx, uint32_t* lds, 
     }
     out->steps = probes; out->visited = visited; out->probes = probes; out->backtracks = expanded;
     out->max_depth = max_sp; out->bucket_reads = rounds; out->tab_log2 = cap_log2;
+    if (verdict != TBC_UNKNOWN && C->progress) {          // tbc_batch_progress: a wavefront per history, every count is published
+      const uint32_t n = atomicAdd(C->progress_dev, 1u) + 1u;
+      __hip_atomic_store(C->progress, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     // (a race of list orders: this history is decided -- whoever searches it in another order may stop)
     uint32_t* const done = C->abort_set;
     const uint32_t* const dmap = C->abort_map;

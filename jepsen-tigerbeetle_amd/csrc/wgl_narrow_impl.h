@@ -442,6 +442,7 @@ WV_DEV void narrow_wave(const BeamArgs& A, const uint32_t wave_idx, uint32_t* ld
       }
       out->steps = probes; out->visited = (uint64_t)visited; out->probes = probes; out->backtracks = expanded;
       out->max_depth = (uint64_t)GS[G_MAXSP]; out->bucket_reads = rounds; out->tab_log2 = cap_log2; out->pad = 0;
+      if (verdict != TBC_UNKNOWN && C->progress) wv::count_decided(C->progress_dev, C->progress, 63u);      // (tbc_batch_progress)
     }
   };
 

@@ -335,6 +335,10 @@ __device__ void search_one(const SearchArgs& A, const uint32_t hidx, uint32_t* r
     out->n_configs = n_cfg;
     out->steps = steps; out->visited = visited; out->probes = probes; out->backtracks = backtracks;
     out->max_depth = max_depth; out->bucket_reads = bucket_reads;
+    if (verdict != TBC_UNKNOWN && A.progress) {           // tbc_batch_progress
+      const uint32_t n = atomicAdd(A.progress_dev, 1u) + 1u;
+      __hip_atomic_store(A.progress, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
 }
 

@@ -121,6 +121,7 @@ inline uint32_t row_shr0_emu(uint32_t v) { return row_shr0_at<N>(v, 100000 + N);
 inline void barrier_at(int site) { (void)gather(0, site); }
 inline void threadfence() {}
 inline void wg_fence() {}
+inline void count_decided(uint32_t* dev, uint32_t* host, uint32_t every_mask) { const uint32_t n = __atomic_fetch_add(dev, 1u, __ATOMIC_RELAXED) + 1u; if ((n & every_mask) == 0u) *host = n; }
 inline uint32_t opaque(uint32_t v) { return v; }
 
 inline uint64_t ld64(const gu64* p) { return *p; }

@@ -39,10 +39,11 @@ def test_struct_layouts_match_header(native):
 #include <stdio.h>
 #include "tbcheck.h"
 #include "tbsynth.h"
-int main(void){ printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(tbc_events), sizeof(tbc_ops),
+int main(void){ printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(tbc_events), sizeof(tbc_ops),
   sizeof(tbc_model), sizeof(tbc_opts), sizeof(tbc_config), sizeof(tbc_counters), sizeof(tbc_result),
   sizeof(tbc_batch_desc), sizeof(tbs_params), offsetof(tbc_result, counters),
-  sizeof(tbc_batch_input), offsetof(tbc_batch_input, word), sizeof(tbc_input_info), offsetof(tbc_input_info, ops_cap)); return 0; }
+  sizeof(tbc_batch_input), offsetof(tbc_batch_input, word), sizeof(tbc_input_info), offsetof(tbc_input_info, ops_cap),
+  sizeof(tbc_progress), offsetof(tbc_progress, elapsed_ns)); return 0; }
 '''
     with tempfile.TemporaryDirectory() as d:
         src = os.path.join(d, "s.c")
@@ -54,7 +55,8 @@ int main(void){ printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\
     mine = [C.sizeof(N.Events), C.sizeof(N.Ops), C.sizeof(N.Model), C.sizeof(N.Opts), C.sizeof(N.Config),
             C.sizeof(N.Counters), C.sizeof(N.Result), C.sizeof(N.BatchDesc), C.sizeof(N.SynthParams),
             N.Result.counters.offset,
-            C.sizeof(N.BatchInput), N.BatchInput.word.offset, C.sizeof(N.InputInfo), N.InputInfo.ops_cap.offset]
+            C.sizeof(N.BatchInput), N.BatchInput.word.offset, C.sizeof(N.InputInfo), N.InputInfo.ops_cap.offset,
+            C.sizeof(N.Progress), N.Progress.elapsed_ns.offset]
     assert mine == sizes
     # the wire word of the streaming inputs, as the header's macro packs it
     assert N.WIRE_NIL == 0xFF and N.COMM_ID_BYTES == 128

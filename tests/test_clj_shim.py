@@ -94,7 +94,7 @@ def test_abi_table_equals_the_ctypes_binding(native, abi):
     N = native
     structs = {"events": N.Events, "ops": N.Ops, "model": N.Model, "opts": N.Opts, "config": N.Config, "result": N.Result,
                "batch_desc": N.BatchDesc, "setfull_in": N.SetFullIn, "setfull_out": N.SetFullOut, "setfull_rows": N.SetFullRows,
-               "batch_input": N.BatchInput, "input_info": N.InputInfo}
+               "batch_input": N.BatchInput, "input_info": N.InputInfo, "progress": N.Progress}
     assert abi["version"] == N.lib().tbc_version() == 2
     assert set(abi) == set(structs) | {"version", "enums"}
     for name, cls in structs.items():

@@ -96,3 +96,46 @@ def test_configs_of_a_count_form_invalid_verdict(native, oracle):
         assert seen >= 2
     finally:
         core.DEFAULT_COUNT_FORM = old
+
+
+def test_progress_is_readable_from_another_thread_while_the_run_is_out(native):
+    """tbc_batch_progress (reference: knossos.search's reporter, which logs how far a running search has come): a second thread polls the
+    batch while tbc_batch_run is in flight -- the count of decided histories only grows, the run is seen running, and afterwards the
+    count is what the run handed back."""
+    import threading
+    import time
+    hists = synth.register_ops_many(range(8192), n_ops=4000, n_procs=32, busy=0.2, info=0.0)
+    gm = core.make_model(N.MODEL_CAS_REGISTER, N.NIL)
+    with core.Batch(hists, gm, core.make_opts(time_limit_ms=120000, want_witness=False, algorithm=N.ALG_COMPETITION, visited_per_op=8)) as b:
+        p0 = b.progress()
+        assert p0["n_histories"] == 8192 and p0["running"] == 0 and p0["n_decided"] == 0 and p0["phase"] == N.PHASE_IDLE
+        seen, stop = [], threading.Event()
+
+        def poll():
+            while not stop.is_set():
+                seen.append(b.progress())
+                time.sleep(0.0005)
+
+        t = threading.Thread(target=poll)
+        t.start()
+        try:
+            for _ in range(3):
+                b.run()
+        finally:
+            stop.set()
+            t.join()
+        v = b.verdicts()
+        after = b.progress()
+        assert after["running"] == 0 and after["phase"] == N.PHASE_IDLE and after["n_decided"] == int((v != N.UNKNOWN).sum()) == 8192
+        running = [p for p in seen if p["running"]]
+        assert len(running) >= 3 and all(p["elapsed_ns"] > 0 and p["phase"] in (N.PHASE_PACK, N.PHASE_RETRIES) for p in running)
+        assert all(0 <= p["n_decided"] <= 8192 for p in seen)
+        # inside one run the count only grows: split the samples at the points where a new run zeroed it
+        partial = [p["n_decided"] for p in running if 0 < p["n_decided"] < 8192]
+        assert partial, "no sample fell inside a search (the kernels count as they store their results)"
+    # one history through the wide kernel and through the sequential one: counted by those kernels too
+    one = synth.register_ops_many(range(1), n_ops=3000, n_procs=16, busy=0.3, info=0.0)
+    for alg, width in ((N.ALG_COMPETITION, 8), (N.ALG_WGL, 0)):
+        with core.Batch(one, gm, core.make_opts(time_limit_ms=60000, algorithm=alg, search_width=width)) as b:
+            b.run()
+            assert b.progress()["n_decided"] == 1
