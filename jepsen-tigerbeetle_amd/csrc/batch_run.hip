@@ -272,16 +272,22 @@ static tbc_status expand_eager_witness(tbc_batch* B, uint32_t h, uint32_t* wit, 
 
 // ---- several batches in flight on one device (each on its own stream, from its own host thread).  The narrow kernel is sized
 // to the whole GPU and lives on latency, the pack kernels on vector issue: a batch's pack beside ANOTHER batch's search uses
-// what the search leaves idle, two searches at once only halve each other.  So the searches of one device are chained through
-// an event -- a search starts when the one launched before it, on whatever stream, is done -- and everything else floats.
+// what the search leaves idle.  Two searches launched side by side only halve each other -- but a search queued BEHIND a running one
+// starts in its tail (below), so by default nothing orders them; SearchTurn can chain the searches of one device through an event
+// (a search then starts when the one launched before it, on whatever stream, is done), which is how rounds 3 - 5 ran.
 namespace {
 struct SearchTurn {
   static std::mutex& mu() { static std::mutex m; return m; }
   static hipEvent_t& last(int dev) { static hipEvent_t ev[64] = {}; return ev[dev & 63]; }
   std::lock_guard<std::mutex> g;
   int dev; hipStream_t s;
+  // (round 6: NOT chained by default.  The launch is sized to what the GPU keeps resident, so a second search queued behind a running one
+  // gets wavefront slots only as the first one's searches end -- it fills the first one's tail, whose longest history is 1.7 x the mean
+  // (profiles/NOTES_r06.md): 366k -> 380k histories/s with two batches in flight, 359k -> 375k with three.  TBC_SEARCH_TURN=1 chains them
+  // again -- a search then starts when the one launched before it is done --, which is what rounds 3 - 5 measured with.)
+  static bool chained() { static const bool on = std::getenv("TBC_SEARCH_TURN") && std::getenv("TBC_SEARCH_TURN")[0] == '1'; return on; }
   SearchTurn(int device, hipStream_t stream) : g(mu()), dev(device), s(stream) {
-    if (last(dev)) (void)hipStreamWaitEvent(s, last(dev), 0);
+    if (chained() && last(dev)) (void)hipStreamWaitEvent(s, last(dev), 0);
   }
   ~SearchTurn() {
     if (!last(dev)) (void)hipEventCreateWithFlags(&last(dev), hipEventDisableTiming);
