@@ -94,6 +94,7 @@ def test_the_other_models_and_the_narrow_shapes_under_the_defaults(native, oracl
     from test_commutative_models import enc_bank, enc_set
     from test_multi_register import encode as enc_mr
     o = core.make_opts(time_limit_ms=60000, algorithm=N.ALG_COMPETITION, want_witness=False)
+    n_bad = 0
     for which, n_ops, procs, info, corrupt in [("set", 800, 8, 0.02, None), ("set", 800, 8, 0.0, "phantom"), ("set", 3000, 5, 0.02, "lost"),
                                                 ("bank", 800, 8, 0.02, False), ("bank", 800, 8, 0.0, True), ("mr", 600, 8, 0.02, False), ("mr", 600, 8, 0.0, True)]:
         for seed in range(2):
@@ -105,9 +106,11 @@ def test_the_other_models_and_the_narrow_shapes_under_the_defaults(native, oracl
                 e, om = enc_mr(multi_register_history(n_ops, procs, seed, n_keys=8, n_values=5, busy=0.25, info=info, corrupt=corrupt))
             exp = oracle.check_beam(e.ops.as_dict(), om, 8)
             got = core.check_ops(e.ops, e.native_model, o)
-            assert got["valid"] == exp["valid"] == (0 if corrupt else 1), (which, seed)
+            assert got["valid"] == exp["valid"] != N.UNKNOWN, (which, seed)
+            n_bad += exp["valid"] == 0           # (a planted loss may leave a history linearizable: the oracle says, not the generator)
             if exp["valid"] == 0:
                 assert got["fail_op"] == exp["fail_op"], (which, seed)
+    assert n_bad >= 6
     shapes = [(40, 4, 0.0, 0.0, 0.5), (200, 8, 0.0, 0.6, 0.3), (1000, 16, 0.0, 0.0, 0.5), (1000, 16, 0.0, 0.6, 0.2), (3000, 64, 0.0, 0.0, 0.1), (3000, 64, 0.0, 0.6, 0.05)]
     base = [columns.pair_events(synth.register_events(n_ops=n, n_procs=p, seed=7700 + s, busy=busy, info=info, corrupt=corrupt))
             for (n, p, info, corrupt, busy) in shapes for s in range(4)]
