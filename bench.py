@@ -175,7 +175,7 @@ def leg_workload(args, local_rank, which):
     def second(busy, B2, vpo, seed0, cpu_n, cpu_cap, warm, info=0.0):
         h2 = synth.register_ops_many(range(seed0, seed0 + B2), n_ops=args.ops, n_procs=args.procs, busy=busy, info=info)
         o2 = core.make_opts(device=local_rank, time_limit_ms=600000, want_witness=False, algorithm=N.ALG_COMPETITION,
-                            search_width=args.width, visited_per_op=vpo)
+                            search_width=args.width, visited_per_op=vpo, lanes_per_history=int(os.environ.get("TBC_BENCH_LEG_LANES", "0")))
         with core.Batch(h2, model, o2) as b2:
             width2, lanes2, order2 = b2.search_width(), b2.lanes_per_history(), b2.list_order()
             if warm:

@@ -33,8 +33,8 @@ doc["entries"] = [{
     "visited_per_op": VPO, "ops": 10000, "procs": 64, "busy": 0.1, "info": 0.0,
     "fetch_bytes": fetch, "write_bytes": write, "traffic_bytes": fetch + write, "kernel_ms": ms,
     "algorithmic_bytes": alg, "traffic_over_algorithmic": round((fetch + write) / alg, 2),
-    "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of scripts/gpu_profile_r05.sh (the bench's own batch: seeds 0 .. B-1 through "
-              "scripts/gpu_narrow_ab.py); summary committed as profiles/r05_pmc_final.txt",
+    "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (the bench's own batch: seeds 0 .. B-1 through scripts/gpu_narrow_ab.py) of " +
+              os.environ.get("TBC_TRAFFIC_SOURCE", "scripts/gpu_profile_r05.sh; summary committed as profiles/r05_pmc_final.txt"),
     "per_new_config_write_bytes": round(write / visited, 1), "per_probe_fetch_bytes": round(fetch / probes, 1)}]
 json.dump(doc, open(path, "w"), indent=1)
 print("traffic", fetch + write, "sha", bench.kernel_sha(), "kernel_ms", ms)
