@@ -183,6 +183,18 @@ def leg_workload(args, local_rank, which):
             t2 = time.perf_counter(); b2.run(); t2 = time.perf_counter() - t2
             c2 = b2.counters(); tm2 = b2.timing_ns(); v2 = b2.verdicts()
             raced2 = b2.last_raced() if hasattr(b2, "last_raced") else 0
+            fresh2 = None
+            if info:
+                # the same batch object fed ANOTHER set of crashed histories (a count-form batch takes fresh inputs since round 6: the classes
+                # of crashed calls are planned on the host when the input is submitted -- csrc/batch_stream.hip plan_count_input)
+                h3 = synth.register_ops_many(range(seed0 + B2, seed0 + 2 * B2), n_ops=args.ops, n_procs=args.procs, busy=busy, info=info)
+                tr = time.perf_counter(); b2.reload(h3); tr = time.perf_counter() - tr
+                tu = time.perf_counter(); b2.run(); tu = time.perf_counter() - tu
+                v3 = b2.verdicts()
+                fresh2 = {"histories_per_s": round(B2 / (tr + tu), 2), "host_marshal_encode_plan_submit_s": round(tr, 3), "of_which_tbc_batch_reload_s": round(getattr(b2, "reload_call_s", 0.0), 3), "run_s": round(tu, 3),
+                          "valid": int((v3 == N.VALID).sum()), "unknown": int((v3 == N.UNKNOWN).sum()),
+                          "what": "tbc_batch_reload of a never-seen batch (wire encoding, the count form's planning on the host, the copy queued) + the run that consumes it, one after the other on one host thread"}
+                del h3
         alg2 = 16 * (c2["probes"] - c2["visited"]) + 32 * c2["visited"]
         k2 = (tm2["search"] + tm2["retries"]) / 1e6
         out = {"workload": workload_name(args.ops, args.procs, busy, info), "histories_per_gpu": B2, "search_width": width2, "lanes_per_history": lanes2, "list_order": order2,
@@ -195,6 +207,8 @@ def leg_workload(args, local_rank, which):
                             "kernel": "wgl_narrow_kernel" if lanes2 != 64 else "wgl_beam_kernel",
                             "kernel_ms": round(k2, 3), "probes_per_launch": c2["probes"], "new_configs_per_launch": c2["visited"]},
                "device_ms": {k: round(x / 1e6, 3) for k, x in tm2.items()}}
+        if fresh2 is not None:
+            out["fresh_input"] = fresh2
         if not args.no_cpu and info:
             # crashed calls: the library's count form; the CPU runs the same passes (oracle/wgl_count.c) on a thread pool
             from concurrent.futures import ThreadPoolExecutor
@@ -351,6 +365,8 @@ def compact_line(line):
             e[w] = {"error": str(d["error"])[:100]} if "error" in d else {
                 "value": d.get("value"), "histories": d.get("histories_per_gpu"), "unknown": d.get("unknown"), "frac": (d.get("roofline") or {}).get("frac"),
                 "traffic": (d.get("roofline") or {}).get("traffic"), "kernel_ms": (d.get("roofline") or {}).get("kernel_ms"), "cpu": (d.get("cpu_baseline") or {}).get("value")}
+            if isinstance(d.get("fresh_input"), dict):
+                e[w]["fresh"] = d["fresh_input"].get("histories_per_s")
     d = ex.get("set_full")
     if isinstance(d, dict):
         e["set_full"] = {"error": str(d["error"])[:100]} if "error" in d else {"scan_ms": d.get("scan_ms"), "end_to_end_ms": d.get("end_to_end_ms"),

@@ -554,8 +554,13 @@ void tbc_batch_destroy(tbc_batch* b);
  * that finds out -- tbc_batch_submit_input or the tbc_batch_run that consumes it -- and the caller destroys and
  * creates): at most the first input's number of histories and an eighth more than its ops; process slots within the
  * batch's mask words; register values within the batch's value domain (the greatest value of the first input,
- * when the dominance rules are on); no crashed call if the first input had none.  Batches of the level sweep, of
- * the count form, of set / bank / multi-register / table models and the sequential schedule take no fresh inputs.
+ * when the dominance rules are on); no crashed call if the first input had none.  A COUNT-FORM batch (created from
+ * histories with crashed calls that have an effect, under the default rules: what a nemesis makes) takes fresh inputs
+ * too: the classes of crashed calls and the re-used process slots are planned on the host inside
+ * tbc_batch_submit_input (a few host threads; the caller's words are not modified), and an input whose crashed calls
+ * do not fit the form (> 128 bits of counts) is refused.  Batches of the level sweep (incl. a count-form batch of
+ * <= 8 histories, which has the relaxed sweep beside it), of set / bank / multi-register / table models and the
+ * sequential schedule take no fresh inputs.
  * Verdict, failing op and every counter of a consumed input equal those of a batch created from the same histories
  * (tests/test_stream_gpu.py).
  */

@@ -235,7 +235,10 @@ class Batch:
         d.n_process = _p(n_process, C.c_uint32)
         d.cols = cols.struct()
         d.model_aux = None
+        import time as _time
+        t0 = _time.perf_counter()
         N.check_status(N.lib().tbc_batch_reload(self._h, C.byref(d)))
+        self.reload_call_s = _time.perf_counter() - t0          # (the C call alone: wire encoding, a count-form batch's planning, the copy queued)
         if not hasattr(self, "_pending_n"):
             self._pending_n = []
         self._pending_n.append(nh)

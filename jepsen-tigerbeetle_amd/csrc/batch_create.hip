@@ -20,7 +20,7 @@ namespace tbc {
 // at (the completions positioned between its invocation and its completion, plus its own).  Exact when
 // the positions are event indices; anything else falls back to the worst case (every slot at every front).
 // branch_lists: the lists hold the live :write / :cas calls only (kRuleBranch), so the reads are not counted.
-static uint64_t open_list_entries(const tbc_ops& c, uint64_t op_off, uint64_t n, uint32_t n_events, uint32_t n_slots,
+uint64_t open_list_entries(const tbc_ops& c, uint64_t op_off, uint64_t n, uint32_t n_events, uint32_t n_slots,
                                   std::vector<uint32_t>& pre, bool branch_lists) {
   const uint64_t worst = std::max<uint64_t>(n, 1) * std::max(1u, n_slots);
   if (n == 0) return 1;
@@ -43,7 +43,7 @@ static uint64_t open_list_entries(const tbc_ops& c, uint64_t op_off, uint64_t n,
 
 // count form of ONE history (tbc_batch.h, CountHist).  Returns false when the form does not apply (more than 128 bits of counts,
 // a process id out of range: the pack kernel will say what is wrong with such a history).
-static bool build_count_form(const tbc_ops& c, uint64_t o0, uint64_t n, uint32_t n_process, bool cas_model, int32_t* slot_col, CountHist& out,
+bool build_count_form(const tbc_ops& c, uint64_t o0, uint64_t n, uint32_t n_process, bool cas_model, int32_t* slot_col, CountHist& out,
                              std::vector<uint32_t>& rets, std::vector<int32_t>& slot_of, std::vector<uint8_t>& used) {
   const uint8_t* f = c.f + o0; const int32_t* a = c.a + o0; const int32_t* b = c.b + o0; const int32_t* proc = c.process + o0;
   const uint32_t* inv = c.inv_pos + o0; const uint32_t* ret = c.ret_pos + o0;
@@ -391,8 +391,10 @@ void plan_sweep_segments(CreatePlan& P) {
 // sweep, visited-set sizing) is read from B; what depends on the input is passed in -- tbc_batch_create and every fresh input
 // (batch_stream.hip) lay their histories out with this one function.
 tbc_status layout_histories(tbc_batch* B, uint32_t nh, const uint64_t* op_off, const uint32_t* n_events, const uint32_t* n_slots, const int32_t* aux,
-                            const uint32_t* list_caps, bool lists_on_device, std::vector<Hist>& hist, std::vector<BeamHist>& bh, LayoutTotals& tot) {
+                            const uint32_t* list_caps, bool lists_on_device, std::vector<Hist>& hist, std::vector<BeamHist>& bh, LayoutTotals& tot,
+                            const std::vector<CountHist>* count_hist) {
   const bool beam = B->width > 1;
+  if (!count_hist) count_hist = &B->count_hist;
   const uint32_t KW = 1 + B->mask_words, EW = B->entry_words();
   const uint64_t default_cap_bytes = 1ull << 30;
   const uint64_t max_bytes = B->opts.max_visited_bytes ? B->opts.max_visited_bytes : default_cap_bytes;
@@ -431,7 +433,7 @@ tbc_status layout_histories(tbc_batch* B, uint32_t nh, const uint64_t* op_off, c
       Q.tab_log2 = blg;
       Q.off_off = tot.boff_n; tot.boff_n += n + 2;
       if (B->count_form) {
-        const CountHist& ch = B->count_hist[h];
+        const CountHist& ch = (*count_hist)[h];
         Q.cmem_off = tot.bocc_n; tot.bocc_n += ch.words.size();
         Q.n_classes = ch.n_classes; Q.top[0] = ch.top[0]; Q.top[1] = ch.top[1];
       }

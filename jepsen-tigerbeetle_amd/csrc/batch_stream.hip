@@ -21,8 +21,13 @@
 //     between the pack and the walk.
 //   * ARENAS GROW (6 % at a time) when an input needs more than the batch has; histories whose lists did not fit are answered by the
 //     sequential kernel that once (batch_run.hip, list_overflow_fallback) and the list arenas are larger for the next input.
-// What it does not take (TBC_ERR_UNSUPPORTED: destroy and create): batches of the level sweep, the count form, set / bank /
-// multi-register / table models, batches of tbc_check's persistent contexts.
+//   * A COUNT-FORM BATCH (crashed calls with an effect under the default rules: what the reference's nemesis makes) takes fresh inputs
+//     too: the classes of crashed calls and the re-numbered process slots of every history are planned on the HOST when the input is
+//     submitted (plan_count_input: batch_create.hip's build_count_form over the wire columns, on up to 16 threads; the words with
+//     the slot numbers go to a pinned copy, which is what travels), the class records go up beside the wire columns, and since such a batch has no sequential
+//     fallback for lists that outgrow their arena, the lists' lengths are counted on the host as well and the arena grown before the run.
+// What it does not take (TBC_ERR_UNSUPPORTED: destroy and create): batches of the level sweep (a count-form batch of <= 8 histories has
+// the relaxed sweep beside it), set / bank / multi-register / table models, batches of tbc_check's persistent contexts.
 #include "tbc_batch.h"
 
 using namespace tbc;
@@ -110,7 +115,6 @@ const char* streamable(const tbc_batch* B) {
   if (B->borrowed) return "a batch of tbc_check's persistent context";
   if (B->width <= 1) return "the sequential knossos.wgl schedule (search_width 1)";
   if (B->sweep || B->rsweep) return "a batch of the level sweep";
-  if (B->count_form) return "a count-form batch (crashed calls with an effect under the default rules)";
   if (!(B->model.kind == TBC_MODEL_REGISTER || B->model.kind == TBC_MODEL_CAS_REGISTER || B->model.kind == TBC_MODEL_MUTEX)) return "a model outside register / cas-register / mutex";
   if (B->pool_len) return "a batch with a value pool";
   return nullptr;
@@ -173,7 +177,8 @@ tbc_status ensure_arenas(tbc_batch* B, const LayoutTotals& t) {
       (s = ensure(B->d_slot8, slot8_bytes(T, nhc), &grew)) || (s = ensure(B->d_stack, t.bstack_n, &grew)))
     return s;
   if (B->opts.want_witness && (s = ensure(B->d_witness, T, &grew))) return s;
-  if (B->any_crashed && (s = ensure(B->d_crashed, T, &grew))) return s;
+  if (B->any_crashed && !B->count_form && (s = ensure(B->d_crashed, T, &grew))) return s;
+  if (B->count_form && (s = ensure(B->d_cmem, t.bocc_n, &grew))) return s;
   if (B->lanes && (s = ensure(B->d_rk8, slot8_bytes(T, nhc), &grew))) return s;
   if (B->lanes) { if ((s = ensure(B->d_rdm, T * B->front_words(), &grew))) return s; }
   else if (B->reg_rules() && (s = ensure(B->d_rdm, T * B->vpad * MW, &grew))) return s;
@@ -192,12 +197,61 @@ tbc_status ensure_arenas(tbc_batch* B, const LayoutTotals& t) {
   return TBC_OK;
 }
 
+// A count-form batch's fresh input: every history's classes of crashed calls and its process column re-numbered (slots re-used), as
+// tbc_batch_create plans them (build_count_form) -- here from the WIRE columns of the pinned slot, a run of histories per host thread.
+// The wire words with the slot numbers in place of the process numbers go to `planned` (pinned, beside the slot: the device unpacks what
+// the pack kernel is to see; the caller's own words stay as written, so a slot may be submitted again as it is); n_slots[] and
+// P.count_hist / P.cmem / P.lst_total are what the layout, the upload and the list arena ask for.
+tbc_status plan_count_input(tbc_batch* B, const tbc_batch_input& in, uint32_t* planned, uint32_t nh, tbc_pending_input& P, std::vector<uint32_t>& n_slots) {
+  P.count_hist.assign(nh, CountHist{});
+  n_slots.assign(nh, 1u);
+  std::vector<uint64_t> lists(nh, 0);
+  const bool cas_model = B->model.kind == TBC_MODEL_CAS_REGISTER;
+  const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+  const unsigned nt = in.op_off[nh] > (1ull << 20) ? std::min(16u, hw) : 1u;
+  std::vector<int> bad(nt, -1);
+  const auto work = [&](unsigned t) {
+    std::vector<uint8_t> f; std::vector<int32_t> a, b, proc, slot; std::vector<uint32_t> rets, pre; std::vector<int32_t> slot_of; std::vector<uint8_t> used;
+    for (uint32_t h = (uint32_t)((uint64_t)nh * t / nt); h < (uint32_t)((uint64_t)nh * (t + 1) / nt); h++) {
+      const uint64_t o0 = in.op_off[h], n = in.op_off[h + 1] - o0;
+      f.resize(n); a.resize(n); b.resize(n); proc.resize(n); slot.assign(n + 1, 0);
+      for (uint64_t i = 0; i < n; i++) {
+        const uint32_t w = in.word[o0 + i], a8 = (w >> 4) & 0xFFu, b8 = (w >> 12) & 0xFFu;
+        f[i] = (uint8_t)(w & 15u); a[i] = a8 == TBC_WIRE_NIL ? TBC_NIL : (int32_t)a8; b[i] = b8 == TBC_WIRE_NIL ? TBC_NIL : (int32_t)b8; proc[i] = (int32_t)(w >> 20);
+      }
+      tbc_ops c{};
+      c.n = (uint32_t)n; c.f = f.data(); c.a = a.data(); c.b = b.data(); c.process = proc.data(); c.inv_pos = in.inv_pos + o0; c.ret_pos = in.ret_pos + o0;
+      if (!build_count_form(c, 0, n, in.n_process[h], cas_model, slot.data(), P.count_hist[h], rets, slot_of, used)) { if (bad[t] < 0) bad[t] = (int)h; continue; }
+      n_slots[h] = std::max(1u, P.count_hist[h].n_slots);
+      for (uint64_t i = 0; i < n; i++) planned[o0 + i] = (in.word[o0 + i] & 0xFFFFFu) | ((uint32_t)slot[i] << 20);
+      c.process = slot.data();
+      lists[h] = open_list_entries(c, 0, n, in.n_events[h], n_slots[h], pre, false);
+    }
+  };
+  if (nt == 1) work(0);
+  else {
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; t++) th.emplace_back(work, t);
+    for (auto& x : th) x.join();
+  }
+  for (int h : bad) if (h >= 0) {
+    set_error("history %d of the input: its crashed calls do not fit the count form (more than 128 bits of counts, or a process number out of range): destroy and create", h);
+    return TBC_ERR_UNSUPPORTED;
+  }
+  size_t words = 0;
+  for (uint32_t h = 0; h < nh; h++) { words += P.count_hist[h].words.size(); P.lst_total += std::max<uint64_t>(1, lists[h]); }
+  P.cmem.clear(); P.cmem.reserve(words);
+  for (uint32_t h = 0; h < nh; h++) P.cmem.insert(P.cmem.end(), P.count_hist[h].words.begin(), P.count_hist[h].words.end());
+  return TBC_OK;
+}
+
 }  // namespace
 
 void stream_release(tbc_batch* B) {
   for (auto& sl : B->in_slots) {
     if (sl.copied) { (void)hipEventSynchronize(sl.copied); (void)hipEventDestroy(sl.copied); }
     if (sl.mem) (void)hipHostFree(sl.mem);
+    if (sl.planned) (void)hipHostFree(sl.planned);
   }
   B->in_slots.clear();
   if (B->stream_copy) { (void)hipStreamSynchronize(B->stream_copy); (void)hipStreamDestroy(B->stream_copy); B->stream_copy = nullptr; }
@@ -236,6 +290,13 @@ tbc_status stream_consume(tbc_batch* B, bool* consumed) {
     }
   }
   if ((st = ensure_arenas(B, want))) return st;
+  if (B->count_form && P.lst_total > B->d_lst.n) {          // (no fallback for lists that do not fit: the arena grows BEFORE the run)
+    const uint64_t need = P.lst_total + P.lst_total / 16;
+    if (B->lanes && need >= (1ull << 32)) { set_error("the input's per-front lists exceed what several histories per wavefront address: destroy and create"); return TBC_ERR_UNSUPPORTED; }
+    if ((st = B->d_lst.regrow(need))) return st;
+    if (B->reg_rules() && (st = B->d_twn.regrow(need * B->mask_words))) return st;
+    B->lists_regrown++;
+  }
   B->count_device_bytes();
   const uint64_t T = P.total_ops;
   const uint32_t* stage = B->d_stage[P.stage].p;
@@ -249,6 +310,7 @@ tbc_status stream_consume(tbc_batch* B, bool* consumed) {
                        B->d_f.p, B->d_a.p, B->d_b.p, B->d_proc.p, B->d_inv.p, B->d_ret.p, vmax, B->any_crashed ? 1u : 0u, B->d_in_flags.p);
     HIP_TRY(hipGetLastError());
   }
+  if (B->count_form && !P.cmem.empty()) HIP_TRY(hipMemcpyAsync(B->d_cmem.p, P.cmem.data(), P.cmem.size() * 8, hipMemcpyHostToDevice, s));      // (synchronised below, before P goes)
   HIP_TRY(hipMemcpyAsync(B->in_flags_host, B->d_in_flags.p, 4, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipEventRecord(B->ev_unpacked[P.stage], s));
   HIP_TRY(hipStreamSynchronize(s));          // (the pack must not run over an input the batch cannot take: its crashed-call arena may not exist)
@@ -266,6 +328,7 @@ tbc_status stream_consume(tbc_batch* B, bool* consumed) {
   B->inputs_stale = false;
   B->hist.swap(P.hist);
   B->bh.swap(P.bh);
+  if (B->count_form) B->count_hist.swap(P.count_hist);
   B->n_hist = P.n_hist;
   B->total_ops = T;
   B->max_ops = P.max_ops;
@@ -351,13 +414,22 @@ tbc_status tbc_batch_submit_input(tbc_batch* b, uint32_t slot, uint32_t n_hist) 
     const uint64_t T = in.op_off[n_hist];
     if (T > b->in_ops_cap) { set_error("tbc_batch_submit_input: %llu ops, a slot holds %llu", (unsigned long long)T, (unsigned long long)b->in_ops_cap); return TBC_ERR_INVALID_ARG; }
     if (T > 0xFFFFFFFFull) { set_error("tbc_batch_submit_input: more than 2^32 - 1 ops"); return TBC_ERR_INVALID_ARG; }
-    if (max_slots > 64u * b->mask_words || max_slots > 4096u) {
-      set_error("the input has a history of %u processes, the batch's kernels were chosen for at most %u: destroy and create", max_slots, 64u * b->mask_words);
-      return TBC_ERR_UNSUPPORTED;
-    }
     tbc_pending_input P;
     P.slot = slot; P.stage = (uint32_t)(b->in_seq & 1u); P.n_hist = n_hist; P.total_ops = T;
-    tbc_status st = layout_histories(b, n_hist, in.op_off, in.n_events, in.n_process, nullptr, nullptr, true, P.hist, P.bh, P.tot);
+    tbc_status st;
+    std::vector<uint32_t> count_slots;
+    if (b->count_form) {          // the classes of crashed calls and the re-used process slots, planned here on the host
+      if (!sl.planned) HIP_TRY(hipHostMalloc((void**)&sl.planned, (size_t)b->in_ops_cap * 4, hipHostMallocDefault));
+      if ((st = plan_count_input(b, in, sl.planned, n_hist, P, count_slots)) != TBC_OK) return st;
+      max_slots = 1;
+      for (uint32_t h = 0; h < n_hist; h++) max_slots = std::max(max_slots, count_slots[h]);
+    }
+    if (max_slots > 64u * b->mask_words || max_slots > 4096u) {
+      set_error("the input has a history of %u process slots, the batch's kernels were chosen for at most %u: destroy and create", max_slots, 64u * b->mask_words);
+      return TBC_ERR_UNSUPPORTED;
+    }
+    st = layout_histories(b, n_hist, in.op_off, in.n_events, b->count_form ? count_slots.data() : in.n_process, nullptr, nullptr, true, P.hist, P.bh, P.tot,
+                          b->count_form ? &P.count_hist : nullptr);
     if (st != TBC_OK) return st;
     P.max_ops = P.tot.max_ops;
     if (b->lanes && (longest >= kNarrowMaxOps || P.tot.boff_n >= (1ull << 32) || look_words(T, b->in_hist_cap, b->mask_words) >= (1ull << 32))) {
@@ -371,7 +443,7 @@ tbc_status tbc_batch_submit_input(tbc_batch* b, uint32_t slot, uint32_t n_hist) 
     b->stage_used[P.stage] = true;
     HIP_TRY(hipEventRecord(b->ev_copy[P.stage][0], sc));
     if (T) {
-      HIP_TRY(hipMemcpyAsync(stage.p, in.word, T * 4, hipMemcpyHostToDevice, sc));
+      HIP_TRY(hipMemcpyAsync(stage.p, b->count_form ? sl.planned : in.word, T * 4, hipMemcpyHostToDevice, sc));
       HIP_TRY(hipMemcpyAsync(stage.p + b->in_ops_cap, in.inv_pos, T * 4, hipMemcpyHostToDevice, sc));
       HIP_TRY(hipMemcpyAsync(stage.p + 2 * b->in_ops_cap, in.ret_pos, T * 4, hipMemcpyHostToDevice, sc));
     }

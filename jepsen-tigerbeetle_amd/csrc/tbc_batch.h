@@ -183,6 +183,10 @@ struct tbc_pending_input {
   std::vector<tbc::Hist> hist;
   std::vector<tbc::BeamHist> bh;
   tbc::LayoutTotals tot;
+  // a count-form batch: the input's classes of crashed calls, planned on the host when it was submitted (batch_stream.hip)
+  std::vector<tbc::CountHist> count_hist;
+  std::vector<uint64_t> cmem;         // ... their records and members, all histories back to back (what goes to BeamArgs.cmem)
+  uint64_t lst_total = 0;             // ... and how many entries its per-front lists hold (a count-form batch has no fallback for lists that do not fit)
 };
 
 struct tbc_batch {
@@ -320,7 +324,7 @@ struct tbc_batch {
   // ---- fresh inputs (batch_stream.hip; include/tbcheck.h "streaming"): the batch's arenas stay, new histories come in as WIRE columns
   // (12 B an op) through pinned host slots the caller fills in place and two device stages, so that the copy of input k + 1 runs
   // under the pass over input k; the run that consumes an input unpacks it into the op columns first (stream_unpack_kernel)
-  struct InputSlot { char* mem = nullptr; size_t bytes = 0; hipEvent_t copied = nullptr; bool busy = false; };
+  struct InputSlot { char* mem = nullptr; size_t bytes = 0; hipEvent_t copied = nullptr; bool busy = false; uint32_t* planned = nullptr; };   // planned: a count-form batch's copy of the wire words with the process field re-numbered (pinned; the caller's words stay as written)
   std::vector<InputSlot> in_slots;          // pinned host memory, one block per slot: [op_off][n_events][n_process][word][inv_pos][ret_pos]
   uint32_t in_hist_cap = 0;                 // histories / ops a slot (and a device stage) holds: the first create's, unless tbc_batch_map_input is told more
   uint64_t in_ops_cap = 0;
@@ -355,7 +359,13 @@ ColumnScan scan_columns(const tbc_ops& c, uint64_t T);
 // per-history descriptors (B->hist, B->bh) of `nh` histories and the arenas' running sums; list_caps (null: the lists' places are dealt on
 // the device or sized later) = entries of each history's per-front lists
 tbc_status layout_histories(tbc_batch* B, uint32_t nh, const uint64_t* op_off, const uint32_t* n_events, const uint32_t* n_slots, const int32_t* aux,
-                            const uint32_t* list_caps, bool lists_on_device, std::vector<Hist>& hist, std::vector<BeamHist>& bh, LayoutTotals& tot);
+                            const uint32_t* list_caps, bool lists_on_device, std::vector<Hist>& hist, std::vector<BeamHist>& bh, LayoutTotals& tot,
+                            const std::vector<CountHist>* count_hist = nullptr);          // (null: the batch's own)
+// count form of ONE history (CountHist) from its op columns; slot_col[] = the process column re-numbered.  false: the form does not apply
+bool build_count_form(const tbc_ops& c, uint64_t o0, uint64_t n, uint32_t n_process, bool cas_model, int32_t* slot_col, CountHist& out,
+                      std::vector<uint32_t>& rets, std::vector<int32_t>& slot_of, std::vector<uint8_t>& used);
+// entries of a history's per-front open-call lists, from the op columns (exact when the positions are event indices)
+uint64_t open_list_entries(const tbc_ops& c, uint64_t op_off, uint64_t n, uint32_t n_events, uint32_t n_slots, std::vector<uint32_t>& pre, bool branch_lists);
 tbc_status batch_create_impl(const tbc_batch_desc* desc, const tbc_model* model, const tbc_opts* opts, tbc_batch* B);
 
 // ---- batch_run.hip

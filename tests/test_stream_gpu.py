@@ -154,3 +154,42 @@ def test_crashed_calls_travel_when_the_batch_was_created_with_some(native, oracl
         b.run()
         b.reload(nxt)
         assert [key(r) for r in b.run().results()] == fresh(nxt, opts)
+
+
+@pytest.mark.parametrize("lanes", [64, 8])
+def test_a_count_form_batch_takes_fresh_inputs(native, oracle, lanes):
+    """Crashed calls with an effect under the default rules -- what the reference's nemesis makes (core.clj:106-125) -- are searched in the
+    COUNT FORM (classes of crashed calls, process slots re-used: planned on the host).  A batch created that way takes fresh inputs since
+    round 6: the planning runs over the wire columns when the input is submitted.  Three inputs of other sizes, crash rates and list
+    lengths (the third with twice the calls in flight: the list arena grows BEFORE the run -- a count-form batch has no sequential fallback) are answered
+    exactly as batches created from them: verdict, failing op, every counter; and the verdicts are the sequential oracle's."""
+    opts = core.make_opts(time_limit_ms=120000, algorithm=N.ALG_COMPETITION, want_witness=False, count_form=True, lanes_per_history=lanes)
+    first = hists_of(7000, 80, n_ops=900, info=0.03)
+    with core.Batch(first, gm(), opts) as b:
+        assert [key(r) for r in b.run().results()] == fresh(first, opts)
+        for rnd, (cnt, n_ops, info, busy) in enumerate([(80, 600, 0.05, 0.3), (61, 450, 0.02, 0.3), (80, 800, 0.04, 0.7)]):
+            nxt = hists_of(7100 + 300 * rnd, cnt, n_ops=n_ops, info=info, busy=busy, bad_every=4)
+            b.reload(nxt)
+            res = b.run().results()
+            assert [key(r) for r in res] == fresh(nxt, opts), rnd
+            assert sum(1 for r in res if r["valid"] == N.INVALID) >= cnt // 8 and all(r["valid"] != N.UNKNOWN for r in res)
+            assert b.input_info()["inputs_consumed"] == rnd + 1
+            for i in (0, 1, 4, cnt - 1):
+                ref = oracle.check(nxt[i].as_dict(), CAS, "window", max_steps=3_000_000, want_witness=False)
+                if ref["valid"] != -1:
+                    assert res[i]["valid"] == ref["valid"] and (ref["valid"] == 1 or res[i]["fail_op"] == ref["fail_op"]), (rnd, i)
+        assert b.input_info()["lists_regrown"] >= 1
+        # a slot submitted again as it is (mapped, not re-filled): the caller's words were not touched by the planning -- same answers
+        again = hists_of(7800, 30, n_ops=500, info=0.03)
+        b.fill_input(0, again)
+        b.submit_input(0, len(again))
+        exp = fresh(again, opts)
+        assert [key(r) for r in b.run().results()] == exp
+        b.map_input(0)
+        b.submit_input(0, len(again))
+        assert [key(r) for r in b.run().results()] == exp
+        # a crash-free input into a count-form batch: no classes; its own batch would not be a count-form one (another schedule, other
+        # counters), so verdict, failing op and the op before it are what must agree
+        calm = hists_of(7900, 40, n_ops=500, info=0.0)
+        b.reload(calm)
+        assert [key(r)[:3] for r in b.run().results()] == [k[:3] for k in fresh(calm, opts)]
