@@ -43,7 +43,7 @@ constexpr uint32_t kWordCounters = 256;      // the words-loaded statistic: a wa
                                              // atomics on ONE address queue up in one L2 channel; the host adds the counters up
 
 __global__ __launch_bounds__(256) void setfull_prefix_kernel(const uint32_t* add_invoke, const uint32_t* read_ok, uint32_t E, uint32_t R,
-                                                             uint32_t rows_per_chunk, uint32_t* P, uint32_t* pmax) {
+                                                             uint32_t rows_per_chunk, uint32_t chunks, uint32_t* P, uint32_t* pmax) {
   const uint32_t r = blockIdx.x * 256u + threadIdx.x;
   if (r >= R) return;
   const uint32_t t = read_ok[r];
@@ -51,6 +51,7 @@ __global__ __launch_bounds__(256) void setfull_prefix_kernel(const uint32_t* add
   while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (add_invoke[mid] < t) lo = mid + 1; else hi = mid; }
   P[r] = lo;
   atomicMax(&pmax[r / rows_per_chunk], lo);
+  atomicMin(&pmax[chunks + r / rows_per_chunk], lo);         // (the minima lie behind the maxima)
 }
 
 __device__ __forceinline__ uint32_t prefix_mask(uint32_t p, uint32_t w) {       // bits of word w below element number p
@@ -61,9 +62,9 @@ __device__ __forceinline__ uint32_t prefix_mask(uint32_t p, uint32_t w) {       
 // ones below top[r], zeros above (a coalesced stream: the matrix is written once, at HBM's write rate) -- and then flips the
 // listed exceptions in it.  No row ever exists on the host.
 __global__ __launch_bounds__(256) void setfull_rows_kernel(const uint32_t* __restrict__ top, const unsigned long long* __restrict__ exc_off,
-                                                           const uint32_t* __restrict__ exc, uint32_t R, uint32_t WPR, uint32_t* __restrict__ M) {
+                                                           const uint32_t* __restrict__ exc, uint32_t R, uint32_t WPR, uint32_t PITCH, uint32_t* __restrict__ M) {
   for (uint32_t r = blockIdx.x; r < R; r += gridDim.x) {
-    uint32_t* row = M + (uint64_t)r * WPR;
+    uint32_t* row = M + (uint64_t)r * PITCH;
     const uint32_t t = top[r];
     for (uint32_t w = threadIdx.x; w < WPR; w += 256u) row[w] = prefix_mask(t, w);
     __syncthreads();
@@ -78,21 +79,100 @@ __global__ __launch_bounds__(256) void setfull_rows_kernel(const uint32_t* __res
 
 // ---- pass 1: per (word column, chunk of rows) -- is any bit of the column present / absent in the chunk?  The streaming
 // pass.  VEC = 4: a lane takes FOUR consecutive word columns (16 B loads, a wavefront 1 KB of a row; rows of a multiple of four
-// words), VEC = 1: one column; four rows are requested while the four before them are used.  Nothing a load returns decides whether
-// the next is issued (a chunk is at most 2,048 rows: stopping at a saturated column saved nothing on set-full's matrices, where an
-// element is absent before its add and present after, and cost a round trip every eight rows); the chunk's row metadata in LDS,
-// no atomics.
-// (115 registers: four wavefronts a SIMD.  Asking for five -- all ~4,400 wavefronts above the diagonal resident at once -- spills 19 of them: 0.21 ms against 0.16)
+// words), VEC = 1: one column; eight rows are requested, then folded.  Nothing a load returns decides whether the next is issued (a
+// chunk is at most 2,048 rows: stopping at a saturated column saved nothing on set-full's matrices, where an element is absent before
+// its add and present after, and cost a round trip every eight rows); no atomics.  Three kinds of tile (256 VEC columns x a chunk):
+// below the diagonal (return), on it (the general path: the chunk's row metadata in LDS, a mask per row and word), above it (the lean
+// path: every column counts in every row).
+// Round 6 (profiles/r06_setfull_*, scripts/exp/strip_read.hip = this access pattern, bare: 6.1 TB/s a rectangle, 5.3 the triangle):
+// 0.16 -> 0.105 ms.  What it was NOT: bytes in flight (4, 8 or 16 rows a lane read alike), the row pitch (a power of two, padded: the
+// same), the per-row masks (the lean path alone: 3 %).  What it was: the summaries' scattered 4 B stores (43 us, below) and the XCDs
+// (column block j in blockIdx.x was XCD j: 7 %).
+// The summaries lie CHUNK-major ([chunk][word column], SP words a chunk, SP a multiple of four): this pass writes a thread's four
+// columns as one 16 B store, a wavefront 1 KB.  Rounds 2 - 5 kept them column-major for pass 2's sake (a column's chunks as one line)
+// and paid for it here without knowing: 4 B stores 1 KB apart, every one a masked write of its own into a line that sixteen
+// workgroups on eight XCDs write -- 43 us of this kernel's 150 (scripts/exp/strip_read.hip: the bare triangle 0.114 ms, with the
+// column-major stores 0.157, with these 0.117).  Pass 2 reads a column's chunks as 64 words of 64 lines now, and is given its
+// columns so that the workgroups of one XCD share those lines (setfull_resolve_kernel).
+template <int VEC>
+__device__ __forceinline__ void store_summary(uint32_t* __restrict__ any_p, uint32_t* __restrict__ any_a, uint32_t SP, uint32_t c, uint32_t w0,
+                                              const uint32_t (&pa)[VEC], const uint32_t (&aa)[VEC]) {
+  const uint64_t at = (uint64_t)c * SP + w0;
+  if constexpr (VEC == 4) {
+    *reinterpret_cast<uint4*>(any_p + at) = make_uint4(pa[0], pa[1], pa[2], pa[3]);
+    *reinterpret_cast<uint4*>(any_a + at) = make_uint4(aa[0], aa[1], aa[2], aa[3]);
+  } else {
+#pragma unroll
+    for (int v = 0; v < VEC; v++) { any_p[at + (uint32_t)v] = pa[v]; any_a[at + (uint32_t)v] = aa[v]; }
+  }
+}
+
 template <int VEC>
 __global__ __launch_bounds__(256) void setfull_any_kernel(const uint32_t* __restrict__ M, const uint32_t* __restrict__ P,
-                                                          const uint32_t* __restrict__ pmax, uint32_t E, uint32_t R, uint32_t WPR,
-                                                          uint32_t rows_per_chunk, uint32_t CHP, uint32_t* __restrict__ any_p,
+                                                          const uint32_t* __restrict__ pmax, uint32_t E, uint32_t R, uint32_t WPR, uint32_t PITCH,
+                                                          uint32_t rows_per_chunk, uint32_t SP, uint32_t* __restrict__ any_p,
                                                           uint32_t* __restrict__ any_a, unsigned long long* words_loaded) {
-  constexpr uint32_t U = 4u;                            // rows a set of registers holds (two sets: 4 .. 8 rows in flight, 16 B each at VEC = 4)
-  const uint32_t w0 = (blockIdx.x * 256u + threadIdx.x) * (uint32_t)VEC, c = blockIdx.y;
+  constexpr uint32_t U = 8u;                            // rows in flight per lane (16 B each at VEC = 4)
+  // grid = (chunks, column blocks), the CHUNK in x.  Workgroup b runs on XCD b % 8 (observed, MI355X_MICROARCH.md "Workgroup dispatch"),
+  // and the work is a triangle: column block j counts in the chunks above j / n of the rows only.  With the column block in x (rounds
+  // 3 - 5: eight of them for 262,144 elements, i.e. column block j WAS XCD j) XCD 0 streamed 256 chunks and XCD 7 32 -- the kernel
+  // lasted as long as XCD 0's 22 % of the matrix through one XCD's fabric port.  With the chunk in x every XCD gets every eighth
+  // chunk of every column block.
+  // The order the workgroups are handed out in (x fastest, then y): the LAST column block first, and in every column block the chunks
+  // from its diagonal on -- the tiles on the diagonal decide per row (the general path below: the longest workgroups) and start first,
+  // the tiles below the diagonal, which return at once, come last.
+  const uint32_t cb = gridDim.y - 1u - blockIdx.y;
+  const uint32_t c = (blockIdx.x + (uint32_t)((uint64_t)cb * gridDim.x / gridDim.y)) % gridDim.x;
+  const uint32_t w0 = (cb * 256u + threadIdx.x) * (uint32_t)VEC;
   uint32_t loaded = 0;
   __shared__ uint32_t s_P[kSetFullRows];
   const uint32_t r0 = min(c * rows_per_chunk, R), r1 = min(r0 + rows_per_chunk, R);     // (a trailing chunk may be empty)
+  // the whole workgroup lies below the diagonal: nothing to stage, nothing to read, nothing to write (which workgroups these are is
+  // fixed with the object -- P is -- and tbc_setfull_create zeroed the summaries)
+  if (pmax[c] <= 32u * (cb * 256u * (uint32_t)VEC)) return;
+  // A workgroup whose columns ALL count in EVERY row of its chunk (the chunk's least prefix reaches past its last column: four tiles in
+  // five of set-full's triangle) has nothing to decide per row: no row metadata, no masks, eight 16 B loads a lane and two instructions
+  // a word -- the fold of the general path below costs ~50 vector instructions a row and wavefront, 43 us of a SIMD's time per launch
+  // beside 88 us of streaming (scripts/exp/strip_read.hip: this very access pattern, bare, reads at 6.1 TB/s, 6.7 non-temporal).
+  const uint32_t tile_hi = 32u * ((cb + 1u) * 256u * (uint32_t)VEC);
+  if (pmax[gridDim.x + c] >= (tile_hi < E ? tile_hi : E)) {
+    if (w0 < WPR) {
+      typedef uint32_t wvec __attribute__((ext_vector_type(VEC)));
+      uint32_t po[VEC], na[VEC];
+#pragma unroll
+      for (int v = 0; v < VEC; v++) { po[v] = 0u; na[v] = 0xFFFFFFFFu; }
+      const uint32_t* src = M + (uint64_t)r0 * PITCH + w0;
+      uint32_t r = r0;
+      constexpr uint32_t UL = 8u;
+      for (; r + UL <= r1; r += UL, src += (uint64_t)UL * PITCH) {
+        wvec x[UL];
+#pragma unroll
+        for (uint32_t q = 0; q < UL; q++) x[q] = __builtin_nontemporal_load(reinterpret_cast<const wvec*>(src + (uint64_t)q * PITCH));
+#pragma unroll
+        for (uint32_t q = 0; q < UL; q++)
+#pragma unroll
+          for (int v = 0; v < VEC; v++) { po[v] |= x[q][v]; na[v] &= x[q][v]; }
+      }
+      for (; r < r1; r++, src += PITCH) {
+        const wvec x = __builtin_nontemporal_load(reinterpret_cast<const wvec*>(src));
+#pragma unroll
+        for (int v = 0; v < VEC; v++) { po[v] |= x[v]; na[v] &= x[v]; }
+      }
+      uint32_t pa[VEC], aa[VEC];
+#pragma unroll
+      for (int v = 0; v < VEC; v++) {
+        const uint32_t lo = 32u * (w0 + (uint32_t)v);
+        const uint32_t full = lo >= E ? 0u : (E - lo >= 32u ? 0xFFFFFFFFu : (1u << (E - lo)) - 1u);
+        pa[v] = po[v] & full; aa[v] = ~na[v] & full;
+        loaded += full ? r1 - r0 : 0u;
+      }
+      store_summary<VEC>(any_p, any_a, SP, c, w0, pa, aa);
+    }
+    unsigned long long tot = loaded;
+    for (int d = 32; d >= 1; d >>= 1) tot += __shfl_xor(tot, d);
+    if ((threadIdx.x & 63u) == 0 && tot) atomicAdd(words_loaded + 16u * ((blockIdx.x + blockIdx.y * gridDim.x) % kWordCounters), tot);
+    return;
+  }
   for (uint32_t i = threadIdx.x; i < r1 - r0; i += 256u) s_P[i] = P[r0 + i];
   __syncthreads();
   if (w0 < WPR) {
@@ -118,7 +198,7 @@ __global__ __launch_bounds__(256) void setfull_any_kernel(const uint32_t* __rest
           // for the whole grid; the fold masks them out, vm = 0).  A branch around every load hides from the compiler how many loads
           // are outstanding, and it then waits for ALL of them (s_waitcnt vmcnt(0)) before the fold: the rows requested ahead would
           // be waited for at once, i.e. nothing would be ahead
-          const uint32_t* src = M + (need ? (uint64_t)r * WPR : 0ull) + w0;
+          const uint32_t* src = M + (need ? (uint64_t)r * PITCH : 0ull) + w0;
           if constexpr (VEC == 4) {
             const uint4 x = *reinterpret_cast<const uint4*>(src);
             wd[q][0] = x.x; wd[q][1] = x.y; wd[q][2] = x.z; wd[q][3] = x.w;
@@ -138,30 +218,17 @@ __global__ __launch_bounds__(256) void setfull_any_kernel(const uint32_t* __rest
           }
         }
       };
-      // two sets of registers: the next U rows are on their way while these are folded
-      uint32_t wa[U][VEC], pra[U], wb[U][VEC], prb[U];
+      // U rows requested, then folded (scripts/exp/strip_read.hip: at this occupancy a second set of registers on its way while the first
+      // is folded reads no faster than this, and a workgroup's chain of waits is half as long with eight rows a wait as with four)
+      uint32_t wa[U][VEC], pra[U];
       uint32_t hi = r1;
-      if (hi > r0) {
+      while (hi > r0) {
         fetch(hi, wa, pra);
         hi = hi - r0 >= U ? hi - U : r0;
-        for (;;) {          // (a fold right behind ITS fetch on one straight path: the compiler then knows that U younger loads may stay out)
-          if (hi <= r0) { fold(wa, pra); break; }
-          fetch(hi, wb, prb); hi = hi - r0 >= U ? hi - U : r0;
-          fold(wa, pra);
-          if (hi <= r0) { fold(wb, prb); break; }
-          fetch(hi, wa, pra); hi = hi - r0 >= U ? hi - U : r0;
-          fold(wb, prb);
-        }
+        fold(wa, pra);
       }
     }
-    // the summaries lie COLUMN-major ([word column][chunk], CHP chunks a column): pass 2 reads a column's chunks, 64 at a time, as one
-    // 256 B line -- chunk-major (what this pass would write coalesced) cost it 64 sectors for 64 words, half of its traffic; here
-    // it is 4 B stores 4 * CHP apart, 16 MB of them against the 550 MB this pass reads
-#pragma unroll
-    for (int v = 0; v < VEC; v++) {        // (VEC = 4: WPR is a multiple of four, all four columns exist)
-      any_p[(uint64_t)(w0 + (uint32_t)v) * CHP + c] = pa[v];
-      any_a[(uint64_t)(w0 + (uint32_t)v) * CHP + c] = aa[v];
-    }
+    store_summary<VEC>(any_p, any_a, SP, c, w0, pa, aa);
   }
   unsigned long long tot = loaded;
   for (int d = 32; d >= 1; d >>= 1) tot += __shfl_xor(tot, d);
@@ -182,7 +249,7 @@ __device__ __forceinline__ uint32_t wave_min_u32_all(uint32_t v) {
 // walk chunk c from its latest row down, lane = row: for every bit of `want` find the latest row where the bit is present
 // (present = true) or absent; lane b keeps read_invoke + 1 of bit b's row in `res`; returns the bits found
 __device__ __forceinline__ uint32_t setfull_last_in_chunk(const uint32_t* __restrict__ M, const uint32_t* __restrict__ P,
-                                                          const uint32_t* __restrict__ read_invoke, uint32_t WPR, uint32_t w, uint32_t full,
+                                                          const uint32_t* __restrict__ read_invoke, uint32_t PITCH, uint32_t w, uint32_t full,
                                                           uint32_t r0, uint32_t r1, uint32_t want, bool present, uint32_t& res, uint32_t lane,
                                                           uint32_t& loaded) {
   uint32_t found = 0;
@@ -190,7 +257,7 @@ __device__ __forceinline__ uint32_t setfull_last_in_chunk(const uint32_t* __rest
     const uint32_t base = hi - r0 > 64u ? hi - 64u : r0;       // rows [base, hi), lane l = row base + l
     const uint32_t r = base + lane;
     const bool in = r < hi;
-    const uint32_t word = in ? M[(uint64_t)r * WPR + w] : 0u;          // (not waiting for P[r] to say whether the row counts: one round trip a step, not two)
+    const uint32_t word = in ? M[(uint64_t)r * PITCH + w] : 0u;          // (not waiting for P[r] to say whether the row counts: one round trip a step, not two)
     const uint32_t valid = in ? prefix_mask(P[r], w) & full : 0u;
     const uint32_t inv1 = in ? read_invoke[r] + 1u : 0u;
     loaded += valid ? 1u : 0u;
@@ -214,11 +281,15 @@ __device__ __forceinline__ uint32_t setfull_last_in_chunk(const uint32_t* __rest
 __global__ __launch_bounds__(256) void setfull_resolve_kernel(const uint32_t* __restrict__ M, const uint32_t* __restrict__ P,
                                                               const uint32_t* __restrict__ read_invoke, const uint32_t* __restrict__ read_ok,
                                                               const uint32_t* __restrict__ any_p, const uint32_t* __restrict__ any_a,
-                                                              uint32_t E, uint32_t R, uint32_t WPR, uint32_t rows_per_chunk, uint32_t chunks, uint32_t CHP,
+                                                              uint32_t E, uint32_t R, uint32_t WPR, uint32_t PITCH, uint32_t rows_per_chunk, uint32_t chunks, uint32_t SP,
                                                               const uint32_t* __restrict__ add_ok, uint32_t* lp, uint32_t* la, uint32_t* known,
                                                               unsigned long long* words_loaded) {
   const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t w = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
+  // workgroup b runs on XCD b % 8 (observed): the eight XCDs take eight contiguous ranges of the columns, so that the lines four
+  // neighbouring workgroups read 16 B each of -- the summaries' and the matrix rows' -- are fetched into ONE L2 instead of eight
+  const uint32_t nb = gridDim.x;
+  const uint32_t bb = nb % 8u == 0u ? (blockIdx.x % 8u) * (nb / 8u) + blockIdx.x / 8u : blockIdx.x;
+  const uint32_t w = __builtin_amdgcn_readfirstlane(bb * 4u + (threadIdx.x >> 6));
   uint32_t loaded = 0;
   if (w < WPR) {
     const uint32_t full = E - 32u * w >= 32u ? 0xFFFFFFFFu : (1u << (E - 32u * w)) - 1u;
@@ -232,8 +303,8 @@ __global__ __launch_bounds__(256) void setfull_resolve_kernel(const uint32_t* __
     for (uint32_t k = 0; k < 4u; k++) {
       const uint32_t cl = lane + 64u * k;
       const bool in = pre && cl < chunks;
-      sp[k] = in ? any_p[(uint64_t)w * CHP + cl] : 0u;
-      sa[k] = in ? any_a[(uint64_t)w * CHP + cl] : 0u;
+      sp[k] = in ? any_p[(uint64_t)cl * SP + w] : 0u;
+      sa[k] = in ? any_a[(uint64_t)cl * SP + w] : 0u;
     }
     const auto pick = [](const uint32_t (&r)[4], uint32_t gi) -> uint32_t { return gi == 0u ? r[0] : gi == 1u ? r[1] : gi == 2u ? r[2] : r[3]; };
     // last present / last absent: the latest chunk that has the bit decides; inside it, the latest row
@@ -245,14 +316,14 @@ __global__ __launch_bounds__(256) void setfull_resolve_kernel(const uint32_t* __
       uint32_t need = full;
       for (uint32_t gi = G; gi-- > 0 && need;) {
         const uint32_t cl = lane + 64u * gi;
-        const uint32_t mine = pre ? pick(pass == 0 ? sp : sa, gi) : (cl < chunks ? any[(uint64_t)w * CHP + cl] : 0u);
+        const uint32_t mine = pre ? pick(pass == 0 ? sp : sa, gi) : (cl < chunks ? any[(uint64_t)cl * SP + w] : 0u);
         uint64_t cand = __ballot((mine & need) != 0u);
         while (cand && need) {
           const uint32_t l = 63u - (uint32_t)__builtin_clzll(cand);
           const uint32_t c = l + 64u * gi;
           const uint32_t mc = (uint32_t)__builtin_amdgcn_readlane((int)mine, l) & need;
           const uint32_t r0 = min(c * rows_per_chunk, R), r1 = min(r0 + rows_per_chunk, R);
-          (void)setfull_last_in_chunk(M, P, read_invoke, WPR, w, full, r0, r1, mc, pass == 0, res, lane, loaded);
+          (void)setfull_last_in_chunk(M, P, read_invoke, PITCH, w, full, r0, r1, mc, pass == 0, res, lane, loaded);
           need &= ~mc;
           cand = __ballot((mine & need) != 0u) & ((1ull << l) - 1ull);
         }
@@ -265,7 +336,7 @@ __global__ __launch_bounds__(256) void setfull_resolve_kernel(const uint32_t* __
     uint32_t ever = 0, first_c = chunks;
     for (uint32_t gi = 0; gi < G; gi++) {
       const uint32_t cl = lane + 64u * gi;
-      uint32_t o = (pre ? pick(sp, gi) : (cl < chunks ? any_p[(uint64_t)w * CHP + cl] : 0u)) & full;
+      uint32_t o = (pre ? pick(sp, gi) : (cl < chunks ? any_p[(uint64_t)cl * SP + w] : 0u)) & full;
       const uint64_t bl = __ballot(o != 0u);
       if (bl && first_c == chunks) first_c = (uint32_t)__builtin_ctzll(bl) + 64u * gi;
 #pragma unroll
@@ -281,7 +352,7 @@ __global__ __launch_bounds__(256) void setfull_resolve_kernel(const uint32_t* __
         const uint32_t inv = in ? read_invoke[r] : 0xFFFFFFFFu;
         const uint32_t inv_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)inv);
         if (seen == ever && inv_first > until) break;
-        const uint32_t word = in ? M[(uint64_t)r * WPR + w] : 0u;
+        const uint32_t word = in ? M[(uint64_t)r * PITCH + w] : 0u;
         const uint32_t valid = in ? prefix_mask(P[r], w) & full : 0u;
         const uint32_t ok = in ? read_ok[r] : 0xFFFFFFFFu;
         loaded += valid ? 1u : 0u;
@@ -333,7 +404,7 @@ __global__ __launch_bounds__(256) void setfull_finish_kernel(uint32_t* lp1, uint
 
 struct tbc_setfull {
   int device = 0;
-  uint32_t E = 0, R = 0, WPR = 0, chunks = 1, rows_per_chunk = 1, chp = 64;      // chp: chunks rounded up to 64 (a column of the summaries)
+  uint32_t E = 0, R = 0, WPR = 0, PITCH = 0, chunks = 1, rows_per_chunk = 1, chp = 4;       // chp: words per chunk of the summaries (words_per_row rounded up to four)
   uint32_t *d_add_invoke = nullptr, *d_add_ok = nullptr, *d_read_invoke = nullptr, *d_read_ok = nullptr, *d_M = nullptr;
   uint32_t *d_P = nullptr, *d_pmax = nullptr, *d_lp = nullptr, *d_la = nullptr, *d_known = nullptr, *d_anyp = nullptr, *d_anya = nullptr;
   unsigned long long* d_words = nullptr;
@@ -388,21 +459,24 @@ static tbc_status setfull_create_impl(const tbc_setfull_in* in, tbc_setfull* S, 
   for (uint32_t e = 1; e < S->E; e++) if (in->add_invoke[e] <= in->add_invoke[e - 1]) { set_error("tbc_setfull: add_invoke must be strictly ascending (element %u)", e); return TBC_ERR_INVALID_ARG; }
   for (uint32_t r = 1; r < S->R; r++) if (in->read_invoke[r] <= in->read_invoke[r - 1]) { set_error("tbc_setfull: read_invoke must be strictly ascending (read %u)", r); return TBC_ERR_INVALID_ARG; }
   SF_TRY(hipSetDevice(S->device));
+  S->PITCH = std::max(1u, S->WPR);
+  // (PITCH: the words between two rows in device memory.  A pitch padded off the power of two was measured -- 16 .. 1,088 words: the
+  // same scan within 3 % either way, profiles/r06_setfull_pad_scan.txt -- so it is words_per_row)
   // enough chunks to fill the GPU with wavefronts that each stream a good stretch of rows
   const uint32_t col_blocks = (S->WPR + 255) / 256;
   uint32_t chunks = std::max(1u, std::min(256u, 8192u / std::max(1u, col_blocks)));     // short chunks: what pass 2 walks again is one chunk
   while (chunks > 1 && S->R / chunks < 64) chunks >>= 1;
   while ((S->R + chunks - 1) / chunks > kSetFullRows) chunks <<= 1;
   S->chunks = chunks; S->rows_per_chunk = std::max(1u, (S->R + chunks - 1) / chunks);
-  const size_t e4 = (size_t)std::max(1u, S->E) * 4, r4 = (size_t)std::max(1u, S->R) * 4, m4 = std::max<size_t>(4, (size_t)S->R * S->WPR * 4);
+  const size_t e4 = (size_t)std::max(1u, S->E) * 4, r4 = (size_t)std::max(1u, S->R) * 4, m4 = std::max<size_t>(4, (size_t)S->R * S->PITCH * 4);
   SF_TRY(hipMalloc((void**)&S->d_add_invoke, e4)); SF_TRY(hipMalloc((void**)&S->d_add_ok, e4));
   SF_TRY(hipMalloc((void**)&S->d_read_invoke, r4)); SF_TRY(hipMalloc((void**)&S->d_read_ok, r4));
-  SF_TRY(hipMalloc((void**)&S->d_M, m4)); SF_TRY(hipMalloc((void**)&S->d_P, r4)); SF_TRY(hipMalloc((void**)&S->d_pmax, (size_t)S->chunks * 4));
+  SF_TRY(hipMalloc((void**)&S->d_M, m4)); SF_TRY(hipMalloc((void**)&S->d_P, r4)); SF_TRY(hipMalloc((void**)&S->d_pmax, (size_t)S->chunks * 8));      // the chunks' greatest prefixes, then their least
   const size_t ew = (size_t)std::max(1u, S->WPR) * 32 * 4;       // per-element outputs padded to whole words
   SF_TRY(hipMalloc((void**)&S->d_lp, ew)); SF_TRY(hipMalloc((void**)&S->d_la, ew)); SF_TRY(hipMalloc((void**)&S->d_known, ew));
   SF_TRY(hipMalloc((void**)&S->d_words, (size_t)kWordCounters * 128));
-  S->chp = (S->chunks + 63u) / 64u * 64u;
-  const size_t any4 = (size_t)S->chp * std::max(1u, S->WPR) * 4;
+  S->chp = (std::max(1u, S->WPR) + 3u) / 4u * 4u;
+  const size_t any4 = (size_t)S->chp * S->chunks * 4;
   SF_TRY(hipMalloc((void**)&S->d_anyp, any4)); SF_TRY(hipMalloc((void**)&S->d_anya, any4));
   SF_TRY(hipStreamCreateWithFlags(&S->stream, hipStreamNonBlocking));
   SF_TRY(hipEventCreate(&S->ev0)); SF_TRY(hipEventCreate(&S->ev1));
@@ -413,7 +487,7 @@ static tbc_status setfull_create_impl(const tbc_setfull_in* in, tbc_setfull* S, 
   if (S->R) {
     SF_TRY(hipMemcpyAsync(S->d_read_invoke, in->read_invoke, (size_t)S->R * 4, hipMemcpyHostToDevice, S->stream));
     SF_TRY(hipMemcpyAsync(S->d_read_ok, in->read_ok, (size_t)S->R * 4, hipMemcpyHostToDevice, S->stream));
-    if (!rows) SF_TRY(hipMemcpyAsync(S->d_M, in->present, (size_t)S->R * S->WPR * 4, hipMemcpyHostToDevice, S->stream));
+    if (!rows && S->WPR) SF_TRY(hipMemcpy2DAsync(S->d_M, (size_t)S->PITCH * 4, in->present, (size_t)S->WPR * 4, (size_t)S->WPR * 4, S->R, hipMemcpyHostToDevice, S->stream));
   }
   if (rows && S->R) {
     const uint64_t ne = rows->exc_off[S->R];
@@ -426,7 +500,7 @@ static tbc_status setfull_create_impl(const tbc_setfull_in* in, tbc_setfull* S, 
     if (e == hipSuccess) e = hipMemcpyAsync(d_off, rows->exc_off, ((size_t)S->R + 1) * 8, hipMemcpyHostToDevice, S->stream);
     if (e == hipSuccess && ne) e = hipMemcpyAsync(d_exc, rows->exc, ne * 4, hipMemcpyHostToDevice, S->stream);
     if (e == hipSuccess) {
-      hipLaunchKernelGGL(setfull_rows_kernel, dim3(std::min<uint32_t>(S->R, 16384u)), dim3(256), 0, S->stream, d_top, d_off, d_exc, S->R, std::max(1u, S->WPR), S->d_M);
+      hipLaunchKernelGGL(setfull_rows_kernel, dim3(std::min<uint32_t>(S->R, 16384u)), dim3(256), 0, S->stream, d_top, d_off, d_exc, S->R, std::max(1u, S->WPR), S->PITCH, S->d_M);
       e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(S->stream);
@@ -437,10 +511,11 @@ static tbc_status setfull_create_impl(const tbc_setfull_in* in, tbc_setfull* S, 
   }
   // p[r] (how many elements had been invoked when read r completed) and the chunks' maxima depend on the inputs only
   SF_TRY(hipMemsetAsync(S->d_pmax, 0, (size_t)S->chunks * 4, S->stream));
-  SF_TRY(hipMemsetAsync(S->d_anyp, 0, any4, S->stream)); SF_TRY(hipMemsetAsync(S->d_anya, 0, any4, S->stream));      // (the padding of a column is never written)
+  SF_TRY(hipMemsetAsync(S->d_pmax + S->chunks, 0xFF, (size_t)S->chunks * 4, S->stream));
+  SF_TRY(hipMemsetAsync(S->d_anyp, 0, any4, S->stream)); SF_TRY(hipMemsetAsync(S->d_anya, 0, any4, S->stream));      // (the workgroups below the diagonal never write theirs)
   if (S->R && S->E)
     hipLaunchKernelGGL(setfull_prefix_kernel, dim3((S->R + 255) / 256), dim3(256), 0, S->stream, S->d_add_invoke, S->d_read_ok, S->E, S->R,
-                       S->rows_per_chunk, S->d_P, S->d_pmax);
+                       S->rows_per_chunk, S->chunks, S->d_P, S->d_pmax);
   SF_TRY(hipGetLastError());
   SF_TRY(hipStreamSynchronize(S->stream));
   return TBC_OK;
@@ -473,13 +548,13 @@ tbc_status tbc_setfull_run(tbc_setfull* S, tbc_setfull_out* out) {
   SF_TRY(hipEventRecord(S->ev0, s));
   if (S->R && S->E) {
     if (S->WPR % 4u == 0u)      // (hipMalloc'ed arrays, rows of a multiple of four words: every 16 B load and store is aligned)
-      hipLaunchKernelGGL(setfull_any_kernel<4>, dim3((S->WPR / 4u + 255) / 256, S->chunks), dim3(256), 0, s, S->d_M, S->d_P, S->d_pmax, S->E, S->R, S->WPR,
+      hipLaunchKernelGGL(setfull_any_kernel<4>, dim3(S->chunks, (S->WPR / 4u + 255) / 256), dim3(256), 0, s, S->d_M, S->d_P, S->d_pmax, S->E, S->R, S->WPR, S->PITCH,
                          S->rows_per_chunk, S->chp, S->d_anyp, S->d_anya, S->d_words);
     else
-      hipLaunchKernelGGL(setfull_any_kernel<1>, dim3((S->WPR + 255) / 256, S->chunks), dim3(256), 0, s, S->d_M, S->d_P, S->d_pmax, S->E, S->R, S->WPR,
+      hipLaunchKernelGGL(setfull_any_kernel<1>, dim3(S->chunks, (S->WPR + 255) / 256), dim3(256), 0, s, S->d_M, S->d_P, S->d_pmax, S->E, S->R, S->WPR, S->PITCH,
                          S->rows_per_chunk, S->chp, S->d_anyp, S->d_anya, S->d_words);
     hipLaunchKernelGGL(setfull_resolve_kernel, dim3((S->WPR + 3) / 4), dim3(256), 0, s, S->d_M, S->d_P, S->d_read_invoke, S->d_read_ok, S->d_anyp,
-                       S->d_anya, S->E, S->R, S->WPR, S->rows_per_chunk, S->chunks, S->chp, S->d_add_ok, S->d_lp, S->d_la, S->d_known, S->d_words);
+                       S->d_anya, S->E, S->R, S->WPR, S->PITCH, S->rows_per_chunk, S->chunks, S->chp, S->d_add_ok, S->d_lp, S->d_la, S->d_known, S->d_words);
   } else if (S->E) {        // no read at all: nothing was seen, known = the add's ack
     hipLaunchKernelGGL(setfull_finish_kernel, dim3((S->E + 255) / 256), dim3(256), 0, s, S->d_lp, S->d_la, S->d_known, S->d_add_ok, S->E);
   }
