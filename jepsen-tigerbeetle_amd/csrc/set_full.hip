@@ -289,22 +289,31 @@ __global__ __launch_bounds__(256) void setfull_resolve_kernel(const uint32_t* __
   // neighbouring workgroups read 16 B each of -- the summaries' and the matrix rows' -- are fetched into ONE L2 instead of eight
   const uint32_t nb = gridDim.x;
   const uint32_t bb = nb % 8u == 0u ? (blockIdx.x % 8u) * (nb / 8u) + blockIdx.x / 8u : blockIdx.x;
-  const uint32_t w = __builtin_amdgcn_readfirstlane(bb * 4u + (threadIdx.x >> 6));
+  const uint32_t wv_ = threadIdx.x >> 6;
+  const uint32_t w = __builtin_amdgcn_readfirstlane(bb * 4u + wv_);
   uint32_t loaded = 0;
+  // the chunk summaries, 64 chunks (one per lane) at a time; any number of chunks
+  const uint32_t G = (chunks + 63u) / 64u;
+  // up to 256 chunks (what tbc_setfull_create makes of up to 524,288 reads): the summaries of the workgroup's FOUR columns are fetched
+  // once, thread t the 16 B of chunk t (chunk-major: its four columns lie side by side), and handed to the four wavefronts through LDS
+  // -- a wavefront reading its own column's 256 words asked for 8 x 64 lines, half of all the lines this kernel asks its L1 for
+  const bool pre = G <= 4u;
+  __shared__ uint4 s_sp[256], s_sa[256];
+  if (pre) {
+    const uint32_t cl = threadIdx.x;
+    const bool in = cl < chunks && bb * 4u < WPR;                     // (SP is a multiple of four: the 16 B lie inside the chunk's row)
+    s_sp[cl] = in ? *reinterpret_cast<const uint4*>(any_p + (uint64_t)cl * SP + bb * 4u) : make_uint4(0u, 0u, 0u, 0u);
+    s_sa[cl] = in ? *reinterpret_cast<const uint4*>(any_a + (uint64_t)cl * SP + bb * 4u) : make_uint4(0u, 0u, 0u, 0u);
+    __syncthreads();
+  }
   if (w < WPR) {
     const uint32_t full = E - 32u * w >= 32u ? 0xFFFFFFFFu : (1u << (E - 32u * w)) - 1u;
-    // the chunk summaries, 64 chunks (one per lane) at a time; any number of chunks
-    const uint32_t G = (chunks + 63u) / 64u;
-    // up to 256 chunks (what tbc_setfull_create makes of up to 524,288 reads): the column's summaries are fetched ONCE, all eight
-    // loads in flight together, instead of group after group in each of the three passes below
-    const bool pre = G <= 4u;
     uint32_t sp[4], sa[4];
 #pragma unroll
     for (uint32_t k = 0; k < 4u; k++) {
       const uint32_t cl = lane + 64u * k;
-      const bool in = pre && cl < chunks;
-      sp[k] = in ? any_p[(uint64_t)cl * SP + w] : 0u;
-      sa[k] = in ? any_a[(uint64_t)cl * SP + w] : 0u;
+      sp[k] = pre ? reinterpret_cast<const uint32_t*>(&s_sp[cl])[wv_] : 0u;
+      sa[k] = pre ? reinterpret_cast<const uint32_t*>(&s_sa[cl])[wv_] : 0u;
     }
     const auto pick = [](const uint32_t (&r)[4], uint32_t gi) -> uint32_t { return gi == 0u ? r[0] : gi == 1u ? r[1] : gi == 2u ? r[2] : r[3]; };
     // last present / last absent: the latest chunk that has the bit decides; inside it, the latest row
