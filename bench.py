@@ -172,7 +172,7 @@ def leg_workload(args, local_rank, which):
     # A history at 32 in flight can need > 10^6 configs (the tail is heavy): 2^21-entry visited sets with their stacks = 67 MB
     # each, 2,048 of them (137 GB) a batch -- a quarter of the GPU's wavefront slots; smaller first sets cost retries that take
     # longer than the whole step (measured: 4,096 histories at 2^20 entries, 134 s of retries).
-    def second(busy, B2, vpo, seed0, cpu_n, cpu_cap, warm, info=0.0):
+    def second(busy, B2, vpo, seed0, cpu_n, cpu_cap, warm, info=0.0, in_flight=1):
         h2 = synth.register_ops_many(range(seed0, seed0 + B2), n_ops=args.ops, n_procs=args.procs, busy=busy, info=info)
         o2 = core.make_opts(device=local_rank, time_limit_ms=600000, want_witness=False, algorithm=N.ALG_COMPETITION,
                             search_width=args.width, visited_per_op=vpo, lanes_per_history=int(os.environ.get("TBC_BENCH_LEG_LANES", "0")))
@@ -195,6 +195,35 @@ def leg_workload(args, local_rank, which):
                           "valid": int((v3 == N.VALID).sum()), "unknown": int((v3 == N.UNKNOWN).sum()),
                           "what": "tbc_batch_reload of a never-seen batch (wire encoding, the count form's planning on the host, the copy queued) + the run that consumes it, one after the other on one host thread"}
                 del h3
+        two = None
+        if in_flight > 1:
+            # the same workload with TWO batch objects in flight, each on its own host thread, as the headline's: one batch's race of list
+            # orders (a few hundred wavefronts for as long as its hardest history takes) runs beside the other batch's first pass.  `value`
+            # above stays one batch at a time (what rounds 3 - 5 reported); this is what a caller that keeps the device fed gets
+            import threading
+            sets = [h2] + [synth.register_ops_many(range(seed0 + k * B2, seed0 + (k + 1) * B2), n_ops=args.ops, n_procs=args.procs, busy=busy, info=info) for k in range(1, in_flight)]
+            bb = [core.Batch(h, model, o2) for h in sets]
+            try:
+                for b in bb:
+                    b.run()
+                steps2 = 3
+                def loop(b):
+                    for _ in range(steps2):
+                        b.run()
+                tt = time.perf_counter()
+                th = [threading.Thread(target=loop, args=(b,)) for b in bb]
+                for x in th:
+                    x.start()
+                for x in th:
+                    x.join()
+                tt = time.perf_counter() - tt
+                vv2 = [b.verdicts() for b in bb]
+                assert np.array_equal(vv2[0], v2), "the same batch, another verdict"
+                two = {"value": round(in_flight * steps2 * B2 / tt, 2), "unit": "histories/s", "batches_in_flight": in_flight, "steps_each": steps2,
+                       "ms_per_step": round(tt / (in_flight * steps2) * 1e3, 3), "unknown": sum(int((v == N.UNKNOWN).sum()) for v in vv2)}
+            finally:
+                for b in bb:
+                    b.close()
         alg2 = 16 * (c2["probes"] - c2["visited"]) + 32 * c2["visited"]
         k2 = (tm2["search"] + tm2["retries"]) / 1e6
         out = {"workload": workload_name(args.ops, args.procs, busy, info), "histories_per_gpu": B2, "search_width": width2, "lanes_per_history": lanes2, "list_order": order2,
@@ -209,6 +238,8 @@ def leg_workload(args, local_rank, which):
                "device_ms": {k: round(x / 1e6, 3) for k, x in tm2.items()}}
         if fresh2 is not None:
             out["fresh_input"] = fresh2
+        if two is not None:
+            out["two_in_flight"] = two
         if not args.no_cpu and info:
             # crashed calls: the library's count form; the CPU runs the same passes (oracle/wgl_count.c) on a thread pool
             from concurrent.futures import ThreadPoolExecutor
@@ -241,7 +272,7 @@ def leg_workload(args, local_rank, which):
     if which == "workload_2":
         return second(args.busy2, args.batch2, 256, 10_000_000, 64, 60_000_000, False)      # (a step is ~25 s: one run, no warm-up)
     if which == "workload_3":
-        return second(args.busy3, args.batch3, 32, 20_000_000, 128, 60_000_000, True)
+        return second(args.busy3, args.batch3, 32, 20_000_000, 128, 60_000_000, True, in_flight=2)
     # the regime the reference produces (a nemesis makes clients time out: :info): the headline workload with 1 % of the
     # calls crashed, a batch of them -- the count form, a wavefront per history
     assert which == "workload_crashed"
@@ -367,6 +398,8 @@ def compact_line(line):
                 "traffic": (d.get("roofline") or {}).get("traffic"), "kernel_ms": (d.get("roofline") or {}).get("kernel_ms"), "cpu": (d.get("cpu_baseline") or {}).get("value")}
             if isinstance(d.get("fresh_input"), dict):
                 e[w]["fresh"] = d["fresh_input"].get("histories_per_s")
+            if isinstance(d.get("two_in_flight"), dict):
+                e[w]["two_in_flight"] = d["two_in_flight"].get("value")
     d = ex.get("set_full")
     if isinstance(d, dict):
         e["set_full"] = {"error": str(d["error"])[:100]} if "error" in d else {"scan_ms": d.get("scan_ms"), "end_to_end_ms": d.get("end_to_end_ms"),
