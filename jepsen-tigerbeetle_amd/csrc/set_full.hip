@@ -417,12 +417,12 @@ struct tbc_setfull {
   uint32_t *d_add_invoke = nullptr, *d_add_ok = nullptr, *d_read_invoke = nullptr, *d_read_ok = nullptr, *d_M = nullptr;
   uint32_t *d_P = nullptr, *d_pmax = nullptr, *d_lp = nullptr, *d_la = nullptr, *d_known = nullptr, *d_anyp = nullptr, *d_anya = nullptr;
   unsigned long long* d_words = nullptr;
+  void* arena = nullptr;            // ONE allocation holds every array above (and create_rows' compact reads): one hipMalloc, one hipFree
   unsigned long long h_words[kWordCounters * 16] = {};
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   ~tbc_setfull() {
-    for (void* p : {(void*)d_add_invoke, (void*)d_add_ok, (void*)d_read_invoke, (void*)d_read_ok, (void*)d_M, (void*)d_P, (void*)d_pmax,
-                    (void*)d_lp, (void*)d_la, (void*)d_known, (void*)d_anyp, (void*)d_anya, (void*)d_words}) if (p) (void)hipFree(p);
+    if (arena) (void)hipFree(arena);
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
     if (stream) (void)hipStreamDestroy(stream);
@@ -478,15 +478,25 @@ static tbc_status setfull_create_impl(const tbc_setfull_in* in, tbc_setfull* S, 
   while ((S->R + chunks - 1) / chunks > kSetFullRows) chunks <<= 1;
   S->chunks = chunks; S->rows_per_chunk = std::max(1u, (S->R + chunks - 1) / chunks);
   const size_t e4 = (size_t)std::max(1u, S->E) * 4, r4 = (size_t)std::max(1u, S->R) * 4, m4 = std::max<size_t>(4, (size_t)S->R * S->PITCH * 4);
-  SF_TRY(hipMalloc((void**)&S->d_add_invoke, e4)); SF_TRY(hipMalloc((void**)&S->d_add_ok, e4));
-  SF_TRY(hipMalloc((void**)&S->d_read_invoke, r4)); SF_TRY(hipMalloc((void**)&S->d_read_ok, r4));
-  SF_TRY(hipMalloc((void**)&S->d_M, m4)); SF_TRY(hipMalloc((void**)&S->d_P, r4)); SF_TRY(hipMalloc((void**)&S->d_pmax, (size_t)S->chunks * 8));      // the chunks' greatest prefixes, then their least
   const size_t ew = (size_t)std::max(1u, S->WPR) * 32 * 4;       // per-element outputs padded to whole words
-  SF_TRY(hipMalloc((void**)&S->d_lp, ew)); SF_TRY(hipMalloc((void**)&S->d_la, ew)); SF_TRY(hipMalloc((void**)&S->d_known, ew));
-  SF_TRY(hipMalloc((void**)&S->d_words, (size_t)kWordCounters * 128));
   S->chp = (std::max(1u, S->WPR) + 3u) / 4u * 4u;
   const size_t any4 = (size_t)S->chp * S->chunks * 4;
-  SF_TRY(hipMalloc((void**)&S->d_anyp, any4)); SF_TRY(hipMalloc((void**)&S->d_anya, any4));
+  // Everything in ONE allocation (round 6: fourteen hipMalloc + three more for the compact reads, and as many hipFree -- each of which
+  // waits for the device -- were most of a caller's 5 ms around a 0.16 ms scan; the reference checks one history per call site,
+  // set_full.clj:157, so create + run + destroy IS its time to verdict)
+  const uint64_t ne = (rows && S->R) ? rows->exc_off[S->R] : 0;
+  size_t cursor = 0;
+  const auto take = [&](size_t bytes) { const size_t at = cursor; cursor += (bytes + 255) & ~(size_t)255; return at; };
+  const size_t o_M = take(m4), o_ai = take(e4), o_ao = take(e4), o_ri = take(r4), o_ro = take(r4), o_P = take(r4), o_pm = take((size_t)S->chunks * 8),
+               o_lp = take(ew), o_la = take(ew), o_kn = take(ew), o_w = take((size_t)kWordCounters * 128), o_ap = take(any4), o_aa = take(any4),
+               o_top = take(rows ? r4 : 0), o_off = take(rows ? ((size_t)S->R + 1) * 8 : 0), o_exc = take(rows ? std::max<size_t>(4, ne * 4) : 0);
+  SF_TRY(hipMalloc(&S->arena, std::max<size_t>(cursor, 256)));
+  char* const A0 = static_cast<char*>(S->arena);
+  S->d_M = (uint32_t*)(A0 + o_M); S->d_add_invoke = (uint32_t*)(A0 + o_ai); S->d_add_ok = (uint32_t*)(A0 + o_ao);
+  S->d_read_invoke = (uint32_t*)(A0 + o_ri); S->d_read_ok = (uint32_t*)(A0 + o_ro); S->d_P = (uint32_t*)(A0 + o_P);
+  S->d_pmax = (uint32_t*)(A0 + o_pm);                              // the chunks' greatest prefixes, then their least
+  S->d_lp = (uint32_t*)(A0 + o_lp); S->d_la = (uint32_t*)(A0 + o_la); S->d_known = (uint32_t*)(A0 + o_kn);
+  S->d_words = (unsigned long long*)(A0 + o_w); S->d_anyp = (uint32_t*)(A0 + o_ap); S->d_anya = (uint32_t*)(A0 + o_aa);
   SF_TRY(hipStreamCreateWithFlags(&S->stream, hipStreamNonBlocking));
   SF_TRY(hipEventCreate(&S->ev0)); SF_TRY(hipEventCreate(&S->ev1));
   if (S->E) {
@@ -499,23 +509,15 @@ static tbc_status setfull_create_impl(const tbc_setfull_in* in, tbc_setfull* S, 
     if (!rows && S->WPR) SF_TRY(hipMemcpy2DAsync(S->d_M, (size_t)S->PITCH * 4, in->present, (size_t)S->WPR * 4, (size_t)S->WPR * 4, S->R, hipMemcpyHostToDevice, S->stream));
   }
   if (rows && S->R) {
-    const uint64_t ne = rows->exc_off[S->R];
-    uint32_t *d_top = nullptr, *d_exc = nullptr; unsigned long long* d_off = nullptr;
-    // (one exit below frees whatever of the three was allocated: an allocation that fails must not leak the ones before it)
-    hipError_t e = hipMalloc((void**)&d_top, r4);
-    if (e == hipSuccess) e = hipMalloc((void**)&d_off, ((size_t)S->R + 1) * 8);
-    if (e == hipSuccess) e = hipMalloc((void**)&d_exc, std::max<size_t>(4, ne * 4));
-    if (e == hipSuccess) e = hipMemcpyAsync(d_top, rows->top, (size_t)S->R * 4, hipMemcpyHostToDevice, S->stream);
+    uint32_t* const d_top = (uint32_t*)(A0 + o_top); uint32_t* const d_exc = (uint32_t*)(A0 + o_exc);
+    unsigned long long* const d_off = (unsigned long long*)(A0 + o_off);
+    hipError_t e = hipMemcpyAsync(d_top, rows->top, (size_t)S->R * 4, hipMemcpyHostToDevice, S->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d_off, rows->exc_off, ((size_t)S->R + 1) * 8, hipMemcpyHostToDevice, S->stream);
     if (e == hipSuccess && ne) e = hipMemcpyAsync(d_exc, rows->exc, ne * 4, hipMemcpyHostToDevice, S->stream);
     if (e == hipSuccess) {
       hipLaunchKernelGGL(setfull_rows_kernel, dim3(std::min<uint32_t>(S->R, 16384u)), dim3(256), 0, S->stream, d_top, d_off, d_exc, S->R, std::max(1u, S->WPR), S->PITCH, S->d_M);
       e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipStreamSynchronize(S->stream);
-    if (d_top) (void)hipFree(d_top);
-    if (d_off) (void)hipFree(d_off);
-    if (d_exc) (void)hipFree(d_exc);
     if (e != hipSuccess) { set_error("tbc_setfull_create_rows: building the matrix failed: %s", hipGetErrorString(e)); return e == hipErrorOutOfMemory ? TBC_ERR_OOM : TBC_ERR_HIP; }
   }
   // p[r] (how many elements had been invoked when read r completed) and the chunks' maxima depend on the inputs only
