@@ -333,13 +333,27 @@ def leg_set_full(args, local_rank):
     ms = statistics.mean(r["ns_scan"] for r in runs) / 1e6
     lost = int(((runs[0]["last_present"].astype(np.int64) < runs[0]["last_absent"].astype(np.int64)) & (runs[0]["last_absent"] != N.NO_OP)).sum())
     gbs = runs[0]["bytes_scanned"] / (ms * 1e-3) / 1e9
+    # HBM bytes per scan from the committed rocprofv3 PMC passes (scripts/gpu_profile_setfull.sh), quoted only for the very source they were taken on
+    import glob, hashlib
+    sf_traffic = None
+    with open(os.path.join(ROOT, "jepsen-tigerbeetle_amd", "csrc", "set_full.hip"), "rb") as fh:
+        sf_sha = hashlib.sha256(fh.read()).hexdigest()[:16]
+    for tf in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_setfull_traffic.json")), reverse=True):
+        try:
+            with open(tf) as fh:
+                tj = json.load(fh)
+            if tj.get("set_full_sha") == sf_sha and (tj.get("elements"), tj.get("reads")) == (E, R):
+                sf_traffic = int(tj["traffic_bytes_per_scan"])
+                break
+        except (OSError, ValueError, KeyError):
+            pass
     return {"elements": E, "reads": R, "matrix_GB": round(runs[0]["bytes_matrix"] / 1e9, 3),
             "scan_ms": round(ms, 3), "bytes_scanned": int(runs[0]["bytes_scanned"]), "lost_elements_found": lost,
             "end_to_end_ms": round(min(t_e2e), 3), "compact_input_MB": round((exc.nbytes + exc_off.nbytes + 4 * R) / 1e6, 2),
             "end_to_end_note": "tbc_setfull_create_rows + tbc_setfull_run + destroy: allocation, H2D of the compact reads, the matrix built on the device, the scan, "
                                "three indices per element back (best of 3); the dense form moves the 1 GB matrix over PCIe instead",
             "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "setfull_any_kernel + setfull_resolve_kernel"}}
+                         "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": sf_traffic, "kernel": "setfull_any_kernel + setfull_resolve_kernel"}}
 
 
 def _pick(d, *keys):

@@ -246,39 +246,94 @@ __device__ __forceinline__ uint32_t wave_min_u32_all(uint32_t v) {
   return v;
 }
 
+// 32 reductions over the 64 lanes at once: lane b < 32 gets min over the lanes l whose `hits` has bit b of val[l] (0xFFFFFFFF if none).
+// Not 32 butterflies of six exchanges each (round 2 - 5: 192 exchanges and as many minima per 64 rows -- 20 us of this kernel's 54,
+// profiles/r06_setfull_pmc.txt) but ONE butterfly that halves what a lane carries as it goes: with the partner 32 lanes
+// away a lane keeps 16 of the 32 bits and hands over the other 16, then 8, 4, 2, 1 -- 31 exchanges -- and one last exchange joins the two
+// lanes that ended with the same bit.  Lane L ends with bit (L5 L4 L3 L2 L1) of its lane number; lane b fetches its own from there.
+__device__ __forceinline__ uint32_t wave_min_by_bit(uint32_t hits, uint32_t val, uint32_t lane) {
+  uint32_t v[16];
+  {                                                    // the first halving builds what it exchanges: sixteen values live, not 32
+    const bool up = (lane & 32u) != 0u;
+    const uint32_t hk = up ? hits >> 16 : hits, hs = up ? hits : hits >> 16;      // the bits kept / handed over, in the low half
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      const uint32_t keep = val | (((hk >> i) & 1u) - 1u), send = val | (((hs >> i) & 1u) - 1u);      // val where the bit is set, all ones where not
+      v[i] = min(keep, (uint32_t)__shfl_xor((int)send, 32));
+    }
+  }
+#pragma unroll
+  for (int n = 8, d = 16; n >= 1; n >>= 1, d >>= 1) {
+    const bool up = (lane & (uint32_t)d) != 0u;
+#pragma unroll
+    for (int i = 0; i < n; i++) {
+      const uint32_t keep = up ? v[i + n] : v[i], send = up ? v[i] : v[i + n];
+      v[i] = min(keep, (uint32_t)__shfl_xor((int)send, d));
+    }
+  }
+  v[0] = min(v[0], (uint32_t)__shfl_xor((int)v[0], 1));
+  const uint32_t b = lane & 31u;
+  const uint32_t src = ((b >> 4) & 1u) << 5 | ((b >> 3) & 1u) << 4 | ((b >> 2) & 1u) << 3 | ((b >> 1) & 1u) << 2 | (b & 1u) << 1;
+  return (uint32_t)__shfl((int)v[0], (int)src);
+}
+__device__ __forceinline__ uint32_t wave_max_u32_all(uint32_t v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, d));
+  return v;
+}
+
+// 64 rows of one word column requested AHEAD of the walk that uses them (lane l = row base + l < hi): the column's word, the row's
+// prefix and read_invoke (read_ok for the walk of `known`).  The three indices of a column are three chains of dependent trips; the
+// first trip of each is known as soon as the summaries are, and the three go out together.
+struct RowsAhead { uint32_t base, hi, word, pv, third; };
+__device__ __forceinline__ RowsAhead rows_ahead(const uint32_t* __restrict__ M, const uint32_t* __restrict__ P, const uint32_t* __restrict__ third,
+                                                uint32_t PITCH, uint32_t w, uint32_t base, uint32_t hi, uint32_t lane) {
+  RowsAhead a; a.base = base; a.hi = hi;
+  const uint32_t r = base + lane;
+  const bool in = r < hi;
+  a.word = in ? M[(uint64_t)r * PITCH + w] : 0u; a.pv = in ? P[r] : 0u; a.third = in ? third[r] : 0u;
+  return a;
+}
+
 // walk chunk c from its latest row down, lane = row: for every bit of `want` find the latest row where the bit is present
 // (present = true) or absent; lane b keeps read_invoke + 1 of bit b's row in `res`; returns the bits found
 __device__ __forceinline__ uint32_t setfull_last_in_chunk(const uint32_t* __restrict__ M, const uint32_t* __restrict__ P,
                                                           const uint32_t* __restrict__ read_invoke, uint32_t PITCH, uint32_t w, uint32_t full,
                                                           uint32_t r0, uint32_t r1, uint32_t want, bool present, uint32_t& res, uint32_t lane,
-                                                          uint32_t& loaded) {
+                                                          uint32_t& loaded, const RowsAhead& ah) {
   uint32_t found = 0;
   for (uint32_t hi = r1; hi > r0 && (want & ~found); hi = hi - r0 > 64u ? hi - 64u : r0) {
     const uint32_t base = hi - r0 > 64u ? hi - 64u : r0;       // rows [base, hi), lane l = row base + l
     const uint32_t r = base + lane;
     const bool in = r < hi;
-    const uint32_t word = in ? M[(uint64_t)r * PITCH + w] : 0u;          // (not waiting for P[r] to say whether the row counts: one round trip a step, not two)
-    const uint32_t valid = in ? prefix_mask(P[r], w) & full : 0u;
-    const uint32_t inv1 = in ? read_invoke[r] + 1u : 0u;
+    const bool got = ah.base == base && ah.hi == hi;           // (uniform) these very rows were requested ahead
+    const uint32_t word = got ? ah.word : (in ? M[(uint64_t)r * PITCH + w] : 0u);          // (not waiting for P[r] to say whether the row counts: one round trip a step, not two)
+    const uint32_t valid = in ? prefix_mask(got ? ah.pv : P[r], w) & full : 0u;
+    const uint32_t inv1 = in ? (got ? ah.third : read_invoke[r]) + 1u : 0u;
     loaded += valid ? 1u : 0u;
     const uint32_t x = (present ? word : ~word) & valid;
+    // row by row, not bit by bit: the latest row that has ANY wanted bit settles all the bits it has (ten instructions), and a group's
+    // wanted bits mostly sit in one or two rows -- the last read holds every element but the lost ones; the row before an add lacks all
+    // the later elements.  (Rounds 2 - 5 took the bits one at a time, ten instructions each: 2,570 vector instructions a wavefront,
+    // 36 us of a SIMD's issue in a 57 us kernel -- profiles/r06_setfull_pmc.txt.)  Never more turns than wanted bits.
     uint32_t todo = want & ~found;
-    while (todo) {
-      const uint32_t b = (uint32_t)__builtin_ctz(todo);
-      todo &= todo - 1u;
-      const uint64_t bal = __ballot((x >> b) & 1u);
-      if (bal) {
-        const uint32_t l = 63u - (uint32_t)__builtin_clzll(bal);
-        const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)inv1, l);
-        if (lane == b) res = v;
-        found |= 1u << b;
-      }
+    uint64_t rows = __ballot((x & todo) != 0u);
+    while (rows) {
+      const uint32_t l = 63u - (uint32_t)__builtin_clzll(rows);
+      const uint32_t xl = (uint32_t)__builtin_amdgcn_readlane((int)x, l) & todo;
+      const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)inv1, l);
+      if (lane < 32u && ((xl >> lane) & 1u)) res = v;
+      found |= xl; todo &= ~xl;
+      rows = __ballot((x & todo) != 0u) & ((1ull << l) - 1ull);
     }
   }
   return found;
 }
 
-__global__ __launch_bounds__(256) void setfull_resolve_kernel(const uint32_t* __restrict__ M, const uint32_t* __restrict__ P,
+#ifndef SF_RESOLVE_MIN_WAVES
+#define SF_RESOLVE_MIN_WAVES 6          /* 75 registers, none spilled: 36 us; at 8 (64 registers, 21 spilled) 37 - 49 */
+#endif
+__global__ __launch_bounds__(256, SF_RESOLVE_MIN_WAVES) void setfull_resolve_kernel(const uint32_t* __restrict__ M, const uint32_t* __restrict__ P,
                                                               const uint32_t* __restrict__ read_invoke, const uint32_t* __restrict__ read_ok,
                                                               const uint32_t* __restrict__ any_p, const uint32_t* __restrict__ any_a,
                                                               uint32_t E, uint32_t R, uint32_t WPR, uint32_t PITCH, uint32_t rows_per_chunk, uint32_t chunks, uint32_t SP,
@@ -316,6 +371,24 @@ __global__ __launch_bounds__(256) void setfull_resolve_kernel(const uint32_t* __
       sa[k] = pre ? reinterpret_cast<const uint32_t*>(&s_sa[cl])[wv_] : 0u;
     }
     const auto pick = [](const uint32_t (&r)[4], uint32_t gi) -> uint32_t { return gi == 0u ? r[0] : gi == 1u ? r[1] : gi == 2u ? r[2] : r[3]; };
+    // the first trip of each of the three walks below, requested now (up to 256 chunks: the summaries are in registers)
+    RowsAhead ah_p = {kNoneU, 0u, 0u, 0u, 0u}, ah_a = ah_p, ah_k = ah_p;
+    if (pre) {
+      uint32_t top_p = kNoneU, top_a = kNoneU, low_p = kNoneU;
+#pragma unroll
+      for (uint32_t k = 0; k < 4u; k++) {
+        const uint64_t bp = __ballot((sp[k] & full) != 0u), ba = __ballot((sa[k] & full) != 0u);
+        if (bp) { top_p = 63u - (uint32_t)__builtin_clzll(bp) + 64u * k; if (low_p == kNoneU) low_p = (uint32_t)__builtin_ctzll(bp) + 64u * k; }
+        if (ba) top_a = 63u - (uint32_t)__builtin_clzll(ba) + 64u * k;
+      }
+      const auto top_rows = [&](uint32_t c, uint32_t& base, uint32_t& hi) {
+        const uint32_t r0 = min(c * rows_per_chunk, R); hi = min(r0 + rows_per_chunk, R); base = hi - r0 > 64u ? hi - 64u : r0;
+      };
+      uint32_t b_, h_;
+      if (top_p != kNoneU) { top_rows(top_p, b_, h_); ah_p = rows_ahead(M, P, read_invoke, PITCH, w, b_, h_, lane); }
+      if (top_a != kNoneU) { top_rows(top_a, b_, h_); ah_a = rows_ahead(M, P, read_invoke, PITCH, w, b_, h_, lane); }
+      if (low_p != kNoneU) { b_ = low_p * rows_per_chunk; ah_k = rows_ahead(M, P, read_ok, PITCH, w, b_, min(b_ + 64u, R), lane); }
+    }
     // last present / last absent: the latest chunk that has the bit decides; inside it, the latest row
     uint32_t res_p = 0u, res_a = 0u;          // read_invoke + 1 of the element's last present / last absent read, 0 = none
 #pragma unroll
@@ -332,7 +405,7 @@ __global__ __launch_bounds__(256) void setfull_resolve_kernel(const uint32_t* __
           const uint32_t c = l + 64u * gi;
           const uint32_t mc = (uint32_t)__builtin_amdgcn_readlane((int)mine, l) & need;
           const uint32_t r0 = min(c * rows_per_chunk, R), r1 = min(r0 + rows_per_chunk, R);
-          (void)setfull_last_in_chunk(M, P, read_invoke, PITCH, w, full, r0, r1, mc, pass == 0, res, lane, loaded);
+          (void)setfull_last_in_chunk(M, P, read_invoke, PITCH, w, full, r0, r1, mc, pass == 0, res, lane, loaded, pass == 0 ? ah_p : ah_a);
           need &= ~mc;
           cand = __ballot((mine & need) != 0u) & ((1ull << l) - 1ull);
         }
@@ -361,21 +434,31 @@ __global__ __launch_bounds__(256) void setfull_resolve_kernel(const uint32_t* __
         const uint32_t inv = in ? read_invoke[r] : 0xFFFFFFFFu;
         const uint32_t inv_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)inv);
         if (seen == ever && inv_first > until) break;
-        const uint32_t word = in ? M[(uint64_t)r * PITCH + w] : 0u;
-        const uint32_t valid = in ? prefix_mask(P[r], w) & full : 0u;
-        const uint32_t ok = in ? read_ok[r] : 0xFFFFFFFFu;
+        const bool got = ah_k.base == base;                    // (uniform) the walk's first 64 rows were requested ahead
+        const uint32_t word = got ? ah_k.word : (in ? M[(uint64_t)r * PITCH + w] : 0u);
+        const uint32_t valid = in ? prefix_mask(got ? ah_k.pv : P[r], w) & full : 0u;
+        const uint32_t ok = in ? (got ? ah_k.third : read_ok[r]) : 0xFFFFFFFFu;
         loaded += valid ? 1u : 0u;
         const uint32_t hits = word & valid;
         uint32_t any_hits = hits;
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) any_hits |= (uint32_t)__shfl_xor((int)any_hits, d);
-        uint32_t todo = any_hits;
-        while (todo) {
-          const uint32_t b = (uint32_t)__builtin_ctz(todo);
-          todo &= todo - 1u;
-          const uint32_t m = wave_min_u32_all(((hits >> b) & 1u) ? ok : 0xFFFFFFFFu);
-          if (lane == b) best = min(best, m);
-          if (!((seen >> b) & 1u)) until = max(until, m);      // (the first batch's minimum bounds the first containing read's completion)
+        // row by row here too: the row that completes first among those holding a still-open bit gives its read_ok to every open bit
+        // it holds; three turns settle nearly every group, what is left after them goes through one halving butterfly
+        uint32_t open_ = any_hits;
+        for (int turn = 0; turn < 3 && open_; turn++) {
+          const uint32_t m = wave_min_u32_all((hits & open_) ? ok : 0xFFFFFFFFu);
+          const uint64_t who = __ballot((hits & open_) != 0u && ok == m);
+          const uint32_t xl = (uint32_t)__builtin_amdgcn_readlane((int)hits, (uint32_t)__builtin_ctzll(who)) & open_;
+          if (lane < 32u && ((xl >> lane) & 1u)) best = min(best, m);
+          if (xl & ~seen) until = max(until, m);              // (the first batch's minimum bounds the first containing read's completion)
+          open_ &= ~xl;
+        }
+        if (open_) {
+          const uint32_t m = wave_min_by_bit(hits & open_, ok, lane);   // lane b < 32: bit b's minimum
+          const bool mine = lane < 32u && ((open_ >> lane) & 1u);
+          if (mine) best = min(best, m);
+          until = max(until, wave_max_u32_all((mine && !((seen >> lane) & 1u)) ? m : 0u));
         }
         seen |= any_hits;
       }

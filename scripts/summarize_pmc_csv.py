@@ -10,7 +10,7 @@ for d in sys.argv[1:]:
                                                                int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), r["VGPR_Count"], r["SGPR_Count"], r["LDS_Block_Size"], r["Scratch_Size"]))
         print("==", p)
         for (k, c), l in sorted(rows.items()):
-            if "tbc" not in k:
+            if "tbc" not in k and "setfull" not in k:
                 continue
             gmax = max(g for g, *_ in l)
             by = defaultdict(float); dur = {}
