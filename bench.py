@@ -676,7 +676,7 @@ def main():
     device_bytes_all_resident = sum(b.device_bytes() for b in batches)
     fresh = None
     G = (args.fresh_batches // F) * F
-    if G > 0 and on_gpu and narrow:
+    if G > 0 and on_gpu and narrow and world == 1:        # (N > 1: the headline only -- every rank would generate and encode G more batches on the one host)
         per = G // F
         fresh_verdicts = {}
         fresh_infos = []
