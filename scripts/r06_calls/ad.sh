@@ -1,3 +1,4 @@
+# (build variants sfw6 = scripts/build_variant.sh with SRC=set_full -DSF_RESOLVE_MIN_WAVES=6, since made the default)
 # set-full resolve with the transposed reductions, at 8 (default build), 6 and <= 6 wavefronts a SIMD
 OUT=gpurun_out/r06_af; mkdir -p $OUT
 timeout 600 python -m pytest tests/test_set_full.py -q -m gpu > $OUT/tests.txt 2>&1; tail -2 $OUT/tests.txt

@@ -1,3 +1,4 @@
+# (the TBC_SETFULL_CHUNKS knob this call scans was an experiment's and is gone from the library: profiles/NOTES_r06.md)
 # set-full: the streaming pass with the chunk in blockIdx.x (XCD balance); GPU tests, the bench leg at several chunk counts, a kernel trace
 OUT=gpurun_out/r06_v
 mkdir -p $OUT

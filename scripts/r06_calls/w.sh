@@ -1,3 +1,4 @@
+# (the TBC_SETFULL_PAD knob this call scans was an experiment's and is gone from the library: profiles/r06_setfull_pad_scan.txt)
 # set-full: a row pitch that is not a multiple of the memory channels' period (pad scan), kernel trace of the best
 OUT=gpurun_out/r06_w
 mkdir -p $OUT
