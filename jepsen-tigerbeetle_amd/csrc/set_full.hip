@@ -246,42 +246,6 @@ __device__ __forceinline__ uint32_t wave_min_u32_all(uint32_t v) {
   return v;
 }
 
-// 32 reductions over the 64 lanes at once: lane b < 32 gets min over the lanes l whose `hits` has bit b of val[l] (0xFFFFFFFF if none).
-// Not 32 butterflies of six exchanges each (round 2 - 5: 192 exchanges and as many minima per 64 rows -- 20 us of this kernel's 54,
-// profiles/r06_setfull_pmc.txt) but ONE butterfly that halves what a lane carries as it goes: with the partner 32 lanes
-// away a lane keeps 16 of the 32 bits and hands over the other 16, then 8, 4, 2, 1 -- 31 exchanges -- and one last exchange joins the two
-// lanes that ended with the same bit.  Lane L ends with bit (L5 L4 L3 L2 L1) of its lane number; lane b fetches its own from there.
-__device__ __forceinline__ uint32_t wave_min_by_bit(uint32_t hits, uint32_t val, uint32_t lane) {
-  uint32_t v[16];
-  {                                                    // the first halving builds what it exchanges: sixteen values live, not 32
-    const bool up = (lane & 32u) != 0u;
-    const uint32_t hk = up ? hits >> 16 : hits, hs = up ? hits : hits >> 16;      // the bits kept / handed over, in the low half
-#pragma unroll
-    for (int i = 0; i < 16; i++) {
-      const uint32_t keep = val | (((hk >> i) & 1u) - 1u), send = val | (((hs >> i) & 1u) - 1u);      // val where the bit is set, all ones where not
-      v[i] = min(keep, (uint32_t)__shfl_xor((int)send, 32));
-    }
-  }
-#pragma unroll
-  for (int n = 8, d = 16; n >= 1; n >>= 1, d >>= 1) {
-    const bool up = (lane & (uint32_t)d) != 0u;
-#pragma unroll
-    for (int i = 0; i < n; i++) {
-      const uint32_t keep = up ? v[i + n] : v[i], send = up ? v[i] : v[i + n];
-      v[i] = min(keep, (uint32_t)__shfl_xor((int)send, d));
-    }
-  }
-  v[0] = min(v[0], (uint32_t)__shfl_xor((int)v[0], 1));
-  const uint32_t b = lane & 31u;
-  const uint32_t src = ((b >> 4) & 1u) << 5 | ((b >> 3) & 1u) << 4 | ((b >> 2) & 1u) << 3 | ((b >> 1) & 1u) << 2 | (b & 1u) << 1;
-  return (uint32_t)__shfl((int)v[0], (int)src);
-}
-__device__ __forceinline__ uint32_t wave_max_u32_all(uint32_t v) {
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, d));
-  return v;
-}
-
 // 64 rows of one word column requested AHEAD of the walk that uses them (lane l = row base + l < hi): the column's word, the row's
 // prefix and read_invoke (read_ok for the walk of `known`).  The three indices of a column are three chains of dependent trips; the
 // first trip of each is known as soon as the summaries are, and the three go out together.
@@ -302,14 +266,24 @@ __device__ __forceinline__ uint32_t setfull_last_in_chunk(const uint32_t* __rest
                                                           uint32_t r0, uint32_t r1, uint32_t want, bool present, uint32_t& res, uint32_t lane,
                                                           uint32_t& loaded, const RowsAhead& ah) {
   uint32_t found = 0;
+  if (!(r1 > r0)) return found;
+  // the rows of a step are requested while the step before is resolved (the first: with the summaries, if the caller did); word, prefix
+  // and read_invoke of a row come in ONE trip (not waiting for P[r] to say whether the row counts)
+  RowsAhead cur = ah;
+  {
+    const uint32_t base = r1 - r0 > 64u ? r1 - 64u : r0;
+    if (!(ah.base == base && ah.hi == r1)) cur = rows_ahead(M, P, read_invoke, PITCH, w, base, r1, lane);
+  }
   for (uint32_t hi = r1; hi > r0 && (want & ~found); hi = hi - r0 > 64u ? hi - 64u : r0) {
     const uint32_t base = hi - r0 > 64u ? hi - 64u : r0;       // rows [base, hi), lane l = row base + l
     const uint32_t r = base + lane;
     const bool in = r < hi;
-    const bool got = ah.base == base && ah.hi == hi;           // (uniform) these very rows were requested ahead
-    const uint32_t word = got ? ah.word : (in ? M[(uint64_t)r * PITCH + w] : 0u);          // (not waiting for P[r] to say whether the row counts: one round trip a step, not two)
-    const uint32_t valid = in ? prefix_mask(got ? ah.pv : P[r], w) & full : 0u;
-    const uint32_t inv1 = in ? (got ? ah.third : read_invoke[r]) + 1u : 0u;
+    RowsAhead nxt = cur;
+    if (base > r0) nxt = rows_ahead(M, P, read_invoke, PITCH, w, base - r0 > 64u ? base - 64u : r0, base, lane);
+    const uint32_t word = cur.word;
+    const uint32_t valid = in ? prefix_mask(cur.pv, w) & full : 0u;
+    const uint32_t inv1 = in ? cur.third + 1u : 0u;
+    cur = nxt;
     loaded += valid ? 1u : 0u;
     const uint32_t x = (present ? word : ~word) & valid;
     // row by row, not bit by bit: the latest row that has ANY wanted bit settles all the bits it has (ten instructions), and a group's
@@ -331,7 +305,7 @@ __device__ __forceinline__ uint32_t setfull_last_in_chunk(const uint32_t* __rest
 }
 
 #ifndef SF_RESOLVE_MIN_WAVES
-#define SF_RESOLVE_MIN_WAVES 6          /* 75 registers, none spilled: 36 us; at 8 (64 registers, 21 spilled) 37 - 49 */
+#define SF_RESOLVE_MIN_WAVES 8          /* 41 registers: every one of the 8,192 wavefronts of 262,144 elements resident at once */
 #endif
 __global__ __launch_bounds__(256, SF_RESOLVE_MIN_WAVES) void setfull_resolve_kernel(const uint32_t* __restrict__ M, const uint32_t* __restrict__ P,
                                                               const uint32_t* __restrict__ read_invoke, const uint32_t* __restrict__ read_ok,
@@ -428,25 +402,34 @@ __global__ __launch_bounds__(256, SF_RESOLVE_MIN_WAVES) void setfull_resolve_ker
     uint32_t best = 0xFFFFFFFFu;                                // lane b < 32 keeps element b's minimum
     if (ever) {
       uint32_t seen = 0, until = 0;
-      for (uint32_t base = first_c * rows_per_chunk; base < R; base += 64u) {
+      // a step's rows (word, prefix, read_ok -- and read_invoke, which says whether the walk goes on) are requested while the step before is
+      // resolved: one trip a step where there were two (read_invoke first, the rest only if the walk went on)
+      const uint32_t base0 = first_c * rows_per_chunk;
+      RowsAhead cur = ah_k.base == base0 ? ah_k : rows_ahead(M, P, read_ok, PITCH, w, base0, min(base0 + 64u, R), lane);
+      uint32_t cur_inv = base0 + lane < R ? read_invoke[base0 + lane] : 0xFFFFFFFFu;
+      for (uint32_t base = base0; base < R; base += 64u) {
         const uint32_t r = base + lane;
         const bool in = r < R;
-        const uint32_t inv = in ? read_invoke[r] : 0xFFFFFFFFu;
-        const uint32_t inv_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)inv);
+        const uint32_t inv_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur_inv);
         if (seen == ever && inv_first > until) break;
-        const bool got = ah_k.base == base;                    // (uniform) the walk's first 64 rows were requested ahead
-        const uint32_t word = got ? ah_k.word : (in ? M[(uint64_t)r * PITCH + w] : 0u);
-        const uint32_t valid = in ? prefix_mask(got ? ah_k.pv : P[r], w) & full : 0u;
-        const uint32_t ok = in ? (got ? ah_k.third : read_ok[r]) : 0xFFFFFFFFu;
+        RowsAhead nxt = cur; uint32_t nxt_inv = 0xFFFFFFFFu;
+        if (base + 64u < R) {
+          nxt = rows_ahead(M, P, read_ok, PITCH, w, base + 64u, min(base + 128u, R), lane);
+          nxt_inv = base + 64u + lane < R ? read_invoke[base + 64u + lane] : 0xFFFFFFFFu;
+        }
+        const uint32_t word = cur.word;
+        const uint32_t valid = in ? prefix_mask(cur.pv, w) & full : 0u;
+        const uint32_t ok = in ? cur.third : 0xFFFFFFFFu;
+        cur = nxt; cur_inv = nxt_inv;
         loaded += valid ? 1u : 0u;
         const uint32_t hits = word & valid;
         uint32_t any_hits = hits;
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) any_hits |= (uint32_t)__shfl_xor((int)any_hits, d);
         // row by row here too: the row that completes first among those holding a still-open bit gives its read_ok to every open bit
-        // it holds; three turns settle nearly every group, what is left after them goes through one halving butterfly
+        // it holds; a turn or two settle nearly every group
         uint32_t open_ = any_hits;
-        for (int turn = 0; turn < 3 && open_; turn++) {
+        for (int turn = 0; turn < 8 && open_; turn++) {
           const uint32_t m = wave_min_u32_all((hits & open_) ? ok : 0xFFFFFFFFu);
           const uint64_t who = __ballot((hits & open_) != 0u && ok == m);
           const uint32_t xl = (uint32_t)__builtin_amdgcn_readlane((int)hits, (uint32_t)__builtin_ctzll(who)) & open_;
@@ -454,11 +437,12 @@ __global__ __launch_bounds__(256, SF_RESOLVE_MIN_WAVES) void setfull_resolve_ker
           if (xl & ~seen) until = max(until, m);              // (the first batch's minimum bounds the first containing read's completion)
           open_ &= ~xl;
         }
-        if (open_) {
-          const uint32_t m = wave_min_by_bit(hits & open_, ok, lane);   // lane b < 32: bit b's minimum
-          const bool mine = lane < 32u && ((open_ >> lane) & 1u);
-          if (mine) best = min(best, m);
-          until = max(until, wave_max_u32_all((mine && !((seen >> lane) & 1u)) ? m : 0u));
+        while (open_) {                                         // (what eight turns leave -- hardly ever anything -- bit by bit)
+          const uint32_t b = (uint32_t)__builtin_ctz(open_);
+          open_ &= open_ - 1u;
+          const uint32_t m = wave_min_u32_all(((hits >> b) & 1u) ? ok : 0xFFFFFFFFu);
+          if (lane == b) best = min(best, m);
+          if (!((seen >> b) & 1u)) until = max(until, m);
         }
         seen |= any_hits;
       }

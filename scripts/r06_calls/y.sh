@@ -1,5 +1,5 @@
 # set-full: the lean path of the streaming pass (tiles whose columns all count in every row), GPU tests, the leg, a kernel trace
-OUT=gpurun_out/r06_y6
+OUT=gpurun_out/r06_y8
 mkdir -p $OUT
 timeout 600 python -m pytest tests/test_set_full.py -q -m gpu > $OUT/tests.txt 2>&1; tail -3 $OUT/tests.txt
 for rep in 1 2 3; do
